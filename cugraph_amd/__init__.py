@@ -1,0 +1,23 @@
+"""cugraph_amd -- MI355X-native PageRank / BFS / SSSP core behind the cuGraph C API.
+
+Layout (only what the hot path needs):
+  csrc/      HIP kernels + the C-ABI implementation (-> lib/libcugraph_c.so)
+  _capi.py   ctypes binding of that C ABI
+  pylib.py   host-side mirror of the reference's pylibcugraph interface for this path
+  mg.py      multi-GPU PageRank (one process per GPU, torch.distributed / RCCL)
+"""
+from .pylib import (  # noqa: F401
+    FailedToConvergeError,
+    GraphProperties,
+    PageRankPlan,
+    ResourceHandle,
+    SGGraph,
+    bfs,
+    generate_rmat_edgelist,
+    has_vertex,
+    pagerank,
+    personalized_pagerank,
+    sssp,
+)
+
+__version__ = "0.1.0"

@@ -1,0 +1,142 @@
+"""ctypes binding of the C-ABI library (cugraph_amd/lib/libcugraph_c.so, headers in include/).
+
+This is the same boundary pylibcugraph's Cython modules bind (python/pylibcugraph/pylibcugraph/_cugraph_c/*.pxd);
+see INTEGRATION.md.  There is NO CPU fallback: if the library is missing or cannot be loaded the import
+of anything that computes fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_DIR = _PKG / "lib"
+LIB_PATH = LIB_DIR / "libcugraph_c.so"
+CSRC = _PKG / "csrc"
+
+# cugraph_error_code_t (include/cugraph_c/error.h)
+CUGRAPH_SUCCESS, CUGRAPH_UNKNOWN_ERROR, CUGRAPH_INVALID_HANDLE, CUGRAPH_ALLOC_ERROR, CUGRAPH_INVALID_INPUT, \
+    CUGRAPH_NOT_IMPLEMENTED, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION = range(7)
+ERROR_NAMES = ["CUGRAPH_SUCCESS", "CUGRAPH_UNKNOWN_ERROR", "CUGRAPH_INVALID_HANDLE", "CUGRAPH_ALLOC_ERROR",
+               "CUGRAPH_INVALID_INPUT", "CUGRAPH_NOT_IMPLEMENTED", "CUGRAPH_UNSUPPORTED_TYPE_COMBINATION"]
+# cugraph_data_type_id_t (include/cugraph_c/types.h)
+INT8, INT16, INT32, INT64, UINT8, UINT16, UINT32, UINT64, FLOAT32, FLOAT64, SIZE_T, BOOL, NTYPES = range(13)
+
+
+class GraphPropertiesStruct(C.Structure):
+    _fields_ = [("is_symmetric", C.c_int), ("is_multigraph", C.c_int)]
+
+
+class TraversalStats(C.Structure):
+    _fields_ = [("steps", C.c_uint64), ("edges_inspected", C.c_uint64), ("vertices_reached", C.c_uint64),
+                ("edges_of_reached", C.c_uint64)]
+
+
+def build(verbose: bool = False) -> Path:
+    """Compile every HIP source for gfx950 into cugraph_amd/lib/ (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", str(CSRC), "-j", str(max(1, min(8, os.cpu_count() or 1)))]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("building libcugraph_c.so failed (see output above)")
+    return LIB_PATH
+
+
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); every symbol declared in include/cugraph_c/*.h and include/cugraph_amd/extensions.h
+PROTOTYPES = {
+    # error.h
+    "cugraph_error_message": (C.c_char_p, [_P]),
+    "cugraph_error_free": (None, [_P]),
+    # resource_handle.h
+    "cugraph_create_resource_handle": (_P, [_P]),
+    "cugraph_resource_handle_get_comm_size": (C.c_int, [_P]),
+    "cugraph_resource_handle_get_rank": (C.c_int, [_P]),
+    "cugraph_free_resource_handle": (None, [_P]),
+    # array.h
+    "cugraph_type_erased_device_array_create": (C.c_int, [_P, C.c_size_t, C.c_int, _PP, _PP]),
+    "cugraph_type_erased_device_array_create_from_view": (C.c_int, [_P, _P, _PP, _PP]),
+    "cugraph_type_erased_device_array_free": (None, [_P]),
+    "cugraph_type_erased_device_array_view": (_P, [_P]),
+    "cugraph_type_erased_device_array_view_as_type": (C.c_int, [_P, C.c_int, _PP, _PP]),
+    "cugraph_type_erased_device_array_view_create": (_P, [_P, C.c_size_t, C.c_int]),
+    "cugraph_type_erased_device_array_view_free": (None, [_P]),
+    "cugraph_type_erased_device_array_view_size": (C.c_size_t, [_P]),
+    "cugraph_type_erased_device_array_view_type": (C.c_int, [_P]),
+    "cugraph_type_erased_device_array_view_pointer": (_P, [_P]),
+    "cugraph_type_erased_host_array_create": (C.c_int, [_P, C.c_size_t, C.c_int, _PP, _PP]),
+    "cugraph_type_erased_host_array_free": (None, [_P]),
+    "cugraph_type_erased_host_array_view": (_P, [_P]),
+    "cugraph_type_erased_host_array_view_create": (_P, [_P, C.c_size_t, C.c_int]),
+    "cugraph_type_erased_host_array_view_free": (None, [_P]),
+    "cugraph_type_erased_host_array_size": (C.c_size_t, [_P]),
+    "cugraph_type_erased_host_array_type": (C.c_int, [_P]),
+    "cugraph_type_erased_host_array_pointer": (_P, [_P]),
+    "cugraph_type_erased_host_array_view_copy": (C.c_int, [_P, _P, _P, _PP]),
+    "cugraph_type_erased_device_array_view_copy_from_host": (C.c_int, [_P, _P, _P, _PP]),
+    "cugraph_type_erased_device_array_view_copy_to_host": (C.c_int, [_P, _P, _P, _PP]),
+    "cugraph_type_erased_device_array_view_copy": (C.c_int, [_P, _P, _P, _PP]),
+    # graph.h
+    "cugraph_graph_create_sg": (C.c_int, [_P, C.POINTER(GraphPropertiesStruct), _P, _P, _P, _P, _P, _P] + [C.c_int] * 6 + [_PP, _PP]),
+    "cugraph_graph_create_with_times_sg": (C.c_int, [_P, C.POINTER(GraphPropertiesStruct), _P, _P, _P, _P, _P, _P, _P, _P] + [C.c_int] * 6 + [_PP, _PP]),
+    "cugraph_graph_create_sg_from_csr": (C.c_int, [_P, C.POINTER(GraphPropertiesStruct), _P, _P, _P, _P, _P] + [C.c_int] * 4 + [_PP, _PP]),
+    "cugraph_graph_free": (None, [_P]),
+    # graph_functions.h
+    "cugraph_has_vertex": (C.c_int, [_P, _P, _P, C.c_int, _PP, _PP]),
+    # centrality_algorithms.h
+    "cugraph_centrality_result_get_vertices": (_P, [_P]),
+    "cugraph_centrality_result_get_values": (_P, [_P]),
+    "cugraph_centrality_result_get_num_iterations": (C.c_size_t, [_P]),
+    "cugraph_centrality_result_converged": (C.c_int, [_P]),
+    "cugraph_centrality_result_free": (None, [_P]),
+    "cugraph_pagerank": (C.c_int, [_P] * 6 + [C.c_double, C.c_double, C.c_size_t, C.c_int, _PP, _PP]),
+    "cugraph_pagerank_allow_nonconvergence": (C.c_int, [_P] * 6 + [C.c_double, C.c_double, C.c_size_t, C.c_int, _PP, _PP]),
+    "cugraph_personalized_pagerank": (C.c_int, [_P] * 8 + [C.c_double, C.c_double, C.c_size_t, C.c_int, _PP, _PP]),
+    "cugraph_personalized_pagerank_allow_nonconvergence": (C.c_int, [_P] * 8 + [C.c_double, C.c_double, C.c_size_t, C.c_int, _PP, _PP]),
+    # traversal_algorithms.h
+    "cugraph_paths_result_get_vertices": (_P, [_P]),
+    "cugraph_paths_result_get_distances": (_P, [_P]),
+    "cugraph_paths_result_get_predecessors": (_P, [_P]),
+    "cugraph_paths_result_free": (None, [_P]),
+    "cugraph_bfs": (C.c_int, [_P, _P, _P, C.c_int, C.c_size_t, C.c_int, C.c_int, _PP, _PP]),
+    "cugraph_sssp": (C.c_int, [_P, _P, C.c_size_t, C.c_double, C.c_int, C.c_int, _PP, _PP]),
+    # cugraph_amd/extensions.h
+    "cugraph_amd_version": (C.c_char_p, []),
+    "cugraph_amd_generate_rmat_edgelist": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_uint64, _P, _P, _PP]),
+    "cugraph_amd_pagerank_plan_create": (C.c_int, [_P] * 8 + [C.c_double, _PP, _PP]),
+    "cugraph_amd_pagerank_plan_step": (C.c_int, [_P, C.c_double, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int), _PP]),
+    "cugraph_amd_pagerank_plan_result": (C.c_int, [_P, C.c_size_t, C.c_int, _PP, _PP]),
+    "cugraph_amd_pagerank_plan_free": (None, [_P]),
+    "cugraph_amd_handle_sync": (C.c_int, [_P, _PP]),
+    "cugraph_amd_kernel_timing_enable": (None, [_P, C.c_int]),
+    "cugraph_amd_kernel_timing_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_double), _PP]),
+    "cugraph_amd_kernel_timing_reset": (None, [_P]),
+    "cugraph_amd_graph_num_vertices": (C.c_size_t, [_P]),
+    "cugraph_amd_graph_num_edges": (C.c_size_t, [_P]),
+    "cugraph_amd_set_pagerank_hot_tile": (C.c_int, [_P, C.c_int]),
+    "cugraph_amd_last_traversal_stats": (None, [_P, C.POINTER(TraversalStats)]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads libcugraph_c.so and attaches the prototypes.  Raises if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension was not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C cugraph_amd/csrc`). cugraph_amd has no CPU fallback.")
+        l = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(l, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib

@@ -1,0 +1,328 @@
+// Internal object model behind the opaque C-ABI structs of include/cugraph_c/*.h.
+// MI355X-native: plain HIP runtime objects (one stream per handle, hipMalloc'ed buffers), no RAFT / RMM /
+// Thrust.  Counterparts in the reference: cpp/src/c_api/{resource_handle,error,array,graph}.hpp.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cugraph_amd/extensions.h>
+#include <cugraph_c/array.h>
+#include <cugraph_c/centrality_algorithms.h>
+#include <cugraph_c/error.h>
+#include <cugraph_c/graph.h>
+#include <cugraph_c/graph_functions.h>
+#include <cugraph_c/resource_handle.h>
+#include <cugraph_c/traversal_algorithms.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace cga {
+
+// ------------------------------------------------------------------------------------------ errors
+struct api_error : std::runtime_error {
+  cugraph_error_code_t code;
+  api_error(cugraph_error_code_t c, std::string const& m) : std::runtime_error(m), code(c) {}
+};
+
+struct err_obj_t {  // behind cugraph_error_t (cpp/src/c_api/error.hpp)
+  std::string message;
+};
+
+#define CGA_EXPECTS(cond, code, msg)                    \
+  do {                                                  \
+    if (!(cond)) throw ::cga::api_error((code), (msg)); \
+  } while (0)
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      (void)hipGetLastError();                                                                     \
+      throw ::cga::api_error(e_ == hipErrorOutOfMemory ? CUGRAPH_ALLOC_ERROR : CUGRAPH_UNKNOWN_ERROR, \
+                             std::string("HIP error: ") + hipGetErrorString(e_) + " at " + __FILE__ + \
+                               ":" + std::to_string(__LINE__));                                    \
+    }                                                                                              \
+  } while (0)
+
+// Runs `f`, converts any exception into (code, *error) -- the reference's run_algorithm try/catch
+// (cpp/src/c_api/utils.hpp).
+template <typename F>
+cugraph_error_code_t guarded(cugraph_error_t** error, F&& f)
+{
+  if (error) *error = nullptr;
+  try {
+    f();
+    return CUGRAPH_SUCCESS;
+  } catch (api_error const& e) {
+    if (error) *error = reinterpret_cast<cugraph_error_t*>(new err_obj_t{e.what()});
+    return e.code;
+  } catch (std::bad_alloc const&) {
+    if (error) *error = reinterpret_cast<cugraph_error_t*>(new err_obj_t{"host allocation failed"});
+    return CUGRAPH_ALLOC_ERROR;
+  } catch (std::exception const& e) {
+    if (error) *error = reinterpret_cast<cugraph_error_t*>(new err_obj_t{e.what()});
+    return CUGRAPH_UNKNOWN_ERROR;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dtypes
+inline size_t dtype_size(cugraph_data_type_id_t t)
+{
+  switch (t) {
+    case INT8:
+    case UINT8:
+    case BOOL: return 1;
+    case INT16:
+    case UINT16: return 2;
+    case INT32:
+    case UINT32:
+    case FLOAT32: return 4;
+    case INT64:
+    case UINT64:
+    case FLOAT64:
+    case SIZE_T: return 8;
+    default: return 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------- device memory
+// Owning device buffer.  Allocation is synchronous hipMalloc: graph-analytics calls allocate a handful
+// of large buffers per API call (never inside an iteration loop), so a pool buys nothing here.
+struct dev_buf {
+  void* ptr{nullptr};
+  size_t bytes{0};
+  dev_buf() = default;
+  explicit dev_buf(size_t n_bytes) { alloc(n_bytes); }
+  dev_buf(dev_buf const&)            = delete;
+  dev_buf& operator=(dev_buf const&) = delete;
+  dev_buf(dev_buf&& o) noexcept : ptr(o.ptr), bytes(o.bytes) { o.ptr = nullptr; o.bytes = 0; }
+  dev_buf& operator=(dev_buf&& o) noexcept
+  {
+    if (this != &o) { release(); ptr = o.ptr; bytes = o.bytes; o.ptr = nullptr; o.bytes = 0; }
+    return *this;
+  }
+  ~dev_buf() { release(); }
+  void alloc(size_t n_bytes)
+  {
+    release();
+    bytes = n_bytes;
+    if (n_bytes == 0) return;
+    hipError_t e = hipMalloc(&ptr, n_bytes);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      ptr = nullptr; bytes = 0;
+      throw api_error(CUGRAPH_ALLOC_ERROR, "hipMalloc of " + std::to_string(n_bytes) + " bytes failed: " + hipGetErrorString(e));
+    }
+  }
+  void release()
+  {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr; bytes = 0;
+  }
+  template <typename T> T* as() const { return static_cast<T*>(ptr); }
+};
+
+template <typename T>
+struct dvec {  // typed convenience wrapper
+  dev_buf buf;
+  size_t n{0};
+  dvec() = default;
+  explicit dvec(size_t n_) : buf(n_ * sizeof(T)), n(n_) {}
+  T* data() const { return buf.as<T>(); }
+  size_t size() const { return n; }
+  void resize_discard(size_t n_) { buf.alloc(n_ * sizeof(T)); n = n_; }
+};
+
+// ------------------------------------------------------------------------------------------ arrays
+struct device_array_view_t {  // behind cugraph_type_erased_device_array_view_t (c_api/array.hpp)
+  void* data;
+  size_t size;
+  cugraph_data_type_id_t type;
+  template <typename T> T* as() const { return static_cast<T*>(data); }
+};
+
+struct device_array_t {  // behind cugraph_type_erased_device_array_t
+  dev_buf buf;
+  size_t size{0};
+  cugraph_data_type_id_t type{INT32};
+  device_array_t(size_t n, cugraph_data_type_id_t t) : buf(n * dtype_size(t)), size(n), type(t) {}
+  device_array_t(dev_buf&& b, size_t n, cugraph_data_type_id_t t) : buf(std::move(b)), size(n), type(t) {}
+  device_array_view_t* new_view() { return new device_array_view_t{buf.ptr, size, type}; }
+};
+
+struct host_array_view_t {
+  void* data;
+  size_t size;
+  cugraph_data_type_id_t type;
+};
+struct host_array_t {
+  std::unique_ptr<uint8_t[]> data;
+  size_t size;
+  cugraph_data_type_id_t type;
+};
+
+// ------------------------------------------------------------------------------------------ handle
+struct kernel_timer {  // HIP-event pairs recorded on the handle's stream (extensions.h)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+};
+
+struct handle_t {  // behind cugraph_resource_handle_t
+  int device{0};
+  hipStream_t stream{nullptr};
+  int num_cus{256};
+  size_t lds_per_block{65536};
+  int rank{0};
+  int comm_size{1};
+  void* pinned{nullptr};  // 4 KiB pinned scratch for scalar read-backs
+  bool timing{false};
+  std::map<std::string, kernel_timer> timers;
+  int pagerank_hot_tile{-1};  // -1 = auto
+  cugraph_amd_traversal_stats_t last_stats{};
+
+  template <typename T> T* pinned_as() const { return static_cast<T*>(pinned); }
+  void sync() const { HIP_TRY(hipStreamSynchronize(stream)); }
+  // D2H of a few scalars through the pinned page; synchronises.
+  template <typename T> void read_back(T* host_out, T const* dev_src, size_t n) const
+  {
+    HIP_TRY(hipMemcpyAsync(pinned, dev_src, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+    sync();
+    std::memcpy(host_out, pinned, n * sizeof(T));
+  }
+};
+
+struct timed_launch {  // RAII bracket: records start/stop events when timing is enabled
+  handle_t* h;
+  kernel_timer* t{nullptr};
+  hipEvent_t stop{nullptr};
+  timed_launch(handle_t const& hc, char const* family) : h(const_cast<handle_t*>(&hc))
+  {
+    if (!h->timing) return;
+    t = &h->timers[family];
+    hipEvent_t start;
+    (void)hipEventCreate(&start);
+    (void)hipEventCreate(&stop);
+    (void)hipEventRecord(start, h->stream);
+    t->events.emplace_back(start, stop);
+  }
+  ~timed_launch()
+  {
+    if (t) (void)hipEventRecord(stop, h->stream);
+  }
+};
+
+// ------------------------------------------------------------------------------------------- graph
+// One compressed-sparse orientation.  `major` = row vertex: source for CSR (store_transposed = false),
+// destination for CSC (store_transposed = true).  Neighbour lists ascending, multi-edges kept.
+// Rows are processed through a degree-descending schedule: row_order == nullptr means rows are already
+// numbered by descending degree (renumber = TRUE, primary orientation).
+struct orientation_t {
+  bool built{false};
+  dvec<int32_t> offsets;    // V + 1
+  dvec<int32_t> indices;    // E (minor ids)
+  dev_buf weights;          // E * sizeof(weight) or empty
+  dvec<int32_t> row_order;  // V (permutation, degree descending) or empty = identity
+  // seg[k] = number of scheduled rows with degree >= seg_threshold[k]
+  static constexpr int n_seg = 4;
+  int64_t seg[n_seg]{0, 0, 0, 0};
+  int32_t max_degree{0};
+};
+
+constexpr int32_t kSegThreshold[orientation_t::n_seg] = {4096, 64, 16, 4};
+
+struct graph_t {  // behind cugraph_graph_t (cpp/src/c_api/graph.hpp:61-77)
+  cugraph_data_type_id_t vertex_type{INT32};
+  cugraph_data_type_id_t edge_type{INT32};
+  cugraph_data_type_id_t weight_type{FLOAT32};
+  bool store_transposed{false};  // orientation requested at creation (primary)
+  bool has_weights{false};
+  bool renumbered{false};
+  cugraph_graph_properties_t props{FALSE, FALSE};
+  int64_t nv{0};
+  int64_t ne{0};
+  dvec<int32_t> number_map;  // internal -> external, size V
+  // external -> internal: dense table over [ext_min, ext_min + ext_range) (-1 = absent); empty when the
+  // graph is not renumbered (identity).
+  int64_t ext_min{0};
+  dvec<int32_t> ext2int;
+  orientation_t csr;  // by source
+  orientation_t csc;  // by destination
+  // cached out-weight sums (a5 in SURVEY 8a): float or double, size V
+  dev_buf out_weight_sums;
+  bool out_weight_sums_valid{false};
+};
+
+inline handle_t const& H(cugraph_resource_handle_t const* h)
+{
+  CGA_EXPECTS(h != nullptr, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
+  return *reinterpret_cast<handle_t const*>(h);
+}
+inline graph_t& G(cugraph_graph_t* g)
+{
+  CGA_EXPECTS(g != nullptr, CUGRAPH_INVALID_INPUT, "graph is NULL");
+  return *reinterpret_cast<graph_t*>(g);
+}
+inline device_array_view_t const* V(cugraph_type_erased_device_array_view_t const* v)
+{
+  return reinterpret_cast<device_array_view_t const*>(v);
+}
+
+// results
+struct centrality_result_t {  // c_api/centrality_result.hpp
+  device_array_t* vertex_ids;
+  device_array_t* values;
+  size_t num_iterations;
+  bool converged;
+};
+struct paths_result_t {  // c_api/paths_result.hpp
+  device_array_t* vertex_ids;
+  device_array_t* distances;
+  device_array_t* predecessors;
+};
+
+// ----------------------------------------------------------------- device primitives (prims.hip)
+constexpr int kBlock = 256;
+inline int grid_for(int64_t n, int block = kBlock, int64_t cap = 1 << 20)
+{
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return static_cast<int>(g);
+}
+
+void fill_i32(handle_t const& h, int32_t* p, int64_t n, int32_t v);
+void fill_u32(handle_t const& h, uint32_t* p, int64_t n, uint32_t v);
+void fill_f32(handle_t const& h, float* p, int64_t n, float v);
+void fill_f64(handle_t const& h, double* p, int64_t n, double v);
+void iota_i32(handle_t const& h, int32_t* p, int64_t n, int32_t first);
+// min / max of an int32 array (n > 0); result on host (synchronises)
+void minmax_i32(handle_t const& h, int32_t const* p, int64_t n, int32_t* mn, int32_t* mx);
+// exclusive prefix sum, out[i] = sum_{j<i} in[j]; in == out allowed; returns nothing (total at out[n] if
+// the caller sized out as n + 1 and passes n + 1 with in[n] = 0).
+void exclusive_scan_u32(handle_t const& h, uint32_t const* in, uint32_t* out, int64_t n);
+// histogram: counts[keys[i]] += 1 (counts pre-zeroed by the caller)
+void histogram_i32(handle_t const& h, int32_t const* keys, int64_t n, uint32_t* counts);
+// stable LSD radix sort of 64-bit keys (only bits [bit_lo, bit_hi) are examined) with a 32-bit payload.
+// keys/vals are sorted in place; tmp buffers of the same size are required.
+void radix_sort_u64_u32(handle_t const& h, uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp,
+                        uint32_t* vals_tmp, int64_t n, int bit_lo, int bit_hi);
+// out[i] = src[idx[i]] for 4- / 8-byte elements
+void gather_b32(handle_t const& h, uint32_t const* src, uint32_t const* idx, uint32_t* out, int64_t n);
+void gather_b64(handle_t const& h, uint64_t const* src, uint32_t const* idx, uint64_t* out, int64_t n);
+
+// graph construction (graph.hip)
+void ensure_orientation(handle_t const& h, graph_t& g, bool transposed);
+// external -> internal ids (in place); absent ids become -1
+void renumber_ext_to_int(handle_t const& h, graph_t const& g, int32_t* ids, int64_t n);
+// internal -> external (in place); negative ids stay as they are
+void unrenumber_int_to_ext(handle_t const& h, graph_t const& g, int32_t* ids, int64_t n);
+int64_t count_negative_i32(handle_t const& h, int32_t const* ids, int64_t n);
+
+}  // namespace cga

@@ -1,0 +1,305 @@
+// Handle, error and type-erased array entry points of the drop-in libcugraph_c.so.
+// Replaces cpp/src/c_api/resource_handle.cpp:11-39, cpp/src/c_api/error.cpp, cpp/src/c_api/array.cpp.
+#include "common.hpp"
+
+using namespace cga;
+
+extern "C" const char* cugraph_amd_version(void) { return "cugraph_amd 0.1.0 (gfx950, HIP, no Thrust/CUB)"; }
+
+// ------------------------------------------------------------------------------------------ errors
+extern "C" const char* cugraph_error_message(const cugraph_error_t* error)
+{
+  return error ? reinterpret_cast<err_obj_t const*>(error)->message.c_str() : nullptr;
+}
+extern "C" void cugraph_error_free(cugraph_error_t* error) { delete reinterpret_cast<err_obj_t*>(error); }
+
+// ------------------------------------------------------------------------------------------ handle
+extern "C" cugraph_resource_handle_t* cugraph_create_resource_handle(void* raft_handle)
+{
+  // A non-NULL argument is a raft::handle_t* in the reference (resource_handle.hpp:12-25); RAFT does not
+  // exist on this platform, so only the library-owned context (NULL) is supported.
+  if (raft_handle != nullptr) return nullptr;
+  try {
+    auto h = std::make_unique<handle_t>();
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { (void)hipGetLastError(); return nullptr; }
+    HIP_TRY(hipGetDevice(&h->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+    h->num_cus       = prop.multiProcessorCount;
+    h->lds_per_block = prop.sharedMemPerBlock;
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc(&h->pinned, 4096, hipHostMallocDefault));
+    return reinterpret_cast<cugraph_resource_handle_t*>(h.release());
+  } catch (...) {
+    return nullptr;
+  }
+}
+
+extern "C" int cugraph_resource_handle_get_comm_size(const cugraph_resource_handle_t* handle)
+{
+  return handle ? reinterpret_cast<handle_t const*>(handle)->comm_size : 0;
+}
+extern "C" int cugraph_resource_handle_get_rank(const cugraph_resource_handle_t* handle)
+{
+  return handle ? reinterpret_cast<handle_t const*>(handle)->rank : 0;
+}
+
+static void free_timers(handle_t* h)
+{
+  for (auto& kv : h->timers)
+    for (auto& ev : kv.second.events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  h->timers.clear();
+}
+
+extern "C" void cugraph_free_resource_handle(cugraph_resource_handle_t* handle)
+{
+  if (!handle) return;
+  auto* h = reinterpret_cast<handle_t*>(handle);
+  (void)hipStreamSynchronize(h->stream);
+  free_timers(h);
+  if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" cugraph_error_code_t cugraph_amd_handle_sync(const cugraph_resource_handle_t* handle, cugraph_error_t** error)
+{
+  return guarded(error, [&] { H(handle).sync(); });
+}
+
+extern "C" void cugraph_amd_kernel_timing_enable(const cugraph_resource_handle_t* handle, bool_t on)
+{
+  if (handle) const_cast<handle_t*>(reinterpret_cast<handle_t const*>(handle))->timing = on == TRUE;
+}
+extern "C" void cugraph_amd_kernel_timing_reset(const cugraph_resource_handle_t* handle)
+{
+  if (!handle) return;
+  auto* h = const_cast<handle_t*>(reinterpret_cast<handle_t const*>(handle));
+  (void)hipStreamSynchronize(h->stream);
+  free_timers(h);
+}
+extern "C" cugraph_error_code_t cugraph_amd_kernel_timing_get(const cugraph_resource_handle_t* handle, const char* family,
+                                                              size_t* launches, double* total_ms, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    h.sync();
+    size_t n = 0;
+    double ms = 0.0;
+    auto it = h.timers.find(family ? family : "");
+    if (it != h.timers.end()) {
+      for (auto const& ev : it->second.events) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, ev.first, ev.second));
+        ms += t;
+        ++n;
+      }
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+  });
+}
+
+extern "C" int cugraph_amd_set_pagerank_hot_tile(const cugraph_resource_handle_t* handle, int n_entries)
+{
+  if (!handle) return -1;
+  auto* h  = const_cast<handle_t*>(reinterpret_cast<handle_t const*>(handle));
+  int prev = h->pagerank_hot_tile;
+  h->pagerank_hot_tile = n_entries;
+  return prev;
+}
+
+extern "C" void cugraph_amd_last_traversal_stats(const cugraph_resource_handle_t* handle, cugraph_amd_traversal_stats_t* out)
+{
+  if (handle && out) *out = reinterpret_cast<handle_t const*>(handle)->last_stats;
+}
+
+// ----------------------------------------------------------------------------------- device arrays
+extern "C" cugraph_error_code_t cugraph_type_erased_device_array_create(const cugraph_resource_handle_t* handle, size_t n_elems,
+                                                                        cugraph_data_type_id_t dtype,
+                                                                        cugraph_type_erased_device_array_t** array,
+                                                                        cugraph_error_t** error)
+{
+  if (array) *array = nullptr;
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    CGA_EXPECTS(array != nullptr, CUGRAPH_INVALID_INPUT, "array is NULL");
+    CGA_EXPECTS(dtype_size(dtype) != 0, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "unsupported data type");
+    HIP_TRY(hipSetDevice(h.device));
+    *array = reinterpret_cast<cugraph_type_erased_device_array_t*>(new device_array_t(n_elems, dtype));
+  });
+}
+
+extern "C" cugraph_error_code_t cugraph_type_erased_device_array_create_from_view(
+  const cugraph_resource_handle_t* handle, const cugraph_type_erased_device_array_view_t* view,
+  cugraph_type_erased_device_array_t** array, cugraph_error_t** error)
+{
+  if (array) *array = nullptr;
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    auto v            = V(view);
+    CGA_EXPECTS(array != nullptr && v != nullptr, CUGRAPH_INVALID_INPUT, "array / view is NULL");
+    auto a = std::make_unique<device_array_t>(v->size, v->type);
+    if (v->size > 0) HIP_TRY(hipMemcpyAsync(a->buf.ptr, v->data, v->size * dtype_size(v->type), hipMemcpyDeviceToDevice, h.stream));
+    h.sync();
+    *array = reinterpret_cast<cugraph_type_erased_device_array_t*>(a.release());
+  });
+}
+
+extern "C" void cugraph_type_erased_device_array_free(cugraph_type_erased_device_array_t* p)
+{
+  delete reinterpret_cast<device_array_t*>(p);
+}
+
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_type_erased_device_array_view(cugraph_type_erased_device_array_t* array)
+{
+  if (!array) return nullptr;
+  return reinterpret_cast<cugraph_type_erased_device_array_view_t*>(reinterpret_cast<device_array_t*>(array)->new_view());
+}
+
+extern "C" cugraph_error_code_t cugraph_type_erased_device_array_view_as_type(cugraph_type_erased_device_array_t* array,
+                                                                              cugraph_data_type_id_t dtype,
+                                                                              cugraph_type_erased_device_array_view_t** result_view,
+                                                                              cugraph_error_t** error)
+{
+  if (result_view) *result_view = nullptr;
+  return guarded(error, [&] {
+    auto a = reinterpret_cast<device_array_t*>(array);
+    CGA_EXPECTS(a != nullptr && result_view != nullptr, CUGRAPH_INVALID_INPUT, "array / result_view is NULL");
+    // array.cpp:187-208: reinterpretation is allowed between types of the same width only
+    CGA_EXPECTS(dtype_size(dtype) == dtype_size(a->type), CUGRAPH_INVALID_INPUT, "Could not treat type erased device array as the requested type");
+    *result_view = reinterpret_cast<cugraph_type_erased_device_array_view_t*>(new device_array_view_t{a->buf.ptr, a->size, dtype});
+  });
+}
+
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_type_erased_device_array_view_create(void* pointer, size_t n_elems,
+                                                                                                cugraph_data_type_id_t dtype)
+{
+  return reinterpret_cast<cugraph_type_erased_device_array_view_t*>(new device_array_view_t{pointer, n_elems, dtype});
+}
+extern "C" void cugraph_type_erased_device_array_view_free(cugraph_type_erased_device_array_view_t* p)
+{
+  delete reinterpret_cast<device_array_view_t*>(p);
+}
+extern "C" size_t cugraph_type_erased_device_array_view_size(const cugraph_type_erased_device_array_view_t* p)
+{
+  return p ? V(p)->size : 0;
+}
+extern "C" cugraph_data_type_id_t cugraph_type_erased_device_array_view_type(const cugraph_type_erased_device_array_view_t* p)
+{
+  return p ? V(p)->type : NTYPES;
+}
+extern "C" const void* cugraph_type_erased_device_array_view_pointer(const cugraph_type_erased_device_array_view_t* p)
+{
+  return p ? V(p)->data : nullptr;
+}
+
+// ------------------------------------------------------------------------------------- host arrays
+extern "C" cugraph_error_code_t cugraph_type_erased_host_array_create(const cugraph_resource_handle_t*, size_t n_elems,
+                                                                      cugraph_data_type_id_t dtype,
+                                                                      cugraph_type_erased_host_array_t** array,
+                                                                      cugraph_error_t** error)
+{
+  if (array) *array = nullptr;
+  return guarded(error, [&] {
+    CGA_EXPECTS(array != nullptr, CUGRAPH_INVALID_INPUT, "array is NULL");
+    CGA_EXPECTS(dtype_size(dtype) != 0, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "unsupported data type");
+    auto a  = new host_array_t{std::unique_ptr<uint8_t[]>(new uint8_t[n_elems * dtype_size(dtype) + 1]), n_elems, dtype};
+    *array  = reinterpret_cast<cugraph_type_erased_host_array_t*>(a);
+  });
+}
+extern "C" void cugraph_type_erased_host_array_free(cugraph_type_erased_host_array_t* p) { delete reinterpret_cast<host_array_t*>(p); }
+extern "C" cugraph_type_erased_host_array_view_t* cugraph_type_erased_host_array_view(cugraph_type_erased_host_array_t* array)
+{
+  if (!array) return nullptr;
+  auto a = reinterpret_cast<host_array_t*>(array);
+  return reinterpret_cast<cugraph_type_erased_host_array_view_t*>(new host_array_view_t{a->data.get(), a->size, a->type});
+}
+extern "C" cugraph_type_erased_host_array_view_t* cugraph_type_erased_host_array_view_create(void* pointer, size_t n_elems,
+                                                                                            cugraph_data_type_id_t dtype)
+{
+  return reinterpret_cast<cugraph_type_erased_host_array_view_t*>(new host_array_view_t{pointer, n_elems, dtype});
+}
+extern "C" void cugraph_type_erased_host_array_view_free(cugraph_type_erased_host_array_view_t* p)
+{
+  delete reinterpret_cast<host_array_view_t*>(p);
+}
+extern "C" size_t cugraph_type_erased_host_array_size(const cugraph_type_erased_host_array_view_t* p)
+{
+  return p ? reinterpret_cast<host_array_view_t const*>(p)->size : 0;
+}
+extern "C" cugraph_data_type_id_t cugraph_type_erased_host_array_type(const cugraph_type_erased_host_array_view_t* p)
+{
+  return p ? reinterpret_cast<host_array_view_t const*>(p)->type : NTYPES;
+}
+extern "C" void* cugraph_type_erased_host_array_pointer(const cugraph_type_erased_host_array_view_t* p)
+{
+  return p ? reinterpret_cast<host_array_view_t const*>(p)->data : nullptr;
+}
+extern "C" cugraph_error_code_t cugraph_type_erased_host_array_view_copy(const cugraph_resource_handle_t*,
+                                                                         cugraph_type_erased_host_array_view_t* dst,
+                                                                         const cugraph_type_erased_host_array_view_t* src,
+                                                                         cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    auto d = reinterpret_cast<host_array_view_t*>(dst);
+    auto s = reinterpret_cast<host_array_view_t const*>(src);
+    CGA_EXPECTS(d && s, CUGRAPH_INVALID_INPUT, "dst / src is NULL");
+    CGA_EXPECTS(d->size == s->size && d->type == s->type, CUGRAPH_INVALID_INPUT, "Type and size of src and dst must match");
+    std::memcpy(d->data, s->data, s->size * dtype_size(s->type));
+  });
+}
+
+// ------------------------------------------------------------------------------------------ copies
+extern "C" cugraph_error_code_t cugraph_type_erased_device_array_view_copy_from_host(const cugraph_resource_handle_t* handle,
+                                                                                     cugraph_type_erased_device_array_view_t* dst,
+                                                                                     const byte_t* h_src, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    auto d            = V(dst);
+    CGA_EXPECTS(d != nullptr, CUGRAPH_INVALID_INPUT, "dst is NULL");
+    size_t bytes = d->size * dtype_size(d->type);
+    if (bytes == 0) return;
+    CGA_EXPECTS(h_src != nullptr, CUGRAPH_INVALID_INPUT, "h_src is NULL");
+    HIP_TRY(hipMemcpyAsync(d->data, h_src, bytes, hipMemcpyHostToDevice, h.stream));
+    h.sync();  // h_src may be pageable and short-lived
+  });
+}
+
+extern "C" cugraph_error_code_t cugraph_type_erased_device_array_view_copy_to_host(const cugraph_resource_handle_t* handle,
+                                                                                   byte_t* h_dst,
+                                                                                   const cugraph_type_erased_device_array_view_t* src,
+                                                                                   cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    auto s            = V(src);
+    CGA_EXPECTS(s != nullptr, CUGRAPH_INVALID_INPUT, "src is NULL");
+    size_t bytes = s->size * dtype_size(s->type);
+    if (bytes == 0) return;
+    CGA_EXPECTS(h_dst != nullptr, CUGRAPH_INVALID_INPUT, "h_dst is NULL");
+    HIP_TRY(hipMemcpyAsync(h_dst, s->data, bytes, hipMemcpyDeviceToHost, h.stream));
+    h.sync();  // array.cpp:348-352 synchronises too
+  });
+}
+
+extern "C" cugraph_error_code_t cugraph_type_erased_device_array_view_copy(const cugraph_resource_handle_t* handle,
+                                                                           cugraph_type_erased_device_array_view_t* dst,
+                                                                           const cugraph_type_erased_device_array_view_t* src,
+                                                                           cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    auto d = V(dst);
+    auto s = V(src);
+    CGA_EXPECTS(d && s, CUGRAPH_INVALID_INPUT, "dst / src is NULL");
+    CGA_EXPECTS(d->type == s->type, CUGRAPH_INVALID_INPUT, "type of src and dst must match");
+    CGA_EXPECTS(d->size == s->size, CUGRAPH_INVALID_INPUT, "size of src and dst must match");
+    size_t bytes = s->size * dtype_size(s->type);
+    if (bytes == 0) return;
+    HIP_TRY(hipMemcpyAsync(d->data, s->data, bytes, hipMemcpyDeviceToDevice, h.stream));
+    h.sync();  // callers free the source right after (pylibcugraph utils.pyx:162-196); see SURVEY section 9.8
+  });
+}

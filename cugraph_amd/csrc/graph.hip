@@ -1,0 +1,526 @@
+// Graph construction for the PageRank / BFS / SSSP path, written for gfx950.
+//
+// Replaces:
+//   cugraph_graph_create_sg / _with_times_sg / _from_csr     cpp/src/c_api/graph_sg.cpp:699, :835, :989
+//   create_graph_from_edgelist (SG)                          cpp/src/structure/create_graph_from_edgelist_impl.cuh:1434-1686
+//   renumber_edgelist / compute_renumber_map                 cpp/src/structure/renumber_edgelist_impl.cuh:425-829
+//   sort_and_compress_edgelist                               cpp/src/structure/detail/structure_utils.cuh:197-464
+//   transpose_graph_storage (as "build the other orientation under the SAME numbering")
+//                                                            cpp/src/structure/transpose_graph_storage_impl.cuh:41-100
+//   renumber_ext_vertices / unrenumber_int_vertices          cpp/src/structure/renumber_utils_impl.cuh:333-660
+//   cugraph_has_vertex                                       cpp/src/c_api/graph_functions.cpp:391
+//
+// Design (MI355X-first, not the reference's): external ids are mapped through a dense HBM-resident table
+// (no hash map: 288 GB of HBM makes a 4 B x id-range table the cheapest ext->int map for analytics inputs);
+// vertices are renumbered by descending major degree with ties by ascending external id (deterministic,
+// where the reference's thrust::sort_by_key is unstable, renumber_edgelist_impl.cuh:734-738); COO -> CSR/CSC
+// is one stable LSD radix sort of packed (major << 32 | minor) keys with the edge position as payload;
+// CSR and CSC coexist under one numbering.
+#include "common.hpp"
+
+namespace cga {
+
+namespace {
+
+__global__ void k_mark(int32_t const* ids, int64_t n, int64_t vmin, uint32_t* flags)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) flags[(int64_t)ids[i] - vmin] = 1u;
+}
+
+// deg[rank[major - vmin]] += 1
+__global__ void k_degree_compact(int32_t const* major, int64_t n, int64_t vmin, uint32_t const* rank, uint32_t* deg)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) atomicAdd(&deg[rank[(int64_t)major[i] - vmin]], 1u);
+}
+
+__global__ void k_degree_keys(uint32_t const* deg, int64_t n, uint32_t maxdeg, uint64_t* keys, uint32_t* vals)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) { keys[i] = (uint64_t)(maxdeg - deg[i]); vals[i] = (uint32_t)i; }
+}
+
+// ext_of_compact[rank[r]] = r for every present r
+__global__ void k_compact_ext(uint32_t const* flags, uint32_t const* rank, int64_t range, int32_t* ext_of_compact, int64_t vmin)
+{
+  int64_t r      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; r < range; r += stride)
+    if (flags[r]) ext_of_compact[rank[r]] = (int32_t)(r + vmin);
+}
+
+// number_map[i] = ext_of_compact[order[i]];  int_of_compact[order[i]] = i
+__global__ void k_number_map(uint32_t const* order, int32_t const* ext_of_compact, int64_t nv, int32_t* number_map, int32_t* int_of_compact)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nv; i += stride) {
+    uint32_t c        = order[i];
+    number_map[i]     = ext_of_compact[c];
+    int_of_compact[c] = (int32_t)i;
+  }
+}
+
+__global__ void k_ext2int(uint32_t const* flags, uint32_t const* rank, int32_t const* int_of_compact, int64_t range, int32_t* ext2int)
+{
+  int64_t r      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; r < range; r += stride) ext2int[r] = flags[r] ? int_of_compact[rank[r]] : -1;
+}
+
+// ids[i] <- table[ids[i] - vmin] (or -1 when out of the table); table == nullptr: identity with bound nv
+__global__ void k_lookup(int32_t* ids, int64_t n, int32_t const* table, int64_t vmin, int64_t range, int64_t nv)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    int64_t v = ids[i];
+    if (table) {
+      int64_t r = v - vmin;
+      ids[i]    = (r >= 0 && r < range) ? table[r] : -1;
+    } else {
+      ids[i] = (v >= 0 && v < nv) ? (int32_t)v : -1;
+    }
+  }
+}
+
+__global__ void k_unrenumber(int32_t* ids, int64_t n, int32_t const* number_map)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    int32_t v = ids[i];
+    if (v >= 0) ids[i] = number_map[v];
+  }
+}
+
+__global__ void k_pack_keys(int32_t const* major, int32_t const* minor, int64_t n, uint64_t* keys, uint32_t* vals)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    keys[i] = ((uint64_t)(uint32_t)major[i] << 32) | (uint32_t)minor[i];
+    vals[i] = (uint32_t)i;
+  }
+}
+
+__global__ void k_unpack_minor(uint64_t const* keys, int64_t n, int32_t* indices, uint32_t* counts)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint64_t k = keys[i];
+    indices[i] = (int32_t)(uint32_t)k;
+    atomicAdd(&counts[k >> 32], 1u);
+  }
+}
+
+__global__ void k_row_degrees(int32_t const* offsets, int64_t nv, uint32_t* deg)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nv; i += stride) deg[i] = (uint32_t)(offsets[i + 1] - offsets[i]);
+}
+
+// sorted[i] = deg[order ? order[i] : i]; checks monotone non-increasing; counts rows >= thresholds
+__global__ void k_schedule_stats(uint32_t const* deg, int32_t const* order, int64_t nv, unsigned long long* seg /*[4]*/,
+                                 uint32_t* not_sorted, uint32_t* maxdeg)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned c[orientation_t::n_seg] = {0, 0, 0, 0};
+  uint32_t mx = 0;
+  bool bad    = false;
+  for (; i < nv; i += stride) {
+    uint32_t d = deg[order ? order[i] : i];
+    if (i + 1 < nv) {
+      uint32_t dn = deg[order ? order[i + 1] : i + 1];
+      bad |= dn > d;
+    }
+    mx = max(mx, d);
+#pragma unroll
+    for (int k = 0; k < orientation_t::n_seg; ++k) c[k] += d >= (uint32_t)kSegThreshold[k];
+  }
+#pragma unroll
+  for (int k = 0; k < orientation_t::n_seg; ++k) {
+    unsigned v = c[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&seg[k], (unsigned long long)v);
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(maxdeg, mx);
+  if (bad) atomicOr(not_sorted, 1u);
+}
+
+// major id of every edge position: rows[e] = v for offsets[v] <= e < offsets[v+1]
+__global__ void k_expand_rows(int32_t const* offsets, int64_t nv, int32_t* rows)
+{
+  // one wave per row chunk: rows are short on average, long rows are striped across the wave
+  int64_t wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int lane       = threadIdx.x & 63;
+  for (int64_t v = wave; v < nv; v += nwaves) {
+    int32_t b = offsets[v], e = offsets[v + 1];
+    for (int32_t p = b + lane; p < e; p += 64) rows[p] = (int32_t)v;
+  }
+}
+
+__global__ void k_has_vertex(int32_t const* ids, int64_t n, int32_t const* table, int64_t vmin, int64_t range, int64_t nv, uint8_t* out)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    int64_t v = ids[i];
+    bool ok;
+    if (table) {
+      int64_t r = v - vmin;
+      ok        = (r >= 0 && r < range) && table[r] >= 0;
+    } else {
+      ok = v >= 0 && v < nv;
+    }
+    out[i] = ok ? 1 : 0;
+  }
+}
+
+int bits_for(uint64_t max_value)
+{
+  int b = 0;
+  while (b < 64 && (max_value >> b) != 0) ++b;
+  return b < 1 ? 1 : b;
+}
+
+// Builds one orientation from an internal-id COO list.  major/minor/weights are left untouched.
+void build_orientation(handle_t const& h, int64_t nv, int64_t ne, int32_t const* major, int32_t const* minor,
+                       void const* weights, size_t wsize, orientation_t& o)
+{
+  o.offsets.resize_discard(nv + 1);
+  o.indices.resize_discard(ne);
+  dvec<uint32_t> counts(nv + 1);
+  HIP_TRY(hipMemsetAsync(counts.data(), 0, (nv + 1) * sizeof(uint32_t), h.stream));
+  if (ne > 0) {
+    dvec<uint64_t> keys(ne), keys_tmp(ne);
+    dvec<uint32_t> vals(ne), vals_tmp(ne);
+    hipLaunchKernelGGL(k_pack_keys, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, major, minor, ne, keys.data(), vals.data());
+    int vb = bits_for(nv > 0 ? (uint64_t)(nv - 1) : 0);
+    radix_sort_u64_u32(h, keys.data(), vals.data(), keys_tmp.data(), vals_tmp.data(), ne, 0, vb);
+    radix_sort_u64_u32(h, keys.data(), vals.data(), keys_tmp.data(), vals_tmp.data(), ne, 32, 32 + vb);
+    hipLaunchKernelGGL(k_unpack_minor, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), ne,
+                       o.indices.data(), counts.data());
+    if (weights) {
+      o.weights.alloc(ne * wsize);
+      if (wsize == 4) gather_b32(h, (uint32_t const*)weights, vals.data(), o.weights.as<uint32_t>(), ne);
+      else            gather_b64(h, (uint64_t const*)weights, vals.data(), o.weights.as<uint64_t>(), ne);
+    }
+    h.sync();  // temporaries die here
+  }
+  exclusive_scan_u32(h, counts.data(), reinterpret_cast<uint32_t*>(o.offsets.data()), nv + 1);
+
+  // degree-descending row schedule + class boundaries
+  dvec<uint32_t> deg(nv > 0 ? nv : 1);
+  dvec<unsigned long long> seg(orientation_t::n_seg);
+  dvec<uint32_t> flags(2);  // [not_sorted, maxdeg]
+  auto stats = [&](int32_t const* order, unsigned long long* seg_h, uint32_t* flags_h) {
+    HIP_TRY(hipMemsetAsync(seg.data(), 0, sizeof(unsigned long long) * orientation_t::n_seg, h.stream));
+    HIP_TRY(hipMemsetAsync(flags.data(), 0, 2 * sizeof(uint32_t), h.stream));
+    if (nv > 0)
+      hipLaunchKernelGGL(k_schedule_stats, grid_for(nv, kBlock, 2048), kBlock, 0, h.stream, (uint32_t const*)deg.data(), order, nv,
+                         seg.data(), flags.data(), flags.data() + 1);
+    h.read_back(seg_h, seg.data(), orientation_t::n_seg);
+    h.read_back(flags_h, flags.data(), 2);
+  };
+  if (nv > 0) hipLaunchKernelGGL(k_row_degrees, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)o.offsets.data(), nv, deg.data());
+  unsigned long long seg_h[orientation_t::n_seg];
+  uint32_t flags_h[2];
+  stats(nullptr, seg_h, flags_h);
+  o.max_degree = (int32_t)flags_h[1];
+  o.row_order  = dvec<int32_t>();
+  if (flags_h[0] != 0) {  // ids are not degree-sorted: build the permutation
+    dvec<uint64_t> keys(nv), keys_tmp(nv);
+    dvec<uint32_t> vals(nv), vals_tmp(nv);
+    hipLaunchKernelGGL(k_degree_keys, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, (uint32_t const*)deg.data(), nv, flags_h[1], keys.data(), vals.data());
+    radix_sort_u64_u32(h, keys.data(), vals.data(), keys_tmp.data(), vals_tmp.data(), nv, 0, bits_for(flags_h[1]));
+    o.row_order.resize_discard(nv);
+    HIP_TRY(hipMemcpyAsync(o.row_order.data(), vals.data(), nv * sizeof(int32_t), hipMemcpyDeviceToDevice, h.stream));
+    h.sync();
+  }
+  for (int k = 0; k < orientation_t::n_seg; ++k) o.seg[k] = (int64_t)seg_h[k];  // counts do not depend on the order
+  o.built = true;
+  h.sync();
+}
+
+void check_view(device_array_view_t const* v, char const* name)
+{
+  CGA_EXPECTS(v == nullptr || v->size == 0 || v->data != nullptr, CUGRAPH_INVALID_INPUT, std::string("Invalid input arguments: ") + name + " has a NULL pointer.");
+}
+
+cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_graph_properties_t const* properties,
+                               device_array_view_t const* vertices, device_array_view_t const* src,
+                               device_array_view_t const* dst, device_array_view_t const* weights,
+                               device_array_view_t const* edge_ids, device_array_view_t const* edge_type_ids,
+                               device_array_view_t const* t0, device_array_view_t const* t1, bool_t store_transposed,
+                               bool_t renumber, bool_t drop_self_loops, bool_t drop_multi_edges, bool_t symmetrize,
+                               cugraph_graph_t** graph, cugraph_error_t** error)
+{
+  if (graph) *graph = nullptr;
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    CGA_EXPECTS(graph != nullptr && properties != nullptr && src != nullptr && dst != nullptr, CUGRAPH_INVALID_INPUT,
+                "Invalid input arguments: NULL graph / properties / src / dst.");
+    HIP_TRY(hipSetDevice(h.device));
+    if (symmetrize == TRUE)
+      CGA_EXPECTS(properties->is_symmetric == TRUE, CUGRAPH_INVALID_INPUT,
+                  "Invalid input arguments: The graph property must be symmetric if 'symmetrize' is set to True.");
+    CGA_EXPECTS(src->size == dst->size, CUGRAPH_INVALID_INPUT, "Invalid input arguments: src size != dst size.");
+    CGA_EXPECTS(weights == nullptr || weights->size == src->size, CUGRAPH_INVALID_INPUT,
+                "Invalid input arguments: src size != weights size.");
+    CGA_EXPECTS(edge_ids == nullptr || edge_ids->size == src->size, CUGRAPH_INVALID_INPUT,
+                "Invalid input arguments: src size != edge id prop size");
+    CGA_EXPECTS(edge_type_ids == nullptr || edge_type_ids->size == src->size, CUGRAPH_INVALID_INPUT,
+                "Invalid input arguments: src size != edge type prop size");
+    if (src->type == INT32)
+      CGA_EXPECTS(src->size < (size_t)INT32_MAX, CUGRAPH_INVALID_INPUT,
+                  "Number of edges won't fit in 32-bit integer, using 32-bit type");
+    // type rules (graph_sg.cpp:745-779): mixed vertex types promote to INT64 -> not in this build
+    bool same = src->type == dst->type && (vertices == nullptr || vertices->type == src->type);
+    CGA_EXPECTS(same && src->type == INT32, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
+                "this build supports INT32 vertex / edge ids only (INT64 graphs: not implemented yet)");
+    CGA_EXPECTS(weights == nullptr || weights->type == FLOAT32 || weights->type == FLOAT64,
+                CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "weights must be FLOAT32 or FLOAT64");
+    CGA_EXPECTS(edge_ids == nullptr && edge_type_ids == nullptr && t0 == nullptr && t1 == nullptr, CUGRAPH_NOT_IMPLEMENTED,
+                "edge ids / edge types / edge times are not on the PageRank/BFS/SSSP path and are not implemented");
+    CGA_EXPECTS(drop_self_loops == FALSE && drop_multi_edges == FALSE && symmetrize == FALSE, CUGRAPH_NOT_IMPLEMENTED,
+                "drop_self_loops / drop_multi_edges / symmetrize are not implemented yet");
+    check_view(src, "src"); check_view(dst, "dst"); check_view(weights, "weights"); check_view(vertices, "vertices");
+
+    auto g              = std::make_unique<graph_t>();
+    g->vertex_type      = INT32;
+    g->edge_type        = INT32;
+    g->weight_type      = weights ? weights->type : FLOAT32;
+    g->has_weights      = weights != nullptr;
+    g->store_transposed = store_transposed == TRUE;
+    g->renumbered       = renumber == TRUE;
+    g->props            = *properties;
+    int64_t const ne    = (int64_t)src->size;
+    g->ne               = ne;
+    size_t const wsize  = weights ? dtype_size(weights->type) : 0;
+
+    // inputs are borrowed: work on copies (graph_sg.cpp:98-183)
+    dvec<int32_t> s(ne), d(ne);
+    if (ne > 0) {
+      HIP_TRY(hipMemcpyAsync(s.data(), src->data, ne * 4, hipMemcpyDeviceToDevice, h.stream));
+      HIP_TRY(hipMemcpyAsync(d.data(), dst->data, ne * 4, hipMemcpyDeviceToDevice, h.stream));
+    }
+    int64_t const nvl = vertices ? (int64_t)vertices->size : 0;
+
+    int32_t vmin = 0, vmax = -1;
+    {
+      int32_t a, b;
+      bool any = false;
+      auto upd = [&](int32_t const* p, int64_t n) {
+        if (n <= 0) return;
+        minmax_i32(h, p, n, &a, &b);
+        if (!any) { vmin = a; vmax = b; any = true; } else { vmin = std::min(vmin, a); vmax = std::max(vmax, b); }
+      };
+      upd(s.data(), ne); upd(d.data(), ne);
+      if (vertices) upd(vertices->as<int32_t>(), nvl);
+    }
+
+    if (renumber == TRUE) {
+      int64_t range = vmax >= vmin ? (int64_t)vmax - vmin + 1 : 0;
+      CGA_EXPECTS(range <= ((int64_t)1 << 31) - 2, CUGRAPH_NOT_IMPLEMENTED, "external vertex id range too wide for the dense renumbering table");
+      dvec<uint32_t> flags(range + 1), rank(range + 1);
+      HIP_TRY(hipMemsetAsync(flags.data(), 0, (range + 1) * 4, h.stream));
+      if (ne > 0) {
+        hipLaunchKernelGGL(k_mark, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)s.data(), ne, (int64_t)vmin, flags.data());
+        hipLaunchKernelGGL(k_mark, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)d.data(), ne, (int64_t)vmin, flags.data());
+      }
+      if (nvl > 0) hipLaunchKernelGGL(k_mark, grid_for(nvl, kBlock, 8192), kBlock, 0, h.stream, vertices->as<int32_t>(), nvl, (int64_t)vmin, flags.data());
+      exclusive_scan_u32(h, flags.data(), rank.data(), range + 1);
+      uint32_t nv32 = 0;
+      h.read_back(&nv32, rank.data() + range, 1);
+      int64_t const nv = nv32;
+      g->nv            = nv;
+      // major degree per compact id
+      dvec<uint32_t> deg(nv > 0 ? nv : 1);
+      HIP_TRY(hipMemsetAsync(deg.data(), 0, (nv > 0 ? nv : 1) * 4, h.stream));
+      int32_t const* major_ext = store_transposed == TRUE ? d.data() : s.data();
+      if (ne > 0) hipLaunchKernelGGL(k_degree_compact, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, major_ext, ne, (int64_t)vmin, (uint32_t const*)rank.data(), deg.data());
+      int32_t dmin = 0, dmax = 0;
+      if (nv > 0) minmax_i32(h, reinterpret_cast<int32_t const*>(deg.data()), nv, &dmin, &dmax);
+      dvec<uint64_t> keys(nv > 0 ? nv : 1), keys_tmp(nv > 0 ? nv : 1);
+      dvec<uint32_t> order(nv > 0 ? nv : 1), order_tmp(nv > 0 ? nv : 1);
+      dvec<int32_t> ext_of_compact(nv > 0 ? nv : 1), int_of_compact(nv > 0 ? nv : 1);
+      g->number_map.resize_discard(nv);
+      g->ext2int.resize_discard(range);
+      g->ext_min = vmin;
+      if (nv > 0) {
+        hipLaunchKernelGGL(k_degree_keys, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, (uint32_t const*)deg.data(), nv, (uint32_t)dmax, keys.data(), order.data());
+        radix_sort_u64_u32(h, keys.data(), order.data(), keys_tmp.data(), order_tmp.data(), nv, 0, bits_for((uint32_t)dmax));
+        hipLaunchKernelGGL(k_compact_ext, grid_for(range, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)flags.data(), (uint32_t const*)rank.data(), range, ext_of_compact.data(), (int64_t)vmin);
+        hipLaunchKernelGGL(k_number_map, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, (uint32_t const*)order.data(), (int32_t const*)ext_of_compact.data(), nv, g->number_map.data(), int_of_compact.data());
+        hipLaunchKernelGGL(k_ext2int, grid_for(range, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)flags.data(), (uint32_t const*)rank.data(), (int32_t const*)int_of_compact.data(), range, g->ext2int.data());
+        if (ne > 0) {
+          hipLaunchKernelGGL(k_lookup, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, s.data(), ne, (int32_t const*)g->ext2int.data(), (int64_t)vmin, range, nv);
+          hipLaunchKernelGGL(k_lookup, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, d.data(), ne, (int32_t const*)g->ext2int.data(), (int64_t)vmin, range, nv);
+        }
+      }
+      h.sync();
+    } else {
+      // ids are 0..V-1, V = |vertices| or max id + 1 (create_graph_from_edgelist_impl.cuh:1519-1521)
+      CGA_EXPECTS(vmax < vmin || vmin >= 0, CUGRAPH_INVALID_INPUT, "Invalid input arguments: negative vertex id with renumber = FALSE.");
+      int64_t nv = vertices ? nvl : (int64_t)vmax + 1;
+      CGA_EXPECTS((int64_t)vmax < nv, CUGRAPH_INVALID_INPUT, "Invalid input arguments: vertex id out of range with renumber = FALSE.");
+      g->nv = nv;
+      g->number_map.resize_discard(nv);
+      iota_i32(h, g->number_map.data(), nv, 0);
+    }
+
+    orientation_t& primary = g->store_transposed ? g->csc : g->csr;
+    int32_t const* major   = g->store_transposed ? d.data() : s.data();
+    int32_t const* minor   = g->store_transposed ? s.data() : d.data();
+    build_orientation(h, g->nv, ne, major, minor, weights ? weights->data : nullptr, wsize, primary);
+    *graph = reinterpret_cast<cugraph_graph_t*>(g.release());
+  });
+}
+
+}  // namespace
+
+// Builds the missing orientation under the same numbering (the reference re-creates and re-numbers the
+// graph instead, cpp/src/c_api/graph.hpp:84-143).
+void ensure_orientation(handle_t const& h, graph_t& g, bool transposed)
+{
+  orientation_t& want = transposed ? g.csc : g.csr;
+  if (want.built) return;
+  orientation_t& have = transposed ? g.csr : g.csc;
+  CGA_EXPECTS(have.built, CUGRAPH_UNKNOWN_ERROR, "graph has no storage");
+  dvec<int32_t> rows(g.ne > 0 ? g.ne : 1);
+  if (g.nv > 0 && g.ne > 0)
+    hipLaunchKernelGGL(k_expand_rows, grid_for(g.nv * 16, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)have.offsets.data(), g.nv, rows.data());
+  size_t wsize = g.has_weights ? dtype_size(g.weight_type) : 0;
+  // new major = old minor (indices), new minor = old major (rows)
+  build_orientation(h, g.nv, g.ne, have.indices.data(), rows.data(), g.has_weights ? have.weights.ptr : nullptr, wsize, want);
+}
+
+void renumber_ext_to_int(handle_t const& h, graph_t const& g, int32_t* ids, int64_t n)
+{
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_lookup, grid_for(n, kBlock, 4096), kBlock, 0, h.stream, ids, n,
+                     g.renumbered ? (int32_t const*)g.ext2int.data() : (int32_t const*)nullptr, g.ext_min, (int64_t)g.ext2int.size(), g.nv);
+}
+
+void unrenumber_int_to_ext(handle_t const& h, graph_t const& g, int32_t* ids, int64_t n)
+{
+  if (n <= 0 || !g.renumbered) return;
+  hipLaunchKernelGGL(k_unrenumber, grid_for(n, kBlock, 4096), kBlock, 0, h.stream, ids, n, (int32_t const*)g.number_map.data());
+}
+
+}  // namespace cga
+
+using namespace cga;
+
+extern "C" cugraph_error_code_t cugraph_graph_create_sg(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* vertices, const cugraph_type_erased_device_array_view_t* src,
+  const cugraph_type_erased_device_array_view_t* dst, const cugraph_type_erased_device_array_view_t* weights,
+  const cugraph_type_erased_device_array_view_t* edge_ids, const cugraph_type_erased_device_array_view_t* edge_type_ids,
+  bool_t store_transposed, bool_t renumber, bool_t drop_self_loops, bool_t drop_multi_edges, bool_t symmetrize,
+  bool_t /*do_expensive_check*/, cugraph_graph_t** graph, cugraph_error_t** error)
+{
+  return create_sg(handle, properties, V(vertices), V(src), V(dst), V(weights), V(edge_ids), V(edge_type_ids), nullptr, nullptr,
+                   store_transposed, renumber, drop_self_loops, drop_multi_edges, symmetrize, graph, error);
+}
+
+extern "C" cugraph_error_code_t cugraph_graph_create_with_times_sg(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* vertices, const cugraph_type_erased_device_array_view_t* src,
+  const cugraph_type_erased_device_array_view_t* dst, const cugraph_type_erased_device_array_view_t* weights,
+  const cugraph_type_erased_device_array_view_t* edge_ids, const cugraph_type_erased_device_array_view_t* edge_type_ids,
+  const cugraph_type_erased_device_array_view_t* edge_start_time_ids,
+  const cugraph_type_erased_device_array_view_t* edge_end_time_ids, bool_t store_transposed, bool_t renumber,
+  bool_t drop_self_loops, bool_t drop_multi_edges, bool_t symmetrize, bool_t /*do_expensive_check*/,
+  cugraph_graph_t** graph, cugraph_error_t** error)
+{
+  return create_sg(handle, properties, V(vertices), V(src), V(dst), V(weights), V(edge_ids), V(edge_type_ids),
+                   V(edge_start_time_ids), V(edge_end_time_ids), store_transposed, renumber, drop_self_loops,
+                   drop_multi_edges, symmetrize, graph, error);
+}
+
+extern "C" cugraph_error_code_t cugraph_graph_create_sg_from_csr(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* offsets, const cugraph_type_erased_device_array_view_t* indices,
+  const cugraph_type_erased_device_array_view_t* weights, const cugraph_type_erased_device_array_view_t* edge_ids,
+  const cugraph_type_erased_device_array_view_t* edge_type_ids, bool_t store_transposed, bool_t renumber,
+  bool_t symmetrize, bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error)
+{
+  // CSR rows are sources (graph_sg.cpp:989-1095 decompresses to an edge list the same way).
+  if (graph) *graph = nullptr;
+  dvec<int32_t> rows;
+  device_array_view_t rows_view{nullptr, 0, INT32};
+  cugraph_error_code_t rc = guarded(error, [&] {
+    handle_t const& h = H(handle);
+    auto off          = V(offsets);
+    auto idx          = V(indices);
+    CGA_EXPECTS(off != nullptr && idx != nullptr && off->size >= 1, CUGRAPH_INVALID_INPUT, "Invalid input arguments: offsets / indices.");
+    CGA_EXPECTS(off->type == INT32 && idx->type == INT32, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
+                "this build supports INT32 offsets / indices only");
+    int64_t nv = (int64_t)off->size - 1;
+    rows.resize_discard(idx->size > 0 ? idx->size : 1);
+    if (nv > 0 && idx->size > 0)
+      hipLaunchKernelGGL(k_expand_rows, grid_for(nv * 16, kBlock, 8192), kBlock, 0, h.stream, off->as<int32_t>(), nv, rows.data());
+    h.sync();
+    rows_view = device_array_view_t{rows.data(), idx->size, INT32};
+  });
+  if (rc != CUGRAPH_SUCCESS) return rc;
+  // the vertex list is 0..nv-1 so isolated trailing vertices survive
+  dvec<int32_t> verts;
+  device_array_view_t verts_view{nullptr, 0, INT32};
+  rc = guarded(error, [&] {
+    handle_t const& h = H(handle);
+    int64_t nv        = (int64_t)V(offsets)->size - 1;
+    verts.resize_discard(nv > 0 ? nv : 1);
+    iota_i32(h, verts.data(), nv, 0);
+    h.sync();
+    verts_view = device_array_view_t{verts.data(), (size_t)nv, INT32};
+  });
+  if (rc != CUGRAPH_SUCCESS) return rc;
+  return create_sg(handle, properties, &verts_view, &rows_view, V(indices), V(weights), V(edge_ids), V(edge_type_ids), nullptr,
+                   nullptr, store_transposed, renumber, FALSE, FALSE, symmetrize, graph, error);
+  (void)do_expensive_check;
+}
+
+extern "C" void cugraph_graph_free(cugraph_graph_t* graph) { delete reinterpret_cast<graph_t*>(graph); }
+
+extern "C" cugraph_error_code_t cugraph_has_vertex(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+                                                   cugraph_type_erased_device_array_view_t* vertices,
+                                                   bool_t /*do_expensive_check*/,
+                                                   cugraph_type_erased_device_array_t** result, cugraph_error_t** error)
+{
+  if (result) *result = nullptr;
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    graph_t& g        = G(graph);
+    auto v            = V(vertices);
+    CGA_EXPECTS(v != nullptr && result != nullptr, CUGRAPH_INVALID_INPUT, "vertices / result is NULL");
+    CGA_EXPECTS(v->type == g.vertex_type, CUGRAPH_INVALID_INPUT, "vertex type of graph and vertices must match");
+    auto out = std::make_unique<device_array_t>(v->size, BOOL);
+    if (v->size > 0)
+      hipLaunchKernelGGL(k_has_vertex, grid_for(v->size, kBlock, 4096), kBlock, 0, h.stream, v->as<int32_t>(), (int64_t)v->size,
+                         g.renumbered ? (int32_t const*)g.ext2int.data() : (int32_t const*)nullptr, g.ext_min,
+                         (int64_t)g.ext2int.size(), g.nv, out->buf.as<uint8_t>());
+    h.sync();
+    *result = reinterpret_cast<cugraph_type_erased_device_array_t*>(out.release());
+  });
+}
+
+extern "C" size_t cugraph_amd_graph_num_vertices(const cugraph_graph_t* graph)
+{
+  return graph ? (size_t) reinterpret_cast<graph_t const*>(graph)->nv : 0;
+}
+extern "C" size_t cugraph_amd_graph_num_edges(const cugraph_graph_t* graph)
+{
+  return graph ? (size_t) reinterpret_cast<graph_t const*>(graph)->ne : 0;
+}

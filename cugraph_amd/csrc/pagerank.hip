@@ -1,0 +1,684 @@
+// PageRank for gfx950: one fused pull-SpMV kernel per power iteration.
+//
+// Replaces:
+//   cugraph_pagerank* C API                       cpp/src/c_api/pagerank.cpp:247, :316, :378, :466
+//   cugraph::pagerank / detail::pagerank          cpp/src/link_analysis/pagerank_impl.cuh:406-447, 39-330
+//   per_v_transform_reduce_incoming_e (4 kernels) cpp/include/cugraph/prims/detail/per_v_transform_reduce_e.cuh:252/389/500/688
+//   update_edge_src_property (SG copy)            cpp/include/cugraph/prims/update_edge_src_dst_property.cuh:656-659
+//   transform_reduce_v x2 + transform + copy      pagerank_impl.cuh:225-251, 311-318
+//   compute_out_degrees / compute_out_weight_sums cpp/src/structure/graph_view_impl.cuh:207-238
+//
+// The reference runs, per iteration, 4 V-length passes + a V-length copy + up to 4 SpMV kernels on 4
+// streams + 2 host-synchronising scalar reductions.  Here an iteration is ONE persistent kernel + a
+// 1-block finisher, with no host synchronisation unless epsilon > 0:
+//
+//   k_spmv:  for every destination row (CSC, degree-descending schedule)
+//              y      = base + sum_{in-edges} x[src] * [w *] alpha         (x = pr / out_w of the previous iterate)
+//              pr[v]  = y (+ personalization term)                          -> |y - pr_old| accumulated (L1 change)
+//              x'[v]  = y / (out_w[v] == 0 ? 1 : out_w[v])                  -> next iteration's gather vector
+//              dangling' += out_w[v] == 0 ? y : 0
+//            Row classes by in-degree: >= 4096 one workgroup per row, 64..4095 one wavefront per row,
+//            16..63 / 4..15 / 0..3 sixteen / four / one lane(s) per row, so lanes of a wave always read
+//            consecutive index words (coalesced HBM stream) and reduce with wave64 cross-lane shuffles.
+//            The first `hot` entries of x (the highest-degree vertices after renumbering: >50 % of all
+//            gathers on RMAT) are staged in LDS once per workgroup; only colder sources go to L2/MALL.
+//   k_finish: fixed-order fp64 reduction of the per-workgroup (diff, dangling) partials -> next `base`.
+//
+// Loop order and stopping rule follow pagerank_impl.cuh:224-329 exactly (see oracle/oracle.c).
+#include "common.hpp"
+
+namespace cga {
+
+namespace {
+
+constexpr int PR_BLOCK = 1024;  // 16 wavefronts
+constexpr int PR_WAVES = PR_BLOCK / 64;
+
+template <typename WT>
+struct pr_scalars {  // device-resident loop state
+  WT base;         // (alpha * dangling + (1 - alpha)) / V, or 0 when personalized
+  WT pers_factor;  // alpha * dangling + (1 - alpha)
+  WT dangling;
+  WT diff;
+};
+
+template <typename WT>
+struct spmv_args {
+  int32_t const* offsets;
+  int32_t const* indices;
+  WT const* weights;      // or nullptr
+  int32_t const* row_order;  // or nullptr (identity)
+  int64_t nv;
+  int64_t seg0, seg1, seg2, seg3;  // schedule positions: [0,seg0) WG/row, [seg0,seg1) wave/row, [seg1,seg2) 16 lanes, [seg2,seg3) 4 lanes, rest 1 lane
+  WT const* x;            // gather vector (previous iterate / out_w)
+  WT* x_next;
+  WT* pr;                 // in: previous iterate, out: new iterate
+  WT const* outw;
+  WT const* pers;         // dense normalised personalization or nullptr
+  pr_scalars<WT> const* scal;
+  double* partials;       // [gridDim.x][2] = (diff, dangling)
+  WT alpha;
+  int hot;                // entries of x staged in LDS
+};
+
+template <typename WT>
+__device__ __forceinline__ WT group_sum(WT v, int width)
+{
+  for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <typename WT, bool WEIGHTED>
+struct gatherer {
+  spmv_args<WT> const& a;
+  WT const* xs;  // LDS tile
+  __device__ __forceinline__ WT val(int32_t i) const { return i < a.hot ? xs[i] : a.x[i]; }
+  // sum over edges e = first, first + stride, ... < end
+  __device__ __forceinline__ WT strided(uint32_t first, uint32_t end, uint32_t stride) const
+  {
+    WT acc = 0;
+    uint32_t e = first;  // unsigned: e + 3 * stride stays below 2^32 for any INT32 edge count
+    for (; e + 3 * stride < end; e += 4 * stride) {
+      int32_t i0 = a.indices[e], i1 = a.indices[e + stride], i2 = a.indices[e + 2 * stride], i3 = a.indices[e + 3 * stride];
+      WT v0 = val(i0), v1 = val(i1), v2 = val(i2), v3 = val(i3);
+      if constexpr (WEIGHTED) {
+        v0 *= a.weights[e]; v1 *= a.weights[e + stride]; v2 *= a.weights[e + 2 * stride]; v3 *= a.weights[e + 3 * stride];
+      }
+      acc = fma(v0, a.alpha, acc); acc = fma(v1, a.alpha, acc); acc = fma(v2, a.alpha, acc); acc = fma(v3, a.alpha, acc);
+    }
+    for (; e < end; e += stride) {
+      WT v = val(a.indices[e]);
+      if constexpr (WEIGHTED) v *= a.weights[e];
+      acc = fma(v, a.alpha, acc);
+    }
+    return acc;
+  }
+};
+
+template <typename WT, bool PERS>
+__device__ __forceinline__ void row_epilogue(spmv_args<WT> const& a, pr_scalars<WT> const& sc, int32_t v, WT sum, double& diff,
+                                             double& dang)
+{
+  WT y = sc.base + sum;
+  if constexpr (PERS) y += sc.pers_factor * a.pers[v];
+  WT old = a.pr[v];
+  WT ow  = a.outw[v];
+  a.pr[v]     = y;
+  a.x_next[v] = y / (ow == WT(0) ? WT(1) : ow);
+  diff += (double)fabs(y - old);
+  if (ow == WT(0)) dang += (double)y;
+}
+
+template <typename WT, bool WEIGHTED, bool PERS>
+__global__ void __launch_bounds__(PR_BLOCK) k_spmv(spmv_args<WT> a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  WT* xs       = reinterpret_cast<WT*>(smem);
+  double* wred = reinterpret_cast<double*>(smem + (size_t)a.hot * sizeof(WT));  // [PR_WAVES][2] + row partials [PR_WAVES]
+  int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  for (int i = tid; i < a.hot; i += PR_BLOCK) xs[i] = a.x[i];
+  __syncthreads();
+
+  pr_scalars<WT> const sc = *a.scal;
+  gatherer<WT, WEIGHTED> g{a, xs};
+  double diff = 0.0, dang = 0.0;
+
+  // ---- class H: one workgroup per row
+  {
+    WT* rowp = reinterpret_cast<WT*>(wred + 2 * PR_WAVES);
+    for (int64_t r = blockIdx.x; r < a.seg0; r += gridDim.x) {
+      int32_t v = a.row_order ? a.row_order[r] : (int32_t)r;
+      int32_t b = a.offsets[v], e = a.offsets[v + 1];
+      WT s = group_sum(g.strided(b + tid, e, PR_BLOCK), 64);
+      if (lane == 0) rowp[wave] = s;
+      __syncthreads();
+      if (tid == 0) {
+        WT t = 0;
+#pragma unroll
+        for (int k = 0; k < PR_WAVES; ++k) t += rowp[k];
+        row_epilogue<WT, PERS>(a, sc, v, t, diff, dang);
+      }
+      __syncthreads();
+    }
+  }
+  int64_t const gwave  = (int64_t)blockIdx.x * PR_WAVES + wave;
+  int64_t const nwaves = (int64_t)gridDim.x * PR_WAVES;
+  // ---- class M: one wavefront per row
+  for (int64_t r = a.seg0 + gwave; r < a.seg1; r += nwaves) {
+    int32_t v = a.row_order ? a.row_order[r] : (int32_t)r;
+    int32_t b = a.offsets[v], e = a.offsets[v + 1];
+    WT s = group_sum(g.strided(b + lane, e, 64), 64);
+    if (lane == 0) row_epilogue<WT, PERS>(a, sc, v, s, diff, dang);
+  }
+  // ---- class L16: 16 lanes per row
+  for (int64_t r = a.seg1 + gwave * 4 + (lane >> 4); r < a.seg2; r += nwaves * 4) {
+    int32_t v = a.row_order ? a.row_order[r] : (int32_t)r;
+    int32_t b = a.offsets[v], e = a.offsets[v + 1];
+    WT s = group_sum(g.strided(b + (lane & 15), e, 16), 16);
+    if ((lane & 15) == 0) row_epilogue<WT, PERS>(a, sc, v, s, diff, dang);
+  }
+  // ---- class L4: 4 lanes per row
+  for (int64_t r = a.seg2 + gwave * 16 + (lane >> 2); r < a.seg3; r += nwaves * 16) {
+    int32_t v = a.row_order ? a.row_order[r] : (int32_t)r;
+    int32_t b = a.offsets[v], e = a.offsets[v + 1];
+    WT s = group_sum(g.strided(b + (lane & 3), e, 4), 4);
+    if ((lane & 3) == 0) row_epilogue<WT, PERS>(a, sc, v, s, diff, dang);
+  }
+  // ---- class L1: one lane per row (degree 0..3)
+  for (int64_t r = a.seg3 + gwave * 64 + lane; r < a.nv; r += nwaves * 64) {
+    int32_t v = a.row_order ? a.row_order[r] : (int32_t)r;
+    int32_t b = a.offsets[v], e = a.offsets[v + 1];
+    WT s = 0;
+    for (int32_t p = b; p < e; ++p) {
+      WT t = g.val(a.indices[p]);
+      if constexpr (WEIGHTED) t *= a.weights[p];
+      s = fma(t, a.alpha, s);
+    }
+    row_epilogue<WT, PERS>(a, sc, v, s, diff, dang);
+  }
+
+  // ---- fixed-order block reduction of the two scalars
+  diff = group_sum(diff, 64);
+  dang = group_sum(dang, 64);
+  __syncthreads();
+  if (lane == 0) { wred[2 * wave] = diff; wred[2 * wave + 1] = dang; }
+  __syncthreads();
+  if (tid == 0) {
+    double d0 = 0, d1 = 0;
+#pragma unroll
+    for (int k = 0; k < PR_WAVES; ++k) { d0 += wred[2 * k]; d1 += wred[2 * k + 1]; }
+    a.partials[2 * blockIdx.x]     = d0;
+    a.partials[2 * blockIdx.x + 1] = d1;
+  }
+}
+
+// x = pr / (outw == 0 ? 1 : outw); partial dangling sums (iteration 0 state)
+template <typename WT>
+__global__ void __launch_bounds__(256) k_prologue(WT const* pr, WT const* outw, WT* x, int64_t nv, double* partials)
+{
+  __shared__ double red[4];
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double dang    = 0.0;
+  for (; i < nv; i += stride) {
+    WT p = pr[i], ow = outw[i];
+    x[i] = p / (ow == WT(0) ? WT(1) : ow);
+    if (ow == WT(0)) dang += (double)p;
+  }
+  dang = group_sum(dang, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dang;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x]     = 0.0;
+    partials[2 * blockIdx.x + 1] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+template <typename WT>
+__global__ void __launch_bounds__(256) k_finish(double const* partials, int n, pr_scalars<WT>* scal, WT alpha, WT one_minus_alpha,
+                                                int64_t nv, int personalized)
+{
+  __shared__ double r0[256], r1[256];
+  double d0 = 0, d1 = 0;
+  for (int i = threadIdx.x; i < n; i += 256) { d0 += partials[2 * i]; d1 += partials[2 * i + 1]; }
+  r0[threadIdx.x] = d0; r1[threadIdx.x] = d1;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { r0[threadIdx.x] += r0[threadIdx.x + s]; r1[threadIdx.x] += r1[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    WT dangling       = (WT)r1[0];
+    WT factor         = dangling * alpha + one_minus_alpha;
+    scal->dangling    = dangling;
+    scal->diff        = (WT)r0[0];
+    scal->pers_factor = factor;
+    scal->base        = personalized ? WT(0) : factor / (WT)nv;
+  }
+}
+
+// ---- out-weight sums --------------------------------------------------------------------------
+template <typename WT>
+__global__ void k_outdeg_from_offsets(int32_t const* offsets, int64_t nv, WT* out)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nv; i += stride) out[i] = (WT)(offsets[i + 1] - offsets[i]);
+}
+template <typename WT>
+__global__ void k_u32_to_wt(uint32_t const* c, int64_t nv, WT* out)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nv; i += stride) out[i] = (WT)c[i];
+}
+template <typename WT>
+__global__ void k_rowsum_weights(int32_t const* offsets, WT const* w, int64_t nv, WT* out)
+{
+  int64_t wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int lane       = threadIdx.x & 63;
+  for (int64_t v = wave; v < nv; v += nwaves) {
+    double s = 0;
+    for (int32_t p = offsets[v] + lane; p < offsets[v + 1]; p += 64) s += (double)w[p];
+    s = group_sum(s, 64);
+    if (lane == 0) out[v] = (WT)s;
+  }
+}
+template <typename WT>
+__global__ void k_scatter_add_weights(int32_t const* indices, WT const* w, int64_t ne, double* acc)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < ne; i += stride) atomicAdd(&acc[indices[i]], (double)w[i]);
+}
+template <typename WT>
+__global__ void k_f64_to_wt(double const* c, int64_t nv, WT* out)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nv; i += stride) out[i] = (WT)c[i];
+}
+
+// dense[ids[i]] (+)= vals[i]
+template <typename WT, bool ADD>
+__global__ void k_scatter_pairs(int32_t const* ids, WT const* vals, int64_t n, WT* dense, WT scale)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    if constexpr (ADD) atomicAdd(&dense[ids[i]], vals[i] * scale);
+    else dense[ids[i]] = vals[i];
+  }
+}
+
+template <typename WT>
+__global__ void k_sum(WT const* v, int64_t n, double* out)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double s       = 0;
+  for (; i < n; i += stride) s += (double)v[i];
+  s = group_sum(s, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+template <typename WT> void fill_wt(handle_t const& h, WT* p, int64_t n, WT v);
+template <> void fill_wt<float>(handle_t const& h, float* p, int64_t n, float v) { fill_f32(h, p, n, v); }
+template <> void fill_wt<double>(handle_t const& h, double* p, int64_t n, double v) { fill_f64(h, p, n, v); }
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------- plan
+struct pagerank_plan_base {
+  virtual ~pagerank_plan_base() = default;
+  virtual void step(double epsilon, size_t max_iterations, size_t* done, bool* converged) = 0;
+  virtual centrality_result_t* result(size_t total_iterations, bool converged)          = 0;
+};
+
+template <typename WT>
+struct pagerank_plan : pagerank_plan_base {
+  handle_t const& h;
+  graph_t& g;
+  WT alpha;
+  bool personalized{false};
+  dvec<WT> pr, x0, x1, outw_own, pers;
+  WT const* outw{nullptr};
+  dvec<pr_scalars<WT>> scal;
+  dvec<double> partials;
+  int grid{0};
+  int hot{0};
+  size_t lds_bytes{0};
+  int cur{0};
+
+  pagerank_plan(handle_t const& h_, graph_t& g_, double alpha_) : h(h_), g(g_), alpha((WT)alpha_) {}
+
+  // (ext ids, values) -> dense vector with `fill` elsewhere; INVALID_INPUT on ids that are not vertices
+  void pairs_to_dense(device_array_view_t const* ids, device_array_view_t const* vals, WT* dense, WT fill, char const* what)
+  {
+    CGA_EXPECTS(ids->size == vals->size, CUGRAPH_INVALID_INPUT, std::string(what) + ": vertices and values differ in size");
+    fill_wt<WT>(h, dense, g.nv, fill);
+    if (ids->size == 0) return;
+    dvec<int32_t> tmp(ids->size);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), ids->data, ids->size * 4, hipMemcpyDeviceToDevice, h.stream));
+    renumber_ext_to_int(h, g, tmp.data(), (int64_t)ids->size);
+    CGA_EXPECTS(count_negative_i32(h, tmp.data(), (int64_t)ids->size) == 0, CUGRAPH_INVALID_INPUT,
+                std::string(what) + ": found a vertex id that is not in the graph");
+    hipLaunchKernelGGL((k_scatter_pairs<WT, false>), grid_for(ids->size, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)tmp.data(),
+                       vals->as<WT const>(), (int64_t)ids->size, dense, WT(1));
+    h.sync();
+  }
+
+  void compute_out_weight_sums()
+  {
+    if (!g.out_weight_sums_valid) {
+      g.out_weight_sums.alloc((size_t)(g.nv > 0 ? g.nv : 1) * sizeof(WT));
+      WT* ow = g.out_weight_sums.as<WT>();
+      if (g.nv > 0) {
+        if (!g.has_weights) {
+          if (g.csr.built) {
+            hipLaunchKernelGGL(k_outdeg_from_offsets<WT>, grid_for(g.nv, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)g.csr.offsets.data(), g.nv, ow);
+          } else {
+            dvec<uint32_t> c(g.nv);
+            HIP_TRY(hipMemsetAsync(c.data(), 0, g.nv * 4, h.stream));
+            histogram_i32(h, g.csc.indices.data(), g.ne, c.data());
+            hipLaunchKernelGGL(k_u32_to_wt<WT>, grid_for(g.nv, kBlock, 4096), kBlock, 0, h.stream, (uint32_t const*)c.data(), g.nv, ow);
+            h.sync();
+          }
+        } else if (g.csr.built) {
+          hipLaunchKernelGGL(k_rowsum_weights<WT>, grid_for(g.nv * 16, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)g.csr.offsets.data(),
+                             g.csr.weights.as<WT const>(), g.nv, ow);
+        } else {
+          dvec<double> acc(g.nv);
+          HIP_TRY(hipMemsetAsync(acc.data(), 0, g.nv * 8, h.stream));
+          if (g.ne > 0)
+            hipLaunchKernelGGL(k_scatter_add_weights<WT>, grid_for(g.ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)g.csc.indices.data(),
+                               g.csc.weights.as<WT const>(), g.ne, acc.data());
+          hipLaunchKernelGGL(k_f64_to_wt<WT>, grid_for(g.nv, kBlock, 4096), kBlock, 0, h.stream, (double const*)acc.data(), g.nv, ow);
+          h.sync();
+        }
+      }
+      g.out_weight_sums_valid = true;
+    }
+    outw = g.out_weight_sums.as<WT const>();
+  }
+
+  void launch_finish()
+  {
+    hipLaunchKernelGGL(k_finish<WT>, 1, 256, 0, h.stream, (double const*)partials.data(), grid, scal.data(), alpha, (WT)(1.0 - (double)alpha),
+                       g.nv, personalized ? 1 : 0);
+  }
+
+  void create(device_array_view_t const* ow_v, device_array_view_t const* ow_s, device_array_view_t const* ig_v,
+              device_array_view_t const* ig_s, device_array_view_t const* p_v, device_array_view_t const* p_s)
+  {
+    HIP_TRY(hipSetDevice(h.device));
+    ensure_orientation(h, g, true);  // PageRank pulls over CSC
+    int64_t const nv = g.nv;
+    size_t const n1  = (size_t)(nv > 0 ? nv : 1);
+    pr.resize_discard(n1); x0.resize_discard(n1); x1.resize_discard(n1);
+    scal.resize_discard(1);
+
+    // persistent launch geometry: 1 or 2 workgroups of 1024 threads per CU depending on the LDS tile
+    int hot_req = h.pagerank_hot_tile;
+    if (hot_req < 0) hot_req = (int)(65536 / sizeof(WT));  // 64 KiB tile -> 2 workgroups per CU
+    size_t red_bytes = (2 * PR_WAVES) * sizeof(double) + PR_WAVES * sizeof(double);
+    size_t max_tile  = (h.lds_per_block > red_bytes + 1024 ? h.lds_per_block - red_bytes - 1024 : 0) / sizeof(WT);
+    hot = (int)std::min<int64_t>({(int64_t)hot_req, (int64_t)max_tile, nv});
+    hot &= ~3;
+    lds_bytes       = (size_t)hot * sizeof(WT) + red_bytes;
+    int blocks_per_cu = lds_bytes <= 80 * 1024 ? 2 : 1;
+    grid            = h.num_cus * blocks_per_cu;
+    partials.resize_discard((size_t)2 * std::max(grid, 2048));
+
+    if (ow_s) {
+      outw_own.resize_discard(n1);
+      pairs_to_dense(ow_v, ow_s, outw_own.data(), WT(0), "precomputed_vertex_out_weight");
+      outw = outw_own.data();
+    } else {
+      compute_out_weight_sums();
+    }
+    if (ig_s) {
+      pairs_to_dense(ig_v, ig_s, pr.data(), WT(0), "initial_guess");  // not renormalised: pagerank_impl.cuh:427-432
+    } else {
+      fill_wt<WT>(h, pr.data(), nv, nv > 0 ? WT(1) / (WT)nv : WT(0));  // pagerank_impl.cuh:422-426
+    }
+    if (p_s) {
+      personalized = true;
+      CGA_EXPECTS(p_v->size == p_s->size, CUGRAPH_INVALID_INPUT, "personalization: vertices and values differ in size");
+      dvec<double> sum(1);
+      HIP_TRY(hipMemsetAsync(sum.data(), 0, 8, h.stream));
+      if (p_s->size > 0)
+        hipLaunchKernelGGL(k_sum<WT>, grid_for(p_s->size, kBlock, 1024), kBlock, 0, h.stream, p_s->as<WT const>(), (int64_t)p_s->size, sum.data());
+      double s;
+      h.read_back(&s, sum.data(), 1);
+      CGA_EXPECTS((WT)s > WT(0), CUGRAPH_INVALID_INPUT, "Invalid input argument: sum of personalization values should be positive.");
+      pers.resize_discard(n1);
+      fill_wt<WT>(h, pers.data(), nv, WT(0));
+      dvec<int32_t> tmp(p_v->size > 0 ? p_v->size : 1);
+      HIP_TRY(hipMemcpyAsync(tmp.data(), p_v->data, p_v->size * 4, hipMemcpyDeviceToDevice, h.stream));
+      renumber_ext_to_int(h, g, tmp.data(), (int64_t)p_v->size);
+      CGA_EXPECTS(count_negative_i32(h, tmp.data(), (int64_t)p_v->size) == 0, CUGRAPH_INVALID_INPUT,
+                  "personalization: found a vertex id that is not in the graph");
+      if (p_v->size > 0)
+        hipLaunchKernelGGL((k_scatter_pairs<WT, true>), grid_for(p_v->size, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)tmp.data(),
+                           p_s->as<WT const>(), (int64_t)p_v->size, pers.data(), WT(1) / (WT)s);
+      h.sync();
+    }
+    // iteration-0 state: x = pr / out_w, dangling mass, base
+    int pgrid = std::min(grid_for(nv, 256, 2048), 2048);
+    hipLaunchKernelGGL(k_prologue<WT>, pgrid, 256, 0, h.stream, (WT const*)pr.data(), outw, x0.data(), nv, partials.data());
+    int keep = grid;
+    grid     = pgrid;
+    launch_finish();
+    grid = keep;
+    cur  = 0;
+    h.sync();
+  }
+
+  template <bool WEIGHTED, bool PERS>
+  void launch_spmv(spmv_args<WT> const& a)
+  {
+    timed_launch t(h, "pagerank_spmv");
+    hipLaunchKernelGGL((k_spmv<WT, WEIGHTED, PERS>), grid, PR_BLOCK, lds_bytes, h.stream, a);
+  }
+
+  void step(double epsilon, size_t max_iterations, size_t* done, bool* converged) override
+  {
+    HIP_TRY(hipSetDevice(h.device));
+    static bool attr_set[4] = {false, false, false, false};
+    auto set_attr = [&](auto kernel, int slot) {
+      if (!attr_set[slot]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_per_block));
+        attr_set[slot] = true;
+      }
+    };
+    set_attr(k_spmv<WT, false, false>, 0); set_attr(k_spmv<WT, true, false>, 1);
+    set_attr(k_spmv<WT, false, true>, 2);  set_attr(k_spmv<WT, true, true>, 3);
+    orientation_t const& o = g.csc;
+    size_t it = 0;
+    bool conv = false;
+    WT const eps = (WT)epsilon;
+    while (it < max_iterations) {
+      spmv_args<WT> a;
+      a.offsets   = o.offsets.data();
+      a.indices   = o.indices.data();
+      a.weights   = g.has_weights ? o.weights.as<WT const>() : nullptr;
+      a.row_order = o.row_order.size() ? o.row_order.data() : nullptr;
+      a.nv        = g.nv;
+      a.seg0 = o.seg[0]; a.seg1 = o.seg[1]; a.seg2 = o.seg[2]; a.seg3 = o.seg[3];
+      a.x         = cur == 0 ? x0.data() : x1.data();
+      a.x_next    = cur == 0 ? x1.data() : x0.data();
+      a.pr        = pr.data();
+      a.outw      = outw;
+      a.pers      = personalized ? pers.data() : nullptr;
+      a.scal      = scal.data();
+      a.partials  = partials.data();
+      a.alpha     = alpha;
+      a.hot       = hot;
+      if (g.has_weights) { if (personalized) launch_spmv<true, true>(a); else launch_spmv<true, false>(a); }
+      else               { if (personalized) launch_spmv<false, true>(a); else launch_spmv<false, false>(a); }
+      launch_finish();
+      cur ^= 1;
+      ++it;
+      if (epsilon > 0.0) {  // pagerank_impl.cuh:320-326: diff < eps -> stop (one 16-byte read-back per iteration)
+        pr_scalars<WT> s;
+        h.read_back(&s, scal.data(), 1);
+        if (s.diff < eps) { conv = true; break; }
+      }
+    }
+    *done      = it;
+    *converged = conv;
+  }
+
+  centrality_result_t* result(size_t total_iterations, bool converged) override
+  {
+    auto ids  = std::make_unique<device_array_t>((size_t)g.nv, g.vertex_type);
+    auto vals = std::make_unique<device_array_t>((size_t)g.nv, g.weight_type);
+    if (g.nv > 0) {
+      HIP_TRY(hipMemcpyAsync(ids->buf.ptr, g.number_map.data(), g.nv * 4, hipMemcpyDeviceToDevice, h.stream));
+      HIP_TRY(hipMemcpyAsync(vals->buf.ptr, pr.data(), g.nv * sizeof(WT), hipMemcpyDeviceToDevice, h.stream));
+    }
+    h.sync();
+    return new centrality_result_t{ids.release(), vals.release(), total_iterations, converged};
+  }
+};
+
+namespace {
+
+void check_pair_types(graph_t const& g, device_array_view_t const* v, device_array_view_t const* s, char const* vmsg, char const* smsg)
+{
+  if (v == nullptr && s == nullptr) return;
+  CGA_EXPECTS(v != nullptr && s != nullptr, CUGRAPH_INVALID_INPUT, std::string(vmsg) + " (vertices and values must both be given)");
+  CGA_EXPECTS(g.vertex_type == v->type, CUGRAPH_INVALID_INPUT, vmsg);
+  CGA_EXPECTS(g.weight_type == s->type, CUGRAPH_INVALID_INPUT, smsg);
+}
+
+pagerank_plan_base* make_plan(cugraph_resource_handle_t const* handle, cugraph_graph_t* graph,
+                              cugraph_type_erased_device_array_view_t const* ow_v, cugraph_type_erased_device_array_view_t const* ow_s,
+                              cugraph_type_erased_device_array_view_t const* ig_v, cugraph_type_erased_device_array_view_t const* ig_s,
+                              cugraph_type_erased_device_array_view_t const* p_v, cugraph_type_erased_device_array_view_t const* p_s, double alpha)
+{
+  handle_t const& h = H(handle);
+  graph_t& g        = G(graph);
+  // messages as cpp/src/c_api/pagerank.cpp:260-296
+  check_pair_types(g, V(ow_v), V(ow_s), "vertex type of graph and precomputed_vertex_out_weight_vertices must match",
+                   "vertex type of graph and precomputed_vertex_out_weight_sums must match");
+  check_pair_types(g, V(ig_v), V(ig_s), "vertex type of graph and initial_guess_vertices must match",
+                   "vertex type of graph and initial_guess_values must match");
+  check_pair_types(g, V(p_v), V(p_s), "vertex type of graph and personalization_vector must match",
+                   "vertex type of graph and personalization_vector must match");
+  if (g.weight_type == FLOAT64) {
+    auto p = std::make_unique<pagerank_plan<double>>(h, g, alpha);
+    p->create(V(ow_v), V(ow_s), V(ig_v), V(ig_s), V(p_v), V(p_s));
+    return p.release();
+  }
+  auto p = std::make_unique<pagerank_plan<float>>(h, g, alpha);
+  p->create(V(ow_v), V(ow_s), V(ig_v), V(ig_s), V(p_v), V(p_s));
+  return p.release();
+}
+
+cugraph_error_code_t run_pagerank(cugraph_resource_handle_t const* handle, cugraph_graph_t* graph,
+                                  cugraph_type_erased_device_array_view_t const* ow_v, cugraph_type_erased_device_array_view_t const* ow_s,
+                                  cugraph_type_erased_device_array_view_t const* ig_v, cugraph_type_erased_device_array_view_t const* ig_s,
+                                  cugraph_type_erased_device_array_view_t const* p_v, cugraph_type_erased_device_array_view_t const* p_s, double alpha,
+                                  double epsilon, size_t max_iterations, bool must_converge, cugraph_centrality_result_t** result,
+                                  cugraph_error_t** error)
+{
+  if (result) *result = nullptr;
+  bool converged = false;
+  cugraph_error_code_t rc = guarded(error, [&] {
+    CGA_EXPECTS(result != nullptr, CUGRAPH_INVALID_INPUT, "result is NULL");
+    std::unique_ptr<pagerank_plan_base> plan(make_plan(handle, graph, ow_v, ow_s, ig_v, ig_s, p_v, p_s, alpha));
+    size_t done = 0;
+    // pagerank_impl.cuh:224-329: the loop body runs at least once; `converged` = iter < max_iterations
+    plan->step(epsilon, max_iterations > 0 ? max_iterations : 1, &done, &converged);
+    converged = done < max_iterations;
+    *result   = reinterpret_cast<cugraph_centrality_result_t*>(plan->result(done, converged));
+  });
+  if (rc == CUGRAPH_SUCCESS && must_converge && !converged) {  // pagerank.cpp:306-313
+    if (error) *error = reinterpret_cast<cugraph_error_t*>(new err_obj_t{"PageRank failed to converge."});
+    return CUGRAPH_UNKNOWN_ERROR;
+  }
+  return rc;
+}
+
+}  // namespace
+}  // namespace cga
+
+using namespace cga;
+
+extern "C" cugraph_error_code_t cugraph_pagerank(CUGRAPH_PAGERANK_COMMON_ARGS, double alpha, double epsilon, size_t max_iterations,
+                                                 bool_t, cugraph_centrality_result_t** result, cugraph_error_t** error)
+{
+  return run_pagerank(handle, graph, precomputed_vertex_out_weight_vertices, precomputed_vertex_out_weight_sums, initial_guess_vertices,
+                      initial_guess_values, nullptr, nullptr, alpha, epsilon, max_iterations, true, result, error);
+}
+extern "C" cugraph_error_code_t cugraph_pagerank_allow_nonconvergence(CUGRAPH_PAGERANK_COMMON_ARGS, double alpha, double epsilon,
+                                                                      size_t max_iterations, bool_t, cugraph_centrality_result_t** result,
+                                                                      cugraph_error_t** error)
+{
+  return run_pagerank(handle, graph, precomputed_vertex_out_weight_vertices, precomputed_vertex_out_weight_sums, initial_guess_vertices,
+                      initial_guess_values, nullptr, nullptr, alpha, epsilon, max_iterations, false, result, error);
+}
+extern "C" cugraph_error_code_t cugraph_personalized_pagerank(CUGRAPH_PAGERANK_COMMON_ARGS,
+                                                              const cugraph_type_erased_device_array_view_t* personalization_vertices,
+                                                              const cugraph_type_erased_device_array_view_t* personalization_values, double alpha,
+                                                              double epsilon, size_t max_iterations, bool_t, cugraph_centrality_result_t** result,
+                                                              cugraph_error_t** error)
+{
+  return run_pagerank(handle, graph, precomputed_vertex_out_weight_vertices, precomputed_vertex_out_weight_sums, initial_guess_vertices,
+                      initial_guess_values, personalization_vertices, personalization_values, alpha, epsilon, max_iterations, true, result, error);
+}
+extern "C" cugraph_error_code_t cugraph_personalized_pagerank_allow_nonconvergence(
+  CUGRAPH_PAGERANK_COMMON_ARGS, const cugraph_type_erased_device_array_view_t* personalization_vertices,
+  const cugraph_type_erased_device_array_view_t* personalization_values, double alpha, double epsilon, size_t max_iterations, bool_t,
+  cugraph_centrality_result_t** result, cugraph_error_t** error)
+{
+  return run_pagerank(handle, graph, precomputed_vertex_out_weight_vertices, precomputed_vertex_out_weight_sums, initial_guess_vertices,
+                      initial_guess_values, personalization_vertices, personalization_values, alpha, epsilon, max_iterations, false, result, error);
+}
+
+// ---- result accessors (cpp/src/c_api/centrality_result.cpp) -------------------------------------
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_centrality_result_get_vertices(cugraph_centrality_result_t* result)
+{
+  return reinterpret_cast<cugraph_type_erased_device_array_view_t*>(reinterpret_cast<centrality_result_t*>(result)->vertex_ids->new_view());
+}
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_centrality_result_get_values(cugraph_centrality_result_t* result)
+{
+  return reinterpret_cast<cugraph_type_erased_device_array_view_t*>(reinterpret_cast<centrality_result_t*>(result)->values->new_view());
+}
+extern "C" size_t cugraph_centrality_result_get_num_iterations(cugraph_centrality_result_t* result)
+{
+  return reinterpret_cast<centrality_result_t*>(result)->num_iterations;
+}
+extern "C" bool_t cugraph_centrality_result_converged(cugraph_centrality_result_t* result)
+{
+  return reinterpret_cast<centrality_result_t*>(result)->converged ? TRUE : FALSE;
+}
+extern "C" void cugraph_centrality_result_free(cugraph_centrality_result_t* result)
+{
+  auto r = reinterpret_cast<centrality_result_t*>(result);
+  if (!r) return;
+  delete r->vertex_ids;
+  delete r->values;
+  delete r;
+}
+
+// ---- plan API (include/cugraph_amd/extensions.h) -------------------------------------------------
+extern "C" cugraph_error_code_t cugraph_amd_pagerank_plan_create(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, const cugraph_type_erased_device_array_view_t* ow_v,
+  const cugraph_type_erased_device_array_view_t* ow_s, const cugraph_type_erased_device_array_view_t* ig_v,
+  const cugraph_type_erased_device_array_view_t* ig_s, const cugraph_type_erased_device_array_view_t* p_v,
+  const cugraph_type_erased_device_array_view_t* p_s, double alpha, cugraph_amd_pagerank_plan_t** plan, cugraph_error_t** error)
+{
+  if (plan) *plan = nullptr;
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr, CUGRAPH_INVALID_INPUT, "plan is NULL");
+    *plan = reinterpret_cast<cugraph_amd_pagerank_plan_t*>(make_plan(handle, graph, ow_v, ow_s, ig_v, ig_s, p_v, p_s, alpha));
+  });
+}
+extern "C" cugraph_error_code_t cugraph_amd_pagerank_plan_step(cugraph_amd_pagerank_plan_t* plan, double epsilon, size_t max_iterations,
+                                                               size_t* iterations_done, bool_t* converged, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr, CUGRAPH_INVALID_INPUT, "plan is NULL");
+    size_t done = 0;
+    bool conv   = false;
+    reinterpret_cast<pagerank_plan_base*>(plan)->step(epsilon, max_iterations, &done, &conv);
+    if (iterations_done) *iterations_done = done;
+    if (converged) *converged = conv ? TRUE : FALSE;
+  });
+}
+extern "C" cugraph_error_code_t cugraph_amd_pagerank_plan_result(cugraph_amd_pagerank_plan_t* plan, size_t total_iterations, bool_t converged,
+                                                                 cugraph_centrality_result_t** result, cugraph_error_t** error)
+{
+  if (result) *result = nullptr;
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr && result != nullptr, CUGRAPH_INVALID_INPUT, "plan / result is NULL");
+    *result = reinterpret_cast<cugraph_centrality_result_t*>(
+      reinterpret_cast<pagerank_plan_base*>(plan)->result(total_iterations, converged == TRUE));
+  });
+}
+extern "C" void cugraph_amd_pagerank_plan_free(cugraph_amd_pagerank_plan_t* plan) { delete reinterpret_cast<pagerank_plan_base*>(plan); }

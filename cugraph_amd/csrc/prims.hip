@@ -1,0 +1,322 @@
+// Device building blocks written directly for gfx950 (wave64): fills, reductions, prefix sums, histogram,
+// stable LSD radix sort, gathers.  These replace the thrust::/cub:: call sites the reference's graph
+// construction sits on (renumber_edgelist_impl.cuh:425-829,
+// structure/detail/structure_utils.cuh:297-464).  No Thrust / CUB / rocPRIM / hipCUB.
+#include "common.hpp"
+
+namespace cga {
+
+namespace {
+
+constexpr int WAVE = 64;
+
+template <typename T>
+__global__ void k_fill(T* p, int64_t n, T v)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+__global__ void k_iota(int32_t* p, int64_t n, int32_t first)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = first + (int32_t)i;
+}
+
+__device__ __forceinline__ int32_t wave_min(int32_t v)
+{
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int32_t wave_max(int32_t v)
+{
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+__global__ void k_minmax(int32_t const* p, int64_t n, int32_t* out /* [min,max] */)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int32_t mn = INT32_MAX, mx = INT32_MIN;
+  for (; i < n; i += stride) { int32_t v = p[i]; mn = min(mn, v); mx = max(mx, v); }
+  mn = wave_min(mn);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) { atomicMin(out, mn); atomicMax(out + 1, mx); }
+}
+
+__global__ void k_count_negative(int32_t const* p, int64_t n, unsigned long long* out)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned c     = 0;
+  for (; i < n; i += stride) c += p[i] < 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+// ---------------------------------------------------------------------------------- prefix sum
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS   = 8;
+constexpr int SCAN_TILE    = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
+{
+  for (int o = 1; o < WAVE; o <<= 1) {
+    uint32_t t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// exclusive scan of one value per thread across a 256-thread block; returns the exclusive prefix and
+// writes the block total to *total
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total)
+{
+  __shared__ uint32_t wsum[SCAN_THREADS / WAVE];
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = wave_inclusive_scan(v, lane);
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_THREADS / WAVE; ++k) {
+    uint32_t s = wsum[k];
+    if (k < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ void k_scan_tile_sums(uint32_t const* in, int64_t n, uint32_t* sums)
+{
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t s   = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k)
+    if (base + k < n) s += in[base + k];
+  uint32_t tot;
+  (void)block_exclusive_scan(s, &tot);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ void k_scan_tile_apply(uint32_t const* in, uint32_t* out, int64_t n, uint32_t const* tile_base)
+{
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    v[k] = (base + k < n) ? in[base + k] : 0u;
+    s += v[k];
+  }
+  uint32_t tot;
+  uint32_t ex = block_exclusive_scan(s, &tot) + (tile_base ? tile_base[blockIdx.x] : 0u);
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    if (base + k < n) out[base + k] = ex;
+    ex += v[k];
+  }
+}
+
+// ----------------------------------------------------------------------------------- histogram
+__global__ void k_histogram(int32_t const* keys, int64_t n, uint32_t* counts)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) atomicAdd(&counts[keys[i]], 1u);
+}
+
+// ---------------------------------------------------------------------------------- radix sort
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES   = RS_THREADS / WAVE;
+constexpr int RS_PER_WAVE_ITERS = 16;
+constexpr int RS_WAVE_CHUNK = WAVE * RS_PER_WAVE_ITERS;  // 1024 keys per wave
+constexpr int RS_TILE    = RS_WAVE_CHUNK * RS_WAVES;     // 4096 keys per block
+constexpr int RS_BINS    = 256;
+
+__global__ void __launch_bounds__(RS_THREADS)
+k_rs_hist(uint64_t const* keys, int64_t n, int shift, uint32_t mask, uint32_t* hist, int nblocks)
+{
+  __shared__ uint32_t h[RS_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll 4
+  for (int it = 0; it < RS_TILE / RS_THREADS; ++it) {
+    int64_t idx = base + it * RS_THREADS + threadIdx.x;
+    if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(RS_THREADS)
+k_rs_scatter(uint64_t const* keys_in, uint32_t const* vals_in, uint64_t* keys_out, uint32_t* vals_out,
+             int64_t n, int shift, uint32_t mask, uint32_t const* offs, int nblocks)
+{
+  __shared__ uint32_t cnt[RS_WAVES][RS_BINS];
+  __shared__ uint32_t base[RS_WAVES][RS_BINS];
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int w = 0; w < RS_WAVES; ++w) cnt[w][threadIdx.x] = 0;
+  __syncthreads();
+  int64_t const chunk = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * RS_WAVE_CHUNK;
+  for (int it = 0; it < RS_PER_WAVE_ITERS; ++it) {
+    int64_t idx = chunk + it * WAVE + lane;
+    if (idx < n) atomicAdd(&cnt[wave][(uint32_t)(keys_in[idx] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  {
+    uint32_t run = offs[(int64_t)threadIdx.x * nblocks + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w) {
+      base[w][threadIdx.x] = run;
+      run += cnt[w][threadIdx.x];
+    }
+  }
+  __syncthreads();
+  uint64_t const lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int it = 0; it < RS_PER_WAVE_ITERS; ++it) {
+    int64_t idx  = chunk + it * WAVE + lane;
+    bool valid   = idx < n;
+    uint64_t key = valid ? keys_in[idx] : 0ull;
+    uint32_t d   = (uint32_t)(key >> shift) & mask;
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      bool bit     = (d >> b) & 1u;
+      uint64_t bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    uint32_t b0 = base[wave][d];
+    if (valid) {
+      uint32_t rank = __popcll(peers & lt_mask);
+      uint32_t pos  = b0 + rank;
+      keys_out[pos] = key;
+      if (vals_in) vals_out[pos] = vals_in[idx];
+      if (rank == 0) base[wave][d] = b0 + (uint32_t)__popcll(peers);
+    }
+  }
+}
+
+template <typename T>
+__global__ void k_gather(T const* src, uint32_t const* idx, T* out, int64_t n)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = src[idx[i]];
+}
+
+}  // namespace
+
+void fill_i32(handle_t const& h, int32_t* p, int64_t n, int32_t v)
+{
+  if (n > 0) hipLaunchKernelGGL(k_fill<int32_t>, grid_for(n, kBlock, 4096), kBlock, 0, h.stream, p, n, v);
+}
+void fill_u32(handle_t const& h, uint32_t* p, int64_t n, uint32_t v)
+{
+  if (n > 0) hipLaunchKernelGGL(k_fill<uint32_t>, grid_for(n, kBlock, 4096), kBlock, 0, h.stream, p, n, v);
+}
+void fill_f32(handle_t const& h, float* p, int64_t n, float v)
+{
+  if (n > 0) hipLaunchKernelGGL(k_fill<float>, grid_for(n, kBlock, 4096), kBlock, 0, h.stream, p, n, v);
+}
+void fill_f64(handle_t const& h, double* p, int64_t n, double v)
+{
+  if (n > 0) hipLaunchKernelGGL(k_fill<double>, grid_for(n, kBlock, 4096), kBlock, 0, h.stream, p, n, v);
+}
+void iota_i32(handle_t const& h, int32_t* p, int64_t n, int32_t first)
+{
+  if (n > 0) hipLaunchKernelGGL(k_iota, grid_for(n, kBlock, 4096), kBlock, 0, h.stream, p, n, first);
+}
+
+void minmax_i32(handle_t const& h, int32_t const* p, int64_t n, int32_t* mn, int32_t* mx)
+{
+  dvec<int32_t> out(2);
+  int32_t init[2] = {INT32_MAX, INT32_MIN};
+  HIP_TRY(hipMemcpyAsync(out.data(), init, sizeof(init), hipMemcpyHostToDevice, h.stream));
+  h.sync();  // `init` is a stack buffer
+  hipLaunchKernelGGL(k_minmax, grid_for(n, kBlock, 2048), kBlock, 0, h.stream, p, n, out.data());
+  int32_t r[2];
+  h.read_back(r, out.data(), 2);
+  *mn = r[0];
+  *mx = r[1];
+}
+
+int64_t count_negative_i32(handle_t const& h, int32_t const* ids, int64_t n)
+{
+  if (n == 0) return 0;
+  dvec<unsigned long long> out(1);
+  HIP_TRY(hipMemsetAsync(out.data(), 0, 8, h.stream));
+  hipLaunchKernelGGL(k_count_negative, grid_for(n, kBlock, 2048), kBlock, 0, h.stream, ids, n, out.data());
+  unsigned long long r;
+  h.read_back(&r, out.data(), 1);
+  return (int64_t)r;
+}
+
+void exclusive_scan_u32(handle_t const& h, uint32_t const* in, uint32_t* out, int64_t n)
+{
+  if (n <= 0) return;
+  int64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (ntiles == 1) {
+    hipLaunchKernelGGL(k_scan_tile_apply, 1, SCAN_THREADS, 0, h.stream, in, out, n, (uint32_t const*)nullptr);
+    return;
+  }
+  dvec<uint32_t> sums(ntiles);
+  hipLaunchKernelGGL(k_scan_tile_sums, (int)ntiles, SCAN_THREADS, 0, h.stream, in, n, sums.data());
+  exclusive_scan_u32(h, sums.data(), sums.data(), ntiles);
+  hipLaunchKernelGGL(k_scan_tile_apply, (int)ntiles, SCAN_THREADS, 0, h.stream, in, out, n,
+                     (uint32_t const*)sums.data());
+  h.sync();  // `sums` is freed on return
+}
+
+void histogram_i32(handle_t const& h, int32_t const* keys, int64_t n, uint32_t* counts)
+{
+  if (n > 0) hipLaunchKernelGGL(k_histogram, grid_for(n, kBlock, 8192), kBlock, 0, h.stream, keys, n, counts);
+}
+
+void radix_sort_u64_u32(handle_t const& h, uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp,
+                        uint32_t* vals_tmp, int64_t n, int bit_lo, int bit_hi)
+{
+  if (n <= 1 || bit_hi <= bit_lo) return;
+  int64_t nblocks64 = (n + RS_TILE - 1) / RS_TILE;
+  CGA_EXPECTS(nblocks64 < (int64_t)1 << 30, CUGRAPH_UNKNOWN_ERROR, "radix sort: input too large");
+  int nblocks = (int)nblocks64;
+  dvec<uint32_t> hist((size_t)nblocks * RS_BINS);
+  uint64_t* kin  = keys;
+  uint64_t* kout = keys_tmp;
+  uint32_t* vin  = vals;
+  uint32_t* vout = vals_tmp;
+  for (int shift = bit_lo; shift < bit_hi; shift += 8) {
+    int bits      = bit_hi - shift < 8 ? bit_hi - shift : 8;
+    uint32_t mask = (1u << bits) - 1u;
+    hipLaunchKernelGGL(k_rs_hist, nblocks, RS_THREADS, 0, h.stream, (uint64_t const*)kin, n, shift, mask,
+                       hist.data(), nblocks);
+    exclusive_scan_u32(h, hist.data(), hist.data(), (int64_t)nblocks * RS_BINS);
+    hipLaunchKernelGGL(k_rs_scatter, nblocks, RS_THREADS, 0, h.stream, (uint64_t const*)kin,
+                       (uint32_t const*)vin, kout, vout, n, shift, mask, (uint32_t const*)hist.data(), nblocks);
+    std::swap(kin, kout);
+    std::swap(vin, vout);
+  }
+  if (kin != keys) {
+    HIP_TRY(hipMemcpyAsync(keys, kin, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, h.stream));
+    if (vals) HIP_TRY(hipMemcpyAsync(vals, vin, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, h.stream));
+  }
+  h.sync();  // `hist` is freed on return
+}
+
+void gather_b32(handle_t const& h, uint32_t const* src, uint32_t const* idx, uint32_t* out, int64_t n)
+{
+  if (n > 0) hipLaunchKernelGGL(k_gather<uint32_t>, grid_for(n, kBlock, 8192), kBlock, 0, h.stream, src, idx, out, n);
+}
+void gather_b64(handle_t const& h, uint64_t const* src, uint32_t const* idx, uint64_t* out, int64_t n)
+{
+  if (n > 0) hipLaunchKernelGGL(k_gather<uint64_t>, grid_for(n, kBlock, 8192), kBlock, 0, h.stream, src, idx, out, n);
+}
+
+}  // namespace cga

@@ -1,0 +1,656 @@
+// BFS and SSSP for gfx950: a frontier engine built from one wave-cooperative edge-expansion kernel.
+//
+// Replaces:
+//   cugraph_bfs / cugraph_sssp C API                      cpp/src/c_api/bfs.cpp:189, cpp/src/c_api/sssp.cpp:136
+//   detail::bfs                                            cpp/src/traversal/bfs_impl.cuh:133-870
+//   detail::sssp (near-far)                                cpp/src/traversal/sssp_impl.cuh:169-566
+//   transform_reduce_if_v_frontier_outgoing_e_by_dst       cpp/include/cugraph/prims/transform_reduce_if_v_frontier_outgoing_e_by_dst.cuh:617-1127
+//   extract_transform_if_v_frontier_e (3 kernels)          cpp/include/cugraph/prims/detail/extract_transform_if_v_frontier_e.cuh:127/309/422
+//   update_v_frontier / vertex_frontier_t buckets          cpp/include/cugraph/prims/update_v_frontier.cuh:164-244, vertex_frontier.cuh:242-550
+//
+// The reference expands a frontier into an edge buffer, radix-sorts it by destination, reduces
+// duplicates (`any` / `minimum`), then applies v_op and re-buckets -- several kernels, a sort of
+// roughly 2-3x the edge bytes, and >= 3 host syncs per level.  Here the reduce-by-destination is done
+// in place with device-scope atomics on the per-vertex state (32-bit visited words / distance bits),
+// which is where the sort's output would be scattered anyway:
+//   BFS   test prev-visited bit -> atomicOr new-visited bit (first setter enqueues, writes distance)
+//         -> atomicMin(parent) : deterministic minimum-id parent (a valid instance of reduce_op::any,
+//         bfs_impl.cuh:467; the reference's own test only validates parents, bfs_test.cpp:217-233).
+//   SSSP  near-far (Davidson) with atomicMin on the order-preserving bit pattern of the non-negative
+//         distance; strict relax new < min(d[v], cutoff) (sssp_impl.cuh:58-71).  The fixed point is unique,
+//         so distances are bit-identical to Dijkstra.  Parents = lexicographic min (distance, parent)
+//         (sssp_impl.cuh:334) recovered by one pass over the settled edges.
+// Expansion kernel: a wavefront takes 64 frontier vertices; vertices with degree < 64 are flattened
+// across the wave (wave64 prefix sum of degrees + per-edge owner search in LDS) so consecutive lanes read
+// consecutive adjacency words; degree >= 64 rows are walked by the whole wave; degree >= 2048 rows are
+// deferred to a second kernel in which the whole grid strides the adjacency list.
+#include "common.hpp"
+
+#include <cfloat>
+#include <cmath>
+
+namespace cga {
+
+namespace {
+
+constexpr int TV_BLOCK = 256;
+constexpr int TV_WAVES = TV_BLOCK / 64;
+constexpr int32_t BIG_DEG = 2048;
+
+struct counters_t {  // device-resident, zeroed per step
+  uint32_t n_next;   // size of the next (near) frontier
+  uint32_t n_far;    // size of the far pile (SSSP)
+  uint32_t n_big;    // deferred high-degree vertices
+  uint32_t pad;
+  unsigned long long edges;  // edges inspected
+  uint32_t far_min_bits_lo;  // (SSSP split) min distance bits kept in far (32-bit types)
+  uint32_t pad2;
+  unsigned long long far_min_bits64;
+};
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t* total)
+{
+  uint32_t inc = v;
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  *total = __shfl(inc, 63);
+  return inc - v;
+}
+
+// wave-aggregated append of `flag` lanes' values to a queue
+__device__ __forceinline__ void wave_push(bool flag, int32_t value, int32_t* q, uint32_t* counter, int lane)
+{
+  uint64_t m = __ballot(flag);
+  if (m == 0) return;
+  uint32_t base = 0;
+  int leader    = __ffsll((unsigned long long)m) - 1;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = __shfl(base, leader);
+  if (flag) q[base + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = value;
+}
+
+// Expands the frontier `q[0..n)` (q == nullptr: vertices 0..n-1): calls f(u, v, edge_position) for every
+// out-edge of every frontier vertex for which keep(u) is true.  Vertices of degree >= BIG_DEG are pushed to
+// bigq for k_expand_big.
+template <typename Keep, typename F>
+__device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices,
+                                                int32_t* bigq, counters_t* cnt, Keep keep, F f)
+{
+  __shared__ uint32_t s_scan[TV_WAVES][64];
+  __shared__ int32_t s_beg[TV_WAVES][64];
+  __shared__ int32_t s_u[TV_WAVES][64];
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t const gwave  = (int64_t)blockIdx.x * TV_WAVES + wave;
+  int64_t const nwaves = (int64_t)gridDim.x * TV_WAVES;
+  unsigned long long inspected = 0;
+  for (int64_t base = gwave * 64; base < n; base += nwaves * 64) {
+    int64_t i = base + lane;
+    int32_t u = -1, beg = 0, deg = 0;
+    if (i < n) {
+      u = q ? q[i] : (int32_t)i;
+      if (keep(u)) { beg = offsets[u]; deg = offsets[u + 1] - beg; } else { u = -1; }
+    }
+    // deferred: huge rows
+    bool big = deg >= BIG_DEG;
+    wave_push(big, u, bigq, &cnt->n_big, lane);
+    // whole-wave rows
+    uint64_t mid = __ballot(deg >= 64 && !big);
+    while (mid) {
+      int src     = __ffsll((unsigned long long)mid) - 1;
+      mid &= mid - 1;
+      int32_t uu = __shfl(u, src), b = __shfl(beg, src), d = __shfl(deg, src);
+      for (int32_t p = lane; p < d; p += 64) f(uu, indices[b + p], b + p);
+      inspected += (lane == 0) ? (unsigned long long)d : 0ull;
+    }
+    // flattened small rows
+    uint32_t sd = (deg < 64) ? (uint32_t)deg : 0u, total;
+    uint32_t ex = wave_excl_scan(sd, lane, &total);
+    s_scan[wave][lane] = ex;
+    s_beg[wave][lane]  = beg;
+    s_u[wave][lane]    = u;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t t = lane; t < total; t += 64) {
+      // owner = last lane j with s_scan[j] <= t (rows of degree 0 share a scan value with their successor;
+      // the search returns the last of them, whose degree is > 0 by construction of `total`)
+      int lo = 0, hi = 63;
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        int m = (lo + hi + 1) >> 1;
+        if (s_scan[wave][m] <= t) lo = m; else hi = m - 1;
+      }
+      int32_t p = s_beg[wave][lo] + (int32_t)(t - s_scan[wave][lo]);
+      f(s_u[wave][lo], indices[p], p);
+    }
+    __builtin_amdgcn_wave_barrier();
+    inspected += (lane == 0) ? (unsigned long long)total : 0ull;
+  }
+  if (lane == 0 && inspected) atomicAdd(&cnt->edges, inspected);
+}
+
+template <typename F>
+__device__ __forceinline__ void expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, counters_t* cnt, F f)
+{
+  uint32_t nbig = cnt->n_big;
+  int64_t const tid  = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t const nthr = (int64_t)gridDim.x * blockDim.x;
+  for (uint32_t k = 0; k < nbig; ++k) {
+    int32_t u = bigq[k];
+    int32_t b = offsets[u], e = offsets[u + 1];
+    for (int64_t p = b + tid; p < e; p += nthr) f(u, indices[p], (int32_t)p);
+    if (tid == 0) atomicAdd(&cnt->edges, (unsigned long long)(e - b));
+  }
+}
+
+// --------------------------------------------------------------------------------------------- BFS
+struct bfs_state {
+  int32_t* dist;
+  uint32_t* pred;              // unsigned so that -1 is the atomicMin identity; nullptr when not requested
+  uint32_t const* vis_prev;    // visited as of the start of the level
+  uint32_t* vis_new;           // cumulative
+  int32_t* q_next;
+  counters_t* cnt;
+  int32_t next_depth;
+};
+
+struct bfs_visit {
+  bfs_state s;
+  __device__ __forceinline__ void operator()(int32_t u, int32_t v, int32_t) const
+  {
+    uint32_t bit = 1u << (v & 31);
+    bool fresh   = false;
+    if (!(s.vis_prev[v >> 5] & bit)) {
+      uint32_t old = atomicOr(&s.vis_new[v >> 5], bit);
+      fresh        = !(old & bit);
+      if (fresh) s.dist[v] = s.next_depth;
+      if (s.pred) atomicMin(&s.pred[v], (uint32_t)u);
+    }
+    wave_push(fresh, v, s.q_next, &s.cnt->n_next, threadIdx.x & 63);
+  }
+};
+
+struct keep_all { __device__ __forceinline__ bool operator()(int32_t) const { return true; } };
+
+__global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices,
+                                                         int32_t* bigq, bfs_state s)
+{
+  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, bfs_visit{s});
+}
+__global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, bfs_state s)
+{
+  expand_big(bigq, offsets, indices, s.cnt, bfs_visit{s});
+}
+
+__global__ void k_bfs_init_sources(int32_t const* src, int64_t n, int32_t* dist, uint32_t* vis_prev, uint32_t* vis_new, int32_t* q,
+                                   counters_t* cnt)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t v    = src[i];
+  uint32_t bit = 1u << (v & 31);
+  uint32_t old = atomicOr(&vis_new[v >> 5], bit);
+  if (!(old & bit)) {  // duplicates in the source list are enqueued once
+    atomicOr(&vis_prev[v >> 5], bit);
+    dist[v] = 0;
+    q[atomicAdd(&cnt->n_next, 1u)] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- SSSP
+template <typename WT> struct dist_bits;
+template <> struct dist_bits<float> {
+  using type = uint32_t;
+  static __device__ __forceinline__ uint32_t to(float x) { return __float_as_uint(x); }
+  static __device__ __forceinline__ float from(uint32_t b) { return __uint_as_float(b); }
+};
+template <> struct dist_bits<double> {
+  using type = unsigned long long;
+  static __device__ __forceinline__ unsigned long long to(double x) { return (unsigned long long)__double_as_longlong(x); }
+  static __device__ __forceinline__ double from(unsigned long long b) { return __longlong_as_double((long long)b); }
+};
+
+template <typename WT>
+struct sssp_state {
+  using bits_t = typename dist_bits<WT>::type;
+  bits_t* dist;        // bit pattern of the (non-negative) tentative distance
+  WT const* weights;
+  int32_t* q_next;     // next near frontier
+  int32_t* far;        // far pile
+  uint32_t* mark_near; // last relax round in which the vertex entered q_next
+  uint32_t* mark_far;  // last far epoch in which the vertex entered the far pile
+  counters_t* cnt;
+  WT threshold;        // near / far split
+  WT cutoff;
+  uint32_t round;
+  uint32_t far_epoch;
+};
+
+template <typename WT>
+struct sssp_relax {
+  sssp_state<WT> s;
+  __device__ __forceinline__ void operator()(int32_t u, int32_t v, int32_t p) const
+  {
+    using B  = dist_bits<WT>;
+    WT du    = B::from(s.dist[u]);
+    WT nd    = du + s.weights[p];
+    bool near = false, far = false;
+    if (nd < s.cutoff && nd < B::from(s.dist[v])) {
+      auto old = atomicMin(&s.dist[v], B::to(nd));
+      if (B::to(nd) < old) {  // this relaxation lowered d[v]
+        if (nd < s.threshold) near = atomicExch(&s.mark_near[v], s.round) != s.round;
+        else                  far  = atomicExch(&s.mark_far[v], s.far_epoch) != s.far_epoch;
+      }
+    }
+    int lane = threadIdx.x & 63;
+    wave_push(near, v, s.q_next, &s.cnt->n_next, lane);
+    wave_push(far, v, s.far, &s.cnt->n_far, lane);
+  }
+};
+
+template <typename WT>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices,
+                                                          int32_t* bigq, sssp_state<WT> s)
+{
+  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, sssp_relax<WT>{s});
+}
+template <typename WT>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices,
+                                                              sssp_state<WT> s)
+{
+  expand_big(bigq, offsets, indices, s.cnt, sssp_relax<WT>{s});
+}
+
+// far pile -> (near frontier | far pile'): d < lower: settled meanwhile, drop; d < upper: near; else keep
+template <typename WT>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_split(int32_t const* far_in, int64_t n, typename dist_bits<WT>::type const* dist, WT lower,
+                                                         WT upper, int32_t* near_out, int32_t* far_out, uint32_t* mark_near,
+                                                         uint32_t* mark_far, uint32_t round, uint32_t new_epoch, counters_t* cnt)
+{
+  using B        = dist_bits<WT>;
+  int const lane = threadIdx.x & 63;
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t n_pad  = (n + 63) & ~(int64_t)63;
+  for (; i < n_pad; i += stride) {
+    bool near = false, keep = false;
+    int32_t v = 0;
+    if (i < n) {
+      v    = far_in[i];
+      WT d = B::from(dist[v]);
+      if (d >= lower) {
+        if (d < upper) near = atomicExch(&mark_near[v], round) != round;
+        else {
+          keep = atomicExch(&mark_far[v], new_epoch) != new_epoch;
+          if (keep) {
+            if constexpr (sizeof(WT) == 4) atomicMin(&cnt->far_min_bits_lo, (uint32_t)B::to(d));
+            else atomicMin(&cnt->far_min_bits64, (unsigned long long)B::to(d));
+          }
+        }
+      }
+    }
+    wave_push(near, v, near_out, &cnt->n_next, lane);
+    wave_push(keep, v, far_out, &cnt->n_far, lane);
+  }
+}
+
+// canonical parents: pred[v] = min u with d[u] + w(u,v) == d[v]
+template <typename WT>
+struct sssp_parent {
+  typename dist_bits<WT>::type const* dist;
+  WT const* weights;
+  uint32_t* pred;
+  int32_t source;
+  __device__ __forceinline__ void operator()(int32_t u, int32_t v, int32_t p) const
+  {
+    using B = dist_bits<WT>;
+    if (v != source && B::to(B::from(dist[u]) + weights[p]) == dist[v]) atomicMin(&pred[v], (uint32_t)u);
+  }
+};
+template <typename WT>
+struct keep_reached {
+  typename dist_bits<WT>::type const* dist;
+  typename dist_bits<WT>::type unreached;
+  __device__ __forceinline__ bool operator()(int32_t u) const { return dist[u] != unreached; }
+};
+template <typename WT>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_parents(int64_t nv, int32_t const* offsets, int32_t const* indices, int32_t* bigq,
+                                                           counters_t* cnt, sssp_parent<WT> f, keep_reached<WT> keep)
+{
+  expand_frontier((int32_t const*)nullptr, nv, offsets, indices, bigq, cnt, keep, f);
+}
+template <typename WT>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_parents_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices,
+                                                               counters_t* cnt, sssp_parent<WT> f)
+{
+  expand_big(bigq, offsets, indices, cnt, f);
+}
+
+template <typename WT>
+__global__ void k_sum_weights(WT const* w, int64_t n, double* out)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double s       = 0;
+  for (; i < n; i += stride) s += (double)w[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+template <typename T>
+__global__ void k_fill_t(T* p, int64_t n, T v)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+__global__ void k_count_reached(uint32_t const* vis, int64_t nwords, unsigned long long* out)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned c     = 0;
+  for (; i < nwords; i += stride) c += __popc(vis[i]);
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+template <typename B>
+__global__ void k_count_reached_dist(B const* dist, int64_t nv, B unreached, unsigned long long* out)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned c     = 0;
+  for (; i < nv; i += stride) c += dist[i] != unreached;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+int expand_grid(handle_t const& h, int64_t n)
+{
+  int64_t waves = (n + 63) / 64;
+  int64_t g     = (waves + TV_WAVES - 1) / TV_WAVES;
+  int64_t cap   = (int64_t)h.num_cus * 8;
+  return (int)std::max<int64_t>(1, std::min(g, cap));
+}
+
+// ------------------------------------------------------------------------------------------ drivers
+paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sources, bool direction_optimizing, size_t depth_limit,
+                        bool compute_predecessors)
+{
+  HIP_TRY(hipSetDevice(h.device));
+  CGA_EXPECTS(sources != nullptr, CUGRAPH_INVALID_INPUT, "sources is NULL");
+  CGA_EXPECTS(g.vertex_type == sources->type, CUGRAPH_INVALID_INPUT, "vertex type of graph and sources must match");
+  if (direction_optimizing)  // bfs_impl.cuh:202-204
+    CGA_EXPECTS(g.props.is_symmetric == TRUE, CUGRAPH_INVALID_INPUT,
+                "Invalid input argument: input graph should be symmetric for direction optimizing BFS.");
+  ensure_orientation(h, g, false);  // BFS pushes over CSR
+  orientation_t const& o = g.csr;
+  int64_t const nv = g.nv, ns = (int64_t)sources->size;
+  size_t const n1  = (size_t)(nv > 0 ? nv : 1);
+
+  dvec<int32_t> src(ns > 0 ? ns : 1);
+  if (ns > 0) HIP_TRY(hipMemcpyAsync(src.data(), sources->data, ns * 4, hipMemcpyDeviceToDevice, h.stream));
+  renumber_ext_to_int(h, g, src.data(), ns);
+  CGA_EXPECTS(count_negative_i32(h, src.data(), ns) == 0, CUGRAPH_INVALID_INPUT, "Found invalid vertex in the input sources");  // bfs.cpp:106-119
+
+  auto ids   = std::make_unique<device_array_t>((size_t)nv, g.vertex_type);
+  auto dist  = std::make_unique<device_array_t>((size_t)nv, g.vertex_type);
+  auto preds = std::make_unique<device_array_t>(compute_predecessors ? (size_t)nv : 0, g.vertex_type);
+  int64_t const nwords = (nv + 31) / 32 + 1;
+  dvec<uint32_t> vis_prev(nwords), vis_new(nwords);
+  dvec<int32_t> qa(n1), qb(n1), bigq(n1);
+  dvec<counters_t> cnt(1);
+  fill_i32(h, dist->buf.as<int32_t>(), nv, INT32_MAX);
+  if (compute_predecessors) fill_i32(h, preds->buf.as<int32_t>(), nv, -1);
+  HIP_TRY(hipMemsetAsync(vis_prev.data(), 0, nwords * 4, h.stream));
+  HIP_TRY(hipMemsetAsync(vis_new.data(), 0, nwords * 4, h.stream));
+  HIP_TRY(hipMemsetAsync(cnt.data(), 0, sizeof(counters_t), h.stream));
+  if (ns > 0)
+    hipLaunchKernelGGL(k_bfs_init_sources, grid_for(ns, kBlock), kBlock, 0, h.stream, (int32_t const*)src.data(), ns, dist->buf.as<int32_t>(),
+                       vis_prev.data(), vis_new.data(), qa.data(), cnt.data());
+  counters_t c;
+  h.read_back(&c, cnt.data(), 1);
+  int64_t n_cur  = c.n_next;
+  int32_t* q_cur = qa.data();
+  int32_t* q_nxt = qb.data();
+  uint64_t depth = 0, edges = 0, levels = 0;
+  // depth_limit is compared after incrementing (bfs_impl.cuh:867-868)
+  uint64_t const limit = depth_limit > (size_t)INT32_MAX ? (uint64_t)INT32_MAX : (uint64_t)depth_limit;
+  while (n_cur > 0) {
+    HIP_TRY(hipMemsetAsync(cnt.data(), 0, sizeof(counters_t), h.stream));
+    bfs_state s{dist->buf.as<int32_t>(), compute_predecessors ? preds->buf.as<uint32_t>() : nullptr, vis_prev.data(), vis_new.data(), q_nxt,
+                cnt.data(), (int32_t)(depth + 1)};
+    {
+      timed_launch t(h, "bfs_expand");
+      hipLaunchKernelGGL(k_bfs_expand, expand_grid(h, n_cur), TV_BLOCK, 0, h.stream, (int32_t const*)q_cur, n_cur, (int32_t const*)o.offsets.data(),
+                         (int32_t const*)o.indices.data(), bigq.data(), s);
+      hipLaunchKernelGGL(k_bfs_expand_big, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
+                         (int32_t const*)o.indices.data(), s);
+    }
+    HIP_TRY(hipMemcpyAsync(vis_prev.data(), vis_new.data(), nwords * 4, hipMemcpyDeviceToDevice, h.stream));
+    h.read_back(&c, cnt.data(), 1);
+    edges += c.edges;
+    n_cur = c.n_next;
+    std::swap(q_cur, q_nxt);
+    ++depth;
+    ++levels;
+    if (depth >= limit) break;
+  }
+  // statistics + result columns
+  dvec<unsigned long long> reached(1);
+  HIP_TRY(hipMemsetAsync(reached.data(), 0, 8, h.stream));
+  hipLaunchKernelGGL(k_count_reached, grid_for(nwords, kBlock, 1024), kBlock, 0, h.stream, (uint32_t const*)vis_new.data(), nwords, reached.data());
+  unsigned long long nreached;
+  h.read_back(&nreached, reached.data(), 1);
+  h.last_stats = cugraph_amd_traversal_stats_t{levels, edges, nreached, edges};
+  if (nv > 0) HIP_TRY(hipMemcpyAsync(ids->buf.ptr, g.number_map.data(), nv * 4, hipMemcpyDeviceToDevice, h.stream));
+  if (compute_predecessors) unrenumber_int_to_ext(h, g, preds->buf.as<int32_t>(), nv);  // bfs.cpp:131-138
+  h.sync();
+  return new paths_result_t{ids.release(), dist.release(), preds.release()};
+}
+
+template <typename WT>
+paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cutoff_d, bool compute_predecessors)
+{
+  using B      = dist_bits<WT>;
+  using bits_t = typename B::type;
+  HIP_TRY(hipSetDevice(h.device));
+  ensure_orientation(h, g, false);
+  orientation_t const& o = g.csr;
+  int64_t const nv = g.nv;
+  size_t const n1  = (size_t)(nv > 0 ? nv : 1);
+  WT const wmax    = std::numeric_limits<WT>::max();
+  WT const cutoff  = cutoff_d >= (double)wmax ? wmax : (WT)cutoff_d;
+
+  // source: external id -> internal (sssp.cpp:84-103)
+  dvec<int32_t> src(1);
+  CGA_EXPECTS(source_ext <= (size_t)INT32_MAX, CUGRAPH_INVALID_INPUT, "invalid source vertex");
+  int32_t s_host = (int32_t)source_ext;
+  HIP_TRY(hipMemcpyAsync(src.data(), &s_host, 4, hipMemcpyHostToDevice, h.stream));
+  h.sync();
+  renumber_ext_to_int(h, g, src.data(), 1);
+  h.read_back(&s_host, src.data(), 1);
+  CGA_EXPECTS(s_host >= 0 && s_host < nv, CUGRAPH_INVALID_INPUT, "Invalid input argument: source vertex is not a vertex of the graph.");
+  int32_t const source = s_host;
+
+  auto ids   = std::make_unique<device_array_t>((size_t)nv, g.vertex_type);
+  auto dist  = std::make_unique<device_array_t>((size_t)nv, g.weight_type);
+  auto preds = std::make_unique<device_array_t>(compute_predecessors ? (size_t)nv : 0, g.vertex_type);
+  bits_t* d  = dist->buf.as<bits_t>();
+  WT const* w = o.weights.as<WT const>();
+  dvec<int32_t> qa(n1), qb(n1), fa(n1), fb(n1), bigq(n1);
+  dvec<uint32_t> mark_near(n1), mark_far(n1);
+  dvec<counters_t> cnt(1);
+  dvec<double> wsum(1);
+
+  bits_t unreached_bits;
+  {
+    WT m = wmax;
+    std::memcpy(&unreached_bits, &m, sizeof(WT));
+  }
+  hipLaunchKernelGGL(k_fill_t<bits_t>, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, d, nv, unreached_bits);
+  HIP_TRY(hipMemsetAsync(mark_near.data(), 0, n1 * 4, h.stream));
+  HIP_TRY(hipMemsetAsync(mark_far.data(), 0, n1 * 4, h.stream));
+  HIP_TRY(hipMemsetAsync(wsum.data(), 0, 8, h.stream));
+  if (g.ne > 0) hipLaunchKernelGGL(k_sum_weights<WT>, grid_for(g.ne, kBlock, 2048), kBlock, 0, h.stream, w, g.ne, wsum.data());
+  double wsum_h = 0;
+  h.read_back(&wsum_h, wsum.data(), 1);
+  // delta = 32 * average weight / average degree (sssp_impl.cuh:233-247)
+  double avg_w   = g.ne > 0 ? wsum_h / (double)g.ne : 1.0;
+  double avg_deg = nv > 0 ? (double)g.ne / (double)nv : 1.0;
+  double delta   = avg_w * 32.0 / std::max(avg_deg, 1.0);
+  if (!(delta > 0.0) || !std::isfinite(delta)) delta = 1.0;
+
+  {  // d[source] = 0, near = {source}
+    bits_t zero_bits = 0;
+    HIP_TRY(hipMemcpyAsync(d + source, &zero_bits, sizeof(bits_t), hipMemcpyHostToDevice, h.stream));
+    HIP_TRY(hipMemcpyAsync(qa.data(), &source, 4, hipMemcpyHostToDevice, h.stream));
+    h.sync();
+  }
+  int32_t* q_cur = qa.data();
+  int32_t* q_nxt = qb.data();
+  int32_t* far_cur = fa.data();
+  int32_t* far_nxt = fb.data();
+  int64_t n_cur = 1, n_far = 0;
+  uint32_t round = 0, far_epoch = 1;
+  double lower = 0.0, upper = delta;
+  uint64_t steps = 0, relaxed = 0;
+  counters_t c;
+  for (;;) {
+    while (n_cur > 0) {
+      ++round;
+      ++steps;
+      // the far counter persists across relax rounds of one bucket; n_next / n_big / edges are per round
+      counters_t z{};
+      z.n_far           = (uint32_t)n_far;
+      z.far_min_bits_lo = 0xFFFFFFFFu;
+      z.far_min_bits64  = ~0ull;
+      std::memcpy(h.pinned, &z, sizeof(z));
+      HIP_TRY(hipMemcpyAsync(cnt.data(), h.pinned, sizeof(z), hipMemcpyHostToDevice, h.stream));
+      sssp_state<WT> s{d, w, q_nxt, far_cur, mark_near.data(), mark_far.data(), cnt.data(), (WT)std::min(upper, (double)wmax), cutoff, round, far_epoch};
+      {
+        timed_launch t(h, "sssp_relax");
+        hipLaunchKernelGGL(k_sssp_expand<WT>, expand_grid(h, n_cur), TV_BLOCK, 0, h.stream, (int32_t const*)q_cur, n_cur,
+                           (int32_t const*)o.offsets.data(), (int32_t const*)o.indices.data(), bigq.data(), s);
+        hipLaunchKernelGGL(k_sssp_expand_big<WT>, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
+                           (int32_t const*)o.indices.data(), s);
+      }
+      h.read_back(&c, cnt.data(), 1);
+      relaxed += c.edges;
+      n_cur = c.n_next;
+      n_far = c.n_far;
+      CGA_EXPECTS(n_far <= nv, CUGRAPH_UNKNOWN_ERROR, "sssp: far pile overflow");
+      std::swap(q_cur, q_nxt);
+    }
+    if (n_far == 0) break;
+    // advance the bucket window until the far pile yields a non-empty near frontier
+    while (n_cur == 0 && n_far > 0) {
+      lower = upper;
+      upper = upper + delta;
+      ++round;
+      ++far_epoch;
+      counters_t z{};
+      z.far_min_bits_lo = 0xFFFFFFFFu;
+      z.far_min_bits64  = ~0ull;
+      std::memcpy(h.pinned, &z, sizeof(z));
+      HIP_TRY(hipMemcpyAsync(cnt.data(), h.pinned, sizeof(z), hipMemcpyHostToDevice, h.stream));
+      hipLaunchKernelGGL(k_sssp_split<WT>, grid_for(n_far, TV_BLOCK, 2048), TV_BLOCK, 0, h.stream, (int32_t const*)far_cur, n_far,
+                         (bits_t const*)d, (WT)std::min(lower, (double)wmax), (WT)std::min(upper, (double)wmax), q_cur, far_nxt,
+                         mark_near.data(), mark_far.data(), round, far_epoch, cnt.data());
+      h.read_back(&c, cnt.data(), 1);
+      n_cur = c.n_next;
+      n_far = c.n_far;
+      std::swap(far_cur, far_nxt);
+      if (n_cur == 0 && n_far > 0) {  // empty buckets: jump to the one holding the smallest far distance
+        double dmin;
+        if constexpr (sizeof(WT) == 4) { float f; uint32_t b = c.far_min_bits_lo; std::memcpy(&f, &b, 4); dmin = f; }
+        else { double f; unsigned long long b = c.far_min_bits64; std::memcpy(&f, &b, 8); dmin = f; }
+        double k = std::floor(dmin / delta);
+        if (k * delta > upper) upper = k * delta;
+      }
+    }
+  }
+
+  if (compute_predecessors) {
+    fill_i32(h, preds->buf.as<int32_t>(), nv, -1);
+    HIP_TRY(hipMemsetAsync(cnt.data(), 0, sizeof(counters_t), h.stream));
+    sssp_parent<WT> f{(bits_t const*)d, w, preds->buf.as<uint32_t>(), source};
+    keep_reached<WT> keep{(bits_t const*)d, unreached_bits};
+    if (nv > 0) {
+      hipLaunchKernelGGL(k_sssp_parents<WT>, expand_grid(h, nv), TV_BLOCK, 0, h.stream, nv, (int32_t const*)o.offsets.data(),
+                         (int32_t const*)o.indices.data(), bigq.data(), cnt.data(), f, keep);
+      hipLaunchKernelGGL(k_sssp_parents_big<WT>, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
+                         (int32_t const*)o.indices.data(), cnt.data(), f);
+    }
+    h.read_back(&c, cnt.data(), 1);
+    unrenumber_int_to_ext(h, g, preds->buf.as<int32_t>(), nv);
+  }
+  dvec<unsigned long long> reached(1);
+  HIP_TRY(hipMemsetAsync(reached.data(), 0, 8, h.stream));
+  if (nv > 0) hipLaunchKernelGGL(k_count_reached_dist<bits_t>, grid_for(nv, kBlock, 1024), kBlock, 0, h.stream, (bits_t const*)d, nv, unreached_bits, reached.data());
+  unsigned long long nreached;
+  h.read_back(&nreached, reached.data(), 1);
+  h.last_stats = cugraph_amd_traversal_stats_t{steps, relaxed, nreached, compute_predecessors ? c.edges : 0};
+  if (nv > 0) HIP_TRY(hipMemcpyAsync(ids->buf.ptr, g.number_map.data(), nv * 4, hipMemcpyDeviceToDevice, h.stream));
+  h.sync();
+  return new paths_result_t{ids.release(), dist.release(), preds.release()};
+}
+
+}  // namespace
+}  // namespace cga
+
+using namespace cga;
+
+extern "C" cugraph_error_code_t cugraph_bfs(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+                                            cugraph_type_erased_device_array_view_t* sources, bool_t direction_optimizing, size_t depth_limit,
+                                            bool_t compute_predecessors, bool_t /*do_expensive_check*/, cugraph_paths_result_t** result,
+                                            cugraph_error_t** error)
+{
+  if (result) *result = nullptr;
+  return guarded(error, [&] {
+    CGA_EXPECTS(result != nullptr, CUGRAPH_INVALID_INPUT, "result is NULL");
+    handle_t& h = const_cast<handle_t&>(H(handle));
+    *result     = reinterpret_cast<cugraph_paths_result_t*>(
+      run_bfs(h, G(graph), V(sources), direction_optimizing == TRUE, depth_limit, compute_predecessors == TRUE));
+  });
+}
+
+extern "C" cugraph_error_code_t cugraph_sssp(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, size_t source, double cutoff,
+                                             bool_t compute_predecessors, bool_t /*do_expensive_check*/, cugraph_paths_result_t** result,
+                                             cugraph_error_t** error)
+{
+  if (result) *result = nullptr;
+  return guarded(error, [&] {
+    CGA_EXPECTS(result != nullptr, CUGRAPH_INVALID_INPUT, "result is NULL");
+    handle_t& h = const_cast<handle_t&>(H(handle));
+    graph_t& g  = G(graph);
+    // sssp.cpp:72-73,105 dereferences the edge weights unconditionally: an unweighted graph is an error
+    CGA_EXPECTS(g.has_weights, CUGRAPH_INVALID_INPUT, "cugraph_sssp requires a weighted graph");
+    paths_result_t* r = g.weight_type == FLOAT64 ? run_sssp<double>(h, g, source, cutoff, compute_predecessors == TRUE)
+                                                 : run_sssp<float>(h, g, source, cutoff, compute_predecessors == TRUE);
+    *result = reinterpret_cast<cugraph_paths_result_t*>(r);
+  });
+}
+
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_paths_result_get_vertices(cugraph_paths_result_t* result)
+{
+  return reinterpret_cast<cugraph_type_erased_device_array_view_t*>(reinterpret_cast<paths_result_t*>(result)->vertex_ids->new_view());
+}
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_paths_result_get_distances(cugraph_paths_result_t* result)
+{
+  return reinterpret_cast<cugraph_type_erased_device_array_view_t*>(reinterpret_cast<paths_result_t*>(result)->distances->new_view());
+}
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_paths_result_get_predecessors(cugraph_paths_result_t* result)
+{
+  return reinterpret_cast<cugraph_type_erased_device_array_view_t*>(reinterpret_cast<paths_result_t*>(result)->predecessors->new_view());
+}
+extern "C" void cugraph_paths_result_free(cugraph_paths_result_t* result)
+{
+  auto r = reinterpret_cast<paths_result_t*>(result);
+  if (!r) return;
+  delete r->vertex_ids;
+  delete r->distances;
+  delete r->predecessors;
+  delete r;
+}

@@ -1,0 +1,385 @@
+"""Host-side mirror of the reference's pylibcugraph interface for the PageRank / BFS / SSSP path.
+
+Same names, argument order, return tuples and exceptions as
+  python/pylibcugraph/pylibcugraph/{resource_handle,graph_properties,graphs,pagerank,personalized_pagerank,
+  bfs,sssp,has_vertex}.pyx and utils.pyx:assert_success,
+so the reference's pylibcugraph tests read unchanged against this module.  Device arrays are torch tensors
+on the HIP device (the reference uses cupy); anything exposing __cuda_array_interface__ is accepted too.
+Everything computes through the C ABI (cugraph_amd/_capi.py); PyTorch is used for device memory only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+
+INT_MAX = 2147483647
+
+_TORCH_TO_C = {
+    torch.int8: capi.INT8, torch.int16: capi.INT16, torch.int32: capi.INT32, torch.int64: capi.INT64,
+    torch.uint8: capi.UINT8, torch.float32: capi.FLOAT32, torch.float64: capi.FLOAT64, torch.bool: capi.BOOL,
+}
+_C_TO_TORCH = {
+    capi.INT8: torch.int8, capi.INT16: torch.int16, capi.INT32: torch.int32, capi.INT64: torch.int64,
+    capi.UINT8: torch.uint8, capi.FLOAT32: torch.float32, capi.FLOAT64: torch.float64, capi.BOOL: torch.bool,
+    capi.SIZE_T: torch.int64,
+}
+_NP_TO_C = {"int8": capi.INT8, "int16": capi.INT16, "int32": capi.INT32, "int64": capi.INT64, "uint8": capi.UINT8,
+            "uint16": capi.UINT16, "uint32": capi.UINT32, "uint64": capi.UINT64, "float32": capi.FLOAT32,
+            "float64": capi.FLOAT64, "bool": capi.BOOL}
+
+
+class FailedToConvergeError(Exception):
+    """Raised when an iterative algorithm does not converge (pylibcugraph/exceptions.py:9)."""
+
+
+def assert_success(code, err, api_name):
+    """utils.pyx:36-83: error code -> Python exception of the same class as the reference raises."""
+    if code == capi.CUGRAPH_SUCCESS:
+        return
+    l = capi.lib()
+    msg = l.cugraph_error_message(err)
+    msg = msg.decode() if isinstance(msg, bytes) else str(msg)
+    l.cugraph_error_free(err)
+    name = capi.ERROR_NAMES[code] if 0 <= code < len(capi.ERROR_NAMES) else "unknown error code"
+    text = f"non-success value returned from {api_name}: {name} {msg}"
+    if code in (capi.CUGRAPH_INVALID_HANDLE, capi.CUGRAPH_INVALID_INPUT, capi.CUGRAPH_UNSUPPORTED_TYPE_COMBINATION):
+        raise ValueError(text)
+    if code == capi.CUGRAPH_ALLOC_ERROR:
+        raise MemoryError(text)
+    if code == capi.CUGRAPH_NOT_IMPLEMENTED:
+        raise NotImplementedError(text)
+    raise RuntimeError(text)
+
+
+def _describe(obj):
+    """(device pointer, length, C type id) of a torch tensor or a __cuda_array_interface__ object."""
+    if isinstance(obj, torch.Tensor):
+        if not obj.is_cuda:
+            raise TypeError("expected a device (cuda/HIP) tensor")
+        if not obj.is_contiguous() or obj.dim() != 1:
+            raise TypeError("expected a contiguous 1-D tensor")
+        return obj.data_ptr(), obj.numel(), _TORCH_TO_C[obj.dtype]
+    cai = getattr(obj, "__cuda_array_interface__", None)
+    if cai is None:
+        raise TypeError(f"object of type {type(obj)} does not support __cuda_array_interface__")
+    return cai["data"][0], int(np.prod(cai["shape"])), _NP_TO_C[np.dtype(cai["typestr"]).name]
+
+
+class _View:
+    """Borrowed cugraph_type_erased_device_array_view_t over a Python device array (utils.pyx:235-246)."""
+
+    def __init__(self, obj):
+        self.ptr = None
+        if obj is None:
+            return
+        p, n, t = _describe(obj)
+        self._keepalive = obj
+        self.ptr = capi.lib().cugraph_type_erased_device_array_view_create(C.c_void_p(p), n, t)
+
+    def free(self):
+        if self.ptr:
+            capi.lib().cugraph_type_erased_device_array_view_free(self.ptr)
+            self.ptr = None
+
+
+def _sync_torch():
+    # inputs may still be in flight on torch's stream; the library runs on its own HIP stream
+    torch.cuda.current_stream().synchronize()
+
+
+def copy_to_torch(handle_ptr, view_ptr):
+    """utils.pyx:162-196 copy_to_cupy_array: new tensor <- device view, then free the view."""
+    l = capi.lib()
+    n = l.cugraph_type_erased_device_array_view_size(view_ptr)
+    t = l.cugraph_type_erased_device_array_view_type(view_ptr)
+    out = torch.empty(n, dtype=_C_TO_TORCH[t], device="cuda")
+    _sync_torch()
+    ov = l.cugraph_type_erased_device_array_view_create(C.c_void_p(out.data_ptr()), n, t)
+    err = C.c_void_p()
+    code = l.cugraph_type_erased_device_array_view_copy(handle_ptr, ov, view_ptr, C.byref(err))
+    l.cugraph_type_erased_device_array_view_free(ov)
+    l.cugraph_type_erased_device_array_view_free(view_ptr)
+    assert_success(code, err, "cugraph_type_erased_device_array_view_copy")
+    return out
+
+
+class ResourceHandle:
+    """resource_handle.pyx: RAII wrapper of cugraph_resource_handle_t (SG: library-owned context)."""
+
+    def __init__(self, handle=None):
+        if handle is not None:
+            raise NotImplementedError("a raft handle cannot be consumed on this platform; pass None")
+        l = capi.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("cugraph_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+        torch.cuda.init()
+        self.c_resource_handle_ptr = l.cugraph_create_resource_handle(None)
+        if not self.c_resource_handle_ptr:
+            raise RuntimeError("cugraph_create_resource_handle failed")
+
+    def __del__(self):
+        p = getattr(self, "c_resource_handle_ptr", None)
+        if p:
+            capi.lib().cugraph_free_resource_handle(p)
+            self.c_resource_handle_ptr = None
+
+    # --- harness helpers (extensions.h)
+    def sync(self):
+        err = C.c_void_p()
+        assert_success(capi.lib().cugraph_amd_handle_sync(self.c_resource_handle_ptr, C.byref(err)), err, "cugraph_amd_handle_sync")
+
+    def kernel_timing(self, on: bool):
+        capi.lib().cugraph_amd_kernel_timing_enable(self.c_resource_handle_ptr, 1 if on else 0)
+
+    def kernel_timing_reset(self):
+        capi.lib().cugraph_amd_kernel_timing_reset(self.c_resource_handle_ptr)
+
+    def kernel_timing_get(self, family: str):
+        n, ms, err = C.c_size_t(0), C.c_double(0), C.c_void_p()
+        assert_success(capi.lib().cugraph_amd_kernel_timing_get(self.c_resource_handle_ptr, family.encode(), C.byref(n), C.byref(ms),
+                                                                C.byref(err)), err, "cugraph_amd_kernel_timing_get")
+        return int(n.value), float(ms.value)
+
+    def set_pagerank_hot_tile(self, n_entries: int) -> int:
+        return capi.lib().cugraph_amd_set_pagerank_hot_tile(self.c_resource_handle_ptr, int(n_entries))
+
+    def last_traversal_stats(self):
+        s = capi.TraversalStats()
+        capi.lib().cugraph_amd_last_traversal_stats(self.c_resource_handle_ptr, C.byref(s))
+        return {"steps": s.steps, "edges_inspected": s.edges_inspected, "vertices_reached": s.vertices_reached,
+                "edges_of_reached": s.edges_of_reached}
+
+
+class GraphProperties:
+    """graph_properties.pyx"""
+
+    def __init__(self, is_symmetric=False, is_multigraph=False):
+        self.c_graph_properties = capi.GraphPropertiesStruct(int(bool(is_symmetric)), int(bool(is_multigraph)))
+
+    @property
+    def is_symmetric(self):
+        return bool(self.c_graph_properties.is_symmetric)
+
+    @property
+    def is_multigraph(self):
+        return bool(self.c_graph_properties.is_multigraph)
+
+
+class SGGraph:
+    """graphs.pyx:42-337 SGGraph: owns a cugraph_graph_t created by cugraph_graph_create_with_times_sg
+    (COO) or cugraph_graph_create_sg_from_csr (CSR)."""
+
+    def __init__(self, resource_handle, graph_properties, src_or_offset_array, dst_or_index_array, weight_array=None,
+                 store_transposed=False, renumber=False, do_expensive_check=False, edge_id_array=None, edge_type_array=None,
+                 edge_start_time_array=None, edge_end_time_array=None, input_array_format="COO", vertices_array=None,
+                 drop_self_loops=False, drop_multi_edges=False, symmetrize=False):
+        self.c_graph_ptr = None
+        l = capi.lib()
+        for name, arr in (("src_or_offset_array", src_or_offset_array), ("dst_or_index_array", dst_or_index_array)):
+            _describe(arr)  # TypeError like assert_CAI_type
+        self.resource_handle = resource_handle
+        views = [_View(a) for a in (vertices_array, src_or_offset_array, dst_or_index_array, weight_array, edge_id_array,
+                                    edge_type_array, edge_start_time_array, edge_end_time_array)]
+        v_vert, v_src, v_dst, v_w, v_eid, v_et, v_t0, v_t1 = [v.ptr for v in views]
+        g, err = C.c_void_p(), C.c_void_p()
+        _sync_torch()
+        try:
+            if input_array_format == "COO":
+                code = l.cugraph_graph_create_with_times_sg(
+                    resource_handle.c_resource_handle_ptr, C.byref(graph_properties.c_graph_properties), v_vert, v_src, v_dst, v_w,
+                    v_eid, v_et, v_t0, v_t1, int(store_transposed), int(renumber), int(drop_self_loops), int(drop_multi_edges),
+                    int(symmetrize), int(do_expensive_check), C.byref(g), C.byref(err))
+                assert_success(code, err, "cugraph_graph_create_with_times_sg()")
+            elif input_array_format == "CSR":
+                code = l.cugraph_graph_create_sg_from_csr(
+                    resource_handle.c_resource_handle_ptr, C.byref(graph_properties.c_graph_properties), v_src, v_dst, v_w, v_eid,
+                    v_et, int(store_transposed), int(renumber), int(symmetrize), int(do_expensive_check), C.byref(g), C.byref(err))
+                assert_success(code, err, "cugraph_graph_create_sg_from_csr()")
+            else:
+                raise ValueError("invalid 'input_array_format'. Only 'COO' and 'CSR' format are supported.")
+        finally:
+            for v in views:
+                v.free()
+        self.c_graph_ptr = g
+
+    def __del__(self):
+        p = getattr(self, "c_graph_ptr", None)
+        if p:
+            capi.lib().cugraph_graph_free(p)
+            self.c_graph_ptr = None
+
+    @property
+    def num_vertices(self):
+        return int(capi.lib().cugraph_amd_graph_num_vertices(self.c_graph_ptr))
+
+    @property
+    def num_edges(self):
+        return int(capi.lib().cugraph_amd_graph_num_edges(self.c_graph_ptr))
+
+
+def has_vertex(resource_handle, graph, vertices, do_expensive_check=False):
+    """has_vertex.pyx:43"""
+    l = capi.lib()
+    v = _View(vertices)
+    res, err = C.c_void_p(), C.c_void_p()
+    _sync_torch()
+    code = l.cugraph_has_vertex(resource_handle.c_resource_handle_ptr, graph.c_graph_ptr, v.ptr, int(do_expensive_check),
+                                C.byref(res), C.byref(err))
+    v.free()
+    assert_success(code, err, "cugraph_has_vertex")
+    view = l.cugraph_type_erased_device_array_view(res)
+    out = copy_to_torch(resource_handle.c_resource_handle_ptr, view)
+    l.cugraph_type_erased_device_array_free(res)
+    return out
+
+
+def _centrality_result(resource_handle, result_ptr, fail_on_nonconvergence):
+    l = capi.lib()
+    converged = bool(l.cugraph_centrality_result_converged(result_ptr))
+    verts = vals = None
+    if (fail_on_nonconvergence is False) or converged:
+        verts = copy_to_torch(resource_handle.c_resource_handle_ptr, l.cugraph_centrality_result_get_vertices(result_ptr))
+        vals = copy_to_torch(resource_handle.c_resource_handle_ptr, l.cugraph_centrality_result_get_values(result_ptr))
+    l.cugraph_centrality_result_free(result_ptr)
+    if fail_on_nonconvergence is False:
+        return (verts, vals, converged)
+    if converged:
+        return (verts, vals)
+    raise FailedToConvergeError
+
+
+def pagerank(resource_handle, graph, precomputed_vertex_out_weight_vertices, precomputed_vertex_out_weight_sums,
+             initial_guess_vertices, initial_guess_values, alpha, epsilon, max_iterations, do_expensive_check,
+             fail_on_nonconvergence=True):
+    """pagerank.pyx:49-237 (always calls cugraph_pagerank_allow_nonconvergence, :196)."""
+    l = capi.lib()
+    views = [_View(a) for a in (precomputed_vertex_out_weight_vertices, precomputed_vertex_out_weight_sums,
+                                initial_guess_vertices, initial_guess_values)]
+    res, err = C.c_void_p(), C.c_void_p()
+    _sync_torch()
+    code = l.cugraph_pagerank_allow_nonconvergence(resource_handle.c_resource_handle_ptr, graph.c_graph_ptr, views[0].ptr, views[1].ptr,
+                                                   views[2].ptr, views[3].ptr, float(alpha), float(epsilon), int(max_iterations),
+                                                   int(do_expensive_check), C.byref(res), C.byref(err))
+    for v in views:
+        v.free()
+    assert_success(code, err, "cugraph_pagerank_allow_nonconvergence")
+    return _centrality_result(resource_handle, res, fail_on_nonconvergence)
+
+
+def personalized_pagerank(resource_handle, graph, precomputed_vertex_out_weight_vertices, precomputed_vertex_out_weight_sums,
+                          initial_guess_vertices, initial_guess_values, personalization_vertices, personalization_values, alpha,
+                          epsilon, max_iterations, do_expensive_check, fail_on_nonconvergence=True):
+    """personalized_pagerank.pyx:49-264"""
+    l = capi.lib()
+    views = [_View(a) for a in (precomputed_vertex_out_weight_vertices, precomputed_vertex_out_weight_sums, initial_guess_vertices,
+                                initial_guess_values, personalization_vertices, personalization_values)]
+    res, err = C.c_void_p(), C.c_void_p()
+    _sync_torch()
+    code = l.cugraph_personalized_pagerank_allow_nonconvergence(
+        resource_handle.c_resource_handle_ptr, graph.c_graph_ptr, *[v.ptr for v in views], float(alpha), float(epsilon),
+        int(max_iterations), int(do_expensive_check), C.byref(res), C.byref(err))
+    for v in views:
+        v.free()
+    assert_success(code, err, "cugraph_personalized_pagerank_allow_nonconvergence")
+    return _centrality_result(resource_handle, res, fail_on_nonconvergence)
+
+
+def bfs(handle, graph, sources, direction_optimizing, depth_limit, compute_predecessors, do_expensive_check):
+    """bfs.pyx:50-196.  Returns (distances, predecessors, vertices)."""
+    l = capi.lib()
+    _describe(sources)
+    if not bool(torch.all(has_vertex(handle, graph, sources, do_expensive_check))):  # bfs.pyx:140-143
+        raise ValueError("one or more vertices are invalid. Call the method 'has_vertex' ", "to identify the invalid vertices")
+    if depth_limit <= 0:
+        depth_limit = INT_MAX - 1  # bfs.pyx:144-145
+    v = _View(sources)
+    res, err = C.c_void_p(), C.c_void_p()
+    _sync_torch()
+    code = l.cugraph_bfs(handle.c_resource_handle_ptr, graph.c_graph_ptr, v.ptr, int(direction_optimizing), int(depth_limit),
+                         int(compute_predecessors), int(do_expensive_check), C.byref(res), C.byref(err))
+    v.free()
+    assert_success(code, err, "cugraph_bfs")
+    h = handle.c_resource_handle_ptr
+    distances = copy_to_torch(h, l.cugraph_paths_result_get_distances(res))
+    predecessors = copy_to_torch(h, l.cugraph_paths_result_get_predecessors(res))
+    vertices = copy_to_torch(h, l.cugraph_paths_result_get_vertices(res))
+    l.cugraph_paths_result_free(res)
+    return (distances, predecessors, vertices)
+
+
+def sssp(resource_handle, graph, source, cutoff, compute_predecessors, do_expensive_check):
+    """sssp.pyx:48-168.  Returns (vertices, distances, predecessors)."""
+    l = capi.lib()
+    res, err = C.c_void_p(), C.c_void_p()
+    _sync_torch()
+    code = l.cugraph_sssp(resource_handle.c_resource_handle_ptr, graph.c_graph_ptr, int(source), float(cutoff), int(compute_predecessors),
+                          int(do_expensive_check), C.byref(res), C.byref(err))
+    assert_success(code, err, "cugraph_sssp")
+    h = resource_handle.c_resource_handle_ptr
+    vertices = copy_to_torch(h, l.cugraph_paths_result_get_vertices(res))
+    distances = copy_to_torch(h, l.cugraph_paths_result_get_distances(res))
+    predecessors = copy_to_torch(h, l.cugraph_paths_result_get_predecessors(res))
+    l.cugraph_paths_result_free(res)
+    return (vertices, distances, predecessors)
+
+
+# ------------------------------------------------------------------------------- harness extensions
+def generate_rmat_edgelist(resource_handle, scale, num_edges, a=0.57, b=0.19, c=0.19, seed=0, first_edge=0):
+    """On-device RMAT slice [first_edge, first_edge + num_edges) -> (src, dst) int32 tensors."""
+    l = capi.lib()
+    src = torch.empty(num_edges, dtype=torch.int32, device="cuda")
+    dst = torch.empty(num_edges, dtype=torch.int32, device="cuda")
+    vs, vd = _View(src), _View(dst)
+    err = C.c_void_p()
+    _sync_torch()
+    code = l.cugraph_amd_generate_rmat_edgelist(resource_handle.c_resource_handle_ptr, int(scale), int(first_edge), int(num_edges),
+                                                float(a), float(b), float(c), int(seed), vs.ptr, vd.ptr, C.byref(err))
+    vs.free()
+    vd.free()
+    assert_success(code, err, "cugraph_amd_generate_rmat_edgelist")
+    return src, dst
+
+
+class PageRankPlan:
+    """Explicit create / step / result form of cugraph_pagerank (extensions.h) so a harness can time
+    exactly K power iterations."""
+
+    def __init__(self, resource_handle, graph, alpha=0.85, initial_guess=None, personalization=None, precomputed_out_weights=None):
+        l = capi.lib()
+        self.handle, self.graph = resource_handle, graph
+        pairs = []
+        for p in (precomputed_out_weights, initial_guess, personalization):
+            pairs += [_View(p[0]), _View(p[1])] if p is not None else [_View(None), _View(None)]
+        plan, err = C.c_void_p(), C.c_void_p()
+        _sync_torch()
+        code = l.cugraph_amd_pagerank_plan_create(resource_handle.c_resource_handle_ptr, graph.c_graph_ptr, *[v.ptr for v in pairs],
+                                                  float(alpha), C.byref(plan), C.byref(err))
+        for v in pairs:
+            v.free()
+        assert_success(code, err, "cugraph_amd_pagerank_plan_create")
+        self.ptr = plan
+        self.iterations = 0
+
+    def step(self, n_iterations, epsilon=0.0):
+        done, conv, err = C.c_size_t(0), C.c_int(0), C.c_void_p()
+        code = capi.lib().cugraph_amd_pagerank_plan_step(self.ptr, float(epsilon), int(n_iterations), C.byref(done), C.byref(conv), C.byref(err))
+        assert_success(code, err, "cugraph_amd_pagerank_plan_step")
+        self.iterations += int(done.value)
+        return int(done.value), bool(conv.value)
+
+    def result(self, converged=False):
+        l = capi.lib()
+        res, err = C.c_void_p(), C.c_void_p()
+        code = l.cugraph_amd_pagerank_plan_result(self.ptr, self.iterations, int(converged), C.byref(res), C.byref(err))
+        assert_success(code, err, "cugraph_amd_pagerank_plan_result")
+        return _centrality_result(self.handle, res, False)
+
+    def __del__(self):
+        p = getattr(self, "ptr", None)
+        if p:
+            capi.lib().cugraph_amd_pagerank_plan_free(p)
+            self.ptr = None

@@ -1,0 +1,85 @@
+/* Entry points of libcugraph_c.so that have NO counterpart in the reference's C API.  They exist for
+ * the benchmark / test harness only (on-device RMAT input, per-iteration stepping so that bench.py can
+ * time exactly K power iterations, HIP-event timing of the dominant kernel).  Everything an existing
+ * cuGraph caller needs is in include/cugraph_c/.
+ */
+#pragma once
+#include <cugraph_c/array.h>
+#include <cugraph_c/centrality_algorithms.h>
+#include <cugraph_c/graph.h>
+#include <cugraph_c/resource_handle.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Library / build identification ("cugraph_amd <ver> gfx950"). */
+CUGRAPH_EXPORT const char* cugraph_amd_version(void);
+
+/* RMAT edge list on the device.  Algorithm of cpp/src/generators/generate_rmat_edgelist.cuh:85-103
+ * (no clip-and-flip, no scramble) with a counter-based splitmix64 RNG, so edge i is a pure function of
+ * (seed, i): any rank can generate any slice [first_edge, first_edge + n).  Bit-identical to
+ * oracle/oracle.c:orc_rmat.  src/dst are INT32 views of size >= n. */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_generate_rmat_edgelist(
+  const cugraph_resource_handle_t* handle, size_t scale, size_t first_edge, size_t num_edges, double a,
+  double b, double c, uint64_t seed, cugraph_type_erased_device_array_view_t* src,
+  cugraph_type_erased_device_array_view_t* dst, cugraph_error_t** error);
+
+/* PageRank as an explicit plan: create (out-weight sums, initial vector), step n power iterations,
+ * finish (result object as cugraph_pagerank returns it).  cugraph_pagerank* are implemented on top of
+ * exactly these calls; stepping never synchronises with the host unless epsilon > 0. */
+typedef struct { int32_t align_; } cugraph_amd_pagerank_plan_t;
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_plan_create(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_vertices,
+  const cugraph_type_erased_device_array_view_t* precomputed_vertex_out_weight_sums,
+  const cugraph_type_erased_device_array_view_t* initial_guess_vertices,
+  const cugraph_type_erased_device_array_view_t* initial_guess_values,
+  const cugraph_type_erased_device_array_view_t* personalization_vertices,
+  const cugraph_type_erased_device_array_view_t* personalization_values, double alpha,
+  cugraph_amd_pagerank_plan_t** plan, cugraph_error_t** error);
+/* Runs up to max_iterations more iterations; stops early when the L1 change drops below epsilon
+ * (epsilon <= 0: never, and no host synchronisation at all).  *iterations_done = iterations run by this
+ * call, *converged = stopped on epsilon. */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_plan_step(
+  cugraph_amd_pagerank_plan_t* plan, double epsilon, size_t max_iterations, size_t* iterations_done,
+  bool_t* converged, cugraph_error_t** error);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_plan_result(
+  cugraph_amd_pagerank_plan_t* plan, size_t total_iterations, bool_t converged,
+  cugraph_centrality_result_t** result, cugraph_error_t** error);
+CUGRAPH_EXPORT void cugraph_amd_pagerank_plan_free(cugraph_amd_pagerank_plan_t* plan);
+
+/* Blocks until everything queued on the handle's stream has finished. */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_handle_sync(const cugraph_resource_handle_t* handle,
+                                                            cugraph_error_t** error);
+
+/* HIP-event timing of the dominant kernels on the handle's own stream.  When enabled, every launch of
+ * the named kernel family is bracketed by hipEventRecord on that stream; get() synchronises and returns
+ * launch count and summed milliseconds since the last reset.  family: "pagerank_spmv", "bfs_expand",
+ * "sssp_relax". */
+CUGRAPH_EXPORT void cugraph_amd_kernel_timing_enable(const cugraph_resource_handle_t* handle, bool_t on);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_kernel_timing_get(
+  const cugraph_resource_handle_t* handle, const char* family, size_t* launches, double* total_ms,
+  cugraph_error_t** error);
+CUGRAPH_EXPORT void cugraph_amd_kernel_timing_reset(const cugraph_resource_handle_t* handle);
+
+/* Graph introspection used by the tests (sizes, degree-class boundaries of the CSC/CSR row schedule). */
+CUGRAPH_EXPORT size_t cugraph_amd_graph_num_vertices(const cugraph_graph_t* graph);
+CUGRAPH_EXPORT size_t cugraph_amd_graph_num_edges(const cugraph_graph_t* graph);
+
+/* Tuning knob for the PageRank SpMV: number of x entries staged in LDS per workgroup (0 = off).
+ * Default is chosen from the graph size; set before plan creation.  Returns the previous value. */
+CUGRAPH_EXPORT int cugraph_amd_set_pagerank_hot_tile(const cugraph_resource_handle_t* handle, int n_entries);
+
+/* Traversal statistics of the last cugraph_bfs / cugraph_sssp on this handle: number of levels or bucket
+ * steps, edges inspected (relaxations), vertices reached. */
+typedef struct {
+  uint64_t steps;
+  uint64_t edges_inspected;
+  uint64_t vertices_reached;
+  uint64_t edges_of_reached;
+} cugraph_amd_traversal_stats_t;
+CUGRAPH_EXPORT void cugraph_amd_last_traversal_stats(const cugraph_resource_handle_t* handle,
+                                                     cugraph_amd_traversal_stats_t* out);
+#ifdef __cplusplus
+}
+#endif

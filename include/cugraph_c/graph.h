@@ -1,0 +1,63 @@
+/* Graph object.  Replaces the SG part of cpp/include/cugraph_c/graph.h
+ * (impl cpp/src/c_api/graph_sg.cpp:699 cugraph_graph_create_sg, :835 cugraph_graph_create_with_times_sg
+ * -- the one pylibcugraph calls, python/pylibcugraph/pylibcugraph/graphs.pyx:282 --,
+ * :989 cugraph_graph_create_sg_from_csr, :1097 cugraph_graph_free).
+ *
+ * Inputs are copied, never mutated (graph_sg.cpp:98-183).  Type rules follow graph_sg.cpp:745-779:
+ * src/dst (and `vertices`) must share one integer type; this build supports INT32 vertices/edges with
+ * FLOAT32 or FLOAT64 weights and returns CUGRAPH_UNSUPPORTED_TYPE_COMBINATION otherwise; an INT32
+ * graph must have fewer than INT32_MAX edges (graph_sg.cpp:918-922).
+ * edge_ids / edge_type_ids / edge times are accepted only as NULL (not on the PageRank/BFS/SSSP path)
+ * and drop_self_loops / drop_multi_edges / symmetrize = TRUE return CUGRAPH_NOT_IMPLEMENTED
+ * ("next").
+ *
+ * Unlike the reference, an algorithm that needs the other storage orientation does not rebuild and
+ * re-number the graph (cpp/src/c_api/graph.hpp:84-143): both CSR and CSC live under ONE numbering,
+ * the second one built lazily on first use. */
+#pragma once
+#include <cugraph_c/array.h>
+#include <cugraph_c/export.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct { int32_t align_; } cugraph_graph_t;
+typedef struct {
+  bool_t is_symmetric;
+  bool_t is_multigraph;
+} cugraph_graph_properties_t;
+
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_graph_create_sg(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* vertices,
+  const cugraph_type_erased_device_array_view_t* src, const cugraph_type_erased_device_array_view_t* dst,
+  const cugraph_type_erased_device_array_view_t* weights,
+  const cugraph_type_erased_device_array_view_t* edge_ids,
+  const cugraph_type_erased_device_array_view_t* edge_type_ids, bool_t store_transposed, bool_t renumber,
+  bool_t drop_self_loops, bool_t drop_multi_edges, bool_t symmetrize, bool_t do_expensive_check,
+  cugraph_graph_t** graph, cugraph_error_t** error);
+
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_graph_create_with_times_sg(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* vertices,
+  const cugraph_type_erased_device_array_view_t* src, const cugraph_type_erased_device_array_view_t* dst,
+  const cugraph_type_erased_device_array_view_t* weights,
+  const cugraph_type_erased_device_array_view_t* edge_ids,
+  const cugraph_type_erased_device_array_view_t* edge_type_ids,
+  const cugraph_type_erased_device_array_view_t* edge_start_time_ids,
+  const cugraph_type_erased_device_array_view_t* edge_end_time_ids, bool_t store_transposed,
+  bool_t renumber, bool_t drop_self_loops, bool_t drop_multi_edges, bool_t symmetrize,
+  bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error);
+
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_graph_create_sg_from_csr(
+  const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+  const cugraph_type_erased_device_array_view_t* offsets,
+  const cugraph_type_erased_device_array_view_t* indices,
+  const cugraph_type_erased_device_array_view_t* weights,
+  const cugraph_type_erased_device_array_view_t* edge_ids,
+  const cugraph_type_erased_device_array_view_t* edge_type_ids, bool_t store_transposed, bool_t renumber,
+  bool_t symmetrize, bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error);
+
+CUGRAPH_EXPORT void cugraph_graph_free(cugraph_graph_t* graph);
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,33 @@
+/* BFS / SSSP.  Replaces cpp/include/cugraph_c/traversal_algorithms.h:24-165
+ * (impl cpp/src/c_api/bfs.cpp:189 cugraph_bfs, :156-187 result accessors; cpp/src/c_api/sssp.cpp:136).
+ *
+ * BFS distances/predecessors have the graph's vertex type, SSSP distances its weight type; unreached
+ * = type max, predecessor -1; the predecessor array has size 0 when not requested.  A source array
+ * whose type differs from the graph's vertex type, or a source that is not a vertex of the graph,
+ * gives CUGRAPH_INVALID_INPUT (bfs.cpp:106-119, 198-205).  depth_limit semantics bfs_impl.cuh:867-868.
+ * Predecessors are deterministic here (minimum-id parent; SSSP: lexicographic min (distance, parent)
+ * as sssp_impl.cuh:334), a valid instance of the reference's reduce_op::any. */
+#pragma once
+#include <cugraph_c/error.h>
+#include <cugraph_c/graph.h>
+#include <cugraph_c/resource_handle.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct { int32_t align_; } cugraph_paths_result_t;
+CUGRAPH_EXPORT cugraph_type_erased_device_array_view_t* cugraph_paths_result_get_vertices(cugraph_paths_result_t* result);
+CUGRAPH_EXPORT cugraph_type_erased_device_array_view_t* cugraph_paths_result_get_distances(cugraph_paths_result_t* result);
+CUGRAPH_EXPORT cugraph_type_erased_device_array_view_t* cugraph_paths_result_get_predecessors(cugraph_paths_result_t* result);
+CUGRAPH_EXPORT void cugraph_paths_result_free(cugraph_paths_result_t* result);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_bfs(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+  cugraph_type_erased_device_array_view_t* sources, bool_t direction_optimizing, size_t depth_limit,
+  bool_t compute_predecessors, bool_t do_expensive_check, cugraph_paths_result_t** result,
+  cugraph_error_t** error);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_sssp(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, size_t source, double cutoff,
+  bool_t compute_predecessors, bool_t do_expensive_check, cugraph_paths_result_t** result,
+  cugraph_error_t** error);
+#ifdef __cplusplus
+}
+#endif

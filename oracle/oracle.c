@@ -1,0 +1,338 @@
+/*
+ * oracle.c -- TEST INFRASTRUCTURE ONLY.  CPU restatement of the reference's algorithms for the
+ * PageRank / BFS / SSSP hot path.  Nothing in the product path (cugraph_amd/, include/) may link,
+ * import or call this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * Parity status: PINNED.  Checked (tests/test_oracle.py) against
+ *   - the reference's C-API golden vectors (cpp/tests/c_api/pagerank_test.c:385-544,
+ *     bfs_test.c:160-210, sssp_test.c:167-223) and pylibcugraph goldens
+ *     (python/pylibcugraph/pylibcugraph/tests/test_pagerank.py:14-147), committed under tests/golden/;
+ *   - the reference's own CPU reference functions compiled in place into oracle/_ref/libref.so
+ *     (recipe oracle/build_ref.sh): pagerank_reference (cpp/tests/link_analysis/pagerank_test.cpp:33-121),
+ *     bfs_reference (cpp/tests/traversal/bfs_test.cpp:32-70), sssp_reference
+ *     (cpp/tests/traversal/sssp_test.cpp:33-75).
+ *
+ * Each function cites the reference file:line it follows.
+ */
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * RMAT edge generator.  Algorithm = cpp/src/generators/generate_rmat_edgelist.cuh:85-103 (per edge,
+ * per bit from the MSB: r0 > a+b sets the src bit; r1 > (srcbit ? c/(1-a-b) : a/(a+b)) sets the dst
+ * bit; no clip-and-flip, no scramble).  The reference draws r0,r1 from raft::random (not vendored,
+ * stream not reproducible here), so the RNG is ours: counter-based splitmix64 on (seed, edge, bit),
+ * compared as 32-bit integers against integer thresholds so CPU and GPU agree bit-for-bit.
+ * The HIP generator (cugraph_amd/csrc/rmat.hip) implements the same function.
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint64_t splitmix64_at(uint64_t seed, uint64_t counter)
+{
+  uint64_t z = seed + (counter + 1) * 0x9E3779B97F4A7C15ull;
+  z          = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z          = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+static inline uint32_t prob_to_u32(double p)
+{
+  if (p <= 0.0) return 0u;
+  if (p >= 1.0) return 0xFFFFFFFFu;
+  return (uint32_t)(p * 4294967296.0);
+}
+
+void orc_rmat_thresholds(double a, double b, double c, uint32_t* t_ab, uint32_t* t_a_norm, uint32_t* t_c_norm)
+{
+  double a_plus_b = a + b;
+  double a_norm   = a_plus_b > 0.0 ? a / a_plus_b : 0.0;
+  double c_norm   = (1.0 - a_plus_b) > 0.0 ? c / (1.0 - a_plus_b) : 0.0;
+  *t_ab           = prob_to_u32(a_plus_b);
+  *t_a_norm       = prob_to_u32(a_norm);
+  *t_c_norm       = prob_to_u32(c_norm);
+}
+
+void orc_rmat(int scale, uint64_t first_edge, uint64_t num_edges, double a, double b, double c,
+              uint64_t seed, int32_t* src, int32_t* dst)
+{
+  uint32_t t_ab, t_an, t_cn;
+  orc_rmat_thresholds(a, b, c, &t_ab, &t_an, &t_cn);
+#pragma omp parallel for schedule(static)
+  for (int64_t k = 0; k < (int64_t)num_edges; ++k) {
+    uint64_t i = first_edge + (uint64_t)k;
+    int32_t s = 0, d = 0;
+    for (int bit = scale - 1; bit >= 0; --bit) {
+      uint64_t z  = splitmix64_at(seed, i * 64ull + (uint64_t)bit);
+      uint32_t r0 = (uint32_t)(z >> 32), r1 = (uint32_t)z;
+      int sb      = r0 > t_ab;
+      int db      = r1 > (sb ? t_cn : t_an);
+      s |= sb << bit;
+      d |= db << bit;
+    }
+    src[k] = s;
+    dst[k] = d;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * COO -> compressed sparse (major-sorted, neighbours ascending, multi-edges / self loops kept):
+ * what sort_and_compress_edgelist produces (cpp/src/structure/detail/structure_utils.cuh:197-464,
+ * pair sort at :435-447).  Ties between equal (major,minor) pairs keep input order (stable), which
+ * only matters for the weight column of multi-edges.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int32_t minor; float w; } pair_f;
+typedef struct { int32_t minor; double w; } pair_d;
+static int cmp_pair_f(const void* x, const void* y) { int32_t a = ((const pair_f*)x)->minor, b = ((const pair_f*)y)->minor; return (a > b) - (a < b); }
+static int cmp_i32(const void* x, const void* y) { int32_t a = *(const int32_t*)x, b = *(const int32_t*)y; return (a > b) - (a < b); }
+
+/* stable insertion/merge: qsort is not stable, so sort (minor, original position) pairs */
+typedef struct { int32_t minor; int32_t pos; } mp_t;
+static int cmp_mp(const void* x, const void* y)
+{
+  const mp_t *a = (const mp_t*)x, *b = (const mp_t*)y;
+  if (a->minor != b->minor) return (a->minor > b->minor) - (a->minor < b->minor);
+  return (a->pos > b->pos) - (a->pos < b->pos);
+}
+
+/* weights may be NULL; wsize = 4 (float) or 8 (double) */
+void orc_coo_to_cs(int64_t nv, int64_t ne, const int32_t* major, const int32_t* minor,
+                   const void* weights, int wsize, int64_t* offsets, int32_t* indices, void* out_w)
+{
+  memset(offsets, 0, sizeof(int64_t) * (size_t)(nv + 1));
+  for (int64_t e = 0; e < ne; ++e) offsets[major[e] + 1]++;
+  for (int64_t v = 0; v < nv; ++v) offsets[v + 1] += offsets[v];
+  int64_t* cur = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nv > 0 ? nv : 1));
+  memcpy(cur, offsets, sizeof(int64_t) * (size_t)nv);
+  int64_t* epos = (int64_t*)malloc(sizeof(int64_t) * (size_t)(ne > 0 ? ne : 1));
+  for (int64_t e = 0; e < ne; ++e) { int64_t p = cur[major[e]]++; indices[p] = minor[e]; epos[p] = e; }
+  free(cur);
+#pragma omp parallel
+  {
+    mp_t* buf = NULL; size_t cap = 0;
+    int64_t* tmp = NULL;
+#pragma omp for schedule(dynamic, 1024)
+    for (int64_t v = 0; v < nv; ++v) {
+      int64_t lo = offsets[v], n = offsets[v + 1] - lo;
+      if (n < 2) continue;
+      if ((size_t)n > cap) { cap = (size_t)n * 2; buf = (mp_t*)realloc(buf, cap * sizeof(mp_t)); tmp = (int64_t*)realloc(tmp, cap * sizeof(int64_t)); }
+      for (int64_t k = 0; k < n; ++k) { buf[k].minor = indices[lo + k]; buf[k].pos = (int32_t)k; }
+      qsort(buf, (size_t)n, sizeof(mp_t), cmp_mp);
+      for (int64_t k = 0; k < n; ++k) tmp[k] = epos[lo + buf[k].pos];
+      for (int64_t k = 0; k < n; ++k) { indices[lo + k] = buf[k].minor; epos[lo + k] = tmp[k]; }
+    }
+    free(buf); free(tmp);
+  }
+  if (weights && out_w) {
+    if (wsize == 4) { const float* w = (const float*)weights; float* o = (float*)out_w; for (int64_t p = 0; p < ne; ++p) o[p] = w[epos[p]]; }
+    else            { const double* w = (const double*)weights; double* o = (double*)out_w; for (int64_t p = 0; p < ne; ++p) o[p] = w[epos[p]]; }
+  }
+  free(epos);
+  (void)cmp_pair_f; (void)cmp_i32;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * PageRank.  Loop order of detail::pagerank, cpp/src/link_analysis/pagerank_impl.cuh:224-327:
+ *   old <- pr; dangling <- sum_{outw==0} pr; pr <- pr/(outw==0?1:outw);
+ *   pr[dst] <- unvarying + sum_in src_val*[w*]alpha (:261-287, e_op :268-283 applies alpha per edge);
+ *   personalization scatter-add (:289-309); diff <- sum |pr-old| (:311-318); ++iter;
+ *   if diff<eps break; else if iter>=max_iter break (:320-326); converged = iter<max_iter (:329).
+ * Initial vector 1/V (:422-426); a supplied initial guess is NOT renormalised by the tuple overload
+ * the C API uses (:427-432).  out-weight sums: :180-198 (degree cast to weight_t when unweighted).
+ * Same maths as the test reference pagerank_reference (cpp/tests/link_analysis/pagerank_test.cpp:33-121),
+ * which divides w/out_w per edge (:97) and normalises the initial guess (:48-56).
+ *
+ * The graph is CSC (row = destination, indices = sources).  acc64 != 0 accumulates every sum in
+ * double (the "truth" the fp32 GPU result is compared with); acc64 == 0 accumulates in WT
+ * sequentially, bit-faithful to the reference's CPU test function.
+ * ---------------------------------------------------------------------------------------------- */
+#define ORC_PAGERANK(NAME, WT)                                                                        \
+  int NAME(int64_t nv, const int64_t* offsets, const int32_t* indices, const WT* weights,            \
+           const WT* precomputed_outw, int64_t n_pers, const int32_t* pers_v, const WT* pers_val,     \
+           int has_initial_guess, double alpha_d, double epsilon_d, int64_t max_iter, int acc64,      \
+           WT* pr, int64_t* iters_out)                                                                \
+  {                                                                                                   \
+    if (nv == 0) { *iters_out = 0; return 1; }                                                        \
+    const WT alpha = (WT)alpha_d, epsilon = (WT)epsilon_d;                                            \
+    if (!has_initial_guess)                                                                           \
+      for (int64_t i = 0; i < nv; ++i) pr[i] = (WT)1.0 / (WT)nv;                                      \
+    WT* outw = (WT*)calloc((size_t)nv, sizeof(WT));                                                   \
+    if (precomputed_outw) memcpy(outw, precomputed_outw, sizeof(WT) * (size_t)nv);                    \
+    else if (weights) {                                                                               \
+      double* t = (double*)calloc((size_t)nv, sizeof(double));                                        \
+      for (int64_t e = 0; e < offsets[nv]; ++e) { if (acc64) t[indices[e]] += (double)weights[e]; else outw[indices[e]] += weights[e]; } \
+      if (acc64) for (int64_t i = 0; i < nv; ++i) outw[i] = (WT)t[i];                                 \
+      free(t);                                                                                        \
+    } else {                                                                                          \
+      int64_t* deg = (int64_t*)calloc((size_t)nv, sizeof(int64_t));                                   \
+      for (int64_t e = 0; e < offsets[nv]; ++e) deg[indices[e]]++;                                    \
+      for (int64_t i = 0; i < nv; ++i) outw[i] = (WT)deg[i];                                          \
+      free(deg);                                                                                      \
+    }                                                                                                 \
+    WT pers_sum = 0;                                                                                  \
+    if (n_pers > 0) { double s = 0; WT sf = 0; for (int64_t i = 0; i < n_pers; ++i) { s += (double)pers_val[i]; sf += pers_val[i]; } pers_sum = acc64 ? (WT)s : sf; } \
+    WT* old = (WT*)malloc(sizeof(WT) * (size_t)nv);                                                   \
+    WT* x   = (WT*)malloc(sizeof(WT) * (size_t)nv);                                                   \
+    int64_t iter = 0;                                                                                 \
+    for (;;) {                                                                                        \
+      memcpy(old, pr, sizeof(WT) * (size_t)nv);                                                       \
+      WT dangling;                                                                                    \
+      { double s = 0; WT sf = 0;                                                                      \
+        for (int64_t i = 0; i < nv; ++i) if (outw[i] == (WT)0) { s += (double)pr[i]; sf += pr[i]; }   \
+        dangling = acc64 ? (WT)s : sf; }                                                              \
+      for (int64_t i = 0; i < nv; ++i) x[i] = pr[i] / (outw[i] == (WT)0 ? (WT)1 : outw[i]);           \
+      WT unvarying = n_pers == 0 ? (dangling * alpha + (WT)(1.0 - alpha_d)) / (WT)nv : (WT)0;         \
+      _Pragma("omp parallel for schedule(dynamic, 4096)")                                             \
+      for (int64_t i = 0; i < nv; ++i) {                                                              \
+        if (acc64) {                                                                                  \
+          double s = 0;                                                                               \
+          if (weights) for (int64_t j = offsets[i]; j < offsets[i + 1]; ++j) s += (double)(x[indices[j]] * weights[j] * alpha); \
+          else         for (int64_t j = offsets[i]; j < offsets[i + 1]; ++j) s += (double)(x[indices[j]] * alpha);              \
+          pr[i] = (WT)((double)unvarying + s);                                                        \
+        } else {                                                                                      \
+          WT s = unvarying;                                                                           \
+          if (weights) for (int64_t j = offsets[i]; j < offsets[i + 1]; ++j) s += x[indices[j]] * weights[j] * alpha; \
+          else         for (int64_t j = offsets[i]; j < offsets[i + 1]; ++j) s += x[indices[j]] * alpha;              \
+          pr[i] = s;                                                                                  \
+        }                                                                                             \
+      }                                                                                               \
+      for (int64_t i = 0; i < n_pers; ++i)                                                            \
+        pr[pers_v[i]] += (dangling * alpha + (WT)(1.0 - alpha_d)) * (pers_val[i] / pers_sum);         \
+      WT diff;                                                                                        \
+      { double s = 0; WT sf = 0;                                                                      \
+        for (int64_t i = 0; i < nv; ++i) { WT d = pr[i] - old[i]; d = d < 0 ? -d : d; s += (double)d; sf += d; } \
+        diff = acc64 ? (WT)s : sf; }                                                                  \
+      iter++;                                                                                         \
+      if (diff < epsilon) break; else if (iter >= max_iter) break;                                    \
+    }                                                                                                 \
+    free(old); free(x); free(outw);                                                                   \
+    *iters_out = iter;                                                                                \
+    return iter < max_iter;                                                                           \
+  }
+
+ORC_PAGERANK(orc_pagerank_f32, float)
+ORC_PAGERANK(orc_pagerank_f64, double)
+
+/* ------------------------------------------------------------------------------------------------
+ * BFS.  bfs_reference, cpp/tests/traversal/bfs_test.cpp:32-70, extended to several sources as
+ * detail::bfs allows (cpp/src/traversal/bfs_impl.cuh:270-285: every source gets distance 0).
+ * depth_limit is compared after incrementing (bfs_test.cpp:66, bfs_impl.cuh:867-868).
+ * Unreached: distance INT32_MAX, predecessor -1.  Graph is CSR (row = source vertex).
+ * Predecessors here are the first discoverer in frontier order, like the reference function; the
+ * reference GPU path uses reduce_op::any (bfs_impl.cuh:467) so any valid parent is accepted by its
+ * own tests (bfs_test.cpp:217-233).  orc_bfs_min_pred() gives the canonical minimum-id parent our
+ * HIP path produces deterministically.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_bfs(int64_t nv, const int64_t* offsets, const int32_t* indices, const int32_t* sources,
+             int64_t n_sources, int64_t depth_limit, int32_t* dist, int32_t* pred)
+{
+  for (int64_t i = 0; i < nv; ++i) { dist[i] = INT32_MAX; pred[i] = -1; }
+  int32_t* cur = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nv > 0 ? nv : 1));
+  int32_t* nxt = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nv > 0 ? nv : 1));
+  int64_t ncur = 0, nnxt = 0;
+  for (int64_t i = 0; i < n_sources; ++i)
+    if (dist[sources[i]] != 0) { dist[sources[i]] = 0; cur[ncur++] = sources[i]; }
+  int64_t depth = 0;
+  while (ncur > 0) {
+    nnxt = 0;
+    for (int64_t f = 0; f < ncur; ++f) {
+      int32_t row = cur[f];
+      for (int64_t j = offsets[row]; j < offsets[row + 1]; ++j) {
+        int32_t nbr = indices[j];
+        if (dist[nbr] == INT32_MAX) { dist[nbr] = (int32_t)(depth + 1); pred[nbr] = row; nxt[nnxt++] = nbr; }
+      }
+    }
+    int32_t* t = cur; cur = nxt; nxt = t; ncur = nnxt;
+    ++depth;
+    if (depth >= depth_limit) break;
+  }
+  free(cur); free(nxt);
+}
+
+/* canonical predecessor: min u with dist[u]+1 == dist[v] and (u,v) an edge */
+void orc_bfs_min_pred(int64_t nv, const int64_t* offsets, const int32_t* indices, const int32_t* dist, int32_t* pred)
+{
+  for (int64_t i = 0; i < nv; ++i) pred[i] = -1;
+  for (int64_t u = 0; u < nv; ++u) {
+    if (dist[u] == INT32_MAX) continue;
+    for (int64_t j = offsets[u]; j < offsets[u + 1]; ++j) {
+      int32_t v = indices[j];
+      if (dist[v] != INT32_MAX && dist[v] == dist[u] + 1 && dist[v] != 0 && (pred[v] == -1 || (int32_t)u < pred[v])) pred[v] = (int32_t)u;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * SSSP.  Dijkstra, sssp_reference, cpp/tests/traversal/sssp_test.cpp:33-75: strict relax
+ * new < min(d[nbr], cutoff) (:61-63; GPU path sssp_impl.cuh:58-71), unreached = type max, pred -1.
+ * Binary heap keyed on (distance, vertex) like std::priority_queue<tuple, greater>.
+ * ---------------------------------------------------------------------------------------------- */
+#define ORC_SSSP(NAME, WT, WMAX)                                                                      \
+  void NAME(int64_t nv, const int64_t* offsets, const int32_t* indices, const WT* weights,            \
+            int32_t source, double cutoff_d, WT* dist, int32_t* pred)                                 \
+  {                                                                                                   \
+    typedef struct { WT d; int32_t v; } item;                                                         \
+    WT cutoff = cutoff_d >= (double)WMAX ? WMAX : (WT)cutoff_d;                                       \
+    for (int64_t i = 0; i < nv; ++i) { dist[i] = WMAX; pred[i] = -1; }                                \
+    size_t cap = 1024, n = 0;                                                                         \
+    item* h = (item*)malloc(cap * sizeof(item));                                                      \
+    dist[source] = (WT)0; h[n].d = (WT)0; h[n].v = source; n++;                                       \
+    while (n > 0) {                                                                                   \
+      item top = h[0]; item last = h[--n];                                                            \
+      size_t i = 0;                                                                                   \
+      for (;;) { size_t l = 2 * i + 1, r = l + 1, m = i; item mv = last;                              \
+        if (l < n && (h[l].d < mv.d || (h[l].d == mv.d && h[l].v < mv.v))) { m = l; mv = h[l]; }      \
+        if (r < n && (h[r].d < mv.d || (h[r].d == mv.d && h[r].v < mv.v))) { m = r; mv = h[r]; }      \
+        if (m == i) break; h[i] = h[m]; i = m; }                                                      \
+      if (n > 0) h[i] = last;                                                                         \
+      if (top.d > dist[top.v]) continue;                                                              \
+      for (int64_t j = offsets[top.v]; j < offsets[top.v + 1]; ++j) {                                 \
+        int32_t nbr = indices[j]; WT nd = top.d + weights[j];                                         \
+        WT thr = dist[nbr] < cutoff ? dist[nbr] : cutoff;                                             \
+        if (nd < thr) {                                                                               \
+          dist[nbr] = nd; pred[nbr] = top.v;                                                          \
+          if (n == cap) { cap *= 2; h = (item*)realloc(h, cap * sizeof(item)); }                      \
+          size_t k = n++; item it; it.d = nd; it.v = nbr;                                             \
+          while (k > 0) { size_t p = (k - 1) / 2;                                                     \
+            if (h[p].d < it.d || (h[p].d == it.d && h[p].v <= it.v)) break; h[k] = h[p]; k = p; }     \
+          h[k] = it;                                                                                  \
+        }                                                                                             \
+      }                                                                                               \
+    }                                                                                                 \
+    free(h);                                                                                          \
+  }
+
+ORC_SSSP(orc_sssp_f32, float, FLT_MAX)
+ORC_SSSP(orc_sssp_f64, double, DBL_MAX)
+
+/* canonical predecessor: lexicographic minimum (d[u]+w, u) over in-edges, the reference's
+ * reduce_op::minimum<tuple<distance,pred>> (sssp_impl.cuh:334); source keeps -1. */
+#define ORC_SSSP_MIN_PRED(NAME, WT, WMAX)                                                             \
+  void NAME(int64_t nv, const int64_t* offsets, const int32_t* indices, const WT* weights,            \
+            int32_t source, const WT* dist, int32_t* pred)                                            \
+  {                                                                                                   \
+    for (int64_t i = 0; i < nv; ++i) pred[i] = -1;                                                    \
+    for (int64_t u = 0; u < nv; ++u) {                                                                \
+      if (dist[u] == WMAX) continue;                                                                  \
+      for (int64_t j = offsets[u]; j < offsets[u + 1]; ++j) {                                         \
+        int32_t v = indices[j];                                                                       \
+        if (v == source || dist[v] == WMAX) continue;                                                 \
+        if (dist[u] + weights[j] == dist[v] && (pred[v] == -1 || (int32_t)u < pred[v])) pred[v] = (int32_t)u; \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+ORC_SSSP_MIN_PRED(orc_sssp_min_pred_f32, float, FLT_MAX)
+ORC_SSSP_MIN_PRED(orc_sssp_min_pred_f64, double, DBL_MAX)
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,219 @@
+"""ctypes front-end of the CPU oracle (oracle/oracle.c) and, when built, of the reference's own CPU
+reference functions compiled in place (oracle/_ref/libref.so, recipe oracle/build_ref.sh).
+
+TEST INFRASTRUCTURE ONLY: the product path (cugraph_amd/) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = _HERE / "_build" / "liboracle.so"
+_REF = _HERE / "_ref" / "libref.so"
+
+INT32_MAX = np.iinfo(np.int32).max
+FLT_MAX = np.finfo(np.float32).max
+DBL_MAX = np.finfo(np.float64).max
+
+
+def build(force: bool = False) -> None:
+    """Compile liboracle.so (gcc) and, if /root/reference is present, libref.so."""
+    if force or not _LIB.exists() or _LIB.stat().st_mtime < (_HERE / "oracle.c").stat().st_mtime:
+        subprocess.check_call(["make", "-C", str(_HERE), "-s"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if os.path.isdir(os.environ.get("CUGRAPH_REFERENCE_DIR", "/root/reference")):
+        if force or not _REF.exists():
+            subprocess.check_call(["bash", str(_HERE / "build_ref.sh")], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(str(_LIB))
+        _lib.orc_num_threads.restype = C.c_int
+    return _lib
+
+
+def ref():
+    """The reference's own compiled CPU functions, or None when libref.so was never built."""
+    global _ref
+    if _ref is None and _REF.exists():
+        _ref = C.CDLL(str(_REF))
+    return _ref
+
+
+def num_threads() -> int:
+    return int(lib().orc_num_threads())
+
+
+def _p(a, t=None):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+# ------------------------------------------------------------------------------------------ RMAT
+def rmat(scale: int, num_edges: int, a=0.57, b=0.19, c=0.19, seed=0, first_edge=0):
+    src = np.empty(num_edges, np.int32)
+    dst = np.empty(num_edges, np.int32)
+    lib().orc_rmat(C.c_int(scale), C.c_uint64(first_edge), C.c_uint64(num_edges), C.c_double(a),
+                   C.c_double(b), C.c_double(c), C.c_uint64(seed), _p(src), _p(dst))
+    return src, dst
+
+
+# ------------------------------------------------------------------------------- COO -> CSR/CSC
+def coo_to_cs(nv: int, major, minor, weights=None):
+    """Compressed sparse by `major`, neighbours ascending; returns (offsets int64, indices int32, w)."""
+    major, minor = _i32(major), _i32(minor)
+    ne = major.size
+    offsets = np.empty(nv + 1, np.int64)
+    indices = np.empty(ne, np.int32)
+    out_w = None
+    wsize = 0
+    if weights is not None:
+        weights = np.ascontiguousarray(weights)
+        assert weights.dtype in (np.float32, np.float64)
+        out_w = np.empty(ne, weights.dtype)
+        wsize = weights.dtype.itemsize
+    lib().orc_coo_to_cs(C.c_int64(nv), C.c_int64(ne), _p(major), _p(minor), _p(weights), C.c_int(wsize),
+                        _p(offsets), _p(indices), _p(out_w))
+    return offsets, indices, out_w
+
+
+# -------------------------------------------------------------------------------------- PageRank
+def pagerank(nv, offsets, indices, weights=None, alpha=0.85, epsilon=1e-6, max_iter=100,
+             personalization=None, initial_guess=None, precomputed_outw=None, acc64=True,
+             dtype=np.float32):
+    """CSC input (row = destination).  Returns (pr, iterations, converged)."""
+    dtype = np.dtype(dtype)
+    fn = lib().orc_pagerank_f32 if dtype == np.float32 else lib().orc_pagerank_f64
+    fn.restype = C.c_int
+    offsets, indices = _i64(offsets), _i32(indices)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=dtype)
+    ow = None if precomputed_outw is None else np.ascontiguousarray(precomputed_outw, dtype=dtype)
+    if personalization is not None:
+        pv, pval = _i32(personalization[0]), np.ascontiguousarray(personalization[1], dtype=dtype)
+        n_pers = pv.size
+    else:
+        pv = pval = None
+        n_pers = 0
+    if initial_guess is not None:
+        pr = np.array(initial_guess, dtype=dtype, copy=True)
+    else:
+        pr = np.empty(nv, dtype)
+    iters = C.c_int64(0)
+    conv = fn(C.c_int64(nv), _p(offsets), _p(indices), _p(w), _p(ow), C.c_int64(n_pers), _p(pv), _p(pval),
+              C.c_int(initial_guess is not None), C.c_double(alpha), C.c_double(epsilon),
+              C.c_int64(max_iter), C.c_int(1 if acc64 else 0), _p(pr), C.byref(iters))
+    return pr, int(iters.value), bool(conv)
+
+
+# ------------------------------------------------------------------------------------------- BFS
+def bfs(nv, offsets, indices, sources, depth_limit=INT32_MAX):
+    """CSR input (row = source).  Returns (dist int32, pred int32) with first-discoverer parents."""
+    offsets, indices, sources = _i64(offsets), _i32(indices), _i32(np.atleast_1d(sources))
+    dist = np.empty(nv, np.int32)
+    pred = np.empty(nv, np.int32)
+    lib().orc_bfs(C.c_int64(nv), _p(offsets), _p(indices), _p(sources), C.c_int64(sources.size),
+                  C.c_int64(depth_limit), _p(dist), _p(pred))
+    return dist, pred
+
+
+def bfs_min_pred(nv, offsets, indices, dist):
+    offsets, indices, dist = _i64(offsets), _i32(indices), _i32(dist)
+    pred = np.empty(nv, np.int32)
+    lib().orc_bfs_min_pred(C.c_int64(nv), _p(offsets), _p(indices), _p(dist), _p(pred))
+    return pred
+
+
+# ------------------------------------------------------------------------------------------ SSSP
+def sssp(nv, offsets, indices, weights, source, cutoff=np.inf):
+    weights = np.ascontiguousarray(weights)
+    dt = weights.dtype
+    fn = lib().orc_sssp_f32 if dt == np.float32 else lib().orc_sssp_f64
+    offsets, indices = _i64(offsets), _i32(indices)
+    dist = np.empty(nv, dt)
+    pred = np.empty(nv, np.int32)
+    cut = float(cutoff) if np.isfinite(cutoff) else float(DBL_MAX)
+    fn(C.c_int64(nv), _p(offsets), _p(indices), _p(weights), C.c_int32(int(source)), C.c_double(cut),
+       _p(dist), _p(pred))
+    return dist, pred
+
+
+def sssp_min_pred(nv, offsets, indices, weights, source, dist):
+    weights = np.ascontiguousarray(weights)
+    dt = weights.dtype
+    fn = lib().orc_sssp_min_pred_f32 if dt == np.float32 else lib().orc_sssp_min_pred_f64
+    offsets, indices = _i64(offsets), _i32(indices)
+    dist = np.ascontiguousarray(dist, dtype=dt)
+    pred = np.empty(nv, np.int32)
+    fn(C.c_int64(nv), _p(offsets), _p(indices), _p(weights), C.c_int32(int(source)), _p(dist), _p(pred))
+    return pred
+
+
+# --------------------------------------------------- the reference's own functions (oracle/_ref)
+def ref_pagerank(nv, offsets, indices, weights=None, alpha=0.85, epsilon=1e-6, max_iter=100,
+                 personalization=None, initial_guess=None, dtype=np.float32):
+    """pagerank_reference (cpp/tests/link_analysis/pagerank_test.cpp:33-121) itself."""
+    r = ref()
+    assert r is not None, "oracle/_ref/libref.so not built"
+    dtype = np.dtype(dtype)
+    f32 = dtype == np.float32
+    fn = r.ref_pagerank_f32 if f32 else r.ref_pagerank_f64
+    fl = C.c_float if f32 else C.c_double
+    offsets, indices = _i64(offsets), _i32(indices)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=dtype)
+    if personalization is not None:
+        pv, pval = _i32(personalization[0]), np.ascontiguousarray(personalization[1], dtype=dtype)
+        n_pers = pv.size
+    else:
+        pv = pval = None
+        n_pers = 0
+    pr = np.array(initial_guess, dtype=dtype, copy=True) if initial_guess is not None else np.zeros(nv, dtype)
+    failed = fn(C.c_int64(nv), _p(offsets), _p(indices), _p(w), C.c_int64(n_pers), _p(pv), _p(pval), _p(pr),
+                fl(alpha), fl(epsilon), C.c_int64(max_iter), C.c_int(initial_guess is not None))
+    return pr, bool(failed)
+
+
+def ref_bfs(nv, offsets, indices, source, depth_limit=INT32_MAX):
+    r = ref()
+    assert r is not None
+    offsets, indices = _i64(offsets), _i32(indices)
+    dist = np.empty(nv, np.int32)
+    pred = np.empty(nv, np.int32)
+    r.ref_bfs(C.c_int64(nv), _p(offsets), _p(indices), _p(dist), _p(pred), C.c_int32(int(source)),
+              C.c_int32(int(depth_limit)))
+    return dist, pred
+
+
+def ref_sssp(nv, offsets, indices, weights, source, cutoff=None):
+    r = ref()
+    assert r is not None
+    weights = np.ascontiguousarray(weights)
+    dt = weights.dtype
+    f32 = dt == np.float32
+    fn = r.ref_sssp_f32 if f32 else r.ref_sssp_f64
+    fl = C.c_float if f32 else C.c_double
+    offsets, indices = _i64(offsets), _i32(indices)
+    dist = np.empty(nv, dt)
+    pred = np.empty(nv, np.int32)
+    cut = (FLT_MAX if f32 else DBL_MAX) if cutoff is None else cutoff
+    fn(C.c_int64(nv), _p(offsets), _p(indices), _p(weights), _p(dist), _p(pred), C.c_int32(int(source)), fl(cut))
+    return dist, pred
