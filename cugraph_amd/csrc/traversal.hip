@@ -146,7 +146,8 @@ __device__ __forceinline__ void expand_big(int32_t const* bigq, int32_t const* o
 // --------------------------------------------------------------------------------------------- BFS
 struct bfs_state {
   int32_t* dist;
-  uint32_t* pred;              // unsigned so that -1 is the atomicMin identity; nullptr when not requested
+  int32_t* pred;               // EXTERNAL id of the parent, INT32_MAX = none yet (fixed up to -1 at the end); nullptr when not requested
+  int32_t const* labels;       // internal -> external id (number_map); nullptr = identity
   uint32_t const* vis_prev;    // visited as of the start of the level
   uint32_t* vis_new;           // cumulative
   int32_t* q_next;
@@ -164,7 +165,7 @@ struct bfs_visit {
       uint32_t old = atomicOr(&s.vis_new[v >> 5], bit);
       fresh        = !(old & bit);
       if (fresh) s.dist[v] = s.next_depth;
-      if (s.pred) atomicMin(&s.pred[v], (uint32_t)u);
+      if (s.pred) atomicMin(&s.pred[v], s.labels ? s.labels[u] : u);  // minimum EXTERNAL parent id: independent of the internal numbering
     }
     wave_push(fresh, v, s.q_next, &s.cnt->n_next, threadIdx.x & 63);
   }
@@ -294,17 +295,18 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split(int32_t const* far_in, 
   }
 }
 
-// canonical parents: pred[v] = min u with d[u] + w(u,v) == d[v]
+// canonical parents: pred[v] = min EXTERNAL id u with d[u] + w(u,v) == d[v]
 template <typename WT>
 struct sssp_parent {
   typename dist_bits<WT>::type const* dist;
   WT const* weights;
-  uint32_t* pred;
+  int32_t* pred;  // INT32_MAX = none
+  int32_t const* labels;
   int32_t source;
   __device__ __forceinline__ void operator()(int32_t u, int32_t v, int32_t p) const
   {
     using B = dist_bits<WT>;
-    if (v != source && B::to(B::from(dist[u]) + weights[p]) == dist[v]) atomicMin(&pred[v], (uint32_t)u);
+    if (v != source && B::to(B::from(dist[u]) + weights[p]) == dist[v]) atomicMin(&pred[v], labels ? labels[u] : u);
   }
 };
 template <typename WT>
@@ -335,6 +337,14 @@ __global__ void k_sum_weights(WT const* w, int64_t n, double* out)
   for (; i < n; i += stride) s += (double)w[i];
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+__global__ void k_fix_pred(int32_t* pred, int64_t n)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride)
+    if (pred[i] == INT32_MAX) pred[i] = -1;  // invalid_vertex_id
 }
 
 template <typename T>
@@ -402,7 +412,8 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   dvec<int32_t> qa(n1), qb(n1), bigq(n1);
   dvec<counters_t> cnt(1);
   fill_i32(h, dist->buf.as<int32_t>(), nv, INT32_MAX);
-  if (compute_predecessors) fill_i32(h, preds->buf.as<int32_t>(), nv, -1);
+  if (compute_predecessors) fill_i32(h, preds->buf.as<int32_t>(), nv, INT32_MAX);
+  int32_t const* labels = g.renumbered ? g.number_map.data() : nullptr;
   HIP_TRY(hipMemsetAsync(vis_prev.data(), 0, nwords * 4, h.stream));
   HIP_TRY(hipMemsetAsync(vis_new.data(), 0, nwords * 4, h.stream));
   HIP_TRY(hipMemsetAsync(cnt.data(), 0, sizeof(counters_t), h.stream));
@@ -419,7 +430,7 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   uint64_t const limit = depth_limit > (size_t)INT32_MAX ? (uint64_t)INT32_MAX : (uint64_t)depth_limit;
   while (n_cur > 0) {
     HIP_TRY(hipMemsetAsync(cnt.data(), 0, sizeof(counters_t), h.stream));
-    bfs_state s{dist->buf.as<int32_t>(), compute_predecessors ? preds->buf.as<uint32_t>() : nullptr, vis_prev.data(), vis_new.data(), q_nxt,
+    bfs_state s{dist->buf.as<int32_t>(), compute_predecessors ? preds->buf.as<int32_t>() : nullptr, labels, vis_prev.data(), vis_new.data(), q_nxt,
                 cnt.data(), (int32_t)(depth + 1)};
     {
       timed_launch t(h, "bfs_expand");
@@ -445,7 +456,8 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   h.read_back(&nreached, reached.data(), 1);
   h.last_stats = cugraph_amd_traversal_stats_t{levels, edges, nreached, edges};
   if (nv > 0) HIP_TRY(hipMemcpyAsync(ids->buf.ptr, g.number_map.data(), nv * 4, hipMemcpyDeviceToDevice, h.stream));
-  if (compute_predecessors) unrenumber_int_to_ext(h, g, preds->buf.as<int32_t>(), nv);  // bfs.cpp:131-138
+  if (compute_predecessors && nv > 0)  // parents already carry external ids (bfs.cpp:131-138 unrenumbers afterwards instead)
+    hipLaunchKernelGGL(k_fix_pred, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, preds->buf.as<int32_t>(), nv);
   h.sync();
   return new paths_result_t{ids.release(), dist.release(), preds.release()};
 }
@@ -573,9 +585,9 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   }
 
   if (compute_predecessors) {
-    fill_i32(h, preds->buf.as<int32_t>(), nv, -1);
+    fill_i32(h, preds->buf.as<int32_t>(), nv, INT32_MAX);
     HIP_TRY(hipMemsetAsync(cnt.data(), 0, sizeof(counters_t), h.stream));
-    sssp_parent<WT> f{(bits_t const*)d, w, preds->buf.as<uint32_t>(), source};
+    sssp_parent<WT> f{(bits_t const*)d, w, preds->buf.as<int32_t>(), g.renumbered ? g.number_map.data() : nullptr, source};
     keep_reached<WT> keep{(bits_t const*)d, unreached_bits};
     if (nv > 0) {
       hipLaunchKernelGGL(k_sssp_parents<WT>, expand_grid(h, nv), TV_BLOCK, 0, h.stream, nv, (int32_t const*)o.offsets.data(),
@@ -583,8 +595,8 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
       hipLaunchKernelGGL(k_sssp_parents_big<WT>, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
                          (int32_t const*)o.indices.data(), cnt.data(), f);
     }
+    if (nv > 0) hipLaunchKernelGGL(k_fix_pred, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, preds->buf.as<int32_t>(), nv);
     h.read_back(&c, cnt.data(), 1);
-    unrenumber_int_to_ext(h, g, preds->buf.as<int32_t>(), nv);
   }
   dvec<unsigned long long> reached(1);
   HIP_TRY(hipMemsetAsync(reached.data(), 0, 8, h.stream));

@@ -1,0 +1,353 @@
+"""GPU parity tests: the HIP path, called through the C ABI (cugraph_amd.pylib -> libcugraph_c.so), against
+  * the reference's golden vectors (tests/golden/golden.json),
+  * the CPU oracle (oracle/) on the same seeded RMAT edge lists,
+  * size-independent properties at larger sizes.
+Tolerances: BFS / SSSP distances and parents bit-exact; PageRank |a-b| <= 1e-6 absolute (north_star) AND
+<= 2e-5 relative to the fp64-accumulating oracle at a fixed iteration count (the reference's own tolerance is
+1e-3 relative, cpp/tests/link_analysis/pagerank_test.cpp:328-334)."""
+import numpy as np
+import pytest
+
+from conftest import int_weights, rmat_graph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cg():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import cugraph_amd
+
+    return cugraph_amd
+
+
+@pytest.fixture(scope="module")
+def handle(cg):
+    return cg.ResourceHandle()
+
+
+def T(a, dtype=None):
+    import torch
+
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=dtype), device="cuda")
+
+
+def make_graph(cg, handle, src, dst, wgt=None, transposed=False, renumber=False, symmetric=False, vertices=None, wdtype=np.float32):
+    props = cg.GraphProperties(is_symmetric=symmetric, is_multigraph=True)
+    return cg.SGGraph(handle, props, T(src, np.int32), T(dst, np.int32), None if wgt is None else T(wgt, wdtype),
+                      store_transposed=transposed, renumber=renumber, vertices_array=None if vertices is None else T(vertices, np.int32))
+
+
+def by_vertex(verts, *cols):
+    """results come in internal order with the external id column: scatter back to external order"""
+    v = verts.cpu().numpy()
+    out = []
+    for c in cols:
+        c = c.cpu().numpy()
+        if c.size == 0:
+            out.append(c)
+            continue
+        r = np.empty_like(c)
+        r[v] = c
+        out.append(r)
+    return out
+
+
+def nearly_equal(a, b, eps):
+    return abs(a - b) <= max(abs(a), abs(b)) * eps
+
+
+# ------------------------------------------------------------------------------ reference goldens
+def test_capi_pagerank_goldens(cg, handle, golden):
+    for case in golden["c_api"]["pagerank"]:
+        gr = case["graph"]
+        for renumber in (False, True):
+            g = make_graph(cg, handle, gr["src"], gr["dst"], gr["wgt"], transposed=case["store_transposed"], renumber=renumber)
+            v, pr, conv = cg.pagerank(handle, g, None, None, None, None, case["alpha"], case["epsilon"], case["max_iterations"], False,
+                                      fail_on_nonconvergence=False)
+            assert conv == case["converged"], case["name"]
+            (pr,) = by_vertex(v, pr)
+            for a, b in zip(pr, case["result"]):
+                assert nearly_equal(float(a), b, golden["c_api"]["tolerance"]), (case["name"], pr)
+            if not case["converged"]:
+                with pytest.raises(cg.FailedToConvergeError):
+                    cg.pagerank(handle, g, None, None, None, None, case["alpha"], case["epsilon"], case["max_iterations"], False)
+
+
+def test_capi_personalized_goldens(cg, handle, golden):
+    for case in golden["c_api"]["personalized_pagerank"]:
+        gr = case["graph"]
+        g = make_graph(cg, handle, gr["src"], gr["dst"], gr["wgt"], transposed=case["store_transposed"])
+        v, pr, conv = cg.personalized_pagerank(handle, g, None, None, None, None, T(case["pers_vertices"], np.int32),
+                                               T(case["pers_values"], np.float32), case["alpha"], case["epsilon"],
+                                               case["max_iterations"], False, fail_on_nonconvergence=False)
+        assert conv == case["converged"]
+        (pr,) = by_vertex(v, pr)
+        for a, b in zip(pr, case["result"]):
+            assert nearly_equal(float(a), b, golden["c_api"]["tolerance"]), (case["name"], pr)
+
+
+def test_pylibcugraph_pagerank_goldens(cg, handle, golden):
+    p = golden["pylibcugraph_pagerank"]["params"]
+    for name in ("karate.csv", "dolphins.csv", "Simple_1", "Simple_2"):
+        gr = golden["graphs"][name]
+        g = make_graph(cg, handle, gr["src"], gr["dst"], gr["wgt"], transposed=True)  # conftest.py: renumber=False
+        v, pr = cg.pagerank(handle, g, None, None, None, None, p["alpha"], p["epsilon"], p["max_iterations"], False)
+        exp = golden["pylibcugraph_pagerank"][name]
+        assert v.cpu().numpy().tolist() == exp["vertex"]  # renumber=False: identity numbering
+        np.testing.assert_allclose(pr.cpu().numpy(), np.array(exp["pagerank"]), rtol=p["rel_tol"], atol=5e-7)
+
+
+def test_capi_bfs_goldens(cg, handle, golden):
+    for case in golden["c_api"]["bfs"]:
+        gr = case["graph"]
+        for renumber in (False, True):
+            g = make_graph(cg, handle, gr["src"], gr["dst"], gr["wgt"], transposed=case["store_transposed"], renumber=renumber)
+            d, p, v = cg.bfs(handle, g, T(case["seeds"], np.int32), False, case["depth_limit"], True, False)
+            d, p = by_vertex(v, d, p)
+            assert d.tolist() == case["distances"]
+            assert p.tolist() == case["predecessors"]
+
+
+def test_bfs_exceptions(cg, handle, golden):
+    """bfs_test.c:108-158 test_bfs_exceptions: INT64 seeds on an INT32 graph -> CUGRAPH_INVALID_INPUT."""
+    import ctypes as C
+
+    from cugraph_amd import _capi
+
+    gr = golden["c_api"]["bfs"][0]["graph"]
+    g = make_graph(cg, handle, gr["src"], gr["dst"], gr["wgt"])
+    seeds = T([0], np.int64)
+    l = _capi.lib()
+    view = l.cugraph_type_erased_device_array_view_create(C.c_void_p(seeds.data_ptr()), 1, _capi.INT64)
+    res, err = C.c_void_p(), C.c_void_p()
+    code = l.cugraph_bfs(handle.c_resource_handle_ptr, g.c_graph_ptr, view, 0, 1, 1, 0, C.byref(res), C.byref(err))
+    assert code == _capi.CUGRAPH_INVALID_INPUT
+    assert b"vertex type of graph and sources must match" in l.cugraph_error_message(err)
+    l.cugraph_error_free(err)
+    l.cugraph_type_erased_device_array_view_free(view)
+    with pytest.raises(ValueError):  # bfs.pyx:140-143: source that is not a vertex
+        cg.bfs(handle, g, T([17], np.int32), False, 0, True, False)
+
+
+def test_capi_sssp_goldens(cg, handle, golden):
+    for case in golden["c_api"]["sssp"]:
+        gr = case["graph"]
+        dt = np.dtype(case["dtype"])
+        for renumber in (False, True):
+            g = make_graph(cg, handle, gr["src"], gr["dst"], gr["wgt"], transposed=case["store_transposed"], renumber=renumber, wdtype=dt)
+            v, d, p = cg.sssp(handle, g, case["source"], float(np.finfo(dt).max), True, False)
+            d, p = by_vertex(v, d, p)
+            assert d.dtype == dt
+            for a, b in zip(d, case["distances"]):
+                assert nearly_equal(float(a), b, golden["c_api"]["tolerance"])
+            assert p.tolist() == case["predecessors"]
+
+
+def test_pylibcugraph_sssp_goldens(cg, handle, golden):
+    for name, exp in golden["pylibcugraph_sssp"].items():
+        gr = golden["graphs"][name]
+        g = make_graph(cg, handle, gr["src"], gr["dst"], gr["wgt"])
+        v, d, p = cg.sssp(handle, g, exp["start_vertex"], float(np.finfo(np.float32).max), True, False)
+        assert v.cpu().numpy().tolist() == exp["vertex"]
+        np.testing.assert_allclose(d.cpu().numpy(), np.array(exp["distance"], np.float32), rtol=1e-4)
+        if exp["check_predecessor"]:
+            assert p.cpu().numpy().tolist() == exp["predecessor"]
+
+
+def test_karate_vs_networkx(cg, handle, golden):
+    """BASELINE.json configs[0]: karate.csv PageRank + BFS against NetworkX."""
+    nx = pytest.importorskip("networkx")
+    gr = golden["graphs"]["karate.csv"]
+    G = nx.DiGraph()
+    G.add_weighted_edges_from(zip(gr["src"], gr["dst"], gr["wgt"]))
+    g = make_graph(cg, handle, gr["src"], gr["dst"], gr["wgt"], transposed=True, renumber=True)
+    v, pr = cg.pagerank(handle, g, None, None, None, None, 0.85, 1e-7, 500, False)
+    (pr,) = by_vertex(v, pr)
+    ref = nx.pagerank(G, alpha=0.85, tol=1e-10, max_iter=1000)
+    np.testing.assert_allclose(pr, np.array([ref[i] for i in range(34)]), rtol=1e-4)
+    d, p, v = cg.bfs(handle, g, T([0], np.int32), False, 0, True, False)
+    (d,) = by_vertex(v, d)
+    sp = nx.single_source_shortest_path_length(G, 0)
+    assert d.tolist() == [sp[i] for i in range(34)]
+
+
+# ------------------------------------------------------------------------------ invalid inputs
+def test_graph_creation_errors(cg, handle):
+    props = cg.GraphProperties()
+    with pytest.raises(ValueError, match="src size != dst size"):  # conftest InvalidNumVerts_1
+        cg.SGGraph(handle, props, T([1, 2], np.int32), T([1, 2, 3], np.int32), T([1, 1, 1], np.float32))
+    with pytest.raises(ValueError, match="src size != weights size"):  # conftest InvalidNumWeights_1
+        cg.SGGraph(handle, props, T([0, 1, 2], np.int32), T([1, 2, 3], np.int32), T([1, 1, 1, 1], np.float32))
+    with pytest.raises(TypeError):
+        cg.SGGraph(handle, props, [0, 1], T([1, 2], np.int32))
+    with pytest.raises(ValueError):  # INT64 graphs: unsupported type combination in this build
+        cg.SGGraph(handle, props, T([0, 1], np.int64), T([1, 2], np.int64))
+    with pytest.raises(NotImplementedError):
+        cg.SGGraph(handle, props, T([0, 1], np.int32), T([1, 2], np.int32), drop_self_loops=True)
+    g = cg.SGGraph(handle, props, T([0, 1], np.int32), T([1, 2], np.int32))  # unweighted
+    with pytest.raises(ValueError, match="weighted"):
+        cg.sssp(handle, g, 0, 1e30, True, False)
+    hv = cg.has_vertex(handle, g, T([0, 2, 3, -1], np.int32))
+    assert hv.cpu().numpy().tolist() == [True, True, False, False]
+
+
+def test_empty_and_isolated(cg, handle):
+    props = cg.GraphProperties()
+    # vertices 0..9 given explicitly, edges only among 0..2: isolated vertices keep base rank
+    g = cg.SGGraph(handle, props, T([0, 1], np.int32), T([1, 2], np.int32), T([1, 1], np.float32), store_transposed=True,
+                   vertices_array=T(np.arange(10), np.int32))
+    assert g.num_vertices == 10 and g.num_edges == 2
+    v, pr, conv = cg.pagerank(handle, g, None, None, None, None, 0.85, 1e-8, 200, False, fail_on_nonconvergence=False)
+    pr = pr.cpu().numpy()
+    assert abs(pr.sum() - 1.0) < 1e-5
+    d, p, v = cg.bfs(handle, g, T([0], np.int32), False, 0, True, False)
+    assert d.cpu().numpy().tolist() == [0, 1, 2] + [2147483647] * 7
+    # an edgeless graph
+    g0 = cg.SGGraph(handle, props, T([], np.int32), T([], np.int32), T([], np.float32), store_transposed=True,
+                    vertices_array=T(np.arange(4), np.int32))
+    v, pr, conv = cg.pagerank(handle, g0, None, None, None, None, 0.85, 1e-8, 10, False, fail_on_nonconvergence=False)
+    np.testing.assert_allclose(pr.cpu().numpy(), 0.25, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------ RMAT vs the oracle
+@pytest.mark.parametrize("scale,weighted,renumber,transposed", [
+    (12, False, True, True), (12, True, True, True), (14, False, False, True), (16, False, True, True),
+    (16, True, True, False), (18, False, True, True)])
+def test_pagerank_rmat_vs_oracle(cg, handle, orc, scale, weighted, renumber, transposed):
+    s, d = rmat_graph(orc, scale)
+    nv = 1 << scale
+    w = int_weights(s.size) if weighted else None
+    # the HIP generator must produce the same edge list
+    gs, gd = cg.generate_rmat_edgelist(handle, scale, s.size)
+    assert np.array_equal(gs.cpu().numpy(), s) and np.array_equal(gd.cpu().numpy(), d)
+    g = make_graph(cg, handle, s, d, w, transposed=transposed, renumber=renumber, vertices=np.arange(nv))
+    iters = 20
+    v, pr, conv = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, iters, False, fail_on_nonconvergence=False)
+    assert not conv
+    (pr,) = by_vertex(v, pr)
+    off, idx, ww = orc.coo_to_cs(nv, d, s, w)
+    truth, it, _ = orc.pagerank(nv, off, idx, ww, 0.85, 0.0, iters, acc64=True)
+    assert it == iters
+    assert np.max(np.abs(pr - truth)) <= 1e-6
+    rel = np.max(np.abs(pr - truth) / np.maximum(truth, 1e-30))
+    assert rel <= 2e-5, rel
+    assert abs(float(pr.astype(np.float64).sum()) - 1.0) < 1e-4  # mass conservation (dangling mass redistributed)
+
+
+def test_pagerank_converged_iterations_and_initial_guess(cg, handle, orc):
+    scale = 13
+    s, d = rmat_graph(orc, scale, seed=5)
+    nv = 1 << scale
+    g = make_graph(cg, handle, s, d, None, transposed=True, renumber=True, vertices=np.arange(nv))
+    off, idx, _ = orc.coo_to_cs(nv, d, s)
+    truth, it, conv = orc.pagerank(nv, off, idx, None, 0.85, 1e-5, 500, acc64=True)
+    plan = cg.PageRankPlan(handle, g, 0.85)
+    done, c = plan.step(500, epsilon=1e-5)
+    assert c and abs(done - it) <= 1  # fp32 vs fp64 L1 sums may flip the last comparison
+    # warm start from the converged vector: one iteration suffices, result unchanged (idempotence)
+    v, pr, _ = plan.result(True)
+    v2, pr2, conv2 = cg.pagerank(handle, g, None, None, v, pr, 0.85, 1e-5, 500, False, fail_on_nonconvergence=False)
+    assert conv2
+    np.testing.assert_allclose(pr2.cpu().numpy(), pr.cpu().numpy(), rtol=1e-4)
+    # precomputed out-weight sums = out-degrees give the same answer
+    outdeg = np.bincount(s, minlength=nv).astype(np.float32)
+    v3, pr3, _ = cg.pagerank(handle, g, T(np.arange(nv), np.int32), T(outdeg), None, None, 0.85, 0.0, 10, False, fail_on_nonconvergence=False)
+    v4, pr4, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 10, False, fail_on_nonconvergence=False)
+    assert np.array_equal(by_vertex(v3, pr3)[0], by_vertex(v4, pr4)[0])
+
+
+def test_pagerank_is_deterministic(cg, handle, orc):
+    s, d = rmat_graph(orc, 15)
+    g = make_graph(cg, handle, s, d, None, transposed=True, renumber=True)
+    a = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 10, False, fail_on_nonconvergence=False)[1].cpu().numpy()
+    b = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 10, False, fail_on_nonconvergence=False)[1].cpu().numpy()
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("hot", [0, 1024, 16384, 32768])
+def test_pagerank_lds_tile_sizes_agree(cg, handle, orc, hot):
+    s, d = rmat_graph(orc, 15, seed=2)
+    nv = 1 << 15
+    g = make_graph(cg, handle, s, d, None, transposed=True, renumber=True, vertices=np.arange(nv))
+    prev = handle.set_pagerank_hot_tile(hot)
+    try:
+        v, pr, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 8, False, fail_on_nonconvergence=False)
+    finally:
+        handle.set_pagerank_hot_tile(prev)
+    off, idx, _ = orc.coo_to_cs(nv, d, s)
+    truth, _, _ = orc.pagerank(nv, off, idx, None, 0.85, 0.0, 8, acc64=True)
+    assert np.max(np.abs(by_vertex(v, pr)[0] - truth)) <= 1e-6
+
+
+@pytest.mark.parametrize("scale,renumber,transposed", [(12, False, False), (14, True, False), (16, True, True), (18, True, False)])
+def test_bfs_rmat_vs_oracle(cg, handle, orc, scale, renumber, transposed):
+    s, d = rmat_graph(orc, scale)
+    nv = 1 << scale
+    g = make_graph(cg, handle, s, d, None, transposed=transposed, renumber=renumber, vertices=np.arange(nv))
+    off, idx, _ = orc.coo_to_cs(nv, s, d)
+    outdeg = np.diff(off)
+    srcs = [int(x) for x in np.nonzero(outdeg > 0)[0][[0, 7, 100]]]
+    for src in srcs:
+        dist, pred, v = cg.bfs(handle, g, T([src], np.int32), False, 0, True, False)
+        dist, pred = by_vertex(v, dist, pred)
+        od, _ = orc.bfs(nv, off, idx, [src])
+        assert np.array_equal(dist, od)                                  # distances bit-exact
+        assert np.array_equal(pred, orc.bfs_min_pred(nv, off, idx, od))  # canonical min-id parents bit-exact
+        st = handle.last_traversal_stats()
+        assert st["vertices_reached"] == int((od != orc.INT32_MAX).sum())
+        assert st["edges_inspected"] == int(outdeg[od != orc.INT32_MAX].sum())
+    # depth limit and multi-source
+    dist, pred, v = cg.bfs(handle, g, T(srcs, np.int32), False, 2, False, False)
+    assert pred.numel() == 0
+    (dist,) = by_vertex(v, dist)
+    od, _ = orc.bfs(nv, off, idx, srcs, 2)
+    assert np.array_equal(dist, od)
+
+
+@pytest.mark.parametrize("scale,kind,dtype", [(12, "unit", np.float32), (14, "int", np.float32), (16, "int", np.float32),
+                                              (14, "real", np.float32), (14, "int", np.float64), (18, "unit", np.float32)])
+def test_sssp_rmat_vs_oracle(cg, handle, orc, scale, kind, dtype):
+    s, d = rmat_graph(orc, scale)
+    nv = 1 << scale
+    if kind == "unit":
+        w = np.ones(s.size, dtype)
+    elif kind == "int":
+        w = int_weights(s.size).astype(dtype)
+    else:
+        w = np.random.default_rng(3).random(s.size).astype(dtype) + dtype(0.01)
+    g = make_graph(cg, handle, s, d, w, transposed=False, renumber=True, vertices=np.arange(nv), wdtype=dtype)
+    off, idx, ww = orc.coo_to_cs(nv, s, d, w)
+    src = int(np.nonzero(np.diff(off) > 0)[0][3])
+    v, dist, pred = cg.sssp(handle, g, src, float(np.finfo(dtype).max), True, False)
+    dist, pred = by_vertex(v, dist, pred)
+    od, _ = orc.sssp(nv, off, idx, ww, src)
+    assert np.array_equal(dist, od)  # the fixed point is unique: bit-identical to Dijkstra, any weights
+    assert np.array_equal(pred, orc.sssp_min_pred(nv, off, idx, ww, src, od))
+    if kind == "unit":  # integer hops == BFS distances bit for bit
+        bd, _, bv = cg.bfs(handle, g, T([src], np.int32), False, 0, False, False)
+        (bd,) = by_vertex(bv, bd)
+        reach = bd != orc.INT32_MAX
+        assert np.array_equal(dist[reach], bd[reach].astype(dtype)) and np.all(dist[~reach] == np.finfo(dtype).max)
+    # cutoff
+    cut = float(np.median(od[od < np.finfo(dtype).max]))
+    v, dist, _ = cg.sssp(handle, g, src, cut, False, False)
+    (dist,) = by_vertex(v, dist)
+    oc, _ = orc.sssp(nv, off, idx, ww, src, cutoff=cut)
+    assert np.array_equal(dist, oc)
+
+
+def test_csr_input_and_orientation_flip_share_one_numbering(cg, handle, orc):
+    s, d = rmat_graph(orc, 12, seed=9)
+    nv = 1 << 12
+    off, idx, _ = orc.coo_to_cs(nv, s, d)
+    props = cg.GraphProperties()
+    g = cg.SGGraph(handle, props, T(off, np.int32), T(idx, np.int32), T(np.ones(idx.size), np.float32), store_transposed=False, renumber=True,
+                   input_array_format="CSR")
+    v1, pr, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 5, False, fail_on_nonconvergence=False)  # builds CSC lazily
+    dist, _, v2 = cg.bfs(handle, g, T([0], np.int32), False, 0, False, False)
+    assert np.array_equal(v1.cpu().numpy(), v2.cpu().numpy())  # unlike the reference, no re-numbering on the flip
+    od, _ = orc.bfs(nv, off, idx, [0])
+    assert np.array_equal(by_vertex(v2, dist)[0], od)
