@@ -229,13 +229,17 @@ struct orientation_t {
   dvec<int32_t> indices;    // E (minor ids)
   dev_buf weights;          // E * sizeof(weight) or empty
   dvec<int32_t> row_order;  // V (permutation, degree descending) or empty = identity
-  // seg[k] = number of scheduled rows with degree >= seg_threshold[k]
-  static constexpr int n_seg = 4;
-  int64_t seg[n_seg]{0, 0, 0, 0};
+  // seg[k] = number of scheduled rows with degree >= seg_threshold[k]; seg[4] = number of non-empty rows
+  static constexpr int n_seg = 5;
+  int64_t seg[n_seg]{0, 0, 0, 0, 0};
   int32_t max_degree{0};
+  // bit e set <=> edge position e is the first edge of a row (built lazily; used by the edge-balanced
+  // PageRank kernel, which needs the non-empty rows to be the id prefix [0, seg[4]))
+  dvec<uint32_t> rowstart_bits;
 };
 
-constexpr int32_t kSegThreshold[orientation_t::n_seg] = {4096, 64, 16, 4};
+constexpr int32_t kSegThreshold[orientation_t::n_seg] = {4096, 64, 16, 4, 1};
+constexpr int64_t kEdgePad = 2048;  // indices / weights are over-allocated so 16-byte tail loads stay in bounds
 
 struct graph_t {  // behind cugraph_graph_t (cpp/src/c_api/graph.hpp:61-77)
   cugraph_data_type_id_t vertex_type{INT32};

@@ -34,7 +34,25 @@ __global__ void k_degree_compact(int32_t const* major, int64_t n, int64_t vmin, 
 {
   int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) atomicAdd(&deg[rank[(int64_t)major[i] - vmin]], 1u);
+  int64_t n_pad  = (n + 63) & ~(int64_t)63;
+  int const lane = threadIdx.x & 63;
+  for (; i < n_pad; i += stride) {
+    // hub vertices dominate power-law inputs: lanes holding the same id as the wave's first active lane are
+    // counted with one atomic (repeat until every lane is served; random inputs finish in a few rounds)
+    bool todo  = i < n;
+    uint32_t c = todo ? rank[(int64_t)major[i] - vmin] : 0u;
+    for (int round = 0; round < 4; ++round) {
+      uint64_t m = __ballot(todo);
+      if (!m) break;
+      int leader    = __ffsll((unsigned long long)m) - 1;
+      uint32_t lead = __shfl(c, leader);
+      bool same     = todo && c == lead;
+      uint64_t sm   = __ballot(same);
+      if (lane == leader) atomicAdd(&deg[lead], (uint32_t)__popcll(sm));
+      todo = todo && !same;
+    }
+    if (todo) atomicAdd(&deg[c], 1u);
+  }
 }
 
 __global__ void k_degree_keys(uint32_t const* deg, int64_t n, uint32_t maxdeg, uint64_t* keys, uint32_t* vals)
@@ -108,14 +126,18 @@ __global__ void k_pack_keys(int32_t const* major, int32_t const* minor, int64_t 
   }
 }
 
-__global__ void k_unpack_minor(uint64_t const* keys, int64_t n, int32_t* indices, uint32_t* counts)
+// keys are sorted by (major, minor): indices = minor column; offsets[v] = first position whose major >= v
+// (row boundaries are detected between neighbouring keys -- no atomics, hub rows cost nothing extra)
+__global__ void k_unpack_minor(uint64_t const* keys, int64_t n, int64_t /*nv*/, int32_t* indices, int32_t* offsets)
 {
   int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    uint64_t k = keys[i];
-    indices[i] = (int32_t)(uint32_t)k;
-    atomicAdd(&counts[k >> 32], 1u);
+    uint64_t k  = keys[i];
+    indices[i]  = (int32_t)(uint32_t)k;
+    int64_t maj = (int64_t)(k >> 32);
+    int64_t prv = i > 0 ? (int64_t)(keys[i - 1] >> 32) : -1;
+    for (int64_t v = prv + 1; v <= maj; ++v) offsets[v] = (int32_t)i;  // rows after the last major keep the pre-filled n
   }
 }
 
@@ -132,7 +154,7 @@ __global__ void k_schedule_stats(uint32_t const* deg, int32_t const* order, int6
 {
   int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  unsigned c[orientation_t::n_seg] = {0, 0, 0, 0};
+  unsigned c[orientation_t::n_seg] = {0, 0, 0, 0, 0};
   uint32_t mx = 0;
   bool bad    = false;
   for (; i < nv; i += stride) {
@@ -198,9 +220,9 @@ void build_orientation(handle_t const& h, int64_t nv, int64_t ne, int32_t const*
                        void const* weights, size_t wsize, orientation_t& o)
 {
   o.offsets.resize_discard(nv + 1);
-  o.indices.resize_discard(ne);
-  dvec<uint32_t> counts(nv + 1);
-  HIP_TRY(hipMemsetAsync(counts.data(), 0, (nv + 1) * sizeof(uint32_t), h.stream));
+  o.indices.resize_discard(ne + kEdgePad);
+  HIP_TRY(hipMemsetAsync(o.indices.data() + ne, 0, kEdgePad * sizeof(int32_t), h.stream));
+  fill_i32(h, o.offsets.data(), nv + 1, (int32_t)ne);
   if (ne > 0) {
     dvec<uint64_t> keys(ne), keys_tmp(ne);
     dvec<uint32_t> vals(ne), vals_tmp(ne);
@@ -208,16 +230,16 @@ void build_orientation(handle_t const& h, int64_t nv, int64_t ne, int32_t const*
     int vb = bits_for(nv > 0 ? (uint64_t)(nv - 1) : 0);
     radix_sort_u64_u32(h, keys.data(), vals.data(), keys_tmp.data(), vals_tmp.data(), ne, 0, vb);
     radix_sort_u64_u32(h, keys.data(), vals.data(), keys_tmp.data(), vals_tmp.data(), ne, 32, 32 + vb);
-    hipLaunchKernelGGL(k_unpack_minor, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), ne,
-                       o.indices.data(), counts.data());
+    hipLaunchKernelGGL(k_unpack_minor, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), ne, nv,
+                       o.indices.data(), o.offsets.data());
     if (weights) {
-      o.weights.alloc(ne * wsize);
+      o.weights.alloc((ne + kEdgePad) * wsize);
+      HIP_TRY(hipMemsetAsync(static_cast<char*>(o.weights.ptr) + ne * wsize, 0, kEdgePad * wsize, h.stream));
       if (wsize == 4) gather_b32(h, (uint32_t const*)weights, vals.data(), o.weights.as<uint32_t>(), ne);
       else            gather_b64(h, (uint64_t const*)weights, vals.data(), o.weights.as<uint64_t>(), ne);
     }
     h.sync();  // temporaries die here
   }
-  exclusive_scan_u32(h, counts.data(), reinterpret_cast<uint32_t*>(o.offsets.data()), nv + 1);
 
   // degree-descending row schedule + class boundaries
   dvec<uint32_t> deg(nv > 0 ? nv : 1);

@@ -27,6 +27,8 @@
 // Loop order and stopping rule follow pagerank_impl.cuh:224-329 exactly (see oracle/oracle.c).
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace cga {
 
 namespace {
@@ -193,6 +195,290 @@ __global__ void __launch_bounds__(PR_BLOCK) k_spmv(spmv_args<WT> a)
   }
 }
 
+
+// =================================================================================================
+// Edge-balanced ("flat") SpMV: y[row] = sum_{in-edges} x[src] * [w *] alpha for rows [0, n_nonempty).
+//
+// Every wavefront owns a contiguous range of the CSC edge array (same number of edges for every wave,
+// whatever the degree distribution) and streams it with 16-byte index loads: lane l of a wave reads edges
+// [base + 256 g + 4 l, +4) for g = 0..3, i.e. each load instruction covers 1 KiB of consecutive addresses.
+// Row boundaries come from a bitmap (bit e = "edge e starts a row", 1 bit per edge, 3 % of the index
+// bytes) instead of per-row offset loads, so there is no load -> load dependency per row: the only
+// dependent chain is index -> gather.  Sums are formed by an in-lane pass over the lane's 4 edges and a
+// wave64 segmented scan (shuffles) across lanes; a completed row is stored by the lane that sees the next
+// row start.  The two partial rows at the ends of a wave's range go to side arrays and are stitched by
+// k_flat_fixup in a fixed order, so the result is deterministic (no floating-point atomics).
+// Requires: non-empty rows are exactly ids [0, n_nonempty) in edge order -- true for the degree-sorted
+// numbering.  Other graphs use k_spmv above.
+// =================================================================================================
+
+// ---- wave64 cross-lane helpers on DPP (data-parallel primitives: 1 VALU op per step instead of an LDS-crossbar
+// ds_bpermute plus address arithmetic).  Row = 16 lanes.  Encodings: row_shr:n = 0x110+n, row_bcast:15 = 0x142,
+// row_bcast:31 = 0x143, wave_shr:1 = 0x138 (gfx9 family incl. gfx950).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t src)
+{  // lanes without a valid source (or outside ROW_MASK) read 0 = identity of both operators below
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, ROW_MASK, 0xF, true);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_val(float src) { return __uint_as_float(dpp_u32<CTRL, ROW_MASK>(__float_as_uint(src))); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_val(double src)
+{
+  unsigned long long b = (unsigned long long)__double_as_longlong(src);
+  uint32_t lo = dpp_u32<CTRL, ROW_MASK>((uint32_t)b), hi = dpp_u32<CTRL, ROW_MASK>((uint32_t)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// inclusive segmented scan over the 64 lanes: s = sum of the lane values back to (and including) the nearest lane
+// whose count c is non-zero; c = inclusive sum of counts.  Operator (left (+) right) = (right.c ? right.s : left.s + right.s).
+template <typename WT, int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_step(WT& s, uint32_t& c)
+{
+  WT ts       = dpp_val<CTRL, ROW_MASK>(s);
+  uint32_t tc = dpp_u32<CTRL, ROW_MASK>(c);
+  s           = c == 0 ? s + ts : s;
+  c += tc;
+}
+template <typename WT>
+__device__ __forceinline__ void wave_seg_scan(WT& s, uint32_t& c)
+{
+  seg_step<WT, 0x111, 0xF>(s, c);  // row_shr:1
+  seg_step<WT, 0x112, 0xF>(s, c);  // row_shr:2
+  seg_step<WT, 0x114, 0xF>(s, c);  // row_shr:4
+  seg_step<WT, 0x118, 0xF>(s, c);  // row_shr:8
+  seg_step<WT, 0x142, 0xA>(s, c);  // row_bcast:15 -> rows 1, 3
+  seg_step<WT, 0x143, 0xC>(s, c);  // row_bcast:31 -> rows 2, 3
+}
+template <typename WT>
+__device__ __forceinline__ WT wave_sum_to_lane63(WT s)
+{
+  s += dpp_val<0x111, 0xF>(s);
+  s += dpp_val<0x112, 0xF>(s);
+  s += dpp_val<0x114, 0xF>(s);
+  s += dpp_val<0x118, 0xF>(s);
+  s += dpp_val<0x142, 0xA>(s);
+  s += dpp_val<0x143, 0xC>(s);
+  return s;  // lane 63 holds the wave total
+}
+template <typename WT> __device__ __forceinline__ WT read_lane63(WT v);
+template <> __device__ __forceinline__ float read_lane63<float>(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63)); }
+template <> __device__ __forceinline__ double read_lane63<double>(double v)
+{
+  unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+constexpr int FL_BLOCK = 1024;
+constexpr int FL_WAVES = FL_BLOCK / 64;
+constexpr int FL_SUB   = 256;           // edges per wave per sub-chunk (4 per lane)
+constexpr int FL_UNROLL = 4;
+constexpr int FL_CHUNK = FL_SUB * FL_UNROLL;
+
+template <typename WT>
+struct flat_args {
+  int32_t const* indices;
+  WT const* weights;          // or nullptr
+  uint8_t const* bits;        // row-start bitmap, byte view
+  uint32_t const* wave_rank;  // [n_waves + 1]: number of row starts in [0, wave range start)
+  int64_t ne;
+  int64_t range_len;          // edges per wave, multiple of FL_CHUNK
+  WT const* x;
+  WT* y;                      // [n_nonempty]
+  WT* head_sum;               // [n_waves] partial of the row running at the wave's range start
+  uint8_t* has_flag;          // [n_waves] wave range contains a row start
+  WT alpha;
+  int hot;
+};
+
+template <typename WT, bool WEIGHTED>
+__global__ void __launch_bounds__(FL_BLOCK, (sizeof(WT) == 4 && !WEIGHTED) ? 8 : 4) k_spmv_flat(flat_args<WT> a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  WT* xs        = reinterpret_cast<WT*>(smem);
+  int const tid = threadIdx.x, lane = tid & 63;
+  int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: range bounds live in SGPRs
+  {  // stage the hot tile with 16-byte loads (a.hot is a multiple of 4; x is 16-byte aligned)
+    using vec4 = typename std::conditional<sizeof(WT) == 4, float4, double4>::type;
+    vec4 const* src = reinterpret_cast<vec4 const*>(a.x);
+    vec4* dst       = reinterpret_cast<vec4*>(xs);
+    for (int i = tid; i < a.hot / 4; i += FL_BLOCK) dst[i] = src[i];
+    if (tid == 0 && a.hot == 0) xs[0] = WT(0);
+  }
+  __syncthreads();
+
+  int64_t const w  = (int64_t)blockIdx.x * FL_WAVES + wave;
+  int64_t const es = w * a.range_len;
+  if (es >= a.ne) {
+    if (lane == 0) { a.head_sum[w] = WT(0); a.has_flag[w] = 0; }
+    return;
+  }
+  int64_t const ee = min(es + a.range_len, a.ne);
+  // row closed by the n-th row start met in this range is row (rank - 1 + n); n = 0 is the partial head
+  int64_t const row0 = (int64_t)a.wave_rank[w] - 1;
+  int32_t const hot_last = a.hot > 0 ? a.hot - 1 : 0;
+  char const* const xbytes = reinterpret_cast<char const*>(a.x);
+  uint32_t closed = 0;  // row starts met so far (wave-uniform)
+  WT carry        = 0;  // running sum of the row open at the current position (wave-uniform)
+
+  for (int64_t base = es; base < ee; base += FL_CHUNK) {
+    int4 id[FL_UNROLL];
+    uint32_t fl[FL_UNROLL];
+    WT v[FL_UNROLL][4];
+    // indices / bitmap / weights are over-allocated by kEdgePad (zero filled), so every load below is in bounds
+    // and UNCONDITIONAL: all four 1 KiB index loads and the bitmap bytes are in flight together.
+#pragma unroll
+    for (int g = 0; g < FL_UNROLL; ++g) {
+      int64_t e = base + g * FL_SUB + 4 * lane;
+      id[g]     = *reinterpret_cast<int4 const*>(a.indices + e);
+      fl[g]     = ((uint32_t)a.bits[e >> 3] >> (e & 4)) & 0xFu;
+    }
+#pragma unroll
+    for (int g = 0; g < FL_UNROLL; ++g) {
+      int64_t e    = base + g * FL_SUB + 4 * lane;
+      int32_t i[4] = {id[g].x, id[g].y, id[g].z, id[g].w};
+      WT cold[4], hotv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // cold sources: exec-masked global gather (no flat loads, no waits inside)
+        cold[k] = WT(0);
+        // 32-bit byte offset from a wave-uniform base: one VGPR per address (SGPR base + VGPR offset form)
+        if (i[k] >= a.hot) cold[k] = *reinterpret_cast<WT const*>(xbytes + (uint32_t)i[k] * (uint32_t)sizeof(WT));
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hotv[k] = xs[min(i[k], hot_last)];  // LDS read with a clamped (always valid) index
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        WT t = i[k] < a.hot ? hotv[k] : cold[k];
+        if constexpr (WEIGHTED) t *= a.weights[e + k];
+        v[g][k] = (e + k < ee) ? t * a.alpha : WT(0);
+      }
+      if (e + 3 >= ee) {  // bits past the range end belong to the next wave
+        uint32_t keep = e >= ee ? 0u : (1u << (ee - e)) - 1u;
+        fl[g] &= keep;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < FL_UNROLL; ++g) {
+      uint32_t const f = fl[g];
+      if (__ballot(f != 0) == 0) {  // no row starts in these 256 edges (inside a long row): plain wave sum
+        WT t = wave_sum_to_lane63((v[g][0] + v[g][1]) + (v[g][2] + v[g][3]));
+        carry += read_lane63(t);
+        continue;
+      }
+      // in-lane: r_k = running sum since the last row start at or before element k
+      WT const r0 = v[g][0];
+      WT const r1 = (f & 2u) ? v[g][1] : r0 + v[g][1];
+      WT const r2 = (f & 4u) ? v[g][2] : r1 + v[g][2];
+      WT const r3 = (f & 8u) ? v[g][3] : r2 + v[g][3];
+      // wave64 segmented scan of (tail = r3, number of row starts in the lane)
+      uint32_t const nf = __popc(f);
+      WT s       = r3;
+      uint32_t c = nf;
+      wave_seg_scan(s, c);
+      WT ex_s         = dpp_val<0x138, 0xF>(s);   // wave_shr:1 (lane 0 reads 0)
+      uint32_t ex_c   = dpp_u32<0x138, 0xF>(c);
+      WT const carry_in = ex_c ? ex_s : ex_s + carry;
+      if (f) {  // emit the rows that end inside this lane: the row closed by a start at element k ran up to element k-1
+        uint32_t ord = closed + ex_c;  // ordinal of this lane's first row start within the wave's range
+        WT before[4] = {WT(0), r0, r1, r2};
+        bool first   = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if ((f >> k) & 1u) {
+            WT total = first ? carry_in + before[k] : before[k];
+            first    = false;
+            if (ord == 0) a.head_sum[w] = total;  // the row running at the range start: partial
+            else a.y[row0 + ord] = total;
+            ++ord;
+          }
+        }
+      }
+      uint32_t const c_last = (uint32_t)__builtin_amdgcn_readlane((int)c, 63);
+      WT const s_last       = read_lane63(s);
+      carry                 = c_last ? s_last : s_last + carry;
+      closed += c_last;
+    }
+  }
+  if (lane == 0) {
+    if (closed == 0) { a.head_sum[w] = carry; a.has_flag[w] = 0; }
+    else { a.y[row0 + closed] = carry; a.has_flag[w] = 1; }  // row opened here (may continue in later waves)
+  }
+}
+
+// Adds to the row left open at the end of wave w's range the heads of the following waves.
+template <typename WT>
+__global__ void k_flat_fixup(uint32_t const* wave_rank, WT const* head_sum, uint8_t const* has_flag, int64_t n_waves, WT* y)
+{
+  int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (w >= n_waves || !has_flag[w]) return;
+  WT acc = 0;
+  bool any = false;
+  for (int64_t k = w + 1; k < n_waves; ++k) {
+    acc += head_sum[k];
+    any = true;
+    if (has_flag[k]) break;
+  }
+  if (any) y[(int64_t)wave_rank[w + 1] - 1] += acc;
+}
+
+// wave_rank[w] = number of rows whose first edge lies before w * range_len (rows [0, n_nonempty) are non-empty,
+// so offsets is strictly increasing there)
+__global__ void k_wave_ranks(int32_t const* offsets, int64_t n_nonempty, int64_t range_len, int64_t n_waves, uint32_t* wave_rank)
+{
+  int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (w > n_waves) return;
+  int64_t es = w * range_len;
+  int64_t lo = 0, hi = n_nonempty;  // first row with offsets[row] >= es
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)offsets[mid] < es) lo = mid + 1; else hi = mid;
+  }
+  wave_rank[w] = (uint32_t)lo;
+}
+
+__global__ void k_rowstart_bits(int32_t const* offsets, int64_t n_nonempty, uint32_t* bits)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n_nonempty; i += stride) {
+    uint32_t e = (uint32_t)offsets[i];
+    atomicOr(&bits[e >> 5], 1u << (e & 31));
+  }
+}
+
+// V-length epilogue of the flat path: pr <- base + y (+ personalization), x' <- pr / out_w, L1 change and
+// dangling mass partials (same arithmetic as row_epilogue above).
+template <typename WT, bool PERS>
+__global__ void __launch_bounds__(256) k_pr_epilogue(WT const* y, int64_t n_nonempty, int64_t nv, WT* pr, WT* x_next, WT const* outw,
+                                                     WT const* pers, pr_scalars<WT> const* scal, double* partials)
+{
+  __shared__ double red[8];
+  pr_scalars<WT> const sc = *scal;
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double diff = 0.0, dang = 0.0;
+  for (; i < nv; i += stride) {
+    WT sum = i < n_nonempty ? y[i] : WT(0);
+    WT val = sc.base + sum;
+    if constexpr (PERS) val += sc.pers_factor * pers[i];
+    WT old = pr[i], ow = outw[i];
+    pr[i]     = val;
+    x_next[i] = val / (ow == WT(0) ? WT(1) : ow);
+    diff += (double)fabs(val - old);
+    if (ow == WT(0)) dang += (double)val;
+  }
+  diff = group_sum(diff, 64);
+  dang = group_sum(dang, 64);
+  int const wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[2 * wv] = diff; red[2 * wv + 1] = dang; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x]     = red[0] + red[2] + red[4] + red[6];
+    partials[2 * blockIdx.x + 1] = red[1] + red[3] + red[5] + red[7];
+  }
+}
+
 // x = pr / (outw == 0 ? 1 : outw); partial dangling sums (iteration 0 state)
 template <typename WT>
 __global__ void __launch_bounds__(256) k_prologue(WT const* pr, WT const* outw, WT* x, int64_t nv, double* partials)
@@ -331,6 +617,14 @@ struct pagerank_plan : pagerank_plan_base {
   int hot{0};
   size_t lds_bytes{0};
   int cur{0};
+  // edge-balanced path
+  bool flat{false};
+  dvec<WT> yv, head_sum;
+  dvec<uint8_t> has_flag;
+  dvec<uint32_t> wave_rank;
+  int64_t range_len{0}, n_waves{0};
+  int flat_grid{0}, epi_grid{0};
+  size_t flat_lds{0};
 
   pagerank_plan(handle_t const& h_, graph_t& g_, double alpha_) : h(h_), g(g_), alpha((WT)alpha_) {}
 
@@ -384,6 +678,78 @@ struct pagerank_plan : pagerank_plan_base {
     outw = g.out_weight_sums.as<WT const>();
   }
 
+  // The edge-balanced kernel applies when ids are degree-sorted (non-empty rows = id prefix in edge order).
+  void setup_flat()
+  {
+    orientation_t& o = g.csc;
+    char const* env  = getenv("CUGRAPH_AMD_PAGERANK_KERNEL");  // "rows" forces the row-classed kernel (testing / profiling)
+    flat = o.row_order.size() == 0 && g.ne > 0 && !(env && std::string(env) == "rows");
+    if (!flat) return;
+    int64_t const nnz_rows = o.seg[4];
+    if (o.rowstart_bits.size() == 0) {
+      size_t words = (size_t)((g.ne + kEdgePad) / 32 + 2);
+      o.rowstart_bits.resize_discard(words);
+      HIP_TRY(hipMemsetAsync(o.rowstart_bits.data(), 0, words * 4, h.stream));
+      hipLaunchKernelGGL(k_rowstart_bits, grid_for(nnz_rows, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)o.offsets.data(), nnz_rows,
+                         o.rowstart_bits.data());
+    }
+    flat_lds      = (size_t)std::max(hot, 4) * sizeof(WT);
+    // fp32 unweighted fits 64 VGPRs (2 workgroups of 16 waves per CU); the other variants get 128 VGPRs, 1 per CU
+    int per_cu    = (flat_lds <= 80 * 1024 && sizeof(WT) == 4 && !g.has_weights) ? 2 : 1;
+    flat_grid     = h.num_cus * per_cu;
+    int64_t waves = (int64_t)flat_grid * FL_WAVES;
+    range_len     = ((g.ne + waves - 1) / waves + FL_CHUNK - 1) / FL_CHUNK * FL_CHUNK;
+    n_waves       = (g.ne + range_len - 1) / range_len;
+    flat_grid     = (int)((n_waves + FL_WAVES - 1) / FL_WAVES);
+    n_waves       = (int64_t)flat_grid * FL_WAVES;  // trailing waves own an empty range
+    yv.resize_discard((size_t)nnz_rows + 1);
+    head_sum.resize_discard((size_t)n_waves);
+    has_flag.resize_discard((size_t)n_waves);
+    wave_rank.resize_discard((size_t)n_waves + 1);
+    hipLaunchKernelGGL(k_wave_ranks, grid_for(n_waves + 1, kBlock), kBlock, 0, h.stream, (int32_t const*)o.offsets.data(), nnz_rows, range_len, n_waves,
+                       wave_rank.data());
+    epi_grid = std::min(grid_for(g.nv, 256, 2048), 2048);
+    h.sync();
+  }
+
+  template <bool WEIGHTED>
+  void launch_flat(WT const* xcur)
+  {
+    orientation_t const& o = g.csc;
+    flat_args<WT> a;
+    a.indices   = o.indices.data();
+    a.weights   = g.has_weights ? o.weights.as<WT const>() : nullptr;
+    a.bits      = reinterpret_cast<uint8_t const*>(o.rowstart_bits.data());
+    a.wave_rank = wave_rank.data();
+    a.ne        = g.ne;
+    a.range_len = range_len;
+    a.x         = xcur;
+    a.y         = yv.data();
+    a.head_sum  = head_sum.data();
+    a.has_flag  = has_flag.data();
+    a.alpha     = alpha;
+    a.hot       = hot;
+    timed_launch t(h, "pagerank_spmv");
+    hipLaunchKernelGGL((k_spmv_flat<WT, WEIGHTED>), flat_grid, FL_BLOCK, flat_lds, h.stream, a);
+  }
+
+  void iterate_flat()
+  {
+    WT const* xcur = cur == 0 ? x0.data() : x1.data();
+    WT* xnext      = cur == 0 ? x1.data() : x0.data();
+    if (g.has_weights) launch_flat<true>(xcur); else launch_flat<false>(xcur);
+    hipLaunchKernelGGL(k_flat_fixup<WT>, grid_for(n_waves, kBlock), kBlock, 0, h.stream, (uint32_t const*)wave_rank.data(), (WT const*)head_sum.data(),
+                       (uint8_t const*)has_flag.data(), n_waves, yv.data());
+    if (personalized)
+      hipLaunchKernelGGL((k_pr_epilogue<WT, true>), epi_grid, 256, 0, h.stream, (WT const*)yv.data(), g.csc.seg[4], g.nv, pr.data(), xnext, outw,
+                         (WT const*)pers.data(), (pr_scalars<WT> const*)scal.data(), partials.data());
+    else
+      hipLaunchKernelGGL((k_pr_epilogue<WT, false>), epi_grid, 256, 0, h.stream, (WT const*)yv.data(), g.csc.seg[4], g.nv, pr.data(), xnext, outw,
+                         (WT const*)nullptr, (pr_scalars<WT> const*)scal.data(), partials.data());
+    hipLaunchKernelGGL(k_finish<WT>, 1, 256, 0, h.stream, (double const*)partials.data(), epi_grid, scal.data(), alpha, (WT)(1.0 - (double)alpha),
+                       g.nv, personalized ? 1 : 0);
+  }
+
   void launch_finish()
   {
     hipLaunchKernelGGL(k_finish<WT>, 1, 256, 0, h.stream, (double const*)partials.data(), grid, scal.data(), alpha, (WT)(1.0 - (double)alpha),
@@ -411,6 +777,7 @@ struct pagerank_plan : pagerank_plan_base {
     int blocks_per_cu = lds_bytes <= 80 * 1024 ? 2 : 1;
     grid            = h.num_cus * blocks_per_cu;
     partials.resize_discard((size_t)2 * std::max(grid, 2048));
+    setup_flat();
 
     if (ow_s) {
       outw_own.resize_discard(n1);
@@ -480,7 +847,23 @@ struct pagerank_plan : pagerank_plan_base {
     size_t it = 0;
     bool conv = false;
     WT const eps = (WT)epsilon;
+    static bool flat_attr[2] = {false, false};
+    if (flat) {
+      if (!flat_attr[0]) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_spmv_flat<WT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_per_block)); flat_attr[0] = true; }
+      if (!flat_attr[1]) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_spmv_flat<WT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_per_block)); flat_attr[1] = true; }
+    }
     while (it < max_iterations) {
+      if (flat) {
+        iterate_flat();
+        cur ^= 1;
+        ++it;
+        if (epsilon > 0.0) {
+          pr_scalars<WT> sc;
+          h.read_back(&sc, scal.data(), 1);
+          if (sc.diff < eps) { conv = true; break; }
+        }
+        continue;
+      }
       spmv_args<WT> a;
       a.offsets   = o.offsets.data();
       a.indices   = o.indices.data();

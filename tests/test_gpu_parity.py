@@ -351,3 +351,40 @@ def test_csr_input_and_orientation_flip_share_one_numbering(cg, handle, orc):
     assert np.array_equal(v1.cpu().numpy(), v2.cpu().numpy())  # unlike the reference, no re-numbering on the flip
     od, _ = orc.bfs(nv, off, idx, [0])
     assert np.array_equal(by_vertex(v2, dist)[0], od)
+
+
+@pytest.mark.parametrize("scale,weighted", [(10, False), (13, True), (17, False)])
+def test_pagerank_flat_and_row_kernels_agree(cg, handle, orc, scale, weighted, monkeypatch):
+    """The edge-balanced kernel (degree-sorted ids) and the row-classed kernel (any numbering) are two
+    schedules of the same sums: both must match the oracle, and each other to fp32 round-off."""
+    s, d = rmat_graph(orc, scale, seed=4)
+    nv = 1 << scale
+    w = int_weights(s.size) if weighted else None
+    g = make_graph(cg, handle, s, d, w, transposed=True, renumber=True, vertices=np.arange(nv))
+    res = {}
+    for kern in ("flat", "rows"):
+        monkeypatch.setenv("CUGRAPH_AMD_PAGERANK_KERNEL", kern)
+        v, pr, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 12, False, fail_on_nonconvergence=False)
+        res[kern] = by_vertex(v, pr)[0]
+    off, idx, ww = orc.coo_to_cs(nv, d, s, w)
+    truth, _, _ = orc.pagerank(nv, off, idx, ww, 0.85, 0.0, 12, acc64=True)
+    for kern in res:
+        assert np.max(np.abs(res[kern] - truth)) <= 1e-6
+        assert np.max(np.abs(res[kern] - truth) / truth) <= 2e-5, kern
+    np.testing.assert_allclose(res["flat"], res["rows"], rtol=1e-5)
+
+
+def test_pagerank_flat_ragged_ranges(cg, handle, orc):
+    """Edge counts that are not multiples of the 1024-edge chunk, a hub row spanning many wave ranges, and
+    single-edge rows: the stitched partial rows must still be exact."""
+    rng = np.random.default_rng(11)
+    nv = 5000
+    hub_in = rng.integers(0, nv, 70001)                      # 70001 in-edges of vertex 7
+    s = np.concatenate([hub_in, rng.integers(0, nv, 12345), np.arange(100, 1100)])
+    d = np.concatenate([np.full(hub_in.size, 7), rng.integers(0, nv, 12345), np.arange(2000, 3000)])
+    g = make_graph(cg, handle, s, d, None, transposed=True, renumber=True, vertices=np.arange(nv))
+    v, pr, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 15, False, fail_on_nonconvergence=False)
+    off, idx, _ = orc.coo_to_cs(nv, d.astype(np.int32), s.astype(np.int32))
+    truth, _, _ = orc.pagerank(nv, off, idx, None, 0.85, 0.0, 15, acc64=True)
+    got = by_vertex(v, pr)[0]
+    assert np.max(np.abs(got - truth) / truth) <= 2e-5
