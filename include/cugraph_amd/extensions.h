@@ -48,6 +48,34 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_plan_result(
   cugraph_centrality_result_t** result, cugraph_error_t** error);
 CUGRAPH_EXPORT void cugraph_amd_pagerank_plan_free(cugraph_amd_pagerank_plan_t* plan);
 
+
+/* Multi-GPU PageRank, one process per GPU (1-D partition by destination).
+ * `graph` is this rank's LOCAL CSC: rows [0, n_local_rows) are the destinations this rank owns, numbered by
+ * descending in-degree; column ids are c = local_index * comm_size + owner_rank of the SOURCE vertex (i.e. the
+ * global degree order) and the graph must have been created with at least comm_size * chunk vertices.
+ * The caller provides two device buffers (views, weight type): `send` (chunk elements: this rank's x = pr / out_w, then 16 bytes holding its
+ * partial L1 change and dangling mass as two doubles) and `recv` (comm_size * chunk elements).  Per iteration the
+ * host layer runs ONE all-gather send -> recv (torch.distributed / RCCL), then reduce_scalars(), then local_step().
+ * comm_size must be a power of two.  cugraph_amd/mg.py is the host layer. */
+typedef struct { int32_t align_; } cugraph_amd_pagerank_mg_plan_t;
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg_plan_create(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, size_t n_local_rows, size_t global_num_vertices, int comm_rank,
+  int comm_size, size_t chunk, const cugraph_type_erased_device_array_view_t* out_weight_sums_local,
+  const cugraph_type_erased_device_array_view_t* initial_local, cugraph_type_erased_device_array_view_t* send,
+  cugraph_type_erased_device_array_view_t* recv, double alpha, cugraph_amd_pagerank_mg_plan_t** plan, cugraph_error_t** error);
+/* send <- x of the initial vector + partial dangling mass (iteration-0 state) */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg_plan_start(cugraph_amd_pagerank_mg_plan_t* plan, cugraph_error_t** error);
+/* sums the comm_size partial (L1 change, dangling) pairs found in recv, in rank order; read_back = TRUE also
+ * returns them to the host (synchronises) -- needed only when epsilon > 0 */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg_plan_reduce_scalars(cugraph_amd_pagerank_mg_plan_t* plan, bool_t read_back,
+                                                                                double* diff, double* dangling, cugraph_error_t** error);
+/* one power iteration on the local rows: pull-SpMV over recv, new pr, next send chunk; blocks until done */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg_plan_local_step(cugraph_amd_pagerank_mg_plan_t* plan, cugraph_error_t** error);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg_plan_values(cugraph_amd_pagerank_mg_plan_t* plan,
+                                                                        cugraph_type_erased_device_array_view_t* out_local,
+                                                                        cugraph_error_t** error);
+CUGRAPH_EXPORT void cugraph_amd_pagerank_mg_plan_free(cugraph_amd_pagerank_mg_plan_t* plan);
+
 /* Blocks until everything queued on the handle's stream has finished. */
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_handle_sync(const cugraph_resource_handle_t* handle,
                                                             cugraph_error_t** error);

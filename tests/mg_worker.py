@@ -1,0 +1,90 @@
+"""Worker for the multi-process PageRank tests (launched by tests/test_mg.py, one process per rank).
+mode "oracle": gloo on CPU, local compute = CPU engine on the oracle (exercises partitioning + collectives);
+mode "hip":    gloo, every rank drives the HIP engine on cuda:0 (exercises the partitioned HIP kernels on one GPU)."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from cugraph_amd import mg  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+class OracleEngine(mg.LocalEngine):
+    """Same contract as HipLocalEngine, arithmetic by numpy/scipy in fp64 then rounded to fp32 storage."""
+
+    def __init__(self, part, col_src, local_dst, weights, outw_local, alpha, initial_local=None):
+        import scipy.sparse as sp
+
+        self.part, self.alpha = part, float(alpha)
+        P, chunk = part.world, part.chunk
+        c = col_src.numpy().astype(np.int64)
+        addr = (c % P) * chunk + c // P  # column id -> position in the rank-blocked all-gather buffer
+        w = np.ones(c.size) if weights is None else weights.numpy().astype(np.float64)
+        self.A = sp.csr_matrix((w, (local_dst.numpy().astype(np.int64), addr)), shape=(part.n_rows, chunk * P))
+        self.outw = outw_local.numpy().astype(np.float32)
+        self.pr = (np.full(part.n_rows, 1.0 / part.nv, np.float32) if initial_local is None else initial_local.numpy().astype(np.float32))
+        self.send = torch.zeros(chunk, dtype=torch.float32)
+        self.recv = torch.zeros(chunk * P, dtype=torch.float32)
+        self.base = 0.0
+
+    def _pack(self, diff):
+        s = self.send.numpy()
+        div = np.where(self.outw == 0, np.float32(1), self.outw)
+        s[: self.part.n_rows] = self.pr / div
+        tail = s[-4:].view(np.float64)
+        tail[0] = diff
+        tail[1] = float(self.pr[self.outw == 0].astype(np.float64).sum())
+
+    def start(self):
+        self._pack(0.0)
+
+    def reduce_scalars(self, read_back):
+        r = self.recv.numpy().reshape(self.part.world, self.part.chunk)
+        tails = r[:, -4:].copy().view(np.float64)
+        diff, dang = float(tails[:, 0].sum()), np.float32(tails[:, 1].sum())
+        self.base = np.float32((dang * np.float32(self.alpha) + np.float32(1.0 - self.alpha)) / np.float32(self.part.nv))
+        return diff, float(dang)
+
+    def local_step(self):
+        x = self.recv.numpy().astype(np.float64) * np.float64(np.float32(self.alpha))
+        y = (self.A @ x).astype(np.float32)
+        new = (self.base + y).astype(np.float32)
+        diff = float(np.abs(new - self.pr).astype(np.float64).sum())
+        self.pr = new
+        self._pack(diff)
+
+    def values(self):
+        return torch.from_numpy(self.pr.copy())
+
+
+def main():
+    mode, scale, out_dir = sys.argv[1], int(sys.argv[2]), Path(sys.argv[3])
+    eps, max_iter = float(sys.argv[4]), int(sys.argv[5])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nv, ne = 1 << scale, 16 << scale
+    per = (ne + world - 1) // world
+    s, d = orc.rmat(scale, min(per, ne - rank * per), first_edge=rank * per)
+    weighted = mode.endswith("w")
+    w = None
+    if weighted:
+        w = torch.from_numpy(np.random.default_rng(1).integers(1, 9, size=ne).astype(np.float32)[rank * per: rank * per + s.size].copy())
+    factory = OracleEngine if mode.startswith("oracle") else None
+    if factory is None:
+        torch.cuda.set_device(0)
+    v, x, iters, conv = mg.pagerank(torch.from_numpy(s), torch.from_numpy(d), nv, weights=w, alpha=0.85, epsilon=eps, max_iterations=max_iter,
+                                    engine_factory=factory)
+    np.savez(out_dir / f"rank{rank}.npz", v=v.cpu().numpy(), x=x.cpu().numpy(), iters=iters, conv=conv)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

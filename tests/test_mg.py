@@ -1,0 +1,106 @@
+"""Multi-process PageRank (cugraph_amd/mg.py): world_size-2 gloo on CPU with the oracle as the local engine
+(partitioning + collectives), and -- on the GPU box -- the HIP engine driven by 2 and 4 ranks sharing cuda:0."""
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import rmat_graph
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_world(mode, world, scale, tmp_path, eps=0.0, max_iter=12):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "mg_worker.py"), mode, str(scale), str(tmp_path), str(eps), str(max_iter)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    nv = 1 << scale
+    pr = np.full(nv, np.nan, np.float32)
+    for r in res:
+        pr[r["v"]] = r["x"]
+    assert not np.isnan(pr).any(), "every vertex must be owned by exactly one rank"
+    return pr, int(res[0]["iters"]), bool(res[0]["conv"])
+
+
+def truth(orc, scale, eps, max_iter, weighted=False):
+    s, d = rmat_graph(orc, scale)
+    nv = 1 << scale
+    w = np.random.default_rng(1).integers(1, 9, size=s.size).astype(np.float32) if weighted else None
+    off, idx, ww = orc.coo_to_cs(nv, d, s, w)
+    return orc.pagerank(nv, off, idx, ww, 0.85, eps, max_iter, acc64=True)
+
+
+def test_partition_is_balanced_and_degree_sorted(orc):
+    import torch
+
+    from cugraph_amd.mg import Partition
+
+    s, d = rmat_graph(orc, 12)
+    nv = 1 << 12
+    indeg = torch.from_numpy(np.bincount(d, minlength=nv))
+    parts = [Partition(indeg, 4, r) for r in range(4)]
+    owned = torch.cat([p.local_vertices for p in parts])
+    assert sorted(owned.tolist()) == list(range(nv))                      # a partition of the vertex set
+    loads = [int(indeg[p.local_vertices].sum()) for p in parts]
+    assert max(loads[1:]) / min(loads) < 1.05                              # in-edges per rank within 5 % ...
+    assert loads[0] - max(loads[1:]) <= int(indeg.max())                   # ... rank 0 additionally carries the top hub
+    for p in parts:
+        deg = indeg[p.local_vertices]
+        assert bool((deg[1:] <= deg[:-1]).all())                           # local rows already degree-sorted
+        assert p.chunk % 4 == 0 and p.chunk >= p.n_rows + 4
+        assert bool((p.pos[p.local_vertices] % 4 == p.rank).all())         # column id = degree-order position
+
+
+@pytest.mark.parametrize("world,mode", [(2, "oracle"), (4, "oracle"), (2, "oraclew")])
+def test_mg_pagerank_gloo_cpu(orc, tmp_path, world, mode):
+    scale = 10
+    pr, iters, conv = run_world(mode, world, scale, tmp_path, eps=0.0, max_iter=12)
+    t, it, _ = truth(orc, scale, 0.0, 12, weighted=mode.endswith("w"))
+    assert iters == 12 and not conv
+    assert np.max(np.abs(pr - t) / t) <= 2e-5
+
+
+def test_mg_pagerank_gloo_cpu_converges_like_single_gpu(orc, tmp_path):
+    scale = 9
+    pr, iters, conv = run_world("oracle", 2, scale, tmp_path, eps=1e-5, max_iter=200)
+    t, it, tconv = truth(orc, scale, 1e-5, 200)
+    assert conv and tconv and abs(iters - it) <= 1
+    np.testing.assert_allclose(pr, t, rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,mode", [(1, "hip"), (2, "hip"), (4, "hip"), (2, "hipw")])
+def test_mg_pagerank_hip_engine(orc, tmp_path, world, mode):
+    """The partitioned HIP path (edge-balanced kernel with the rank-interleaved column ids, piggybacked scalars),
+    ranks sharing one GPU and exchanging through gloo."""
+    scale = 12
+    pr, iters, conv = run_world(mode, world, scale, tmp_path, eps=0.0, max_iter=12)
+    t, _, _ = truth(orc, scale, 0.0, 12, weighted=mode.endswith("w"))
+    assert np.max(np.abs(pr - t)) <= 1e-6
+    assert np.max(np.abs(pr - t) / t) <= 2e-5
+
+
+@pytest.mark.gpu
+def test_mg_pagerank_hip_engine_convergence(orc, tmp_path):
+    pr, iters, conv = run_world("hip", 2, 11, tmp_path, eps=1e-5, max_iter=200)
+    t, it, tconv = truth(orc, 11, 1e-5, 200)
+    assert conv and abs(iters - it) <= 1
+    np.testing.assert_allclose(pr, t, rtol=1e-4)
