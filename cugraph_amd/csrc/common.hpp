@@ -218,6 +218,8 @@ struct timed_launch {  // RAII bracket: records start/stop events when timing is
   }
 };
 
+struct tiled_csc_t;  // spmv_tiled.hpp
+
 // ------------------------------------------------------------------------------------------- graph
 // One compressed-sparse orientation.  `major` = row vertex: source for CSR (store_transposed = false),
 // destination for CSC (store_transposed = true).  Neighbour lists ascending, multi-edges kept.
@@ -236,6 +238,8 @@ struct orientation_t {
   // bit e set <=> edge position e is the first edge of a row (built lazily; used by the edge-balanced
   // PageRank kernel, which needs the non-empty rows to be the id prefix [0, seg[4]))
   dvec<uint32_t> rowstart_bits;
+  // column-tiled re-blocking of this orientation (built lazily by the PageRank plan, cached for later calls)
+  std::shared_ptr<tiled_csc_t> tiled;
 };
 
 constexpr int32_t kSegThreshold[orientation_t::n_seg] = {4096, 64, 16, 4, 1};

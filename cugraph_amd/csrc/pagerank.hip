@@ -26,6 +26,8 @@
 //
 // Loop order and stopping rule follow pagerank_impl.cuh:224-329 exactly (see oracle/oracle.c).
 #include "common.hpp"
+#include "spmv_tiled.hpp"
+#include "wave_ops.hpp"
 
 #include <type_traits>
 
@@ -35,14 +37,6 @@ namespace {
 
 constexpr int PR_BLOCK = 1024;  // 16 wavefronts
 constexpr int PR_WAVES = PR_BLOCK / 64;
-
-template <typename WT>
-struct pr_scalars {  // device-resident loop state
-  WT base;         // (alpha * dangling + (1 - alpha)) / V, or 0 when personalized
-  WT pers_factor;  // alpha * dangling + (1 - alpha)
-  WT dangling;
-  WT diff;
-};
 
 template <typename WT>
 struct spmv_args {
@@ -62,13 +56,6 @@ struct spmv_args {
   WT alpha;
   int hot;                // entries of x staged in LDS
 };
-
-template <typename WT>
-__device__ __forceinline__ WT group_sum(WT v, int width)
-{
-  for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
 
 template <typename WT, bool WEIGHTED>
 struct gatherer {
@@ -211,64 +198,6 @@ __global__ void __launch_bounds__(PR_BLOCK) k_spmv(spmv_args<WT> a)
 // Requires: non-empty rows are exactly ids [0, n_nonempty) in edge order -- true for the degree-sorted
 // numbering.  Other graphs use k_spmv above.
 // =================================================================================================
-
-// ---- wave64 cross-lane helpers on DPP (data-parallel primitives: 1 VALU op per step instead of an LDS-crossbar
-// ds_bpermute plus address arithmetic).  Row = 16 lanes.  Encodings: row_shr:n = 0x110+n, row_bcast:15 = 0x142,
-// row_bcast:31 = 0x143, wave_shr:1 = 0x138 (gfx9 family incl. gfx950).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t src)
-{  // lanes without a valid source (or outside ROW_MASK) read 0 = identity of both operators below
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, ROW_MASK, 0xF, true);
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_val(float src) { return __uint_as_float(dpp_u32<CTRL, ROW_MASK>(__float_as_uint(src))); }
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_val(double src)
-{
-  unsigned long long b = (unsigned long long)__double_as_longlong(src);
-  uint32_t lo = dpp_u32<CTRL, ROW_MASK>((uint32_t)b), hi = dpp_u32<CTRL, ROW_MASK>((uint32_t)(b >> 32));
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
-// inclusive segmented scan over the 64 lanes: s = sum of the lane values back to (and including) the nearest lane
-// whose count c is non-zero; c = inclusive sum of counts.  Operator (left (+) right) = (right.c ? right.s : left.s + right.s).
-template <typename WT, int CTRL, int ROW_MASK>
-__device__ __forceinline__ void seg_step(WT& s, uint32_t& c)
-{
-  WT ts       = dpp_val<CTRL, ROW_MASK>(s);
-  uint32_t tc = dpp_u32<CTRL, ROW_MASK>(c);
-  s           = c == 0 ? s + ts : s;
-  c += tc;
-}
-template <typename WT>
-__device__ __forceinline__ void wave_seg_scan(WT& s, uint32_t& c)
-{
-  seg_step<WT, 0x111, 0xF>(s, c);  // row_shr:1
-  seg_step<WT, 0x112, 0xF>(s, c);  // row_shr:2
-  seg_step<WT, 0x114, 0xF>(s, c);  // row_shr:4
-  seg_step<WT, 0x118, 0xF>(s, c);  // row_shr:8
-  seg_step<WT, 0x142, 0xA>(s, c);  // row_bcast:15 -> rows 1, 3
-  seg_step<WT, 0x143, 0xC>(s, c);  // row_bcast:31 -> rows 2, 3
-}
-template <typename WT>
-__device__ __forceinline__ WT wave_sum_to_lane63(WT s)
-{
-  s += dpp_val<0x111, 0xF>(s);
-  s += dpp_val<0x112, 0xF>(s);
-  s += dpp_val<0x114, 0xF>(s);
-  s += dpp_val<0x118, 0xF>(s);
-  s += dpp_val<0x142, 0xA>(s);
-  s += dpp_val<0x143, 0xC>(s);
-  return s;  // lane 63 holds the wave total
-}
-template <typename WT> __device__ __forceinline__ WT read_lane63(WT v);
-template <> __device__ __forceinline__ float read_lane63<float>(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63)); }
-template <> __device__ __forceinline__ double read_lane63<double>(double v)
-{
-  unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
 
 constexpr int FL_BLOCK = 1024;
 constexpr int FL_WAVES = FL_BLOCK / 64;
@@ -636,6 +565,12 @@ struct pagerank_plan : pagerank_plan_base {
   int64_t range_len{0}, n_waves{0};
   int flat_grid{0}, epi_grid{0};
   size_t flat_lds{0};
+  // column-tiled two-phase path (spmv_tiled.hpp): the default
+  bool tiled{false};
+  std::shared_ptr<tiled_csc_t> tc;
+  dvec<WT> part;
+  dvec<double> tpartials;  // [max(nI, 1024)][3]
+  dvec<uint32_t> counters;
 
   pagerank_plan(handle_t const& h_, graph_t& g_, double alpha_) : h(h_), g(g_), alpha((WT)alpha_) {}
 
@@ -693,8 +628,31 @@ struct pagerank_plan : pagerank_plan_base {
   void setup_flat()
   {
     orientation_t& o = g.csc;
-    char const* env  = getenv("CUGRAPH_AMD_PAGERANK_KERNEL");  // "rows" forces the row-classed kernel (testing / profiling)
-    flat = o.row_order.size() == 0 && g.ne > 0 && !(env && std::string(env) == "rows");
+    char const* env  = getenv("CUGRAPH_AMD_PAGERANK_KERNEL");  // "flat" / "rows" select the single-pass kernels (testing / profiling)
+    std::string const kern = env ? env : "tiled";
+    tiled = g.ne > 0 && kern != "flat" && kern != "rows";
+    if (tiled) {
+      int const T = tiled_default_T(h, sizeof(WT), g.nv);
+      if (!o.tiled || o.tiled->T != T) {
+        auto t = std::make_shared<tiled_csc_t>();
+        build_tiled_csc(h, g.nv, g.ne, o, g.has_weights, sizeof(WT), T, *t);
+        o.tiled = t;
+      }
+      tc = o.tiled;
+      part.resize_discard((size_t)tc->n_slots + 64);
+      HIP_TRY(hipMemsetAsync(part.data(), 0, ((size_t)tc->n_slots + 64) * sizeof(WT), h.stream));
+      tpartials.resize_discard((size_t)3 * std::max(tc->nI, 1024));
+      counters.resize_discard(4);
+      HIP_TRY(hipMemsetAsync(counters.data(), 0, 4 * sizeof(uint32_t), h.stream));
+      // the gather vectors are read tile-wise: pad them to whole tiles (zero tail)
+      size_t const nx = (size_t)tc->nJ * tc->T + 8;
+      x0.resize_discard(nx); x1.resize_discard(nx);
+      HIP_TRY(hipMemsetAsync(x0.data(), 0, nx * sizeof(WT), h.stream));
+      HIP_TRY(hipMemsetAsync(x1.data(), 0, nx * sizeof(WT), h.stream));
+      h.sync();
+      return;
+    }
+    flat = o.row_order.size() == 0 && g.ne > 0 && kern != "rows";
     if (!flat) return;
     int64_t const nnz_rows = o.seg[4];
     if (o.rowstart_bits.size() == 0) {
@@ -761,6 +719,31 @@ struct pagerank_plan : pagerank_plan_base {
                        g.nv, personalized ? 1 : 0);
   }
 
+  bool pending_finish{false};  // tiled: phase 2 ran, its scalar partials are not folded into `scal` yet
+  tiled_epilogue<WT> tiled_epi(WT* xnext)
+  {
+    tiled_epilogue<WT> e;
+    e.nv = g.nv; e.pr = pr.data(); e.x_next = xnext; e.outw = outw; e.pers = personalized ? pers.data() : nullptr;
+    e.scal = scal.data(); e.partials = tpartials.data(); e.totals = nullptr; e.alpha = alpha; e.nv_global = g.nv;
+    e.wmax = tc->wmax;
+    return e;
+  }
+  void iterate_tiled()
+  {
+    WT const* xcur = cur == 0 ? x0.data() : x1.data();
+    WT* xnext      = cur == 0 ? x1.data() : x0.data();
+    tiled_epilogue<WT> e = tiled_epi(xnext);
+    tiled_phase1<WT>(h, *tc, xcur, alpha, part.data(), counters.data(), tiled_x_map<WT>{}, pending_finish ? &e : nullptr);
+    tiled_phase2<WT>(h, *tc, (WT const*)part.data(), e, counters.data());
+    pending_finish = true;
+  }
+  void flush_tiled_scalars()
+  {
+    if (!pending_finish) return;
+    tiled_finish<WT>(h, tiled_epi(nullptr), tc->nI);
+    pending_finish = false;
+  }
+
   void launch_finish()
   {
     hipLaunchKernelGGL(k_finish<WT>, 1, 256, 0, h.stream, (double const*)partials.data(), grid, scal.data(), alpha, (WT)(1.0 - (double)alpha),
@@ -825,6 +808,13 @@ struct pagerank_plan : pagerank_plan_base {
       h.sync();
     }
     // iteration-0 state: x = pr / out_w, dangling mass, base
+    if (tiled) {
+      int n = tiled_prologue<WT>(h, *tc, (WT const*)pr.data(), outw, x0.data(), nv, tpartials.data());
+      tiled_finish<WT>(h, tiled_epi(nullptr), n);
+      cur = 0;
+      h.sync();
+      return;
+    }
     int pgrid = std::min(grid_for(nv, 256, 2048), 2048);
     hipLaunchKernelGGL(k_prologue<WT>, pgrid, 256, 0, h.stream, (WT const*)pr.data(), outw, x0.data(), nv, partials.data());
     int keep = grid;
@@ -864,11 +854,12 @@ struct pagerank_plan : pagerank_plan_base {
       if (!flat_attr[1]) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_spmv_flat<WT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_per_block)); flat_attr[1] = true; }
     }
     while (it < max_iterations) {
-      if (flat) {
-        iterate_flat();
+      if (tiled || flat) {
+        if (tiled) iterate_tiled(); else iterate_flat();
         cur ^= 1;
         ++it;
         if (epsilon > 0.0) {
+          if (tiled) flush_tiled_scalars();
           pr_scalars<WT> sc;
           h.read_back(&sc, scal.data(), 1);
           if (sc.diff < eps) { conv = true; break; }
@@ -902,6 +893,7 @@ struct pagerank_plan : pagerank_plan_base {
         if (s.diff < eps) { conv = true; break; }
       }
     }
+    if (tiled) flush_tiled_scalars();
     *done      = it;
     *converged = conv;
   }

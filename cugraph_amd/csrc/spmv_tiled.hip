@@ -1,0 +1,975 @@
+// Column-tiled two-phase pull-SpMV (see spmv_tiled.hpp for the design and the reference call sites it replaces).
+#include "spmv_tiled.hpp"
+#include "wave_ops.hpp"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace cga {
+
+namespace {
+
+// =================================================================================================
+// build: CSC -> tiles
+// =================================================================================================
+__global__ void k_expand_rows_u32(int32_t const* offsets, int64_t nv, uint32_t* rows)
+{
+  int64_t wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int lane       = threadIdx.x & 63;
+  for (int64_t v = wave; v < nv; v += nwaves) {
+    int32_t b = offsets[v], e = offsets[v + 1];
+    for (int32_t p = b + lane; p < e; p += 64) rows[p] = (uint32_t)v;
+  }
+}
+
+__global__ void k_tile_keys(int32_t const* indices, int64_t ne, uint32_t T, uint64_t* keys, uint32_t* vals)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < ne; i += stride) {
+    keys[i] = (uint64_t)((uint32_t)indices[i] / T);
+    vals[i] = (uint32_t)i;
+  }
+}
+
+// first[key] = first position holding that key in a sorted key array (entries of absent keys keep the pre-filled value)
+__global__ void k_first_of_key(uint64_t const* keys, int64_t n, uint32_t* first)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride)
+    if (i == 0 || keys[i] != keys[i - 1]) first[keys[i]] = (uint32_t)i;
+}
+
+// tiled position k (sorted by source tile, then CSC order) -> padded position, 16-bit source, run-start flag
+template <typename WB>
+__global__ void k_tile_emit(uint64_t const* keys, uint32_t const* vals, int64_t ne, int32_t const* indices, uint32_t const* rows,
+                            WB const* w_in, uint32_t const* tile_off, uint32_t const* tile_off_pad, uint32_t T, uint16_t* src16,
+                            WB* w_out, uint32_t* bits, uint32_t* flag32, uint32_t* dsts)
+{
+  int64_t k      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; k < ne; k += stride) {
+    uint32_t J  = (uint32_t)keys[k];
+    uint32_t e  = vals[k];
+    uint32_t pk = tile_off_pad[J] + ((uint32_t)k - tile_off[J]);
+    uint32_t d  = rows[e];
+    src16[pk]   = (uint16_t)((uint32_t)indices[e] - J * T);
+    if (w_in) w_out[pk] = w_in[e];
+    bool flag = (uint32_t)k == tile_off[J] || rows[vals[k - 1]] != d;
+    flag32[k] = flag ? 1u : 0u;
+    dsts[k]   = d;
+    if (flag) atomicOr(&bits[pk >> 5], 1u << (pk & 31));
+  }
+}
+
+__global__ void k_run_dst(uint32_t const* flag32, uint32_t const* ord, uint32_t const* dsts, int64_t ne, uint32_t* run_dst, uint32_t* cnt_dst)
+{
+  int64_t k      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; k < ne; k += stride)
+    if (flag32[k]) {
+      uint32_t d      = dsts[k];
+      run_dst[ord[k]] = d;
+      atomicAdd(&cnt_dst[d], 1u);
+    }
+}
+
+// cut[q] = smallest row d with cost(d) >= q * total / nq, cost(d) = 6 * (runs of rows < d) + 16 * d
+__global__ void k_cost_cuts(uint32_t const* csum, int64_t nv, uint64_t total, int nq, uint32_t* cut)
+{
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  uint64_t target = total * (uint64_t)q / (uint64_t)nq;  // total < 2^36, q < 2^12
+  int64_t lo = 0, hi = nv;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    uint64_t c  = 6ull * csum[mid] + 16ull * (uint64_t)mid;
+    if (c < target) lo = mid + 1; else hi = mid;
+  }
+  cut[q] = (uint32_t)lo;
+}
+
+__device__ __forceinline__ uint32_t tile_of_row(uint32_t const* tile_row0, int nI, uint32_t d)
+{  // largest I with tile_row0[I] <= d
+  int lo = 0, hi = nI;  // invariant: tile_row0[lo] <= d < tile_row0[hi]
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (tile_row0[mid] <= d) lo = mid; else hi = mid;
+  }
+  return (uint32_t)lo;
+}
+
+__global__ void k_run_keys(uint32_t const* run_dst, int64_t n_runs, uint32_t const* tile_row0, int nI, uint64_t* keys, uint32_t* vals)
+{
+  int64_t q      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; q < n_runs; q += stride) {
+    keys[q] = tile_of_row(tile_row0, nI, run_dst[q]);
+    vals[q] = (uint32_t)q;
+  }
+}
+
+__global__ void k_wave_desc(int32_t const* item_tile, uint32_t const* item_end, int n_items,
+                            uint32_t const* tile_off, uint32_t const* tile_off_pad, uint32_t const* flag32, uint32_t const* ord,
+                            uint32_t const* run_dst, uint32_t const* tile_row0, int nI, int64_t n_runs, tiled_wave_t* waves,
+                            uint64_t* keys, uint32_t* vals)
+{
+  int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n_items * TP_WAVES) return;
+  int item = (int)(idx / TP_WAVES), w = (int)(idx % TP_WAVES);
+  uint32_t J   = (uint32_t)item_tile[item];
+  uint32_t end = item_end[item];
+  uint64_t es64 = (uint64_t)item * TP_ITEM + (uint64_t)w * TP_WLEN;
+  tiled_wave_t d{0, 0, 0, 0};
+  uint64_t key = (uint64_t)nI;  // no head: dummy region
+  if (es64 < end) {
+    uint32_t es = (uint32_t)es64;
+    d.es        = es;
+    d.ee        = (uint32_t)min((uint64_t)end, es64 + TP_WLEN);
+    uint32_t k  = tile_off[J] + (es - tile_off_pad[J]);
+    d.rank      = ord[k];
+    if (!flag32[k]) key = tile_of_row(tile_row0, nI, run_dst[d.rank - 1]);  // the run open at es is run (rank - 1)
+  }
+  waves[idx]          = d;
+  keys[n_runs + idx] = key;
+  vals[n_runs + idx] = (uint32_t)(n_runs + idx);
+}
+
+__global__ void k_assign_slots(uint64_t const* keys, uint32_t const* vals, int64_t n, int64_t n_runs, uint32_t const* shift,
+                               uint32_t const* run_dst, uint32_t const* tile_row0, int nI, uint32_t* rpos, tiled_wave_t* waves,
+                               uint16_t* dstl16)
+{
+  int64_t s      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; s < n; s += stride) {
+    uint32_t I    = (uint32_t)keys[s];
+    uint32_t idx  = vals[s];
+    uint32_t slot = (uint32_t)s + shift[I];  // modulo 2^32
+    if ((int64_t)idx < n_runs) {
+      rpos[idx]    = slot;
+      dstl16[slot] = (uint16_t)(run_dst[idx] - tile_row0[I]);
+    } else {
+      tiled_wave_t& wd = waves[idx - n_runs];
+      wd.head_slot     = slot;
+      if ((int)I < nI) dstl16[slot] = (uint16_t)(run_dst[wd.rank - 1] - tile_row0[I]);
+    }
+  }
+}
+
+int bits_for_u(uint64_t max_value)
+{
+  int b = 0;
+  while (b < 64 && (max_value >> b) != 0) ++b;
+  return b < 1 ? 1 : b;
+}
+
+template <typename T>
+std::vector<T> to_host(handle_t const& h, T const* dev, size_t n)
+{
+  std::vector<T> out(n);
+  if (n) HIP_TRY(hipMemcpyAsync(out.data(), dev, n * sizeof(T), hipMemcpyDeviceToHost, h.stream));
+  h.sync();
+  return out;
+}
+template <typename T>
+void to_device(handle_t const& h, dvec<T>& dev, std::vector<T> const& host)
+{
+  dev.resize_discard(host.size() ? host.size() : 1);
+  if (host.size()) HIP_TRY(hipMemcpyAsync(dev.data(), host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, h.stream));
+  h.sync();  // `host` may be a temporary
+}
+
+// first-occurrence table of a sorted key array over keys [0, nkeys]; absent keys take the next present key's position
+std::vector<uint32_t> key_starts(handle_t const& h, uint64_t const* keys, int64_t n, int64_t nkeys)
+{
+  dvec<uint32_t> first(nkeys + 1);
+  fill_u32(h, first.data(), nkeys + 1, 0xFFFFFFFFu);
+  if (n > 0) hipLaunchKernelGGL(k_first_of_key, grid_for(n, kBlock, 8192), kBlock, 0, h.stream, keys, n, first.data());
+  std::vector<uint32_t> f = to_host(h, first.data(), (size_t)nkeys + 1);
+  f[nkeys] = (uint32_t)n;
+  for (int64_t k = nkeys - 1; k >= 0; --k)
+    if (f[k] == 0xFFFFFFFFu) f[k] = f[k + 1];
+  return f;
+}
+
+}  // namespace
+
+int tiled_default_T(handle_t const& h, size_t vsize, int64_t nv)
+{
+  // LDS = tile (T values) + one TP_SUB-entry staging row per wavefront + a few static words
+  int64_t const lds_max = ((int64_t)h.lds_per_block - 2048) / (int64_t)vsize - (int64_t)TP_WAVES * TP_SUB;
+  int64_t T = h.pagerank_hot_tile > 0 ? h.pagerank_hot_tile : lds_max;
+  T = std::min<int64_t>({T, lds_max, 65536});
+  T = std::min<int64_t>(T, (std::max<int64_t>(nv, 1) + 255) / 256 * 256);  // small graphs: one small tile
+  T = std::max<int64_t>(T / 256 * 256, 256);
+  return (int)T;
+}
+
+// max over rows of sum |w|
+template <typename WB>
+__global__ void k_row_abs_max(int32_t const* offsets, WB const* w, int64_t nv, unsigned long long* out)
+{
+  int64_t wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int lane       = threadIdx.x & 63;
+  double best    = 0;
+  for (int64_t v = wave; v < nv; v += nwaves) {
+    double s = 0;
+    for (int32_t p = offsets[v] + lane; p < offsets[v + 1]; p += 64) s += fabs((double)w[p]);
+    s    = group_sum(s, 64);
+    best = fmax(best, s);
+  }
+  if (lane == 0) atomicMax(out, (unsigned long long)__double_as_longlong(best));  // non-negative doubles order like their bit patterns
+}
+
+void build_tiled_csc(handle_t const& h, int64_t nv, int64_t ne, orientation_t const& csc, bool has_weights, size_t vsize, int T,
+                     tiled_csc_t& t)
+{
+  size_t const wsize = has_weights ? vsize : 0;
+  CGA_EXPECTS(nv < ((int64_t)1 << 31) && ne < ((int64_t)1 << 31), CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: graph too large for 32-bit positions");
+  t       = tiled_csc_t{};
+  t.T     = T;
+  t.nv    = nv;
+  t.ne    = ne;
+  t.nJ    = (int)std::max<int64_t>(1, (nv + T - 1) / T);
+  int const nJ = t.nJ;
+
+  // ---- edges ordered by (source tile, destination, source): stable sort of the CSC positions by source tile
+  dvec<uint64_t> keys, keys_tmp;
+  dvec<uint32_t> vals, vals_tmp, rows, flag32, ord, dsts;
+  std::vector<uint32_t> tile_off(nJ + 1, 0), tile_off_pad(nJ + 1, 0);
+  if (ne > 0) {
+    keys.resize_discard(ne); keys_tmp.resize_discard(ne); vals.resize_discard(ne); vals_tmp.resize_discard(ne); rows.resize_discard(ne);
+    hipLaunchKernelGGL(k_expand_rows_u32, grid_for(nv * 16, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)csc.offsets.data(), nv, rows.data());
+    hipLaunchKernelGGL(k_tile_keys, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)csc.indices.data(), ne, (uint32_t)T, keys.data(), vals.data());
+    radix_sort_u64_u32(h, keys.data(), vals.data(), keys_tmp.data(), vals_tmp.data(), ne, 0, bits_for_u((uint64_t)nJ - 1));
+    keys_tmp = dvec<uint64_t>(); vals_tmp = dvec<uint32_t>();
+    tile_off = key_starts(h, keys.data(), ne, nJ);
+  }
+  {  // every tile starts on a work-item boundary: item i covers padded positions [i * TP_ITEM, (i + 1) * TP_ITEM)
+    uint64_t pos = 0;
+    for (int J = 0; J < nJ; ++J) {
+      pos += ((uint64_t)(tile_off[J + 1] - tile_off[J]) + TP_ITEM - 1) / TP_ITEM * TP_ITEM;
+      CGA_EXPECTS(pos + TP_ITEM < ((uint64_t)1 << 32), CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: padded edge count overflows 32 bits");
+      tile_off_pad[J + 1] = (uint32_t)pos;
+    }
+  }
+  t.ne_pad = tile_off_pad[nJ];
+  size_t const epad = (size_t)t.ne_pad + TP_WLEN + 64;  // tail loads of the last wavefront stay in bounds
+  t.src16.resize_discard(epad);
+  HIP_TRY(hipMemsetAsync(t.src16.data(), 0, epad * sizeof(uint16_t), h.stream));
+  t.bits.resize_discard(epad / 32 + 2);
+  HIP_TRY(hipMemsetAsync(t.bits.data(), 0, (epad / 32 + 2) * sizeof(uint32_t), h.stream));
+  if (has_weights) {
+    t.weights.alloc(epad * wsize);
+    HIP_TRY(hipMemsetAsync(t.weights.ptr, 0, epad * wsize, h.stream));
+  }
+  dvec<uint32_t> d_tile_off, d_tile_off_pad;
+  to_device(h, d_tile_off, tile_off);
+  to_device(h, d_tile_off_pad, tile_off_pad);
+
+  // ---- runs
+  dvec<uint32_t> run_dst, cnt_dst(nv + 1);
+  HIP_TRY(hipMemsetAsync(cnt_dst.data(), 0, (nv + 1) * sizeof(uint32_t), h.stream));
+  if (ne > 0) {
+    flag32.resize_discard(ne + 1); ord.resize_discard(ne + 1); dsts.resize_discard(ne);
+    HIP_TRY(hipMemsetAsync(flag32.data() + ne, 0, sizeof(uint32_t), h.stream));
+    int const g = grid_for(ne, kBlock, 8192);
+    if (!has_weights)
+      hipLaunchKernelGGL(k_tile_emit<uint32_t>, g, kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), ne, (int32_t const*)csc.indices.data(),
+                         (uint32_t const*)rows.data(), (uint32_t const*)nullptr, (uint32_t const*)d_tile_off.data(), (uint32_t const*)d_tile_off_pad.data(),
+                         (uint32_t)T, t.src16.data(), (uint32_t*)nullptr, t.bits.data(), flag32.data(), dsts.data());
+    else if (wsize == 4)
+      hipLaunchKernelGGL(k_tile_emit<uint32_t>, g, kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), ne, (int32_t const*)csc.indices.data(),
+                         (uint32_t const*)rows.data(), csc.weights.as<uint32_t const>(), (uint32_t const*)d_tile_off.data(), (uint32_t const*)d_tile_off_pad.data(),
+                         (uint32_t)T, t.src16.data(), t.weights.as<uint32_t>(), t.bits.data(), flag32.data(), dsts.data());
+    else
+      hipLaunchKernelGGL(k_tile_emit<uint64_t>, g, kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), ne, (int32_t const*)csc.indices.data(),
+                         (uint32_t const*)rows.data(), csc.weights.as<uint64_t const>(), (uint32_t const*)d_tile_off.data(), (uint32_t const*)d_tile_off_pad.data(),
+                         (uint32_t)T, t.src16.data(), t.weights.as<uint64_t>(), t.bits.data(), flag32.data(), dsts.data());
+    exclusive_scan_u32(h, flag32.data(), ord.data(), ne + 1);
+    uint32_t p32 = 0;
+    h.read_back(&p32, ord.data() + ne, 1);
+    t.n_runs = p32;
+    keys = dvec<uint64_t>(); vals = dvec<uint32_t>(); rows = dvec<uint32_t>();
+    run_dst.resize_discard(t.n_runs);
+    hipLaunchKernelGGL(k_run_dst, g, kBlock, 0, h.stream, (uint32_t const*)flag32.data(), (uint32_t const*)ord.data(), (uint32_t const*)dsts.data(), ne,
+                       run_dst.data(), cnt_dst.data());
+    h.sync();
+    dsts = dvec<uint32_t>();
+  }
+
+  // ---- destination tiles: equal cost (6 bytes per partial + 16 bytes per row), at most TP2_ROWS rows
+  std::vector<uint32_t> row0;
+  {
+    dvec<uint32_t> csum(nv + 1);
+    exclusive_scan_u32(h, cnt_dst.data(), csum.data(), nv + 1);
+    uint64_t total = 6ull * (uint64_t)t.n_runs + 16ull * (uint64_t)nv;
+    int nq = (int)std::min<uint64_t>(4096, std::max<uint64_t>(1, total / 32768));
+    dvec<uint32_t> cut(nq);
+    hipLaunchKernelGGL(k_cost_cuts, (nq + 255) / 256, 256, 0, h.stream, (uint32_t const*)csum.data(), nv, total, nq, cut.data());
+    std::vector<uint32_t> c = to_host(h, cut.data(), (size_t)nq);
+    c.push_back((uint32_t)nv);
+    uint32_t prev = 0;
+    row0.push_back(0);
+    for (uint32_t b : c) {
+      if (b <= prev) continue;
+      while (b - prev > (uint32_t)TP2_ROWS) { prev += TP2_ROWS; row0.push_back(prev); }
+      row0.push_back(b);
+      prev = b;
+    }
+    if (row0.size() == 1) row0.push_back((uint32_t)nv);  // nv == 0
+  }
+  t.nI = (int)row0.size() - 1;
+  to_device(h, t.tile_row0, row0);
+
+  // ---- phase-1 work items (source tile order = hottest tiles first)
+  std::vector<int32_t> item_tile;
+  std::vector<uint32_t> item_end;  // end of the real edges of the item's tile (padded position)
+  for (int J = 0; J < nJ; ++J) {
+    uint32_t const e = tile_off_pad[J] + (tile_off[J + 1] - tile_off[J]);
+    for (uint32_t s = tile_off_pad[J]; s < tile_off_pad[J + 1]; s += TP_ITEM) {
+      item_tile.push_back(J);
+      item_end.push_back(e);
+    }
+  }
+  t.n_items = (int)item_tile.size();
+  int64_t const n_waves = (int64_t)t.n_items * TP_WAVES;
+  to_device(h, t.item_tile, item_tile);
+  t.waves.resize_discard(n_waves > 0 ? n_waves : 1);
+
+  // ---- slots: runs and wave heads ordered by (destination tile, source tile, destination)
+  int64_t const n_el = t.n_runs + n_waves;
+  std::vector<uint32_t> region_off(t.nI + 2, 0);
+  if (n_el > 0) {
+    dvec<uint32_t> d_item_end;
+    to_device(h, d_item_end, item_end);
+    keys.resize_discard(n_el); keys_tmp.resize_discard(n_el); vals.resize_discard(n_el); vals_tmp.resize_discard(n_el);
+    if (t.n_runs > 0)
+      hipLaunchKernelGGL(k_run_keys, grid_for(t.n_runs, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)run_dst.data(), t.n_runs,
+                         (uint32_t const*)t.tile_row0.data(), t.nI, keys.data(), vals.data());
+    hipLaunchKernelGGL(k_wave_desc, grid_for(n_waves, kBlock), kBlock, 0, h.stream, (int32_t const*)t.item_tile.data(),
+                       (uint32_t const*)d_item_end.data(), t.n_items, (uint32_t const*)d_tile_off.data(), (uint32_t const*)d_tile_off_pad.data(),
+                       (uint32_t const*)flag32.data(), (uint32_t const*)ord.data(), (uint32_t const*)run_dst.data(), (uint32_t const*)t.tile_row0.data(), t.nI,
+                       t.n_runs, t.waves.data(), keys.data(), vals.data());
+    radix_sort_u64_u32(h, keys.data(), vals.data(), keys_tmp.data(), vals_tmp.data(), n_el, 0, bits_for_u((uint64_t)t.nI));
+    std::vector<uint32_t> first = key_starts(h, keys.data(), n_el, (int64_t)t.nI + 1);  // regions 0..nI (nI = dummy)
+    std::vector<uint32_t> shift(t.nI + 1);
+    for (int I = 0; I <= t.nI; ++I) {
+      region_off[I + 1] = region_off[I] + ((first[I + 1] - first[I] + 7u) & ~7u);
+      shift[I]          = region_off[I] - first[I];
+    }
+    t.n_slots = region_off[t.nI + 1];
+    size_t const spad = (size_t)t.n_slots + 64;
+    t.dstl16.resize_discard(spad);
+    HIP_TRY(hipMemsetAsync(t.dstl16.data(), 0, spad * sizeof(uint16_t), h.stream));
+    t.rpos.resize_discard(t.n_runs > 0 ? t.n_runs : 1);
+    dvec<uint32_t> d_shift;
+    to_device(h, d_shift, shift);
+    hipLaunchKernelGGL(k_assign_slots, grid_for(n_el, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), n_el,
+                       t.n_runs, (uint32_t const*)d_shift.data(), (uint32_t const*)run_dst.data(), (uint32_t const*)t.tile_row0.data(), t.nI, t.rpos.data(),
+                       t.waves.data(), t.dstl16.data());
+    h.sync();
+  } else {
+    t.n_slots = 0;
+    t.dstl16.resize_discard(64);
+    t.rpos.resize_discard(1);
+  }
+  to_device(h, t.region_off, region_off);
+
+  // ---- phase-1 chunks: up to TP_CHUNK consecutive items of one source tile; handed out dynamically in this order
+  {
+    size_t const lds = ((size_t)T + (size_t)TP_WAVES * TP_SUB) * vsize;
+    int const per_cu = std::max<int>(1, std::min<int>(2, (int)((h.lds_per_block - 1024) / (lds + 64))));
+    std::vector<int32_t> begin;
+    int const max_wg = h.num_cus * per_cu;
+    int const chunk  = std::max(1, std::min<int>(TP_CHUNK, t.n_items / (max_wg * 8)));  // >= 8 chunks per workgroup when possible
+    for (int i = 0; i < t.n_items;) {
+      begin.push_back(i);
+      int j = i + 1;
+      while (j < t.n_items && j - i < chunk && item_tile[j] == item_tile[i]) ++j;
+      i = j;
+    }
+    t.n_chunks = (int)begin.size();
+    begin.push_back(t.n_items);
+    t.n_wg = std::max(1, std::min<int>(t.n_chunks, h.num_cus * per_cu));
+    to_device(h, t.chunk_begin, begin);
+  }
+
+  // ---- bound used by the fixed-point accumulation of phase 2
+  t.wmax = (double)csc.max_degree;
+  if (has_weights && ne > 0) {
+    dvec<unsigned long long> mx(1);
+    HIP_TRY(hipMemsetAsync(mx.data(), 0, sizeof(unsigned long long), h.stream));
+    int const g = grid_for(nv * 16, kBlock, 8192);
+    if (vsize == 4) hipLaunchKernelGGL(k_row_abs_max<float>, g, kBlock, 0, h.stream, (int32_t const*)csc.offsets.data(), csc.weights.as<float const>(), nv, mx.data());
+    else            hipLaunchKernelGGL(k_row_abs_max<double>, g, kBlock, 0, h.stream, (int32_t const*)csc.offsets.data(), csc.weights.as<double const>(), nv, mx.data());
+    unsigned long long bits = 0;
+    h.read_back(&bits, mx.data(), 1);
+    std::memcpy(&t.wmax, &bits, sizeof(double));
+  }
+  t.built = true;
+  h.sync();
+}
+
+namespace {
+
+// =================================================================================================
+// per-iteration scalars: fixed-order fp64 reduction of the per-destination-tile (L1 change, dangling mass, max |x|)
+// partials; also picks the fixed-point scale of the next phase 2
+// =================================================================================================
+template <typename WT>
+struct fin_args {
+  double const* partials{nullptr};  // [n][3]; nullptr = nothing to finish
+  int n{0};
+  pr_scalars<WT>* scal{nullptr};
+  double* totals{nullptr};  // multi-GPU: this rank's (diff, dangling, xmax) go here instead of into scal
+  WT alpha{0};
+  int64_t nv_global{0};
+  int personalized{0};
+  double wmax{0};
+};
+
+// 2^k with  alpha * xmax * wmax * 2^k < 2^61  (every row sum of phase 2 fits a signed 64-bit accumulator with room to spare)
+__device__ __forceinline__ void fixed_point_scale(double bound, int32_t* k, double* inv)
+{
+  int kk = 0;
+  if (bound > 0.0 && bound < 1.0e300) {
+    int e;
+    (void)frexp(bound, &e);  // bound = m * 2^e, 0.5 <= m < 1  =>  bound < 2^e
+    kk = 61 - e;
+  }
+  kk   = max(-900, min(900, kk));
+  *k   = kk;
+  *inv = ldexp(1.0, -kk);
+}
+
+template <typename WT>
+__device__ __forceinline__ void write_scalars(pr_scalars<WT>* scal, double diff, double dang, double xmax, WT alpha, int64_t nv_global,
+                                              int personalized, double wmax)
+{
+  WT dangling       = (WT)dang;
+  WT factor         = dangling * alpha + (WT)(1.0 - (double)alpha);
+  scal->dangling    = dangling;
+  scal->diff        = (WT)diff;
+  scal->pers_factor = factor;
+  scal->base        = personalized ? WT(0) : factor / (WT)nv_global;
+  fixed_point_scale((double)alpha * xmax * wmax, &scal->fx_k, &scal->fx_inv);
+}
+
+// executed by ONE workgroup of `nthreads` threads; scratch = 3 * nthreads doubles of LDS
+template <typename WT>
+__device__ __forceinline__ void finish_scalars(fin_args<WT> const& f, double* scratch, int tid, int nthreads)
+{
+  double* r0 = scratch;
+  double* r1 = scratch + nthreads;
+  double* r2 = scratch + 2 * nthreads;
+  double d0 = 0, d1 = 0, d2 = 0;
+  for (int i = tid; i < f.n; i += nthreads) { d0 += f.partials[3 * i]; d1 += f.partials[3 * i + 1]; d2 = fmax(d2, f.partials[3 * i + 2]); }
+  r0[tid] = d0; r1[tid] = d1; r2[tid] = d2;
+  __syncthreads();
+  for (int s = nthreads >> 1; s > 0; s >>= 1) {
+    if (tid < s) { r0[tid] += r0[tid + s]; r1[tid] += r1[tid + s]; r2[tid] = fmax(r2[tid], r2[tid + s]); }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (f.totals) { f.totals[0] = r0[0]; f.totals[1] = r1[0]; f.totals[2] = r2[0]; }
+    else write_scalars<WT>(f.scal, r0[0], r1[0], r2[0], f.alpha, f.nv_global, f.personalized, f.wmax);
+  }
+  __syncthreads();
+}
+
+template <typename WT>
+__global__ void __launch_bounds__(TP2_BLOCK) k_tiled_finish(fin_args<WT> f)
+{
+  __shared__ double scratch[3 * TP2_BLOCK];
+  finish_scalars<WT>(f, scratch, threadIdx.x, TP2_BLOCK);
+}
+
+// multi-GPU: folds the per-rank (diff, dangling, xmax) triples found at stride `stride_bytes` in the all-gathered buffer
+template <typename WT>
+__global__ void k_tiled_scalars_from_ranks(unsigned char const* recv, size_t first_off, size_t stride_bytes, int nranks, fin_args<WT> f)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double diff = 0, dang = 0, xmax = 0;
+  for (int r = 0; r < nranks; ++r) {
+    double const* t = reinterpret_cast<double const*>(recv + first_off + (size_t)r * stride_bytes);
+    diff += t[0]; dang += t[1]; xmax = fmax(xmax, t[2]);
+  }
+  write_scalars<WT>(f.scal, diff, dang, xmax, f.alpha, f.nv_global, f.personalized, f.wmax);
+}
+
+// iteration-0 state: x = pr / out_w, partial dangling mass and max |x| per block
+template <typename WT>
+__global__ void __launch_bounds__(256) k_tiled_prologue(WT const* pr, WT const* outw, WT* x, int64_t nv, double* partials)
+{
+  __shared__ double red[8];
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double dang = 0.0, xmax = 0.0;
+  for (; i < nv; i += stride) {
+    WT p = pr[i], ow = outw[i];
+    WT xv = p / (ow == WT(0) ? WT(1) : ow);
+    x[i] = xv;
+    xmax = fmax(xmax, fabs((double)xv));
+    if (ow == WT(0)) dang += (double)p;
+  }
+  dang = group_sum(dang, 64);
+  for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_xor(xmax, o));
+  if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = dang; red[2 * (threadIdx.x >> 6) + 1] = xmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[3 * blockIdx.x]     = 0.0;
+    partials[3 * blockIdx.x + 1] = red[0] + red[2] + red[4] + red[6];
+    partials[3 * blockIdx.x + 2] = fmax(fmax(red[1], red[3]), fmax(red[5], red[7]));
+  }
+}
+
+// =================================================================================================
+// phase 1
+// =================================================================================================
+template <typename WT>
+struct p1_args {
+  uint16_t const* src16;
+  uint8_t const* bits;
+  WT const* weights;
+  uint32_t const* rpos;
+  int32_t const* item_tile;
+  tiled_wave_t const* waves;
+  int32_t const* chunk_begin;  // [n_chunks + 1] first work item of each chunk (items of a chunk share one source tile)
+  int n_chunks;
+  uint32_t* counter;           // chunk cursor: 0 on entry, reset by phase 2
+  int T;
+  WT const* x;
+  WT* part;
+  WT alpha;
+  uint32_t pmask, plog, chunk, ncols;
+  fin_args<WT> fin;  // scalars of the PREVIOUS iteration, folded by workgroup 0 before it starts streaming
+  unsigned long long* dbg{nullptr};  // CUGRAPH_AMD_TILED_DEBUG: per-workgroup (cycles, tile loads)
+};
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+struct p1_regs {  // one work item's data for one lane: TP_U rounds of 8 edges + the wavefront's descriptor
+  uint4 id[TP_U];
+  uint32_t fl[TP_U];
+  uint4 wd;  // tiled_wave_t (same address in every lane)
+};
+
+template <typename WT>
+__device__ __forceinline__ void p1_load(p1_args<WT> const& a, int item, int wave, int lane, p1_regs& r)
+{  // arrays are over-allocated and zero padded: no bounds checks, all loads of the item in flight together
+  uint32_t const es = (uint32_t)item * (uint32_t)TP_ITEM + (uint32_t)wave * TP_WLEN;
+#pragma unroll
+  for (int g = 0; g < TP_U; ++g) {
+    uint32_t e = es + g * TP_SUB + 8 * lane;
+    r.id[g]    = *reinterpret_cast<uint4 const*>(a.src16 + e);
+    r.fl[g]    = a.bits[e >> 3];
+  }
+  r.wd = *reinterpret_cast<uint4 const*>(a.waves + (size_t)item * TP_WAVES + wave);
+}
+
+// `stage`: this wavefront's TP_SUB-entry LDS scratch (run totals of one round, in run order)
+template <typename WT, bool WEIGHTED>
+__device__ __forceinline__ void p1_process(p1_args<WT> const& a, WT const* xs, WT* stage, int lane, p1_regs const& rg)
+{
+  uint32_t const es = rfl(rg.wd.x), ee = rfl(rg.wd.y), rank = rfl(rg.wd.z), head_slot = rfl(rg.wd.w);
+  if (es >= ee) return;  // empty share (tail of a tile)
+
+  // ---- pass A (bitmap only): run counts of every round, then the slots of the first 64 runs of each round are
+  // requested right away -- their latency hides behind the LDS gathers and scans of pass B
+  uint32_t f[TP_U], nf[TP_U], ex_c[TP_U], c_all[TP_U], closed_at[TP_U], slot0[TP_U];
+  {
+    uint32_t closed = 0;
+#pragma unroll
+    for (int g = 0; g < TP_U; ++g) {
+      uint32_t const e     = es + g * TP_SUB + 8 * lane;
+      uint32_t const nval  = min((uint32_t)8, ee > e ? ee - e : 0u);
+      f[g]                 = rg.fl[g] & ((1u << nval) - 1u);
+      nf[g]                = __popc(f[g]);
+      uint32_t const c_inc = wave_inclusive_sum_u32(nf[g]);
+      ex_c[g]              = c_inc - nf[g];
+      c_all[g]             = (uint32_t)__builtin_amdgcn_readlane((int)c_inc, 63);
+      closed_at[g]         = closed;
+      closed += c_all[g];
+    }
+#pragma unroll
+    for (int g = 0; g < TP_U; ++g) {
+      // ordinal n within the wavefront's range: n = 0 is the run that was already open at `es` (its partial goes to the
+      // head slot), n >= 1 is run (rank - 1 + n)
+      uint32_t const n = closed_at[g] + (uint32_t)lane;
+      slot0[g]         = head_slot;
+      if ((uint32_t)lane < c_all[g] && n != 0) slot0[g] = a.rpos[rank - 1 + n];
+    }
+  }
+
+  // ---- pass B: values
+  WT carry = 0;  // running sum of the run open at the current position (wave-uniform)
+#pragma unroll
+  for (int g = 0; g < TP_U; ++g) {
+    uint32_t const e = es + g * TP_SUB + 8 * lane;
+    if (es + g * TP_SUB >= ee) break;  // wave-uniform
+    uint32_t const w4[4] = {rg.id[g].x, rg.id[g].y, rg.id[g].z, rg.id[g].w};
+    WT v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      uint32_t i = (k & 1) ? (w4[k >> 1] >> 16) : (w4[k >> 1] & 0xFFFFu);
+      v[k]       = xs[i];
+    }
+    if constexpr (WEIGHTED) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] *= a.weights[e + k];
+    }
+    if (e + 8 > ee) {
+      uint32_t const nval = ee > e ? ee - e : 0u;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (uint32_t)k < nval ? v[k] : WT(0);
+    }
+
+    if (c_all[g] == 0) {  // no run starts in these 512 edges (inside a long run): plain wave sum
+      WT t = wave_sum_to_lane63(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+      carry += read_lane63(t);
+      continue;
+    }
+    // in-lane: r[k] = running sum since the last run start at or before element k
+    uint32_t const fg = f[g];
+    WT r[8];
+    r[0] = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) r[k] = ((fg >> k) & 1u) ? v[k] : r[k - 1] + v[k];
+    WT s       = r[7];
+    uint32_t c = nf[g];
+    wave_seg_scan(s, c);
+    WT const ex_s     = dpp_val<0x138, 0xF>(s);  // wave_shr:1 (lane 0 reads 0)
+    WT const carry_in = ex_c[g] ? ex_s : ex_s + carry;
+    if (fg) {  // the run closed by a start at element k ran up to element k - 1; totals go to LDS in run order
+      uint32_t pos = ex_c[g];
+      bool first   = true;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if ((fg >> k) & 1u) {
+          WT before  = k == 0 ? WT(0) : r[k - 1];
+          stage[pos] = first ? carry_in + before : before;
+          first      = false;
+          ++pos;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // coalesced write-out: lane i takes the i-th run closed in this round
+    if ((uint32_t)lane < c_all[g]) a.part[slot0[g]] = stage[lane];
+    for (uint32_t i = 64 + lane; i < c_all[g]; i += 64) a.part[a.rpos[rank - 1 + closed_at[g] + i]] = stage[i];
+    __builtin_amdgcn_wave_barrier();  // the next round overwrites the staging area
+    carry = read_lane63(s);           // c_all != 0: the open run started inside this round
+  }
+  if (lane == 0) {  // the run still open at the end of the range (it may continue in the next wavefront's range: that
+                    // wavefront contributes its part through its own head slot)
+    uint32_t const closed = closed_at[TP_U - 1] + c_all[TP_U - 1];
+    uint32_t sl = closed == 0 ? head_slot : a.rpos[rank - 1 + closed];
+    a.part[sl]  = carry;
+  }
+}
+
+template <typename WT, bool WEIGHTED, bool MG>
+__global__ void __launch_bounds__(TP_BLOCK) k_tiled_phase1(p1_args<WT> a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  WT* xs = reinterpret_cast<WT*>(smem);
+  __shared__ int s_chunk[3];
+  int const tid = threadIdx.x, lane = tid & 63;
+  int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  WT* stage = xs + a.T + wave * TP_SUB;
+
+  if (blockIdx.x == 0 && a.fin.partials) finish_scalars<WT>(a.fin, reinterpret_cast<double*>(smem), tid, TP_BLOCK);
+
+  // Work is handed out dynamically in CHUNKS (a few consecutive work items of one source tile; hottest tiles first, the
+  // small cold tiles last), two chunks ahead, so that the first item of the next chunk is already on its way while the
+  // current chunk is processed.  One barrier per chunk; the LDS tile is reloaded only when the source tile changes.
+  unsigned long long const t_start = wall_clock64();
+  int n_tiles = 0;
+  if (tid == 0) { s_chunk[0] = (int)atomicAdd(a.counter, 1u); s_chunk[1] = (int)atomicAdd(a.counter, 1u); }
+  __syncthreads();
+  int curJ = -1;
+  p1_regs r0, r1;
+  {
+    int const c0 = s_chunk[0];
+    if (c0 < a.n_chunks) p1_load<WT>(a, a.chunk_begin[c0], wave, lane, r0);
+  }
+  bool cur_is_r0 = true;
+  for (int it = 0;; ++it) {
+    int const c = s_chunk[it % 3], cn = s_chunk[(it + 1) % 3];
+    if (c >= a.n_chunks) break;
+    if (tid == 0) s_chunk[(it + 2) % 3] = (int)atomicAdd(a.counter, 1u);
+    int item = a.chunk_begin[c];
+    int const item_end  = a.chunk_begin[c + 1];
+    int const next_item = cn < a.n_chunks ? a.chunk_begin[cn] : -1;  // first item of the next chunk
+    auto body = [&](p1_regs const& cur, p1_regs& nxt) {
+      int const J   = a.item_tile[item];
+      int const pre = item + 1 < item_end ? item + 1 : next_item;
+      if (pre >= 0) p1_load<WT>(a, pre, wave, lane, nxt);
+      if (J != curJ) {  // only at the first item of a chunk: every wavefront has passed the chunk barrier
+        if constexpr (MG) {
+          uint32_t c0 = (uint32_t)J * (uint32_t)a.T;
+          for (int i = tid; i < a.T; i += TP_BLOCK) {
+            uint32_t cc = c0 + (uint32_t)i;
+            xs[i]       = cc < a.ncols ? a.x[(size_t)(cc & a.pmask) * a.chunk + (cc >> a.plog)] * a.alpha : WT(0);
+          }
+        } else {  // x is allocated (and zero-filled) up to nJ * T elements
+          using vec4 = typename std::conditional<sizeof(WT) == 4, float4, double4>::type;
+          vec4 const* src = reinterpret_cast<vec4 const*>(a.x + (size_t)J * a.T);
+          vec4* dst       = reinterpret_cast<vec4*>(xs);
+          for (int i = tid; i < a.T / 4; i += TP_BLOCK) {
+            vec4 v = src[i];
+            v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
+            dst[i] = v;
+          }
+        }
+        __syncthreads();
+        curJ = J;
+        ++n_tiles;
+      }
+      p1_process<WT, WEIGHTED>(a, xs, stage, lane, cur);
+      ++item;
+    };
+    while (item < item_end) {
+      if (cur_is_r0) body(r0, r1); else body(r1, r0);
+      cur_is_r0 = !cur_is_r0;
+    }
+    __syncthreads();  // chunk done: the tile may be replaced, s_chunk[(it + 2) % 3] is visible
+  }
+  if (a.dbg) {
+    __syncthreads();
+    if (tid == 0) { a.dbg[2 * blockIdx.x] = wall_clock64() - t_start; a.dbg[2 * blockIdx.x + 1] = (unsigned long long)n_tiles; }
+  }
+}
+
+// =================================================================================================
+// phase 2 + PageRank epilogue
+// =================================================================================================
+template <typename WT>
+struct p2_args {
+  WT const* part;
+  uint16_t const* dstl16;
+  uint32_t const* tile_row0;
+  uint32_t const* region_off;
+  int nI;
+  tiled_epilogue<WT> e;
+  uint32_t* counters;
+};
+
+// fp32 partials are accumulated as signed 64-bit fixed point (value * 2^k, truncated): LDS integer atomics run at
+// full rate on gfx950 while ds_add_f32 is ~5x slower (tools/ubench/lds_update_bench.hip), and integer addition is
+// associative, so the result does not depend on the order in which wavefronts reach a row (bit-reproducible).
+__device__ __forceinline__ unsigned long long to_fixed(float v, int k)
+{
+  uint32_t const b = __float_as_uint(v);
+  int const e      = (int)((b >> 23) & 0xFFu);
+  unsigned long long m = (unsigned long long)((b & 0x7FFFFFu) | 0x800000u);
+  int const sh     = e - 150 + k;  // v = m * 2^(e - 150)
+  unsigned long long fx = sh >= 0 ? m << min(sh, 63) : m >> min(-sh, 63);
+  fx = e == 0 ? 0ull : fx;         // zero / denormal
+  return (b >> 31) ? (0ull - fx) : fx;
+}
+
+template <typename WT> struct p2_acc { using type = WT; };
+template <> struct p2_acc<float> { using type = unsigned long long; };
+
+template <typename WT, bool PERS>
+__global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
+{
+  using ACC = typename p2_acc<WT>::type;
+  constexpr int RPT = TP2_ROWS / TP2_BLOCK;  // rows per thread in the epilogue
+  __shared__ ACC acc[TP2_ROWS];
+  __shared__ double red[3 * (TP2_BLOCK / 64)];
+  int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int const I   = blockIdx.x;
+  uint32_t const row0 = a.tile_row0[I], nrows = a.tile_row0[I + 1] - row0;
+  uint32_t const s0 = a.region_off[I], s1 = a.region_off[I + 1];
+  tiled_epilogue<WT> const& e = a.e;
+  pr_scalars<WT> const sc     = *e.scal;
+
+  // the epilogue's inputs do not depend on the accumulation: request them first
+  WT old[RPT], ow[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    uint32_t i = tid + j * TP2_BLOCK;
+    old[j] = i < nrows ? e.pr[(size_t)row0 + i] : WT(0);
+    ow[j]  = i < nrows ? e.outw[(size_t)row0 + i] : WT(1);
+  }
+  for (uint32_t i = tid; i < nrows; i += TP2_BLOCK) acc[i] = ACC(0);
+  __syncthreads();
+  for (uint32_t s = s0 + 8 * tid; s < s1; s += 8 * TP2_BLOCK) {
+    uint4 const d = *reinterpret_cast<uint4 const*>(a.dstl16 + s);
+    WT v[8];
+    if constexpr (sizeof(WT) == 4) {
+      float4 const p0 = *reinterpret_cast<float4 const*>(a.part + s), p1 = *reinterpret_cast<float4 const*>(a.part + s + 4);
+      v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double2 const p = *reinterpret_cast<double2 const*>(a.part + s + 2 * k);
+        v[2 * k] = p.x; v[2 * k + 1] = p.y;
+      }
+    }
+    uint32_t const w4[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      uint32_t i = (k & 1) ? (w4[k >> 1] >> 16) : (w4[k >> 1] & 0xFFFFu);
+      if constexpr (sizeof(WT) == 4) atomicAdd(&acc[i], to_fixed(v[k], sc.fx_k));  // ds_add_u64; padding slots hold 0
+      else atomicAdd(&acc[i], v[k]);                                              // ds_add_f64
+    }
+  }
+  __syncthreads();
+
+  double diff = 0.0, dang = 0.0, xmax = 0.0;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    uint32_t i = tid + j * TP2_BLOCK;
+    if (i < nrows) {
+      size_t const v = (size_t)row0 + i;
+      WT sum;
+      if constexpr (sizeof(WT) == 4) sum = (WT)((double)(long long)acc[i] * sc.fx_inv);
+      else sum = acc[i];
+      WT val = sc.base + sum;
+      if constexpr (PERS) val += sc.pers_factor * e.pers[v];
+      WT const xn = val / (ow[j] == WT(0) ? WT(1) : ow[j]);
+      e.pr[v]     = val;
+      e.x_next[v] = xn;
+      diff += (double)fabs(val - old[j]);
+      xmax = fmax(xmax, fabs((double)xn));
+      if (ow[j] == WT(0)) dang += (double)val;
+    }
+  }
+  diff = group_sum(diff, 64);
+  dang = group_sum(dang, 64);
+  for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_xor(xmax, o));
+  if (lane == 0) { red[3 * wave] = diff; red[3 * wave + 1] = dang; red[3 * wave + 2] = xmax; }
+  __syncthreads();
+  if (tid == 0) {  // folded by the next phase-1 launch (or k_tiled_finish): no device-scope fence per workgroup here
+    if (I == 0) a.counters[0] = 0;  // phase 1 is over: rewind its chunk cursor for the next iteration
+    double d0 = 0, d1 = 0, d2 = 0;
+#pragma unroll
+    for (int k = 0; k < TP2_BLOCK / 64; ++k) { d0 += red[3 * k]; d1 += red[3 * k + 1]; d2 = fmax(d2, red[3 * k + 2]); }
+    e.partials[3 * I]     = d0;
+    e.partials[3 * I + 1] = d1;
+    e.partials[3 * I + 2] = d2;
+  }
+}
+
+template <typename K>
+void ensure_max_lds(K kernel, int bytes)
+{
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes - 1024));  // the kernels also hold a few static LDS words
+}
+
+template <typename WT>
+fin_args<WT> make_fin(tiled_epilogue<WT> const& e, int n)
+{
+  fin_args<WT> f;
+  f.partials = e.partials; f.n = n; f.scal = e.scal; f.totals = e.totals; f.alpha = e.alpha; f.nv_global = e.nv_global;
+  f.personalized = e.pers != nullptr;
+  f.wmax = e.wmax;
+  return f;
+}
+
+}  // namespace
+
+template <typename WT>
+void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha, WT* part, uint32_t* counters, tiled_x_map<WT> const& map,
+                  tiled_epilogue<WT> const* pending)
+{
+  if (t.n_items == 0) {
+    if (pending) tiled_finish<WT>(h, *pending, t.nI);
+    return;
+  }
+  p1_args<WT> a;
+  a.src16     = t.src16.data();
+  a.bits      = reinterpret_cast<uint8_t const*>(t.bits.data());
+  a.weights   = t.weights.ptr ? t.weights.as<WT const>() : nullptr;
+  a.rpos      = t.rpos.data();
+  a.item_tile = t.item_tile.data();
+  a.waves     = t.waves.data();
+  a.chunk_begin = t.chunk_begin.data();
+  a.n_chunks    = t.n_chunks;
+  a.counter     = counters;
+  a.T         = t.T;
+  a.x         = x;
+  a.part      = part;
+  a.alpha     = alpha;
+  a.pmask = map.pmask; a.plog = map.plog; a.chunk = map.chunk; a.ncols = map.ncols;
+  if (pending) a.fin = make_fin<WT>(*pending, t.nI);
+  size_t const lds = std::max<size_t>(((size_t)t.T + (size_t)TP_WAVES * TP_SUB) * sizeof(WT), 3 * TP_BLOCK * sizeof(double));
+  bool const w     = a.weights != nullptr;
+  static bool attr_done[4] = {false, false, false, false};
+  static int dbg_calls = getenv("CUGRAPH_AMD_TILED_DEBUG") ? 3 : 0;
+  dvec<unsigned long long> dbg;
+  if (dbg_calls > 0) { dbg.resize_discard((size_t)2 * t.n_wg); a.dbg = dbg.data(); }
+  auto launch = [&](auto kernel, int slot) {
+    if (!attr_done[slot]) { ensure_max_lds(kernel, (int)h.lds_per_block); attr_done[slot] = true; }
+    timed_launch tl(h, "pagerank_spmv");
+    hipLaunchKernelGGL(kernel, t.n_wg, TP_BLOCK, lds, h.stream, a);
+  };
+  if (map.mg) { if (w) launch(k_tiled_phase1<WT, true, true>, 0); else launch(k_tiled_phase1<WT, false, true>, 1); }
+  else        { if (w) launch(k_tiled_phase1<WT, true, false>, 2); else launch(k_tiled_phase1<WT, false, false>, 3); }
+  if (a.dbg) {
+    --dbg_calls;
+    std::vector<unsigned long long> d = to_host(h, dbg.data(), (size_t)2 * t.n_wg);
+    std::vector<unsigned long long> v;
+    for (int b = 0; b < t.n_wg; ++b) v.push_back(d[2 * b]);
+    std::sort(v.begin(), v.end());
+    fprintf(stderr, "[tiled phase1] %d workgroups, %d items, %d chunks; ticks (100 MHz) min %llu p10 %llu p50 %llu p90 %llu max %llu\n", t.n_wg, t.n_items,
+            t.n_chunks, v[0], v[t.n_wg / 10], v[t.n_wg / 2], v[t.n_wg * 9 / 10], v[t.n_wg - 1]);
+  }
+}
+
+template <typename WT>
+void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters)
+{
+  p2_args<WT> a;
+  a.part       = part;
+  a.dstl16     = t.dstl16.data();
+  a.tile_row0  = t.tile_row0.data();
+  a.region_off = t.region_off.data();
+  a.nI         = t.nI;
+  a.e          = e;
+  a.counters   = counters;
+  timed_launch tl(h, "pagerank_reduce");
+  if (e.pers) hipLaunchKernelGGL((k_tiled_phase2<WT, true>), t.nI, TP2_BLOCK, 0, h.stream, a);
+  else        hipLaunchKernelGGL((k_tiled_phase2<WT, false>), t.nI, TP2_BLOCK, 0, h.stream, a);
+}
+
+template <typename WT>
+void tiled_finish(handle_t const& h, tiled_epilogue<WT> const& e, int n_partials)
+{
+  hipLaunchKernelGGL(k_tiled_finish<WT>, 1, TP2_BLOCK, 0, h.stream, make_fin<WT>(e, n_partials));
+}
+
+template <typename WT>
+int tiled_prologue(handle_t const& h, tiled_csc_t const& t, WT const* pr, WT const* outw, WT* x, int64_t nv, double* partials)
+{
+  int const grid = std::max(1, std::min(t.nI, grid_for(nv, 256, 1024)));
+  hipLaunchKernelGGL(k_tiled_prologue<WT>, grid, 256, 0, h.stream, pr, outw, x, nv, partials);
+  return grid;
+}
+
+template <typename WT>
+void tiled_scalars_from_ranks(handle_t const& h, tiled_epilogue<WT> const& e, void const* recv, size_t first_off, size_t stride_bytes, int nranks)
+{
+  hipLaunchKernelGGL(k_tiled_scalars_from_ranks<WT>, 1, 64, 0, h.stream, static_cast<unsigned char const*>(recv), first_off, stride_bytes, nranks,
+                     make_fin<WT>(e, 0));
+}
+
+#define CGA_INSTANTIATE_TILED(WT)                                                                                                          \
+  template void tiled_phase1<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT, WT*, uint32_t*, tiled_x_map<WT> const&, tiled_epilogue<WT> const*); \
+  template void tiled_phase2<WT>(handle_t const&, tiled_csc_t const&, WT const*, tiled_epilogue<WT> const&, uint32_t*);                                  \
+  template void tiled_finish<WT>(handle_t const&, tiled_epilogue<WT> const&, int);                                                           \
+  template int tiled_prologue<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT const*, WT*, int64_t, double*);                          \
+  template void tiled_scalars_from_ranks<WT>(handle_t const&, tiled_epilogue<WT> const&, void const*, size_t, size_t, int);
+CGA_INSTANTIATE_TILED(float)
+CGA_INSTANTIATE_TILED(double)
+
+}  // namespace cga

@@ -1,0 +1,131 @@
+// Column-tiled two-phase pull-SpMV for gfx950: every gather of the source-vertex vector is served from LDS.
+//
+// Replaces the reference's per_v_transform_reduce_incoming_e kernels on the PageRank path
+// (cpp/include/cugraph/prims/detail/per_v_transform_reduce_e.cuh:252/389/500/688) -- see DESIGN.md, "tiled SpMV".
+//
+// Why: on MI355X a random 4-byte gather that misses LDS costs one L2 (or Infinity-Cache / HBM) request per edge and
+// the texture-addresser path tops out near 260 G requests/s even when the whole vector is L2-resident (measured,
+// tools/ubench/gather_bench.hip) -- 3x below what an HBM-bound edge stream needs.  So the edge list is re-blocked once
+// per graph:
+//   * sources are cut into tiles of T consecutive ids (T * sizeof(weight) = 128 KiB of LDS);
+//   * edges are ordered by (source tile J, destination, source); a maximal group of edges with equal (J, destination)
+//     is a RUN; per edge we keep a 16-bit tile-local source id and one bit "starts a run";
+//   * phase 1 (k_tiled_phase1): a workgroup stages x[J*T, (J+1)*T) * alpha in LDS, streams its share of tile J's
+//     edges (2 bytes + 1 bit each), forms the run sums with an in-lane pass + wave64 DPP segmented scan, and stores
+//     one partial per run into a slot of the partial buffer;
+//   * destinations are cut into tiles I (<= 8192 rows, equal cost); the slots of all runs whose destination lies in I
+//     form the contiguous REGION I (ordered by J, then destination);
+//   * phase 2 (k_tiled_phase2): one workgroup per destination tile streams its region (4-byte partial + 16-bit
+//     tile-local destination), accumulates in LDS (ds_add), and runs the fused PageRank epilogue for its rows
+//     (new pr, next x = pr / out_w, L1 change, dangling mass); workgroup 0 of the next phase 1 folds the per-tile
+//     scalar partials in a fixed order into the next iteration's constants (no extra launch, no device-scope fences).
+//     fp32 partials are accumulated in 64-bit fixed point: LDS integer atomics run at full rate on gfx950 (ds_add_f32
+//     is ~5x slower) and make the result independent of the accumulation order.
+// HBM traffic per iteration = 2.125 E + 14 P + 16 V bytes (P = number of runs; RMAT-22: P = 0.15 E, RMAT-26: 0.29 E),
+// all of it streaming; nothing is gathered from global memory.
+#pragma once
+
+#include "common.hpp"
+
+namespace cga {
+
+template <typename WT>
+struct pr_scalars {  // device-resident PageRank loop state
+  WT base;         // (alpha * dangling + (1 - alpha)) / V, or 0 when personalized
+  WT pers_factor;  // alpha * dangling + (1 - alpha)
+  WT dangling;
+  WT diff;
+  int32_t fx_k;   // tiled path, fp32: phase 2 accumulates value * 2^fx_k in 64-bit fixed point
+  double fx_inv;  // 2^-fx_k
+};
+
+constexpr int TP_BLOCK = 1024;               // phase-1 workgroup: 16 wavefronts sharing one LDS tile
+constexpr int TP_WAVES = TP_BLOCK / 64;
+constexpr int TP_SUB   = 512;                // edges per wavefront per load round (8 per lane, one 16-byte load)
+constexpr int TP_U     = 4;                  // load rounds in flight
+constexpr int TP_WLEN  = TP_SUB * TP_U;      // edges per wavefront per work item
+constexpr int TP_ITEM  = TP_WLEN * TP_WAVES;  // edges per work item
+constexpr int TP_CHUNK = 4;                  // work items per dynamically scheduled chunk
+constexpr int TP2_BLOCK = 512;               // phase-2 workgroup
+constexpr int TP2_ROWS  = 4096;              // max destination rows per phase-2 tile (64-bit LDS accumulators: 32 KiB)
+
+struct tiled_wave_t {  // static description of one wavefront's share of a work item
+  uint32_t es, ee;     // padded edge positions [es, ee); es is a multiple of 8
+  uint32_t rank;       // number of run starts before es (global run ordinal of the first run that starts in the range)
+  uint32_t head_slot;  // slot for the partial of the run already open at es (dummy slot when there is none)
+};
+
+struct tiled_csc_t {
+  bool built{false};
+  int T{0};    // sources per tile
+  int nJ{0};   // source tiles
+  int nI{0};   // destination tiles
+  int n_items{0};
+  int n_wg{0};  // phase-1 workgroups
+  int n_chunks{0};
+  int64_t nv{0}, ne{0}, ne_pad{0}, n_runs{0}, n_slots{0};
+  double wmax{0};  // max over destinations of sum |w| of the in-edges (in-degree when unweighted): bounds a row sum by alpha * max|x| * wmax
+  dvec<uint16_t> src16;       // [ne_pad + pad] tile-local source id
+  dvec<uint32_t> bits;        // [ne_pad / 32 + pad] bit p = edge position p starts a run
+  dev_buf weights;            // [ne_pad + pad] or empty
+  dvec<uint32_t> rpos;        // [n_runs] slot of run q
+  dvec<int32_t> item_tile;    // [n_items] source tile of work item
+  dvec<tiled_wave_t> waves;   // [n_items * TP_WAVES]
+  dvec<int32_t> chunk_begin;  // [n_chunks + 1] first item of each chunk (<= TP_CHUNK items of one source tile)
+  dvec<uint32_t> tile_row0;   // [nI + 1] destination tile boundaries
+  dvec<uint32_t> region_off;  // [nI + 2] slot range of region I (multiples of 8); region nI = dummy
+  dvec<uint16_t> dstl16;      // [n_slots + pad] tile-local destination of slot
+};
+
+// Re-blocks the CSC orientation of g (offsets / indices / weights) into tiles of T sources.
+// `vsize` = sizeof(value type); weights (if any) have the same type.
+void build_tiled_csc(handle_t const& h, int64_t nv, int64_t ne, orientation_t const& csc, bool has_weights, size_t vsize, int T,
+                     tiled_csc_t& t);
+
+template <typename WT>
+struct tiled_x_map {  // where x[c] lives; single GPU: identity.  Multi-GPU all-gather buffer: (c & pmask) * chunk + (c >> plog)
+  uint32_t pmask{0}, plog{0}, chunk{0}, ncols{0};
+  bool mg{false};
+};
+
+template <typename WT>
+struct tiled_epilogue {
+  int64_t nv{0};         // rows (local rows in the multi-GPU case)
+  WT* pr{nullptr};       // in: previous iterate, out: new iterate
+  WT* x_next{nullptr};   // pr / out_w (next gather vector; the multi-GPU send chunk)
+  WT const* outw{nullptr};
+  WT const* pers{nullptr};  // dense normalised personalization or nullptr
+  pr_scalars<WT>* scal{nullptr};
+  double* partials{nullptr};  // [max(nI, 1024)][3] per-destination-tile (L1 change, dangling mass, max |x_next|)
+  double* totals{nullptr};    // multi-GPU: the folded (diff, dangling, xmax) of this rank are written here instead of into scal
+  WT alpha{0};
+  int64_t nv_global{0};
+  double wmax{0};             // tiled_csc_t::wmax
+};
+
+// phase 1: part[slot of run] = sum over the run's edges of alpha * x[src] (* w).  counters[0] = chunk cursor (0 on entry;
+// phase 2 rewinds it).  `pending` != nullptr: the scalars of the
+// previous phase 2 have not been folded yet -- workgroup 0 does it first (saves a launch per iteration).
+template <typename WT>
+void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha, WT* part, uint32_t* counters, tiled_x_map<WT> const& map,
+                  tiled_epilogue<WT> const* pending);
+
+// phase 2 + fused PageRank epilogue; leaves per-tile scalar partials in e.partials (fold them with the next phase 1 or tiled_finish)
+template <typename WT>
+void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters);
+
+// folds e.partials[0 .. n_partials) in a fixed order into e.scal (or e.totals)
+template <typename WT>
+void tiled_finish(handle_t const& h, tiled_epilogue<WT> const& e, int n_partials);
+
+// iteration-0 state: x = pr / out_w plus per-block (0, dangling, max |x|) partials; returns the number of partial triples
+template <typename WT>
+int tiled_prologue(handle_t const& h, tiled_csc_t const& t, WT const* pr, WT const* outw, WT* x, int64_t nv, double* partials);
+
+// multi-GPU: e.scal <- fold of the per-rank (diff, dangling, xmax) triples at recv + first_off + r * stride_bytes
+template <typename WT>
+void tiled_scalars_from_ranks(handle_t const& h, tiled_epilogue<WT> const& e, void const* recv, size_t first_off, size_t stride_bytes, int nranks);
+
+int tiled_default_T(handle_t const& h, size_t weight_size, int64_t nv);
+
+}  // namespace cga

@@ -259,15 +259,20 @@ def test_pagerank_converged_iterations_and_initial_guess(cg, handle, orc):
     assert np.array_equal(by_vertex(v3, pr3)[0], by_vertex(v4, pr4)[0])
 
 
-def test_pagerank_is_deterministic(cg, handle, orc):
+def test_pagerank_is_reproducible(cg, handle, orc, monkeypatch):
+    """The single-pass kernels reduce in a fixed order (bit-reproducible); the tiled default accumulates the per-run
+    partials with LDS floating-point atomics, so repeated runs agree to fp32 round-off only."""
     s, d = rmat_graph(orc, 15)
     g = make_graph(cg, handle, s, d, None, transposed=True, renumber=True)
-    a = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 10, False, fail_on_nonconvergence=False)[1].cpu().numpy()
-    b = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 10, False, fail_on_nonconvergence=False)[1].cpu().numpy()
+    run = lambda: cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 10, False, fail_on_nonconvergence=False)[1].cpu().numpy()
+    a, b = run(), run()
+    np.testing.assert_allclose(a, b, rtol=2e-6)
+    monkeypatch.setenv("CUGRAPH_AMD_PAGERANK_KERNEL", "flat")
+    a, b = run(), run()
     assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("hot", [0, 1024, 16384, 32768])
+@pytest.mark.parametrize("hot", [0, 256, 1024, 16384, 32768])
 def test_pagerank_lds_tile_sizes_agree(cg, handle, orc, hot):
     s, d = rmat_graph(orc, 15, seed=2)
     nv = 1 << 15
@@ -362,7 +367,7 @@ def test_pagerank_flat_and_row_kernels_agree(cg, handle, orc, scale, weighted, m
     w = int_weights(s.size) if weighted else None
     g = make_graph(cg, handle, s, d, w, transposed=True, renumber=True, vertices=np.arange(nv))
     res = {}
-    for kern in ("flat", "rows"):
+    for kern in ("tiled", "flat", "rows"):
         monkeypatch.setenv("CUGRAPH_AMD_PAGERANK_KERNEL", kern)
         v, pr, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 12, False, fail_on_nonconvergence=False)
         res[kern] = by_vertex(v, pr)[0]
@@ -372,19 +377,52 @@ def test_pagerank_flat_and_row_kernels_agree(cg, handle, orc, scale, weighted, m
         assert np.max(np.abs(res[kern] - truth)) <= 1e-6
         assert np.max(np.abs(res[kern] - truth) / truth) <= 2e-5, kern
     np.testing.assert_allclose(res["flat"], res["rows"], rtol=1e-5)
+    np.testing.assert_allclose(res["tiled"], res["rows"], rtol=1e-5)
 
 
-def test_pagerank_flat_ragged_ranges(cg, handle, orc):
-    """Edge counts that are not multiples of the 1024-edge chunk, a hub row spanning many wave ranges, and
-    single-edge rows: the stitched partial rows must still be exact."""
+@pytest.mark.parametrize("kern,tile", [("tiled", 0), ("tiled", 256), ("tiled", 1000), ("flat", 0)])
+def test_pagerank_ragged_ranges(cg, handle, orc, kern, tile, monkeypatch):
+    """Edge counts that are not multiples of the per-wavefront chunk, a hub row spanning many wavefront ranges (and,
+    tiled, many source tiles), and single-edge rows: the stitched partial sums must still be exact."""
+    monkeypatch.setenv("CUGRAPH_AMD_PAGERANK_KERNEL", kern)
+    prev = handle.set_pagerank_hot_tile(tile if tile else -1)
     rng = np.random.default_rng(11)
     nv = 5000
     hub_in = rng.integers(0, nv, 70001)                      # 70001 in-edges of vertex 7
     s = np.concatenate([hub_in, rng.integers(0, nv, 12345), np.arange(100, 1100)])
     d = np.concatenate([np.full(hub_in.size, 7), rng.integers(0, nv, 12345), np.arange(2000, 3000)])
     g = make_graph(cg, handle, s, d, None, transposed=True, renumber=True, vertices=np.arange(nv))
-    v, pr, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 15, False, fail_on_nonconvergence=False)
+    try:
+        v, pr, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 15, False, fail_on_nonconvergence=False)
+    finally:
+        handle.set_pagerank_hot_tile(prev)
     off, idx, _ = orc.coo_to_cs(nv, d.astype(np.int32), s.astype(np.int32))
     truth, _, _ = orc.pagerank(nv, off, idx, None, 0.85, 0.0, 15, acc64=True)
     got = by_vertex(v, pr)[0]
     assert np.max(np.abs(got - truth) / truth) <= 2e-5
+
+
+@pytest.mark.parametrize("tile", [0, 512])
+def test_pagerank_tiled_fp64_weights_and_personalization(cg, handle, orc, tile):
+    """fp64 weights select the double-precision instantiation of both phases; personalization goes through the fused epilogue."""
+    scale = 13
+    s, d = rmat_graph(orc, scale, seed=9)
+    nv = 1 << scale
+    w = int_weights(s.size, seed=3).astype(np.float64)
+    g = make_graph(cg, handle, s, d, w, transposed=True, renumber=True, vertices=np.arange(nv), wdtype=np.float64)
+    prev = handle.set_pagerank_hot_tile(tile if tile else -1)
+    try:
+        v, pr, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 15, False, fail_on_nonconvergence=False)
+        pv = np.array([3, 77, 1000, 4095], np.int32)
+        pw = np.array([0.1, 0.2, 0.3, 0.4], np.float64)
+        v2, pr2, _ = cg.personalized_pagerank(handle, g, None, None, None, None, T(pv, np.int32), T(pw, np.float64), 0.85, 0.0, 15, False,
+                                              fail_on_nonconvergence=False)
+    finally:
+        handle.set_pagerank_hot_tile(prev)
+    off, idx, ww = orc.coo_to_cs(nv, d, s, w)
+    truth, _, _ = orc.pagerank(nv, off, idx, ww, 0.85, 0.0, 15, acc64=True, dtype=np.float64)
+    got = by_vertex(v, pr)[0]
+    assert got.dtype == np.float64
+    np.testing.assert_allclose(got, truth, rtol=1e-9)
+    truth2, _, _ = orc.pagerank(nv, off, idx, ww, 0.85, 0.0, 15, acc64=True, personalization=(pv, pw), dtype=np.float64)
+    np.testing.assert_allclose(by_vertex(v2, pr2)[0], truth2, rtol=1e-9, atol=1e-18)

@@ -29,7 +29,7 @@ def summarize(db):
             for k, cn, v, n in rows:
                 agg[k][cn] = (v, n)
             for k, d in agg.items():
-                if "spmv" in k or "expand" in k:
+                if any(t in k for t in ("spmv", "tiled", "bfs", "sssp", "advance")):
                     print(f"  PMC {k[:80]}")
                     for cn, (v, n) in sorted(d.items()):
                         print(f"      {cn:<40} avg/dispatch = {v:,.1f}   (n={n})")
