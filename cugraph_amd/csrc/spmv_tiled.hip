@@ -571,112 +571,141 @@ __device__ __forceinline__ void p1_load(p1_args<WT> const& a, int item, int wave
   r.wd = *reinterpret_cast<uint4 const*>(a.waves + (size_t)item * TP_WAVES + wave);
 }
 
-// `stage`: this wavefront's TP_SUB-entry LDS scratch (run totals of one round, in run order)
-template <typename WT, bool WEIGHTED>
-__device__ __forceinline__ void p1_process(p1_args<WT> const& a, WT const* xs, WT* stage, int lane, p1_regs const& rg)
+struct p1_runs {  // what pass A derives from the bitmap of one work item
+  uint32_t f[TP_U], nf[TP_U], ex_c[TP_U], c_all[TP_U], closed_at[TP_U];
+  uint32_t slot0[TP_U], slot1[TP_U];  // slots of runs lane and 64 + lane of each round
+  uint32_t es, ee, rank, head_slot;
+};
+
+// pass A (bitmap only): run counts of every round; the slots of the first 128 runs of each round are requested right away
+// (BEFORE the next item's edge data is requested: vmcnt retires in order, so waiting for these must not imply waiting
+// for the prefetch) -- their latency hides behind the LDS gathers and scans of pass B
+template <typename WT>
+__device__ __forceinline__ void p1_pass_a(p1_args<WT> const& a, int lane, p1_regs const& rg, p1_runs& q)
 {
-  uint32_t const es = rfl(rg.wd.x), ee = rfl(rg.wd.y), rank = rfl(rg.wd.z), head_slot = rfl(rg.wd.w);
-  if (es >= ee) return;  // empty share (tail of a tile)
-
-  // ---- pass A (bitmap only): run counts of every round, then the slots of the first 64 runs of each round are
-  // requested right away -- their latency hides behind the LDS gathers and scans of pass B
-  uint32_t f[TP_U], nf[TP_U], ex_c[TP_U], c_all[TP_U], closed_at[TP_U], slot0[TP_U];
-  {
-    uint32_t closed = 0;
-#pragma unroll
-    for (int g = 0; g < TP_U; ++g) {
-      uint32_t const e     = es + g * TP_SUB + 8 * lane;
-      uint32_t const nval  = min((uint32_t)8, ee > e ? ee - e : 0u);
-      f[g]                 = rg.fl[g] & ((1u << nval) - 1u);
-      nf[g]                = __popc(f[g]);
-      uint32_t const c_inc = wave_inclusive_sum_u32(nf[g]);
-      ex_c[g]              = c_inc - nf[g];
-      c_all[g]             = (uint32_t)__builtin_amdgcn_readlane((int)c_inc, 63);
-      closed_at[g]         = closed;
-      closed += c_all[g];
-    }
-#pragma unroll
-    for (int g = 0; g < TP_U; ++g) {
-      // ordinal n within the wavefront's range: n = 0 is the run that was already open at `es` (its partial goes to the
-      // head slot), n >= 1 is run (rank - 1 + n)
-      uint32_t const n = closed_at[g] + (uint32_t)lane;
-      slot0[g]         = head_slot;
-      if ((uint32_t)lane < c_all[g] && n != 0) slot0[g] = a.rpos[rank - 1 + n];
-    }
-  }
-
-  // ---- pass B: values
-  WT carry = 0;  // running sum of the run open at the current position (wave-uniform)
+  q.es = rfl(rg.wd.x); q.ee = rfl(rg.wd.y); q.rank = rfl(rg.wd.z); q.head_slot = rfl(rg.wd.w);
+  uint32_t closed = 0;
 #pragma unroll
   for (int g = 0; g < TP_U; ++g) {
-    uint32_t const e = es + g * TP_SUB + 8 * lane;
-    if (es + g * TP_SUB >= ee) break;  // wave-uniform
-    uint32_t const w4[4] = {rg.id[g].x, rg.id[g].y, rg.id[g].z, rg.id[g].w};
-    WT v[8];
+    uint32_t const e     = q.es + g * TP_SUB + 8 * lane;
+    uint32_t const nval  = min((uint32_t)8, q.ee > e ? q.ee - e : 0u);
+    q.f[g]               = rg.fl[g] & ((1u << nval) - 1u);
+    q.nf[g]              = __popc(q.f[g]);
+    uint32_t const c_inc = wave_inclusive_sum_u32(q.nf[g]);
+    q.ex_c[g]            = c_inc - q.nf[g];
+    q.c_all[g]           = (uint32_t)__builtin_amdgcn_readlane((int)c_inc, 63);
+    q.closed_at[g]       = closed;
+    closed += q.c_all[g];
+  }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      uint32_t i = (k & 1) ? (w4[k >> 1] >> 16) : (w4[k >> 1] & 0xFFFFu);
-      v[k]       = xs[i];
-    }
-    if constexpr (WEIGHTED) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] *= a.weights[e + k];
-    }
-    if (e + 8 > ee) {
-      uint32_t const nval = ee > e ? ee - e : 0u;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = (uint32_t)k < nval ? v[k] : WT(0);
-    }
+  for (int g = 0; g < TP_U; ++g) {
+    // ordinal n within the wavefront's range: n = 0 is the run that was already open at `es` (its partial goes to the
+    // head slot), n >= 1 is run (rank - 1 + n)
+    uint32_t const n = q.closed_at[g] + (uint32_t)lane;
+    q.slot0[g]       = q.head_slot;
+    q.slot1[g]       = q.head_slot;
+    if ((uint32_t)lane < q.c_all[g] && n != 0) q.slot0[g] = a.rpos[q.rank - 1 + n];
+    if ((uint32_t)lane + 64 < q.c_all[g]) q.slot1[g] = a.rpos[q.rank - 1 + n + 64];
+  }
+}
 
-    if (c_all[g] == 0) {  // no run starts in these 512 edges (inside a long run): plain wave sum
-      WT t = wave_sum_to_lane63(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
-      carry += read_lane63(t);
-      continue;
-    }
-    // in-lane: r[k] = running sum since the last run start at or before element k
-    uint32_t const fg = f[g];
-    WT r[8];
-    r[0] = v[0];
+// pass B: values.  `stage`: this wavefront's TP_SUB-entry LDS scratch (run totals of one round, in run order).
+// Rounds are handled in pairs: B1 computes the LDS gathers, in-lane segmented sums and wave64 segmented scans of both
+// rounds (two independent dependency chains the scheduler can interleave -- 4 wavefronts per SIMD is all the occupancy a
+// 126 KiB tile leaves, and the 128-VGPR budget does not fit more than two rounds of values); B2 emits the run totals.
+template <typename WT, bool WEIGHTED>
+__device__ __forceinline__ void p1_pass_b(p1_args<WT> const& a, WT const* xs, WT* stage, int lane, p1_regs const& rg, p1_runs const& q)
+{
+  constexpr int PAIR = 2;
+  uint32_t const es = q.es, ee = q.ee;
+  WT carry = 0;  // running sum of the run open at the current position (wave-uniform)
 #pragma unroll
-    for (int k = 1; k < 8; ++k) r[k] = ((fg >> k) & 1u) ? v[k] : r[k - 1] + v[k];
-    WT s       = r[7];
-    uint32_t c = nf[g];
-    wave_seg_scan(s, c);
-    WT const ex_s     = dpp_val<0x138, 0xF>(s);  // wave_shr:1 (lane 0 reads 0)
-    WT const carry_in = ex_c[g] ? ex_s : ex_s + carry;
-    if (fg) {  // the run closed by a start at element k ran up to element k - 1; totals go to LDS in run order
-      uint32_t pos = ex_c[g];
-      bool first   = true;
+  for (int g0 = 0; g0 < TP_U; g0 += PAIR) {
+    if (es + g0 * TP_SUB >= ee) break;  // wave-uniform
+    WT r[PAIR][8];   // values, then in place: running sum since the last run start at or before element k
+    WT s[PAIR];      // wave-level inclusive segmented scan of the lane tails
+    WT ex_s[PAIR];   // ... of the previous lane (0 in lane 0)
+    // ---- B1
+#pragma unroll
+    for (int j = 0; j < PAIR; ++j) {
+      int const g = g0 + j;
+      uint32_t const w4[4] = {rg.id[g].x, rg.id[g].y, rg.id[g].z, rg.id[g].w};
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        if ((fg >> k) & 1u) {
-          WT before  = k == 0 ? WT(0) : r[k - 1];
-          stage[pos] = first ? carry_in + before : before;
-          first      = false;
-          ++pos;
-        }
+        uint32_t i = (k & 1) ? (w4[k >> 1] >> 16) : (w4[k >> 1] & 0xFFFFu);
+        r[j][k]    = xs[i];  // rounds past `ee` read zero-padded indices: valid addresses, values masked below
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // coalesced write-out: lane i takes the i-th run closed in this round
-    if ((uint32_t)lane < c_all[g]) a.part[slot0[g]] = stage[lane];
-    for (uint32_t i = 64 + lane; i < c_all[g]; i += 64) a.part[a.rpos[rank - 1 + closed_at[g] + i]] = stage[i];
-    __builtin_amdgcn_wave_barrier();  // the next round overwrites the staging area
-    carry = read_lane63(s);           // c_all != 0: the open run started inside this round
+#pragma unroll
+    for (int j = 0; j < PAIR; ++j) {
+      int const g = g0 + j;
+      uint32_t const e = es + g * TP_SUB + 8 * lane;
+      if constexpr (WEIGHTED) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[j][k] *= a.weights[e + k];
+      }
+      if (e + 8 > ee) {
+        uint32_t const nval = ee > e ? ee - e : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[j][k] = (uint32_t)k < nval ? r[j][k] : WT(0);
+      }
+      uint32_t const fg = q.f[g];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) r[j][k] = ((fg >> k) & 1u) ? r[j][k] : r[j][k - 1] + r[j][k];
+      s[j]       = r[j][7];
+      uint32_t c = q.nf[g];
+      wave_seg_scan(s[j], c);
+      ex_s[j] = dpp_val<0x138, 0xF>(s[j]);  // wave_shr:1
+    }
+    // ---- B2
+#pragma unroll
+    for (int j = 0; j < PAIR; ++j) {
+      int const g = g0 + j;
+      if (es + g * TP_SUB >= ee) break;  // wave-uniform
+      uint32_t const c_all = q.c_all[g];
+      WT const s_last      = read_lane63(s[j]);
+      if (c_all == 0) {  // no run starts in these 512 edges (inside a long run)
+        carry += s_last;
+        continue;
+      }
+      uint32_t const fg = q.f[g];
+      WT const carry_in = q.ex_c[g] ? ex_s[j] : ex_s[j] + carry;
+      if (fg) {  // the run closed by a start at element k ran up to element k - 1; totals go to LDS in run order
+        uint32_t pos = q.ex_c[g];
+        bool first   = true;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if ((fg >> k) & 1u) {
+            WT before  = k == 0 ? WT(0) : r[j][k - 1];
+            stage[pos] = first ? carry_in + before : before;
+            first      = false;
+            ++pos;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // coalesced write-out: lane i takes the i-th run closed in this round
+      if ((uint32_t)lane < c_all) a.part[q.slot0[g]] = stage[lane];
+      if ((uint32_t)lane + 64 < c_all) a.part[q.slot1[g]] = stage[lane + 64];
+      for (uint32_t i = 128 + lane; i < c_all; i += 64) a.part[a.rpos[q.rank - 1 + q.closed_at[g] + i]] = stage[i];
+      __builtin_amdgcn_wave_barrier();  // the next round overwrites the staging area
+      carry = s_last;                   // c_all != 0: the open run started inside this round
+    }
   }
   if (lane == 0) {  // the run still open at the end of the range (it may continue in the next wavefront's range: that
                     // wavefront contributes its part through its own head slot)
-    uint32_t const closed = closed_at[TP_U - 1] + c_all[TP_U - 1];
-    uint32_t sl = closed == 0 ? head_slot : a.rpos[rank - 1 + closed];
+    uint32_t const closed = q.closed_at[TP_U - 1] + q.c_all[TP_U - 1];
+    uint32_t sl = closed == 0 ? q.head_slot : a.rpos[q.rank - 1 + closed];
     a.part[sl]  = carry;
   }
 }
 
-template <typename WT, bool WEIGHTED, bool MG>
+template <typename WT, bool WEIGHTED, bool MG, bool DBG = false>
 __global__ void __launch_bounds__(TP_BLOCK) k_tiled_phase1(p1_args<WT> a)
 {
+  long long tA = 0, tT = 0, tB = 0, tW = 0, tc0 = 0, tc1 = 0;  // DBG: cycles in pass A (incl. wait for data) / tile loads / pass B / chunk barrier
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   WT* xs = reinterpret_cast<WT*>(smem);
   __shared__ int s_chunk[3];
@@ -710,7 +739,7 @@ __global__ void __launch_bounds__(TP_BLOCK) k_tiled_phase1(p1_args<WT> a)
     auto body = [&](p1_regs const& cur, p1_regs& nxt) {
       int const J   = a.item_tile[item];
       int const pre = item + 1 < item_end ? item + 1 : next_item;
-      if (pre >= 0) p1_load<WT>(a, pre, wave, lane, nxt);
+      if constexpr (DBG) tc0 = clock64();
       if (J != curJ) {  // only at the first item of a chunk: every wavefront has passed the chunk barrier
         if constexpr (MG) {
           uint32_t c0 = (uint32_t)J * (uint32_t)a.T;
@@ -722,28 +751,51 @@ __global__ void __launch_bounds__(TP_BLOCK) k_tiled_phase1(p1_args<WT> a)
           using vec4 = typename std::conditional<sizeof(WT) == 4, float4, double4>::type;
           vec4 const* src = reinterpret_cast<vec4 const*>(a.x + (size_t)J * a.T);
           vec4* dst       = reinterpret_cast<vec4*>(xs);
-          for (int i = tid; i < a.T / 4; i += TP_BLOCK) {
-            vec4 v = src[i];
-            v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
-            dst[i] = v;
+          int const n4    = a.T / 4;
+          for (int i0 = 0; i0 < n4; i0 += 8 * TP_BLOCK) {  // 8 loads per thread in flight (T <= 65536: two trips at most)
+            vec4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              int i = i0 + j * TP_BLOCK + tid;
+              if (i < n4) v[j] = src[i];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              int i = i0 + j * TP_BLOCK + tid;
+              if (i < n4) {
+                v[j].x *= a.alpha; v[j].y *= a.alpha; v[j].z *= a.alpha; v[j].w *= a.alpha;
+                dst[i] = v[j];
+              }
+            }
           }
         }
         __syncthreads();
         curJ = J;
         ++n_tiles;
       }
-      p1_process<WT, WEIGHTED>(a, xs, stage, lane, cur);
+      if constexpr (DBG) { tc1 = clock64(); tT += tc1 - tc0; tc0 = tc1; }
+      p1_runs q;
+      p1_pass_a<WT>(a, lane, cur, q);
+      if constexpr (DBG) { __builtin_amdgcn_s_waitcnt(0); tc1 = clock64(); tA += tc1 - tc0; tc0 = tc1; }
+      if (pre >= 0) p1_load<WT>(a, pre, wave, lane, nxt);
+      if (q.es < q.ee) p1_pass_b<WT, WEIGHTED>(a, xs, stage, lane, cur, q);
+      if constexpr (DBG) { tc1 = clock64(); tB += tc1 - tc0; tc0 = tc1; }
       ++item;
     };
     while (item < item_end) {
       if (cur_is_r0) body(r0, r1); else body(r1, r0);
       cur_is_r0 = !cur_is_r0;
     }
+    if constexpr (DBG) tc0 = clock64();
     __syncthreads();  // chunk done: the tile may be replaced, s_chunk[(it + 2) % 3] is visible
+    if constexpr (DBG) tW += clock64() - tc0;
   }
-  if (a.dbg) {
-    __syncthreads();
-    if (tid == 0) { a.dbg[2 * blockIdx.x] = wall_clock64() - t_start; a.dbg[2 * blockIdx.x + 1] = (unsigned long long)n_tiles; }
+  if constexpr (DBG) {
+    if (lane == 0) {
+      unsigned long long* o = a.dbg + ((size_t)blockIdx.x * TP_WAVES + wave) * 6;
+      o[0] = (unsigned long long)(wall_clock64() - t_start); o[1] = (unsigned long long)n_tiles;
+      o[2] = (unsigned long long)tA; o[3] = (unsigned long long)tT; o[4] = (unsigned long long)tB; o[5] = (unsigned long long)tW;
+    }
   }
 }
 
@@ -905,25 +957,30 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
   size_t const lds = std::max<size_t>(((size_t)t.T + (size_t)TP_WAVES * TP_SUB) * sizeof(WT), 3 * TP_BLOCK * sizeof(double));
   bool const w     = a.weights != nullptr;
   static bool attr_done[4] = {false, false, false, false};
-  static int dbg_calls = getenv("CUGRAPH_AMD_TILED_DEBUG") ? 3 : 0;
-  dvec<unsigned long long> dbg;
-  if (dbg_calls > 0) { dbg.resize_discard((size_t)2 * t.n_wg); a.dbg = dbg.data(); }
+  static int dbg_calls = getenv("CUGRAPH_AMD_TILED_DEBUG") ? 2 : 0;
   auto launch = [&](auto kernel, int slot) {
     if (!attr_done[slot]) { ensure_max_lds(kernel, (int)h.lds_per_block); attr_done[slot] = true; }
     timed_launch tl(h, "pagerank_spmv");
     hipLaunchKernelGGL(kernel, t.n_wg, TP_BLOCK, lds, h.stream, a);
   };
+  if (dbg_calls > 0 && !map.mg && !w && sizeof(WT) == 4) {  // instrumented variant: per-wavefront cycle breakdown to stderr
+    --dbg_calls;
+    size_t const n = (size_t)t.n_wg * TP_WAVES * 6;
+    dvec<unsigned long long> dbg(n);
+    a.dbg = dbg.data();
+    ensure_max_lds(k_tiled_phase1<WT, false, false, true>, (int)h.lds_per_block);
+    hipLaunchKernelGGL((k_tiled_phase1<WT, false, false, true>), t.n_wg, TP_BLOCK, lds, h.stream, a);
+    std::vector<unsigned long long> d = to_host(h, dbg.data(), n);
+    double sum[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < n; ++i) { sum[i % 6] += (double)d[i]; mx[i % 6] = std::max(mx[i % 6], (double)d[i]); }
+    double const nw = (double)t.n_wg * TP_WAVES;
+    fprintf(stderr, "[tiled phase1 dbg] %d wgs %d items %d chunks | per wavefront avg (max): wall %.0f (%.0f) x10ns, tiles %.1f, cycles: passA+data wait %.0f (%.0f), "
+            "prefetch issue+tile load %.0f (%.0f), passB %.0f (%.0f), chunk barrier %.0f (%.0f)\n", t.n_wg, t.n_items, t.n_chunks, sum[0] / nw, mx[0], sum[1] / nw,
+            sum[2] / nw, mx[2], sum[3] / nw, mx[3], sum[4] / nw, mx[4], sum[5] / nw, mx[5]);
+    return;
+  }
   if (map.mg) { if (w) launch(k_tiled_phase1<WT, true, true>, 0); else launch(k_tiled_phase1<WT, false, true>, 1); }
   else        { if (w) launch(k_tiled_phase1<WT, true, false>, 2); else launch(k_tiled_phase1<WT, false, false>, 3); }
-  if (a.dbg) {
-    --dbg_calls;
-    std::vector<unsigned long long> d = to_host(h, dbg.data(), (size_t)2 * t.n_wg);
-    std::vector<unsigned long long> v;
-    for (int b = 0; b < t.n_wg; ++b) v.push_back(d[2 * b]);
-    std::sort(v.begin(), v.end());
-    fprintf(stderr, "[tiled phase1] %d workgroups, %d items, %d chunks; ticks (100 MHz) min %llu p10 %llu p50 %llu p90 %llu max %llu\n", t.n_wg, t.n_items,
-            t.n_chunks, v[0], v[t.n_wg / 10], v[t.n_wg / 2], v[t.n_wg * 9 / 10], v[t.n_wg - 1]);
-  }
 }
 
 template <typename WT>

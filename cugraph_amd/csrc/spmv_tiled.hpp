@@ -42,10 +42,10 @@ struct pr_scalars {  // device-resident PageRank loop state
 constexpr int TP_BLOCK = 1024;               // phase-1 workgroup: 16 wavefronts sharing one LDS tile
 constexpr int TP_WAVES = TP_BLOCK / 64;
 constexpr int TP_SUB   = 512;                // edges per wavefront per load round (8 per lane, one 16-byte load)
-constexpr int TP_U     = 4;                  // load rounds in flight
+constexpr int TP_U     = 2;                  // load rounds per work item (register budget: 2 items x TP_U rounds are resident)
 constexpr int TP_WLEN  = TP_SUB * TP_U;      // edges per wavefront per work item
 constexpr int TP_ITEM  = TP_WLEN * TP_WAVES;  // edges per work item
-constexpr int TP_CHUNK = 4;                  // work items per dynamically scheduled chunk
+constexpr int TP_CHUNK = 8;                  // work items per dynamically scheduled chunk
 constexpr int TP2_BLOCK = 512;               // phase-2 workgroup
 constexpr int TP2_ROWS  = 4096;              // max destination rows per phase-2 tile (64-bit LDS accumulators: 32 KiB)
 
