@@ -635,7 +635,7 @@ struct pagerank_plan : pagerank_plan_base {
       int const T = tiled_default_T(h, sizeof(WT), g.nv);
       if (!o.tiled || o.tiled->T != T) {
         auto t = std::make_shared<tiled_csc_t>();
-        build_tiled_csc(h, g.nv, g.ne, o, g.has_weights, sizeof(WT), T, *t);
+        build_tiled_csc(h, g.nv, g.nv, g.ne, o, g.has_weights, sizeof(WT), T, *t);
         o.tiled = t;
       }
       tc = o.tiled;
@@ -922,71 +922,6 @@ struct pagerank_plan : pagerank_plan_base {
 // The reference instead uses a 2-D partition with a row broadcast + column reduce + 2 scalar all-reduces per
 // iteration (update_edge_src_dst_property.cuh:550-579, per_v_transform_reduce_e.cuh:3390-3406).
 // =================================================================================================
-template <typename WT>
-__global__ void k_mg_scalars(WT const* recv, int comm_size, uint32_t chunk, pr_scalars<WT>* scal, WT alpha, WT one_minus_alpha, int64_t nv_global)
-{
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double diff = 0.0, dang = 0.0;
-  for (int r = 0; r < comm_size; ++r) {
-    double const* t = reinterpret_cast<double const*>(recv + (size_t)(r + 1) * chunk - 4 * (8 / sizeof(WT)) / 2);
-    diff += t[0];
-    dang += t[1];
-  }
-  WT dangling       = (WT)dang;
-  WT factor         = dangling * alpha + one_minus_alpha;
-  scal->dangling    = dangling;
-  scal->diff        = (WT)diff;
-  scal->pers_factor = factor;
-  scal->base        = factor / (WT)nv_global;
-}
-
-template <typename WT>
-__global__ void __launch_bounds__(256) k_mg_epilogue(WT const* y, int64_t n_nonempty, int64_t n_rows, WT* pr, WT* send, WT const* outw,
-                                                     pr_scalars<WT> const* scal, double* partials, int first)
-{
-  __shared__ double red[8];
-  pr_scalars<WT> const sc = *scal;
-  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  double diff = 0.0, dang = 0.0;
-  for (; i < n_rows; i += stride) {
-    WT old = pr[i], ow = outw[i];
-    WT val = old;
-    if (!first) {  // first == 1: only derive x and the dangling mass from the initial vector
-      WT sum = i < n_nonempty ? y[i] : WT(0);
-      val    = sc.base + sum;
-      pr[i]  = val;
-      diff += (double)fabs(val - old);
-    }
-    send[i] = val / (ow == WT(0) ? WT(1) : ow);
-    if (ow == WT(0)) dang += (double)val;
-  }
-  diff = group_sum(diff, 64);
-  dang = group_sum(dang, 64);
-  int const wv = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { red[2 * wv] = diff; red[2 * wv + 1] = dang; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    partials[2 * blockIdx.x]     = red[0] + red[2] + red[4] + red[6];
-    partials[2 * blockIdx.x + 1] = red[1] + red[3] + red[5] + red[7];
-  }
-}
-
-// block partials -> the two doubles at the tail of this rank's send chunk
-__global__ void __launch_bounds__(256) k_mg_pack_scalars(double const* partials, int n, double* tail)
-{
-  __shared__ double r0[256], r1[256];
-  double d0 = 0, d1 = 0;
-  for (int i = threadIdx.x; i < n; i += 256) { d0 += partials[2 * i]; d1 += partials[2 * i + 1]; }
-  r0[threadIdx.x] = d0; r1[threadIdx.x] = d1;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) { r0[threadIdx.x] += r0[threadIdx.x + s]; r1[threadIdx.x] += r1[threadIdx.x + s]; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { tail[0] = r0[0]; tail[1] = r1[0]; }
-}
-
 struct pagerank_mg_plan_base {
   virtual ~pagerank_mg_plan_base() = default;
   virtual void start()                                           = 0;
@@ -997,22 +932,20 @@ struct pagerank_mg_plan_base {
 
 template <typename WT>
 struct pagerank_mg_plan : pagerank_mg_plan_base {
+  static constexpr size_t kTailBytes = 32;  // (L1 change, dangling mass, max |x|) as 3 doubles + pad, at the end of every rank's chunk
   handle_t const& h;
   graph_t& g;
   WT alpha;
   int64_t n_rows, nv_global;
   int rank, size;
   uint32_t chunk, plog;
-  dvec<WT> pr, outw, yv, head_sum;
+  dvec<WT> pr, outw, part;
   WT* send{nullptr};  // caller-owned exchange buffers (torch tensors on the host side)
   WT* recv{nullptr};
-  dvec<uint8_t> has_flag;
-  dvec<uint32_t> wave_rank;
   dvec<pr_scalars<WT>> scal;
-  dvec<double> partials;
-  int64_t range_len{0}, n_waves{0};
-  int flat_grid{0}, epi_grid{0}, hot{0};
-  size_t flat_lds{0};
+  dvec<double> tpartials;
+  dvec<uint32_t> counters;
+  std::shared_ptr<tiled_csc_t> tc;
 
   pagerank_mg_plan(handle_t const& h_, graph_t& g_, double alpha_, int64_t n_rows_, int64_t nv_global_, int rank_, int size_, size_t chunk_)
     : h(h_), g(g_), alpha((WT)alpha_), n_rows(n_rows_), nv_global(nv_global_), rank(rank_), size(size_), chunk((uint32_t)chunk_), plog(0)
@@ -1030,19 +963,19 @@ struct pagerank_mg_plan : pagerank_mg_plan_base {
     recv = recv_v->as<WT>();
     CGA_EXPECTS(size >= 1 && (size & (size - 1)) == 0, CUGRAPH_NOT_IMPLEMENTED, "multi-GPU PageRank: the number of ranks must be a power of two");
     while ((1 << plog) < size) ++plog;
-    CGA_EXPECTS((size_t)chunk * sizeof(WT) % 16 == 0 && (int64_t)chunk >= n_rows + (int64_t)(16 / sizeof(WT)), CUGRAPH_INVALID_INPUT,
-                "multi-GPU PageRank: chunk must hold the local rows plus 16 bytes of scalars and be 16-byte aligned");
+    CGA_EXPECTS((size_t)chunk * sizeof(WT) % 16 == 0 && (int64_t)chunk >= n_rows + (int64_t)(kTailBytes / sizeof(WT)), CUGRAPH_INVALID_INPUT,
+                "multi-GPU PageRank: chunk must hold the local rows plus 32 bytes of scalars and be 16-byte aligned");
     CGA_EXPECTS((int64_t)chunk * size <= g.nv && (uint64_t)chunk * (uint64_t)size < ((uint64_t)1 << 30), CUGRAPH_INVALID_INPUT,
                 "multi-GPU PageRank: local graph must have at least comm_size * chunk column ids");
     CGA_EXPECTS(outw_local != nullptr && (int64_t)outw_local->size == n_rows && outw_local->type == g.weight_type, CUGRAPH_INVALID_INPUT,
                 "multi-GPU PageRank: out_weight_sums must have one weight-typed value per local row");
     ensure_orientation(h, g, true);
     orientation_t& o = g.csc;
-    CGA_EXPECTS(o.row_order.size() == 0, CUGRAPH_INVALID_INPUT, "multi-GPU PageRank: local rows must be numbered by descending in-degree");
     CGA_EXPECTS(o.seg[4] <= n_rows, CUGRAPH_INVALID_INPUT, "multi-GPU PageRank: edges point to rows outside the local range");
     size_t const n1 = (size_t)(n_rows > 0 ? n_rows : 1);
     pr.resize_discard(n1); outw.resize_discard(n1);
     scal.resize_discard(1);
+    HIP_TRY(hipMemsetAsync(scal.data(), 0, sizeof(pr_scalars<WT>), h.stream));
     HIP_TRY(hipMemsetAsync(send, 0, (size_t)chunk * sizeof(WT), h.stream));
     HIP_TRY(hipMemsetAsync(recv, 0, (size_t)chunk * size * sizeof(WT), h.stream));
     if (n_rows > 0) HIP_TRY(hipMemcpyAsync(outw.data(), outw_local->data, n_rows * sizeof(WT), hipMemcpyDeviceToDevice, h.stream));
@@ -1052,50 +985,46 @@ struct pagerank_mg_plan : pagerank_mg_plan_base {
     } else {
       fill_wt<WT>(h, pr.data(), n_rows, WT(1) / (WT)nv_global);
     }
-    int hot_req = h.pagerank_hot_tile < 0 ? (int)(65536 / sizeof(WT)) : h.pagerank_hot_tile;
-    size_t max_tile = (h.lds_per_block > 2048 ? h.lds_per_block - 2048 : 0) / sizeof(WT);
-    hot      = (int)std::min<int64_t>({(int64_t)hot_req, (int64_t)max_tile, (int64_t)chunk * size}) & ~3;
-    flat_lds = (size_t)std::max(hot, 4) * sizeof(WT);
-    int per_cu = (flat_lds <= 80 * 1024 && sizeof(WT) == 4 && !g.has_weights) ? 2 : 1;
-    epi_grid   = std::min(grid_for(n_rows, 256, 2048), 2048);
-    partials.resize_discard((size_t)2 * 2048);
-    int64_t const nnz_rows = o.seg[4];
-    yv.resize_discard((size_t)nnz_rows + 1);
-    if (g.ne > 0) {
-      if (o.rowstart_bits.size() == 0) {
-        size_t words = (size_t)((g.ne + kEdgePad) / 32 + 2);
-        o.rowstart_bits.resize_discard(words);
-        HIP_TRY(hipMemsetAsync(o.rowstart_bits.data(), 0, words * 4, h.stream));
-        hipLaunchKernelGGL(k_rowstart_bits, grid_for(nnz_rows, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)o.offsets.data(), nnz_rows, o.rowstart_bits.data());
-      }
-      flat_grid     = h.num_cus * per_cu;
-      int64_t waves = (int64_t)flat_grid * FL_WAVES;
-      range_len     = ((g.ne + waves - 1) / waves + FL_CHUNK - 1) / FL_CHUNK * FL_CHUNK;
-      n_waves       = (g.ne + range_len - 1) / range_len;
-      flat_grid     = (int)((n_waves + FL_WAVES - 1) / FL_WAVES);
-      n_waves       = (int64_t)flat_grid * FL_WAVES;
-      head_sum.resize_discard((size_t)n_waves); has_flag.resize_discard((size_t)n_waves); wave_rank.resize_discard((size_t)n_waves + 1);
-      hipLaunchKernelGGL(k_wave_ranks, grid_for(n_waves + 1, kBlock), kBlock, 0, h.stream, (int32_t const*)o.offsets.data(), nnz_rows, range_len, n_waves, wave_rank.data());
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_spmv_flat<WT, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_per_block));
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_spmv_flat<WT, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_per_block));
+    // column ids are global degree-order positions (hot sources first): the column-tiled re-blocking applies unchanged,
+    // only the tile load follows the rank-blocked layout of the all-gathered vector
+    int const T = tiled_default_T(h, sizeof(WT), (int64_t)chunk * size);
+    if (!o.tiled || o.tiled->T != T || o.tiled->nv != n_rows) {
+      auto t = std::make_shared<tiled_csc_t>();
+      build_tiled_csc(h, g.nv, n_rows, g.ne, o, g.has_weights, sizeof(WT), T, *t);
+      o.tiled = t;
     }
+    tc = o.tiled;
+    part.resize_discard((size_t)tc->n_slots + 64);
+    HIP_TRY(hipMemsetAsync(part.data(), 0, ((size_t)tc->n_slots + 64) * sizeof(WT), h.stream));
+    counters.resize_discard(4);
+    HIP_TRY(hipMemsetAsync(counters.data(), 0, 4 * sizeof(uint32_t), h.stream));
+    tpartials.resize_discard((size_t)3 * std::max(tc->nI, 1024));
     h.sync();
   }
 
-  double* send_tail() { return reinterpret_cast<double*>(send + chunk) - 2; }
+  double* send_tail() { return reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(send) + (size_t)chunk * sizeof(WT) - kTailBytes); }
 
-  void pack(int first)
+  tiled_epilogue<WT> epi()
   {
-    hipLaunchKernelGGL(k_mg_epilogue<WT>, epi_grid, 256, 0, h.stream, (WT const*)yv.data(), g.csc.seg[4], n_rows, pr.data(), send, (WT const*)outw.data(),
-                       (pr_scalars<WT> const*)scal.data(), partials.data(), first);
-    hipLaunchKernelGGL(k_mg_pack_scalars, 1, 256, 0, h.stream, (double const*)partials.data(), epi_grid, send_tail());
+    tiled_epilogue<WT> e;
+    e.nv = n_rows; e.pr = pr.data(); e.x_next = send; e.outw = outw.data(); e.pers = nullptr; e.scal = scal.data();
+    e.partials = tpartials.data(); e.totals = send_tail(); e.alpha = alpha; e.nv_global = nv_global; e.wmax = tc->wmax;
+    return e;
   }
 
-  void start() override { HIP_TRY(hipSetDevice(h.device)); pack(1); h.sync(); }
+  void start() override
+  {  // send <- x of the initial vector, tail <- (0, partial dangling mass, max |x|)
+    HIP_TRY(hipSetDevice(h.device));
+    int n = tiled_prologue<WT>(h, *tc, (WT const*)pr.data(), (WT const*)outw.data(), send, n_rows, tpartials.data());
+    tiled_finish<WT>(h, epi(), n);
+    h.sync();
+  }
 
   void reduce_scalars(bool read_back, double* diff, double* dangling) override
   {
-    hipLaunchKernelGGL(k_mg_scalars<WT>, 1, 64, 0, h.stream, (WT const*)recv, size, chunk, scal.data(), alpha, (WT)(1.0 - (double)alpha), nv_global);
+    tiled_epilogue<WT> e = epi();
+    e.totals = nullptr;
+    tiled_scalars_from_ranks<WT>(h, e, recv, (size_t)chunk * sizeof(WT) - kTailBytes, (size_t)chunk * sizeof(WT), size);
     if (read_back) {
       pr_scalars<WT> sc;
       h.read_back(&sc, scal.data(), 1);
@@ -1107,22 +1036,12 @@ struct pagerank_mg_plan : pagerank_mg_plan_base {
   void local_step() override
   {
     HIP_TRY(hipSetDevice(h.device));
-    orientation_t const& o = g.csc;
-    if (g.ne > 0) {
-      flat_args<WT> a;
-      a.indices = o.indices.data(); a.weights = g.has_weights ? o.weights.as<WT const>() : nullptr;
-      a.bits = reinterpret_cast<uint8_t const*>(o.rowstart_bits.data()); a.wave_rank = wave_rank.data();
-      a.ne = g.ne; a.range_len = range_len; a.x = recv; a.y = yv.data(); a.head_sum = head_sum.data(); a.has_flag = has_flag.data();
-      a.alpha = alpha; a.hot = hot; a.pmask = (uint32_t)size - 1; a.plog = plog; a.chunk = chunk;
-      {
-        timed_launch t(h, "pagerank_spmv");
-        if (g.has_weights) hipLaunchKernelGGL((k_spmv_flat<WT, true, true>), flat_grid, FL_BLOCK, flat_lds, h.stream, a);
-        else               hipLaunchKernelGGL((k_spmv_flat<WT, false, true>), flat_grid, FL_BLOCK, flat_lds, h.stream, a);
-      }
-      hipLaunchKernelGGL(k_flat_fixup<WT>, grid_for(n_waves, kBlock), kBlock, 0, h.stream, (uint32_t const*)wave_rank.data(), (WT const*)head_sum.data(),
-                         (uint8_t const*)has_flag.data(), n_waves, yv.data());
-    }
-    pack(0);
+    tiled_x_map<WT> map;
+    map.mg = true; map.pmask = (uint32_t)size - 1; map.plog = plog; map.chunk = chunk; map.ncols = chunk * (uint32_t)size;
+    tiled_epilogue<WT> e = epi();
+    tiled_phase1<WT>(h, *tc, (WT const*)recv, alpha, part.data(), counters.data(), map, nullptr);
+    tiled_phase2<WT>(h, *tc, (WT const*)part.data(), e, counters.data());
+    tiled_finish<WT>(h, e, tc->nI);  // this rank's (diff, dangling, xmax) -> tail of the send chunk
     h.sync();  // the host layer issues the next all-gather on its own stream
   }
 

@@ -224,14 +224,16 @@ __global__ void k_row_abs_max(int32_t const* offsets, WB const* w, int64_t nv, u
   if (lane == 0) atomicMax(out, (unsigned long long)__double_as_longlong(best));  // non-negative doubles order like their bit patterns
 }
 
-void build_tiled_csc(handle_t const& h, int64_t nv, int64_t ne, orientation_t const& csc, bool has_weights, size_t vsize, int T,
+void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, orientation_t const& csc, bool has_weights, size_t vsize, int T,
                      tiled_csc_t& t)
 {
+  // nv = number of column (source) ids and of CSC rows; n_dst <= nv = rows that can have in-edges and get an epilogue
+  // (single GPU: n_dst = nv; multi-GPU: the local rows, while the columns span the whole graph)
   size_t const wsize = has_weights ? vsize : 0;
   CGA_EXPECTS(nv < ((int64_t)1 << 31) && ne < ((int64_t)1 << 31), CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: graph too large for 32-bit positions");
   t       = tiled_csc_t{};
   t.T     = T;
-  t.nv    = nv;
+  t.nv    = n_dst;
   t.ne    = ne;
   t.nJ    = (int)std::max<int64_t>(1, (nv + T - 1) / T);
   int const nJ = t.nJ;
@@ -271,8 +273,8 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t ne, orientation_t co
   to_device(h, d_tile_off_pad, tile_off_pad);
 
   // ---- runs
-  dvec<uint32_t> run_dst, cnt_dst(nv + 1);
-  HIP_TRY(hipMemsetAsync(cnt_dst.data(), 0, (nv + 1) * sizeof(uint32_t), h.stream));
+  dvec<uint32_t> run_dst, cnt_dst(n_dst + 1);
+  HIP_TRY(hipMemsetAsync(cnt_dst.data(), 0, (n_dst + 1) * sizeof(uint32_t), h.stream));
   if (ne > 0) {
     flag32.resize_discard(ne + 1); ord.resize_discard(ne + 1); dsts.resize_discard(ne);
     HIP_TRY(hipMemsetAsync(flag32.data() + ne, 0, sizeof(uint32_t), h.stream));
@@ -304,14 +306,14 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t ne, orientation_t co
   // ---- destination tiles: equal cost (6 bytes per partial + 16 bytes per row), at most TP2_ROWS rows
   std::vector<uint32_t> row0;
   {
-    dvec<uint32_t> csum(nv + 1);
-    exclusive_scan_u32(h, cnt_dst.data(), csum.data(), nv + 1);
-    uint64_t total = 6ull * (uint64_t)t.n_runs + 16ull * (uint64_t)nv;
+    dvec<uint32_t> csum(n_dst + 1);
+    exclusive_scan_u32(h, cnt_dst.data(), csum.data(), n_dst + 1);
+    uint64_t total = 6ull * (uint64_t)t.n_runs + 16ull * (uint64_t)n_dst;
     int nq = (int)std::min<uint64_t>(4096, std::max<uint64_t>(1, total / 32768));
     dvec<uint32_t> cut(nq);
-    hipLaunchKernelGGL(k_cost_cuts, (nq + 255) / 256, 256, 0, h.stream, (uint32_t const*)csum.data(), nv, total, nq, cut.data());
+    hipLaunchKernelGGL(k_cost_cuts, (nq + 255) / 256, 256, 0, h.stream, (uint32_t const*)csum.data(), n_dst, total, nq, cut.data());
     std::vector<uint32_t> c = to_host(h, cut.data(), (size_t)nq);
-    c.push_back((uint32_t)nv);
+    c.push_back((uint32_t)n_dst);
     uint32_t prev = 0;
     row0.push_back(0);
     for (uint32_t b : c) {
@@ -320,7 +322,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t ne, orientation_t co
       row0.push_back(b);
       prev = b;
     }
-    if (row0.size() == 1) row0.push_back((uint32_t)nv);  // nv == 0
+    if (row0.size() == 1) row0.push_back((uint32_t)n_dst);  // n_dst == 0
   }
   t.nI = (int)row0.size() - 1;
   to_device(h, t.tile_row0, row0);

@@ -79,7 +79,8 @@ struct tiled_csc_t {
 
 // Re-blocks the CSC orientation of g (offsets / indices / weights) into tiles of T sources.
 // `vsize` = sizeof(value type); weights (if any) have the same type.
-void build_tiled_csc(handle_t const& h, int64_t nv, int64_t ne, orientation_t const& csc, bool has_weights, size_t vsize, int T,
+// nv = number of column (source) ids = CSC rows; n_dst <= nv = leading rows that may have in-edges (single GPU: nv).
+void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, orientation_t const& csc, bool has_weights, size_t vsize, int T,
                      tiled_csc_t& t);
 
 template <typename WT>

@@ -8,7 +8,7 @@ Partitioning (re-designed for a full-mesh xGMI node instea
     reduction over ranks (the reference's 2-D scheme needs a row broadcast AND a column reduce per iteration,
     prims/update_edge_src_dst_property.cuh:550-579 + prims/detail/per_v_transform_reduce_e.cuh:3390-3406);
   * per iteration ONE collective: all-gather of x = pr / out_w (chunk of V/P values per rank) with the two scalars of
-    the iteration (partial L1 change, partial dangling mass) riding in the last 16 bytes of every chunk -- no scalar
+    the iteration (partial L1 change, partial dangling mass, max |x|) riding in the last 32 bytes of every chunk -- no scalar
     all-reduce, every rank adds the P partials in rank order (deterministic).
 Column ids stored in the local CSC are the global degree-order positions, so the hottest sources are ids [0, K)
 and the LDS hot tile of the SpMV kernel keeps working across ranks.
@@ -41,7 +41,7 @@ class Partition:
         self.local_vertices = order[rank::world]             # external ids of the rows this rank owns, local order
         self.n_rows = int(self.local_vertices.numel())
         lmax = (self.nv + world - 1) // world
-        self.chunk = (lmax + 4 + 3) // 4 * 4                 # local rows + 16 B of scalars, 16-byte multiple (fp32)
+        self.chunk = (lmax + 8 + 3) // 4 * 4                 # local rows + 32 B of scalars (3 doubles + pad), 16-byte multiple
         self.ncols = self.chunk * world
 
 

@@ -53,8 +53,8 @@ CUGRAPH_EXPORT void cugraph_amd_pagerank_plan_free(cugraph_amd_pagerank_plan_t* 
  * `graph` is this rank's LOCAL CSC: rows [0, n_local_rows) are the destinations this rank owns, numbered by
  * descending in-degree; column ids are c = local_index * comm_size + owner_rank of the SOURCE vertex (i.e. the
  * global degree order) and the graph must have been created with at least comm_size * chunk vertices.
- * The caller provides two device buffers (views, weight type): `send` (chunk elements: this rank's x = pr / out_w, then 16 bytes holding its
- * partial L1 change and dangling mass as two doubles) and `recv` (comm_size * chunk elements).  Per iteration the
+ * The caller provides two device buffers (views, weight type): `send` (chunk elements: this rank's x = pr / out_w; the LAST 32 bytes hold its
+ * partial L1 change, dangling mass and max |x| as three doubles + 8 bytes of padding) and `recv` (comm_size * chunk elements).  Per iteration the
  * host layer runs ONE all-gather send -> recv (torch.distributed / RCCL), then reduce_scalars(), then local_step().
  * comm_size must be a power of two.  cugraph_amd/mg.py is the host layer. */
 typedef struct { int32_t align_; } cugraph_amd_pagerank_mg_plan_t;

@@ -38,16 +38,17 @@ class OracleEngine(mg.LocalEngine):
         s = self.send.numpy()
         div = np.where(self.outw == 0, np.float32(1), self.outw)
         s[: self.part.n_rows] = self.pr / div
-        tail = s[-4:].view(np.float64)
+        tail = s[-8:].view(np.float64)  # (L1 change, dangling mass, max |x|, pad)
         tail[0] = diff
         tail[1] = float(self.pr[self.outw == 0].astype(np.float64).sum())
+        tail[2] = float(np.abs(s[: self.part.n_rows]).max()) if self.part.n_rows else 0.0
 
     def start(self):
         self._pack(0.0)
 
     def reduce_scalars(self, read_back):
         r = self.recv.numpy().reshape(self.part.world, self.part.chunk)
-        tails = r[:, -4:].copy().view(np.float64)
+        tails = r[:, -8:].copy().view(np.float64)
         diff, dang = float(tails[:, 0].sum()), np.float32(tails[:, 1].sum())
         self.base = np.float32((dang * np.float32(self.alpha) + np.float32(1.0 - self.alpha)) / np.float32(self.part.nv))
         return diff, float(dang)
