@@ -265,6 +265,7 @@ struct graph_t {  // behind cugraph_graph_t (cpp/src/c_api/graph.hpp:61-77)
   // cached out-weight sums (a5 in SURVEY 8a): float or double, size V
   dev_buf out_weight_sums;
   bool out_weight_sums_valid{false};
+  int bfs_calls{0};  // the CSC (bottom-up BFS levels) is built from the second traversal of a non-symmetric graph on
 };
 
 inline handle_t const& H(cugraph_resource_handle_t const* h)

@@ -46,6 +46,8 @@ struct counters_t {  // device-resident, zeroed per step
   uint32_t far_min_bits_lo;  // (SSSP split) min distance bits kept in far (32-bit types)
   uint32_t pad2;
   unsigned long long far_min_bits64;
+  unsigned long long out_edges;  // BFS: sum of out-degrees of the vertices discovered in this level (top-down cost of the next)
+  unsigned long long in_edges;   // BFS: sum of their in-degrees (they leave the bottom-up work)
 };
 
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t* total)
@@ -76,7 +78,7 @@ __device__ __forceinline__ void wave_push(bool flag, int32_t value, int32_t* q, 
 // bigq for k_expand_big.
 template <typename Keep, typename F>
 __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices,
-                                                int32_t* bigq, counters_t* cnt, Keep keep, F f)
+                                                int32_t* bigq, counters_t* cnt, Keep keep, F& f)
 {
   __shared__ uint32_t s_scan[TV_WAVES][64];
   __shared__ int32_t s_beg[TV_WAVES][64];
@@ -130,7 +132,7 @@ __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int
 }
 
 template <typename F>
-__device__ __forceinline__ void expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, counters_t* cnt, F f)
+__device__ __forceinline__ void expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, counters_t* cnt, F& f)
 {
   uint32_t nbig = cnt->n_big;
   int64_t const tid  = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -144,30 +146,57 @@ __device__ __forceinline__ void expand_big(int32_t const* bigq, int32_t const* o
 }
 
 // --------------------------------------------------------------------------------------------- BFS
+// Level-synchronous, direction-optimising (Beamer): small frontiers are expanded top-down from a queue (push over the
+// out-edges, visited bits claimed with atomicOr after a plain pre-test), large ones bottom-up (every unvisited vertex
+// scans its in-neighbours -- ascending ids = hubs first under the degree-sorted numbering -- and stops at the first one
+// in the frontier bitmap; one wavefront owns 64 consecutive vertices = two bitmap words, so there are no atomics at all).
+// Replaces bfs_impl.cuh:133-870 incl. the bottom-up branch (per_v_transform_reduce_if_outgoing_e, :587-805 there).
+// Distances do not depend on the direction.  The parent reported for v is, among its valid parents (in-neighbours one
+// level up), the one with the smallest INTERNAL id -- i.e. the highest-degree one: top-down levels claim it with atomicMin
+// (after a plain pre-test), bottom-up levels get it for free because neighbour lists are sorted by internal id and the scan
+// stops at the first frontier member.  A valid instance of the reference's reduce_op::any (bfs_impl.cuh:467; its test only
+// validates parents, bfs_test.cpp:217-233), deterministic, and identical whichever direction each level ran in.
 struct bfs_state {
   int32_t* dist;
-  int32_t* pred;               // EXTERNAL id of the parent, INT32_MAX = none yet (fixed up to -1 at the end); nullptr when not requested
-  int32_t const* labels;       // internal -> external id (number_map); nullptr = identity
+  int32_t* pred;               // INTERNAL id of the parent, INT32_MAX = none yet (mapped to external ids / -1 at the end); nullptr when not requested
   uint32_t const* vis_prev;    // visited as of the start of the level
   uint32_t* vis_new;           // cumulative
   int32_t* q_next;
   counters_t* cnt;
+  int32_t const* out_offsets;  // degree sums for the direction heuristic
+  int32_t const* in_offsets;
   int32_t next_depth;
 };
 
 struct bfs_visit {
   bfs_state s;
-  __device__ __forceinline__ void operator()(int32_t u, int32_t v, int32_t) const
+  unsigned long long acc_out{0}, acc_in{0};
+  __device__ __forceinline__ void operator()(int32_t u, int32_t v, int32_t)
   {
     uint32_t bit = 1u << (v & 31);
     bool fresh   = false;
     if (!(s.vis_prev[v >> 5] & bit)) {
-      uint32_t old = atomicOr(&s.vis_new[v >> 5], bit);
-      fresh        = !(old & bit);
-      if (fresh) s.dist[v] = s.next_depth;
-      if (s.pred) atomicMin(&s.pred[v], s.labels ? s.labels[u] : u);  // minimum EXTERNAL parent id: independent of the internal numbering
+      // plain pre-test of the cumulative word: hub destinations are claimed once and then skipped without an atomic
+      // (a stale read only costs a redundant atomicOr)
+      bool claimed = (__builtin_nontemporal_load(&s.vis_new[v >> 5]) & bit) != 0;
+      if (!claimed) {
+        uint32_t old = atomicOr(&s.vis_new[v >> 5], bit);
+        fresh        = !(old & bit);
+      }
+      if (fresh) {
+        s.dist[v] = s.next_depth;
+        acc_out += (unsigned long long)(s.out_offsets[v + 1] - s.out_offsets[v]);
+        acc_in += (unsigned long long)(s.in_offsets[v + 1] - s.in_offsets[v]);
+      }
+      if (s.pred && u < __builtin_nontemporal_load(&s.pred[v])) atomicMin(&s.pred[v], u);  // minimum internal id among the frontier parents
     }
     wave_push(fresh, v, s.q_next, &s.cnt->n_next, threadIdx.x & 63);
+  }
+  __device__ __forceinline__ void flush()
+  {
+    unsigned long long a = acc_out, b = acc_in;
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if ((threadIdx.x & 63) == 0 && (a | b)) { atomicAdd(&s.cnt->out_edges, a); atomicAdd(&s.cnt->in_edges, b); }
   }
 };
 
@@ -176,15 +205,137 @@ struct keep_all { __device__ __forceinline__ bool operator()(int32_t) const { re
 __global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices,
                                                          int32_t* bigq, bfs_state s)
 {
-  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, bfs_visit{s});
+  bfs_visit f{s};
+  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f);
+  f.flush();
 }
 __global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, bfs_state s)
 {
-  expand_big(bigq, offsets, indices, s.cnt, bfs_visit{s});
+  bfs_visit f{s};
+  expand_big(bigq, offsets, indices, s.cnt, f);
+  f.flush();
+}
+
+// Bottom-up level.  in_offsets / in_indices = the orientation whose rows are DESTINATIONS (CSC; the CSR itself when the
+// graph is symmetric).  front = frontier bitmap of the current level; next (fully rewritten) = vertices found.
+constexpr int32_t BU_COOP_DEG = 512;  // rows at least this long that a single lane did not settle quickly are scanned by the whole wave
+__global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_offsets, int32_t const* in_indices, int32_t const* out_offsets,
+                                                            int64_t nv, uint32_t* vis, uint32_t const* front, uint32_t* next, int32_t* dist,
+                                                            int32_t* pred, int32_t next_depth, counters_t* cnt)
+{
+  int const lane       = threadIdx.x & 63;
+  int64_t const gwave  = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t const nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int64_t const ngroup = (nv + 63) >> 6;
+  unsigned long long inspected = 0, acc_out = 0, acc_in = 0;
+  uint32_t found_total = 0;
+  for (int64_t grp = gwave; grp < ngroup; grp += nwaves) {
+    int64_t const v = grp * 64 + lane;
+    uint32_t const word = vis[(grp * 2) + (lane >> 5)];
+    bool const unvisited = v < nv && !((word >> (lane & 31)) & 1u);
+    bool found = false;
+    int32_t b = 0, e = 0, parent = -1;
+    if (unvisited) { b = in_offsets[v]; e = in_offsets[v + 1]; }
+    bool const coop = unvisited && (e - b) >= BU_COOP_DEG;
+    if (unvisited && !coop) {
+      int32_t p = b;
+      for (; p < e; ++p) {
+        int32_t u = in_indices[p];
+        if ((front[u >> 5] >> (u & 31)) & 1u) { found = true; parent = u; ++p; break; }  // ascending ids: the first hit is the minimum
+      }
+      inspected += (unsigned long long)(p - b);
+    }
+    uint64_t cm = __ballot(coop);
+    while (cm) {  // long rows: the wavefront strides the row, 64 neighbours per step, and stops at the first hit
+      int src = __ffsll((unsigned long long)cm) - 1;
+      cm &= cm - 1;
+      int32_t bb = __shfl(b, src), ee = __shfl(e, src);
+      bool hit = false;
+      int32_t p = bb, par = -1;
+      for (; p < ee && !hit; p += 64) {
+        int32_t q = p + lane, u = -1;
+        bool h    = false;
+        if (q < ee) { u = in_indices[q]; h = ((front[u >> 5] >> (u & 31)) & 1u) != 0; }
+        uint64_t hm = __ballot(h);
+        hit         = hm != 0;
+        if (hit) par = __shfl(u, __ffsll((unsigned long long)hm) - 1);  // lowest lane = smallest position = smallest id
+      }
+      if (lane == src) { found = hit; parent = par; inspected += (unsigned long long)(min(p, ee) - bb); }
+    }
+    uint64_t const fm = __ballot(found);
+    if (lane == 0) {
+      uint32_t lo = (uint32_t)fm, hi = (uint32_t)(fm >> 32);
+      next[grp * 2]     = lo;
+      next[grp * 2 + 1] = hi;
+      if (lo) vis[grp * 2] |= lo;       // this wavefront is the only writer of these two words
+      if (hi) vis[grp * 2 + 1] |= hi;
+    }
+    if (found) {
+      dist[v] = next_depth;
+      if (pred) pred[v] = parent;
+      acc_out += (unsigned long long)(out_offsets[v + 1] - out_offsets[v]);
+      acc_in += (unsigned long long)(e - b);
+    }
+    found_total += (uint32_t)__popcll(fm);
+  }
+  for (int o = 32; o > 0; o >>= 1) { inspected += __shfl_xor(inspected, o); acc_out += __shfl_xor(acc_out, o); acc_in += __shfl_xor(acc_in, o); }
+  if (lane == 0) {
+    if (found_total) atomicAdd(&cnt->n_next, found_total);
+    if (inspected) atomicAdd(&cnt->edges, inspected);
+    if (acc_out | acc_in) { atomicAdd(&cnt->out_edges, acc_out); atomicAdd(&cnt->in_edges, acc_in); }
+  }
+}
+
+// front <- snapshot of the visited set (an unvisited vertex cannot have an in-neighbour that was visited before the
+// latest level, so testing against everything visited so far is the same as testing against the frontier);
+// vis_prev <- vis_new
+__global__ void k_bfs_front_from_vis(uint32_t* vis_prev, uint32_t const* vis_new, uint32_t* front, int64_t nwords)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nwords; i += stride) {
+    uint32_t n  = vis_new[i];
+    front[i]    = n;
+    vis_prev[i] = n;
+  }
+}
+
+// queue <- set bits of a bitmap (order within the queue is immaterial)
+__global__ void __launch_bounds__(TV_BLOCK) k_bfs_bitmap_to_queue(uint32_t const* bits, int64_t nwords, int32_t* q, counters_t* cnt)
+{
+  int const lane = threadIdx.x & 63;
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t n_pad  = (nwords + 63) & ~(int64_t)63;
+  for (; i < n_pad; i += stride) {
+    uint32_t w = i < nwords ? bits[i] : 0u;
+    uint32_t c = __popc(w), total;
+    uint32_t ex = wave_excl_scan(c, lane, &total);
+    if (total == 0) continue;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&cnt->n_big, total);  // n_big doubles as the queue cursor of this kernel
+    base = __shfl(base, 0) + ex;
+    while (w) {
+      int b = __ffs((int)w) - 1;
+      w &= w - 1;
+      q[base++] = (int32_t)(i * 32 + b);
+    }
+  }
+}
+
+// parents: internal ids -> external ids, INT32_MAX (none) -> -1 (invalid_vertex_id)
+__global__ void k_bfs_finish_pred(int32_t* pred, int64_t n, int32_t const* labels)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    int32_t p = pred[i];
+    pred[i]   = p == INT32_MAX ? -1 : (labels ? labels[p] : p);
+  }
 }
 
 __global__ void k_bfs_init_sources(int32_t const* src, int64_t n, int32_t* dist, uint32_t* vis_prev, uint32_t* vis_new, int32_t* q,
-                                   counters_t* cnt)
+                                   counters_t* cnt, int32_t const* out_offsets, int32_t const* in_offsets)
 {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -195,6 +346,8 @@ __global__ void k_bfs_init_sources(int32_t const* src, int64_t n, int32_t* dist,
     atomicOr(&vis_prev[v >> 5], bit);
     dist[v] = 0;
     q[atomicAdd(&cnt->n_next, 1u)] = v;
+    atomicAdd(&cnt->out_edges, (unsigned long long)(out_offsets[v + 1] - out_offsets[v]));
+    atomicAdd(&cnt->in_edges, (unsigned long long)(in_offsets[v + 1] - in_offsets[v]));
   }
 }
 
@@ -253,13 +406,15 @@ template <typename WT>
 __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices,
                                                           int32_t* bigq, sssp_state<WT> s)
 {
-  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, sssp_relax<WT>{s});
+  sssp_relax<WT> f{s};
+  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f);
 }
 template <typename WT>
 __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices,
                                                               sssp_state<WT> s)
 {
-  expand_big(bigq, offsets, indices, s.cnt, sssp_relax<WT>{s});
+  sssp_relax<WT> f{s};
+  expand_big(bigq, offsets, indices, s.cnt, f);
 }
 
 // far pile -> (near frontier | far pile'): d < lower: settled meanwhile, drop; d < upper: near; else keep
@@ -355,6 +510,17 @@ __global__ void k_fill_t(T* p, int64_t n, T v)
   for (; i < n; i += stride) p[i] = v;
 }
 
+__global__ void k_bfs_edges_of_reached(int32_t const* dist, int32_t const* out_offsets, int64_t nv, unsigned long long* out)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long c = 0;
+  for (; i < nv; i += stride)
+    if (dist[i] != INT32_MAX) c += (unsigned long long)(out_offsets[i + 1] - out_offsets[i]);
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
 __global__ void k_count_reached(uint32_t const* vis, int64_t nwords, unsigned long long* out)
 {
   int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -389,15 +555,32 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
                         bool compute_predecessors)
 {
   HIP_TRY(hipSetDevice(h.device));
+  static bool const trace = getenv("CUGRAPH_AMD_BFS_TRACE") != nullptr;
+  auto mark = [&](char const* what, long long a0 = 0, long long a1 = 0) { if (trace) { h.sync(); fprintf(stderr, "[bfs] %s %lld %lld\n", what, a0, a1); fflush(stderr); } };
   CGA_EXPECTS(sources != nullptr, CUGRAPH_INVALID_INPUT, "sources is NULL");
   CGA_EXPECTS(g.vertex_type == sources->type, CUGRAPH_INVALID_INPUT, "vertex type of graph and sources must match");
   if (direction_optimizing)  // bfs_impl.cuh:202-204
     CGA_EXPECTS(g.props.is_symmetric == TRUE, CUGRAPH_INVALID_INPUT,
                 "Invalid input argument: input graph should be symmetric for direction optimizing BFS.");
-  ensure_orientation(h, g, false);  // BFS pushes over CSR
+  ensure_orientation(h, g, false);  // top-down pushes over CSR
   orientation_t const& o = g.csr;
   int64_t const nv = g.nv, ns = (int64_t)sources->size;
   size_t const n1  = (size_t)(nv > 0 ? nv : 1);
+
+  // Bottom-up levels need the in-edges.  A symmetric graph's CSR is its CSC; otherwise the CSC is used when it exists
+  // already (e.g. after a PageRank call) and built from the second BFS on (it costs about as much as three traversals).
+  // The direction never changes distances, so this is independent of the API's direction_optimizing flag.
+  char const* env = getenv("CUGRAPH_AMD_BFS");  // "topdown" pins the push-only path (testing / profiling)
+  bool const pin_topdown = env && std::string(env) == "topdown";
+  ++g.bfs_calls;
+  orientation_t const* in = nullptr;
+  if (!pin_topdown) {
+    if (g.props.is_symmetric == TRUE) in = &g.csr;
+    else if (g.csc.built || g.bfs_calls >= 2 || (env && std::string(env) == "bottomup")) { ensure_orientation(h, g, true); in = &g.csc; }
+  }
+  int32_t const* in_off  = in ? in->offsets.data() : o.offsets.data();
+  int32_t const* in_idx  = in ? in->indices.data() : nullptr;
+  int32_t const* out_off = o.offsets.data();
 
   dvec<int32_t> src(ns > 0 ? ns : 1);
   if (ns > 0) HIP_TRY(hipMemcpyAsync(src.data(), sources->data, ns * 4, hipMemcpyDeviceToDevice, h.stream));
@@ -407,43 +590,93 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   auto ids   = std::make_unique<device_array_t>((size_t)nv, g.vertex_type);
   auto dist  = std::make_unique<device_array_t>((size_t)nv, g.vertex_type);
   auto preds = std::make_unique<device_array_t>(compute_predecessors ? (size_t)nv : 0, g.vertex_type);
-  int64_t const nwords = (nv + 31) / 32 + 1;
-  dvec<uint32_t> vis_prev(nwords), vis_new(nwords);
+  int64_t const nwords = ((nv + 63) / 64) * 2 + 2;  // whole 64-vertex groups
+  dvec<uint32_t> vis_prev(nwords), vis_new(nwords), front(in ? nwords : 1), next(in ? nwords : 1);
   dvec<int32_t> qa(n1), qb(n1), bigq(n1);
   dvec<counters_t> cnt(1);
   fill_i32(h, dist->buf.as<int32_t>(), nv, INT32_MAX);
   if (compute_predecessors) fill_i32(h, preds->buf.as<int32_t>(), nv, INT32_MAX);
+  int32_t* const pred_p = compute_predecessors ? preds->buf.as<int32_t>() : nullptr;
   int32_t const* labels = g.renumbered ? g.number_map.data() : nullptr;
   HIP_TRY(hipMemsetAsync(vis_prev.data(), 0, nwords * 4, h.stream));
   HIP_TRY(hipMemsetAsync(vis_new.data(), 0, nwords * 4, h.stream));
+  if (in) {  // the bottom-up kernel rewrites whole 64-vertex groups only: the two slack words must read as "no vertex"
+    HIP_TRY(hipMemsetAsync(front.data(), 0, nwords * 4, h.stream));
+    HIP_TRY(hipMemsetAsync(next.data(), 0, nwords * 4, h.stream));
+  }
   HIP_TRY(hipMemsetAsync(cnt.data(), 0, sizeof(counters_t), h.stream));
   if (ns > 0)
     hipLaunchKernelGGL(k_bfs_init_sources, grid_for(ns, kBlock), kBlock, 0, h.stream, (int32_t const*)src.data(), ns, dist->buf.as<int32_t>(),
-                       vis_prev.data(), vis_new.data(), qa.data(), cnt.data());
+                       vis_prev.data(), vis_new.data(), qa.data(), cnt.data(), out_off, in_off);
+  mark("init", nv, ns);
   counters_t c;
   h.read_back(&c, cnt.data(), 1);
   int64_t n_cur  = c.n_next;
   int32_t* q_cur = qa.data();
   int32_t* q_nxt = qb.data();
-  uint64_t depth = 0, edges = 0, levels = 0;
+  uint64_t depth = 0, edges = 0, levels = 0, bu_levels = 0;
+  // Beamer's heuristic: go bottom-up when the frontier's out-edges exceed 1/alpha of the unvisited vertices' in-edges,
+  // come back when the frontier has shrunk below V / beta
+  double const alpha = 14.0, beta = 24.0;
+  uint64_t frontier_out = c.out_edges;            // out-edges of the current frontier
+  uint64_t unvisited_in = (uint64_t)g.ne - c.in_edges;
+  bool bottom_up = false, front_is_bitmap = false;
   // depth_limit is compared after incrementing (bfs_impl.cuh:867-868)
   uint64_t const limit = depth_limit > (size_t)INT32_MAX ? (uint64_t)INT32_MAX : (uint64_t)depth_limit;
+  int const bu_grid = (int)std::max<int64_t>(1, std::min<int64_t>(((nv + 63) / 64 + TV_WAVES - 1) / TV_WAVES, (int64_t)h.num_cus * 16));
   while (n_cur > 0) {
-    HIP_TRY(hipMemsetAsync(cnt.data(), 0, sizeof(counters_t), h.stream));
-    bfs_state s{dist->buf.as<int32_t>(), compute_predecessors ? preds->buf.as<int32_t>() : nullptr, labels, vis_prev.data(), vis_new.data(), q_nxt,
-                cnt.data(), (int32_t)(depth + 1)};
-    {
-      timed_launch t(h, "bfs_expand");
-      hipLaunchKernelGGL(k_bfs_expand, expand_grid(h, n_cur), TV_BLOCK, 0, h.stream, (int32_t const*)q_cur, n_cur, (int32_t const*)o.offsets.data(),
-                         (int32_t const*)o.indices.data(), bigq.data(), s);
-      hipLaunchKernelGGL(k_bfs_expand_big, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
-                         (int32_t const*)o.indices.data(), s);
+    if (in) {
+      if (!bottom_up) bottom_up = (double)frontier_out > (double)unvisited_in / alpha && n_cur > 1024;
+      else bottom_up = !((double)n_cur < (double)nv / beta);
+      if (env && std::string(env) == "bottomup") bottom_up = true;
     }
-    HIP_TRY(hipMemcpyAsync(vis_prev.data(), vis_new.data(), nwords * 4, hipMemcpyDeviceToDevice, h.stream));
+    HIP_TRY(hipMemsetAsync(cnt.data(), 0, sizeof(counters_t), h.stream));
+    if (bottom_up) {
+      if (!front_is_bitmap)  // the last level ran top-down (queue): snapshot the visited set as the bitmap to test against
+        hipLaunchKernelGGL(k_bfs_front_from_vis, grid_for(nwords, kBlock, 2048), kBlock, 0, h.stream, vis_prev.data(), (uint32_t const*)vis_new.data(),
+                           front.data(), nwords);
+      {
+        timed_launch t(h, "bfs_bottom_up");
+        hipLaunchKernelGGL(k_bfs_bottom_up, bu_grid, TV_BLOCK, 0, h.stream, in_off, in_idx, out_off, nv, vis_new.data(), (uint32_t const*)front.data(),
+                           next.data(), dist->buf.as<int32_t>(), pred_p, (int32_t)(depth + 1), cnt.data());
+      }
+      mark("bottom_up", (long long)depth, n_cur);
+      std::swap(front, next);  // `next` of this level is the frontier bitmap of the following one
+      front_is_bitmap = true;
+      ++bu_levels;
+    } else {
+      if (front_is_bitmap) {  // the last level ran bottom-up: materialise its discoveries as a queue
+        hipLaunchKernelGGL(k_bfs_bitmap_to_queue, grid_for(nwords, TV_BLOCK, 2048), TV_BLOCK, 0, h.stream, (uint32_t const*)front.data(), nwords, q_cur,
+                           cnt.data());
+        HIP_TRY(hipMemsetAsync(cnt.data(), 0, sizeof(counters_t), h.stream));
+        HIP_TRY(hipMemcpyAsync(vis_prev.data(), vis_new.data(), nwords * 4, hipMemcpyDeviceToDevice, h.stream));
+        front_is_bitmap = false;
+        mark("bitmap_to_queue", (long long)depth, n_cur);
+      }
+      bfs_state s{dist->buf.as<int32_t>(), pred_p, vis_prev.data(), vis_new.data(), q_nxt,
+                  cnt.data(), out_off, in_off, (int32_t)(depth + 1)};
+      {
+        timed_launch t(h, "bfs_expand");
+        hipLaunchKernelGGL(k_bfs_expand, expand_grid(h, n_cur), TV_BLOCK, 0, h.stream, (int32_t const*)q_cur, n_cur, (int32_t const*)o.offsets.data(),
+                           (int32_t const*)o.indices.data(), bigq.data(), s);
+        hipLaunchKernelGGL(k_bfs_expand_big, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
+                           (int32_t const*)o.indices.data(), s);
+      }
+      if (!in) HIP_TRY(hipMemcpyAsync(vis_prev.data(), vis_new.data(), nwords * 4, hipMemcpyDeviceToDevice, h.stream));
+      mark("top_down", (long long)depth, n_cur);
+      std::swap(q_cur, q_nxt);
+    }
     h.read_back(&c, cnt.data(), 1);
     edges += c.edges;
-    n_cur = c.n_next;
-    std::swap(q_cur, q_nxt);
+    n_cur        = c.n_next;
+    frontier_out = c.out_edges;
+    unvisited_in -= std::min<uint64_t>(unvisited_in, c.in_edges);
+    if (in && !bottom_up && !front_is_bitmap) {
+      // keep vis_prev one level behind only while the next level may need vis_new & ~vis_prev; a following top-down
+      // level needs vis_prev = vis_new (done lazily here when the decision is known to be top-down again)
+      bool next_bu = ((double)frontier_out > (double)unvisited_in / alpha && n_cur > 1024) || (env && std::string(env) == "bottomup");
+      if (!next_bu) HIP_TRY(hipMemcpyAsync(vis_prev.data(), vis_new.data(), nwords * 4, hipMemcpyDeviceToDevice, h.stream));
+    }
     ++depth;
     ++levels;
     if (depth >= limit) break;
@@ -452,12 +685,23 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   dvec<unsigned long long> reached(1);
   HIP_TRY(hipMemsetAsync(reached.data(), 0, 8, h.stream));
   hipLaunchKernelGGL(k_count_reached, grid_for(nwords, kBlock, 1024), kBlock, 0, h.stream, (uint32_t const*)vis_new.data(), nwords, reached.data());
+  mark("count_reached");
   unsigned long long nreached;
   h.read_back(&nreached, reached.data(), 1);
-  h.last_stats = cugraph_amd_traversal_stats_t{levels, edges, nreached, edges};
+  h.last_stats = cugraph_amd_traversal_stats_t{levels, edges, nreached, edges};  // push-only: every out-edge of a reached vertex was inspected once
+  if (in) {  // bottom-up levels inspect in-edges (and stop early): count the out-edges of the reached vertices directly
+    dvec<unsigned long long> er(1);
+    HIP_TRY(hipMemsetAsync(er.data(), 0, 8, h.stream));
+    hipLaunchKernelGGL(k_bfs_edges_of_reached, grid_for(nv, kBlock, 2048), kBlock, 0, h.stream, dist->buf.as<int32_t const>(), out_off, nv, er.data());
+    unsigned long long ev;
+    h.read_back(&ev, er.data(), 1);
+    h.last_stats.edges_of_reached = ev;
+  }
+  (void)bu_levels;
   if (nv > 0) HIP_TRY(hipMemcpyAsync(ids->buf.ptr, g.number_map.data(), nv * 4, hipMemcpyDeviceToDevice, h.stream));
-  if (compute_predecessors && nv > 0)  // parents already carry external ids (bfs.cpp:131-138 unrenumbers afterwards instead)
-    hipLaunchKernelGGL(k_fix_pred, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, preds->buf.as<int32_t>(), nv);
+  if (compute_predecessors && nv > 0)  // bfs.cpp:131-138 unrenumbers the predecessors the same way
+    hipLaunchKernelGGL(k_bfs_finish_pred, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, pred_p, nv, labels);
+  mark("finish_pred");
   h.sync();
   return new paths_result_t{ids.release(), dist.release(), preds.release()};
 }
