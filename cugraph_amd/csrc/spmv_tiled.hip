@@ -148,7 +148,7 @@ __global__ void k_assign_slots(uint64_t const* keys, uint32_t const* vals, int64
     uint32_t idx  = vals[s];
     uint32_t slot = (uint32_t)s + shift[I];  // modulo 2^32
     if ((int64_t)idx < n_runs) {
-      rpos[idx]    = slot;
+      rpos[idx + 1] = slot;
       dstl16[slot] = (uint16_t)(run_dst[idx] - tile_row0[I]);
     } else {
       tiled_wave_t& wd = waves[idx - n_runs];
@@ -199,7 +199,7 @@ std::vector<uint32_t> key_starts(handle_t const& h, uint64_t const* keys, int64_
 int tiled_default_T(handle_t const& h, size_t vsize, int64_t nv)
 {
   // LDS = tile (T values) + one TP_SUB-entry staging row per wavefront + a few static words
-  int64_t const lds_max = ((int64_t)h.lds_per_block - 2048) / (int64_t)vsize - (int64_t)TP_WAVES * TP_SUB;
+  int64_t const lds_max = ((int64_t)h.lds_per_block / TP_WG_PER_CU - 1536) / (int64_t)vsize - (int64_t)TP_WAVES * TP_STAGE;
   int64_t T = h.pagerank_hot_tile > 0 ? h.pagerank_hot_tile : lds_max;
   T = std::min<int64_t>({T, lds_max, 65536});
   T = std::min<int64_t>(T, (std::max<int64_t>(nv, 1) + 255) / 256 * 256);  // small graphs: one small tile
@@ -367,7 +367,11 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     size_t const spad = (size_t)t.n_slots + 64;
     t.dstl16.resize_discard(spad);
     HIP_TRY(hipMemsetAsync(t.dstl16.data(), 0, spad * sizeof(uint16_t), h.stream));
-    t.rpos.resize_discard(t.n_runs > 0 ? t.n_runs : 1);
+    CGA_EXPECTS((uint64_t)t.ne_pad * 2 + 65536 < ((uint64_t)1 << 32) && ((uint64_t)t.n_runs + 512) * 4 < ((uint64_t)1 << 32) &&
+                  ((uint64_t)t.n_slots + 64) * vsize < ((uint64_t)1 << 32),
+                CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: an array exceeds the 32-bit byte-offset addressing of phase 1");
+    t.rpos.resize_discard((size_t)t.n_runs + 512);  // [0] = dummy (the "run" before run 0), run q at [q + 1], zero padding behind
+    HIP_TRY(hipMemsetAsync(t.rpos.data(), 0, ((size_t)t.n_runs + 512) * sizeof(uint32_t), h.stream));
     dvec<uint32_t> d_shift;
     to_device(h, d_shift, shift);
     hipLaunchKernelGGL(k_assign_slots, grid_for(n_el, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), n_el,
@@ -377,13 +381,14 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   } else {
     t.n_slots = 0;
     t.dstl16.resize_discard(64);
-    t.rpos.resize_discard(1);
+    t.rpos.resize_discard(512);
+    HIP_TRY(hipMemsetAsync(t.rpos.data(), 0, 512 * sizeof(uint32_t), h.stream));
   }
   to_device(h, t.region_off, region_off);
 
   // ---- phase-1 chunks: up to TP_CHUNK consecutive items of one source tile; handed out dynamically in this order
   {
-    size_t const lds = ((size_t)T + (size_t)TP_WAVES * TP_SUB) * vsize;
+    size_t const lds = ((size_t)T + (size_t)TP_WAVES * TP_STAGE) * vsize;
     int const per_cu = std::max<int>(1, std::min<int>(2, (int)((h.lds_per_block - 1024) / (lds + 64))));
     std::vector<int32_t> begin;
     int const max_wg = h.num_cus * per_cu;
@@ -537,7 +542,7 @@ struct p1_args {
   uint16_t const* src16;
   uint8_t const* bits;
   WT const* weights;
-  uint32_t const* rpos;
+  uint32_t const* rpos1;  // rpos shifted by one entry: slot of run q at [q + 1], padded
   int32_t const* item_tile;
   tiled_wave_t const* waves;
   int32_t const* chunk_begin;  // [n_chunks + 1] first work item of each chunk (items of a chunk share one source tile)
@@ -554,158 +559,160 @@ struct p1_args {
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-struct p1_regs {  // one work item's data for one lane: TP_U rounds of 8 edges + the wavefront's descriptor
-  uint4 id[TP_U];
-  uint32_t fl[TP_U];
-  uint4 wd;  // tiled_wave_t (same address in every lane)
+// 32-bit byte offsets from a wave-uniform base: the load/store takes the SGPR-base + VGPR-offset form (one VGPR and no
+// 64-bit address arithmetic per access).  build_tiled_csc checks that every array stays below 4 GiB.
+template <typename T>
+__device__ __forceinline__ T ld32(void const* base, uint32_t byte_off)
+{
+  return *reinterpret_cast<T const*>(static_cast<char const*>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ void st32(void* base, uint32_t byte_off, T v)
+{
+  *reinterpret_cast<T*>(static_cast<char*>(base) + byte_off) = v;
+}
+
+struct p1_regs {  // one work item's data for one lane: TP_EPL consecutive edges + the wavefront's descriptor
+  uint4 id[TP_EPL / 8];
+  uint32_t fl;  // TP_EPL run-start bits
+  uint4 wd;     // tiled_wave_t (same address in every lane)
 };
 
 template <typename WT>
 __device__ __forceinline__ void p1_load(p1_args<WT> const& a, int item, int wave, int lane, p1_regs& r)
-{  // arrays are over-allocated and zero padded: no bounds checks, all loads of the item in flight together
-  uint32_t const es = (uint32_t)item * (uint32_t)TP_ITEM + (uint32_t)wave * TP_WLEN;
+{  // arrays are over-allocated and zero padded: no bounds checks
+  uint32_t const e = (uint32_t)item * (uint32_t)TP_ITEM + (uint32_t)wave * TP_WLEN + (uint32_t)TP_EPL * (uint32_t)lane;
 #pragma unroll
-  for (int g = 0; g < TP_U; ++g) {
-    uint32_t e = es + g * TP_SUB + 8 * lane;
-    r.id[g]    = *reinterpret_cast<uint4 const*>(a.src16 + e);
-    r.fl[g]    = a.bits[e >> 3];
-  }
-  r.wd = *reinterpret_cast<uint4 const*>(a.waves + (size_t)item * TP_WAVES + wave);
+  for (int j = 0; j < TP_EPL / 8; ++j) r.id[j] = ld32<uint4>(a.src16, 2u * e + 16u * j);
+  if constexpr (TP_EPL == 16) r.fl = ld32<uint16_t>(a.bits, e >> 3);
+  else r.fl = ld32<uint8_t>(a.bits, e >> 3);
+  r.wd    = ld32<uint4>(a.waves, ((uint32_t)item * TP_WAVES + (uint32_t)wave) * (uint32_t)sizeof(tiled_wave_t));
 }
 
-struct p1_runs {  // what pass A derives from the bitmap of one work item
-  uint32_t f[TP_U], nf[TP_U], ex_c[TP_U], c_all[TP_U], closed_at[TP_U];
-  uint32_t slot0[TP_U], slot1[TP_U];  // slots of runs lane and 64 + lane of each round
+struct p1_runs {  // what part 1 derives from the bitmap of one work item
+  uint32_t f, nf, ex_c, c_all;
+  uint32_t slot0, slot1;  // slots of runs `lane` and `64 + lane`
   uint32_t es, ee, rank, head_slot;
 };
 
-// pass A (bitmap only): run counts of every round; the slots of the first 128 runs of each round are requested right away
-// (BEFORE the next item's edge data is requested: vmcnt retires in order, so waiting for these must not imply waiting
-// for the prefetch) -- their latency hides behind the LDS gathers and scans of pass B
+// Part 1 (bitmap only): run counts of the wavefront's 1024 edges; the slots of its first 128 runs are requested right away
+// (BEFORE the next item's edge data is requested: vmcnt retires in order, so waiting for these must not imply waiting for
+// the prefetch) -- their latency hides behind the LDS gathers and scans of part 2.
+// Run ordinal n within the wavefront's range: n = 0 is the run that was already open at `es` (its partial goes to the
+// head slot), n >= 1 is run (rank - 1 + n), whose slot is rpos1[rank + n] (rpos1 = rpos shifted by one entry).
 template <typename WT>
-__device__ __forceinline__ void p1_pass_a(p1_args<WT> const& a, int lane, p1_regs const& rg, p1_runs& q)
+__device__ __forceinline__ void p1_part1(p1_args<WT> const& a, int lane, p1_regs const& rg, p1_runs& q)
 {
   q.es = rfl(rg.wd.x); q.ee = rfl(rg.wd.y); q.rank = rfl(rg.wd.z); q.head_slot = rfl(rg.wd.w);
-  uint32_t closed = 0;
-#pragma unroll
-  for (int g = 0; g < TP_U; ++g) {
-    uint32_t const e     = q.es + g * TP_SUB + 8 * lane;
-    uint32_t const nval  = min((uint32_t)8, q.ee > e ? q.ee - e : 0u);
-    q.f[g]               = rg.fl[g] & ((1u << nval) - 1u);
-    q.nf[g]              = __popc(q.f[g]);
-    uint32_t const c_inc = wave_inclusive_sum_u32(q.nf[g]);
-    q.ex_c[g]            = c_inc - q.nf[g];
-    q.c_all[g]           = (uint32_t)__builtin_amdgcn_readlane((int)c_inc, 63);
-    q.closed_at[g]       = closed;
-    closed += q.c_all[g];
-  }
-#pragma unroll
-  for (int g = 0; g < TP_U; ++g) {
-    // ordinal n within the wavefront's range: n = 0 is the run that was already open at `es` (its partial goes to the
-    // head slot), n >= 1 is run (rank - 1 + n)
-    uint32_t const n = q.closed_at[g] + (uint32_t)lane;
-    q.slot0[g]       = q.head_slot;
-    q.slot1[g]       = q.head_slot;
-    if ((uint32_t)lane < q.c_all[g] && n != 0) q.slot0[g] = a.rpos[q.rank - 1 + n];
-    if ((uint32_t)lane + 64 < q.c_all[g]) q.slot1[g] = a.rpos[q.rank - 1 + n + 64];
-  }
+  uint32_t const e     = q.es + (uint32_t)TP_EPL * (uint32_t)lane;
+  uint32_t const nval  = min((uint32_t)TP_EPL, q.ee > e ? q.ee - e : 0u);
+  q.f                  = rg.fl & ((1u << nval) - 1u);
+  q.nf                 = __popc(q.f);
+  uint32_t const c_inc = wave_inclusive_sum_u32(q.nf);
+  q.ex_c               = c_inc - q.nf;
+  q.c_all              = (uint32_t)__builtin_amdgcn_readlane((int)c_inc, 63);
+  uint32_t const o     = 4u * (q.rank + (uint32_t)lane);
+  uint32_t const s0    = ld32<uint32_t>(a.rpos1, o);  // unconditional (rpos1 is padded): no exec juggling
+  uint32_t const s1    = ld32<uint32_t>(a.rpos1, o + 256u);
+  q.slot0              = lane == 0 ? q.head_slot : s0;
+  q.slot1              = s1;
 }
 
-// pass B: values.  `stage`: this wavefront's TP_SUB-entry LDS scratch (run totals of one round, in run order).
-// Rounds are handled in pairs: B1 computes the LDS gathers, in-lane segmented sums and wave64 segmented scans of both
-// rounds (two independent dependency chains the scheduler can interleave -- 4 wavefronts per SIMD is all the occupancy a
-// 126 KiB tile leaves, and the 128-VGPR budget does not fit more than two rounds of values); B2 emits the run totals.
-template <typename WT, bool WEIGHTED>
-__device__ __forceinline__ void p1_pass_b(p1_args<WT> const& a, WT const* xs, WT* stage, int lane, p1_regs const& rg, p1_runs const& q)
+// run totals of lanes [lane_lo, lane_hi) -> staging area (in run order) -> coalesced stores
+template <typename WT>
+__device__ __forceinline__ void p1_emit(p1_args<WT> const& a, WT* stage, int lane, p1_runs const& q, WT const (&r)[TP_EPL], WT carry_in, uint32_t base_c,
+                                        uint32_t count, bool mine, bool preloaded)
 {
-  constexpr int PAIR = 2;
-  uint32_t const es = q.es, ee = q.ee;
-  WT carry = 0;  // running sum of the run open at the current position (wave-uniform)
+  if (mine && q.f) {  // the run closed by a start at element k ran up to element k - 1
+    uint32_t pos = q.ex_c - base_c;
+    bool first   = true;
 #pragma unroll
-  for (int g0 = 0; g0 < TP_U; g0 += PAIR) {
-    if (es + g0 * TP_SUB >= ee) break;  // wave-uniform
-    WT r[PAIR][8];   // values, then in place: running sum since the last run start at or before element k
-    WT s[PAIR];      // wave-level inclusive segmented scan of the lane tails
-    WT ex_s[PAIR];   // ... of the previous lane (0 in lane 0)
-    // ---- B1
-#pragma unroll
-    for (int j = 0; j < PAIR; ++j) {
-      int const g = g0 + j;
-      uint32_t const w4[4] = {rg.id[g].x, rg.id[g].y, rg.id[g].z, rg.id[g].w};
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        uint32_t i = (k & 1) ? (w4[k >> 1] >> 16) : (w4[k >> 1] & 0xFFFFu);
-        r[j][k]    = xs[i];  // rounds past `ee` read zero-padded indices: valid addresses, values masked below
+    for (int k = 0; k < TP_EPL; ++k) {
+      if ((q.f >> k) & 1u) {
+        WT before  = k == 0 ? WT(0) : r[k - 1];
+        stage[pos] = first ? carry_in + before : before;
+        first      = false;
+        ++pos;
       }
-    }
-#pragma unroll
-    for (int j = 0; j < PAIR; ++j) {
-      int const g = g0 + j;
-      uint32_t const e = es + g * TP_SUB + 8 * lane;
-      if constexpr (WEIGHTED) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) r[j][k] *= a.weights[e + k];
-      }
-      if (e + 8 > ee) {
-        uint32_t const nval = ee > e ? ee - e : 0u;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) r[j][k] = (uint32_t)k < nval ? r[j][k] : WT(0);
-      }
-      uint32_t const fg = q.f[g];
-#pragma unroll
-      for (int k = 1; k < 8; ++k) r[j][k] = ((fg >> k) & 1u) ? r[j][k] : r[j][k - 1] + r[j][k];
-      s[j]       = r[j][7];
-      uint32_t c = q.nf[g];
-      wave_seg_scan(s[j], c);
-      ex_s[j] = dpp_val<0x138, 0xF>(s[j]);  // wave_shr:1
-    }
-    // ---- B2
-#pragma unroll
-    for (int j = 0; j < PAIR; ++j) {
-      int const g = g0 + j;
-      if (es + g * TP_SUB >= ee) break;  // wave-uniform
-      uint32_t const c_all = q.c_all[g];
-      WT const s_last      = read_lane63(s[j]);
-      if (c_all == 0) {  // no run starts in these 512 edges (inside a long run)
-        carry += s_last;
-        continue;
-      }
-      uint32_t const fg = q.f[g];
-      WT const carry_in = q.ex_c[g] ? ex_s[j] : ex_s[j] + carry;
-      if (fg) {  // the run closed by a start at element k ran up to element k - 1; totals go to LDS in run order
-        uint32_t pos = q.ex_c[g];
-        bool first   = true;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if ((fg >> k) & 1u) {
-            WT before  = k == 0 ? WT(0) : r[j][k - 1];
-            stage[pos] = first ? carry_in + before : before;
-            first      = false;
-            ++pos;
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // coalesced write-out: lane i takes the i-th run closed in this round
-      if ((uint32_t)lane < c_all) a.part[q.slot0[g]] = stage[lane];
-      if ((uint32_t)lane + 64 < c_all) a.part[q.slot1[g]] = stage[lane + 64];
-      for (uint32_t i = 128 + lane; i < c_all; i += 64) a.part[a.rpos[q.rank - 1 + q.closed_at[g] + i]] = stage[i];
-      __builtin_amdgcn_wave_barrier();  // the next round overwrites the staging area
-      carry = s_last;                   // c_all != 0: the open run started inside this round
     }
   }
-  if (lane == 0) {  // the run still open at the end of the range (it may continue in the next wavefront's range: that
-                    // wavefront contributes its part through its own head slot)
-    uint32_t const closed = q.closed_at[TP_U - 1] + q.c_all[TP_U - 1];
-    uint32_t sl = closed == 0 ? q.head_slot : a.rpos[q.rank - 1 + closed];
-    a.part[sl]  = carry;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  uint32_t i = (uint32_t)lane;
+  if (preloaded) {  // base_c == 0: runs `lane` and `64 + lane` have their slots in registers already
+    if (i < count) st32<WT>(a.part, q.slot0 * (uint32_t)sizeof(WT), stage[i]);
+    if (i + 64 < count) st32<WT>(a.part, q.slot1 * (uint32_t)sizeof(WT), stage[i + 64]);
+    i += 128;
+  }
+  for (; i < count; i += 64) {
+    uint32_t const n  = base_c + i;
+    uint32_t const sl = n == 0 ? q.head_slot : ld32<uint32_t>(a.rpos1, 4u * (q.rank + n));
+    st32<WT>(a.part, sl * (uint32_t)sizeof(WT), stage[i]);
+  }
+  __builtin_amdgcn_wave_barrier();  // the staging area is reused
+}
+
+// Part 2: values.  `stage`: this wavefront's TP_STAGE-entry LDS scratch.
+template <typename WT, bool WEIGHTED>
+__device__ __forceinline__ void p1_part2(p1_args<WT> const& a, WT const* xs, WT* stage, int lane, p1_regs const& rg, p1_runs const& q)
+{
+  uint32_t const e = q.es + (uint32_t)TP_EPL * (uint32_t)lane;
+  WT r[TP_EPL];  // values, then in place: running sum since the last run start at or before element k
+#pragma unroll
+  for (int k = 0; k < TP_EPL; ++k) {
+    uint32_t const w = k % 8 < 2 ? rg.id[k / 8].x : k % 8 < 4 ? rg.id[k / 8].y : k % 8 < 6 ? rg.id[k / 8].z : rg.id[k / 8].w;
+    uint32_t const i = (k & 1) ? (w >> 16) : (w & 0xFFFFu);
+    r[k]             = xs[i];  // positions past `ee` hold zero-padded (valid) indices; their values are masked below
+  }
+  if constexpr (WEIGHTED) {
+#pragma unroll
+    for (int k = 0; k < TP_EPL; ++k) r[k] *= ld32<WT>(a.weights, (e + (uint32_t)k) * (uint32_t)sizeof(WT));
+  }
+  if (e + TP_EPL > q.ee) {
+    uint32_t const nval = q.ee > e ? q.ee - e : 0u;
+#pragma unroll
+    for (int k = 0; k < TP_EPL; ++k) r[k] = (uint32_t)k < nval ? r[k] : WT(0);
+  }
+  if (q.c_all == 0) {  // no run starts in the wavefront's edges (inside a long run): plain sum into the head slot
+    WT t = r[0];
+#pragma unroll
+    for (int k = 1; k < TP_EPL; ++k) t += r[k];
+    t = wave_sum_to_lane63(t);
+    if (lane == 63) st32<WT>(a.part, q.head_slot * (uint32_t)sizeof(WT), t);
+    return;
+  }
+  // in-lane segmented sum: r[k] = v[k] + (run start at k ? 0 : r[k-1]); the select is a bit mask (0 / ~0 from the flag bit)
+  uint32_t const nflags = ~q.f;
+#pragma unroll
+  for (int k = 1; k < TP_EPL; ++k) {
+    if constexpr (sizeof(WT) == 4) {
+      uint32_t const m = (uint32_t)__builtin_amdgcn_sbfe((int)nflags, k, 1);  // ~0 when element k continues the run
+      r[k] += __uint_as_float(__float_as_uint(r[k - 1]) & m);
+    } else {
+      r[k] = ((q.f >> k) & 1u) ? r[k] : r[k - 1] + r[k];
+    }
+  }
+  WT s       = r[TP_EPL - 1];
+  uint32_t c = q.nf;
+  wave_seg_scan(s, c);
+  WT const carry_in = dpp_val<0x138, 0xF>(s);  // wave_shr:1: segmented sum up to the previous lane (0 in lane 0; the range starts with an empty carry)
+  if (q.c_all <= (uint32_t)TP_STAGE) {
+    p1_emit<WT>(a, stage, lane, q, r, carry_in, 0u, q.c_all, true, true);
+  } else {  // more run totals than the staging area holds: lanes 0-31 first (at most TP_STAGE runs), then lanes 32-63
+    uint32_t const half = (uint32_t)__builtin_amdgcn_readlane((int)c, 31);
+    p1_emit<WT>(a, stage, lane, q, r, carry_in, 0u, half, lane < 32, true);
+    p1_emit<WT>(a, stage, lane, q, r, carry_in, half, q.c_all - half, lane >= 32, false);
+  }
+  if (lane == 63) {  // the run still open at the end of the range (it may continue in the next wavefront's range: that
+                     // wavefront contributes its part through its own head slot)
+    uint32_t const sl = ld32<uint32_t>(a.rpos1, 4u * (q.rank + q.c_all));
+    st32<WT>(a.part, sl * (uint32_t)sizeof(WT), s);
   }
 }
 
 template <typename WT, bool WEIGHTED, bool MG, bool DBG = false>
-__global__ void __launch_bounds__(TP_BLOCK) k_tiled_phase1(p1_args<WT> a)
+__global__ void __launch_bounds__(TP_BLOCK, 4 * TP_WG_PER_CU) k_tiled_phase1(p1_args<WT> a)
 {
   long long tA = 0, tT = 0, tB = 0, tW = 0, tc0 = 0, tc1 = 0;  // DBG: cycles in pass A (incl. wait for data) / tile loads / pass B / chunk barrier
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -713,7 +720,7 @@ __global__ void __launch_bounds__(TP_BLOCK) k_tiled_phase1(p1_args<WT> a)
   __shared__ int s_chunk[3];
   int const tid = threadIdx.x, lane = tid & 63;
   int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  WT* stage = xs + a.T + wave * TP_SUB;
+  WT* stage = xs + a.T + wave * TP_STAGE;
 
   if (blockIdx.x == 0 && a.fin.partials) finish_scalars<WT>(a.fin, reinterpret_cast<double*>(smem), tid, TP_BLOCK);
 
@@ -726,7 +733,7 @@ __global__ void __launch_bounds__(TP_BLOCK) k_tiled_phase1(p1_args<WT> a)
   __syncthreads();
   int curJ = -1;
   p1_regs r0, r1;
-  {
+  if constexpr (TP_PREFETCH) {
     int const c0 = s_chunk[0];
     if (c0 < a.n_chunks) p1_load<WT>(a, a.chunk_begin[c0], wave, lane, r0);
   }
@@ -777,16 +784,21 @@ __global__ void __launch_bounds__(TP_BLOCK) k_tiled_phase1(p1_args<WT> a)
       }
       if constexpr (DBG) { tc1 = clock64(); tT += tc1 - tc0; tc0 = tc1; }
       p1_runs q;
-      p1_pass_a<WT>(a, lane, cur, q);
+      if constexpr (!TP_PREFETCH) p1_load<WT>(a, item, wave, lane, const_cast<p1_regs&>(cur));  // 8 wavefronts per SIMD hide the latency
+      p1_part1<WT>(a, lane, cur, q);
       if constexpr (DBG) { __builtin_amdgcn_s_waitcnt(0); tc1 = clock64(); tA += tc1 - tc0; tc0 = tc1; }
-      if (pre >= 0) p1_load<WT>(a, pre, wave, lane, nxt);
-      if (q.es < q.ee) p1_pass_b<WT, WEIGHTED>(a, xs, stage, lane, cur, q);
+      if constexpr (TP_PREFETCH) { if (pre >= 0) p1_load<WT>(a, pre, wave, lane, nxt); }
+      if (q.es < q.ee) p1_part2<WT, WEIGHTED>(a, xs, stage, lane, cur, q);
       if constexpr (DBG) { tc1 = clock64(); tB += tc1 - tc0; tc0 = tc1; }
       ++item;
     };
     while (item < item_end) {
-      if (cur_is_r0) body(r0, r1); else body(r1, r0);
-      cur_is_r0 = !cur_is_r0;
+      if constexpr (TP_PREFETCH) {
+        if (cur_is_r0) body(r0, r1); else body(r1, r0);
+        cur_is_r0 = !cur_is_r0;
+      } else {
+        body(r0, r0);
+      }
     }
     if constexpr (DBG) tc0 = clock64();
     __syncthreads();  // chunk done: the tile may be replaced, s_chunk[(it + 2) % 3] is visible
@@ -944,7 +956,7 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
   a.src16     = t.src16.data();
   a.bits      = reinterpret_cast<uint8_t const*>(t.bits.data());
   a.weights   = t.weights.ptr ? t.weights.as<WT const>() : nullptr;
-  a.rpos      = t.rpos.data();
+  a.rpos1     = t.rpos.data();
   a.item_tile = t.item_tile.data();
   a.waves     = t.waves.data();
   a.chunk_begin = t.chunk_begin.data();
@@ -956,7 +968,7 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
   a.alpha     = alpha;
   a.pmask = map.pmask; a.plog = map.plog; a.chunk = map.chunk; a.ncols = map.ncols;
   if (pending) a.fin = make_fin<WT>(*pending, t.nI);
-  size_t const lds = std::max<size_t>(((size_t)t.T + (size_t)TP_WAVES * TP_SUB) * sizeof(WT), 3 * TP_BLOCK * sizeof(double));
+  size_t const lds = std::max<size_t>(((size_t)t.T + (size_t)TP_WAVES * TP_STAGE) * sizeof(WT), 3 * TP_BLOCK * sizeof(double));
   bool const w     = a.weights != nullptr;
   static bool attr_done[4] = {false, false, false, false};
   static int dbg_calls = getenv("CUGRAPH_AMD_TILED_DEBUG") ? 2 : 0;

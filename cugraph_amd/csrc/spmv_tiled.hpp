@@ -41,11 +41,24 @@ struct pr_scalars {  // device-resident PageRank loop state
 
 constexpr int TP_BLOCK = 1024;               // phase-1 workgroup: 16 wavefronts sharing one LDS tile
 constexpr int TP_WAVES = TP_BLOCK / 64;
-constexpr int TP_SUB   = 512;                // edges per wavefront per load round (8 per lane, one 16-byte load)
-constexpr int TP_U     = 2;                  // load rounds per work item (register budget: 2 items x TP_U rounds are resident)
-constexpr int TP_WLEN  = TP_SUB * TP_U;      // edges per wavefront per work item
+// Two shapes of phase 1 (compile-time; CGA_TILED_OCC2 selects the second):
+//   big tile : one workgroup per CU (tile ~126 KiB), 16 consecutive edges per lane, next item's edge data prefetched in registers
+//   occupancy: two workgroups per CU (tile ~62 KiB, 8 wavefronts per SIMD, <= 64 VGPRs), 8 edges per lane, no register prefetch
+#ifdef CGA_TILED_OCC2
+constexpr int TP_EPL = 8;
+constexpr bool TP_PREFETCH = false;
+constexpr int TP_WG_PER_CU = 2;
+constexpr int TP_STAGE = 256;                // per-wavefront LDS staging entries (run totals awaiting the coalesced write-out)
+#else
+constexpr int TP_EPL = 16;
+constexpr bool TP_PREFETCH = true;
+constexpr int TP_WG_PER_CU = 1;
+constexpr int TP_STAGE = 512;
+#endif
+constexpr int TP_SUB   = 64 * TP_EPL;        // edges per wavefront per work item (TP_EPL consecutive edges per lane)
+constexpr int TP_WLEN  = TP_SUB;
 constexpr int TP_ITEM  = TP_WLEN * TP_WAVES;  // edges per work item
-constexpr int TP_CHUNK = 8;                  // work items per dynamically scheduled chunk
+constexpr int TP_CHUNK = 128 / TP_EPL;       // work items per dynamically scheduled chunk (128 Ki edges)
 constexpr int TP2_BLOCK = 512;               // phase-2 workgroup
 constexpr int TP2_ROWS  = 4096;              // max destination rows per phase-2 tile (64-bit LDS accumulators: 32 KiB)
 
@@ -68,7 +81,7 @@ struct tiled_csc_t {
   dvec<uint16_t> src16;       // [ne_pad + pad] tile-local source id
   dvec<uint32_t> bits;        // [ne_pad / 32 + pad] bit p = edge position p starts a run
   dev_buf weights;            // [ne_pad + pad] or empty
-  dvec<uint32_t> rpos;        // [n_runs] slot of run q
+  dvec<uint32_t> rpos;        // [n_runs + 512] slot of run q at [q + 1] ([0] and the tail are padding)
   dvec<int32_t> item_tile;    // [n_items] source tile of work item
   dvec<tiled_wave_t> waves;   // [n_items * TP_WAVES]
   dvec<int32_t> chunk_begin;  // [n_chunks + 1] first item of each chunk (<= TP_CHUNK items of one source tile)
