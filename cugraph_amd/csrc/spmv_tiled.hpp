@@ -58,7 +58,7 @@ constexpr int TP_STAGE = 512;
 constexpr int TP_SUB   = 64 * TP_EPL;        // edges per wavefront per work item (TP_EPL consecutive edges per lane)
 constexpr int TP_WLEN  = TP_SUB;
 constexpr int TP_ITEM  = TP_WLEN * TP_WAVES;  // edges per work item
-constexpr int TP_CHUNK = 128 / TP_EPL;       // work items per dynamically scheduled chunk (128 Ki edges)
+constexpr int TP_CHUNK = 128 / TP_EPL;       // work items per dynamically scheduled chunk (128 Ki edges: larger chunks reload fewer tiles but balance worse)
 constexpr int TP2_BLOCK = 512;               // phase-2 workgroup
 constexpr int TP2_ROWS  = 4096;              // max destination rows per phase-2 tile (64-bit LDS accumulators: 32 KiB)
 

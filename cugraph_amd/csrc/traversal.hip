@@ -36,6 +36,7 @@ namespace {
 constexpr int TV_BLOCK = 256;
 constexpr int TV_WAVES = TV_BLOCK / 64;
 constexpr int32_t BIG_DEG = 2048;
+constexpr int32_t BIG_SEG = 4096;  // edges per deferred (row, segment) work unit
 
 struct counters_t {  // device-resident, zeroed per step
   uint32_t n_next;   // size of the next (near) frontier
@@ -94,9 +95,13 @@ __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int
       u = q ? q[i] : (int32_t)i;
       if (keep(u)) { beg = offsets[u]; deg = offsets[u + 1] - beg; } else { u = -1; }
     }
-    // deferred: huge rows
+    // deferred: huge rows, cut into BIG_SEG-edge segments (one workgroup of k_*_big each)
     bool big = deg >= BIG_DEG;
-    wave_push(big, u, bigq, &cnt->n_big, lane);
+    if (big) {
+      uint32_t nseg = ((uint32_t)deg + BIG_SEG - 1) / BIG_SEG;
+      uint32_t at   = atomicAdd(&cnt->n_big, nseg);
+      for (uint32_t sgm = 0; sgm < nseg; ++sgm) { bigq[2 * (at + sgm)] = u; bigq[2 * (at + sgm) + 1] = (int32_t)sgm; }
+    }
     // whole-wave rows
     uint64_t mid = __ballot(deg >= 64 && !big);
     while (mid) {
@@ -133,16 +138,17 @@ __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int
 
 template <typename F>
 __device__ __forceinline__ void expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, counters_t* cnt, F& f)
-{
-  uint32_t nbig = cnt->n_big;
-  int64_t const tid  = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t const nthr = (int64_t)gridDim.x * blockDim.x;
-  for (uint32_t k = 0; k < nbig; ++k) {
-    int32_t u = bigq[k];
-    int32_t b = offsets[u], e = offsets[u + 1];
-    for (int64_t p = b + tid; p < e; p += nthr) f(u, indices[p], (int32_t)p);
-    if (tid == 0) atomicAdd(&cnt->edges, (unsigned long long)(e - b));
+{  // one workgroup per (row, segment) pair: rows of 10^3..10^6 edges all get parallelism proportional to their length
+  uint32_t const nseg = cnt->n_big;
+  unsigned long long inspected = 0;
+  for (uint32_t k = blockIdx.x; k < nseg; k += gridDim.x) {
+    int32_t const u = bigq[2 * k], sgm = bigq[2 * k + 1];
+    int32_t const b = offsets[u] + sgm * BIG_SEG;
+    int32_t const e = min(offsets[u + 1], b + BIG_SEG);
+    for (int32_t p = b + (int32_t)threadIdx.x; p < e; p += (int32_t)blockDim.x) f(u, indices[p], p);
+    if (threadIdx.x == 0) inspected += (unsigned long long)(e - b);
   }
+  if (threadIdx.x == 0 && inspected) atomicAdd(&cnt->edges, inspected);
 }
 
 // --------------------------------------------------------------------------------------------- BFS
@@ -389,7 +395,10 @@ struct sssp_relax {
     WT du    = B::from(s.dist[u]);
     WT nd    = du + s.weights[p];
     bool near = false, far = false;
-    if (nd < s.cutoff && nd < B::from(s.dist[v])) {
+    // agent-scope load: bypasses the per-CU vector cache, so once a hub has been lowered the other relaxations of this
+    // round see it and skip the atomic (a plain load keeps reading the stale value from L1 and every edge into the hub
+    // issues an atomicMin)
+    if (nd < s.cutoff && nd < B::from(__hip_atomic_load(&s.dist[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
       auto old = atomicMin(&s.dist[v], B::to(nd));
       if (B::to(nd) < old) {  // this relaxation lowered d[v]
         if (nd < s.threshold) near = atomicExch(&s.mark_near[v], s.round) != s.round;
@@ -542,6 +551,9 @@ __global__ void k_count_reached_dist(B const* dist, int64_t nv, B unreached, uns
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
 }
 
+// (row, segment) pairs: at most E / BIG_DEG deferred rows, each with ceil(deg / BIG_SEG) <= deg / BIG_SEG + 1 segments
+size_t big_queue_entries(int64_t ne) { return (size_t)(2 * (ne / BIG_DEG + ne / BIG_SEG + 64)); }
+
 int expand_grid(handle_t const& h, int64_t n)
 {
   int64_t waves = (n + 63) / 64;
@@ -592,7 +604,7 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   auto preds = std::make_unique<device_array_t>(compute_predecessors ? (size_t)nv : 0, g.vertex_type);
   int64_t const nwords = ((nv + 63) / 64) * 2 + 2;  // whole 64-vertex groups
   dvec<uint32_t> vis_prev(nwords), vis_new(nwords), front(in ? nwords : 1), next(in ? nwords : 1);
-  dvec<int32_t> qa(n1), qb(n1), bigq(n1);
+  dvec<int32_t> qa(n1), qb(n1), bigq(big_queue_entries(g.ne));
   dvec<counters_t> cnt(1);
   fill_i32(h, dist->buf.as<int32_t>(), nv, INT32_MAX);
   if (compute_predecessors) fill_i32(h, preds->buf.as<int32_t>(), nv, INT32_MAX);
@@ -659,7 +671,7 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
         timed_launch t(h, "bfs_expand");
         hipLaunchKernelGGL(k_bfs_expand, expand_grid(h, n_cur), TV_BLOCK, 0, h.stream, (int32_t const*)q_cur, n_cur, (int32_t const*)o.offsets.data(),
                            (int32_t const*)o.indices.data(), bigq.data(), s);
-        hipLaunchKernelGGL(k_bfs_expand_big, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
+        hipLaunchKernelGGL(k_bfs_expand_big, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
                            (int32_t const*)o.indices.data(), s);
       }
       if (!in) HIP_TRY(hipMemcpyAsync(vis_prev.data(), vis_new.data(), nwords * 4, hipMemcpyDeviceToDevice, h.stream));
@@ -735,7 +747,7 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   auto preds = std::make_unique<device_array_t>(compute_predecessors ? (size_t)nv : 0, g.vertex_type);
   bits_t* d  = dist->buf.as<bits_t>();
   WT const* w = o.weights.as<WT const>();
-  dvec<int32_t> qa(n1), qb(n1), fa(n1), fb(n1), bigq(n1);
+  dvec<int32_t> qa(n1), qb(n1), fa(n1), fb(n1), bigq(big_queue_entries(g.ne));
   dvec<uint32_t> mark_near(n1), mark_far(n1);
   dvec<counters_t> cnt(1);
   dvec<double> wsum(1);
@@ -789,7 +801,7 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
         timed_launch t(h, "sssp_relax");
         hipLaunchKernelGGL(k_sssp_expand<WT>, expand_grid(h, n_cur), TV_BLOCK, 0, h.stream, (int32_t const*)q_cur, n_cur,
                            (int32_t const*)o.offsets.data(), (int32_t const*)o.indices.data(), bigq.data(), s);
-        hipLaunchKernelGGL(k_sssp_expand_big<WT>, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
+        hipLaunchKernelGGL(k_sssp_expand_big<WT>, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
                            (int32_t const*)o.indices.data(), s);
       }
       h.read_back(&c, cnt.data(), 1);
@@ -836,7 +848,7 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
     if (nv > 0) {
       hipLaunchKernelGGL(k_sssp_parents<WT>, expand_grid(h, nv), TV_BLOCK, 0, h.stream, nv, (int32_t const*)o.offsets.data(),
                          (int32_t const*)o.indices.data(), bigq.data(), cnt.data(), f, keep);
-      hipLaunchKernelGGL(k_sssp_parents_big<WT>, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
+      hipLaunchKernelGGL(k_sssp_parents_big<WT>, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
                          (int32_t const*)o.indices.data(), cnt.data(), f);
     }
     if (nv > 0) hipLaunchKernelGGL(k_fix_pred, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, preds->buf.as<int32_t>(), nv);
