@@ -913,15 +913,60 @@ struct pagerank_plan : pagerank_plan_base {
 
 
 // =================================================================================================
-// Multi-GPU PageRank, one process per GPU.  1-D partition by destination: this rank owns
-// n_rows destination vertices and ALL their in-edges (local CSC whose column ids are global), so the pull-SpMV
-// needs no partial-result reduction; the only data-path exchange is one all-gather of x = pr / out_w per
-// iteration, issued by the host layer (torch.distributed -> RCCL over xGMI) on the two device buffers this plan
-// exposes.  The two scalars of the iteration (L1 change, dangling mass) travel in the last 4 slots of every
-// rank's chunk, so there is no separate all-reduce: every rank sums the P partials in rank order (deterministic).
-// The reference instead uses a 2-D partition with a row broadcast + column reduce + 2 scalar all-reduces per
-// iteration (update_edge_src_dst_property.cuh:550-579, per_v_transform_reduce_e.cuh:3390-3406).
+// Multi-GPU PageRank, one process per GPU, re-designed for a full-mesh xGMI node.
+// 1-D partition by destination: this rank owns n_rows destination vertices and ALL their in-edges, so the pull-SpMV needs
+// no partial-result reduction.  The only data-path exchange is a SPARSE all-to-all of x = pr / out_w: every rank receives
+// exactly the source values its local edges reference (vertices without out-edges -- more than half of an RMAT graph --
+// are never sent; a low-degree source travels only to the few ranks that hold one of its out-edges), as one
+// point-to-point message per peer, so all seven xGMI links of a GPU carry traffic at once (a ring all-gather of the whole
+// vector would be bound by ONE link and move (P-1)/P * 4V bytes into every GPU).  The host layer (cugraph_amd/mg.py)
+// issues that collective (torch.distributed all_to_all_single = RCCL) on the two device buffers this plan exposes.
+// The three scalars of an iteration (L1 change, dangling mass, max |x|) ride in a 32-byte tail behind every message, so
+// there is no separate all-reduce: every rank folds the P triples in rank order (deterministic).
+// Local column ids are COMPACT (0 .. ncols-1 = the distinct sources this rank references, hottest first), so the
+// column-tiled kernels run unchanged on x_compact[c] = recv[col_pos[c]].
+// The reference instead uses a 2-D partition with a row broadcast + column reduce + 2 scalar all-reduces per iteration
+// (update_edge_src_dst_property.cuh:550-579, per_v_transform_reduce_e.cuh:3390-3406).
 // =================================================================================================
+template <typename WT>
+__global__ void k_mg_unpack(WT const* recv, int32_t const* col_pos, int64_t ncols, WT* x)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < ncols; i += stride) x[i] = recv[col_pos[i]];
+}
+
+// send[seg_off[s] + j] = x_own[send_index[first[s] + j]]; the tail of every segment <- totals (3 doubles)
+template <typename WT>
+__global__ void k_mg_pack(WT const* x_own, int32_t const* send_index, int64_t n_send, int64_t const* first /*[P+1] value index*/,
+                          int64_t const* seg_off /*[P] element offset of segment s in send*/, int comm_size, double const* totals, WT* send)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = i; k < n_send; k += stride) {
+    int s = 0;
+    while (s + 1 < comm_size && k >= first[s + 1]) ++s;
+    send[seg_off[s] + (k - first[s])] = x_own[send_index[k]];
+  }
+  if (i < comm_size) {
+    double* tail = reinterpret_cast<double*>(send + seg_off[i] + (first[i + 1] - first[i]));
+    tail[0] = totals[0]; tail[1] = totals[1]; tail[2] = totals[2]; tail[3] = 0.0;
+  }
+}
+
+template <typename WT>
+__global__ void k_mg_fold_tails(WT const* recv, int64_t const* tail_off /*[P] element offset of the tail of segment s*/, int comm_size,
+                                pr_scalars<WT>* scal, WT alpha, int64_t nv_global, double wmax)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double diff = 0, dang = 0, xmax = 0;
+  for (int r = 0; r < comm_size; ++r) {
+    double const* t = reinterpret_cast<double const*>(recv + tail_off[r]);
+    diff += t[0]; dang += t[1]; xmax = fmax(xmax, t[2]);
+  }
+  tiled_write_scalars<WT>(scal, diff, dang, xmax, alpha, nv_global, 0, wmax);
+}
+
 struct pagerank_mg_plan_base {
   virtual ~pagerank_mg_plan_base() = default;
   virtual void start()                                           = 0;
@@ -932,52 +977,70 @@ struct pagerank_mg_plan_base {
 
 template <typename WT>
 struct pagerank_mg_plan : pagerank_mg_plan_base {
-  static constexpr size_t kTailBytes = 32;  // (L1 change, dangling mass, max |x|) as 3 doubles + pad, at the end of every rank's chunk
+  static constexpr size_t kTailBytes = 32;
+  static constexpr int64_t kTail     = (int64_t)(kTailBytes / sizeof(WT));  // tail length in elements
   handle_t const& h;
   graph_t& g;
   WT alpha;
-  int64_t n_rows, nv_global;
+  int64_t n_rows, nv_global, ncols{0}, n_send{0}, n_recv{0};
   int rank, size;
-  uint32_t chunk, plog;
-  dvec<WT> pr, outw, part;
+  dvec<WT> pr, outw, part, x_own, x_compact;
+  dvec<int32_t> send_index, col_pos;
+  dvec<int64_t> d_first, d_send_off, d_recv_tail;
   WT* send{nullptr};  // caller-owned exchange buffers (torch tensors on the host side)
   WT* recv{nullptr};
   dvec<pr_scalars<WT>> scal;
-  dvec<double> tpartials;
+  dvec<double> tpartials, totals;
   dvec<uint32_t> counters;
   std::shared_ptr<tiled_csc_t> tc;
 
-  pagerank_mg_plan(handle_t const& h_, graph_t& g_, double alpha_, int64_t n_rows_, int64_t nv_global_, int rank_, int size_, size_t chunk_)
-    : h(h_), g(g_), alpha((WT)alpha_), n_rows(n_rows_), nv_global(nv_global_), rank(rank_), size(size_), chunk((uint32_t)chunk_), plog(0)
+  pagerank_mg_plan(handle_t const& h_, graph_t& g_, double alpha_, int64_t n_rows_, int64_t nv_global_, int rank_, int size_)
+    : h(h_), g(g_), alpha((WT)alpha_), n_rows(n_rows_), nv_global(nv_global_), rank(rank_), size(size_)
   {
   }
 
-  void create(device_array_view_t const* outw_local, device_array_view_t const* init_local, device_array_view_t const* send_v,
+  void create(device_array_view_t const* outw_local, device_array_view_t const* init_local, device_array_view_t const* send_index_v,
+              size_t const* send_counts, size_t const* recv_counts, device_array_view_t const* col_pos_v, device_array_view_t const* send_v,
               device_array_view_t const* recv_v)
   {
     HIP_TRY(hipSetDevice(h.device));
-    CGA_EXPECTS(send_v && recv_v && send_v->type == g.weight_type && recv_v->type == g.weight_type && send_v->size == chunk &&
-                  recv_v->size == (size_t)chunk * size,
-                CUGRAPH_INVALID_INPUT, "multi-GPU PageRank: send must hold chunk and recv comm_size * chunk weight-typed elements");
+    CGA_EXPECTS(size >= 1 && send_counts && recv_counts, CUGRAPH_INVALID_INPUT, "multi-GPU PageRank: comm_size / counts");
+    std::vector<int64_t> first(size + 1, 0), send_off(size, 0), recv_tail(size, 0);
+    int64_t so = 0, ro = 0;
+    for (int s = 0; s < size; ++s) {
+      first[s + 1] = first[s] + (int64_t)send_counts[s];
+      send_off[s]  = so;
+      so += (int64_t)send_counts[s] + kTail;
+      ro += (int64_t)recv_counts[s];
+      recv_tail[s] = ro;
+      ro += kTail;
+      CGA_EXPECTS(((int64_t)send_counts[s] * (int64_t)sizeof(WT)) % 8 == 0 && ((int64_t)recv_counts[s] * (int64_t)sizeof(WT)) % 8 == 0, CUGRAPH_INVALID_INPUT,
+                  "multi-GPU PageRank: per-peer counts must keep the 8-byte alignment of the tails (even counts for fp32)");
+    }
+    n_send = first[size];
+    n_recv = ro - (int64_t)size * kTail;
+    CGA_EXPECTS(send_v && recv_v && send_v->type == g.weight_type && recv_v->type == g.weight_type && (int64_t)send_v->size == so &&
+                  (int64_t)recv_v->size == ro,
+                CUGRAPH_INVALID_INPUT, "multi-GPU PageRank: send / recv must hold the per-peer values plus a 32-byte tail per peer");
+    CGA_EXPECTS(send_index_v && send_index_v->type == INT32 && (int64_t)send_index_v->size == n_send, CUGRAPH_INVALID_INPUT,
+                "multi-GPU PageRank: send_index must be INT32 with sum(send_counts) entries");
+    CGA_EXPECTS(col_pos_v && col_pos_v->type == INT32, CUGRAPH_INVALID_INPUT, "multi-GPU PageRank: col_pos must be INT32");
+    ncols = (int64_t)col_pos_v->size;
+    CGA_EXPECTS(ncols <= g.nv && n_rows <= g.nv, CUGRAPH_INVALID_INPUT, "multi-GPU PageRank: the local graph must have max(columns, local rows) vertices");
     send = send_v->as<WT>();
     recv = recv_v->as<WT>();
-    CGA_EXPECTS(size >= 1 && (size & (size - 1)) == 0, CUGRAPH_NOT_IMPLEMENTED, "multi-GPU PageRank: the number of ranks must be a power of two");
-    while ((1 << plog) < size) ++plog;
-    CGA_EXPECTS((size_t)chunk * sizeof(WT) % 16 == 0 && (int64_t)chunk >= n_rows + (int64_t)(kTailBytes / sizeof(WT)), CUGRAPH_INVALID_INPUT,
-                "multi-GPU PageRank: chunk must hold the local rows plus 32 bytes of scalars and be 16-byte aligned");
-    CGA_EXPECTS((int64_t)chunk * size <= g.nv && (uint64_t)chunk * (uint64_t)size < ((uint64_t)1 << 30), CUGRAPH_INVALID_INPUT,
-                "multi-GPU PageRank: local graph must have at least comm_size * chunk column ids");
     CGA_EXPECTS(outw_local != nullptr && (int64_t)outw_local->size == n_rows && outw_local->type == g.weight_type, CUGRAPH_INVALID_INPUT,
                 "multi-GPU PageRank: out_weight_sums must have one weight-typed value per local row");
     ensure_orientation(h, g, true);
     orientation_t& o = g.csc;
     CGA_EXPECTS(o.seg[4] <= n_rows, CUGRAPH_INVALID_INPUT, "multi-GPU PageRank: edges point to rows outside the local range");
     size_t const n1 = (size_t)(n_rows > 0 ? n_rows : 1);
-    pr.resize_discard(n1); outw.resize_discard(n1);
-    scal.resize_discard(1);
+    pr.resize_discard(n1); outw.resize_discard(n1); x_own.resize_discard(n1);
+    scal.resize_discard(1); totals.resize_discard(4);
     HIP_TRY(hipMemsetAsync(scal.data(), 0, sizeof(pr_scalars<WT>), h.stream));
-    HIP_TRY(hipMemsetAsync(send, 0, (size_t)chunk * sizeof(WT), h.stream));
-    HIP_TRY(hipMemsetAsync(recv, 0, (size_t)chunk * size * sizeof(WT), h.stream));
+    HIP_TRY(hipMemsetAsync(totals.data(), 0, 4 * sizeof(double), h.stream));
+    HIP_TRY(hipMemsetAsync(send, 0, (size_t)so * sizeof(WT), h.stream));
+    HIP_TRY(hipMemsetAsync(recv, 0, (size_t)ro * sizeof(WT), h.stream));
     if (n_rows > 0) HIP_TRY(hipMemcpyAsync(outw.data(), outw_local->data, n_rows * sizeof(WT), hipMemcpyDeviceToDevice, h.stream));
     if (init_local) {
       CGA_EXPECTS((int64_t)init_local->size == n_rows && init_local->type == g.weight_type, CUGRAPH_INVALID_INPUT, "initial guess: one value per local row");
@@ -985,9 +1048,18 @@ struct pagerank_mg_plan : pagerank_mg_plan_base {
     } else {
       fill_wt<WT>(h, pr.data(), n_rows, WT(1) / (WT)nv_global);
     }
-    // column ids are global degree-order positions (hot sources first): the column-tiled re-blocking applies unchanged,
-    // only the tile load follows the rank-blocked layout of the all-gathered vector
-    int const T = tiled_default_T(h, sizeof(WT), (int64_t)chunk * size);
+    send_index.resize_discard(n_send > 0 ? n_send : 1);
+    col_pos.resize_discard(ncols > 0 ? ncols : 1);
+    if (n_send > 0) HIP_TRY(hipMemcpyAsync(send_index.data(), send_index_v->data, n_send * 4, hipMemcpyDeviceToDevice, h.stream));
+    if (ncols > 0) HIP_TRY(hipMemcpyAsync(col_pos.data(), col_pos_v->data, ncols * 4, hipMemcpyDeviceToDevice, h.stream));
+    auto upload = [&](dvec<int64_t>& d, std::vector<int64_t> const& v) {
+      d.resize_discard(v.size());
+      HIP_TRY(hipMemcpyAsync(d.data(), v.data(), v.size() * sizeof(int64_t), hipMemcpyHostToDevice, h.stream));
+      h.sync();
+    };
+    upload(d_first, first); upload(d_send_off, send_off); upload(d_recv_tail, recv_tail);
+    // compact column ids (hottest sources first): the column-tiled re-blocking applies unchanged
+    int const T = tiled_default_T(h, sizeof(WT), std::max<int64_t>(ncols, 1));
     if (!o.tiled || o.tiled->T != T || o.tiled->nv != n_rows) {
       auto t = std::make_shared<tiled_csc_t>();
       build_tiled_csc(h, g.nv, n_rows, g.ne, o, g.has_weights, sizeof(WT), T, *t);
@@ -996,35 +1068,43 @@ struct pagerank_mg_plan : pagerank_mg_plan_base {
     tc = o.tiled;
     part.resize_discard((size_t)tc->n_slots + 64);
     HIP_TRY(hipMemsetAsync(part.data(), 0, ((size_t)tc->n_slots + 64) * sizeof(WT), h.stream));
+    size_t const nx = (size_t)tc->nJ * tc->T + 8;
+    x_compact.resize_discard(nx);
+    HIP_TRY(hipMemsetAsync(x_compact.data(), 0, nx * sizeof(WT), h.stream));
     counters.resize_discard(4);
     HIP_TRY(hipMemsetAsync(counters.data(), 0, 4 * sizeof(uint32_t), h.stream));
     tpartials.resize_discard((size_t)3 * std::max(tc->nI, 1024));
     h.sync();
   }
 
-  double* send_tail() { return reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(send) + (size_t)chunk * sizeof(WT) - kTailBytes); }
-
   tiled_epilogue<WT> epi()
   {
     tiled_epilogue<WT> e;
-    e.nv = n_rows; e.pr = pr.data(); e.x_next = send; e.outw = outw.data(); e.pers = nullptr; e.scal = scal.data();
-    e.partials = tpartials.data(); e.totals = send_tail(); e.alpha = alpha; e.nv_global = nv_global; e.wmax = tc->wmax;
+    e.nv = n_rows; e.pr = pr.data(); e.x_next = x_own.data(); e.outw = outw.data(); e.pers = nullptr; e.scal = scal.data();
+    e.partials = tpartials.data(); e.totals = totals.data(); e.alpha = alpha; e.nv_global = nv_global; e.wmax = tc->wmax;
     return e;
   }
 
+  void pack()
+  {
+    int const grid = std::max(1, std::min(grid_for(std::max<int64_t>(n_send, size), kBlock, 2048), 2048));
+    hipLaunchKernelGGL(k_mg_pack<WT>, grid, kBlock, 0, h.stream, (WT const*)x_own.data(), (int32_t const*)send_index.data(), n_send,
+                       (int64_t const*)d_first.data(), (int64_t const*)d_send_off.data(), size, (double const*)totals.data(), send);
+  }
+
   void start() override
-  {  // send <- x of the initial vector, tail <- (0, partial dangling mass, max |x|)
+  {  // x_own <- x of the initial vector, totals <- (0, partial dangling mass, max |x|); messages packed
     HIP_TRY(hipSetDevice(h.device));
-    int n = tiled_prologue<WT>(h, *tc, (WT const*)pr.data(), (WT const*)outw.data(), send, n_rows, tpartials.data());
+    int n = tiled_prologue<WT>(h, *tc, (WT const*)pr.data(), (WT const*)outw.data(), x_own.data(), n_rows, tpartials.data());
     tiled_finish<WT>(h, epi(), n);
+    pack();
     h.sync();
   }
 
   void reduce_scalars(bool read_back, double* diff, double* dangling) override
   {
-    tiled_epilogue<WT> e = epi();
-    e.totals = nullptr;
-    tiled_scalars_from_ranks<WT>(h, e, recv, (size_t)chunk * sizeof(WT) - kTailBytes, (size_t)chunk * sizeof(WT), size);
+    hipLaunchKernelGGL(k_mg_fold_tails<WT>, 1, 64, 0, h.stream, (WT const*)recv, (int64_t const*)d_recv_tail.data(), size, scal.data(), alpha, nv_global,
+                       tc->wmax);
     if (read_back) {
       pr_scalars<WT> sc;
       h.read_back(&sc, scal.data(), 1);
@@ -1036,13 +1116,15 @@ struct pagerank_mg_plan : pagerank_mg_plan_base {
   void local_step() override
   {
     HIP_TRY(hipSetDevice(h.device));
-    tiled_x_map<WT> map;
-    map.mg = true; map.pmask = (uint32_t)size - 1; map.plog = plog; map.chunk = chunk; map.ncols = chunk * (uint32_t)size;
+    if (ncols > 0)
+      hipLaunchKernelGGL(k_mg_unpack<WT>, grid_for(ncols, kBlock, 4096), kBlock, 0, h.stream, (WT const*)recv, (int32_t const*)col_pos.data(), ncols,
+                         x_compact.data());
     tiled_epilogue<WT> e = epi();
-    tiled_phase1<WT>(h, *tc, (WT const*)recv, alpha, part.data(), counters.data(), map, nullptr);
+    tiled_phase1<WT>(h, *tc, (WT const*)x_compact.data(), alpha, part.data(), counters.data(), tiled_x_map<WT>{}, nullptr);
     tiled_phase2<WT>(h, *tc, (WT const*)part.data(), e, counters.data());
-    tiled_finish<WT>(h, e, tc->nI);  // this rank's (diff, dangling, xmax) -> tail of the send chunk
-    h.sync();  // the host layer issues the next all-gather on its own stream
+    tiled_finish<WT>(h, e, tc->nI);  // this rank's (diff, dangling, xmax)
+    pack();
+    h.sync();  // the host layer issues the next all-to-all on its own stream
   }
 
   void values(device_array_view_t const* out) override
@@ -1214,10 +1296,12 @@ extern "C" void cugraph_amd_pagerank_plan_free(cugraph_amd_pagerank_plan_t* plan
 // ---- multi-GPU plan API (include/cugraph_amd/extensions.h) ---------------------------------------
 extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg_plan_create(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
                                                                     size_t n_local_rows, size_t global_num_vertices, int comm_rank, int comm_size,
-                                                                    size_t chunk, const cugraph_type_erased_device_array_view_t* out_weight_sums_local,
+                                                                    const cugraph_type_erased_device_array_view_t* out_weight_sums_local,
                                                                     const cugraph_type_erased_device_array_view_t* initial_local,
-                                                                    cugraph_type_erased_device_array_view_t* send, cugraph_type_erased_device_array_view_t* recv, double alpha,
-                                                                    cugraph_amd_pagerank_mg_plan_t** plan, cugraph_error_t** error)
+                                                                    const cugraph_type_erased_device_array_view_t* send_index, const size_t* send_counts,
+                                                                    const size_t* recv_counts, const cugraph_type_erased_device_array_view_t* col_pos,
+                                                                    cugraph_type_erased_device_array_view_t* send, cugraph_type_erased_device_array_view_t* recv,
+                                                                    double alpha, cugraph_amd_pagerank_mg_plan_t** plan, cugraph_error_t** error)
 {
   if (plan) *plan = nullptr;
   return guarded(error, [&] {
@@ -1225,12 +1309,12 @@ extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg_plan_create(const cugrap
     handle_t const& h = H(handle);
     graph_t& g        = G(graph);
     if (g.weight_type == FLOAT64) {
-      auto p = std::make_unique<pagerank_mg_plan<double>>(h, g, alpha, (int64_t)n_local_rows, (int64_t)global_num_vertices, comm_rank, comm_size, chunk);
-      p->create(V(out_weight_sums_local), V(initial_local), V(send), V(recv));
+      auto p = std::make_unique<pagerank_mg_plan<double>>(h, g, alpha, (int64_t)n_local_rows, (int64_t)global_num_vertices, comm_rank, comm_size);
+      p->create(V(out_weight_sums_local), V(initial_local), V(send_index), send_counts, recv_counts, V(col_pos), V(send), V(recv));
       *plan = reinterpret_cast<cugraph_amd_pagerank_mg_plan_t*>(static_cast<pagerank_mg_plan_base*>(p.release()));
     } else {
-      auto p = std::make_unique<pagerank_mg_plan<float>>(h, g, alpha, (int64_t)n_local_rows, (int64_t)global_num_vertices, comm_rank, comm_size, chunk);
-      p->create(V(out_weight_sums_local), V(initial_local), V(send), V(recv));
+      auto p = std::make_unique<pagerank_mg_plan<float>>(h, g, alpha, (int64_t)n_local_rows, (int64_t)global_num_vertices, comm_rank, comm_size);
+      p->create(V(out_weight_sums_local), V(initial_local), V(send_index), send_counts, recv_counts, V(col_pos), V(send), V(recv));
       *plan = reinterpret_cast<cugraph_amd_pagerank_mg_plan_t*>(static_cast<pagerank_mg_plan_base*>(p.release()));
     }
   });

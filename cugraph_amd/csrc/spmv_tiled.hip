@@ -439,33 +439,6 @@ struct fin_args {
   double wmax{0};
 };
 
-// 2^k with  alpha * xmax * wmax * 2^k < 2^61  (every row sum of phase 2 fits a signed 64-bit accumulator with room to spare)
-__device__ __forceinline__ void fixed_point_scale(double bound, int32_t* k, double* inv)
-{
-  int kk = 0;
-  if (bound > 0.0 && bound < 1.0e300) {
-    int e;
-    (void)frexp(bound, &e);  // bound = m * 2^e, 0.5 <= m < 1  =>  bound < 2^e
-    kk = 61 - e;
-  }
-  kk   = max(-900, min(900, kk));
-  *k   = kk;
-  *inv = ldexp(1.0, -kk);
-}
-
-template <typename WT>
-__device__ __forceinline__ void write_scalars(pr_scalars<WT>* scal, double diff, double dang, double xmax, WT alpha, int64_t nv_global,
-                                              int personalized, double wmax)
-{
-  WT dangling       = (WT)dang;
-  WT factor         = dangling * alpha + (WT)(1.0 - (double)alpha);
-  scal->dangling    = dangling;
-  scal->diff        = (WT)diff;
-  scal->pers_factor = factor;
-  scal->base        = personalized ? WT(0) : factor / (WT)nv_global;
-  fixed_point_scale((double)alpha * xmax * wmax, &scal->fx_k, &scal->fx_inv);
-}
-
 // executed by ONE workgroup of `nthreads` threads; scratch = 3 * nthreads doubles of LDS
 template <typename WT>
 __device__ __forceinline__ void finish_scalars(fin_args<WT> const& f, double* scratch, int tid, int nthreads)
@@ -483,7 +456,7 @@ __device__ __forceinline__ void finish_scalars(fin_args<WT> const& f, double* sc
   }
   if (tid == 0) {
     if (f.totals) { f.totals[0] = r0[0]; f.totals[1] = r1[0]; f.totals[2] = r2[0]; }
-    else write_scalars<WT>(f.scal, r0[0], r1[0], r2[0], f.alpha, f.nv_global, f.personalized, f.wmax);
+    else tiled_write_scalars<WT>(f.scal, r0[0], r1[0], r2[0], f.alpha, f.nv_global, f.personalized, f.wmax);
   }
   __syncthreads();
 }
@@ -505,7 +478,7 @@ __global__ void k_tiled_scalars_from_ranks(unsigned char const* recv, size_t fir
     double const* t = reinterpret_cast<double const*>(recv + first_off + (size_t)r * stride_bytes);
     diff += t[0]; dang += t[1]; xmax = fmax(xmax, t[2]);
   }
-  write_scalars<WT>(f.scal, diff, dang, xmax, f.alpha, f.nv_global, f.personalized, f.wmax);
+  tiled_write_scalars<WT>(f.scal, diff, dang, xmax, f.alpha, f.nv_global, f.personalized, f.wmax);
 }
 
 // iteration-0 state: x = pr / out_w, partial dangling mass and max |x| per block

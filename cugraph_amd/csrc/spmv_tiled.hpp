@@ -142,4 +142,32 @@ void tiled_scalars_from_ranks(handle_t const& h, tiled_epilogue<WT> const& e, vo
 
 int tiled_default_T(handle_t const& h, size_t weight_size, int64_t nv);
 
+// 2^k with alpha * xmax * wmax * 2^k < 2^61 (every row sum of phase 2 fits a signed 64-bit accumulator with room to spare)
+__device__ __forceinline__ void tiled_fixed_point_scale(double bound, int32_t* k, double* inv)
+{
+  int kk = 0;
+  if (bound > 0.0 && bound < 1.0e300) {
+    int e;
+    (void)frexp(bound, &e);  // bound = m * 2^e, 0.5 <= m < 1  =>  bound < 2^e
+    kk = 61 - e;
+  }
+  kk   = max(-900, min(900, kk));
+  *k   = kk;
+  *inv = ldexp(1.0, -kk);
+}
+
+// the iteration's scalars -> constants of the next iteration (base term, personalization factor, fixed-point scale)
+template <typename WT>
+__device__ __forceinline__ void tiled_write_scalars(pr_scalars<WT>* scal, double diff, double dang, double xmax, WT alpha, int64_t nv_global,
+                                                    int personalized, double wmax)
+{
+  WT dangling       = (WT)dang;
+  WT factor         = dangling * alpha + (WT)(1.0 - (double)alpha);
+  scal->dangling    = dangling;
+  scal->diff        = (WT)diff;
+  scal->pers_factor = factor;
+  scal->base        = personalized ? WT(0) : factor / (WT)nv_global;
+  tiled_fixed_point_scale((double)alpha * xmax * wmax, &scal->fx_k, &scal->fx_inv);
+}
+
 }  // namespace cga

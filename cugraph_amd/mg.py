@@ -3,15 +3,18 @@
 Partitioning (re-designed for a full-mesh xGMI node instead of translated):
   * vertices are ordered by descending GLOBAL in-degree (ties: ascending id) and dealt round-robin to the P ranks:
     position p -> owner p % P, local row p // P.  Every rank gets the same mix of hub and tail rows (balanced edge
-    counts) and its local rows are already degree-sorted, which is what the edge-balanced SpMV kernel wants;
+    counts) and its local rows are already degree-sorted;
   * 1-D by destination: the owner of a destination holds ALL its in-edges, so the pull-SpMV needs no partial-sum
     reduction over ranks (the reference's 2-D scheme needs a row broadcast AND a column reduce per iteration,
     prims/update_edge_src_dst_property.cuh:550-579 + prims/detail/per_v_transform_reduce_e.cuh:3390-3406);
-  * per iteration ONE collective: all-gather of x = pr / out_w (chunk of V/P values per rank) with the two scalars of
-    the iteration (partial L1 change, partial dangling mass, max |x|) riding in the last 32 bytes of every chunk -- no scalar
-    all-reduce, every rank adds the P partials in rank order (deterministic).
-Column ids stored in the local CSC are the global degree-order positions, so the hottest sources are ids [0, K)
-and the LDS hot tile of the SpMV kernel keeps working across ranks.
+  * per iteration ONE collective: a SPARSE all-to-all of x = pr / out_w.  A rank receives exactly the source values
+    its edges reference -- vertices without out-edges (most of an RMAT graph) are never sent, a low-degree source only
+    goes where one of its out-edges lives -- as one point-to-point message per peer, so all xGMI links of a GPU work at
+    once; a ring all-gather of the whole vector would be bound by one link and move (P-1)/P * 4V bytes into every GPU.
+    The iteration's scalars (partial L1 change, partial dangling mass, max |x|) ride in a 32-byte tail of every message
+    -- no scalar all-reduce, every rank adds the P partials in rank order (deterministic).
+Local column ids are compact (the distinct sources a rank references, hottest first), so the column-tiled SpMV kernels
+run unchanged on the unpacked receive buffer.
 
 The local compute sits behind `LocalEngine`; the product engine is `HipLocalEngine` (C ABI, HIP).  Tests plug a
 CPU engine built on the oracle into the same orchestration to exercise partitioning + collectives under gloo.
@@ -25,6 +28,8 @@ import time
 import torch
 import torch.distributed as dist
 
+TAIL_BYTES = 32  # (L1 change, dangling mass, max |x|) as 3 doubles + padding, behind every message
+
 
 # ------------------------------------------------------------------------------------------ partition
 class Partition:
@@ -37,12 +42,15 @@ class Partition:
         _, order = torch.sort(in_degree, descending=True, stable=True)
         self.order = order                                   # position -> vertex
         self.pos = torch.empty_like(order)
-        self.pos[order] = torch.arange(self.nv, dtype=order.dtype, device=order.device)  # vertex -> position (= column id)
+        self.pos[order] = torch.arange(self.nv, dtype=order.dtype, device=order.device)  # vertex -> position
         self.local_vertices = order[rank::world]             # external ids of the rows this rank owns, local order
         self.n_rows = int(self.local_vertices.numel())
-        lmax = (self.nv + world - 1) // world
-        self.chunk = (lmax + 8 + 3) // 4 * 4                 # local rows + 32 B of scalars (3 doubles + pad), 16-byte multiple
-        self.ncols = self.chunk * world
+
+
+def _a2a(t, send_counts, recv_counts, group):
+    out = torch.empty(int(sum(recv_counts)), dtype=t.dtype, device=t.device)
+    dist.all_to_all_single(out, t, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=group)
+    return out
 
 
 def _exchange_edges(col_src, local_dst, owner_dst, weights, world, group):
@@ -56,22 +64,71 @@ def _exchange_edges(col_src, local_dst, owner_dst, weights, world, group):
     recv_counts = torch.empty_like(send_counts)
     dist.all_to_all_single(recv_counts, send_counts, group=group)
     sc, rc = send_counts.tolist(), recv_counts.tolist()
-    n_recv = int(sum(rc))
+    return (_a2a(col_src, sc, rc, group), _a2a(local_dst, sc, rc, group), (_a2a(weights, sc, rc, group) if weights is not None else None))
 
-    def a2a(t):
-        out = torch.empty(n_recv, dtype=t.dtype, device=t.device)
-        dist.all_to_all_single(out, t, output_split_sizes=rc, input_split_sizes=sc, group=group)
-        return out
 
-    return a2a(col_src), a2a(local_dst), (a2a(weights) if weights is not None else None)
+class Exchange:
+    """Static plan of the per-iteration sparse all-to-all of x (built once, collectively).
+
+    need          sorted global positions of the distinct sources this rank's edges reference (= compact column c -> position)
+    recv_counts   values received from each rank;  send_counts: values sent to each rank
+    send_index    local row (of this rank) of the k-th value sent, grouped by destination rank
+    col_pos       element offset in the receive buffer of compact column c
+    """
+
+    def __init__(self, src_pos: torch.Tensor, world: int, rank: int, itemsize: int, group):
+        self.world, self.rank = world, rank
+        self.tail = TAIL_BYTES // itemsize
+        need, self.col_of_edge = torch.unique(src_pos, sorted=True, return_inverse=True)
+        self.ncols = int(need.numel())
+        owner = need % world
+        order = torch.argsort(owner, stable=True)            # requests grouped by owner, ascending position inside
+        req = (need // world)[order].to(torch.int32)
+        counts = torch.bincount(owner, minlength=world).tolist()
+        # fp32 tails hold doubles: keep every message 8-byte aligned by padding odd requests with a repeat of local row 0
+        pad_to = 8 // itemsize
+        pieces, rc, first = [], [], 0
+        for s in range(world):
+            piece = req[first:first + counts[s]]
+            first += counts[s]
+            extra = (-counts[s]) % pad_to
+            if extra:
+                piece = torch.cat([piece, torch.zeros(extra, dtype=torch.int32, device=piece.device)])
+            pieces.append(piece)
+            rc.append(int(piece.numel()))
+        req_padded = torch.cat(pieces) if pieces else req
+        self.recv_counts = rc
+        # element offset of every compact column in the receive buffer (messages are followed by their tails)
+        seg_start, off = [], 0
+        for s in range(world):
+            seg_start.append(off)
+            off += rc[s] + self.tail
+        self.recv_elems = off
+        pos_in_group = torch.empty(self.ncols, dtype=torch.int64, device=need.device)
+        first = 0
+        for s in range(world):
+            pos_in_group[first:first + counts[s]] = torch.arange(counts[s], device=need.device) + seg_start[s]
+            first += counts[s]
+        col_pos = torch.empty(self.ncols, dtype=torch.int64, device=need.device)
+        col_pos[order] = pos_in_group
+        self.col_pos = col_pos.to(torch.int32)
+        # tell every owner what we need from it
+        rc_t = torch.tensor(rc, dtype=torch.int64, device=need.device)
+        sc_t = torch.empty_like(rc_t)
+        dist.all_to_all_single(sc_t, rc_t, group=group)
+        self.send_counts = sc_t.tolist()
+        self.send_index = _a2a(req_padded, rc, self.send_counts, group)  # what the others asked of us
+        self.send_elems = int(sum(self.send_counts)) + world * self.tail
+        self.send_splits = [c + self.tail for c in self.send_counts]
+        self.recv_splits = [c + self.tail for c in self.recv_counts]
 
 
 # --------------------------------------------------------------------------------------------- engines
 class LocalEngine:
     """What the orchestration needs from the per-rank compute."""
 
-    send: torch.Tensor  # chunk elements
-    recv: torch.Tensor  # world * chunk elements
+    send: torch.Tensor  # Exchange.send_elems elements
+    recv: torch.Tensor  # Exchange.recv_elems elements
 
     def start(self):
         raise NotImplementedError
@@ -89,33 +146,37 @@ class LocalEngine:
 class HipLocalEngine(LocalEngine):
     """The product path: local CSC + fused step on the GPU through the C ABI (cugraph_amd_pagerank_mg_plan_*)."""
 
-    def __init__(self, part: Partition, col_src, local_dst, weights, outw_local, alpha, initial_local=None):
+    def __init__(self, part: Partition, ex: Exchange, local_dst, weights, outw_local, alpha, initial_local=None):
         from . import _capi as capi
         from .pylib import GraphProperties, ResourceHandle, SGGraph, _View, assert_success
 
         self._capi, self._assert = capi, assert_success
         self.part = part
         dev = torch.device("cuda", torch.cuda.current_device())
-        col_src, local_dst, outw_local = col_src.to(dev), local_dst.to(dev), outw_local.to(dev)
+        col, local_dst, outw_local = ex.col_of_edge.to(dev), local_dst.to(dev), outw_local.to(dev)
         weights = None if weights is None else weights.to(dev)
         initial_local = None if initial_local is None else initial_local.to(dev)
         self.handle = ResourceHandle()
         dtype = torch.float64 if (weights is not None and weights.dtype == torch.float64) else torch.float32
-        cols = torch.arange(part.ncols, dtype=torch.int32, device=dev)
-        # local rows are ids [0, n_rows); ncols >= n_rows vertices so that every column id is a vertex of the local graph
-        self.graph = SGGraph(self.handle, GraphProperties(is_multigraph=True), col_src.to(torch.int32), local_dst.to(torch.int32),
-                             weights, store_transposed=True, renumber=False, vertices_array=cols)
-        chunk = part.chunk if dtype == torch.float32 else part.chunk  # fp64: same element count (32-byte multiple)
-        self.send = torch.zeros(chunk, dtype=dtype, device=dev)
-        self.recv = torch.zeros(chunk * part.world, dtype=dtype, device=dev)
+        nverts = max(ex.ncols, part.n_rows, 1)
+        verts = torch.arange(nverts, dtype=torch.int32, device=dev)
+        # local rows are ids [0, n_rows), columns the compact ids [0, ncols): both are vertices of the local graph
+        self.graph = SGGraph(self.handle, GraphProperties(is_multigraph=True), col.to(torch.int32), local_dst.to(torch.int32),
+                             weights, store_transposed=True, renumber=False, vertices_array=verts)
+        self.send = torch.zeros(ex.send_elems, dtype=dtype, device=dev)
+        self.recv = torch.zeros(ex.recv_elems, dtype=dtype, device=dev)
         self._outw = outw_local.to(dtype).contiguous()
         self._init = None if initial_local is None else initial_local.to(dtype).contiguous()
-        views = [_View(self._outw), _View(self._init), _View(self.send), _View(self.recv)]
+        self._sidx = ex.send_index.to(dev).to(torch.int32).contiguous()
+        self._cpos = ex.col_pos.to(dev).contiguous()
+        views = [_View(self._outw), _View(self._init), _View(self._sidx), _View(self._cpos), _View(self.send), _View(self.recv)]
+        sc = (C.c_size_t * part.world)(*ex.send_counts)
+        rc = (C.c_size_t * part.world)(*ex.recv_counts)
         plan, err = C.c_void_p(), C.c_void_p()
         torch.cuda.current_stream().synchronize()
         code = capi.lib().cugraph_amd_pagerank_mg_plan_create(
-            self.handle.c_resource_handle_ptr, self.graph.c_graph_ptr, part.n_rows, part.nv, part.rank, part.world, chunk, views[0].ptr,
-            views[1].ptr, views[2].ptr, views[3].ptr, float(alpha), C.byref(plan), C.byref(err))
+            self.handle.c_resource_handle_ptr, self.graph.c_graph_ptr, part.n_rows, part.nv, part.rank, part.world, views[0].ptr,
+            views[1].ptr, views[2].ptr, sc, rc, views[3].ptr, views[4].ptr, views[5].ptr, float(alpha), C.byref(plan), C.byref(err))
         for v in views:
             v.free()
         assert_success(code, err, "cugraph_amd_pagerank_mg_plan_create")
@@ -163,7 +224,6 @@ class MGPageRank:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        dev = src.device
         nv = int(num_vertices)
         src64, dst64 = src.to(torch.int64), dst.to(torch.int64)
         # global in-degrees (schedule) and out-weight sums (PageRank's divisor): local histogram + all-reduce
@@ -176,25 +236,27 @@ class MGPageRank:
         dist.all_reduce(out_w, group=group)
         self.part = part = Partition(in_deg, self.world, self.rank)
         pos_dst = part.pos[dst64]
-        col_src, local_dst, w = _exchange_edges(part.pos[src64].to(torch.int32), (pos_dst // self.world).to(torch.int32),
+        src_pos, local_dst, w = _exchange_edges(part.pos[src64], (pos_dst // self.world).to(torch.int32),
                                                 pos_dst % self.world, weights, self.world, group)
-        self.num_local_edges = int(col_src.numel())
+        self.num_local_edges = int(src_pos.numel())
+        itemsize = 8 if (w is not None and w.dtype == torch.float64) else 4
+        self.ex = ex = Exchange(src_pos, self.world, self.rank, itemsize, group)
         outw_local = out_w[part.local_vertices]
         init_local = None if initial_guess is None else initial_guess[part.local_vertices]
         factory = engine_factory or HipLocalEngine
-        self.engine = factory(part, col_src, local_dst, w, outw_local, alpha, init_local)
+        self.engine = factory(part, ex, local_dst, w, outw_local, alpha, init_local)
         self.iterations = 0
         self.engine.start()
 
-    def _gather(self):
-        e = self.engine
+    def _exchange(self):
+        e, ex = self.engine, self.ex
         if e.recv.is_cuda and dist.get_backend(self.group) == "gloo":
             # test configuration (several ranks sharing one GPU): gloo moves host memory
             recv = torch.empty(e.recv.shape, dtype=e.recv.dtype)
-            dist.all_gather_into_tensor(recv, e.send.cpu(), group=self.group)
+            dist.all_to_all_single(recv, e.send.cpu(), output_split_sizes=ex.recv_splits, input_split_sizes=ex.send_splits, group=self.group)
             e.recv.copy_(recv)
         else:
-            dist.all_gather_into_tensor(e.recv, e.send, group=self.group)
+            dist.all_to_all_single(e.recv, e.send, output_split_sizes=ex.recv_splits, input_split_sizes=ex.send_splits, group=self.group)
         if e.recv.is_cuda:
             torch.cuda.current_stream().synchronize()  # the library computes on its own HIP stream
 
@@ -203,7 +265,7 @@ class MGPageRank:
         (pagerank_impl.cuh:320-326).  Returns (iterations_done, converged)."""
         done = 0
         while done < n_iterations:
-            self._gather()
+            self._exchange()
             diff, _ = self.engine.reduce_scalars(epsilon > 0.0)
             if epsilon > 0.0 and self.iterations > 0 and diff < epsilon:
                 return done, True
@@ -211,7 +273,7 @@ class MGPageRank:
             self.iterations += 1
             done += 1
         if epsilon > 0.0:  # did the last allowed iteration converge?
-            self._gather()
+            self._exchange()
             diff, _ = self.engine.reduce_scalars(True)
             return done, diff < epsilon
         return done, False
@@ -266,6 +328,17 @@ def bench_main(args):
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
+    # HIP-event timing of this rank's two SpMV kernels over a few extra (untimed) iterations: the per-GPU roofline fraction
+    eh = pr.engine.handle
+    eh.kernel_timing(True)
+    eh.kernel_timing_reset()
+    pr.step(3)
+    torch.cuda.synchronize()
+    n1, ms1 = eh.kernel_timing_get("pagerank_spmv")
+    n2, ms2 = eh.kernel_timing_get("pagerank_reduce")
+    eh.kernel_timing(False)
+    kernel_s = (ms1 / max(n1, 1) + ms2 / max(n2, 1)) / 1e3
+    local_bytes = 4 * pr.num_local_edges + 16 * pr.part.n_rows + 4  # this rank's share of 4E + 16V + 4
     out = None
     if rank == 0:
         out = {
@@ -274,9 +347,14 @@ def bench_main(args):
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"PageRank power iteration, RMAT scale {args.scale} edge factor {args.edge_factor} (a,b,c)=(0.57,0.19,0.19) "
                                    "seed 0, int32 ids, fp32 ranks, alpha 0.85; 1-D destination partition, degree-order round-robin, "
-                                   "one all-gather of x per iteration over RCCL",
+                                   "one sparse all-to-all of x per iteration over RCCL",
                        "vertices": nv, "edges": ne, "parallelism": f"{world} GPUs, 1 process per GPU"},
             "iters_per_sec": round(args.steps / dt, 2), "graph_build_s": round(build_s, 3), "local_edges_rank0": pr.num_local_edges,
+            "exchange_rank0": {"columns": pr.ex.ncols, "recv_bytes_per_iteration": pr.ex.recv_elems * 4, "send_bytes_per_iteration": pr.ex.send_elems * 4},
+            "roofline": {"bound": "hbm", "achieved": round(local_bytes / kernel_s / 1e9, 1) if kernel_s > 0 else None, "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(local_bytes / kernel_s / 1e9 / 8000.0, 4) if kernel_s > 0 else None, "traffic": None,
+                         "kernel": "k_tiled_phase1 + k_tiled_phase2 on rank 0 (per-GPU share of the algorithmic bytes / its kernel time)",
+                         "avg_kernel_ms": round(kernel_s * 1e3, 4)},
         }
     dist.barrier()
     return out

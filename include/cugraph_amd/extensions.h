@@ -49,27 +49,32 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_plan_result(
 CUGRAPH_EXPORT void cugraph_amd_pagerank_plan_free(cugraph_amd_pagerank_plan_t* plan);
 
 
-/* Multi-GPU PageRank, one process per GPU (1-D partition by destination).
- * `graph` is this rank's LOCAL CSC: rows [0, n_local_rows) are the destinations this rank owns, numbered by
- * descending in-degree; column ids are c = local_index * comm_size + owner_rank of the SOURCE vertex (i.e. the
- * global degree order) and the graph must have been created with at least comm_size * chunk vertices.
- * The caller provides two device buffers (views, weight type): `send` (chunk elements: this rank's x = pr / out_w; the LAST 32 bytes hold its
- * partial L1 change, dangling mass and max |x| as three doubles + 8 bytes of padding) and `recv` (comm_size * chunk elements).  Per iteration the
- * host layer runs ONE all-gather send -> recv (torch.distributed / RCCL), then reduce_scalars(), then local_step().
- * comm_size must be a power of two.  cugraph_amd/mg.py is the host layer. */
+/* Multi-GPU PageRank, one process per GPU (1-D partition by destination; design in DESIGN.md section 5).
+ * `graph` is this rank's LOCAL CSC: rows [0, n_local_rows) are the destinations this rank owns, numbered by descending
+ * in-degree; column ids are COMPACT: 0 .. ncols-1 = the distinct sources its edges reference, hottest first (the graph
+ * must be created with max(ncols, n_local_rows) vertices).  Per iteration the host layer runs ONE sparse all-to-all
+ * (torch.distributed.all_to_all_single = RCCL over xGMI), then reduce_scalars(), then local_step().
+ *   send_index[k]   INT32, k < sum(send_counts): local row whose x = pr / out_w is the k-th value sent (grouped by peer)
+ *   send_counts[s], recv_counts[s]  number of values sent to / received from rank s (host arrays; even for fp32)
+ *   col_pos[c]      INT32, c < ncols: ELEMENT offset in `recv` of the value of column c
+ *   send / recv     device views (weight type): for every peer s, in rank order, its values followed by a 32-byte tail
+ *                   holding the sender's (L1 change, dangling mass, max |x|) as three doubles + 8 bytes of padding.
+ * cugraph_amd/mg.py is the host layer. */
 typedef struct { int32_t align_; } cugraph_amd_pagerank_mg_plan_t;
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg_plan_create(
   const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, size_t n_local_rows, size_t global_num_vertices, int comm_rank,
-  int comm_size, size_t chunk, const cugraph_type_erased_device_array_view_t* out_weight_sums_local,
-  const cugraph_type_erased_device_array_view_t* initial_local, cugraph_type_erased_device_array_view_t* send,
-  cugraph_type_erased_device_array_view_t* recv, double alpha, cugraph_amd_pagerank_mg_plan_t** plan, cugraph_error_t** error);
-/* send <- x of the initial vector + partial dangling mass (iteration-0 state) */
+  int comm_size, const cugraph_type_erased_device_array_view_t* out_weight_sums_local,
+  const cugraph_type_erased_device_array_view_t* initial_local, const cugraph_type_erased_device_array_view_t* send_index,
+  const size_t* send_counts, const size_t* recv_counts, const cugraph_type_erased_device_array_view_t* col_pos,
+  cugraph_type_erased_device_array_view_t* send, cugraph_type_erased_device_array_view_t* recv, double alpha,
+  cugraph_amd_pagerank_mg_plan_t** plan, cugraph_error_t** error);
+/* messages <- x of the initial vector + (0, partial dangling mass, max |x|) (iteration-0 state) */
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg_plan_start(cugraph_amd_pagerank_mg_plan_t* plan, cugraph_error_t** error);
-/* sums the comm_size partial (L1 change, dangling) pairs found in recv, in rank order; read_back = TRUE also
+/* folds the comm_size (L1 change, dangling, max |x|) tails found in recv, in rank order; read_back = TRUE also
  * returns them to the host (synchronises) -- needed only when epsilon > 0 */
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg_plan_reduce_scalars(cugraph_amd_pagerank_mg_plan_t* plan, bool_t read_back,
                                                                                 double* diff, double* dangling, cugraph_error_t** error);
-/* one power iteration on the local rows: pull-SpMV over recv, new pr, next send chunk; blocks until done */
+/* one power iteration on the local rows: unpack recv, tiled SpMV, new pr, next messages packed into send; blocks until done */
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg_plan_local_step(cugraph_amd_pagerank_mg_plan_t* plan, cugraph_error_t** error);
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg_plan_values(cugraph_amd_pagerank_mg_plan_t* plan,
                                                                         cugraph_type_erased_device_array_view_t* out_local,

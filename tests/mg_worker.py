@@ -19,42 +19,55 @@ from oracle import oracle as orc  # noqa: E402
 class OracleEngine(mg.LocalEngine):
     """Same contract as HipLocalEngine, arithmetic by numpy/scipy in fp64 then rounded to fp32 storage."""
 
-    def __init__(self, part, col_src, local_dst, weights, outw_local, alpha, initial_local=None):
+    def __init__(self, part, ex, local_dst, weights, outw_local, alpha, initial_local=None):
         import scipy.sparse as sp
 
-        self.part, self.alpha = part, float(alpha)
-        P, chunk = part.world, part.chunk
-        c = col_src.numpy().astype(np.int64)
-        addr = (c % P) * chunk + c // P  # column id -> position in the rank-blocked all-gather buffer
+        self.part, self.ex, self.alpha = part, ex, float(alpha)
+        c = ex.col_of_edge.numpy().astype(np.int64)
         w = np.ones(c.size) if weights is None else weights.numpy().astype(np.float64)
-        self.A = sp.csr_matrix((w, (local_dst.numpy().astype(np.int64), addr)), shape=(part.n_rows, chunk * P))
+        self.A = sp.csr_matrix((w, (local_dst.numpy().astype(np.int64), c)), shape=(part.n_rows, max(ex.ncols, 1)))
         self.outw = outw_local.numpy().astype(np.float32)
         self.pr = (np.full(part.n_rows, 1.0 / part.nv, np.float32) if initial_local is None else initial_local.numpy().astype(np.float32))
-        self.send = torch.zeros(chunk, dtype=torch.float32)
-        self.recv = torch.zeros(chunk * P, dtype=torch.float32)
+        self.send = torch.zeros(ex.send_elems, dtype=torch.float32)
+        self.recv = torch.zeros(ex.recv_elems, dtype=torch.float32)
         self.base = 0.0
 
     def _pack(self, diff):
-        s = self.send.numpy()
+        ex, s = self.ex, self.send.numpy()
         div = np.where(self.outw == 0, np.float32(1), self.outw)
-        s[: self.part.n_rows] = self.pr / div
-        tail = s[-8:].view(np.float64)  # (L1 change, dangling mass, max |x|, pad)
-        tail[0] = diff
-        tail[1] = float(self.pr[self.outw == 0].astype(np.float64).sum())
-        tail[2] = float(np.abs(s[: self.part.n_rows]).max()) if self.part.n_rows else 0.0
+        x = (self.pr / div).astype(np.float32)
+        idx = ex.send_index.numpy().astype(np.int64)
+        dang = float(self.pr[self.outw == 0].astype(np.float64).sum())
+        xmax = float(np.abs(x).max()) if x.size else 0.0
+        off = first = 0
+        for r in range(ex.world):
+            n = ex.send_counts[r]
+            s[off:off + n] = x[idx[first:first + n]] if x.size else 0
+            tail = s[off + n: off + n + ex.tail].view(np.float64)  # (L1 change, dangling mass, max |x|, pad)
+            tail[0], tail[1], tail[2] = diff, dang, xmax
+            off += n + ex.tail
+            first += n
 
     def start(self):
         self._pack(0.0)
 
     def reduce_scalars(self, read_back):
-        r = self.recv.numpy().reshape(self.part.world, self.part.chunk)
-        tails = r[:, -8:].copy().view(np.float64)
-        diff, dang = float(tails[:, 0].sum()), np.float32(tails[:, 1].sum())
+        ex, r = self.ex, self.recv.numpy()
+        diff = dang = 0.0
+        off = 0
+        for k in range(ex.world):
+            off += ex.recv_counts[k]
+            t = r[off: off + ex.tail].copy().view(np.float64)
+            diff += t[0]
+            dang += t[1]
+            off += ex.tail
+        dang = np.float32(dang)
         self.base = np.float32((dang * np.float32(self.alpha) + np.float32(1.0 - self.alpha)) / np.float32(self.part.nv))
         return diff, float(dang)
 
     def local_step(self):
-        x = self.recv.numpy().astype(np.float64) * np.float64(np.float32(self.alpha))
+        xc = self.recv.numpy()[self.ex.col_pos.numpy().astype(np.int64)] if self.ex.ncols else np.zeros(1, np.float32)
+        x = xc.astype(np.float64) * np.float64(np.float32(self.alpha))
         y = (self.A @ x).astype(np.float32)
         new = (self.base + y).astype(np.float32)
         diff = float(np.abs(new - self.pr).astype(np.float64).sum())
