@@ -300,9 +300,15 @@ def bench_main(args):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    single = os.environ.get("CUGRAPH_AMD_MG_TEST_SINGLE_GPU") == "1"  # plumbing check: all ranks share cuda:0, gloo moves the data
+    if single:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if not dist.is_initialized():
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if single:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     nv, ne = 1 << args.scale, args.edge_factor << args.scale
     h = ResourceHandle()
     if args.hot_tile is not None:
@@ -312,6 +318,8 @@ def bench_main(args):
     count = max(0, min(per, ne - first))
     t0 = time.perf_counter()
     src, dst = generate_rmat_edgelist(h, args.scale, count, first_edge=first)
+    if single:
+        src, dst = src.cpu(), dst.cpu()  # gloo: the setup collectives run on host tensors
     pr = MGPageRank(src, dst, nv, alpha=0.85)
     del src, dst
     torch.cuda.synchronize()
@@ -325,7 +333,7 @@ def bench_main(args):
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if single else "cuda")
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
     # HIP-event timing of this rank's two SpMV kernels over a few extra (untimed) iterations: the per-GPU roofline fraction
