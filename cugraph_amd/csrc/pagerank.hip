@@ -635,9 +635,18 @@ struct pagerank_plan : pagerank_plan_base {
       int const T = tiled_default_T(h, sizeof(WT), g.nv);
       if (!o.tiled || o.tiled->T != T) {
         auto t = std::make_shared<tiled_csc_t>();
-        build_tiled_csc(h, g.nv, g.nv, g.ne, o, g.has_weights, sizeof(WT), T, *t);
-        o.tiled = t;
+        try {
+          build_tiled_csc(h, g.nv, g.nv, g.ne, o, g.has_weights, sizeof(WT), T, *t);
+          o.tiled = t;
+        } catch (api_error const& e) {
+          // the re-blocked arrays are addressed with 32-bit byte offsets; a graph that outgrows them (or the memory for
+          // the build temporaries) still gets an answer from the single-pass kernels
+          if (e.code == CUGRAPH_ALLOC_ERROR || std::string(e.what()).find("tiled SpMV") != std::string::npos) tiled = false;
+          else throw;
+        }
       }
+    }
+    if (tiled) {
       tc = o.tiled;
       part.resize_discard((size_t)tc->n_slots + 64);
       HIP_TRY(hipMemsetAsync(part.data(), 0, ((size_t)tc->n_slots + 64) * sizeof(WT), h.stream));

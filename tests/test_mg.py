@@ -68,6 +68,32 @@ def test_partition_is_balanced_and_degree_sorted(orc):
         assert bool((p.pos[p.local_vertices] % 4 == p.rank).all())         # owner of degree-order position p is p % P
 
 
+def test_exchange_plan_is_sparse_and_consistent(tmp_path):
+    """The static all-to-all plan (world 1, so no process group traffic is needed beyond a self-exchange): every
+    referenced source gets exactly one receive slot, unreferenced sources none, messages stay 8-byte aligned."""
+    import torch
+    import torch.distributed as dist
+
+    from cugraph_amd.mg import TAIL_BYTES, Exchange
+
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1)
+    try:
+        src_pos = torch.tensor([5, 5, 9, 0, 9, 2, 7, 7, 7], dtype=torch.int64)
+        ex = Exchange(src_pos, 1, 0, 4, None)
+        assert ex.ncols == 5 and ex.tail == TAIL_BYTES // 4
+        assert ex.recv_counts == [6] and ex.send_counts == [6]            # 5 distinct sources, padded to an even count
+        assert ex.recv_elems == 6 + ex.tail and ex.send_elems == 6 + ex.tail
+        need = torch.unique(src_pos)
+        assert torch.equal(need[ex.col_of_edge], src_pos)                 # compact column of every edge
+        x = torch.arange(100, 110, dtype=torch.float32)                   # this rank owns positions 0..9 (world 1)
+        recv = torch.zeros(ex.recv_elems)
+        recv[: 6] = x[ex.send_index.long()]                               # what the exchange delivers
+        assert torch.equal(recv[ex.col_pos.long()], x[need])              # unpacked: the value of every referenced source
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("world,mode", [(2, "oracle"), (4, "oracle"), (2, "oraclew")])
 def test_mg_pagerank_gloo_cpu(orc, tmp_path, world, mode):
     scale = 10
