@@ -46,7 +46,11 @@ constexpr int TP_WAVES = TP_BLOCK / 64;
 //   occupancy: two workgroups per CU (tile ~62 KiB, 8 wavefronts per SIMD, <= 64 VGPRs), 8 edges per lane, no register prefetch
 #ifdef CGA_TILED_OCC2
 constexpr int TP_EPL = 8;
+#ifdef CGA_TILED_OCC2_PREFETCH
+constexpr bool TP_PREFETCH = true;
+#else
 constexpr bool TP_PREFETCH = false;
+#endif
 constexpr int TP_WG_PER_CU = 2;
 constexpr int TP_STAGE = 256;                // per-wavefront LDS staging entries (run totals awaiting the coalesced write-out)
 #else
