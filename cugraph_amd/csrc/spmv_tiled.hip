@@ -559,42 +559,47 @@ __device__ __forceinline__ void p1_load(p1_args<WT> const& a, int item, int wave
   for (int j = 0; j < TP_EPL / 8; ++j) r.id[j] = ld32<uint4>(a.src16, 2u * e + 16u * j);
   if constexpr (TP_EPL == 16) r.fl = ld32<uint16_t>(a.bits, e >> 3);
   else r.fl = ld32<uint8_t>(a.bits, e >> 3);
-  r.wd    = ld32<uint4>(a.waves, ((uint32_t)item * TP_WAVES + (uint32_t)wave) * (uint32_t)sizeof(tiled_wave_t));
+  r.wd = ld32<uint4>(a.waves, ((uint32_t)item * TP_WAVES + (uint32_t)wave) * (uint32_t)sizeof(tiled_wave_t));
 }
 
-struct p1_runs {  // what part 1 derives from the bitmap of one work item
-  uint32_t f, nf, ex_c, c_all;
-  uint32_t slot0, slot1;  // slots of runs `lane` and `64 + lane`
+// Run ordinal n within the wavefront's range: n = 0 is the run that was already open at `es` (its partial goes to the
+// head slot), n >= 1 is run (rank - 1 + n), whose slot is rpos1[rank + n] (rpos1 = rpos shifted by one entry).
+struct p1_runs {  // what the bitmap of one work item says about its runs
+  uint32_t f, ex_c, c_all;
+  uint32_t slot[TP_NSLOT];  // slots of runs lane, 64 + lane, ...
+  uint32_t slot_tail;       // slot of the run still open at the end of the range
   uint32_t es, ee, rank, head_slot;
 };
 
-// Part 1 (bitmap only): run counts of the wavefront's 1024 edges; the slots of its first 128 runs are requested right away
-// (BEFORE the next item's edge data is requested: vmcnt retires in order, so waiting for these must not imply waiting for
-// the prefetch) -- their latency hides behind the LDS gathers and scans of part 2.
-// Run ordinal n within the wavefront's range: n = 0 is the run that was already open at `es` (its partial goes to the
-// head slot), n >= 1 is run (rank - 1 + n), whose slot is rpos1[rank + n] (rpos1 = rpos shifted by one entry).
-template <typename WT>
-__device__ __forceinline__ void p1_part1(p1_args<WT> const& a, int lane, p1_regs const& rg, p1_runs& q)
+__device__ __forceinline__ void p1_counts(int lane, p1_regs const& rg, p1_runs& q)
 {
   q.es = rfl(rg.wd.x); q.ee = rfl(rg.wd.y); q.rank = rfl(rg.wd.z); q.head_slot = rfl(rg.wd.w);
   uint32_t const e     = q.es + (uint32_t)TP_EPL * (uint32_t)lane;
   uint32_t const nval  = min((uint32_t)TP_EPL, q.ee > e ? q.ee - e : 0u);
   q.f                  = rg.fl & ((1u << nval) - 1u);
-  q.nf                 = __popc(q.f);
-  uint32_t const c_inc = wave_inclusive_sum_u32(q.nf);
-  q.ex_c               = c_inc - q.nf;
+  uint32_t const nf    = __popc(q.f);
+  uint32_t const c_inc = wave_inclusive_sum_u32(nf);
+  q.ex_c               = c_inc - nf;
   q.c_all              = (uint32_t)__builtin_amdgcn_readlane((int)c_inc, 63);
-  uint32_t const o     = 4u * (q.rank + (uint32_t)lane);
-  uint32_t const s0    = ld32<uint32_t>(a.rpos1, o);  // unconditional (rpos1 is padded): no exec juggling
-  uint32_t const s1    = ld32<uint32_t>(a.rpos1, o + 256u);
-  q.slot0              = lane == 0 ? q.head_slot : s0;
-  q.slot1              = s1;
 }
 
-// run totals of lanes [lane_lo, lane_hi) -> staging area (in run order) -> coalesced stores
 template <typename WT>
-__device__ __forceinline__ void p1_emit(p1_args<WT> const& a, WT* stage, int lane, p1_runs const& q, WT const (&r)[TP_EPL], WT carry_in, uint32_t base_c,
-                                        uint32_t count, bool mine, bool preloaded)
+__device__ __forceinline__ void p1_issue_slots(p1_args<WT> const& a, int lane, p1_runs& q)
+{  // whole-wave loads behind wave-uniform guards (rpos1 is padded)
+  uint32_t const o = 4u * (q.rank + (uint32_t)lane);
+#pragma unroll
+  for (int j = 0; j < TP_NSLOT; ++j) {
+    q.slot[j] = 0;
+    if ((uint32_t)(64 * j) < q.c_all) q.slot[j] = ld32<uint32_t>(a.rpos1, o + 256u * (uint32_t)j);
+  }
+  if (lane == 0) q.slot[0] = q.head_slot;
+  q.slot_tail = q.head_slot;
+  if (q.c_all != 0) q.slot_tail = ld32<uint32_t>(a.rpos1, 4u * (q.rank + q.c_all));
+}
+
+// run totals of the lanes selected by `mine` -> staging area, in run order, starting at ordinal base_c
+template <typename WT>
+__device__ __forceinline__ void p1_stage(WT* stage, p1_runs const& q, WT const (&r)[TP_EPL], WT carry_in, uint32_t base_c, bool mine)
 {
   if (mine && q.f) {  // the run closed by a start at element k ran up to element k - 1
     uint32_t pos = q.ex_c - base_c;
@@ -609,26 +614,50 @@ __device__ __forceinline__ void p1_emit(p1_args<WT> const& a, WT* stage, int lan
       }
     }
   }
+}
+
+// staging area -> partial buffer: lane i takes the i-th staged total (coalesced); ordinals [base_c, base_c + count)
+template <typename WT>
+__device__ __forceinline__ void p1_writeout(p1_args<WT> const& a, WT const* stage, int lane, p1_runs const& q, uint32_t base_c, uint32_t count)
+{
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  uint32_t i = (uint32_t)lane;
-  if (preloaded) {  // base_c == 0: runs `lane` and `64 + lane` have their slots in registers already
-    if (i < count) st32<WT>(a.part, q.slot0 * (uint32_t)sizeof(WT), stage[i]);
-    if (i + 64 < count) st32<WT>(a.part, q.slot1 * (uint32_t)sizeof(WT), stage[i + 64]);
-    i += 128;
+  uint32_t b = 0;
+  if (base_c == 0) {  // the slots of the first 64 * TP_NSLOT runs were requested an item ago
+#pragma unroll
+    for (int j = 0; j < TP_NSLOT; ++j) {
+      if ((uint32_t)(64 * j) < count) {
+        uint32_t const i = (uint32_t)lane + 64u * (uint32_t)j;
+        if (i < count) st32<WT>(a.part, q.slot[j] * (uint32_t)sizeof(WT), stage[i]);
+      }
+    }
+    b = 64 * TP_NSLOT;
   }
-  for (; i < count; i += 64) {
-    uint32_t const n  = base_c + i;
-    uint32_t const sl = n == 0 ? q.head_slot : ld32<uint32_t>(a.rpos1, 4u * (q.rank + n));
-    st32<WT>(a.part, sl * (uint32_t)sizeof(WT), stage[i]);
+  for (; b < count; b += 256) {  // the rest in batches of four loads, then four stores (one wait per batch)
+    uint32_t sl[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      sl[t] = 0;
+      if (b + 64u * (uint32_t)t < count) sl[t] = ld32<uint32_t>(a.rpos1, 4u * (q.rank + base_c + b + 64u * (uint32_t)t + (uint32_t)lane));
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      uint32_t const i = b + 64u * (uint32_t)t + (uint32_t)lane;
+      if (i < count) st32<WT>(a.part, sl[t] * (uint32_t)sizeof(WT), stage[i]);
+    }
   }
-  __builtin_amdgcn_wave_barrier();  // the staging area is reused
+  __builtin_amdgcn_wave_barrier();  // the staging area is reused by the next item
 }
 
-// Part 2: values.  `stage`: this wavefront's TP_STAGE-entry LDS scratch.
+struct p1_pending {  // what compute leaves for the (later) write-out of the same item
+  uint32_t base_c, count;
+};
+
+// Values: LDS gathers, in-lane segmented sum, wave64 segmented scan; run totals staged in LDS.  Returns (lane 63) the total
+// of the run still open at the end of the range -- or of the whole range when no run starts in it.
 template <typename WT, bool WEIGHTED>
-__device__ __forceinline__ void p1_part2(p1_args<WT> const& a, WT const* xs, WT* stage, int lane, p1_regs const& rg, p1_runs const& q)
+__device__ __forceinline__ WT p1_compute(p1_args<WT> const& a, WT const* xs, WT* stage, int lane, p1_regs const& rg, p1_runs const& q, p1_pending& pend)
 {
   uint32_t const e = q.es + (uint32_t)TP_EPL * (uint32_t)lane;
   WT r[TP_EPL];  // values, then in place: running sum since the last run start at or before element k
@@ -647,13 +676,13 @@ __device__ __forceinline__ void p1_part2(p1_args<WT> const& a, WT const* xs, WT*
 #pragma unroll
     for (int k = 0; k < TP_EPL; ++k) r[k] = (uint32_t)k < nval ? r[k] : WT(0);
   }
-  if (q.c_all == 0) {  // no run starts in the wavefront's edges (inside a long run): plain sum into the head slot
+  pend.base_c = 0;
+  pend.count  = 0;
+  if (q.c_all == 0) {  // no run starts in the wavefront's edges (inside a long run): plain sum (goes to the head slot)
     WT t = r[0];
 #pragma unroll
     for (int k = 1; k < TP_EPL; ++k) t += r[k];
-    t = wave_sum_to_lane63(t);
-    if (lane == 63) st32<WT>(a.part, q.head_slot * (uint32_t)sizeof(WT), t);
-    return;
+    return wave_sum_to_lane63(t);
   }
   // in-lane segmented sum: r[k] = v[k] + (run start at k ? 0 : r[k-1]); the select is a bit mask (0 / ~0 from the flag bit)
   uint32_t const nflags = ~q.f;
@@ -667,30 +696,33 @@ __device__ __forceinline__ void p1_part2(p1_args<WT> const& a, WT const* xs, WT*
     }
   }
   WT s       = r[TP_EPL - 1];
-  uint32_t c = q.nf;
+  uint32_t c = __popc(q.f);
   wave_seg_scan(s, c);
   WT const carry_in = dpp_val<0x138, 0xF>(s);  // wave_shr:1: segmented sum up to the previous lane (0 in lane 0; the range starts with an empty carry)
   if (q.c_all <= (uint32_t)TP_STAGE) {
-    p1_emit<WT>(a, stage, lane, q, r, carry_in, 0u, q.c_all, true, true);
-  } else {  // more run totals than the staging area holds: lanes 0-31 first (at most TP_STAGE runs), then lanes 32-63
+    p1_stage<WT>(stage, q, r, carry_in, 0u, true);
+    pend.count = q.c_all;
+  } else {  // more run totals than the staging area holds: lanes 0-31 (at most TP_STAGE runs) are written out right away
     uint32_t const half = (uint32_t)__builtin_amdgcn_readlane((int)c, 31);
-    p1_emit<WT>(a, stage, lane, q, r, carry_in, 0u, half, lane < 32, true);
-    p1_emit<WT>(a, stage, lane, q, r, carry_in, half, q.c_all - half, lane >= 32, false);
+    p1_stage<WT>(stage, q, r, carry_in, 0u, lane < 32);
+    p1_writeout<WT>(a, stage, lane, q, 0u, half);
+    p1_stage<WT>(stage, q, r, carry_in, half, lane >= 32);
+    pend.base_c = half;
+    pend.count  = q.c_all - half;
   }
-  if (lane == 63) {  // the run still open at the end of the range (it may continue in the next wavefront's range: that
-                     // wavefront contributes its part through its own head slot)
-    uint32_t const sl = ld32<uint32_t>(a.rpos1, 4u * (q.rank + q.c_all));
-    st32<WT>(a.part, sl * (uint32_t)sizeof(WT), s);
-  }
+  return s;
 }
 
-template <typename WT, bool WEIGHTED, bool MG, bool DBG = false>
-__global__ void __launch_bounds__(TP_BLOCK, 4 * TP_WG_PER_CU) k_tiled_phase1(p1_args<WT> a)
+struct p1_iter {  // position in this workgroup's item sequence (all fields wave-uniform); item < 0: exhausted
+  int item, end, pos;
+};
+
+template <typename WT, bool WEIGHTED, bool DBG = false>
+__global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
 {
-  long long tA = 0, tT = 0, tB = 0, tW = 0, tc0 = 0, tc1 = 0;  // DBG: cycles in pass A (incl. wait for data) / tile loads / pass B / chunk barrier
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   WT* xs = reinterpret_cast<WT*>(smem);
-  __shared__ int s_chunk[3];
+  __shared__ int s_chunk[4];
   int const tid = threadIdx.x, lane = tid & 63;
   int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   WT* stage = xs + a.T + wave * TP_STAGE;
@@ -698,91 +730,94 @@ __global__ void __launch_bounds__(TP_BLOCK, 4 * TP_WG_PER_CU) k_tiled_phase1(p1_
   if (blockIdx.x == 0 && a.fin.partials) finish_scalars<WT>(a.fin, reinterpret_cast<double*>(smem), tid, TP_BLOCK);
 
   // Work is handed out dynamically in CHUNKS (a few consecutive work items of one source tile; hottest tiles first, the
-  // small cold tiles last), two chunks ahead, so that the first item of the next chunk is already on its way while the
-  // current chunk is processed.  One barrier per chunk; the LDS tile is reloaded only when the source tile changes.
+  // small cold tiles last); chunk ids are fetched three chunks ahead so the item sequence is known two items ahead.
+  //
+  // The loop is software-pipelined around the ONE memory counter of gfx9 (vmcnt counts loads AND stores and retires in
+  // order, and the compiler waits with vmcnt(0) across the loop back edge).  Per item i:
+  //     compute(i)                      LDS gathers + scans; run totals staged in LDS; no global memory use
+  //     -- wait --                      covers data(i+1), slots(i), stores(i-1): all issued a whole item earlier
+  //     counts(i+1); stores(i); request slots(i+1) and data(i+2)
+  // so nothing that was just issued is ever waited for.  (Storing first and waiting at the top of the next item, the
+  // natural order, exposes the store round trip and the prefetch latency once per item: 1.6 -> x ms at RMAT-26.)
   unsigned long long const t_start = wall_clock64();
   int n_tiles = 0;
-  if (tid == 0) { s_chunk[0] = (int)atomicAdd(a.counter, 1u); s_chunk[1] = (int)atomicAdd(a.counter, 1u); }
+  if (tid == 0) { s_chunk[0] = (int)atomicAdd(a.counter, 1u); s_chunk[1] = (int)atomicAdd(a.counter, 1u); s_chunk[2] = (int)atomicAdd(a.counter, 1u); }
   __syncthreads();
+  auto enter = [&](p1_iter& x) {
+    int const cid = s_chunk[x.pos & 3];
+    if (cid >= a.n_chunks) { x.item = -1; } else { x.item = a.chunk_begin[cid]; x.end = a.chunk_begin[cid + 1]; }
+  };
+  auto advance = [&](p1_iter& x) {
+    if (x.item < 0) return;
+    if (++x.item >= x.end) { ++x.pos; enter(x); }
+  };
+  p1_iter I{0, 0, 0};
+  enter(I);
+  if (tid == 0) s_chunk[3] = (int)atomicAdd(a.counter, 1u);  // read only after the next chunk-transition barrier
   int curJ = -1;
-  p1_regs r0, r1;
-  if constexpr (TP_PREFETCH) {
-    int const c0 = s_chunk[0];
-    if (c0 < a.n_chunks) p1_load<WT>(a, a.chunk_begin[c0], wave, lane, r0);
+  p1_regs rA, rB;
+  p1_runs qA, qB;
+  p1_iter Jt = I;
+  if (I.item >= 0) {
+    p1_load<WT>(a, I.item, wave, lane, rA);
+    p1_counts(lane, rA, qA);
+    p1_issue_slots<WT>(a, lane, qA);
+    advance(Jt);
+    if (Jt.item >= 0) p1_load<WT>(a, Jt.item, wave, lane, rB);
   }
-  bool cur_is_r0 = true;
-  for (int it = 0;; ++it) {
-    int const c = s_chunk[it % 3], cn = s_chunk[(it + 1) % 3];
-    if (c >= a.n_chunks) break;
-    if (tid == 0) s_chunk[(it + 2) % 3] = (int)atomicAdd(a.counter, 1u);
-    int item = a.chunk_begin[c];
-    int const item_end  = a.chunk_begin[c + 1];
-    int const next_item = cn < a.n_chunks ? a.chunk_begin[cn] : -1;  // first item of the next chunk
-    auto body = [&](p1_regs const& cur, p1_regs& nxt) {
-      int const J   = a.item_tile[item];
-      int const pre = item + 1 < item_end ? item + 1 : next_item;
-      if constexpr (DBG) tc0 = clock64();
-      if (J != curJ) {  // only at the first item of a chunk: every wavefront has passed the chunk barrier
-        if constexpr (MG) {
-          uint32_t c0 = (uint32_t)J * (uint32_t)a.T;
-          for (int i = tid; i < a.T; i += TP_BLOCK) {
-            uint32_t cc = c0 + (uint32_t)i;
-            xs[i]       = cc < a.ncols ? a.x[(size_t)(cc & a.pmask) * a.chunk + (cc >> a.plog)] * a.alpha : WT(0);
-          }
-        } else {  // x is allocated (and zero-filled) up to nJ * T elements
-          using vec4 = typename std::conditional<sizeof(WT) == 4, float4, double4>::type;
-          vec4 const* src = reinterpret_cast<vec4 const*>(a.x + (size_t)J * a.T);
-          vec4* dst       = reinterpret_cast<vec4*>(xs);
-          int const n4    = a.T / 4;
-          for (int i0 = 0; i0 < n4; i0 += 8 * TP_BLOCK) {  // 8 loads per thread in flight (T <= 65536: two trips at most)
-            vec4 v[8];
+  auto body = [&](p1_regs& cur, p1_runs& qc, p1_regs& nxt, p1_runs& qn) {
+    int const J = a.item_tile[I.item];
+    if (J != curJ) {  // only at the first item of a chunk: every wavefront has passed the chunk-transition barrier
+      // x is allocated (and zero-filled) up to nJ * T elements; indices are clamped instead of guarded so that the loads
+      // stay straight-line (8 in flight per thread)
+      using vec4 = typename std::conditional<sizeof(WT) == 4, float4, double4>::type;
+      vec4 const* src = reinterpret_cast<vec4 const*>(a.x + (size_t)J * a.T);
+      vec4* dst       = reinterpret_cast<vec4*>(xs);
+      int const n4    = a.T / 4;
+      for (int i0 = 0; i0 < n4; i0 += 8 * TP_BLOCK) {
+        vec4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              int i = i0 + j * TP_BLOCK + tid;
-              if (i < n4) v[j] = src[i];
-            }
+        for (int j = 0; j < 8; ++j) v[j] = src[min(i0 + j * TP_BLOCK + tid, n4 - 1)];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              int i = i0 + j * TP_BLOCK + tid;
-              if (i < n4) {
-                v[j].x *= a.alpha; v[j].y *= a.alpha; v[j].z *= a.alpha; v[j].w *= a.alpha;
-                dst[i] = v[j];
-              }
-            }
-          }
+        for (int j = 0; j < 8; ++j) {
+          v[j].x *= a.alpha; v[j].y *= a.alpha; v[j].z *= a.alpha; v[j].w *= a.alpha;
+          dst[min(i0 + j * TP_BLOCK + tid, n4 - 1)] = v[j];  // the clamped duplicates write the same value
         }
-        __syncthreads();
-        curJ = J;
-        ++n_tiles;
       }
-      if constexpr (DBG) { tc1 = clock64(); tT += tc1 - tc0; tc0 = tc1; }
-      p1_runs q;
-      if constexpr (!TP_PREFETCH) p1_load<WT>(a, item, wave, lane, const_cast<p1_regs&>(cur));  // 8 wavefronts per SIMD hide the latency
-      p1_part1<WT>(a, lane, cur, q);
-      if constexpr (DBG) { __builtin_amdgcn_s_waitcnt(0); tc1 = clock64(); tA += tc1 - tc0; tc0 = tc1; }
-      if constexpr (TP_PREFETCH) { if (pre >= 0) p1_load<WT>(a, pre, wave, lane, nxt); }
-      if (q.es < q.ee) p1_part2<WT, WEIGHTED>(a, xs, stage, lane, cur, q);
-      if constexpr (DBG) { tc1 = clock64(); tB += tc1 - tc0; tc0 = tc1; }
-      ++item;
-    };
-    while (item < item_end) {
-      if constexpr (TP_PREFETCH) {
-        if (cur_is_r0) body(r0, r1); else body(r1, r0);
-        cur_is_r0 = !cur_is_r0;
-      } else {
-        body(r0, r0);
-      }
+      __syncthreads();
+      curJ = J;
+      ++n_tiles;
     }
-    if constexpr (DBG) tc0 = clock64();
-    __syncthreads();  // chunk done: the tile may be replaced, s_chunk[(it + 2) % 3] is visible
-    if constexpr (DBG) tW += clock64() - tc0;
+    p1_pending pend;
+    WT tail = WT(0);
+    bool const busy = qc.es < qc.ee;  // wave-uniform; an empty share (tail of a tile) has nothing to compute or store
+    if (busy) tail = p1_compute<WT, WEIGHTED>(a, xs, stage, lane, cur, qc, pend);
+    // ---- wait point: first use of data(i+1) and of slots(i)
+    if (Jt.item >= 0) p1_counts(lane, nxt, qn);
+    if (busy) {
+      if (pend.count) p1_writeout<WT>(a, stage, lane, qc, pend.base_c, pend.count);
+      if (lane == 63) st32<WT>(a.part, qc.slot_tail * (uint32_t)sizeof(WT), tail);  // slot_tail = head slot when no run starts in the range
+    }
+    if (Jt.item >= 0) p1_issue_slots<WT>(a, lane, qn);
+    p1_iter K = Jt;
+    advance(K);
+    if (K.item >= 0) p1_load<WT>(a, K.item, wave, lane, cur);  // `cur` is free: data(i+2)
+    int const old_pos = I.pos;
+    I  = Jt;
+    Jt = K;
+    if (I.item >= 0 && I.pos != old_pos) {  // next item belongs to another chunk: all wavefronts are done with the tile
+      __syncthreads();
+      if (tid == 0) s_chunk[(I.pos + 3) & 3] = (int)atomicAdd(a.counter, 1u);
+    }
+  };
+  while (I.item >= 0) {
+    body(rA, qA, rB, qB);
+    if (I.item < 0) break;
+    body(rB, qB, rA, qA);
   }
   if constexpr (DBG) {
-    if (lane == 0) {
-      unsigned long long* o = a.dbg + ((size_t)blockIdx.x * TP_WAVES + wave) * 6;
-      o[0] = (unsigned long long)(wall_clock64() - t_start); o[1] = (unsigned long long)n_tiles;
-      o[2] = (unsigned long long)tA; o[3] = (unsigned long long)tT; o[4] = (unsigned long long)tB; o[5] = (unsigned long long)tW;
-    }
+    __syncthreads();
+    if (tid == 0) { a.dbg[2 * blockIdx.x] = wall_clock64() - t_start; a.dbg[2 * blockIdx.x + 1] = (unsigned long long)n_tiles; }
   }
 }
 
@@ -943,31 +978,30 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
   if (pending) a.fin = make_fin<WT>(*pending, t.nI);
   size_t const lds = std::max<size_t>(((size_t)t.T + (size_t)TP_WAVES * TP_STAGE) * sizeof(WT), 3 * TP_BLOCK * sizeof(double));
   bool const w     = a.weights != nullptr;
-  static bool attr_done[4] = {false, false, false, false};
+  static bool attr_done[2] = {false, false};
   static int dbg_calls = getenv("CUGRAPH_AMD_TILED_DEBUG") ? 2 : 0;
   auto launch = [&](auto kernel, int slot) {
     if (!attr_done[slot]) { ensure_max_lds(kernel, (int)h.lds_per_block); attr_done[slot] = true; }
     timed_launch tl(h, "pagerank_spmv");
     hipLaunchKernelGGL(kernel, t.n_wg, TP_BLOCK, lds, h.stream, a);
   };
-  if (dbg_calls > 0 && !map.mg && !w && sizeof(WT) == 4) {  // instrumented variant: per-wavefront cycle breakdown to stderr
+  if (dbg_calls > 0 && !w && sizeof(WT) == 4) {  // instrumented variant: per-workgroup wall time / tile loads to stderr
     --dbg_calls;
-    size_t const n = (size_t)t.n_wg * TP_WAVES * 6;
+    size_t const n = (size_t)t.n_wg * 2;
     dvec<unsigned long long> dbg(n);
     a.dbg = dbg.data();
-    ensure_max_lds(k_tiled_phase1<WT, false, false, true>, (int)h.lds_per_block);
-    hipLaunchKernelGGL((k_tiled_phase1<WT, false, false, true>), t.n_wg, TP_BLOCK, lds, h.stream, a);
+    ensure_max_lds(k_tiled_phase1<WT, false, true>, (int)h.lds_per_block);
+    hipLaunchKernelGGL((k_tiled_phase1<WT, false, true>), t.n_wg, TP_BLOCK, lds, h.stream, a);
     std::vector<unsigned long long> d = to_host(h, dbg.data(), n);
-    double sum[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0};
-    for (size_t i = 0; i < n; ++i) { sum[i % 6] += (double)d[i]; mx[i % 6] = std::max(mx[i % 6], (double)d[i]); }
-    double const nw = (double)t.n_wg * TP_WAVES;
-    fprintf(stderr, "[tiled phase1 dbg] %d wgs %d items %d chunks | per wavefront avg (max): wall %.0f (%.0f) x10ns, tiles %.1f, cycles: passA+data wait %.0f (%.0f), "
-            "prefetch issue+tile load %.0f (%.0f), passB %.0f (%.0f), chunk barrier %.0f (%.0f)\n", t.n_wg, t.n_items, t.n_chunks, sum[0] / nw, mx[0], sum[1] / nw,
-            sum[2] / nw, mx[2], sum[3] / nw, mx[3], sum[4] / nw, mx[4], sum[5] / nw, mx[5]);
+    std::vector<unsigned long long> v;
+    double tiles = 0;
+    for (int b = 0; b < t.n_wg; ++b) { v.push_back(d[2 * b]); tiles += (double)d[2 * b + 1]; }
+    std::sort(v.begin(), v.end());
+    fprintf(stderr, "[tiled phase1 dbg] %d workgroups, %d items, %d chunks; wall ticks (100 MHz) min %llu p10 %llu p50 %llu p90 %llu max %llu; tile loads per workgroup %.1f\n",
+            t.n_wg, t.n_items, t.n_chunks, v[0], v[t.n_wg / 10], v[t.n_wg / 2], v[t.n_wg * 9 / 10], v[t.n_wg - 1], tiles / t.n_wg);
     return;
   }
-  if (map.mg) { if (w) launch(k_tiled_phase1<WT, true, true>, 0); else launch(k_tiled_phase1<WT, false, true>, 1); }
-  else        { if (w) launch(k_tiled_phase1<WT, true, false>, 2); else launch(k_tiled_phase1<WT, false, false>, 3); }
+  if (w) launch(k_tiled_phase1<WT, true>, 0); else launch(k_tiled_phase1<WT, false>, 1);
 }
 
 template <typename WT>

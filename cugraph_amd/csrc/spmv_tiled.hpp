@@ -41,24 +41,10 @@ struct pr_scalars {  // device-resident PageRank loop state
 
 constexpr int TP_BLOCK = 1024;               // phase-1 workgroup: 16 wavefronts sharing one LDS tile
 constexpr int TP_WAVES = TP_BLOCK / 64;
-// Two shapes of phase 1 (compile-time; CGA_TILED_OCC2 selects the second):
-//   big tile : one workgroup per CU (tile ~126 KiB), 16 consecutive edges per lane, next item's edge data prefetched in registers
-//   occupancy: two workgroups per CU (tile ~62 KiB, 8 wavefronts per SIMD, <= 64 VGPRs), 8 edges per lane, no register prefetch
-#ifdef CGA_TILED_OCC2
-constexpr int TP_EPL = 8;
-#ifdef CGA_TILED_OCC2_PREFETCH
-constexpr bool TP_PREFETCH = true;
-#else
-constexpr bool TP_PREFETCH = false;
-#endif
-constexpr int TP_WG_PER_CU = 2;
-constexpr int TP_STAGE = 256;                // per-wavefront LDS staging entries (run totals awaiting the coalesced write-out)
-#else
-constexpr int TP_EPL = 16;
-constexpr bool TP_PREFETCH = true;
-constexpr int TP_WG_PER_CU = 1;
-constexpr int TP_STAGE = 512;
-#endif
+constexpr int TP_EPL = 16;                   // consecutive edges per lane per work item (two 16-byte loads)
+constexpr int TP_WG_PER_CU = 1;              // the source tile takes ~126 KiB of the 160 KiB LDS
+constexpr int TP_STAGE = 512;                // per-wavefront LDS staging entries (run totals awaiting the coalesced write-out)
+constexpr int TP_NSLOT = 4;                  // partial slots requested one item ahead per lane (256 runs; the rest in batches)
 constexpr int TP_SUB   = 64 * TP_EPL;        // edges per wavefront per work item (TP_EPL consecutive edges per lane)
 constexpr int TP_WLEN  = TP_SUB;
 constexpr int TP_ITEM  = TP_WLEN * TP_WAVES;  // edges per work item
