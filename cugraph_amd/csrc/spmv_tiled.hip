@@ -386,23 +386,27 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   }
   to_device(h, t.region_off, region_off);
 
-  // ---- phase-1 chunks: up to TP_CHUNK consecutive items of one source tile; handed out dynamically in this order
+  // ---- phase-1 chunks: up to TP_CHUNK consecutive items of one source tile, handed out dynamically LARGEST FIRST
+  // (long chunks keep an LDS tile for many items; the one-item chunks of the cold tiles fill the tail evenly)
   {
     size_t const lds = ((size_t)T + (size_t)TP_WAVES * TP_STAGE) * vsize;
     int const per_cu = std::max<int>(1, std::min<int>(2, (int)((h.lds_per_block - 1024) / (lds + 64))));
-    std::vector<int32_t> begin;
     int const max_wg = h.num_cus * per_cu;
-    int const chunk  = std::max(1, std::min<int>(TP_CHUNK, t.n_items / (max_wg * 8)));  // >= 8 chunks per workgroup when possible
+    int const chunk  = std::max(1, std::min<int>(TP_CHUNK, t.n_items / (max_wg * 4)));  // small graphs: more, shorter chunks
+    std::vector<std::pair<int32_t, int32_t>> ch;  // (first item, items)
     for (int i = 0; i < t.n_items;) {
-      begin.push_back(i);
       int j = i + 1;
       while (j < t.n_items && j - i < chunk && item_tile[j] == item_tile[i]) ++j;
+      ch.push_back({i, j - i});
       i = j;
     }
-    t.n_chunks = (int)begin.size();
-    begin.push_back(t.n_items);
-    t.n_wg = std::max(1, std::min<int>(t.n_chunks, h.num_cus * per_cu));
-    to_device(h, t.chunk_begin, begin);
+    std::stable_sort(ch.begin(), ch.end(), [](auto const& x, auto const& y) { return x.second > y.second; });
+    t.n_chunks = (int)ch.size();
+    std::vector<int32_t> cb;  // [2 * n_chunks]: first item, end item
+    for (auto const& c : ch) { cb.push_back(c.first); cb.push_back(c.first + c.second); }
+    if (cb.empty()) { cb.push_back(0); cb.push_back(0); }
+    t.n_wg = std::max(1, std::min<int>(t.n_chunks, max_wg));
+    to_device(h, t.chunk_begin, cb);
   }
 
   // ---- bound used by the fixed-point accumulation of phase 2
@@ -518,7 +522,7 @@ struct p1_args {
   uint32_t const* rpos1;  // rpos shifted by one entry: slot of run q at [q + 1], padded
   int32_t const* item_tile;
   tiled_wave_t const* waves;
-  int32_t const* chunk_begin;  // [n_chunks + 1] first work item of each chunk (items of a chunk share one source tile)
+  int32_t const* chunk_begin;  // [n_chunks][2] first / end work item of each chunk (items of a chunk share one source tile)
   int n_chunks;
   uint32_t* counter;           // chunk cursor: 0 on entry, reset by phase 2
   int T;
@@ -745,7 +749,7 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
   __syncthreads();
   auto enter = [&](p1_iter& x) {
     int const cid = s_chunk[x.pos & 3];
-    if (cid >= a.n_chunks) { x.item = -1; } else { x.item = a.chunk_begin[cid]; x.end = a.chunk_begin[cid + 1]; }
+    if (cid >= a.n_chunks) { x.item = -1; } else { x.item = a.chunk_begin[2 * cid]; x.end = a.chunk_begin[2 * cid + 1]; }
   };
   auto advance = [&](p1_iter& x) {
     if (x.item < 0) return;

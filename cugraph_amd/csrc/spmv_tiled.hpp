@@ -44,11 +44,11 @@ constexpr int TP_WAVES = TP_BLOCK / 64;
 constexpr int TP_EPL = 16;                   // consecutive edges per lane per work item (two 16-byte loads)
 constexpr int TP_WG_PER_CU = 1;              // the source tile takes ~126 KiB of the 160 KiB LDS
 constexpr int TP_STAGE = 512;                // per-wavefront LDS staging entries (run totals awaiting the coalesced write-out)
-constexpr int TP_NSLOT = 4;                  // partial slots requested one item ahead per lane (256 runs; the rest in batches)
+constexpr int TP_NSLOT = 8;                  // partial slots requested one item ahead per lane (512 runs; the rest in batches of four)
 constexpr int TP_SUB   = 64 * TP_EPL;        // edges per wavefront per work item (TP_EPL consecutive edges per lane)
 constexpr int TP_WLEN  = TP_SUB;
 constexpr int TP_ITEM  = TP_WLEN * TP_WAVES;  // edges per work item
-constexpr int TP_CHUNK = 128 / TP_EPL;       // work items per dynamically scheduled chunk (128 Ki edges: larger chunks reload fewer tiles but balance worse)
+constexpr int TP_CHUNK = 16;                 // max work items per dynamically scheduled chunk (256 Ki edges); chunks are handed out largest first
 constexpr int TP2_BLOCK = 512;               // phase-2 workgroup
 constexpr int TP2_ROWS  = 4096;              // max destination rows per phase-2 tile (64-bit LDS accumulators: 32 KiB)
 
@@ -74,7 +74,7 @@ struct tiled_csc_t {
   dvec<uint32_t> rpos;        // [n_runs + 512] slot of run q at [q + 1] ([0] and the tail are padding)
   dvec<int32_t> item_tile;    // [n_items] source tile of work item
   dvec<tiled_wave_t> waves;   // [n_items * TP_WAVES]
-  dvec<int32_t> chunk_begin;  // [n_chunks + 1] first item of each chunk (<= TP_CHUNK items of one source tile)
+  dvec<int32_t> chunk_begin;  // [n_chunks][2] first / end item of each chunk (<= TP_CHUNK items of one source tile), largest chunks first
   dvec<uint32_t> tile_row0;   // [nI + 1] destination tile boundaries
   dvec<uint32_t> region_off;  // [nI + 2] slot range of region I (multiples of 8); region nI = dummy
   dvec<uint16_t> dstl16;      // [n_slots + pad] tile-local destination of slot
