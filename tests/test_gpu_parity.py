@@ -445,3 +445,109 @@ def test_pagerank_tiled_fp64_weights_and_personalization(cg, handle, orc, tile):
     np.testing.assert_allclose(got, truth, rtol=1e-9)
     truth2, _, _ = orc.pagerank(nv, off, idx, ww, 0.85, 0.0, 15, acc64=True, personalization=(pv, pw), dtype=np.float64)
     np.testing.assert_allclose(by_vertex(v2, pr2)[0], truth2, rtol=1e-9, atol=1e-18)
+
+
+# ------------------------------------------------------------------ full-size checks through size-independent properties
+def _rmat_on_device(cg, handle, scale, weights=None, transposed=False):
+    import torch
+
+    nv, ne = 1 << scale, 16 << scale
+    src, dst = cg.generate_rmat_edgelist(handle, scale, ne)
+    w = None
+    if weights == "unit":
+        w = torch.ones(ne, dtype=torch.float32, device="cuda")
+    elif weights == "int":
+        w = torch.randint(1, 256, (ne,), generator=torch.Generator(device="cuda").manual_seed(7), device="cuda").to(torch.float32)
+    verts = torch.arange(nv, dtype=torch.int32, device="cuda")
+    g = cg.SGGraph(handle, cg.GraphProperties(is_multigraph=True), src, dst, w, store_transposed=transposed, renumber=True, vertices_array=verts)
+    return g, src.long(), dst.long(), w, nv, ne
+
+
+@pytest.mark.parametrize("scale", [22, 24])
+def test_bfs_full_size_properties(cg, handle, scale):
+    """RMAT-22 / RMAT-24 (BASELINE.json config 3): the distance vector is THE BFS solution iff d[s] = 0, no edge skips a level
+    (d[v] <= d[u] + 1 for every edge out of a reached u) and every reached v != s has an in-neighbour one level up; the
+    returned parent must be such an in-neighbour.  Checked for all ~2.7e8 edges on the device, both BFS directions."""
+    import torch
+
+    g, src, dst, _, nv, ne = _rmat_on_device(cg, handle, scale)
+    outdeg = torch.bincount(src, minlength=nv)
+    root = int(torch.nonzero(outdeg > 100)[3])
+    INF = 2147483647
+    res = {}
+    for call in range(2):  # the second call on a directed graph runs direction-optimised (CSC built), the first push-only
+        d, p, v = cg.bfs(handle, g, torch.tensor([root], dtype=torch.int32, device="cuda"), False, 0, True, False)
+        dist = torch.empty(nv, dtype=torch.int64, device="cuda"); dist[v.long()] = d.long()
+        pred = torch.empty(nv, dtype=torch.int64, device="cuda"); pred[v.long()] = p.long()
+        assert int(dist[root]) == 0 and int(pred[root]) == -1
+        du, dv = dist[src], dist[dst]
+        reached_u = du != INF
+        assert bool((dv[reached_u] <= du[reached_u] + 1).all())                       # no edge skips a level (and reaches its head)
+        has_parent = torch.zeros(nv, dtype=torch.bool, device="cuda")
+        has_parent[dst[reached_u & (dv == du + 1)]] = True
+        reached = dist != INF
+        nonroot = reached.clone(); nonroot[root] = False
+        assert bool(has_parent[nonroot].all())                                         # every level is supported from the one above
+        assert bool((pred[~reached] == -1).all()) and bool((pred[nonroot] >= 0).all())
+        assert bool((dist[pred[nonroot]] == dist[nonroot] - 1).all())                  # parents sit one level up ...
+        key = src * nv + dst
+        pk = pred[nonroot] * nv + torch.nonzero(nonroot).flatten()
+        assert bool(torch.isin(pk, key).all())                                         # ... and are joined to their child by an edge
+        res[call] = (dist, pred)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])     # push-only == direction-optimised, bit for bit
+
+
+def test_sssp_full_size_properties(cg, handle):
+    """RMAT-22, integer weights (exact fp32 sums): d is THE shortest-path solution iff d[s] = 0, every edge is relaxed
+    (d[v] <= d[u] + w) and every reached v != s has a tight in-edge; with unit weights it must equal the BFS levels."""
+    import torch
+
+    for kind in ("int", "unit"):
+        g, src, dst, w, nv, ne = _rmat_on_device(cg, handle, 22, weights=kind)
+        outdeg = torch.bincount(src, minlength=nv)
+        root = int(torch.nonzero(outdeg > 100)[5])
+        v, d, p = cg.sssp(handle, g, root, 3.0e38, True, False)
+        dist = torch.empty(nv, dtype=torch.float32, device="cuda"); dist[v.long()] = d
+        pred = torch.empty(nv, dtype=torch.int64, device="cuda"); pred[v.long()] = p.long()
+        FMAX = torch.finfo(torch.float32).max
+        assert float(dist[root]) == 0.0
+        du, dv = dist[src], dist[dst]
+        ru = du != FMAX
+        assert bool((dv[ru] <= du[ru] + w[ru]).all())
+        tight = torch.zeros(nv, dtype=torch.bool, device="cuda")
+        tight[dst[ru & (dv == du + w)]] = True
+        reached = dist != FMAX
+        nonroot = reached.clone(); nonroot[root] = False
+        assert bool(tight[nonroot].all())
+        assert bool((pred[nonroot] >= 0).all()) and bool((dist[pred[nonroot]] < dist[nonroot]).all() or kind == "unit")
+        if kind == "unit":
+            bd, _, bv = cg.bfs(handle, g, torch.tensor([root], dtype=torch.int32, device="cuda"), False, 0, False, False)
+            lev = torch.empty(nv, dtype=torch.int64, device="cuda"); lev[bv.long()] = bd.long()
+            assert torch.equal(lev[reached].to(torch.float32), dist[reached]) and bool((lev[~reached] == 2147483647).all())
+
+
+def test_pagerank_full_size_properties(cg, handle, monkeypatch):
+    """RMAT-22 (BASELINE.json config 2): mass is conserved, two independent kernels (column-tiled two-phase vs single-pass
+    gather) agree to fp32 round-off after 20 iterations, and one more iteration of either reproduces the other's update."""
+    import torch
+
+    g, src, dst, _, nv, ne = _rmat_on_device(cg, handle, 22, transposed=True)
+    out = {}
+    for kern in ("tiled", "flat"):
+        monkeypatch.setenv("CUGRAPH_AMD_PAGERANK_KERNEL", kern)
+        v, pr, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 20, False, fail_on_nonconvergence=False)
+        x = torch.empty(nv, dtype=torch.float32, device="cuda"); x[v.long()] = pr
+        out[kern] = x
+        assert abs(float(x.double().sum()) - 1.0) < 1e-5
+    a, b = out["tiled"], out["flat"]
+    assert float((a - b).abs().max()) <= 1e-8 and float(((a - b).abs() / b).max()) <= 2e-5
+    # one explicit power iteration in fp64 from the 19-iteration state reproduces the 20-iteration state
+    monkeypatch.setenv("CUGRAPH_AMD_PAGERANK_KERNEL", "tiled")
+    v, pr19, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 19, False, fail_on_nonconvergence=False)
+    p19 = torch.empty(nv, dtype=torch.float64, device="cuda"); p19[v.long()] = pr19.double()
+    outw = torch.bincount(src, minlength=nv).double()
+    xs = p19 / torch.where(outw == 0, torch.ones_like(outw), outw)
+    y = torch.zeros(nv, dtype=torch.float64, device="cuda").index_add_(0, dst, xs[src] * 0.85)
+    dangling = p19[outw == 0].sum()
+    expect = y + (0.85 * dangling + 0.15) / nv
+    assert float(((a.double() - expect).abs() / expect).max()) <= 5e-6
