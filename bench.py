@@ -48,6 +48,31 @@ def cpu_baseline(scale: int, iters: int):
                       f"{dt:.2f} s; includes the reference loop's 4 V-length passes per iteration"}
 
 
+def networkx_baseline(scale: int, iters: int):
+    """NetworkX (the CPU library cuGraph's own Python tests compare against, tests/link_analysis/test_pagerank.py) on the
+    same generator's edge list, single process.  nx.pagerank raises after exactly max_iter power iterations when tol = 0,
+    so the timed region is `iters` iterations (plus its conversion to a scipy matrix, which is part of every call)."""
+    try:
+        import networkx as nx
+
+        from oracle import oracle as orc
+    except Exception as e:  # not installed on this box
+        return {"error": repr(e)}
+    ne = 16 << scale
+    s, d = orc.rmat(scale, ne)
+    G = nx.MultiDiGraph()
+    G.add_nodes_from(range(1 << scale))
+    G.add_edges_from(zip(s.tolist(), d.tolist()))
+    t0 = time.perf_counter()
+    try:
+        nx.pagerank(G, alpha=0.85, max_iter=iters, tol=0.0)
+    except nx.PowerIterationFailedConvergence:
+        pass
+    dt = time.perf_counter() - t0
+    return {"value": round(ne * iters / dt / 1e6, 2), "unit": "MTEPS", "cores": 1, "version": nx.__version__,
+            "sample": f"RMAT-{scale} (same generator, seed 0), nx.pagerank alpha=0.85 max_iter={iters} tol=0 on a MultiDiGraph; {dt:.2f} s"}
+
+
 def run_single(args):
     import torch
 
@@ -151,6 +176,7 @@ def main():
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(min(args.cpu_scale, args.scale), 10)
+        out["cpu_baseline"]["networkx"] = networkx_baseline(min(16, args.scale), 10)
     print(json.dumps(out), flush=True)
 
 
