@@ -326,6 +326,17 @@ void radix_sort_u64_u32(handle_t const& h, uint64_t* keys, uint32_t* vals, uint6
 void gather_b32(handle_t const& h, uint32_t const* src, uint32_t const* idx, uint32_t* out, int64_t n);
 void gather_b64(handle_t const& h, uint64_t const* src, uint32_t const* idx, uint64_t* out, int64_t n);
 
+// edge-list preprocessing behind the graph-creation flags (edgelist.hip); ids are EXTERNAL ids in [vmin, vmin + vrange)
+struct edge_list_t {
+  dvec<int32_t> s, d;
+  dev_buf w;         // optional weights (wsize bytes each)
+  size_t wsize{0};
+  int64_t n{0};
+};
+void edgelist_drop_self_loops(handle_t const& h, edge_list_t& el);
+void edgelist_drop_multi_edges(handle_t const& h, edge_list_t& el, int64_t vmin, int64_t vrange);
+void edgelist_symmetrize(handle_t const& h, edge_list_t& el, int64_t vmin, int64_t vrange);
+
 // graph construction (graph.hip)
 void ensure_orientation(handle_t const& h, graph_t& g, bool transposed);
 // external -> internal ids (in place); absent ids become -1

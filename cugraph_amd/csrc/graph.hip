@@ -314,8 +314,6 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
                 CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "weights must be FLOAT32 or FLOAT64");
     CGA_EXPECTS(edge_ids == nullptr && edge_type_ids == nullptr && t0 == nullptr && t1 == nullptr, CUGRAPH_NOT_IMPLEMENTED,
                 "edge ids / edge types / edge times are not on the PageRank/BFS/SSSP path and are not implemented");
-    CGA_EXPECTS(drop_self_loops == FALSE && drop_multi_edges == FALSE && symmetrize == FALSE, CUGRAPH_NOT_IMPLEMENTED,
-                "drop_self_loops / drop_multi_edges / symmetrize are not implemented yet");
     check_view(src, "src"); check_view(dst, "dst"); check_view(weights, "weights"); check_view(vertices, "vertices");
 
     auto g              = std::make_unique<graph_t>();
@@ -331,10 +329,18 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
     size_t const wsize  = weights ? dtype_size(weights->type) : 0;
 
     // inputs are borrowed: work on copies (graph_sg.cpp:98-183)
-    dvec<int32_t> s(ne), d(ne);
+    edge_list_t el;
+    el.n = ne;
+    el.wsize = wsize;
+    el.s.resize_discard(ne > 0 ? ne : 1); el.d.resize_discard(ne > 0 ? ne : 1);
     if (ne > 0) {
-      HIP_TRY(hipMemcpyAsync(s.data(), src->data, ne * 4, hipMemcpyDeviceToDevice, h.stream));
-      HIP_TRY(hipMemcpyAsync(d.data(), dst->data, ne * 4, hipMemcpyDeviceToDevice, h.stream));
+      HIP_TRY(hipMemcpyAsync(el.s.data(), src->data, ne * 4, hipMemcpyDeviceToDevice, h.stream));
+      HIP_TRY(hipMemcpyAsync(el.d.data(), dst->data, ne * 4, hipMemcpyDeviceToDevice, h.stream));
+    }
+    bool const preprocess = drop_self_loops == TRUE || drop_multi_edges == TRUE || symmetrize == TRUE;
+    if (preprocess && weights && ne > 0) {  // the flags rewrite the edge list: the weights need an owned copy too
+      el.w.alloc(ne * wsize);
+      HIP_TRY(hipMemcpyAsync(el.w.ptr, weights->data, ne * wsize, hipMemcpyDeviceToDevice, h.stream));
     }
     int64_t const nvl = vertices ? (int64_t)vertices->size : 0;
 
@@ -347,18 +353,33 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
         minmax_i32(h, p, n, &a, &b);
         if (!any) { vmin = a; vmax = b; any = true; } else { vmin = std::min(vmin, a); vmax = std::max(vmax, b); }
       };
-      upd(s.data(), ne); upd(d.data(), ne);
+      upd(el.s.data(), ne); upd(el.d.data(), ne);
       if (vertices) upd(vertices->as<int32_t>(), nvl);
     }
+
+    if (preprocess && ne > 0) {  // graph_sg.cpp:185-248: self-loops, then multi-edges, then symmetrize
+      int64_t const vrange = (int64_t)vmax - vmin + 1;
+      if (drop_self_loops == TRUE) edgelist_drop_self_loops(h, el);
+      if (drop_multi_edges == TRUE) edgelist_drop_multi_edges(h, el, vmin, vrange);
+      if (symmetrize == TRUE) edgelist_symmetrize(h, el, vmin, vrange);
+      CGA_EXPECTS(el.n < (int64_t)INT32_MAX, CUGRAPH_INVALID_INPUT, "Number of edges won't fit in 32-bit integer, using 32-bit type");
+    }
+    int64_t const ne_in = ne;
+    (void)ne_in;
+    dvec<int32_t>& s = el.s;
+    dvec<int32_t>& d = el.d;
+    void const* wptr = weights ? (preprocess && ne_in > 0 ? el.w.ptr : weights->data) : nullptr;
+    int64_t const ne2 = el.n;
+    g->ne = ne2;
 
     if (renumber == TRUE) {
       int64_t range = vmax >= vmin ? (int64_t)vmax - vmin + 1 : 0;
       CGA_EXPECTS(range <= ((int64_t)1 << 31) - 2, CUGRAPH_NOT_IMPLEMENTED, "external vertex id range too wide for the dense renumbering table");
       dvec<uint32_t> flags(range + 1), rank(range + 1);
       HIP_TRY(hipMemsetAsync(flags.data(), 0, (range + 1) * 4, h.stream));
-      if (ne > 0) {
-        hipLaunchKernelGGL(k_mark, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)s.data(), ne, (int64_t)vmin, flags.data());
-        hipLaunchKernelGGL(k_mark, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)d.data(), ne, (int64_t)vmin, flags.data());
+      if (ne2 > 0) {
+        hipLaunchKernelGGL(k_mark, grid_for(ne2, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)s.data(), ne2, (int64_t)vmin, flags.data());
+        hipLaunchKernelGGL(k_mark, grid_for(ne2, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)d.data(), ne2, (int64_t)vmin, flags.data());
       }
       if (nvl > 0) hipLaunchKernelGGL(k_mark, grid_for(nvl, kBlock, 8192), kBlock, 0, h.stream, vertices->as<int32_t>(), nvl, (int64_t)vmin, flags.data());
       exclusive_scan_u32(h, flags.data(), rank.data(), range + 1);
@@ -370,7 +391,7 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
       dvec<uint32_t> deg(nv > 0 ? nv : 1);
       HIP_TRY(hipMemsetAsync(deg.data(), 0, (nv > 0 ? nv : 1) * 4, h.stream));
       int32_t const* major_ext = store_transposed == TRUE ? d.data() : s.data();
-      if (ne > 0) hipLaunchKernelGGL(k_degree_compact, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, major_ext, ne, (int64_t)vmin, (uint32_t const*)rank.data(), deg.data());
+      if (ne2 > 0) hipLaunchKernelGGL(k_degree_compact, grid_for(ne2, kBlock, 8192), kBlock, 0, h.stream, major_ext, ne2, (int64_t)vmin, (uint32_t const*)rank.data(), deg.data());
       int32_t dmin = 0, dmax = 0;
       if (nv > 0) minmax_i32(h, reinterpret_cast<int32_t const*>(deg.data()), nv, &dmin, &dmax);
       dvec<uint64_t> keys(nv > 0 ? nv : 1), keys_tmp(nv > 0 ? nv : 1);
@@ -385,9 +406,9 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
         hipLaunchKernelGGL(k_compact_ext, grid_for(range, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)flags.data(), (uint32_t const*)rank.data(), range, ext_of_compact.data(), (int64_t)vmin);
         hipLaunchKernelGGL(k_number_map, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, (uint32_t const*)order.data(), (int32_t const*)ext_of_compact.data(), nv, g->number_map.data(), int_of_compact.data());
         hipLaunchKernelGGL(k_ext2int, grid_for(range, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)flags.data(), (uint32_t const*)rank.data(), (int32_t const*)int_of_compact.data(), range, g->ext2int.data());
-        if (ne > 0) {
-          hipLaunchKernelGGL(k_lookup, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, s.data(), ne, (int32_t const*)g->ext2int.data(), (int64_t)vmin, range, nv);
-          hipLaunchKernelGGL(k_lookup, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, d.data(), ne, (int32_t const*)g->ext2int.data(), (int64_t)vmin, range, nv);
+        if (ne2 > 0) {
+          hipLaunchKernelGGL(k_lookup, grid_for(ne2, kBlock, 8192), kBlock, 0, h.stream, s.data(), ne2, (int32_t const*)g->ext2int.data(), (int64_t)vmin, range, nv);
+          hipLaunchKernelGGL(k_lookup, grid_for(ne2, kBlock, 8192), kBlock, 0, h.stream, d.data(), ne2, (int32_t const*)g->ext2int.data(), (int64_t)vmin, range, nv);
         }
       }
       h.sync();
@@ -404,7 +425,7 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
     orientation_t& primary = g->store_transposed ? g->csc : g->csr;
     int32_t const* major   = g->store_transposed ? d.data() : s.data();
     int32_t const* minor   = g->store_transposed ? s.data() : d.data();
-    build_orientation(h, g->nv, ne, major, minor, weights ? weights->data : nullptr, wsize, primary);
+    build_orientation(h, g->nv, ne2, major, minor, wptr, wsize, primary);
     *graph = reinterpret_cast<cugraph_graph_t*>(g.release());
   });
 }

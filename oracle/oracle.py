@@ -217,3 +217,62 @@ def ref_sssp(nv, offsets, indices, weights, source, cutoff=None):
     cut = (FLT_MAX if f32 else DBL_MAX) if cutoff is None else cutoff
     fn(C.c_int64(nv), _p(offsets), _p(indices), _p(weights), _p(dist), _p(pred), C.c_int32(int(source)), fl(cut))
     return dist, pred
+
+
+# ------------------------------------------------------------------------- edge-list preprocessing
+# CPU restatement of the graph-creation flags (cpp/src/c_api/graph_sg.cpp:185-248).  Parity status: UNPINNED -- the
+# reference's C-API tests hold no golden vectors for these flags; the restatement follows the documented semantics
+# (graph_functions.hpp:420-466, 1073-1140) and the operator of symmetrize_edgelist_impl.cuh:60-135.
+def remove_self_loops(src, dst, w=None):
+    keep = src != dst
+    return src[keep], dst[keep], (None if w is None else w[keep])
+
+
+def remove_multi_edges(src, dst, w=None):
+    """One edge per (src, dst); with weights the minimum-weight one (keep_min_value_edge; a valid 'arbitrary' pick too)."""
+    if w is None:
+        order = np.lexsort((dst, src))
+    else:
+        order = np.lexsort((w, dst, src))
+    s, d = src[order], dst[order]
+    first = np.ones(s.size, bool)
+    first[1:] = (s[1:] != s[:-1]) | (d[1:] != d[:-1])
+    return s[first], d[first], (None if w is None else w[order][first])
+
+
+def symmetrize_edgelist(src, dst, w=None):
+    """reciprocal = False: self-loops kept; per unordered pair the lower (src > dst) and upper (src < dst) edges are sorted
+    by weight and paired rank by rank -- matched pairs become one edge with the average weight, unmatched edges keep
+    theirs -- and every resulting edge appears in both directions (symmetrize_edgelist_impl.cuh:78-110, 949-960)."""
+    diag = src == dst
+    ds, dd = src[diag], dst[diag]
+    dw = None if w is None else w[diag]
+    s, d = src[~diag], dst[~diag]
+    ww = None if w is None else w[~diag]
+    hi, lo = np.maximum(s, d), np.minimum(s, d)
+    upper = (s < d).astype(np.int8)
+    order = np.lexsort((upper, lo, hi)) if ww is None else np.lexsort((ww, upper, lo, hi))
+    hi, lo, upper = hi[order], lo[order], upper[order]
+    ww = None if ww is None else ww[order]
+    out_hi, out_lo, out_w = [], [], []
+    n, i = hi.size, 0
+    while i < n:
+        j = i
+        while j < n and hi[j] == hi[i] and lo[j] == lo[i]:
+            j += 1
+        nlo = int((upper[i:j] == 0).sum())
+        nup = (j - i) - nlo
+        for k in range(max(nlo, nup)):
+            out_hi.append(hi[i]); out_lo.append(lo[i])
+            if ww is not None:
+                if k < nlo and k < nup:
+                    out_w.append((ww[i + k] + ww[i + nlo + k]) / ww.dtype.type(2))
+                elif k < nlo:
+                    out_w.append(ww[i + k])
+                else:
+                    out_w.append(ww[i + nlo + k])
+        i = j
+    oh, ol = np.array(out_hi, src.dtype), np.array(out_lo, src.dtype)
+    rs = np.concatenate([oh, ol, ds]); rd = np.concatenate([ol, oh, dd])
+    rw = None if w is None else np.concatenate([np.array(out_w, w.dtype), np.array(out_w, w.dtype), dw])
+    return rs, rd, rw

@@ -203,7 +203,7 @@ def test_graph_creation_errors(cg, handle):
     with pytest.raises(ValueError):  # INT64 graphs: unsupported type combination in this build
         cg.SGGraph(handle, props, T([0, 1], np.int64), T([1, 2], np.int64))
     with pytest.raises(NotImplementedError):
-        cg.SGGraph(handle, props, T([0, 1], np.int32), T([1, 2], np.int32), drop_self_loops=True)
+        cg.SGGraph(handle, props, T([0, 1], np.int32), T([1, 2], np.int32), edge_id_array=T([0, 1], np.int32))
     g = cg.SGGraph(handle, props, T([0, 1], np.int32), T([1, 2], np.int32))  # unweighted
     with pytest.raises(ValueError, match="weighted"):
         cg.sssp(handle, g, 0, 1e30, True, False)
@@ -551,3 +551,43 @@ def test_pagerank_full_size_properties(cg, handle, monkeypatch):
     dangling = p19[outw == 0].sum()
     expect = y + (0.85 * dangling + 0.15) / nv
     assert float(((a.double() - expect).abs() / expect).max()) <= 5e-6
+
+
+@pytest.mark.parametrize("flags", [dict(drop_self_loops=True), dict(drop_multi_edges=True), dict(symmetrize=True),
+                                   dict(drop_self_loops=True, drop_multi_edges=True, symmetrize=True)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_graph_creation_flags(cg, handle, orc, flags, weighted):
+    """drop_self_loops / drop_multi_edges / symmetrize (graph_sg.cpp:185-248): the graph built with the flags must behave
+    exactly like a graph built from the oracle's preprocessed edge list -- same number of edges, same PageRank, same BFS."""
+    from cugraph_amd import _capi
+
+    rng = np.random.default_rng(5)
+    nv, ne = 300, 6000                                     # dense enough for many multi-edges, reciprocal pairs and self-loops
+    s = rng.integers(0, nv, ne).astype(np.int32)
+    d = rng.integers(0, nv, ne).astype(np.int32)
+    d[:200] = s[:200]                                      # self-loops
+    w = rng.integers(1, 9, ne).astype(np.float32) if weighted else None
+    es, ed, ew = s, d, w
+    if flags.get("drop_self_loops"):
+        es, ed, ew = orc.remove_self_loops(es, ed, ew)
+    if flags.get("drop_multi_edges"):
+        es, ed, ew = orc.remove_multi_edges(es, ed, ew)
+    if flags.get("symmetrize"):
+        es, ed, ew = orc.symmetrize_edgelist(es, ed, ew)
+    props = cg.GraphProperties(is_symmetric=bool(flags.get("symmetrize")), is_multigraph=not flags.get("drop_multi_edges"))
+    g = cg.SGGraph(handle, props, T(s, np.int32), T(d, np.int32), None if w is None else T(w, np.float32), store_transposed=True,
+                   renumber=True, vertices_array=T(np.arange(nv), np.int32), **flags)
+    assert _capi.lib().cugraph_amd_graph_num_edges(g.c_graph_ptr) == es.size
+    v, pr, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 30, False, fail_on_nonconvergence=False)
+    off, idx, ww = orc.coo_to_cs(nv, ed, es, ew)
+    truth, _, _ = orc.pagerank(nv, off, idx, ww, 0.85, 0.0, 30, acc64=True)
+    np.testing.assert_allclose(by_vertex(v, pr)[0], truth, rtol=3e-5)
+    coff, cidx, _ = orc.coo_to_cs(nv, es, ed)
+    dist, _, bv = cg.bfs(handle, g, T([int(es[0])], np.int32), False, 0, False, False)
+    od, _ = orc.bfs(nv, coff, cidx, [int(es[0])])
+    assert np.array_equal(by_vertex(bv, dist)[0], od)
+
+
+def test_symmetrize_needs_symmetric_property(cg, handle):
+    with pytest.raises(Exception):
+        cg.SGGraph(handle, cg.GraphProperties(is_symmetric=False), T([0, 1], np.int32), T([1, 2], np.int32), None, symmetrize=True)

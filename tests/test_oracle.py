@@ -179,3 +179,25 @@ def test_unit_weight_sssp_equals_bfs(orc):
     reach = dist != orc.INT32_MAX
     assert np.array_equal(sd[reach], dist[reach].astype(np.float32))
     assert np.all(sd[~reach] == orc.FLT_MAX)
+
+
+def test_edge_list_flags_restatement(orc):
+    """Hand-checked cases of the three graph-creation flags (reference semantics: graph_functions.hpp:420-466, 1073-1140;
+    symmetrize_edgelist_impl.cuh:78-110)."""
+    s = np.array([0, 1, 1, 2, 2, 2, 3, 3, 0], np.int32)
+    d = np.array([1, 0, 0, 2, 1, 1, 3, 0, 3], np.int32)
+    w = np.array([1.0, 3.0, 5.0, 9.0, 2.0, 4.0, 7.0, 6.0, 8.0], np.float32)
+    a, b, c = orc.remove_self_loops(s, d, w)
+    assert a.tolist() == [0, 1, 1, 2, 2, 3, 0] and c.tolist() == [1.0, 3.0, 5.0, 2.0, 4.0, 6.0, 8.0]
+    a, b, c = orc.remove_multi_edges(s, d, w)  # (1,0) x2 -> 3.0, (2,1) x2 -> 2.0
+    assert list(zip(a.tolist(), b.tolist(), c.tolist())) == [(0, 1, 1.0), (0, 3, 8.0), (1, 0, 3.0), (2, 1, 2.0), (2, 2, 9.0), (3, 0, 6.0), (3, 3, 7.0)]
+    a, b, c = orc.symmetrize_edgelist(s, d, w)
+    und = sorted((int(x), int(y), float(z)) for x, y, z in zip(a, b, c) if x > y)
+    # pair {1,0}: lower (1,0) w 3,5 ; upper (0,1) w 1 -> (3+1)/2 = 2 and 5.   pair {2,1}: lower 2,4.   pair {3,0}: lower 6, upper 8 -> 7
+    assert und == [(1, 0, 2.0), (1, 0, 5.0), (2, 1, 2.0), (2, 1, 4.0), (3, 0, 7.0)]
+    mirrored = sorted((int(y), int(x), float(z)) for x, y, z in zip(a, b, c) if x < y)
+    assert mirrored == und                                     # every edge in both directions
+    loops = sorted((int(x), float(z)) for x, y, z in zip(a, b, c) if x == y)
+    assert loops == [(2, 9.0), (3, 7.0)]                       # self-loops kept once
+    a, b, c = orc.symmetrize_edgelist(s, d)                    # unweighted: multiplicity max(#lower, #upper)
+    assert sorted(zip(a.tolist(), b.tolist())).count((1, 0)) == 2 and sorted(zip(a.tolist(), b.tolist())).count((0, 1)) == 2
