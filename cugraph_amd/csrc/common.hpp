@@ -336,6 +336,10 @@ struct edge_list_t {
 void edgelist_drop_self_loops(handle_t const& h, edge_list_t& el);
 void edgelist_drop_multi_edges(handle_t const& h, edge_list_t& el, int64_t vmin, int64_t vrange);
 void edgelist_symmetrize(handle_t const& h, edge_list_t& el, int64_t vmin, int64_t vrange);
+// do_expensive_check helpers (create_graph_from_edgelist_impl.cuh:72-126, 261-333)
+bool edgelist_is_symmetric(handle_t const& h, edge_list_t const& el, int64_t vmin, int64_t vrange);
+bool edgelist_has_parallel_edges(handle_t const& h, edge_list_t const& el, int64_t vmin, int64_t vrange);
+bool vertex_list_has_duplicates(handle_t const& h, int32_t const* v, int64_t n, int64_t vmin, int64_t vrange);
 
 // graph construction (graph.hip)
 void ensure_orientation(handle_t const& h, graph_t& g, bool transposed);

@@ -323,6 +323,87 @@ void symmetrize_t(handle_t const& h, edge_list_t& el, int64_t vmin, int64_t vran
 
 }  // namespace
 
+namespace {
+
+__global__ void k_directed_keys(int32_t const* s, int32_t const* d, int64_t n, int64_t vmin, uint64_t* fwd, uint64_t* rev)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t const stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint64_t const a = (uint64_t)((int64_t)s[i] - vmin), b = (uint64_t)((int64_t)d[i] - vmin);
+    fwd[i] = (a << 32) | b;
+    if (rev) rev[i] = (b << 32) | a;
+  }
+}
+__global__ void k_vertex_keys(int32_t const* v, int64_t n, int64_t vmin, uint64_t* keys)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t const stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) keys[i] = (uint64_t)((int64_t)v[i] - vmin);
+}
+// *flag = 1 if a[i] != b[i] anywhere (b != nullptr) or a[i] == a[i - 1] anywhere (b == nullptr)
+__global__ void k_any_mismatch(uint64_t const* a, uint64_t const* b, int64_t n, uint32_t* flag)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t const stride = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (; i < n; i += stride) bad |= b ? a[i] != b[i] : (i > 0 && a[i] == a[i - 1]);
+  if (bad) *flag = 1u;  // same value from every writer
+}
+
+void sort_keys(handle_t const& h, dvec<uint64_t>& keys, int64_t n, int lo_bits, int hi_bits)
+{
+  dvec<uint64_t> keys_tmp(n);
+  dvec<uint32_t> idx(n), idx_tmp(n);
+  radix_sort_u64_u32(h, keys.data(), idx.data(), keys_tmp.data(), idx_tmp.data(), n, 0, lo_bits);
+  if (hi_bits > 0) radix_sort_u64_u32(h, keys.data(), idx.data(), keys_tmp.data(), idx_tmp.data(), n, 32, 32 + hi_bits);
+}
+
+bool any_mismatch(handle_t const& h, uint64_t const* a, uint64_t const* b, int64_t n)
+{
+  dvec<uint32_t> flag(1);
+  HIP_TRY(hipMemsetAsync(flag.data(), 0, sizeof(uint32_t), h.stream));
+  hipLaunchKernelGGL(k_any_mismatch, grid_for(n, kBlock, 8192), kBlock, 0, h.stream, a, b, n, flag.data());
+  uint32_t f = 0;
+  h.read_back(&f, flag.data(), 1);
+  return f != 0;
+}
+
+}  // namespace
+
+// do_expensive_check (create_graph_from_edgelist_impl.cuh:261-333): the edge multiset equals its transpose
+bool edgelist_is_symmetric(handle_t const& h, edge_list_t const& el, int64_t vmin, int64_t vrange)
+{
+  int64_t const n = el.n;
+  if (n == 0) return true;
+  int const vb = bits_of(vrange > 0 ? (uint64_t)(vrange - 1) : 0);
+  dvec<uint64_t> fwd(n), rev(n);
+  hipLaunchKernelGGL(k_directed_keys, grid_for(n, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)el.s.data(), (int32_t const*)el.d.data(), n, vmin, fwd.data(), rev.data());
+  sort_keys(h, fwd, n, vb, vb);
+  sort_keys(h, rev, n, vb, vb);
+  return !any_mismatch(h, fwd.data(), rev.data(), n);
+}
+
+bool edgelist_has_parallel_edges(handle_t const& h, edge_list_t const& el, int64_t vmin, int64_t vrange)
+{
+  int64_t const n = el.n;
+  if (n <= 1) return false;
+  int const vb = bits_of(vrange > 0 ? (uint64_t)(vrange - 1) : 0);
+  dvec<uint64_t> fwd(n);
+  hipLaunchKernelGGL(k_directed_keys, grid_for(n, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)el.s.data(), (int32_t const*)el.d.data(), n, vmin, fwd.data(), (uint64_t*)nullptr);
+  sort_keys(h, fwd, n, vb, vb);
+  return any_mismatch(h, fwd.data(), nullptr, n);
+}
+
+bool vertex_list_has_duplicates(handle_t const& h, int32_t const* v, int64_t n, int64_t vmin, int64_t vrange)
+{
+  if (n <= 1) return false;
+  dvec<uint64_t> keys(n);
+  hipLaunchKernelGGL(k_vertex_keys, grid_for(n, kBlock, 8192), kBlock, 0, h.stream, v, n, vmin, keys.data());
+  sort_keys(h, keys, n, bits_of(vrange > 0 ? (uint64_t)(vrange - 1) : 0), 0);
+  return any_mismatch(h, keys.data(), nullptr, n);
+}
+
 void edgelist_drop_self_loops(handle_t const& h, edge_list_t& el)
 {
   int64_t const n = el.n;

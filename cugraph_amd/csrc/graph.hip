@@ -285,7 +285,7 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
                                device_array_view_t const* edge_ids, device_array_view_t const* edge_type_ids,
                                device_array_view_t const* t0, device_array_view_t const* t1, bool_t store_transposed,
                                bool_t renumber, bool_t drop_self_loops, bool_t drop_multi_edges, bool_t symmetrize,
-                               cugraph_graph_t** graph, cugraph_error_t** error)
+                               bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error)
 {
   if (graph) *graph = nullptr;
   return guarded(error, [&] {
@@ -365,7 +365,25 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
       CGA_EXPECTS(el.n < (int64_t)INT32_MAX, CUGRAPH_INVALID_INPUT, "Number of edges won't fit in 32-bit integer, using 32-bit type");
     }
     int64_t const ne_in = ne;
-    (void)ne_in;
+    if (do_expensive_check == TRUE) {  // create_graph_from_edgelist_impl.cuh:72-126, 1466-1494
+      int64_t const vrange = vmax >= vmin ? (int64_t)vmax - vmin + 1 : 0;
+      if (vertices && nvl > 0) {
+        CGA_EXPECTS(!vertex_list_has_duplicates(h, vertices->as<int32_t>(), nvl, vmin, vrange), CUGRAPH_INVALID_INPUT,
+                    "Invalid input argument: vertices should not have duplicates.");
+        if (renumber != TRUE) {
+          int32_t a = 0, b = -1;
+          minmax_i32(h, vertices->as<int32_t>(), nvl, &a, &b);
+          CGA_EXPECTS(a == 0 && (int64_t)b == nvl - 1, CUGRAPH_INVALID_INPUT,
+                      "Invalid input argument: vertex IDs should be consecutive integers starting from 0 if renumber is false.");
+        }
+      }
+      if (properties->is_symmetric == TRUE)
+        CGA_EXPECTS(edgelist_is_symmetric(h, el, vmin, vrange), CUGRAPH_INVALID_INPUT,
+                    "Invalid input arguments: graph_properties.is_symmetric is true but the input edge list is not symmetric.");
+      if (properties->is_multigraph != TRUE)
+        CGA_EXPECTS(!edgelist_has_parallel_edges(h, el, vmin, vrange), CUGRAPH_INVALID_INPUT,
+                    "Invalid input arguments: graph_properties.is_multigraph is false but the input edge list has parallel edges.");
+    }
     dvec<int32_t>& s = el.s;
     dvec<int32_t>& d = el.d;
     void const* wptr = weights ? (preprocess && ne_in > 0 ? el.w.ptr : weights->data) : nullptr;
@@ -471,10 +489,10 @@ extern "C" cugraph_error_code_t cugraph_graph_create_sg(
   const cugraph_type_erased_device_array_view_t* dst, const cugraph_type_erased_device_array_view_t* weights,
   const cugraph_type_erased_device_array_view_t* edge_ids, const cugraph_type_erased_device_array_view_t* edge_type_ids,
   bool_t store_transposed, bool_t renumber, bool_t drop_self_loops, bool_t drop_multi_edges, bool_t symmetrize,
-  bool_t /*do_expensive_check*/, cugraph_graph_t** graph, cugraph_error_t** error)
+  bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error)
 {
   return create_sg(handle, properties, V(vertices), V(src), V(dst), V(weights), V(edge_ids), V(edge_type_ids), nullptr, nullptr,
-                   store_transposed, renumber, drop_self_loops, drop_multi_edges, symmetrize, graph, error);
+                   store_transposed, renumber, drop_self_loops, drop_multi_edges, symmetrize, do_expensive_check, graph, error);
 }
 
 extern "C" cugraph_error_code_t cugraph_graph_create_with_times_sg(
@@ -484,12 +502,12 @@ extern "C" cugraph_error_code_t cugraph_graph_create_with_times_sg(
   const cugraph_type_erased_device_array_view_t* edge_ids, const cugraph_type_erased_device_array_view_t* edge_type_ids,
   const cugraph_type_erased_device_array_view_t* edge_start_time_ids,
   const cugraph_type_erased_device_array_view_t* edge_end_time_ids, bool_t store_transposed, bool_t renumber,
-  bool_t drop_self_loops, bool_t drop_multi_edges, bool_t symmetrize, bool_t /*do_expensive_check*/,
+  bool_t drop_self_loops, bool_t drop_multi_edges, bool_t symmetrize, bool_t do_expensive_check,
   cugraph_graph_t** graph, cugraph_error_t** error)
 {
   return create_sg(handle, properties, V(vertices), V(src), V(dst), V(weights), V(edge_ids), V(edge_type_ids),
                    V(edge_start_time_ids), V(edge_end_time_ids), store_transposed, renumber, drop_self_loops,
-                   drop_multi_edges, symmetrize, graph, error);
+                   drop_multi_edges, symmetrize, do_expensive_check, graph, error);
 }
 
 extern "C" cugraph_error_code_t cugraph_graph_create_sg_from_csr(
@@ -531,8 +549,7 @@ extern "C" cugraph_error_code_t cugraph_graph_create_sg_from_csr(
   });
   if (rc != CUGRAPH_SUCCESS) return rc;
   return create_sg(handle, properties, &verts_view, &rows_view, V(indices), V(weights), V(edge_ids), V(edge_type_ids), nullptr,
-                   nullptr, store_transposed, renumber, FALSE, FALSE, symmetrize, graph, error);
-  (void)do_expensive_check;
+                   nullptr, store_transposed, renumber, FALSE, FALSE, symmetrize, do_expensive_check, graph, error);
 }
 
 extern "C" void cugraph_graph_free(cugraph_graph_t* graph) { delete reinterpret_cast<graph_t*>(graph); }

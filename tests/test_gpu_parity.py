@@ -591,3 +591,39 @@ def test_graph_creation_flags(cg, handle, orc, flags, weighted):
 def test_symmetrize_needs_symmetric_property(cg, handle):
     with pytest.raises(Exception):
         cg.SGGraph(handle, cg.GraphProperties(is_symmetric=False), T([0, 1], np.int32), T([1, 2], np.int32), None, symmetrize=True)
+
+
+def test_graph_creation_expensive_check(cg, handle):
+    """do_expensive_check = TRUE: cpp/tests/c_api/create_graph_test.c:435-535 (symmetric property on an asymmetric edge
+    list must fail) and the other checks of create_graph_from_edgelist_impl.cuh:72-126, 1466-1494."""
+    src = T([0, 1, 1, 2, 2, 2, 3, 4], np.int32)
+    dst = T([1, 3, 4, 0, 1, 3, 5, 5], np.int32)
+    wgt = T([0.1, 2.1, 1.1, 5.1, 3.1, 4.1, 7.2, 3.2], np.float32)
+    sym = cg.GraphProperties(is_symmetric=True, is_multigraph=False)
+    with pytest.raises(ValueError, match="not symmetric"):
+        cg.SGGraph(handle, sym, src, dst, wgt, do_expensive_check=True)
+    cg.SGGraph(handle, sym, src, dst, wgt, do_expensive_check=False)  # unchecked, as in the reference
+    cg.SGGraph(handle, sym, src, dst, wgt, symmetrize=True, do_expensive_check=True)  # symmetrised first, then checked
+    import torch
+    s2, d2 = torch.cat([src, dst]), torch.cat([dst, src])
+    cg.SGGraph(handle, sym, s2, d2, torch.cat([wgt, wgt]), renumber=True, do_expensive_check=True)
+    # a symmetric multiset needs equal multiplicities in both directions
+    with pytest.raises(ValueError, match="not symmetric"):
+        cg.SGGraph(handle, cg.GraphProperties(is_symmetric=True, is_multigraph=True), T([0, 0, 1], np.int32), T([1, 1, 0], np.int32),
+                   do_expensive_check=True)
+    plain = cg.GraphProperties(is_symmetric=False, is_multigraph=False)
+    with pytest.raises(ValueError, match="parallel edges"):
+        cg.SGGraph(handle, plain, T([0, 0, 1], np.int32), T([1, 1, 2], np.int32), do_expensive_check=True)
+    cg.SGGraph(handle, cg.GraphProperties(is_symmetric=False, is_multigraph=True), T([0, 0, 1], np.int32), T([1, 1, 2], np.int32),
+               do_expensive_check=True)
+    cg.SGGraph(handle, plain, T([0, 0, 1], np.int32), T([1, 1, 2], np.int32), drop_multi_edges=True, do_expensive_check=True)
+    with pytest.raises(ValueError, match="duplicates"):
+        cg.SGGraph(handle, plain, T([0, 1], np.int32), T([1, 2], np.int32), vertices_array=T([0, 1, 2, 2], np.int32),
+                   do_expensive_check=True)
+    with pytest.raises(ValueError, match="consecutive"):
+        cg.SGGraph(handle, plain, T([0, 1], np.int32), T([1, 2], np.int32), vertices_array=T([0, 1, 2, 4], np.int32),
+                   do_expensive_check=True)
+    cg.SGGraph(handle, plain, T([0, 1], np.int32), T([1, 2], np.int32), vertices_array=T([3, 1, 2, 0], np.int32),
+               do_expensive_check=True)
+    cg.SGGraph(handle, plain, T([10, 11], np.int32), T([11, 12], np.int32), vertices_array=T([10, 11, 12, 40], np.int32), renumber=True,
+               do_expensive_check=True)
