@@ -114,7 +114,7 @@ __global__ void k_run_keys(uint32_t const* run_dst, int64_t n_runs, uint32_t con
 __global__ void k_wave_desc(int32_t const* item_tile, uint32_t const* item_end, int n_items,
                             uint32_t const* tile_off, uint32_t const* tile_off_pad, uint32_t const* flag32, uint32_t const* ord,
                             uint32_t const* run_dst, uint32_t const* tile_row0, int nI, int64_t n_runs, tiled_wave_t* waves,
-                            uint64_t* keys, uint32_t* vals)
+                            uint32_t* call, uint64_t* keys, uint32_t* vals)
 {
   int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (idx >= (int64_t)n_items * TP_WAVES) return;
@@ -123,6 +123,7 @@ __global__ void k_wave_desc(int32_t const* item_tile, uint32_t const* item_end, 
   uint32_t end = item_end[item];
   uint64_t es64 = (uint64_t)item * TP_ITEM + (uint64_t)w * TP_WLEN;
   tiled_wave_t d{0, 0, 0, 0};
+  uint32_t c_all = 0;
   uint64_t key = (uint64_t)nI;  // no head: dummy region
   if (es64 < end) {
     uint32_t es = (uint32_t)es64;
@@ -130,11 +131,72 @@ __global__ void k_wave_desc(int32_t const* item_tile, uint32_t const* item_end, 
     d.ee        = (uint32_t)min((uint64_t)end, es64 + TP_WLEN);
     uint32_t k  = tile_off[J] + (es - tile_off_pad[J]);
     d.rank      = ord[k];
+    c_all       = ord[k + (d.ee - es)] - d.rank;  // run starts inside [es, ee)
     if (!flag32[k]) key = tile_of_row(tile_row0, nI, run_dst[d.rank - 1]);  // the run open at es is run (rank - 1)
   }
   waves[idx]          = d;
+  call[idx]           = c_all;
   keys[n_runs + idx] = key;
   vals[n_runs + idx] = (uint32_t)(n_runs + idx);
+}
+
+// block starts: run q opens a new slot block when its slot does not continue the previous run's (rpos: run q at [q + 1])
+__global__ void k_block_flags(uint32_t const* rpos, int64_t n_runs, uint32_t* flag)
+{
+  int64_t q      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; q < n_runs; q += stride) flag[q] = (q == 0 || rpos[q + 1] != rpos[q] + 1u) ? 1u : 0u;
+}
+
+__global__ void k_block_delta(uint32_t const* rpos, uint32_t const* flag, uint32_t const* bidx, int64_t n_runs, uint32_t* delta1)
+{
+  int64_t q      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; q < n_runs; q += stride)
+    if (flag[q]) delta1[bidx[q] + 1] = rpos[q + 1] - (uint32_t)q;  // modulo 2^32
+}
+
+__global__ void k_pack_flags(uint32_t const* flag, int64_t n_runs, uint32_t* gbits, int64_t n_words)
+{
+  int64_t w      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; w < n_words; w += stride) {
+    uint32_t word = 0;
+    for (int b = 0; b < 32; ++b) {
+      int64_t const q = 32 * w + b;
+      if (q < n_runs && flag[q]) word |= 1u << b;
+    }
+    gbits[w] = word;
+  }
+}
+
+// the per-wavefront records phase 1 reads (layout: spmv_tiled.hpp)
+__global__ void k_wave_records(tiled_wave_t const* waves, uint32_t const* call, uint32_t const* rpos, uint32_t const* bidx, uint32_t const* gbits,
+                               int64_t n_waves, uint32_t* rec)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n_waves * TP_REC_DWORDS; i += stride) {
+    int64_t const w     = i / TP_REC_DWORDS;
+    int const L         = (int)(i % TP_REC_DWORDS);
+    tiled_wave_t const d = waves[w];
+    uint32_t const c    = call[w];
+    uint32_t v          = 0;
+    if (L < 32) {
+      uint32_t const t0 = 32u * (uint32_t)L;
+      if (t0 < c) {
+        uint64_t const r0 = (uint64_t)d.rank + t0;
+        uint64_t const two = ((uint64_t)gbits[(r0 >> 5) + 1] << 32) | gbits[r0 >> 5];
+        v = (uint32_t)(two >> (r0 & 31));
+        if (c - t0 < 32u) v &= (1u << (c - t0)) - 1u;
+      }
+    } else if (L == TP_REC_NVAL) v = d.ee - d.es;
+    else if (L == TP_REC_RANK) v = d.rank;
+    else if (L == TP_REC_HEAD) v = d.head_slot;
+    else if (L == TP_REC_TAIL) v = c ? rpos[d.rank + c] : d.head_slot;
+    else if (L == TP_REC_BLK) v = bidx[d.rank];
+    rec[i] = v;
+  }
 }
 
 __global__ void k_assign_slots(uint64_t const* keys, uint32_t const* vals, int64_t n, int64_t n_runs, uint32_t const* shift,
@@ -340,7 +402,10 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   t.n_items = (int)item_tile.size();
   int64_t const n_waves = (int64_t)t.n_items * TP_WAVES;
   to_device(h, t.item_tile, item_tile);
-  t.waves.resize_discard(n_waves > 0 ? n_waves : 1);
+  dvec<tiled_wave_t> waves(n_waves > 0 ? n_waves : 1);
+  dvec<uint32_t> call(n_waves > 0 ? n_waves : 1);  // run starts inside each wavefront's range
+  t.wrec.resize_discard((size_t)(n_waves > 0 ? n_waves : 1) * TP_REC_DWORDS);
+  HIP_TRY(hipMemsetAsync(t.wrec.data(), 0, (size_t)(n_waves > 0 ? n_waves : 1) * TP_REC_DWORDS * sizeof(uint32_t), h.stream));
 
   // ---- slots: runs and wave heads ordered by (destination tile, source tile, destination)
   int64_t const n_el = t.n_runs + n_waves;
@@ -355,7 +420,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     hipLaunchKernelGGL(k_wave_desc, grid_for(n_waves, kBlock), kBlock, 0, h.stream, (int32_t const*)t.item_tile.data(),
                        (uint32_t const*)d_item_end.data(), t.n_items, (uint32_t const*)d_tile_off.data(), (uint32_t const*)d_tile_off_pad.data(),
                        (uint32_t const*)flag32.data(), (uint32_t const*)ord.data(), (uint32_t const*)run_dst.data(), (uint32_t const*)t.tile_row0.data(), t.nI,
-                       t.n_runs, t.waves.data(), keys.data(), vals.data());
+                       t.n_runs, waves.data(), call.data(), keys.data(), vals.data());
     radix_sort_u64_u32(h, keys.data(), vals.data(), keys_tmp.data(), vals_tmp.data(), n_el, 0, bits_for_u((uint64_t)t.nI));
     std::vector<uint32_t> first = key_starts(h, keys.data(), n_el, (int64_t)t.nI + 1);  // regions 0..nI (nI = dummy)
     std::vector<uint32_t> shift(t.nI + 1);
@@ -368,21 +433,44 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     t.dstl16.resize_discard(spad);
     HIP_TRY(hipMemsetAsync(t.dstl16.data(), 0, spad * sizeof(uint16_t), h.stream));
     CGA_EXPECTS((uint64_t)t.ne_pad * 2 + 65536 < ((uint64_t)1 << 32) && ((uint64_t)t.n_runs + 512) * 4 < ((uint64_t)1 << 32) &&
-                  ((uint64_t)t.n_slots + 64) * vsize < ((uint64_t)1 << 32),
+                  ((uint64_t)t.n_slots + 64) * vsize < ((uint64_t)1 << 32) && (uint64_t)(n_waves + 2) * TP_REC_DWORDS * 4 < ((uint64_t)1 << 32),
                 CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: an array exceeds the 32-bit byte-offset addressing of phase 1");
-    t.rpos.resize_discard((size_t)t.n_runs + 512);  // [0] = dummy (the "run" before run 0), run q at [q + 1], zero padding behind
-    HIP_TRY(hipMemsetAsync(t.rpos.data(), 0, ((size_t)t.n_runs + 512) * sizeof(uint32_t), h.stream));
+    // slot of every run (build-time only): [0] = dummy (the "run" before run 0), run q at [q + 1], zero padding behind
+    dvec<uint32_t> rpos((size_t)t.n_runs + 512);
+    HIP_TRY(hipMemsetAsync(rpos.data(), 0, ((size_t)t.n_runs + 512) * sizeof(uint32_t), h.stream));
     dvec<uint32_t> d_shift;
     to_device(h, d_shift, shift);
     hipLaunchKernelGGL(k_assign_slots, grid_for(n_el, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), n_el,
-                       t.n_runs, (uint32_t const*)d_shift.data(), (uint32_t const*)run_dst.data(), (uint32_t const*)t.tile_row0.data(), t.nI, t.rpos.data(),
-                       t.waves.data(), t.dstl16.data());
+                       t.n_runs, (uint32_t const*)d_shift.data(), (uint32_t const*)run_dst.data(), (uint32_t const*)t.tile_row0.data(), t.nI, rpos.data(),
+                       waves.data(), t.dstl16.data());
+    h.sync();
+    keys = dvec<uint64_t>(); keys_tmp = dvec<uint64_t>(); vals = dvec<uint32_t>(); vals_tmp = dvec<uint32_t>();
+    // ---- slot blocks: inside one (destination tile, source tile) block the slots follow the run order, so phase 1 needs
+    // 4 bytes per block (slot - run index) and one bit per run instead of 4 bytes per run
+    dvec<uint32_t> bflag((size_t)t.n_runs + 1), bidx((size_t)t.n_runs + 1);
+    HIP_TRY(hipMemsetAsync(bflag.data() + t.n_runs, 0, sizeof(uint32_t), h.stream));
+    if (t.n_runs > 0) hipLaunchKernelGGL(k_block_flags, grid_for(t.n_runs, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)rpos.data(), t.n_runs, bflag.data());
+    exclusive_scan_u32(h, bflag.data(), bidx.data(), t.n_runs + 1);
+    uint32_t nb = 0;
+    h.read_back(&nb, bidx.data() + t.n_runs, 1);
+    t.n_blocks = nb;
+    t.delta1.resize_discard((size_t)nb + 1 + 64);
+    HIP_TRY(hipMemsetAsync(t.delta1.data(), 0, ((size_t)nb + 1 + 64) * sizeof(uint32_t), h.stream));
+    int64_t const n_words = t.n_runs / 32 + 4;
+    dvec<uint32_t> gbits(n_words);
+    if (t.n_runs > 0)
+      hipLaunchKernelGGL(k_block_delta, grid_for(t.n_runs, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)rpos.data(), (uint32_t const*)bflag.data(),
+                         (uint32_t const*)bidx.data(), t.n_runs, t.delta1.data());
+    hipLaunchKernelGGL(k_pack_flags, grid_for(n_words, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)bflag.data(), t.n_runs, gbits.data(), n_words);
+    hipLaunchKernelGGL(k_wave_records, grid_for(n_waves * TP_REC_DWORDS, kBlock, 8192), kBlock, 0, h.stream, (tiled_wave_t const*)waves.data(),
+                       (uint32_t const*)call.data(), (uint32_t const*)rpos.data(), (uint32_t const*)bidx.data(), (uint32_t const*)gbits.data(), n_waves,
+                       t.wrec.data());
     h.sync();
   } else {
     t.n_slots = 0;
     t.dstl16.resize_discard(64);
-    t.rpos.resize_discard(512);
-    HIP_TRY(hipMemsetAsync(t.rpos.data(), 0, 512 * sizeof(uint32_t), h.stream));
+    t.delta1.resize_discard(65);
+    HIP_TRY(hipMemsetAsync(t.delta1.data(), 0, 65 * sizeof(uint32_t), h.stream));
   }
   to_device(h, t.region_off, region_off);
 
@@ -519,9 +607,9 @@ struct p1_args {
   uint16_t const* src16;
   uint8_t const* bits;
   WT const* weights;
-  uint32_t const* rpos1;  // rpos shifted by one entry: slot of run q at [q + 1], padded
+  uint32_t const* delta1;  // slot - run index of slot block b at [b + 1], padded
   int32_t const* item_tile;
-  tiled_wave_t const* waves;
+  uint32_t const* wrec;    // per-wavefront records (TP_REC_DWORDS dwords each, layout in spmv_tiled.hpp)
   int32_t const* chunk_begin;  // [n_chunks][2] first / end work item of each chunk (items of a chunk share one source tile)
   int n_chunks;
   uint32_t* counter;           // chunk cursor: 0 on entry, reset by phase 2
@@ -535,6 +623,7 @@ struct p1_args {
 };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
 // 32-bit byte offsets from a wave-uniform base: the load/store takes the SGPR-base + VGPR-offset form (one VGPR and no
 // 64-bit address arithmetic per access).  build_tiled_csc checks that every array stays below 4 GiB.
@@ -549,35 +638,41 @@ __device__ __forceinline__ void st32(void* base, uint32_t byte_off, T v)
   *reinterpret_cast<T*>(static_cast<char*>(base) + byte_off) = v;
 }
 
-struct p1_regs {  // one work item's data for one lane: TP_EPL consecutive edges + the wavefront's descriptor
+struct p1_regs {  // one work item's data for one lane: TP_EPL consecutive edges + one dword of the wavefront's record
   uint4 id[TP_EPL / 8];
-  uint32_t fl;  // TP_EPL run-start bits
-  uint4 wd;     // tiled_wave_t (same address in every lane)
+  uint32_t fl;   // TP_EPL run-start bits
+  uint32_t rec;  // dword `lane` of the record (lanes >= TP_REC_DWORDS: 0)
+  uint32_t es;   // first edge position of the wavefront's share (wave-uniform)
 };
 
 template <typename WT>
 __device__ __forceinline__ void p1_load(p1_args<WT> const& a, int item, int wave, int lane, p1_regs& r)
 {  // arrays are over-allocated and zero padded: no bounds checks
-  uint32_t const e = (uint32_t)item * (uint32_t)TP_ITEM + (uint32_t)wave * TP_WLEN + (uint32_t)TP_EPL * (uint32_t)lane;
+  r.es = (uint32_t)item * (uint32_t)TP_ITEM + (uint32_t)wave * TP_WLEN;
+  uint32_t const e = r.es + (uint32_t)TP_EPL * (uint32_t)lane;
 #pragma unroll
   for (int j = 0; j < TP_EPL / 8; ++j) r.id[j] = ld32<uint4>(a.src16, 2u * e + 16u * j);
   if constexpr (TP_EPL == 16) r.fl = ld32<uint16_t>(a.bits, e >> 3);
   else r.fl = ld32<uint8_t>(a.bits, e >> 3);
-  r.wd = ld32<uint4>(a.waves, ((uint32_t)item * TP_WAVES + (uint32_t)wave) * (uint32_t)sizeof(tiled_wave_t));
+  r.rec = 0;
+  if (lane < TP_REC_DWORDS) r.rec = ld32<uint32_t>(a.wrec, ((uint32_t)item * TP_WAVES + (uint32_t)wave) * (uint32_t)(TP_REC_DWORDS * 4) + 4u * (uint32_t)lane);
 }
 
 // Run ordinal n within the wavefront's range: n = 0 is the run that was already open at `es` (its partial goes to the
-// head slot), n >= 1 is run (rank - 1 + n), whose slot is rpos1[rank + n] (rpos1 = rpos shifted by one entry).
-struct p1_runs {  // what the bitmap of one work item says about its runs
+// head slot), n >= 1 is run (rank - 1 + n), whose slot is (rank - 1 + n) + delta1[blk + #block starts among the first n runs
+// of the range] (record bits 0 .. n - 1).
+struct p1_runs {  // what the bitmap and the record of one work item say about its runs
   uint32_t f, ex_c, c_all;
-  uint32_t slot[TP_NSLOT];  // slots of runs lane, 64 + lane, ...
+  uint32_t pre;             // lane L < 32: number of block starts in record dwords 0 .. L - 1
+  uint32_t slot[TP_NSLOT];  // delta1 entries of runs lane, 64 + lane, ...
   uint32_t slot_tail;       // slot of the run still open at the end of the range
-  uint32_t es, ee, rank, head_slot;
+  uint32_t es, ee, rank, head_slot, blk;
 };
 
 __device__ __forceinline__ void p1_counts(int lane, p1_regs const& rg, p1_runs& q)
 {
-  q.es = rfl(rg.wd.x); q.ee = rfl(rg.wd.y); q.rank = rfl(rg.wd.z); q.head_slot = rfl(rg.wd.w);
+  q.es = rg.es; q.ee = rg.es + rdl(rg.rec, TP_REC_NVAL); q.rank = rdl(rg.rec, TP_REC_RANK); q.head_slot = rdl(rg.rec, TP_REC_HEAD);
+  q.slot_tail = rdl(rg.rec, TP_REC_TAIL); q.blk = rdl(rg.rec, TP_REC_BLK);
   uint32_t const e     = q.es + (uint32_t)TP_EPL * (uint32_t)lane;
   uint32_t const nval  = min((uint32_t)TP_EPL, q.ee > e ? q.ee - e : 0u);
   q.f                  = rg.fl & ((1u << nval) - 1u);
@@ -585,20 +680,27 @@ __device__ __forceinline__ void p1_counts(int lane, p1_regs const& rg, p1_runs& 
   uint32_t const c_inc = wave_inclusive_sum_u32(nf);
   q.ex_c               = c_inc - nf;
   q.c_all              = (uint32_t)__builtin_amdgcn_readlane((int)c_inc, 63);
+  uint32_t const nb    = __popc(rg.rec);
+  q.pre                = wave_inclusive_sum_u32(nb) - nb;
+}
+
+// delta1 entry of run ordinal n = 64 * j + lane (j wave-uniform): block index = blk + (block starts among record bits < n)
+template <typename WT>
+__device__ __forceinline__ uint32_t p1_delta_group(p1_args<WT> const& a, uint32_t rec, p1_runs const& q, uint32_t j)
+{
+  uint32_t const lo = rdl(rec, 2u * j), hi = rdl(rec, 2u * j + 1u), before = rdl(q.pre, 2u * j);
+  uint32_t const idx = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, q.blk + before));
+  return ld32<uint32_t>(a.delta1, 4u * idx);
 }
 
 template <typename WT>
-__device__ __forceinline__ void p1_issue_slots(p1_args<WT> const& a, int lane, p1_runs& q)
-{  // whole-wave loads behind wave-uniform guards (rpos1 is padded)
-  uint32_t const o = 4u * (q.rank + (uint32_t)lane);
+__device__ __forceinline__ void p1_issue_slots(p1_args<WT> const& a, int lane, p1_regs const& rg, p1_runs& q)
+{  // whole-wave loads behind wave-uniform guards
 #pragma unroll
   for (int j = 0; j < TP_NSLOT; ++j) {
     q.slot[j] = 0;
-    if ((uint32_t)(64 * j) < q.c_all) q.slot[j] = ld32<uint32_t>(a.rpos1, o + 256u * (uint32_t)j);
+    if ((uint32_t)(64 * j) < q.c_all) q.slot[j] = p1_delta_group<WT>(a, rg.rec, q, (uint32_t)j);
   }
-  if (lane == 0) q.slot[0] = q.head_slot;
-  q.slot_tail = q.head_slot;
-  if (q.c_all != 0) q.slot_tail = ld32<uint32_t>(a.rpos1, 4u * (q.rank + q.c_all));
 }
 
 // run totals of the lanes selected by `mine` -> staging area, in run order, starting at ordinal base_c
@@ -620,35 +722,39 @@ __device__ __forceinline__ void p1_stage(WT* stage, p1_runs const& q, WT const (
   }
 }
 
-// staging area -> partial buffer: lane i takes the i-th staged total (coalesced); ordinals [base_c, base_c + count)
+// staging area -> partial buffer: lane i takes staged totals i, 64 + i, ... (coalesced); run ordinals [n_lo, n_hi), staged at
+// [0, n_hi - n_lo)
 template <typename WT>
-__device__ __forceinline__ void p1_writeout(p1_args<WT> const& a, WT const* stage, int lane, p1_runs const& q, uint32_t base_c, uint32_t count)
+__device__ __forceinline__ void p1_writeout(p1_args<WT> const& a, WT const* stage, int lane, p1_regs const& rg, p1_runs const& q, uint32_t n_lo, uint32_t n_hi)
 {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  uint32_t b = 0;
-  if (base_c == 0) {  // the slots of the first 64 * TP_NSLOT runs were requested an item ago
+  uint32_t const rm1 = q.rank - 1u;  // run index of ordinal n = rm1 + n (modulo 2^32)
+  uint32_t j = n_lo >> 6;
+  if (n_lo == 0) {  // the delta entries of the first 64 * TP_NSLOT runs were requested an item ago
 #pragma unroll
-    for (int j = 0; j < TP_NSLOT; ++j) {
-      if ((uint32_t)(64 * j) < count) {
-        uint32_t const i = (uint32_t)lane + 64u * (uint32_t)j;
-        if (i < count) st32<WT>(a.part, q.slot[j] * (uint32_t)sizeof(WT), stage[i]);
+    for (int jj = 0; jj < TP_NSLOT; ++jj) {
+      if ((uint32_t)(64 * jj) < n_hi) {
+        uint32_t const n = (uint32_t)lane + 64u * (uint32_t)jj;
+        uint32_t slot    = q.slot[jj] + (rm1 + 64u * (uint32_t)jj) + (uint32_t)lane;
+        if (jj == 0) slot = lane == 0 ? q.head_slot : slot;
+        if (n < n_hi) st32<WT>(a.part, slot * (uint32_t)sizeof(WT), stage[n]);
       }
     }
-    b = 64 * TP_NSLOT;
+    j = TP_NSLOT;
   }
-  for (; b < count; b += 256) {  // the rest in batches of four loads, then four stores (one wait per batch)
+  for (; 64u * j < n_hi; j += 4) {  // the rest in batches of four loads, then four stores (one wait per batch)
     uint32_t sl[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       sl[t] = 0;
-      if (b + 64u * (uint32_t)t < count) sl[t] = ld32<uint32_t>(a.rpos1, 4u * (q.rank + base_c + b + 64u * (uint32_t)t + (uint32_t)lane));
+      if (64u * (j + (uint32_t)t) < n_hi) sl[t] = p1_delta_group<WT>(a, rg.rec, q, j + (uint32_t)t);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      uint32_t const i = b + 64u * (uint32_t)t + (uint32_t)lane;
-      if (i < count) st32<WT>(a.part, sl[t] * (uint32_t)sizeof(WT), stage[i]);
+      uint32_t const n = 64u * (j + (uint32_t)t) + (uint32_t)lane;
+      if (n >= n_lo && n < n_hi) st32<WT>(a.part, (sl[t] + rm1 + n) * (uint32_t)sizeof(WT), stage[n - n_lo]);
     }
   }
   __builtin_amdgcn_wave_barrier();  // the staging area is reused by the next item
@@ -709,7 +815,7 @@ __device__ __forceinline__ WT p1_compute(p1_args<WT> const& a, WT const* xs, WT*
   } else {  // more run totals than the staging area holds: lanes 0-31 (at most TP_STAGE runs) are written out right away
     uint32_t const half = (uint32_t)__builtin_amdgcn_readlane((int)c, 31);
     p1_stage<WT>(stage, q, r, carry_in, 0u, lane < 32);
-    p1_writeout<WT>(a, stage, lane, q, 0u, half);
+    p1_writeout<WT>(a, stage, lane, rg, q, 0u, half);
     p1_stage<WT>(stage, q, r, carry_in, half, lane >= 32);
     pend.base_c = half;
     pend.count  = q.c_all - half;
@@ -765,7 +871,7 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
   if (I.item >= 0) {
     p1_load<WT>(a, I.item, wave, lane, rA);
     p1_counts(lane, rA, qA);
-    p1_issue_slots<WT>(a, lane, qA);
+    p1_issue_slots<WT>(a, lane, rA, qA);
     advance(Jt);
     if (Jt.item >= 0) p1_load<WT>(a, Jt.item, wave, lane, rB);
   }
@@ -799,10 +905,10 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
     // ---- wait point: first use of data(i+1) and of slots(i)
     if (Jt.item >= 0) p1_counts(lane, nxt, qn);
     if (busy) {
-      if (pend.count) p1_writeout<WT>(a, stage, lane, qc, pend.base_c, pend.count);
+      if (pend.count) p1_writeout<WT>(a, stage, lane, cur, qc, pend.base_c, pend.base_c + pend.count);
       if (lane == 63) st32<WT>(a.part, qc.slot_tail * (uint32_t)sizeof(WT), tail);  // slot_tail = head slot when no run starts in the range
     }
-    if (Jt.item >= 0) p1_issue_slots<WT>(a, lane, qn);
+    if (Jt.item >= 0) p1_issue_slots<WT>(a, lane, nxt, qn);
     p1_iter K = Jt;
     advance(K);
     if (K.item >= 0) p1_load<WT>(a, K.item, wave, lane, cur);  // `cur` is free: data(i+2)
@@ -968,9 +1074,9 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
   a.src16     = t.src16.data();
   a.bits      = reinterpret_cast<uint8_t const*>(t.bits.data());
   a.weights   = t.weights.ptr ? t.weights.as<WT const>() : nullptr;
-  a.rpos1     = t.rpos.data();
+  a.delta1    = t.delta1.data();
   a.item_tile = t.item_tile.data();
-  a.waves     = t.waves.data();
+  a.wrec      = t.wrec.data();
   a.chunk_begin = t.chunk_begin.data();
   a.n_chunks    = t.n_chunks;
   a.counter     = counters;

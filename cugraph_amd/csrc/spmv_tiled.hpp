@@ -52,11 +52,21 @@ constexpr int TP_CHUNK = 16;                 // max work items per dynamically s
 constexpr int TP2_BLOCK = 512;               // phase-2 workgroup
 constexpr int TP2_ROWS  = 4096;              // max destination rows per phase-2 tile (64-bit LDS accumulators: 32 KiB)
 
-struct tiled_wave_t {  // static description of one wavefront's share of a work item
-  uint32_t es, ee;     // padded edge positions [es, ee); es is a multiple of 8
+struct tiled_wave_t {  // build-time description of one wavefront's share of a work item
+  uint32_t es, ee;     // padded edge positions [es, ee); es = item * TP_ITEM + wave * TP_WLEN
   uint32_t rank;       // number of run starts before es (global run ordinal of the first run that starts in the range)
   uint32_t head_slot;  // slot for the partial of the run already open at es (dummy slot when there is none)
 };
+
+// What phase 1 reads per wavefront and work item: ONE record of TP_REC_DWORDS dwords, dword L loaded by lane L.
+//   dwords 0..31   block-start bits: bit t = run (rank + t), the (t + 1)-th run that starts in the range, is the first run of
+//                  a slot block (slot - run index is constant inside a block; zero beyond the runs of the range)
+//   dword 32..     TP_REC_NVAL = ee - es, TP_REC_RANK, TP_REC_HEAD (head slot), TP_REC_TAIL (slot of the run still open at
+//                  ee; the head slot when no run starts in the range), TP_REC_BLK (index into delta1 of the block of run rank - 1)
+// Slot of run r = r + delta1[1 + block(r)]: 4 bytes per BLOCK (runs of one source tile falling into one destination tile)
+// instead of 4 bytes per run.
+constexpr int TP_REC_DWORDS = 40;
+constexpr int TP_REC_NVAL = 32, TP_REC_RANK = 33, TP_REC_HEAD = 34, TP_REC_TAIL = 35, TP_REC_BLK = 36;
 
 struct tiled_csc_t {
   bool built{false};
@@ -66,14 +76,14 @@ struct tiled_csc_t {
   int n_items{0};
   int n_wg{0};  // phase-1 workgroups
   int n_chunks{0};
-  int64_t nv{0}, ne{0}, ne_pad{0}, n_runs{0}, n_slots{0};
+  int64_t nv{0}, ne{0}, ne_pad{0}, n_runs{0}, n_slots{0}, n_blocks{0};
   double wmax{0};  // max over destinations of sum |w| of the in-edges (in-degree when unweighted): bounds a row sum by alpha * max|x| * wmax
   dvec<uint16_t> src16;       // [ne_pad + pad] tile-local source id
   dvec<uint32_t> bits;        // [ne_pad / 32 + pad] bit p = edge position p starts a run
   dev_buf weights;            // [ne_pad + pad] or empty
-  dvec<uint32_t> rpos;        // [n_runs + 512] slot of run q at [q + 1] ([0] and the tail are padding)
+  dvec<uint32_t> delta1;      // [n_blocks + 1 + pad] slot - run index of block b at [b + 1]
   dvec<int32_t> item_tile;    // [n_items] source tile of work item
-  dvec<tiled_wave_t> waves;   // [n_items * TP_WAVES]
+  dvec<uint32_t> wrec;        // [n_items * TP_WAVES][TP_REC_DWORDS] per-wavefront records (see above)
   dvec<int32_t> chunk_begin;  // [n_chunks][2] first / end item of each chunk (<= TP_CHUNK items of one source tile), largest chunks first
   dvec<uint32_t> tile_row0;   // [nI + 1] destination tile boundaries
   dvec<uint32_t> region_off;  // [nI + 2] slot range of region I (multiples of 8); region nI = dummy
