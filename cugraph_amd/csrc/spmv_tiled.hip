@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <type_traits>
+#include <utility>
 
 namespace cga {
 
@@ -490,9 +491,9 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     }
     std::stable_sort(ch.begin(), ch.end(), [](auto const& x, auto const& y) { return x.second > y.second; });
     t.n_chunks = (int)ch.size();
-    std::vector<int32_t> cb;  // [2 * n_chunks]: first item, end item
-    for (auto const& c : ch) { cb.push_back(c.first); cb.push_back(c.first + c.second); }
-    if (cb.empty()) { cb.push_back(0); cb.push_back(0); }
+    std::vector<int32_t> cb;  // [4 * n_chunks]: (unused, first item, end item, source tile)
+    for (auto const& c : ch) { cb.push_back(0); cb.push_back(c.first); cb.push_back(c.first + c.second); cb.push_back(item_tile[c.first]); }
+    if (cb.empty()) cb.assign(4, 0);
     t.n_wg = std::max(1, std::min<int>(t.n_chunks, max_wg));
     to_device(h, t.chunk_begin, cb);
   }
@@ -608,9 +609,8 @@ struct p1_args {
   uint8_t const* bits;
   WT const* weights;
   uint32_t const* delta1;  // slot - run index of slot block b at [b + 1], padded
-  int32_t const* item_tile;
   uint32_t const* wrec;    // per-wavefront records (TP_REC_DWORDS dwords each, layout in spmv_tiled.hpp)
-  int32_t const* chunk_begin;  // [n_chunks][2] first / end work item of each chunk (items of a chunk share one source tile)
+  int32_t const* chunk_begin;  // [n_chunks][4] (unused, first work item, end work item, source tile); items of a chunk share one source tile
   int n_chunks;
   uint32_t* counter;           // chunk cursor: 0 on entry, reset by phase 2
   int T;
@@ -638,6 +638,36 @@ __device__ __forceinline__ void st32(void* base, uint32_t byte_off, T v)
   *reinterpret_cast<T*>(static_cast<char*>(base) + byte_off) = v;
 }
 
+
+// LDS byte offset of 16-bit tile-local index number HALF of w, scaled by the element size, in ONE VALU op (SDWA word select
+// + shift); the x tile starts at LDS address 0
+template <int HALF, int SHIFT>
+__device__ __forceinline__ uint32_t idx_offset(uint32_t w)
+{
+  uint32_t r;
+  if constexpr (HALF == 0) asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(w), "n"(SHIFT));
+  else asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(w), "n"(SHIFT));
+  return r;
+}
+// ~0 when bit K of v is set, else 0 (one op; kept opaque so that the select below stays a bit mask)
+template <int K>
+__device__ __forceinline__ uint32_t bit_fill(uint32_t v)
+{
+  uint32_t m;
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(v), "n"(K));
+  return m;
+}
+template <int... K, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, K...>, F&& f)
+{
+  (f(std::integral_constant<int, K>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
 struct p1_regs {  // one work item's data for one lane: TP_EPL consecutive edges + one dword of the wavefront's record
   uint4 id[TP_EPL / 8];
   uint32_t fl;   // TP_EPL run-start bits
@@ -663,7 +693,7 @@ __device__ __forceinline__ void p1_load(p1_args<WT> const& a, int item, int wave
 // of the range] (record bits 0 .. n - 1).
 struct p1_runs {  // what the bitmap and the record of one work item say about its runs
   uint32_t f, ex_c, c_all;
-  uint32_t pre;             // lane L < 32: number of block starts in record dwords 0 .. L - 1
+  uint32_t blk8;            // delta1 index base of run ordinal 64 * TP_NSLOT (wave-uniform)
   uint32_t slot[TP_NSLOT];  // delta1 entries of runs lane, 64 + lane, ...
   uint32_t slot_tail;       // slot of the run still open at the end of the range
   uint32_t es, ee, rank, head_slot, blk;
@@ -680,45 +710,49 @@ __device__ __forceinline__ void p1_counts(int lane, p1_regs const& rg, p1_runs& 
   uint32_t const c_inc = wave_inclusive_sum_u32(nf);
   q.ex_c               = c_inc - nf;
   q.c_all              = (uint32_t)__builtin_amdgcn_readlane((int)c_inc, 63);
-  uint32_t const nb    = __popc(rg.rec);
-  q.pre                = wave_inclusive_sum_u32(nb) - nb;
 }
 
 // delta1 entry of run ordinal n = 64 * j + lane (j wave-uniform): block index = blk + (block starts among record bits < n)
+// `base` = delta1 index of ordinal 64 * j; advanced to that of ordinal 64 * (j + 1) (scalar popcounts)
 template <typename WT>
-__device__ __forceinline__ uint32_t p1_delta_group(p1_args<WT> const& a, uint32_t rec, p1_runs const& q, uint32_t j)
+__device__ __forceinline__ uint32_t p1_delta_group(p1_args<WT> const& a, uint32_t rec, uint32_t j, uint32_t& base)
 {
-  uint32_t const lo = rdl(rec, 2u * j), hi = rdl(rec, 2u * j + 1u), before = rdl(q.pre, 2u * j);
-  uint32_t const idx = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, q.blk + before));
+  uint32_t const lo = rdl(rec, 2u * j), hi = rdl(rec, 2u * j + 1u);
+  uint32_t const idx = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, base));
+  base += (uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi);
   return ld32<uint32_t>(a.delta1, 4u * idx);
 }
-
 template <typename WT>
 __device__ __forceinline__ void p1_issue_slots(p1_args<WT> const& a, int lane, p1_regs const& rg, p1_runs& q)
 {  // whole-wave loads behind wave-uniform guards
+  uint32_t base = q.blk;
 #pragma unroll
   for (int j = 0; j < TP_NSLOT; ++j) {
     q.slot[j] = 0;
-    if ((uint32_t)(64 * j) < q.c_all) q.slot[j] = p1_delta_group<WT>(a, rg.rec, q, (uint32_t)j);
+    if ((uint32_t)(64 * j) < q.c_all) q.slot[j] = p1_delta_group<WT>(a, rg.rec, (uint32_t)j, base);
   }
+  q.blk8 = base;  // only meaningful (and only used) when c_all > 64 * TP_NSLOT
 }
 
 // run totals of the lanes selected by `mine` -> staging area, in run order, starting at ordinal base_c
+// start[k] != 0 <=> a run starts at element k (it closes the run that ran up to element k - 1).  The totals are staged without
+// the carry of the previous lanes; the lane's FIRST staged total is patched afterwards (LDS operations of one wavefront
+// execute in order), which keeps the select out of the 16 predicated stores.
 template <typename WT>
-__device__ __forceinline__ void p1_stage(WT* stage, p1_runs const& q, WT const (&r)[TP_EPL], WT carry_in, uint32_t base_c, bool mine)
+__device__ __forceinline__ void p1_stage(WT* stage, p1_runs const& q, WT const (&r)[TP_EPL], uint32_t const (&cont)[TP_EPL], WT carry_in, uint32_t base_c, bool mine)
 {
-  if (mine && q.f) {  // the run closed by a start at element k ran up to element k - 1
-    uint32_t pos = q.ex_c - base_c;
-    bool first   = true;
-#pragma unroll
-    for (int k = 0; k < TP_EPL; ++k) {
-      if ((q.f >> k) & 1u) {
-        WT before  = k == 0 ? WT(0) : r[k - 1];
-        stage[pos] = first ? carry_in + before : before;
-        first      = false;
-        ++pos;
+  if (mine && q.f) {
+    WT* p             = stage + (q.ex_c - base_c);
+    WT* const p_first = p;
+    static_for<TP_EPL>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if (cont[k] == 0u) {
+        if constexpr (k == 0) *p = WT(0);
+        else *p = r[k - 1];
+        ++p;
       }
-    }
+    });
+    *p_first += carry_in;
   }
 }
 
@@ -744,12 +778,17 @@ __device__ __forceinline__ void p1_writeout(p1_args<WT> const& a, WT const* stag
     }
     j = TP_NSLOT;
   }
+  uint32_t base = q.blk8;
+  if (n_lo != 0) {  // rare (more than TP_STAGE run starts in the range): recount the block starts before ordinal 64 * j
+    base = q.blk;
+    for (uint32_t jj = 0; jj < j; ++jj) base += (uint32_t)__builtin_popcount(rdl(rg.rec, 2u * jj)) + (uint32_t)__builtin_popcount(rdl(rg.rec, 2u * jj + 1u));
+  }
   for (; 64u * j < n_hi; j += 4) {  // the rest in batches of four loads, then four stores (one wait per batch)
     uint32_t sl[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       sl[t] = 0;
-      if (64u * (j + (uint32_t)t) < n_hi) sl[t] = p1_delta_group<WT>(a, rg.rec, q, j + (uint32_t)t);
+      if (64u * (j + (uint32_t)t) < n_hi) sl[t] = p1_delta_group<WT>(a, rg.rec, j + (uint32_t)t, base);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -771,12 +810,12 @@ __device__ __forceinline__ WT p1_compute(p1_args<WT> const& a, WT const* xs, WT*
 {
   uint32_t const e = q.es + (uint32_t)TP_EPL * (uint32_t)lane;
   WT r[TP_EPL];  // values, then in place: running sum since the last run start at or before element k
-#pragma unroll
-  for (int k = 0; k < TP_EPL; ++k) {
+  static_for<TP_EPL>([&](auto kc) {  // positions past `ee` hold zero-padded (valid) indices; their values are masked below
+    constexpr int k  = decltype(kc)::value;
     uint32_t const w = k % 8 < 2 ? rg.id[k / 8].x : k % 8 < 4 ? rg.id[k / 8].y : k % 8 < 6 ? rg.id[k / 8].z : rg.id[k / 8].w;
-    uint32_t const i = (k & 1) ? (w >> 16) : (w & 0xFFFFu);
-    r[k]             = xs[i];  // positions past `ee` hold zero-padded (valid) indices; their values are masked below
-  }
+    constexpr int sh = sizeof(WT) == 4 ? 2 : 3;
+    r[k] = *reinterpret_cast<WT const*>(reinterpret_cast<unsigned char const*>(xs) + idx_offset<(k & 1), sh>(w));
+  });
   if constexpr (WEIGHTED) {
 #pragma unroll
     for (int k = 0; k < TP_EPL; ++k) r[k] *= ld32<WT>(a.weights, (e + (uint32_t)k) * (uint32_t)sizeof(WT));
@@ -796,27 +835,28 @@ __device__ __forceinline__ WT p1_compute(p1_args<WT> const& a, WT const* xs, WT*
   }
   // in-lane segmented sum: r[k] = v[k] + (run start at k ? 0 : r[k-1]); the select is a bit mask (0 / ~0 from the flag bit)
   uint32_t const nflags = ~q.f;
-#pragma unroll
-  for (int k = 1; k < TP_EPL; ++k) {
-    if constexpr (sizeof(WT) == 4) {
-      uint32_t const m = (uint32_t)__builtin_amdgcn_sbfe((int)nflags, k, 1);  // ~0 when element k continues the run
-      r[k] += __uint_as_float(__float_as_uint(r[k - 1]) & m);
-    } else {
-      r[k] = ((q.f >> k) & 1u) ? r[k] : r[k - 1] + r[k];
+  uint32_t cont[TP_EPL];  // ~0 when element k continues the run of element k - 1, 0 when a run starts at k
+  static_for<TP_EPL>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    cont[k]         = bit_fill<k>(nflags);
+    if constexpr (k >= 1) {
+      if constexpr (sizeof(WT) == 4) r[k] += __uint_as_float(__float_as_uint(r[k - 1]) & cont[k]);
+      else r[k] += __longlong_as_double(__double_as_longlong(r[k - 1]) & (long long)(int)cont[k]);
     }
-  }
+  });
   WT s       = r[TP_EPL - 1];
   uint32_t c = __popc(q.f);
   wave_seg_scan(s, c);
   WT const carry_in = dpp_val<0x138, 0xF>(s);  // wave_shr:1: segmented sum up to the previous lane (0 in lane 0; the range starts with an empty carry)
   if (q.c_all <= (uint32_t)TP_STAGE) {
-    p1_stage<WT>(stage, q, r, carry_in, 0u, true);
+    p1_stage<WT>(stage, q, r, cont, carry_in, 0u, true);
     pend.count = q.c_all;
   } else {  // more run totals than the staging area holds: lanes 0-31 (at most TP_STAGE runs) are written out right away
     uint32_t const half = (uint32_t)__builtin_amdgcn_readlane((int)c, 31);
-    p1_stage<WT>(stage, q, r, carry_in, 0u, lane < 32);
+    p1_stage<WT>(stage, q, r, cont, carry_in, 0u, lane < 32);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the delta entries requested an item ago (see the wait point in the item loop)
     p1_writeout<WT>(a, stage, lane, rg, q, 0u, half);
-    p1_stage<WT>(stage, q, r, carry_in, half, lane >= 32);
+    p1_stage<WT>(stage, q, r, cont, carry_in, half, lane >= 32);
     pend.base_c = half;
     pend.count  = q.c_all - half;
   }
@@ -824,7 +864,7 @@ __device__ __forceinline__ WT p1_compute(p1_args<WT> const& a, WT const* xs, WT*
 }
 
 struct p1_iter {  // position in this workgroup's item sequence (all fields wave-uniform); item < 0: exhausted
-  int item, end, pos;
+  int item, end, pos, tile;
 };
 
 template <typename WT, bool WEIGHTED, bool DBG = false>
@@ -832,7 +872,8 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   WT* xs = reinterpret_cast<WT*>(smem);
-  __shared__ int s_chunk[4];
+  // ring of four chunk descriptors (chunk id, first item, end item, source tile) behind tile + staging; the tile sits at LDS address 0
+  int4* s_chunk = reinterpret_cast<int4*>(smem + ((size_t)a.T + (size_t)TP_WAVES * TP_STAGE) * sizeof(WT));
   int const tid = threadIdx.x, lane = tid & 63;
   int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   WT* stage = xs + a.T + wave * TP_STAGE;
@@ -851,19 +892,28 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
   // natural order, exposes the store round trip and the prefetch latency once per item: 1.6 -> x ms at RMAT-26.)
   unsigned long long const t_start = wall_clock64();
   int n_tiles = 0;
-  if (tid == 0) { s_chunk[0] = (int)atomicAdd(a.counter, 1u); s_chunk[1] = (int)atomicAdd(a.counter, 1u); s_chunk[2] = (int)atomicAdd(a.counter, 1u); }
+  // thread 0 draws the next chunk and stages its descriptor in LDS: nothing in the item loop depends on a global load that
+  // was just issued (a dependent load is followed by vmcnt(0), which also waits for every prefetch and store in flight)
+  auto draw = [&](int slot) {
+    int const cid = (int)atomicAdd(a.counter, 1u);
+    int4 c{cid, 0, 0, 0};
+    if (cid < a.n_chunks) c = reinterpret_cast<int4 const*>(a.chunk_begin)[cid];
+    c.x = cid;
+    s_chunk[slot] = c;
+  };
+  if (tid == 0) { draw(0); draw(1); draw(2); }
   __syncthreads();
   auto enter = [&](p1_iter& x) {
-    int const cid = s_chunk[x.pos & 3];
-    if (cid >= a.n_chunks) { x.item = -1; } else { x.item = a.chunk_begin[2 * cid]; x.end = a.chunk_begin[2 * cid + 1]; }
+    int4 const c = s_chunk[x.pos & 3];
+    if (c.x >= a.n_chunks) { x.item = -1; } else { x.item = c.y; x.end = c.z; x.tile = c.w; }
   };
   auto advance = [&](p1_iter& x) {
     if (x.item < 0) return;
     if (++x.item >= x.end) { ++x.pos; enter(x); }
   };
-  p1_iter I{0, 0, 0};
+  p1_iter I{0, 0, 0, 0};
   enter(I);
-  if (tid == 0) s_chunk[3] = (int)atomicAdd(a.counter, 1u);  // read only after the next chunk-transition barrier
+  if (tid == 0) draw(3);  // read only after the next chunk-transition barrier
   int curJ = -1;
   p1_regs rA, rB;
   p1_runs qA, qB;
@@ -876,7 +926,7 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
     if (Jt.item >= 0) p1_load<WT>(a, Jt.item, wave, lane, rB);
   }
   auto body = [&](p1_regs& cur, p1_runs& qc, p1_regs& nxt, p1_runs& qn) {
-    int const J = a.item_tile[I.item];
+    int const J = I.tile;
     if (J != curJ) {  // only at the first item of a chunk: every wavefront has passed the chunk-transition barrier
       // x is allocated (and zero-filled) up to nJ * T elements; indices are clamped instead of guarded so that the loads
       // stay straight-line (8 in flight per thread)
@@ -902,7 +952,10 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
     WT tail = WT(0);
     bool const busy = qc.es < qc.ee;  // wave-uniform; an empty share (tail of a tile) has nothing to compute or store
     if (busy) tail = p1_compute<WT, WEIGHTED>(a, xs, stage, lane, cur, qc, pend);
-    // ---- wait point: first use of data(i+1) and of slots(i)
+    // ---- wait point: first use of data(i+1) and of slots(i).  Explicit (vmcnt(0), lgkmcnt/expcnt untouched): the compiler's
+    // own waits are per basic block and conservative -- left to itself it puts vmcnt(0) in front of every conditional
+    // store and delta load below, which serialises them on each other's round trips.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     if (Jt.item >= 0) p1_counts(lane, nxt, qn);
     if (busy) {
       if (pend.count) p1_writeout<WT>(a, stage, lane, cur, qc, pend.base_c, pend.base_c + pend.count);
@@ -917,7 +970,7 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
     Jt = K;
     if (I.item >= 0 && I.pos != old_pos) {  // next item belongs to another chunk: all wavefronts are done with the tile
       __syncthreads();
-      if (tid == 0) s_chunk[(I.pos + 3) & 3] = (int)atomicAdd(a.counter, 1u);
+      if (tid == 0) draw((I.pos + 3) & 3);
     }
   };
   while (I.item >= 0) {
@@ -1075,7 +1128,6 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
   a.bits      = reinterpret_cast<uint8_t const*>(t.bits.data());
   a.weights   = t.weights.ptr ? t.weights.as<WT const>() : nullptr;
   a.delta1    = t.delta1.data();
-  a.item_tile = t.item_tile.data();
   a.wrec      = t.wrec.data();
   a.chunk_begin = t.chunk_begin.data();
   a.n_chunks    = t.n_chunks;
@@ -1086,7 +1138,7 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
   a.alpha     = alpha;
   a.pmask = map.pmask; a.plog = map.plog; a.chunk = map.chunk; a.ncols = map.ncols;
   if (pending) a.fin = make_fin<WT>(*pending, t.nI);
-  size_t const lds = std::max<size_t>(((size_t)t.T + (size_t)TP_WAVES * TP_STAGE) * sizeof(WT), 3 * TP_BLOCK * sizeof(double));
+  size_t const lds = std::max<size_t>(((size_t)t.T + (size_t)TP_WAVES * TP_STAGE) * sizeof(WT) + 64, 3 * TP_BLOCK * sizeof(double));
   bool const w     = a.weights != nullptr;
   static bool attr_done[2] = {false, false};
   static int dbg_calls = getenv("CUGRAPH_AMD_TILED_DEBUG") ? 2 : 0;

@@ -84,7 +84,7 @@ struct tiled_csc_t {
   dvec<uint32_t> delta1;      // [n_blocks + 1 + pad] slot - run index of block b at [b + 1]
   dvec<int32_t> item_tile;    // [n_items] source tile of work item
   dvec<uint32_t> wrec;        // [n_items * TP_WAVES][TP_REC_DWORDS] per-wavefront records (see above)
-  dvec<int32_t> chunk_begin;  // [n_chunks][2] first / end item of each chunk (<= TP_CHUNK items of one source tile), largest chunks first
+  dvec<int32_t> chunk_begin;  // [n_chunks][4] (unused, first item, end item, source tile) of each chunk (<= TP_CHUNK items of one source tile), largest first
   dvec<uint32_t> tile_row0;   // [nI + 1] destination tile boundaries
   dvec<uint32_t> region_off;  // [nI + 2] slot range of region I (multiples of 8); region nI = dummy
   dvec<uint16_t> dstl16;      // [n_slots + pad] tile-local destination of slot
