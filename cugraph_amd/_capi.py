@@ -119,6 +119,15 @@ PROTOTYPES = {
     "cugraph_amd_pagerank_mg_plan_local_step": (C.c_int, [_P, _PP]),
     "cugraph_amd_pagerank_mg_plan_values": (C.c_int, [_P, _P, _PP]),
     "cugraph_amd_pagerank_mg_plan_free": (None, [_P]),
+    "cugraph_amd_traversal_mg_plan_create": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _P, C.c_int, _P,
+                                                     C.c_size_t, _PP, _PP]),
+    "cugraph_amd_traversal_mg_plan_reset": (C.c_int, [_P, _P, C.c_size_t, C.c_double, C.c_int, _PP]),
+    "cugraph_amd_traversal_mg_plan_expand": (C.c_int, [_P, C.POINTER(C.c_size_t), _PP]),
+    "cugraph_amd_traversal_mg_plan_apply": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.POINTER(C.c_size_t), _PP]),
+    "cugraph_amd_traversal_mg_plan_frontier_bits": (C.c_int, [_P, _PP, _PP]),
+    "cugraph_amd_traversal_mg_plan_merge_visited": (C.c_int, [_P, _P, _PP]),
+    "cugraph_amd_traversal_mg_plan_results": (C.c_int, [_P, _P, _P, _PP]),
+    "cugraph_amd_traversal_mg_plan_free": (None, [_P]),
     "cugraph_amd_handle_sync": (C.c_int, [_P, _PP]),
     "cugraph_amd_kernel_timing_enable": (None, [_P, C.c_int]),
     "cugraph_amd_kernel_timing_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_double), _PP]),

@@ -1,0 +1,140 @@
+// Frontier expansion shared by the single-GPU drivers (traversal.hip) and the partitioned engine (traversal_mg.hip):
+// one wave-cooperative, edge-balanced walk over the out-edges of a vertex list, parameterised by a per-edge functor.
+// Replaces extract_transform_if_v_frontier_e (cpp/include/cugraph/prims/detail/extract_transform_if_v_frontier_e.cuh:127/309/422).
+#pragma once
+#include "common.hpp"
+
+namespace cga {
+namespace {
+
+constexpr int TV_BLOCK = 256;
+constexpr int TV_WAVES = TV_BLOCK / 64;
+constexpr int32_t BIG_DEG = 2048;
+constexpr int32_t BIG_SEG = 4096;  // edges per deferred (row, segment) work unit
+
+struct counters_t {  // device-resident, zeroed per step
+  uint32_t n_next;   // size of the next (near) frontier
+  uint32_t n_far;    // size of the far pile (SSSP)
+  uint32_t n_big;    // deferred high-degree vertices
+  uint32_t pad;
+  unsigned long long edges;  // edges inspected
+  uint32_t far_min_bits_lo;  // (SSSP split) min distance bits kept in far (32-bit types)
+  uint32_t pad2;
+  unsigned long long far_min_bits64;
+  unsigned long long out_edges;  // BFS: sum of out-degrees of the vertices discovered in this level (top-down cost of the next)
+  unsigned long long in_edges;   // BFS: sum of their in-degrees (they leave the bottom-up work)
+};
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t* total)
+{
+  uint32_t inc = v;
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  *total = __shfl(inc, 63);
+  return inc - v;
+}
+
+// wave-aggregated append of `flag` lanes' values to a queue
+__device__ __forceinline__ void wave_push(bool flag, int32_t value, int32_t* q, uint32_t* counter, int lane)
+{
+  uint64_t m = __ballot(flag);
+  if (m == 0) return;
+  uint32_t base = 0;
+  int leader    = __ffsll((unsigned long long)m) - 1;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = __shfl(base, leader);
+  if (flag) q[base + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = value;
+}
+
+// Expands the frontier `q[0..n)` (q == nullptr: vertices 0..n-1): calls f(u, v, edge_position) for every
+// out-edge of every frontier vertex for which keep(u) is true.  Vertices of degree >= BIG_DEG are pushed to
+// bigq for k_expand_big.
+template <typename Keep, typename F>
+__device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices,
+                                                int32_t* bigq, counters_t* cnt, Keep keep, F& f)
+{
+  __shared__ uint32_t s_scan[TV_WAVES][64];
+  __shared__ int32_t s_beg[TV_WAVES][64];
+  __shared__ int32_t s_u[TV_WAVES][64];
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t const gwave  = (int64_t)blockIdx.x * TV_WAVES + wave;
+  int64_t const nwaves = (int64_t)gridDim.x * TV_WAVES;
+  unsigned long long inspected = 0;
+  for (int64_t base = gwave * 64; base < n; base += nwaves * 64) {
+    int64_t i = base + lane;
+    int32_t u = -1, beg = 0, deg = 0;
+    if (i < n) {
+      u = q ? q[i] : (int32_t)i;
+      if (keep(u)) { beg = offsets[u]; deg = offsets[u + 1] - beg; } else { u = -1; }
+    }
+    // deferred: huge rows, cut into BIG_SEG-edge segments (one workgroup of k_*_big each)
+    bool big = deg >= BIG_DEG;
+    if (big) {
+      uint32_t nseg = ((uint32_t)deg + BIG_SEG - 1) / BIG_SEG;
+      uint32_t at   = atomicAdd(&cnt->n_big, nseg);
+      for (uint32_t sgm = 0; sgm < nseg; ++sgm) { bigq[2 * (at + sgm)] = u; bigq[2 * (at + sgm) + 1] = (int32_t)sgm; }
+    }
+    // whole-wave rows
+    uint64_t mid = __ballot(deg >= 64 && !big);
+    while (mid) {
+      int src     = __ffsll((unsigned long long)mid) - 1;
+      mid &= mid - 1;
+      int32_t uu = __shfl(u, src), b = __shfl(beg, src), d = __shfl(deg, src);
+      for (int32_t p = lane; p < d; p += 64) f(uu, indices[b + p], b + p);
+      inspected += (lane == 0) ? (unsigned long long)d : 0ull;
+    }
+    // flattened small rows
+    uint32_t sd = (deg < 64) ? (uint32_t)deg : 0u, total;
+    uint32_t ex = wave_excl_scan(sd, lane, &total);
+    s_scan[wave][lane] = ex;
+    s_beg[wave][lane]  = beg;
+    s_u[wave][lane]    = u;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t t = lane; t < total; t += 64) {
+      // owner = last lane j with s_scan[j] <= t (rows of degree 0 share a scan value with their successor;
+      // the search returns the last of them, whose degree is > 0 by construction of `total`)
+      int lo = 0, hi = 63;
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        int m = (lo + hi + 1) >> 1;
+        if (s_scan[wave][m] <= t) lo = m; else hi = m - 1;
+      }
+      int32_t p = s_beg[wave][lo] + (int32_t)(t - s_scan[wave][lo]);
+      f(s_u[wave][lo], indices[p], p);
+    }
+    __builtin_amdgcn_wave_barrier();
+    inspected += (lane == 0) ? (unsigned long long)total : 0ull;
+  }
+  if (lane == 0 && inspected) atomicAdd(&cnt->edges, inspected);
+}
+
+template <typename F>
+__device__ __forceinline__ void expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, counters_t* cnt, F& f)
+{  // one workgroup per (row, segment) pair: rows of 10^3..10^6 edges all get parallelism proportional to their length
+  uint32_t const nseg = cnt->n_big;
+  unsigned long long inspected = 0;
+  for (uint32_t k = blockIdx.x; k < nseg; k += gridDim.x) {
+    int32_t const u = bigq[2 * k], sgm = bigq[2 * k + 1];
+    int32_t const b = offsets[u] + sgm * BIG_SEG;
+    int32_t const e = min(offsets[u + 1], b + BIG_SEG);
+    for (int32_t p = b + (int32_t)threadIdx.x; p < e; p += (int32_t)blockDim.x) f(u, indices[p], p);
+    if (threadIdx.x == 0) inspected += (unsigned long long)(e - b);
+  }
+  if (threadIdx.x == 0 && inspected) atomicAdd(&cnt->edges, inspected);
+}
+
+
+inline size_t big_queue_entries(int64_t ne) { return (size_t)(2 * (ne / BIG_DEG + ne / BIG_SEG + 64)); }
+
+inline int expand_grid(handle_t const& h, int64_t n)
+{
+  int64_t waves = (n + 63) / 64;
+  int64_t g     = (waves + TV_WAVES - 1) / TV_WAVES;
+  int64_t cap   = (int64_t)h.num_cus * 8;
+  return (int)std::max<int64_t>(1, std::min(g, cap));
+}
+
+}  // namespace
+}  // namespace cga

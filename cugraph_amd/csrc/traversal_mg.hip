@@ -1,0 +1,528 @@
+// Partitioned BFS / SSSP: the per-rank engine behind cugraph_amd/mg_traversal.py (one process per GPU; the all-to-all of
+// candidates between the calls below is torch.distributed = RCCL).
+//
+// Replaces the multi-GPU halves of:
+//   detail::bfs / detail::sssp with multi_gpu = true        cpp/src/traversal/bfs_impl.cuh:133-870, sssp_impl.cuh:169-566
+//   transform_reduce_if_v_frontier_outgoing_e_by_dst (MG)   prims/transform_reduce_if_v_frontier_outgoing_e_by_dst.cuh:617-1127
+//     (local expansion -> (dst, payload) shuffled to the dst owner -> reduced again there)
+//   update_v_frontier / fill_edge_dst_property (MG)         prims/update_v_frontier.cuh:164-244, fill_edge_src_dst_property.cuh
+//
+// Layout.  P ranks; vertices in global degree order are dealt round-robin (position p -> rank p % P, local row p / P),
+// L = rows per rank rounded up to a multiple of 64.  A vertex is named by its COMPACT GLOBAL ID g = owner * L + row:
+// the owner of g is g / L, and the concatenation of the ranks' L-bit local bitmaps IS the global bitmap, so the
+// "who has been visited" knowledge travels as one all-gather of L / 8 bytes per rank and level.  A rank holds the CSR
+// of the out-edges of its rows with destinations as compact global ids.
+//
+// One level / relaxation round on a rank:
+//   expand   walk the out-edges of the local frontier (the edge-balanced walk of traversal_common.hpp).  Candidates are
+//            REDUCED AT THE SENDER in a table indexed by g (BFS: minimum parent; SSSP: minimum (distance, parent) packed in
+//            64 bits) -- a destination is sent at most once per rank and round whatever its in-degree -- then bucketed by
+//            owner (counting sort: per-workgroup LDS histograms, one scan, one scatter) into the send buffer;
+//   (all-to-all of the buckets: host layer)
+//   apply    the owner folds the received candidates into its rows with atomicMin / atomicCAS -- the result does not depend
+//            on arrival order -- and builds the next local frontier.
+// BFS keeps an exact global visited bitmap (all-gather of the new-frontier bits per level), so only genuinely new vertices
+// are ever sent.  SSSP is a frontier Bellman-Ford (a vertex is re-expanded whenever its distance dropped); its fixed point
+// is the same as Dijkstra's, so distances are bit-identical to the single-GPU path and to the oracle.
+// Parents: the minimum EXTERNAL id among the valid parents (BFS: in-neighbours one level up; SSSP: tight in-edges) --
+// deterministic and independent of P and of the numbering.
+#include "common.hpp"
+#include "traversal_common.hpp"
+
+#include <cfloat>
+#include <climits>
+#include <cstring>
+#include <vector>
+
+#include "cugraph_amd/extensions.h"
+
+namespace cga {
+
+namespace {
+
+constexpr int MG_MAX_RANKS = 64;
+constexpr int MG_BUCKET_BLOCKS = 512;
+constexpr unsigned long long MG_NONE64 = ~0ull;
+
+struct mg_bfs_state {
+  uint32_t const* seen;   // global bitmap: visited as of the start of the level
+  uint32_t* touched;      // global bitmap: candidates of this level (first setter lists the vertex)
+  int32_t* cand_parent;   // [P * L] minimum external id of a frontier parent, INT32_MAX = none
+  int32_t const* row_vertex;
+  int32_t* cand;          // candidate list (compact global ids)
+  counters_t* cnt;
+  int with_pred;
+};
+
+struct mg_bfs_visit {
+  mg_bfs_state s;
+  __device__ __forceinline__ void operator()(int32_t u, int32_t g, int32_t) const
+  {
+    uint32_t const bit = 1u << (g & 31);
+    bool fresh = false;
+    if (!(s.seen[g >> 5] & bit)) {
+      if (s.with_pred) {
+        int32_t const pu = s.row_vertex[u];
+        if (pu < __builtin_nontemporal_load(&s.cand_parent[g])) atomicMin(&s.cand_parent[g], pu);
+      }
+      if (!(__builtin_nontemporal_load(&s.touched[g >> 5]) & bit)) fresh = !(atomicOr(&s.touched[g >> 5], bit) & bit);
+    }
+    wave_push(fresh, g, s.cand, &s.cnt->n_next, threadIdx.x & 63);
+  }
+};
+
+struct mg_sssp_state {
+  unsigned long long const* st;  // [n_rows] (distance bits << 32) | (parent external id + 1)
+  unsigned long long* cand_best; // [P * L] best candidate of this round per destination
+  uint32_t* touched;
+  float const* weights;
+  int32_t const* row_vertex;
+  int32_t* cand;
+  counters_t* cnt;
+  float cutoff;
+};
+
+struct mg_sssp_relax {
+  mg_sssp_state s;
+  __device__ __forceinline__ void operator()(int32_t u, int32_t g, int32_t p) const
+  {
+    float const du = __uint_as_float((uint32_t)(s.st[u] >> 32));
+    float const nd = du + s.weights[p];
+    bool fresh = false;
+    if (nd < s.cutoff) {  // strict, as sssp_impl.cuh:58-71
+      unsigned long long const packed = ((unsigned long long)__float_as_uint(nd) << 32) | (uint32_t)(s.row_vertex[u] + 1);  // parent + 1: 0 = none
+      if (packed < __hip_atomic_load(&s.cand_best[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        atomicMin(&s.cand_best[g], packed);
+        uint32_t const bit = 1u << (g & 31);
+        if (!(__builtin_nontemporal_load(&s.touched[g >> 5]) & bit)) fresh = !(atomicOr(&s.touched[g >> 5], bit) & bit);
+      }
+    }
+    wave_push(fresh, g, s.cand, &s.cnt->n_next, threadIdx.x & 63);
+  }
+};
+
+struct keep_all_mg { __device__ __forceinline__ bool operator()(int32_t) const { return true; } };
+
+__global__ void __launch_bounds__(TV_BLOCK) k_mg_bfs_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices, int32_t* bigq,
+                                                            mg_bfs_state s)
+{
+  mg_bfs_visit f{s};
+  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all_mg{}, f);
+}
+__global__ void __launch_bounds__(TV_BLOCK) k_mg_bfs_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, mg_bfs_state s)
+{
+  mg_bfs_visit f{s};
+  expand_big(bigq, offsets, indices, s.cnt, f);
+}
+__global__ void __launch_bounds__(TV_BLOCK) k_mg_sssp_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices, int32_t* bigq,
+                                                             mg_sssp_state s)
+{
+  mg_sssp_relax f{s};
+  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all_mg{}, f);
+}
+__global__ void __launch_bounds__(TV_BLOCK) k_mg_sssp_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, mg_sssp_state s)
+{
+  mg_sssp_relax f{s};
+  expand_big(bigq, offsets, indices, s.cnt, f);
+}
+
+// ---- bucketing by owner: counting sort of the candidate list.  Workgroup b owns the contiguous slice
+// [b * chunk, (b + 1) * chunk) of the list in both passes, chunk = ceil(n / MG_BUCKET_BLOCKS) with n read on the device.
+__global__ void __launch_bounds__(256) k_mg_bucket_count(int32_t const* cand, counters_t const* cnt, uint32_t L, int P, uint32_t* block_hist)
+{
+  __shared__ uint32_t h[MG_MAX_RANKS];
+  if (threadIdx.x < MG_MAX_RANKS) h[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t const n = cnt->n_next, chunk = (n + gridDim.x - 1) / gridDim.x;
+  uint32_t const b = blockIdx.x * chunk, e = min(n, b + chunk);
+  for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) atomicAdd(&h[(uint32_t)cand[i] / L], 1u);
+  __syncthreads();
+  if ((int)threadIdx.x < P) block_hist[threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];  // owner-major
+}
+
+// exclusive scan of the owner-major histogram (P * nb entries, one workgroup) + per-owner totals
+__global__ void __launch_bounds__(1024) k_mg_bucket_scan(uint32_t* block_hist, int P, int nb, unsigned long long* totals)
+{
+  __shared__ uint32_t part[1024];
+  int const n = P * nb, per = (n + 1023) / 1024;
+  int const b = threadIdx.x * per, e = min(n, b + per);
+  uint32_t s = 0;
+  for (int i = b; i < e; ++i) s += block_hist[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < 1024; ++i) { uint32_t t = part[i]; part[i] = run; run += t; }
+  }
+  __syncthreads();
+  uint32_t run = part[threadIdx.x];
+  for (int i = b; i < e; ++i) { uint32_t t = block_hist[i]; block_hist[i] = run; run += t; }
+  __syncthreads();
+  if ((int)threadIdx.x < P) {
+    uint32_t const first = block_hist[threadIdx.x * nb];
+    uint32_t const next  = (int)threadIdx.x + 1 < P ? block_hist[(threadIdx.x + 1) * nb] : 0xFFFFFFFFu;
+    totals[threadIdx.x]  = (unsigned long long)first | ((unsigned long long)next << 32);  // (start, start of the next owner); the last one is fixed on the host
+  }
+}
+
+// scatter of (row, payload) tuples into the owner buckets; resets the sender-side tables for the next round
+template <int MODE>  // 0 = BFS: (row, parent); 1 = SSSP: (row, distance bits, parent)
+__global__ void __launch_bounds__(256) k_mg_bucket_scatter(int32_t const* cand, counters_t const* cnt, uint32_t L, int P, uint32_t const* block_base,
+                                                           int32_t* cand_parent, unsigned long long* cand_best, uint32_t* touched, int32_t* out)
+{
+  __shared__ uint32_t cur[MG_MAX_RANKS];
+  if ((int)threadIdx.x < P) cur[threadIdx.x] = block_base[threadIdx.x * gridDim.x + blockIdx.x];
+  __syncthreads();
+  uint32_t const n = cnt->n_next, chunk = (n + gridDim.x - 1) / gridDim.x;
+  uint32_t const b = blockIdx.x * chunk, e = min(n, b + chunk);
+  for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+    uint32_t const g = (uint32_t)cand[i], o = g / L;
+    uint32_t const at = atomicAdd(&cur[o], 1u);
+    if constexpr (MODE == 0) {
+      out[2 * (size_t)at]     = (int32_t)(g - o * L);
+      out[2 * (size_t)at + 1] = cand_parent[g];
+      cand_parent[g]          = INT32_MAX;
+    } else {
+      unsigned long long const v = cand_best[g];
+      out[3 * (size_t)at]     = (int32_t)(g - o * L);
+      out[3 * (size_t)at + 1] = (int32_t)(uint32_t)(v >> 32);
+      out[3 * (size_t)at + 2] = (int32_t)(uint32_t)v;
+      cand_best[g]            = MG_NONE64;
+    }
+    touched[g >> 5] = 0;  // every set bit of the word belongs to a listed candidate: plain stores of zero suffice
+  }
+}
+
+// ---- owner side
+__global__ void k_mg_bfs_apply(int32_t const* in, size_t n, int32_t level, int32_t* dist, int32_t* pred, int32_t* q_next, uint32_t* newfront, counters_t* cnt)
+{
+  size_t i      = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  bool fresh    = false;
+  int32_t row   = 0;
+  if (i < n) {
+    row                = in[2 * i];
+    int32_t const par  = in[2 * i + 1];
+    int32_t const old  = atomicCAS(&dist[row], INT32_MAX, level);
+    fresh              = old == INT32_MAX;
+    if (fresh) atomicOr(&newfront[row >> 5], 1u << (row & 31));
+    if (pred && (fresh || old == level) && par < __builtin_nontemporal_load(&pred[row])) atomicMin(&pred[row], par);
+  }
+  wave_push(fresh, row, q_next, &cnt->n_next, threadIdx.x & 63);
+}
+
+__global__ void k_mg_sssp_apply(int32_t const* in, size_t n, uint32_t round, unsigned long long* st, uint32_t* mark, int32_t* q_next, counters_t* cnt)
+{
+  size_t i    = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  bool push   = false;
+  int32_t row = 0;
+  if (i < n) {
+    row = in[3 * i];
+    unsigned long long const packed = ((unsigned long long)(uint32_t)in[3 * i + 1] << 32) | (uint32_t)in[3 * i + 2];
+    if (packed < __hip_atomic_load(&st[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      unsigned long long const old = atomicMin(&st[row], packed);
+      if ((uint32_t)(packed >> 32) < (uint32_t)(old >> 32)) push = atomicExch(&mark[row], round) != round;  // the DISTANCE dropped: expand again
+    }
+  }
+  wave_push(push, row, q_next, &cnt->n_next, threadIdx.x & 63);
+}
+
+__global__ void k_mg_bfs_sources(int32_t const* rows, size_t n, int32_t* dist, int32_t* q, uint32_t* newfront, counters_t* cnt)
+{
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t const r = rows[i];
+  if (atomicCAS(&dist[r], INT32_MAX, 0) == INT32_MAX) {  // duplicates in the source list are enqueued once
+    atomicOr(&newfront[r >> 5], 1u << (r & 31));
+    q[atomicAdd(&cnt->n_next, 1u)] = r;
+  }
+}
+__global__ void k_mg_sssp_sources(int32_t const* rows, size_t n, unsigned long long* st, int32_t* q, counters_t* cnt)
+{
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t const r = rows[i];
+  if (atomicExch(&st[r], 0ull) != 0ull) q[atomicAdd(&cnt->n_next, 1u)] = r;  // (distance 0, no parent): the smallest key, nothing overrides it
+}
+
+__global__ void k_mg_or(uint32_t* a, uint32_t const* b, size_t n)
+{
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) a[i] |= b[i];
+}
+template <typename T>
+__global__ void k_mg_fill(T* p, size_t n, T v)
+{
+  size_t i      = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+__global__ void k_mg_bfs_results(int32_t const* dist, int32_t const* pred, size_t n, int32_t* dist_out, int32_t* pred_out)
+{
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  dist_out[i] = dist[i];
+  if (pred_out) pred_out[i] = (pred && pred[i] != INT32_MAX) ? pred[i] : -1;
+}
+__global__ void k_mg_sssp_results(unsigned long long const* st, size_t n, float* dist_out, int32_t* pred_out)
+{
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long const v = st[i];
+  bool const reached = v != MG_NONE64;
+  dist_out[i] = reached ? __uint_as_float((uint32_t)(v >> 32)) : FLT_MAX;  // unreached = type max (sssp_impl.cuh)
+  if (pred_out) pred_out[i] = reached ? (int32_t)(uint32_t)v - 1 : -1;  // low word = parent + 1; 0 (-> -1) for the sources
+}
+
+template <typename T>
+void fill(handle_t const& h, T* p, size_t n, T v)
+{
+  if (n) hipLaunchKernelGGL(k_mg_fill<T>, grid_for((int64_t)n, kBlock, 8192), kBlock, 0, h.stream, p, n, v);
+}
+
+struct traversal_mg_plan {
+  handle_t const* h{nullptr};
+  int mode{0}, rank{0}, P{1};
+  size_t n_rows{0}, n_edges{0}, L{0}, capacity{0};
+  int32_t const* offsets{nullptr};
+  int32_t const* indices{nullptr};
+  float const* weights{nullptr};
+  int32_t const* row_vertex{nullptr};
+  int32_t* send{nullptr};
+  bool with_pred{true};
+  float cutoff{FLT_MAX};
+  // state
+  dvec<int32_t> dist, pred, cand_parent, cand, q_a, q_b, bigq;
+  dvec<unsigned long long> st, cand_best, totals;
+  dvec<uint32_t> seen, touched, newfront, mark, block_hist;
+  dvec<counters_t> cnt;
+  int32_t* q_cur{nullptr};
+  int32_t* q_next{nullptr};
+  size_t n_frontier{0};
+  int tuple_words() const { return mode == 0 ? 2 : 3; }
+};
+
+}  // namespace
+}  // namespace cga
+
+using namespace cga;
+
+static traversal_mg_plan& TP(cugraph_amd_traversal_mg_plan_t* p) { return *reinterpret_cast<traversal_mg_plan*>(p); }
+
+extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_create(const cugraph_resource_handle_t* handle, const int32_t* offsets,
+                                                                     const int32_t* indices, const float* weights, size_t n_rows, size_t n_edges,
+                                                                     size_t rows_per_rank, int comm_rank, int comm_size,
+                                                                     const int32_t* row_vertex, int mode, int32_t* send, size_t capacity_tuples,
+                                                                     cugraph_amd_traversal_mg_plan_t** plan, cugraph_error_t** error)
+{
+  if (plan) *plan = nullptr;
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    CGA_EXPECTS(plan != nullptr && offsets != nullptr && row_vertex != nullptr && send != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
+    CGA_EXPECTS(mode == 0 || mode == 1, CUGRAPH_INVALID_INPUT, "mode must be 0 (BFS) or 1 (SSSP)");
+    CGA_EXPECTS(mode == 0 || weights != nullptr, CUGRAPH_INVALID_INPUT, "SSSP needs (float) weights");
+    CGA_EXPECTS(comm_size >= 1 && comm_size <= MG_MAX_RANKS && comm_rank >= 0 && comm_rank < comm_size, CUGRAPH_INVALID_INPUT, "bad rank / size");
+    CGA_EXPECTS(rows_per_rank % 64 == 0 && n_rows <= rows_per_rank, CUGRAPH_INVALID_INPUT, "rows_per_rank must be a multiple of 64 and >= n_rows");
+    CGA_EXPECTS((uint64_t)rows_per_rank * (uint64_t)comm_size < ((uint64_t)1 << 31), CUGRAPH_INVALID_INPUT, "compact global ids must fit 31 bits");
+    HIP_TRY(hipSetDevice(h.device));
+    auto p       = std::make_unique<traversal_mg_plan>();
+    p->h         = &h;
+    p->mode      = mode;
+    p->rank      = comm_rank;
+    p->P         = comm_size;
+    p->n_rows    = n_rows;
+    p->n_edges   = n_edges;
+    p->L         = rows_per_rank;
+    p->capacity  = capacity_tuples;
+    p->offsets   = offsets;
+    p->indices   = indices;
+    p->weights   = weights;
+    p->row_vertex = row_vertex;
+    p->send      = send;
+    size_t const G = rows_per_rank * (size_t)comm_size, n1 = std::max<size_t>(n_rows, 1);
+    CGA_EXPECTS(capacity_tuples >= std::min<size_t>(G, std::max<size_t>(n_edges, 1)), CUGRAPH_INVALID_INPUT,
+                "send capacity must hold min(P * L, local edges) tuples");
+    p->cand.resize_discard(capacity_tuples + 64);
+    p->q_a.resize_discard(n1);
+    p->q_b.resize_discard(n1);
+    p->bigq.resize_discard(big_queue_entries((int64_t)n_edges));
+    p->touched.resize_discard(G / 32);
+    p->block_hist.resize_discard((size_t)MG_MAX_RANKS * MG_BUCKET_BLOCKS);
+    p->totals.resize_discard(MG_MAX_RANKS);
+    p->cnt.resize_discard(1);
+    if (mode == 0) {
+      p->dist.resize_discard(n1);
+      p->pred.resize_discard(n1);
+      p->cand_parent.resize_discard(G);
+      p->seen.resize_discard(G / 32);
+      p->newfront.resize_discard(rows_per_rank / 32);
+    } else {
+      p->st.resize_discard(n1);
+      p->cand_best.resize_discard(G);
+      p->mark.resize_discard(n1);
+    }
+    h.sync();
+    *plan = reinterpret_cast<cugraph_amd_traversal_mg_plan_t*>(p.release());
+  });
+}
+
+extern "C" void cugraph_amd_traversal_mg_plan_free(cugraph_amd_traversal_mg_plan_t* plan) { delete reinterpret_cast<traversal_mg_plan*>(plan); }
+
+extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_reset(cugraph_amd_traversal_mg_plan_t* plan, const int32_t* source_rows,
+                                                                    size_t n_sources, double cutoff, bool_t compute_predecessors,
+                                                                    cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr, CUGRAPH_INVALID_INPUT, "plan is NULL");
+    traversal_mg_plan& p = TP(plan);
+    handle_t const& h    = *p.h;
+    HIP_TRY(hipSetDevice(h.device));
+    size_t const G = p.L * (size_t)p.P, n1 = std::max<size_t>(p.n_rows, 1);
+    p.with_pred = compute_predecessors == TRUE;
+    p.cutoff    = cutoff >= (double)FLT_MAX ? FLT_MAX : (float)cutoff;
+    HIP_TRY(hipMemsetAsync(p.touched.data(), 0, G / 8, h.stream));
+    HIP_TRY(hipMemsetAsync(p.cnt.data(), 0, sizeof(counters_t), h.stream));
+    p.q_cur  = p.q_a.data();
+    p.q_next = p.q_b.data();
+    int const g = (int)((n_sources + 255) / 256);
+    if (p.mode == 0) {
+      fill<int32_t>(h, p.dist.data(), n1, INT32_MAX);
+      fill<int32_t>(h, p.pred.data(), n1, INT32_MAX);
+      fill<int32_t>(h, p.cand_parent.data(), G, INT32_MAX);
+      HIP_TRY(hipMemsetAsync(p.seen.data(), 0, G / 8, h.stream));
+      HIP_TRY(hipMemsetAsync(p.newfront.data(), 0, p.L / 8, h.stream));
+      if (n_sources) hipLaunchKernelGGL(k_mg_bfs_sources, g, 256, 0, h.stream, source_rows, n_sources, p.dist.data(), p.q_cur, p.newfront.data(), p.cnt.data());
+    } else {
+      fill<unsigned long long>(h, p.st.data(), n1, MG_NONE64);
+      fill<unsigned long long>(h, p.cand_best.data(), G, MG_NONE64);
+      HIP_TRY(hipMemsetAsync(p.mark.data(), 0, n1 * 4, h.stream));
+      if (n_sources) hipLaunchKernelGGL(k_mg_sssp_sources, g, 256, 0, h.stream, source_rows, n_sources, p.st.data(), p.q_cur, p.cnt.data());
+    }
+    counters_t c{};
+    h.read_back(&c, p.cnt.data(), 1);
+    p.n_frontier = c.n_next;
+  });
+}
+
+/* Expands the local frontier; on return send holds, grouped by owner rank, send_counts[r] tuples for rank r. */
+extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_expand(cugraph_amd_traversal_mg_plan_t* plan, size_t* send_counts, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr && send_counts != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
+    traversal_mg_plan& p = TP(plan);
+    handle_t const& h    = *p.h;
+    HIP_TRY(hipSetDevice(h.device));
+    HIP_TRY(hipMemsetAsync(p.cnt.data(), 0, sizeof(counters_t), h.stream));
+    int64_t const n = (int64_t)p.n_frontier;
+    if (n > 0) {
+      int const g = expand_grid(h, n);
+      timed_launch tl(h, p.mode == 0 ? "bfs_expand" : "sssp_relax");
+      if (p.mode == 0) {
+        mg_bfs_state s{p.seen.data(), p.touched.data(), p.cand_parent.data(), p.row_vertex, p.cand.data(), p.cnt.data(), p.with_pred ? 1 : 0};
+        hipLaunchKernelGGL(k_mg_bfs_expand, g, TV_BLOCK, 0, h.stream, (int32_t const*)p.q_cur, n, p.offsets, p.indices, p.bigq.data(), s);
+        hipLaunchKernelGGL(k_mg_bfs_expand_big, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)p.bigq.data(), p.offsets, p.indices, s);
+      } else {
+        mg_sssp_state s{p.st.data(), p.cand_best.data(), p.touched.data(), p.weights, p.row_vertex, p.cand.data(), p.cnt.data(), p.cutoff};
+        hipLaunchKernelGGL(k_mg_sssp_expand, g, TV_BLOCK, 0, h.stream, (int32_t const*)p.q_cur, n, p.offsets, p.indices, p.bigq.data(), s);
+        hipLaunchKernelGGL(k_mg_sssp_expand_big, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)p.bigq.data(), p.offsets, p.indices, s);
+      }
+    }
+    // bucket by owner
+    int const nb = MG_BUCKET_BLOCKS;
+    hipLaunchKernelGGL(k_mg_bucket_count, nb, 256, 0, h.stream, (int32_t const*)p.cand.data(), (counters_t const*)p.cnt.data(), (uint32_t)p.L, p.P, p.block_hist.data());
+    hipLaunchKernelGGL(k_mg_bucket_scan, 1, 1024, 0, h.stream, p.block_hist.data(), p.P, nb, p.totals.data());
+    if (p.mode == 0)
+      hipLaunchKernelGGL(k_mg_bucket_scatter<0>, nb, 256, 0, h.stream, (int32_t const*)p.cand.data(), (counters_t const*)p.cnt.data(), (uint32_t)p.L, p.P,
+                         (uint32_t const*)p.block_hist.data(), p.cand_parent.data(), (unsigned long long*)nullptr, p.touched.data(), p.send);
+    else
+      hipLaunchKernelGGL(k_mg_bucket_scatter<1>, nb, 256, 0, h.stream, (int32_t const*)p.cand.data(), (counters_t const*)p.cnt.data(), (uint32_t)p.L, p.P,
+                         (uint32_t const*)p.block_hist.data(), (int32_t*)nullptr, p.cand_best.data(), p.touched.data(), p.send);
+    // counts: totals[r] = (start of r, start of r + 1); the list length closes the last bucket
+    struct { unsigned long long t[MG_MAX_RANKS]; } tot;
+    HIP_TRY(hipMemcpyAsync(h.pinned, p.totals.data(), sizeof(unsigned long long) * MG_MAX_RANKS, hipMemcpyDeviceToHost, h.stream));
+    counters_t c{};
+    HIP_TRY(hipMemcpyAsync(static_cast<char*>(h.pinned) + 1024, p.cnt.data(), sizeof(counters_t), hipMemcpyDeviceToHost, h.stream));
+    h.sync();
+    std::memcpy(&tot, h.pinned, sizeof(tot));
+    std::memcpy(&c, static_cast<char*>(h.pinned) + 1024, sizeof(c));
+    CGA_EXPECTS((size_t)c.n_next <= p.capacity, CUGRAPH_UNKNOWN_ERROR, "candidate list overflowed the send capacity");
+    for (int r = 0; r < p.P; ++r) {
+      uint32_t const first = (uint32_t)tot.t[r];
+      uint32_t const next  = r + 1 < p.P ? (uint32_t)(tot.t[r] >> 32) : c.n_next;
+      send_counts[r]       = (size_t)(next - first);
+    }
+  });
+}
+
+/* Folds n_tuples received candidates into the local rows; n_next = size of the next local frontier. */
+extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_apply(cugraph_amd_traversal_mg_plan_t* plan, const int32_t* recv, size_t n_tuples,
+                                                                    uint32_t level, size_t* n_next, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr && n_next != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
+    traversal_mg_plan& p = TP(plan);
+    handle_t const& h    = *p.h;
+    HIP_TRY(hipSetDevice(h.device));
+    HIP_TRY(hipMemsetAsync(p.cnt.data(), 0, sizeof(counters_t), h.stream));
+    if (p.mode == 0) HIP_TRY(hipMemsetAsync(p.newfront.data(), 0, p.L / 8, h.stream));
+    if (n_tuples) {
+      int const g = (int)((n_tuples + 255) / 256);
+      if (p.mode == 0)
+        hipLaunchKernelGGL(k_mg_bfs_apply, g, 256, 0, h.stream, recv, n_tuples, (int32_t)level, p.dist.data(), p.with_pred ? p.pred.data() : (int32_t*)nullptr,
+                           p.q_next, p.newfront.data(), p.cnt.data());
+      else
+        hipLaunchKernelGGL(k_mg_sssp_apply, g, 256, 0, h.stream, recv, n_tuples, level, p.st.data(), p.mark.data(), p.q_next, p.cnt.data());
+    }
+    counters_t c{};
+    h.read_back(&c, p.cnt.data(), 1);
+    std::swap(p.q_cur, p.q_next);
+    p.n_frontier = c.n_next;
+    *n_next      = c.n_next;
+  });
+}
+
+/* BFS: device pointer to this rank's new-frontier bits of the last apply / reset (rows_per_rank / 32 words). */
+extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_frontier_bits(cugraph_amd_traversal_mg_plan_t* plan, const uint32_t** bits,
+                                                                            cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr && bits != nullptr && TP(plan).mode == 0, CUGRAPH_INVALID_INPUT, "BFS plan expected");
+    *bits = TP(plan).newfront.data();
+  });
+}
+
+/* BFS: visited |= the all-gathered new-frontier bits of every rank (comm_size * rows_per_rank / 32 words). */
+extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_merge_visited(cugraph_amd_traversal_mg_plan_t* plan, const uint32_t* gathered,
+                                                                            cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr && gathered != nullptr && TP(plan).mode == 0, CUGRAPH_INVALID_INPUT, "BFS plan expected");
+    traversal_mg_plan& p = TP(plan);
+    handle_t const& h    = *p.h;
+    HIP_TRY(hipSetDevice(h.device));
+    size_t const n = p.L * (size_t)p.P / 32;
+    hipLaunchKernelGGL(k_mg_or, (int)((n + 255) / 256), 256, 0, h.stream, p.seen.data(), gathered, n);
+    h.sync();
+  });
+}
+
+/* distances (BFS: int32, INT32_MAX unreached; SSSP: float, FLT_MAX unreached) and predecessors (external ids, -1) of the local rows */
+extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_results(cugraph_amd_traversal_mg_plan_t* plan, void* distances, int32_t* predecessors,
+                                                                      cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr && distances != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
+    traversal_mg_plan& p = TP(plan);
+    handle_t const& h    = *p.h;
+    HIP_TRY(hipSetDevice(h.device));
+    if (p.n_rows) {
+      int const g = (int)((p.n_rows + 255) / 256);
+      if (p.mode == 0)
+        hipLaunchKernelGGL(k_mg_bfs_results, g, 256, 0, h.stream, (int32_t const*)p.dist.data(), p.with_pred ? (int32_t const*)p.pred.data() : (int32_t const*)nullptr,
+                           p.n_rows, static_cast<int32_t*>(distances), predecessors);
+      else
+        hipLaunchKernelGGL(k_mg_sssp_results, g, 256, 0, h.stream, (unsigned long long const*)p.st.data(), p.n_rows, static_cast<float*>(distances),
+                           p.with_pred ? predecessors : (int32_t*)nullptr);
+    }
+    h.sync();
+  });
+}

@@ -1,0 +1,373 @@
+"""Multi-GPU BFS / SSSP: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in CPU tests).
+
+Replaces the multi-GPU path of cugraph_bfs / cugraph_sssp ("one all-to-all per BFS/SSSP level";
+cpp/src/traversal/bfs_impl.cuh:133-870 and sssp_impl.cuh:169-566 with multi_gpu = true, whose frontier expansion ends in a
+shuffle of (dst, payload) pairs to the dst owner, prims/transform_reduce_if_v_frontier_outgoing_e_by_dst.cuh:617-1127).
+
+Partitioning: vertices ordered by descending global OUT-degree (ties: ascending id) are dealt round-robin to the P ranks
+(position p -> owner p % P, local row p // P): every rank gets the same mix of hub and tail rows.  1-D by source: the
+owner of a vertex holds all its out-edges, so a frontier vertex is expanded on exactly one rank.  A vertex is named by its
+compact global id g = owner * L + row (L = rows per rank, padded to a multiple of 64): the owner is g // L and the
+concatenation of the ranks' L-bit bitmaps is the global bitmap.
+
+Per level / relaxation round (collective):
+    expand      local frontier -> candidates, reduced at the sender per destination, bucketed by owner
+    all-to-all  counts, then the tuples (one message per peer: all xGMI links of a GPU carry traffic at once)
+    apply       the owner folds the candidates into its rows (order-independent) and builds its next frontier
+    BFS only    all-gather of the L-bit new-frontier bitmaps -> every rank's visited bitmap stays exact, so a vertex is
+                sent at most once per rank in the whole search
+    all-reduce  of the next-frontier sizes: the search ends when the global frontier is empty.
+SSSP is a frontier Bellman-Ford; its fixed point equals Dijkstra's, so distances are bit-identical to the single-GPU path.
+Parents: minimum external id among the valid parents -- independent of P.
+
+The per-rank compute sits behind `TraversalEngine`; the product engine is `HipTraversalEngine` (C ABI, HIP kernels of
+csrc/traversal_mg.hip).  Tests plug `NumpyTraversalEngine` into the same orchestration to exercise partitioning and
+collectives under gloo on CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .mg import Partition, _a2a
+
+INT32_MAX = 2**31 - 1
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+class TraversalEngine:
+    """What the orchestration needs from the per-rank compute.  Tuples are int32 rows: BFS (row, parent), SSSP (row,
+    distance bits, parent + 1)."""
+
+    tuple_words: int
+
+    def reset(self, source_rows: torch.Tensor, cutoff: float, with_pred: bool) -> int:
+        raise NotImplementedError
+
+    def expand(self):
+        """-> (send tensor [n, tuple_words] grouped by owner, counts per owner)"""
+        raise NotImplementedError
+
+    def apply(self, recv: torch.Tensor, level: int) -> int:
+        raise NotImplementedError
+
+    def frontier_bits(self) -> torch.Tensor:  # BFS: int32 words, L / 32
+        raise NotImplementedError
+
+    def merge_visited(self, gathered: torch.Tensor):
+        raise NotImplementedError
+
+    def results(self):
+        raise NotImplementedError
+
+
+class NumpyTraversalEngine(TraversalEngine):
+    """Reference engine (CPU, numpy): the same contract as the HIP engine, used by the gloo tests."""
+
+    def __init__(self, mode, offsets, indices, weights, n_rows, L, rank, world, row_vertex):
+        self.mode, self.n_rows, self.L, self.rank, self.world = mode, n_rows, L, rank, world
+        self.off = offsets.numpy().astype(np.int64)
+        self.idx = indices.numpy().astype(np.int64)
+        self.w = None if weights is None else weights.numpy().astype(np.float32)
+        self.row_vertex = row_vertex.numpy().astype(np.int64)
+        self.tuple_words = 2 if mode == 0 else 3
+        self.device = torch.device("cpu")
+
+    def reset(self, source_rows, cutoff, with_pred):
+        src = np.unique(source_rows.numpy().astype(np.int64))
+        self.with_pred = with_pred
+        self.cutoff = np.float32(min(cutoff, FLT_MAX))
+        self.frontier = src
+        if self.mode == 0:
+            self.dist = np.full(self.n_rows, INT32_MAX, np.int64)
+            self.pred = np.full(self.n_rows, INT32_MAX, np.int64)
+            self.dist[src] = 0
+            self.seen = np.zeros(self.L * self.world, bool)
+            self.new = np.zeros(self.L, bool)
+            self.new[src] = True
+        else:
+            self.key = np.full(self.n_rows, np.iinfo(np.uint64).max, np.uint64)
+            self.key[src] = 0
+        return int(src.size)
+
+    def _edges_of_frontier(self):
+        f = self.frontier
+        deg = self.off[f + 1] - self.off[f]
+        u = np.repeat(f, deg)
+        pos = np.repeat(self.off[f], deg) + (np.arange(int(deg.sum())) - np.repeat(np.cumsum(deg) - deg, deg))
+        return u, pos
+
+    def expand(self):
+        u, pos = self._edges_of_frontier()
+        g = self.idx[pos]
+        if self.mode == 0:
+            keep = ~self.seen[g]
+            g, par = g[keep], self.row_vertex[u[keep]]
+            order = np.lexsort((par, g))
+            g, par = g[order], par[order]
+            first = np.ones(g.size, bool)
+            first[1:] = g[1:] != g[:-1]
+            g, par = g[first], par[first]
+            out = np.stack([g % self.L, par], axis=1).astype(np.int32)
+        else:
+            du = (self.key[u] >> np.uint64(32)).astype(np.uint32).view(np.float32)
+            nd = (du + self.w[pos]).astype(np.float32)
+            keep = nd < self.cutoff
+            g, nd, par = g[keep], nd[keep], self.row_vertex[u[keep]] + 1
+            key = (nd.view(np.uint32).astype(np.uint64) << np.uint64(32)) | par.astype(np.uint64)
+            order = np.lexsort((key, g))
+            g, key = g[order], key[order]
+            first = np.ones(g.size, bool)
+            first[1:] = g[1:] != g[:-1]
+            g, key = g[first], key[first]
+            out = np.stack([g % self.L, (key >> np.uint64(32)).astype(np.uint32).view(np.int32),
+                            (key & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)], axis=1).astype(np.int32)
+        counts = np.bincount(g // self.L, minlength=self.world).tolist()  # g is sorted, so the tuples are grouped by owner
+        return torch.from_numpy(np.ascontiguousarray(out)), counts
+
+    def apply(self, recv, level):
+        r = recv.numpy()
+        if self.mode == 0:
+            self.new[:] = False
+            if r.size:
+                rows, par = r[:, 0].astype(np.int64), r[:, 1].astype(np.int64)
+                fresh = self.dist[rows] == INT32_MAX
+                rows, par = rows[fresh], par[fresh]
+                self.dist[rows] = level
+                np.minimum.at(self.pred, rows, par)
+                self.new[rows] = True
+            self.frontier = np.flatnonzero(self.new[: self.n_rows])
+        else:
+            nxt = np.zeros(self.n_rows, bool)
+            if r.size:
+                rows = r[:, 0].astype(np.int64)
+                key = (r[:, 1].view(np.uint32).astype(np.uint64) << np.uint64(32)) | r[:, 2].view(np.uint32).astype(np.uint64)
+                old = self.key.copy()
+                np.minimum.at(self.key, rows, key)
+                nxt = (self.key >> np.uint64(32)) < (old >> np.uint64(32))
+            self.frontier = np.flatnonzero(nxt)
+        return int(self.frontier.size)
+
+    def frontier_bits(self):
+        return torch.from_numpy(np.packbits(self.new, bitorder="little").view(np.int32).copy())
+
+    def merge_visited(self, gathered):
+        self.seen |= np.unpackbits(gathered.numpy().view(np.uint8), bitorder="little").astype(bool)
+
+    def results(self):
+        if self.mode == 0:
+            pred = np.where(self.pred == INT32_MAX, -1, self.pred).astype(np.int32)
+            return torch.from_numpy(self.dist.astype(np.int32)), (torch.from_numpy(pred) if self.with_pred else None)
+        reached = self.key != np.iinfo(np.uint64).max
+        d = np.where(reached, (self.key >> np.uint64(32)).astype(np.uint32).view(np.float32), np.float32(FLT_MAX)).astype(np.float32)
+        p = np.where(reached, (self.key & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1, -1).astype(np.int32)
+        return torch.from_numpy(d), (torch.from_numpy(p) if self.with_pred else None)
+
+
+class HipTraversalEngine(TraversalEngine):
+    """The product path: the kernels of csrc/traversal_mg.hip through the C ABI (cugraph_amd_traversal_mg_plan_*)."""
+
+    def __init__(self, mode, offsets, indices, weights, n_rows, L, rank, world, row_vertex):
+        from . import _capi as capi
+        from .pylib import ResourceHandle, assert_success
+
+        self._capi, self._assert = capi, assert_success
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self.mode, self.n_rows, self.L, self.world = mode, n_rows, L, world
+        self.tuple_words = 2 if mode == 0 else 3
+        self.handle = ResourceHandle()
+        self._off = offsets.to(dev).to(torch.int32).contiguous()
+        self._idx = indices.to(dev).to(torch.int32).contiguous()
+        if self._idx.numel() == 0:
+            self._idx = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._w = None if weights is None else weights.to(dev).to(torch.float32).contiguous()
+        self._rv = row_vertex.to(dev).to(torch.int32).contiguous()
+        if self._rv.numel() == 0:
+            self._rv = torch.zeros(1, dtype=torch.int32, device=dev)
+        n_edges = int(indices.numel())
+        self.capacity = max(min(L * world, max(n_edges, 1)), 1)
+        self.send = torch.zeros((self.capacity, self.tuple_words), dtype=torch.int32, device=dev)
+        plan, err = C.c_void_p(), C.c_void_p()
+        torch.cuda.current_stream().synchronize()
+        code = capi.lib().cugraph_amd_traversal_mg_plan_create(
+            self.handle.c_resource_handle_ptr, self._off.data_ptr(), self._idx.data_ptr(), (self._w.data_ptr() if self._w is not None else None),
+            n_rows, n_edges, L, rank, world, self._rv.data_ptr(), mode, self.send.data_ptr(), self.capacity, C.byref(plan), C.byref(err))
+        assert_success(code, err, "cugraph_amd_traversal_mg_plan_create")
+        self.plan = plan
+
+    def _call(self, name, *args):
+        err = C.c_void_p()
+        code = getattr(self._capi.lib(), name)(self.plan, *args, C.byref(err))
+        self._assert(code, err, name)
+
+    def reset(self, source_rows, cutoff, with_pred):
+        self.with_pred = with_pred
+        src = source_rows.to(self.device).to(torch.int32).contiguous()
+        torch.cuda.current_stream().synchronize()
+        self._call("cugraph_amd_traversal_mg_plan_reset", (src.data_ptr() if src.numel() else None), int(src.numel()), float(cutoff), 1 if with_pred else 0)
+
+    def expand(self):
+        counts = (C.c_size_t * self.world)()
+        self._call("cugraph_amd_traversal_mg_plan_expand", counts)
+        counts = [int(c) for c in counts]
+        return self.send[: sum(counts)], counts
+
+    def apply(self, recv, level):
+        n_next = C.c_size_t(0)
+        recv = recv.contiguous()
+        torch.cuda.current_stream().synchronize()  # the library computes on its own HIP stream
+        self._call("cugraph_amd_traversal_mg_plan_apply", (recv.data_ptr() if recv.numel() else None), int(recv.shape[0]), int(level), C.byref(n_next))
+        return int(n_next.value)
+
+    def frontier_bits(self):
+        ptr = C.c_void_p()
+        self._call("cugraph_amd_traversal_mg_plan_frontier_bits", C.byref(ptr))
+        out = torch.empty(self.L // 32, dtype=torch.int32, device=self.device)
+        _memcpy_d2d(out, ptr.value, self.L // 8)
+        return out
+
+    def merge_visited(self, gathered):
+        g = gathered.to(self.device).contiguous()
+        torch.cuda.current_stream().synchronize()
+        self._call("cugraph_amd_traversal_mg_plan_merge_visited", g.data_ptr())
+
+    def results(self):
+        n = max(self.n_rows, 1)
+        d = torch.empty(n, dtype=(torch.int32 if self.mode == 0 else torch.float32), device=self.device)
+        p = torch.empty(n, dtype=torch.int32, device=self.device) if self.with_pred else None
+        torch.cuda.current_stream().synchronize()
+        self._call("cugraph_amd_traversal_mg_plan_results", d.data_ptr(), (p.data_ptr() if p is not None else None))
+        return d[: self.n_rows], (p[: self.n_rows] if p is not None else None)
+
+    def __del__(self):
+        p = getattr(self, "plan", None)
+        if p:
+            self._capi.lib().cugraph_amd_traversal_mg_plan_free(p)
+            self.plan = None
+
+
+def _memcpy_d2d(dst: torch.Tensor, src_ptr: int, nbytes: int):
+    """Copies nbytes of library-owned device memory into a torch tensor (plumbing: torch owns the collective buffers)."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    rc = hip.hipMemcpy(dst.data_ptr(), src_ptr, nbytes, 3)  # hipMemcpyDeviceToDevice
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpy failed with {rc}")
+
+
+# --------------------------------------------------------------------------------------- orchestration
+class MGTraversal:
+    """Collective: every rank of `group` constructs it with ITS slice of the edge list (external ids 0..V-1)."""
+
+    def __init__(self, src, dst, num_vertices, weights=None, mode="bfs", group=None, engine_factory=None):
+        assert mode in ("bfs", "sssp")
+        self.group = group
+        self.world = world = dist.get_world_size(group)
+        self.rank = rank = dist.get_rank(group)
+        self.mode = 0 if mode == "bfs" else 1
+        if self.mode == 1:
+            assert weights is not None, "SSSP needs weights"
+        nv = int(num_vertices)
+        self.nv = nv
+        src64, dst64 = src.to(torch.int64), dst.to(torch.int64)
+        out_deg = torch.bincount(src64, minlength=nv)
+        dist.all_reduce(out_deg, group=group)
+        self.part = part = Partition(out_deg, world, rank)
+        self.L = L = ((nv + world - 1) // world + 63) // 64 * 64
+        pos_s, pos_d = part.pos[src64], part.pos[dst64]
+        g_dst = (pos_d % world) * L + pos_d // world                 # compact global id of the destination
+        owner = pos_s % world
+        order = torch.argsort(owner, stable=True)
+        send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=group)
+        sc, rc = send_counts.tolist(), recv_counts.tolist()
+        rows = _a2a((pos_s // world)[order].contiguous(), sc, rc, group)
+        cols = _a2a(g_dst[order].contiguous(), sc, rc, group)
+        w = None if weights is None else _a2a(weights.to(torch.float32)[order].contiguous(), sc, rc, group)
+        # local CSR (rows ascending, destinations ascending inside a row)
+        n_rows = part.n_rows
+        key = rows * (L * world) + cols
+        o2 = torch.argsort(key, stable=True)
+        rows, cols = rows[o2], cols[o2]
+        w = None if w is None else w[o2].contiguous()
+        offsets = torch.zeros(n_rows + 1, dtype=torch.int64, device=rows.device)
+        if rows.numel():
+            offsets[1:] = torch.cumsum(torch.bincount(rows, minlength=n_rows), 0)
+        self.num_local_edges = int(cols.numel())
+        assert self.num_local_edges < 2**31 and L * world < 2**31
+        factory = engine_factory or HipTraversalEngine
+        self.engine = factory(self.mode, offsets.to(torch.int32), cols.to(torch.int32), w, n_rows, L, rank, world, part.local_vertices.to(torch.int32))
+        self.levels = 0
+
+    # -- collectives on device tensors (nccl) or through the host (gloo moves host memory)
+    def _to_comm(self, t):
+        return t.cpu() if (t.is_cuda and dist.get_backend(self.group) == "gloo") else t
+
+    def _exchange(self, send, counts):
+        """All-to-all-v of the candidate tuples: counts first, then one message per peer."""
+        dev, tw = send.device, self.engine.tuple_words
+        host = dist.get_backend(self.group) == "gloo"
+        sc = torch.tensor(counts, dtype=torch.int64, device=("cpu" if host else dev))
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        rc = rc.tolist()
+        s = self._to_comm(send.reshape(-1))
+        if s.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        r = torch.empty(sum(rc) * tw, dtype=torch.int32, device=s.device)
+        dist.all_to_all_single(r, s, output_split_sizes=[c * tw for c in rc], input_split_sizes=[c * tw for c in counts], group=self.group)
+        return r.reshape(-1, tw).to(dev)
+
+    def _share_frontier_bits(self):
+        bits = self._to_comm(self.engine.frontier_bits())
+        out = torch.empty(self.world * bits.numel(), dtype=bits.dtype, device=bits.device)
+        dist.all_gather_into_tensor(out, bits, group=self.group)
+        self.engine.merge_visited(out)
+
+    def run(self, sources, cutoff=FLT_MAX, compute_predecessors=True, depth_limit=None):
+        """sources: external vertex ids (the same list on every rank).  Returns (vertices, distances, predecessors) of the
+        vertices this rank owns.  BFS: depth_limit as cugraph_bfs; SSSP: cutoff as cugraph_sssp."""
+        e, part, world = self.engine, self.part, self.world
+        sources = torch.as_tensor(sources, dtype=torch.int64).reshape(-1)
+        if sources.numel() and (int(sources.min()) < 0 or int(sources.max()) >= self.nv):
+            raise ValueError("Found invalid vertex in the input sources")  # bfs.cpp:106-119
+        pos = part.pos.cpu()[sources]
+        mine = pos[pos % world == self.rank] // world
+        e.reset(mine.to(torch.int32), cutoff, compute_predecessors)
+        if self.mode == 0:
+            self._share_frontier_bits()
+        level = 0
+        while True:
+            level += 1
+            if self.mode == 0 and depth_limit is not None and level > depth_limit:
+                break
+            send, counts = e.expand()
+            recv = self._exchange(send, counts)
+            n_next = e.apply(recv, level)
+            if self.mode == 0:
+                self._share_frontier_bits()
+            tot = torch.tensor([n_next], dtype=torch.int64, device=(send.device if dist.get_backend(self.group) != "gloo" else "cpu"))
+            dist.all_reduce(tot, group=self.group)
+            if int(tot.item()) == 0:
+                break
+        self.levels = level
+        d, p = e.results()
+        return part.local_vertices, d, p
+
+
+def bfs(src, dst, num_vertices, sources, depth_limit=None, compute_predecessors=True, group=None, engine_factory=None):
+    """Collective BFS; returns (vertices, distances, predecessors) for this rank's vertices."""
+    t = MGTraversal(src, dst, num_vertices, None, "bfs", group, engine_factory)
+    return t.run(sources, compute_predecessors=compute_predecessors, depth_limit=depth_limit)
+
+
+def sssp(src, dst, weights, num_vertices, source, cutoff=FLT_MAX, compute_predecessors=True, group=None, engine_factory=None):
+    """Collective SSSP (float weights); returns (vertices, distances, predecessors) for this rank's vertices."""
+    t = MGTraversal(src, dst, num_vertices, weights, "sssp", group, engine_factory)
+    return t.run([source], cutoff=cutoff, compute_predecessors=compute_predecessors)

@@ -81,6 +81,42 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg_plan_values(cugraph_
                                                                         cugraph_error_t** error);
 CUGRAPH_EXPORT void cugraph_amd_pagerank_mg_plan_free(cugraph_amd_pagerank_mg_plan_t* plan);
 
+/* Partitioned BFS / SSSP: the per-rank engine (cugraph_amd/csrc/traversal_mg.hip; host layer cugraph_amd/mg_traversal.py).
+ * Replaces the multi_gpu = true halves of cpp/src/traversal/bfs_impl.cuh:133-870, sssp_impl.cuh:169-566 and of
+ * prims/transform_reduce_if_v_frontier_outgoing_e_by_dst.cuh:617-1127 (the (dst, payload) shuffle to the dst owner is the
+ * all-to-all the host layer runs between expand and apply).
+ *   Vertices: position p in the global degree order -> rank p % comm_size, local row p / comm_size; a vertex is named by its
+ *   compact global id g = owner * rows_per_rank + row (rows_per_rank a multiple of 64, the same on every rank).
+ *   offsets / indices / weights   CSR of the out-edges of the local rows (device, borrowed), destinations as compact global ids
+ *   row_vertex                    external id of every local row (device, borrowed)
+ *   mode                          0 = BFS (tuples of 2 int32: row at the owner, parent external id)
+ *                                 1 = SSSP, float weights (3 int32: row, distance bits, parent external id + 1)
+ *   send                          device buffer for capacity_tuples tuples, >= min(comm_size * rows_per_rank, n_edges)
+ * One level: expand (send <- candidates grouped by owner, send_counts[r] tuples for rank r) -> all-to-all -> apply (n_next =
+ * size of the next local frontier; the search ends when it is 0 on every rank).  BFS additionally all-gathers
+ * frontier_bits after reset and after every apply and hands the result to merge_visited. */
+typedef struct { int32_t align_; } cugraph_amd_traversal_mg_plan_t;
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_create(
+  const cugraph_resource_handle_t* handle, const int32_t* offsets, const int32_t* indices, const float* weights, size_t n_rows,
+  size_t n_edges, size_t rows_per_rank, int comm_rank, int comm_size, const int32_t* row_vertex, int mode, int32_t* send,
+  size_t capacity_tuples, cugraph_amd_traversal_mg_plan_t** plan, cugraph_error_t** error);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_reset(cugraph_amd_traversal_mg_plan_t* plan, const int32_t* source_rows,
+                                                                        size_t n_sources, double cutoff, bool_t compute_predecessors,
+                                                                        cugraph_error_t** error);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_expand(cugraph_amd_traversal_mg_plan_t* plan, size_t* send_counts,
+                                                                         cugraph_error_t** error);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_apply(cugraph_amd_traversal_mg_plan_t* plan, const int32_t* recv,
+                                                                        size_t n_tuples, uint32_t level, size_t* n_next,
+                                                                        cugraph_error_t** error);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_frontier_bits(cugraph_amd_traversal_mg_plan_t* plan, const uint32_t** bits,
+                                                                                cugraph_error_t** error);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_merge_visited(cugraph_amd_traversal_mg_plan_t* plan, const uint32_t* gathered,
+                                                                                cugraph_error_t** error);
+/* distances of the local rows (BFS: int32, INT32_MAX unreached; SSSP: float, FLT_MAX unreached) and predecessors (external ids, -1) */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_results(cugraph_amd_traversal_mg_plan_t* plan, void* distances,
+                                                                          int32_t* predecessors, cugraph_error_t** error);
+CUGRAPH_EXPORT void cugraph_amd_traversal_mg_plan_free(cugraph_amd_traversal_mg_plan_t* plan);
+
 /* Blocks until everything queued on the handle's stream has finished. */
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_handle_sync(const cugraph_resource_handle_t* handle,
                                                             cugraph_error_t** error);
