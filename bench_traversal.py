@@ -18,6 +18,86 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+def main_partitioned(args):
+    """Partitioned BFS / SSSP (cugraph_amd/mg_traversal.py): the SAME RMAT graph over all ranks (strong scaling)."""
+    import torch
+    import torch.distributed as dist
+
+    import cugraph_amd as cg
+    from cugraph_amd import mg_traversal as mt
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    single = os.environ.get("CUGRAPH_AMD_MG_TEST_SINGLE_GPU") == "1"  # plumbing check: all ranks share cuda:0, gloo moves the data
+    torch.cuda.set_device(0 if single else local_rank)
+    if not dist.is_initialized():
+        if world == 1 and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+        if single:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    h = cg.ResourceHandle()
+    nv, ne = 1 << args.scale, args.edge_factor << args.scale
+    per = (ne + world - 1) // world
+    first = rank * per
+    count = max(0, min(per, ne - first))
+    src, dst = cg.generate_rmat_edgelist(h, args.scale, count, first_edge=first)
+    if args.weights == "unit":
+        w = torch.ones(count, dtype=torch.float32, device="cuda")
+    else:
+        w = torch.randint(1, 256, (count,), generator=torch.Generator(device="cuda").manual_seed(1 + rank), device="cuda").to(torch.float32)
+    if single:
+        src, dst, w = src.cpu(), dst.cpu(), w.cpu()
+    t0 = time.perf_counter()
+    engines = {"bfs": mt.MGTraversal(src, dst, nv, None, "bfs")}
+    if not args.no_sssp:
+        engines["sssp"] = mt.MGTraversal(src, dst, nv, w, "sssp")
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    part = engines["bfs"].part
+    outdeg = torch.bincount(src.to(torch.int64), minlength=nv)
+    dist.all_reduce(outdeg)
+    cand = torch.nonzero(outdeg > 0).flatten().cpu()
+    perm = torch.randperm(cand.numel(), generator=torch.Generator().manual_seed(0))[: args.roots]
+    roots = cand[perm].tolist()
+    my_outdeg = outdeg[part.local_vertices].to(torch.float64).to(engines["bfs"].engine.device)
+    del src, dst
+
+    def run(kind):
+        e = engines[kind]
+        times, teps, levels = [], [], []
+        for i, r in enumerate([roots[0], roots[0]] + roots):  # two warm-ups
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            _, d, _ = e.run([r], compute_predecessors=args.predecessors)
+            torch.cuda.synchronize()
+            dist.barrier()
+            dt = time.perf_counter() - t0
+            unreached = mt.INT32_MAX if kind == "bfs" else mt.FLT_MAX
+            er = (my_outdeg * (d.to(my_outdeg.device) != unreached)).sum().reshape(1)
+            er = er.cpu() if single else er
+            dist.all_reduce(er)
+            if i >= 2:
+                times.append(dt)
+                teps.append(float(er.item()) / dt)
+                levels.append(e.levels)
+        hm = len(teps) / sum(1.0 / t for t in teps)
+        return {"ms_mean": round(1e3 * sum(times) / len(times), 3), "ms_min": round(1e3 * min(times), 3), "ms_max": round(1e3 * max(times), 3),
+                "mteps_harmonic_mean": round(hm / 1e6, 1), "rounds_mean": round(sum(levels) / len(levels), 1)}
+
+    out = {"workload": f"partitioned BFS/SSSP, RMAT scale {args.scale} edge factor {args.edge_factor}, weights {args.weights}, {world} rank(s)",
+           "n_gpus": world, "vertices": nv, "edges": ne, "roots": len(roots), "graph_build_s": round(build_s, 3), "scaling": "strong",
+           "bfs": run("bfs")}
+    if not args.no_sssp:
+        out["sssp"] = run("sssp")
+    if rank == 0:
+        print(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     import numpy as np
     import torch
@@ -32,7 +112,11 @@ def main():
     ap.add_argument("--symmetric", action="store_true", help="add the reverse of every edge (Graph500 input)")
     ap.add_argument("--no-sssp", action="store_true")
     ap.add_argument("--predecessors", action="store_true")
+    ap.add_argument("--gpus", type=int, default=1, help="> 1 (under torch.distributed.run): the partitioned engine, one rank per GPU")
+    ap.add_argument("--partitioned", action="store_true", help="run the partitioned engine even with one rank (comparison with the single-GPU path)")
     args = ap.parse_args()
+    if args.gpus > 1 or args.partitioned:
+        return main_partitioned(args)
 
     torch.cuda.set_device(0)
     h = cg.ResourceHandle()

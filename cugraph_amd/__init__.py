@@ -5,6 +5,7 @@ Layout (only what the hot path needs):
   _capi.py   ctypes binding of that C ABI
   pylib.py   host-side mirror of the reference's pylibcugraph interface for this path
   mg.py      multi-GPU PageRank (one process per GPU, torch.distributed / RCCL)
+  mg_traversal.py  multi-GPU BFS / SSSP (same process model)
 """
 from .pylib import (  # noqa: F401
     FailedToConvergeError,
@@ -13,8 +14,12 @@ from .pylib import (  # noqa: F401
     ResourceHandle,
     SGGraph,
     bfs,
+    bfs_extract_paths,
+    degrees,
     generate_rmat_edgelist,
     has_vertex,
+    in_degrees,
+    out_degrees,
     pagerank,
     personalized_pagerank,
     sssp,

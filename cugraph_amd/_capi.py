@@ -99,6 +99,17 @@ PROTOTYPES = {
     "cugraph_personalized_pagerank": (C.c_int, [_P] * 8 + [C.c_double, C.c_double, C.c_size_t, C.c_int, _PP, _PP]),
     "cugraph_personalized_pagerank_allow_nonconvergence": (C.c_int, [_P] * 8 + [C.c_double, C.c_double, C.c_size_t, C.c_int, _PP, _PP]),
     # traversal_algorithms.h
+    "cugraph_in_degrees": (C.c_int, [_P, _P, _P, C.c_int, _PP, _PP]),
+    "cugraph_out_degrees": (C.c_int, [_P, _P, _P, C.c_int, _PP, _PP]),
+    "cugraph_degrees": (C.c_int, [_P, _P, _P, C.c_int, _PP, _PP]),
+    "cugraph_degrees_result_get_vertices": (_P, [_P]),
+    "cugraph_degrees_result_get_in_degrees": (_P, [_P]),
+    "cugraph_degrees_result_get_out_degrees": (_P, [_P]),
+    "cugraph_degrees_result_free": (None, [_P]),
+    "cugraph_extract_paths": (C.c_int, [_P, _P, _P, _P, _P, _PP, _PP]),
+    "cugraph_extract_paths_result_get_max_path_length": (C.c_size_t, [_P]),
+    "cugraph_extract_paths_result_get_paths": (_P, [_P]),
+    "cugraph_extract_paths_result_free": (None, [_P]),
     "cugraph_paths_result_get_vertices": (_P, [_P]),
     "cugraph_paths_result_get_distances": (_P, [_P]),
     "cugraph_paths_result_get_predecessors": (_P, [_P]),

@@ -1,0 +1,235 @@
+// cugraph_degrees / cugraph_in_degrees / cugraph_out_degrees and cugraph_extract_paths (the calls
+// user code makes right after building a graph and right after a BFS).
+//
+// Replaces:
+//   cugraph_{in_,out_,}degrees, cugraph_degrees_result_*   cpp/src/c_api/degrees.cu:24-213, degrees_result.cpp:9-57
+//     (graph_view_t::compute_in_degrees / compute_out_degrees, cpp/src/structure/graph_view_impl.cuh:649-690)
+//   cugraph_extract_paths, cugraph_extract_paths_result_*  cpp/src/c_api/extract_paths.cpp:24-170
+//     (cugraph::extract_bfs_paths, cpp/src/traversal/extract_bfs_paths_impl.cuh:130-240)
+// Degrees come straight from the offsets of the orientation whose rows are the wanted endpoint; when only the other
+// orientation exists they are a histogram of its minor ids (no transposition of the storage is forced).
+#include "common.hpp"
+
+#include <climits>
+
+#include "cugraph_c/graph_functions.h"
+#include "cugraph_c/traversal_algorithms.h"
+
+namespace cga {
+
+struct degrees_result_t {  // c_api/degrees_result.hpp
+  bool is_symmetric{false};
+  device_array_t* vertex_ids{nullptr};
+  device_array_t* in_degrees{nullptr};
+  device_array_t* out_degrees{nullptr};
+  ~degrees_result_t() { delete vertex_ids; delete in_degrees; delete out_degrees; }
+};
+
+struct extract_paths_result_t {  // c_api/extract_paths.cpp:24-30
+  size_t max_path_length{0};
+  device_array_t* paths{nullptr};
+  ~extract_paths_result_t() { delete paths; }
+};
+
+namespace {
+
+__global__ void k_offsets_to_degrees(int32_t const* offsets, int64_t nv, int32_t* deg)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nv; i += stride) deg[i] = offsets[i + 1] - offsets[i];
+}
+
+__global__ void k_gather_degrees(int32_t const* deg, int32_t const* internal_ids, int64_t n, int32_t* out)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = deg[internal_ids[i]];
+}
+
+// degree of every internal vertex as the endpoint `rows_are_sources ? source : destination`
+void endpoint_degrees(handle_t const& h, graph_t const& g, bool as_source, int32_t* deg)
+{
+  int64_t const nv = g.nv;
+  if (nv == 0) return;
+  orientation_t const& same  = as_source ? g.csr : g.csc;   // rows are the wanted endpoint
+  orientation_t const& other = as_source ? g.csc : g.csr;
+  if (same.built) {
+    hipLaunchKernelGGL(k_offsets_to_degrees, grid_for(nv, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)same.offsets.data(), nv, deg);
+  } else {
+    CGA_EXPECTS(other.built, CUGRAPH_UNKNOWN_ERROR, "graph has no adjacency storage");
+    HIP_TRY(hipMemsetAsync(deg, 0, nv * sizeof(int32_t), h.stream));
+    if (g.ne > 0) histogram_i32(h, other.indices.data(), g.ne, reinterpret_cast<uint32_t*>(deg));
+  }
+}
+
+cugraph_error_code_t degrees_impl(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+                                  const cugraph_type_erased_device_array_view_t* source_vertices, bool want_in, bool want_out,
+                                  cugraph_degrees_result_t** result, cugraph_error_t** error)
+{
+  if (result) *result = nullptr;
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    graph_t& g        = G(graph);
+    CGA_EXPECTS(result != nullptr, CUGRAPH_INVALID_INPUT, "result is NULL");
+    HIP_TRY(hipSetDevice(h.device));
+    auto sv = reinterpret_cast<device_array_view_t const*>(source_vertices);
+    CGA_EXPECTS(sv == nullptr || sv->type == g.vertex_type, CUGRAPH_INVALID_INPUT, "vertex type of graph and source_vertices must match");
+    int64_t const nv = g.nv, n1 = nv > 0 ? nv : 1;
+    bool const sym   = g.props.is_symmetric == TRUE;
+    bool const share = want_in && want_out && sym;  // degrees.cu:84-88: one array serves both
+    dvec<int32_t> din, dout;
+    if (want_in) { din.resize_discard(n1); endpoint_degrees(h, g, false, din.data()); }
+    if (want_out && !share) { dout.resize_discard(n1); endpoint_degrees(h, g, true, dout.data()); }
+    auto res          = std::make_unique<degrees_result_t>();
+    res->is_symmetric = sym;
+    int64_t n_out     = nv;
+    dvec<int32_t> ids;
+    if (sv) {
+      n_out = (int64_t)sv->size;
+      ids.resize_discard(n_out > 0 ? n_out : 1);
+      res->vertex_ids = new device_array_t((size_t)n_out, INT32);
+      if (n_out > 0) {
+        HIP_TRY(hipMemcpyAsync(ids.data(), sv->data, n_out * 4, hipMemcpyDeviceToDevice, h.stream));
+        HIP_TRY(hipMemcpyAsync(res->vertex_ids->buf.ptr, sv->data, n_out * 4, hipMemcpyDeviceToDevice, h.stream));
+        renumber_ext_to_int(h, g, ids.data(), n_out);
+        CGA_EXPECTS(count_negative_i32(h, ids.data(), n_out) == 0, CUGRAPH_INVALID_INPUT, "Invalid input argument: source_vertices contains a vertex that is not in the graph");
+      }
+    } else {
+      res->vertex_ids = new device_array_t((size_t)nv, INT32);
+      if (nv > 0) HIP_TRY(hipMemcpyAsync(res->vertex_ids->buf.ptr, g.number_map.data(), nv * 4, hipMemcpyDeviceToDevice, h.stream));
+    }
+    auto emit = [&](dvec<int32_t> const& d) {
+      auto* a = new device_array_t((size_t)n_out, g.edge_type);
+      if (n_out > 0) {
+        if (sv) hipLaunchKernelGGL(k_gather_degrees, grid_for(n_out, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)d.data(), (int32_t const*)ids.data(), n_out, a->buf.as<int32_t>());
+        else HIP_TRY(hipMemcpyAsync(a->buf.ptr, d.data(), n_out * 4, hipMemcpyDeviceToDevice, h.stream));
+      }
+      return a;
+    };
+    if (want_in) res->in_degrees = emit(din);
+    if (want_out && !share) res->out_degrees = emit(dout);
+    h.sync();
+    *result = reinterpret_cast<cugraph_degrees_result_t*>(res.release());
+  });
+}
+
+// ---- extract_paths
+__global__ void k_max_path(int32_t const* dest, int64_t n, int32_t const* dist, int32_t const* pred, int32_t* out_max, int32_t* bad)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t const v = dest[i];
+  if (v < 0) { *bad = 1; return; }
+  int32_t const d = dist[v];
+  if (pred[v] >= 0 && d != INT32_MAX) atomicMax(out_max, d);  // compute_max_distance: 0 for vertices without a predecessor
+}
+
+// one thread walks one path back from its destination (BFS depths are tens of hops, so the walk is short and the rows of the
+// matrix are written by consecutive threads)
+__global__ void k_walk_paths(int32_t const* dest, int64_t n, int32_t const* dist, int32_t const* pred_int, int32_t const* number_map, int64_t L,
+                             int32_t* paths)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t v = dest[i];
+  int32_t d = dist[v];
+  if (d == INT32_MAX || (int64_t)d >= L) return;  // unreached destination: the row stays invalid (-1)
+  for (int32_t pos = d; pos >= 0 && v >= 0; --pos) {
+    paths[i * L + pos] = number_map[v];
+    v                  = pred_int[v];
+  }
+}
+
+}  // namespace
+}  // namespace cga
+
+using namespace cga;
+
+extern "C" cugraph_error_code_t cugraph_in_degrees(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+                                                   const cugraph_type_erased_device_array_view_t* source_vertices, bool_t /*do_expensive_check*/,
+                                                   cugraph_degrees_result_t** result, cugraph_error_t** error)
+{
+  return degrees_impl(handle, graph, source_vertices, true, false, result, error);
+}
+extern "C" cugraph_error_code_t cugraph_out_degrees(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+                                                    const cugraph_type_erased_device_array_view_t* source_vertices, bool_t /*do_expensive_check*/,
+                                                    cugraph_degrees_result_t** result, cugraph_error_t** error)
+{
+  return degrees_impl(handle, graph, source_vertices, false, true, result, error);
+}
+extern "C" cugraph_error_code_t cugraph_degrees(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+                                                const cugraph_type_erased_device_array_view_t* source_vertices, bool_t /*do_expensive_check*/,
+                                                cugraph_degrees_result_t** result, cugraph_error_t** error)
+{
+  return degrees_impl(handle, graph, source_vertices, true, true, result, error);
+}
+
+static degrees_result_t& DR(cugraph_degrees_result_t* r) { return *reinterpret_cast<degrees_result_t*>(r); }
+static cugraph_type_erased_device_array_view_t* as_view(device_array_t* a)
+{
+  return a ? reinterpret_cast<cugraph_type_erased_device_array_view_t*>(a->new_view()) : nullptr;
+}
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_degrees_result_get_vertices(cugraph_degrees_result_t* r) { return as_view(DR(r).vertex_ids); }
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_degrees_result_get_in_degrees(cugraph_degrees_result_t* r) { return as_view(DR(r).in_degrees); }
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_degrees_result_get_out_degrees(cugraph_degrees_result_t* r)
+{  // degrees_result.cpp:30-42: a symmetric graph's out-degrees ARE its in-degrees
+  degrees_result_t& d = DR(r);
+  return d.out_degrees ? as_view(d.out_degrees) : d.is_symmetric ? as_view(d.in_degrees) : nullptr;
+}
+extern "C" void cugraph_degrees_result_free(cugraph_degrees_result_t* r) { delete reinterpret_cast<degrees_result_t*>(r); }
+
+extern "C" cugraph_error_code_t cugraph_extract_paths(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+                                                      const cugraph_type_erased_device_array_view_t* /*sources*/,
+                                                      const cugraph_paths_result_t* paths_result,
+                                                      const cugraph_type_erased_device_array_view_t* destinations,
+                                                      cugraph_extract_paths_result_t** result, cugraph_error_t** error)
+{
+  if (result) *result = nullptr;
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    graph_t& g        = G(graph);
+    auto pr           = reinterpret_cast<paths_result_t const*>(paths_result);
+    auto dv           = reinterpret_cast<device_array_view_t const*>(destinations);
+    CGA_EXPECTS(result != nullptr && pr != nullptr && dv != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
+    CGA_EXPECTS(pr->distances != nullptr && pr->distances->type == g.vertex_type, CUGRAPH_INVALID_INPUT,
+                "Invalid input argument: distances must come from cugraph_bfs (vertex-typed hop counts)");
+    CGA_EXPECTS(pr->predecessors != nullptr && (int64_t)pr->predecessors->size == g.nv, CUGRAPH_INVALID_INPUT,
+                "Invalid input argument: predecessors cannot be null");  // extract_bfs_paths_impl.cuh:140-142
+    CGA_EXPECTS(dv->type == g.vertex_type, CUGRAPH_INVALID_INPUT, "vertex type of graph and destinations must match");
+    HIP_TRY(hipSetDevice(h.device));
+    int64_t const nv = g.nv, nd = (int64_t)dv->size;
+    dvec<int32_t> dest(nd > 0 ? nd : 1), pred(nv > 0 ? nv : 1), scal(2);
+    if (nd > 0) HIP_TRY(hipMemcpyAsync(dest.data(), dv->data, nd * 4, hipMemcpyDeviceToDevice, h.stream));
+    if (nv > 0) HIP_TRY(hipMemcpyAsync(pred.data(), pr->predecessors->buf.ptr, nv * 4, hipMemcpyDeviceToDevice, h.stream));
+    renumber_ext_to_int(h, g, dest.data(), nd);   // extract_paths.cpp:93-109: destinations and predecessors to internal ids
+    renumber_ext_to_int(h, g, pred.data(), nv);   // -1 (no predecessor) stays negative
+    HIP_TRY(hipMemsetAsync(scal.data(), 0, 2 * sizeof(int32_t), h.stream));
+    int32_t const* dist = pr->distances->buf.as<int32_t>();
+    if (nd > 0) hipLaunchKernelGGL(k_max_path, grid_for(nd), kBlock, 0, h.stream, (int32_t const*)dest.data(), nd, dist, (int32_t const*)pred.data(), scal.data(), scal.data() + 1);
+    int32_t hs[2] = {0, 0};
+    h.read_back(hs, scal.data(), 2);
+    CGA_EXPECTS(hs[1] == 0, CUGRAPH_INVALID_INPUT, "Invalid input argument: destinations contains a vertex that is not in the graph");
+    int64_t const L = (int64_t)hs[0] + 1;  // extract_bfs_paths_impl.cuh:165-173
+    auto res        = std::make_unique<extract_paths_result_t>();
+    res->max_path_length = (size_t)L;
+    res->paths      = new device_array_t((size_t)(nd * L), g.vertex_type);
+    if (nd > 0) {
+      HIP_TRY(hipMemsetAsync(res->paths->buf.ptr, 0xFF, (size_t)(nd * L) * 4, h.stream));  // invalid_vertex_id = -1
+      hipLaunchKernelGGL(k_walk_paths, grid_for(nd), kBlock, 0, h.stream, (int32_t const*)dest.data(), nd, dist, (int32_t const*)pred.data(),
+                         (int32_t const*)g.number_map.data(), L, res->paths->buf.as<int32_t>());
+    }
+    h.sync();
+    *result = reinterpret_cast<cugraph_extract_paths_result_t*>(res.release());
+  });
+}
+
+extern "C" size_t cugraph_extract_paths_result_get_max_path_length(cugraph_extract_paths_result_t* result)
+{
+  return reinterpret_cast<extract_paths_result_t*>(result)->max_path_length;
+}
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_extract_paths_result_get_paths(cugraph_extract_paths_result_t* result)
+{
+  return as_view(reinterpret_cast<extract_paths_result_t*>(result)->paths);
+}
+extern "C" void cugraph_extract_paths_result_free(cugraph_extract_paths_result_t* result) { delete reinterpret_cast<extract_paths_result_t*>(result); }

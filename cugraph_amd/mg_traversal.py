@@ -337,7 +337,7 @@ class MGTraversal:
         sources = torch.as_tensor(sources, dtype=torch.int64).reshape(-1)
         if sources.numel() and (int(sources.min()) < 0 or int(sources.max()) >= self.nv):
             raise ValueError("Found invalid vertex in the input sources")  # bfs.cpp:106-119
-        pos = part.pos.cpu()[sources]
+        pos = part.pos[sources.to(part.pos.device)].cpu()
         mine = pos[pos % world == self.rank] // world
         e.reset(mine.to(torch.int32), cutoff, compute_predecessors)
         if self.mode == 0:

@@ -311,6 +311,77 @@ def bfs(handle, graph, sources, direction_optimizing, depth_limit, compute_prede
     return (distances, predecessors, vertices)
 
 
+def bfs_extract_paths(handle, graph, sources, destinations, direction_optimizing=False, depth_limit=0):
+    """cugraph_bfs with predecessors followed by cugraph_extract_paths (traversal_algorithms.h:167-201) on the same result,
+    the way cpp/tests/c_api/extract_paths_test.c drives it.  Returns (distances, predecessors, vertices, paths) with paths a
+    (len(destinations), max_path_length) int32 matrix of external ids padded with -1."""
+    l = capi.lib()
+    _describe(sources)
+    _describe(destinations)
+    if depth_limit <= 0:
+        depth_limit = INT_MAX - 1
+    v, dv = _View(sources), _View(destinations)
+    res, ext, err = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _sync_torch()
+    h = handle.c_resource_handle_ptr
+    try:
+        code = l.cugraph_bfs(h, graph.c_graph_ptr, v.ptr, int(direction_optimizing), int(depth_limit), 1, 0, C.byref(res), C.byref(err))
+        assert_success(code, err, "cugraph_bfs")
+        code = l.cugraph_extract_paths(h, graph.c_graph_ptr, v.ptr, res, dv.ptr, C.byref(ext), C.byref(err))
+        assert_success(code, err, "cugraph_extract_paths")
+        distances = copy_to_torch(h, l.cugraph_paths_result_get_distances(res))
+        predecessors = copy_to_torch(h, l.cugraph_paths_result_get_predecessors(res))
+        vertices = copy_to_torch(h, l.cugraph_paths_result_get_vertices(res))
+        length = int(l.cugraph_extract_paths_result_get_max_path_length(ext))
+        paths = copy_to_torch(h, l.cugraph_extract_paths_result_get_paths(ext)).reshape(-1, length)
+    finally:
+        v.free()
+        dv.free()
+        if ext:
+            l.cugraph_extract_paths_result_free(ext)
+        if res:
+            l.cugraph_paths_result_free(res)
+    return (distances, predecessors, vertices, paths)
+
+
+def _degrees(name, resource_handle, graph, source_vertices, do_expensive_check, want_in, want_out):
+    l = capi.lib()
+    sv = None
+    if source_vertices is not None:
+        _describe(source_vertices)
+        sv = _View(source_vertices)
+    res, err = C.c_void_p(), C.c_void_p()
+    _sync_torch()
+    code = getattr(l, name)(resource_handle.c_resource_handle_ptr, graph.c_graph_ptr, (sv.ptr if sv else None), int(do_expensive_check),
+                            C.byref(res), C.byref(err))
+    if sv:
+        sv.free()
+    assert_success(code, err, name)
+    h = resource_handle.c_resource_handle_ptr
+    out = [copy_to_torch(h, l.cugraph_degrees_result_get_vertices(res))]
+    if want_in:
+        out.append(copy_to_torch(h, l.cugraph_degrees_result_get_in_degrees(res)))
+    if want_out:
+        out.append(copy_to_torch(h, l.cugraph_degrees_result_get_out_degrees(res)))
+    l.cugraph_degrees_result_free(res)
+    return tuple(out)
+
+
+def in_degrees(resource_handle, graph, source_vertices=None, do_expensive_check=False):
+    """degrees.pyx in_degrees: (vertices, in_degrees)."""
+    return _degrees("cugraph_in_degrees", resource_handle, graph, source_vertices, do_expensive_check, True, False)
+
+
+def out_degrees(resource_handle, graph, source_vertices=None, do_expensive_check=False):
+    """degrees.pyx out_degrees: (vertices, out_degrees)."""
+    return _degrees("cugraph_out_degrees", resource_handle, graph, source_vertices, do_expensive_check, False, True)
+
+
+def degrees(resource_handle, graph, source_vertices=None, do_expensive_check=False):
+    """degrees.pyx degrees: (vertices, in_degrees, out_degrees)."""
+    return _degrees("cugraph_degrees", resource_handle, graph, source_vertices, do_expensive_check, True, True)
+
+
 def sssp(resource_handle, graph, source, cutoff, compute_predecessors, do_expensive_check):
     """sssp.pyx:48-168.  Returns (vertices, distances, predecessors)."""
     l = capi.lib()

@@ -6,7 +6,12 @@
  * whose type differs from the graph's vertex type, or a source that is not a vertex of the graph,
  * gives CUGRAPH_INVALID_INPUT (bfs.cpp:106-119, 198-205).  depth_limit semantics bfs_impl.cuh:867-868.
  * Predecessors are deterministic here (minimum-id parent; SSSP: lexicographic min (distance, parent)
- * as sssp_impl.cuh:334), a valid instance of the reference's reduce_op::any. */
+ * as sssp_impl.cuh:334), a valid instance of the reference's reduce_op::any.
+ *
+ * cugraph_extract_paths (traversal_algorithms.h:167-201, impl cpp/src/c_api/extract_paths.cpp:24-170 over
+ * cugraph::extract_bfs_paths, cpp/src/traversal/extract_bfs_paths_impl.cuh:130-240): for every destination the path from its
+ * BFS source, as one row of a row-major (n_destinations x max_path_length) matrix of external ids padded with -1;
+ * max_path_length = 1 + the largest hop count among the destinations.  Takes the result of cugraph_bfs with predecessors. */
 #pragma once
 #include <cugraph_c/error.h>
 #include <cugraph_c/graph.h>
@@ -28,6 +33,14 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_sssp(
   const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, size_t source, double cutoff,
   bool_t compute_predecessors, bool_t do_expensive_check, cugraph_paths_result_t** result,
   cugraph_error_t** error);
+typedef struct { int32_t align_; } cugraph_extract_paths_result_t;
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_extract_paths(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, const cugraph_type_erased_device_array_view_t* sources,
+  const cugraph_paths_result_t* paths_result, const cugraph_type_erased_device_array_view_t* destinations,
+  cugraph_extract_paths_result_t** result, cugraph_error_t** error);
+CUGRAPH_EXPORT size_t cugraph_extract_paths_result_get_max_path_length(cugraph_extract_paths_result_t* result);
+CUGRAPH_EXPORT cugraph_type_erased_device_array_view_t* cugraph_extract_paths_result_get_paths(cugraph_extract_paths_result_t* result);
+CUGRAPH_EXPORT void cugraph_extract_paths_result_free(cugraph_extract_paths_result_t* result);
 #ifdef __cplusplus
 }
 #endif

@@ -101,8 +101,39 @@ int main(void)
       OK(cugraph_type_erased_device_array_view_copy_to_host(h, (byte_t*)p, pv, &err));
       for (int i = 0; i < 6; ++i) CHECK(d[i] == ed[v[i]] && p[i] == ep[v[i]], "bfs distance / predecessor");
       cugraph_type_erased_device_array_view_free(vv); cugraph_type_erased_device_array_view_free(dv); cugraph_type_erased_device_array_view_free(pv);
+      /* extract_paths_test.c test_bfs_with_extract_paths: destination 5 -> max path length 4, path 0 1 3 5 */
+      {
+        int32_t dest = 5, path[4], ex[] = {0, 1, 3, 5};
+        cugraph_type_erased_device_array_t* ad; cugraph_type_erased_device_array_view_t* vdst;
+        if (upload(h, &dest, 1, INT32, &ad, &vdst)) return 1;
+        cugraph_extract_paths_result_t* er = NULL;
+        OK(cugraph_extract_paths(h, g, vs, r, vdst, &er, &err));
+        CHECK(cugraph_extract_paths_result_get_max_path_length(er) == 4, "max path length");
+        cugraph_type_erased_device_array_view_t* pth = cugraph_extract_paths_result_get_paths(er);
+        CHECK(cugraph_type_erased_device_array_view_size(pth) == 4, "paths size");
+        OK(cugraph_type_erased_device_array_view_copy_to_host(h, (byte_t*)path, pth, &err));
+        for (int i = 0; i < 4; ++i) CHECK(path[i] == ex[i], "extracted path");
+        cugraph_type_erased_device_array_view_free(pth);
+        cugraph_extract_paths_result_free(er);
+        cugraph_type_erased_device_array_view_free(vdst); cugraph_type_erased_device_array_free(ad);
+      }
       cugraph_paths_result_free(r);
       cugraph_type_erased_device_array_view_free(vs); cugraph_type_erased_device_array_free(as);
+    }
+    /* degrees (degrees_test.c test_degrees) */
+    {
+      int32_t ein[] = {1, 2, 0, 2, 1, 2}, eout[] = {1, 2, 3, 1, 1, 0}, v[6], di[6], dout[6];
+      cugraph_degrees_result_t* dr = NULL;
+      OK(cugraph_degrees(h, g, NULL, FALSE, &dr, &err));
+      cugraph_type_erased_device_array_view_t *vv = cugraph_degrees_result_get_vertices(dr), *iv = cugraph_degrees_result_get_in_degrees(dr),
+                                              *ov = cugraph_degrees_result_get_out_degrees(dr);
+      CHECK(vv != NULL && iv != NULL && ov != NULL && cugraph_type_erased_device_array_view_size(vv) == 6, "degrees result shape");
+      OK(cugraph_type_erased_device_array_view_copy_to_host(h, (byte_t*)v, vv, &err));
+      OK(cugraph_type_erased_device_array_view_copy_to_host(h, (byte_t*)di, iv, &err));
+      OK(cugraph_type_erased_device_array_view_copy_to_host(h, (byte_t*)dout, ov, &err));
+      for (int i = 0; i < 6; ++i) CHECK(di[i] == ein[v[i]] && dout[i] == eout[v[i]], "in / out degree");
+      cugraph_type_erased_device_array_view_free(vv); cugraph_type_erased_device_array_view_free(iv); cugraph_type_erased_device_array_view_free(ov);
+      cugraph_degrees_result_free(dr);
     }
     /* SSSP from 0 (sssp_test.c test_sssp) */
     {

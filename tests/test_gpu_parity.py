@@ -627,3 +627,94 @@ def test_graph_creation_expensive_check(cg, handle):
                do_expensive_check=True)
     cg.SGGraph(handle, plain, T([10, 11], np.int32), T([11, 12], np.int32), vertices_array=T([10, 11, 12, 40], np.int32), renumber=True,
                do_expensive_check=True)
+
+
+# ---------------------------------------------------------------- degrees / extract_paths
+GOLD_SRC = [0, 1, 1, 2, 2, 2, 3, 4]
+GOLD_DST = [1, 3, 4, 0, 1, 3, 5, 5]
+GOLD_WGT = [0.1, 2.1, 1.1, 5.1, 3.1, 4.1, 7.2, 3.2]
+
+
+@pytest.mark.parametrize("store_transposed", [False, True])
+@pytest.mark.parametrize("renumber", [False, True])
+def test_capi_degrees_golden(cg, handle, store_transposed, renumber):
+    """cpp/tests/c_api/degrees_test.c: test_degrees, test_in_degrees, test_out_degrees, test_degrees_subset."""
+    g = cg.SGGraph(handle, cg.GraphProperties(), T(GOLD_SRC, np.int32), T(GOLD_DST, np.int32), T(GOLD_WGT, np.float32),
+                   store_transposed=store_transposed, renumber=renumber)
+    want_in, want_out = np.array([1, 2, 0, 2, 1, 2]), np.array([1, 2, 3, 1, 1, 0])
+    v, din, dout = cg.degrees(handle, g)
+    v = v.cpu().numpy()
+    assert sorted(v.tolist()) == list(range(6))
+    assert np.array_equal(din.cpu().numpy(), want_in[v]) and np.array_equal(dout.cpu().numpy(), want_out[v])
+    v, din = cg.in_degrees(handle, g)
+    assert np.array_equal(din.cpu().numpy(), want_in[v.cpu().numpy()])
+    v, dout = cg.out_degrees(handle, g)
+    assert np.array_equal(dout.cpu().numpy(), want_out[v.cpu().numpy()])
+    v, din, dout = cg.degrees(handle, g, T([2, 3, 5], np.int32))
+    assert v.cpu().numpy().tolist() == [2, 3, 5]
+    assert din.cpu().numpy().tolist() == [0, 2, 2] and dout.cpu().numpy().tolist() == [3, 1, 0]
+    with pytest.raises(ValueError):
+        cg.degrees(handle, g, T([2, 17], np.int32))
+
+
+def test_capi_degrees_symmetric_golden(cg, handle):
+    """degrees_test.c test_degrees_symmetric: the out-degrees of a symmetric graph are served from its in-degrees."""
+    s = GOLD_SRC + GOLD_DST
+    d = GOLD_DST + GOLD_SRC
+    g = cg.SGGraph(handle, cg.GraphProperties(is_symmetric=True), T(s, np.int32), T(d, np.int32), T(GOLD_WGT + GOLD_WGT, np.float32), renumber=True)
+    v, din, dout = cg.degrees(handle, g)
+    want = np.array([2, 4, 3, 3, 2, 2])
+    v = v.cpu().numpy()
+    assert np.array_equal(din.cpu().numpy(), want[v]) and np.array_equal(dout.cpu().numpy(), want[v])
+
+
+def test_degrees_rmat_with_multi_edges(cg, handle, orc):
+    """every edge counts (multi-edges, self-loops), whichever orientation the graph stores"""
+    s, d = rmat_graph(orc, 12)
+    nv = 1 << 12
+    for st in (False, True):
+        g = cg.SGGraph(handle, cg.GraphProperties(is_multigraph=True), T(s, np.int32), T(d, np.int32), store_transposed=st, renumber=True,
+                       vertices_array=T(np.arange(nv), np.int32))
+        v, din, dout = cg.degrees(handle, g)
+        v = v.cpu().numpy()
+        assert np.array_equal(din.cpu().numpy(), np.bincount(d, minlength=nv)[v])
+        assert np.array_equal(dout.cpu().numpy(), np.bincount(s, minlength=nv)[v])
+
+
+@pytest.mark.parametrize("store_transposed", [False, True])
+def test_capi_extract_paths_golden(cg, handle, store_transposed):
+    """cpp/tests/c_api/extract_paths_test.c: test_bfs_with_extract_paths(_with_transpose): seeds {0}, destinations {5} ->
+    max path length 4, path 0 1 3 5."""
+    g = cg.SGGraph(handle, cg.GraphProperties(), T(GOLD_SRC, np.int32), T(GOLD_DST, np.int32), T(GOLD_WGT, np.float32),
+                   store_transposed=store_transposed, renumber=False)
+    dist, pred, verts, paths = cg.bfs_extract_paths(handle, g, T([0], np.int32), T([5], np.int32), depth_limit=10)
+    assert paths.shape == (1, 4) and paths.cpu().numpy().tolist() == [[0, 1, 3, 5]]
+    # several destinations incl. the source itself and an unreachable vertex: rows padded with -1
+    dist, pred, verts, paths = cg.bfs_extract_paths(handle, g, T([0], np.int32), T([4, 0, 2, 5], np.int32))
+    assert paths.cpu().numpy().tolist() == [[0, 1, 4, -1], [0, -1, -1, -1], [-1, -1, -1, -1], [0, 1, 3, 5]]
+
+
+def test_extract_paths_rmat(cg, handle, orc):
+    """every extracted path is a shortest path: starts at the source, ends at the destination, consecutive vertices are joined
+    by an edge and the length equals the BFS distance"""
+    scale = 12
+    s, d = rmat_graph(orc, scale)
+    nv = 1 << scale
+    g = cg.SGGraph(handle, cg.GraphProperties(is_multigraph=True), T(s, np.int32), T(d, np.int32), renumber=True, vertices_array=T(np.arange(nv), np.int32))
+    src = int(np.flatnonzero(np.bincount(s, minlength=nv) > 0)[7])
+    dest = np.random.default_rng(5).choice(nv, 200, replace=False).astype(np.int32)
+    dist, pred, verts, paths = cg.bfs_extract_paths(handle, g, T([src], np.int32), T(dest, np.int32))
+    dd = np.empty(nv, np.int64)
+    dd[verts.cpu().numpy()] = dist.cpu().numpy()
+    edges = set(zip(s.tolist(), d.tolist()))
+    paths = paths.cpu().numpy()
+    INT32_MAX = orc.INT32_MAX
+    reach = dd[dest] != INT32_MAX
+    assert paths.shape[1] == 1 + int(dd[dest][reach & (dest != src)].max(initial=0))
+    for row, t in zip(paths, dest):
+        if dd[t] == INT32_MAX:
+            assert (row == -1).all()
+            continue
+        n = int(dd[t]) + 1
+        assert row[0] == src and row[n - 1] == t and (row[n:] == -1).all()
+        assert all((int(a), int(b)) in edges for a, b in zip(row[:n - 1], row[1:n]))
