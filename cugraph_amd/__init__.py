@@ -22,6 +22,7 @@ from .pylib import (  # noqa: F401
     out_degrees,
     pagerank,
     personalized_pagerank,
+    rmat_edgelist,
     sssp,
 )
 

@@ -99,6 +99,16 @@ PROTOTYPES = {
     "cugraph_personalized_pagerank": (C.c_int, [_P] * 8 + [C.c_double, C.c_double, C.c_size_t, C.c_int, _PP, _PP]),
     "cugraph_personalized_pagerank_allow_nonconvergence": (C.c_int, [_P] * 8 + [C.c_double, C.c_double, C.c_size_t, C.c_int, _PP, _PP]),
     # traversal_algorithms.h
+    "cugraph_rng_state_create": (C.c_int, [_P, C.c_uint64, _PP, _PP]),
+    "cugraph_rng_state_free": (None, [_P]),
+    "cugraph_generate_rmat_edgelist": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _PP, _PP]),
+    "cugraph_generate_edge_weights": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, _PP]),
+    "cugraph_coo_get_sources": (_P, [_P]),
+    "cugraph_coo_get_destinations": (_P, [_P]),
+    "cugraph_coo_get_edge_weights": (_P, [_P]),
+    "cugraph_coo_get_edge_id": (_P, [_P]),
+    "cugraph_coo_get_edge_type": (_P, [_P]),
+    "cugraph_coo_free": (None, [_P]),
     "cugraph_in_degrees": (C.c_int, [_P, _P, _P, C.c_int, _PP, _PP]),
     "cugraph_out_degrees": (C.c_int, [_P, _P, _P, C.c_int, _PP, _PP]),
     "cugraph_degrees": (C.c_int, [_P, _P, _P, C.c_int, _PP, _PP]),

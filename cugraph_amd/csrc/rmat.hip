@@ -4,6 +4,8 @@
 // bit-identical to oracle/oracle.c:orc_rmat, so the GPU path and the CPU oracle see the same edge list.
 #include "common.hpp"
 
+#include "cugraph_c/graph_generators.h"
+
 namespace cga {
 namespace {
 
@@ -15,8 +17,22 @@ __device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t counte
   return z ^ (z >> 31);
 }
 
+// Vertex-id permutation of the Graph500 generator (cpp/src/generators/scramble.cuh:41-67 uses the same construction): two
+// rounds of (add, multiply by an odd constant, reverse the low lgN bits) -- each step is a bijection on lgN-bit values.
+__device__ __forceinline__ int32_t scramble_id(int32_t value, int lgN)
+{
+  uint32_t const c0 = 282475248u, c1 = 2617694917u;
+  uint32_t v = (uint32_t)value;
+  v += c0 + c1;
+  v *= (c0 | 0x11493211u);
+  v = __brev(v) >> (32 - lgN);
+  v *= (c1 | 0x02C843A5u);
+  v = __brev(v) >> (32 - lgN);
+  return (int32_t)v;
+}
+
 __global__ void k_rmat(int scale, uint64_t first_edge, uint64_t num_edges, uint32_t t_ab, uint32_t t_an, uint32_t t_cn, uint64_t seed,
-                       int32_t* src, int32_t* dst)
+                       int32_t* src, int32_t* dst, int clip_and_flip = 0, int scramble = 0)
 {
   uint64_t k      = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -28,9 +44,11 @@ __global__ void k_rmat(int scale, uint64_t first_edge, uint64_t num_edges, uint3
       uint32_t r0 = (uint32_t)(z >> 32), r1 = (uint32_t)z;
       int sb      = r0 > t_ab;
       int db      = r1 > (sb ? t_cn : t_an);
+      if (clip_and_flip && s == d && !sb && db) { sb = 1; db = 0; }  // generate_rmat_edgelist.cuh:90-97: keep the lower triangle
       s |= sb << bit;
       d |= db << bit;
     }
+    if (scramble) { s = scramble_id(s, scale); d = scramble_id(d, scale); }
     src[k] = s;
     dst[k] = d;
   }
@@ -73,3 +91,112 @@ extern "C" cugraph_error_code_t cugraph_amd_generate_rmat_edgelist(const cugraph
     h.sync();
   });
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The reference's generator API: cugraph_rng_state_*, cugraph_generate_rmat_edgelist,
+// cugraph_generate_edge_weights, cugraph_coo_*.  Replaces cpp/src/c_api/random.cpp, cpp/src/c_api/graph_generators.cpp:24-330
+// (cugraph::generate_rmat_edgelist, cpp/src/generators/generate_rmat_edgelist.cuh:38-112).  The reference draws its uniforms
+// from raft::random (not vendored, so its streams cannot be reproduced); here the state is (seed, number of edges drawn so
+// far) of the counter-based generator above, so a fresh state with seed s yields exactly the edge list of
+// cugraph_amd_generate_rmat_edgelist(seed = s) and of the CPU oracle.
+namespace cga {
+struct rng_state_t {
+  uint64_t seed{0};
+  uint64_t drawn{0};
+};
+struct coo_t {  // c_api/coo.hpp
+  device_array_t* src{nullptr};
+  device_array_t* dst{nullptr};
+  device_array_t* wgt{nullptr};
+  ~coo_t() { delete src; delete dst; delete wgt; }
+};
+namespace {
+template <typename T>
+__global__ void k_uniform_weights(T* w, uint64_t n, uint64_t seed, uint64_t first, double lo, double hi)
+{
+  uint64_t k      = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; k < n; k += stride) {
+    uint64_t const z = splitmix64_at(seed ^ 0x5851F42D4C957F2Dull, first + k);
+    double const u   = (double)(z >> 11) * (1.0 / 9007199254740992.0);  // [0, 1)
+    w[k]             = (T)(lo + (hi - lo) * u);
+  }
+}
+}  // namespace
+}  // namespace cga
+
+extern "C" cugraph_error_code_t cugraph_rng_state_create(const cugraph_resource_handle_t* handle, uint64_t seed, cugraph_rng_state_t** state,
+                                                         cugraph_error_t** error)
+{
+  if (state) *state = nullptr;
+  return guarded(error, [&] {
+    (void)H(handle);
+    CGA_EXPECTS(state != nullptr, CUGRAPH_INVALID_INPUT, "state is NULL");
+    *state = reinterpret_cast<cugraph_rng_state_t*>(new rng_state_t{seed, 0});
+  });
+}
+extern "C" void cugraph_rng_state_free(cugraph_rng_state_t* p) { delete reinterpret_cast<rng_state_t*>(p); }
+
+extern "C" cugraph_error_code_t cugraph_generate_rmat_edgelist(const cugraph_resource_handle_t* handle, cugraph_rng_state_t* rng_state, size_t scale,
+                                                               size_t num_edges, double a, double b, double c, bool_t clip_and_flip,
+                                                               bool_t scramble_vertex_ids, cugraph_coo_t** result, cugraph_error_t** error)
+{
+  if (result) *result = nullptr;
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    CGA_EXPECTS(rng_state != nullptr && result != nullptr, CUGRAPH_INVALID_INPUT, "rng_state / result is NULL");
+    CGA_EXPECTS(scale >= 1 && scale <= 30, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "Invalid input argument: scale too large for the 32-bit vertex type of this build.");
+    CGA_EXPECTS(a >= 0.0 && b >= 0.0 && c >= 0.0 && a + b + c <= 1.0, CUGRAPH_INVALID_INPUT,
+                "Invalid input argument: a, b, c should be non-negative and a + b + c should not be larger than 1.0.");
+    rng_state_t& st = *reinterpret_cast<rng_state_t*>(rng_state);
+    HIP_TRY(hipSetDevice(h.device));
+    auto coo = std::make_unique<coo_t>();
+    coo->src = new device_array_t(num_edges, INT32);
+    coo->dst = new device_array_t(num_edges, INT32);
+    double const a_plus_b = a + b;
+    double const a_norm   = a_plus_b > 0.0 ? a / a_plus_b : 0.0;
+    double const c_norm   = (1.0 - a_plus_b) > 0.0 ? c / (1.0 - a_plus_b) : 0.0;
+    if (num_edges > 0)
+      hipLaunchKernelGGL(k_rmat, grid_for((int64_t)num_edges, kBlock, 16384), kBlock, 0, h.stream, (int)scale, st.drawn, (uint64_t)num_edges,
+                         prob_to_u32(a_plus_b), prob_to_u32(a_norm), prob_to_u32(c_norm), st.seed, coo->src->buf.as<int32_t>(),
+                         coo->dst->buf.as<int32_t>(), clip_and_flip == TRUE ? 1 : 0, scramble_vertex_ids == TRUE ? 1 : 0);
+    h.sync();
+    st.drawn += num_edges;
+    *result = reinterpret_cast<cugraph_coo_t*>(coo.release());
+  });
+}
+
+extern "C" cugraph_error_code_t cugraph_generate_edge_weights(const cugraph_resource_handle_t* handle, cugraph_rng_state_t* rng_state, cugraph_coo_t* coo,
+                                                              cugraph_data_type_id_t dtype, double minimum_weight, double maximum_weight,
+                                                              cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    CGA_EXPECTS(rng_state != nullptr && coo != nullptr, CUGRAPH_INVALID_INPUT, "rng_state / coo is NULL");
+    CGA_EXPECTS(dtype == FLOAT32 || dtype == FLOAT64, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "weights must be FLOAT32 or FLOAT64");
+    rng_state_t& st = *reinterpret_cast<rng_state_t*>(rng_state);
+    coo_t& c        = *reinterpret_cast<coo_t*>(coo);
+    size_t const n  = c.src ? c.src->size : 0;
+    HIP_TRY(hipSetDevice(h.device));
+    delete c.wgt;
+    c.wgt = new device_array_t(n, dtype);
+    if (n > 0) {
+      int const g = grid_for((int64_t)n, kBlock, 16384);
+      if (dtype == FLOAT32) hipLaunchKernelGGL(k_uniform_weights<float>, g, kBlock, 0, h.stream, c.wgt->buf.as<float>(), (uint64_t)n, st.seed, st.drawn, minimum_weight, maximum_weight);
+      else hipLaunchKernelGGL(k_uniform_weights<double>, g, kBlock, 0, h.stream, c.wgt->buf.as<double>(), (uint64_t)n, st.seed, st.drawn, minimum_weight, maximum_weight);
+    }
+    h.sync();
+    st.drawn += n;
+  });
+}
+
+static cugraph_type_erased_device_array_view_t* coo_view(device_array_t* a)
+{
+  return a ? reinterpret_cast<cugraph_type_erased_device_array_view_t*>(a->new_view()) : nullptr;
+}
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_coo_get_sources(cugraph_coo_t* coo) { return coo_view(reinterpret_cast<coo_t*>(coo)->src); }
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_coo_get_destinations(cugraph_coo_t* coo) { return coo_view(reinterpret_cast<coo_t*>(coo)->dst); }
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_coo_get_edge_weights(cugraph_coo_t* coo) { return coo_view(reinterpret_cast<coo_t*>(coo)->wgt); }
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_coo_get_edge_id(cugraph_coo_t*) { return nullptr; }
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_coo_get_edge_type(cugraph_coo_t*) { return nullptr; }
+extern "C" void cugraph_coo_free(cugraph_coo_t* coo) { delete reinterpret_cast<coo_t*>(coo); }

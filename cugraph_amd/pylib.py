@@ -399,6 +399,34 @@ def sssp(resource_handle, graph, source, cutoff, compute_predecessors, do_expens
 
 
 # ------------------------------------------------------------------------------- harness extensions
+def rmat_edgelist(resource_handle, seed, scale, num_edges, a=0.57, b=0.19, c=0.19, clip_and_flip=False, scramble_vertex_ids=False,
+                  include_edge_weights=False, minimum_weight=0.0, maximum_weight=1.0, dtype=None):
+    """The reference's generator API (pylibcugraph generate_rmat_edgelist.pyx: cugraph_rng_state_create,
+    cugraph_generate_rmat_edgelist, cugraph_generate_edge_weights, cugraph_coo_*).  Returns (src, dst, weights or None)."""
+    l = capi.lib()
+    h = resource_handle.c_resource_handle_ptr
+    rng, coo, err = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert_success(l.cugraph_rng_state_create(h, int(seed), C.byref(rng), C.byref(err)), err, "cugraph_rng_state_create")
+    try:
+        code = l.cugraph_generate_rmat_edgelist(h, rng, int(scale), int(num_edges), float(a), float(b), float(c), int(clip_and_flip),
+                                                int(scramble_vertex_ids), C.byref(coo), C.byref(err))
+        assert_success(code, err, "cugraph_generate_rmat_edgelist")
+        w = None
+        if include_edge_weights:
+            t = capi.FLOAT64 if dtype in (torch.float64, "float64") else capi.FLOAT32
+            code = l.cugraph_generate_edge_weights(h, rng, coo, t, float(minimum_weight), float(maximum_weight), C.byref(err))
+            assert_success(code, err, "cugraph_generate_edge_weights")
+            w = copy_to_torch(h, l.cugraph_coo_get_edge_weights(coo))
+        src = copy_to_torch(h, l.cugraph_coo_get_sources(coo))
+        dst = copy_to_torch(h, l.cugraph_coo_get_destinations(coo))
+        assert not l.cugraph_coo_get_edge_id(coo) and not l.cugraph_coo_get_edge_type(coo)
+    finally:
+        if coo:
+            l.cugraph_coo_free(coo)
+        l.cugraph_rng_state_free(rng)
+    return src, dst, w
+
+
 def generate_rmat_edgelist(resource_handle, scale, num_edges, a=0.57, b=0.19, c=0.19, seed=0, first_edge=0):
     """On-device RMAT slice [first_edge, first_edge + num_edges) -> (src, dst) int32 tensors."""
     l = capi.lib()

@@ -718,3 +718,36 @@ def test_extract_paths_rmat(cg, handle, orc):
         n = int(dd[t]) + 1
         assert row[0] == src and row[n - 1] == t and (row[n:] == -1).all()
         assert all((int(a), int(b)) in edges for a, b in zip(row[:n - 1], row[1:n]))
+
+
+# ---------------------------------------------------------------- the reference's generator API
+def test_capi_generate_rmat_edgelist(cg, handle, orc):
+    """cugraph_generate_rmat_edgelist behind cugraph_rng_state_t / cugraph_coo_t: a fresh state with seed s gives the edge list of
+    the oracle (and of the benchmark generator); sizes and ranges as cpp/tests/c_api/generate_rmat_test.c checks them."""
+    scale, ne = 10, 5000
+    src, dst, w = cg.rmat_edgelist(handle, 0, scale, ne)
+    os_, od_ = orc.rmat(scale, ne, seed=0)
+    assert w is None and np.array_equal(src.cpu().numpy(), os_) and np.array_equal(dst.cpu().numpy(), od_)
+    src7, dst7, _ = cg.rmat_edgelist(handle, 7, scale, ne)
+    assert not np.array_equal(src7.cpu().numpy(), os_)
+    # clip_and_flip keeps the lower triangle (generate_rmat_edgelist.cuh:90-97)
+    s, d, _ = cg.rmat_edgelist(handle, 0, scale, ne, clip_and_flip=True)
+    s, d = s.cpu().numpy(), d.cpu().numpy()
+    assert (s >= d).all() and s.min() >= 0 and s.max() < (1 << scale)
+    # the id scramble is one permutation of [0, 2^scale) applied to both endpoints
+    s2, d2, _ = cg.rmat_edgelist(handle, 0, scale, ne, scramble_vertex_ids=True)
+    s2, d2 = s2.cpu().numpy(), d2.cpu().numpy()
+    perm = {}
+    for a, b in list(zip(os_.tolist(), s2.tolist())) + list(zip(od_.tolist(), d2.tolist())):
+        assert perm.setdefault(a, b) == b
+    assert len(set(perm.values())) == len(perm) and max(perm.values()) < (1 << scale) and min(perm.values()) >= 0
+    assert any(k != v for k, v in perm.items())
+    # weights: uniform in [lo, hi), the requested type
+    import torch
+    _, _, w = cg.rmat_edgelist(handle, 3, scale, ne, include_edge_weights=True, minimum_weight=2.0, maximum_weight=5.0)
+    w = w.cpu().numpy()
+    assert w.dtype == np.float32 and w.size == ne and w.min() >= 2.0 and w.max() < 5.0 and 3.3 < w.mean() < 3.7
+    _, _, w64 = cg.rmat_edgelist(handle, 3, scale, ne, include_edge_weights=True, dtype=torch.float64)
+    assert w64.cpu().numpy().dtype == np.float64
+    with pytest.raises(ValueError):
+        cg.rmat_edgelist(handle, 0, scale, ne, a=0.9, b=0.2, c=0.1)
