@@ -59,6 +59,7 @@ struct bfs_state {
 
 struct bfs_visit {
   bfs_state s;
+  wave_queue wq;
   unsigned long long acc_out{0}, acc_in{0};
   __device__ __forceinline__ void operator()(int32_t u, int32_t v, int32_t)
   {
@@ -79,10 +80,11 @@ struct bfs_visit {
       }
       if (s.pred && u < __builtin_nontemporal_load(&s.pred[v])) atomicMin(&s.pred[v], u);  // minimum internal id among the frontier parents
     }
-    wave_push(fresh, v, s.q_next, &s.cnt->n_next, threadIdx.x & 63);
+    wq.push(fresh, v);
   }
   __device__ __forceinline__ void flush()
   {
+    wq.flush();
     unsigned long long a = acc_out, b = acc_in;
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
     if ((threadIdx.x & 63) == 0 && (a | b)) { atomicAdd(&s.cnt->out_edges, a); atomicAdd(&s.cnt->in_edges, b); }
@@ -94,13 +96,17 @@ struct keep_all { __device__ __forceinline__ bool operator()(int32_t) const { re
 __global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices,
                                                          int32_t* bigq, bfs_state s)
 {
-  bfs_visit f{s};
+  __shared__ wave_queue_storage<1> wqs;
+  wqs.init();
+  bfs_visit f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next)};
   expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f);
   f.flush();
 }
 __global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, bfs_state s)
 {
-  bfs_visit f{s};
+  __shared__ wave_queue_storage<1> wqs;
+  wqs.init();
+  bfs_visit f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next)};
   expand_big(bigq, offsets, indices, s.cnt, f);
   f.flush();
 }
@@ -272,7 +278,9 @@ struct sssp_state {
 template <typename WT>
 struct sssp_relax {
   sssp_state<WT> s;
-  __device__ __forceinline__ void operator()(int32_t u, int32_t v, int32_t p) const
+  wave_queue wq_near, wq_far;
+  __device__ __forceinline__ void flush() { wq_near.flush(); wq_far.flush(); }
+  __device__ __forceinline__ void operator()(int32_t u, int32_t v, int32_t p)
   {
     using B  = dist_bits<WT>;
     WT du    = B::from(s.dist[u]);
@@ -288,9 +296,8 @@ struct sssp_relax {
         else                  far  = atomicExch(&s.mark_far[v], s.far_epoch) != s.far_epoch;
       }
     }
-    int lane = threadIdx.x & 63;
-    wave_push(near, v, s.q_next, &s.cnt->n_next, lane);
-    wave_push(far, v, s.far, &s.cnt->n_far, lane);
+    wq_near.push(near, v);
+    wq_far.push(far, v);
   }
 };
 
@@ -298,15 +305,21 @@ template <typename WT>
 __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices,
                                                           int32_t* bigq, sssp_state<WT> s)
 {
-  sssp_relax<WT> f{s};
+  __shared__ wave_queue_storage<2> wqs;
+  wqs.init();
+  sssp_relax<WT> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far)};
   expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f);
+  f.flush();
 }
 template <typename WT>
 __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices,
                                                               sssp_state<WT> s)
 {
-  sssp_relax<WT> f{s};
+  __shared__ wave_queue_storage<2> wqs;
+  wqs.init();
+  sssp_relax<WT> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far)};
   expand_big(bigq, offsets, indices, s.cnt, f);
+  f.flush();
 }
 
 // far pile -> (near frontier | far pile'): d < lower: settled meanwhile, drop; d < upper: near; else keep
@@ -642,6 +655,7 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   double avg_w   = g.ne > 0 ? wsum_h / (double)g.ne : 1.0;
   double avg_deg = nv > 0 ? (double)g.ne / (double)nv : 1.0;
   double delta   = avg_w * 32.0 / std::max(avg_deg, 1.0);
+  if (char const* e = getenv("CUGRAPH_AMD_SSSP_DELTA_SCALE")) delta *= atof(e);  // tuning knob (bucket width multiplier)
   if (!(delta > 0.0) || !std::isfinite(delta)) delta = 1.0;
 
   {  // d[source] = 0, near = {source}

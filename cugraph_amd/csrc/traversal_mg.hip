@@ -56,7 +56,8 @@ struct mg_bfs_state {
 
 struct mg_bfs_visit {
   mg_bfs_state s;
-  __device__ __forceinline__ void operator()(int32_t u, int32_t g, int32_t) const
+  wave_queue wq;
+  __device__ __forceinline__ void operator()(int32_t u, int32_t g, int32_t)
   {
     uint32_t const bit = 1u << (g & 31);
     bool fresh = false;
@@ -67,7 +68,7 @@ struct mg_bfs_visit {
       }
       if (!(__builtin_nontemporal_load(&s.touched[g >> 5]) & bit)) fresh = !(atomicOr(&s.touched[g >> 5], bit) & bit);
     }
-    wave_push(fresh, g, s.cand, &s.cnt->n_next, threadIdx.x & 63);
+    wq.push(fresh, g);
   }
 };
 
@@ -84,7 +85,8 @@ struct mg_sssp_state {
 
 struct mg_sssp_relax {
   mg_sssp_state s;
-  __device__ __forceinline__ void operator()(int32_t u, int32_t g, int32_t p) const
+  wave_queue wq;
+  __device__ __forceinline__ void operator()(int32_t u, int32_t g, int32_t p)
   {
     float const du = __uint_as_float((uint32_t)(s.st[u] >> 32));
     float const nd = du + s.weights[p];
@@ -97,7 +99,7 @@ struct mg_sssp_relax {
         if (!(__builtin_nontemporal_load(&s.touched[g >> 5]) & bit)) fresh = !(atomicOr(&s.touched[g >> 5], bit) & bit);
       }
     }
-    wave_push(fresh, g, s.cand, &s.cnt->n_next, threadIdx.x & 63);
+    wq.push(fresh, g);
   }
 };
 
@@ -106,24 +108,36 @@ struct keep_all_mg { __device__ __forceinline__ bool operator()(int32_t) const {
 __global__ void __launch_bounds__(TV_BLOCK) k_mg_bfs_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices, int32_t* bigq,
                                                             mg_bfs_state s)
 {
-  mg_bfs_visit f{s};
+  __shared__ wave_queue_storage<1> wqs;
+  wqs.init();
+  mg_bfs_visit f{s, wave_queue(wqs, 0, s.cand, &s.cnt->n_next)};
   expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all_mg{}, f);
+  f.wq.flush();
 }
 __global__ void __launch_bounds__(TV_BLOCK) k_mg_bfs_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, mg_bfs_state s)
 {
-  mg_bfs_visit f{s};
+  __shared__ wave_queue_storage<1> wqs;
+  wqs.init();
+  mg_bfs_visit f{s, wave_queue(wqs, 0, s.cand, &s.cnt->n_next)};
   expand_big(bigq, offsets, indices, s.cnt, f);
+  f.wq.flush();
 }
 __global__ void __launch_bounds__(TV_BLOCK) k_mg_sssp_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices, int32_t* bigq,
                                                              mg_sssp_state s)
 {
-  mg_sssp_relax f{s};
+  __shared__ wave_queue_storage<1> wqs;
+  wqs.init();
+  mg_sssp_relax f{s, wave_queue(wqs, 0, s.cand, &s.cnt->n_next)};
   expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all_mg{}, f);
+  f.wq.flush();
 }
 __global__ void __launch_bounds__(TV_BLOCK) k_mg_sssp_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, mg_sssp_state s)
 {
-  mg_sssp_relax f{s};
+  __shared__ wave_queue_storage<1> wqs;
+  wqs.init();
+  mg_sssp_relax f{s, wave_queue(wqs, 0, s.cand, &s.cnt->n_next)};
   expand_big(bigq, offsets, indices, s.cnt, f);
+  f.wq.flush();
 }
 
 // ---- bucketing by owner: counting sort of the candidate list.  Workgroup b owns the contiguous slice
