@@ -29,31 +29,6 @@ __global__ void k_mark(int32_t const* ids, int64_t n, int64_t vmin, uint32_t* fl
   for (; i < n; i += stride) flags[(int64_t)ids[i] - vmin] = 1u;
 }
 
-// deg[rank[major - vmin]] += 1
-__global__ void k_degree_compact(int32_t const* major, int64_t n, int64_t vmin, uint32_t const* rank, uint32_t* deg)
-{
-  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t n_pad  = (n + 63) & ~(int64_t)63;
-  int const lane = threadIdx.x & 63;
-  for (; i < n_pad; i += stride) {
-    // hub vertices dominate power-law inputs: lanes holding the same id as the wave's first active lane are
-    // counted with one atomic (repeat until every lane is served; random inputs finish in a few rounds)
-    bool todo  = i < n;
-    uint32_t c = todo ? rank[(int64_t)major[i] - vmin] : 0u;
-    for (int round = 0; round < 4; ++round) {
-      uint64_t m = __ballot(todo);
-      if (!m) break;
-      int leader    = __ffsll((unsigned long long)m) - 1;
-      uint32_t lead = __shfl(c, leader);
-      bool same     = todo && c == lead;
-      uint64_t sm   = __ballot(same);
-      if (lane == leader) atomicAdd(&deg[lead], (uint32_t)__popcll(sm));
-      todo = todo && !same;
-    }
-    if (todo) atomicAdd(&deg[c], 1u);
-  }
-}
 
 __global__ void k_degree_keys(uint32_t const* deg, int64_t n, uint32_t maxdeg, uint64_t* keys, uint32_t* vals)
 {
@@ -409,7 +384,7 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
       dvec<uint32_t> deg(nv > 0 ? nv : 1);
       HIP_TRY(hipMemsetAsync(deg.data(), 0, (nv > 0 ? nv : 1) * 4, h.stream));
       int32_t const* major_ext = store_transposed == TRUE ? d.data() : s.data();
-      if (ne2 > 0) hipLaunchKernelGGL(k_degree_compact, grid_for(ne2, kBlock, 8192), kBlock, 0, h.stream, major_ext, ne2, (int64_t)vmin, (uint32_t const*)rank.data(), deg.data());
+      histogram_i32_mapped(h, major_ext, ne2, (int64_t)vmin, (uint32_t const*)rank.data(), deg.data());
       int32_t dmin = 0, dmax = 0;
       if (nv > 0) minmax_i32(h, reinterpret_cast<int32_t const*>(deg.data()), nv, &dmin, &dmax);
       dvec<uint64_t> keys(nv > 0 ? nv : 1), keys_tmp(nv > 0 ? nv : 1);
