@@ -22,6 +22,7 @@ from .pylib import (  # noqa: F401
     out_degrees,
     pagerank,
     personalized_pagerank,
+    read_matrix_market,
     rmat_edgelist,
     sssp,
 )

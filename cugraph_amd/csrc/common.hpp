@@ -290,6 +290,13 @@ struct centrality_result_t {  // c_api/centrality_result.hpp
   size_t num_iterations;
   bool converged;
 };
+struct coo_t {  // behind cugraph_coo_t (c_api/coo.hpp)
+  device_array_t* src{nullptr};
+  device_array_t* dst{nullptr};
+  device_array_t* wgt{nullptr};
+  ~coo_t() { delete src; delete dst; delete wgt; }
+};
+
 struct paths_result_t {  // c_api/paths_result.hpp
   device_array_t* vertex_ids;
   device_array_t* distances;

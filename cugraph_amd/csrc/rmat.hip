@@ -104,12 +104,6 @@ struct rng_state_t {
   uint64_t seed{0};
   uint64_t drawn{0};
 };
-struct coo_t {  // c_api/coo.hpp
-  device_array_t* src{nullptr};
-  device_array_t* dst{nullptr};
-  device_array_t* wgt{nullptr};
-  ~coo_t() { delete src; delete dst; delete wgt; }
-};
 namespace {
 template <typename T>
 __global__ void k_uniform_weights(T* w, uint64_t n, uint64_t seed, uint64_t first, double lo, double hi)

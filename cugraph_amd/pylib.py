@@ -427,6 +427,24 @@ def rmat_edgelist(resource_handle, seed, scale, num_edges, a=0.57, b=0.19, c=0.1
     return src, dst, w
 
 
+def read_matrix_market(resource_handle, path):
+    """MatrixMarket coordinate file -> (src, dst, weights, num_vertices, is_symmetric, has_weights) on the device
+    (cugraph_amd_read_matrix_market; conventions of the reference's test reader, matrix_market_file_utilities.cu)."""
+    l = capi.lib()
+    h = resource_handle.c_resource_handle_ptr
+    coo, err = C.c_void_p(), C.c_void_p()
+    nv, sym, hw = C.c_size_t(0), C.c_int(0), C.c_int(0)
+    code = l.cugraph_amd_read_matrix_market(h, str(path).encode(), C.byref(coo), C.byref(nv), C.byref(sym), C.byref(hw), C.byref(err))
+    assert_success(code, err, "cugraph_amd_read_matrix_market")
+    try:
+        src = copy_to_torch(h, l.cugraph_coo_get_sources(coo))
+        dst = copy_to_torch(h, l.cugraph_coo_get_destinations(coo))
+        w = copy_to_torch(h, l.cugraph_coo_get_edge_weights(coo))
+    finally:
+        l.cugraph_coo_free(coo)
+    return src, dst, w, int(nv.value), bool(sym.value), bool(hw.value)
+
+
 def generate_rmat_edgelist(resource_handle, scale, num_edges, a=0.57, b=0.19, c=0.19, seed=0, first_edge=0):
     """On-device RMAT slice [first_edge, first_edge + num_edges) -> (src, dst) int32 tensors."""
     l = capi.lib()

@@ -7,6 +7,7 @@
 #include <cugraph_c/array.h>
 #include <cugraph_c/centrality_algorithms.h>
 #include <cugraph_c/graph.h>
+#include <cugraph_c/graph_generators.h>
 #include <cugraph_c/resource_handle.h>
 #ifdef __cplusplus
 extern "C" {
@@ -116,6 +117,13 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_merge_visited(
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_results(cugraph_amd_traversal_mg_plan_t* plan, void* distances,
                                                                           int32_t* predecessors, cugraph_error_t** error);
 CUGRAPH_EXPORT void cugraph_amd_traversal_mg_plan_free(cugraph_amd_traversal_mg_plan_t* plan);
+
+/* MatrixMarket coordinate file -> device edge list (the format of the reference's datasets/karate.mtx etc.; conventions of
+ * cpp/tests/utilities/matrix_market_file_utilities.cu: 0-based ids, `pattern` -> weight 1, a `symmetric` file's off-diagonal
+ * entries are mirrored, vertex count = matrix dimension).  The result is a cugraph_coo_t (INT32 ids, FLOAT32 weights). */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_read_matrix_market(const cugraph_resource_handle_t* handle, const char* path,
+                                                                   cugraph_coo_t** result, size_t* num_vertices, bool_t* is_symmetric,
+                                                                   bool_t* has_weights, cugraph_error_t** error);
 
 /* Blocks until everything queued on the handle's stream has finished. */
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_handle_sync(const cugraph_resource_handle_t* handle,

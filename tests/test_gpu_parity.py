@@ -751,3 +751,48 @@ def test_capi_generate_rmat_edgelist(cg, handle, orc):
     assert w64.cpu().numpy().dtype == np.float64
     with pytest.raises(ValueError):
         cg.rmat_edgelist(handle, 0, scale, ne, a=0.9, b=0.2, c=0.1)
+
+
+# ---------------------------------------------------------------- MatrixMarket reader
+def test_read_matrix_market(cg, handle, golden, tmp_path):
+    """The karate graph written the way datasets/karate.mtx stores it (symmetric, one triangle, 1-based, comments) reads back as
+    the 156 directed edges of karate.csv and reproduces the pylibcugraph PageRank golden; general / pattern / integer files,
+    isolated vertices and malformed input."""
+    gr = golden["graphs"]["karate.csv"]
+    s, d = np.array(gr["src"]), np.array(gr["dst"])
+    lower = s > d
+    path = tmp_path / "karate.mtx"
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n% Zachary karate club\n%\n34 34 78\n")
+        for a, b in zip(s[lower], d[lower]):
+            f.write(f"{a + 1} {b + 1} 1.0\n")
+    src, dst, w, nv, sym, hw = cg.read_matrix_market(handle, path)
+    assert nv == 34 and sym and hw and src.numel() == 156
+    got = sorted(zip(src.cpu().numpy().tolist(), dst.cpu().numpy().tolist()))
+    assert got == sorted(zip(s.tolist(), d.tolist())) and bool((w == 1.0).all())
+    p = golden["pylibcugraph_pagerank"]["params"]
+    g = cg.SGGraph(handle, cg.GraphProperties(is_symmetric=True), src, dst, w, store_transposed=True, renumber=False,
+                   vertices_array=T(np.arange(nv), np.int32))
+    v, pr = cg.pagerank(handle, g, None, None, None, None, p["alpha"], p["epsilon"], p["max_iterations"], False)
+    exp = golden["pylibcugraph_pagerank"]["karate.csv"]
+    np.testing.assert_allclose(pr.cpu().numpy(), np.array(exp["pagerank"]), rtol=p["rel_tol"], atol=5e-7)
+    # general + integer values, a self-loop, an isolated last vertex
+    path2 = tmp_path / "small.mtx"
+    path2.write_text("%%MatrixMarket matrix coordinate integer general\n5 5 4\n1 2 7\n2 3 2\n3 3 9\n4 1 1\n")
+    src, dst, w, nv, sym, hw = cg.read_matrix_market(handle, path2)
+    assert (nv, sym, hw) == (5, False, True)
+    assert src.cpu().numpy().tolist() == [0, 1, 2, 3] and dst.cpu().numpy().tolist() == [1, 2, 2, 0] and w.cpu().numpy().tolist() == [7.0, 2.0, 9.0, 1.0]
+    # pattern + symmetric: weights 1, the diagonal entry is not mirrored
+    path3 = tmp_path / "pat.mtx"
+    path3.write_text("%%MatrixMarket matrix coordinate pattern symmetric\n3 3 3\n2 1\n3 1\n3 3\n")
+    src, dst, w, nv, sym, hw = cg.read_matrix_market(handle, path3)
+    assert (nv, sym, hw) == (3, True, False) and src.numel() == 5 and bool((w == 1.0).all())
+    assert sorted(zip(src.cpu().numpy().tolist(), dst.cpu().numpy().tolist())) == [(0, 1), (0, 2), (1, 0), (2, 0), (2, 2)]
+    for bad in ("garbage\n1 1 0\n", "%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n", "%%MatrixMarket matrix coordinate real general\n3 3 2\n1 2 1.0\n",
+                "%%MatrixMarket matrix coordinate real general\n3 3 1\n1 4 1.0\n", "%%MatrixMarket matrix coordinate real general\n3 4 0\n"):
+        pb = tmp_path / "bad.mtx"
+        pb.write_text(bad)
+        with pytest.raises(ValueError):
+            cg.read_matrix_market(handle, pb)
+    with pytest.raises(ValueError):
+        cg.read_matrix_market(handle, tmp_path / "missing.mtx")
