@@ -333,6 +333,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split(int32_t const* far_in, 
   int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t n_pad  = (n + 63) & ~(int64_t)63;
+  unsigned long long kept_min = ~0ull;  // smallest distance bits this lane kept in the far pile
   for (; i < n_pad; i += stride) {
     bool near = false, keep = false;
     int32_t v = 0;
@@ -343,15 +344,18 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split(int32_t const* far_in, 
         if (d < upper) near = atomicExch(&mark_near[v], round) != round;
         else {
           keep = atomicExch(&mark_far[v], new_epoch) != new_epoch;
-          if (keep) {
-            if constexpr (sizeof(WT) == 4) atomicMin(&cnt->far_min_bits_lo, (uint32_t)B::to(d));
-            else atomicMin(&cnt->far_min_bits64, (unsigned long long)B::to(d));
-          }
+          if (keep) kept_min = min(kept_min, (unsigned long long)B::to(d));
         }
       }
     }
     wave_push(near, v, near_out, &cnt->n_next, lane);
     wave_push(keep, v, far_out, &cnt->n_far, lane);
+  }
+  // one atomicMin per wavefront (per kept vertex they would all hit the same word)
+  for (int o = 32; o > 0; o >>= 1) kept_min = min(kept_min, (unsigned long long)__shfl_xor(kept_min, o));
+  if (lane == 0 && kept_min != ~0ull) {
+    if constexpr (sizeof(WT) == 4) atomicMin(&cnt->far_min_bits_lo, (uint32_t)kept_min);
+    else atomicMin(&cnt->far_min_bits64, kept_min);
   }
 }
 
