@@ -150,6 +150,7 @@ PROTOTYPES = {
     "cugraph_amd_traversal_mg_plan_results": (C.c_int, [_P, _P, _P, _PP]),
     "cugraph_amd_traversal_mg_plan_free": (None, [_P]),
     "cugraph_amd_read_matrix_market": (C.c_int, [_P, C.c_char_p, _PP, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int), _PP]),
+    "cugraph_amd_handle_set_stream": (C.c_int, [_P, _P, _PP]),
     "cugraph_amd_handle_sync": (C.c_int, [_P, _PP]),
     "cugraph_amd_kernel_timing_enable": (None, [_P, C.c_int]),
     "cugraph_amd_kernel_timing_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_double), _PP]),

@@ -177,6 +177,8 @@ struct kernel_timer {  // HIP-event pairs recorded on the handle's stream (exten
 struct handle_t {  // behind cugraph_resource_handle_t
   int device{0};
   hipStream_t stream{nullptr};
+  hipStream_t own_stream{nullptr};  // the stream created with the handle (destroyed with it); `stream` may be a borrowed one
+  bool stream_borrowed{false};      // the caller's stream is shared: stream order replaces the host syncs of the stepping APIs
   int num_cus{256};
   size_t lds_per_block{65536};
   int rank{0};

@@ -29,6 +29,7 @@ extern "C" cugraph_resource_handle_t* cugraph_create_resource_handle(void* raft_
     h->num_cus       = prop.multiProcessorCount;
     h->lds_per_block = prop.sharedMemPerBlock;
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = h->stream;
     HIP_TRY(hipHostMalloc(&h->pinned, 4096, hipHostMallocDefault));
     return reinterpret_cast<cugraph_resource_handle_t*>(h.release());
   } catch (...) {
@@ -59,8 +60,20 @@ extern "C" void cugraph_free_resource_handle(cugraph_resource_handle_t* handle)
   (void)hipStreamSynchronize(h->stream);
   free_timers(h);
   if (h->pinned) (void)hipHostFree(h->pinned);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
+}
+
+// The library then enqueues everything on the caller's stream (e.g. torch's current stream, on which RCCL collectives are
+// ordered too): no host synchronisation is needed between a collective and the kernels that consume its result.
+extern "C" cugraph_error_code_t cugraph_amd_handle_set_stream(const cugraph_resource_handle_t* handle, void* hip_stream, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    auto* h = const_cast<handle_t*>(&H(handle));
+    h->sync();
+    if (hip_stream == nullptr) { h->stream = h->own_stream; h->stream_borrowed = false; }
+    else { h->stream = static_cast<hipStream_t>(hip_stream); h->stream_borrowed = true; }
+  });
 }
 
 extern "C" cugraph_error_code_t cugraph_amd_handle_sync(const cugraph_resource_handle_t* handle, cugraph_error_t** error)

@@ -1133,7 +1133,7 @@ struct pagerank_mg_plan : pagerank_mg_plan_base {
     tiled_phase2<WT>(h, *tc, (WT const*)part.data(), e, counters.data());
     tiled_finish<WT>(h, e, tc->nI);  // this rank's (diff, dangling, xmax)
     pack();
-    h.sync();  // the host layer issues the next all-to-all on its own stream
+    if (!h.stream_borrowed) h.sync();  // the host layer issues the next all-to-all on its own stream -- unless it shares ours
   }
 
   void values(device_array_view_t const* out) override

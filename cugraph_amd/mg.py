@@ -47,6 +47,12 @@ class Partition:
         self.n_rows = int(self.local_vertices.numel())
 
 
+def _count_owners(owner: torch.Tensor, world: int) -> torch.Tensor:
+    """Elements per owner rank.  Not torch.bincount: its histogram kernel dies with SIGFPE for ~10^9 elements and a handful
+    of bins (seen on ROCm 7 / torch 2.10 at RMAT-26 with one rank); `world` compare-and-sum passes are cheap."""
+    return torch.stack([(owner == r).sum() for r in range(world)]).to(torch.int64)
+
+
 def _a2a(t, send_counts, recv_counts, group):
     out = torch.empty(int(sum(recv_counts)), dtype=t.dtype, device=t.device)
     dist.all_to_all_single(out, t, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=group)
@@ -60,7 +66,7 @@ def _exchange_edges(col_src, local_dst, owner_dst, weights, world, group):
     col_src, local_dst = col_src[order].contiguous(), local_dst[order].contiguous()
     if weights is not None:
         weights = weights[order].contiguous()
-    send_counts = torch.bincount(owner_dst, minlength=world).to(torch.int64)
+    send_counts = _count_owners(owner_dst, world)
     recv_counts = torch.empty_like(send_counts)
     dist.all_to_all_single(recv_counts, send_counts, group=group)
     sc, rc = send_counts.tolist(), recv_counts.tolist()
@@ -84,7 +90,7 @@ class Exchange:
         owner = need % world
         order = torch.argsort(owner, stable=True)            # requests grouped by owner, ascending position inside
         req = (need // world)[order].to(torch.int32)
-        counts = torch.bincount(owner, minlength=world).tolist()
+        counts = _count_owners(owner, world).tolist()
         # fp32 tails hold doubles: keep every message 8-byte aligned by padding odd requests with a repeat of local row 0
         pad_to = 8 // itemsize
         pieces, rc, first = [], [], 0
@@ -182,6 +188,11 @@ class HipLocalEngine(LocalEngine):
         assert_success(code, err, "cugraph_amd_pagerank_mg_plan_create")
         self.plan = plan
         self.dtype = dtype
+        # from here on the library works on torch's current stream, the one the collectives are ordered on: the exchange and
+        # the kernels that consume / produce its buffers need no host synchronisation between them
+        self.shared_stream = os.environ.get("CUGRAPH_AMD_MG_OWN_STREAM") != "1"
+        if self.shared_stream:
+            self.handle.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def _call(self, name, *args):
         err = C.c_void_p()
@@ -257,7 +268,7 @@ class MGPageRank:
             e.recv.copy_(recv)
         else:
             dist.all_to_all_single(e.recv, e.send, output_split_sizes=ex.recv_splits, input_split_sizes=ex.send_splits, group=self.group)
-        if e.recv.is_cuda:
+        if e.recv.is_cuda and not getattr(e, "shared_stream", False):
             torch.cuda.current_stream().synchronize()  # the library computes on its own HIP stream
 
     def step(self, n_iterations, epsilon=0.0):

@@ -32,7 +32,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .mg import Partition, _a2a
+from .mg import Partition, _a2a, _count_owners
 
 INT32_MAX = 2**31 - 1
 FLT_MAX = float(np.finfo(np.float32).max)
@@ -283,7 +283,7 @@ class MGTraversal:
         g_dst = (pos_d % world) * L + pos_d // world                 # compact global id of the destination
         owner = pos_s % world
         order = torch.argsort(owner, stable=True)
-        send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
+        send_counts = _count_owners(owner, world)
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts, group=group)
         sc, rc = send_counts.tolist(), recv_counts.tolist()

@@ -128,6 +128,12 @@ class ResourceHandle:
             self.c_resource_handle_ptr = None
 
     # --- harness helpers (extensions.h)
+    def set_stream(self, hip_stream):
+        """Share a caller's HIP stream (an integer handle, e.g. torch.cuda.current_stream().cuda_stream; None = own stream)."""
+        err = C.c_void_p()
+        assert_success(capi.lib().cugraph_amd_handle_set_stream(self.c_resource_handle_ptr, C.c_void_p(hip_stream) if hip_stream else None, C.byref(err)),
+                       err, "cugraph_amd_handle_set_stream")
+
     def sync(self):
         err = C.c_void_p()
         assert_success(capi.lib().cugraph_amd_handle_sync(self.c_resource_handle_ptr, C.byref(err)), err, "cugraph_amd_handle_sync")

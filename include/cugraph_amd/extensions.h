@@ -125,6 +125,12 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_read_matrix_market(const cugraph
                                                                    cugraph_coo_t** result, size_t* num_vertices, bool_t* is_symmetric,
                                                                    bool_t* has_weights, cugraph_error_t** error);
 
+/* Makes the library enqueue its work on `hip_stream` (a hipStream_t; NULL = back to the handle's own stream).  With the
+ * stream the caller's collectives run on (torch's current stream for RCCL), stream order replaces host synchronisation:
+ * cugraph_amd_pagerank_mg_plan_local_step then returns without waiting. */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_handle_set_stream(const cugraph_resource_handle_t* handle, void* hip_stream,
+                                                                  cugraph_error_t** error);
+
 /* Blocks until everything queued on the handle's stream has finished. */
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_handle_sync(const cugraph_resource_handle_t* handle,
                                                             cugraph_error_t** error);
