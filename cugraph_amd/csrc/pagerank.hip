@@ -636,7 +636,7 @@ struct pagerank_plan : pagerank_plan_base {
       if (!o.tiled || o.tiled->T != T) {
         auto t = std::make_shared<tiled_csc_t>();
         try {
-          build_tiled_csc(h, g.nv, g.nv, g.ne, o, g.has_weights, sizeof(WT), T, *t);
+          build_tiled_csc(h, g.nv, g.nv, g.ne, o, g.has_weights, sizeof(WT), T, *t, getenv("CUGRAPH_AMD_PAGERANK_DENSE_COLUMNS") == nullptr);
           o.tiled = t;
         } catch (api_error const& e) {
           // the re-blocked arrays are addressed with 32-bit byte offsets; a graph that outgrows them (or the memory for
@@ -735,6 +735,7 @@ struct pagerank_plan : pagerank_plan_base {
     e.nv = g.nv; e.pr = pr.data(); e.x_next = xnext; e.outw = outw; e.pers = personalized ? pers.data() : nullptr;
     e.scal = scal.data(); e.partials = tpartials.data(); e.totals = nullptr; e.alpha = alpha; e.nv_global = g.nv;
     e.wmax = tc->wmax;
+    e.xcol = tc->xcol.size() ? tc->xcol.data() : nullptr;
     return e;
   }
   void iterate_tiled()

@@ -24,14 +24,28 @@ __global__ void k_expand_rows_u32(int32_t const* offsets, int64_t nv, uint32_t* 
   }
 }
 
-__global__ void k_tile_keys(int32_t const* indices, int64_t ne, uint32_t T, uint64_t* keys, uint32_t* vals)
+__global__ void k_tile_keys(int32_t const* indices, int32_t const* xcol, int64_t ne, uint32_t T, uint64_t* keys, uint32_t* vals)
 {
   int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < ne; i += stride) {
-    keys[i] = (uint64_t)((uint32_t)indices[i] / T);
+    uint32_t const c = xcol ? (uint32_t)xcol[indices[i]] : (uint32_t)indices[i];
+    keys[i] = (uint64_t)(c / T);
     vals[i] = (uint32_t)i;
   }
+}
+
+__global__ void k_mark_sources(int32_t const* indices, int64_t ne, uint32_t* live)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < ne; i += stride) live[indices[i]] = 1u;  // same value from every writer
+}
+__global__ void k_xcol(uint32_t const* live, uint32_t const* rank, int64_t nv, int32_t* xcol)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nv; i += stride) xcol[i] = live[i] ? (int32_t)rank[i] : -1;
 }
 
 // first[key] = first position holding that key in a sorted key array (entries of absent keys keep the pre-filled value)
@@ -45,7 +59,7 @@ __global__ void k_first_of_key(uint64_t const* keys, int64_t n, uint32_t* first)
 
 // tiled position k (sorted by source tile, then CSC order) -> padded position, 16-bit source, run-start flag
 template <typename WB>
-__global__ void k_tile_emit(uint64_t const* keys, uint32_t const* vals, int64_t ne, int32_t const* indices, uint32_t const* rows,
+__global__ void k_tile_emit(uint64_t const* keys, uint32_t const* vals, int64_t ne, int32_t const* indices, int32_t const* xcol, uint32_t const* rows,
                             WB const* w_in, uint32_t const* tile_off, uint32_t const* tile_off_pad, uint32_t T, uint16_t* src16,
                             WB* w_out, uint32_t* bits, uint32_t* flag32, uint32_t* dsts)
 {
@@ -56,7 +70,7 @@ __global__ void k_tile_emit(uint64_t const* keys, uint32_t const* vals, int64_t 
     uint32_t e  = vals[k];
     uint32_t pk = tile_off_pad[J] + ((uint32_t)k - tile_off[J]);
     uint32_t d  = rows[e];
-    src16[pk]   = (uint16_t)((uint32_t)indices[e] - J * T);
+    src16[pk]   = (uint16_t)((xcol ? (uint32_t)xcol[indices[e]] : (uint32_t)indices[e]) - J * T);
     if (w_in) w_out[pk] = w_in[e];
     bool flag = (uint32_t)k == tile_off[J] || rows[vals[k - 1]] != d;
     flag32[k] = flag ? 1u : 0u;
@@ -288,7 +302,7 @@ __global__ void k_row_abs_max(int32_t const* offsets, WB const* w, int64_t nv, u
 }
 
 void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, orientation_t const& csc, bool has_weights, size_t vsize, int T,
-                     tiled_csc_t& t)
+                     tiled_csc_t& t, bool compact_columns)
 {
   // nv = number of column (source) ids and of CSC rows; n_dst <= nv = rows that can have in-edges and get an epilogue
   // (single GPU: n_dst = nv; multi-GPU: the local rows, while the columns span the whole graph)
@@ -298,7 +312,22 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   t.T     = T;
   t.nv    = n_dst;
   t.ne    = ne;
-  t.nJ    = (int)std::max<int64_t>(1, (nv + T - 1) / T);
+  t.ncols = nv;
+  if (compact_columns && ne > 0) {  // columns = the sources that occur, in id order
+    CGA_EXPECTS(nv == n_dst, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: compact columns need a square local graph");
+    dvec<uint32_t> live((size_t)nv + 1), rank((size_t)nv + 1);
+    HIP_TRY(hipMemsetAsync(live.data(), 0, ((size_t)nv + 1) * sizeof(uint32_t), h.stream));
+    hipLaunchKernelGGL(k_mark_sources, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)csc.indices.data(), ne, live.data());
+    exclusive_scan_u32(h, live.data(), rank.data(), nv + 1);
+    uint32_t nc = 0;
+    h.read_back(&nc, rank.data() + nv, 1);
+    t.ncols = nc;
+    t.xcol.resize_discard((size_t)nv);
+    hipLaunchKernelGGL(k_xcol, grid_for(nv, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)live.data(), (uint32_t const*)rank.data(), nv, t.xcol.data());
+    h.sync();
+  }
+  int32_t const* xcol = t.xcol.size() ? t.xcol.data() : nullptr;
+  t.nJ    = (int)std::max<int64_t>(1, (t.ncols + T - 1) / T);
   int const nJ = t.nJ;
 
   // ---- edges ordered by (source tile, destination, source): stable sort of the CSC positions by source tile
@@ -308,7 +337,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   if (ne > 0) {
     keys.resize_discard(ne); keys_tmp.resize_discard(ne); vals.resize_discard(ne); vals_tmp.resize_discard(ne); rows.resize_discard(ne);
     hipLaunchKernelGGL(k_expand_rows_u32, grid_for(nv * 16, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)csc.offsets.data(), nv, rows.data());
-    hipLaunchKernelGGL(k_tile_keys, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)csc.indices.data(), ne, (uint32_t)T, keys.data(), vals.data());
+    hipLaunchKernelGGL(k_tile_keys, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)csc.indices.data(), xcol, ne, (uint32_t)T, keys.data(), vals.data());
     radix_sort_u64_u32(h, keys.data(), vals.data(), keys_tmp.data(), vals_tmp.data(), ne, 0, bits_for_u((uint64_t)nJ - 1));
     keys_tmp = dvec<uint64_t>(); vals_tmp = dvec<uint32_t>();
     tile_off = key_starts(h, keys.data(), ne, nJ);
@@ -343,15 +372,15 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     HIP_TRY(hipMemsetAsync(flag32.data() + ne, 0, sizeof(uint32_t), h.stream));
     int const g = grid_for(ne, kBlock, 8192);
     if (!has_weights)
-      hipLaunchKernelGGL(k_tile_emit<uint32_t>, g, kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), ne, (int32_t const*)csc.indices.data(),
+      hipLaunchKernelGGL(k_tile_emit<uint32_t>, g, kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), ne, (int32_t const*)csc.indices.data(), xcol,
                          (uint32_t const*)rows.data(), (uint32_t const*)nullptr, (uint32_t const*)d_tile_off.data(), (uint32_t const*)d_tile_off_pad.data(),
                          (uint32_t)T, t.src16.data(), (uint32_t*)nullptr, t.bits.data(), flag32.data(), dsts.data());
     else if (wsize == 4)
-      hipLaunchKernelGGL(k_tile_emit<uint32_t>, g, kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), ne, (int32_t const*)csc.indices.data(),
+      hipLaunchKernelGGL(k_tile_emit<uint32_t>, g, kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), ne, (int32_t const*)csc.indices.data(), xcol,
                          (uint32_t const*)rows.data(), csc.weights.as<uint32_t const>(), (uint32_t const*)d_tile_off.data(), (uint32_t const*)d_tile_off_pad.data(),
                          (uint32_t)T, t.src16.data(), t.weights.as<uint32_t>(), t.bits.data(), flag32.data(), dsts.data());
     else
-      hipLaunchKernelGGL(k_tile_emit<uint64_t>, g, kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), ne, (int32_t const*)csc.indices.data(),
+      hipLaunchKernelGGL(k_tile_emit<uint64_t>, g, kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), ne, (int32_t const*)csc.indices.data(), xcol,
                          (uint32_t const*)rows.data(), csc.weights.as<uint64_t const>(), (uint32_t const*)d_tile_off.data(), (uint32_t const*)d_tile_off_pad.data(),
                          (uint32_t)T, t.src16.data(), t.weights.as<uint64_t>(), t.bits.data(), flag32.data(), dsts.data());
     exclusive_scan_u32(h, flag32.data(), ord.data(), ne + 1);
@@ -576,7 +605,7 @@ __global__ void k_tiled_scalars_from_ranks(unsigned char const* recv, size_t fir
 
 // iteration-0 state: x = pr / out_w, partial dangling mass and max |x| per block
 template <typename WT>
-__global__ void __launch_bounds__(256) k_tiled_prologue(WT const* pr, WT const* outw, WT* x, int64_t nv, double* partials)
+__global__ void __launch_bounds__(256) k_tiled_prologue(WT const* pr, WT const* outw, int32_t const* xcol, WT* x, int64_t nv, double* partials)
 {
   __shared__ double red[8];
   int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -585,7 +614,8 @@ __global__ void __launch_bounds__(256) k_tiled_prologue(WT const* pr, WT const* 
   for (; i < nv; i += stride) {
     WT p = pr[i], ow = outw[i];
     WT xv = p / (ow == WT(0) ? WT(1) : ow);
-    x[i] = xv;
+    if (xcol) { int32_t const c = xcol[i]; if (c >= 0) x[c] = xv; }
+    else x[i] = xv;
     xmax = fmax(xmax, fabs((double)xv));
     if (ow == WT(0)) dang += (double)p;
   }
@@ -1031,11 +1061,13 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
 
   // the epilogue's inputs do not depend on the accumulation: request them first
   WT old[RPT], ow[RPT];
+  int32_t col[RPT];
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     uint32_t i = tid + j * TP2_BLOCK;
     old[j] = i < nrows ? e.pr[(size_t)row0 + i] : WT(0);
     ow[j]  = i < nrows ? e.outw[(size_t)row0 + i] : WT(1);
+    col[j] = (e.xcol && i < nrows) ? e.xcol[(size_t)row0 + i] : (int32_t)(row0 + i);
   }
   for (uint32_t i = tid; i < nrows; i += TP2_BLOCK) acc[i] = ACC(0);
   __syncthreads();
@@ -1075,7 +1107,7 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
       if constexpr (PERS) val += sc.pers_factor * e.pers[v];
       WT const xn = val / (ow[j] == WT(0) ? WT(1) : ow[j]);
       e.pr[v]     = val;
-      e.x_next[v] = xn;
+      if (col[j] >= 0) e.x_next[col[j]] = xn;  // sources without out-edges have no column
       diff += (double)fabs(val - old[j]);
       xmax = fmax(xmax, fabs((double)xn));
       if (ow[j] == WT(0)) dang += (double)val;
@@ -1192,7 +1224,7 @@ template <typename WT>
 int tiled_prologue(handle_t const& h, tiled_csc_t const& t, WT const* pr, WT const* outw, WT* x, int64_t nv, double* partials)
 {
   int const grid = std::max(1, std::min(t.nI, grid_for(nv, 256, 1024)));
-  hipLaunchKernelGGL(k_tiled_prologue<WT>, grid, 256, 0, h.stream, pr, outw, x, nv, partials);
+  hipLaunchKernelGGL(k_tiled_prologue<WT>, grid, 256, 0, h.stream, pr, outw, t.xcol.size() ? (int32_t const*)t.xcol.data() : (int32_t const*)nullptr, x, nv, partials);
   return grid;
 }
 

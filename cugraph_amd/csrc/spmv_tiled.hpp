@@ -88,13 +88,20 @@ struct tiled_csc_t {
   dvec<uint32_t> tile_row0;   // [nI + 1] destination tile boundaries
   dvec<uint32_t> region_off;  // [nI + 2] slot range of region I (multiples of 8); region nI = dummy
   dvec<uint16_t> dstl16;      // [n_slots + pad] tile-local destination of slot
+  // Compact column ids (single-GPU plans): sources WITHOUT out-edges are never gathered, so they get no column; column of a
+  // live source = number of live sources with a smaller id (monotone, so rows of one destination tile map to consecutive
+  // columns and the epilogue's x writes stay coalesced).  At RMAT-26 two thirds of the vertices have no out-edge: the tiles
+  // become 3x denser (longer runs, a third of the tile loads).  Empty = identity (multi-GPU: columns are compact already).
+  dvec<int32_t> xcol;         // [nv] row -> column, -1 = no out-edges
+  int64_t ncols{0};           // number of columns (= nv when xcol is empty)
 };
 
 // Re-blocks the CSC orientation of g (offsets / indices / weights) into tiles of T sources.
 // `vsize` = sizeof(value type); weights (if any) have the same type.
 // nv = number of column (source) ids = CSC rows; n_dst <= nv = leading rows that may have in-edges (single GPU: nv).
+// compact_columns: renumber the sources that have out-edges densely (see tiled_csc_t::xcol); needs nv == n_dst.
 void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, orientation_t const& csc, bool has_weights, size_t vsize, int T,
-                     tiled_csc_t& t);
+                     tiled_csc_t& t, bool compact_columns = false);
 
 template <typename WT>
 struct tiled_x_map {  // where x[c] lives; single GPU: identity.  Multi-GPU all-gather buffer: (c & pmask) * chunk + (c >> plog)
@@ -107,6 +114,7 @@ struct tiled_epilogue {
   int64_t nv{0};         // rows (local rows in the multi-GPU case)
   WT* pr{nullptr};       // in: previous iterate, out: new iterate
   WT* x_next{nullptr};   // pr / out_w (next gather vector; the multi-GPU send chunk)
+  int32_t const* xcol{nullptr};  // tiled_csc_t::xcol: where row r's x goes in x_next (nullptr: x_next[r])
   WT const* outw{nullptr};
   WT const* pers{nullptr};  // dense normalised personalization or nullptr
   pr_scalars<WT>* scal{nullptr};
@@ -134,7 +142,7 @@ void tiled_finish(handle_t const& h, tiled_epilogue<WT> const& e, int n_partials
 
 // iteration-0 state: x = pr / out_w plus per-block (0, dangling, max |x|) partials; returns the number of partial triples
 template <typename WT>
-int tiled_prologue(handle_t const& h, tiled_csc_t const& t, WT const* pr, WT const* outw, WT* x, int64_t nv, double* partials);
+int tiled_prologue(handle_t const& h, tiled_csc_t const& t, WT const* pr, WT const* outw, WT* x, int64_t nv, double* partials);  // honours t.xcol
 
 // multi-GPU: e.scal <- fold of the per-rank (diff, dangling, xmax) triples at recv + first_off + r * stride_bytes
 template <typename WT>

@@ -373,7 +373,7 @@ def bench_main(args):
             "roofline": {"bound": "hbm", "achieved": round(local_bytes / kernel_s / 1e9, 1) if kernel_s > 0 else None, "peak": 8000.0, "unit": "GB/s",
                          "frac": round(local_bytes / kernel_s / 1e9 / 8000.0, 4) if kernel_s > 0 else None, "traffic": None,
                          "kernel": "k_tiled_phase1 + k_tiled_phase2 on rank 0 (per-GPU share of the algorithmic bytes / its kernel time)",
-                         "avg_kernel_ms": round(kernel_s * 1e3, 4)},
+                         "avg_kernel_ms": round(kernel_s * 1e3, 4), "avg_phase1_ms": round(ms1 / max(n1, 1), 4), "avg_phase2_ms": round(ms2 / max(n2, 1), 4)},
         }
     dist.barrier()
     return out
