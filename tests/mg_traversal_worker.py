@@ -1,5 +1,5 @@
 """Worker for the multi-process BFS / SSSP tests (launched by tests/test_mg_traversal.py, one process per rank).
-engine "numpy": gloo on CPU, local compute = NumpyTraversalEngine (exercises partitioning + collectives);
+engine "numpy": gloo on CPU, local compute = tests/numpy_traversal_engine.py (exercises partitioning + collectives);
 engine "hip":   gloo, every rank drives the HIP engine on cuda:0 (exercises the partitioned HIP kernels on one GPU)."""
 import os
 import sys
@@ -11,9 +11,11 @@ import torch.distributed as dist
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
 
 from cugraph_amd import mg_traversal as mt  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
+from numpy_traversal_engine import NumpyTraversalEngine  # noqa: E402
 
 
 def main():
@@ -25,7 +27,7 @@ def main():
     nv, ne = 1 << scale, 16 << scale
     per = (ne + world - 1) // world
     s, d = orc.rmat(scale, min(per, ne - rank * per), first_edge=rank * per)
-    factory = mt.NumpyTraversalEngine if engine == "numpy" else None
+    factory = NumpyTraversalEngine if engine == "numpy" else None
     if factory is None:
         torch.cuda.set_device(0)
     if algo == "bfs":
