@@ -140,6 +140,13 @@ def main():
         out = mg.bench_main(args)
         if rank == 0 and out is not None:
             print(json.dumps(out), flush=True)
+        try:  # orderly shutdown of the RCCL communicator (every rank has passed bench_main's final barrier)
+            import torch.distributed as dist
+
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:
+            pass
         return
 
     nv, ne, dt, launches, kernel_ms, build_s, launches2, kernel2_ms, plan_s = run_single(args)
