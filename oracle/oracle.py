@@ -276,3 +276,117 @@ def symmetrize_edgelist(src, dst, w=None):
     rs = np.concatenate([oh, ol, ds]); rd = np.concatenate([ol, oh, dd])
     rw = None if w is None else np.concatenate([np.array(out_w, w.dtype), np.array(out_w, w.dtype), dw])
     return rs, rd, rw
+
+
+# ----------------------------------------------------------------------------------------- Louvain
+# Restatement of cugraph::louvain with rng_state = nullopt (cpp/src/community/louvain_impl.cuh:40-287) and of its
+# helpers (cpp/src/community/detail/common_methods.cuh:52-479): synchronous local moving with the up/down rule, modularity
+# test per sweep, graph contraction per level, dendrogram flattening.  Arithmetic in fp64, every formula written in the
+# operation order of the reference so that the HIP path (which evaluates the same expressions without contraction) takes
+# the same decisions.  Cluster LABELS of a contracted level are the rank of the old label among the labels in use
+# (ascending); the reference takes the vertex ids its coarsen_graph renumbering happens to assign (degree order, unstable
+# sort on ties), so labels are comparable only up to a renaming -- the tests compare partitions and the modularity.
+# Pinned by cpp/tests/c_api/louvain_test.c: test_louvain (Q = 0.215969, {0,1,2},{3,4,5}) and test_louvain_no_weight
+# (Q = 0.125, {0,1,2,3},{4,5}).
+def louvain_modularity(src, dst, w, clusters, resolution=1.0):
+    """Q of a clustering, as detail::compute_modularity (common_methods.cuh:176-228)."""
+    src, dst = np.asarray(src, np.int64), np.asarray(dst, np.int64)
+    w = np.asarray(w, np.float64)
+    c = np.asarray(clusters, np.int64)
+    m = w.sum()
+    k = np.bincount(src, weights=w, minlength=c.size)
+    a = np.bincount(c, weights=k, minlength=int(c.max()) + 1 if c.size else 1)
+    internal = w[c[src] == c[dst]].sum()
+    return internal / m - (resolution * (a * a).sum()) / (m * m)
+
+
+def _louvain_level(nv, src, dst, w, threshold, resolution, m):
+    """One level: returns (clusters of the level's vertices, Q reached)."""
+    k = np.zeros(nv)
+    np.add.at(k, src, w)                                     # vertex weights (out-weight sums)
+    c = np.arange(nv, dtype=np.int64)                        # every vertex its own cluster
+    accepted = c.copy()
+
+    def q_of(cl, a):
+        internal = w[cl[src] == cl[dst]].sum()
+        return internal / m - (resolution * (a * a).sum()) / (m * m)
+
+    a = k.copy()                                             # cluster weights, indexed by cluster label
+    new_q = q_of(c, a)
+    cur_q = new_q - 1.0
+    up_down = True
+    min_gain = max(threshold / max(nv, 1), 1e-15)            # compute_louvain_min_vertex_move_gain, fp64 noise floor
+    order = np.arange(src.size)
+    while new_q > cur_q + threshold:
+        cur_q = new_q
+        # aggregated weight from every vertex to every neighbouring cluster (edges in input order inside a pair)
+        cd = c[dst]
+        o = np.lexsort((order, cd, src))
+        s_s, s_c, s_w, s_d = src[o], cd[o], w[o], dst[o]
+        head = np.ones(s_s.size, bool)
+        head[1:] = (s_s[1:] != s_s[:-1]) | (s_c[1:] != s_c[:-1])
+        starts = np.flatnonzero(head)
+        seg_v, seg_c = s_s[starts], s_c[starts]
+        seg_sum = np.add.reduceat(s_w, starts) if starts.size else np.zeros(0)
+        # old_cluster_sum (same cluster, not a self-loop) and cluster_subtract (self-loops) per vertex
+        old_sum = np.zeros(nv)
+        sub = np.zeros(nv)
+        same = (s_c == c[s_s])
+        loop = (s_d == s_s)
+        np.add.at(old_sum, s_s[same & ~loop], s_w[same & ~loop])
+        np.add.at(sub, s_s[loop], s_w[loop])
+        kk = k[seg_v]
+        new_sum = np.where(seg_c == c[seg_v], seg_sum - sub[seg_v], seg_sum)
+        a_new, a_old = a[seg_c], a[c[seg_v]]
+        delta = 2.0 * (((new_sum - old_sum[seg_v]) / m) - resolution * (a_new * kk - a_old * kk + kk * kk) / (m * m))
+        best_c = np.full(nv, -1, np.int64)
+        best_d = np.zeros(nv)
+        for v, cc, dd in zip(seg_v.tolist(), seg_c.tolist(), delta.tolist()):  # segments ascend in (vertex, cluster)
+            if dd > best_d[v]:
+                best_d[v], best_c[v] = dd, cc
+        want = best_d > min_gain
+        moves = want & ((best_c > c) == up_down)
+        if not moves.any():
+            up_down = not up_down
+            moves = want & ((best_c > c) == up_down)
+        c = np.where(moves, best_c, c)
+        a = np.zeros(nv)
+        np.add.at(a, c, k)
+        up_down = not up_down
+        new_q = q_of(c, a)
+        if new_q > cur_q + threshold:
+            accepted = c.copy()
+    return accepted, cur_q
+
+
+def louvain(nv, src, dst, w=None, max_level=100, threshold=1e-7, resolution=1.0):
+    """Returns (clusters per vertex, modularity, levels).  Graph = directed edge list (an undirected graph lists both
+    directions, as the C API's symmetric graphs do); w = None means weight 1."""
+    src, dst = np.asarray(src, np.int64), np.asarray(dst, np.int64)
+    w = np.ones(src.size) if w is None else np.asarray(w, np.float64)
+    m = w.sum()
+    part = np.arange(nv, dtype=np.int64)
+    best = -1.0
+    levels = 0
+    cur_nv = nv
+    while levels < max_level:
+        levels += 1
+        c, q = _louvain_level(cur_nv, src, dst, w, threshold, resolution, m)
+        if q <= best:
+            break
+        best = q
+        used = np.zeros(cur_nv, bool)
+        used[c] = True
+        rank = np.cumsum(used) - 1                            # new id = rank of the label among the labels in use
+        c = rank[c]
+        part = c[part]
+        cur_nv = int(used.sum())
+        cs, cd = c[src], c[dst]
+        o = np.lexsort((np.arange(src.size), cd, cs))
+        cs, cd, ww = cs[o], cd[o], w[o]
+        head = np.ones(cs.size, bool)
+        head[1:] = (cs[1:] != cs[:-1]) | (cd[1:] != cd[:-1])
+        starts = np.flatnonzero(head)
+        src, dst = cs[starts], cd[starts]
+        w = np.add.reduceat(ww, starts) if starts.size else np.zeros(0)
+    return part.astype(np.int32), float(best), levels

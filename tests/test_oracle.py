@@ -201,3 +201,42 @@ def test_edge_list_flags_restatement(orc):
     assert loops == [(2, 9.0), (3, 7.0)]                       # self-loops kept once
     a, b, c = orc.symmetrize_edgelist(s, d)                    # unweighted: multiplicity max(#lower, #upper)
     assert sorted(zip(a.tolist(), b.tolist())).count((1, 0)) == 2 and sorted(zip(a.tolist(), b.tolist())).count((0, 1)) == 2
+
+
+def test_louvain_restatement_pinned_to_c_api_goldens(orc):
+    """cpp/tests/c_api/louvain_test.c: test_louvain (weighted: clusters {0,0,0,1,1,1}, Q = 0.215969) and
+    test_louvain_no_weight (clusters {1,1,1,1,0,0}, Q = 0.125), max_level 10, threshold 1e-7, resolution 1."""
+    src = [0, 1, 1, 2, 2, 2, 3, 4, 1, 3, 4, 0, 1, 3, 5, 5]
+    dst = [1, 3, 4, 0, 1, 3, 5, 5, 0, 1, 1, 2, 2, 2, 3, 4]
+    w = np.array([0.1, 2.1, 1.1, 5.1, 3.1, 4.1, 7.2, 3.2] * 2, np.float32)
+    c, q, _ = orc.louvain(6, src, dst, w, 10, 1e-7, 1.0)
+    assert c.tolist() == [0, 0, 0, 1, 1, 1] and abs(q - 0.215969) <= 0.001 * 0.215969
+    c, q, _ = orc.louvain(6, src, dst, None, 10, 1e-7, 1.0)
+    assert c.tolist() == [1, 1, 1, 1, 0, 0] and abs(q - 0.125) <= 1e-9
+    assert abs(orc.louvain_modularity(src, dst, np.ones(16), c) - q) <= 1e-12
+
+
+def test_louvain_restatement_vs_networkx_modularity(orc):
+    """The reported modularity is the modularity of the returned partition (NetworkX's definition on the same
+    undirected weighted graph), and it is not worse than NetworkX's own Louvain by more than a few percent."""
+    import networkx as nx
+
+    s, d = orc.rmat(9, 4 << 9, seed=3)
+    keep = s != d
+    s, d = s[keep], d[keep]
+    lo, hi = np.minimum(s, d), np.maximum(s, d)
+    pairs = np.unique(np.stack([lo, hi], 1), axis=0)
+    wt = (1 + (pairs[:, 0] * 7 + pairs[:, 1] * 13) % 8).astype(np.float64)  # integer weights: sums are exact
+    src = np.concatenate([pairs[:, 0], pairs[:, 1]])
+    dst = np.concatenate([pairs[:, 1], pairs[:, 0]])
+    w = np.concatenate([wt, wt])
+    nv = 1 << 9
+    c, q, levels = orc.louvain(nv, src, dst, w, 100, 1e-7, 1.0)
+    g = nx.Graph()
+    g.add_nodes_from(range(nv))
+    g.add_weighted_edges_from(zip(pairs[:, 0].tolist(), pairs[:, 1].tolist(), wt.tolist()))
+    comms = [set(np.flatnonzero(c == k).tolist()) for k in np.unique(c)]
+    assert abs(nx.community.modularity(g, comms, weight="weight") - q) <= 1e-9
+    ref = nx.community.louvain_communities(g, weight="weight", seed=1)
+    assert q >= nx.community.modularity(g, ref, weight="weight") - 0.05
+    assert levels >= 2
