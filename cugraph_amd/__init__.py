@@ -19,6 +19,7 @@ from .pylib import (  # noqa: F401
     generate_rmat_edgelist,
     has_vertex,
     in_degrees,
+    louvain,
     out_degrees,
     pagerank,
     personalized_pagerank,

@@ -109,6 +109,11 @@ PROTOTYPES = {
     "cugraph_coo_get_edge_id": (_P, [_P]),
     "cugraph_coo_get_edge_type": (_P, [_P]),
     "cugraph_coo_free": (None, [_P]),
+    "cugraph_louvain": (C.c_int, [_P, _P, C.c_size_t, C.c_double, C.c_double, C.c_int, _PP, _PP]),
+    "cugraph_hierarchical_clustering_result_get_vertices": (_P, [_P]),
+    "cugraph_hierarchical_clustering_result_get_clusters": (_P, [_P]),
+    "cugraph_hierarchical_clustering_result_get_modularity": (C.c_double, [_P]),
+    "cugraph_hierarchical_clustering_result_free": (None, [_P]),
     "cugraph_in_degrees": (C.c_int, [_P, _P, _P, C.c_int, _PP, _PP]),
     "cugraph_out_degrees": (C.c_int, [_P, _P, _P, C.c_int, _PP, _PP]),
     "cugraph_degrees": (C.c_int, [_P, _P, _P, C.c_int, _PP, _PP]),

@@ -350,6 +350,22 @@ def bfs_extract_paths(handle, graph, sources, destinations, direction_optimizing
     return (distances, predecessors, vertices, paths)
 
 
+def louvain(resource_handle, graph, max_level, threshold, resolution, do_expensive_check):
+    """louvain.pyx: returns (vertices, clusters, modularity)."""
+    l = capi.lib()
+    res, err = C.c_void_p(), C.c_void_p()
+    _sync_torch()
+    code = l.cugraph_louvain(resource_handle.c_resource_handle_ptr, graph.c_graph_ptr, int(max_level), float(threshold), float(resolution),
+                             int(do_expensive_check), C.byref(res), C.byref(err))
+    assert_success(code, err, "cugraph_louvain")
+    h = resource_handle.c_resource_handle_ptr
+    vertices = copy_to_torch(h, l.cugraph_hierarchical_clustering_result_get_vertices(res))
+    clusters = copy_to_torch(h, l.cugraph_hierarchical_clustering_result_get_clusters(res))
+    modularity = float(l.cugraph_hierarchical_clustering_result_get_modularity(res))
+    l.cugraph_hierarchical_clustering_result_free(res)
+    return (vertices, clusters, modularity)
+
+
 def _degrees(name, resource_handle, graph, source_vertices, do_expensive_check, want_in, want_out):
     l = capi.lib()
     sv = None

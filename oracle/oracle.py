@@ -327,7 +327,9 @@ def _louvain_level(nv, src, dst, w, threshold, resolution, m):
         head[1:] = (s_s[1:] != s_s[:-1]) | (s_c[1:] != s_c[:-1])
         starts = np.flatnonzero(head)
         seg_v, seg_c = s_s[starts], s_c[starts]
-        seg_sum = np.add.reduceat(s_w, starts) if starts.size else np.zeros(0)
+        seg_id = np.cumsum(head) - 1
+        seg_sum = np.zeros(starts.size)
+        np.add.at(seg_sum, seg_id, s_w)                      # sequential, in sorted order (reduceat sums pairwise)
         # old_cluster_sum (same cluster, not a self-loop) and cluster_subtract (self-loops) per vertex
         old_sum = np.zeros(nv)
         sub = np.zeros(nv)
@@ -388,5 +390,6 @@ def louvain(nv, src, dst, w=None, max_level=100, threshold=1e-7, resolution=1.0)
         head[1:] = (cs[1:] != cs[:-1]) | (cd[1:] != cd[:-1])
         starts = np.flatnonzero(head)
         src, dst = cs[starts], cd[starts]
-        w = np.add.reduceat(ww, starts) if starts.size else np.zeros(0)
+        w = np.zeros(starts.size)
+        np.add.at(w, np.cumsum(head) - 1, ww)
     return part.astype(np.int32), float(best), levels

@@ -796,3 +796,60 @@ def test_read_matrix_market(cg, handle, golden, tmp_path):
             cg.read_matrix_market(handle, pb)
     with pytest.raises(ValueError):
         cg.read_matrix_market(handle, tmp_path / "missing.mtx")
+
+
+# ---------------------------------------------------------------- Louvain
+LOUVAIN_SRC = [0, 1, 1, 2, 2, 2, 3, 4, 1, 3, 4, 0, 1, 3, 5, 5]
+LOUVAIN_DST = [1, 3, 4, 0, 1, 3, 5, 5, 0, 1, 1, 2, 2, 2, 3, 4]
+LOUVAIN_WGT = [0.1, 2.1, 1.1, 5.1, 3.1, 4.1, 7.2, 3.2] * 2
+
+
+def canonical_partition(c):
+    """labels renamed by first occurrence (cluster ids are arbitrary names)"""
+    seen = {}
+    return [seen.setdefault(int(x), len(seen)) for x in c]
+
+
+@pytest.mark.parametrize("store_transposed", [False, True])
+def test_capi_louvain_goldens(cg, handle, orc, store_transposed):
+    """cpp/tests/c_api/louvain_test.c: test_louvain ({0,0,0,1,1,1}, Q = 0.215969) and test_louvain_no_weight ({1,1,1,1,0,0},
+    Q = 0.125); max_level 10, threshold 1e-7, resolution 1.0 -- cluster ids included."""
+    props = cg.GraphProperties(is_symmetric=True)
+    g = cg.SGGraph(handle, props, T(LOUVAIN_SRC, np.int32), T(LOUVAIN_DST, np.int32), T(LOUVAIN_WGT, np.float32), store_transposed=store_transposed,
+                   renumber=False)
+    v, c, q = cg.louvain(handle, g, 10, 1e-7, 1.0, False)
+    (c,) = by_vertex(v, c)
+    assert c.tolist() == [0, 0, 0, 1, 1, 1] and nearly_equal(q, 0.215969, 0.001)
+    g = cg.SGGraph(handle, props, T(LOUVAIN_SRC, np.int32), T(LOUVAIN_DST, np.int32), None, store_transposed=store_transposed, renumber=False)
+    v, c, q = cg.louvain(handle, g, 10, 1e-7, 1.0, False)
+    (c,) = by_vertex(v, c)
+    assert c.tolist() == [1, 1, 1, 1, 0, 0] and nearly_equal(q, 0.125, 0.001)
+    # max_level 1: one sweep level only (the level's clustering, not contracted further)
+    v, c1, q1 = cg.louvain(handle, g, 1, 1e-7, 1.0, False)
+    oc, oq, _ = orc.louvain(6, LOUVAIN_SRC, LOUVAIN_DST, None, 1, 1e-7, 1.0)
+    assert canonical_partition(by_vertex(v, c1)[0]) == canonical_partition(oc) and abs(q1 - oq) <= 1e-12
+
+
+@pytest.mark.parametrize("scale,resolution", [(8, 1.0), (10, 1.0), (10, 0.5)])
+def test_louvain_rmat_vs_oracle(cg, handle, orc, scale, resolution):
+    """Undirected RMAT with integer weights (every sum is exact): the clustering must equal the oracle's vertex for vertex, the
+    reported modularity must be the modularity of that clustering."""
+    s, d = orc.rmat(scale, 8 << scale, seed=5)
+    keep = s != d
+    lo, hi = np.minimum(s[keep], d[keep]), np.maximum(s[keep], d[keep])
+    pairs = np.unique(np.stack([lo, hi], 1), axis=0)
+    wt = (1 + (pairs[:, 0] * 7 + pairs[:, 1] * 13) % 8).astype(np.float32)
+    src = np.concatenate([pairs[:, 0], pairs[:, 1]]).astype(np.int32)
+    dst = np.concatenate([pairs[:, 1], pairs[:, 0]]).astype(np.int32)
+    w = np.concatenate([wt, wt])
+    nv = 1 << scale
+    o = np.lexsort((dst, src))  # the order the graph stores its edges in
+    oc, oq, olevels = orc.louvain(nv, src[o], dst[o], w[o], 100, 1e-7, resolution)
+    g = cg.SGGraph(handle, cg.GraphProperties(is_symmetric=True), T(src, np.int32), T(dst, np.int32), T(w, np.float32), renumber=False,
+                   vertices_array=T(np.arange(nv), np.int32))
+    v, c, q = cg.louvain(handle, g, 100, 1e-7, resolution, False)
+    (c,) = by_vertex(v, c)
+    assert abs(q - orc.louvain_modularity(src, dst, w, c, resolution)) <= 1e-9
+    assert abs(q - oq) <= 1e-9
+    assert np.array_equal(c, oc)
+    assert olevels >= 2 and len(np.unique(c)) < nv // 2
