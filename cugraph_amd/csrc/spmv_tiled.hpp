@@ -12,8 +12,10 @@
 //     is a RUN; per edge we keep a 16-bit tile-local source id and one bit "starts a run";
 //   * phase 1 (k_tiled_phase1): a workgroup stages x[J*T, (J+1)*T) * alpha in LDS, streams its share of tile J's
 //     edges (2 bytes + 1 bit each), forms the run sums with an in-lane pass + wave64 DPP segmented scan, and stores
-//     one partial per run into a slot of the partial buffer;
-//   * destinations are cut into tiles I (<= 8192 rows, equal cost); the slots of all runs whose destination lies in I
+//     one partial per run into a slot of the partial buffer (slot = run index + a per-block delta: inside one
+//     (destination tile, source tile) block the slots follow the run order, so 4 bytes per block + 1 bit per run
+//     replace a 4-byte slot per run);
+//   * destinations are cut into tiles I (<= 4096 rows, equal cost); the slots of all runs whose destination lies in I
 //     form the contiguous REGION I (ordered by J, then destination);
 //   * phase 2 (k_tiled_phase2): one workgroup per destination tile streams its region (4-byte partial + 16-bit
 //     tile-local destination), accumulates in LDS (ds_add), and runs the fused PageRank epilogue for its rows
@@ -21,8 +23,9 @@
 //     scalar partials in a fixed order into the next iteration's constants (no extra launch, no device-scope fences).
 //     fp32 partials are accumulated in 64-bit fixed point: LDS integer atomics run at full rate on gfx950 (ds_add_f32
 //     is ~5x slower) and make the result independent of the accumulation order.
-// HBM traffic per iteration = 2.125 E + 14 P + 16 V bytes (P = number of runs; RMAT-22: P = 0.15 E, RMAT-26: 0.29 E),
-// all of it streaming; nothing is gathered from global memory.
+// HBM traffic per iteration = 2.125 E + 10 P + 16 V bytes + per-wavefront records + block deltas + tile reloads
+// (P = number of runs; RMAT-22: P = 0.15 E, RMAT-26: 0.29 E; measured 7.1 GB at RMAT-26), all of it streaming; nothing is
+// gathered from global memory.  Single-GPU plans number only the sources that have out-edges as columns (xcol).
 #pragma once
 
 #include "common.hpp"
