@@ -110,14 +110,43 @@ def run_single(args):
     except Exception:
         launches2, kernel2_ms = 0, 0.0
     h.kernel_timing(False)
-    # un-instrumented repeat for the headline value (event records cost a few microseconds per launch)
-    t0 = time.perf_counter()
-    plan.step(args.steps)
-    h.sync()
-    torch.cuda.synchronize()
-    dt2 = time.perf_counter() - t0
-    dt = min(dt, dt2)
-    return nv, ne, dt, launches, kernel_ms, build_s, launches2, kernel2_ms, plan_s
+    check = None if args.no_check else check_result(cg, h, plan, args.scale, ne, nv)
+    return nv, ne, dt, launches, kernel_ms, build_s, launches2, kernel2_ms, plan_s, check
+
+
+def check_result(cg, h, plan, scale, ne, nv, alpha=0.85):
+    """OUTSIDE the timed region: is the vector the timed iterations produced a PageRank iterate?  (a) mass: |sum(pr) - 1|;
+    (b) one more iteration of the library must equal ONE explicit fp64 power iteration (torch, on the regenerated edge list)
+    of the state the timed region left behind (the update rule of pagerank_impl.cuh:224-327).  The same kernels are compared
+    with the CPU oracle over all 20 iterations at RMAT-22 in tests/test_gpu_parity.py; this is the check that the 32-bit
+    offsets of the tiled layout still hold at the benchmarked size.  Reference tolerance: pagerank_test.cpp:328-334 (1e-3
+    relative); used here: 2e-5 relative on every vertex."""
+    import torch
+
+    v, pr_k, _ = plan.result()
+    plan.step(1)
+    _, pr_k1, _ = plan.result()
+    p = torch.empty(nv, dtype=torch.float64, device="cuda")
+    p[v.long()] = pr_k.double()
+    q = torch.empty(nv, dtype=torch.float64, device="cuda")
+    q[v.long()] = pr_k1.double()
+    del pr_k, pr_k1, v
+    src, dst = cg.generate_rmat_edgelist(h, scale, ne)
+    outw = torch.zeros(nv, dtype=torch.float64, device="cuda")
+    y = torch.zeros(nv, dtype=torch.float64, device="cuda")
+    step = 1 << 27
+    for b in range(0, ne, step):
+        s = src[b:b + step]
+        outw.index_add_(0, s, torch.ones(s.numel(), dtype=torch.float64, device="cuda"))
+    xs = p / torch.where(outw == 0, torch.ones_like(outw), outw) * alpha
+    for b in range(0, ne, step):
+        y.index_add_(0, dst[b:b + step], xs[src[b:b + step]])
+    expect = y + (alpha * float(p[outw == 0].sum()) + (1.0 - alpha)) / nv
+    rel = float(((q - expect).abs() / expect).max())
+    mass = abs(float(p.sum()) - 1.0)
+    ok = rel <= 2e-5 and mass <= 1e-4
+    return {"mass_err": mass, "one_step_rel": rel, "l1_step": float((q - p).abs().sum()), "tolerance": {"one_step_rel": 2e-5, "mass_err": 1e-4},
+            "what": "one more library iteration vs one explicit fp64 power iteration (torch) from the state the timed steps left", "ok": bool(ok)}
 
 
 def main():
@@ -130,6 +159,7 @@ def main():
     ap.add_argument("--hot-tile", type=int, default=None, help="x entries staged in LDS per workgroup (default: library choice)")
     ap.add_argument("--cpu-scale", type=int, default=22, help="RMAT scale of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the post-timing correctness check of the timed result")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,20 +179,21 @@ def main():
             pass
         return
 
-    nv, ne, dt, launches, kernel_ms, build_s, launches2, kernel2_ms, plan_s = run_single(args)
+    nv, ne, dt, launches, kernel_ms, build_s, launches2, kernel2_ms, plan_s, check = run_single(args)
     value = ne * args.steps / dt / 1e6
     bytes_per_launch = algorithmic_bytes(nv, ne)
     avg1_s = kernel_ms / 1e3 / max(launches, 1)
     avg2_s = kernel2_ms / 1e3 / max(launches2, 1) if launches2 else 0.0
     avg_kernel_s = avg1_s + avg2_s  # one iteration = one launch of each; the algorithmic bytes are those of the iteration
     achieved = bytes_per_launch / avg_kernel_s / 1e9 if launches else None
-    traffic = None
+    traffic, traffic_source = None, None
     tfile = ROOT / "profiles" / "traffic_latest.json"
     if tfile.exists():
         try:
             t = json.loads(tfile.read_text())
             if t.get("scale") == args.scale:
                 traffic = t.get("hbm_bytes_per_launch")
+                traffic_source = f"profiles/traffic_latest.json ({t.get('source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes')}); not measured by this run"
         except Exception:
             traffic = None
     out = {
@@ -175,12 +206,14 @@ def main():
         "iters_per_sec": round(args.steps / dt, 2),
         "graph_build_s": round(build_s, 3), "plan_build_s": round(plan_s, 3),
         "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "k_tiled_phase1 + k_tiled_phase2 (one launch each per iteration)" if launches2 else "k_spmv_flat",
                      "launches": launches, "avg_kernel_ms": round(avg_kernel_s * 1e3, 4),
                      "avg_phase1_ms": round(avg1_s * 1e3, 4), "avg_phase2_ms": round(avg2_s * 1e3, 4),
                      "algorithmic_bytes_per_launch": bytes_per_launch},
     }
+    if check is not None:
+        out["check"] = check
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(min(args.cpu_scale, args.scale), 10)
         out["cpu_baseline"]["networkx"] = networkx_baseline(min(16, args.scale), 10)

@@ -534,6 +534,38 @@ template <typename WT> void fill_wt(handle_t const& h, WT* p, int64_t n, WT v);
 template <> void fill_wt<float>(handle_t const& h, float* p, int64_t n, float v) { fill_f32(h, p, n, v); }
 template <> void fill_wt<double>(handle_t const& h, double* p, int64_t n, double v) { fill_f64(h, p, n, v); }
 
+// rows [n_act, n_act + n) have no in-edge: out-weight sums of their live columns in column order, how many of them are dangling,
+// max 1 / out-weight (red[0] = count, red[1] = bits of the max, a non-negative double)
+template <typename WT>
+__global__ void k_const_rows_setup(WT const* outw, int32_t const* xcol, int64_t n, int64_t n_act, int64_t c0, WT* outw_c, unsigned long long* red)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long dangling = 0;
+  double best = 0.0;
+  for (; i < n; i += stride) {
+    WT const ow     = outw[i];
+    int64_t const c = xcol ? (int64_t)xcol[i] : n_act + i;
+    if (c >= 0) outw_c[c - c0] = ow;
+    dangling += ow == WT(0) ? 1ull : 0ull;
+    best = fmax(best, 1.0 / (double)(ow == WT(0) ? WT(1) : ow));
+  }
+  for (int o = 32; o > 0; o >>= 1) { dangling += __shfl_xor(dangling, o); best = fmax(best, __shfl_xor(best, o)); }
+  if ((threadIdx.x & 63) == 0) {
+    if (dangling) atomicAdd(&red[0], dangling);
+    atomicMax(&red[1], (unsigned long long)__double_as_longlong(best));
+  }
+}
+
+template <typename WT>
+__global__ void k_fill_from_base_prev(WT* out, int64_t n, pr_scalars<WT> const* scal)
+{
+  WT const v     = scal->base_prev;
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = v;
+}
+
 }  // namespace
 
 // ----------------------------------------------------------------------------------------- plan
@@ -729,6 +761,40 @@ struct pagerank_plan : pagerank_plan_base {
   }
 
   bool pending_finish{false};  // tiled: phase 2 ran, its scalar partials are not folded into `scal` yet
+  // rows without in-edges stay out of the per-iteration epilogue (spmv_tiled.hpp: tiled_const_rows) unless the plan is
+  // personalized or starts from a user vector
+  tiled_const_rows<WT> crows;
+  dvec<WT> outw_c;
+  bool const_rows_stale{false};  // pr[n_act ..) has to be filled with the rows' common value before it is read
+  void setup_const_rows(bool allowed)
+  {
+    crows = tiled_const_rows<WT>{};
+    if (!allowed || !tiled || getenv("CUGRAPH_AMD_PAGERANK_ALL_ROWS") || tc->n_act >= g.nv || tc->nI_act <= 0) return;
+    int64_t const n = g.nv - tc->n_act;
+    crows.n_rows = n;
+    crows.c0     = tc->c0;
+    crows.n_cols = tc->ncols - tc->c0;
+    outw_c.resize_discard((size_t)std::max<int64_t>(crows.n_cols, 1));
+    dvec<unsigned long long> red(2);
+    HIP_TRY(hipMemsetAsync(red.data(), 0, 2 * sizeof(unsigned long long), h.stream));
+    hipLaunchKernelGGL(k_const_rows_setup<WT>, grid_for(n, kBlock, 4096), kBlock, 0, h.stream, outw + tc->n_act,
+                       tc->xcol.size() ? (int32_t const*)tc->xcol.data() + tc->n_act : (int32_t const*)nullptr, n, (int64_t)tc->n_act, (int64_t)tc->c0, outw_c.data(),
+                       red.data());
+    unsigned long long r[2];
+    h.read_back(r, red.data(), 2);
+    crows.n_dangling = (int64_t)r[0];
+    std::memcpy(&crows.max_inv_outw, &r[1], sizeof(double));
+    crows.outw_c = outw_c.data();
+    crows.nI_act = tc->nI_act;
+  }
+  void materialize_const_rows()
+  {
+    if (!const_rows_stale) return;
+    hipLaunchKernelGGL(k_fill_from_base_prev<WT>, grid_for(crows.n_rows, kBlock, 4096), kBlock, 0, h.stream, pr.data() + tc->n_act, crows.n_rows,
+                       (pr_scalars<WT> const*)scal.data());
+    const_rows_stale = false;
+  }
+
   tiled_epilogue<WT> tiled_epi(WT* xnext)
   {
     tiled_epilogue<WT> e;
@@ -736,6 +802,7 @@ struct pagerank_plan : pagerank_plan_base {
     e.scal = scal.data(); e.partials = tpartials.data(); e.totals = nullptr; e.alpha = alpha; e.nv_global = g.nv;
     e.wmax = tc->wmax;
     e.xcol = tc->xcol.size() ? tc->xcol.data() : nullptr;
+    e.cr   = crows;
     return e;
   }
   void iterate_tiled()
@@ -745,12 +812,14 @@ struct pagerank_plan : pagerank_plan_base {
     tiled_epilogue<WT> e = tiled_epi(xnext);
     tiled_phase1<WT>(h, *tc, xcur, alpha, part.data(), counters.data(), tiled_x_map<WT>{}, pending_finish ? &e : nullptr);
     tiled_phase2<WT>(h, *tc, (WT const*)part.data(), e, counters.data());
-    pending_finish = true;
+    pending_finish   = true;
+    const_rows_stale = crows.nI_act > 0;
   }
   void flush_tiled_scalars()
   {
     if (!pending_finish) return;
-    tiled_finish<WT>(h, tiled_epi(nullptr), tc->nI);
+    tiled_epilogue<WT> const e = tiled_epi(nullptr);
+    tiled_finish<WT>(h, e, tiled_fold_count(*tc, e));
     pending_finish = false;
   }
 
@@ -819,8 +888,10 @@ struct pagerank_plan : pagerank_plan_base {
     }
     // iteration-0 state: x = pr / out_w, dangling mass, base
     if (tiled) {
+      setup_const_rows(!personalized && !ig_s);
       int n = tiled_prologue<WT>(h, *tc, (WT const*)pr.data(), outw, x0.data(), nv, tpartials.data());
-      tiled_finish<WT>(h, tiled_epi(nullptr), n);
+      // the rows without in-edges start from the uniform value (there is no user vector when they are left out)
+      tiled_finish<WT>(h, tiled_epi(nullptr), n, crows.nI_act > 0 ? (double)(WT(1) / (WT)nv) : -1.0);
       cur = 0;
       h.sync();
       return;
@@ -912,6 +983,7 @@ struct pagerank_plan : pagerank_plan_base {
   {
     auto ids  = std::make_unique<device_array_t>((size_t)g.nv, g.vertex_type);
     auto vals = std::make_unique<device_array_t>((size_t)g.nv, g.weight_type);
+    if (tiled) { flush_tiled_scalars(); materialize_const_rows(); }
     if (g.nv > 0) {
       HIP_TRY(hipMemcpyAsync(ids->buf.ptr, g.number_map.data(), g.nv * 4, hipMemcpyDeviceToDevice, h.stream));
       HIP_TRY(hipMemcpyAsync(vals->buf.ptr, pr.data(), g.nv * sizeof(WT), hipMemcpyDeviceToDevice, h.stream));

@@ -106,6 +106,18 @@ __global__ void k_cost_cuts(uint32_t const* csum, int64_t nv, uint64_t total, in
   cut[q] = (uint32_t)lo;
 }
 
+// out[0] = smallest d in [0, n] with csum[d] == total (csum non-decreasing, csum[n] == total): rows >= d have no run
+__global__ void k_first_rowless(uint32_t const* csum, int64_t n, uint32_t total, uint32_t* out)
+{
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (csum[mid] < total) lo = mid + 1; else hi = mid;
+  }
+  out[0] = (uint32_t)lo;
+}
+
 __device__ __forceinline__ uint32_t tile_of_row(uint32_t const* tile_row0, int nI, uint32_t d)
 {  // largest I with tile_row0[I] <= d
   int lo = 0, hi = nI;  // invariant: tile_row0[lo] <= d < tile_row0[hi]
@@ -309,13 +321,16 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   size_t const wsize = has_weights ? vsize : 0;
   CGA_EXPECTS(nv < ((int64_t)1 << 31) && ne < ((int64_t)1 << 31), CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: graph too large for 32-bit positions");
   t       = tiled_csc_t{};
+  dvec<uint32_t> live_rank;  // compact columns: live_rank[r] = number of live sources with an id < r
   t.T     = T;
   t.nv    = n_dst;
   t.ne    = ne;
   t.ncols = nv;
   if (compact_columns && ne > 0) {  // columns = the sources that occur, in id order
     CGA_EXPECTS(nv == n_dst, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: compact columns need a square local graph");
-    dvec<uint32_t> live((size_t)nv + 1), rank((size_t)nv + 1);
+    live_rank.resize_discard((size_t)nv + 1);
+    dvec<uint32_t> live((size_t)nv + 1);
+    dvec<uint32_t>& rank = live_rank;
     HIP_TRY(hipMemsetAsync(live.data(), 0, ((size_t)nv + 1) * sizeof(uint32_t), h.stream));
     hipLaunchKernelGGL(k_mark_sources, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)csc.indices.data(), ne, live.data());
     exclusive_scan_u32(h, live.data(), rank.data(), nv + 1);
@@ -406,6 +421,15 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     hipLaunchKernelGGL(k_cost_cuts, (nq + 255) / 256, 256, 0, h.stream, (uint32_t const*)csum.data(), n_dst, total, nq, cut.data());
     std::vector<uint32_t> c = to_host(h, cut.data(), (size_t)nq);
     c.push_back((uint32_t)n_dst);
+    // rows >= n_act have no in-edge (with degree-sorted ids: the zero-in-degree suffix, 60 % of an RMAT-26 graph): a tile
+    // boundary is forced there so that a plan may leave those rows out of its per-iteration epilogue (tiled_const_rows)
+    dvec<uint32_t> d_nact(1);
+    hipLaunchKernelGGL(k_first_rowless, 1, 64, 0, h.stream, (uint32_t const*)csum.data(), n_dst, (uint32_t)t.n_runs, d_nact.data());
+    uint32_t nact = 0;
+    h.read_back(&nact, d_nact.data(), 1);
+    t.n_act = nact;
+    c.push_back(nact);
+    std::sort(c.begin(), c.end());
     uint32_t prev = 0;
     row0.push_back(0);
     for (uint32_t b : c) {
@@ -415,9 +439,17 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
       prev = b;
     }
     if (row0.size() == 1) row0.push_back((uint32_t)n_dst);  // n_dst == 0
+    t.nI_act = (int)(std::lower_bound(row0.begin(), row0.end(), nact) - row0.begin());  // tiles [0, nI_act) cover rows [0, n_act)
   }
   t.nI = (int)row0.size() - 1;
   to_device(h, t.tile_row0, row0);
+  t.c0 = t.n_act;  // first column of a row >= n_act (identity columns: the row itself)
+  if (live_rank.size()) {
+    uint32_t c0 = 0;
+    h.read_back(&c0, live_rank.data() + t.n_act, 1);
+    t.c0 = c0;
+    live_rank = dvec<uint32_t>();
+  }
 
   // ---- phase-1 work items (source tile order = hottest tiles first)
   std::vector<int32_t> item_tile;
@@ -511,11 +543,20 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     int const per_cu = std::max<int>(1, std::min<int>(2, (int)((h.lds_per_block - 1024) / (lds + 64))));
     int const max_wg = h.num_cus * per_cu;
     int const chunk  = std::max(1, std::min<int>(TP_CHUNK, t.n_items / (max_wg * 4)));  // small graphs: more, shorter chunks
+    // the hottest tiles span thousands of items: their first items go out in LONG chunks (a workgroup reloads the 126 KiB
+    // tile once per chunk, with nothing else in flight), the rest in `chunk`-item pieces that balance the tail
+    char const* env_big  = getenv("CUGRAPH_AMD_TP_CHUNK_BIG");
+    char const* env_frac = getenv("CUGRAPH_AMD_TP_CHUNK_BIG_FRAC");
+    int const big        = std::max(chunk, env_big ? atoi(env_big) : TP_CHUNK_BIG);
+    double const frac    = env_frac ? atof(env_frac) : 0.55;
+    int64_t big_budget   = t.n_items / (max_wg * 4) >= TP_CHUNK ? (int64_t)(frac * t.n_items) : 0;
     std::vector<std::pair<int32_t, int32_t>> ch;  // (first item, items)
     for (int i = 0; i < t.n_items;) {
       int j = i + 1;
-      while (j < t.n_items && j - i < chunk && item_tile[j] == item_tile[i]) ++j;
-      ch.push_back({i, j - i});
+      while (j < t.n_items && item_tile[j] == item_tile[i]) ++j;  // [i, j) = the items of one tile
+      int k = i;
+      while (big > chunk && big_budget >= big && j - k >= 2 * big) { ch.push_back({k, big}); k += big; big_budget -= big; }
+      while (k < j) { int const n = std::min(chunk, j - k); ch.push_back({k, n}); k += n; }
       i = j;
     }
     std::stable_sort(ch.begin(), ch.end(), [](auto const& x, auto const& y) { return x.second > y.second; });
@@ -541,6 +582,11 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   }
   t.built = true;
   h.sync();
+  if (getenv("CUGRAPH_AMD_TILED_DEBUG"))
+    fprintf(stderr, "[tiled build] T %d nJ %d nI %d items %d chunks %d wg %d | ne %lld ne_pad %lld runs %lld slots %lld blocks %lld | rows %lld cols %lld\n", t.T,
+            t.nJ, t.nI, t.n_items, t.n_chunks, t.n_wg, (long long)t.ne, (long long)t.ne_pad, (long long)t.n_runs, (long long)t.n_slots,
+            (long long)t.n_blocks, (long long)t.nv, (long long)t.ncols);
+  if (getenv("CUGRAPH_AMD_TILED_DEBUG")) fprintf(stderr, "[tiled build] rows with in-edges end at %lld (tiles [0, %d)), first column of the rest %lld\n", (long long)t.n_act, t.nI_act, (long long)t.c0);
 }
 
 namespace {
@@ -559,6 +605,9 @@ struct fin_args {
   int64_t nv_global{0};
   int personalized{0};
   double wmax{0};
+  // rows left out of the epilogue (tiled_const_rows): their analytic share; init_prev >= 0: iteration-0 fold, base_prev := init_prev
+  double cr_rows{0}, cr_dangling{0}, cr_max_inv_outw{0};
+  double init_prev{-1};
 };
 
 // executed by ONE workgroup of `nthreads` threads; scratch = 3 * nthreads doubles of LDS
@@ -578,7 +627,17 @@ __device__ __forceinline__ void finish_scalars(fin_args<WT> const& f, double* sc
   }
   if (tid == 0) {
     if (f.totals) { f.totals[0] = r0[0]; f.totals[1] = r1[0]; f.totals[2] = r2[0]; }
-    else tiled_write_scalars<WT>(f.scal, r0[0], r1[0], r2[0], f.alpha, f.nv_global, f.personalized, f.wmax);
+    else {
+      double diff = r0[0], dang = r1[0], xmax = r2[0];
+      if (f.cr_rows > 0 && f.init_prev < 0) {  // the rows without in-edges were not visited: pr' = base for each of them
+        WT const b = f.scal->base, bp = f.scal->base_prev;
+        diff += f.cr_rows * (double)fabs(b - bp);
+        dang += f.cr_dangling * (double)b;
+        xmax = fmax(xmax, fabs((double)b) * f.cr_max_inv_outw);
+      }
+      if (f.init_prev >= 0) f.scal->base = (WT)f.init_prev;  // becomes base_prev: the rows' value before the first iteration
+      tiled_write_scalars<WT>(f.scal, diff, dang, xmax, f.alpha, f.nv_global, f.personalized, f.wmax);
+    }
   }
   __syncthreads();
 }
@@ -669,6 +728,41 @@ __device__ __forceinline__ void st32(void* base, uint32_t byte_off, T v)
 }
 
 
+// ---- vector-memory operations of phase 1's item loop and its explicit wait.
+// gfx9 has ONE counter for loads and stores (vmcnt, retired in order).  The loop is rotated so that its back edge follows
+// the one explicit vmcnt(0) of an iteration: nothing is in flight across the back edge, so the compiler's wait insertion
+// (which merges states conservatively at joins: it put vmcnt(1) in front of the first use of an item's edge data and
+// vmcnt(0) between the partial stores of the long-run path in the previous, un-rotated loop -- measured: the partial
+// stores cost 0.36 of phase 1's 1.04 ms at RMAT-26) finds nothing pending at the loop header and adds no wait of its own
+// in the steady state.  CGA_P1_ASM=1 issues the same operations through inline asm (invisible to that pass; then a
+// register written by vm_ld* is valid only after vm_wait + vm_fence on it) -- kept for experiments, NOT the default:
+// the compiler is free to copy a register whose asm load is still in flight.
+#ifndef CGA_P1_ASM
+#define CGA_P1_ASM 0
+#endif
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+#if CGA_P1_ASM
+__device__ __forceinline__ void vm_ld128(u32x4_t& d, void const* base, uint32_t off) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(off), "s"(base)); }
+__device__ __forceinline__ void vm_ld128_o16(u32x4_t& d, void const* base, uint32_t off) { asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(d) : "v"(off), "s"(base)); }
+__device__ __forceinline__ void vm_ld16u(uint32_t& d, void const* base, uint32_t off) { asm volatile("global_load_ushort %0, %1, %2" : "=v"(d) : "v"(off), "s"(base)); }
+__device__ __forceinline__ void vm_ld32(uint32_t& d, void const* base, uint32_t off) { asm volatile("global_load_dword %0, %1, %2" : "=v"(d) : "v"(off), "s"(base)); }
+__device__ __forceinline__ void vm_st(void* base, uint32_t off, float v) { asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory"); }
+__device__ __forceinline__ void vm_st(void* base, uint32_t off, double v) { asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory"); }
+__device__ __forceinline__ void vm_wait0() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
+__device__ __forceinline__ void vm_fence(uint32_t& r) { asm volatile("" : "+v"(r)); }
+__device__ __forceinline__ void vm_fence(u32x4_t& r) { asm volatile("" : "+v"(r)); }
+#else
+__device__ __forceinline__ void vm_ld128(u32x4_t& d, void const* base, uint32_t off) { d = *reinterpret_cast<u32x4_t const*>(static_cast<char const*>(base) + off); }
+__device__ __forceinline__ void vm_ld128_o16(u32x4_t& d, void const* base, uint32_t off) { d = *reinterpret_cast<u32x4_t const*>(static_cast<char const*>(base) + off + 16); }
+__device__ __forceinline__ void vm_ld16u(uint32_t& d, void const* base, uint32_t off) { d = *reinterpret_cast<uint16_t const*>(static_cast<char const*>(base) + off); }
+__device__ __forceinline__ void vm_ld32(uint32_t& d, void const* base, uint32_t off) { d = *reinterpret_cast<uint32_t const*>(static_cast<char const*>(base) + off); }
+template <typename V>
+__device__ __forceinline__ void vm_st(void* base, uint32_t off, V v) { *reinterpret_cast<V*>(static_cast<char*>(base) + off) = v; }
+__device__ __forceinline__ void vm_wait0() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0); lgkmcnt / expcnt untouched
+__device__ __forceinline__ void vm_fence(uint32_t&) {}
+__device__ __forceinline__ void vm_fence(u32x4_t&) {}
+#endif
+
 // LDS byte offset of 16-bit tile-local index number HALF of w, scaled by the element size, in ONE VALU op (SDWA word select
 // + shift); the x tile starts at LDS address 0
 template <int HALF, int SHIFT>
@@ -699,24 +793,24 @@ __device__ __forceinline__ void static_for(F&& f)
 }
 
 struct p1_regs {  // one work item's data for one lane: TP_EPL consecutive edges + one dword of the wavefront's record
-  uint4 id[TP_EPL / 8];
+  u32x4_t id[TP_EPL / 8];
   uint32_t fl;   // TP_EPL run-start bits
-  uint32_t rec;  // dword `lane` of the record (lanes >= TP_REC_DWORDS: 0)
+  uint32_t rec;  // dword min(lane, TP_REC_DWORDS - 1) of the record (only lanes < TP_REC_DWORDS are ever read)
   uint32_t es;   // first edge position of the wavefront's share (wave-uniform)
 };
-
+static_assert(TP_EPL == 16, "p1_load issues two 16-byte index loads and one 16-bit flag load per lane");
+// straight-line (4 loads, no branch; lanes past the record re-read its last dword)
 template <typename WT>
 __device__ __forceinline__ void p1_load(p1_args<WT> const& a, int item, int wave, int lane, p1_regs& r)
 {  // arrays are over-allocated and zero padded: no bounds checks
   r.es = (uint32_t)item * (uint32_t)TP_ITEM + (uint32_t)wave * TP_WLEN;
   uint32_t const e = r.es + (uint32_t)TP_EPL * (uint32_t)lane;
-#pragma unroll
-  for (int j = 0; j < TP_EPL / 8; ++j) r.id[j] = ld32<uint4>(a.src16, 2u * e + 16u * j);
-  if constexpr (TP_EPL == 16) r.fl = ld32<uint16_t>(a.bits, e >> 3);
-  else r.fl = ld32<uint8_t>(a.bits, e >> 3);
-  r.rec = 0;
-  if (lane < TP_REC_DWORDS) r.rec = ld32<uint32_t>(a.wrec, ((uint32_t)item * TP_WAVES + (uint32_t)wave) * (uint32_t)(TP_REC_DWORDS * 4) + 4u * (uint32_t)lane);
+  vm_ld128(r.id[0], a.src16, 2u * e);
+  vm_ld128_o16(r.id[1], a.src16, 2u * e);
+  vm_ld16u(r.fl, a.bits, e >> 3);
+  vm_ld32(r.rec, a.wrec, ((uint32_t)item * TP_WAVES + (uint32_t)wave) * (uint32_t)(TP_REC_DWORDS * 4) + 4u * (uint32_t)min(lane, TP_REC_DWORDS - 1));
 }
+__device__ __forceinline__ void p1_fence(p1_regs& r) { vm_fence(r.id[0]); vm_fence(r.id[1]); vm_fence(r.fl); vm_fence(r.rec); }
 
 // Run ordinal n within the wavefront's range: n = 0 is the run that was already open at `es` (its partial goes to the
 // head slot), n >= 1 is run (rank - 1 + n), whose slot is (rank - 1 + n) + delta1[blk + #block starts among the first n runs
@@ -750,7 +844,9 @@ __device__ __forceinline__ uint32_t p1_delta_group(p1_args<WT> const& a, uint32_
   uint32_t const lo = rdl(rec, 2u * j), hi = rdl(rec, 2u * j + 1u);
   uint32_t const idx = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, base));
   base += (uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi);
-  return ld32<uint32_t>(a.delta1, 4u * idx);
+  uint32_t d;
+  vm_ld32(d, a.delta1, 4u * idx);
+  return d;
 }
 template <typename WT>
 __device__ __forceinline__ void p1_issue_slots(p1_args<WT> const& a, int lane, p1_regs const& rg, p1_runs& q)
@@ -759,9 +855,16 @@ __device__ __forceinline__ void p1_issue_slots(p1_args<WT> const& a, int lane, p
 #pragma unroll
   for (int j = 0; j < TP_NSLOT; ++j) {
     q.slot[j] = 0;
+#ifndef CGA_ABL_NODELTA
     if ((uint32_t)(64 * j) < q.c_all) q.slot[j] = p1_delta_group<WT>(a, rg.rec, (uint32_t)j, base);
+#endif
   }
   q.blk8 = base;  // only meaningful (and only used) when c_all > 64 * TP_NSLOT
+}
+__device__ __forceinline__ void p1_fence_slots(p1_runs& q)
+{
+#pragma unroll
+  for (int j = 0; j < TP_NSLOT; ++j) vm_fence(q.slot[j]);
 }
 
 // run totals of the lanes selected by `mine` -> staging area, in run order, starting at ordinal base_c
@@ -769,14 +872,14 @@ __device__ __forceinline__ void p1_issue_slots(p1_args<WT> const& a, int lane, p
 // the carry of the previous lanes; the lane's FIRST staged total is patched afterwards (LDS operations of one wavefront
 // execute in order), which keeps the select out of the 16 predicated stores.
 template <typename WT>
-__device__ __forceinline__ void p1_stage(WT* stage, p1_runs const& q, WT const (&r)[TP_EPL], uint32_t const (&cont)[TP_EPL], WT carry_in, uint32_t base_c, bool mine)
+__device__ __forceinline__ void p1_stage(WT* stage, p1_runs const& q, WT const (&r)[TP_EPL], WT carry_in, uint32_t base_c, bool mine)
 {
   if (mine && q.f) {
     WT* p             = stage + (q.ex_c - base_c);
     WT* const p_first = p;
     static_for<TP_EPL>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
-      if (cont[k] == 0u) {
+      if (q.f & (1u << k)) {  // (the flag word is re-tested here rather than kept as 16 masks: registers)
         if constexpr (k == 0) *p = WT(0);
         else *p = r[k - 1];
         ++p;
@@ -787,9 +890,9 @@ __device__ __forceinline__ void p1_stage(WT* stage, p1_runs const& q, WT const (
 }
 
 // staging area -> partial buffer: lane i takes staged totals i, 64 + i, ... (coalesced); run ordinals [n_lo, n_hi), staged at
-// [0, n_hi - n_lo)
+// [0, n_hi - n_lo).  The caller has waited for q.slot.
 template <typename WT>
-__device__ __forceinline__ void p1_writeout(p1_args<WT> const& a, WT const* stage, int lane, p1_regs const& rg, p1_runs const& q, uint32_t n_lo, uint32_t n_hi)
+__device__ __forceinline__ void p1_writeout(p1_args<WT> const& a, WT const* stage, int lane, uint32_t rec, p1_runs const& q, uint32_t n_lo, uint32_t n_hi)
 {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -803,7 +906,9 @@ __device__ __forceinline__ void p1_writeout(p1_args<WT> const& a, WT const* stag
         uint32_t const n = (uint32_t)lane + 64u * (uint32_t)jj;
         uint32_t slot    = q.slot[jj] + (rm1 + 64u * (uint32_t)jj) + (uint32_t)lane;
         if (jj == 0) slot = lane == 0 ? q.head_slot : slot;
-        if (n < n_hi) st32<WT>(a.part, slot * (uint32_t)sizeof(WT), stage[n]);
+#ifndef CGA_ABL_NOSTORE
+        if (n < n_hi) vm_st(a.part, slot * (uint32_t)sizeof(WT), stage[n]);
+#endif
       }
     }
     j = TP_NSLOT;
@@ -811,19 +916,24 @@ __device__ __forceinline__ void p1_writeout(p1_args<WT> const& a, WT const* stag
   uint32_t base = q.blk8;
   if (n_lo != 0) {  // rare (more than TP_STAGE run starts in the range): recount the block starts before ordinal 64 * j
     base = q.blk;
-    for (uint32_t jj = 0; jj < j; ++jj) base += (uint32_t)__builtin_popcount(rdl(rg.rec, 2u * jj)) + (uint32_t)__builtin_popcount(rdl(rg.rec, 2u * jj + 1u));
+    for (uint32_t jj = 0; jj < j; ++jj) base += (uint32_t)__builtin_popcount(rdl(rec, 2u * jj)) + (uint32_t)__builtin_popcount(rdl(rec, 2u * jj + 1u));
   }
-  for (; 64u * j < n_hi; j += 4) {  // the rest in batches of four loads, then four stores (one wait per batch)
+  for (; 64u * j < n_hi; j += 4) {  // the rest in batches: four delta loads, ONE full wait, four stores
     uint32_t sl[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       sl[t] = 0;
-      if (64u * (j + (uint32_t)t) < n_hi) sl[t] = p1_delta_group<WT>(a, rg.rec, j + (uint32_t)t, base);
+      if (64u * (j + (uint32_t)t) < n_hi) sl[t] = p1_delta_group<WT>(a, rec, j + (uint32_t)t, base);
     }
+    vm_wait0();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) vm_fence(sl[t]);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       uint32_t const n = 64u * (j + (uint32_t)t) + (uint32_t)lane;
-      if (n >= n_lo && n < n_hi) st32<WT>(a.part, (sl[t] + rm1 + n) * (uint32_t)sizeof(WT), stage[n - n_lo]);
+#ifndef CGA_ABL_NOSTORE
+      if (n >= n_lo && n < n_hi) vm_st(a.part, (sl[t] + rm1 + n) * (uint32_t)sizeof(WT), stage[n - n_lo]);
+#endif
     }
   }
   __builtin_amdgcn_wave_barrier();  // the staging area is reused by the next item
@@ -836,7 +946,7 @@ struct p1_pending {  // what compute leaves for the (later) write-out of the sam
 // Values: LDS gathers, in-lane segmented sum, wave64 segmented scan; run totals staged in LDS.  Returns (lane 63) the total
 // of the run still open at the end of the range -- or of the whole range when no run starts in it.
 template <typename WT, bool WEIGHTED>
-__device__ __forceinline__ WT p1_compute(p1_args<WT> const& a, WT const* xs, WT* stage, int lane, p1_regs const& rg, p1_runs const& q, p1_pending& pend)
+__device__ __forceinline__ WT p1_compute(p1_args<WT> const& a, WT const* xs, WT* stage, int lane, p1_regs const& rg, p1_runs& q, p1_pending& pend)
 {
   uint32_t const e = q.es + (uint32_t)TP_EPL * (uint32_t)lane;
   WT r[TP_EPL];  // values, then in place: running sum since the last run start at or before element k
@@ -844,7 +954,11 @@ __device__ __forceinline__ WT p1_compute(p1_args<WT> const& a, WT const* xs, WT*
     constexpr int k  = decltype(kc)::value;
     uint32_t const w = k % 8 < 2 ? rg.id[k / 8].x : k % 8 < 4 ? rg.id[k / 8].y : k % 8 < 6 ? rg.id[k / 8].z : rg.id[k / 8].w;
     constexpr int sh = sizeof(WT) == 4 ? 2 : 3;
+#ifdef CGA_ABL_NOGATHER
+    r[k] = (WT)__uint_as_float(0x3f800000u | (idx_offset<(k & 1), sh>(w) >> 2));
+#else
     r[k] = *reinterpret_cast<WT const*>(reinterpret_cast<unsigned char const*>(xs) + idx_offset<(k & 1), sh>(w));
+#endif
   });
   if constexpr (WEIGHTED) {
 #pragma unroll
@@ -865,13 +979,12 @@ __device__ __forceinline__ WT p1_compute(p1_args<WT> const& a, WT const* xs, WT*
   }
   // in-lane segmented sum: r[k] = v[k] + (run start at k ? 0 : r[k-1]); the select is a bit mask (0 / ~0 from the flag bit)
   uint32_t const nflags = ~q.f;
-  uint32_t cont[TP_EPL];  // ~0 when element k continues the run of element k - 1, 0 when a run starts at k
   static_for<TP_EPL>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    cont[k]         = bit_fill<k>(nflags);
     if constexpr (k >= 1) {
-      if constexpr (sizeof(WT) == 4) r[k] += __uint_as_float(__float_as_uint(r[k - 1]) & cont[k]);
-      else r[k] += __longlong_as_double(__double_as_longlong(r[k - 1]) & (long long)(int)cont[k]);
+      uint32_t const cont = bit_fill<k>(nflags);  // ~0 when element k continues the run of element k - 1, 0 when a run starts at k
+      if constexpr (sizeof(WT) == 4) r[k] += __uint_as_float(__float_as_uint(r[k - 1]) & cont);
+      else r[k] += __longlong_as_double(__double_as_longlong(r[k - 1]) & (long long)(int)cont);
     }
   });
   WT s       = r[TP_EPL - 1];
@@ -879,14 +992,15 @@ __device__ __forceinline__ WT p1_compute(p1_args<WT> const& a, WT const* xs, WT*
   wave_seg_scan(s, c);
   WT const carry_in = dpp_val<0x138, 0xF>(s);  // wave_shr:1: segmented sum up to the previous lane (0 in lane 0; the range starts with an empty carry)
   if (q.c_all <= (uint32_t)TP_STAGE) {
-    p1_stage<WT>(stage, q, r, cont, carry_in, 0u, true);
+    p1_stage<WT>(stage, q, r, carry_in, 0u, true);
     pend.count = q.c_all;
   } else {  // more run totals than the staging area holds: lanes 0-31 (at most TP_STAGE runs) are written out right away
     uint32_t const half = (uint32_t)__builtin_amdgcn_readlane((int)c, 31);
-    p1_stage<WT>(stage, q, r, cont, carry_in, 0u, lane < 32);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the delta entries requested an item ago (see the wait point in the item loop)
-    p1_writeout<WT>(a, stage, lane, rg, q, 0u, half);
-    p1_stage<WT>(stage, q, r, cont, carry_in, half, lane >= 32);
+    p1_stage<WT>(stage, q, r, carry_in, 0u, lane < 32);
+    vm_wait0();  // the delta entries of this item were requested just before this compute (rare path: a full stall)
+    p1_fence_slots(q);
+    p1_writeout<WT>(a, stage, lane, rg.rec, q, 0u, half);
+    p1_stage<WT>(stage, q, r, carry_in, half, lane >= 32);
     pend.base_c = half;
     pend.count  = q.c_all - half;
   }
@@ -913,13 +1027,6 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
   // Work is handed out dynamically in CHUNKS (a few consecutive work items of one source tile; hottest tiles first, the
   // small cold tiles last); chunk ids are fetched three chunks ahead so the item sequence is known two items ahead.
   //
-  // The loop is software-pipelined around the ONE memory counter of gfx9 (vmcnt counts loads AND stores and retires in
-  // order, and the compiler waits with vmcnt(0) across the loop back edge).  Per item i:
-  //     compute(i)                      LDS gathers + scans; run totals staged in LDS; no global memory use
-  //     -- wait --                      covers data(i+1), slots(i), stores(i-1): all issued a whole item earlier
-  //     counts(i+1); stores(i); request slots(i+1) and data(i+2)
-  // so nothing that was just issued is ever waited for.  (Storing first and waiting at the top of the next item, the
-  // natural order, exposes the store round trip and the prefetch latency once per item: 1.6 -> x ms at RMAT-26.)
   unsigned long long const t_start = wall_clock64();
   int n_tiles = 0;
   // thread 0 draws the next chunk and stages its descriptor in LDS: nothing in the item loop depends on a global load that
@@ -933,9 +1040,11 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
   };
   if (tid == 0) { draw(0); draw(1); draw(2); }
   __syncthreads();
-  auto enter = [&](p1_iter& x) {
-    int4 const c = s_chunk[x.pos & 3];
-    if (c.x >= a.n_chunks) { x.item = -1; } else { x.item = c.y; x.end = c.z; x.tile = c.w; }
+  auto enter = [&](p1_iter& x) {  // (readfirstlane: the item sequence is wave-uniform, and the compiler should know it -- scalar
+    int4 const c = s_chunk[x.pos & 3];  // branches keep the loop's control flow, and with it the wait insertion, simple)
+    int const cid = __builtin_amdgcn_readfirstlane(c.x);
+    if (cid >= a.n_chunks) { x.item = -1; }
+    else { x.item = __builtin_amdgcn_readfirstlane(c.y); x.end = __builtin_amdgcn_readfirstlane(c.z); x.tile = __builtin_amdgcn_readfirstlane(c.w); }
   };
   auto advance = [&](p1_iter& x) {
     if (x.item < 0) return;
@@ -948,16 +1057,16 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
   p1_regs rA, rB;
   p1_runs qA, qB;
   p1_iter Jt = I;
-  if (I.item >= 0) {
-    p1_load<WT>(a, I.item, wave, lane, rA);
-    p1_counts(lane, rA, qA);
-    p1_issue_slots<WT>(a, lane, rA, qA);
-    advance(Jt);
-    if (Jt.item >= 0) p1_load<WT>(a, Jt.item, wave, lane, rB);
-  }
-  auto body = [&](p1_regs& cur, p1_runs& qc, p1_regs& nxt, p1_runs& qn) {
+  // loop state carried from an item's compute to its store phase (wave-uniform except `tail`, which lives in lane 63)
+  p1_pending pend{0, 0};
+  WT tail   = WT(0);
+  bool busy = false;
+
+  // stage the source tile of item I (first item of a chunk: every wavefront has passed the chunk-transition barrier), then
+  // LDS gathers + scans of its edges: run totals staged in LDS, no use of global memory besides the tile itself
+  auto compute_item = [&](p1_regs& rg, p1_runs& q) {
     int const J = I.tile;
-    if (J != curJ) {  // only at the first item of a chunk: every wavefront has passed the chunk-transition barrier
+    if (J != curJ) {
       // x is allocated (and zero-filled) up to nJ * T elements; indices are clamped instead of guarded so that the loads
       // stay straight-line (8 in flight per thread)
       using vec4 = typename std::conditional<sizeof(WT) == 4, float4, double4>::type;
@@ -978,34 +1087,68 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
       curJ = J;
       ++n_tiles;
     }
-    p1_pending pend;
-    WT tail = WT(0);
-    bool const busy = qc.es < qc.ee;  // wave-uniform; an empty share (tail of a tile) has nothing to compute or store
-    if (busy) tail = p1_compute<WT, WEIGHTED>(a, xs, stage, lane, cur, qc, pend);
-    // ---- wait point: first use of data(i+1) and of slots(i).  Explicit (vmcnt(0), lgkmcnt/expcnt untouched): the compiler's
-    // own waits are per basic block and conservative -- left to itself it puts vmcnt(0) in front of every conditional
-    // store and delta load below, which serialises them on each other's round trips.
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    if (Jt.item >= 0) p1_counts(lane, nxt, qn);
+    pend.base_c = 0; pend.count = 0;
+    tail = WT(0);
+    busy = q.es < q.ee;  // wave-uniform; an empty share (tail of a tile) has nothing to compute or store
+#ifdef CGA_ABL_LOADONLY
+    if (busy) tail = (WT)__uint_as_float((rg.id[0].x ^ rg.id[0].y ^ rg.id[0].z ^ rg.id[0].w ^ rg.id[1].x ^ rg.id[1].y ^ rg.id[1].z ^ rg.id[1].w ^ rg.fl ^ rg.rec) & 0x3fffffffu);
+#else
+    if (busy) tail = p1_compute<WT, WEIGHTED>(a, xs, stage, lane, rg, q, pend);
+#endif
+  };
+
+  // Software pipeline around the ONE memory counter of gfx9 (vmcnt counts loads AND stores and retires in order).  Steady
+  // state, per iteration (item i = I was computed in the previous iteration; its edge data sits in `cur`, item i+1's in `nxt`):
+  //     counts(i+1); stores(i); request slot deltas(i+1) and edge data(i+2)      <- everything is ISSUED here ...
+  //     [chunk transition: barrier, next chunk id, source tile of item i+1]
+  //     compute(i+1)                                                              <- ... has a whole compute to complete ...
+  //     vmcnt(0)                                                                  <- ... and is waited for here, once.
+  // The back edge follows the wait, so no operation is in flight across it (see the note on vm_ld*).
+  if (I.item >= 0) {
+    p1_load<WT>(a, I.item, wave, lane, rA);
+    vm_wait0();
+    p1_fence(rA);
+    p1_counts(lane, rA, qA);
+    p1_issue_slots<WT>(a, lane, rA, qA);
+    advance(Jt);
+    p1_load<WT>(a, max(Jt.item, 0), wave, lane, rB);  // unconditional (a dummy re-read of item 0 when there is no next item)
+    compute_item(rA, qA);
+    vm_wait0();
+    p1_fence(rB);
+    p1_fence_slots(qA);
+  }
+  auto body = [&](p1_regs& cur, p1_runs& qc, p1_regs& nxt, p1_runs& qn) {
+    bool const have_next = Jt.item >= 0;
+    if (have_next) p1_counts(lane, nxt, qn);
     if (busy) {
-      if (pend.count) p1_writeout<WT>(a, stage, lane, cur, qc, pend.base_c, pend.base_c + pend.count);
-      if (lane == 63) st32<WT>(a.part, qc.slot_tail * (uint32_t)sizeof(WT), tail);  // slot_tail = head slot when no run starts in the range
+      if (pend.count) p1_writeout<WT>(a, stage, lane, cur.rec, qc, pend.base_c, pend.base_c + pend.count);
+#ifndef CGA_ABL_NOSTORE
+      if (lane == 63) vm_st(a.part, qc.slot_tail * (uint32_t)sizeof(WT), tail);  // slot_tail = head slot when no run starts in the range
+#endif
     }
-    if (Jt.item >= 0) p1_issue_slots<WT>(a, lane, nxt, qn);
+    if (have_next) p1_issue_slots<WT>(a, lane, nxt, qn);
     p1_iter K = Jt;
     advance(K);
-    if (K.item >= 0) p1_load<WT>(a, K.item, wave, lane, cur);  // `cur` is free: data(i+2)
+    p1_load<WT>(a, max(K.item, 0), wave, lane, cur);  // `cur` is free: data(i+2); unconditional
     int const old_pos = I.pos;
     I  = Jt;
     Jt = K;
-    if (I.item >= 0 && I.pos != old_pos) {  // next item belongs to another chunk: all wavefronts are done with the tile
-      __syncthreads();
-      if (tid == 0) draw((I.pos + 3) & 3);
+    busy = false;
+    if (I.item >= 0) {
+      if (I.pos != old_pos) {  // next item belongs to another chunk: all wavefronts are done with the tile
+        __syncthreads();
+        if (tid == 0) draw((I.pos + 3) & 3);
+      }
+      compute_item(nxt, qn);
     }
+    // every path through an iteration ends here (no early exit: a loop exit that bypasses the wait would reach the loop
+    // header's join with operations in flight, and the compiler would then guard every later use with its own vmcnt(0))
+    vm_wait0();
+    p1_fence(cur);
+    p1_fence_slots(qn);
   };
-  while (I.item >= 0) {
+  while (I.item >= 0) {  // (the second call is a no-op apart from a dummy load when the first one consumed the last item)
     body(rA, qA, rB, qB);
-    if (I.item < 0) break;
     body(rB, qB, rA, qA);
   }
   if constexpr (DBG) {
@@ -1050,10 +1193,21 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
 {
   using ACC = typename p2_acc<WT>::type;
   constexpr int RPT = TP2_ROWS / TP2_BLOCK;  // rows per thread in the epilogue
-  __shared__ ACC acc[TP2_ROWS];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+  ACC* acc = reinterpret_cast<ACC*>(smem2);  // [TP2_ROWS]
   __shared__ double red[3 * (TP2_BLOCK / 64)];
   int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int const I   = blockIdx.x;
+  if (a.e.cr.nI_act > 0 && I >= a.e.cr.nI_act) {  // tiled_const_rows: x of the live columns whose rows have no in-edge
+    WT const b       = a.e.scal->base;
+    int64_t const n  = a.e.cr.n_cols;
+    WT* const xo     = a.e.x_next + a.e.cr.c0;
+    for (int64_t j = (int64_t)(I - a.e.cr.nI_act) * (TP2_BLOCK * 8) + tid, k = 0; k < 8 && j < n; ++k, j += TP2_BLOCK) {
+      WT const ow = a.e.cr.outw_c[j];
+      xo[j]       = b / (ow == WT(0) ? WT(1) : ow);
+    }
+    return;
+  }
   uint32_t const row0 = a.tile_row0[I], nrows = a.tile_row0[I + 1] - row0;
   uint32_t const s0 = a.region_off[I], s1 = a.region_off[I + 1];
   tiled_epilogue<WT> const& e = a.e;
@@ -1142,6 +1296,7 @@ fin_args<WT> make_fin(tiled_epilogue<WT> const& e, int n)
   f.partials = e.partials; f.n = n; f.scal = e.scal; f.totals = e.totals; f.alpha = e.alpha; f.nv_global = e.nv_global;
   f.personalized = e.pers != nullptr;
   f.wmax = e.wmax;
+  if (e.cr.nI_act > 0) { f.cr_rows = (double)e.cr.n_rows; f.cr_dangling = (double)e.cr.n_dangling; f.cr_max_inv_outw = e.cr.max_inv_outw; }
   return f;
 }
 
@@ -1152,7 +1307,7 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
                   tiled_epilogue<WT> const* pending)
 {
   if (t.n_items == 0) {
-    if (pending) tiled_finish<WT>(h, *pending, t.nI);
+    if (pending) tiled_finish<WT>(h, *pending, tiled_fold_count(t, *pending));
     return;
   }
   p1_args<WT> a;
@@ -1169,7 +1324,7 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
   a.part      = part;
   a.alpha     = alpha;
   a.pmask = map.pmask; a.plog = map.plog; a.chunk = map.chunk; a.ncols = map.ncols;
-  if (pending) a.fin = make_fin<WT>(*pending, t.nI);
+  if (pending) a.fin = make_fin<WT>(*pending, tiled_fold_count(t, *pending));
   size_t const lds = std::max<size_t>(((size_t)t.T + (size_t)TP_WAVES * TP_STAGE) * sizeof(WT) + 64, 3 * TP_BLOCK * sizeof(double));
   bool const w     = a.weights != nullptr;
   static bool attr_done[2] = {false, false};
@@ -1209,15 +1364,27 @@ void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled
   a.nI         = t.nI;
   a.e          = e;
   a.counters   = counters;
+  using ACC = typename p2_acc<WT>::type;
+  size_t const lds = (size_t)TP2_ROWS * sizeof(ACC);
+  static bool attr_done = false;
+  if (!attr_done && lds > 48 * 1024) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_tiled_phase2<WT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_tiled_phase2<WT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  int grid = t.nI;
+  if (e.cr.nI_act > 0) grid = e.cr.nI_act + (int)((e.cr.n_cols + TP2_BLOCK * 8 - 1) / (TP2_BLOCK * 8));
   timed_launch tl(h, "pagerank_reduce");
-  if (e.pers) hipLaunchKernelGGL((k_tiled_phase2<WT, true>), t.nI, TP2_BLOCK, 0, h.stream, a);
-  else        hipLaunchKernelGGL((k_tiled_phase2<WT, false>), t.nI, TP2_BLOCK, 0, h.stream, a);
+  if (e.pers) hipLaunchKernelGGL((k_tiled_phase2<WT, true>), grid, TP2_BLOCK, lds, h.stream, a);
+  else        hipLaunchKernelGGL((k_tiled_phase2<WT, false>), grid, TP2_BLOCK, lds, h.stream, a);
 }
 
 template <typename WT>
-void tiled_finish(handle_t const& h, tiled_epilogue<WT> const& e, int n_partials)
+void tiled_finish(handle_t const& h, tiled_epilogue<WT> const& e, int n_partials, double init_prev)
 {
-  hipLaunchKernelGGL(k_tiled_finish<WT>, 1, TP2_BLOCK, 0, h.stream, make_fin<WT>(e, n_partials));
+  fin_args<WT> f = make_fin<WT>(e, n_partials);
+  f.init_prev    = init_prev;
+  hipLaunchKernelGGL(k_tiled_finish<WT>, 1, TP2_BLOCK, 0, h.stream, f);
 }
 
 template <typename WT>
@@ -1238,7 +1405,7 @@ void tiled_scalars_from_ranks(handle_t const& h, tiled_epilogue<WT> const& e, vo
 #define CGA_INSTANTIATE_TILED(WT)                                                                                                          \
   template void tiled_phase1<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT, WT*, uint32_t*, tiled_x_map<WT> const&, tiled_epilogue<WT> const*); \
   template void tiled_phase2<WT>(handle_t const&, tiled_csc_t const&, WT const*, tiled_epilogue<WT> const&, uint32_t*);                                  \
-  template void tiled_finish<WT>(handle_t const&, tiled_epilogue<WT> const&, int);                                                           \
+  template void tiled_finish<WT>(handle_t const&, tiled_epilogue<WT> const&, int, double);                                                           \
   template int tiled_prologue<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT const*, WT*, int64_t, double*);                          \
   template void tiled_scalars_from_ranks<WT>(handle_t const&, tiled_epilogue<WT> const&, void const*, size_t, size_t, int);
 CGA_INSTANTIATE_TILED(float)

@@ -40,6 +40,22 @@ struct pr_scalars {  // device-resident PageRank loop state
   WT diff;
   int32_t fx_k;   // tiled path, fp32: phase 2 accumulates value * 2^fx_k in 64-bit fixed point
   double fx_inv;  // 2^-fx_k
+  WT base_prev;   // tiled_const_rows: the value the rows without in-edges hold BEFORE the iteration that uses `base`
+};
+
+// Rows without in-edges (ids >= tiled_csc_t::n_act) have pr' = base in every iteration: a plan that is neither personalized nor
+// started from a user vector leaves them out of the per-iteration epilogue.  Their share of the iteration's scalars is
+// analytic (n_rows * |base - base_prev|, n_dangling * base, base * max_inv_outw), the x of their live columns
+// [c0, c0 + n_cols) is base / outw_c[.] (written by a few extra workgroups of phase 2), and pr itself is materialized when the
+// result is read.  Saves 16 B x 60 % of the rows of an RMAT-26 graph per iteration.
+template <typename WT>
+struct tiled_const_rows {
+  int nI_act{0};             // 0 = off (every destination tile runs its epilogue)
+  int64_t n_rows{0};         // rows >= n_act
+  int64_t n_dangling{0};     // of those, rows without out-edges
+  double max_inv_outw{0};    // max over those rows of 1 / (outw == 0 ? 1 : outw)
+  WT const* outw_c{nullptr}; // out-weight sums of the live columns >= c0, in column order
+  int64_t c0{0}, n_cols{0};
 };
 
 constexpr int TP_BLOCK = 1024;               // phase-1 workgroup: 16 wavefronts sharing one LDS tile
@@ -52,8 +68,15 @@ constexpr int TP_SUB   = 64 * TP_EPL;        // edges per wavefront per work ite
 constexpr int TP_WLEN  = TP_SUB;
 constexpr int TP_ITEM  = TP_WLEN * TP_WAVES;  // edges per work item
 constexpr int TP_CHUNK = 16;                 // max work items per dynamically scheduled chunk (256 Ki edges); chunks are handed out largest first
-constexpr int TP2_BLOCK = 512;               // phase-2 workgroup
-constexpr int TP2_ROWS  = 4096;              // max destination rows per phase-2 tile (64-bit LDS accumulators: 32 KiB)
+constexpr int TP_CHUNK_BIG = 16;             // chunk length for the first part of a tile that spans many chunks (see build_tiled_csc)
+#ifndef CGA_TP2_BLOCK
+#define CGA_TP2_BLOCK 512
+#endif
+#ifndef CGA_TP2_ROWS
+#define CGA_TP2_ROWS 4096
+#endif
+constexpr int TP2_BLOCK = CGA_TP2_BLOCK;     // phase-2 workgroup
+constexpr int TP2_ROWS  = CGA_TP2_ROWS;      // max destination rows per phase-2 tile (64-bit LDS accumulators: 32 KiB at 4096)
 
 struct tiled_wave_t {  // build-time description of one wavefront's share of a work item
   uint32_t es, ee;     // padded edge positions [es, ee); es = item * TP_ITEM + wave * TP_WLEN
@@ -80,6 +103,9 @@ struct tiled_csc_t {
   int n_wg{0};  // phase-1 workgroups
   int n_chunks{0};
   int64_t nv{0}, ne{0}, ne_pad{0}, n_runs{0}, n_slots{0}, n_blocks{0};
+  int64_t n_act{0};  // rows >= n_act have no in-edge; a destination-tile boundary is forced there
+  int nI_act{0};     // destination tiles [0, nI_act) cover rows [0, n_act)
+  int64_t c0{0};     // columns >= c0 belong to rows >= n_act (columns are monotone in the row id)
   double wmax{0};  // max over destinations of sum |w| of the in-edges (in-degree when unweighted): bounds a row sum by alpha * max|x| * wmax
   dvec<uint16_t> src16;       // [ne_pad + pad] tile-local source id
   dvec<uint32_t> bits;        // [ne_pad / 32 + pad] bit p = edge position p starts a run
@@ -126,6 +152,7 @@ struct tiled_epilogue {
   WT alpha{0};
   int64_t nv_global{0};
   double wmax{0};             // tiled_csc_t::wmax
+  tiled_const_rows<WT> cr;    // nI_act == 0: off
 };
 
 // phase 1: part[slot of run] = sum over the run's edges of alpha * x[src] (* w).  counters[0] = chunk cursor (0 on entry;
@@ -139,9 +166,14 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
 template <typename WT>
 void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters);
 
-// folds e.partials[0 .. n_partials) in a fixed order into e.scal (or e.totals)
+// folds e.partials[0 .. n_partials) in a fixed order into e.scal (or e.totals).  init_prev >= 0: this is the fold of the
+// iteration-0 state (tiled_prologue visited every row); scal->base_prev becomes init_prev, the rows' initial value
 template <typename WT>
-void tiled_finish(handle_t const& h, tiled_epilogue<WT> const& e, int n_partials);
+void tiled_finish(handle_t const& h, tiled_epilogue<WT> const& e, int n_partials, double init_prev = -1.0);
+
+// number of per-tile scalar triples phase 2 leaves for the fold
+template <typename WT>
+inline int tiled_fold_count(tiled_csc_t const& t, tiled_epilogue<WT> const& e) { return e.cr.nI_act > 0 ? e.cr.nI_act : t.nI; }
 
 // iteration-0 state: x = pr / out_w plus per-block (0, dangling, max |x|) partials; returns the number of partial triples
 template <typename WT>
@@ -172,6 +204,7 @@ template <typename WT>
 __device__ __forceinline__ void tiled_write_scalars(pr_scalars<WT>* scal, double diff, double dang, double xmax, WT alpha, int64_t nv_global,
                                                     int personalized, double wmax)
 {
+  scal->base_prev   = scal->base;  // what the iteration that just ended wrote into the rows without in-edges
   WT dangling       = (WT)dang;
   WT factor         = dangling * alpha + (WT)(1.0 - (double)alpha);
   scal->dangling    = dangling;

@@ -553,6 +553,77 @@ def test_pagerank_full_size_properties(cg, handle, monkeypatch):
     assert float(((a.double() - expect).abs() / expect).max()) <= 5e-6
 
 
+def test_pagerank_config2_rmat22_vs_oracle(cg, handle, orc, monkeypatch):
+    """BASELINE.json config 2 at full size: RMAT-22 (67 M edges) PageRank fp32, 20 fixed iterations, HIP path vs the CPU
+    oracle (restatement of pagerank_reference / detail::pagerank, fp64 accumulation): max|delta| <= 1e-6 AND relative <= 2e-5 on
+    every vertex (reference tolerance: cpp/tests/link_analysis/pagerank_test.cpp:328-334, 1e-3 relative).  Run twice: with the
+    rows without in-edges left out of the per-iteration epilogue (default) and with every row visited."""
+    scale, iters = 22, 20
+    nv, ne = 1 << scale, 16 << scale
+    s, d = orc.rmat(scale, ne)
+    off, idx, _ = orc.coo_to_cs(nv, d, s)
+    truth, it, _ = orc.pagerank(nv, off, idx, None, 0.85, 0.0, iters, acc64=True)
+    assert it == iters
+    g = make_graph(cg, handle, s, d, None, transposed=True, renumber=True, vertices=np.arange(nv))
+    got = {}
+    for mode in ("const_rows", "all_rows"):
+        if mode == "all_rows":
+            monkeypatch.setenv("CUGRAPH_AMD_PAGERANK_ALL_ROWS", "1")
+        v, pr, conv = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, iters, False, fail_on_nonconvergence=False)
+        (pr,) = by_vertex(v, pr)
+        got[mode] = pr
+        assert np.max(np.abs(pr - truth)) <= 1e-6
+        rel = np.max(np.abs(pr - truth) / np.maximum(truth, 1e-30))
+        assert rel <= 2e-5, (mode, rel)
+        assert abs(float(pr.astype(np.float64).sum()) - 1.0) < 1e-4
+    assert np.max(np.abs(got["const_rows"] - got["all_rows"]) / got["all_rows"]) <= 1e-6
+    # the stopping rule sees the same L1 change either way: same iteration count to epsilon
+    monkeypatch.delenv("CUGRAPH_AMD_PAGERANK_ALL_ROWS", raising=False)
+    p1 = cg.PageRankPlan(handle, g, 0.85); n1, c1 = p1.step(100, epsilon=1e-7)
+    monkeypatch.setenv("CUGRAPH_AMD_PAGERANK_ALL_ROWS", "1")
+    p2 = cg.PageRankPlan(handle, g, 0.85); n2, c2 = p2.step(100, epsilon=1e-7)
+    tr, it2, conv2 = orc.pagerank(nv, off, idx, None, 0.85, 1e-7, 100, acc64=True)
+    assert c1 and c2 and conv2 and n1 == n2 and abs(n1 - it2) <= 1, (n1, n2, it2)
+
+
+def test_bfs_sssp_config3_rmat24_vs_oracle(cg, handle, orc):
+    """BASELINE.json config 3 at full size: RMAT-24 (268 M edges) BFS from 3 roots and SSSP (unit weights = integer hops, and
+    integer weights 1..255) from 1 root: distances bit-exact vs the CPU oracle (bfs_reference / Dijkstra sssp_reference
+    restatements; cpp/tests/traversal/bfs_test.cpp:213-233, sssp_test.cpp:212-240)."""
+    import torch
+
+    scale = 24
+    nv, ne = 1 << scale, 16 << scale
+    s, d = orc.rmat(scale, ne)
+    rng = np.random.default_rng(7)
+    wint = rng.integers(1, 256, ne).astype(np.float32)
+    coff, cidx, cw = orc.coo_to_cs(nv, s, d, wint)
+    outdeg = np.diff(coff)
+    roots = [int(r) for r in np.flatnonzero(outdeg > 50)[[3, 1000, 50000]]]
+    g = make_graph(cg, handle, s, d, wint, transposed=False, renumber=True, vertices=np.arange(nv))
+    for k, root in enumerate(roots):
+        dist, pred, bv = cg.bfs(handle, g, T([root], np.int32), False, 0, True, False)
+        od, _ = orc.bfs(nv, coff, cidx, [root])
+        got_d, got_p = by_vertex(bv, dist, pred)
+        assert np.array_equal(got_d, od), f"BFS distances differ (root {root})"
+        reached = od != 2147483647
+        par = got_p[reached & (np.arange(nv) != root)]
+        assert (par >= 0).all() and np.array_equal(od[par] + 1, od[reached & (np.arange(nv) != root)])  # a valid parent one level up
+    root = roots[0]
+    sv, sd, sp = cg.sssp(handle, g, root, 3.0e38, True, False)
+    osd, _ = orc.sssp(nv, coff, cidx, cw, root)
+    got_s, got_sp = by_vertex(sv, sd, sp)
+    assert np.array_equal(got_s, osd), "SSSP (integer weights) distances differ"
+    del g
+    ones = np.ones(ne, np.float32)
+    g1 = make_graph(cg, handle, s, d, ones, transposed=False, renumber=True, vertices=np.arange(nv))
+    sv, sd, _ = cg.sssp(handle, g1, root, 3.0e38, False, False)
+    (got_u,) = by_vertex(sv, sd)
+    od, _ = orc.bfs(nv, coff, cidx, [root])
+    hops = np.where(od == 2147483647, np.float32(np.finfo(np.float32).max), od.astype(np.float32))
+    assert np.array_equal(got_u, hops), "SSSP with unit weights must equal the BFS levels bit for bit"
+
+
 @pytest.mark.parametrize("flags", [dict(drop_self_loops=True), dict(drop_multi_edges=True), dict(symmetrize=True),
                                    dict(drop_self_loops=True, drop_multi_edges=True, symmetrize=True)])
 @pytest.mark.parametrize("weighted", [False, True])

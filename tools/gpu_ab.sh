@@ -11,7 +11,7 @@ for l in sys.stdin:
 for lib in ${LIBS:-base}; do for scale in ${SCALES:-26}; do
   cp "gpurun_libs/$lib.so" cugraph_amd/lib/libcugraph_c.so
   echo "== lib=$lib scale=$scale" >> "$O/ab.log"
-  timeout 600 python bench.py --scale $scale --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline 2>&1 | tail -3 | python -c "$fmt" >> "$O/ab.log" 2>&1
+  timeout 600 python bench.py --scale $scale --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline ${BENCH_EXTRA:-} 2>&1 | tail -3 | python -c "$fmt" >> "$O/ab.log" 2>&1
 done; done
 cp /tmp/orig.so cugraph_amd/lib/libcugraph_c.so
 cat "$O/ab.log"
