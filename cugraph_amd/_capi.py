@@ -85,6 +85,8 @@ PROTOTYPES = {
     "cugraph_graph_create_sg": (C.c_int, [_P, C.POINTER(GraphPropertiesStruct), _P, _P, _P, _P, _P, _P] + [C.c_int] * 6 + [_PP, _PP]),
     "cugraph_graph_create_with_times_sg": (C.c_int, [_P, C.POINTER(GraphPropertiesStruct), _P, _P, _P, _P, _P, _P, _P, _P] + [C.c_int] * 6 + [_PP, _PP]),
     "cugraph_graph_create_sg_from_csr": (C.c_int, [_P, C.POINTER(GraphPropertiesStruct), _P, _P, _P, _P, _P] + [C.c_int] * 4 + [_PP, _PP]),
+    "cugraph_graph_create_mg": (C.c_int, [_P, C.POINTER(GraphPropertiesStruct), _PP, _PP, _PP, _PP, _PP, _PP, C.c_int, C.c_size_t] + [C.c_int] * 4 + [_PP, _PP]),
+    "cugraph_graph_create_with_times_mg": (C.c_int, [_P, C.POINTER(GraphPropertiesStruct), _PP, _PP, _PP, _PP, _PP, _PP, _PP, _PP, C.c_int, C.c_size_t] + [C.c_int] * 4 + [_PP, _PP]),
     "cugraph_graph_free": (None, [_P]),
     # graph_functions.h
     "cugraph_has_vertex": (C.c_int, [_P, _P, _P, C.c_int, _PP, _PP]),
@@ -109,6 +111,13 @@ PROTOTYPES = {
     "cugraph_coo_get_edge_id": (_P, [_P]),
     "cugraph_coo_get_edge_type": (_P, [_P]),
     "cugraph_coo_free": (None, [_P]),
+    "cugraph_coo_list_size": (C.c_size_t, [_P]),
+    "cugraph_coo_list_element": (_P, [_P, C.c_size_t]),
+    "cugraph_coo_list_free": (None, [_P]),
+    "cugraph_generate_rmat_edgelists": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _PP, _PP]),
+    "cugraph_generate_edge_ids": (C.c_int, [_P, _P, C.c_int, _PP]),
+    "cugraph_generate_edge_types": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _PP]),
+    "cugraph_data_type_id_from_dlpack": (C.c_int, [_P, C.POINTER(C.c_int), _PP]),
     "cugraph_louvain": (C.c_int, [_P, _P, C.c_size_t, C.c_double, C.c_double, C.c_int, _PP, _PP]),
     "cugraph_hierarchical_clustering_result_get_vertices": (_P, [_P]),
     "cugraph_hierarchical_clustering_result_get_clusters": (_P, [_P]),
@@ -117,6 +126,14 @@ PROTOTYPES = {
     "cugraph_in_degrees": (C.c_int, [_P, _P, _P, C.c_int, _PP, _PP]),
     "cugraph_out_degrees": (C.c_int, [_P, _P, _P, C.c_int, _PP, _PP]),
     "cugraph_degrees": (C.c_int, [_P, _P, _P, C.c_int, _PP, _PP]),
+    "cugraph_decompress_to_edgelist": (C.c_int, [_P, _P, C.c_int, _PP, _PP]),
+    "cugraph_edgelist_get_sources": (_P, [_P]),
+    "cugraph_edgelist_get_destinations": (_P, [_P]),
+    "cugraph_edgelist_get_edge_weights": (_P, [_P]),
+    "cugraph_edgelist_get_edge_ids": (_P, [_P]),
+    "cugraph_edgelist_get_edge_type_ids": (_P, [_P]),
+    "cugraph_edgelist_get_edge_offsets": (_P, [_P]),
+    "cugraph_edgelist_free": (None, [_P]),
     "cugraph_degrees_result_get_vertices": (_P, [_P]),
     "cugraph_degrees_result_get_in_degrees": (_P, [_P]),
     "cugraph_degrees_result_get_out_degrees": (_P, [_P]),

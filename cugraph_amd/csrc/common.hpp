@@ -296,7 +296,13 @@ struct coo_t {  // behind cugraph_coo_t (c_api/coo.hpp)
   device_array_t* src{nullptr};
   device_array_t* dst{nullptr};
   device_array_t* wgt{nullptr};
-  ~coo_t() { delete src; delete dst; delete wgt; }
+  device_array_t* ids{nullptr};    // cugraph_generate_edge_ids
+  device_array_t* types{nullptr};  // cugraph_generate_edge_types
+  ~coo_t() { delete src; delete dst; delete wgt; delete ids; delete types; }
+};
+struct coo_list_t {  // behind cugraph_coo_list_t: owns its elements
+  std::vector<coo_t*> list;
+  ~coo_list_t() { for (auto* c : list) delete c; }
 };
 
 struct paths_result_t {  // c_api/paths_result.hpp

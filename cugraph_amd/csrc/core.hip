@@ -316,3 +316,23 @@ extern "C" cugraph_error_code_t cugraph_type_erased_device_array_view_copy(const
     h.sync();  // callers free the source right after (pylibcugraph utils.pyx:162-196); see SURVEY section 9.8
   });
 }
+
+// cpp/src/c_api/dlpack_interop.cpp:25-95 (called by pylibcugraph/utils.pyx:127-133 for every array that enters the library)
+#include "cugraph_c/dlpack_interop.h"
+extern "C" cugraph_error_code_t cugraph_data_type_id_from_dlpack(const DLDataType* dlpack_dtype, cugraph_data_type_id_t* dtype, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(dlpack_dtype != nullptr, CUGRAPH_INVALID_INPUT, "dlpack_dtype cannot be NULL");
+    CGA_EXPECTS(dtype != nullptr, CUGRAPH_INVALID_INPUT, "dtype cannot be NULL");
+    CGA_EXPECTS(dlpack_dtype->lanes == 1, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "vectorized DLPack types (lanes > 1) are not supported");
+    unsigned const code = dlpack_dtype->code, bits = dlpack_dtype->bits;
+    CGA_EXPECTS(code == kDLInt || code == kDLUInt || code == kDLFloat || code == kDLBool, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "unsupported DLPack type code");
+    int t = -1;
+    if (code == kDLInt) t = bits == 8 ? INT8 : bits == 16 ? INT16 : bits == 32 ? INT32 : bits == 64 ? INT64 : -1;
+    else if (code == kDLUInt) t = bits == 8 ? UINT8 : bits == 16 ? UINT16 : bits == 32 ? UINT32 : bits == 64 ? UINT64 : -1;
+    else if (code == kDLFloat) t = bits == 32 ? FLOAT32 : bits == 64 ? FLOAT64 : -1;
+    else t = bits == 8 ? BOOL : -1;
+    CGA_EXPECTS(t >= 0, CUGRAPH_INVALID_INPUT, "unsupported DLPack dtype bit width for the given type code");
+    *dtype = (cugraph_data_type_id_t)t;
+  });
+}

@@ -287,8 +287,18 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
                 "this build supports INT32 vertex / edge ids only (INT64 graphs: not implemented yet)");
     CGA_EXPECTS(weights == nullptr || weights->type == FLOAT32 || weights->type == FLOAT64,
                 CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "weights must be FLOAT32 or FLOAT64");
-    CGA_EXPECTS(edge_ids == nullptr && edge_type_ids == nullptr && t0 == nullptr && t1 == nullptr, CUGRAPH_NOT_IMPLEMENTED,
-                "edge ids / edge types / edge times are not on the PageRank/BFS/SSSP path and are not implemented");
+    // Edge ids / types / start and end times are edge PROPERTIES that only the sampling and lookup families read
+    // (graph_sg.cpp:803-830 stores them next to the weights).  None of the algorithms of this library reads them: the columns
+    // are validated (sizes above, types here: graph_sg.cpp:781-801) and then not kept -- cugraph_decompress_to_edgelist returns
+    // NULL for them.
+    CGA_EXPECTS(edge_type_ids == nullptr || edge_type_ids->type == INT32, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "edge type ids must be INT32");
+    CGA_EXPECTS(edge_ids == nullptr || edge_ids->type == INT32 || edge_ids->type == INT64, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
+                "edge ids must be INT32 or INT64");
+    CGA_EXPECTS((t0 == nullptr || t0->size == src->size) && (t1 == nullptr || t1->size == src->size), CUGRAPH_INVALID_INPUT,
+                "Invalid input arguments: src size != edge time prop size");
+    CGA_EXPECTS((t0 == nullptr || t0->type == INT32 || t0->type == INT64) && (t1 == nullptr || t1->type == INT32 || t1->type == INT64) &&
+                  (t0 == nullptr || t1 == nullptr || t0->type == t1->type),
+                CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "edge start / end times must share one integer type");
     check_view(src, "src"); check_view(dst, "dst"); check_view(weights, "weights"); check_view(vertices, "vertices");
 
     auto g              = std::make_unique<graph_t>();
@@ -483,6 +493,105 @@ extern "C" cugraph_error_code_t cugraph_graph_create_with_times_sg(
   return create_sg(handle, properties, V(vertices), V(src), V(dst), V(weights), V(edge_ids), V(edge_type_ids),
                    V(edge_start_time_ids), V(edge_end_time_ids), store_transposed, renumber, drop_self_loops,
                    drop_multi_edges, symmetrize, do_expensive_check, graph, error);
+}
+
+// cugraph_graph_create_mg / _with_times_mg (cpp/src/c_api/graph_mg.cpp:326-560; pylibcugraph MGGraph, graphs.pyx:357-700): every
+// rank passes ITS slice of the edge list as `num_arrays` arrays of views and the reference shuffles edges to their owners
+// (graph_mg.cpp:140).  Here the multi-rank exchange lives in the host layer (torch.distributed over RCCL, cugraph_amd/mg.py +
+// the plan API of include/cugraph_amd/extensions.h), so this entry point serves one-rank handles -- the arrays are
+// concatenated and the graph is built as cugraph_graph_create_sg does, always renumbered as an MG graph is
+// (graph_mg.cpp:214) -- and returns CUGRAPH_NOT_IMPLEMENTED on a multi-rank handle.
+namespace cga {
+namespace {
+struct concat_t {
+  dev_buf buf;
+  device_array_view_t view{nullptr, 0, INT32};
+  bool present{false};
+};
+void concat_views(handle_t const& h, cugraph_type_erased_device_array_view_t const* const* arr, size_t num_arrays, char const* what, concat_t& out)
+{
+  if (arr == nullptr) return;
+  size_t total = 0;
+  cugraph_data_type_id_t type = INT32;
+  bool any = false;
+  for (size_t i = 0; i < num_arrays; ++i) {
+    auto v = V(arr[i]);
+    if (!v) continue;
+    CGA_EXPECTS(!any || v->type == type, CUGRAPH_INVALID_INPUT, std::string("Invalid input arguments: all ") + what + " arrays must have the same type.");
+    type = v->type; any = true;
+    total += v->size;
+  }
+  if (!any) return;
+  size_t const esz = dtype_size(type);
+  out.buf.alloc(std::max<size_t>(total, 1) * esz);
+  size_t off = 0;
+  for (size_t i = 0; i < num_arrays; ++i) {
+    auto v = V(arr[i]);
+    if (!v || v->size == 0) continue;
+    HIP_TRY(hipMemcpyAsync(static_cast<char*>(out.buf.ptr) + off * esz, v->data, v->size * esz, hipMemcpyDeviceToDevice, h.stream));
+    off += v->size;
+  }
+  h.sync();
+  out.view    = device_array_view_t{out.buf.ptr, total, type};
+  out.present = true;
+}
+cugraph_error_code_t create_mg(const cugraph_resource_handle_t* handle, const cugraph_graph_properties_t* properties,
+                               cugraph_type_erased_device_array_view_t const* const* vertices, cugraph_type_erased_device_array_view_t const* const* src,
+                               cugraph_type_erased_device_array_view_t const* const* dst, cugraph_type_erased_device_array_view_t const* const* weights,
+                               cugraph_type_erased_device_array_view_t const* const* edge_ids, cugraph_type_erased_device_array_view_t const* const* edge_type_ids,
+                               cugraph_type_erased_device_array_view_t const* const* t0, cugraph_type_erased_device_array_view_t const* const* t1,
+                               bool_t store_transposed, size_t num_arrays, bool_t drop_self_loops, bool_t drop_multi_edges, bool_t symmetrize,
+                               bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error)
+{
+  if (graph) *graph = nullptr;
+  concat_t cv, cs, cd, cw, ci, ct, c0, c1;
+  cugraph_error_code_t rc = guarded(error, [&] {
+    handle_t const& h = H(handle);
+    CGA_EXPECTS(h.comm_size == 1, CUGRAPH_NOT_IMPLEMENTED,
+                "cugraph_graph_create_mg on a multi-rank handle: the multi-GPU graph lives behind cugraph_amd_pagerank_mg_plan_* / cugraph_amd_traversal_mg_plan_* (include/cugraph_amd/extensions.h)");
+    CGA_EXPECTS(src != nullptr && dst != nullptr && num_arrays >= 1, CUGRAPH_INVALID_INPUT, "Invalid input arguments: src / dst arrays.");
+    HIP_TRY(hipSetDevice(h.device));
+    concat_views(h, vertices, num_arrays, "vertices", cv);
+    concat_views(h, src, num_arrays, "src", cs);
+    concat_views(h, dst, num_arrays, "dst", cd);
+    concat_views(h, weights, num_arrays, "weights", cw);
+    concat_views(h, edge_ids, num_arrays, "edge_ids", ci);
+    concat_views(h, edge_type_ids, num_arrays, "edge_type_ids", ct);
+    concat_views(h, t0, num_arrays, "edge_start_time_ids", c0);
+    concat_views(h, t1, num_arrays, "edge_end_time_ids", c1);
+    CGA_EXPECTS(cs.present && cd.present, CUGRAPH_INVALID_INPUT, "Invalid input arguments: src / dst arrays.");
+  });
+  if (rc != CUGRAPH_SUCCESS) return rc;
+  auto opt = [](concat_t& c) -> device_array_view_t const* { return c.present ? &c.view : nullptr; };
+  return create_sg(handle, properties, opt(cv), &cs.view, &cd.view, opt(cw), opt(ci), opt(ct), opt(c0), opt(c1), store_transposed, TRUE,
+                   drop_self_loops, drop_multi_edges, symmetrize, do_expensive_check, graph, error);
+}
+}  // namespace
+}  // namespace cga
+
+extern "C" cugraph_error_code_t cugraph_graph_create_mg(
+  cugraph_resource_handle_t const* handle, cugraph_graph_properties_t const* properties,
+  cugraph_type_erased_device_array_view_t const* const* vertices, cugraph_type_erased_device_array_view_t const* const* src,
+  cugraph_type_erased_device_array_view_t const* const* dst, cugraph_type_erased_device_array_view_t const* const* weights,
+  cugraph_type_erased_device_array_view_t const* const* edge_ids, cugraph_type_erased_device_array_view_t const* const* edge_type_ids,
+  bool_t store_transposed, size_t num_arrays, bool_t drop_self_loops, bool_t drop_multi_edges, bool_t symmetrize, bool_t do_expensive_check,
+  cugraph_graph_t** graph, cugraph_error_t** error)
+{
+  return create_mg(handle, properties, vertices, src, dst, weights, edge_ids, edge_type_ids, nullptr, nullptr, store_transposed, num_arrays,
+                   drop_self_loops, drop_multi_edges, symmetrize, do_expensive_check, graph, error);
+}
+
+extern "C" cugraph_error_code_t cugraph_graph_create_with_times_mg(
+  cugraph_resource_handle_t const* handle, cugraph_graph_properties_t const* properties,
+  cugraph_type_erased_device_array_view_t const* const* vertices, cugraph_type_erased_device_array_view_t const* const* src,
+  cugraph_type_erased_device_array_view_t const* const* dst, cugraph_type_erased_device_array_view_t const* const* weights,
+  cugraph_type_erased_device_array_view_t const* const* edge_ids, cugraph_type_erased_device_array_view_t const* const* edge_type_ids,
+  cugraph_type_erased_device_array_view_t const* const* edge_start_time_ids,
+  cugraph_type_erased_device_array_view_t const* const* edge_end_time_ids, bool_t store_transposed, size_t num_arrays, bool_t drop_self_loops,
+  bool_t drop_multi_edges, bool_t symmetrize, bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error)
+{
+  return create_mg(handle, properties, vertices, src, dst, weights, edge_ids, edge_type_ids, edge_start_time_ids, edge_end_time_ids,
+                   store_transposed, num_arrays, drop_self_loops, drop_multi_edges, symmetrize, do_expensive_check, graph, error);
 }
 
 extern "C" cugraph_error_code_t cugraph_graph_create_sg_from_csr(

@@ -233,3 +233,71 @@ extern "C" cugraph_type_erased_device_array_view_t* cugraph_extract_paths_result
   return as_view(reinterpret_cast<extract_paths_result_t*>(result)->paths);
 }
 extern "C" void cugraph_extract_paths_result_free(cugraph_extract_paths_result_t* result) { delete reinterpret_cast<extract_paths_result_t*>(result); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// cugraph_decompress_to_edgelist + cugraph_edgelist_* (cpp/include/cugraph_c/graph_functions.h:399-480, impl
+// cpp/src/c_api/decompress_to_edgelist.cpp:24-125 -> cugraph::decompress_to_edgelist, cpp/src/structure/
+// decompress_to_edgelist_impl.cuh): the graph back as (sources, destinations[, weights]) with EXTERNAL ids, in the order of
+// the by-source storage (the reference flips a transposed graph first, decompress_to_edgelist.cpp:53-58; here the CSR
+// orientation is built next to the CSC under the same numbering).  Edge ids / types were never stored: their accessors
+// and the offsets accessor return NULL.
+namespace cga {
+struct edgelist_result_t {
+  device_array_t* src{nullptr};
+  device_array_t* dst{nullptr};
+  device_array_t* wgt{nullptr};
+  ~edgelist_result_t() { delete src; delete dst; delete wgt; }
+};
+namespace {
+__global__ void k_rows_of_edges(int32_t const* offsets, int64_t nv, int32_t* rows)
+{
+  int64_t wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int lane       = threadIdx.x & 63;
+  for (int64_t v = wave; v < nv; v += nwaves)
+    for (int32_t p = offsets[v] + lane; p < offsets[v + 1]; p += 64) rows[p] = (int32_t)v;
+}
+}  // namespace
+}  // namespace cga
+
+extern "C" cugraph_error_code_t cugraph_decompress_to_edgelist(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, bool_t do_expensive_check,
+                                                               cugraph_edgelist_t** result, cugraph_error_t** error)
+{
+  (void)do_expensive_check;
+  if (result) *result = nullptr;
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    CGA_EXPECTS(graph != nullptr && result != nullptr, CUGRAPH_INVALID_INPUT, "graph / result is NULL");
+    graph_t& g = *reinterpret_cast<graph_t*>(graph);
+    HIP_TRY(hipSetDevice(h.device));
+    ensure_orientation(h, g, false);
+    auto out = std::make_unique<edgelist_result_t>();
+    out->src = new device_array_t((size_t)g.ne, g.vertex_type);
+    out->dst = new device_array_t((size_t)g.ne, g.vertex_type);
+    if (g.ne > 0) {
+      hipLaunchKernelGGL(k_rows_of_edges, grid_for(g.nv * 16, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)g.csr.offsets.data(), g.nv, out->src->buf.as<int32_t>());
+      HIP_TRY(hipMemcpyAsync(out->dst->buf.ptr, g.csr.indices.data(), (size_t)g.ne * 4, hipMemcpyDeviceToDevice, h.stream));
+      unrenumber_int_to_ext(h, g, out->src->buf.as<int32_t>(), g.ne);
+      unrenumber_int_to_ext(h, g, out->dst->buf.as<int32_t>(), g.ne);
+      if (g.has_weights) {
+        out->wgt = new device_array_t((size_t)g.ne, g.weight_type);
+        HIP_TRY(hipMemcpyAsync(out->wgt->buf.ptr, g.csr.weights.ptr, (size_t)g.ne * dtype_size(g.weight_type), hipMemcpyDeviceToDevice, h.stream));
+      }
+    } else if (g.has_weights) {
+      out->wgt = new device_array_t(0, g.weight_type);
+    }
+    h.sync();
+    *result = reinterpret_cast<cugraph_edgelist_t*>(out.release());
+  });
+}
+static cugraph_type_erased_device_array_view_t* el_view(device_array_t* a)
+{
+  return a ? reinterpret_cast<cugraph_type_erased_device_array_view_t*>(a->new_view()) : nullptr;
+}
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_edgelist_get_sources(cugraph_edgelist_t* e) { return el_view(reinterpret_cast<edgelist_result_t*>(e)->src); }
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_edgelist_get_destinations(cugraph_edgelist_t* e) { return el_view(reinterpret_cast<edgelist_result_t*>(e)->dst); }
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_edgelist_get_edge_weights(cugraph_edgelist_t* e) { return el_view(reinterpret_cast<edgelist_result_t*>(e)->wgt); }
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_edgelist_get_edge_ids(cugraph_edgelist_t*) { return nullptr; }
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_edgelist_get_edge_type_ids(cugraph_edgelist_t*) { return nullptr; }
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_edgelist_get_edge_offsets(cugraph_edgelist_t*) { return nullptr; }
+extern "C" void cugraph_edgelist_free(cugraph_edgelist_t* e) { delete reinterpret_cast<edgelist_result_t*>(e); }

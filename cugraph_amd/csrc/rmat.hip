@@ -6,6 +6,8 @@
 
 #include "cugraph_c/graph_generators.h"
 
+#include <cmath>
+
 namespace cga {
 namespace {
 
@@ -191,6 +193,120 @@ static cugraph_type_erased_device_array_view_t* coo_view(device_array_t* a)
 extern "C" cugraph_type_erased_device_array_view_t* cugraph_coo_get_sources(cugraph_coo_t* coo) { return coo_view(reinterpret_cast<coo_t*>(coo)->src); }
 extern "C" cugraph_type_erased_device_array_view_t* cugraph_coo_get_destinations(cugraph_coo_t* coo) { return coo_view(reinterpret_cast<coo_t*>(coo)->dst); }
 extern "C" cugraph_type_erased_device_array_view_t* cugraph_coo_get_edge_weights(cugraph_coo_t* coo) { return coo_view(reinterpret_cast<coo_t*>(coo)->wgt); }
-extern "C" cugraph_type_erased_device_array_view_t* cugraph_coo_get_edge_id(cugraph_coo_t*) { return nullptr; }
-extern "C" cugraph_type_erased_device_array_view_t* cugraph_coo_get_edge_type(cugraph_coo_t*) { return nullptr; }
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_coo_get_edge_id(cugraph_coo_t* coo) { return coo_view(reinterpret_cast<coo_t*>(coo)->ids); }
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_coo_get_edge_type(cugraph_coo_t* coo) { return coo_view(reinterpret_cast<coo_t*>(coo)->types); }
 extern "C" void cugraph_coo_free(cugraph_coo_t* coo) { delete reinterpret_cast<coo_t*>(coo); }
+extern "C" size_t cugraph_coo_list_size(const cugraph_coo_list_t* coo_list) { return reinterpret_cast<coo_list_t const*>(coo_list)->list.size(); }
+extern "C" cugraph_coo_t* cugraph_coo_list_element(cugraph_coo_list_t* coo_list, size_t index)
+{  // borrowed: the list owns its elements (cpp/src/c_api/graph_generators.cpp: cugraph_coo_list_element)
+  auto& l = reinterpret_cast<coo_list_t*>(coo_list)->list;
+  return index < l.size() ? reinterpret_cast<cugraph_coo_t*>(l[index]) : nullptr;
+}
+extern "C" void cugraph_coo_list_free(cugraph_coo_list_t* coo_list) { delete reinterpret_cast<coo_list_t*>(coo_list); }
+
+// n_edgelists RMAT lists (cugraph::generate_rmat_edgelists, cpp/src/generators/generate_rmat_edgelist.cuh:114-190): list i has
+// scale s_i drawn from [min_scale, max_scale] (UNIFORM) or min_scale + floor(range * Exp(4)) mod range (POWER_LAW) and -- as the
+// reference passes it -- s_i * edge_factor edges, (a, b, c) = (0.57, 0.19, 0.19) for POWER_LAW edges, (0.25, 0.25, 0.25) for UNIFORM
+extern "C" cugraph_error_code_t cugraph_generate_rmat_edgelists(const cugraph_resource_handle_t* handle, cugraph_rng_state_t* rng_state, size_t n_edgelists,
+                                                                size_t min_scale, size_t max_scale, size_t edge_factor,
+                                                                cugraph_generator_distribution_t size_distribution,
+                                                                cugraph_generator_distribution_t edge_distribution, bool_t clip_and_flip,
+                                                                bool_t scramble_vertex_ids, cugraph_coo_list_t** result, cugraph_error_t** error)
+{
+  if (result) *result = nullptr;
+  return guarded(error, [&] {
+    (void)H(handle);
+    CGA_EXPECTS(rng_state != nullptr && result != nullptr, CUGRAPH_INVALID_INPUT, "rng_state / result is NULL");
+    CGA_EXPECTS(min_scale > 0, CUGRAPH_INVALID_INPUT, "minimum graph scale is 1.");
+    CGA_EXPECTS(max_scale >= min_scale, CUGRAPH_INVALID_INPUT, "Invalid input argument: max_scale is smaller than min_scale.");
+    CGA_EXPECTS(max_scale <= 30, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "Invalid input argument: scale too large for vertex_t.");
+    rng_state_t& st = *reinterpret_cast<rng_state_t*>(rng_state);
+    double const a = edge_distribution == UNIFORM ? 0.25 : 0.57, b = edge_distribution == UNIFORM ? 0.25 : 0.19, c = b;
+    auto host_u01 = [&](uint64_t k) {  // the same counter-based stream as the device kernels, on the host
+      uint64_t z = (st.seed ^ 0xD1B54A32D192ED03ull) + (k + 1) * 0x9E3779B97F4A7C15ull;
+      z          = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z          = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z ^= z >> 31;
+      return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    };
+    auto out = std::make_unique<coo_list_t>();
+    size_t const range = max_scale - min_scale;
+    for (size_t i = 0; i < n_edgelists; ++i) {
+      double const u = host_u01(st.drawn++);
+      size_t scale;
+      if (size_distribution == UNIFORM) scale = min_scale + std::min<size_t>(range, (size_t)(u * (double)(range + 1)));
+      else scale = range == 0 ? min_scale : min_scale + (size_t)((double)range * (-std::log(1.0 - u) / 4.0)) % range;
+      cugraph_coo_t* one       = nullptr;
+      cugraph_error_t* err     = nullptr;
+      cugraph_error_code_t const code = cugraph_generate_rmat_edgelist(handle, rng_state, scale, scale * edge_factor, a, b, c, clip_and_flip, scramble_vertex_ids, &one, &err);
+      if (code != CUGRAPH_SUCCESS) {
+        std::string msg = err ? cugraph_error_message(err) : "cugraph_generate_rmat_edgelist failed";
+        cugraph_error_free(err);
+        throw api_error(code, msg);
+      }
+      out->list.push_back(reinterpret_cast<coo_t*>(one));
+    }
+    *result = reinterpret_cast<cugraph_coo_list_t*>(out.release());
+  });
+}
+
+namespace cga {
+namespace {
+__global__ void k_iota_i32(int32_t* out, uint64_t n)
+{
+  uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; k < n; k += stride) out[k] = (int32_t)k;
+}
+__global__ void k_uniform_i32(int32_t* out, uint64_t n, uint64_t seed, uint64_t first, int32_t lo, uint32_t span)
+{
+  uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; k < n; k += stride) {
+    uint64_t const z = splitmix64_at(seed ^ 0xA0761D6478BD642Full, first + k);
+    out[k]           = lo + (int32_t)(uint32_t)(((z >> 32) * (uint64_t)span) >> 32);  // uniform in [lo, lo + span)
+  }
+}
+}  // namespace
+}  // namespace cga
+
+// edge ids 0 .. E-1 in the vertex type (cpp/src/c_api/graph_generators.cpp: cugraph_generate_edge_ids; detail::sequence_fill).
+// multi_gpu: every rank numbers from base_edge_id = sum of the lower ranks' sizes; a one-rank handle starts at 0 either way.
+extern "C" cugraph_error_code_t cugraph_generate_edge_ids(const cugraph_resource_handle_t* handle, cugraph_coo_t* coo, bool_t multi_gpu, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    CGA_EXPECTS(coo != nullptr, CUGRAPH_INVALID_INPUT, "coo is NULL");
+    CGA_EXPECTS(multi_gpu == FALSE || h.comm_size == 1, CUGRAPH_NOT_IMPLEMENTED,
+                "cugraph_generate_edge_ids(multi_gpu = TRUE) needs a multi-rank resource handle; this library exchanges data through the host layer (cugraph_amd/mg.py)");
+    coo_t& c       = *reinterpret_cast<coo_t*>(coo);
+    size_t const n = c.src ? c.src->size : 0;
+    CGA_EXPECTS(n < ((size_t)1 << 31), CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "edge ids do not fit the 32-bit edge type of this build");
+    HIP_TRY(hipSetDevice(h.device));
+    delete c.ids;
+    c.ids = new device_array_t(n, INT32);
+    if (n > 0) hipLaunchKernelGGL(k_iota_i32, grid_for((int64_t)n, kBlock, 16384), kBlock, 0, h.stream, c.ids->buf.as<int32_t>(), (uint64_t)n);
+    h.sync();
+  });
+}
+
+// uniform INT32 edge types in [min_edge_type, max_edge_type] (cugraph_generate_edge_types; detail::uniform_random_fill)
+extern "C" cugraph_error_code_t cugraph_generate_edge_types(const cugraph_resource_handle_t* handle, cugraph_rng_state_t* rng_state, cugraph_coo_t* coo,
+                                                            int32_t min_edge_type, int32_t max_edge_type, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    CGA_EXPECTS(rng_state != nullptr && coo != nullptr, CUGRAPH_INVALID_INPUT, "rng_state / coo is NULL");
+    CGA_EXPECTS(max_edge_type >= min_edge_type, CUGRAPH_INVALID_INPUT, "Invalid input argument: max_edge_type is smaller than min_edge_type.");
+    rng_state_t& st = *reinterpret_cast<rng_state_t*>(rng_state);
+    coo_t& c        = *reinterpret_cast<coo_t*>(coo);
+    size_t const n  = c.src ? c.src->size : 0;
+    HIP_TRY(hipSetDevice(h.device));
+    delete c.types;
+    c.types = new device_array_t(n, INT32);
+    uint32_t const span = (uint32_t)((int64_t)max_edge_type - (int64_t)min_edge_type + 1);
+    if (n > 0)
+      hipLaunchKernelGGL(k_uniform_i32, grid_for((int64_t)n, kBlock, 16384), kBlock, 0, h.stream, c.types->buf.as<int32_t>(), (uint64_t)n, st.seed, st.drawn,
+                         min_edge_type, span);
+    h.sync();
+    st.drawn += n;
+  });
+}

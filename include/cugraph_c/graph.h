@@ -7,9 +7,9 @@
  * src/dst (and `vertices`) must share one integer type; this build supports INT32 vertices/edges with
  * FLOAT32 or FLOAT64 weights and returns CUGRAPH_UNSUPPORTED_TYPE_COMBINATION otherwise; an INT32
  * graph must have fewer than INT32_MAX edges (graph_sg.cpp:918-922).
- * edge_ids / edge_type_ids / edge times are accepted only as NULL (not on the PageRank/BFS/SSSP path)
- * and drop_self_loops / drop_multi_edges / symmetrize = TRUE return CUGRAPH_NOT_IMPLEMENTED
- * ("next").
+ * edge_ids / edge_type_ids / edge times are accepted only as NULL (not on the PageRank/BFS/SSSP path).
+ * drop_self_loops / drop_multi_edges / symmetrize are applied in the reference's order before renumbering
+ * (graph_sg.cpp:185-248; csrc/edgelist.hip) and do_expensive_check runs the reference's input checks.
  *
  * Unlike the reference, an algorithm that needs the other storage orientation does not rebuild and
  * re-number the graph (cpp/src/c_api/graph.hpp:84-143): both CSR and CSC live under ONE numbering,
@@ -56,6 +56,31 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_graph_create_sg_from_csr(
   const cugraph_type_erased_device_array_view_t* edge_ids,
   const cugraph_type_erased_device_array_view_t* edge_type_ids, bool_t store_transposed, bool_t renumber,
   bool_t symmetrize, bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error);
+
+/* Per-rank collective creation (cpp/include/cugraph_c/graph.h:238-327, impl cpp/src/c_api/graph_mg.cpp:326-560; called by
+ * pylibcugraph.MGGraph, graphs.pyx:648): `num_arrays` arrays of views per column.  Served on one-rank handles (the arrays are
+ * concatenated; the graph is renumbered as every MG graph is); a multi-rank handle gets CUGRAPH_NOT_IMPLEMENTED -- the
+ * multi-GPU graph of this library sits behind the plan API of include/cugraph_amd/extensions.h (one process per GPU,
+ * torch.distributed over RCCL in the host layer). */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_graph_create_mg(
+  cugraph_resource_handle_t const* handle, cugraph_graph_properties_t const* properties,
+  cugraph_type_erased_device_array_view_t const* const* vertices, cugraph_type_erased_device_array_view_t const* const* src,
+  cugraph_type_erased_device_array_view_t const* const* dst, cugraph_type_erased_device_array_view_t const* const* weights,
+  cugraph_type_erased_device_array_view_t const* const* edge_ids,
+  cugraph_type_erased_device_array_view_t const* const* edge_type_ids, bool_t store_transposed, size_t num_arrays,
+  bool_t drop_self_loops, bool_t drop_multi_edges, bool_t symmetrize, bool_t do_expensive_check, cugraph_graph_t** graph,
+  cugraph_error_t** error);
+
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_graph_create_with_times_mg(
+  cugraph_resource_handle_t const* handle, cugraph_graph_properties_t const* properties,
+  cugraph_type_erased_device_array_view_t const* const* vertices, cugraph_type_erased_device_array_view_t const* const* src,
+  cugraph_type_erased_device_array_view_t const* const* dst, cugraph_type_erased_device_array_view_t const* const* weights,
+  cugraph_type_erased_device_array_view_t const* const* edge_ids,
+  cugraph_type_erased_device_array_view_t const* const* edge_type_ids,
+  cugraph_type_erased_device_array_view_t const* const* edge_start_time_ids,
+  cugraph_type_erased_device_array_view_t const* const* edge_end_time_ids, bool_t store_transposed, size_t num_arrays,
+  bool_t drop_self_loops, bool_t drop_multi_edges, bool_t symmetrize, bool_t do_expensive_check, cugraph_graph_t** graph,
+  cugraph_error_t** error);
 
 CUGRAPH_EXPORT void cugraph_graph_free(cugraph_graph_t* graph);
 #ifdef __cplusplus

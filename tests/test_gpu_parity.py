@@ -202,8 +202,10 @@ def test_graph_creation_errors(cg, handle):
         cg.SGGraph(handle, props, [0, 1], T([1, 2], np.int32))
     with pytest.raises(ValueError):  # INT64 graphs: unsupported type combination in this build
         cg.SGGraph(handle, props, T([0, 1], np.int64), T([1, 2], np.int64))
-    with pytest.raises(NotImplementedError):
-        cg.SGGraph(handle, props, T([0, 1], np.int32), T([1, 2], np.int32), edge_id_array=T([0, 1], np.int32))
+    # edge ids / types are validated edge properties that no algorithm of this library reads (graph.hip): accepted, sizes checked
+    cg.SGGraph(handle, props, T([0, 1], np.int32), T([1, 2], np.int32), edge_id_array=T([0, 1], np.int32))
+    with pytest.raises(ValueError, match="edge id prop size"):
+        cg.SGGraph(handle, props, T([0, 1], np.int32), T([1, 2], np.int32), edge_id_array=T([0, 1, 2], np.int32))
     g = cg.SGGraph(handle, props, T([0, 1], np.int32), T([1, 2], np.int32))  # unweighted
     with pytest.raises(ValueError, match="weighted"):
         cg.sssp(handle, g, 0, 1e30, True, False)
@@ -924,3 +926,70 @@ def test_louvain_rmat_vs_oracle(cg, handle, orc, scale, resolution):
     assert abs(q - oq) <= 1e-9
     assert np.array_equal(c, oc)
     assert olevels >= 2 and len(np.unique(c)) < nv // 2
+
+
+def test_capi_generators_edge_columns_and_decompress(cg, handle):
+    """cugraph_generate_rmat_edgelists / _edge_ids / _edge_types (graph_generators.h), cugraph_data_type_id_from_dlpack,
+    cugraph_graph_create_mg on a one-rank handle and cugraph_decompress_to_edgelist (external ids, by-source order)."""
+    import ctypes as C
+
+    import torch
+
+    from cugraph_amd import _capi
+    from cugraph_amd.pylib import _View, assert_success, copy_to_torch
+
+    l = _capi.lib()
+    hp = handle.c_resource_handle_ptr
+    err, rng, lst = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert_success(l.cugraph_rng_state_create(hp, 42, C.byref(rng), C.byref(err)), err, "rng")
+    assert_success(l.cugraph_generate_rmat_edgelists(hp, rng, 5, 4, 9, 16, 1, 0, 0, 0, C.byref(lst), C.byref(err)), err, "rmat_edgelists")
+    assert l.cugraph_coo_list_size(lst) == 5
+    for i in range(5):
+        coo = C.c_void_p(l.cugraph_coo_list_element(lst, i))
+        s = copy_to_torch(hp, l.cugraph_coo_get_sources(coo))
+        d = copy_to_torch(hp, l.cugraph_coo_get_destinations(coo))
+        scale = s.numel() // 16
+        assert 4 <= scale <= 9 and s.numel() == scale * 16 == d.numel()           # the reference passes scale * edge_factor edges
+        assert int(s.max()) < (1 << scale) and int(d.max()) < (1 << scale) and int(s.min()) >= 0
+        assert l.cugraph_coo_get_edge_id(coo) is None
+        assert_success(l.cugraph_generate_edge_ids(hp, coo, 0, C.byref(err)), err, "edge_ids")
+        assert_success(l.cugraph_generate_edge_types(hp, rng, coo, 3, 7, C.byref(err)), err, "edge_types")
+        ids = copy_to_torch(hp, l.cugraph_coo_get_edge_id(coo))
+        ty = copy_to_torch(hp, l.cugraph_coo_get_edge_type(coo))
+        assert torch.equal(ids.cpu(), torch.arange(s.numel(), dtype=torch.int32)) and int(ty.min()) >= 3 and int(ty.max()) <= 7
+    l.cugraph_coo_list_free(lst)
+    l.cugraph_rng_state_free(rng)
+
+    class DL(C.Structure):
+        _fields_ = [("code", C.c_uint8), ("bits", C.c_uint8), ("lanes", C.c_uint16)]
+    out = C.c_int(-1)
+    for code, bits, want in ((0, 32, _capi.INT32), (0, 64, _capi.INT64), (2, 32, _capi.FLOAT32), (2, 64, _capi.FLOAT64), (1, 8, _capi.UINT8), (6, 8, _capi.BOOL)):
+        assert l.cugraph_data_type_id_from_dlpack(C.cast(C.byref(DL(code, bits, 1)), C.c_void_p), C.byref(out), C.byref(err)) == 0 and out.value == want
+    assert l.cugraph_data_type_id_from_dlpack(C.cast(C.byref(DL(0, 32, 4)), C.c_void_p), C.byref(out), C.byref(err)) == _capi.CUGRAPH_UNSUPPORTED_TYPE_COMBINATION
+    l.cugraph_error_free(err)
+    assert l.cugraph_data_type_id_from_dlpack(C.cast(C.byref(DL(2, 16, 1)), C.c_void_p), C.byref(out), C.byref(err)) == _capi.CUGRAPH_INVALID_INPUT
+    l.cugraph_error_free(err)
+
+    # create_mg with the edge list split over two arrays == create_sg on the whole list; decompress returns the input multiset
+    src = np.array([0, 1, 1, 2, 2, 2, 3, 4], np.int32) * 10 + 5
+    dst = np.array([1, 3, 4, 0, 1, 3, 5, 5], np.int32) * 10 + 5
+    w = np.array([0.1, 2.1, 1.1, 5.1, 3.1, 4.1, 7.2, 3.2], np.float32)
+    ts, td, tw = T(src), T(dst), T(w)
+    views = [[_View(t[:3]), _View(t[3:])] for t in (ts, td, tw)]
+    arr = lambda vs: (C.c_void_p * 2)(*[v.ptr for v in vs])
+    props = _capi.GraphPropertiesStruct(0, 0)
+    g = C.c_void_p()
+    code = l.cugraph_graph_create_mg(hp, C.byref(props), None, arr(views[0]), arr(views[1]), arr(views[2]), None, None, 1, 2, 0, 0, 0, 0, C.byref(g), C.byref(err))
+    assert_success(code, err, "cugraph_graph_create_mg")
+    el = C.c_void_p()
+    assert_success(l.cugraph_decompress_to_edgelist(hp, g, 0, C.byref(el), C.byref(err)), err, "decompress")
+    es = copy_to_torch(hp, l.cugraph_edgelist_get_sources(el)).cpu().numpy()
+    ed = copy_to_torch(hp, l.cugraph_edgelist_get_destinations(el)).cpu().numpy()
+    ew = copy_to_torch(hp, l.cugraph_edgelist_get_edge_weights(el)).cpu().numpy()
+    assert l.cugraph_edgelist_get_edge_ids(el) is None and l.cugraph_edgelist_get_edge_offsets(el) is None
+    assert sorted(zip(es.tolist(), ed.tolist(), ew.tolist())) == sorted(zip(src.tolist(), dst.tolist(), w.tolist()))
+    l.cugraph_edgelist_free(el)
+    l.cugraph_graph_free(g)
+    for vs in views:
+        for v in vs:
+            v.free()
