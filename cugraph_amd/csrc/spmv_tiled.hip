@@ -516,8 +516,8 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     uint32_t nb = 0;
     h.read_back(&nb, bidx.data() + t.n_runs, 1);
     t.n_blocks = nb;
-    t.delta1.resize_discard((size_t)nb + 1 + 64);
-    HIP_TRY(hipMemsetAsync(t.delta1.data(), 0, ((size_t)nb + 1 + 64) * sizeof(uint32_t), h.stream));
+    t.delta1.resize_discard((size_t)nb + 1 + 64 * (TP_NDREG + 1));
+    HIP_TRY(hipMemsetAsync(t.delta1.data(), 0, ((size_t)nb + 1 + 64 * (TP_NDREG + 1)) * sizeof(uint32_t), h.stream));
     int64_t const n_words = t.n_runs / 32 + 4;
     dvec<uint32_t> gbits(n_words);
     if (t.n_runs > 0)
@@ -531,8 +531,8 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   } else {
     t.n_slots = 0;
     t.dstl16.resize_discard(64);
-    t.delta1.resize_discard(65);
-    HIP_TRY(hipMemsetAsync(t.delta1.data(), 0, 65 * sizeof(uint32_t), h.stream));
+    t.delta1.resize_discard(1 + 64 * (TP_NDREG + 1));
+    HIP_TRY(hipMemsetAsync(t.delta1.data(), 0, (1 + 64 * (TP_NDREG + 1)) * sizeof(uint32_t), h.stream));
   }
   to_device(h, t.region_off, region_off);
 
@@ -817,8 +817,7 @@ __device__ __forceinline__ void p1_fence(p1_regs& r) { vm_fence(r.id[0]); vm_fen
 // of the range] (record bits 0 .. n - 1).
 struct p1_runs {  // what the bitmap and the record of one work item say about its runs
   uint32_t f, ex_c, c_all;
-  uint32_t blk8;            // delta1 index base of run ordinal 64 * TP_NSLOT (wave-uniform)
-  uint32_t slot[TP_NSLOT];  // delta1 entries of runs lane, 64 + lane, ...
+  uint32_t dreg[TP_NDREG];  // delta1[blk + 64 k + lane]: the block deltas this item's runs can need (lane = block relative to blk)
   uint32_t slot_tail;       // slot of the run still open at the end of the range
   uint32_t es, ee, rank, head_slot, blk;
 };
@@ -834,37 +833,54 @@ __device__ __forceinline__ void p1_counts(int lane, p1_regs const& rg, p1_runs& 
   uint32_t const c_inc = wave_inclusive_sum_u32(nf);
   q.ex_c               = c_inc - nf;
   q.c_all              = (uint32_t)__builtin_amdgcn_readlane((int)c_inc, 63);
+#ifdef CGA_ABL_NOOVERFLOW  // timing experiment: drop the run starts of the lanes that would overflow the staging area (WRONG results)
+  if (q.c_all > (uint32_t)TP_STAGE) { q.f = q.ex_c + nf <= (uint32_t)TP_STAGE ? q.f : 0u; q.c_all = (uint32_t)TP_STAGE; }
+#endif
 }
 
-// delta1 entry of run ordinal n = 64 * j + lane (j wave-uniform): block index = blk + (block starts among record bits < n)
-// `base` = delta1 index of ordinal 64 * j; advanced to that of ordinal 64 * (j + 1) (scalar popcounts)
-template <typename WT>
-__device__ __forceinline__ uint32_t p1_delta_group(p1_args<WT> const& a, uint32_t rec, uint32_t j, uint32_t& base)
-{
-  uint32_t const lo = rdl(rec, 2u * j), hi = rdl(rec, 2u * j + 1u);
-  uint32_t const idx = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, base));
-  base += (uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi);
-  uint32_t d;
-  vm_ld32(d, a.delta1, 4u * idx);
-  return d;
-}
+// The slot of run ordinal n >= 1 is (rank - 1 + n) + delta1[blk + B(n)], B(n) = number of block starts among the record bits
+// [0, n): a wavefront's runs fall into few consecutive slot blocks (5 on average at RMAT-26, one per ~24 runs in the coldest
+// tiles), so instead of one delta load per 64 runs the item requests delta1[blk .. blk + 64 * TP_NDREG) ONCE, lane-wise (one
+// or two coalesced loads, one or two registers), an item ahead; the write-out picks a run's delta from lane B(n) of that
+// register with ds_bpermute (LDS crossbar, no memory access).  Items with more blocks fall back to a direct load.
 template <typename WT>
 __device__ __forceinline__ void p1_issue_slots(p1_args<WT> const& a, int lane, p1_regs const& rg, p1_runs& q)
-{  // whole-wave loads behind wave-uniform guards
-  uint32_t base = q.blk;
+{
 #pragma unroll
-  for (int j = 0; j < TP_NSLOT; ++j) {
-    q.slot[j] = 0;
+  for (int k = 0; k < TP_NDREG; ++k) {
+    q.dreg[k] = 0;
 #ifndef CGA_ABL_NODELTA
-    if ((uint32_t)(64 * j) < q.c_all) q.slot[j] = p1_delta_group<WT>(a, rg.rec, (uint32_t)j, base);
+    if (k == 0 || q.c_all > (uint32_t)(64 * k)) vm_ld32(q.dreg[k], a.delta1, 4u * (q.blk + (uint32_t)(64 * k) + (uint32_t)lane));  // (block starts <= run starts)
 #endif
   }
-  q.blk8 = base;  // only meaningful (and only used) when c_all > 64 * TP_NSLOT
 }
 __device__ __forceinline__ void p1_fence_slots(p1_runs& q)
 {
 #pragma unroll
-  for (int j = 0; j < TP_NSLOT; ++j) vm_fence(q.slot[j]);
+  for (int k = 0; k < TP_NDREG; ++k) vm_fence(q.dreg[k]);
+}
+// delta of run ordinal n = 64 * j + lane (j wave-uniform); `base` = B(64 j) on entry, B(64 (j + 1)) on exit (scalar popcounts)
+template <typename WT>
+__device__ __forceinline__ uint32_t p1_delta_of_group(p1_args<WT> const& a, p1_runs const& q, uint32_t rec, uint32_t j, uint32_t& base)
+{
+  uint32_t const lo = rdl(rec, 2u * j), hi = rdl(rec, 2u * j + 1u);
+  uint32_t const b  = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, base));  // B(n) of this lane's run
+  base += (uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi);               // >= every lane's b
+  uint32_t d = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(b << 2), (int)q.dreg[0]);
+#pragma unroll
+  for (int k = 1; k < TP_NDREG; ++k)
+    if (base >= (uint32_t)(64 * k)) {  // wave-uniform: some lane of the group may need blocks [64 k, 64 k + 64)
+      uint32_t const dk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(b << 2), (int)q.dreg[k]);
+      d = (b >> 6) == (uint32_t)k ? dk : d;
+    }
+  if (base >= (uint32_t)(64 * TP_NDREG)) {  // rare: more slot blocks than the prefetched registers cover
+    uint32_t direct;
+    vm_ld32(direct, a.delta1, 4u * (q.blk + b));
+    vm_wait0();
+    vm_fence(direct);
+    d = b >= (uint32_t)(64 * TP_NDREG) ? direct : d;
+  }
+  return d;
 }
 
 // run totals of the lanes selected by `mine` -> staging area, in run order, starting at ordinal base_c
@@ -890,49 +906,25 @@ __device__ __forceinline__ void p1_stage(WT* stage, p1_runs const& q, WT const (
 }
 
 // staging area -> partial buffer: lane i takes staged totals i, 64 + i, ... (coalesced); run ordinals [n_lo, n_hi), staged at
-// [0, n_hi - n_lo).  The caller has waited for q.slot.
+// [0, n_hi - n_lo).  The caller has waited for q.dreg.
 template <typename WT>
 __device__ __forceinline__ void p1_writeout(p1_args<WT> const& a, WT const* stage, int lane, uint32_t rec, p1_runs const& q, uint32_t n_lo, uint32_t n_hi)
 {
+  static_assert(TP_WLEN <= 1024, "a wavefront's share of an item starts at most 1024 runs: 16 groups of 64 ordinals, 32 record dwords");
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   uint32_t const rm1 = q.rank - 1u;  // run index of ordinal n = rm1 + n (modulo 2^32)
-  uint32_t j = n_lo >> 6;
-  if (n_lo == 0) {  // the delta entries of the first 64 * TP_NSLOT runs were requested an item ago
+  uint32_t base = 0;                 // B(64 jj): block starts among the record bits below the group
 #pragma unroll
-    for (int jj = 0; jj < TP_NSLOT; ++jj) {
-      if ((uint32_t)(64 * jj) < n_hi) {
-        uint32_t const n = (uint32_t)lane + 64u * (uint32_t)jj;
-        uint32_t slot    = q.slot[jj] + (rm1 + 64u * (uint32_t)jj) + (uint32_t)lane;
-        if (jj == 0) slot = lane == 0 ? q.head_slot : slot;
+  for (int jj = 0; jj < TP_WLEN / 64; ++jj) {
+    if ((uint32_t)(64 * jj) < n_hi) {  // wave-uniform
+      uint32_t const d = p1_delta_of_group<WT>(a, q, rec, (uint32_t)jj, base);
+      uint32_t const n = (uint32_t)lane + 64u * (uint32_t)jj;
+      uint32_t slot    = d + (rm1 + 64u * (uint32_t)jj) + (uint32_t)lane;
+      if (jj == 0) slot = lane == 0 ? q.head_slot : slot;
 #ifndef CGA_ABL_NOSTORE
-        if (n < n_hi) vm_st(a.part, slot * (uint32_t)sizeof(WT), stage[n]);
-#endif
-      }
-    }
-    j = TP_NSLOT;
-  }
-  uint32_t base = q.blk8;
-  if (n_lo != 0) {  // rare (more than TP_STAGE run starts in the range): recount the block starts before ordinal 64 * j
-    base = q.blk;
-    for (uint32_t jj = 0; jj < j; ++jj) base += (uint32_t)__builtin_popcount(rdl(rec, 2u * jj)) + (uint32_t)__builtin_popcount(rdl(rec, 2u * jj + 1u));
-  }
-  for (; 64u * j < n_hi; j += 4) {  // the rest in batches: four delta loads, ONE full wait, four stores
-    uint32_t sl[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      sl[t] = 0;
-      if (64u * (j + (uint32_t)t) < n_hi) sl[t] = p1_delta_group<WT>(a, rec, j + (uint32_t)t, base);
-    }
-    vm_wait0();
-#pragma unroll
-    for (int t = 0; t < 4; ++t) vm_fence(sl[t]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      uint32_t const n = 64u * (j + (uint32_t)t) + (uint32_t)lane;
-#ifndef CGA_ABL_NOSTORE
-      if (n >= n_lo && n < n_hi) vm_st(a.part, (sl[t] + rm1 + n) * (uint32_t)sizeof(WT), stage[n - n_lo]);
+      if (n >= n_lo && n < n_hi) vm_st(a.part, slot * (uint32_t)sizeof(WT), stage[n - n_lo]);
 #endif
     }
   }

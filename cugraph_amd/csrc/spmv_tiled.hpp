@@ -62,8 +62,12 @@ constexpr int TP_BLOCK = 1024;               // phase-1 workgroup: 16 wavefronts
 constexpr int TP_WAVES = TP_BLOCK / 64;
 constexpr int TP_EPL = 16;                   // consecutive edges per lane per work item (two 16-byte loads)
 constexpr int TP_WG_PER_CU = 1;              // the source tile takes ~126 KiB of the 160 KiB LDS
-constexpr int TP_STAGE = 512;                // per-wavefront LDS staging entries (run totals awaiting the coalesced write-out)
-constexpr int TP_NSLOT = 8;                  // partial slots requested one item ahead per lane (512 runs; the rest in batches of four)
+#ifndef CGA_TP_STAGE
+#define CGA_TP_STAGE 512
+#endif
+static_assert(CGA_TP_STAGE >= 512, "the long-run path stages the run totals of 32 lanes x 16 edges at a time");
+constexpr int TP_STAGE = CGA_TP_STAGE;                // per-wavefront LDS staging entries (run totals awaiting the coalesced write-out)
+constexpr int TP_NDREG = 2;                  // registers of prefetched slot-block deltas per lane: 64 * TP_NDREG blocks per wavefront and item
 constexpr int TP_SUB   = 64 * TP_EPL;        // edges per wavefront per work item (TP_EPL consecutive edges per lane)
 constexpr int TP_WLEN  = TP_SUB;
 constexpr int TP_ITEM  = TP_WLEN * TP_WAVES;  // edges per work item
