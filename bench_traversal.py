@@ -107,7 +107,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=int, default=24)
     ap.add_argument("--edge-factor", type=int, default=16)
-    ap.add_argument("--roots", type=int, default=16)
+    ap.add_argument("--roots", type=int, default=64, help="Graph500 protocol: 64 roots after the warm-ups")
+    ap.add_argument("--cpu-scale", type=int, default=20, help="RMAT scale of the bounded CPU-baseline sample (oracle BFS / Dijkstra)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--out", type=str, default=None, help="also write the JSON line to this file")
     ap.add_argument("--weights", choices=["unit", "int"], default="unit")
     ap.add_argument("--symmetric", action="store_true", help="add the reverse of every edge (Graph500 input)")
     ap.add_argument("--no-sssp", action="store_true")
@@ -162,24 +165,81 @@ def main():
             last = (v, d)
         return times, edges, steps, last
 
-    out = {"workload": f"RMAT scale {args.scale} edge factor {args.edge_factor}{' symmetrised' if args.symmetric else ''}, {args.roots} roots, "
-                       f"weights {args.weights}", "vertices": nv, "edges": ne, "graph_build_s": round(build_s, 3)}
+    HBM_PEAK = 8000.0  # GB/s, /opt/skills/guides/MI355X_MICROARCH.md
+
+    def roofline(kind, e_r, v_r, t_s, pred):
+        """algorithmic bytes of one traversal from the reached sub-graph (E_r out-edges of the V_r reached
+        vertices): BFS 4 E_r + 8 V_r + 4 V + 4 V_r (+ 4 V + 4 V_r with predecessors) + V / 4; SSSP 8 E_r + 8 V_r + 8 V + 8 V_r."""
+        if kind == "bfs":
+            b = 4 * e_r + 8 * v_r + 4 * nv + 4 * v_r + (4 * nv + 4 * v_r if pred else 0) + nv // 4
+        else:
+            b = 8 * e_r + 8 * v_r + 8 * nv + 8 * v_r
+        ach = b / t_s / 1e9
+        return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4), "traffic": None,
+                "algorithmic_bytes_per_traversal": int(b), "kernel": "whole traversal (all levels / rounds, harmonic-mean time)"}
+
+    out = {"metric": f"bfs_sssp_mteps_rmat{args.scale}", "unit": "MTEPS", "n_gpus": 1, "higher_is_better": True, "data": "synthetic",
+           "workload": f"RMAT scale {args.scale} edge factor {args.edge_factor}{' symmetrised' if args.symmetric else ''}, {args.roots} roots "
+                       f"(fixed-seed choice among the vertices with out-edges; 2 warm-ups), weights {args.weights}; TEPS = out-edges of the reached "
+                       "vertices / time, harmonic mean (mg_graph500_bfs_test.cu:113-114, 757-763)",
+           "vertices": nv, "edges": ne, "roots": args.roots, "predecessors": bool(args.predecessors), "graph_build_s": round(build_s, 3)}
     bt, be, bs, (bv, bd) = run("bfs")
+    reached = [int((bd != 2147483647).sum())]  # last root; the reached set of an RMAT giant component hardly varies between roots
     teps = [e / t for e, t in zip(be, bt)]
-    out["bfs"] = {"mean_ms": round(1e3 * float(np.mean(bt)), 3), "min_ms": round(1e3 * float(np.min(bt)), 3), "max_ms": round(1e3 * float(np.max(bt)), 3), "harmonic_mean_mteps": round(len(teps) / sum(1.0 / x for x in teps) / 1e6, 1),
-                  "mean_levels": float(np.mean(bs)), "mean_edges_of_reached": float(np.mean(be))}
+    hm = len(teps) / sum(1.0 / x for x in teps)
+    t_hm = float(np.mean(be)) / hm
+    out["bfs"] = {"mean_ms": round(1e3 * float(np.mean(bt)), 3), "min_ms": round(1e3 * float(np.min(bt)), 3), "max_ms": round(1e3 * float(np.max(bt)), 3),
+                  "harmonic_mean_mteps": round(hm / 1e6, 1), "mean_levels": float(np.mean(bs)), "mean_edges_of_reached": float(np.mean(be)),
+                  "dtype": "int32", "roofline": roofline("bfs", float(np.mean(be)), reached[0], t_hm, args.predecessors)}
+    out["value"] = out["bfs"]["harmonic_mean_mteps"]
     if not args.no_sssp:
         st, _, ss, (sv, sd) = run("sssp")
         teps = [e / t for e, t in zip(be, st)]  # same roots: same reached set, scored on the same edge count
-        out["sssp"] = {"mean_ms": round(1e3 * float(np.mean(st)), 3), "min_ms": round(1e3 * float(np.min(st)), 3), "max_ms": round(1e3 * float(np.max(st)), 3), "harmonic_mean_mteps": round(len(teps) / sum(1.0 / x for x in teps) / 1e6, 1),
-                       "mean_steps": float(np.mean(ss))}
+        hm = len(teps) / sum(1.0 / x for x in teps)
+        t_hm = float(np.mean(be)) / hm
+        out["sssp"] = {"mean_ms": round(1e3 * float(np.mean(st)), 3), "min_ms": round(1e3 * float(np.min(st)), 3), "max_ms": round(1e3 * float(np.max(st)), 3),
+                       "harmonic_mean_mteps": round(hm / 1e6, 1), "mean_steps": float(np.mean(ss)), "dtype": "f32",
+                       "roofline": roofline("sssp", float(np.mean(be)), reached[0], t_hm, args.predecessors)}
         if args.weights == "unit":  # integer hops: bit-exact against BFS (last root)
             a = torch.empty(nv, dtype=torch.int64, device="cuda"); a[bv.to(torch.int64)] = bd.to(torch.int64)
             b = torch.empty(nv, dtype=torch.float32, device="cuda"); b[sv.to(torch.int64)] = sd
             reach = a != 2147483647
             ok = bool(torch.equal(a[reach].to(torch.float32), b[reach])) and bool((b[~reach] == torch.finfo(torch.float32).max).all())
             out["sssp"]["unit_weight_distances_equal_bfs"] = ok
-    print(json.dumps(out), flush=True)
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(min(args.cpu_scale, args.scale), args.weights)
+    line = json.dumps(out)
+    print(line, flush=True)
+    if args.out:
+        Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+        Path(args.out).write_text(line + "\n")
+
+
+def cpu_baseline(scale, weights):
+    """The oracle (C restatements of bfs_reference / sssp_reference = Dijkstra, single-threaded like the reference's own) on a bounded
+    sample: the same generator at a smaller scale, 4 roots."""
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    nv, ne = 1 << scale, 16 << scale
+    s, d = orc.rmat(scale, ne)
+    w = np.ones(ne, np.float32) if weights == "unit" else np.random.default_rng(1).integers(1, 256, ne).astype(np.float32)
+    off, idx, ww = orc.coo_to_cs(nv, s, d, w)
+    outdeg = np.diff(off)
+    roots = np.flatnonzero(outdeg > 0)[:: max(1, int((outdeg > 0).sum()) // 4)][:4]
+    res = {}
+    for kind in ("bfs", "sssp"):
+        teps = []
+        for r in roots:
+            t0 = time.perf_counter()
+            dist = orc.bfs(nv, off, idx, [int(r)])[0] if kind == "bfs" else orc.sssp(nv, off, idx, ww, int(r))[0]
+            dt = time.perf_counter() - t0
+            reached = dist != (2147483647 if kind == "bfs" else np.finfo(np.float32).max)
+            teps.append(float(outdeg[reached].sum()) / dt)
+        res[kind] = round(len(teps) / sum(1.0 / t for t in teps) / 1e6, 2)
+    return {"value": res["bfs"], "sssp_value": res["sssp"], "unit": "MTEPS", "cores": 1, "kind": "port",
+            "sample": f"RMAT-{scale} (same generator, seed 0), {len(roots)} roots, oracle/oracle.c bfs + Dijkstra, harmonic mean"}
 
 
 if __name__ == "__main__":

@@ -94,38 +94,43 @@ inline size_t dtype_size(cugraph_data_type_id_t t)
 }
 
 // ---------------------------------------------------------------------------------- device memory
-// Owning device buffer.  Allocation is synchronous hipMalloc: graph-analytics calls allocate a handful
-// of large buffers per API call (never inside an iteration loop), so a pool buys nothing here.
+// Owning device buffer on top of a process-wide caching pool (core.hip: pool_alloc / pool_free).  hipMalloc / hipFree are
+// synchronous and slow for the sizes of this library (a BFS call used to spend more time in its dozen hipMalloc / hipFree
+// pairs than in two of its levels; a PageRank plan build waited seconds for the driver after 60 GB of temporaries had just
+// been freed), so freed blocks are kept and handed out again: best fit within 25 % slack, at most CUGRAPH_AMD_POOL_MAX_GB
+// (default 128) cached, everything is released and the request retried when hipMalloc fails.  A cached block is reused
+// without waiting for the work that last touched it: correct for the reference's threading contract (one host thread per
+// handle, one stream per handle, API calls blocking at return -- SURVEY.md section 8b), where a reuse is always ordered
+// behind the previous use on the same stream.  CUGRAPH_AMD_POOL=0 turns the pool off.
+void* pool_alloc(size_t n_bytes, size_t* granted);
+void pool_free(void* ptr, size_t granted) noexcept;
+
 struct dev_buf {
   void* ptr{nullptr};
   size_t bytes{0};
+  size_t granted{0};  // what the pool handed out (>= bytes)
   dev_buf() = default;
   explicit dev_buf(size_t n_bytes) { alloc(n_bytes); }
   dev_buf(dev_buf const&)            = delete;
   dev_buf& operator=(dev_buf const&) = delete;
-  dev_buf(dev_buf&& o) noexcept : ptr(o.ptr), bytes(o.bytes) { o.ptr = nullptr; o.bytes = 0; }
+  dev_buf(dev_buf&& o) noexcept : ptr(o.ptr), bytes(o.bytes), granted(o.granted) { o.ptr = nullptr; o.bytes = 0; o.granted = 0; }
   dev_buf& operator=(dev_buf&& o) noexcept
   {
-    if (this != &o) { release(); ptr = o.ptr; bytes = o.bytes; o.ptr = nullptr; o.bytes = 0; }
+    if (this != &o) { release(); ptr = o.ptr; bytes = o.bytes; granted = o.granted; o.ptr = nullptr; o.bytes = 0; o.granted = 0; }
     return *this;
   }
   ~dev_buf() { release(); }
   void alloc(size_t n_bytes)
   {
     release();
-    bytes = n_bytes;
     if (n_bytes == 0) return;
-    hipError_t e = hipMalloc(&ptr, n_bytes);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      ptr = nullptr; bytes = 0;
-      throw api_error(CUGRAPH_ALLOC_ERROR, "hipMalloc of " + std::to_string(n_bytes) + " bytes failed: " + hipGetErrorString(e));
-    }
+    ptr   = pool_alloc(n_bytes, &granted);  // throws api_error(CUGRAPH_ALLOC_ERROR)
+    bytes = n_bytes;
   }
   void release()
   {
-    if (ptr) (void)hipFree(ptr);
-    ptr = nullptr; bytes = 0;
+    if (ptr) pool_free(ptr, granted);
+    ptr = nullptr; bytes = 0; granted = 0;
   }
   template <typename T> T* as() const { return static_cast<T*>(ptr); }
 };
@@ -267,6 +272,8 @@ struct graph_t {  // behind cugraph_graph_t (cpp/src/c_api/graph.hpp:61-77)
   // cached out-weight sums (a5 in SURVEY 8a): float or double, size V
   dev_buf out_weight_sums;
   bool out_weight_sums_valid{false};
+  double weight_sum{0};  // sum of the edge weights (SSSP bucket width), cached
+  bool weight_sum_valid{false};
   int bfs_calls{0};  // the CSC (bottom-up BFS levels) is built from the second traversal of a non-symmetric graph on
 };
 

@@ -336,3 +336,112 @@ extern "C" cugraph_error_code_t cugraph_data_type_id_from_dlpack(const DLDataTyp
     *dtype = (cugraph_data_type_id_t)t;
   });
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// caching device-memory pool behind dev_buf (see common.hpp)
+#include <map>
+#include <mutex>
+namespace cga {
+namespace {
+struct pool_t {
+  std::mutex m;
+  std::multimap<std::pair<int, size_t>, void*> free_blocks;  // (device, size) -> block
+  size_t cached{0};
+  size_t max_cached{(size_t)128 << 30};
+  bool enabled{true};
+  pool_t()
+  {
+    if (char const* e = getenv("CUGRAPH_AMD_POOL")) enabled = atoi(e) != 0;
+    if (char const* e = getenv("CUGRAPH_AMD_POOL_MAX_GB")) max_cached = (size_t)std::max(0.0, atof(e)) << 30;
+  }
+  void trim_locked(size_t keep)
+  {  // largest blocks first
+    while (cached > keep && !free_blocks.empty()) {
+      auto it = std::prev(free_blocks.end());
+      (void)hipFree(it->second);
+      cached -= it->first.second;
+      free_blocks.erase(it);
+    }
+  }
+};
+pool_t& pool()
+{
+  static pool_t* p = new pool_t();  // leaked on purpose: buffers may be released during static destruction
+  return *p;
+}
+size_t round_size(size_t n)
+{
+  if (n <= 256) return 256;
+  if (n < ((size_t)1 << 20)) {  // next power of two
+    size_t r = 256;
+    while (r < n) r <<= 1;
+    return r;
+  }
+  size_t const g = (size_t)2 << 20;  // 2 MiB granules
+  return (n + g - 1) / g * g;
+}
+}  // namespace
+
+void* pool_alloc(size_t n_bytes, size_t* granted)
+{
+  pool_t& p = pool();
+  int dev   = 0;
+  (void)hipGetDevice(&dev);
+  size_t const want = p.enabled ? round_size(n_bytes) : n_bytes;
+  if (p.enabled) {
+    std::lock_guard<std::mutex> lock(p.m);
+    auto it = p.free_blocks.lower_bound({dev, want});
+    if (it != p.free_blocks.end() && it->first.first == dev && it->first.second <= want + want / 4) {
+      void* ptr = it->second;
+      *granted  = it->first.second;
+      p.cached -= it->first.second;
+      p.free_blocks.erase(it);
+      return ptr;
+    }
+  }
+  void* ptr    = nullptr;
+  hipError_t e = hipMalloc(&ptr, want);
+  if (e != hipSuccess && p.enabled) {  // give the cached blocks back to the driver and try once more
+    (void)hipGetLastError();
+    { std::lock_guard<std::mutex> lock(p.m); p.trim_locked(0); }
+    e = hipMalloc(&ptr, want);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    throw api_error(CUGRAPH_ALLOC_ERROR, "hipMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
+  }
+  *granted = want;
+  return ptr;
+}
+
+void pool_free(void* ptr, size_t granted) noexcept
+{
+  if (!ptr) return;
+  pool_t& p = pool();
+  if (!p.enabled || granted > p.max_cached) { (void)hipFree(ptr); return; }
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, ptr) == hipSuccess) dev = attr.device; else (void)hipGetLastError();
+  std::lock_guard<std::mutex> lock(p.m);
+  p.free_blocks.insert({{dev, granted}, ptr});
+  p.cached += granted;
+  if (p.cached > p.max_cached) p.trim_locked(p.max_cached / 2);
+}
+}  // namespace cga
+
+// releases every cached device block to the driver (returns the number of bytes released)
+extern "C" size_t cugraph_amd_memory_pool_trim(void)
+{
+  cga::pool_t& p = cga::pool();
+  std::lock_guard<std::mutex> lock(p.m);
+  size_t const had = p.cached;
+  p.trim_locked(0);
+  return had;
+}
+extern "C" size_t cugraph_amd_memory_pool_cached_bytes(void)
+{
+  cga::pool_t& p = cga::pool();
+  std::lock_guard<std::mutex> lock(p.m);
+  return p.cached;
+}

@@ -25,6 +25,8 @@
 // consecutive adjacency words; degree >= 64 rows are walked by the whole wave; degree >= 2048 rows are
 // deferred to a second kernel in which the whole grid strides the adjacency list.
 #include "common.hpp"
+
+#include <chrono>
 #include "traversal_common.hpp"
 
 #include <cfloat>
@@ -94,12 +96,12 @@ struct bfs_visit {
 struct keep_all { __device__ __forceinline__ bool operator()(int32_t) const { return true; } };
 
 __global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices,
-                                                         int32_t* bigq, bfs_state s)
+                                                         int32_t* bigq, bfs_state s, int32_t big_deg)
 {
   __shared__ wave_queue_storage<1> wqs;
   wqs.init();
   bfs_visit f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next)};
-  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f);
+  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f, big_deg);
   f.flush();
 }
 __global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, bfs_state s)
@@ -113,65 +115,135 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand_big(int32_t const* bigq
 
 // Bottom-up level.  in_offsets / in_indices = the orientation whose rows are DESTINATIONS (CSC; the CSR itself when the
 // graph is symmetric).  front = frontier bitmap of the current level; next (fully rewritten) = vertices found.
-constexpr int32_t BU_COOP_DEG = 512;  // rows at least this long that a single lane did not settle quickly are scanned by the whole wave
+constexpr int BU_GROUPS     = 4;   // 64-vertex groups a wavefront keeps in flight
+constexpr int BU_CHUNK      = 4;   // independent probes per lane and step (one 16-byte neighbour load)
+constexpr int BU_LANE_MAX   = 64;  // neighbours a lane scans on its own; the rest of a still unsettled row is scanned by the whole wave
+// the next BU_CHUNK neighbour ids of a row as ONE 16-byte load per lane (4-byte aligned: gfx950 global loads take it): a lane's
+// neighbours are consecutive, but to the memory pipeline every dword load of a row start is a separate random access, and
+// those, not bytes, bound a bottom-up level (~65 G random accesses/s beyond the Infinity Cache, tools/ubench/gather_bench.hip).
+// Entries past `left` (the row's remaining length; the index array is padded) come back as -1.
+typedef int32_t bu_i32x4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void bu_load_chunk(int32_t const* indices, int32_t pos, int32_t left, int32_t (&u)[BU_CHUNK])
+{
+  static_assert(BU_CHUNK == 4, "one dwordx4 load per chunk");
+  bu_i32x4 v = {-1, -1, -1, -1};
+  if (left > 0) v = *reinterpret_cast<bu_i32x4 const*>(indices + pos);
+  u[0] = left > 0 ? v.x : -1; u[1] = left > 1 ? v.y : -1; u[2] = left > 2 ? v.z : -1; u[3] = left > 3 ? v.w : -1;
+}
+
 __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_offsets, int32_t const* in_indices, int32_t const* out_offsets,
                                                             int64_t nv, uint32_t* vis, uint32_t const* front, uint32_t* next, int32_t* dist,
                                                             int32_t* pred, int32_t next_depth, counters_t* cnt)
 {
+  // A level is a chain of dependent memory round trips per 64-vertex group (visited word -> offsets -> neighbour ids -> frontier
+  // bits): with one group per wavefront at a time the level was latency-bound (0.9 ms at RMAT-24 whatever the frontier).  So a
+  // wavefront walks BU_GROUPS groups at once through the common part -- the first BU_CHUNK neighbours of every unvisited
+  // vertex, which settle most of them because in-neighbours are sorted hubs first -- and only then finishes the rows that
+  // are still open, group by group.
   int const lane       = threadIdx.x & 63;
   int64_t const gwave  = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int64_t const nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   int64_t const ngroup = (nv + 63) >> 6;
   unsigned long long inspected = 0, acc_out = 0, acc_in = 0;
   uint32_t found_total = 0;
-  for (int64_t grp = gwave; grp < ngroup; grp += nwaves) {
-    int64_t const v = grp * 64 + lane;
-    uint32_t const word = vis[(grp * 2) + (lane >> 5)];
-    bool const unvisited = v < nv && !((word >> (lane & 31)) & 1u);
-    bool found = false;
-    int32_t b = 0, e = 0, parent = -1;
-    if (unvisited) { b = in_offsets[v]; e = in_offsets[v + 1]; }
-    bool const coop = unvisited && (e - b) >= BU_COOP_DEG;
-    if (unvisited && !coop) {
-      int32_t p = b;
-      for (; p < e; ++p) {
-        int32_t u = in_indices[p];
-        if ((front[u >> 5] >> (u & 31)) & 1u) { found = true; parent = u; ++p; break; }  // ascending ids: the first hit is the minimum
+  for (int64_t grp0 = gwave * BU_GROUPS; grp0 < ngroup; grp0 += nwaves * BU_GROUPS) {
+    bool unvisited[BU_GROUPS], found[BU_GROUPS], open_row[BU_GROUPS];
+    int32_t b[BU_GROUPS], e[BU_GROUPS], parent[BU_GROUPS], scanned[BU_GROUPS];
+    int32_t u[BU_GROUPS][BU_CHUNK];
+#pragma unroll
+    for (int g = 0; g < BU_GROUPS; ++g) {
+      int64_t const grp = grp0 + g, v = grp * 64 + lane;
+      uint32_t const word = grp < ngroup ? vis[(grp * 2) + (lane >> 5)] : 0xFFFFFFFFu;
+      unvisited[g] = v < nv && !((word >> (lane & 31)) & 1u);
+    }
+#pragma unroll
+    for (int g = 0; g < BU_GROUPS; ++g) {
+      int64_t const v = (grp0 + g) * 64 + lane;
+      b[g] = 0; e[g] = 0; parent[g] = -1; found[g] = false; scanned[g] = 0;
+      if (unvisited[g]) { b[g] = in_offsets[v]; e[g] = in_offsets[v + 1]; }
+    }
+#pragma unroll
+    for (int g = 0; g < BU_GROUPS; ++g) {
+      open_row[g] = unvisited[g] && e[g] > b[g];
+      bu_load_chunk(in_indices, b[g], open_row[g] ? e[g] - b[g] : 0, u[g]);
+    }
+#pragma unroll
+    for (int g = 0; g < BU_GROUPS; ++g) {
+      int first = BU_CHUNK;
+#pragma unroll
+      for (int k = BU_CHUNK - 1; k >= 0; --k)
+        if (u[g][k] >= 0 && ((front[u[g][k] >> 5] >> (u[g][k] & 31)) & 1u)) first = k;  // ascending ids: the first hit is the minimum
+      if (open_row[g]) {
+        int32_t const deg = e[g] - b[g];
+        if (first < BU_CHUNK) {
+#pragma unroll
+          for (int k = 0; k < BU_CHUNK; ++k) if (k == first) parent[g] = u[g][k];
+          found[g] = true; open_row[g] = false; scanned[g] = first + 1;
+        } else {
+          scanned[g] = min(deg, BU_CHUNK);
+          if (scanned[g] >= deg) open_row[g] = false;
+        }
       }
-      inspected += (unsigned long long)(p - b);
     }
-    uint64_t cm = __ballot(coop);
-    while (cm) {  // long rows: the wavefront strides the row, 64 neighbours per step, and stops at the first hit
-      int src = __ffsll((unsigned long long)cm) - 1;
-      cm &= cm - 1;
-      int32_t bb = __shfl(b, src), ee = __shfl(e, src);
-      bool hit = false;
-      int32_t p = bb, par = -1;
-      for (; p < ee && !hit; p += 64) {
-        int32_t q = p + lane, u = -1;
-        bool h    = false;
-        if (q < ee) { u = in_indices[q]; h = ((front[u >> 5] >> (u & 31)) & 1u) != 0; }
-        uint64_t hm = __ballot(h);
-        hit         = hm != 0;
-        if (hit) par = __shfl(u, __ffsll((unsigned long long)hm) - 1);  // lowest lane = smallest position = smallest id
+    // the rows that are still open: further chunks per lane up to BU_LANE_MAX neighbours, the rest with the whole wavefront
+#pragma unroll
+    for (int g = 0; g < BU_GROUPS; ++g) {
+      int64_t const grp = grp0 + g, v = grp * 64 + lane;
+      if (grp >= ngroup) break;  // wave-uniform
+      int32_t const deg = e[g] - b[g];
+      while (__ballot(open_row[g] && scanned[g] < BU_LANE_MAX)) {
+        int32_t w[BU_CHUNK];
+        bu_load_chunk(in_indices, b[g] + scanned[g], open_row[g] ? deg - scanned[g] : 0, w);
+        int first = BU_CHUNK;
+#pragma unroll
+        for (int k = BU_CHUNK - 1; k >= 0; --k)
+          if (w[k] >= 0 && ((front[w[k] >> 5] >> (w[k] & 31)) & 1u)) first = k;
+        if (open_row[g]) {
+          if (first < BU_CHUNK) {
+#pragma unroll
+            for (int k = 0; k < BU_CHUNK; ++k) if (k == first) parent[g] = w[k];
+            found[g] = true; open_row[g] = false; scanned[g] += first + 1;
+          } else {
+            scanned[g] = min(deg, scanned[g] + BU_CHUNK);
+            if (scanned[g] >= deg) open_row[g] = false;
+          }
+        }
       }
-      if (lane == src) { found = hit; parent = par; inspected += (unsigned long long)(min(p, ee) - bb); }
+      inspected += (unsigned long long)scanned[g];
+      uint64_t cm = __ballot(open_row[g]);  // deg > BU_LANE_MAX and nothing found among the first BU_LANE_MAX neighbours
+      int32_t const rest = b[g] + scanned[g];
+      while (cm) {  // long rows: the wavefront strides the row, 64 neighbours per step, and stops at the first hit
+        int src = __ffsll((unsigned long long)cm) - 1;
+        cm &= cm - 1;
+        int32_t bb = __shfl(rest, src), ee = __shfl(e[g], src);
+        bool hit = false;
+        int32_t p = bb, par = -1;
+        for (; p < ee && !hit; p += 64) {
+          int32_t q = p + lane, x = -1;
+          bool h    = false;
+          if (q < ee) { x = in_indices[q]; h = ((front[x >> 5] >> (x & 31)) & 1u) != 0; }
+          uint64_t hm = __ballot(h);
+          hit         = hm != 0;
+          if (hit) par = __shfl(x, __ffsll((unsigned long long)hm) - 1);  // lowest lane = smallest position = smallest id
+        }
+        if (lane == src) { found[g] = hit; parent[g] = par; inspected += (unsigned long long)(min(p, ee) - bb); }
+      }
+      uint64_t const fm = __ballot(found[g]);
+      if (lane == 0) {
+        uint32_t lo = (uint32_t)fm, hi = (uint32_t)(fm >> 32);
+        next[grp * 2]     = lo;
+        next[grp * 2 + 1] = hi;
+        if (lo) vis[grp * 2] |= lo;       // this wavefront is the only writer of these two words
+        if (hi) vis[grp * 2 + 1] |= hi;
+      }
+      if (found[g]) {
+        dist[v] = next_depth;
+        if (pred) pred[v] = parent[g];
+        acc_out += (unsigned long long)(out_offsets[v + 1] - out_offsets[v]);
+        acc_in += (unsigned long long)deg;
+      }
+      found_total += (uint32_t)__popcll(fm);
     }
-    uint64_t const fm = __ballot(found);
-    if (lane == 0) {
-      uint32_t lo = (uint32_t)fm, hi = (uint32_t)(fm >> 32);
-      next[grp * 2]     = lo;
-      next[grp * 2 + 1] = hi;
-      if (lo) vis[grp * 2] |= lo;       // this wavefront is the only writer of these two words
-      if (hi) vis[grp * 2 + 1] |= hi;
-    }
-    if (found) {
-      dist[v] = next_depth;
-      if (pred) pred[v] = parent;
-      acc_out += (unsigned long long)(out_offsets[v + 1] - out_offsets[v]);
-      acc_in += (unsigned long long)(e - b);
-    }
-    found_total += (uint32_t)__popcll(fm);
   }
   for (int o = 32; o > 0; o >>= 1) { inspected += __shfl_xor(inspected, o); acc_out += __shfl_xor(acc_out, o); acc_in += __shfl_xor(acc_in, o); }
   if (lane == 0) {
@@ -303,12 +375,12 @@ struct sssp_relax {
 
 template <typename WT>
 __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices,
-                                                          int32_t* bigq, sssp_state<WT> s)
+                                                          int32_t* bigq, sssp_state<WT> s, int32_t big_deg)
 {
   __shared__ wave_queue_storage<2> wqs;
   wqs.init();
   sssp_relax<WT> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far)};
-  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f);
+  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f, big_deg);
   f.flush();
 }
 template <typename WT>
@@ -459,7 +531,14 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
 {
   HIP_TRY(hipSetDevice(h.device));
   static bool const trace = getenv("CUGRAPH_AMD_BFS_TRACE") != nullptr;
-  auto mark = [&](char const* what, long long a0 = 0, long long a1 = 0) { if (trace) { h.sync(); fprintf(stderr, "[bfs] %s %lld %lld\n", what, a0, a1); fflush(stderr); } };
+  auto const t_trace0 = std::chrono::steady_clock::now();
+  auto mark = [&](char const* what, long long a0 = 0, long long a1 = 0) {
+    if (trace) {
+      h.sync();
+      fprintf(stderr, "[bfs] %8.1f us  %s %lld %lld\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_trace0).count(), what, a0, a1);
+      fflush(stderr);
+    }
+  };
   CGA_EXPECTS(sources != nullptr, CUGRAPH_INVALID_INPUT, "sources is NULL");
   CGA_EXPECTS(g.vertex_type == sources->type, CUGRAPH_INVALID_INPUT, "vertex type of graph and sources must match");
   if (direction_optimizing)  // bfs_impl.cuh:202-204
@@ -522,11 +601,12 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   // come back when the frontier has shrunk below V / beta
   double const alpha = 14.0, beta = 24.0;
   uint64_t frontier_out = c.out_edges;            // out-edges of the current frontier
+  uint64_t reached_total = c.n_next, edges_of_reached = c.out_edges;
   uint64_t unvisited_in = (uint64_t)g.ne - c.in_edges;
   bool bottom_up = false, front_is_bitmap = false;
   // depth_limit is compared after incrementing (bfs_impl.cuh:867-868)
   uint64_t const limit = depth_limit > (size_t)INT32_MAX ? (uint64_t)INT32_MAX : (uint64_t)depth_limit;
-  int const bu_grid = (int)std::max<int64_t>(1, std::min<int64_t>(((nv + 63) / 64 + TV_WAVES - 1) / TV_WAVES, (int64_t)h.num_cus * 16));
+  int const bu_grid = (int)std::max<int64_t>(1, std::min<int64_t>(((nv + 63) / 64 + TV_WAVES * BU_GROUPS - 1) / (TV_WAVES * BU_GROUPS), (int64_t)h.num_cus * 16));
   while (n_cur > 0) {
     if (in) {
       if (!bottom_up) bottom_up = (double)frontier_out > (double)unvisited_in / alpha && n_cur > 1024;
@@ -561,7 +641,7 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
       {
         timed_launch t(h, "bfs_expand");
         hipLaunchKernelGGL(k_bfs_expand, expand_grid(h, n_cur), TV_BLOCK, 0, h.stream, (int32_t const*)q_cur, n_cur, (int32_t const*)o.offsets.data(),
-                           (int32_t const*)o.indices.data(), bigq.data(), s);
+                           (int32_t const*)o.indices.data(), bigq.data(), s, big_deg_for(h, n_cur));
         hipLaunchKernelGGL(k_bfs_expand_big, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
                            (int32_t const*)o.indices.data(), s);
       }
@@ -573,6 +653,8 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
     edges += c.edges;
     n_cur        = c.n_next;
     frontier_out = c.out_edges;
+    reached_total += c.n_next;
+    edges_of_reached += c.out_edges;
     unvisited_in -= std::min<uint64_t>(unvisited_in, c.in_edges);
     if (in && !bottom_up && !front_is_bitmap) {
       // keep vis_prev one level behind only while the next level may need vis_new & ~vis_prev; a following top-down
@@ -584,22 +666,8 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
     ++levels;
     if (depth >= limit) break;
   }
-  // statistics + result columns
-  dvec<unsigned long long> reached(1);
-  HIP_TRY(hipMemsetAsync(reached.data(), 0, 8, h.stream));
-  hipLaunchKernelGGL(k_count_reached, grid_for(nwords, kBlock, 1024), kBlock, 0, h.stream, (uint32_t const*)vis_new.data(), nwords, reached.data());
-  mark("count_reached");
-  unsigned long long nreached;
-  h.read_back(&nreached, reached.data(), 1);
-  h.last_stats = cugraph_amd_traversal_stats_t{levels, edges, nreached, edges};  // push-only: every out-edge of a reached vertex was inspected once
-  if (in) {  // bottom-up levels inspect in-edges (and stop early): count the out-edges of the reached vertices directly
-    dvec<unsigned long long> er(1);
-    HIP_TRY(hipMemsetAsync(er.data(), 0, 8, h.stream));
-    hipLaunchKernelGGL(k_bfs_edges_of_reached, grid_for(nv, kBlock, 2048), kBlock, 0, h.stream, dist->buf.as<int32_t const>(), out_off, nv, er.data());
-    unsigned long long ev;
-    h.read_back(&ev, er.data(), 1);
-    h.last_stats.edges_of_reached = ev;
-  }
+  // statistics: every discovered vertex was counted (with its out-degree) by the level that found it -- no extra pass
+  h.last_stats = cugraph_amd_traversal_stats_t{levels, edges, reached_total, edges_of_reached};
   (void)bu_levels;
   if (nv > 0) HIP_TRY(hipMemcpyAsync(ids->buf.ptr, g.number_map.data(), nv * 4, hipMemcpyDeviceToDevice, h.stream));
   if (compute_predecessors && nv > 0)  // bfs.cpp:131-138 unrenumbers the predecessors the same way
@@ -651,10 +719,13 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   hipLaunchKernelGGL(k_fill_t<bits_t>, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, d, nv, unreached_bits);
   HIP_TRY(hipMemsetAsync(mark_near.data(), 0, n1 * 4, h.stream));
   HIP_TRY(hipMemsetAsync(mark_far.data(), 0, n1 * 4, h.stream));
-  HIP_TRY(hipMemsetAsync(wsum.data(), 0, 8, h.stream));
-  if (g.ne > 0) hipLaunchKernelGGL(k_sum_weights<WT>, grid_for(g.ne, kBlock, 2048), kBlock, 0, h.stream, w, g.ne, wsum.data());
-  double wsum_h = 0;
-  h.read_back(&wsum_h, wsum.data(), 1);
+  if (!g.weight_sum_valid) {  // the weights of a graph never change: one pass per graph, not per call
+    HIP_TRY(hipMemsetAsync(wsum.data(), 0, 8, h.stream));
+    if (g.ne > 0) hipLaunchKernelGGL(k_sum_weights<WT>, grid_for(g.ne, kBlock, 2048), kBlock, 0, h.stream, w, g.ne, wsum.data());
+    h.read_back(&g.weight_sum, wsum.data(), 1);
+    g.weight_sum_valid = true;
+  }
+  double const wsum_h = g.weight_sum;
   // delta = 32 * average weight / average degree (sssp_impl.cuh:233-247)
   double avg_w   = g.ne > 0 ? wsum_h / (double)g.ne : 1.0;
   double avg_deg = nv > 0 ? (double)g.ne / (double)nv : 1.0;
@@ -692,7 +763,7 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
       {
         timed_launch t(h, "sssp_relax");
         hipLaunchKernelGGL(k_sssp_expand<WT>, expand_grid(h, n_cur), TV_BLOCK, 0, h.stream, (int32_t const*)q_cur, n_cur,
-                           (int32_t const*)o.offsets.data(), (int32_t const*)o.indices.data(), bigq.data(), s);
+                           (int32_t const*)o.offsets.data(), (int32_t const*)o.indices.data(), bigq.data(), s, big_deg_for(h, n_cur));
         hipLaunchKernelGGL(k_sssp_expand_big<WT>, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
                            (int32_t const*)o.indices.data(), s);
       }
@@ -727,6 +798,7 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
         if constexpr (sizeof(WT) == 4) { float f; uint32_t b = c.far_min_bits_lo; std::memcpy(&f, &b, 4); dmin = f; }
         else { double f; unsigned long long b = c.far_min_bits64; std::memcpy(&f, &b, 8); dmin = f; }
         double k = std::floor(dmin / delta);
+        while (k > 0.0 && k * delta > dmin) k -= 1.0;  // fl(dmin / delta) may round up to an integer: never jump past the smallest far distance
         if (k * delta > upper) upper = k * delta;
       }
     }

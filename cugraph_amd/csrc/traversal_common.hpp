@@ -9,7 +9,11 @@ namespace {
 
 constexpr int TV_BLOCK = 256;
 constexpr int TV_WAVES = TV_BLOCK / 64;
-constexpr int32_t BIG_DEG = 2048;
+constexpr int32_t BIG_DEG = 2048;      // rows at least this long are deferred to k_*_big when the frontier is wide ...
+constexpr int32_t BIG_DEG_NARROW = 64; // ... and rows at least THIS long when it is narrow: a wavefront walks its "whole-wave" rows one after
+                                       // the other, so a frontier of a few hundred vertices with 10^2..10^3 out-edges each (a level or a
+                                       // relaxation round right after the source) ran on a handful of wavefronts: 3.6 ms for one BFS level
+                                       // of 1141 vertices at RMAT-24, 0.5 ms for one of 30.  Deferred rows get one workgroup per 4096 edges.
 constexpr int32_t BIG_SEG = 4096;  // edges per deferred (row, segment) work unit
 
 struct counters_t {  // device-resident, zeroed per step
@@ -117,7 +121,7 @@ struct wave_queue {
 // bigq for k_expand_big.
 template <typename Keep, typename F>
 __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices,
-                                                int32_t* bigq, counters_t* cnt, Keep keep, F& f)
+                                                int32_t* bigq, counters_t* cnt, Keep keep, F& f, int32_t big_deg = BIG_DEG)
 {
   __shared__ uint32_t s_scan[TV_WAVES][64];
   __shared__ int32_t s_beg[TV_WAVES][64];
@@ -134,7 +138,7 @@ __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int
       if (keep(u)) { beg = offsets[u]; deg = offsets[u + 1] - beg; } else { u = -1; }
     }
     // deferred: huge rows, cut into BIG_SEG-edge segments (one workgroup of k_*_big each)
-    bool big = deg >= BIG_DEG;
+    bool big = deg >= big_deg;
     if (big) {
       uint32_t nseg = ((uint32_t)deg + BIG_SEG - 1) / BIG_SEG;
       uint32_t at   = atomicAdd(&cnt->n_big, nseg);
@@ -190,7 +194,10 @@ __device__ __forceinline__ void expand_big(int32_t const* bigq, int32_t const* o
 }
 
 
-inline size_t big_queue_entries(int64_t ne) { return (size_t)(2 * (ne / BIG_DEG + ne / BIG_SEG + 64)); }
+inline size_t big_queue_entries(int64_t ne) { return (size_t)(2 * (ne / BIG_DEG_NARROW + ne / BIG_SEG + 64)); }
+
+// narrow frontier (fewer vertices than the chip has wavefront slots): defer every row a wavefront would otherwise walk alone
+inline int32_t big_deg_for(handle_t const& h, int64_t n) { return n < (int64_t)h.num_cus * 64 ? BIG_DEG_NARROW : BIG_DEG; }
 
 inline int expand_grid(handle_t const& h, int64_t n)
 {

@@ -163,6 +163,12 @@ typedef struct {
 } cugraph_amd_traversal_stats_t;
 CUGRAPH_EXPORT void cugraph_amd_last_traversal_stats(const cugraph_resource_handle_t* handle,
                                                      cugraph_amd_traversal_stats_t* out);
+/* Device memory of the library comes from a process-wide caching pool (csrc/common.hpp: dev_buf): freed blocks are kept and
+ * reused (hipMalloc / hipFree are synchronous and slow at graph sizes).  _trim returns every cached block to the driver and
+ * reports how many bytes that were; environment: CUGRAPH_AMD_POOL=0 (off), CUGRAPH_AMD_POOL_MAX_GB (cache cap, default 128). */
+CUGRAPH_EXPORT size_t cugraph_amd_memory_pool_trim(void);
+CUGRAPH_EXPORT size_t cugraph_amd_memory_pool_cached_bytes(void);
+
 #ifdef __cplusplus
 }
 #endif

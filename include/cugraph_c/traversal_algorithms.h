@@ -5,8 +5,14 @@
  * = type max, predecessor -1; the predecessor array has size 0 when not requested.  A source array
  * whose type differs from the graph's vertex type, or a source that is not a vertex of the graph,
  * gives CUGRAPH_INVALID_INPUT (bfs.cpp:106-119, 198-205).  depth_limit semantics bfs_impl.cuh:867-868.
- * Predecessors are deterministic here (minimum-id parent; SSSP: lexicographic min (distance, parent)
- * as sssp_impl.cuh:334), a valid instance of the reference's reduce_op::any.
+ * Predecessors are deterministic here: BFS returns, among the valid parents (one level up), the one with the smallest
+ * INTERNAL id (= the highest-degree one; equal to the smallest external id when the graph is not renumbered); SSSP the
+ * lexicographic min (distance, external parent id) as sssp_impl.cuh:334 -- both valid instances of the reference's
+ * reduce_op::any, whose own tests accept any valid parent (bfs_test.cpp:217-233).
+ * direction_optimizing: TRUE on a non-symmetric graph is CUGRAPH_INVALID_INPUT as in the reference (bfs_impl.cuh:202-204).
+ * The flag does not select the algorithm here: levels run bottom-up whenever the in-edges are at hand (symmetric graph,
+ * or a CSC built by an earlier call) and Beamer's heuristic says so -- distances do not depend on the direction, and the
+ * parent rule above is direction-independent too.  CUGRAPH_AMD_BFS=topdown pins the push-only path.
  *
  * cugraph_extract_paths (traversal_algorithms.h:167-201, impl cpp/src/c_api/extract_paths.cpp:24-170 over
  * cugraph::extract_bfs_paths, cpp/src/traversal/extract_bfs_paths_impl.cuh:130-240): for every destination the path from its
