@@ -252,7 +252,17 @@ struct orientation_t {
 constexpr int32_t kSegThreshold[orientation_t::n_seg] = {4096, 64, 16, 4, 1};
 constexpr int64_t kEdgePad = 2048;  // indices / weights are over-allocated so 16-byte tail loads stay in bounds
 
+// INT64 / sparse external ids are translated at the C-API boundary (outer_ids.hip): compact id c <-> ext[c], ext ascending
+struct outer_ids_t {
+  bool active{false};
+  bool identity{false};                     // ext[c] == c (renumber = FALSE graphs: only the id TYPE differs)
+  cugraph_data_type_id_t type{INT32};       // the vertex type the caller sees
+  dvec<int64_t> ext;
+};
+
 struct graph_t {  // behind cugraph_graph_t (cpp/src/c_api/graph.hpp:61-77)
+  outer_ids_t outer;
+  cugraph_data_type_id_t api_vertex_type() const { return outer.active ? outer.type : vertex_type; }
   cugraph_data_type_id_t vertex_type{INT32};
   cugraph_data_type_id_t edge_type{INT32};
   cugraph_data_type_id_t weight_type{FLOAT32};
@@ -372,5 +382,30 @@ void renumber_ext_to_int(handle_t const& h, graph_t const& g, int32_t* ids, int6
 // internal -> external (in place); negative ids stay as they are
 void unrenumber_int_to_ext(handle_t const& h, graph_t const& g, int32_t* ids, int64_t n);
 int64_t count_negative_i32(handle_t const& h, int32_t const* ids, int64_t n);
+
+// INT64 / sparse external ids at the C-API boundary (outer_ids.hip)
+void outer_collect(handle_t const& h, device_array_view_t const* const* cols, int ncols, dvec<int64_t>& ext);
+void outer_to_compact(handle_t const& h, outer_ids_t const& o, void const* ids, cugraph_data_type_id_t type, int64_t n, int32_t* out);
+device_array_t* outer_from_compact(handle_t const& h, outer_ids_t const& o, int32_t const* ids, int64_t n);
+void outer_replace_ids(handle_t const& h, graph_t const& g, device_array_t*& col);
+void outer_replace_dist(handle_t const& h, graph_t const& g, device_array_t*& col);
+void outer_narrow_dist(handle_t const& h, int64_t const* d, int64_t n, int32_t* out);
+// A vertex-id column handed to an algorithm: checks its type against the graph's (CUGRAPH_INVALID_INPUT as bfs.cpp:198-205)
+// and, for graphs with outer ids, replaces it by an owned column of compact int32 ids (-1 = not a vertex).
+struct vertex_column_in {
+  dvec<int32_t> owned;
+  device_array_view_t view{nullptr, 0, INT32};
+  device_array_view_t const* get(handle_t const& h, graph_t const& g, device_array_view_t const* v, char const* what)
+  {
+    if (v == nullptr) return nullptr;
+    CGA_EXPECTS(v->type == g.api_vertex_type(), CUGRAPH_INVALID_INPUT, std::string("vertex type of graph and ") + what + " must match");
+    if (!g.outer.active) return v;
+    owned.resize_discard(v->size > 0 ? v->size : 1);
+    outer_to_compact(h, g.outer, v->data, v->type, (int64_t)v->size, owned.data());
+    h.sync();
+    view = device_array_view_t{owned.data(), v->size, INT32};
+    return &view;
+  }
+};
 
 }  // namespace cga

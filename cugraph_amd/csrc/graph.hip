@@ -278,13 +278,57 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
                 "Invalid input arguments: src size != edge id prop size");
     CGA_EXPECTS(edge_type_ids == nullptr || edge_type_ids->size == src->size, CUGRAPH_INVALID_INPUT,
                 "Invalid input arguments: src size != edge type prop size");
-    if (src->type == INT32)
+    // type rules (graph_sg.cpp:745-779): vertex columns are INT32 or INT64; a mix promotes the graph to INT64.  INT64 ids and
+    // INT32 ids too sparse for the dense external->internal table are translated at the API boundary (outer_ids.hip); the
+    // kernels keep 32-bit internal ids, so the vertex and edge COUNTS stay below 2^31 either way.
+    auto is_id_type = [](device_array_view_t const* v) { return v == nullptr || v->type == INT32 || v->type == INT64; };
+    CGA_EXPECTS(is_id_type(src) && is_id_type(dst) && is_id_type(vertices), CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
+                "vertex ids must be INT32 or INT64");
+    bool const any64 = src->type == INT64 || dst->type == INT64 || (vertices && vertices->type == INT64);
+    if (!any64)
       CGA_EXPECTS(src->size < (size_t)INT32_MAX, CUGRAPH_INVALID_INPUT,
                   "Number of edges won't fit in 32-bit integer, using 32-bit type");
-    // type rules (graph_sg.cpp:745-779): mixed vertex types promote to INT64 -> not in this build
-    bool same = src->type == dst->type && (vertices == nullptr || vertices->type == src->type);
-    CGA_EXPECTS(same && src->type == INT32, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
-                "this build supports INT32 vertex / edge ids only (INT64 graphs: not implemented yet)");
+    else
+      CGA_EXPECTS(src->size < (size_t)INT32_MAX, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
+                  "INT64 graphs with 2^31 or more edges need 64-bit edge offsets, which this build does not have");
+    check_view(src, "src"); check_view(dst, "dst"); check_view(vertices, "vertices");
+    outer_ids_t outer;
+    dvec<int32_t> c_src, c_dst, c_vtx;  // compact ids when the external ids are translated
+    device_array_view_t v_src{nullptr, 0, INT32}, v_dst{nullptr, 0, INT32}, v_vtx{nullptr, 0, INT32};
+    {
+      bool sparse32 = false;
+      if (!any64 && renumber == TRUE) {  // dense table = 4 bytes per id of the RANGE: fine up to a few times the number of ids
+        int64_t lo = INT64_MAX, hi = INT64_MIN;
+        for (device_array_view_t const* v : {src, dst, vertices}) {
+          if (!v || v->size == 0) continue;
+          int32_t a, b;
+          minmax_i32(h, v->as<int32_t>(), (int64_t)v->size, &a, &b);
+          lo = std::min<int64_t>(lo, a); hi = std::max<int64_t>(hi, b);
+        }
+        int64_t const ids = 2 * (int64_t)src->size + (vertices ? (int64_t)vertices->size : 0);
+        sparse32 = hi >= lo && ((hi - lo + 1) > 4 * ids + 65536 || (hi - lo + 1) > ((int64_t)1 << 31) - 2);
+      }
+      if (any64 || sparse32) {
+        outer.active   = true;
+        outer.type     = any64 ? INT64 : INT32;
+        outer.identity = renumber != TRUE;
+        if (!outer.identity) {
+          device_array_view_t const* cols[3] = {src, dst, vertices};
+          outer_collect(h, cols, 3, outer.ext);
+        }
+        auto conv = [&](device_array_view_t const* v, dvec<int32_t>& owned, device_array_view_t& view) -> device_array_view_t const* {
+          if (!v) return nullptr;
+          owned.resize_discard(v->size > 0 ? v->size : 1);
+          outer_to_compact(h, outer, v->data, v->type, (int64_t)v->size, owned.data());
+          view = device_array_view_t{owned.data(), v->size, INT32};
+          return &view;
+        };
+        src      = conv(src, c_src, v_src);
+        dst      = conv(dst, c_dst, v_dst);
+        vertices = conv(vertices, c_vtx, v_vtx);
+        h.sync();
+      }
+    }
     CGA_EXPECTS(weights == nullptr || weights->type == FLOAT32 || weights->type == FLOAT64,
                 CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "weights must be FLOAT32 or FLOAT64");
     // Edge ids / types / start and end times are edge PROPERTIES that only the sampling and lookup families read
@@ -299,9 +343,10 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
     CGA_EXPECTS((t0 == nullptr || t0->type == INT32 || t0->type == INT64) && (t1 == nullptr || t1->type == INT32 || t1->type == INT64) &&
                   (t0 == nullptr || t1 == nullptr || t0->type == t1->type),
                 CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "edge start / end times must share one integer type");
-    check_view(src, "src"); check_view(dst, "dst"); check_view(weights, "weights"); check_view(vertices, "vertices");
+    check_view(weights, "weights");
 
     auto g              = std::make_unique<graph_t>();
+    g->outer            = std::move(outer);
     g->vertex_type      = INT32;
     g->edge_type        = INT32;
     g->weight_type      = weights ? weights->type : FLOAT32;
@@ -649,7 +694,8 @@ extern "C" cugraph_error_code_t cugraph_has_vertex(const cugraph_resource_handle
     graph_t& g        = G(graph);
     auto v            = V(vertices);
     CGA_EXPECTS(v != nullptr && result != nullptr, CUGRAPH_INVALID_INPUT, "vertices / result is NULL");
-    CGA_EXPECTS(v->type == g.vertex_type, CUGRAPH_INVALID_INPUT, "vertex type of graph and vertices must match");
+    vertex_column_in c_v;  // INT64 / sparse external ids: compact int32 ids (absent ones -1) from here on (outer_ids.hip)
+    v = c_v.get(h, g, v, "vertices");
     auto out = std::make_unique<device_array_t>(v->size, BOOL);
     if (v->size > 0)
       hipLaunchKernelGGL(k_has_vertex, grid_for(v->size, kBlock, 4096), kBlock, 0, h.stream, v->as<int32_t>(), (int64_t)v->size,

@@ -73,8 +73,9 @@ cugraph_error_code_t degrees_impl(const cugraph_resource_handle_t* handle, cugra
     graph_t& g        = G(graph);
     CGA_EXPECTS(result != nullptr, CUGRAPH_INVALID_INPUT, "result is NULL");
     HIP_TRY(hipSetDevice(h.device));
-    auto sv = reinterpret_cast<device_array_view_t const*>(source_vertices);
-    CGA_EXPECTS(sv == nullptr || sv->type == g.vertex_type, CUGRAPH_INVALID_INPUT, "vertex type of graph and source_vertices must match");
+    auto const sv_user = reinterpret_cast<device_array_view_t const*>(source_vertices);
+    vertex_column_in c_sv;  // INT64 / sparse external ids: compact int32 ids from here on (outer_ids.hip)
+    device_array_view_t const* sv = c_sv.get(h, g, sv_user, "source_vertices");
     int64_t const nv = g.nv, n1 = nv > 0 ? nv : 1;
     bool const sym   = g.props.is_symmetric == TRUE;
     bool const share = want_in && want_out && sym;  // degrees.cu:84-88: one array serves both
@@ -110,6 +111,16 @@ cugraph_error_code_t degrees_impl(const cugraph_resource_handle_t* handle, cugra
     if (want_in) res->in_degrees = emit(din);
     if (want_out && !share) res->out_degrees = emit(dout);
     h.sync();
+    if (g.outer.active) {  // the vertex column goes back in the caller's id type: its own column, or the mapped number_map
+      if (sv_user) {
+        delete res->vertex_ids;
+        res->vertex_ids = new device_array_t((size_t)n_out, sv_user->type);
+        if (n_out > 0) HIP_TRY(hipMemcpyAsync(res->vertex_ids->buf.ptr, sv_user->data, n_out * dtype_size(sv_user->type), hipMemcpyDeviceToDevice, h.stream));
+        h.sync();
+      } else {
+        outer_replace_ids(h, g, res->vertex_ids);
+      }
+    }
     *result = reinterpret_cast<cugraph_degrees_result_t*>(res.release());
   });
 }
@@ -192,20 +203,30 @@ extern "C" cugraph_error_code_t cugraph_extract_paths(const cugraph_resource_han
     auto pr           = reinterpret_cast<paths_result_t const*>(paths_result);
     auto dv           = reinterpret_cast<device_array_view_t const*>(destinations);
     CGA_EXPECTS(result != nullptr && pr != nullptr && dv != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
-    CGA_EXPECTS(pr->distances != nullptr && pr->distances->type == g.vertex_type, CUGRAPH_INVALID_INPUT,
+    CGA_EXPECTS(pr->distances != nullptr && pr->distances->type == g.api_vertex_type(), CUGRAPH_INVALID_INPUT,
                 "Invalid input argument: distances must come from cugraph_bfs (vertex-typed hop counts)");
     CGA_EXPECTS(pr->predecessors != nullptr && (int64_t)pr->predecessors->size == g.nv, CUGRAPH_INVALID_INPUT,
                 "Invalid input argument: predecessors cannot be null");  // extract_bfs_paths_impl.cuh:140-142
-    CGA_EXPECTS(dv->type == g.vertex_type, CUGRAPH_INVALID_INPUT, "vertex type of graph and destinations must match");
     HIP_TRY(hipSetDevice(h.device));
+    vertex_column_in c_dv;  // INT64 / sparse external ids: compact int32 ids from here on (outer_ids.hip)
+    dv = c_dv.get(h, g, dv, "destinations");
     int64_t const nv = g.nv, nd = (int64_t)dv->size;
-    dvec<int32_t> dest(nd > 0 ? nd : 1), pred(nv > 0 ? nv : 1), scal(2);
+    dvec<int32_t> dest(nd > 0 ? nd : 1), pred(nv > 0 ? nv : 1), scal(2), dist32;
     if (nd > 0) HIP_TRY(hipMemcpyAsync(dest.data(), dv->data, nd * 4, hipMemcpyDeviceToDevice, h.stream));
-    if (nv > 0) HIP_TRY(hipMemcpyAsync(pred.data(), pr->predecessors->buf.ptr, nv * 4, hipMemcpyDeviceToDevice, h.stream));
+    int32_t const* dist = pr->distances->buf.as<int32_t>();
+    if (g.outer.active) {  // the BFS result carries outer ids / widened hop counts: back to compact ids and int32 hops
+      if (nv > 0) outer_to_compact(h, g.outer, pr->predecessors->buf.ptr, pr->predecessors->type, nv, pred.data());  // -1 stays -1
+      if (g.outer.type == INT64) {
+        dist32.resize_discard(nv > 0 ? nv : 1);
+        outer_narrow_dist(h, pr->distances->buf.as<int64_t const>(), nv, dist32.data());
+        dist = dist32.data();
+      }
+    } else if (nv > 0) {
+      HIP_TRY(hipMemcpyAsync(pred.data(), pr->predecessors->buf.ptr, nv * 4, hipMemcpyDeviceToDevice, h.stream));
+    }
     renumber_ext_to_int(h, g, dest.data(), nd);   // extract_paths.cpp:93-109: destinations and predecessors to internal ids
     renumber_ext_to_int(h, g, pred.data(), nv);   // -1 (no predecessor) stays negative
     HIP_TRY(hipMemsetAsync(scal.data(), 0, 2 * sizeof(int32_t), h.stream));
-    int32_t const* dist = pr->distances->buf.as<int32_t>();
     if (nd > 0) hipLaunchKernelGGL(k_max_path, grid_for(nd), kBlock, 0, h.stream, (int32_t const*)dest.data(), nd, dist, (int32_t const*)pred.data(), scal.data(), scal.data() + 1);
     int32_t hs[2] = {0, 0};
     h.read_back(hs, scal.data(), 2);
@@ -220,6 +241,7 @@ extern "C" cugraph_error_code_t cugraph_extract_paths(const cugraph_resource_han
                          (int32_t const*)g.number_map.data(), L, res->paths->buf.as<int32_t>());
     }
     h.sync();
+    outer_replace_ids(h, g, res->paths);  // -1 padding passes through
     *result = reinterpret_cast<cugraph_extract_paths_result_t*>(res.release());
   });
 }
@@ -287,6 +309,8 @@ extern "C" cugraph_error_code_t cugraph_decompress_to_edgelist(const cugraph_res
       out->wgt = new device_array_t(0, g.weight_type);
     }
     h.sync();
+    outer_replace_ids(h, g, out->src);
+    outer_replace_ids(h, g, out->dst);
     *result = reinterpret_cast<cugraph_edgelist_t*>(out.release());
   });
 }

@@ -373,6 +373,15 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
     if (nv0 > 0) HIP_TRY(hipMemcpyAsync(res->vertices->buf.ptr, g.number_map.data(), nv0 * sizeof(int32_t), hipMemcpyDeviceToDevice, h.stream));
     res->clusters = part.release();
     h.sync();
+    outer_replace_ids(h, g, res->vertices);
+    if (g.outer.active && g.outer.type == INT64) {  // cluster ids carry the vertex type (louvain.cpp:24-135): widen
+      outer_ids_t widen;
+      widen.active = true; widen.identity = true; widen.type = INT64;
+      device_array_t* wide = outer_from_compact(h, widen, res->clusters->buf.as<int32_t>(), (int64_t)res->clusters->size);
+      h.sync();
+      delete res->clusters;
+      res->clusters = wide;
+    }
     *result = reinterpret_cast<cugraph_hierarchical_clustering_result_t*>(res.release());
   });
 }

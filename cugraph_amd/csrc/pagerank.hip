@@ -989,7 +989,9 @@ struct pagerank_plan : pagerank_plan_base {
       HIP_TRY(hipMemcpyAsync(vals->buf.ptr, pr.data(), g.nv * sizeof(WT), hipMemcpyDeviceToDevice, h.stream));
     }
     h.sync();
-    return new centrality_result_t{ids.release(), vals.release(), total_iterations, converged};
+    auto* r = new centrality_result_t{ids.release(), vals.release(), total_iterations, converged};
+    outer_replace_ids(h, g, r->vertex_ids);
+    return r;
   }
 };
 
@@ -1223,7 +1225,7 @@ void check_pair_types(graph_t const& g, device_array_view_t const* v, device_arr
 {
   if (v == nullptr && s == nullptr) return;
   CGA_EXPECTS(v != nullptr && s != nullptr, CUGRAPH_INVALID_INPUT, std::string(vmsg) + " (vertices and values must both be given)");
-  CGA_EXPECTS(g.vertex_type == v->type, CUGRAPH_INVALID_INPUT, vmsg);
+  CGA_EXPECTS(g.api_vertex_type() == v->type, CUGRAPH_INVALID_INPUT, vmsg);
   CGA_EXPECTS(g.weight_type == s->type, CUGRAPH_INVALID_INPUT, smsg);
 }
 
@@ -1241,13 +1243,19 @@ pagerank_plan_base* make_plan(cugraph_resource_handle_t const* handle, cugraph_g
                    "vertex type of graph and initial_guess_values must match");
   check_pair_types(g, V(p_v), V(p_s), "vertex type of graph and personalization_vector must match",
                    "vertex type of graph and personalization_vector must match");
+  // INT64 / sparse external ids: the vertex columns become compact int32 ids (outer_ids.hip); ids that are not vertices map
+  // to -1 and are rejected by create() exactly as unknown int32 ids are
+  vertex_column_in c_ow, c_ig, c_p;
+  device_array_view_t const* ow = c_ow.get(h, g, V(ow_v), "precomputed_vertex_out_weight_vertices");
+  device_array_view_t const* ig = c_ig.get(h, g, V(ig_v), "initial_guess_vertices");
+  device_array_view_t const* pv = c_p.get(h, g, V(p_v), "personalization_vector");
   if (g.weight_type == FLOAT64) {
     auto p = std::make_unique<pagerank_plan<double>>(h, g, alpha);
-    p->create(V(ow_v), V(ow_s), V(ig_v), V(ig_s), V(p_v), V(p_s));
+    p->create(ow, V(ow_s), ig, V(ig_s), pv, V(p_s));
     return p.release();
   }
   auto p = std::make_unique<pagerank_plan<float>>(h, g, alpha);
-  p->create(V(ow_v), V(ow_s), V(ig_v), V(ig_s), V(p_v), V(p_s));
+  p->create(ow, V(ow_s), ig, V(ig_s), pv, V(p_s));
   return p.release();
 }
 

@@ -540,7 +540,8 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
     }
   };
   CGA_EXPECTS(sources != nullptr, CUGRAPH_INVALID_INPUT, "sources is NULL");
-  CGA_EXPECTS(g.vertex_type == sources->type, CUGRAPH_INVALID_INPUT, "vertex type of graph and sources must match");
+  vertex_column_in c_sources;  // INT64 / sparse external ids: compact int32 ids from here on (outer_ids.hip)
+  sources = c_sources.get(h, g, sources, "sources");
   if (direction_optimizing)  // bfs_impl.cuh:202-204
     CGA_EXPECTS(g.props.is_symmetric == TRUE, CUGRAPH_INVALID_INPUT,
                 "Invalid input argument: input graph should be symmetric for direction optimizing BFS.");
@@ -674,7 +675,11 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
     hipLaunchKernelGGL(k_bfs_finish_pred, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, pred_p, nv, labels);
   mark("finish_pred");
   h.sync();
-  return new paths_result_t{ids.release(), dist.release(), preds.release()};
+  auto* r = new paths_result_t{ids.release(), dist.release(), preds.release()};
+  outer_replace_ids(h, g, r->vertex_ids);
+  outer_replace_dist(h, g, r->distances);  // BFS distances carry the vertex type (bfs.cpp:156-187)
+  outer_replace_ids(h, g, r->predecessors);
+  return r;
 }
 
 template <typename WT>
@@ -692,6 +697,16 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
 
   // source: external id -> internal (sssp.cpp:84-103)
   dvec<int32_t> src(1);
+  if (g.outer.active) {  // INT64 / sparse external ids: look the source up in the sorted id list first
+    dvec<int64_t> one(1);
+    int64_t const sv = (int64_t)source_ext;
+    HIP_TRY(hipMemcpyAsync(one.data(), &sv, 8, hipMemcpyHostToDevice, h.stream));
+    outer_to_compact(h, g.outer, one.data(), INT64, 1, src.data());
+    int32_t c = -1;
+    h.read_back(&c, src.data(), 1);
+    CGA_EXPECTS(c >= 0, CUGRAPH_INVALID_INPUT, "Invalid input argument: source vertex is not a vertex of the graph.");
+    source_ext = (size_t)c;
+  }
   CGA_EXPECTS(source_ext <= (size_t)INT32_MAX, CUGRAPH_INVALID_INPUT, "invalid source vertex");
   int32_t s_host = (int32_t)source_ext;
   HIP_TRY(hipMemcpyAsync(src.data(), &s_host, 4, hipMemcpyHostToDevice, h.stream));
@@ -826,7 +841,10 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   h.last_stats = cugraph_amd_traversal_stats_t{steps, relaxed, nreached, compute_predecessors ? c.edges : 0};
   if (nv > 0) HIP_TRY(hipMemcpyAsync(ids->buf.ptr, g.number_map.data(), nv * 4, hipMemcpyDeviceToDevice, h.stream));
   h.sync();
-  return new paths_result_t{ids.release(), dist.release(), preds.release()};
+  auto* r = new paths_result_t{ids.release(), dist.release(), preds.release()};
+  outer_replace_ids(h, g, r->vertex_ids);
+  outer_replace_ids(h, g, r->predecessors);
+  return r;
 }
 
 }  // namespace

@@ -200,8 +200,9 @@ def test_graph_creation_errors(cg, handle):
         cg.SGGraph(handle, props, T([0, 1, 2], np.int32), T([1, 2, 3], np.int32), T([1, 1, 1, 1], np.float32))
     with pytest.raises(TypeError):
         cg.SGGraph(handle, props, [0, 1], T([1, 2], np.int32))
-    with pytest.raises(ValueError):  # INT64 graphs: unsupported type combination in this build
-        cg.SGGraph(handle, props, T([0, 1], np.int64), T([1, 2], np.int64))
+    g64 = cg.SGGraph(handle, props, T([0, 1], np.int64), T([1, 2], np.int64))  # INT64 ids (graph_sg.cpp:745-779): accepted
+    with pytest.raises(ValueError, match="vertex type of graph and (sources|vertices) must match"):  # (bfs.pyx:140 checks has_vertex first)
+        cg.bfs(handle, g64, T([0], np.int32), False, 0, True, False)
     # edge ids / types are validated edge properties that no algorithm of this library reads (graph.hip): accepted, sizes checked
     cg.SGGraph(handle, props, T([0, 1], np.int32), T([1, 2], np.int32), edge_id_array=T([0, 1], np.int32))
     with pytest.raises(ValueError, match="edge id prop size"):
@@ -993,3 +994,105 @@ def test_capi_generators_edge_columns_and_decompress(cg, handle):
     for vs in views:
         for v in vs:
             v.free()
+
+
+# ----------------------------------------------------------------------- INT64 ids, sparse ids (outer_ids.hip)
+def _ext(ids, mapping, dtype):
+    return T(np.asarray([mapping[i] for i in ids]), dtype)
+
+
+@pytest.mark.parametrize("kind", ["int64_dense", "int64_sparse", "int32_sparse", "int64_norenumber"])
+def test_goldens_with_int64_and_sparse_ids(cg, handle, golden, kind):
+    """The reference's C-API goldens (pagerank_test.c, bfs_test.c, sssp_test.c) with the vertex ids as INT64 columns
+    (graph_sg.cpp:745-779 instantiates int64 graphs; python-cugraph's default column type) and with ids spread over ranges far
+    too wide for a dense table (renumber_utils_impl.cuh:333-660 uses a hash map): every vertex-id column comes back in the
+    caller's type and id space, BFS distances in the vertex type; has_vertex / degrees / decompress_to_edgelist follow."""
+    import ctypes as C
+
+    import torch
+
+    from cugraph_amd import _capi
+    from cugraph_amd.pylib import assert_success, copy_to_torch
+
+    dtype = np.int32 if kind == "int32_sparse" else np.int64
+    if kind == "int32_sparse":
+        m = {0: 7, 1: 10**9, 2: 2 * 10**9, 3: 123456789, 4: 42, 5: 1999999999}
+    elif kind == "int64_sparse":
+        m = {0: 7, 1: 10**9, 2: 2 * 10**9, 3: 3 * 10**12, 4: -5, 5: 2**62}
+    else:
+        m = {i: i for i in range(8)}
+    inv = {v: k for k, v in m.items()}
+    renumber = kind != "int64_norenumber"
+    tdtype = torch.int32 if dtype == np.int32 else torch.int64
+
+    def back(t):
+        return np.array([inv.get(int(x), int(x)) for x in t.cpu().numpy().tolist()])
+
+    props = cg.GraphProperties(is_multigraph=True)
+
+    def graph(gr, transposed, wdtype=np.float32):
+        return cg.SGGraph(handle, props, _ext(gr["src"], m, dtype), _ext(gr["dst"], m, dtype), T(gr["wgt"], wdtype), store_transposed=transposed, renumber=renumber)
+
+    case = golden["c_api"]["pagerank"][0]
+    g = graph(case["graph"], case["store_transposed"])
+    v, pr, conv = cg.pagerank(handle, g, None, None, None, None, case["alpha"], case["epsilon"], case["max_iterations"], False, fail_on_nonconvergence=False)
+    assert v.dtype == tdtype
+    got = np.empty(len(case["result"]))
+    got[back(v)] = pr.cpu().numpy()
+    for a, b in zip(got, case["result"]):
+        assert nearly_equal(float(a), b, golden["c_api"]["tolerance"])
+    pc = golden["c_api"]["personalized_pagerank"][0]
+    gp = graph(pc["graph"], pc["store_transposed"])
+    v, pr, _ = cg.personalized_pagerank(handle, gp, None, None, None, None, _ext(pc["pers_vertices"], m, dtype), T(pc["pers_values"], np.float32),
+                                        pc["alpha"], pc["epsilon"], pc["max_iterations"], False, fail_on_nonconvergence=False)
+    got = np.empty(len(pc["result"]))
+    got[back(v)] = pr.cpu().numpy()
+    for a, b in zip(got, pc["result"]):
+        assert nearly_equal(float(a), b, golden["c_api"]["tolerance"])
+    bc = golden["c_api"]["bfs"][0]
+    gb = graph(bc["graph"], bc["store_transposed"])
+    d, p, v = cg.bfs(handle, gb, _ext(bc["seeds"], m, dtype), False, bc["depth_limit"], True, False)
+    assert d.dtype == tdtype and v.dtype == tdtype and p.dtype == tdtype
+    order = np.argsort(back(v))
+    tmax = int(np.iinfo(dtype).max)
+    assert d.cpu().numpy()[order].tolist() == [x if x != 2147483647 else tmax for x in bc["distances"]]
+    pb, db = back(p)[order].tolist(), bc["distances"]
+    if "sparse" in kind:  # the tie-break among valid parents follows the id order, which the sparse mapping permutes: any valid parent
+        edges = set(zip(bc["graph"]["src"], bc["graph"]["dst"]))
+        for x, par in enumerate(pb):
+            assert (par == -1 and (db[x] == 0 or db[x] == 2147483647)) or ((par, x) in edges and db[par] + 1 == db[x])
+    else:
+        assert pb == bc["predecessors"]
+    with pytest.raises(ValueError):  # a source that is not a vertex
+        cg.bfs(handle, gb, T([999], dtype), False, 0, True, False)
+    sc = golden["c_api"]["sssp"][0]
+    gs = graph(sc["graph"], sc["store_transposed"], np.dtype(sc["dtype"]))
+    v, d, p = cg.sssp(handle, gs, m[sc["source"]], float(np.finfo(np.dtype(sc["dtype"])).max), True, False)
+    order = np.argsort(back(v))
+    for a, b in zip(d.cpu().numpy()[order], sc["distances"]):
+        assert nearly_equal(float(a), b, golden["c_api"]["tolerance"])
+    ps, ds = back(p)[order].tolist(), d.cpu().numpy()[order].tolist()
+    if "sparse" in kind:
+        wmap = {(a, b): w for a, b, w in zip(sc["graph"]["src"], sc["graph"]["dst"], sc["graph"]["wgt"])}
+        for x, par in enumerate(ps):
+            assert (par == -1) or ((par, x) in wmap and nearly_equal(ds[par] + wmap[(par, x)], ds[x], 1e-5))
+    else:
+        assert ps == sc["predecessors"]
+    hv = cg.has_vertex(handle, gb, T([m[0], m[5], 31337], dtype))
+    assert hv.cpu().numpy().tolist() == [True, True, False]
+    l, hp, err = _capi.lib(), handle.c_resource_handle_ptr, C.c_void_p()
+    el = C.c_void_p()
+    assert_success(l.cugraph_decompress_to_edgelist(hp, gb.c_graph_ptr, 0, C.byref(el), C.byref(err)), err, "decompress")
+    es = copy_to_torch(hp, l.cugraph_edgelist_get_sources(el))
+    ed = copy_to_torch(hp, l.cugraph_edgelist_get_destinations(el))
+    assert es.dtype == tdtype
+    assert sorted(zip(back(es).tolist(), back(ed).tolist())) == sorted(zip(bc["graph"]["src"], bc["graph"]["dst"]))
+    l.cugraph_edgelist_free(el)
+    res = C.c_void_p()
+    assert_success(l.cugraph_degrees(hp, gb.c_graph_ptr, None, 0, C.byref(res), C.byref(err)), err, "degrees")
+    dv = copy_to_torch(hp, l.cugraph_degrees_result_get_vertices(res))
+    do = copy_to_torch(hp, l.cugraph_degrees_result_get_out_degrees(res))
+    outd = np.zeros(6, np.int64)
+    outd[back(dv)] = do.cpu().numpy()
+    assert outd.tolist() == np.bincount(bc["graph"]["src"], minlength=6).tolist()
+    l.cugraph_degrees_result_free(res)
