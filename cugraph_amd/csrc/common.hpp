@@ -382,6 +382,8 @@ void renumber_ext_to_int(handle_t const& h, graph_t const& g, int32_t* ids, int6
 // internal -> external (in place); negative ids stay as they are
 void unrenumber_int_to_ext(handle_t const& h, graph_t const& g, int32_t* ids, int64_t n);
 int64_t count_negative_i32(handle_t const& h, int32_t const* ids, int64_t n);
+int64_t count_negative_f32(handle_t const& h, float const* v, int64_t n);
+int64_t count_negative_f64(handle_t const& h, double const* v, int64_t n);
 
 // INT64 / sparse external ids at the C-API boundary (outer_ids.hip)
 void outer_collect(handle_t const& h, device_array_view_t const* const* cols, int ncols, dvec<int64_t>& ext);

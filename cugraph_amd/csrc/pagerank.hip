@@ -1232,10 +1232,27 @@ void check_pair_types(graph_t const& g, device_array_view_t const* v, device_arr
 pagerank_plan_base* make_plan(cugraph_resource_handle_t const* handle, cugraph_graph_t* graph,
                               cugraph_type_erased_device_array_view_t const* ow_v, cugraph_type_erased_device_array_view_t const* ow_s,
                               cugraph_type_erased_device_array_view_t const* ig_v, cugraph_type_erased_device_array_view_t const* ig_s,
-                              cugraph_type_erased_device_array_view_t const* p_v, cugraph_type_erased_device_array_view_t const* p_s, double alpha)
+                              cugraph_type_erased_device_array_view_t const* p_v, cugraph_type_erased_device_array_view_t const* p_s, double alpha,
+                              bool do_expensive_check = false)
 {
   handle_t const& h = H(handle);
   graph_t& g        = G(graph);
+  // pagerank_impl.cuh:78-88
+  CGA_EXPECTS(alpha >= 0.0 && alpha <= 1.0, CUGRAPH_INVALID_INPUT, "Invalid input argument: alpha should be in [0.0, 1.0].");
+  CGA_EXPECTS(p_v == nullptr || V(p_v)->size > 0, CUGRAPH_INVALID_INPUT,
+              "Invalid input argument: if personalizations.has_value() is true, the input personalization vector size should not be 0.");
+  if (do_expensive_check) {  // pagerank_impl.cuh:90-117
+    auto negatives = [&](device_array_view_t const* v) -> int64_t {
+      if (v == nullptr || v->size == 0) return 0;
+      return v->type == FLOAT64 ? count_negative_f64(h, v->as<double const>(), (int64_t)v->size) : count_negative_f32(h, v->as<float const>(), (int64_t)v->size);
+    };
+    CGA_EXPECTS(negatives(V(ow_s)) == 0, CUGRAPH_INVALID_INPUT, "Invalid input argument: outgoing edge weight sum values should be non-negative.");
+    if (g.has_weights && g.ne > 0) {
+      orientation_t const& o = g.csc.built ? g.csc : g.csr;
+      device_array_view_t wv{o.weights.ptr, (size_t)g.ne, g.weight_type};
+      CGA_EXPECTS(negatives(&wv) == 0, CUGRAPH_INVALID_INPUT, "Invalid input argument: input edge weights should have non-negative values.");
+    }
+  }
   // messages as cpp/src/c_api/pagerank.cpp:260-296
   check_pair_types(g, V(ow_v), V(ow_s), "vertex type of graph and precomputed_vertex_out_weight_vertices must match",
                    "vertex type of graph and precomputed_vertex_out_weight_sums must match");
@@ -1264,13 +1281,14 @@ cugraph_error_code_t run_pagerank(cugraph_resource_handle_t const* handle, cugra
                                   cugraph_type_erased_device_array_view_t const* ig_v, cugraph_type_erased_device_array_view_t const* ig_s,
                                   cugraph_type_erased_device_array_view_t const* p_v, cugraph_type_erased_device_array_view_t const* p_s, double alpha,
                                   double epsilon, size_t max_iterations, bool must_converge, cugraph_centrality_result_t** result,
-                                  cugraph_error_t** error)
+                                  cugraph_error_t** error, bool do_expensive_check = false)
 {
   if (result) *result = nullptr;
   bool converged = false;
   cugraph_error_code_t rc = guarded(error, [&] {
     CGA_EXPECTS(result != nullptr, CUGRAPH_INVALID_INPUT, "result is NULL");
-    std::unique_ptr<pagerank_plan_base> plan(make_plan(handle, graph, ow_v, ow_s, ig_v, ig_s, p_v, p_s, alpha));
+    CGA_EXPECTS(epsilon >= 0.0, CUGRAPH_INVALID_INPUT, "Invalid input argument: epsilon should be non-negative.");  // pagerank_impl.cuh:88
+    std::unique_ptr<pagerank_plan_base> plan(make_plan(handle, graph, ow_v, ow_s, ig_v, ig_s, p_v, p_s, alpha, do_expensive_check));
     size_t done = 0;
     // pagerank_impl.cuh:224-329: the loop body runs at least once; `converged` = iter < max_iterations
     plan->step(epsilon, max_iterations > 0 ? max_iterations : 1, &done, &converged);
@@ -1290,34 +1308,36 @@ cugraph_error_code_t run_pagerank(cugraph_resource_handle_t const* handle, cugra
 using namespace cga;
 
 extern "C" cugraph_error_code_t cugraph_pagerank(CUGRAPH_PAGERANK_COMMON_ARGS, double alpha, double epsilon, size_t max_iterations,
-                                                 bool_t, cugraph_centrality_result_t** result, cugraph_error_t** error)
+                                                 bool_t do_expensive_check, cugraph_centrality_result_t** result, cugraph_error_t** error)
 {
   return run_pagerank(handle, graph, precomputed_vertex_out_weight_vertices, precomputed_vertex_out_weight_sums, initial_guess_vertices,
-                      initial_guess_values, nullptr, nullptr, alpha, epsilon, max_iterations, true, result, error);
+                      initial_guess_values, nullptr, nullptr, alpha, epsilon, max_iterations, true, result, error, do_expensive_check == TRUE);
 }
 extern "C" cugraph_error_code_t cugraph_pagerank_allow_nonconvergence(CUGRAPH_PAGERANK_COMMON_ARGS, double alpha, double epsilon,
-                                                                      size_t max_iterations, bool_t, cugraph_centrality_result_t** result,
+                                                                      size_t max_iterations, bool_t do_expensive_check, cugraph_centrality_result_t** result,
                                                                       cugraph_error_t** error)
 {
   return run_pagerank(handle, graph, precomputed_vertex_out_weight_vertices, precomputed_vertex_out_weight_sums, initial_guess_vertices,
-                      initial_guess_values, nullptr, nullptr, alpha, epsilon, max_iterations, false, result, error);
+                      initial_guess_values, nullptr, nullptr, alpha, epsilon, max_iterations, false, result, error, do_expensive_check == TRUE);
 }
 extern "C" cugraph_error_code_t cugraph_personalized_pagerank(CUGRAPH_PAGERANK_COMMON_ARGS,
                                                               const cugraph_type_erased_device_array_view_t* personalization_vertices,
                                                               const cugraph_type_erased_device_array_view_t* personalization_values, double alpha,
-                                                              double epsilon, size_t max_iterations, bool_t, cugraph_centrality_result_t** result,
+                                                              double epsilon, size_t max_iterations, bool_t do_expensive_check, cugraph_centrality_result_t** result,
                                                               cugraph_error_t** error)
 {
   return run_pagerank(handle, graph, precomputed_vertex_out_weight_vertices, precomputed_vertex_out_weight_sums, initial_guess_vertices,
-                      initial_guess_values, personalization_vertices, personalization_values, alpha, epsilon, max_iterations, true, result, error);
+                      initial_guess_values, personalization_vertices, personalization_values, alpha, epsilon, max_iterations, true, result, error,
+                      do_expensive_check == TRUE);
 }
 extern "C" cugraph_error_code_t cugraph_personalized_pagerank_allow_nonconvergence(
   CUGRAPH_PAGERANK_COMMON_ARGS, const cugraph_type_erased_device_array_view_t* personalization_vertices,
-  const cugraph_type_erased_device_array_view_t* personalization_values, double alpha, double epsilon, size_t max_iterations, bool_t,
-  cugraph_centrality_result_t** result, cugraph_error_t** error)
+  const cugraph_type_erased_device_array_view_t* personalization_values, double alpha, double epsilon, size_t max_iterations,
+  bool_t do_expensive_check, cugraph_centrality_result_t** result, cugraph_error_t** error)
 {
   return run_pagerank(handle, graph, precomputed_vertex_out_weight_vertices, precomputed_vertex_out_weight_sums, initial_guess_vertices,
-                      initial_guess_values, personalization_vertices, personalization_values, alpha, epsilon, max_iterations, false, result, error);
+                      initial_guess_values, personalization_vertices, personalization_values, alpha, epsilon, max_iterations, false, result, error,
+                      do_expensive_check == TRUE);
 }
 
 // ---- result accessors (cpp/src/c_api/centrality_result.cpp) -------------------------------------

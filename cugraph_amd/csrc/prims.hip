@@ -374,4 +374,29 @@ void gather_b64(handle_t const& h, uint64_t const* src, uint32_t const* idx, uin
   if (n > 0) hipLaunchKernelGGL(k_gather<uint64_t>, grid_for(n, kBlock, 8192), kBlock, 0, h.stream, src, idx, out, n);
 }
 
+namespace {
+template <typename T>
+__global__ void k_count_negative_fp(T const* v, int64_t n, unsigned long long* out)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned c = 0;
+  for (; i < n; i += stride) c += v[i] < T(0);
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+template <typename T>
+int64_t count_negative_fp(handle_t const& h, T const* v, int64_t n)
+{
+  if (n <= 0) return 0;
+  dvec<unsigned long long> c(1);
+  HIP_TRY(hipMemsetAsync(c.data(), 0, 8, h.stream));
+  hipLaunchKernelGGL(k_count_negative_fp<T>, grid_for(n, kBlock, 4096), kBlock, 0, h.stream, v, n, c.data());
+  unsigned long long r = 0;
+  h.read_back(&r, c.data(), 1);
+  return (int64_t)r;
+}
+}  // namespace
+int64_t count_negative_f32(handle_t const& h, float const* v, int64_t n) { return count_negative_fp<float>(h, v, n); }
+int64_t count_negative_f64(handle_t const& h, double const* v, int64_t n) { return count_negative_fp<double>(h, v, n); }
+
 }  // namespace cga

@@ -53,9 +53,41 @@ def _count_owners(owner: torch.Tensor, world: int) -> torch.Tensor:
     return torch.stack([(owner == r).sum() for r in range(world)]).to(torch.int64)
 
 
+_A2A_MAX_BYTES = 1 << 30  # per message and round
+
+
 def _a2a(t, send_counts, recv_counts, group):
+    """all-to-all-v of a 1-D tensor.  Messages are cut into rounds of at most 1 GiB: a single 8.6 GB message (RMAT-26 edge
+    list, one rank) came back truncated from all_to_all_single on ROCm 7 / torch 2.10 -- the one-rank 'exchange' then produced a
+    graph with 20 % fewer distinct sources, silently.  One rank needs no collective at all."""
+    world = len(send_counts)
+    if world == 1:
+        return t.clone()
     out = torch.empty(int(sum(recv_counts)), dtype=t.dtype, device=t.device)
-    dist.all_to_all_single(out, t, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=group)
+    lim = max(1, _A2A_MAX_BYTES // t.element_size())
+    biggest = max(max(send_counts), max(recv_counts), 0)
+    # every rank must run the same number of rounds: agree on the largest message anywhere
+    big_t = torch.tensor([biggest], dtype=torch.int64, device=t.device if dist.get_backend(group) != "gloo" else "cpu")
+    dist.all_reduce(big_t, op=dist.ReduceOp.MAX, group=group)
+    rounds = max(1, -(-int(big_t.item()) // lim))
+    if rounds == 1:
+        dist.all_to_all_single(out, t, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=group)
+        return out
+    s_off = [0] * world
+    r_off = [0] * world
+    for p in range(1, world):
+        s_off[p] = s_off[p - 1] + send_counts[p - 1]
+        r_off[p] = r_off[p - 1] + recv_counts[p - 1]
+    for k in range(rounds):
+        sc = [max(0, min(lim, send_counts[p] - k * lim)) for p in range(world)]
+        rc = [max(0, min(lim, recv_counts[p] - k * lim)) for p in range(world)]
+        send = torch.cat([t[s_off[p] + k * lim: s_off[p] + k * lim + sc[p]] for p in range(world)]) if sum(sc) else t[:0]
+        recv = torch.empty(int(sum(rc)), dtype=t.dtype, device=t.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc, group=group)
+        at = 0
+        for p in range(world):
+            out[r_off[p] + k * lim: r_off[p] + k * lim + rc[p]] = recv[at: at + rc[p]]
+            at += rc[p]
     return out
 
 
@@ -357,6 +389,20 @@ def bench_main(args):
     n2, ms2 = eh.kernel_timing_get("pagerank_reduce")
     eh.kernel_timing(False)
     kernel_s = (ms1 / max(n1, 1) + ms2 / max(n2, 1)) / 1e3
+    # phase split of an iteration (3 extra untimed iterations with a synchronisation after every phase; max over ranks):
+    # exchange = the sparse all-to-all of x, scalars = folding the P message tails, local = unpack + phase 1 + phase 2 + pack
+    split = torch.zeros(3, dtype=torch.float64)
+    for _ in range(3):
+        for k, fn in enumerate((pr._exchange, lambda: pr.engine.reduce_scalars(False), pr.engine.local_step)):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            split[k] += (time.perf_counter() - t1) / 3
+        pr.iterations += 1
+    split = split if single else split.cuda()
+    dist.all_reduce(split, op=dist.ReduceOp.MAX)
+    split = split.cpu().tolist()
     local_bytes = 4 * pr.num_local_edges + 16 * pr.part.n_rows + 4  # this rank's share of 4E + 16V + 4
     out = None
     if rank == 0:
@@ -370,6 +416,8 @@ def bench_main(args):
                        "vertices": nv, "edges": ne, "parallelism": f"{world} GPUs, 1 process per GPU"},
             "iters_per_sec": round(args.steps / dt, 2), "graph_build_s": round(build_s, 3), "local_edges_rank0": pr.num_local_edges,
             "exchange_rank0": {"columns": pr.ex.ncols, "recv_bytes_per_iteration": pr.ex.recv_elems * 4, "send_bytes_per_iteration": pr.ex.send_elems * 4},
+            "phase_split_ms": {"exchange": round(split[0] * 1e3, 4), "reduce_scalars": round(split[1] * 1e3, 4), "local_step": round(split[2] * 1e3, 4),
+                               "note": "each phase bracketed by synchronisations (no overlap), max over ranks, mean of 3 iterations"},
             "roofline": {"bound": "hbm", "achieved": round(local_bytes / kernel_s / 1e9, 1) if kernel_s > 0 else None, "peak": 8000.0, "unit": "GB/s",
                          "frac": round(local_bytes / kernel_s / 1e9 / 8000.0, 4) if kernel_s > 0 else None, "traffic": None,
                          "kernel": "k_tiled_phase1 + k_tiled_phase2 on rank 0 (per-GPU share of the algorithmic bytes / its kernel time)",

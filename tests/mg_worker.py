@@ -87,6 +87,8 @@ def main():
     per = (ne + world - 1) // world
     s, d = orc.rmat(scale, min(per, ne - rank * per), first_edge=rank * per)
     weighted = mode.endswith("w")
+    if mode.endswith("_rounds"):  # exercise the multi-round path of mg._a2a: every message of more than 64 bytes is cut
+        mg._A2A_MAX_BYTES = 64
     w = None
     if weighted:
         w = torch.from_numpy(np.random.default_rng(1).integers(1, 9, size=ne).astype(np.float32)[rank * per: rank * per + s.size].copy())

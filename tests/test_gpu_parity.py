@@ -1096,3 +1096,89 @@ def test_goldens_with_int64_and_sparse_ids(cg, handle, golden, kind):
     outd[back(dv)] = do.cpu().numpy()
     assert outd.tolist() == np.bincount(bc["graph"]["src"], minlength=6).tolist()
     l.cugraph_degrees_result_free(res)
+
+
+def test_pagerank_argument_checks(cg, handle):
+    """pagerank_impl.cuh:78-117: alpha in [0, 1], epsilon >= 0, a personalization vector must not be empty; with
+    do_expensive_check negative edge weights / out-weight sums are rejected."""
+    g = make_graph(cg, handle, [0, 1, 2], [1, 2, 0], [1.0, -2.0, 1.0], transposed=True)
+    with pytest.raises(ValueError, match="alpha should be in"):
+        cg.pagerank(handle, g, None, None, None, None, 1.5, 1e-6, 10, False)
+    with pytest.raises(ValueError, match="epsilon should be non-negative"):
+        cg.pagerank(handle, g, None, None, None, None, 0.85, -1.0, 10, False)
+    with pytest.raises(ValueError, match="personalization vector size should not be 0"):
+        cg.personalized_pagerank(handle, g, None, None, None, None, T([], np.int32), T([], np.float32), 0.85, 1e-6, 10, False)
+    with pytest.raises(ValueError, match="edge weights should have non-negative values"):
+        cg.pagerank(handle, g, None, None, None, None, 0.85, 1e-6, 10, True)
+    g2 = make_graph(cg, handle, [0, 1, 2], [1, 2, 0], [1.0, 2.0, 1.0], transposed=True)
+    with pytest.raises(ValueError, match="outgoing edge weight sum values should be non-negative"):
+        cg.pagerank(handle, g2, T([0, 1, 2], np.int32), T([1.0, -1.0, 1.0], np.float32), None, None, 0.85, 1e-6, 10, True)
+    cg.pagerank(handle, g2, None, None, None, None, 0.85, 1e-6, 100, True)  # clean input passes the expensive checks
+
+
+def _decompress(cg, handle, g):
+    import ctypes as C
+
+    from cugraph_amd import _capi
+    from cugraph_amd.pylib import assert_success, copy_to_torch
+
+    l, hp, err, el = _capi.lib(), handle.c_resource_handle_ptr, C.c_void_p(), C.c_void_p()
+    assert_success(l.cugraph_decompress_to_edgelist(hp, g.c_graph_ptr, 0, C.byref(el), C.byref(err)), err, "decompress")
+    s = copy_to_torch(hp, l.cugraph_edgelist_get_sources(el)).cpu().numpy()
+    d = copy_to_torch(hp, l.cugraph_edgelist_get_destinations(el)).cpu().numpy()
+    wv = l.cugraph_edgelist_get_edge_weights(el)
+    w = copy_to_torch(hp, wv).cpu().numpy() if wv else None
+    l.cugraph_edgelist_free(el)
+    return s, d, w
+
+
+def test_graph_creation_flags_vs_networkx(cg, handle):
+    """Second opinion for the creation flags (graph_sg.cpp:185-248), independent of this repo's numpy restatement: the edge list
+    that comes back from cugraph_decompress_to_edgelist must be what NetworkX makes of the same input --
+    drop_self_loops: the input minus its loops; drop_multi_edges: one edge per (src, dst) with the MINIMUM weight
+    (remove_multi_edges keep_min_value_edge, as the C API passes it); symmetrize (simple input): the edge set of
+    nx.Graph(G) in both directions, weights of one-directional edges kept, reciprocal pairs averaged."""
+    nx = pytest.importorskip("networkx")
+    rng = np.random.default_rng(11)
+    nv, ne = 200, 3000
+    s = rng.integers(0, nv, ne).astype(np.int32)
+    d = rng.integers(0, nv, ne).astype(np.int32)
+    d[:100] = s[:100]
+    w = rng.integers(1, 50, ne).astype(np.float32)
+    verts = T(np.arange(nv), np.int32)
+    # drop_self_loops
+    g = cg.SGGraph(handle, cg.GraphProperties(is_multigraph=True), T(s), T(d), T(w), renumber=True, vertices_array=verts, drop_self_loops=True)
+    gs, gd, gw = _decompress(cg, handle, g)
+    keep = s != d
+    assert sorted(zip(gs.tolist(), gd.tolist(), gw.tolist())) == sorted(zip(s[keep].tolist(), d[keep].tolist(), w[keep].tolist()))
+    # drop_multi_edges: NetworkX DiGraph keeps one edge per pair; feed it the minimum weight per pair
+    g = cg.SGGraph(handle, cg.GraphProperties(is_multigraph=False), T(s), T(d), T(w), renumber=True, vertices_array=verts, drop_multi_edges=True)
+    gs, gd, gw = _decompress(cg, handle, g)
+    G = nx.DiGraph()
+    for a, b, c in zip(s.tolist(), d.tolist(), w.tolist()):
+        if not G.has_edge(a, b) or G[a][b]["weight"] > c:
+            G.add_edge(a, b, weight=c)
+    assert sorted(zip(gs.tolist(), gd.tolist(), gw.tolist())) == sorted((a, b, dd["weight"]) for a, b, dd in G.edges(data=True))
+    # symmetrize on the simple graph (no multi-edges): undirected closure
+    es = np.array([e[0] for e in G.edges()], np.int32)
+    ed = np.array([e[1] for e in G.edges()], np.int32)
+    ew = np.array([G[a][b]["weight"] for a, b in G.edges()], np.float32)
+    g = cg.SGGraph(handle, cg.GraphProperties(is_symmetric=True, is_multigraph=False), T(es), T(ed), T(ew), renumber=True, vertices_array=verts,
+                   symmetrize=True)
+    gs, gd, gw = _decompress(cg, handle, g)
+    U = nx.Graph(G)  # undirected closure; self-loops stay single
+    want = {}
+    for a, b in U.edges():
+        fw = G[a][b]["weight"] if G.has_edge(a, b) else None
+        bw = G[b][a]["weight"] if G.has_edge(b, a) else None
+        wt = (fw + bw) / 2 if (fw is not None and bw is not None and a != b) else (fw if fw is not None else bw)
+        want[(a, b)] = wt
+        want[(b, a)] = wt
+    got = {(a, b): c for a, b, c in zip(gs.tolist(), gd.tolist(), gw.tolist())}
+    assert len(got) == len(gs), "symmetrize must not create duplicate edges on a simple graph"
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert abs(got[k] - v) <= 1e-6 * max(1.0, abs(v)), (k, got[k], v)
+    # and the result is symmetric in NetworkX's eyes too
+    H = nx.DiGraph(); H.add_edges_from(zip(gs.tolist(), gd.tolist()))
+    assert all(H.has_edge(b, a) for a, b in H.edges())

@@ -94,7 +94,24 @@ def test_exchange_plan_is_sparse_and_consistent(tmp_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "oracle"), (4, "oracle"), (2, "oraclew")])
+def test_a2a_rounds_match_one_shot(tmp_path, monkeypatch):
+    """_a2a cuts messages above its per-round limit into rounds (a single multi-GB message came back truncated on the GPU box):
+    with a tiny limit the result must equal the one-shot exchange; one rank needs no collective."""
+    import torch
+    import torch.distributed as dist
+
+    from cugraph_amd import mg
+
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1)
+    try:
+        t = torch.arange(1000, dtype=torch.int64)
+        assert torch.equal(mg._a2a(t, [1000], [1000], None), t)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "oracle"), (4, "oracle"), (8, "oracle"), (2, "oraclew"), (3, "oracle_rounds")])
 def test_mg_pagerank_gloo_cpu(orc, tmp_path, world, mode):
     scale = 10
     pr, iters, conv = run_world(mode, world, scale, tmp_path, eps=0.0, max_iter=12)
