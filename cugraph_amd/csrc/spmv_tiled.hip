@@ -247,6 +247,21 @@ __global__ void k_assign_slots(uint64_t const* keys, uint32_t const* vals, int64
   }
 }
 
+// 8 tile-local destinations (< 4096 each) -> 3 dwords; slot groups of 8 never straddle a region (regions are multiples of 8 slots)
+__global__ void k_pack_dstl12(uint16_t const* d16, int64_t n_groups, uint32_t* out)
+{
+  int64_t g      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; g < n_groups; g += stride) {
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = d16[8 * g + k] & 0xFFFu;
+    out[3 * g]     = v[0] | (v[1] << 12) | (v[2] << 24);
+    out[3 * g + 1] = (v[2] >> 8) | (v[3] << 4) | (v[4] << 16) | (v[5] << 28);
+    out[3 * g + 2] = (v[5] >> 4) | (v[6] << 8) | (v[7] << 20);
+  }
+}
+
 int bits_for_u(uint64_t max_value)
 {
   int b = 0;
@@ -528,6 +543,14 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
                        (uint32_t const*)call.data(), (uint32_t const*)rpos.data(), (uint32_t const*)bidx.data(), (uint32_t const*)gbits.data(), n_waves,
                        t.wrec.data());
     h.sync();
+    if (TP2_ROWS <= 4096 && getenv("CUGRAPH_AMD_TILED_DSTL16") == nullptr) {
+      int64_t const n_groups = (int64_t)(spad + 7) / 8;
+      t.dstl12.resize_discard((size_t)n_groups * 3 + 16);
+      HIP_TRY(hipMemsetAsync(t.dstl12.data(), 0, ((size_t)n_groups * 3 + 16) * sizeof(uint32_t), h.stream));
+      hipLaunchKernelGGL(k_pack_dstl12, grid_for(n_groups - 1, kBlock, 8192), kBlock, 0, h.stream, (uint16_t const*)t.dstl16.data(), n_groups - 1, t.dstl12.data());
+      h.sync();
+      t.dstl16 = dvec<uint16_t>();
+    }
   } else {
     t.n_slots = 0;
     t.dstl16.resize_discard(64);
@@ -1156,6 +1179,7 @@ template <typename WT>
 struct p2_args {
   WT const* part;
   uint16_t const* dstl16;
+  uint32_t const* dstl12;  // non-null: 12-bit packed destinations (see tiled_csc_t)
   uint32_t const* tile_row0;
   uint32_t const* region_off;
   int nI;
@@ -1218,7 +1242,18 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
   for (uint32_t i = tid; i < nrows; i += TP2_BLOCK) acc[i] = ACC(0);
   __syncthreads();
   for (uint32_t s = s0 + 8 * tid; s < s1; s += 8 * TP2_BLOCK) {
-    uint4 const d = *reinterpret_cast<uint4 const*>(a.dstl16 + s);
+    uint32_t idx8[8];
+    if (a.dstl12) {  // wave-uniform: 8 slots = 3 dwords of 12-bit tile-local rows
+      uint32_t const* p12 = a.dstl12 + 3u * (s >> 3);
+      uint32_t const w0 = p12[0], w1 = p12[1], w2 = p12[2];
+      idx8[0] = w0 & 0xFFFu; idx8[1] = (w0 >> 12) & 0xFFFu; idx8[2] = (w0 >> 24) | ((w1 & 0xFu) << 8); idx8[3] = (w1 >> 4) & 0xFFFu;
+      idx8[4] = (w1 >> 16) & 0xFFFu; idx8[5] = (w1 >> 28) | ((w2 & 0xFFu) << 4); idx8[6] = (w2 >> 8) & 0xFFFu; idx8[7] = w2 >> 20;
+    } else {
+      uint4 const d = *reinterpret_cast<uint4 const*>(a.dstl16 + s);
+      uint32_t const w4[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) idx8[k] = (k & 1) ? (w4[k >> 1] >> 16) : (w4[k >> 1] & 0xFFFFu);
+    }
     WT v[8];
     if constexpr (sizeof(WT) == 4) {
       float4 const p0 = *reinterpret_cast<float4 const*>(a.part + s), p1 = *reinterpret_cast<float4 const*>(a.part + s + 4);
@@ -1230,10 +1265,9 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
         v[2 * k] = p.x; v[2 * k + 1] = p.y;
       }
     }
-    uint32_t const w4[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      uint32_t i = (k & 1) ? (w4[k >> 1] >> 16) : (w4[k >> 1] & 0xFFFFu);
+      uint32_t const i = idx8[k];
       if constexpr (sizeof(WT) == 4) atomicAdd(&acc[i], to_fixed(v[k], sc.fx_k));  // ds_add_u64; padding slots hold 0
       else atomicAdd(&acc[i], v[k]);                                              // ds_add_f64
     }
@@ -1350,7 +1384,8 @@ void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled
 {
   p2_args<WT> a;
   a.part       = part;
-  a.dstl16     = t.dstl16.data();
+  a.dstl16     = t.dstl16.size() ? t.dstl16.data() : nullptr;
+  a.dstl12     = t.dstl12.size() ? t.dstl12.data() : nullptr;
   a.tile_row0  = t.tile_row0.data();
   a.region_off = t.region_off.data();
   a.nI         = t.nI;

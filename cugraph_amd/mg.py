@@ -403,6 +403,17 @@ def bench_main(args):
     split = split if single else split.cuda()
     dist.all_reduce(split, op=dist.ReduceOp.MAX)
     split = split.cpu().tolist()
+    # outside the timed region: is the distributed vector still a probability vector, and does every rank hold one value per
+    # owned vertex?  (the kernels are the single-GPU ones, checked against an explicit fp64 step by bench.py at N = 1)
+    _, vals = pr.result()
+    mass = vals.double().sum().reshape(1)
+    rows = torch.tensor([float(vals.numel())], dtype=torch.float64, device=mass.device)
+    mass = mass.cpu() if single else mass
+    rows = rows.cpu() if single else rows
+    dist.all_reduce(mass)
+    dist.all_reduce(rows)
+    check = {"mass_err": abs(float(mass.item()) - 1.0), "rows": int(rows.item()), "ok": abs(float(mass.item()) - 1.0) <= 1e-4 and int(rows.item()) == nv,
+             "what": "sum of the distributed PageRank vector and number of owned rows over all ranks"}
     local_bytes = 4 * pr.num_local_edges + 16 * pr.part.n_rows + 4  # this rank's share of 4E + 16V + 4
     out = None
     if rank == 0:
@@ -416,6 +427,7 @@ def bench_main(args):
                        "vertices": nv, "edges": ne, "parallelism": f"{world} GPUs, 1 process per GPU"},
             "iters_per_sec": round(args.steps / dt, 2), "graph_build_s": round(build_s, 3), "local_edges_rank0": pr.num_local_edges,
             "exchange_rank0": {"columns": pr.ex.ncols, "recv_bytes_per_iteration": pr.ex.recv_elems * 4, "send_bytes_per_iteration": pr.ex.send_elems * 4},
+            "check": check,
             "phase_split_ms": {"exchange": round(split[0] * 1e3, 4), "reduce_scalars": round(split[1] * 1e3, 4), "local_step": round(split[2] * 1e3, 4),
                                "note": "each phase bracketed by synchronisations (no overlap), max over ranks, mean of 3 iterations"},
             "roofline": {"bound": "hbm", "achieved": round(local_bytes / kernel_s / 1e9, 1) if kernel_s > 0 else None, "peak": 8000.0, "unit": "GB/s",
