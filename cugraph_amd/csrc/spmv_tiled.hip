@@ -775,12 +775,24 @@ __device__ __forceinline__ void vm_wait0() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ void vm_fence(uint32_t& r) { asm volatile("" : "+v"(r)); }
 __device__ __forceinline__ void vm_fence(u32x4_t& r) { asm volatile("" : "+v"(r)); }
 #else
+#ifdef CGA_P1_NT_LOAD  // experiment: the edge stream is read once per iteration
+__device__ __forceinline__ void vm_ld128(u32x4_t& d, void const* base, uint32_t off) { d = __builtin_nontemporal_load(reinterpret_cast<u32x4_t const*>(static_cast<char const*>(base) + off)); }
+__device__ __forceinline__ void vm_ld128_o16(u32x4_t& d, void const* base, uint32_t off) { d = __builtin_nontemporal_load(reinterpret_cast<u32x4_t const*>(static_cast<char const*>(base) + off + 16)); }
+#else
 __device__ __forceinline__ void vm_ld128(u32x4_t& d, void const* base, uint32_t off) { d = *reinterpret_cast<u32x4_t const*>(static_cast<char const*>(base) + off); }
 __device__ __forceinline__ void vm_ld128_o16(u32x4_t& d, void const* base, uint32_t off) { d = *reinterpret_cast<u32x4_t const*>(static_cast<char const*>(base) + off + 16); }
+#endif
 __device__ __forceinline__ void vm_ld16u(uint32_t& d, void const* base, uint32_t off) { d = *reinterpret_cast<uint16_t const*>(static_cast<char const*>(base) + off); }
 __device__ __forceinline__ void vm_ld32(uint32_t& d, void const* base, uint32_t off) { d = *reinterpret_cast<uint32_t const*>(static_cast<char const*>(base) + off); }
 template <typename V>
-__device__ __forceinline__ void vm_st(void* base, uint32_t off, V v) { *reinterpret_cast<V*>(static_cast<char*>(base) + off) = v; }
+__device__ __forceinline__ void vm_st(void* base, uint32_t off, V v)
+{
+#ifdef CGA_P1_NT_STORE  // experiment: the partials are not read again by this kernel
+  __builtin_nontemporal_store(v, reinterpret_cast<V*>(static_cast<char*>(base) + off));
+#else
+  *reinterpret_cast<V*>(static_cast<char*>(base) + off) = v;
+#endif
+}
 __device__ __forceinline__ void vm_wait0() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0); lgkmcnt / expcnt untouched
 __device__ __forceinline__ void vm_fence(uint32_t&) {}
 __device__ __forceinline__ void vm_fence(u32x4_t&) {}
@@ -1245,7 +1257,11 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
     uint32_t idx8[8];
     if (a.dstl12) {  // wave-uniform: 8 slots = 3 dwords of 12-bit tile-local rows
       uint32_t const* p12 = a.dstl12 + 3u * (s >> 3);
+#ifndef CGA_P2_PLAIN_LOAD  // streamed once per iteration: non-temporal loads (phase 2 0.457 -> 0.442 ms at RMAT-26)
+      uint32_t const w0 = __builtin_nontemporal_load(p12), w1 = __builtin_nontemporal_load(p12 + 1), w2 = __builtin_nontemporal_load(p12 + 2);
+#else
       uint32_t const w0 = p12[0], w1 = p12[1], w2 = p12[2];
+#endif
       idx8[0] = w0 & 0xFFFu; idx8[1] = (w0 >> 12) & 0xFFFu; idx8[2] = (w0 >> 24) | ((w1 & 0xFu) << 8); idx8[3] = (w1 >> 4) & 0xFFFu;
       idx8[4] = (w1 >> 16) & 0xFFFu; idx8[5] = (w1 >> 28) | ((w2 & 0xFFu) << 4); idx8[6] = (w2 >> 8) & 0xFFFu; idx8[7] = w2 >> 20;
     } else {
@@ -1256,7 +1272,13 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
     }
     WT v[8];
     if constexpr (sizeof(WT) == 4) {
+#ifndef CGA_P2_PLAIN_LOAD
+      typedef float f32x4_t __attribute__((ext_vector_type(4)));
+      f32x4_t const q0 = __builtin_nontemporal_load(reinterpret_cast<f32x4_t const*>(a.part + s)), q1 = __builtin_nontemporal_load(reinterpret_cast<f32x4_t const*>(a.part + s + 4));
+      float4 const p0 = {q0.x, q0.y, q0.z, q0.w}, p1 = {q1.x, q1.y, q1.z, q1.w};
+#else
       float4 const p0 = *reinterpret_cast<float4 const*>(a.part + s), p1 = *reinterpret_cast<float4 const*>(a.part + s + 4);
+#endif
       v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
     } else {
 #pragma unroll
