@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Louvain on a synthetic undirected RMAT graph (BASELINE.json config 5 names RMAT-26 on 8 GPUs -- this is
+the single-GPU timing line for the row).
+
+Graph: RMAT scale S, edge factor F, self-loops and duplicate pairs removed, both directions listed, integer weights 1..8 (so the
+C oracle and the GPU must agree vertex for vertex).  Times cugraph_louvain end to end (all levels), reports edges * sweeps / s,
+the modularity, and -- on a bounded sample -- the C oracle (oracle/oracle.c: orc_louvain, one core) beside it with a parity check.
+Prints one JSON line.  Not the driver's bench (bench.py is).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def undirected_rmat(cg, h, scale, edge_factor, seed=5):
+    """device tensors (src, dst, w) sorted by (src, dst); the same graph tests/test_gpu_parity.py: louvain_rmat_input builds"""
+    import torch
+
+    src, dst = cg.generate_rmat_edgelist(h, scale, edge_factor << scale, seed=seed)
+    s, d = src.to(torch.int64), dst.to(torch.int64)
+    keep = s != d
+    lo, hi = torch.minimum(s[keep], d[keep]), torch.maximum(s[keep], d[keep])
+    key = torch.unique(lo << 32 | hi)
+    lo, hi = key >> 32, key & 0xFFFFFFFF
+    wt = (1 + (lo * 7 + hi * 13) % 8).to(torch.float32)
+    s2, d2, w2 = torch.cat([lo, hi]), torch.cat([hi, lo]), torch.cat([wt, wt])
+    order = torch.argsort(s2 << 32 | d2)
+    return s2[order].to(torch.int32), d2[order].to(torch.int32), w2[order]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=int, default=22)
+    ap.add_argument("--edge-factor", type=int, default=8)
+    ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--cpu-scale", type=int, default=18, help="RMAT scale of the bounded CPU sample (0 = skip)")
+    ap.add_argument("--out", type=str, default=None)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import cugraph_amd as cg
+
+    torch.cuda.set_device(0)
+    h = cg.ResourceHandle()
+
+    def run(scale, repeats):
+        nv = 1 << scale
+        src, dst, w = undirected_rmat(cg, h, scale, args.edge_factor)
+        g = cg.SGGraph(h, cg.GraphProperties(is_symmetric=True), src, dst, w, renumber=False, vertices_array=torch.arange(nv, dtype=torch.int32, device="cuda"))
+        times = []
+        for _ in range(repeats + 1):  # one warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            v, c, q = cg.louvain(h, g, 100, 1e-7, 1.0, False)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        return src, dst, w, v, c, q, times[1:]
+
+    src, dst, w, v, c, q, times = run(args.scale, args.repeats)
+    ne = int(src.numel())
+    best = min(times)
+    out = {
+        "metric": f"louvain_seconds_rmat{args.scale}", "value": round(best, 4), "unit": "s", "higher_is_better": False, "n_gpus": 1,
+        "config": {"workload": f"Louvain (max_level 100, threshold 1e-7, resolution 1), undirected simple RMAT scale {args.scale} edge factor {args.edge_factor}, "
+                               f"integer weights 1..8, both directions stored", "vertices": 1 << args.scale, "directed_edges": ne},
+        "modularity": q, "clusters": int(torch.unique(c).numel()), "seconds_all": [round(t, 4) for t in times],
+        "directed_edges_per_second": round(ne / best, 1), "dtype": "f64", "data": "synthetic",
+    }
+    if args.cpu_scale:
+        from oracle import oracle as orc
+
+        s2, d2, w2, v2, c2, q2, t2 = (src, dst, w, v, c, q, times) if args.cpu_scale == args.scale else run(args.cpu_scale, 1)
+        s_h, d_h, w_h = s2.cpu().numpy(), d2.cpu().numpy(), w2.cpu().numpy()
+        t0 = time.perf_counter()
+        oc, oq, olevels, osweeps = orc.louvain_c(1 << args.cpu_scale, s_h, d_h, w_h, 100, 1e-7, 1.0)
+        cpu_s = time.perf_counter() - t0
+        got = np.empty(1 << args.cpu_scale, np.int64)
+        got[v2.cpu().numpy()] = c2.cpu().numpy()
+        out["cpu_baseline"] = {"value": round(cpu_s, 3), "unit": "s", "cores": 1, "kind": "port",
+                               "sample": f"oracle/oracle.c orc_louvain, RMAT-{args.cpu_scale} (same construction), {olevels} levels, {osweeps} sweeps",
+                               "gpu_seconds_same_graph": round(min(t2), 4)}
+        out["check"] = {"clusters_equal": bool(np.array_equal(got, oc)), "modularity_abs_err": abs(q2 - oq), "ok": bool(np.array_equal(got, oc) and abs(q2 - oq) <= 1e-9)}
+    line = json.dumps(out)
+    print(line, flush=True)
+    if args.out:
+        Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+        Path(args.out).write_text(line + "\n")
+
+
+if __name__ == "__main__":
+    main()

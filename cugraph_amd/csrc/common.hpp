@@ -349,9 +349,11 @@ void minmax_i32(handle_t const& h, int32_t const* p, int64_t n, int32_t* mn, int
 // the caller sized out as n + 1 and passes n + 1 with in[n] = 0).
 void exclusive_scan_u32(handle_t const& h, uint32_t const* in, uint32_t* out, int64_t n);
 // histogram: counts[keys[i]] += 1 (counts pre-zeroed by the caller)
-void histogram_i32(handle_t const& h, int32_t const* keys, int64_t n, uint32_t* counts);
+// `range` (number of counters) lets large inputs take the partitioned path of prims.hip; 0 = unknown / small
+void histogram_i32(handle_t const& h, int32_t const* keys, int64_t n, uint32_t* counts, int64_t range = 0);
 // counts[rank[keys[i] - vmin]] += 1 (rank == nullptr: counts[keys[i]] += 1)
-void histogram_i32_mapped(handle_t const& h, int32_t const* keys, int64_t n, int64_t vmin, uint32_t const* rank, uint32_t* counts);
+void histogram_i32_mapped(handle_t const& h, int32_t const* keys, int64_t n, int64_t vmin, uint32_t const* rank, uint32_t* counts,
+                          int64_t range = 0);
 // stable LSD radix sort of 64-bit keys (only bits [bit_lo, bit_hi) are examined) with a 32-bit payload.
 // keys/vals are sorted in place; tmp buffers of the same size are required.
 void radix_sort_u64_u32(handle_t const& h, uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp,

@@ -59,7 +59,7 @@ void endpoint_degrees(handle_t const& h, graph_t const& g, bool as_source, int32
   } else {
     CGA_EXPECTS(other.built, CUGRAPH_UNKNOWN_ERROR, "graph has no adjacency storage");
     HIP_TRY(hipMemsetAsync(deg, 0, nv * sizeof(int32_t), h.stream));
-    if (g.ne > 0) histogram_i32(h, other.indices.data(), g.ne, reinterpret_cast<uint32_t*>(deg));
+    if (g.ne > 0) histogram_i32(h, other.indices.data(), g.ne, reinterpret_cast<uint32_t*>(deg), g.nv);
   }
 }
 

@@ -16,12 +16,20 @@
 // the two see the same edge order.  All arithmetic is fp64, expressions in the reference's operation order, contraction off.
 // Cluster labels of a contracted level = rank of the old label among the labels in use (the reference's labels are whatever
 // its coarsen_graph renumbering assigns; its two C-API goldens come out identically, labels included).
-// First version: one thread walks one vertex's (sorted) edges, so a hub row is serial -- fine up to ~10^7 edges, not tuned.
+// Scale (round 2): a wavefront owns 64 consecutive vertices -- rows of fewer than 64 edges are walked by their lane, longer rows
+// by the whole wavefront (segmented scan over the sorted (cluster, weight) entries, 64 per step); cluster weights and coarse edge
+// weights are accumulated as 64-bit FIXED POINT with integer atomics (scale 2^s, s chosen from the total edge weight so nothing
+// can overflow): integer addition is associative, so the result does not depend on the order the atomics land in, and for
+// weights that are multiples of 2^-s -- integers, and every fp32 weight of moderate range -- it is exact, i.e. equal to the
+// sequential fp64 sum the oracle forms.  The modularity reductions run over fixed 64 Ki-element chunks + one fixed-order fold.
 #pragma clang fp contract(off)
 #include "common.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "cugraph_c/community_algorithms.h"
@@ -48,129 +56,246 @@ int bits_of_u(uint64_t max_value)
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride_ = (int64_t)gridDim.x * blockDim.x; i < (n); i += stride_)
 
 __global__ void k_expand_src(int32_t const* offsets, int64_t nv, int32_t* src)
-{
-  LV_LOOP(v, nv) for (int32_t p = offsets[v]; p < offsets[v + 1]; ++p) src[p] = (int32_t)v;
+{  // one wavefront per row (long rows are striped across the lanes)
+  int64_t const wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int const lane = threadIdx.x & 63;
+  for (int64_t v = wave; v < nv; v += nwaves) {
+    int32_t const b = offsets[v], e = offsets[v + 1];
+    for (int32_t p = b + lane; p < e; p += 64) src[p] = (int32_t)v;
+  }
 }
 template <typename WT>
 __global__ void k_to_double(WT const* w, int64_t n, double* out) { LV_LOOP(i, n) out[i] = w ? (double)w[i] : 1.0; }
 
-// keys (hi[i] or map_hi[hi[i]]) << 32 | (lo[i] or map_lo[lo[i]]), payload i
-__global__ void k_pair_keys(int32_t const* hi, int32_t const* map_hi, int32_t const* lo, int32_t const* map_lo, int64_t n, uint64_t* keys, uint32_t* vals)
+// keys (hi[i] or map_hi[hi[i]]) << shift | (lo[i] or map_lo[lo[i]]), payload i  (shift = bits of the low part: the significant
+// bits are contiguous and one radix sort over 2 * shift bits orders the pairs)
+__global__ void k_pair_keys(int32_t const* hi, int32_t const* map_hi, int32_t const* lo, int32_t const* map_lo, int64_t n, int shift, uint64_t* keys,
+                            uint32_t* vals)
 {
   LV_LOOP(i, n)
   {
     uint32_t const a = (uint32_t)(map_hi ? map_hi[hi[i]] : hi[i]), b = (uint32_t)(map_lo ? map_lo[lo[i]] : lo[i]);
-    keys[i] = ((uint64_t)a << 32) | b;
+    keys[i] = ((uint64_t)a << shift) | b;
     vals[i] = (uint32_t)i;
   }
 }
-__global__ void k_single_keys(int32_t const* c, int64_t n, uint64_t* keys, uint32_t* vals)
-{
-  LV_LOOP(i, n) { keys[i] = (uint32_t)c[i]; vals[i] = (uint32_t)i; }
-}
 __global__ void k_heads(uint64_t const* keys, int64_t n, uint32_t* head) { LV_LOOP(i, n) head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u; }
 
-// vertex weights: sequential sum of the vertex's edges in stored order (edges are grouped by source)
-__global__ void k_vertex_weights(int32_t const* off, double const* w, int64_t nv, double* k)
+// inclusive segmented scan over the 64 lanes (Hillis-Steele); `head` marks the first element of a segment, `open` tells on
+// return whether the lane's segment started before lane 0 (no head at or below the lane)
+template <typename T>
+__device__ __forceinline__ T seg_scan64(T val, bool head, int lane, bool& open)
 {
-  LV_LOOP(v, nv)
-  {
-    double s = 0.0;
-    for (int32_t p = off[v]; p < off[v + 1]; ++p) s += w[p];
-    k[v] = s;
+  unsigned f = head ? 1u : 0u;
+  for (int o = 1; o < 64; o <<= 1) {
+    T const t         = __shfl_up(val, o);
+    unsigned const tf = __shfl_up(f, o);
+    if (lane >= o && !f) { val += t; f |= tf; }
   }
+  open = f == 0;
+  return val;
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum64(T v)
+{
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
 }
 
-// cluster weights: vertices sorted by cluster (stable); the head of a segment sums its members' weights in vertex order
-__global__ void k_cluster_weights(uint64_t const* keys, uint32_t const* perm, uint32_t const* head, double const* k, int64_t nv, double* a)
-{
-  LV_LOOP(i, nv)
-  {
-    if (!head[i]) continue;
-    double s = 0.0;
-    int64_t j = i;
-    do { s += k[perm[j]]; ++j; } while (j < nv && !head[j]);
-    a[(uint32_t)keys[i]] = s;
-  }
-}
+constexpr int LV_WIDE = 64;  // rows with at least this many edges are walked by the whole wavefront
 
-// One thread per vertex over its edges sorted by (vertex, cluster of destination, stored order):
-// detail::key_aggregated_edge_op_t + reduce_op_t (common_methods.cuh:70-125) after the old_cluster_sum / cluster_subtract pass (:335-362)
-__global__ void k_best_move(int32_t const* off, uint64_t const* keys, uint32_t const* perm, int32_t const* dst, double const* w, int32_t const* c,
-                            double const* k, double const* a, double m, double resolution, int64_t nv, int32_t* best_c, double* best_d)
+// vertex weights k[v] = sum of the vertex's edge weights; kfix = the same in fixed point (for the cluster-weight atomics)
+__global__ void k_vertex_weights(int32_t const* off, double const* w, int64_t nv, double scale, double* k, long long* kfix)
 {
-  LV_LOOP(v, nv)
-  {
-    int32_t const b = off[v], e = off[v + 1];
-    int32_t const cv = c[v];
-    double old_sum = 0.0, sub = 0.0;
-    for (int32_t p = b; p < e; ++p) {
-      uint32_t const ep = perm[p];
-      if (dst[ep] == (int32_t)v) sub += w[ep];
-      else if ((int32_t)(uint32_t)keys[p] == cv) old_sum += w[ep];
+  int const lane       = threadIdx.x & 63;
+  int64_t const wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t const nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t v0 = wave * 64; v0 < nv; v0 += nwaves * 64) {
+    int64_t const v = v0 + lane;
+    int32_t b = 0, e = 0;
+    if (v < nv) { b = off[v]; e = off[v + 1]; }
+    bool const wide = e - b >= LV_WIDE;
+    double s = 0.0;
+    if (!wide) for (int32_t p = b; p < e; ++p) s += w[p];
+    uint64_t todo = __ballot(wide);
+    while (todo) {
+      int const l = __ffsll((unsigned long long)todo) - 1;
+      todo &= todo - 1;
+      int32_t const rb = __shfl(b, l), re = __shfl(e, l);
+      double t = 0.0;
+      for (int32_t p = rb + lane; p < re; p += 64) t += w[p];
+      t = wave_sum64(t);
+      if (lane == l) s = t;
     }
-    double const kk = k[v], a_old = a[cv];
+    if (v < nv) { k[v] = s; kfix[v] = __double2ll_rn(s * scale); }
+  }
+}
+
+// One wavefront per 64 vertices over their edges sorted by (vertex, cluster of destination, stored order):
+// detail::key_aggregated_edge_op_t + reduce_op_t (common_methods.cuh:70-125) after the old_cluster_sum / cluster_subtract pass (:335-362)
+struct lv_move_args {
+  int32_t const* off; uint64_t const* keys; uint32_t const* perm; int32_t const* dst; double const* w; int32_t const* c;
+  double const* k; double const* a; double m, resolution; int64_t nv; int32_t* best_c; double* best_d;
+  uint64_t cmask;  // low bits of a key = cluster of the edge's destination
+};
+__device__ __forceinline__ double lv_delta(double new_sum, double old_sum, double a_new, double a_old, double kk, double m, double resolution)
+{
+  return 2.0 * (((new_sum - old_sum) / m) - resolution * (a_new * kk - a_old * kk + kk * kk) / (m * m));
+}
+__global__ void k_best_move(lv_move_args A)
+{
+  int const lane       = threadIdx.x & 63;
+  int64_t const wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t const nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t v0 = wave * 64; v0 < A.nv; v0 += nwaves * 64) {
+    int64_t const v = v0 + lane;
+    int32_t b = 0, e = 0, cv = -1;
+    double kk = 0.0, a_old = 0.0;
+    if (v < A.nv) { b = A.off[v]; e = A.off[v + 1]; cv = A.c[v]; kk = A.k[v]; a_old = A.a[cv]; }
+    bool const wide = e - b >= LV_WIDE;
     int32_t bc = -1;
     double bd  = 0.0;
-    int32_t p = b;
-    while (p < e) {
-      int32_t const cl = (int32_t)(uint32_t)keys[p];
-      double s = 0.0;
-      do { s += w[perm[p]]; ++p; } while (p < e && (int32_t)(uint32_t)keys[p] == cl);
-      double const new_sum = cl == cv ? s - sub : s;
-      double const a_new   = a[cl];
-      double const delta   = 2.0 * (((new_sum - old_sum) / m) - resolution * (a_new * kk - a_old * kk + kk * kk) / (m * m));
-      if (delta > bd) { bd = delta; bc = cl; }  // clusters ascend: ties keep the smaller id
+    if (!wide && b < e) {
+      double old_sum = 0.0, sub = 0.0;
+      for (int32_t p = b; p < e; ++p) {
+        uint32_t const ep = A.perm[p];
+        if (A.dst[ep] == (int32_t)v) sub += A.w[ep];
+        else if ((int32_t)(A.keys[p] & A.cmask) == cv) old_sum += A.w[ep];
+      }
+      int32_t p = b;
+      while (p < e) {
+        int32_t const cl = (int32_t)(A.keys[p] & A.cmask);
+        double s = 0.0;
+        do { s += A.w[A.perm[p]]; ++p; } while (p < e && (int32_t)(A.keys[p] & A.cmask) == cl);
+        double const new_sum = cl == cv ? s - sub : s;
+        double const delta   = lv_delta(new_sum, old_sum, A.a[cl], a_old, kk, A.m, A.resolution);
+        if (delta > bd) { bd = delta; bc = cl; }  // clusters ascend: ties keep the smaller id
+      }
     }
-    best_c[v] = bc;
-    best_d[v] = bd;
+    uint64_t todo = __ballot(wide);
+    while (todo) {
+      int const l = __ffsll((unsigned long long)todo) - 1;
+      todo &= todo - 1;
+      int32_t const rb = __shfl(b, l), re = __shfl(e, l), rcv = __shfl(cv, l);
+      int32_t const rv = (int32_t)(v0 + l);
+      double const rkk = __shfl(kk, l), ra_old = __shfl(a_old, l);
+      double old_sum = 0.0, sub = 0.0;
+      for (int32_t p = rb + lane; p < re; p += 64) {
+        uint32_t const ep = A.perm[p];
+        double const wv   = A.w[ep];
+        if (A.dst[ep] == rv) sub += wv;
+        else if ((int32_t)(A.keys[p] & A.cmask) == rcv) old_sum += wv;
+      }
+      old_sum = wave_sum64(old_sum);
+      sub     = wave_sum64(sub);
+      int32_t wbc = -1;   // this lane's best over the segments that END in it (clusters ascend from step to step)
+      double wbd  = 0.0;
+      double carry = 0.0;  // sum of the segment that is open at the end of the previous step
+      for (int32_t p0 = rb; p0 < re; p0 += 64) {
+        int32_t const p  = p0 + lane;
+        bool const valid = p < re;
+        int32_t cl = -1, cl_prev = -2, cl_next = -3;
+        double wv = 0.0;
+        if (valid) {
+          cl = (int32_t)(A.keys[p] & A.cmask);
+          wv = A.w[A.perm[p]];
+          if (p > rb) cl_prev = (int32_t)(A.keys[p - 1] & A.cmask);
+          if (p + 1 < re) cl_next = (int32_t)(A.keys[p + 1] & A.cmask);
+        }
+        bool const head = valid && cl != cl_prev;
+        bool open;
+        double sum = seg_scan64(wv, head || !valid, lane, open);
+        if (open) sum += carry;
+        bool const end = valid && cl != cl_next;
+        if (end) {
+          double const new_sum = cl == rcv ? sum - sub : sum;
+          double const delta   = lv_delta(new_sum, old_sum, A.a[cl], ra_old, rkk, A.m, A.resolution);
+          if (delta > wbd) { wbd = delta; wbc = cl; }
+        }
+        int const last = (re - p0 < 64 ? re - p0 : 64) - 1;  // last valid lane of the step
+        carry = __shfl(sum, last);
+      }
+      for (int o = 32; o > 0; o >>= 1) {  // largest gain, ties to the smaller cluster id
+        double const od  = __shfl_xor(wbd, o);
+        int32_t const oc = __shfl_xor(wbc, o);
+        if (oc >= 0 && (od > wbd || (od == wbd && (wbc < 0 || oc < wbc)))) { wbd = od; wbc = oc; }
+      }
+      if (lane == l) { bd = wbd; bc = wbc; }
+    }
+    if (v < A.nv) { A.best_c[v] = bc; A.best_d[v] = bd; }
   }
 }
 
-__global__ void k_count_moves(int32_t const* c, int32_t const* best_c, double const* best_d, double min_gain, int up_down, int64_t nv, uint32_t* count)
+// moves wanted in each direction: count[0] = "down" (best_c < c), count[1] = "up"
+__global__ void k_count_moves(int32_t const* c, int32_t const* best_c, double const* best_d, double min_gain, int64_t nv, uint32_t* count)
 {
   LV_LOOP(v, nv)
   {
-    bool const move = best_d[v] > min_gain && ((best_c[v] > c[v]) == (up_down != 0));
-    uint64_t const mm = __ballot(move);
-    if ((threadIdx.x & 63) == (unsigned)(__ffsll((unsigned long long)mm) - 1) && mm) atomicAdd(count, (uint32_t)__popcll(mm));
+    bool const want = best_d[v] > min_gain;
+    bool const up   = want && best_c[v] > c[v];
+    bool const down = want && !(best_c[v] > c[v]);
+    uint64_t const mu = __ballot(up), md = __ballot(down);
+    int const lane = threadIdx.x & 63;
+    if (mu && lane == __ffsll((unsigned long long)mu) - 1) atomicAdd(count + 1, (uint32_t)__popcll(mu));
+    if (md && lane == __ffsll((unsigned long long)md) - 1) atomicAdd(count + 0, (uint32_t)__popcll(md));
   }
 }
-__global__ void k_apply_moves(int32_t* c, int32_t const* best_c, double const* best_d, double min_gain, int up_down, int64_t nv)
+// the move, and the two cluster weights it changes (fixed point: exact, order-free)
+__global__ void k_apply_moves(int32_t* c, int32_t const* best_c, double const* best_d, double min_gain, int up_down, int64_t nv,
+                              long long const* kfix, unsigned long long* afix)
 {
-  LV_LOOP(v, nv) if (best_d[v] > min_gain && ((best_c[v] > c[v]) == (up_down != 0))) c[v] = best_c[v];
+  LV_LOOP(v, nv)
+  {
+    if (best_d[v] > min_gain && ((best_c[v] > c[v]) == (up_down != 0))) {
+      unsigned long long const kv = (unsigned long long)kfix[v];
+      atomicAdd(&afix[best_c[v]], kv);
+      atomicAdd(&afix[c[v]], 0ull - kv);
+      c[v] = best_c[v];
+    }
+  }
+}
+__global__ void k_fix_to_double(unsigned long long const* fix, int64_t n, double inv_scale, double* out)
+{
+  LV_LOOP(i, n) out[i] = (double)(long long)fix[i] * inv_scale;
 }
 
-// fixed-order reductions (one workgroup): sum of w over intra-cluster edges; sum of squares
-__global__ void __launch_bounds__(1024) k_sum_internal(int32_t const* src, int32_t const* dst, double const* w, int32_t const* c, int64_t ne, double* out)
+// fixed-order reductions: every workgroup folds one 64 Ki-element chunk (thread-strided, then a tree), one workgroup folds the
+// chunk sums in index order -- the result does not depend on the launch geometry
+constexpr int64_t LV_RCHUNK = 65536;
+__device__ __forceinline__ void lv_block_fold(double s, double* out)
 {
   __shared__ double red[1024];
-  double s = 0.0;
-  for (int64_t i = threadIdx.x; i < ne; i += 1024) s += c[src[i]] == c[dst[i]] ? w[i] : 0.0;
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) *out = red[0];
 }
-__global__ void __launch_bounds__(1024) k_sum_squares(double const* a, int64_t n, double* out)
+__global__ void __launch_bounds__(1024) k_part_internal(int32_t const* src, int32_t const* dst, double const* w, int32_t const* c, int64_t ne, double* part)
 {
-  __shared__ double red[1024];
+  int64_t const b = (int64_t)blockIdx.x * LV_RCHUNK, e = b + LV_RCHUNK < ne ? b + LV_RCHUNK : ne;
   double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) s += a[i] * a[i];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-  if (threadIdx.x == 0) *out = red[0];
+  for (int64_t i = b + threadIdx.x; i < e; i += 1024) s += c[src[i]] == c[dst[i]] ? w[i] : 0.0;
+  lv_block_fold(s, part + blockIdx.x);
 }
-__global__ void __launch_bounds__(1024) k_sum_all(double const* w, int64_t n, double* out)
+__global__ void __launch_bounds__(1024) k_part_squares(double const* a, int64_t n, double* part)
 {
-  __shared__ double red[1024];
+  int64_t const b = (int64_t)blockIdx.x * LV_RCHUNK, e = b + LV_RCHUNK < n ? b + LV_RCHUNK : n;
   double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) s += w[i];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-  if (threadIdx.x == 0) *out = red[0];
+  for (int64_t i = b + threadIdx.x; i < e; i += 1024) s += a[i] * a[i];
+  lv_block_fold(s, part + blockIdx.x);
+}
+__global__ void __launch_bounds__(1024) k_part_sum(double const* w, int64_t n, double* part)
+{
+  int64_t const b = (int64_t)blockIdx.x * LV_RCHUNK, e = b + LV_RCHUNK < n ? b + LV_RCHUNK : n;
+  double s = 0.0;
+  for (int64_t i = b + threadIdx.x; i < e; i += 1024) s += w[i];
+  lv_block_fold(s, part + blockIdx.x);
+}
+__global__ void __launch_bounds__(1024) k_fold_parts(double const* part, int64_t n, double* out)
+{
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s += part[i];
+  lv_block_fold(s, out);
 }
 
 __global__ void k_mark_labels(int32_t const* c, int64_t nv, uint32_t* used) { LV_LOOP(v, nv) used[c[v]] = 1u; }
@@ -178,21 +303,32 @@ __global__ void k_relabel(int32_t* c, uint32_t const* rank, int64_t nv) { LV_LOO
 __global__ void k_compose(int32_t* part, int32_t const* c, int64_t n) { LV_LOOP(i, n) part[i] = c[part[i]]; }
 __global__ void k_copy_i32(int32_t* dst, int32_t const* src, int64_t n) { LV_LOOP(i, n) dst[i] = src[i]; }
 
-// contraction: edges sorted by (cluster of src, cluster of dst); the head of a segment emits one coarse edge whose weight is
-// the sequential sum of the segment
+// contraction: edges sorted by (cluster of src, cluster of dst); segment number = pos[i] (exclusive scan of the heads).  The head
+// of a segment emits the coarse edge's endpoints; the weights are summed in fixed point: a wavefront reduces its 64 sorted
+// entries by segment and adds one value per (wavefront, segment) with an integer atomic
 __global__ void k_coarse_edges(uint64_t const* keys, uint32_t const* perm, uint32_t const* head, uint32_t const* pos, double const* w, int64_t ne,
-                               int32_t* csrc, int32_t* cdst, double* cw)
+                               int shift,
+                               double scale, int32_t* csrc, int32_t* cdst, unsigned long long* cwfix)
 {
-  LV_LOOP(i, ne)
-  {
-    if (!head[i]) continue;
-    double s = 0.0;
-    int64_t j = i;
-    do { s += w[perm[j]]; ++j; } while (j < ne && !head[j]);
-    uint32_t const o = pos[i];
-    csrc[o] = (int32_t)(keys[i] >> 32);
-    cdst[o] = (int32_t)(uint32_t)keys[i];
-    cw[o]   = s;
+  int const lane       = threadIdx.x & 63;
+  int64_t const wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t const nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i0 = wave * 64; i0 < ne; i0 += nwaves * 64) {
+    int64_t const i  = i0 + lane;
+    bool const valid = i < ne;
+    uint32_t seg = 0;
+    long long wf = 0;
+    bool hd = true;
+    if (valid) {
+      seg = pos[i];
+      hd  = head[i] != 0;
+      wf  = __double2ll_rn(w[perm[i]] * scale);
+      if (hd) { csrc[seg] = (int32_t)(keys[i] >> shift); cdst[seg] = (int32_t)(keys[i] & ((1ull << shift) - 1ull)); }
+    }
+    bool open;
+    long long const sum = seg_scan64(wf, hd || lane == 0, lane, open);
+    bool const end = valid && (i + 1 >= ne || lane == 63 || head[i + 1] != 0);
+    if (end) atomicAdd(&cwfix[seg], (unsigned long long)sum);
   }
 }
 
@@ -207,45 +343,65 @@ void build_offsets(handle_t const& h, level_t& L)
   L.off.resize_discard((size_t)L.nv + 1);
   dvec<uint32_t> cnt((size_t)L.nv + 1);
   HIP_TRY(hipMemsetAsync(cnt.data(), 0, ((size_t)L.nv + 1) * sizeof(uint32_t), h.stream));
-  if (L.ne > 0) histogram_i32(h, L.src.data(), L.ne, cnt.data());
+  if (L.ne > 0) histogram_i32(h, L.src.data(), L.ne, cnt.data(), L.nv);
   exclusive_scan_u32(h, cnt.data(), reinterpret_cast<uint32_t*>(L.off.data()), L.nv + 1);
 }
 
-void sort_pairs(handle_t const& h, dvec<uint64_t>& keys, dvec<uint32_t>& vals, int64_t n, int bits_hi, int bits_lo)
+void sort_pairs(handle_t const& h, dvec<uint64_t>& keys, dvec<uint32_t>& vals, int64_t n, int bits)
 {
   if (n <= 1) return;
   dvec<uint64_t> kt((size_t)n);
   dvec<uint32_t> vt((size_t)n);
-  radix_sort_u64_u32(h, keys.data(), vals.data(), kt.data(), vt.data(), n, 0, bits_lo);
-  if (bits_hi > 0) radix_sort_u64_u32(h, keys.data(), vals.data(), kt.data(), vt.data(), n, 32, 32 + bits_hi);
+  radix_sort_u64_u32(h, keys.data(), vals.data(), kt.data(), vt.data(), n, 0, bits);
 }
 
-double read_double(handle_t const& h, double const* p)
+// fixed-order sum of n values produced chunk-wise by `launch_parts(parts)`
+template <typename F>
+void chunked_sum(handle_t const& h, int64_t n, dvec<double>& parts, double* out, F&& launch_parts)
 {
-  double v = 0;
-  h.read_back(&v, p, 1);
-  return v;
+  int64_t const np = std::max<int64_t>(1, (n + LV_RCHUNK - 1) / LV_RCHUNK);
+  if (parts.size() < (size_t)np) parts.resize_discard((size_t)np);
+  if (n > 0) launch_parts((int)np, parts.data());
+  else HIP_TRY(hipMemsetAsync(parts.data(), 0, sizeof(double), h.stream));
+  hipLaunchKernelGGL(k_fold_parts, 1, 1024, 0, h.stream, (double const*)parts.data(), np, out);
 }
+
+// fixed-point scale 2^s for sums bounded by the total edge weight m: |sum| * 2^s < 2^61
+double fixed_scale(double m)
+{
+  int e = 0;
+  (void)std::frexp(m > 1.0 ? m : 1.0, &e);  // m < 2^e
+  return std::ldexp(1.0, 61 - e);
+}
+
+struct louvain_stats_t { int sweeps{0}; };
 
 // one level (the body of the while loop of detail::louvain, louvain_impl.cuh:78-262): accepted clustering and its modularity
-double run_level(handle_t const& h, level_t const& L, double m, double threshold, double resolution, dvec<int32_t>& accepted)
+double run_level(handle_t const& h, level_t const& L, double m, double threshold, double resolution, dvec<int32_t>& accepted, louvain_stats_t& st)
 {
   int64_t const nv = L.nv, ne = L.ne;
   int const g_v = grid_for(nv, kBlock, 8192), g_e = grid_for(ne, kBlock, 8192);
-  dvec<double> k((size_t)nv), a((size_t)nv), best_d((size_t)nv), scal(2);
+  int const g_w = grid_for(nv, kBlock, 16384);  // wavefront-per-64-vertices kernels
+  double const scale = fixed_scale(m);
+  dvec<double> k((size_t)nv), a((size_t)nv), best_d((size_t)nv), scal(2), parts;
+  dvec<long long> kfix((size_t)nv);
+  dvec<unsigned long long> afix((size_t)nv);
   dvec<int32_t> c((size_t)nv), best_c((size_t)nv);
-  dvec<uint32_t> count(1), vhead((size_t)nv), vperm((size_t)nv), eperm((size_t)std::max<int64_t>(ne, 1));
-  dvec<uint64_t> vkeys((size_t)nv), ekeys((size_t)std::max<int64_t>(ne, 1));
+  dvec<uint32_t> count(2), eperm((size_t)std::max<int64_t>(ne, 1));
+  dvec<uint64_t> ekeys((size_t)std::max<int64_t>(ne, 1));
   accepted.resize_discard((size_t)nv);
-  hipLaunchKernelGGL(k_vertex_weights, g_v, kBlock, 0, h.stream, (int32_t const*)L.off.data(), (double const*)L.w.data(), nv, k.data());
+  hipLaunchKernelGGL(k_vertex_weights, g_w, kBlock, 0, h.stream, (int32_t const*)L.off.data(), (double const*)L.w.data(), nv, scale, k.data(), kfix.data());
   iota_i32(h, c.data(), nv, 0);
   iota_i32(h, accepted.data(), nv, 0);
-  HIP_TRY(hipMemcpyAsync(a.data(), k.data(), nv * sizeof(double), hipMemcpyDeviceToDevice, h.stream));
+  HIP_TRY(hipMemcpyAsync(afix.data(), kfix.data(), nv * sizeof(long long), hipMemcpyDeviceToDevice, h.stream));
+  hipLaunchKernelGGL(k_fix_to_double, g_v, kBlock, 0, h.stream, (unsigned long long const*)afix.data(), nv, 1.0 / scale, a.data());
   int const vb = bits_of_u((uint64_t)std::max<int64_t>(nv - 1, 1));
   auto modularity = [&]() {  // detail::compute_modularity (common_methods.cuh:176-228)
-    hipLaunchKernelGGL(k_sum_internal, 1, 1024, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.dst.data(), (double const*)L.w.data(),
-                       (int32_t const*)c.data(), ne, scal.data());
-    hipLaunchKernelGGL(k_sum_squares, 1, 1024, 0, h.stream, (double const*)a.data(), nv, scal.data() + 1);
+    chunked_sum(h, ne, parts, scal.data(), [&](int np, double* p) {
+      hipLaunchKernelGGL(k_part_internal, np, 1024, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.dst.data(), (double const*)L.w.data(),
+                         (int32_t const*)c.data(), ne, p);
+    });
+    chunked_sum(h, nv, parts, scal.data() + 1, [&](int np, double* p) { hipLaunchKernelGGL(k_part_squares, np, 1024, 0, h.stream, (double const*)a.data(), nv, p); });
     double s[2];
     h.read_back(s, scal.data(), 2);
     return s[0] / m - (resolution * s[1]) / (m * m);
@@ -256,29 +412,26 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   double const min_gain = std::max(threshold / (double)std::max<int64_t>(nv, 1), 1e-15);  // compute_louvain_min_vertex_move_gain
   while (new_q > cur_q + threshold) {
     cur_q = new_q;
+    ++st.sweeps;
     // update_clustering_by_delta_modularity (common_methods.cuh:259-447)
     if (ne > 0) {
       hipLaunchKernelGGL(k_pair_keys, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)nullptr, (int32_t const*)L.dst.data(),
-                         (int32_t const*)c.data(), ne, ekeys.data(), eperm.data());
-      sort_pairs(h, ekeys, eperm, ne, vb, vb);
+                         (int32_t const*)c.data(), ne, vb, ekeys.data(), eperm.data());
+      sort_pairs(h, ekeys, eperm, ne, 2 * vb);
     }
-    hipLaunchKernelGGL(k_best_move, g_v, kBlock, 0, h.stream, (int32_t const*)L.off.data(), (uint64_t const*)ekeys.data(), (uint32_t const*)eperm.data(),
-                       (int32_t const*)L.dst.data(), (double const*)L.w.data(), (int32_t const*)c.data(), (double const*)k.data(), (double const*)a.data(), m,
-                       resolution, nv, best_c.data(), best_d.data());
-    HIP_TRY(hipMemsetAsync(count.data(), 0, sizeof(uint32_t), h.stream));
+    lv_move_args A{L.off.data(), ekeys.data(), eperm.data(), L.dst.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, nv,
+                   best_c.data(), best_d.data(), (1ull << vb) - 1ull};
+    hipLaunchKernelGGL(k_best_move, g_w, kBlock, 0, h.stream, A);
+    HIP_TRY(hipMemsetAsync(count.data(), 0, 2 * sizeof(uint32_t), h.stream));
     hipLaunchKernelGGL(k_count_moves, g_v, kBlock, 0, h.stream, (int32_t const*)c.data(), (int32_t const*)best_c.data(), (double const*)best_d.data(), min_gain,
-                       up_down ? 1 : 0, nv, count.data());
-    uint32_t nr_moves = 0;
-    h.read_back(&nr_moves, count.data(), 1);
-    if (nr_moves == 0) up_down = !up_down;
-    hipLaunchKernelGGL(k_apply_moves, g_v, kBlock, 0, h.stream, c.data(), (int32_t const*)best_c.data(), (double const*)best_d.data(), min_gain, up_down ? 1 : 0, nv);
-    // compute_cluster_keys_and_values: cluster weights of the new clustering
-    hipLaunchKernelGGL(k_single_keys, g_v, kBlock, 0, h.stream, (int32_t const*)c.data(), nv, vkeys.data(), vperm.data());
-    sort_pairs(h, vkeys, vperm, nv, 0, vb);
-    hipLaunchKernelGGL(k_heads, g_v, kBlock, 0, h.stream, (uint64_t const*)vkeys.data(), nv, vhead.data());
-    HIP_TRY(hipMemsetAsync(a.data(), 0, nv * sizeof(double), h.stream));
-    hipLaunchKernelGGL(k_cluster_weights, g_v, kBlock, 0, h.stream, (uint64_t const*)vkeys.data(), (uint32_t const*)vperm.data(), (uint32_t const*)vhead.data(),
-                       (double const*)k.data(), nv, a.data());
+                       nv, count.data());
+    uint32_t nr_moves[2] = {0, 0};
+    h.read_back(nr_moves, count.data(), 2);
+    if (nr_moves[up_down ? 1 : 0] == 0) up_down = !up_down;
+    // the moves + compute_cluster_keys_and_values: cluster weights of the new clustering
+    hipLaunchKernelGGL(k_apply_moves, g_v, kBlock, 0, h.stream, c.data(), (int32_t const*)best_c.data(), (double const*)best_d.data(), min_gain, up_down ? 1 : 0, nv,
+                       (long long const*)kfix.data(), afix.data());
+    hipLaunchKernelGGL(k_fix_to_double, g_v, kBlock, 0, h.stream, (unsigned long long const*)afix.data(), nv, 1.0 / scale, a.data());
     up_down = !up_down;
     new_q   = modularity();
     if (new_q > cur_q + threshold) HIP_TRY(hipMemcpyAsync(accepted.data(), c.data(), nv * sizeof(int32_t), hipMemcpyDeviceToDevice, h.stream));
@@ -311,16 +464,20 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
     size_t const e1 = (size_t)std::max<int64_t>(L.ne, 1);
     L.src.resize_discard(e1); L.dst.resize_discard(e1); L.w.resize_discard(e1);
     if (L.ne > 0) {
-      hipLaunchKernelGGL(k_expand_src, grid_for(nv0, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)o.offsets.data(), nv0, L.src.data());
+      hipLaunchKernelGGL(k_expand_src, grid_for(nv0 * 16, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)o.offsets.data(), nv0, L.src.data());
       HIP_TRY(hipMemcpyAsync(L.dst.data(), o.indices.data(), L.ne * sizeof(int32_t), hipMemcpyDeviceToDevice, h.stream));
       int const ge = grid_for(L.ne, kBlock, 8192);
       if (!g.has_weights) hipLaunchKernelGGL(k_to_double<float>, ge, kBlock, 0, h.stream, (float const*)nullptr, L.ne, L.w.data());  // constant weight 1 (louvain.cpp:86-92)
       else if (g.weight_type == FLOAT64) hipLaunchKernelGGL(k_to_double<double>, ge, kBlock, 0, h.stream, o.weights.as<double const>(), L.ne, L.w.data());
       else hipLaunchKernelGGL(k_to_double<float>, ge, kBlock, 0, h.stream, o.weights.as<float const>(), L.ne, L.w.data());
     }
-    dvec<double> scal(1);
-    hipLaunchKernelGGL(k_sum_all, 1, 1024, 0, h.stream, (double const*)L.w.data(), L.ne, scal.data());
-    double const m = read_double(h, scal.data());  // compute_total_edge_weight
+    dvec<double> scal(1), parts;
+    chunked_sum(h, L.ne, parts, scal.data(), [&](int np, double* p) { hipLaunchKernelGGL(k_part_sum, np, 1024, 0, h.stream, (double const*)L.w.data(), L.ne, p); });
+    double m = 0.0;  // compute_total_edge_weight
+    h.read_back(&m, (double const*)scal.data(), 1);
+    double const scale = fixed_scale(m);
+    bool const trace = getenv("CUGRAPH_AMD_LOUVAIN_TRACE") != nullptr;
+    auto const t_begin = std::chrono::steady_clock::now();
     auto part      = std::make_unique<device_array_t>((size_t)nv0, g.vertex_type);
     iota_i32(h, part->buf.as<int32_t>(), nv0, 0);
     double best = -1.0;
@@ -329,7 +486,12 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
       ++levels;
       build_offsets(h, L);
       dvec<int32_t> c;
-      double const q = run_level(h, L, m, threshold, resolution, c);
+      louvain_stats_t st;
+      auto const t_level = std::chrono::steady_clock::now();
+      double const q = run_level(h, L, m, threshold, resolution, c, st);
+      if (trace)
+        fprintf(stderr, "[louvain] level %zu: %lld vertices, %lld edges, %d sweeps, Q = %.9f, %.1f ms\n", levels, (long long)L.nv, (long long)L.ne, st.sweeps, q,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_level).count());
       if (q <= best) break;
       best = q;
       // graph_contraction (common_methods.cuh:230-257): dense labels, flattening, coarse edges
@@ -346,10 +508,10 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
       if (L.ne > 0) {
         dvec<uint64_t> keys((size_t)L.ne);
         dvec<uint32_t> perm((size_t)L.ne), head((size_t)L.ne + 1), pos((size_t)L.ne + 1);
-        hipLaunchKernelGGL(k_pair_keys, grid_for(L.ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)c.data(),
-                           (int32_t const*)L.dst.data(), (int32_t const*)c.data(), L.ne, keys.data(), perm.data());
         int const cb = bits_of_u((uint64_t)std::max<int64_t>((int64_t)ncl - 1, 1));
-        sort_pairs(h, keys, perm, L.ne, cb, cb);
+        hipLaunchKernelGGL(k_pair_keys, grid_for(L.ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)c.data(),
+                           (int32_t const*)L.dst.data(), (int32_t const*)c.data(), L.ne, cb, keys.data(), perm.data());
+        sort_pairs(h, keys, perm, L.ne, 2 * cb);
         hipLaunchKernelGGL(k_heads, grid_for(L.ne, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), L.ne, head.data());
         HIP_TRY(hipMemsetAsync(head.data() + L.ne, 0, sizeof(uint32_t), h.stream));
         exclusive_scan_u32(h, head.data(), pos.data(), L.ne + 1);
@@ -358,8 +520,13 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
         N.ne = nce;
         size_t const n1 = (size_t)std::max<uint32_t>(nce, 1);
         N.src.resize_discard(n1); N.dst.resize_discard(n1); N.w.resize_discard(n1);
+        dvec<unsigned long long> cwfix(n1);
+        HIP_TRY(hipMemsetAsync(cwfix.data(), 0, n1 * sizeof(unsigned long long), h.stream));
         hipLaunchKernelGGL(k_coarse_edges, grid_for(L.ne, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)perm.data(),
-                           (uint32_t const*)head.data(), (uint32_t const*)pos.data(), (double const*)L.w.data(), L.ne, N.src.data(), N.dst.data(), N.w.data());
+                           (uint32_t const*)head.data(), (uint32_t const*)pos.data(), (double const*)L.w.data(), L.ne, cb, scale, N.src.data(), N.dst.data(),
+                           cwfix.data());
+        hipLaunchKernelGGL(k_fix_to_double, grid_for((int64_t)n1, kBlock, 8192), kBlock, 0, h.stream, (unsigned long long const*)cwfix.data(), (int64_t)n1,
+                           1.0 / scale, N.w.data());
         h.sync();
       } else {
         N.ne = 0;
@@ -367,6 +534,9 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
       }
       L = std::move(N);
     }
+    if (trace)
+      fprintf(stderr, "[louvain] %zu levels, Q = %.9f, %.1f ms\n", levels, best,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     auto res        = std::make_unique<clustering_result_t>();
     res->modularity = best;
     res->vertices   = new device_array_t((size_t)nv0, g.vertex_type);

@@ -634,7 +634,7 @@ struct pagerank_plan : pagerank_plan_base {
           } else {
             dvec<uint32_t> c(g.nv);
             HIP_TRY(hipMemsetAsync(c.data(), 0, g.nv * 4, h.stream));
-            histogram_i32(h, g.csc.indices.data(), g.ne, c.data());
+            histogram_i32(h, g.csc.indices.data(), g.ne, c.data(), g.nv);
             hipLaunchKernelGGL(k_u32_to_wt<WT>, grid_for(g.nv, kBlock, 4096), kBlock, 0, h.stream, (uint32_t const*)c.data(), g.nv, ow);
             h.sync();
           }

@@ -328,6 +328,153 @@ ORC_SSSP(orc_sssp_f64, double, DBL_MAX)
 ORC_SSSP_MIN_PRED(orc_sssp_min_pred_f32, float, FLT_MAX)
 ORC_SSSP_MIN_PRED(orc_sssp_min_pred_f64, double, DBL_MAX)
 
+/* ------------------------------------------------------------------------------------------------
+ * Louvain, C twin of oracle.py: _louvain_level / louvain for graphs too large for the numpy version.
+ * Follows detail::louvain (cpp/src/community/louvain_impl.cuh:78-262) with rng_state = nullopt: synchronous local moving --
+ * every vertex takes the neighbouring cluster with the largest modularity gain (update_clustering_by_delta_modularity,
+ * detail/common_methods.cuh:259-447; gain expression :70-125), ties to the smaller cluster id, moves only "up" or only "down"
+ * in alternate sweeps -- a modularity test per sweep (compute_modularity, :176-228) and contraction per level
+ * (graph_contraction, :230-257).  Per vertex the weights are accumulated per neighbouring cluster in STORED EDGE ORDER (a
+ * marker array instead of the numpy version's lexsort: same sums in the same order), clusters are then visited in ascending
+ * order.  Edges must be grouped by source (any order inside a source).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int32_t c; double w; } lv_cw;
+static int cmp_lv_cw(const void* x, const void* y) { int32_t a = ((const lv_cw*)x)->c, b = ((const lv_cw*)y)->c; return (a > b) - (a < b); }
+
+static double lv_q(int64_t ne, const int32_t* src, const int32_t* dst, const double* w, const int32_t* c, int64_t nv, const double* a, double m, double res)
+{
+  double internal = 0.0, sq = 0.0;
+  for (int64_t i = 0; i < ne; ++i) if (c[src[i]] == c[dst[i]]) internal += w[i];
+  for (int64_t i = 0; i < nv; ++i) sq += a[i] * a[i];
+  return internal / m - (res * sq) / (m * m);
+}
+
+/* one level: accepted clustering (labels = vertex ids of the level) and the modularity it reached */
+static double lv_level(int64_t nv, int64_t ne, const int32_t* src, const int32_t* dst, const double* w, double threshold, double res, double m,
+                       int32_t* accepted, int* sweeps)
+{
+  int64_t* off = (int64_t*)calloc((size_t)nv + 1, sizeof(int64_t));
+  for (int64_t i = 0; i < ne; ++i) off[src[i] + 1]++;
+  for (int64_t v = 0; v < nv; ++v) off[v + 1] += off[v];
+  double* k = (double*)calloc((size_t)nv, sizeof(double));
+  for (int64_t i = 0; i < ne; ++i) k[src[i]] += w[i];
+  int32_t* c = (int32_t*)malloc(sizeof(int32_t) * (size_t)nv);
+  int32_t* best_c = (int32_t*)malloc(sizeof(int32_t) * (size_t)nv);
+  double* best_d = (double*)malloc(sizeof(double) * (size_t)nv);
+  double* a = (double*)malloc(sizeof(double) * (size_t)nv);
+  int64_t* mark = (int64_t*)malloc(sizeof(int64_t) * (size_t)nv);
+  double* acc = (double*)malloc(sizeof(double) * (size_t)nv);
+  int64_t maxdeg = 0;
+  for (int64_t v = 0; v < nv; ++v) { c[v] = (int32_t)v; accepted[v] = (int32_t)v; a[v] = k[v]; mark[v] = -1; if (off[v + 1] - off[v] > maxdeg) maxdeg = off[v + 1] - off[v]; }
+  lv_cw* lst = (lv_cw*)malloc(sizeof(lv_cw) * (size_t)(maxdeg > 0 ? maxdeg : 1));
+  double new_q = lv_q(ne, src, dst, w, c, nv, a, m, res), cur_q = new_q - 1.0;
+  int up_down = 1;
+  double min_gain = threshold / (double)(nv > 0 ? nv : 1);
+  if (min_gain < 1e-15) min_gain = 1e-15;
+  while (new_q > cur_q + threshold) {
+    cur_q = new_q;
+    ++*sweeps;
+    for (int64_t v = 0; v < nv; ++v) {
+      int32_t cv = c[v];
+      double old_sum = 0.0, sub = 0.0;
+      int64_t n = 0;
+      for (int64_t p = off[v]; p < off[v + 1]; ++p) {
+        int32_t u = dst[p], cl = c[u];
+        if (mark[cl] != v) { mark[cl] = v; acc[cl] = 0.0; lst[n++].c = cl; }
+        acc[cl] += w[p];
+        if (u == (int32_t)v) sub += w[p];
+        else if (cl == cv) old_sum += w[p];
+      }
+      qsort(lst, (size_t)n, sizeof(lv_cw), cmp_lv_cw);
+      int32_t bc = -1;
+      double bd = 0.0, kk = k[v], a_old = a[cv];
+      for (int64_t j = 0; j < n; ++j) {
+        int32_t cl = lst[j].c;
+        double s = acc[cl];
+        double new_sum = cl == cv ? s - sub : s;
+        double delta = 2.0 * (((new_sum - old_sum) / m) - res * (a[cl] * kk - a_old * kk + kk * kk) / (m * m));
+        if (delta > bd) { bd = delta; bc = cl; }
+      }
+      best_c[v] = bc; best_d[v] = bd;
+    }
+    int64_t moves = 0;
+    for (int64_t v = 0; v < nv; ++v) moves += best_d[v] > min_gain && ((best_c[v] > c[v]) == (up_down != 0));
+    if (moves == 0) up_down = !up_down;
+    for (int64_t v = 0; v < nv; ++v) if (best_d[v] > min_gain && ((best_c[v] > c[v]) == (up_down != 0))) c[v] = best_c[v];
+    for (int64_t v = 0; v < nv; ++v) a[v] = 0.0;
+    for (int64_t v = 0; v < nv; ++v) a[c[v]] += k[v];
+    up_down = !up_down;
+    new_q = lv_q(ne, src, dst, w, c, nv, a, m, res);
+    if (new_q > cur_q + threshold) memcpy(accepted, c, sizeof(int32_t) * (size_t)nv);
+  }
+  free(off); free(k); free(c); free(best_c); free(best_d); free(a); free(mark); free(acc); free(lst);
+  return cur_q;
+}
+
+/* returns the number of levels; clusters[nv], *modularity, *total_sweeps */
+int orc_louvain(int64_t nv, int64_t ne, const int32_t* src_in, const int32_t* dst_in, const double* w_in, int64_t max_level, double threshold,
+                double resolution, int32_t* clusters, double* modularity, int* total_sweeps)
+{
+  size_t e1 = (size_t)(ne > 0 ? ne : 1);
+  int32_t* src = (int32_t*)malloc(sizeof(int32_t) * e1);
+  int32_t* dst = (int32_t*)malloc(sizeof(int32_t) * e1);
+  double* w = (double*)malloc(sizeof(double) * e1);
+  double m = 0.0;
+  for (int64_t i = 0; i < ne; ++i) { src[i] = src_in[i]; dst[i] = dst_in[i]; w[i] = w_in ? w_in[i] : 1.0; }
+  for (int64_t i = 0; i < ne; ++i) m += w[i];
+  for (int64_t v = 0; v < nv; ++v) clusters[v] = (int32_t)v;
+  double best = -1.0;
+  int levels = 0;
+  int64_t cur_nv = nv, cur_ne = ne;
+  *total_sweeps = 0;
+  while (levels < max_level && cur_nv > 0 && m > 0.0) {
+    ++levels;
+    int32_t* c = (int32_t*)malloc(sizeof(int32_t) * (size_t)cur_nv);
+    double q = lv_level(cur_nv, cur_ne, src, dst, w, threshold, resolution, m, c, total_sweeps);
+    if (q <= best) { free(c); break; }
+    best = q;
+    /* new id = rank of the label among the labels in use */
+    int32_t* rank = (int32_t*)calloc((size_t)cur_nv + 1, sizeof(int32_t));
+    for (int64_t v = 0; v < cur_nv; ++v) rank[c[v]] = 1;
+    int32_t ncl = 0;
+    for (int64_t v = 0; v < cur_nv; ++v) { int32_t u = rank[v]; rank[v] = ncl; ncl += u; }
+    for (int64_t v = 0; v < cur_nv; ++v) c[v] = rank[c[v]];
+    for (int64_t v = 0; v < nv; ++v) clusters[v] = c[clusters[v]];
+    /* coarse edges: (cs, cd) ascending, weight = sum in stored order.  Stable counting sort by cs, then a marker pass per cs */
+    int64_t* coff = (int64_t*)calloc((size_t)ncl + 1, sizeof(int64_t));
+    for (int64_t i = 0; i < cur_ne; ++i) coff[c[src[i]] + 1]++;
+    for (int32_t v = 0; v < ncl; ++v) coff[v + 1] += coff[v];
+    int64_t* fill = (int64_t*)malloc(sizeof(int64_t) * ((size_t)ncl + 1));
+    memcpy(fill, coff, sizeof(int64_t) * ((size_t)ncl + 1));
+    int32_t* gd = (int32_t*)malloc(sizeof(int32_t) * e1);
+    double* gw = (double*)malloc(sizeof(double) * e1);
+    for (int64_t i = 0; i < cur_ne; ++i) { int64_t p = fill[c[src[i]]]++; gd[p] = c[dst[i]]; gw[p] = w[i]; }
+    int64_t* mark = (int64_t*)malloc(sizeof(int64_t) * (size_t)(ncl > 0 ? ncl : 1));
+    double* acc = (double*)malloc(sizeof(double) * (size_t)(ncl > 0 ? ncl : 1));
+    for (int32_t v = 0; v < ncl; ++v) mark[v] = -1;
+    int64_t maxg = 0;
+    for (int32_t v = 0; v < ncl; ++v) if (coff[v + 1] - coff[v] > maxg) maxg = coff[v + 1] - coff[v];
+    lv_cw* lst = (lv_cw*)malloc(sizeof(lv_cw) * (size_t)(maxg > 0 ? maxg : 1));
+    int64_t out = 0;
+    for (int32_t cs = 0; cs < ncl; ++cs) {
+      int64_t n = 0;
+      for (int64_t p = coff[cs]; p < coff[cs + 1]; ++p) {
+        int32_t cd = gd[p];
+        if (mark[cd] != cs) { mark[cd] = cs; acc[cd] = 0.0; lst[n++].c = cd; }
+        acc[cd] += gw[p];
+      }
+      qsort(lst, (size_t)n, sizeof(lv_cw), cmp_lv_cw);
+      for (int64_t j = 0; j < n; ++j) { src[out] = cs; dst[out] = lst[j].c; w[out] = acc[lst[j].c]; ++out; }  /* out <= cur_ne: in place is safe (reads are in gd/gw) */
+    }
+    cur_ne = out;
+    cur_nv = ncl;
+    free(c); free(rank); free(coff); free(fill); free(gd); free(gw); free(mark); free(acc); free(lst);
+  }
+  *modularity = best;
+  free(src); free(dst); free(w);
+  return levels;
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -393,3 +393,23 @@ def louvain(nv, src, dst, w=None, max_level=100, threshold=1e-7, resolution=1.0)
         w = np.zeros(starts.size)
         np.add.at(w, np.cumsum(head) - 1, ww)
     return part.astype(np.int32), float(best), levels
+
+
+def louvain_c(nv, src, dst, w=None, max_level=100, threshold=1e-7, resolution=1.0):
+    """oracle.c: orc_louvain -- the same algorithm as louvain() above, in C, for graphs beyond the numpy version's reach
+    (tests/test_oracle.py checks the two against each other).  Returns (clusters, modularity, levels, sweeps)."""
+    src, dst = _i32(src), _i32(dst)
+    if src.size and np.any(src[1:] < src[:-1]):  # edges must be grouped by source; a stable sort keeps the order inside a source
+        o = np.argsort(src, kind="stable")
+        src, dst = np.ascontiguousarray(src[o]), np.ascontiguousarray(dst[o])
+        w = None if w is None else np.asarray(w)[o]
+    wd = None if w is None else np.ascontiguousarray(w, np.float64)
+    clusters = np.empty(nv, np.int32)
+    q = C.c_double(0.0)
+    sweeps = C.c_int(0)
+    fn = lib().orc_louvain
+    fn.restype = C.c_int
+    levels = fn(C.c_int64(nv), C.c_int64(src.size), _p(src), _p(dst), None if wd is None else _p(wd), C.c_int64(max_level), C.c_double(threshold),
+                C.c_double(resolution), _p(clusters), C.byref(q), C.byref(sweeps))
+    return clusters, float(q.value), int(levels), int(sweeps.value)
+

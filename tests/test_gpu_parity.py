@@ -755,6 +755,27 @@ def test_degrees_rmat_with_multi_edges(cg, handle, orc):
         assert np.array_equal(dout.cpu().numpy(), np.bincount(s, minlength=nv)[v])
 
 
+def test_degrees_partitioned_histogram(cg, handle, orc, monkeypatch):
+    """the large-input path of histogram_i32_mapped (keys grouped by their top 16 bits, windowed LDS counters; prims.hip) forced on
+    a graph small enough to check: vertex ids spread over a range of 3 * 2^17 so a chunk's window does not cover everything;
+    renumbering by degree (the mapped variant) and cugraph_degrees (the plain variant) both go through it"""
+    monkeypatch.setenv("CUGRAPH_AMD_HISTOGRAM", "partition")
+    scale = 17
+    s, d = rmat_graph(orc, scale)
+    s, d = s.astype(np.int64) * 3 + 5, d.astype(np.int64) * 3 + 5
+    verts = np.arange(1 << scale, dtype=np.int64) * 3 + 5
+    for st in (False, True):
+        g = cg.SGGraph(handle, cg.GraphProperties(is_multigraph=True), T(s, np.int32), T(d, np.int32), store_transposed=st, renumber=True,
+                       vertices_array=T(verts, np.int32))
+        v, din, dout = cg.degrees(handle, g)
+        v = v.cpu().numpy()
+        assert np.array_equal(np.sort(v), verts)
+        assert np.array_equal(din.cpu().numpy(), np.bincount(d, minlength=int(verts[-1]) + 1)[v])
+        assert np.array_equal(dout.cpu().numpy(), np.bincount(s, minlength=int(verts[-1]) + 1)[v])
+        major = din if st else dout  # internal ids descend in the major degree
+        assert np.all(np.diff(major.cpu().numpy().astype(np.int64)) <= 0)
+
+
 @pytest.mark.parametrize("store_transposed", [False, True])
 def test_capi_extract_paths_golden(cg, handle, store_transposed):
     """cpp/tests/c_api/extract_paths_test.c: test_bfs_with_extract_paths(_with_transpose): seeds {0}, destinations {5} ->
@@ -927,6 +948,36 @@ def test_louvain_rmat_vs_oracle(cg, handle, orc, scale, resolution):
     assert abs(q - oq) <= 1e-9
     assert np.array_equal(c, oc)
     assert olevels >= 2 and len(np.unique(c)) < nv // 2
+
+
+def louvain_rmat_input(orc, scale, edge_factor=8, seed=5):
+    """undirected simple RMAT graph with integer weights 1..8 (every sum exact), both directions listed, sorted by (src, dst)"""
+    s, d = orc.rmat(scale, edge_factor << scale, seed=seed)
+    keep = s != d
+    lo, hi = np.minimum(s[keep], d[keep]).astype(np.int64), np.maximum(s[keep], d[keep]).astype(np.int64)
+    key = np.unique(lo << 32 | hi)
+    lo, hi = (key >> 32).astype(np.int32), (key & 0xFFFFFFFF).astype(np.int32)
+    wt = (1 + (lo.astype(np.int64) * 7 + hi.astype(np.int64) * 13) % 8).astype(np.float32)
+    src, dst, w = np.concatenate([lo, hi]), np.concatenate([hi, lo]), np.concatenate([wt, wt])
+    o = np.lexsort((dst, src))
+    return src[o], dst[o], w[o]
+
+
+@pytest.mark.parametrize("scale", [16, 18, 20])
+def test_louvain_scale_vs_oracle(cg, handle, orc, scale):
+    """Louvain beyond toy size (hub rows of 10^4..10^5 edges walked by whole wavefronts, fixed-point cluster / coarse-edge weights,
+    chunked reductions): the clustering equals the C oracle's (oracle.c: orc_louvain, itself checked against the numpy
+    restatement in tests/test_oracle.py) vertex for vertex, the modularity to 1e-9, level for level the same number of sweeps."""
+    src, dst, w = louvain_rmat_input(orc, scale)
+    nv = 1 << scale
+    oc, oq, olevels, _ = orc.louvain_c(nv, src, dst, w, 100, 1e-7, 1.0)
+    g = cg.SGGraph(handle, cg.GraphProperties(is_symmetric=True), T(src, np.int32), T(dst, np.int32), T(w, np.float32), renumber=False,
+                   vertices_array=T(np.arange(nv), np.int32))
+    v, c, q = cg.louvain(handle, g, 100, 1e-7, 1.0, False)
+    (c,) = by_vertex(v, c)
+    assert abs(q - oq) <= 1e-9
+    assert np.array_equal(c, oc)
+    assert abs(q - orc.louvain_modularity(src, dst, w, c, 1.0)) <= 1e-9
 
 
 def test_capi_generators_edge_columns_and_decompress(cg, handle):

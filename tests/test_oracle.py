@@ -240,3 +240,26 @@ def test_louvain_restatement_vs_networkx_modularity(orc):
     ref = nx.community.louvain_communities(g, weight="weight", seed=1)
     assert q >= nx.community.modularity(g, ref, weight="weight") - 0.05
     assert levels >= 2
+
+
+@pytest.mark.parametrize("scale,resolution,real_weights", [(8, 1.0, False), (10, 0.5, False), (10, 1.0, True), (12, 1.0, False)])
+def test_louvain_c_equals_numpy_restatement(orc, scale, resolution, real_weights):
+    """oracle.c: orc_louvain (used for the RMAT-16..20 GPU tests) against oracle.py: louvain (pinned to the C-API goldens above):
+    same clustering, modularity and level count -- with real weights too, because both accumulate in stored edge order."""
+    s, d = orc.rmat(scale, 8 << scale, seed=5)
+    keep = s != d
+    pairs = np.unique(np.stack([np.minimum(s[keep], d[keep]), np.maximum(s[keep], d[keep])], 1), axis=0)
+    if real_weights:
+        wt = (np.random.default_rng(3).random(len(pairs)) + 0.1).astype(np.float32)
+    else:
+        wt = (1 + (pairs[:, 0] * 7 + pairs[:, 1] * 13) % 8).astype(np.float32)
+    src = np.concatenate([pairs[:, 0], pairs[:, 1]]).astype(np.int32)
+    dst = np.concatenate([pairs[:, 1], pairs[:, 0]]).astype(np.int32)
+    w = np.concatenate([wt, wt])
+    o = np.lexsort((dst, src))
+    nv = 1 << scale
+    c1, q1, l1 = orc.louvain(nv, src[o], dst[o], w[o], 100, 1e-7, resolution)
+    c2, q2, l2, sweeps = orc.louvain_c(nv, src[o], dst[o], w[o], 100, 1e-7, resolution)
+    assert np.array_equal(c1, c2) and l1 == l2 and sweeps >= l2
+    assert abs(q1 - q2) <= 1e-12
+
