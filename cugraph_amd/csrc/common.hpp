@@ -16,6 +16,9 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -202,6 +205,31 @@ struct handle_t {  // behind cugraph_resource_handle_t
     HIP_TRY(hipMemcpyAsync(pinned, dev_src, n * sizeof(T), hipMemcpyDeviceToHost, stream));
     sync();
     std::memcpy(host_out, pinned, n * sizeof(T));
+  }
+};
+
+// CUGRAPH_AMD_BUILD_TRACE=1: wall time of the steps of graph / plan construction on stderr (each step ends with a stream
+// sync, so host-side costs -- allocations, read-backs -- are inside the step that incurs them)
+struct build_trace {
+  handle_t const& h;
+  char const* scope;
+  bool on;
+  std::chrono::steady_clock::time_point t0, t;
+  build_trace(handle_t const& h_, char const* scope_) : h(h_), scope(scope_), on(getenv("CUGRAPH_AMD_BUILD_TRACE") != nullptr)
+  {
+    if (on) { h.sync(); t0 = t = std::chrono::steady_clock::now(); }
+  }
+  void step(char const* what)
+  {
+    if (!on) return;
+    h.sync();
+    auto const now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[build] %-12s %-28s %8.2f ms\n", scope, what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+  ~build_trace()
+  {
+    if (on) fprintf(stderr, "[build] %-12s %-28s %8.2f ms\n", scope, "TOTAL", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
 };
 

@@ -198,6 +198,7 @@ int bits_for(uint64_t max_value)
 void build_orientation(handle_t const& h, int64_t nv, int64_t ne, int32_t const* major, int32_t const* minor,
                        void const* weights, size_t wsize, orientation_t& o)
 {
+  build_trace tr(h, "orientation");
   o.offsets.resize_discard(nv + 1);
   o.indices.resize_discard(ne + kEdgePad);
   HIP_TRY(hipMemsetAsync(o.indices.data() + ne, 0, kEdgePad * sizeof(int32_t), h.stream));
@@ -209,7 +210,9 @@ void build_orientation(handle_t const& h, int64_t nv, int64_t ne, int32_t const*
     uint32_t* const vtp = weights ? vals_tmp.data() : nullptr;
     int const vb = bits_for(nv > 0 ? (uint64_t)(nv - 1) : 0);  // <= 31
     hipLaunchKernelGGL(k_pack_keys, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, major, minor, ne, vb, keys.data(), vp);
+    tr.step("pack keys");
     radix_sort_u64_u32(h, keys.data(), vp, keys_tmp.data(), vtp, ne, 0, 2 * vb);
+    tr.step("sort");
     hipLaunchKernelGGL(k_unpack_minor, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), ne, vb,
                        o.indices.data(), o.offsets.data());
     if (weights) {
@@ -220,6 +223,7 @@ void build_orientation(handle_t const& h, int64_t nv, int64_t ne, int32_t const*
     }
     h.sync();  // temporaries die here
   }
+  tr.step("unpack (+ weights)");
 
   // degree-descending row schedule + class boundaries
   dvec<uint32_t> deg(nv > 0 ? nv : 1);
@@ -249,6 +253,7 @@ void build_orientation(handle_t const& h, int64_t nv, int64_t ne, int32_t const*
     HIP_TRY(hipMemcpyAsync(o.row_order.data(), vals.data(), nv * sizeof(int32_t), hipMemcpyDeviceToDevice, h.stream));
     h.sync();
   }
+  tr.step("row schedule");
   for (int k = 0; k < orientation_t::n_seg; ++k) o.seg[k] = (int64_t)seg_h[k];  // counts do not depend on the order
   o.built = true;
   h.sync();
@@ -428,6 +433,7 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
     if (renumber == TRUE) {
       int64_t range = vmax >= vmin ? (int64_t)vmax - vmin + 1 : 0;
       CGA_EXPECTS(range <= ((int64_t)1 << 31) - 2, CUGRAPH_NOT_IMPLEMENTED, "external vertex id range too wide for the dense renumbering table");
+      build_trace tr(h, "renumber");
       dvec<uint32_t> flags(range + 1), rank(range + 1);
       HIP_TRY(hipMemsetAsync(flags.data(), 0, (range + 1) * 4, h.stream));
       uint32_t nv32 = 0;
@@ -448,11 +454,13 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
       }
       int64_t const nv = nv32;
       g->nv            = nv;
+      tr.step("vertex set");
       // major degree per compact id
       dvec<uint32_t> deg(nv > 0 ? nv : 1);
       HIP_TRY(hipMemsetAsync(deg.data(), 0, (nv > 0 ? nv : 1) * 4, h.stream));
       int32_t const* major_ext = store_transposed == TRUE ? d.data() : s.data();
       histogram_i32_mapped(h, major_ext, ne2, (int64_t)vmin, (uint32_t const*)rank.data(), deg.data(), range);
+      tr.step("major degrees");
       int32_t dmin = 0, dmax = 0;
       if (nv > 0) minmax_i32(h, reinterpret_cast<int32_t const*>(deg.data()), nv, &dmin, &dmax);
       dvec<uint64_t> keys(nv > 0 ? nv : 1), keys_tmp(nv > 0 ? nv : 1);
@@ -467,11 +475,13 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
         hipLaunchKernelGGL(k_compact_ext, grid_for(range, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)flags.data(), (uint32_t const*)rank.data(), range, ext_of_compact.data(), (int64_t)vmin);
         hipLaunchKernelGGL(k_number_map, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, (uint32_t const*)order.data(), (int32_t const*)ext_of_compact.data(), nv, g->number_map.data(), int_of_compact.data());
         hipLaunchKernelGGL(k_ext2int, grid_for(range, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)flags.data(), (uint32_t const*)rank.data(), (int32_t const*)int_of_compact.data(), range, g->ext2int.data());
+        tr.step("degree order + maps");
         if (ne2 > 0) {
           hipLaunchKernelGGL(k_lookup, grid_for(ne2, kBlock, 8192), kBlock, 0, h.stream, s.data(), ne2, (int32_t const*)g->ext2int.data(), (int64_t)vmin, range, nv);
           hipLaunchKernelGGL(k_lookup, grid_for(ne2, kBlock, 8192), kBlock, 0, h.stream, d.data(), ne2, (int32_t const*)g->ext2int.data(), (int64_t)vmin, range, nv);
         }
       }
+      tr.step("relabel endpoints");
       h.sync();
     } else {
       // ids are 0..V-1, V = |vertices| or max id + 1 (create_graph_from_edgelist_impl.cuh:1519-1521)

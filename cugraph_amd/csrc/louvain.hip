@@ -16,12 +16,13 @@
 // the two see the same edge order.  All arithmetic is fp64, expressions in the reference's operation order, contraction off.
 // Cluster labels of a contracted level = rank of the old label among the labels in use (the reference's labels are whatever
 // its coarsen_graph renumbering assigns; its two C-API goldens come out identically, labels included).
-// Scale (round 2): a wavefront owns 64 consecutive vertices -- rows of fewer than 64 edges are walked by their lane, longer rows
-// by the whole wavefront (segmented scan over the sorted (cluster, weight) entries, 64 per step); cluster weights and coarse edge
-// weights are accumulated as 64-bit FIXED POINT with integer atomics (scale 2^s, s chosen from the total edge weight so nothing
-// can overflow): integer addition is associative, so the result does not depend on the order the atomics land in, and for
-// weights that are multiples of 2^-s -- integers, and every fp32 weight of moderate range -- it is exact, i.e. equal to the
-// sequential fp64 sum the oracle forms.  The modularity reductions run over fixed 64 Ki-element chunks + one fixed-order fold.
+// Scale (round 2): the per-vertex search for the best move is FLAT over the sorted edges (k_segment_sums / k_segment_best below):
+// no loop over a vertex's row anywhere, so hub rows of 10^5 edges cost what their edges cost.  Segment sums, cluster weights and
+// coarse edge weights are accumulated as 64-bit FIXED POINT with integer atomics (scale 2^s, s chosen from the total edge weight
+// so nothing can overflow): integer addition is associative, so the result does not depend on the order the atomics land in,
+// and for weights that are multiples of 2^-s -- integers, and every fp32 weight of moderate range -- it is exact, i.e. equal to
+// the sequential fp64 sum the oracle forms.  The modularity reductions run over fixed 64 Ki-element chunks + one fixed-order fold.
+// Still one radix sort of all edges per sweep (re-sorting only the rows whose neighbours moved is the next step).
 #pragma clang fp contract(off)
 #include "common.hpp"
 
@@ -131,98 +132,135 @@ __global__ void k_vertex_weights(int32_t const* off, double const* w, int64_t nv
   }
 }
 
-// One wavefront per 64 vertices over their edges sorted by (vertex, cluster of destination, stored order):
-// detail::key_aggregated_edge_op_t + reduce_op_t (common_methods.cuh:70-125) after the old_cluster_sum / cluster_subtract pass (:335-362)
-struct lv_move_args {
-  int32_t const* off; uint64_t const* keys; uint32_t const* perm; int32_t const* dst; double const* w; int32_t const* c;
-  double const* k; double const* a; double m, resolution; int64_t nv; int32_t* best_c; double* best_d;
-  uint64_t cmask;  // low bits of a key = cluster of the edge's destination
+// The best move of every vertex, flat over the edges sorted by (vertex, cluster of destination, stored order) -- no per-row loop,
+// so a hub row costs what its edges cost.  detail::key_aggregated_edge_op_t + reduce_op_t (common_methods.cuh:70-125) after the
+// old_cluster_sum / cluster_subtract pass (:335-362):
+//   k_segment_sums   a wavefront takes 64 consecutive entries; a SEGMENT is a run of equal keys (vertex, cluster).  Segmented scan
+//                    of the fixed-point weights; every piece of a segment that ends in the wavefront is added to segfix[position
+//                    of the segment's first entry] (a plain store when the whole segment lies in the wavefront; the first entry
+//                    of a segment that started in an earlier wavefront is found by a galloping search in the sorted keys).  The
+//                    same pieces feed selffix[v] (weight into the vertex's own cluster) and subfix[v] (self-loops).
+//   k_segment_best<0> at every segment head: the modularity gain of moving the vertex to that cluster; maximum per vertex
+//                    (positive doubles order like their bit patterns: integer atomicMax, reduced per wavefront first)
+//   k_segment_best<1> the smallest cluster id among the segments that attain the maximum (atomicMin)
+struct lv_flat_args {
+  uint64_t const* keys; uint32_t const* perm; int32_t const* dst; double const* w; int32_t const* c;
+  double const* k; double const* a; double m, resolution, scale, inv_scale; int64_t ne; int vb;
+  unsigned long long* segfix;     // [ne], indexed by the position of a segment's first entry; zero on entry
+  unsigned long long* selffix;    // [nv] zero on entry
+  unsigned long long* subfix;     // [nv] zero on entry
+  unsigned long long* best_bits;  // [nv] zero on entry
+  int32_t* best_c;                // [nv] 0x7f7f7f7f on entry
 };
 __device__ __forceinline__ double lv_delta(double new_sum, double old_sum, double a_new, double a_old, double kk, double m, double resolution)
 {
   return 2.0 * (((new_sum - old_sum) / m) - resolution * (a_new * kk - a_old * kk + kk * kk) / (m * m));
 }
-__global__ void k_best_move(lv_move_args A)
+// first position q <= hi with keys[q] == key, given keys[hi] == key (keys ascending)
+__device__ __forceinline__ int64_t lv_first_equal(uint64_t const* keys, uint64_t key, int64_t hi)
+{
+  int64_t lo = hi, step = 64;
+  while (lo - step >= 0 && keys[lo - step] == key) { lo -= step; step <<= 1; }
+  int64_t below = lo - step >= 0 ? lo - step : -1;  // keys[below] != key (or below == -1); keys[lo] == key
+  while (lo - below > 1) {
+    int64_t const mid = below + (lo - below) / 2;
+    if (keys[mid] == key) lo = mid; else below = mid;
+  }
+  return lo;
+}
+__global__ void k_segment_sums(lv_flat_args A)
 {
   int const lane       = threadIdx.x & 63;
   int64_t const wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   int64_t const nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t v0 = wave * 64; v0 < A.nv; v0 += nwaves * 64) {
-    int64_t const v = v0 + lane;
-    int32_t b = 0, e = 0, cv = -1;
-    double kk = 0.0, a_old = 0.0;
-    if (v < A.nv) { b = A.off[v]; e = A.off[v + 1]; cv = A.c[v]; kk = A.k[v]; a_old = A.a[cv]; }
-    bool const wide = e - b >= LV_WIDE;
-    int32_t bc = -1;
-    double bd  = 0.0;
-    if (!wide && b < e) {
-      double old_sum = 0.0, sub = 0.0;
-      for (int32_t p = b; p < e; ++p) {
-        uint32_t const ep = A.perm[p];
-        if (A.dst[ep] == (int32_t)v) sub += A.w[ep];
-        else if ((int32_t)(A.keys[p] & A.cmask) == cv) old_sum += A.w[ep];
-      }
-      int32_t p = b;
-      while (p < e) {
-        int32_t const cl = (int32_t)(A.keys[p] & A.cmask);
-        double s = 0.0;
-        do { s += A.w[A.perm[p]]; ++p; } while (p < e && (int32_t)(A.keys[p] & A.cmask) == cl);
-        double const new_sum = cl == cv ? s - sub : s;
-        double const delta   = lv_delta(new_sum, old_sum, A.a[cl], a_old, kk, A.m, A.resolution);
-        if (delta > bd) { bd = delta; bc = cl; }  // clusters ascend: ties keep the smaller id
-      }
+  uint64_t const cmask = (1ull << A.vb) - 1ull;
+  for (int64_t i0 = wave * 64; i0 < A.ne; i0 += nwaves * 64) {
+    int64_t const p  = i0 + lane;
+    bool const valid = p < A.ne;
+    uint64_t key = ~0ull, prev = ~1ull, next = ~2ull;  // real keys have at most 62 significant bits
+    if (valid) {
+      key = A.keys[p];
+      if (p > 0) prev = A.keys[p - 1];
+      if (p + 1 < A.ne) next = A.keys[p + 1];
     }
-    uint64_t todo = __ballot(wide);
-    while (todo) {
-      int const l = __ffsll((unsigned long long)todo) - 1;
-      todo &= todo - 1;
-      int32_t const rb = __shfl(b, l), re = __shfl(e, l), rcv = __shfl(cv, l);
-      int32_t const rv = (int32_t)(v0 + l);
-      double const rkk = __shfl(kk, l), ra_old = __shfl(a_old, l);
-      double old_sum = 0.0, sub = 0.0;
-      for (int32_t p = rb + lane; p < re; p += 64) {
-        uint32_t const ep = A.perm[p];
-        double const wv   = A.w[ep];
-        if (A.dst[ep] == rv) sub += wv;
-        else if ((int32_t)(A.keys[p] & A.cmask) == rcv) old_sum += wv;
-      }
-      old_sum = wave_sum64(old_sum);
-      sub     = wave_sum64(sub);
-      int32_t wbc = -1;   // this lane's best over the segments that END in it (clusters ascend from step to step)
-      double wbd  = 0.0;
-      double carry = 0.0;  // sum of the segment that is open at the end of the previous step
-      for (int32_t p0 = rb; p0 < re; p0 += 64) {
-        int32_t const p  = p0 + lane;
-        bool const valid = p < re;
-        int32_t cl = -1, cl_prev = -2, cl_next = -3;
-        double wv = 0.0;
-        if (valid) {
-          cl = (int32_t)(A.keys[p] & A.cmask);
-          wv = A.w[A.perm[p]];
-          if (p > rb) cl_prev = (int32_t)(A.keys[p - 1] & A.cmask);
-          if (p + 1 < re) cl_next = (int32_t)(A.keys[p + 1] & A.cmask);
-        }
-        bool const head = valid && cl != cl_prev;
-        bool open;
-        double sum = seg_scan64(wv, head || !valid, lane, open);
-        if (open) sum += carry;
-        bool const end = valid && cl != cl_next;
-        if (end) {
-          double const new_sum = cl == rcv ? sum - sub : sum;
-          double const delta   = lv_delta(new_sum, old_sum, A.a[cl], ra_old, rkk, A.m, A.resolution);
-          if (delta > wbd) { wbd = delta; wbc = cl; }
-        }
-        int const last = (re - p0 < 64 ? re - p0 : 64) - 1;  // last valid lane of the step
-        carry = __shfl(sum, last);
-      }
-      for (int o = 32; o > 0; o >>= 1) {  // largest gain, ties to the smaller cluster id
-        double const od  = __shfl_xor(wbd, o);
-        int32_t const oc = __shfl_xor(wbc, o);
-        if (oc >= 0 && (od > wbd || (od == wbd && (wbc < 0 || oc < wbc)))) { wbd = od; wbc = oc; }
-      }
-      if (lane == l) { bd = wbd; bc = wbc; }
+    bool const head = key != prev;  // (invalid lanes are heads of their own)
+    bool const end  = valid && key != next;
+    int32_t const v  = (int32_t)(key >> A.vb);
+    int32_t const cl = (int32_t)(key & cmask);
+    long long wf = 0;
+    if (valid) {
+      uint32_t const ep = A.perm[p];
+      wf = __double2ll_rn(A.w[ep] * A.scale);
+      if (A.dst[ep] == v) atomicAdd(&A.subfix[v], (unsigned long long)wf);  // self-loop
     }
-    if (v < A.nv) { A.best_c[v] = bc; A.best_d[v] = bd; }
+    bool open;
+    long long const sum = seg_scan64(wf, head || lane == 0, lane, open);
+    int hl = head ? lane : -1;  // lane of the piece's first entry when the segment starts in this wavefront
+    for (int o = 1; o < 64; o <<= 1) {
+      int const t = __shfl_up(hl, o);
+      if (lane >= o && t > hl) hl = t;
+    }
+    if (valid && (end || lane == 63)) {  // a piece of a segment ends here
+      int64_t const hp = hl >= 0 ? i0 + hl : lv_first_equal(A.keys, key, i0 - 1);
+      if (hl >= 0 && end) A.segfix[hp] = (unsigned long long)sum;  // the whole segment lies in this wavefront
+      else atomicAdd(&A.segfix[hp], (unsigned long long)sum);
+      if (cl == A.c[v]) atomicAdd(&A.selffix[v], (unsigned long long)sum);
+    }
+  }
+}
+template <int PHASE>
+__global__ void k_segment_best(lv_flat_args A)
+{
+  int const lane       = threadIdx.x & 63;
+  int64_t const wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t const nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  uint64_t const cmask = (1ull << A.vb) - 1ull;
+  for (int64_t i0 = wave * 64; i0 < A.ne; i0 += nwaves * 64) {
+    int64_t const p  = i0 + lane;
+    bool const valid = p < A.ne;
+    uint64_t key = ~0ull, prev = ~1ull;
+    if (valid) {
+      key = A.keys[p];
+      if (p > 0) prev = A.keys[p - 1];
+    }
+    bool const head  = valid && key != prev;
+    int32_t const v  = valid ? (int32_t)(key >> A.vb) : -1;
+    int32_t const cl = (int32_t)(key & cmask);
+    unsigned long long bits = 0;
+    if (head) {
+      int32_t const cv     = A.c[v];
+      double const s       = (double)(long long)A.segfix[p] * A.inv_scale;
+      double const sub     = (double)(long long)A.subfix[v] * A.inv_scale;
+      double const old_sum = (double)(long long)(A.selffix[v] - A.subfix[v]) * A.inv_scale;
+      double const new_sum = cl == cv ? s - sub : s;
+      double const delta   = lv_delta(new_sum, old_sum, A.a[cl], A.a[cv], A.k[v], A.m, A.resolution);
+      if (delta > 0.0) bits = (unsigned long long)__double_as_longlong(delta);
+    }
+    if (PHASE == 0) {
+      // maximum over the lanes of one vertex (consecutive lanes), then one atomic per (wavefront, vertex)
+      int32_t const vprev = __shfl_up(v, 1), vnext = __shfl_down(v, 1);
+      bool vhead = lane == 0 || v != vprev;
+      unsigned long long mx = bits;
+      unsigned f = vhead ? 1u : 0u;
+      for (int o = 1; o < 64; o <<= 1) {
+        unsigned long long const t = __shfl_up(mx, o);
+        unsigned const tf          = __shfl_up(f, o);
+        if (lane >= o && !f) { mx = t > mx ? t : mx; f |= tf; }
+      }
+      bool const vend = lane == 63 || v != vnext;
+      if (valid && vend && mx) atomicMax(&A.best_bits[v], mx);
+    } else {
+      if (bits && bits == A.best_bits[v]) atomicMin(&A.best_c[v], cl);
+    }
+  }
+}
+__global__ void k_best_finalize(unsigned long long const* best_bits, int32_t* best_c, double* best_d, int64_t nv)
+{
+  LV_LOOP(v, nv)
+  {
+    unsigned long long const b = best_bits[v];
+    best_d[v] = __longlong_as_double((long long)b);
+    if (!b) best_c[v] = -1;
   }
 }
 
@@ -320,8 +358,8 @@ __global__ void k_coarse_edges(uint64_t const* keys, uint32_t const* perm, uint3
     long long wf = 0;
     bool hd = true;
     if (valid) {
-      seg = pos[i];
       hd  = head[i] != 0;
+      seg = pos[i] - (hd ? 0u : 1u);  // pos = exclusive scan of the heads: a segment's later entries already count their own head
       wf  = __double2ll_rn(w[perm[i]] * scale);
       if (hd) { csrc[seg] = (int32_t)(keys[i] >> shift); cdst[seg] = (int32_t)(keys[i] & ((1ull << shift) - 1ull)); }
     }
@@ -385,7 +423,7 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   double const scale = fixed_scale(m);
   dvec<double> k((size_t)nv), a((size_t)nv), best_d((size_t)nv), scal(2), parts;
   dvec<long long> kfix((size_t)nv);
-  dvec<unsigned long long> afix((size_t)nv);
+  dvec<unsigned long long> afix((size_t)nv), vfix((size_t)nv * 3), segfix((size_t)std::max<int64_t>(ne, 1));
   dvec<int32_t> c((size_t)nv), best_c((size_t)nv);
   dvec<uint32_t> count(2), eperm((size_t)std::max<int64_t>(ne, 1));
   dvec<uint64_t> ekeys((size_t)std::max<int64_t>(ne, 1));
@@ -419,9 +457,17 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
                          (int32_t const*)c.data(), ne, vb, ekeys.data(), eperm.data());
       sort_pairs(h, ekeys, eperm, ne, 2 * vb);
     }
-    lv_move_args A{L.off.data(), ekeys.data(), eperm.data(), L.dst.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, nv,
-                   best_c.data(), best_d.data(), (1ull << vb) - 1ull};
-    hipLaunchKernelGGL(k_best_move, g_w, kBlock, 0, h.stream, A);
+    HIP_TRY(hipMemsetAsync(vfix.data(), 0, (size_t)nv * 3 * sizeof(unsigned long long), h.stream));  // selffix, subfix, best_bits
+    HIP_TRY(hipMemsetAsync(best_c.data(), 0x7f, (size_t)nv * sizeof(int32_t), h.stream));
+    if (ne > 0) {
+      HIP_TRY(hipMemsetAsync(segfix.data(), 0, (size_t)ne * sizeof(unsigned long long), h.stream));
+      lv_flat_args A{ekeys.data(), eperm.data(), L.dst.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, ne, vb,
+                     segfix.data(), vfix.data(), vfix.data() + nv, vfix.data() + 2 * nv, best_c.data()};
+      hipLaunchKernelGGL(k_segment_sums, g_e, kBlock, 0, h.stream, A);
+      hipLaunchKernelGGL(k_segment_best<0>, g_e, kBlock, 0, h.stream, A);
+      hipLaunchKernelGGL(k_segment_best<1>, g_e, kBlock, 0, h.stream, A);
+    }
+    hipLaunchKernelGGL(k_best_finalize, g_v, kBlock, 0, h.stream, (unsigned long long const*)(vfix.data() + 2 * nv), best_c.data(), best_d.data(), nv);
     HIP_TRY(hipMemsetAsync(count.data(), 0, 2 * sizeof(uint32_t), h.stream));
     hipLaunchKernelGGL(k_count_moves, g_v, kBlock, 0, h.stream, (int32_t const*)c.data(), (int32_t const*)best_c.data(), (double const*)best_d.data(), min_gain,
                        nv, count.data());

@@ -850,7 +850,10 @@ struct pagerank_plan : pagerank_plan_base {
     int blocks_per_cu = lds_bytes <= 80 * 1024 ? 2 : 1;
     grid            = h.num_cus * blocks_per_cu;
     partials.resize_discard((size_t)2 * std::max(grid, 2048));
+    build_trace tr(h, "plan");
+    tr.step("vectors");
     setup_flat();
+    tr.step("re-blocked structure");
 
     if (ow_s) {
       outw_own.resize_discard(n1);
@@ -859,6 +862,7 @@ struct pagerank_plan : pagerank_plan_base {
     } else {
       compute_out_weight_sums();
     }
+    tr.step("out-weight sums");
     if (ig_s) {
       pairs_to_dense(ig_v, ig_s, pr.data(), WT(0), "initial_guess");  // not renormalised: pagerank_impl.cuh:427-432
     } else {

@@ -193,32 +193,57 @@ constexpr int RS_WAVE_CHUNK = WAVE * RS_PER_WAVE_ITERS;  // 1024 keys per wave
 constexpr int RS_TILE    = RS_WAVE_CHUNK * RS_WAVES;     // 4096 keys per block
 constexpr int RS_BINS    = 256;
 
+// lanes of the wavefront that hold the same digit as this lane (among the valid ones): 8 ballots
+__device__ __forceinline__ uint64_t rs_match_digit(uint32_t d, bool valid)
+{
+  uint64_t peers = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    bool const bit     = (d >> b) & 1u;
+    uint64_t const bal = __ballot(bit);
+    peers &= bit ? bal : ~bal;
+  }
+  return peers;
+}
+
+// Digit counts per tile.  One LDS atomic per (wavefront, distinct digit) instead of one per key: the sort keys of a degree-sorted
+// graph put most of a tile into one or two bins of the high digits, and same-address LDS atomics serialise.
 __global__ void __launch_bounds__(RS_THREADS)
 k_rs_hist(uint64_t const* keys, int64_t n, int shift, uint32_t mask, uint32_t* hist, int nblocks)
 {
   __shared__ uint32_t h[RS_BINS];
   h[threadIdx.x] = 0;
   __syncthreads();
+  int const lane = threadIdx.x & 63;
   int64_t base = (int64_t)blockIdx.x * RS_TILE;
 #pragma unroll 4
   for (int it = 0; it < RS_TILE / RS_THREADS; ++it) {
-    int64_t idx = base + it * RS_THREADS + threadIdx.x;
-    if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & mask], 1u);
+    int64_t idx       = base + it * RS_THREADS + threadIdx.x;
+    bool const valid  = idx < n;
+    uint32_t const d  = valid ? (uint32_t)(keys[idx] >> shift) & mask : 0u;
+    // skewed digit (many lanes share the first lane's): one atomic per distinct digit; flat digit: plain atomics are cheaper
+    uint32_t const d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+    if (__popcll(__ballot(valid && d == d0)) >= 8) {
+      uint64_t const pe = rs_match_digit(d, valid);
+      if (valid && lane == __ffsll((unsigned long long)pe) - 1) atomicAdd(&h[d], (uint32_t)__popcll(pe));
+    } else if (valid) {
+      atomicAdd(&h[d], 1u);
+    }
   }
   __syncthreads();
   hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
 // Stable scatter of one 8-bit digit.  The tile (RS_TILE keys) is first sorted by digit INSIDE LDS -- rank of a key = start
-// of its digit in the tile + keys of that digit in earlier wavefronts + wave-ballot rank -- and then written out in tile
-// order, so consecutive threads write consecutive addresses within each digit's run (16 keys = 128 B on average) instead of
-// one isolated 8-byte store per key (the first version: 1.6 TB/s at RMAT-26).
+// of its digit in the tile + keys of that digit in earlier wavefronts + rank inside its wavefront -- and then written out in
+// tile order, so consecutive threads write consecutive addresses within each digit's run (16 keys = 128 B on average) instead
+// of one isolated 8-byte store per key (the first version: 1.6 TB/s at RMAT-26).  A wavefront's 1024 keys are read ONCE, all
+// 16 loads in flight, and stay in registers; the rank inside the wavefront comes from the ballot match (no per-key LDS atomic).
 __global__ void __launch_bounds__(RS_THREADS)
 k_rs_scatter(uint64_t const* keys_in, uint32_t const* vals_in, uint64_t* keys_out, uint32_t* vals_out,
              int64_t n, int shift, uint32_t mask, uint32_t const* offs, int nblocks)
 {
-  __shared__ uint32_t cnt[RS_WAVES][RS_BINS];
-  __shared__ uint32_t base[RS_WAVES][RS_BINS];   // tile-local position of the next key of (wave, digit)
+  __shared__ uint32_t cnt[RS_WAVES][RS_BINS];    // keys of (wave, digit); after the scan: tile-local position of the first of them
   __shared__ uint32_t lstart[RS_BINS];           // tile-local start of the digit
   __shared__ uint32_t gbase[RS_BINS];            // global start of the digit's run of this tile
   __shared__ uint32_t wsum[RS_WAVES];
@@ -230,9 +255,26 @@ k_rs_scatter(uint64_t const* keys_in, uint32_t const* vals_in, uint64_t* keys_ou
   __syncthreads();
   int64_t const tile0 = (int64_t)blockIdx.x * RS_TILE;
   int64_t const chunk = tile0 + (int64_t)wave * RS_WAVE_CHUNK;
+  uint64_t key[RS_PER_WAVE_ITERS];
+  uint32_t val[RS_PER_WAVE_ITERS];
+  uint32_t dr[RS_PER_WAVE_ITERS];  // digit | rank among the wavefront's keys of that digit << 8
+#pragma unroll
   for (int it = 0; it < RS_PER_WAVE_ITERS; ++it) {
-    int64_t idx = chunk + it * WAVE + lane;
-    if (idx < n) atomicAdd(&cnt[wave][(uint32_t)(keys_in[idx] >> shift) & mask], 1u);
+    int64_t const idx = chunk + it * WAVE + lane;
+    key[it] = idx < n ? keys_in[idx] : 0ull;
+    val[it] = (vals_in && idx < n) ? vals_in[idx] : 0u;
+  }
+  uint64_t const lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  volatile uint32_t* my_cnt = cnt[wave];
+#pragma unroll
+  for (int it = 0; it < RS_PER_WAVE_ITERS; ++it) {
+    bool const valid  = chunk + it * WAVE + lane < n;
+    uint32_t const d  = (uint32_t)(key[it] >> shift) & mask;
+    uint64_t const pe = rs_match_digit(d, valid);
+    uint32_t const before = my_cnt[d];  // every lane reads before the group's first lane writes (LDS operations of a wavefront execute in order)
+    uint32_t const rank   = before + (uint32_t)__popcll(pe & lt_mask);
+    if (valid && (pe & lt_mask) == 0) my_cnt[d] = before + (uint32_t)__popcll(pe);
+    dr[it] = d | (rank << 8);
   }
   __syncthreads();
   {  // thread d: digit d.  Exclusive scan of the digit totals over the workgroup (RS_THREADS == RS_BINS)
@@ -253,41 +295,28 @@ k_rs_scatter(uint64_t const* keys_in, uint32_t const* vals_in, uint64_t* keys_ou
     gbase[threadIdx.x]    = offs[(int64_t)threadIdx.x * nblocks + blockIdx.x];
 #pragma unroll
     for (int w = 0; w < RS_WAVES; ++w) {
-      base[w][threadIdx.x] = run;
-      run += cnt[w][threadIdx.x];
+      uint32_t const c     = cnt[w][threadIdx.x];
+      cnt[w][threadIdx.x]  = run;
+      run += c;
     }
   }
   __syncthreads();
-  uint64_t const lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (int it = 0; it < RS_PER_WAVE_ITERS; ++it) {
-    int64_t idx  = chunk + it * WAVE + lane;
-    bool valid   = idx < n;
-    uint64_t key = valid ? keys_in[idx] : 0ull;
-    uint32_t d   = (uint32_t)(key >> shift) & mask;
-    uint64_t peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      bool bit     = (d >> b) & 1u;
-      uint64_t bal = __ballot(bit);
-      peers &= bit ? bal : ~bal;
-    }
-    uint32_t b0 = base[wave][d];
-    if (valid) {
-      uint32_t rank = __popcll(peers & lt_mask);
-      uint32_t pos  = b0 + rank;
-      skey[pos]     = key;
-      if (vals_in) sval[pos] = vals_in[idx];
-      if (rank == 0) base[wave][d] = b0 + (uint32_t)__popcll(peers);
+  for (int it = 0; it < RS_PER_WAVE_ITERS; ++it) {
+    if (chunk + it * WAVE + lane < n) {
+      uint32_t const pos = cnt[wave][dr[it] & 0xFFu] + (dr[it] >> 8);
+      skey[pos]          = key[it];
+      if (vals_in) sval[pos] = val[it];
     }
   }
   __syncthreads();
   int64_t const left = n - tile0;
   uint32_t const nt  = left < (int64_t)RS_TILE ? (uint32_t)left : (uint32_t)RS_TILE;
   for (uint32_t t = threadIdx.x; t < nt; t += RS_THREADS) {
-    uint64_t const key = skey[t];
-    uint32_t const d   = (uint32_t)(key >> shift) & mask;
-    uint32_t const pos = gbase[d] + (t - lstart[d]);
-    keys_out[pos]      = key;
+    uint64_t const key_t = skey[t];
+    uint32_t const d     = (uint32_t)(key_t >> shift) & mask;
+    uint32_t const pos   = gbase[d] + (t - lstart[d]);
+    keys_out[pos]        = key_t;
     if (vals_in) vals_out[pos] = sval[t];
   }
 }

@@ -336,6 +336,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   size_t const wsize = has_weights ? vsize : 0;
   CGA_EXPECTS(nv < ((int64_t)1 << 31) && ne < ((int64_t)1 << 31), CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: graph too large for 32-bit positions");
   t       = tiled_csc_t{};
+  build_trace tr(h, "tiled");
   dvec<uint32_t> live_rank;  // compact columns: live_rank[r] = number of live sources with an id < r
   t.T     = T;
   t.nv    = n_dst;
@@ -360,6 +361,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   t.nJ    = (int)std::max<int64_t>(1, (t.ncols + T - 1) / T);
   int const nJ = t.nJ;
 
+  tr.step("live columns");
   // ---- edges ordered by (source tile, destination, source): stable sort of the CSC positions by source tile
   dvec<uint64_t> keys, keys_tmp;
   dvec<uint32_t> vals, vals_tmp, rows, flag32, ord, dsts;
@@ -372,6 +374,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     keys_tmp = dvec<uint64_t>(); vals_tmp = dvec<uint32_t>();
     tile_off = key_starts(h, keys.data(), ne, nJ);
   }
+  tr.step("sort by source tile");
   {  // every tile starts on a work-item boundary: item i covers padded positions [i * TP_ITEM, (i + 1) * TP_ITEM)
     uint64_t pos = 0;
     for (int J = 0; J < nJ; ++J) {
@@ -394,6 +397,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   to_device(h, d_tile_off, tile_off);
   to_device(h, d_tile_off_pad, tile_off_pad);
 
+  tr.step("edge arrays");
   // ---- runs
   dvec<uint32_t> run_dst, cnt_dst(n_dst + 1);
   HIP_TRY(hipMemsetAsync(cnt_dst.data(), 0, (n_dst + 1) * sizeof(uint32_t), h.stream));
@@ -425,6 +429,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     dsts = dvec<uint32_t>();
   }
 
+  tr.step("runs");
   // ---- destination tiles: equal cost (6 bytes per partial + 16 bytes per row), at most TP2_ROWS rows
   std::vector<uint32_t> row0;
   {
@@ -466,6 +471,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     live_rank = dvec<uint32_t>();
   }
 
+  tr.step("destination tiles");
   // ---- phase-1 work items (source tile order = hottest tiles first)
   std::vector<int32_t> item_tile;
   std::vector<uint32_t> item_end;  // end of the real edges of the item's tile (padded position)
@@ -484,6 +490,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   t.wrec.resize_discard((size_t)(n_waves > 0 ? n_waves : 1) * TP_REC_DWORDS);
   HIP_TRY(hipMemsetAsync(t.wrec.data(), 0, (size_t)(n_waves > 0 ? n_waves : 1) * TP_REC_DWORDS * sizeof(uint32_t), h.stream));
 
+  tr.step("work items");
   // ---- slots: runs and wave heads ordered by (destination tile, source tile, destination)
   int64_t const n_el = t.n_runs + n_waves;
   std::vector<uint32_t> region_off(t.nI + 2, 0);
@@ -559,6 +566,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   }
   to_device(h, t.region_off, region_off);
 
+  tr.step("slots");
   // ---- phase-1 chunks: up to TP_CHUNK consecutive items of one source tile, handed out dynamically LARGEST FIRST
   // (long chunks keep an LDS tile for many items; the one-item chunks of the cold tiles fill the tail evenly)
   {
@@ -591,6 +599,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     to_device(h, t.chunk_begin, cb);
   }
 
+  tr.step("chunks");
   // ---- bound used by the fixed-point accumulation of phase 2
   t.wmax = (double)csc.max_degree;
   if (has_weights && ne > 0) {

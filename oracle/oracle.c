@@ -18,6 +18,7 @@
 #include <limits.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -378,9 +379,10 @@ static double lv_level(int64_t nv, int64_t ne, const int32_t* src, const int32_t
       int32_t cv = c[v];
       double old_sum = 0.0, sub = 0.0;
       int64_t n = 0;
+      int64_t const stamp = (int64_t)(*sweeps) * nv + v;  /* unique per (sweep, vertex): marks of earlier sweeps must not match */
       for (int64_t p = off[v]; p < off[v + 1]; ++p) {
         int32_t u = dst[p], cl = c[u];
-        if (mark[cl] != v) { mark[cl] = v; acc[cl] = 0.0; lst[n++].c = cl; }
+        if (mark[cl] != stamp) { mark[cl] = stamp; acc[cl] = 0.0; lst[n++].c = cl; }
         acc[cl] += w[p];
         if (u == (int32_t)v) sub += w[p];
         else if (cl == cv) old_sum += w[p];
@@ -405,6 +407,7 @@ static double lv_level(int64_t nv, int64_t ne, const int32_t* src, const int32_t
     for (int64_t v = 0; v < nv; ++v) a[c[v]] += k[v];
     up_down = !up_down;
     new_q = lv_q(ne, src, dst, w, c, nv, a, m, res);
+    if (getenv("ORC_LOUVAIN_TRACE")) fprintf(stderr, "[orc louvain] sweep %d: moves %lld, Q %.17g -> %.17g\n", *sweeps, (long long)moves, cur_q, new_q);
     if (new_q > cur_q + threshold) memcpy(accepted, c, sizeof(int32_t) * (size_t)nv);
   }
   free(off); free(k); free(c); free(best_c); free(best_d); free(a); free(mark); free(acc); free(lst);

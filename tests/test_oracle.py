@@ -242,7 +242,7 @@ def test_louvain_restatement_vs_networkx_modularity(orc):
     assert levels >= 2
 
 
-@pytest.mark.parametrize("scale,resolution,real_weights", [(8, 1.0, False), (10, 0.5, False), (10, 1.0, True), (12, 1.0, False)])
+@pytest.mark.parametrize("scale,resolution,real_weights", [(8, 1.0, False), (10, 0.5, False), (10, 1.0, True), (12, 1.0, False), (14, 1.0, False)])
 def test_louvain_c_equals_numpy_restatement(orc, scale, resolution, real_weights):
     """oracle.c: orc_louvain (used for the RMAT-16..20 GPU tests) against oracle.py: louvain (pinned to the C-API goldens above):
     same clustering, modularity and level count -- with real weights too, because both accumulate in stored edge order."""
