@@ -665,7 +665,7 @@ struct pagerank_plan : pagerank_plan_base {
     tiled = g.ne > 0 && kern != "flat" && kern != "rows";
     if (tiled) {
       int const T = tiled_default_T(h, sizeof(WT), g.nv);
-      if (!o.tiled || o.tiled->T != T) {
+      if (!o.tiled || o.tiled->T != T || getenv("CUGRAPH_AMD_TILED_REBUILD")) {  // (the env: parameter sweeps on one graph, tools/plan_sweep.py)
         auto t = std::make_shared<tiled_csc_t>();
         try {
           build_tiled_csc(h, g.nv, g.nv, g.ne, o, g.has_weights, sizeof(WT), T, *t, getenv("CUGRAPH_AMD_PAGERANK_DENSE_COLUMNS") == nullptr);

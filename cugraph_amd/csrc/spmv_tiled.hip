@@ -581,13 +581,20 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     int const big        = std::max(chunk, env_big ? atoi(env_big) : TP_CHUNK_BIG);
     double const frac    = env_frac ? atof(env_frac) : 0.55;
     int64_t big_budget   = t.n_items / (max_wg * 4) >= TP_CHUNK ? (int64_t)(frac * t.n_items) : 0;
+    // the items of the coldest tiles (the last `tail_frac` of all items; an item there costs about twice a hot one: ten times the
+    // runs and partial stores) go out in short chunks, so the workgroups finish within one short chunk of each other
+    char const* env_tf = getenv("CUGRAPH_AMD_TP_TAIL_FRAC");
+    char const* env_tc = getenv("CUGRAPH_AMD_TP_TAIL_CHUNK");
+    double const tail_frac = env_tf ? atof(env_tf) : TP_TAIL_FRAC;
+    int const tail_chunk   = std::max(1, std::min(chunk, env_tc ? atoi(env_tc) : TP_TAIL_CHUNK));
+    int const tail_first   = t.n_items / (max_wg * 4) >= TP_CHUNK ? (int)((1.0 - tail_frac) * t.n_items) : t.n_items;
     std::vector<std::pair<int32_t, int32_t>> ch;  // (first item, items)
     for (int i = 0; i < t.n_items;) {
       int j = i + 1;
       while (j < t.n_items && item_tile[j] == item_tile[i]) ++j;  // [i, j) = the items of one tile
       int k = i;
       while (big > chunk && big_budget >= big && j - k >= 2 * big) { ch.push_back({k, big}); k += big; big_budget -= big; }
-      while (k < j) { int const n = std::min(chunk, j - k); ch.push_back({k, n}); k += n; }
+      while (k < j) { int const n = std::min(k >= tail_first ? tail_chunk : chunk, j - k); ch.push_back({k, n}); k += n; }
       i = j;
     }
     std::stable_sort(ch.begin(), ch.end(), [](auto const& x, auto const& y) { return x.second > y.second; });

@@ -89,7 +89,7 @@ struct bfs_visit {
     wq.flush();
     unsigned long long a = acc_out, b = acc_in;
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-    if ((threadIdx.x & 63) == 0 && (a | b)) { atomicAdd(&s.cnt->out_edges, a); atomicAdd(&s.cnt->in_edges, b); }
+    if ((threadIdx.x & 63) == 0 && (a | b)) { counter_sums_t* r = cnt_replica(s.cnt); atomicAdd(&r->out_edges, a); atomicAdd(&r->in_edges, b); }
   }
 };
 
@@ -115,7 +115,10 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand_big(int32_t const* bigq
 
 // Bottom-up level.  in_offsets / in_indices = the orientation whose rows are DESTINATIONS (CSC; the CSR itself when the
 // graph is symmetric).  front = frontier bitmap of the current level; next (fully rewritten) = vertices found.
-constexpr int BU_GROUPS     = 4;   // 64-vertex groups a wavefront keeps in flight
+#ifndef CGA_BU_GROUPS
+#define CGA_BU_GROUPS 4
+#endif
+constexpr int BU_GROUPS     = CGA_BU_GROUPS;   // 64-vertex groups a wavefront keeps in flight
 constexpr int BU_CHUNK      = 4;   // independent probes per lane and step (one 16-byte neighbour load)
 constexpr int BU_LANE_MAX   = 64;  // neighbours a lane scans on its own; the rest of a still unsettled row is scanned by the whole wave
 // the next BU_CHUNK neighbour ids of a row as ONE 16-byte load per lane (4-byte aligned: gfx950 global loads take it): a lane's
@@ -131,10 +134,13 @@ __device__ __forceinline__ void bu_load_chunk(int32_t const* indices, int32_t po
   u[0] = left > 0 ? v.x : -1; u[1] = left > 1 ? v.y : -1; u[2] = left > 2 ? v.z : -1; u[3] = left > 3 ? v.w : -1;
 }
 
+template <bool PROF>
 __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_offsets, int32_t const* in_indices, int32_t const* out_offsets,
                                                             int64_t nv, uint32_t* vis, uint32_t const* front, uint32_t* next, int32_t* dist,
-                                                            int32_t* pred, int32_t next_depth, counters_t* cnt)
+                                                            int32_t* pred, int32_t next_depth, counters_t* cnt, unsigned long long* prof)
 {
+  // PROF (CUGRAPH_AMD_BFS_PROFILE): wall ticks per wavefront in the three parts of an iteration, tail steps, long rows and their steps
+  unsigned long long pt[3] = {0, 0, 0}, pn[3] = {0, 0, 0};
   // A level is a chain of dependent memory round trips per 64-vertex group (visited word -> offsets -> neighbour ids -> frontier
   // bits): with one group per wavefront at a time the level was latency-bound (0.9 ms at RMAT-24 whatever the frontier).  So a
   // wavefront walks BU_GROUPS groups at once through the common part -- the first BU_CHUNK neighbours of every unvisited
@@ -146,33 +152,47 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_of
   int64_t const ngroup = (nv + 63) >> 6;
   unsigned long long inspected = 0, acc_out = 0, acc_in = 0;
   uint32_t found_total = 0;
+  int32_t od0[BU_GROUPS], od1[BU_GROUPS];  // out-degree bounds of the vertices discovered in the previous iteration (summed one iteration late)
+#pragma unroll
+  for (int g = 0; g < BU_GROUPS; ++g) { od0[g] = 0; od1[g] = 0; }
   for (int64_t grp0 = gwave * BU_GROUPS; grp0 < ngroup; grp0 += nwaves * BU_GROUPS) {
+    unsigned long long const tk0 = PROF ? wall_clock64() : 0;
     bool unvisited[BU_GROUPS], found[BU_GROUPS], open_row[BU_GROUPS];
     int32_t b[BU_GROUPS], e[BU_GROUPS], parent[BU_GROUPS], scanned[BU_GROUPS];
     int32_t u[BU_GROUPS][BU_CHUNK];
+    uint32_t word[BU_GROUPS];
 #pragma unroll
-    for (int g = 0; g < BU_GROUPS; ++g) {
-      int64_t const grp = grp0 + g, v = grp * 64 + lane;
-      uint32_t const word = grp < ngroup ? vis[(grp * 2) + (lane >> 5)] : 0xFFFFFFFFu;
-      unvisited[g] = v < nv && !((word >> (lane & 31)) & 1u);
+    for (int g = 0; g < BU_GROUPS; ++g) {  // visited words and row bounds are requested together (the bounds of the visited vertices
+      int64_t const grp = grp0 + g, v = grp * 64 + lane;  // too: 64 consecutive offsets are one cheap coalesced load, a dependent step is not)
+      word[g] = grp < ngroup ? vis[(grp * 2) + (lane >> 5)] : 0xFFFFFFFFu;
+      b[g] = 0; e[g] = 0; parent[g] = -1; found[g] = false; scanned[g] = 0;
+      if (v < nv) { b[g] = in_offsets[v]; e[g] = in_offsets[v + 1]; }
     }
 #pragma unroll
     for (int g = 0; g < BU_GROUPS; ++g) {
       int64_t const v = (grp0 + g) * 64 + lane;
-      b[g] = 0; e[g] = 0; parent[g] = -1; found[g] = false; scanned[g] = 0;
-      if (unvisited[g]) { b[g] = in_offsets[v]; e[g] = in_offsets[v + 1]; }
+      unvisited[g] = v < nv && !((word[g] >> (lane & 31)) & 1u);
+      acc_out += (unsigned long long)(od1[g] - od0[g]);  // requested an iteration ago: complete by the time `word` is (loads retire in order)
     }
 #pragma unroll
     for (int g = 0; g < BU_GROUPS; ++g) {
       open_row[g] = unvisited[g] && e[g] > b[g];
+#if defined(CGA_BU_ABL) && CGA_BU_ABL == 2  // timing experiment: no neighbour load either
+      u[g][0] = open_row[g] ? 0 : -1; u[g][1] = u[g][2] = u[g][3] = -1;
+#else
       bu_load_chunk(in_indices, b[g], open_row[g] ? e[g] - b[g] : 0, u[g]);
+#endif
     }
 #pragma unroll
     for (int g = 0; g < BU_GROUPS; ++g) {
       int first = BU_CHUNK;
 #pragma unroll
       for (int k = BU_CHUNK - 1; k >= 0; --k)
+#if defined(CGA_BU_ABL) && CGA_BU_ABL == 1  // timing experiment: no frontier probe (every neighbour "hits")
+        if (u[g][k] >= 0) first = k;
+#else
         if (u[g][k] >= 0 && ((front[u[g][k] >> 5] >> (u[g][k] & 31)) & 1u)) first = k;  // ascending ids: the first hit is the minimum
+#endif
       if (open_row[g]) {
         int32_t const deg = e[g] - b[g];
         if (first < BU_CHUNK) {
@@ -185,40 +205,64 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_of
         }
       }
     }
-    // the rows that are still open: further chunks per lane up to BU_LANE_MAX neighbours, the rest with the whole wavefront
+    // the rows that are still open: further neighbours per lane up to BU_LANE_MAX.  A step is a dependent round trip (neighbour
+    // ids -> frontier bits) whatever the number of lanes still scanning, and in the mid-degree range nearly every group has a
+    // few lanes that scan to the end (vertices that are reached a level later): the BU_GROUPS groups therefore take their steps
+    // TOGETHER, two 16-byte chunks per lane and step -- eight times the requests in flight of a group-by-group walk
+    unsigned long long const tk1 = PROF ? wall_clock64() : 0;
+    for (;;) {
+      if (PROF) ++pn[0];
+      bool act[BU_GROUPS];
+      bool any = false;
 #pragma unroll
-    for (int g = 0; g < BU_GROUPS; ++g) {
-      int64_t const grp = grp0 + g, v = grp * 64 + lane;
-      if (grp >= ngroup) break;  // wave-uniform
-      int32_t const deg = e[g] - b[g];
-      while (__ballot(open_row[g] && scanned[g] < BU_LANE_MAX)) {
-        int32_t w[BU_CHUNK];
-        bu_load_chunk(in_indices, b[g] + scanned[g], open_row[g] ? deg - scanned[g] : 0, w);
-        int first = BU_CHUNK;
+      for (int g = 0; g < BU_GROUPS; ++g) { act[g] = open_row[g] && scanned[g] < BU_LANE_MAX; any |= act[g]; }
+      if (!__ballot(any)) break;
+      int32_t w[BU_GROUPS][2 * BU_CHUNK];
 #pragma unroll
-        for (int k = BU_CHUNK - 1; k >= 0; --k)
-          if (w[k] >= 0 && ((front[w[k] >> 5] >> (w[k] & 31)) & 1u)) first = k;
-        if (open_row[g]) {
-          if (first < BU_CHUNK) {
+      for (int g = 0; g < BU_GROUPS; ++g) {
+        int32_t const left = act[g] ? (e[g] - b[g]) - scanned[g] : 0;
+        int32_t lo[BU_CHUNK], hi[BU_CHUNK];
+        bu_load_chunk(in_indices, b[g] + scanned[g], left, lo);
+        bu_load_chunk(in_indices, b[g] + scanned[g] + BU_CHUNK, left - BU_CHUNK, hi);
 #pragma unroll
-            for (int k = 0; k < BU_CHUNK; ++k) if (k == first) parent[g] = w[k];
+        for (int k = 0; k < BU_CHUNK; ++k) { w[g][k] = lo[k]; w[g][BU_CHUNK + k] = hi[k]; }
+      }
+#pragma unroll
+      for (int g = 0; g < BU_GROUPS; ++g) {
+        int first = 2 * BU_CHUNK;
+#pragma unroll
+        for (int k = 2 * BU_CHUNK - 1; k >= 0; --k)
+          if (w[g][k] >= 0 && ((front[w[g][k] >> 5] >> (w[g][k] & 31)) & 1u)) first = k;
+        if (act[g]) {
+          int32_t const deg = e[g] - b[g];
+          if (first < 2 * BU_CHUNK) {
+#pragma unroll
+            for (int k = 0; k < 2 * BU_CHUNK; ++k) if (k == first) parent[g] = w[g][k];
             found[g] = true; open_row[g] = false; scanned[g] += first + 1;
           } else {
-            scanned[g] = min(deg, scanned[g] + BU_CHUNK);
+            scanned[g] = min(deg, scanned[g] + 2 * BU_CHUNK);
             if (scanned[g] >= deg) open_row[g] = false;
           }
         }
       }
+    }
+    unsigned long long const tk2 = PROF ? wall_clock64() : 0;
+    // rows longer than BU_LANE_MAX with nothing found so far (rare): the wavefront strides the row, 64 neighbours per step, and
+    // stops at the first hit
+#pragma unroll
+    for (int g = 0; g < BU_GROUPS; ++g) {
       inspected += (unsigned long long)scanned[g];
-      uint64_t cm = __ballot(open_row[g]);  // deg > BU_LANE_MAX and nothing found among the first BU_LANE_MAX neighbours
+      uint64_t cm = __ballot(open_row[g]);
       int32_t const rest = b[g] + scanned[g];
-      while (cm) {  // long rows: the wavefront strides the row, 64 neighbours per step, and stops at the first hit
+      while (cm) {
         int src = __ffsll((unsigned long long)cm) - 1;
         cm &= cm - 1;
+        if (PROF) ++pn[1];
         int32_t bb = __shfl(rest, src), ee = __shfl(e[g], src);
         bool hit = false;
         int32_t p = bb, par = -1;
         for (; p < ee && !hit; p += 64) {
+          if (PROF) ++pn[2];
           int32_t q = p + lane, x = -1;
           bool h    = false;
           if (q < ee) { x = in_indices[q]; h = ((front[x >> 5] >> (x & 31)) & 1u) != 0; }
@@ -228,28 +272,46 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_of
         }
         if (lane == src) { found[g] = hit; parent[g] = par; inspected += (unsigned long long)(min(p, ee) - bb); }
       }
+    }
+    // results: nothing below waits for memory (the visited words are still in registers; the out-degrees of the discovered
+    // vertices -- the top-down cost of the next level -- are requested for all groups and summed after the loop)
+#pragma unroll
+    for (int g = 0; g < BU_GROUPS; ++g) {
+      int64_t const v = (grp0 + g) * 64 + lane;
+      od0[g] = 0; od1[g] = 0;
+      if (found[g]) { od0[g] = out_offsets[v]; od1[g] = out_offsets[v + 1]; }
+    }
+#pragma unroll
+    for (int g = 0; g < BU_GROUPS; ++g) {
+      int64_t const grp = grp0 + g, v = grp * 64 + lane;
       uint64_t const fm = __ballot(found[g]);
-      if (lane == 0) {
-        uint32_t lo = (uint32_t)fm, hi = (uint32_t)(fm >> 32);
-        next[grp * 2]     = lo;
-        next[grp * 2 + 1] = hi;
-        if (lo) vis[grp * 2] |= lo;       // this wavefront is the only writer of these two words
-        if (hi) vis[grp * 2 + 1] |= hi;
+      if (grp < ngroup && (lane & 31) == 0) {  // lanes 0 and 32 hold the two visited words of the group; this wavefront is their only writer
+        uint32_t const bits = lane ? (uint32_t)(fm >> 32) : (uint32_t)fm;
+        next[grp * 2 + (lane >> 5)] = bits;
+        if (bits) vis[grp * 2 + (lane >> 5)] = word[g] | bits;
       }
       if (found[g]) {
         dist[v] = next_depth;
         if (pred) pred[v] = parent[g];
-        acc_out += (unsigned long long)(out_offsets[v + 1] - out_offsets[v]);
-        acc_in += (unsigned long long)deg;
+        acc_in += (unsigned long long)(e[g] - b[g]);
       }
       found_total += (uint32_t)__popcll(fm);
     }
+    if (PROF) { unsigned long long const tk3 = wall_clock64(); pt[0] += tk1 - tk0; pt[1] += tk2 - tk1; pt[2] += tk3 - tk2; }
   }
+  if (PROF && lane == 0) {
+    for (int k = 0; k < 3; ++k) { atomicAdd(prof + k, pt[k]); atomicAdd(prof + 3 + k, pn[k]); }
+    atomicMax(prof + 6, pt[0] + pt[1] + pt[2]);
+    atomicMax(prof + 7, pt[2]);
+  }
+#pragma unroll
+  for (int g = 0; g < BU_GROUPS; ++g) acc_out += (unsigned long long)(od1[g] - od0[g]);
   for (int o = 32; o > 0; o >>= 1) { inspected += __shfl_xor(inspected, o); acc_out += __shfl_xor(acc_out, o); acc_in += __shfl_xor(acc_in, o); }
   if (lane == 0) {
-    if (found_total) atomicAdd(&cnt->n_next, found_total);
-    if (inspected) atomicAdd(&cnt->edges, inspected);
-    if (acc_out | acc_in) { atomicAdd(&cnt->out_edges, acc_out); atomicAdd(&cnt->in_edges, acc_in); }
+    counter_sums_t* r = cnt_replica(cnt);
+    if (found_total) atomicAdd(&r->n_found, (unsigned long long)found_total);
+    if (inspected) atomicAdd(&r->edges, inspected);
+    if (acc_out | acc_in) { atomicAdd(&r->out_edges, acc_out); atomicAdd(&r->in_edges, acc_in); }
   }
 }
 
@@ -594,6 +656,7 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   mark("init", nv, ns);
   counters_t c;
   h.read_back(&c, cnt.data(), 1);
+  c.fold();
   int64_t n_cur  = c.n_next;
   int32_t* q_cur = qa.data();
   int32_t* q_nxt = qb.data();
@@ -607,7 +670,10 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   bool bottom_up = false, front_is_bitmap = false;
   // depth_limit is compared after incrementing (bfs_impl.cuh:867-868)
   uint64_t const limit = depth_limit > (size_t)INT32_MAX ? (uint64_t)INT32_MAX : (uint64_t)depth_limit;
-  int const bu_grid = (int)std::max<int64_t>(1, std::min<int64_t>(((nv + 63) / 64 + TV_WAVES * BU_GROUPS - 1) / (TV_WAVES * BU_GROUPS), (int64_t)h.num_cus * 16));
+  bool const bu_profile = getenv("CUGRAPH_AMD_BFS_PROFILE") != nullptr;
+  char const* env_bug = getenv("CUGRAPH_AMD_BU_GRID");  // workgroups per CU of the bottom-up kernel (experiments)
+  int const bu_grid = (int)std::max<int64_t>(1, std::min<int64_t>(((nv + 63) / 64 + TV_WAVES * BU_GROUPS - 1) / (TV_WAVES * BU_GROUPS),
+                                                                  (int64_t)h.num_cus * (env_bug ? atoi(env_bug) : 16)));
   while (n_cur > 0) {
     if (in) {
       if (!bottom_up) bottom_up = (double)frontier_out > (double)unvisited_in / alpha && n_cur > 1024;
@@ -621,8 +687,21 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
                            front.data(), nwords);
       {
         timed_launch t(h, "bfs_bottom_up");
-        hipLaunchKernelGGL(k_bfs_bottom_up, bu_grid, TV_BLOCK, 0, h.stream, in_off, in_idx, out_off, nv, vis_new.data(), (uint32_t const*)front.data(),
-                           next.data(), dist->buf.as<int32_t>(), pred_p, (int32_t)(depth + 1), cnt.data());
+        if (bu_profile) {
+          dvec<unsigned long long> prof(8);
+          HIP_TRY(hipMemsetAsync(prof.data(), 0, 8 * sizeof(unsigned long long), h.stream));
+          hipLaunchKernelGGL(k_bfs_bottom_up<true>, bu_grid, TV_BLOCK, 0, h.stream, in_off, in_idx, out_off, nv, vis_new.data(), (uint32_t const*)front.data(),
+                             next.data(), dist->buf.as<int32_t>(), pred_p, (int32_t)(depth + 1), cnt.data(), prof.data());
+          unsigned long long pr[8];
+          h.read_back(pr, (unsigned long long const*)prof.data(), 8);
+          double const nw = (double)bu_grid * TV_WAVES;
+          fprintf(stderr, "[bfs bottom-up profile] depth %lld: per wavefront (100 MHz ticks) first chunk %.0f, lane tail %.0f, long rows + write %.0f; slowest wavefront %llu "
+                          "(long rows %llu); tail steps %.1f, long rows %.2f, long-row steps %.1f per wavefront\n",
+                  (long long)depth, pr[0] / nw, pr[1] / nw, pr[2] / nw, pr[6], pr[7], pr[3] / nw, pr[4] / nw, pr[5] / nw);
+        } else {
+          hipLaunchKernelGGL(k_bfs_bottom_up<false>, bu_grid, TV_BLOCK, 0, h.stream, in_off, in_idx, out_off, nv, vis_new.data(), (uint32_t const*)front.data(),
+                             next.data(), dist->buf.as<int32_t>(), pred_p, (int32_t)(depth + 1), cnt.data(), (unsigned long long*)nullptr);
+        }
       }
       mark("bottom_up", (long long)depth, n_cur);
       std::swap(front, next);  // `next` of this level is the frontier bitmap of the following one
@@ -651,6 +730,7 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
       std::swap(q_cur, q_nxt);
     }
     h.read_back(&c, cnt.data(), 1);
+    c.fold();
     edges += c.edges;
     n_cur        = c.n_next;
     frontier_out = c.out_edges;
@@ -783,6 +863,7 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
                            (int32_t const*)o.indices.data(), s);
       }
       h.read_back(&c, cnt.data(), 1);
+      c.fold();
       relaxed += c.edges;
       n_cur = c.n_next;
       n_far = c.n_far;
@@ -805,6 +886,7 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
                          (bits_t const*)d, (WT)std::min(lower, (double)wmax), (WT)std::min(upper, (double)wmax), q_cur, far_nxt,
                          mark_near.data(), mark_far.data(), round, far_epoch, cnt.data());
       h.read_back(&c, cnt.data(), 1);
+      c.fold();
       n_cur = c.n_next;
       n_far = c.n_far;
       std::swap(far_cur, far_nxt);
@@ -832,6 +914,7 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
     }
     if (nv > 0) hipLaunchKernelGGL(k_fix_pred, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, preds->buf.as<int32_t>(), nv);
     h.read_back(&c, cnt.data(), 1);
+    c.fold();
   }
   dvec<unsigned long long> reached(1);
   HIP_TRY(hipMemsetAsync(reached.data(), 0, 8, h.stream));

@@ -16,6 +16,17 @@ constexpr int32_t BIG_DEG_NARROW = 64; // ... and rows at least THIS long when i
                                        // of 1141 vertices at RMAT-24, 0.5 ms for one of 30.  Deferred rows get one workgroup per 4096 edges.
 constexpr int32_t BIG_SEG = 4096;  // edges per deferred (row, segment) work unit
 
+// Plain sums (edges inspected, degree sums of the discoveries, discoveries of the bottom-up kernel) are added once per wavefront
+// at kernel exit.  With one counter per quantity that is 10^4..10^5 atomics on ONE 64-byte line per launch, and same-line atomics
+// retire one after the other in their L2 channel (~12 ns each): a BFS bottom-up level of 16 Ki wavefronts took 0.85 ms whatever
+// it did, 1.6 ms with twice the wavefronts.  The sums therefore go to one of CNT_REPLICAS lines picked by wavefront; the host
+// folds them after the read-back (counters_t::fold).  Cursors (n_next / n_far / n_big of the queue-producing kernels) cannot be
+// replicated -- they hand out positions -- but they are touched once per 64+ items, not once per wavefront.
+constexpr int CNT_REPLICAS = 32;
+struct counter_sums_t {  // one 64-byte line
+  unsigned long long edges, out_edges, in_edges, n_found;
+  unsigned long long pad[4];
+};
 struct counters_t {  // device-resident, zeroed per step
   uint32_t n_next;   // size of the next (near) frontier
   uint32_t n_far;    // size of the far pile (SSSP)
@@ -27,7 +38,24 @@ struct counters_t {  // device-resident, zeroed per step
   unsigned long long far_min_bits64;
   unsigned long long out_edges;  // BFS: sum of out-degrees of the vertices discovered in this level (top-down cost of the next)
   unsigned long long in_edges;   // BFS: sum of their in-degrees (they leave the bottom-up work)
+  unsigned long long pad3;
+  counter_sums_t rep[CNT_REPLICAS];
+  __host__ __device__ void fold()  // host, after the read-back: replicas -> the plain fields
+  {
+    for (int r = 0; r < CNT_REPLICAS; ++r) {
+      edges += rep[r].edges; out_edges += rep[r].out_edges; in_edges += rep[r].in_edges; n_next += (uint32_t)rep[r].n_found;
+      rep[r] = counter_sums_t{};
+    }
+  }
 };
+static_assert(sizeof(counters_t) == 64 + CNT_REPLICAS * 64 && sizeof(counters_t) <= 3072, "counters_t: one line + the replica lines; read back through the pinned page");
+
+// the calling wavefront's replica line (all lanes get the same one)
+__device__ __forceinline__ counter_sums_t* cnt_replica(counters_t* cnt)
+{
+  unsigned const w = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  return &cnt->rep[w % CNT_REPLICAS];
+}
 
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t* total)
 {
@@ -175,7 +203,7 @@ __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int
     __builtin_amdgcn_wave_barrier();
     inspected += (lane == 0) ? (unsigned long long)total : 0ull;
   }
-  if (lane == 0 && inspected) atomicAdd(&cnt->edges, inspected);
+  if (lane == 0 && inspected) atomicAdd(&cnt_replica(cnt)->edges, inspected);
 }
 
 template <typename F>
@@ -190,7 +218,7 @@ __device__ __forceinline__ void expand_big(int32_t const* bigq, int32_t const* o
     for (int32_t p = b + (int32_t)threadIdx.x; p < e; p += (int32_t)blockDim.x) f(u, indices[p], p);
     if (threadIdx.x == 0) inspected += (unsigned long long)(e - b);
   }
-  if (threadIdx.x == 0 && inspected) atomicAdd(&cnt->edges, inspected);
+  if (threadIdx.x == 0 && inspected) atomicAdd(&cnt_replica(cnt)->edges, inspected);
 }
 
 

@@ -413,6 +413,7 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_reset(cugraph_amd_
     }
     counters_t c{};
     h.read_back(&c, p.cnt.data(), 1);
+    c.fold();
     p.n_frontier = c.n_next;
   });
 }
@@ -458,6 +459,7 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_expand(cugraph_amd
     h.sync();
     std::memcpy(&tot, h.pinned, sizeof(tot));
     std::memcpy(&c, static_cast<char*>(h.pinned) + 1024, sizeof(c));
+    c.fold();
     CGA_EXPECTS((size_t)c.n_next <= p.capacity, CUGRAPH_UNKNOWN_ERROR, "candidate list overflowed the send capacity");
     for (int r = 0; r < p.P; ++r) {
       uint32_t const first = (uint32_t)tot.t[r];
@@ -488,6 +490,7 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_apply(cugraph_amd_
     }
     counters_t c{};
     h.read_back(&c, p.cnt.data(), 1);
+    c.fold();
     std::swap(p.q_cur, p.q_next);
     p.n_frontier = c.n_next;
     *n_next      = c.n_next;

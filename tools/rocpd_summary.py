@@ -37,7 +37,57 @@ def summarize(db):
         print("counters_collection:", e)
 
 
+def per_dispatch(db, regex):
+    """one line per dispatch of the kernels matching `regex`: duration (when the kernels view has it) and every counter"""
+    import re
+
+    c = sqlite3.connect(db)
+    cur = c.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+    if not cols:
+        return
+    kn = "kernel_name" if "kernel_name" in cols else "name"
+    did = next((x for x in ("dispatch_id", "id", "kernel_id") if x in cols), None)
+    if did is None:
+        print("per-dispatch: no dispatch id column in", cols)
+        return
+    rows = cur.execute(f"select {did}, {kn}, counter_name, sum(value) from counters_collection group by {did}, {kn}, counter_name order by {did}").fetchall()
+    dur = {}
+    try:
+        kcols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+        kd = next((x for x in ("dispatch_id", "id") if x in kcols), None)
+        if kd:
+            dur = {r[0]: r[1] for r in cur.execute(f"select {kd}, duration from kernels")}
+    except Exception:
+        pass
+    table = defaultdict(dict)
+    names = {}
+    for d, k, cn, v in rows:
+        if re.search(regex, k):
+            table[d][cn] = v
+            names[d] = k
+    if not table:
+        return
+    cn_all = sorted({cn for d in table.values() for cn in d})
+    print(f"# per dispatch ({regex}) {db}")
+    print("dispatch  dur_us " + " ".join(f"{cn:>22}" for cn in cn_all))
+    for d in sorted(table):
+        print(f"{d:>8} {dur.get(d, 0) / 1e3:>7.1f} " + " ".join(f"{table[d].get(cn, 0):>22,.0f}" for cn in cn_all))
+
+
 if __name__ == "__main__":
+    if "--per-dispatch" in sys.argv:
+        i = sys.argv.index("--per-dispatch")
+        rx = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
+        for a in sys.argv[1:]:
+            dbs = [a] if a.endswith(".db") else sorted(glob.glob(os.path.join(a, "**", "*.db"), recursive=True))
+            for d in dbs:
+                try:
+                    per_dispatch(d, rx)
+                except Exception as e:
+                    print("per-dispatch:", d, e)
+        sys.exit(0)
     for a in sys.argv[1:]:
         dbs = [a] if a.endswith(".db") else sorted(glob.glob(os.path.join(a, "**", "*.db"), recursive=True))
         for d in dbs:
