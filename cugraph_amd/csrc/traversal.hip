@@ -662,8 +662,12 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   int32_t* q_nxt = qb.data();
   uint64_t depth = 0, edges = 0, levels = 0, bu_levels = 0;
   // Beamer's heuristic: go bottom-up when the frontier's out-edges exceed 1/alpha of the unvisited vertices' in-edges,
-  // come back when the frontier has shrunk below V / beta
-  double const alpha = 14.0, beta = 24.0;
+  // come back when the frontier has shrunk below V / beta.  alpha = 60 (Beamer: 14): a bottom-up level costs 0.2-0.3 ms at RMAT-24
+  // whatever the frontier, a top-down level ~25-70 G edges/s -- the level of the ~10^3 hubs right after the source (10-20 M
+  // out-edges, 0.7 ms top-down) is cheaper bottom-up (64 roots: mean 1.47 -> 1.38 ms, max 1.93 -> 1.61 ms)
+  char const* env_alpha = getenv("CUGRAPH_AMD_BFS_ALPHA");
+  char const* env_beta  = getenv("CUGRAPH_AMD_BFS_BETA");
+  double const alpha = env_alpha ? atof(env_alpha) : 60.0, beta = env_beta ? atof(env_beta) : 24.0;
   uint64_t frontier_out = c.out_edges;            // out-edges of the current frontier
   uint64_t reached_total = c.n_next, edges_of_reached = c.out_edges;
   uint64_t unvisited_in = (uint64_t)g.ne - c.in_edges;

@@ -28,8 +28,12 @@ struct counter_sums_t {  // one 64-byte line
   unsigned long long pad[4];
 };
 struct counters_t {  // device-resident, zeroed per step
+  // the three queue cursors sit in three different 64-byte lines: appends to the near and the far queue of an SSSP round would
+  // otherwise queue up behind each other in one L2 channel
   uint32_t n_next;   // size of the next (near) frontier
+  uint32_t padl0[15];
   uint32_t n_far;    // size of the far pile (SSSP)
+  uint32_t padl1[15];
   uint32_t n_big;    // deferred high-degree vertices
   uint32_t pad;
   unsigned long long edges;  // edges inspected
@@ -38,7 +42,7 @@ struct counters_t {  // device-resident, zeroed per step
   unsigned long long far_min_bits64;
   unsigned long long out_edges;  // BFS: sum of out-degrees of the vertices discovered in this level (top-down cost of the next)
   unsigned long long in_edges;   // BFS: sum of their in-degrees (they leave the bottom-up work)
-  unsigned long long pad3;
+  unsigned long long pad3[2];
   counter_sums_t rep[CNT_REPLICAS];
   __host__ __device__ void fold()  // host, after the read-back: replicas -> the plain fields
   {
@@ -48,7 +52,7 @@ struct counters_t {  // device-resident, zeroed per step
     }
   }
 };
-static_assert(sizeof(counters_t) == 64 + CNT_REPLICAS * 64 && sizeof(counters_t) <= 3072, "counters_t: one line + the replica lines; read back through the pinned page");
+static_assert(sizeof(counters_t) == 3 * 64 + CNT_REPLICAS * 64 && sizeof(counters_t) <= 3072, "counters_t: one line + the replica lines; read back through the pinned page");
 
 // the calling wavefront's replica line (all lanes get the same one)
 __device__ __forceinline__ counter_sums_t* cnt_replica(counters_t* cnt)
@@ -84,7 +88,10 @@ __device__ __forceinline__ void wave_push(bool flag, int32_t value, int32_t* q, 
 // wavefront and call.  In a wide frontier the per-call atomics all hit the SAME counter word and serialise in one L2 channel
 // (profiles: k_sssp_expand 17.8 ms for one relaxation round at RMAT-24 with per-call appends).  No wave-uniform register
 // state: lanes that sit out a call (ragged loop tails) simply do not take part, the fill counter lives in LDS.
-constexpr int WQ_CAP = 256;
+#ifndef CGA_WQ_CAP
+#define CGA_WQ_CAP 256
+#endif
+constexpr int WQ_CAP = CGA_WQ_CAP;  // (1024 measured equal for BFS, 5 % slower for SSSP: the cursor is not what a round waits for)
 template <int NQ>
 struct wave_queue_storage {
   int32_t buf[NQ][TV_WAVES][WQ_CAP];

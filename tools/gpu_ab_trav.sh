@@ -6,11 +6,11 @@ cp cugraph_amd/lib/libcugraph_c.so /tmp/orig.so
 for lib in ${LIBS:-bu_base}; do for envs in ${ENVS:-X=0}; do
   cp "gpurun_libs/$lib.so" cugraph_amd/lib/libcugraph_c.so
   echo "== lib=$lib env=$envs"
-  env $envs CUGRAPH_AMD_BFS_TRACE=1 timeout 300 python bench_traversal.py --scale 24 --roots ${ROOTS:-8} --weights unit --no-sssp --no-cpu-baseline 2>"$O/ab_trav.err" | python -c "
+  env $envs CUGRAPH_AMD_BFS_TRACE=1 timeout 300 python bench_traversal.py --scale 24 --roots ${ROOTS:-8} --weights ${WEIGHTS:-unit} ${SSSP:---no-sssp} --no-cpu-baseline 2>"$O/ab_trav.err" | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l)['bfs']; print('bfs mean_ms', d['mean_ms'], 'min', d['min_ms'], 'max', d['max_ms'])"
+        j=json.loads(l); d=j['bfs']; print('bfs mean_ms', d['mean_ms'], 'min', d['min_ms'], 'max', d['max_ms'], 'sssp', (j.get('sssp') or {}).get('mean_ms'))"
   python - "$O/ab_trav.err" <<'PY'
 import sys,re
 prev=None; acc={}
