@@ -805,11 +805,16 @@ struct pagerank_plan : pagerank_plan_base {
     e.cr   = crows;
     return e;
   }
-  void iterate_tiled()
+  void iterate_tiled(bool need_diff, bool last_of_call)
   {
     WT const* xcur = cur == 0 ? x0.data() : x1.data();
     WT* xnext      = cur == 0 ? x1.data() : x0.data();
     tiled_epilogue<WT> e = tiled_epi(xnext);
+    e.need_diff = need_diff || getenv("CUGRAPH_AMD_PAGERANK_DIFF") != nullptr;
+    // pr is this plan's result buffer, not its iteration state (that is x): an iteration whose L1 change is not wanted and that is
+    // followed by another one in the same call leaves pr alone.  Rows of dangling vertices have no x: they need pr itself, but only
+    // to be summed, which happens in registers.  (CUGRAPH_AMD_PAGERANK_WRITE_PR=1 writes it every iteration.)
+    e.write_pr = e.need_diff || last_of_call || getenv("CUGRAPH_AMD_PAGERANK_WRITE_PR") != nullptr;
     tiled_phase1<WT>(h, *tc, xcur, alpha, part.data(), counters.data(), tiled_x_map<WT>{}, pending_finish ? &e : nullptr);
     tiled_phase2<WT>(h, *tc, (WT const*)part.data(), e, counters.data());
     pending_finish   = true;
@@ -940,7 +945,7 @@ struct pagerank_plan : pagerank_plan_base {
     }
     while (it < max_iterations) {
       if (tiled || flat) {
-        if (tiled) iterate_tiled(); else iterate_flat();
+        if (tiled) iterate_tiled(epsilon > 0.0, it + 1 == max_iterations); else iterate_flat();  // epsilon == 0: nobody looks at the L1 change
         cur ^= 1;
         ++it;
         if (epsilon > 0.0) {

@@ -1263,7 +1263,7 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     uint32_t i = tid + j * TP2_BLOCK;
-    old[j] = i < nrows ? e.pr[(size_t)row0 + i] : WT(0);
+    old[j] = (e.need_diff && i < nrows) ? e.pr[(size_t)row0 + i] : WT(0);
     ow[j]  = i < nrows ? e.outw[(size_t)row0 + i] : WT(1);
     col[j] = (e.xcol && i < nrows) ? e.xcol[(size_t)row0 + i] : (int32_t)(row0 + i);
   }
@@ -1324,9 +1324,9 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
       WT val = sc.base + sum;
       if constexpr (PERS) val += sc.pers_factor * e.pers[v];
       WT const xn = val / (ow[j] == WT(0) ? WT(1) : ow[j]);
-      e.pr[v]     = val;
+      if (e.write_pr) e.pr[v] = val;
       if (col[j] >= 0) e.x_next[col[j]] = xn;  // sources without out-edges have no column
-      diff += (double)fabs(val - old[j]);
+      if (e.need_diff) diff += (double)fabs(val - old[j]);
       xmax = fmax(xmax, fabs((double)xn));
       if (ow[j] == WT(0)) dang += (double)val;
     }

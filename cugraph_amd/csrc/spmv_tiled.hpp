@@ -152,6 +152,11 @@ struct tiled_epilogue {
   WT* pr{nullptr};       // in: previous iterate, out: new iterate
   WT* x_next{nullptr};   // pr / out_w (next gather vector; the multi-GPU send chunk)
   int32_t const* xcol{nullptr};  // tiled_csc_t::xcol: where row r's x goes in x_next (nullptr: x_next[r])
+  bool write_pr{true};           // false: the new iterate is kept as x_next only (an iteration that is followed by another one inside the
+                                 // same step() call and is not asked for its L1 change: nobody reads pr before it is overwritten)
+  bool need_diff{true};          // false: the L1 change is not wanted (fixed iteration count): the previous iterate is not read
+                                 // (-0.11 GB per iteration at RMAT-26, phase 2 0.436 -> 0.418 ms).  Deriving the row -> column map from one
+                                 // bit per row instead of reading xcol was tried with it and lost (+0.012 ms: the lookups sit at the end)
   WT const* outw{nullptr};
   WT const* pers{nullptr};  // dense normalised personalization or nullptr
   pr_scalars<WT>* scal{nullptr};
