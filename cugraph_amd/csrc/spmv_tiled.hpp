@@ -71,10 +71,10 @@ constexpr int TP_NDREG = 2;                  // registers of prefetched slot-blo
 constexpr int TP_SUB   = 64 * TP_EPL;        // edges per wavefront per work item (TP_EPL consecutive edges per lane)
 constexpr int TP_WLEN  = TP_SUB;
 constexpr int TP_ITEM  = TP_WLEN * TP_WAVES;  // edges per work item
-constexpr double TP_TAIL_FRAC = 0.3;         // share of the items (coldest tiles) handed out in chunks of TP_TAIL_CHUNK items
+constexpr double TP_TAIL_FRAC = 0.15;        // share of the items (coldest tiles) handed out in chunks of TP_TAIL_CHUNK items
 constexpr int TP_TAIL_CHUNK = 8;
 constexpr int TP_CHUNK = 16;                 // max work items per dynamically scheduled chunk (256 Ki edges); chunks are handed out largest first
-constexpr int TP_CHUNK_BIG = 16;             // chunk length for the first part of a tile that spans many chunks (see build_tiled_csc)
+constexpr int TP_CHUNK_BIG = 32;             // chunk length for the first part of a tile that spans many chunks (see build_tiled_csc)
 #ifndef CGA_TP2_BLOCK
 #define CGA_TP2_BLOCK 512
 #endif
