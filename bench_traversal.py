@@ -147,7 +147,7 @@ def main():
     roots = cand[perm.to(cand.device)].to(torch.int32)
 
     def run(kind):
-        times, edges, steps = [], [], []
+        times, edges, steps, inspected = [], [], [], []
         for i, r in enumerate([roots[0], roots[0]] + list(roots)):  # two warm-ups (the second BFS of a directed graph builds its CSC)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -162,7 +162,9 @@ def main():
                 times.append(dt)
                 edges.append(st["edges_of_reached"] if kind == "bfs" else None)
                 steps.append(st["steps"])
+                inspected.append(st["edges_inspected"])
             last = (v, d)
+        run.inspected = inspected
         return times, edges, steps, last
 
     HBM_PEAK = 8000.0  # GB/s, /opt/skills/guides/MI355X_MICROARCH.md
@@ -198,7 +200,7 @@ def main():
         hm = len(teps) / sum(1.0 / x for x in teps)
         t_hm = float(np.mean(be)) / hm
         out["sssp"] = {"mean_ms": round(1e3 * float(np.mean(st)), 3), "min_ms": round(1e3 * float(np.min(st)), 3), "max_ms": round(1e3 * float(np.max(st)), 3),
-                       "harmonic_mean_mteps": round(hm / 1e6, 1), "mean_steps": float(np.mean(ss)), "dtype": "f32",
+                       "harmonic_mean_mteps": round(hm / 1e6, 1), "mean_steps": float(np.mean(ss)), "mean_relaxations_per_edge": round(float(np.mean(run.inspected)) / ne, 3), "dtype": "f32",
                        "roofline": roofline("sssp", float(np.mean(be)), reached[0], t_hm, args.predecessors)}
         if args.weights == "unit":  # integer hops: bit-exact against BFS (last root)
             a = torch.empty(nv, dtype=torch.int64, device="cuda"); a[bv.to(torch.int64)] = bd.to(torch.int64)

@@ -34,6 +34,8 @@ struct counters_t {  // device-resident, zeroed per step
   uint32_t padl0[15];
   uint32_t n_far;    // size of the far pile (SSSP)
   uint32_t padl1[15];
+  uint32_t n_set;    // SSSP (light / heavy): vertices that entered the current bucket (their heavy edges are relaxed when it closes)
+  uint32_t padl2[15];
   uint32_t n_big;    // deferred high-degree vertices
   uint32_t pad;
   unsigned long long edges;  // edges inspected
@@ -52,7 +54,7 @@ struct counters_t {  // device-resident, zeroed per step
     }
   }
 };
-static_assert(sizeof(counters_t) == 3 * 64 + CNT_REPLICAS * 64 && sizeof(counters_t) <= 3072, "counters_t: one line + the replica lines; read back through the pinned page");
+static_assert(sizeof(counters_t) == 4 * 64 + CNT_REPLICAS * 64 && sizeof(counters_t) <= 3072, "counters_t: one line + the replica lines; read back through the pinned page");
 
 // the calling wavefront's replica line (all lanes get the same one)
 __device__ __forceinline__ counter_sums_t* cnt_replica(counters_t* cnt)
@@ -156,7 +158,8 @@ struct wave_queue {
 // bigq for k_expand_big.
 template <typename Keep, typename F>
 __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices,
-                                                int32_t* bigq, counters_t* cnt, Keep keep, F& f, int32_t big_deg = BIG_DEG)
+                                                int32_t* bigq, counters_t* cnt, Keep keep, F& f, int32_t big_deg = BIG_DEG,
+                                                int32_t const* row_end = nullptr)  // row u = [offsets[u], row_end ? row_end[u] : offsets[u + 1])
 {
   __shared__ uint32_t s_scan[TV_WAVES][64];
   __shared__ int32_t s_beg[TV_WAVES][64];
@@ -170,7 +173,7 @@ __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int
     int32_t u = -1, beg = 0, deg = 0;
     if (i < n) {
       u = q ? q[i] : (int32_t)i;
-      if (keep(u)) { beg = offsets[u]; deg = offsets[u + 1] - beg; } else { u = -1; }
+      if (keep(u)) { beg = offsets[u]; deg = (row_end ? row_end[u] : offsets[u + 1]) - beg; } else { u = -1; }
     }
     // deferred: huge rows, cut into BIG_SEG-edge segments (one workgroup of k_*_big each)
     bool big = deg >= big_deg;
@@ -214,14 +217,15 @@ __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int
 }
 
 template <typename F>
-__device__ __forceinline__ void expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, counters_t* cnt, F& f)
+__device__ __forceinline__ void expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, counters_t* cnt, F& f,
+                                           int32_t const* row_end = nullptr)
 {  // one workgroup per (row, segment) pair: rows of 10^3..10^6 edges all get parallelism proportional to their length
   uint32_t const nseg = cnt->n_big;
   unsigned long long inspected = 0;
   for (uint32_t k = blockIdx.x; k < nseg; k += gridDim.x) {
     int32_t const u = bigq[2 * k], sgm = bigq[2 * k + 1];
     int32_t const b = offsets[u] + sgm * BIG_SEG;
-    int32_t const e = min(offsets[u + 1], b + BIG_SEG);
+    int32_t const e = min(row_end ? row_end[u] : offsets[u + 1], b + BIG_SEG);
     for (int32_t p = b + (int32_t)threadIdx.x; p < e; p += (int32_t)blockDim.x) f(u, indices[p], p);
     if (threadIdx.x == 0) inspected += (unsigned long long)(e - b);
   }

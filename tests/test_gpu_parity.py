@@ -366,6 +366,43 @@ def test_sssp_rmat_vs_oracle(cg, handle, orc, scale, kind, dtype):
     assert np.array_equal(dist, oc)
 
 
+@pytest.mark.parametrize("scale,kind,dtype,lh_scale", [(12, "int", np.float32, 0.25), (14, "int", np.float32, 0.25), (14, "int", np.float32, 0.05),
+                                                       (14, "real", np.float32, 0.25), (14, "int", np.float64, 0.5), (14, "unit", np.float32, 0.25),
+                                                       (16, "int", np.float32, 1.0)])
+def test_sssp_light_heavy_buckets_vs_oracle(cg, handle, orc, monkeypatch, scale, kind, dtype, lh_scale):
+    """the delta-stepping path of large graphs (light edges inside a bucket, heavy edges once when it closes; sssp_lh_t) forced at
+    sizes the oracle handles: distances bit-identical to Dijkstra, canonical parents, cutoff honoured -- for narrow buckets (many
+    empty windows, every edge heavy with unit weights) and wide ones (every edge light)"""
+    monkeypatch.setenv("CUGRAPH_AMD_SSSP_LH", "1")
+    monkeypatch.setenv("CUGRAPH_AMD_SSSP_LH_SCALE", str(lh_scale))
+    s, d = rmat_graph(orc, scale, seed=2)
+    nv = 1 << scale
+    if kind == "unit":
+        w = np.ones(s.size, dtype)
+    elif kind == "int":
+        w = int_weights(s.size).astype(dtype)
+    else:
+        w = np.random.default_rng(5).random(s.size).astype(dtype) + dtype(0.01)
+    g = make_graph(cg, handle, s, d, w, transposed=False, renumber=True, vertices=np.arange(nv), wdtype=dtype)
+    off, idx, ww = orc.coo_to_cs(nv, s, d, w)
+    for src in np.nonzero(np.diff(off) > 0)[0][[1, 7]]:
+        src = int(src)
+        v, dist, pred = cg.sssp(handle, g, src, float(np.finfo(dtype).max), True, False)
+        dist, pred = by_vertex(v, dist, pred)
+        od, _ = orc.sssp(nv, off, idx, ww, src)
+        assert np.array_equal(dist, od)
+        assert np.array_equal(pred, orc.sssp_min_pred(nv, off, idx, ww, src, od))
+    cut = float(np.median(od[od < np.finfo(dtype).max]))
+    v, dist, _ = cg.sssp(handle, g, src, cut, False, False)
+    (dist,) = by_vertex(v, dist)
+    oc, _ = orc.sssp(nv, off, idx, ww, src, cutoff=cut)
+    assert np.array_equal(dist, oc)
+    monkeypatch.setenv("CUGRAPH_AMD_SSSP_LH", "0")  # and the wide-bucket path on the same graph object (the cached copy is not used)
+    v, dist, _ = cg.sssp(handle, g, src, float(np.finfo(dtype).max), False, False)
+    (dist,) = by_vertex(v, dist)
+    assert np.array_equal(dist, od)
+
+
 def test_csr_input_and_orientation_flip_share_one_numbering(cg, handle, orc):
     s, d = rmat_graph(orc, 12, seed=9)
     nv = 1 << 12
