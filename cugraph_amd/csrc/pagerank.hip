@@ -599,6 +599,8 @@ struct pagerank_plan : pagerank_plan_base {
   size_t flat_lds{0};
   // column-tiled two-phase path (spmv_tiled.hpp): the default
   bool tiled{false};
+  bool const force_diff{getenv("CUGRAPH_AMD_PAGERANK_DIFF") != nullptr};          // measurement switches, read once per plan
+  bool const force_write_pr{getenv("CUGRAPH_AMD_PAGERANK_WRITE_PR") != nullptr};
   std::shared_ptr<tiled_csc_t> tc;
   dvec<WT> part;
   dvec<double> tpartials;  // [max(nI, 1024)][3]
@@ -810,11 +812,11 @@ struct pagerank_plan : pagerank_plan_base {
     WT const* xcur = cur == 0 ? x0.data() : x1.data();
     WT* xnext      = cur == 0 ? x1.data() : x0.data();
     tiled_epilogue<WT> e = tiled_epi(xnext);
-    e.need_diff = need_diff || getenv("CUGRAPH_AMD_PAGERANK_DIFF") != nullptr;
+    e.need_diff = need_diff || force_diff;
     // pr is this plan's result buffer, not its iteration state (that is x): an iteration whose L1 change is not wanted and that is
     // followed by another one in the same call leaves pr alone.  Rows of dangling vertices have no x: they need pr itself, but only
     // to be summed, which happens in registers.  (CUGRAPH_AMD_PAGERANK_WRITE_PR=1 writes it every iteration.)
-    e.write_pr = e.need_diff || last_of_call || getenv("CUGRAPH_AMD_PAGERANK_WRITE_PR") != nullptr;
+    e.write_pr = e.need_diff || last_of_call || force_write_pr;
     tiled_phase1<WT>(h, *tc, xcur, alpha, part.data(), counters.data(), tiled_x_map<WT>{}, pending_finish ? &e : nullptr);
     tiled_phase2<WT>(h, *tc, (WT const*)part.data(), e, counters.data());
     pending_finish   = true;
