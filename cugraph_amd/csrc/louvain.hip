@@ -96,39 +96,22 @@ __device__ __forceinline__ T seg_scan64(T val, bool head, int lane, bool& open)
   open = f == 0;
   return val;
 }
-template <typename T>
-__device__ __forceinline__ T wave_sum64(T v)
-{
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-constexpr int LV_WIDE = 64;  // rows with at least this many edges are walked by the whole wavefront
-
-// vertex weights k[v] = sum of the vertex's edge weights; kfix = the same in fixed point (for the cluster-weight atomics)
-__global__ void k_vertex_weights(int32_t const* off, double const* w, int64_t nv, double scale, double* k, long long* kfix)
+// vertex weights k[v] = sum of the vertex's edge weights, in fixed point (kfix, for the cluster-weight atomics) and as double:
+// flat over the edges (grouped by source), a wavefront reduces its 64 entries by source and adds one value per (wavefront, source)
+__global__ void k_vertex_weights(int32_t const* src, double const* w, int64_t ne, double scale, unsigned long long* kfix)
 {
   int const lane       = threadIdx.x & 63;
   int64_t const wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   int64_t const nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t v0 = wave * 64; v0 < nv; v0 += nwaves * 64) {
-    int64_t const v = v0 + lane;
-    int32_t b = 0, e = 0;
-    if (v < nv) { b = off[v]; e = off[v + 1]; }
-    bool const wide = e - b >= LV_WIDE;
-    double s = 0.0;
-    if (!wide) for (int32_t p = b; p < e; ++p) s += w[p];
-    uint64_t todo = __ballot(wide);
-    while (todo) {
-      int const l = __ffsll((unsigned long long)todo) - 1;
-      todo &= todo - 1;
-      int32_t const rb = __shfl(b, l), re = __shfl(e, l);
-      double t = 0.0;
-      for (int32_t p = rb + lane; p < re; p += 64) t += w[p];
-      t = wave_sum64(t);
-      if (lane == l) s = t;
-    }
-    if (v < nv) { k[v] = s; kfix[v] = __double2ll_rn(s * scale); }
+  for (int64_t i0 = wave * 64; i0 < ne; i0 += nwaves * 64) {
+    int64_t const i  = i0 + lane;
+    bool const valid = i < ne;
+    int32_t const v     = valid ? src[i] : -1;
+    int32_t const vprev = __shfl_up(v, 1), vnext = __shfl_down(v, 1);
+    long long const wf  = valid ? __double2ll_rn(w[i] * scale) : 0;
+    bool open;
+    long long const sum = seg_scan64(wf, lane == 0 || v != vprev, lane, open);
+    if (valid && (lane == 63 || v != vnext)) atomicAdd(&kfix[v], (unsigned long long)sum);
   }
 }
 
@@ -419,7 +402,6 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
 {
   int64_t const nv = L.nv, ne = L.ne;
   int const g_v = grid_for(nv, kBlock, 8192), g_e = grid_for(ne, kBlock, 8192);
-  int const g_w = grid_for(nv, kBlock, 16384);  // wavefront-per-64-vertices kernels
   double const scale = fixed_scale(m);
   dvec<double> k((size_t)nv), a((size_t)nv), best_d((size_t)nv), scal(2), parts;
   dvec<long long> kfix((size_t)nv);
@@ -428,7 +410,10 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   dvec<uint32_t> count(2), eperm((size_t)std::max<int64_t>(ne, 1));
   dvec<uint64_t> ekeys((size_t)std::max<int64_t>(ne, 1));
   accepted.resize_discard((size_t)nv);
-  hipLaunchKernelGGL(k_vertex_weights, g_w, kBlock, 0, h.stream, (int32_t const*)L.off.data(), (double const*)L.w.data(), nv, scale, k.data(), kfix.data());
+  HIP_TRY(hipMemsetAsync(kfix.data(), 0, (size_t)nv * sizeof(long long), h.stream));
+  if (ne > 0) hipLaunchKernelGGL(k_vertex_weights, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (double const*)L.w.data(), ne, scale,
+                                 reinterpret_cast<unsigned long long*>(kfix.data()));
+  hipLaunchKernelGGL(k_fix_to_double, g_v, kBlock, 0, h.stream, reinterpret_cast<unsigned long long const*>(kfix.data()), nv, 1.0 / scale, k.data());
   iota_i32(h, c.data(), nv, 0);
   iota_i32(h, accepted.data(), nv, 0);
   HIP_TRY(hipMemcpyAsync(afix.data(), kfix.data(), nv * sizeof(long long), hipMemcpyDeviceToDevice, h.stream));

@@ -369,6 +369,7 @@ __global__ void k_bfs_init_sources(int32_t const* src, int64_t n, int32_t* dist,
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   int32_t v    = src[i];
+  if (v < 0) { atomicAdd(&cnt->n_big, 1u); return; }  // not a vertex of the graph (renumber_ext_to_int): reported by the host after the read-back
   uint32_t bit = 1u << (v & 31);
   uint32_t old = atomicOr(&vis_new[v >> 5], bit);
   if (!(old & bit)) {  // duplicates in the source list are enqueued once
@@ -642,8 +643,7 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
 
   dvec<int32_t> src(ns > 0 ? ns : 1);
   if (ns > 0) HIP_TRY(hipMemcpyAsync(src.data(), sources->data, ns * 4, hipMemcpyDeviceToDevice, h.stream));
-  renumber_ext_to_int(h, g, src.data(), ns);
-  CGA_EXPECTS(count_negative_i32(h, src.data(), ns) == 0, CUGRAPH_INVALID_INPUT, "Found invalid vertex in the input sources");  // bfs.cpp:106-119
+  renumber_ext_to_int(h, g, src.data(), ns);  // ids that are not vertices become -1: counted by k_bfs_init_sources (no extra round trip)
 
   auto ids   = std::make_unique<device_array_t>((size_t)nv, g.vertex_type);
   auto dist  = std::make_unique<device_array_t>((size_t)nv, g.vertex_type);
@@ -670,6 +670,7 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   counters_t c;
   h.read_back(&c, cnt.data(), 1);
   c.fold();
+  CGA_EXPECTS(c.n_big == 0, CUGRAPH_INVALID_INPUT, "Found invalid vertex in the input sources");  // bfs.cpp:106-119
   int64_t n_cur  = c.n_next;
   int32_t* q_cur = qa.data();
   int32_t* q_nxt = qb.data();
