@@ -395,7 +395,7 @@ double fixed_scale(double m)
   return std::ldexp(1.0, 61 - e);
 }
 
-struct louvain_stats_t { int sweeps{0}; };
+struct louvain_stats_t { int sweeps{0}, sweeps_in_level{0}; };
 
 // one level (the body of the while loop of detail::louvain, louvain_impl.cuh:78-262): accepted clustering and its modularity
 double run_level(handle_t const& h, level_t const& L, double m, double threshold, double resolution, dvec<int32_t>& accepted, louvain_stats_t& st)
@@ -436,11 +436,14 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   while (new_q > cur_q + threshold) {
     cur_q = new_q;
     ++st.sweeps;
+    ++st.sweeps_in_level;
     // update_clustering_by_delta_modularity (common_methods.cuh:259-447)
     if (ne > 0) {
       hipLaunchKernelGGL(k_pair_keys, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)nullptr, (int32_t const*)L.dst.data(),
                          (int32_t const*)c.data(), ne, vb, ekeys.data(), eperm.data());
-      sort_pairs(h, ekeys, eperm, ne, 2 * vb);
+      // first sweep of a level: every vertex is its own cluster, so the key is (source, destination) -- the order the level's
+      // edges are stored in (CSR order / the contraction's output): nothing to sort
+      if (st.sweeps_in_level > 1) sort_pairs(h, ekeys, eperm, ne, 2 * vb);
     }
     HIP_TRY(hipMemsetAsync(vfix.data(), 0, (size_t)nv * 3 * sizeof(unsigned long long), h.stream));  // selffix, subfix, best_bits
     HIP_TRY(hipMemsetAsync(best_c.data(), 0x7f, (size_t)nv * sizeof(int32_t), h.stream));
