@@ -111,6 +111,21 @@ def run_single(args):
         launches2, kernel2_ms = 0, 0.0
     h.kernel_timing(False)
     check = None if args.no_check else check_result(cg, h, plan, args.scale, ne, nv)
+    if check is not None:
+        # for the record, outside the timed region: the same iteration when the caller DOES want the L1 change every iteration
+        # (what an epsilon > 0 run executes between its stopping tests): previous iterate re-read, pr written every time
+        os.environ["CUGRAPH_AMD_PAGERANK_DIFF"] = "1"
+        try:
+            plan2 = cg.PageRankPlan(h, g, 0.85)
+            plan2.step(args.warmup)
+            h.sync()
+            t0 = time.perf_counter()
+            plan2.step(args.steps)
+            h.sync()
+            check["ms_per_step_tracking_l1_change"] = round((time.perf_counter() - t0) / args.steps * 1e3, 4)
+            del plan2
+        finally:
+            os.environ.pop("CUGRAPH_AMD_PAGERANK_DIFF", None)
     return nv, ne, dt, launches, kernel_ms, build_s, launches2, kernel2_ms, plan_s, check
 
 
@@ -202,7 +217,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"PageRank power iteration, RMAT scale {args.scale} edge factor {args.edge_factor} "
                                "(a,b,c)=(0.57,0.19,0.19) seed 0, int32 ids, fp32 ranks, alpha 0.85, CSC with degree-descending renumbering",
-                   "vertices": nv, "edges": ne, "parallelism": "1 GPU"},
+                   "vertices": nv, "edges": ne, "parallelism": "1 GPU", "iterations": "fixed count (epsilon = 0, no host synchronisation inside the timed region): the L1 change is not evaluated, so the epilogue does not re-read the previous iterate, and pr -- the result buffer; the iteration state is x = pr/out_w -- is written by the last iteration of the call (DESIGN.md section 3.1, item 5; CUGRAPH_AMD_PAGERANK_DIFF=1 CUGRAPH_AMD_PAGERANK_WRITE_PR=1 restore both)"},
         "iters_per_sec": round(args.steps / dt, 2),
         "graph_build_s": round(build_s, 3), "plan_build_s": round(plan_s, 3),
         "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
