@@ -987,6 +987,28 @@ def test_louvain_rmat_vs_oracle(cg, handle, orc, scale, resolution):
     assert olevels >= 2 and len(np.unique(c)) < nv // 2
 
 
+@pytest.mark.parametrize("scale", [10, 12])
+def test_louvain_real_weights_vs_oracle(cg, handle, orc, scale):
+    """fp32 weights that are not integers: the fixed-point sums of the GPU path (scale 2^s from the total weight) and the sequential
+    fp64 sums of the oracle are both exact for fp32 inputs of moderate range, so the clustering is still equal vertex for vertex"""
+    s, d = orc.rmat(scale, 8 << scale, seed=7)
+    keep = s != d
+    pairs = np.unique(np.stack([np.minimum(s[keep], d[keep]), np.maximum(s[keep], d[keep])], 1), axis=0)
+    wt = (np.random.default_rng(11).random(len(pairs)) + 0.1).astype(np.float32)
+    src = np.concatenate([pairs[:, 0], pairs[:, 1]]).astype(np.int32)
+    dst = np.concatenate([pairs[:, 1], pairs[:, 0]]).astype(np.int32)
+    w = np.concatenate([wt, wt])
+    nv = 1 << scale
+    o = np.lexsort((dst, src))
+    oc, oq, _ = orc.louvain(nv, src[o], dst[o], w[o], 100, 1e-7, 1.0)
+    g = cg.SGGraph(handle, cg.GraphProperties(is_symmetric=True), T(src, np.int32), T(dst, np.int32), T(w, np.float32), renumber=False,
+                   vertices_array=T(np.arange(nv), np.int32))
+    v, c, q = cg.louvain(handle, g, 100, 1e-7, 1.0, False)
+    (c,) = by_vertex(v, c)
+    assert np.array_equal(c, oc)
+    assert abs(q - oq) <= 1e-9
+
+
 def louvain_rmat_input(orc, scale, edge_factor=8, seed=5):
     """undirected simple RMAT graph with integer weights 1..8 (every sum exact), both directions listed, sorted by (src, dst)"""
     s, d = orc.rmat(scale, edge_factor << scale, seed=seed)
