@@ -139,9 +139,12 @@ def main():
                    vertices_array=verts)
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
-    outdeg = torch.bincount(src.to(torch.int64), minlength=nv)
     del src, dst
-    # roots: fixed-seed hash order over the vertices with out-edges
+    # roots: fixed-seed hash order over the vertices with out-edges (the library's own degrees: no framework kernel in the profiles)
+    dv, dd = cg.out_degrees(h, g)
+    outdeg = torch.zeros(nv, dtype=torch.int64, device="cuda")
+    outdeg[dv.to(torch.int64)] = dd.to(torch.int64)
+    del dv, dd
     cand = torch.nonzero(outdeg > 0).flatten()
     perm = torch.randperm(cand.numel(), generator=torch.Generator().manual_seed(0))[: args.roots]
     roots = cand[perm.to(cand.device)].to(torch.int32)
