@@ -693,6 +693,9 @@ struct pagerank_plan : pagerank_plan_base {
       HIP_TRY(hipMemsetAsync(x0.data(), 0, nx * sizeof(WT), h.stream));
       HIP_TRY(hipMemsetAsync(x1.data(), 0, nx * sizeof(WT), h.stream));
       h.sync();
+      if (getenv("CUGRAPH_AMD_TILED_DEBUG"))  // where the streamed arrays sit (run-to-run spread of phase 1: placement?)
+        fprintf(stderr, "[tiled plan] src16 %p bits %p wrec %p delta1 %p dstl12 %p part %p x0 %p x1 %p pr %p\n", (void*)tc->src16.data(), (void*)tc->bits.data(),
+                (void*)tc->wrec.data(), (void*)tc->delta1.data(), (void*)tc->dstl12.data(), (void*)part.data(), (void*)x0.data(), (void*)x1.data(), (void*)pr.data());
       return;
     }
     flat = o.row_order.size() == 0 && g.ne > 0 && kern != "rows";
