@@ -13,25 +13,22 @@ namespace {
 // =================================================================================================
 // build: CSC -> tiles
 // =================================================================================================
-__global__ void k_expand_rows_u32(int32_t const* offsets, int64_t nv, uint32_t* rows)
+// Sort key of every edge, one wavefront per CSC row: source tile << 47 | destination row << 16 | tile-local source.  Only the tile
+// bits are sorted on (stable: the CSC order -- destination, then source -- survives inside a tile); everything k_tile_emit needs
+// travels in the key, so it gathers nothing (it used to chase positions -> rows / indices -> xcol: four random reads per edge).
+constexpr int TK_TILE_SHIFT = 47, TK_ROW_SHIFT = 16;
+__global__ void k_tile_keys(int32_t const* offsets, int32_t const* indices, int32_t const* xcol, int64_t nv, uint32_t T, uint64_t* keys, uint32_t* vals)
 {
-  int64_t wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  int lane       = threadIdx.x & 63;
+  int64_t const wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int const lane = threadIdx.x & 63;
   for (int64_t v = wave; v < nv; v += nwaves) {
-    int32_t b = offsets[v], e = offsets[v + 1];
-    for (int32_t p = b + lane; p < e; p += 64) rows[p] = (uint32_t)v;
-  }
-}
-
-__global__ void k_tile_keys(int32_t const* indices, int32_t const* xcol, int64_t ne, uint32_t T, uint64_t* keys, uint32_t* vals)
-{
-  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < ne; i += stride) {
-    uint32_t const c = xcol ? (uint32_t)xcol[indices[i]] : (uint32_t)indices[i];
-    keys[i] = (uint64_t)(c / T);
-    vals[i] = (uint32_t)i;
+    int32_t const b = offsets[v], e = offsets[v + 1];
+    for (int32_t p = b + lane; p < e; p += 64) {
+      uint32_t const c = xcol ? (uint32_t)xcol[indices[p]] : (uint32_t)indices[p];
+      uint32_t const J = c / T;
+      keys[p] = ((uint64_t)J << TK_TILE_SHIFT) | ((uint64_t)(uint32_t)v << TK_ROW_SHIFT) | (uint64_t)(c - J * T);
+      if (vals) vals[p] = (uint32_t)p;
+    }
   }
 }
 
@@ -49,30 +46,29 @@ __global__ void k_xcol(uint32_t const* live, uint32_t const* rank, int64_t nv, i
 }
 
 // first[key] = first position holding that key in a sorted key array (entries of absent keys keep the pre-filled value)
-__global__ void k_first_of_key(uint64_t const* keys, int64_t n, uint32_t* first)
+__global__ void k_first_of_key(uint64_t const* keys, int64_t n, int shift, uint32_t* first)
 {
   int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride)
-    if (i == 0 || keys[i] != keys[i - 1]) first[keys[i]] = (uint32_t)i;
+    if (i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift)) first[keys[i] >> shift] = (uint32_t)i;
 }
 
 // tiled position k (sorted by source tile, then CSC order) -> padded position, 16-bit source, run-start flag
 template <typename WB>
-__global__ void k_tile_emit(uint64_t const* keys, uint32_t const* vals, int64_t ne, int32_t const* indices, int32_t const* xcol, uint32_t const* rows,
-                            WB const* w_in, uint32_t const* tile_off, uint32_t const* tile_off_pad, uint32_t T, uint16_t* src16,
-                            WB* w_out, uint32_t* bits, uint32_t* flag32, uint32_t* dsts)
+__global__ void k_tile_emit(uint64_t const* keys, uint32_t const* vals, int64_t ne, WB const* w_in, uint32_t const* tile_off, uint32_t const* tile_off_pad,
+                            uint16_t* src16, WB* w_out, uint32_t* bits, uint32_t* flag32, uint32_t* dsts)
 {
   int64_t k      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; k < ne; k += stride) {
-    uint32_t J  = (uint32_t)keys[k];
-    uint32_t e  = vals[k];
-    uint32_t pk = tile_off_pad[J] + ((uint32_t)k - tile_off[J]);
-    uint32_t d  = rows[e];
-    src16[pk]   = (uint16_t)((xcol ? (uint32_t)xcol[indices[e]] : (uint32_t)indices[e]) - J * T);
-    if (w_in) w_out[pk] = w_in[e];
-    bool flag = (uint32_t)k == tile_off[J] || rows[vals[k - 1]] != d;
+    uint64_t const key = keys[k];
+    uint32_t const J   = (uint32_t)(key >> TK_TILE_SHIFT);
+    uint32_t const d   = (uint32_t)(key >> TK_ROW_SHIFT) & 0x7FFFFFFFu;
+    uint32_t const pk  = tile_off_pad[J] + ((uint32_t)k - tile_off[J]);
+    src16[pk]          = (uint16_t)(key & 0xFFFFu);
+    if (w_in) w_out[pk] = w_in[vals[k]];
+    bool const flag = (uint32_t)k == tile_off[J] || ((uint32_t)(keys[k - 1] >> TK_ROW_SHIFT) & 0x7FFFFFFFu) != d;
     flag32[k] = flag ? 1u : 0u;
     dsts[k]   = d;
     if (flag) atomicOr(&bits[pk >> 5], 1u << (pk & 31));
@@ -286,11 +282,11 @@ void to_device(handle_t const& h, dvec<T>& dev, std::vector<T> const& host)
 }
 
 // first-occurrence table of a sorted key array over keys [0, nkeys]; absent keys take the next present key's position
-std::vector<uint32_t> key_starts(handle_t const& h, uint64_t const* keys, int64_t n, int64_t nkeys)
+std::vector<uint32_t> key_starts(handle_t const& h, uint64_t const* keys, int64_t n, int64_t nkeys, int shift = 0)
 {
   dvec<uint32_t> first(nkeys + 1);
   fill_u32(h, first.data(), nkeys + 1, 0xFFFFFFFFu);
-  if (n > 0) hipLaunchKernelGGL(k_first_of_key, grid_for(n, kBlock, 8192), kBlock, 0, h.stream, keys, n, first.data());
+  if (n > 0) hipLaunchKernelGGL(k_first_of_key, grid_for(n, kBlock, 8192), kBlock, 0, h.stream, keys, n, shift, first.data());
   std::vector<uint32_t> f = to_host(h, first.data(), (size_t)nkeys + 1);
   f[nkeys] = (uint32_t)n;
   for (int64_t k = nkeys - 1; k >= 0; --k)
@@ -364,15 +360,19 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   tr.step("live columns");
   // ---- edges ordered by (source tile, destination, source): stable sort of the CSC positions by source tile
   dvec<uint64_t> keys, keys_tmp;
-  dvec<uint32_t> vals, vals_tmp, rows, flag32, ord, dsts;
+  dvec<uint32_t> vals, vals_tmp, flag32, ord, dsts;
   std::vector<uint32_t> tile_off(nJ + 1, 0), tile_off_pad(nJ + 1, 0);
   if (ne > 0) {
-    keys.resize_discard(ne); keys_tmp.resize_discard(ne); vals.resize_discard(ne); vals_tmp.resize_discard(ne); rows.resize_discard(ne);
-    hipLaunchKernelGGL(k_expand_rows_u32, grid_for(nv * 16, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)csc.offsets.data(), nv, rows.data());
-    hipLaunchKernelGGL(k_tile_keys, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)csc.indices.data(), xcol, ne, (uint32_t)T, keys.data(), vals.data());
-    radix_sort_u64_u32(h, keys.data(), vals.data(), keys_tmp.data(), vals_tmp.data(), ne, 0, bits_for_u((uint64_t)nJ - 1));
+    CGA_EXPECTS(nJ <= (1 << (64 - TK_TILE_SHIFT)) && T <= (1 << TK_ROW_SHIFT), CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: too many source tiles for the packed sort key");
+    keys.resize_discard(ne); keys_tmp.resize_discard(ne);
+    if (has_weights) { vals.resize_discard(ne); vals_tmp.resize_discard(ne); }  // the edge position only has to travel when weights follow it
+    uint32_t* const vp  = has_weights ? vals.data() : nullptr;
+    uint32_t* const vtp = has_weights ? vals_tmp.data() : nullptr;
+    hipLaunchKernelGGL(k_tile_keys, grid_for(nv * 16, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)csc.offsets.data(), (int32_t const*)csc.indices.data(), xcol,
+                       nv, (uint32_t)T, keys.data(), vp);
+    radix_sort_u64_u32(h, keys.data(), vp, keys_tmp.data(), vtp, ne, TK_TILE_SHIFT, TK_TILE_SHIFT + bits_for_u((uint64_t)nJ - 1));
     keys_tmp = dvec<uint64_t>(); vals_tmp = dvec<uint32_t>();
-    tile_off = key_starts(h, keys.data(), ne, nJ);
+    tile_off = key_starts(h, keys.data(), ne, nJ, TK_TILE_SHIFT);
   }
   tr.step("sort by source tile");
   {  // every tile starts on a work-item boundary: item i covers padded positions [i * TP_ITEM, (i + 1) * TP_ITEM)
@@ -405,23 +405,24 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     flag32.resize_discard(ne + 1); ord.resize_discard(ne + 1); dsts.resize_discard(ne);
     HIP_TRY(hipMemsetAsync(flag32.data() + ne, 0, sizeof(uint32_t), h.stream));
     int const g = grid_for(ne, kBlock, 8192);
+    uint32_t const* const vk = has_weights ? vals.data() : nullptr;
     if (!has_weights)
-      hipLaunchKernelGGL(k_tile_emit<uint32_t>, g, kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), ne, (int32_t const*)csc.indices.data(), xcol,
-                         (uint32_t const*)rows.data(), (uint32_t const*)nullptr, (uint32_t const*)d_tile_off.data(), (uint32_t const*)d_tile_off_pad.data(),
-                         (uint32_t)T, t.src16.data(), (uint32_t*)nullptr, t.bits.data(), flag32.data(), dsts.data());
+      hipLaunchKernelGGL(k_tile_emit<uint32_t>, g, kBlock, 0, h.stream, (uint64_t const*)keys.data(), vk, ne, (uint32_t const*)nullptr,
+                         (uint32_t const*)d_tile_off.data(), (uint32_t const*)d_tile_off_pad.data(), t.src16.data(), (uint32_t*)nullptr, t.bits.data(),
+                         flag32.data(), dsts.data());
     else if (wsize == 4)
-      hipLaunchKernelGGL(k_tile_emit<uint32_t>, g, kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), ne, (int32_t const*)csc.indices.data(), xcol,
-                         (uint32_t const*)rows.data(), csc.weights.as<uint32_t const>(), (uint32_t const*)d_tile_off.data(), (uint32_t const*)d_tile_off_pad.data(),
-                         (uint32_t)T, t.src16.data(), t.weights.as<uint32_t>(), t.bits.data(), flag32.data(), dsts.data());
+      hipLaunchKernelGGL(k_tile_emit<uint32_t>, g, kBlock, 0, h.stream, (uint64_t const*)keys.data(), vk, ne, csc.weights.as<uint32_t const>(),
+                         (uint32_t const*)d_tile_off.data(), (uint32_t const*)d_tile_off_pad.data(), t.src16.data(), t.weights.as<uint32_t>(), t.bits.data(),
+                         flag32.data(), dsts.data());
     else
-      hipLaunchKernelGGL(k_tile_emit<uint64_t>, g, kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), ne, (int32_t const*)csc.indices.data(), xcol,
-                         (uint32_t const*)rows.data(), csc.weights.as<uint64_t const>(), (uint32_t const*)d_tile_off.data(), (uint32_t const*)d_tile_off_pad.data(),
-                         (uint32_t)T, t.src16.data(), t.weights.as<uint64_t>(), t.bits.data(), flag32.data(), dsts.data());
+      hipLaunchKernelGGL(k_tile_emit<uint64_t>, g, kBlock, 0, h.stream, (uint64_t const*)keys.data(), vk, ne, csc.weights.as<uint64_t const>(),
+                         (uint32_t const*)d_tile_off.data(), (uint32_t const*)d_tile_off_pad.data(), t.src16.data(), t.weights.as<uint64_t>(), t.bits.data(),
+                         flag32.data(), dsts.data());
     exclusive_scan_u32(h, flag32.data(), ord.data(), ne + 1);
     uint32_t p32 = 0;
     h.read_back(&p32, ord.data() + ne, 1);
     t.n_runs = p32;
-    keys = dvec<uint64_t>(); vals = dvec<uint32_t>(); rows = dvec<uint32_t>();
+    keys = dvec<uint64_t>(); vals = dvec<uint32_t>();
     run_dst.resize_discard(t.n_runs);
     hipLaunchKernelGGL(k_run_dst, g, kBlock, 0, h.stream, (uint32_t const*)flag32.data(), (uint32_t const*)ord.data(), (uint32_t const*)dsts.data(), ne,
                        run_dst.data(), cnt_dst.data());
