@@ -536,6 +536,14 @@ template <> void fill_wt<double>(handle_t const& h, double* p, int64_t n, double
 
 // rows [n_act, n_act + n) have no in-edge: out-weight sums of their live columns in column order, how many of them are dangling,
 // max 1 / out-weight (red[0] = count, red[1] = bits of the max, a non-negative double)
+// flags[i] = v[i] != 0 for i < n, flags[n] = 0
+template <typename WT>
+__global__ void k_nonzero_flags(WT const* v, int64_t n, uint32_t* flags)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i <= n; i += stride) flags[i] = (i < n && v[i] != WT(0)) ? 1u : 0u;
+}
+
 template <typename WT>
 __global__ void k_const_rows_setup(WT const* outw, int32_t const* xcol, int64_t n, int64_t n_act, int64_t c0, WT* outw_c, unsigned long long* red)
 {
@@ -670,7 +678,14 @@ struct pagerank_plan : pagerank_plan_base {
       if (!o.tiled || o.tiled->T != T || getenv("CUGRAPH_AMD_TILED_REBUILD")) {  // (the env: parameter sweeps on one graph, tools/plan_sweep.py)
         auto t = std::make_shared<tiled_csc_t>();
         try {
-          build_tiled_csc(h, g.nv, g.nv, g.ne, o, g.has_weights, sizeof(WT), T, *t, getenv("CUGRAPH_AMD_PAGERANK_DENSE_COLUMNS") == nullptr);
+          bool const compact = getenv("CUGRAPH_AMD_PAGERANK_DENSE_COLUMNS") == nullptr;
+          dvec<uint32_t> live;  // unweighted graph: a vertex has an out-edge <=> its out-degree (= out-weight sum, cached on the graph) is non-zero
+          if (compact && !g.has_weights) {
+            compute_out_weight_sums();
+            live.resize_discard((size_t)g.nv + 1);
+            hipLaunchKernelGGL(k_nonzero_flags<WT>, grid_for(g.nv + 1, kBlock, 4096), kBlock, 0, h.stream, g.out_weight_sums.template as<WT const>(), g.nv, live.data());
+          }
+          build_tiled_csc(h, g.nv, g.nv, g.ne, o, g.has_weights, sizeof(WT), T, *t, compact, live.size() ? live.data() : nullptr);
           o.tiled = t;
         } catch (api_error const& e) {
           // the re-blocked arrays are addressed with 32-bit byte offsets; a graph that outgrows them (or the memory for

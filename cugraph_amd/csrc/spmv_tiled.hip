@@ -325,7 +325,7 @@ __global__ void k_row_abs_max(int32_t const* offsets, WB const* w, int64_t nv, u
 }
 
 void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, orientation_t const& csc, bool has_weights, size_t vsize, int T,
-                     tiled_csc_t& t, bool compact_columns)
+                     tiled_csc_t& t, bool compact_columns, uint32_t const* live_hint)
 {
   // nv = number of column (source) ids and of CSC rows; n_dst <= nv = rows that can have in-edges and get an epilogue
   // (single GPU: n_dst = nv; multi-GPU: the local rows, while the columns span the whole graph)
@@ -341,16 +341,19 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   if (compact_columns && ne > 0) {  // columns = the sources that occur, in id order
     CGA_EXPECTS(nv == n_dst, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: compact columns need a square local graph");
     live_rank.resize_discard((size_t)nv + 1);
-    dvec<uint32_t> live((size_t)nv + 1);
+    dvec<uint32_t> live_own(live_hint ? 1 : (size_t)nv + 1);
     dvec<uint32_t>& rank = live_rank;
-    HIP_TRY(hipMemsetAsync(live.data(), 0, ((size_t)nv + 1) * sizeof(uint32_t), h.stream));
-    hipLaunchKernelGGL(k_mark_sources, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)csc.indices.data(), ne, live.data());
-    exclusive_scan_u32(h, live.data(), rank.data(), nv + 1);
+    if (!live_hint) {  // mark the sources that occur: one random 4-byte store per edge (16 ms at RMAT-26)
+      HIP_TRY(hipMemsetAsync(live_own.data(), 0, ((size_t)nv + 1) * sizeof(uint32_t), h.stream));
+      hipLaunchKernelGGL(k_mark_sources, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)csc.indices.data(), ne, live_own.data());
+    }
+    uint32_t const* const live_p = live_hint ? live_hint : live_own.data();
+    exclusive_scan_u32(h, live_p, rank.data(), nv + 1);
     uint32_t nc = 0;
     h.read_back(&nc, rank.data() + nv, 1);
     t.ncols = nc;
     t.xcol.resize_discard((size_t)nv);
-    hipLaunchKernelGGL(k_xcol, grid_for(nv, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)live.data(), (uint32_t const*)rank.data(), nv, t.xcol.data());
+    hipLaunchKernelGGL(k_xcol, grid_for(nv, kBlock, 8192), kBlock, 0, h.stream, live_p, (uint32_t const*)rank.data(), nv, t.xcol.data());
     h.sync();
   }
   int32_t const* xcol = t.xcol.size() ? t.xcol.data() : nullptr;

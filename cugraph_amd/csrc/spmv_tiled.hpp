@@ -138,7 +138,8 @@ struct tiled_csc_t {
 // nv = number of column (source) ids = CSC rows; n_dst <= nv = leading rows that may have in-edges (single GPU: nv).
 // compact_columns: renumber the sources that have out-edges densely (see tiled_csc_t::xcol); needs nv == n_dst.
 void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, orientation_t const& csc, bool has_weights, size_t vsize, int T,
-                     tiled_csc_t& t, bool compact_columns = false);
+                     tiled_csc_t& t, bool compact_columns = false, uint32_t const* live_hint = nullptr);  // live_hint[v] != 0 <=> v has an
+                                                                                                         // out-edge ([nv + 1], last entry 0): saves the marking pass
 
 template <typename WT>
 struct tiled_x_map {  // where x[c] lives; single GPU: identity.  Multi-GPU all-gather buffer: (c & pmask) * chunk + (c >> plog)
