@@ -11,9 +11,9 @@
 // The reference's algorithm with rng_state = nullopt is deterministic: synchronous local moving (every vertex picks the
 // neighbouring cluster with the largest modularity gain, ties to the smaller cluster id, and moves only "up" or only "down"
 // in alternate sweeps), a modularity test per sweep, contraction per level.  Here the key aggregation is a stable radix sort
-// of the level's edges by (source, cluster of destination) followed by sequential segment sums -- no hash maps, and the
-// summation order is fixed, so the result is bit-reproducible and equal to the oracle's (oracle/oracle.py: louvain) whenever
-// the two see the same edge order.  All arithmetic is fp64, expressions in the reference's operation order, contraction off.
+// of the level's edges by (source, cluster of destination) followed by segment sums -- no hash maps -- and the sums do not depend
+// on any execution order (below), so the result is bit-reproducible and equal to the oracle's (oracle/oracle.py: louvain,
+// oracle.c: orc_louvain).  The gains are fp64, expressions in the reference's operation order, contraction off.
 // Cluster labels of a contracted level = rank of the old label among the labels in use (the reference's labels are whatever
 // its coarsen_graph renumbering assigns; its two C-API goldens come out identically, labels included).
 // Scale (round 2): the per-vertex search for the best move is FLAT over the sorted edges (k_segment_sums / k_segment_best below):
@@ -22,7 +22,8 @@
 // so nothing can overflow): integer addition is associative, so the result does not depend on the order the atomics land in,
 // and for weights that are multiples of 2^-s -- integers, and every fp32 weight of moderate range -- it is exact, i.e. equal to
 // the sequential fp64 sum the oracle forms.  The modularity reductions run over fixed 64 Ki-element chunks + one fixed-order fold.
-// Still one radix sort of all edges per sweep (re-sorting only the rows whose neighbours moved is the next step).
+// One radix sort of all edges per sweep except the first of a level, whose keys are the stored edge order (re-sorting only the
+// rows whose neighbours moved is the next step).
 #pragma clang fp contract(off)
 #include "common.hpp"
 
