@@ -62,6 +62,7 @@ PROTOTYPES = {
     "cugraph_type_erased_device_array_create": (C.c_int, [_P, C.c_size_t, C.c_int, _PP, _PP]),
     "cugraph_type_erased_device_array_create_from_view": (C.c_int, [_P, _P, _PP, _PP]),
     "cugraph_type_erased_device_array_free": (None, [_P]),
+    "cugraph_type_erased_device_array_release": (_P, [_P]),
     "cugraph_type_erased_device_array_view": (_P, [_P]),
     "cugraph_type_erased_device_array_view_as_type": (C.c_int, [_P, C.c_int, _PP, _PP]),
     "cugraph_type_erased_device_array_view_create": (_P, [_P, C.c_size_t, C.c_int]),
@@ -71,6 +72,7 @@ PROTOTYPES = {
     "cugraph_type_erased_device_array_view_pointer": (_P, [_P]),
     "cugraph_type_erased_host_array_create": (C.c_int, [_P, C.c_size_t, C.c_int, _PP, _PP]),
     "cugraph_type_erased_host_array_free": (None, [_P]),
+    "cugraph_type_erased_host_array_release": (_P, [_P]),
     "cugraph_type_erased_host_array_view": (_P, [_P]),
     "cugraph_type_erased_host_array_view_create": (_P, [_P, C.c_size_t, C.c_int]),
     "cugraph_type_erased_host_array_view_free": (None, [_P]),

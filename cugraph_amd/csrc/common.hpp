@@ -101,12 +101,16 @@ inline size_t dtype_size(cugraph_data_type_id_t t)
 // synchronous and slow for the sizes of this library (a BFS call used to spend more time in its dozen hipMalloc / hipFree
 // pairs than in two of its levels; a PageRank plan build waited seconds for the driver after 60 GB of temporaries had just
 // been freed), so freed blocks are kept and handed out again: best fit within 25 % slack, at most CUGRAPH_AMD_POOL_MAX_GB
-// (default 128) cached, everything is released and the request retried when hipMalloc fails.  A cached block is reused
-// without waiting for the work that last touched it: correct for the reference's threading contract (one host thread per
-// handle, one stream per handle, API calls blocking at return -- SURVEY.md section 8b), where a reuse is always ordered
-// behind the previous use on the same stream.  CUGRAPH_AMD_POOL=0 turns the pool off.
+// (default 32) cached, everything is released and the request retried when hipMalloc fails; graph and plan construction hand
+// their large temporaries back to the driver when they end (pool_release_large_blocks), so other allocators of the process
+// (torch, cupy, RMM) find the memory.  Stream order: every API entry point names its handle's stream (H() -> pool_set_stream);
+// a freed block records an event on that stream, and a reuse from a different stream waits for it (a reuse on the same stream
+// is ordered by the stream).  CUGRAPH_AMD_POOL=0 turns the pool off; CUGRAPH_AMD_POOL_DEBUG=1 reports blocks that are freed
+// while their stream still has work queued.
 void* pool_alloc(size_t n_bytes, size_t* granted);
 void pool_free(void* ptr, size_t granted) noexcept;
+void pool_set_stream(hipStream_t s) noexcept;
+size_t pool_release_large_blocks(size_t block_bytes = (size_t)256 << 20) noexcept;
 
 struct dev_buf {
   void* ptr{nullptr};
@@ -172,7 +176,9 @@ struct host_array_view_t {
   cugraph_data_type_id_t type;
 };
 struct host_array_t {
-  std::unique_ptr<uint8_t[]> data;
+  struct free_deleter { void operator()(uint8_t* q) const { std::free(q); } };
+  using storage_t = std::unique_ptr<uint8_t[], free_deleter>;
+  storage_t data;
   size_t size;
   cugraph_data_type_id_t type;
 };
@@ -329,7 +335,9 @@ struct graph_t {  // behind cugraph_graph_t (cpp/src/c_api/graph.hpp:61-77)
 inline handle_t const& H(cugraph_resource_handle_t const* h)
 {
   CGA_EXPECTS(h != nullptr, CUGRAPH_INVALID_HANDLE, "resource handle is NULL");
-  return *reinterpret_cast<handle_t const*>(h);
+  handle_t const& hh = *reinterpret_cast<handle_t const*>(h);
+  pool_set_stream(hh.stream);  // frees and reuses of device blocks made by this call are ordered on this stream
+  return hh;
 }
 inline graph_t& G(cugraph_graph_t* g)
 {

@@ -165,6 +165,19 @@ extern "C" void cugraph_type_erased_device_array_free(cugraph_type_erased_device
   delete reinterpret_cast<device_array_t*>(p);
 }
 
+// array.h:85 / array.cpp:105 (declared by the reference, compiled out there because rmm::device_buffer cannot give up its
+// pointer).  Here an array's storage is one hipMalloc block of its own: the block leaves the library's cache for good and the
+// caller frees it with hipFree; the array object stays valid as an EMPTY array (size 0) until cugraph_type_erased_device_array_free.
+extern "C" void* cugraph_type_erased_device_array_release(cugraph_type_erased_device_array_t* p)
+{
+  if (!p) return nullptr;
+  auto* a   = reinterpret_cast<device_array_t*>(p);
+  void* ptr = a->buf.ptr;
+  a->buf.ptr = nullptr; a->buf.bytes = 0; a->buf.granted = 0;  // ownership moves to the caller: not returned to the pool
+  a->size = 0;
+  return ptr;
+}
+
 extern "C" cugraph_type_erased_device_array_view_t* cugraph_type_erased_device_array_view(cugraph_type_erased_device_array_t* array)
 {
   if (!array) return nullptr;
@@ -218,11 +231,21 @@ extern "C" cugraph_error_code_t cugraph_type_erased_host_array_create(const cugr
   return guarded(error, [&] {
     CGA_EXPECTS(array != nullptr, CUGRAPH_INVALID_INPUT, "array is NULL");
     CGA_EXPECTS(dtype_size(dtype) != 0, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "unsupported data type");
-    auto a  = new host_array_t{std::unique_ptr<uint8_t[]>(new uint8_t[n_elems * dtype_size(dtype) + 1]), n_elems, dtype};
+    void* mem = std::malloc(n_elems * dtype_size(dtype) + 1);  // malloc: cugraph_type_erased_host_array_release hands it to a C caller
+    if (!mem) throw std::bad_alloc();
+    auto a  = new host_array_t{host_array_t::storage_t(static_cast<uint8_t*>(mem)), n_elems, dtype};
     *array  = reinterpret_cast<cugraph_type_erased_host_array_t*>(a);
   });
 }
 extern "C" void cugraph_type_erased_host_array_free(cugraph_type_erased_host_array_t* p) { delete reinterpret_cast<host_array_t*>(p); }
+// array.h:207 / array.cpp:200: the caller takes the storage over and frees it with free(); the array object stays valid, empty
+extern "C" void* cugraph_type_erased_host_array_release(cugraph_type_erased_host_array_t* p)
+{
+  if (!p) return nullptr;
+  auto* a = reinterpret_cast<host_array_t*>(p);
+  a->size = 0;
+  return a->data.release();
+}
 extern "C" cugraph_type_erased_host_array_view_t* cugraph_type_erased_host_array_view(cugraph_type_erased_host_array_t* array)
 {
   if (!array) return nullptr;
@@ -343,25 +366,64 @@ extern "C" cugraph_error_code_t cugraph_data_type_id_from_dlpack(const DLDataTyp
 #include <mutex>
 namespace cga {
 namespace {
+// The stream of the API call this host thread is executing (set by H() at every entry point).  A freed block remembers the
+// stream it was last used on together with an event recorded behind that use; a reuse from ANOTHER stream (a second handle in
+// the same process, or a handle whose stream was swapped with cugraph_amd_handle_set_stream) waits for the event first.  A reuse
+// on the same stream is ordered by the stream itself and costs nothing.
+thread_local hipStream_t tl_stream = nullptr;
+thread_local bool tl_stream_known  = false;
+
+struct free_block_t {
+  void* ptr;
+  hipStream_t stream;
+  hipEvent_t ev;  // nullptr: the freeing thread had no API stream (static destruction, host-only paths)
+};
+
 struct pool_t {
   std::mutex m;
-  std::multimap<std::pair<int, size_t>, void*> free_blocks;  // (device, size) -> block
+  std::multimap<std::pair<int, size_t>, free_block_t> free_blocks;  // (device, size) -> block
+  std::vector<hipEvent_t> spare_events;
   size_t cached{0};
-  size_t max_cached{(size_t)128 << 30};
+  size_t max_cached{(size_t)32 << 30};
   bool enabled{true};
+  bool debug{false};
   pool_t()
   {
     if (char const* e = getenv("CUGRAPH_AMD_POOL")) enabled = atoi(e) != 0;
     if (char const* e = getenv("CUGRAPH_AMD_POOL_MAX_GB")) max_cached = (size_t)std::max(0.0, atof(e)) << 30;
+    debug = getenv("CUGRAPH_AMD_POOL_DEBUG") != nullptr;
+  }
+  hipEvent_t get_event()
+  {
+    if (!spare_events.empty()) { hipEvent_t e = spare_events.back(); spare_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return e;
+  }
+  void put_event(hipEvent_t e)
+  {
+    if (!e) return;
+    if (spare_events.size() < 256) spare_events.push_back(e); else (void)hipEventDestroy(e);
+  }
+  void drop_locked(std::multimap<std::pair<int, size_t>, free_block_t>::iterator it)
+  {
+    if (it->second.ev) { (void)hipEventSynchronize(it->second.ev); put_event(it->second.ev); }
+    (void)hipFree(it->second.ptr);
+    cached -= it->first.second;
+    free_blocks.erase(it);
   }
   void trim_locked(size_t keep)
   {  // largest blocks first
-    while (cached > keep && !free_blocks.empty()) {
-      auto it = std::prev(free_blocks.end());
-      (void)hipFree(it->second);
-      cached -= it->first.second;
-      free_blocks.erase(it);
+    while (cached > keep && !free_blocks.empty()) drop_locked(std::prev(free_blocks.end()));
+  }
+  size_t trim_blocks_above_locked(size_t block_bytes)
+  {
+    size_t freed = 0;
+    for (auto it = free_blocks.begin(); it != free_blocks.end();) {
+      auto cur = it++;
+      if (cur->first.second > block_bytes) { freed += cur->first.second; drop_locked(cur); }
     }
+    return freed;
   }
 };
 pool_t& pool()
@@ -382,6 +444,8 @@ size_t round_size(size_t n)
 }
 }  // namespace
 
+void pool_set_stream(hipStream_t s) noexcept { tl_stream = s; tl_stream_known = true; }
+
 void* pool_alloc(size_t n_bytes, size_t* granted)
 {
   pool_t& p = pool();
@@ -389,14 +453,25 @@ void* pool_alloc(size_t n_bytes, size_t* granted)
   (void)hipGetDevice(&dev);
   size_t const want = p.enabled ? round_size(n_bytes) : n_bytes;
   if (p.enabled) {
-    std::lock_guard<std::mutex> lock(p.m);
-    auto it = p.free_blocks.lower_bound({dev, want});
-    if (it != p.free_blocks.end() && it->first.first == dev && it->first.second <= want + want / 4) {
-      void* ptr = it->second;
-      *granted  = it->first.second;
-      p.cached -= it->first.second;
-      p.free_blocks.erase(it);
-      return ptr;
+    free_block_t blk{nullptr, nullptr, nullptr};
+    {
+      std::lock_guard<std::mutex> lock(p.m);
+      auto it = p.free_blocks.lower_bound({dev, want});
+      if (it != p.free_blocks.end() && it->first.first == dev && it->first.second <= want + want / 4) {
+        blk      = it->second;
+        *granted = it->first.second;
+        p.cached -= it->first.second;
+        p.free_blocks.erase(it);
+      }
+    }
+    if (blk.ptr) {
+      if (blk.ev) {
+        // last used on another stream (or the requester's stream is unknown): order the reuse behind that use
+        if (!tl_stream_known || blk.stream != tl_stream) (void)hipEventSynchronize(blk.ev);
+        std::lock_guard<std::mutex> lock(p.m);
+        p.put_event(blk.ev);
+      }
+      return blk.ptr;
     }
   }
   void* ptr    = nullptr;
@@ -423,10 +498,28 @@ void pool_free(void* ptr, size_t granted) noexcept
   (void)hipGetDevice(&dev);
   hipPointerAttribute_t attr;
   if (hipPointerGetAttributes(&attr, ptr) == hipSuccess) dev = attr.device; else (void)hipGetLastError();
+  free_block_t blk{ptr, tl_stream, nullptr};
+  if (p.debug && tl_stream_known && hipStreamQuery(tl_stream) == hipErrorNotReady)
+    fprintf(stderr, "[pool] block %p (%zu bytes) freed while its stream still has work queued (reuse is ordered by the recorded event)\n", ptr, granted);
+  (void)hipGetLastError();
   std::lock_guard<std::mutex> lock(p.m);
-  p.free_blocks.insert({{dev, granted}, ptr});
+  if (tl_stream_known) {
+    blk.ev = p.get_event();
+    if (blk.ev && hipEventRecord(blk.ev, tl_stream) != hipSuccess) { (void)hipGetLastError(); p.put_event(blk.ev); blk.ev = nullptr; (void)hipDeviceSynchronize(); }
+  }
+  p.free_blocks.insert({{dev, granted}, blk});
   p.cached += granted;
   if (p.cached > p.max_cached) p.trim_locked(p.max_cached / 2);
+}
+
+// Graph and plan construction free tens of GB of temporaries (sort buffers): those go back to the driver when the build ends,
+// so that torch / cupy / RMM allocations of the same process do not find the memory held by this library's cache; the small and
+// medium blocks the per-call paths (BFS / SSSP state, result columns) recycle stay cached.
+size_t pool_release_large_blocks(size_t block_bytes) noexcept
+{
+  pool_t& p = pool();
+  std::lock_guard<std::mutex> lock(p.m);
+  return p.trim_blocks_above_locked(block_bytes);
 }
 }  // namespace cga
 

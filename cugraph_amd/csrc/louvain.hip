@@ -406,7 +406,8 @@ double fixed_scale(double m)
 struct louvain_stats_t { int sweeps{0}, sweeps_in_level{0}; };
 
 // one level (the body of the while loop of detail::louvain, louvain_impl.cuh:78-262): accepted clustering and its modularity
-double run_level(handle_t const& h, level_t const& L, double m, double threshold, double resolution, dvec<int32_t>& accepted, louvain_stats_t& st)
+double run_level(handle_t const& h, level_t const& L, double m, double threshold, double resolution, double noise_floor, dvec<int32_t>& accepted,
+                 louvain_stats_t& st)
 {
   int64_t const nv = L.nv, ne = L.ne;
   int const g_v = grid_for(nv, kBlock, 8192), g_e = grid_for(ne, kBlock, 8192);
@@ -440,7 +441,8 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   double new_q = modularity();
   double cur_q = new_q - 1.0;
   bool up_down = true;
-  double const min_gain = std::max(threshold / (double)std::max<int64_t>(nv, 1), 1e-15);  // compute_louvain_min_vertex_move_gain
+  // compute_louvain_min_vertex_move_gain with the reference's noise floor per weight type (common_methods.cuh:52-66)
+  double const min_gain = std::max(threshold / (double)std::max<int64_t>(nv, 1), noise_floor);
   while (new_q > cur_q + threshold) {
     cur_q = new_q;
     ++st.sweeps;
@@ -530,7 +532,7 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
       dvec<int32_t> c;
       louvain_stats_t st;
       auto const t_level = std::chrono::steady_clock::now();
-      double const q = run_level(h, L, m, threshold, resolution, c, st);
+      double const q = run_level(h, L, m, threshold, resolution, g.weight_type == FLOAT64 ? 1e-15 : 1e-12, c, st);
       if (trace)
         fprintf(stderr, "[louvain] level %zu: %lld vertices, %lld edges, %d sweeps, Q = %.9f, %.1f ms\n", levels, (long long)L.nv, (long long)L.ne, st.sweeps, q,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_level).count());

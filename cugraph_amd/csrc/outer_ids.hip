@@ -92,7 +92,6 @@ void outer_collect(handle_t const& h, device_array_view_t const* const* cols, in
   if (total == 0) return;
   CGA_EXPECTS(total < ((int64_t)1 << 32), CUGRAPH_ALLOC_ERROR, "too many vertex ids for the id compaction (positions are 32-bit)");
   dvec<uint64_t> keys(total), keys_tmp(total);
-  dvec<uint32_t> vals(total), vals_tmp(total);
   int64_t at = 0;
   for (int c = 0; c < ncols; ++c) {
     if (!cols[c] || cols[c]->size == 0) continue;
@@ -102,8 +101,8 @@ void outer_collect(handle_t const& h, device_array_view_t const* const* cols, in
     else hipLaunchKernelGGL(k_ids_to_keys<int32_t>, g, kBlock, 0, h.stream, cols[c]->as<int32_t const>(), n, keys.data() + at);
     at += n;
   }
-  radix_sort_u64_u32(h, keys.data(), vals.data(), keys_tmp.data(), vals_tmp.data(), total, 0, 64);  // payload unused
-  keys_tmp = dvec<uint64_t>(); vals_tmp = dvec<uint32_t>();
+  radix_sort_u64_u32(h, keys.data(), nullptr, keys_tmp.data(), nullptr, total, 0, 64);  // keys only
+  keys_tmp = dvec<uint64_t>();
   dvec<uint32_t> flag(total + 1), pos(total + 1);
   hipLaunchKernelGGL(k_unique_flags, grid_for(total, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), total, flag.data());
   HIP_TRY(hipMemsetAsync(flag.data() + total, 0, sizeof(uint32_t), h.stream));

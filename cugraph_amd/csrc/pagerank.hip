@@ -1295,6 +1295,7 @@ pagerank_plan_base* make_plan(cugraph_resource_handle_t const* handle, cugraph_g
   device_array_view_t const* ow = c_ow.get(h, g, V(ow_v), "precomputed_vertex_out_weight_vertices");
   device_array_view_t const* ig = c_ig.get(h, g, V(ig_v), "initial_guess_vertices");
   device_array_view_t const* pv = c_p.get(h, g, V(p_v), "personalization_vector");
+  struct release_temporaries { ~release_temporaries() { pool_release_large_blocks(); } } on_exit;  // the plan build's sort buffers
   if (g.weight_type == FLOAT64) {
     auto p = std::make_unique<pagerank_plan<double>>(h, g, alpha);
     p->create(ow, V(ow_s), ig, V(ig_s), pv, V(p_s));

@@ -3,6 +3,7 @@
 // construction sits on (renumber_edgelist_impl.cuh:425-829,
 // structure/detail/structure_utils.cuh:297-464).  No Thrust / CUB / rocPRIM / hipCUB.
 #include "common.hpp"
+#include <mutex>
 
 namespace cga {
 
@@ -402,7 +403,8 @@ void histogram_i32_mapped(handle_t const& h, int32_t const* keys, int64_t n, int
 {
   if (n <= 0) return;
   char const* mode = getenv("CUGRAPH_AMD_HISTOGRAM");  // "direct" / "partition" force a path (tests, A/B runs)
-  bool const partition = mode && mode[0] == 'p' ? range > 0 : (n >= ((int64_t)1 << 24) && range >= ((int64_t)1 << 20) && !(mode && mode[0] == 'd'));
+  bool partition = mode && mode[0] == 'p' ? range > 0 : (n >= ((int64_t)1 << 24) && range >= ((int64_t)1 << 20) && !(mode && mode[0] == 'd'));
+  if (h.lds_per_block < (size_t)HW_WINDOW * sizeof(uint32_t) + 1024) partition = false;  // the counting window must fit one workgroup's LDS
   if (!partition) {
     hipLaunchKernelGGL(k_histogram, (int)((n + HC_CHUNK - 1) / HC_CHUNK), 256, 0, h.stream, keys, n, vmin, rank, counts);
     return;
@@ -413,10 +415,15 @@ void histogram_i32_mapped(handle_t const& h, int32_t const* keys, int64_t n, int
   while (bits < 63 && ((uint64_t)(range - 1) >> bits) != 0) ++bits;
   int const low_bits = bits > 16 ? bits - 16 : 0;
   radix_sort_u64_u32(h, wide.data(), nullptr, tmp.data(), nullptr, n, low_bits, bits);
-  static bool attr_done = false;
-  if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_histogram_window), hipFuncAttributeMaxDynamicSharedMemorySize, HW_WINDOW * 4));
-    attr_done = true;
+  {  // per device (the attribute belongs to the function ON a device), guarded for callers on several host threads
+    static std::mutex attr_m;
+    static std::vector<bool> attr_done;
+    std::lock_guard<std::mutex> lock(attr_m);
+    if ((int)attr_done.size() <= h.device) attr_done.resize(h.device + 1, false);
+    if (!attr_done[h.device]) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_histogram_window), hipFuncAttributeMaxDynamicSharedMemorySize, HW_WINDOW * 4));
+      attr_done[h.device] = true;
+    }
   }
   hipLaunchKernelGGL(k_histogram_window, (int)((n + HW_CHUNK - 1) / HW_CHUNK), 1024, HW_WINDOW * sizeof(uint32_t), h.stream,
                      (uint64_t const*)wide.data(), n, low_bits, rank, counts);

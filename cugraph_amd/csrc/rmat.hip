@@ -257,12 +257,12 @@ __global__ void k_iota_i32(int32_t* out, uint64_t n)
   uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
   for (; k < n; k += stride) out[k] = (int32_t)k;
 }
-__global__ void k_uniform_i32(int32_t* out, uint64_t n, uint64_t seed, uint64_t first, int32_t lo, uint32_t span)
+__global__ void k_uniform_i32(int32_t* out, uint64_t n, uint64_t seed, uint64_t first, int32_t lo, uint64_t span)
 {
   uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
   for (; k < n; k += stride) {
     uint64_t const z = splitmix64_at(seed ^ 0xA0761D6478BD642Full, first + k);
-    out[k]           = lo + (int32_t)(uint32_t)(((z >> 32) * (uint64_t)span) >> 32);  // uniform in [lo, lo + span)
+    out[k]           = (int32_t)((int64_t)lo + (int64_t)(((z >> 32) * span) >> 32));  // uniform in [lo, lo + span), span <= 2^32
   }
 }
 }  // namespace
@@ -302,7 +302,7 @@ extern "C" cugraph_error_code_t cugraph_generate_edge_types(const cugraph_resour
     HIP_TRY(hipSetDevice(h.device));
     delete c.types;
     c.types = new device_array_t(n, INT32);
-    uint32_t const span = (uint32_t)((int64_t)max_edge_type - (int64_t)min_edge_type + 1);
+    uint64_t const span = (uint64_t)((int64_t)max_edge_type - (int64_t)min_edge_type + 1);  // up to 2^32: 64 bits
     if (n > 0)
       hipLaunchKernelGGL(k_uniform_i32, grid_for((int64_t)n, kBlock, 16384), kBlock, 0, h.stream, c.types->buf.as<int32_t>(), (uint64_t)n, st.seed, st.drawn,
                          min_edge_type, span);

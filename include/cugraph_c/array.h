@@ -22,6 +22,10 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_type_erased_device_array_create_from
   const cugraph_resource_handle_t* handle, const cugraph_type_erased_device_array_view_t* view,
   cugraph_type_erased_device_array_t** array, cugraph_error_t** error);
 CUGRAPH_EXPORT void cugraph_type_erased_device_array_free(cugraph_type_erased_device_array_t* p);
+/* cpp/include/cugraph_c/array.h:85 (declared by the reference, compiled out there: cpp/src/c_api/array.cpp:105).  Gives up the
+ * array's device storage: the caller owns the returned pointer and frees it with hipFree(); `p` stays valid as an empty array
+ * and is still freed with cugraph_type_erased_device_array_free. */
+CUGRAPH_EXPORT void* cugraph_type_erased_device_array_release(cugraph_type_erased_device_array_t* p);
 CUGRAPH_EXPORT cugraph_type_erased_device_array_view_t* cugraph_type_erased_device_array_view(
   cugraph_type_erased_device_array_t* array);
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_type_erased_device_array_view_as_type(
@@ -40,6 +44,8 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_type_erased_host_array_create(
   const cugraph_resource_handle_t* handle, size_t n_elems, cugraph_data_type_id_t dtype,
   cugraph_type_erased_host_array_t** array, cugraph_error_t** error);
 CUGRAPH_EXPORT void cugraph_type_erased_host_array_free(cugraph_type_erased_host_array_t* p);
+/* array.h:207 / array.cpp:200: same for host arrays; the storage comes from malloc(), the caller frees it with free(). */
+CUGRAPH_EXPORT void* cugraph_type_erased_host_array_release(cugraph_type_erased_host_array_t* p);
 CUGRAPH_EXPORT cugraph_type_erased_host_array_view_t* cugraph_type_erased_host_array_view(
   cugraph_type_erased_host_array_t* array);
 CUGRAPH_EXPORT cugraph_type_erased_host_array_view_t* cugraph_type_erased_host_array_view_create(

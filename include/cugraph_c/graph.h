@@ -4,10 +4,13 @@
  * :989 cugraph_graph_create_sg_from_csr, :1097 cugraph_graph_free).
  *
  * Inputs are copied, never mutated (graph_sg.cpp:98-183).  Type rules follow graph_sg.cpp:745-779:
- * src/dst (and `vertices`) must share one integer type; this build supports INT32 vertices/edges with
- * FLOAT32 or FLOAT64 weights and returns CUGRAPH_UNSUPPORTED_TYPE_COMBINATION otherwise; an INT32
- * graph must have fewer than INT32_MAX edges (graph_sg.cpp:918-922).
- * edge_ids / edge_type_ids / edge times are accepted only as NULL (not on the PageRank/BFS/SSSP path).
+ * src / dst / `vertices` are INT32 or INT64 (mixed widths promote to INT64, :745-754), weights FLOAT32 or FLOAT64, anything
+ * else is CUGRAPH_UNSUPPORTED_TYPE_COMBINATION.  INT64 ids and INT32 ids spread over a sparse range are translated to compact
+ * 32-bit internal ids at this boundary (csrc/outer_ids.hip) and translated back in every result; limits, named in the error
+ * message: fewer than 2^31 distinct vertex ids per graph (edge counts: see DESIGN.md section 6).
+ * edge_ids (INT32 / INT64), edge_type_ids (INT32) and edge start / end times are VALIDATED (sizes and types as
+ * graph_sg.cpp:781-830) and then NOT STORED: no algorithm behind this library reads edge properties, and
+ * cugraph_decompress_to_edgelist returns NULL for those columns -- a caller that needs them back must keep its own copy.
  * drop_self_loops / drop_multi_edges / symmetrize are applied in the reference's order before renumbering
  * (graph_sg.cpp:185-248; csrc/edgelist.hip) and do_expensive_check runs the reference's input checks.
  *

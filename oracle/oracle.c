@@ -339,6 +339,9 @@ ORC_SSSP_MIN_PRED(orc_sssp_min_pred_f64, double, DBL_MAX)
  * marker array instead of the numpy version's lexsort: same sums in the same order), clusters are then visited in ascending
  * order.  Edges must be grouped by source (any order inside a source).
  * ---------------------------------------------------------------------------------------------- */
+/* louvain_delta_modularity_noise_floor (common_methods.cuh:52-58): 1e-12 for float graphs, 1e-15 for double */
+static double lv_noise_floor = 1e-15;
+void orc_louvain_set_noise_floor(double f) { lv_noise_floor = f; }
 typedef struct { int32_t c; double w; } lv_cw;
 static int cmp_lv_cw(const void* x, const void* y) { int32_t a = ((const lv_cw*)x)->c, b = ((const lv_cw*)y)->c; return (a > b) - (a < b); }
 
@@ -371,7 +374,7 @@ static double lv_level(int64_t nv, int64_t ne, const int32_t* src, const int32_t
   double new_q = lv_q(ne, src, dst, w, c, nv, a, m, res), cur_q = new_q - 1.0;
   int up_down = 1;
   double min_gain = threshold / (double)(nv > 0 ? nv : 1);
-  if (min_gain < 1e-15) min_gain = 1e-15;
+  if (min_gain < lv_noise_floor) min_gain = lv_noise_floor;
   while (new_q > cur_q + threshold) {
     cur_q = new_q;
     ++*sweeps;

@@ -300,7 +300,7 @@ def louvain_modularity(src, dst, w, clusters, resolution=1.0):
     return internal / m - (resolution * (a * a).sum()) / (m * m)
 
 
-def _louvain_level(nv, src, dst, w, threshold, resolution, m):
+def _louvain_level(nv, src, dst, w, threshold, resolution, m, noise_floor=1e-15):
     """One level: returns (clusters of the level's vertices, Q reached)."""
     k = np.zeros(nv)
     np.add.at(k, src, w)                                     # vertex weights (out-weight sums)
@@ -315,7 +315,7 @@ def _louvain_level(nv, src, dst, w, threshold, resolution, m):
     new_q = q_of(c, a)
     cur_q = new_q - 1.0
     up_down = True
-    min_gain = max(threshold / max(nv, 1), 1e-15)            # compute_louvain_min_vertex_move_gain, fp64 noise floor
+    min_gain = max(threshold / max(nv, 1), noise_floor)      # compute_louvain_min_vertex_move_gain (common_methods.cuh:60-66)
     order = np.arange(src.size)
     while new_q > cur_q + threshold:
         cur_q = new_q
@@ -361,9 +361,17 @@ def _louvain_level(nv, src, dst, w, threshold, resolution, m):
     return accepted, cur_q
 
 
-def louvain(nv, src, dst, w=None, max_level=100, threshold=1e-7, resolution=1.0):
+def louvain_noise_floor(w):
+    """louvain_delta_modularity_noise_floor (common_methods.cuh:52-58): 1e-12 for a float graph, 1e-15 for a double one.
+    A graph without weights, or with float32 weights, is a float graph at the C API (graph_sg.cpp:775-779)."""
+    return 1e-15 if (w is not None and np.asarray(w).dtype == np.float64) else 1e-12
+
+
+def louvain(nv, src, dst, w=None, max_level=100, threshold=1e-7, resolution=1.0, noise_floor=None):
     """Returns (clusters per vertex, modularity, levels).  Graph = directed edge list (an undirected graph lists both
     directions, as the C API's symmetric graphs do); w = None means weight 1."""
+    if noise_floor is None:
+        noise_floor = louvain_noise_floor(w)
     src, dst = np.asarray(src, np.int64), np.asarray(dst, np.int64)
     w = np.ones(src.size) if w is None else np.asarray(w, np.float64)
     m = w.sum()
@@ -373,7 +381,7 @@ def louvain(nv, src, dst, w=None, max_level=100, threshold=1e-7, resolution=1.0)
     cur_nv = nv
     while levels < max_level:
         levels += 1
-        c, q = _louvain_level(cur_nv, src, dst, w, threshold, resolution, m)
+        c, q = _louvain_level(cur_nv, src, dst, w, threshold, resolution, m, noise_floor)
         if q <= best:
             break
         best = q
@@ -395,7 +403,7 @@ def louvain(nv, src, dst, w=None, max_level=100, threshold=1e-7, resolution=1.0)
     return part.astype(np.int32), float(best), levels
 
 
-def louvain_c(nv, src, dst, w=None, max_level=100, threshold=1e-7, resolution=1.0):
+def louvain_c(nv, src, dst, w=None, max_level=100, threshold=1e-7, resolution=1.0, noise_floor=None):
     """oracle.c: orc_louvain -- the same algorithm as louvain() above, in C, for graphs beyond the numpy version's reach
     (tests/test_oracle.py checks the two against each other).  Returns (clusters, modularity, levels, sweeps)."""
     src, dst = _i32(src), _i32(dst)
@@ -407,6 +415,7 @@ def louvain_c(nv, src, dst, w=None, max_level=100, threshold=1e-7, resolution=1.
     clusters = np.empty(nv, np.int32)
     q = C.c_double(0.0)
     sweeps = C.c_int(0)
+    lib().orc_louvain_set_noise_floor(C.c_double(louvain_noise_floor(w) if noise_floor is None else noise_floor))
     fn = lib().orc_louvain
     fn.restype = C.c_int
     levels = fn(C.c_int64(nv), C.c_int64(src.size), _p(src), _p(dst), None if wd is None else _p(wd), C.c_int64(max_level), C.c_double(threshold),

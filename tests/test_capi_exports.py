@@ -81,6 +81,21 @@ def test_error_objects_are_null_safe(library):
     assert l.cugraph_type_erased_host_array_size(v) == 5 and l.cugraph_type_erased_host_array_type(v) == library.INT32
     l.cugraph_type_erased_host_array_view_free(v)
     l.cugraph_type_erased_host_array_free(arr)
+    # array.h:207: release hands the malloc'ed storage to the caller; the array object survives as an empty array
+    assert l.cugraph_type_erased_host_array_create(None, 3, library.INT64, ctypes.byref(arr), ctypes.byref(err)) == 0
+    v = l.cugraph_type_erased_host_array_view(arr)
+    ptr = l.cugraph_type_erased_host_array_pointer(v)
+    l.cugraph_type_erased_host_array_view_free(v)
+    ctypes.memmove(ptr, (ctypes.c_int64 * 3)(7, 8, 9), 24)
+    raw = l.cugraph_type_erased_host_array_release(arr)
+    assert raw == ptr and list((ctypes.c_int64 * 3).from_address(raw)) == [7, 8, 9]
+    v = l.cugraph_type_erased_host_array_view(arr)
+    assert l.cugraph_type_erased_host_array_size(v) == 0
+    l.cugraph_type_erased_host_array_view_free(v)
+    l.cugraph_type_erased_host_array_free(arr)  # must not free `raw`
+    assert list((ctypes.c_int64 * 3).from_address(raw)) == [7, 8, 9]
+    ctypes.CDLL(None).free(ctypes.c_void_p(raw))
+    assert l.cugraph_type_erased_host_array_release(None) is None and l.cugraph_type_erased_device_array_release(None) is None
     # a NULL handle is reported, not dereferenced
     code = l.cugraph_type_erased_device_array_create(None, 4, library.INT32, ctypes.byref(arr), ctypes.byref(err))
     assert code == library.CUGRAPH_INVALID_HANDLE

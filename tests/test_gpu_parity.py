@@ -1292,3 +1292,46 @@ def test_graph_creation_flags_vs_networkx(cg, handle):
     # and the result is symmetric in NetworkX's eyes too
     H = nx.DiGraph(); H.add_edges_from(zip(gs.tolist(), gd.tolist()))
     assert all(H.has_edge(b, a) for a, b in H.edges())
+
+
+def test_device_array_release_and_pool_trim(cg, handle):
+    """cugraph_type_erased_device_array_release (cpp/include/cugraph_c/array.h:85): the caller takes the device block over and
+    frees it with hipFree; the array object stays a valid empty array.  Also: graph construction returns its large temporaries
+    to the driver (the cache keeps no block above 256 MiB afterwards)."""
+    import ctypes as C
+
+    import torch
+
+    l, capi = cg.pylib.capi.lib(), cg.pylib.capi
+    arr, err = C.c_void_p(), C.c_void_p()
+    assert l.cugraph_type_erased_device_array_create(handle.c_resource_handle_ptr, 1000, capi.INT32, C.byref(arr), C.byref(err)) == 0
+    view = l.cugraph_type_erased_device_array_view(arr)
+    host = np.arange(1000, dtype=np.int32)
+    assert l.cugraph_type_erased_device_array_view_copy_from_host(handle.c_resource_handle_ptr, view, host.ctypes.data_as(C.c_void_p), C.byref(err)) == 0
+    ptr = l.cugraph_type_erased_device_array_view_pointer(view)
+    l.cugraph_type_erased_device_array_view_free(view)
+    raw = l.cugraph_type_erased_device_array_release(arr)
+    assert raw == ptr
+    v2 = l.cugraph_type_erased_device_array_view(arr)
+    assert l.cugraph_type_erased_device_array_view_size(v2) == 0
+    l.cugraph_type_erased_device_array_view_free(v2)
+    l.cugraph_type_erased_device_array_free(arr)  # must not free `raw`
+    back = np.empty(1000, np.int32)
+    borrowed = l.cugraph_type_erased_device_array_view_create(raw, 1000, capi.INT32)
+    assert l.cugraph_type_erased_device_array_view_copy_to_host(handle.c_resource_handle_ptr, back.ctypes.data_as(C.c_void_p), borrowed, C.byref(err)) == 0
+    l.cugraph_type_erased_device_array_view_free(borrowed)
+    assert np.array_equal(back, host)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipFree.argtypes = [C.c_void_p]
+    assert hip.hipFree(raw) == 0
+    # large temporaries of a graph build leave the cache when the build returns
+    src, dst = cg.generate_rmat_edgelist(handle, 22, 16 << 22)  # 512 MiB of edge-list temporaries and more
+    g = cg.SGGraph(handle, cg.GraphProperties(is_multigraph=True), src, dst, None, store_transposed=True, renumber=True)
+    del src, dst
+    cached = l.cugraph_amd_memory_pool_cached_bytes()
+    assert cached <= (32 << 30)
+    n_before = l.cugraph_amd_memory_pool_trim()
+    assert n_before == cached and l.cugraph_amd_memory_pool_cached_bytes() == 0
+    v, pr, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 3, False, fail_on_nonconvergence=False)
+    assert abs(float(pr.sum()) - 1.0) < 1e-4
+    torch.cuda.synchronize()
