@@ -175,15 +175,41 @@ def main():
     ap.add_argument("--cpu-scale", type=int, default=22, help="RMAT scale of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-timing correctness check of the timed result")
+    ap.add_argument("--no-extras", action="store_true", help="skip the bounded BFS / SSSP (RMAT-24) and Louvain (RMAT-22) sub-lines appended at N = 1")
+    ap.add_argument("--extra-roots", type=int, default=16)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, the launch line the driver uses)
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        try:
+            import torch
+
+            if torch.cuda.device_count() < args.gpus:  # fewer devices than ranks: refuse, unless the plumbing switch is set
+                if env.get("CUGRAPH_AMD_MG_TEST_SINGLE_GPU") != "1":
+                    print(json.dumps({"error": f"--gpus {args.gpus} needs {args.gpus} devices, torch sees {torch.cuda.device_count()} "
+                                               "(CUGRAPH_AMD_MG_TEST_SINGLE_GPU=1 runs all ranks on cuda:0 over gloo as a plumbing check)"}), flush=True)
+                    sys.exit(2)
+        except ImportError:
+            pass
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
     if args.gpus > 1 or world > 1:
         from cugraph_amd import mg
 
         out = mg.bench_main(args)
         if rank == 0 and out is not None:
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(min(args.cpu_scale, args.scale), 10)
             print(json.dumps(out), flush=True)
         try:  # orderly shutdown of the RCCL communicator (every rank has passed bench_main's final barrier)
             import torch.distributed as dist
@@ -201,16 +227,9 @@ def main():
     avg2_s = kernel2_ms / 1e3 / max(launches2, 1) if launches2 else 0.0
     avg_kernel_s = avg1_s + avg2_s  # one iteration = one launch of each; the algorithmic bytes are those of the iteration
     achieved = bytes_per_launch / avg_kernel_s / 1e9 if launches else None
-    traffic, traffic_source = None, None
-    tfile = ROOT / "profiles" / "traffic_latest.json"
-    if tfile.exists():
-        try:
-            t = json.loads(tfile.read_text())
-            if t.get("scale") == args.scale:
-                traffic = t.get("hbm_bytes_per_launch")
-                traffic_source = f"profiles/traffic_latest.json ({t.get('source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes')}); not measured by this run"
-        except Exception:
-            traffic = None
+    from bench_traversal import counter_traffic
+
+    traffic, traffic_source = counter_traffic(f"pagerank_s{args.scale}")
     out = {
         "metric": f"pagerank_mteps_rmat{args.scale}", "value": round(value, 1), "unit": "MTEPS", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
@@ -232,7 +251,48 @@ def main():
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(min(args.cpu_scale, args.scale), 10)
         out["cpu_baseline"]["networkx"] = networkx_baseline(min(16, args.scale), 10)
+    if not args.no_extras:
+        out["extra"] = extras(args)
     print(json.dumps(out), flush=True)
+
+
+def extras(args):
+    """BASELINE.json configs 3 and 5 through the driver, OUTSIDE the PageRank timed region and bounded to a few seconds each:
+    BFS + SSSP at RMAT-24 (integer weights 1..255 and unit weights; --extra-roots roots of the Graph500 protocol) and Louvain at
+    RMAT-22, each with its own `roofline`, `cpu_baseline` (oracle on a smaller sample) and `check`.  The same functions print the
+    stand-alone lines of bench_traversal.py / bench_louvain.py."""
+    import torch
+
+    import cugraph_amd as cg
+    from bench_louvain import louvain_bench
+    from bench_traversal import traversal_bench
+
+    res = {}
+    h = cg.ResourceHandle()
+    cg.pylib.capi.lib().cugraph_amd_memory_pool_trim()
+    torch.cuda.empty_cache()
+    try:
+        t = traversal_bench(cg, h, 24, 16, args.extra_roots, "int", False, False, True, 20, not args.no_cpu_baseline, not args.no_check)
+        res["bfs"] = dict(t["bfs"], workload=t["workload"], metric="bfs_mteps_rmat24", unit="MTEPS", value=t["bfs"]["harmonic_mean_mteps"],
+                          cpu_baseline=None if "cpu_baseline" not in t else {k: v for k, v in t["cpu_baseline"].items() if k != "sssp_value"})
+        cb = t.get("cpu_baseline")
+        res["sssp"] = dict(t["sssp"], workload=t["workload"], metric="sssp_mteps_rmat24_int_weights", unit="MTEPS", value=t["sssp"]["harmonic_mean_mteps"],
+                           cpu_baseline=None if cb is None else dict({k: v for k, v in cb.items() if k not in ("value", "sssp_value")}, value=cb["sssp_value"]))
+        del t
+        cg.pylib.capi.lib().cugraph_amd_memory_pool_trim()
+        torch.cuda.empty_cache()
+        u = traversal_bench(cg, h, 24, 16, args.extra_roots, "unit", False, False, True, 20, False, not args.no_check)
+        res["sssp_unit"] = dict(u["sssp"], workload=u["workload"], metric="sssp_mteps_rmat24_unit_weights", unit="MTEPS", value=u["sssp"]["harmonic_mean_mteps"])
+        del u
+    except Exception as e:  # an extra must never cost the headline line
+        res["traversal_error"] = repr(e)
+    cg.pylib.capi.lib().cugraph_amd_memory_pool_trim()
+    torch.cuda.empty_cache()
+    try:
+        res["louvain"] = louvain_bench(cg, h, 22, 8, 2, 0 if args.no_cpu_baseline else 18)
+    except Exception as e:
+        res["louvain_error"] = repr(e)
+    return res
 
 
 if __name__ == "__main__":

@@ -35,6 +35,74 @@ def undirected_rmat(cg, h, scale, edge_factor, seed=5):
     return s2[order].to(torch.int32), d2[order].to(torch.int32), w2[order]
 
 
+def louvain_bench(cg, h, scale=22, edge_factor=8, repeats=3, cpu_scale=18):
+    """Times cugraph_louvain on the undirected RMAT graph of `scale`; returns the dict of the JSON line (roofline, cpu_baseline, check)."""
+    import numpy as np
+    import torch
+
+    def run(sc, reps):
+        nv = 1 << sc
+        src, dst, w = undirected_rmat(cg, h, sc, edge_factor)
+        g = cg.SGGraph(h, cg.GraphProperties(is_symmetric=True), src, dst, w, renumber=False, vertices_array=torch.arange(nv, dtype=torch.int32, device="cuda"))
+        times = []
+        for _ in range(reps + 1):  # one warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            v, c, q = cg.louvain(h, g, 100, 1e-7, 1.0, False)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        return src, dst, w, v, c, q, times[1:], h.last_traversal_stats()
+
+    src, dst, w, v, c, q, times, work = run(scale, repeats)
+    ne = int(src.numel())
+    best = min(times)
+    # Algorithmic bytes (DESIGN.md section 3.6): a local-moving sweep over a level with E_l directed edges and V_l vertices must read every
+    # edge's (destination, weight) and the cluster of its destination (4 + 8 + 4 bytes) and, per vertex, its offset, cluster, weight and
+    # the weight of its cluster, and write its new cluster (4 + 4 + 8 + 8 + 4 bytes); a contraction reads and writes the level's edges once
+    # (2 x 16 bytes per edge).  Sums over the sweeps / levels come from the library (cugraph_amd_last_traversal_stats).
+    alg = 16 * work["edges_inspected"] + 28 * work["vertices_reached"] + 32 * work["edges_of_reached"]
+    from bench_traversal import counter_traffic
+
+    traffic, tsrc = counter_traffic(f"louvain_s{scale}")
+    out = {
+        "metric": f"louvain_seconds_rmat{scale}", "value": round(best, 4), "unit": "s", "higher_is_better": False, "n_gpus": 1,
+        "config": {"workload": f"Louvain (max_level 100, threshold 1e-7, resolution 1), undirected simple RMAT scale {scale} edge factor {edge_factor}, "
+                               f"integer weights 1..8, both directions stored", "vertices": 1 << scale, "directed_edges": ne},
+        "modularity": q, "clusters": int(torch.unique(c).numel()), "seconds_all": [round(t, 4) for t in times], "sweeps": int(work["steps"]),
+        "directed_edges_per_second": round(ne / best, 1), "edge_sweeps_per_second": round(work["edges_inspected"] / best, 1), "dtype": "f64", "data": "synthetic",
+        "roofline": {"bound": "hbm", "achieved": round(alg / best / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / best / 1e9 / 8000.0, 4),
+                     "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes": int(alg),
+                     "kernel": "whole call (all levels: sort + segment passes + contraction); 16 B x edge-sweeps + 28 B x vertex-sweeps + 32 B x contracted edges"},
+    }
+    # the returned clustering's modularity, recomputed from the edge list with torch (fp64), must be the reported one
+    cl = torch.empty(1 << scale, dtype=torch.int64, device="cuda")
+    cl[v.to(torch.int64)] = c.to(torch.int64)
+    wd = w.double()
+    m = wd.sum()
+    k = torch.zeros(1 << scale, dtype=torch.float64, device="cuda").index_add_(0, src.long(), wd)
+    a = torch.zeros(1 << scale, dtype=torch.float64, device="cuda").index_add_(0, cl, k)
+    internal = wd[cl[src.long()] == cl[dst.long()]].sum()
+    q_torch = float(internal / m - (a * a).sum() / (m * m))
+    out["check"] = {"modularity_recomputed_abs_err": abs(q_torch - q), "ok": abs(q_torch - q) <= 1e-9,
+                    "what": "modularity of the returned clustering recomputed from the edge list (torch, fp64)"}
+    if cpu_scale:
+        from oracle import oracle as orc
+
+        s2, d2, w2, v2, c2, q2, t2, _ = (src, dst, w, v, c, q, times, work) if cpu_scale == scale else run(cpu_scale, 1)
+        s_h, d_h, w_h = s2.cpu().numpy(), d2.cpu().numpy(), w2.cpu().numpy()
+        t0 = time.perf_counter()
+        oc, oq, olevels, osweeps = orc.louvain_c(1 << cpu_scale, s_h, d_h, w_h, 100, 1e-7, 1.0)
+        cpu_s = time.perf_counter() - t0
+        got = np.empty(1 << cpu_scale, np.int64)
+        got[v2.cpu().numpy()] = c2.cpu().numpy()
+        out["cpu_baseline"] = {"value": round(cpu_s, 3), "unit": "s", "cores": 1, "kind": "port",
+                               "sample": f"oracle/oracle.c orc_louvain, RMAT-{cpu_scale} (same construction), {olevels} levels, {osweeps} sweeps",
+                               "gpu_seconds_same_graph": round(min(t2), 4)}
+        out["check"].update({"clusters_equal_oracle": bool(np.array_equal(got, oc)), "modularity_abs_err_vs_oracle": abs(q2 - oq), "oracle_scale": cpu_scale})
+        out["check"]["ok"] = bool(out["check"]["ok"] and np.array_equal(got, oc) and abs(q2 - oq) <= 1e-9)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=int, default=22)
@@ -44,51 +112,13 @@ def main():
     ap.add_argument("--out", type=str, default=None)
     args = ap.parse_args()
 
-    import numpy as np
     import torch
 
     import cugraph_amd as cg
 
     torch.cuda.set_device(0)
     h = cg.ResourceHandle()
-
-    def run(scale, repeats):
-        nv = 1 << scale
-        src, dst, w = undirected_rmat(cg, h, scale, args.edge_factor)
-        g = cg.SGGraph(h, cg.GraphProperties(is_symmetric=True), src, dst, w, renumber=False, vertices_array=torch.arange(nv, dtype=torch.int32, device="cuda"))
-        times = []
-        for _ in range(repeats + 1):  # one warm-up
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            v, c, q = cg.louvain(h, g, 100, 1e-7, 1.0, False)
-            torch.cuda.synchronize()
-            times.append(time.perf_counter() - t0)
-        return src, dst, w, v, c, q, times[1:]
-
-    src, dst, w, v, c, q, times = run(args.scale, args.repeats)
-    ne = int(src.numel())
-    best = min(times)
-    out = {
-        "metric": f"louvain_seconds_rmat{args.scale}", "value": round(best, 4), "unit": "s", "higher_is_better": False, "n_gpus": 1,
-        "config": {"workload": f"Louvain (max_level 100, threshold 1e-7, resolution 1), undirected simple RMAT scale {args.scale} edge factor {args.edge_factor}, "
-                               f"integer weights 1..8, both directions stored", "vertices": 1 << args.scale, "directed_edges": ne},
-        "modularity": q, "clusters": int(torch.unique(c).numel()), "seconds_all": [round(t, 4) for t in times],
-        "directed_edges_per_second": round(ne / best, 1), "dtype": "f64", "data": "synthetic",
-    }
-    if args.cpu_scale:
-        from oracle import oracle as orc
-
-        s2, d2, w2, v2, c2, q2, t2 = (src, dst, w, v, c, q, times) if args.cpu_scale == args.scale else run(args.cpu_scale, 1)
-        s_h, d_h, w_h = s2.cpu().numpy(), d2.cpu().numpy(), w2.cpu().numpy()
-        t0 = time.perf_counter()
-        oc, oq, olevels, osweeps = orc.louvain_c(1 << args.cpu_scale, s_h, d_h, w_h, 100, 1e-7, 1.0)
-        cpu_s = time.perf_counter() - t0
-        got = np.empty(1 << args.cpu_scale, np.int64)
-        got[v2.cpu().numpy()] = c2.cpu().numpy()
-        out["cpu_baseline"] = {"value": round(cpu_s, 3), "unit": "s", "cores": 1, "kind": "port",
-                               "sample": f"oracle/oracle.c orc_louvain, RMAT-{args.cpu_scale} (same construction), {olevels} levels, {osweeps} sweeps",
-                               "gpu_seconds_same_graph": round(min(t2), 4)}
-        out["check"] = {"clusters_equal": bool(np.array_equal(got, oc)), "modularity_abs_err": abs(q2 - oq), "ok": bool(np.array_equal(got, oc) and abs(q2 - oq) <= 1e-9)}
+    out = louvain_bench(cg, h, args.scale, args.edge_factor, args.repeats, args.cpu_scale)
     line = json.dumps(out)
     print(line, flush=True)
     if args.out:

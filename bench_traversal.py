@@ -98,55 +98,67 @@ def main_partitioned(args):
     dist.destroy_process_group()
 
 
-def main():
+def kernel_source_hash():
+    """sha256 over the HIP sources of the library: profiles/traffic_latest.json is only believed when it was measured on this code."""
+    import hashlib
+
+    hsh = hashlib.sha256()
+    for f in sorted((ROOT / "cugraph_amd" / "csrc").glob("*.h*")):
+        hsh.update(f.name.encode())
+        hsh.update(f.read_bytes())
+    return hsh.hexdigest()[:16]
+
+
+def counter_traffic(key):
+    """(bytes, source) of a workload from profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/gpu_traffic.sh;
+    FETCH_SIZE doubled per the gfx950 note of the guide).  The file names the source hash it was measured on: a stale file gives
+    (None, reason) -- never a number from other kernels."""
+    f = ROOT / "profiles" / "traffic_latest.json"
+    if not f.exists():
+        return None, "profiles/traffic_latest.json absent"
+    try:
+        t = json.loads(f.read_text())
+    except Exception as e:
+        return None, f"profiles/traffic_latest.json unreadable: {e!r}"
+    if t.get("source_hash") != kernel_source_hash():
+        return None, f"STALE: profiles/traffic_latest.json was measured on source hash {t.get('source_hash')}, this build is {kernel_source_hash()} (re-run tools/gpu_traffic.sh)"
+    e = t.get("entries", {}).get(key)
+    if e is None:
+        return None, f"profiles/traffic_latest.json has no entry {key}"
+    return e.get("hbm_bytes"), f"profiles/traffic_latest.json[{key}] ({t.get('source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes')}; same source hash; not measured by this run)"
+
+
+def traversal_bench(cg, h, scale=24, edge_factor=16, n_roots=64, weights="unit", symmetric=False, predecessors=False, do_sssp=True, cpu_scale=20,
+                    cpu=True, check=True):
+    """One Graph500-protocol measurement (see the module docstring); returns the dict of the JSON line."""
     import numpy as np
     import torch
 
-    import cugraph_amd as cg
-
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--scale", type=int, default=24)
-    ap.add_argument("--edge-factor", type=int, default=16)
-    ap.add_argument("--roots", type=int, default=64, help="Graph500 protocol: 64 roots after the warm-ups")
-    ap.add_argument("--cpu-scale", type=int, default=20, help="RMAT scale of the bounded CPU-baseline sample (oracle BFS / Dijkstra)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--out", type=str, default=None, help="also write the JSON line to this file")
-    ap.add_argument("--weights", choices=["unit", "int"], default="unit")
-    ap.add_argument("--symmetric", action="store_true", help="add the reverse of every edge (Graph500 input)")
-    ap.add_argument("--no-sssp", action="store_true")
-    ap.add_argument("--predecessors", action="store_true")
-    ap.add_argument("--gpus", type=int, default=1, help="> 1 (under torch.distributed.run): the partitioned engine, one rank per GPU")
-    ap.add_argument("--partitioned", action="store_true", help="run the partitioned engine even with one rank (comparison with the single-GPU path)")
-    args = ap.parse_args()
-    if args.gpus > 1 or args.partitioned:
-        return main_partitioned(args)
-
-    torch.cuda.set_device(0)
-    h = cg.ResourceHandle()
-    nv, ne = 1 << args.scale, args.edge_factor << args.scale
-    src, dst = cg.generate_rmat_edgelist(h, args.scale, ne)
-    if args.symmetric:
+    nv, ne = 1 << scale, edge_factor << scale
+    src, dst = cg.generate_rmat_edgelist(h, scale, ne)
+    if symmetric:
         src, dst = torch.cat([src, dst]), torch.cat([dst, src])
         ne *= 2
-    if args.weights == "unit":
+    if weights == "unit":
         w = torch.ones(ne, dtype=torch.float32, device="cuda")
     else:
         g_ = torch.Generator(device="cuda").manual_seed(1)
         w = torch.randint(1, 256, (ne,), generator=g_, device="cuda").to(torch.float32)
     verts = torch.arange(nv, dtype=torch.int32, device="cuda")
     t0 = time.perf_counter()
-    g = cg.SGGraph(h, cg.GraphProperties(is_multigraph=True, is_symmetric=args.symmetric), src, dst, w, store_transposed=False, renumber=True,
+    g = cg.SGGraph(h, cg.GraphProperties(is_multigraph=True, is_symmetric=symmetric), src, dst, w, store_transposed=False, renumber=True,
                    vertices_array=verts)
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
-    del src, dst
+    if not check:
+        del src, dst, w
     # roots: fixed-seed hash order over the vertices with out-edges (the library's own degrees: no framework kernel in the profiles)
     dv, dd = cg.out_degrees(h, g)
     outdeg = torch.zeros(nv, dtype=torch.int64, device="cuda")
     outdeg[dv.to(torch.int64)] = dd.to(torch.int64)
     del dv, dd
     cand = torch.nonzero(outdeg > 0).flatten()
-    perm = torch.randperm(cand.numel(), generator=torch.Generator().manual_seed(0))[: args.roots]
+    perm = torch.randperm(cand.numel(), generator=torch.Generator().manual_seed(0))[: n_roots]
     roots = cand[perm.to(cand.device)].to(torch.int32)
 
     def run(kind):
@@ -155,9 +167,9 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             if kind == "bfs":
-                d, p, v = cg.bfs(h, g, r.reshape(1).clone(), False, 0, args.predecessors, False)
+                d, p, v = cg.bfs(h, g, r.reshape(1).clone(), False, 0, predecessors, False)
             else:
-                v, d, p = cg.sssp(h, g, int(r), 3.0e38, args.predecessors, False)
+                v, d, p = cg.sssp(h, g, int(r), 3.0e38, predecessors, False)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             st = h.last_traversal_stats()
@@ -180,14 +192,39 @@ def main():
         else:
             b = 8 * e_r + 8 * v_r + 8 * nv + 8 * v_r
         ach = b / t_s / 1e9
-        return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4), "traffic": None,
-                "algorithmic_bytes_per_traversal": int(b), "kernel": "whole traversal (all levels / rounds, harmonic-mean time)"}
+        key = f"{kind}_s{scale}_{'sym' if symmetric else weights}{'_pred' if pred else ''}"
+        traffic, tsrc = counter_traffic(key)
+        return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4), "traffic": traffic,
+                "traffic_source": tsrc, "algorithmic_bytes_per_traversal": int(b), "kernel": "whole traversal (all levels / rounds, harmonic-mean time)"}
 
-    out = {"metric": f"bfs_sssp_mteps_rmat{args.scale}", "unit": "MTEPS", "n_gpus": 1, "higher_is_better": True, "data": "synthetic",
-           "workload": f"RMAT scale {args.scale} edge factor {args.edge_factor}{' symmetrised' if args.symmetric else ''}, {args.roots} roots "
-                       f"(fixed-seed choice among the vertices with out-edges; 2 warm-ups), weights {args.weights}; TEPS = out-edges of the reached "
+    def bellman_check(kind, v, d):
+        """OUTSIDE the timed region, on the last root's result: the distances are THE fixed point of d[v] = min over in-edges of
+        d[u] + w (w = 1 for BFS; fp32 addition is monotone, so the fixed point is unique and equals Dijkstra's):
+        recomputed here with one torch scatter-min over the edge list, compared bit for bit."""
+        root = int(roots[-1])
+        if kind == "bfs":
+            dist = torch.empty(nv, dtype=torch.int64, device="cuda")
+            dist[v.to(torch.int64)] = d.to(torch.int64)
+            INF = 2147483647
+            cand = torch.where(dist[src.long()] == INF, torch.full_like(dist[:1], INF).expand(ne), dist[src.long()] + 1)
+            best = torch.full((nv,), INF, dtype=torch.int64, device="cuda").scatter_reduce(0, dst.long(), cand, "amin", include_self=True)
+        else:
+            dist = torch.empty(nv, dtype=torch.float32, device="cuda")
+            dist[v.to(torch.int64)] = d
+            INF = torch.finfo(torch.float32).max
+            du = dist[src.long()]
+            cand = torch.where(du == INF, du, du + w)
+            best = torch.full((nv,), INF, dtype=torch.float32, device="cuda").scatter_reduce(0, dst.long(), cand, "amin", include_self=True)
+        best[root] = 0
+        bad = int((best != dist).sum())
+        return {"what": "d[v] == min over in-edges (d[u] + w), d[root] == 0, recomputed with torch on the last root's result (bit for bit)",
+                "root": root, "violations": bad, "reached": int((dist != INF).sum()), "ok": bad == 0}
+
+    out = {"metric": f"bfs_sssp_mteps_rmat{scale}", "unit": "MTEPS", "n_gpus": 1, "higher_is_better": True, "data": "synthetic",
+           "workload": f"RMAT scale {scale} edge factor {edge_factor}{' symmetrised' if symmetric else ''}, {n_roots} roots "
+                       f"(fixed-seed choice among the vertices with out-edges; 2 warm-ups), weights {weights}; TEPS = out-edges of the reached "
                        "vertices / time, harmonic mean (mg_graph500_bfs_test.cu:113-114, 757-763)",
-           "vertices": nv, "edges": ne, "roots": args.roots, "predecessors": bool(args.predecessors), "graph_build_s": round(build_s, 3)}
+           "vertices": nv, "edges": ne, "roots": n_roots, "predecessors": bool(predecessors), "graph_build_s": round(build_s, 3)}
     bt, be, bs, (bv, bd) = run("bfs")
     reached = [int((bd != 2147483647).sum())]  # last root; the reached set of an RMAT giant component hardly varies between roots
     teps = [e / t for e, t in zip(be, bt)]
@@ -195,24 +232,58 @@ def main():
     t_hm = float(np.mean(be)) / hm
     out["bfs"] = {"mean_ms": round(1e3 * float(np.mean(bt)), 3), "min_ms": round(1e3 * float(np.min(bt)), 3), "max_ms": round(1e3 * float(np.max(bt)), 3),
                   "harmonic_mean_mteps": round(hm / 1e6, 1), "mean_levels": float(np.mean(bs)), "mean_edges_of_reached": float(np.mean(be)),
-                  "dtype": "int32", "roofline": roofline("bfs", float(np.mean(be)), reached[0], t_hm, args.predecessors)}
+                  "dtype": "int32", "roofline": roofline("bfs", float(np.mean(be)), reached[0], t_hm, predecessors)}
+    if check:
+        out["bfs"]["check"] = bellman_check("bfs", bv, bd)
     out["value"] = out["bfs"]["harmonic_mean_mteps"]
-    if not args.no_sssp:
+    if do_sssp:
         st, _, ss, (sv, sd) = run("sssp")
         teps = [e / t for e, t in zip(be, st)]  # same roots: same reached set, scored on the same edge count
         hm = len(teps) / sum(1.0 / x for x in teps)
         t_hm = float(np.mean(be)) / hm
         out["sssp"] = {"mean_ms": round(1e3 * float(np.mean(st)), 3), "min_ms": round(1e3 * float(np.min(st)), 3), "max_ms": round(1e3 * float(np.max(st)), 3),
                        "harmonic_mean_mteps": round(hm / 1e6, 1), "mean_steps": float(np.mean(ss)), "mean_relaxations_per_edge": round(float(np.mean(run.inspected)) / ne, 3), "dtype": "f32",
-                       "roofline": roofline("sssp", float(np.mean(be)), reached[0], t_hm, args.predecessors)}
-        if args.weights == "unit":  # integer hops: bit-exact against BFS (last root)
+                       "roofline": roofline("sssp", float(np.mean(be)), reached[0], t_hm, predecessors)}
+        if check:
+            out["sssp"]["check"] = bellman_check("sssp", sv, sd)
+        if weights == "unit":  # integer hops: bit-exact against BFS (last root)
             a = torch.empty(nv, dtype=torch.int64, device="cuda"); a[bv.to(torch.int64)] = bd.to(torch.int64)
             b = torch.empty(nv, dtype=torch.float32, device="cuda"); b[sv.to(torch.int64)] = sd
             reach = a != 2147483647
             ok = bool(torch.equal(a[reach].to(torch.float32), b[reach])) and bool((b[~reach] == torch.finfo(torch.float32).max).all())
             out["sssp"]["unit_weight_distances_equal_bfs"] = ok
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(min(args.cpu_scale, args.scale), args.weights)
+    if cpu:
+        out["cpu_baseline"] = cpu_baseline(min(cpu_scale, scale), weights)
+    return out
+
+
+def main():
+    import torch
+
+    import cugraph_amd as cg
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=int, default=24)
+    ap.add_argument("--edge-factor", type=int, default=16)
+    ap.add_argument("--roots", type=int, default=64, help="Graph500 protocol: 64 roots after the warm-ups")
+    ap.add_argument("--cpu-scale", type=int, default=20, help="RMAT scale of the bounded CPU-baseline sample (oracle BFS / Dijkstra)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--out", type=str, default=None, help="also write the JSON line to this file")
+    ap.add_argument("--weights", choices=["unit", "int"], default="unit")
+    ap.add_argument("--symmetric", action="store_true", help="add the reverse of every edge (Graph500 input)")
+    ap.add_argument("--no-sssp", action="store_true")
+    ap.add_argument("--predecessors", action="store_true")
+    ap.add_argument("--gpus", type=int, default=1, help="> 1 (under torch.distributed.run): the partitioned engine, one rank per GPU")
+    ap.add_argument("--partitioned", action="store_true", help="run the partitioned engine even with one rank (comparison with the single-GPU path)")
+    args = ap.parse_args()
+    if args.gpus > 1 or args.partitioned:
+        return main_partitioned(args)
+
+    torch.cuda.set_device(0)
+    h = cg.ResourceHandle()
+    out = traversal_bench(cg, h, args.scale, args.edge_factor, args.roots, args.weights, args.symmetric, args.predecessors, not args.no_sssp,
+                          args.cpu_scale, not args.no_cpu_baseline, not args.no_check)
     line = json.dumps(out)
     print(line, flush=True)
     if args.out:

@@ -526,6 +526,9 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
     iota_i32(h, part->buf.as<int32_t>(), nv0, 0);
     double best = -1.0;
     size_t levels = 0;
+    // work done (cugraph_amd_last_traversal_stats): steps = sweeps, edges_inspected = sum over sweeps of the level's edges,
+    // vertices_reached = sum over sweeps of the level's vertices, edges_of_reached = sum over levels of the level's edges (contractions)
+    cugraph_amd_traversal_stats_t work{0, 0, 0, 0};
     while (levels < max_level && L.nv > 0 && m > 0.0) {
       ++levels;
       build_offsets(h, L);
@@ -536,6 +539,10 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
       if (trace)
         fprintf(stderr, "[louvain] level %zu: %lld vertices, %lld edges, %d sweeps, Q = %.9f, %.1f ms\n", levels, (long long)L.nv, (long long)L.ne, st.sweeps, q,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_level).count());
+      work.steps += (uint64_t)st.sweeps;
+      work.edges_inspected += (uint64_t)st.sweeps * (uint64_t)L.ne;
+      work.vertices_reached += (uint64_t)st.sweeps * (uint64_t)L.nv;
+      work.edges_of_reached += (uint64_t)L.ne;
       if (q <= best) break;
       best = q;
       // graph_contraction (common_methods.cuh:230-257): dense labels, flattening, coarse edges
@@ -581,6 +588,7 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
     if (trace)
       fprintf(stderr, "[louvain] %zu levels, Q = %.9f, %.1f ms\n", levels, best,
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    const_cast<handle_t&>(h).last_stats = work;
     auto res        = std::make_unique<clustering_result_t>();
     res->modularity = best;
     res->vertices   = new device_array_t((size_t)nv0, g.vertex_type);

@@ -134,6 +134,22 @@ __global__ void k_run_keys(uint32_t const* run_dst, int64_t n_runs, uint32_t con
   }
 }
 
+// run starts inside every work item (cost estimate of the phase-1 schedule)
+__global__ void k_item_runs(int32_t const* item_tile, uint32_t const* item_end, int n_items, uint32_t const* tile_off, uint32_t const* tile_off_pad,
+                            uint32_t const* ord, uint32_t* runs)
+{
+  int const i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_items) return;
+  uint32_t const J = (uint32_t)item_tile[i];
+  uint64_t const s = (uint64_t)i * TP_ITEM, e = min((uint64_t)item_end[i], s + TP_ITEM);
+  uint32_t r = 0;
+  if (e > s) {
+    uint32_t const ks = tile_off[J] + ((uint32_t)s - tile_off_pad[J]);
+    r = ord[ks + (uint32_t)(e - s)] - ord[ks];
+  }
+  runs[i] = r;
+}
+
 __global__ void k_wave_desc(int32_t const* item_tile, uint32_t const* item_end, int n_items,
                             uint32_t const* tile_off, uint32_t const* tile_off_pad, uint32_t const* flag32, uint32_t const* ord,
                             uint32_t const* run_dst, uint32_t const* tile_row0, int nI, int64_t n_runs, tiled_wave_t* waves,
@@ -495,6 +511,107 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   HIP_TRY(hipMemsetAsync(t.wrec.data(), 0, (size_t)(n_waves > 0 ? n_waves : 1) * TP_REC_DWORDS * sizeof(uint32_t), h.stream));
 
   tr.step("work items");
+  // ---- phase-1 chunks: up to TP_CHUNK consecutive items of one source tile, handed out dynamically LARGEST FIRST
+  // (long chunks keep an LDS tile for many items; the one-item chunks of the cold tiles fill the tail evenly)
+  {
+    size_t const lds = ((size_t)T + (size_t)TP_WAVES * TP_STAGE) * vsize;
+    int const per_cu = std::max<int>(1, std::min<int>(2, (int)((h.lds_per_block - 1024) / (lds + 64))));
+    int const max_wg = h.num_cus * per_cu;
+    char const* env_chunk = getenv("CUGRAPH_AMD_TP_CHUNK");  // tests: multi-item chunks on small graphs
+    int const chunk  = env_chunk ? std::max(1, atoi(env_chunk)) : std::max(1, std::min<int>(TP_CHUNK, t.n_items / (max_wg * 4)));  // small graphs: more, shorter chunks
+    // the hottest tiles span thousands of items: their first items go out in LONG chunks (a workgroup reloads the 126 KiB
+    // tile once per chunk, with nothing else in flight), the rest in `chunk`-item pieces that balance the tail
+    char const* env_big  = getenv("CUGRAPH_AMD_TP_CHUNK_BIG");
+    char const* env_frac = getenv("CUGRAPH_AMD_TP_CHUNK_BIG_FRAC");
+    int const big        = std::max(chunk, env_big ? atoi(env_big) : TP_CHUNK_BIG);
+    double const frac    = env_frac ? atof(env_frac) : 0.55;
+    int64_t big_budget   = t.n_items / (max_wg * 4) >= TP_CHUNK ? (int64_t)(frac * t.n_items) : 0;
+    // the items of the coldest tiles (the last `tail_frac` of all items; an item there costs about twice a hot one: ten times the
+    // runs and partial stores) go out in short chunks, so the workgroups finish within one short chunk of each other
+    char const* env_tf = getenv("CUGRAPH_AMD_TP_TAIL_FRAC");
+    char const* env_tc = getenv("CUGRAPH_AMD_TP_TAIL_CHUNK");
+    double const tail_frac = env_tf ? atof(env_tf) : TP_TAIL_FRAC;
+    int const tail_chunk   = std::max(1, std::min(chunk, env_tc ? atoi(env_tc) : TP_TAIL_CHUNK));
+    int const tail_first   = t.n_items / (max_wg * 4) >= TP_CHUNK ? (int)((1.0 - tail_frac) * t.n_items) : t.n_items;
+    // STATIC PREFIX (sticky tiles): every workgroup first walks a private, contiguous range of work items -- equal shares, by
+    // estimated cost, of the first `static_frac` of the total cost -- so that it loads a hot source tile ONCE (a 126 KiB tile
+    // load drains the workgroup's memory pipeline: with every chunk drawn from one global queue a workgroup reloaded tile 0
+    // every 32 items, 13.7 tile loads per workgroup and 0.44 GB of x per iteration at RMAT-26); the cold remainder -- hundreds
+    // of tiles of a few items each, one tile load per chunk whoever takes it -- stays dynamic and evens out the finish.
+    // Cost of an item = its edges + TP_RUN_COST x its run starts (a cold item stores ten times the partials of a hot one and
+    // takes about twice as long).
+    char const* env_sf = getenv("CUGRAPH_AMD_TP_STATIC_FRAC");
+    char const* env_rc = getenv("CUGRAPH_AMD_TP_RUN_COST");
+    double const static_frac = env_sf ? atof(env_sf) : 0.0;  // off by default: see DESIGN.md section 3.1 (round 3) for the measurements
+    double const run_cost    = env_rc ? atof(env_rc) : 1.3;
+    std::vector<int32_t> cb;              // [4 * n_chunks]: (unused, first item, end item, source tile); static chunks first, grouped by workgroup
+    std::vector<int32_t> wg_static;       // [2 * n_wg]: (first static chunk, end static chunk) of every workgroup
+    int static_items = 0;
+    bool const use_static = static_frac > 0.0 && ne > 0 && (t.n_items / (max_wg * 4) >= TP_CHUNK || getenv("CUGRAPH_AMD_TP_STATIC_FORCE") != nullptr);
+    t.n_wg = use_static ? max_wg : 0;
+    if (use_static) {
+      dvec<uint32_t> d_item_end, d_item_runs((size_t)t.n_items);
+      to_device(h, d_item_end, item_end);
+      hipLaunchKernelGGL(k_item_runs, grid_for(t.n_items, kBlock), kBlock, 0, h.stream, (int32_t const*)t.item_tile.data(), (uint32_t const*)d_item_end.data(), t.n_items,
+                         (uint32_t const*)d_tile_off.data(), (uint32_t const*)d_tile_off_pad.data(), (uint32_t const*)ord.data(), d_item_runs.data());
+      std::vector<uint32_t> item_runs = to_host(h, d_item_runs.data(), (size_t)t.n_items);
+      std::vector<double> cum(t.n_items + 1, 0.0);
+      for (int i = 0; i < t.n_items; ++i) {
+        double const runs = (double)item_runs[i];
+        uint32_t const first = (uint32_t)i * (uint32_t)TP_ITEM;
+        double const edges   = (double)std::min<uint32_t>((uint32_t)TP_ITEM, item_end[i] > first ? item_end[i] - first : 0u);
+        cum[i + 1] = cum[i] + edges + run_cost * runs;
+      }
+      double const share = static_frac * cum[t.n_items] / max_wg;
+      wg_static.assign((size_t)2 * max_wg, 0);
+      int i = 0;
+      for (int w = 0; w < max_wg; ++w) {
+        int j = i;
+        while (j < t.n_items && cum[j + 1] <= share * (w + 1)) ++j;
+        wg_static[2 * w] = (int32_t)(cb.size() / 4);
+        for (int k = i; k < j;) {  // one chunk per source tile of the range
+          int e = k + 1;
+          while (e < j && item_tile[e] == item_tile[k]) ++e;
+          cb.push_back(0); cb.push_back(k); cb.push_back(e); cb.push_back(item_tile[k]);
+          k = e;
+        }
+        wg_static[2 * w + 1] = (int32_t)(cb.size() / 4);
+        i = j;
+      }
+      static_items = i;
+    }
+    t.n_static_chunks = (int)(cb.size() / 4);
+    std::vector<std::pair<int32_t, int32_t>> ch;  // dynamic part: (first item, items)
+    for (int i = static_items; i < t.n_items;) {
+      int j = i + 1;
+      while (j < t.n_items && item_tile[j] == item_tile[i]) ++j;  // [i, j) = the (remaining) items of one tile
+      int k = i;
+      while (!use_static && big > chunk && big_budget >= big && j - k >= 2 * big) { ch.push_back({k, big}); k += big; big_budget -= big; }
+      while (k < j) { int const n = std::min((use_static || k >= tail_first) ? tail_chunk : chunk, j - k); ch.push_back({k, n}); k += n; }
+      i = j;
+    }
+    std::stable_sort(ch.begin(), ch.end(), [](auto const& x, auto const& y) { return x.second > y.second; });
+    if (char const* env_ord = getenv("CUGRAPH_AMD_TP_ORDER")) {  // experiment: "mix" = hot (load-bound) and cold (store-bound) chunks alternate in time
+      if (env_ord[0] == 'm' && ch.size() >= 16) {
+        size_t const n = ch.size() * 4 / 5 / 2 * 2;  // the smallest fifth keeps its place: it evens out the finish
+        std::vector<std::pair<int32_t, int32_t>> mixed;
+        for (size_t k = 0; k < n / 2; ++k) { mixed.push_back(ch[k]); mixed.push_back(ch[n / 2 + k]); }
+        std::copy(mixed.begin(), mixed.end(), ch.begin());
+      }
+    }
+    for (auto const& c : ch) { cb.push_back(0); cb.push_back(c.first); cb.push_back(c.first + c.second); cb.push_back(item_tile[c.first]); }
+    t.n_chunks = (int)(cb.size() / 4);
+    if (cb.empty()) cb.assign(4, 0);
+    if (!use_static) t.n_wg = std::max(1, std::min<int>(t.n_chunks, max_wg));
+    if (wg_static.empty()) wg_static.assign((size_t)2 * std::max(t.n_wg, 1), 0);
+    to_device(h, t.wg_static, wg_static);
+    if (getenv("CUGRAPH_AMD_TILED_DEBUG"))
+      fprintf(stderr, "[tiled build] chunks: %d static (items [0, %d) of %d, %d workgroups), %d dynamic\n", t.n_static_chunks, static_items, t.n_items, t.n_wg,
+              t.n_chunks - t.n_static_chunks);
+    to_device(h, t.chunk_begin, cb);
+  }
+
+  tr.step("chunks");
   // ---- slots: runs and wave heads ordered by (destination tile, source tile, destination)
   int64_t const n_el = t.n_runs + n_waves;
   std::vector<uint32_t> region_off(t.nI + 2, 0);
@@ -571,46 +688,6 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   to_device(h, t.region_off, region_off);
 
   tr.step("slots");
-  // ---- phase-1 chunks: up to TP_CHUNK consecutive items of one source tile, handed out dynamically LARGEST FIRST
-  // (long chunks keep an LDS tile for many items; the one-item chunks of the cold tiles fill the tail evenly)
-  {
-    size_t const lds = ((size_t)T + (size_t)TP_WAVES * TP_STAGE) * vsize;
-    int const per_cu = std::max<int>(1, std::min<int>(2, (int)((h.lds_per_block - 1024) / (lds + 64))));
-    int const max_wg = h.num_cus * per_cu;
-    int const chunk  = std::max(1, std::min<int>(TP_CHUNK, t.n_items / (max_wg * 4)));  // small graphs: more, shorter chunks
-    // the hottest tiles span thousands of items: their first items go out in LONG chunks (a workgroup reloads the 126 KiB
-    // tile once per chunk, with nothing else in flight), the rest in `chunk`-item pieces that balance the tail
-    char const* env_big  = getenv("CUGRAPH_AMD_TP_CHUNK_BIG");
-    char const* env_frac = getenv("CUGRAPH_AMD_TP_CHUNK_BIG_FRAC");
-    int const big        = std::max(chunk, env_big ? atoi(env_big) : TP_CHUNK_BIG);
-    double const frac    = env_frac ? atof(env_frac) : 0.55;
-    int64_t big_budget   = t.n_items / (max_wg * 4) >= TP_CHUNK ? (int64_t)(frac * t.n_items) : 0;
-    // the items of the coldest tiles (the last `tail_frac` of all items; an item there costs about twice a hot one: ten times the
-    // runs and partial stores) go out in short chunks, so the workgroups finish within one short chunk of each other
-    char const* env_tf = getenv("CUGRAPH_AMD_TP_TAIL_FRAC");
-    char const* env_tc = getenv("CUGRAPH_AMD_TP_TAIL_CHUNK");
-    double const tail_frac = env_tf ? atof(env_tf) : TP_TAIL_FRAC;
-    int const tail_chunk   = std::max(1, std::min(chunk, env_tc ? atoi(env_tc) : TP_TAIL_CHUNK));
-    int const tail_first   = t.n_items / (max_wg * 4) >= TP_CHUNK ? (int)((1.0 - tail_frac) * t.n_items) : t.n_items;
-    std::vector<std::pair<int32_t, int32_t>> ch;  // (first item, items)
-    for (int i = 0; i < t.n_items;) {
-      int j = i + 1;
-      while (j < t.n_items && item_tile[j] == item_tile[i]) ++j;  // [i, j) = the items of one tile
-      int k = i;
-      while (big > chunk && big_budget >= big && j - k >= 2 * big) { ch.push_back({k, big}); k += big; big_budget -= big; }
-      while (k < j) { int const n = std::min(k >= tail_first ? tail_chunk : chunk, j - k); ch.push_back({k, n}); k += n; }
-      i = j;
-    }
-    std::stable_sort(ch.begin(), ch.end(), [](auto const& x, auto const& y) { return x.second > y.second; });
-    t.n_chunks = (int)ch.size();
-    std::vector<int32_t> cb;  // [4 * n_chunks]: (unused, first item, end item, source tile)
-    for (auto const& c : ch) { cb.push_back(0); cb.push_back(c.first); cb.push_back(c.first + c.second); cb.push_back(item_tile[c.first]); }
-    if (cb.empty()) cb.assign(4, 0);
-    t.n_wg = std::max(1, std::min<int>(t.n_chunks, max_wg));
-    to_device(h, t.chunk_begin, cb);
-  }
-
-  tr.step("chunks");
   // ---- bound used by the fixed-point accumulation of phase 2
   t.wmax = (double)csc.max_degree;
   if (has_weights && ne > 0) {
@@ -744,7 +821,9 @@ struct p1_args {
   uint32_t const* wrec;    // per-wavefront records (TP_REC_DWORDS dwords each, layout in spmv_tiled.hpp)
   int32_t const* chunk_begin;  // [n_chunks][4] (unused, first work item, end work item, source tile); items of a chunk share one source tile
   int n_chunks;
-  uint32_t* counter;           // chunk cursor: 0 on entry, reset by phase 2
+  int n_static_chunks;         // chunks [0, n_static_chunks) are pre-assigned: workgroup b owns [wg_static[2b], wg_static[2b + 1])
+  int32_t const* wg_static;
+  uint32_t* counter;           // cursor of the dynamic chunks: 0 on entry, reset by phase 2
   int T;
   WT const* x;
   WT* part;
@@ -1078,8 +1157,10 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
   int n_tiles = 0;
   // thread 0 draws the next chunk and stages its descriptor in LDS: nothing in the item loop depends on a global load that
   // was just issued (a dependent load is followed by vmcnt(0), which also waits for every prefetch and store in flight)
+  int my_next = 0, my_end = 0;  // thread 0: this workgroup's private (static) chunks
+  if (tid == 0) { my_next = a.wg_static[2 * blockIdx.x]; my_end = a.wg_static[2 * blockIdx.x + 1]; }
   auto draw = [&](int slot) {
-    int const cid = (int)atomicAdd(a.counter, 1u);
+    int const cid = my_next < my_end ? my_next++ : a.n_static_chunks + (int)atomicAdd(a.counter, 1u);
     int4 c{cid, 0, 0, 0};
     if (cid < a.n_chunks) c = reinterpret_cast<int4 const*>(a.chunk_begin)[cid];
     c.x = cid;
@@ -1386,6 +1467,8 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
   a.wrec      = t.wrec.data();
   a.chunk_begin = t.chunk_begin.data();
   a.n_chunks    = t.n_chunks;
+  a.n_static_chunks = t.n_static_chunks;
+  a.wg_static   = t.wg_static.data();
   a.counter     = counters;
   a.T         = t.T;
   a.x         = x;

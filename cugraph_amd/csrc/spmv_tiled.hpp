@@ -108,6 +108,7 @@ struct tiled_csc_t {
   int n_items{0};
   int n_wg{0};  // phase-1 workgroups
   int n_chunks{0};
+  int n_static_chunks{0};     // chunks [0, n_static_chunks) are pre-assigned to workgroups (wg_static), the rest are drawn dynamically
   int64_t nv{0}, ne{0}, ne_pad{0}, n_runs{0}, n_slots{0}, n_blocks{0};
   int64_t n_act{0};  // rows >= n_act have no in-edge; a destination-tile boundary is forced there
   int nI_act{0};     // destination tiles [0, nI_act) cover rows [0, n_act)
@@ -120,6 +121,7 @@ struct tiled_csc_t {
   dvec<int32_t> item_tile;    // [n_items] source tile of work item
   dvec<uint32_t> wrec;        // [n_items * TP_WAVES][TP_REC_DWORDS] per-wavefront records (see above)
   dvec<int32_t> chunk_begin;  // [n_chunks][4] (unused, first item, end item, source tile) of each chunk (<= TP_CHUNK items of one source tile), largest first
+  dvec<int32_t> wg_static;    // [n_wg][2] (first, end) static chunk of each phase-1 workgroup
   dvec<uint32_t> tile_row0;   // [nI + 1] destination tile boundaries
   dvec<uint32_t> region_off;  // [nI + 2] slot range of region I (multiples of 8); region nI = dummy
   dvec<uint16_t> dstl16;      // [n_slots + pad] tile-local destination of slot (16 bits per slot: tiles of more than 4096 rows)

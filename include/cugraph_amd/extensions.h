@@ -154,7 +154,9 @@ CUGRAPH_EXPORT size_t cugraph_amd_graph_num_edges(const cugraph_graph_t* graph);
 CUGRAPH_EXPORT int cugraph_amd_set_pagerank_hot_tile(const cugraph_resource_handle_t* handle, int n_entries);
 
 /* Traversal statistics of the last cugraph_bfs / cugraph_sssp on this handle: number of levels or bucket
- * steps, edges inspected (relaxations), vertices reached. */
+ * steps, edges inspected (relaxations), vertices reached.  cugraph_louvain reports its work in the same struct: steps = sweeps,
+ * edges_inspected / vertices_reached = sum over the sweeps of the level's edges / vertices, edges_of_reached = sum over the
+ * levels of the level's edges (one contraction each). */
 typedef struct {
   uint64_t steps;
   uint64_t edges_inspected;

@@ -1335,3 +1335,37 @@ def test_device_array_release_and_pool_trim(cg, handle):
     v, pr, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 3, False, fail_on_nonconvergence=False)
     assert abs(float(pr.sum()) - 1.0) < 1e-4
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("chunk,static,tile,weighted", [
+    (1, False, 256, False), (3, False, 256, False), (7, True, 256, False), (4, True, 1024, True), (16, True, 0, False), (2, False, 4096, True)])
+def test_pagerank_phase1_schedules_agree(cg, handle, orc, monkeypatch, chunk, static, tile, weighted):
+    """Phase 1's schedule (round 3): pre-assigned ("static") chunk ranges per workgroup in front of the dynamically drawn chunks.
+    Forced here at a size the oracle checks: chunks of several items, a hub row (one run over many wavefront ranges), runs that
+    end exactly at range ends, tiles whose last item is mostly padding.  Every schedule must give the oracle's vector."""
+    monkeypatch.setenv("CUGRAPH_AMD_PAGERANK_KERNEL", "tiled")
+    monkeypatch.setenv("CUGRAPH_AMD_TILED_REBUILD", "1")
+    monkeypatch.setenv("CUGRAPH_AMD_TP_CHUNK", str(chunk))
+    if static:
+        monkeypatch.setenv("CUGRAPH_AMD_TP_STATIC_FORCE", "1")
+        monkeypatch.setenv("CUGRAPH_AMD_TP_STATIC_FRAC", "0.7")
+    else:
+        monkeypatch.setenv("CUGRAPH_AMD_TP_STATIC_FRAC", "0")
+    prev = handle.set_pagerank_hot_tile(tile if tile else -1)
+    rng = np.random.default_rng(5)
+    nv = 20000
+    hub_in = rng.integers(0, 700, 200003)                       # 200003 in-edges of vertex 3 from 700 sources: long runs in few tiles
+    exact = np.repeat(np.arange(1024), 16)                      # 1024 rows x 16 in-edges from sources 0..15: runs that end at range ends
+    s = np.concatenate([hub_in, rng.integers(0, nv, 300000), np.tile(np.arange(16), 1024), np.arange(100, 1100)])
+    d = np.concatenate([np.full(hub_in.size, 3), rng.integers(0, nv, 300000), 5000 + exact, np.arange(2000, 3000)])
+    w = int_weights(s.size, seed=8) if weighted else None
+    g = make_graph(cg, handle, s, d, w, transposed=True, renumber=True, vertices=np.arange(nv))
+    try:
+        v, pr, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 12, False, fail_on_nonconvergence=False)
+    finally:
+        handle.set_pagerank_hot_tile(prev)
+    off, idx, ww = orc.coo_to_cs(nv, d.astype(np.int32), s.astype(np.int32), None if w is None else w.astype(np.float32))
+    truth, _, _ = orc.pagerank(nv, off, idx, ww, 0.85, 0.0, 12, acc64=True)
+    got = by_vertex(v, pr)[0]
+    assert np.max(np.abs(got - truth) / truth) <= 2e-5
+    assert abs(float(got.sum()) - 1.0) <= 1e-5
