@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the post-timing correctness check of the timed result")
     ap.add_argument("--no-extras", action="store_true", help="skip the bounded BFS / SSSP (RMAT-24) and Louvain (RMAT-22) sub-lines appended at N = 1")
     ap.add_argument("--extra-roots", type=int, default=16)
+    ap.add_argument("--layout", choices=["1d", "2d"], default=os.environ.get("CUGRAPH_AMD_MG_LAYOUT", "1d"),
+                    help="N > 1: 1d = destination partition + sparse all-to-all (default), 2d = the reference's R x C layout (all-gather + reduce-scatter)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

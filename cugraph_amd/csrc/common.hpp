@@ -110,6 +110,7 @@ inline size_t dtype_size(cugraph_data_type_id_t t)
 void* pool_alloc(size_t n_bytes, size_t* granted);
 void pool_free(void* ptr, size_t granted) noexcept;
 void pool_set_stream(hipStream_t s) noexcept;
+void pool_forget_stream(hipStream_t s) noexcept;
 size_t pool_release_large_blocks(size_t block_bytes = (size_t)256 << 20) noexcept;
 
 struct dev_buf {

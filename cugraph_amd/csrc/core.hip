@@ -58,6 +58,10 @@ extern "C" void cugraph_free_resource_handle(cugraph_resource_handle_t* handle)
   if (!handle) return;
   auto* h = reinterpret_cast<handle_t*>(handle);
   (void)hipStreamSynchronize(h->stream);
+  if (h->own_stream && h->own_stream != h->stream) (void)hipStreamSynchronize(h->own_stream);
+  // device blocks that outlive the handle (graphs, plans, results freed later) must not record events on its stream any more
+  pool_forget_stream(h->stream);
+  pool_forget_stream(h->own_stream);
   free_timers(h);
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -445,6 +449,10 @@ size_t round_size(size_t n)
 }  // namespace
 
 void pool_set_stream(hipStream_t s) noexcept { tl_stream = s; tl_stream_known = true; }
+void pool_forget_stream(hipStream_t s) noexcept
+{  // the stream is about to be destroyed (it has been synchronised): later frees of this thread have no stream to order against
+  if (tl_stream_known && tl_stream == s) { tl_stream = nullptr; tl_stream_known = false; }
+}
 
 void* pool_alloc(size_t n_bytes, size_t* granted)
 {

@@ -238,6 +238,128 @@ __global__ void k_segment_best(lv_flat_args A)
     }
   }
 }
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 3: the best move of every vertex WITHOUT sorting, for the rows of at most LVH_B edges.
+// A workgroup takes the rows whose first edge lies in one window of LVH_B consecutive edge positions (fewer than 2 * LVH_B
+// edges: every row but the last ends inside the window, the last has at most LVH_B edges; a longer row -- a hub, which goes
+// through the sorted path below -- can only be the LAST row that starts in a window, so the edges of a chunk are contiguous).
+// The weight from a vertex into every neighbouring cluster is accumulated in an LDS hash table keyed by (row slot, cluster) with
+// 64-bit fixed-point integer atomics -- the same sums as the sorted path, bit for bit, whatever order the edges arrive in --,
+// then every edge looks its (row, cluster) sum up, forms the modularity gain with the reference's expression
+// (common_methods.cuh:70-125) and the row's maximum / smallest cluster among the maxima are reduced in LDS.  One pass over
+// (destination, weight, cluster of destination) per edge instead of key construction + 6 radix passes + three segment passes.
+// The row slot of a vertex is the position of its first edge relative to the window (unique per non-empty row, < LVH_B).
+constexpr int LVH_B = 512, LVH_CAP = 2 * LVH_B, LVH_SLOTS = 2048, LVH_THREADS = 256;
+constexpr unsigned long long LVH_EMPTY = ~0ull;
+struct lv_hash_args {
+  int32_t const* src; int32_t const* dst; int32_t const* off; double const* w; int32_t const* c; double const* k; double const* a;
+  double m, resolution, scale, inv_scale; int64_t ne;
+  unsigned long long* best_bits;  // [nv]
+  int32_t* best_c;                // [nv]
+};
+__device__ __forceinline__ uint32_t lvh_slot(uint32_t rs, uint32_t cl) { return ((rs * 0x9E3779B1u) ^ (cl * 0x85EBCA6Bu) ^ (cl >> 15)) & (LVH_SLOTS - 1); }
+__global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
+{
+  __shared__ unsigned long long s_key[LVH_SLOTS], s_sum[LVH_SLOTS];
+  __shared__ unsigned long long s_bits[LVH_CAP];
+  __shared__ unsigned long long s_sub[LVH_B], s_best[LVH_B];
+  __shared__ int32_t s_bestc[LVH_B];
+  __shared__ uint32_t s_cl[LVH_CAP];
+  __shared__ uint16_t s_rs[LVH_CAP];
+  __shared__ long long s_range[2];
+  int const tid = threadIdx.x;
+  int64_t const e_lo = blockIdx.x * (int64_t)LVH_B, e_hi = e_lo + LVH_B < A.ne ? e_lo + LVH_B : A.ne;
+  if (tid == 0) {
+    int64_t p0 = e_lo, p1 = e_lo;
+    if (e_lo > 0 && A.src[e_lo - 1] == A.src[e_lo]) p0 = A.off[A.src[e_lo] + 1];  // the window opens inside a row of an earlier chunk (or a hub)
+    if (p0 < e_hi) {
+      int32_t const vl = A.src[e_hi - 1];  // the last row that starts in the window
+      int64_t const b = A.off[vl], e = A.off[vl + 1];
+      p1 = e - b > LVH_B ? b : e;          // a hub can only be the last row of a window
+    }
+    s_range[0] = p0;
+    s_range[1] = p1 > p0 ? p1 : p0;
+  }
+  for (int i = tid; i < LVH_SLOTS; i += LVH_THREADS) { s_key[i] = LVH_EMPTY; s_sum[i] = 0; }
+  for (int i = tid; i < LVH_B; i += LVH_THREADS) { s_sub[i] = 0; s_best[i] = 0; s_bestc[i] = 0x7f7f7f7f; }
+  __syncthreads();
+  int64_t const p0 = s_range[0];
+  int const n      = (int)(s_range[1] - p0);  // < 2 * LVH_B
+  if (n <= 0) return;
+  // pass 1: (row slot, cluster of destination) -> sum of weights; self-loops per row
+  for (int i = tid; i < n; i += LVH_THREADS) {
+    int64_t const e  = p0 + i;
+    int32_t const v  = A.src[e], u = A.dst[e];
+    uint32_t const cl = (uint32_t)A.c[u];
+    uint32_t const rs = (uint32_t)((int64_t)A.off[v] - e_lo);
+    unsigned long long const wf  = (unsigned long long)__double2ll_rn(A.w[e] * A.scale);
+    unsigned long long const key = ((unsigned long long)rs << 32) | cl;
+    s_cl[i] = cl;
+    s_rs[i] = (uint16_t)rs;
+    uint32_t slot = lvh_slot(rs, cl);
+    for (;;) {
+      unsigned long long const old = atomicCAS(&s_key[slot], LVH_EMPTY, key);
+      if (old == LVH_EMPTY || old == key) break;
+      slot = (slot + 1) & (LVH_SLOTS - 1);
+    }
+    atomicAdd(&s_sum[slot], wf);
+    if (u == v) atomicAdd(&s_sub[rs], wf);
+  }
+  __syncthreads();
+  auto lookup = [&](uint32_t rs, uint32_t cl) -> unsigned long long {  // 0 when the row has no edge into the cluster
+    unsigned long long const key = ((unsigned long long)rs << 32) | cl;
+    uint32_t slot = lvh_slot(rs, cl);
+    for (;;) {
+      unsigned long long const k2 = s_key[slot];
+      if (k2 == key) return s_sum[slot];
+      if (k2 == LVH_EMPTY) return 0ull;
+      slot = (slot + 1) & (LVH_SLOTS - 1);
+    }
+  };
+  // pass 2: the gain of every edge's (row, cluster) pair (pairs that occur on several edges are evaluated as often: same value)
+  for (int i = tid; i < n; i += LVH_THREADS) {
+    int32_t const v   = A.src[p0 + i];
+    uint32_t const rs = s_rs[i], cl = s_cl[i];
+    int32_t const cv  = A.c[v];
+    unsigned long long const sfix = lookup(rs, cl);
+    unsigned long long const self = (int32_t)cl == cv ? sfix : lookup(rs, (uint32_t)cv);
+    unsigned long long const subf = s_sub[rs];
+    double const s       = (double)(long long)sfix * A.inv_scale;
+    double const sub     = (double)(long long)subf * A.inv_scale;
+    double const old_sum = (double)(long long)(self - subf) * A.inv_scale;
+    double const new_sum = (int32_t)cl == cv ? s - sub : s;
+    double const delta   = lv_delta(new_sum, old_sum, A.a[cl], A.a[cv], A.k[v], A.m, A.resolution);
+    unsigned long long const bits = delta > 0.0 ? (unsigned long long)__double_as_longlong(delta) : 0ull;
+    s_bits[i] = bits;
+    if (bits) atomicMax(&s_best[rs], bits);  // positive doubles order like their bit patterns
+  }
+  __syncthreads();
+  // pass 3: the smallest cluster id among the pairs that attain the row's maximum (the reference's tie rule)
+  for (int i = tid; i < n; i += LVH_THREADS) {
+    unsigned long long const bits = s_bits[i];
+    if (bits && bits == s_best[s_rs[i]]) atomicMin(&s_bestc[s_rs[i]], (int32_t)s_cl[i]);
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += LVH_THREADS) {
+    int64_t const e = p0 + i;
+    int32_t const v = A.src[e];
+    if (i == 0 || A.src[e - 1] != v) {  // first edge of a row
+      uint32_t const rs = s_rs[i];
+      A.best_bits[v] = s_best[rs];
+      A.best_c[v]    = s_best[rs] ? s_bestc[rs] : 0x7f7f7f7f;
+    }
+  }
+}
+// hub rows (more than LVH_B edges): their edges, compacted once per level, go through the sorted path
+__global__ void k_lv_hub_flags(int32_t const* src, int32_t const* off, int64_t ne, uint32_t* flag)
+{
+  LV_LOOP(e, ne) { int32_t const v = src[e]; flag[e] = (off[v + 1] - off[v] > LVH_B) ? 1u : 0u; }
+}
+__global__ void k_lv_hub_compact(int32_t const* src, int32_t const* dst, double const* w, uint32_t const* flag, uint32_t const* pos, int64_t ne, int32_t* hs,
+                                 int32_t* hd, double* hw)
+{
+  LV_LOOP(e, ne) if (flag[e]) { uint32_t const q = pos[e]; hs[q] = src[e]; hd[q] = dst[e]; hw[q] = w[e]; }
+}
 __global__ void k_best_finalize(unsigned long long const* best_bits, int32_t* best_c, double* best_d, int64_t nv)
 {
   LV_LOOP(v, nv)
@@ -414,10 +536,35 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   double const scale = fixed_scale(m);
   dvec<double> k((size_t)nv), a((size_t)nv), best_d((size_t)nv), scal(2), parts;
   dvec<long long> kfix((size_t)nv);
-  dvec<unsigned long long> afix((size_t)nv), vfix((size_t)nv * 3), segfix((size_t)std::max<int64_t>(ne, 1));
+  dvec<unsigned long long> afix((size_t)nv), vfix((size_t)nv * 3), segfix;
   dvec<int32_t> c((size_t)nv), best_c((size_t)nv);
-  dvec<uint32_t> count(2), eperm((size_t)std::max<int64_t>(ne, 1));
-  dvec<uint64_t> ekeys((size_t)std::max<int64_t>(ne, 1));
+  // rows of at most LVH_B edges: hash path (k_lv_hash_chunks); longer rows ("hubs"): their edges are compacted once per level
+  // and take the sorted path.  CUGRAPH_AMD_LOUVAIN_HASH=0: every row takes the sorted path (round 2's behaviour).
+  bool const use_hash = ne > 0 && !(getenv("CUGRAPH_AMD_LOUVAIN_HASH") && atoi(getenv("CUGRAPH_AMD_LOUVAIN_HASH")) == 0);
+  level_t Lh;  // the hub rows' edges (use_hash) -- src / dst / w only
+  int64_t n_sorted = ne;
+  if (use_hash) {
+    dvec<uint32_t> flag((size_t)ne + 1), pos((size_t)ne + 1);
+    hipLaunchKernelGGL(k_lv_hub_flags, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.off.data(), ne, flag.data());
+    HIP_TRY(hipMemsetAsync(flag.data() + ne, 0, sizeof(uint32_t), h.stream));
+    exclusive_scan_u32(h, flag.data(), pos.data(), ne + 1);
+    uint32_t nh = 0;
+    h.read_back(&nh, pos.data() + ne, 1);
+    n_sorted = nh;
+    size_t const h1 = (size_t)std::max<int64_t>(n_sorted, 1);
+    Lh.src.resize_discard(h1); Lh.dst.resize_discard(h1); Lh.w.resize_discard(h1);
+    if (n_sorted > 0)
+      hipLaunchKernelGGL(k_lv_hub_compact, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.dst.data(), (double const*)L.w.data(),
+                         (uint32_t const*)flag.data(), (uint32_t const*)pos.data(), ne, Lh.src.data(), Lh.dst.data(), Lh.w.data());
+    h.sync();
+  }
+  int32_t const* const s_src = use_hash ? Lh.src.data() : L.src.data();
+  int32_t const* const s_dst = use_hash ? Lh.dst.data() : L.dst.data();
+  double const* const s_w    = use_hash ? Lh.w.data() : L.w.data();
+  int const g_s = grid_for(n_sorted, kBlock, 8192);
+  dvec<uint32_t> count(2), eperm((size_t)std::max<int64_t>(n_sorted, 1));
+  dvec<uint64_t> ekeys((size_t)std::max<int64_t>(n_sorted, 1));
+  segfix.resize_discard((size_t)std::max<int64_t>(n_sorted, 1));
   accepted.resize_discard((size_t)nv);
   HIP_TRY(hipMemsetAsync(kfix.data(), 0, (size_t)nv * sizeof(long long), h.stream));
   if (ne > 0) hipLaunchKernelGGL(k_vertex_weights, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (double const*)L.w.data(), ne, scale,
@@ -448,22 +595,27 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     ++st.sweeps;
     ++st.sweeps_in_level;
     // update_clustering_by_delta_modularity (common_methods.cuh:259-447)
-    if (ne > 0) {
-      hipLaunchKernelGGL(k_pair_keys, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)nullptr, (int32_t const*)L.dst.data(),
-                         (int32_t const*)c.data(), ne, vb, ekeys.data(), eperm.data());
+    if (n_sorted > 0) {
+      hipLaunchKernelGGL(k_pair_keys, g_s, kBlock, 0, h.stream, s_src, (int32_t const*)nullptr, s_dst, (int32_t const*)c.data(), n_sorted, vb, ekeys.data(),
+                         eperm.data());
       // first sweep of a level: every vertex is its own cluster, so the key is (source, destination) -- the order the level's
       // edges are stored in (CSR order / the contraction's output): nothing to sort
-      if (st.sweeps_in_level > 1) sort_pairs(h, ekeys, eperm, ne, 2 * vb);
+      if (st.sweeps_in_level > 1) sort_pairs(h, ekeys, eperm, n_sorted, 2 * vb);
     }
     HIP_TRY(hipMemsetAsync(vfix.data(), 0, (size_t)nv * 3 * sizeof(unsigned long long), h.stream));  // selffix, subfix, best_bits
     HIP_TRY(hipMemsetAsync(best_c.data(), 0x7f, (size_t)nv * sizeof(int32_t), h.stream));
-    if (ne > 0) {
-      HIP_TRY(hipMemsetAsync(segfix.data(), 0, (size_t)ne * sizeof(unsigned long long), h.stream));
-      lv_flat_args A{ekeys.data(), eperm.data(), L.dst.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, ne, vb,
+    if (n_sorted > 0) {
+      HIP_TRY(hipMemsetAsync(segfix.data(), 0, (size_t)n_sorted * sizeof(unsigned long long), h.stream));
+      lv_flat_args A{ekeys.data(), eperm.data(), s_dst, s_w, c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, n_sorted, vb,
                      segfix.data(), vfix.data(), vfix.data() + nv, vfix.data() + 2 * nv, best_c.data()};
-      hipLaunchKernelGGL(k_segment_sums, g_e, kBlock, 0, h.stream, A);
-      hipLaunchKernelGGL(k_segment_best<0>, g_e, kBlock, 0, h.stream, A);
-      hipLaunchKernelGGL(k_segment_best<1>, g_e, kBlock, 0, h.stream, A);
+      hipLaunchKernelGGL(k_segment_sums, g_s, kBlock, 0, h.stream, A);
+      hipLaunchKernelGGL(k_segment_best<0>, g_s, kBlock, 0, h.stream, A);
+      hipLaunchKernelGGL(k_segment_best<1>, g_s, kBlock, 0, h.stream, A);
+    }
+    if (use_hash && n_sorted < ne) {
+      lv_hash_args HA{L.src.data(), L.dst.data(), L.off.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, ne,
+                      vfix.data() + 2 * nv, best_c.data()};
+      hipLaunchKernelGGL(k_lv_hash_chunks, (int)((ne + LVH_B - 1) / LVH_B), LVH_THREADS, 0, h.stream, HA);
     }
     hipLaunchKernelGGL(k_best_finalize, g_v, kBlock, 0, h.stream, (unsigned long long const*)(vfix.data() + 2 * nv), best_c.data(), best_d.data(), nv);
     HIP_TRY(hipMemsetAsync(count.data(), 0, 2 * sizeof(uint32_t), h.stream));

@@ -1248,6 +1248,206 @@ struct pagerank_mg_plan : pagerank_mg_plan_base {
   }
 };
 
+// =================================================================================================
+// 2-D layout (north_star / the reference's own scheme; cpp/include/cugraph/graph_view.hpp:159-216,
+// partition_manager.hpp:42-51): P = R x C ranks, rank = c * R + r.  Vertex partitions 0 .. P-1 of L rows each (position p of the
+// global degree order -> partition p % P, row p / P); rank (r, c) OWNS partition c * R + r and STORES the edges whose source lies
+// in the R partitions of its column group [c * R, (c + 1) * R) and whose destination lies in the C partitions {i * R + r}:
+// local column id = (q_src % R) * L + row, local row id = (q_dst / R) * L + row.  Per iteration (host layer: cugraph_amd/mg.py,
+// MGPageRank2D): all-gather of x over the column group (update_edge_src_dst_property.cuh:550-579) -> spmv() = plain tiled SpMV
+// of the local block (phase 2 in raw mode: no epilogue) -> reduce-scatter of the C partial row blocks over the row group
+// (per_v_transform_reduce_e.cuh:3390-3406) -> epilogue() on the owned L rows -> all-gather of the (L1 change, dangling, max|x|)
+// triples, folded in rank order by set_scalars().  Built to be measured against the 1-D sparse all-to-all on real hardware;
+// DESIGN.md section 5 has the byte counts of both.
+// =================================================================================================
+// iteration-0 state of an owned slice: x = pr / out_w, per-block (0, dangling mass, max |x|) partials
+template <typename WT>
+__global__ void __launch_bounds__(256) k_tiled_prologue_plain(WT const* pr, WT const* outw, WT* x, int64_t n, double* partials)
+{
+  __shared__ double red[2][4];
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double dang = 0.0, xmax = 0.0;
+  for (; i < n; i += stride) {
+    WT const p = pr[i], ow = outw[i];
+    WT const xv = p / (ow == WT(0) ? WT(1) : ow);
+    x[i] = xv;
+    xmax = fmax(xmax, fabs((double)xv));
+    if (ow == WT(0)) dang += (double)p;
+  }
+  dang = group_sum(dang, 64);
+  for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_xor(xmax, o));
+  int const wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = dang; red[1][wave] = xmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[3 * blockIdx.x]     = 0.0;
+    partials[3 * blockIdx.x + 1] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partials[3 * blockIdx.x + 2] = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
+  }
+}
+
+template <typename WT>
+__global__ void __launch_bounds__(256) k_mg2d_epilogue(WT const* y_own, WT const* outw, WT* pr, WT* x_own, int64_t n, pr_scalars<WT> const* scal, double* partials)
+{
+  __shared__ double red[3][4];
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  WT const base  = scal->base;
+  double diff = 0.0, dang = 0.0, xmax = 0.0;
+  for (; i < n; i += stride) {
+    WT const old = pr[i], ow = outw[i];
+    WT const val = base + y_own[i];
+    WT const xn  = val / (ow == WT(0) ? WT(1) : ow);
+    pr[i]    = val;
+    x_own[i] = xn;
+    diff += (double)fabs(val - old);
+    xmax = fmax(xmax, fabs((double)xn));
+    if (ow == WT(0)) dang += (double)val;
+  }
+  diff = group_sum(diff, 64);
+  dang = group_sum(dang, 64);
+  for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_xor(xmax, o));
+  int const wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = diff; red[1][wave] = dang; red[2][wave] = xmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[3 * blockIdx.x]     = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partials[3 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    partials[3 * blockIdx.x + 2] = fmax(fmax(red[2][0], red[2][1]), fmax(red[2][2], red[2][3]));
+  }
+}
+
+struct pagerank_mg2d_plan_base {
+  virtual ~pagerank_mg2d_plan_base() = default;
+  virtual void start()                                                          = 0;
+  virtual void set_scalars(void const* gathered, int nranks, bool read_back, double* diff, double* dangling) = 0;
+  virtual void spmv()                                                           = 0;
+  virtual void epilogue()                                                       = 0;
+  virtual void values(device_array_view_t const* out)                           = 0;
+};
+
+template <typename WT>
+struct pagerank_mg2d_plan : pagerank_mg2d_plan_base {
+  handle_t const& h;
+  graph_t& g;
+  WT alpha;
+  int64_t L, n_block_rows, n_block_cols, nv_global;
+  dvec<WT> pr, outw, part, x_pad;
+  WT* x_own{nullptr};    // [L]        caller-owned: this rank's x = pr / out_w (input of the column all-gather)
+  WT const* x_cols{nullptr};  // [R * L]  caller-owned: the gathered x of the column group
+  WT* y_part{nullptr};   // [C * L]    caller-owned: partial row sums of the local block (input of the row reduce-scatter)
+  WT const* y_own{nullptr};   // [L]      caller-owned: the reduced rows this rank owns
+  double* triple{nullptr};    // [4]      caller-owned: this rank's (L1 change, dangling mass, max |x|, 0)
+  dvec<pr_scalars<WT>> scal;
+  dvec<double> tpartials;
+  dvec<uint32_t> counters;
+  std::shared_ptr<tiled_csc_t> tc;
+  int epi_grid{1};
+
+  pagerank_mg2d_plan(handle_t const& h_, graph_t& g_, double alpha_, int64_t L_, int64_t rows_, int64_t cols_, int64_t nv_global_)
+    : h(h_), g(g_), alpha((WT)alpha_), L(L_), n_block_rows(rows_), n_block_cols(cols_), nv_global(nv_global_)
+  {
+  }
+
+  void create(device_array_view_t const* outw_own, device_array_view_t const* init_own, device_array_view_t const* x_own_v, device_array_view_t const* x_cols_v,
+              device_array_view_t const* y_part_v, device_array_view_t const* y_own_v, device_array_view_t const* triple_v)
+  {
+    HIP_TRY(hipSetDevice(h.device));
+    auto typed = [&](device_array_view_t const* v, int64_t n) { return v != nullptr && v->type == g.weight_type && (int64_t)v->size == n; };
+    CGA_EXPECTS(typed(outw_own, L) && typed(x_own_v, L) && typed(y_own_v, L) && typed(x_cols_v, n_block_cols) && typed(y_part_v, n_block_rows), CUGRAPH_INVALID_INPUT,
+                "2-D multi-GPU PageRank: out_weight_sums / x_own / y_own need L values, x_cols R * L, y_part C * L, all of the weight type");
+    CGA_EXPECTS(triple_v != nullptr && triple_v->type == FLOAT64 && triple_v->size == 4, CUGRAPH_INVALID_INPUT, "2-D multi-GPU PageRank: triple must hold 4 doubles");
+    CGA_EXPECTS(n_block_rows <= g.nv && n_block_cols <= g.nv, CUGRAPH_INVALID_INPUT, "2-D multi-GPU PageRank: the local graph must have max(block rows, block columns) vertices");
+    x_own = x_own_v->as<WT>(); x_cols = x_cols_v->as<WT const>(); y_part = y_part_v->as<WT>(); y_own = y_own_v->as<WT const>();
+    triple = triple_v->as<double>();
+    ensure_orientation(h, g, true);
+    orientation_t& o = g.csc;
+    CGA_EXPECTS(o.seg[4] <= n_block_rows, CUGRAPH_INVALID_INPUT, "2-D multi-GPU PageRank: edges point to rows outside the local block");
+    size_t const n1 = (size_t)(L > 0 ? L : 1);
+    pr.resize_discard(n1); outw.resize_discard(n1);
+    scal.resize_discard(1);
+    HIP_TRY(hipMemsetAsync(scal.data(), 0, sizeof(pr_scalars<WT>), h.stream));
+    HIP_TRY(hipMemsetAsync(triple, 0, 4 * sizeof(double), h.stream));
+    if (L > 0) HIP_TRY(hipMemcpyAsync(outw.data(), outw_own->data, L * sizeof(WT), hipMemcpyDeviceToDevice, h.stream));
+    if (init_own) {
+      CGA_EXPECTS(typed(init_own, L), CUGRAPH_INVALID_INPUT, "initial guess: one value per owned row");
+      if (L > 0) HIP_TRY(hipMemcpyAsync(pr.data(), init_own->data, L * sizeof(WT), hipMemcpyDeviceToDevice, h.stream));
+    } else {
+      fill_wt<WT>(h, pr.data(), L, WT(1) / (WT)nv_global);
+    }
+    int const T = tiled_default_T(h, sizeof(WT), std::max<int64_t>(n_block_cols, 1));
+    if (!o.tiled || o.tiled->T != T || o.tiled->nv != n_block_rows) {
+      auto t = std::make_shared<tiled_csc_t>();
+      build_tiled_csc(h, g.nv, n_block_rows, g.ne, o, g.has_weights, sizeof(WT), T, *t);
+      o.tiled = t;
+    }
+    tc = o.tiled;
+    part.resize_discard((size_t)tc->n_slots + 64);
+    HIP_TRY(hipMemsetAsync(part.data(), 0, ((size_t)tc->n_slots + 64) * sizeof(WT), h.stream));
+    size_t const nx = (size_t)tc->nJ * tc->T + 8;  // the gather vector is read tile-wise: padded copy of x_cols
+    x_pad.resize_discard(nx);
+    HIP_TRY(hipMemsetAsync(x_pad.data(), 0, nx * sizeof(WT), h.stream));
+    counters.resize_discard(4);
+    HIP_TRY(hipMemsetAsync(counters.data(), 0, 4 * sizeof(uint32_t), h.stream));
+    epi_grid = std::max(1, std::min(grid_for(L, 256, 1024), 1024));
+    tpartials.resize_discard((size_t)3 * std::max({tc->nI, 1024, epi_grid}));
+    h.sync();
+  }
+
+  tiled_epilogue<WT> epi()
+  {
+    tiled_epilogue<WT> e;
+    e.nv = L; e.pr = pr.data(); e.x_next = x_own; e.outw = outw.data(); e.pers = nullptr; e.scal = scal.data();
+    e.partials = tpartials.data(); e.totals = triple; e.alpha = alpha; e.nv_global = nv_global; e.wmax = tc->wmax;
+    return e;
+  }
+  void done() { if (!h.stream_borrowed) h.sync(); }  // the host layer's collectives run on its own stream -- unless it shares ours
+
+  void start() override
+  {  // x_own <- x of the initial vector, triple <- (0, partial dangling mass, max |x|)
+    HIP_TRY(hipSetDevice(h.device));
+    int const grid = std::max(1, std::min(grid_for(L, 256, 1024), 1024));
+    hipLaunchKernelGGL(k_tiled_prologue_plain<WT>, grid, 256, 0, h.stream, (WT const*)pr.data(), (WT const*)outw.data(), x_own, L, tpartials.data());
+    tiled_finish<WT>(h, epi(), grid);
+    h.sync();
+  }
+  void set_scalars(void const* gathered, int nranks, bool read_back, double* diff, double* dangling) override
+  {
+    tiled_scalars_from_ranks<WT>(h, epi(), gathered, 0, 4 * sizeof(double), nranks);
+    if (read_back) {
+      pr_scalars<WT> sc;
+      h.read_back(&sc, scal.data(), 1);
+      if (diff) *diff = (double)sc.diff;
+      if (dangling) *dangling = (double)sc.dangling;
+    }
+  }
+  void spmv() override
+  {
+    HIP_TRY(hipSetDevice(h.device));
+    if (n_block_cols > 0) HIP_TRY(hipMemcpyAsync(x_pad.data(), x_cols, n_block_cols * sizeof(WT), hipMemcpyDeviceToDevice, h.stream));
+    tiled_epilogue<WT> e = epi();
+    e.nv    = n_block_rows;
+    e.raw_y = y_part;
+    tiled_phase1<WT>(h, *tc, (WT const*)x_pad.data(), alpha, part.data(), counters.data(), tiled_x_map<WT>{}, nullptr);
+    tiled_phase2<WT>(h, *tc, (WT const*)part.data(), e, counters.data());
+    done();
+  }
+  void epilogue() override
+  {
+    hipLaunchKernelGGL(k_mg2d_epilogue<WT>, epi_grid, 256, 0, h.stream, y_own, (WT const*)outw.data(), pr.data(), x_own, L, (pr_scalars<WT> const*)scal.data(),
+                       tpartials.data());
+    tiled_finish<WT>(h, epi(), epi_grid);  // this rank's (L1 change, dangling, max |x|) -> triple
+    done();
+  }
+  void values(device_array_view_t const* out) override
+  {
+    CGA_EXPECTS(out != nullptr && (int64_t)out->size == L && out->type == g.weight_type, CUGRAPH_INVALID_INPUT, "values: one weight-typed value per owned row");
+    if (L > 0) HIP_TRY(hipMemcpyAsync(out->data, pr.data(), L * sizeof(WT), hipMemcpyDeviceToDevice, h.stream));
+    h.sync();
+  }
+};
+
 namespace {
 
 void check_pair_types(graph_t const& g, device_array_view_t const* v, device_array_view_t const* s, char const* vmsg, char const* smsg)
@@ -1481,3 +1681,53 @@ extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg_plan_values(cugraph_amd_
   return guarded(error, [&] { CGA_EXPECTS(plan, CUGRAPH_INVALID_INPUT, "plan is NULL"); reinterpret_cast<pagerank_mg_plan_base*>(plan)->values(V(out_local)); });
 }
 extern "C" void cugraph_amd_pagerank_mg_plan_free(cugraph_amd_pagerank_mg_plan_t* plan) { delete reinterpret_cast<pagerank_mg_plan_base*>(plan); }
+
+// ---- 2-D layout (see pagerank_mg2d_plan)
+extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_create(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, size_t rows_per_partition, size_t block_rows, size_t block_cols, size_t global_num_vertices,
+  const cugraph_type_erased_device_array_view_t* out_weight_sums_own, const cugraph_type_erased_device_array_view_t* initial_own,
+  cugraph_type_erased_device_array_view_t* x_own, const cugraph_type_erased_device_array_view_t* x_cols, cugraph_type_erased_device_array_view_t* y_part,
+  const cugraph_type_erased_device_array_view_t* y_own, cugraph_type_erased_device_array_view_t* triple, double alpha, cugraph_amd_pagerank_mg2d_plan_t** plan,
+  cugraph_error_t** error)
+{
+  if (plan) *plan = nullptr;
+  return guarded(error, [&] {
+    handle_t const& h = H(handle);
+    graph_t& g        = G(graph);
+    CGA_EXPECTS(plan != nullptr, CUGRAPH_INVALID_INPUT, "plan is NULL");
+    CGA_EXPECTS(alpha >= 0.0 && alpha <= 1.0, CUGRAPH_INVALID_INPUT, "Invalid input argument: alpha should be in [0.0, 1.0].");
+    struct release_temporaries { ~release_temporaries() { pool_release_large_blocks(); } } on_exit;
+    if (g.weight_type == FLOAT64) {
+      auto p = std::make_unique<pagerank_mg2d_plan<double>>(h, g, alpha, (int64_t)rows_per_partition, (int64_t)block_rows, (int64_t)block_cols, (int64_t)global_num_vertices);
+      p->create(V(out_weight_sums_own), V(initial_own), V(x_own), V(x_cols), V(y_part), V(y_own), V(triple));
+      *plan = reinterpret_cast<cugraph_amd_pagerank_mg2d_plan_t*>(static_cast<pagerank_mg2d_plan_base*>(p.release()));
+    } else {
+      auto p = std::make_unique<pagerank_mg2d_plan<float>>(h, g, alpha, (int64_t)rows_per_partition, (int64_t)block_rows, (int64_t)block_cols, (int64_t)global_num_vertices);
+      p->create(V(out_weight_sums_own), V(initial_own), V(x_own), V(x_cols), V(y_part), V(y_own), V(triple));
+      *plan = reinterpret_cast<cugraph_amd_pagerank_mg2d_plan_t*>(static_cast<pagerank_mg2d_plan_base*>(p.release()));
+    }
+  });
+}
+extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_start(cugraph_amd_pagerank_mg2d_plan_t* plan, cugraph_error_t** error)
+{
+  return guarded(error, [&] { reinterpret_cast<pagerank_mg2d_plan_base*>(plan)->start(); });
+}
+extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_set_scalars(cugraph_amd_pagerank_mg2d_plan_t* plan, const void* gathered_triples, int comm_size,
+                                                                          bool_t read_back, double* diff, double* dangling, cugraph_error_t** error)
+{
+  return guarded(error, [&] { reinterpret_cast<pagerank_mg2d_plan_base*>(plan)->set_scalars(gathered_triples, comm_size, read_back == TRUE, diff, dangling); });
+}
+extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_spmv(cugraph_amd_pagerank_mg2d_plan_t* plan, cugraph_error_t** error)
+{
+  return guarded(error, [&] { reinterpret_cast<pagerank_mg2d_plan_base*>(plan)->spmv(); });
+}
+extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_epilogue(cugraph_amd_pagerank_mg2d_plan_t* plan, cugraph_error_t** error)
+{
+  return guarded(error, [&] { reinterpret_cast<pagerank_mg2d_plan_base*>(plan)->epilogue(); });
+}
+extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_values(cugraph_amd_pagerank_mg2d_plan_t* plan, cugraph_type_erased_device_array_view_t* out_own,
+                                                                     cugraph_error_t** error)
+{
+  return guarded(error, [&] { reinterpret_cast<pagerank_mg2d_plan_base*>(plan)->values(V(out_own)); });
+}
+extern "C" void cugraph_amd_pagerank_mg2d_plan_free(cugraph_amd_pagerank_mg2d_plan_t* plan) { delete reinterpret_cast<pagerank_mg2d_plan_base*>(plan); }

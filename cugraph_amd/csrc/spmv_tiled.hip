@@ -1348,9 +1348,10 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     uint32_t i = tid + j * TP2_BLOCK;
-    old[j] = (e.need_diff && i < nrows) ? e.pr[(size_t)row0 + i] : WT(0);
-    ow[j]  = i < nrows ? e.outw[(size_t)row0 + i] : WT(1);
-    col[j] = (e.xcol && i < nrows) ? e.xcol[(size_t)row0 + i] : (int32_t)(row0 + i);
+    bool const in = i < nrows && e.raw_y == nullptr;  // (plain SpMV mode has no epilogue)
+    old[j] = (e.need_diff && in) ? e.pr[(size_t)row0 + i] : WT(0);
+    ow[j]  = in ? e.outw[(size_t)row0 + i] : WT(1);
+    col[j] = (e.xcol && in) ? e.xcol[(size_t)row0 + i] : (int32_t)(row0 + i);
   }
   for (uint32_t i = tid; i < nrows; i += TP2_BLOCK) acc[i] = ACC(0);
   __syncthreads();
@@ -1396,6 +1397,20 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
     }
   }
   __syncthreads();
+  if (e.raw_y) {  // (workgroup-uniform) plain SpMV: the row sums and nothing else -- the 2-D multi-GPU layout reduces them over ranks first
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      uint32_t i = tid + j * TP2_BLOCK;
+      if (i < nrows) {
+        WT sum;
+        if constexpr (sizeof(WT) == 4) sum = (WT)((double)(long long)acc[i] * sc.fx_inv);
+        else sum = acc[i];
+        e.raw_y[(size_t)row0 + i] = sum;
+      }
+    }
+    if (tid == 0 && I == 0) a.counters[0] = 0;  // rewind phase 1's chunk cursor
+    return;
+  }
 
   double diff = 0.0, dang = 0.0, xmax = 0.0;
 #pragma unroll

@@ -160,6 +160,8 @@ struct tiled_epilogue {
   bool need_diff{true};          // false: the L1 change is not wanted (fixed iteration count): the previous iterate is not read
                                  // (-0.11 GB per iteration at RMAT-26, phase 2 0.436 -> 0.418 ms).  Deriving the row -> column map from one
                                  // bit per row instead of reading xcol was tried with it and lost (+0.012 ms: the lookups sit at the end)
+  WT* raw_y{nullptr};            // non-null: plain SpMV -- phase 2 stores y[row] = sum of the row's partials and nothing else (no base term, no
+                                 // division, no scalars): the 2-D multi-GPU layout reduces the partial rows over a column of ranks first
   WT const* outw{nullptr};
   WT const* pers{nullptr};  // dense normalised personalization or nullptr
   pr_scalars<WT>* scal{nullptr};

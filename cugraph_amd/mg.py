@@ -335,6 +335,268 @@ def pagerank(src, dst, num_vertices, weights=None, alpha=0.85, epsilon=1e-6, max
     return v, x, done, (conv and done < max_iterations)
 
 
+# ============================================================================================================
+# 2-D layout: the reference's partitioning (partition_t, cpp/include/cugraph/graph_view.hpp:63-230; partition_manager.hpp:42-51,165-178)
+# behind the same orchestration, as an A/B against the 1-D sparse all-to-all above.
+# ============================================================================================================
+def grid_shape(world: int):
+    """(R, C) with R * C = world and R the largest divisor <= sqrt(world): 1x2, 2x2, 2x4 for 2, 4, 8 ranks
+    (cpp/tests/utilities/mg_utilities.cpp:48-52 picks the row size the same way)."""
+    r = int(world ** 0.5)
+    while world % r:
+        r -= 1
+    return r, world // r
+
+
+class Partition2D:
+    """partition_t arithmetic for P = R x C ranks, rank = c * R + r (partition_manager.hpp:42-51).
+
+    Vertices: position p in the global descending in-degree order (ties: ascending id) -> vertex partition q = p % P, row l = p // P;
+    every partition has L = ceil(V / P) rows (the last ones padded).  Rank (r, c) OWNS partition q = c * R + r = its rank.
+    Edge (s, d) is STORED on the rank whose column group holds s and whose row group holds d:
+        c = q_s // R,  r = q_d % R;   local column (q_s % R) * L + l_s in [0, R * L);   local row (q_d // R) * L + l_d in [0, C * L).
+    Column group of rank (r, c) = ranks {c * R + r'}: their owned partitions are exactly the block's R source partitions, in local
+    column order (all-gather).  Row group = ranks {c' * R + r}: member c' owns the block's destination partition c' (reduce-scatter)."""
+
+    def __init__(self, in_degree: torch.Tensor, world: int, rank: int, shape=None):
+        self.nv = int(in_degree.numel())
+        self.world, self.rank = world, rank
+        self.R, self.C = shape or grid_shape(world)
+        assert self.R * self.C == world
+        self.r, self.c = rank % self.R, rank // self.R
+        _, order = torch.sort(in_degree, descending=True, stable=True)
+        self.order = order
+        self.pos = torch.empty_like(order)
+        self.pos[order] = torch.arange(self.nv, dtype=order.dtype, device=order.device)
+        self.L = -(-self.nv // world)
+        self.local_vertices = order[rank::world]
+        self.n_rows = int(self.local_vertices.numel())  # owned (unpadded) rows
+        self.col_group = [self.c * self.R + rr for rr in range(self.R)]
+        self.row_group = [cc * self.R + self.r for cc in range(self.C)]
+
+    def edge_owner(self, pos_src, pos_dst):
+        P, R = self.world, self.R
+        return ((pos_src % P) // R) * R + (pos_dst % P) % R
+
+    def local_col(self, pos_src):
+        return ((pos_src % self.world) % self.R) * self.L + pos_src // self.world
+
+    def local_row(self, pos_dst):
+        return ((pos_dst % self.world) // self.R) * self.L + pos_dst // self.world
+
+
+class LocalEngine2D:
+    """Per-rank compute of the 2-D layout.  Buffers (torch tensors): x_own [L], x_cols [R * L], y_part [C * L], y_own [L], triple [4] f64."""
+
+    def start(self):
+        raise NotImplementedError
+
+    def set_scalars(self, gathered, read_back: bool):
+        raise NotImplementedError
+
+    def spmv(self):
+        raise NotImplementedError
+
+    def epilogue(self):
+        raise NotImplementedError
+
+    def values(self) -> torch.Tensor:
+        raise NotImplementedError
+
+
+class HipLocalEngine2D(LocalEngine2D):
+    """The product path: local block as a CSC graph + cugraph_amd_pagerank_mg2d_plan_* (HIP)."""
+
+    def __init__(self, part: Partition2D, local_col, local_row, weights, outw_own, alpha, initial_own=None):
+        from . import _capi as capi
+        from .pylib import GraphProperties, ResourceHandle, SGGraph, _View, assert_success
+
+        self._capi, self._assert = capi, assert_success
+        self.part = part
+        dev = torch.device("cuda", torch.cuda.current_device())
+        L, R, Cc = part.L, part.R, part.C
+        weights = None if weights is None else weights.to(dev)
+        dtype = torch.float64 if (weights is not None and weights.dtype == torch.float64) else torch.float32
+        self.dtype = dtype
+        self.handle = ResourceHandle()
+        nverts = max(R * L, Cc * L, 1)
+        verts = torch.arange(nverts, dtype=torch.int32, device=dev)
+        self.graph = SGGraph(self.handle, GraphProperties(is_multigraph=True), local_col.to(dev).to(torch.int32), local_row.to(dev).to(torch.int32), weights,
+                             store_transposed=True, renumber=False, vertices_array=verts)
+        self.x_own = torch.zeros(L, dtype=dtype, device=dev)
+        self.x_cols = torch.zeros(R * L, dtype=dtype, device=dev)
+        self.y_part = torch.zeros(Cc * L, dtype=dtype, device=dev)
+        self.y_own = torch.zeros(L, dtype=dtype, device=dev)
+        self.triple = torch.zeros(4, dtype=torch.float64, device=dev)
+        outw = torch.zeros(L, dtype=dtype, device=dev)
+        outw[: part.n_rows] = outw_own.to(dev).to(dtype)
+        init = None
+        if initial_own is not None:
+            init = torch.zeros(L, dtype=dtype, device=dev)
+            init[: part.n_rows] = initial_own.to(dev).to(dtype)
+        self._keep = (outw, init)
+        views = [_View(outw), _View(init), _View(self.x_own), _View(self.x_cols), _View(self.y_part), _View(self.y_own), _View(self.triple)]
+        plan, err = C.c_void_p(), C.c_void_p()
+        torch.cuda.current_stream().synchronize()
+        code = capi.lib().cugraph_amd_pagerank_mg2d_plan_create(
+            self.handle.c_resource_handle_ptr, self.graph.c_graph_ptr, L, Cc * L, R * L, part.nv, views[0].ptr, views[1].ptr, views[2].ptr, views[3].ptr,
+            views[4].ptr, views[5].ptr, views[6].ptr, float(alpha), C.byref(plan), C.byref(err))
+        for v in views:
+            v.free()
+        assert_success(code, err, "cugraph_amd_pagerank_mg2d_plan_create")
+        self.plan = plan
+        self.shared_stream = os.environ.get("CUGRAPH_AMD_MG_OWN_STREAM") != "1"
+        if self.shared_stream:
+            self.handle.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def _call(self, name, *args):
+        err = C.c_void_p()
+        code = getattr(self._capi.lib(), name)(self.plan, *args, C.byref(err))
+        self._assert(code, err, name)
+
+    def start(self):
+        self._call("cugraph_amd_pagerank_mg2d_plan_start")
+
+    def set_scalars(self, gathered, read_back):
+        diff, dang = C.c_double(0), C.c_double(0)
+        g = gathered.to(self.x_own.device).contiguous()
+        self._call("cugraph_amd_pagerank_mg2d_plan_set_scalars", C.c_void_p(g.data_ptr()), int(g.numel() // 4), 1 if read_back else 0, C.byref(diff), C.byref(dang))
+        self._last_gathered = g  # stays alive until the kernel that reads it has been ordered behind the next call
+        return float(diff.value), float(dang.value)
+
+    def spmv(self):
+        self._call("cugraph_amd_pagerank_mg2d_plan_spmv")
+
+    def epilogue(self):
+        self._call("cugraph_amd_pagerank_mg2d_plan_epilogue")
+
+    def values(self):
+        from .pylib import _View
+
+        out = torch.empty(self.part.L, dtype=self.dtype, device=self.x_own.device)
+        v = _View(out)
+        self._call("cugraph_amd_pagerank_mg2d_plan_values", v.ptr)
+        v.free()
+        return out[: self.part.n_rows]
+
+    def __del__(self):
+        p = getattr(self, "plan", None)
+        if p:
+            self._capi.lib().cugraph_amd_pagerank_mg2d_plan_free(p)
+            self.plan = None
+
+
+class MGPageRank2D:
+    """Collective: every rank of the world constructs it with ITS slice of the edge list (external ids 0..V-1).  Per iteration:
+    all-gather of x over the column group, local SpMV, reduce-scatter of the partial rows over the row group, epilogue on the owned
+    rows, all-gather of the scalar triples (folded in rank order: deterministic)."""
+
+    def __init__(self, src, dst, num_vertices, weights=None, alpha=0.85, group=None, engine_factory=None, initial_guess=None, shape=None):
+        assert group is None, "the 2-D layout builds its row / column groups from the default process group"
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        nv = int(num_vertices)
+        src64, dst64 = src.to(torch.int64), dst.to(torch.int64)
+        in_deg = torch.bincount(dst64, minlength=nv)
+        if weights is None:
+            out_w = torch.bincount(src64, minlength=nv).to(torch.float64)
+        else:
+            out_w = torch.bincount(src64, weights=weights.to(torch.float64), minlength=nv)
+        dist.all_reduce(in_deg)
+        dist.all_reduce(out_w)
+        self.part = part = Partition2D(in_deg, self.world, self.rank, shape)
+        # every rank creates every group, in the same order (torch.distributed contract)
+        self.col_pg = self.row_pg = None
+        for c in range(part.C):
+            g = dist.new_group([c * part.R + rr for rr in range(part.R)])
+            if c == part.c:
+                self.col_pg = g
+        for r in range(part.R):
+            g = dist.new_group([cc * part.R + r for cc in range(part.C)])
+            if r == part.r:
+                self.row_pg = g
+        pos_src, pos_dst = part.pos[src64], part.pos[dst64]
+        lcol, lrow, w = _exchange_edges(part.local_col(pos_src).to(torch.int32), part.local_row(pos_dst).to(torch.int32), part.edge_owner(pos_src, pos_dst),
+                                        weights, self.world, None)
+        self.num_local_edges = int(lcol.numel())
+        outw_own = out_w[part.local_vertices]
+        init_own = None if initial_guess is None else initial_guess[part.local_vertices]
+        factory = engine_factory or HipLocalEngine2D
+        self.engine = factory(part, lcol, lrow, w, outw_own, alpha, init_own)
+        self.iterations = 0
+        self.engine.start()
+        self.bytes_per_iteration = {"all_gather_in": (part.R - 1) * part.L * self.engine.x_own.element_size(),
+                                    "reduce_scatter_out": (part.C - 1) * part.L * self.engine.x_own.element_size()}
+
+    def _host(self, t):
+        """gloo moves host memory (test configuration: several ranks sharing one GPU)"""
+        return t.is_cuda and dist.get_backend() == "gloo"
+
+    def _gather_x(self):
+        e = self.engine
+        if self._host(e.x_own):
+            out = torch.empty(e.x_cols.shape, dtype=e.x_cols.dtype)
+            dist.all_gather_into_tensor(out, e.x_own.cpu(), group=self.col_pg)
+            e.x_cols.copy_(out)
+        else:
+            dist.all_gather_into_tensor(e.x_cols, e.x_own, group=self.col_pg)
+
+    def _reduce_y(self):
+        e = self.engine
+        if self._host(e.y_part):
+            out = torch.empty(e.y_own.shape, dtype=e.y_own.dtype)
+            dist.reduce_scatter_tensor(out, e.y_part.cpu(), group=self.row_pg)
+            e.y_own.copy_(out)
+        else:
+            dist.reduce_scatter_tensor(e.y_own, e.y_part, group=self.row_pg)
+
+    def _gather_scalars(self, read_back):
+        e = self.engine
+        if self._host(e.triple):
+            out = torch.empty(4 * self.world, dtype=torch.float64)
+            dist.all_gather_into_tensor(out, e.triple.cpu())
+        else:
+            out = torch.empty(4 * self.world, dtype=torch.float64, device=e.triple.device)
+            dist.all_gather_into_tensor(out, e.triple)
+        if e.x_own.is_cuda and not getattr(e, "shared_stream", False):
+            torch.cuda.current_stream().synchronize()
+        return e.set_scalars(out, read_back)
+
+    def _sync_for_library(self):
+        e = self.engine
+        if e.x_own.is_cuda and not getattr(e, "shared_stream", False):
+            torch.cuda.current_stream().synchronize()  # the library computes on its own HIP stream
+
+    def step(self, n_iterations, epsilon=0.0):
+        done = 0
+        while done < n_iterations:
+            diff, _ = self._gather_scalars(epsilon > 0.0)
+            if epsilon > 0.0 and self.iterations > 0 and diff < epsilon:
+                return done, True
+            self._gather_x()
+            self._sync_for_library()
+            self.engine.spmv()
+            self._reduce_y()
+            self._sync_for_library()
+            self.engine.epilogue()
+            self.iterations += 1
+            done += 1
+        if epsilon > 0.0:
+            diff, _ = self._gather_scalars(True)
+            return done, diff < epsilon
+        return done, False
+
+    def result(self):
+        return self.part.local_vertices, self.engine.values()
+
+
+def pagerank_2d(src, dst, num_vertices, weights=None, alpha=0.85, epsilon=1e-6, max_iterations=100, engine_factory=None, shape=None):
+    """Collective PageRank on the 2-D layout; returns (vertices, values, iterations, converged) for this rank's vertices."""
+    pr = MGPageRank2D(src, dst, num_vertices, weights, alpha, None, engine_factory, None, shape)
+    done, conv = pr.step(max_iterations, epsilon)
+    v, x = pr.result()
+    return v, x, done, (conv and done < max_iterations)
+
+
 # ----------------------------------------------------------------------------------------------- bench
 def bench_main(args):
     """bench.py --gpus N (N > 1): strong scaling of the SAME RMAT graph over N ranks, one per GPU."""
@@ -363,7 +625,8 @@ def bench_main(args):
     src, dst = generate_rmat_edgelist(h, args.scale, count, first_edge=first)
     if single:
         src, dst = src.cpu(), dst.cpu()  # gloo: the setup collectives run on host tensors
-    pr = MGPageRank(src, dst, nv, alpha=0.85)
+    layout = getattr(args, "layout", "1d")
+    pr = MGPageRank2D(src, dst, nv, alpha=0.85) if layout == "2d" else MGPageRank(src, dst, nv, alpha=0.85)
     del src, dst
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
@@ -391,9 +654,15 @@ def bench_main(args):
     kernel_s = (ms1 / max(n1, 1) + ms2 / max(n2, 1)) / 1e3
     # phase split of an iteration (3 extra untimed iterations with a synchronisation after every phase; max over ranks):
     # exchange = the sparse all-to-all of x, scalars = folding the P message tails, local = unpack + phase 1 + phase 2 + pack
-    split = torch.zeros(3, dtype=torch.float64)
+    if layout == "2d":
+        # the phases of one real iteration, in order
+        phases = (("scalars", lambda: pr._gather_scalars(False)), ("exchange", lambda: (pr._gather_x(), pr._sync_for_library())), ("spmv", pr.engine.spmv),
+                  ("reduce_rows", lambda: (pr._reduce_y(), pr._sync_for_library())), ("epilogue", pr.engine.epilogue))
+    else:
+        phases = (("exchange", pr._exchange), ("reduce_scalars", lambda: pr.engine.reduce_scalars(False)), ("local_step", pr.engine.local_step))
+    split = torch.zeros(len(phases), dtype=torch.float64)
     for _ in range(3):
-        for k, fn in enumerate((pr._exchange, lambda: pr.engine.reduce_scalars(False), pr.engine.local_step)):
+        for k, (_, fn) in enumerate(phases):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             fn()
@@ -415,6 +684,13 @@ def bench_main(args):
     check = {"mass_err": abs(float(mass.item()) - 1.0), "rows": int(rows.item()), "ok": abs(float(mass.item()) - 1.0) <= 1e-4 and int(rows.item()) == nv,
              "what": "sum of the distributed PageRank vector and number of owned rows over all ranks"}
     local_bytes = 4 * pr.num_local_edges + 16 * pr.part.n_rows + 4  # this rank's share of 4E + 16V + 4
+    if layout == "2d":
+        workload_tail = (f"2-D layout {pr.part.R} x {pr.part.C} (rank = c * R + r): column all-gather of x, block SpMV, row reduce-scatter of the partial rows, "
+                         "scalar all-gather, over RCCL")
+        exchange_info = dict(pr.bytes_per_iteration, grid=[pr.part.R, pr.part.C], rows_per_partition=pr.part.L)
+    else:
+        workload_tail = "1-D destination partition, degree-order round-robin, one sparse all-to-all of x per iteration over RCCL"
+        exchange_info = {"columns": pr.ex.ncols, "recv_bytes_per_iteration": pr.ex.recv_elems * 4, "send_bytes_per_iteration": pr.ex.send_elems * 4}
     out = None
     if rank == 0:
         out = {
@@ -422,14 +698,14 @@ def bench_main(args):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"PageRank power iteration, RMAT scale {args.scale} edge factor {args.edge_factor} (a,b,c)=(0.57,0.19,0.19) "
-                                   "seed 0, int32 ids, fp32 ranks, alpha 0.85; 1-D destination partition, degree-order round-robin, "
-                                   "one sparse all-to-all of x per iteration over RCCL",
-                       "vertices": nv, "edges": ne, "parallelism": f"{world} GPUs, 1 process per GPU"},
+                                   "seed 0, int32 ids, fp32 ranks, alpha 0.85; " + workload_tail,
+                       "vertices": nv, "edges": ne, "parallelism": f"{world} GPUs, 1 process per GPU", "layout": layout,
+                       "backend": dist.get_backend(), "world_size_reported_by_backend": dist.get_world_size()},
             "iters_per_sec": round(args.steps / dt, 2), "graph_build_s": round(build_s, 3), "local_edges_rank0": pr.num_local_edges,
-            "exchange_rank0": {"columns": pr.ex.ncols, "recv_bytes_per_iteration": pr.ex.recv_elems * 4, "send_bytes_per_iteration": pr.ex.send_elems * 4},
+            "exchange_rank0": exchange_info,
             "check": check,
-            "phase_split_ms": {"exchange": round(split[0] * 1e3, 4), "reduce_scalars": round(split[1] * 1e3, 4), "local_step": round(split[2] * 1e3, 4),
-                               "note": "each phase bracketed by synchronisations (no overlap), max over ranks, mean of 3 iterations"},
+            "phase_split_ms": dict({name: round(split[k] * 1e3, 4) for k, (name, _) in enumerate(phases)},
+                                   note="each phase bracketed by synchronisations (no overlap), max over ranks, mean of 3 iterations"),
             "roofline": {"bound": "hbm", "achieved": round(local_bytes / kernel_s / 1e9, 1) if kernel_s > 0 else None, "peak": 8000.0, "unit": "GB/s",
                          "frac": round(local_bytes / kernel_s / 1e9 / 8000.0, 4) if kernel_s > 0 else None, "traffic": None,
                          "kernel": "k_tiled_phase1 + k_tiled_phase2 on rank 0 (per-GPU share of the algorithmic bytes / its kernel time)",

@@ -82,6 +82,37 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg_plan_values(cugraph_
                                                                         cugraph_error_t** error);
 CUGRAPH_EXPORT void cugraph_amd_pagerank_mg_plan_free(cugraph_amd_pagerank_mg_plan_t* plan);
 
+/* 2-D layout of the same iteration (the reference's scheme: cpp/include/cugraph/graph_view.hpp:159-216, partition_manager.hpp:42-51,
+ * prims/update_edge_src_dst_property.cuh:550-579, prims/detail/per_v_transform_reduce_e.cuh:3390-3406): P = R x C ranks, rank = c * R + r;
+ * vertex partitions of rows_per_partition rows (position p of the global degree order -> partition p % P, row p / P); rank (r, c) owns
+ * partition c * R + r and stores the edges with source in partitions [c * R, (c + 1) * R) -- local column (q_src % R) * L + row -- and
+ * destination in partitions {i * R + r} -- local row (q_dst / R) * L + row.  `graph` = that block (CSC, renumber = FALSE,
+ * max(block_rows, block_cols) vertices).  Caller-owned device buffers (weight type): x_own [L] (out: this rank's x = pr / out_w,
+ * the input of the column group's all-gather), x_cols [block_cols = R * L] (in: the gathered x), y_part [block_rows = C * L]
+ * (out: partial row sums, the input of the row group's reduce-scatter), y_own [L] (in: the reduced owned rows), triple [4 doubles]
+ * (out: this rank's L1 change, dangling mass, max |x|).  One iteration = all-gather(x_own -> x_cols), spmv, reduce-scatter(y_part ->
+ * y_own), epilogue, all-gather(triple) + set_scalars.  cugraph_amd/mg.py: MGPageRank2D is the host layer. */
+typedef struct { int32_t align_; } cugraph_amd_pagerank_mg2d_plan_t;
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_create(
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, size_t rows_per_partition, size_t block_rows, size_t block_cols, size_t global_num_vertices,
+  const cugraph_type_erased_device_array_view_t* out_weight_sums_own, const cugraph_type_erased_device_array_view_t* initial_own,
+  cugraph_type_erased_device_array_view_t* x_own, const cugraph_type_erased_device_array_view_t* x_cols, cugraph_type_erased_device_array_view_t* y_part,
+  const cugraph_type_erased_device_array_view_t* y_own, cugraph_type_erased_device_array_view_t* triple, double alpha, cugraph_amd_pagerank_mg2d_plan_t** plan,
+  cugraph_error_t** error);
+/* x_own <- x of the initial vector, triple <- (0, partial dangling mass, max |x|) */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_start(cugraph_amd_pagerank_mg2d_plan_t* plan, cugraph_error_t** error);
+/* folds comm_size gathered triples (4 doubles each, device) in rank order into the iteration's constants; read_back as for the 1-D plan */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_set_scalars(cugraph_amd_pagerank_mg2d_plan_t* plan, const void* gathered_triples,
+                                                                               int comm_size, bool_t read_back, double* diff, double* dangling,
+                                                                               cugraph_error_t** error);
+/* y_part <- (local block) x (alpha * x_cols) */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_spmv(cugraph_amd_pagerank_mg2d_plan_t* plan, cugraph_error_t** error);
+/* pr <- base + y_own, x_own <- pr / out_w, triple <- this rank's scalars */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_epilogue(cugraph_amd_pagerank_mg2d_plan_t* plan, cugraph_error_t** error);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_values(cugraph_amd_pagerank_mg2d_plan_t* plan,
+                                                                          cugraph_type_erased_device_array_view_t* out_own, cugraph_error_t** error);
+CUGRAPH_EXPORT void cugraph_amd_pagerank_mg2d_plan_free(cugraph_amd_pagerank_mg2d_plan_t* plan);
+
 /* Partitioned BFS / SSSP: the per-rank engine (cugraph_amd/csrc/traversal_mg.hip; host layer cugraph_amd/mg_traversal.py).
  * Replaces the multi_gpu = true halves of cpp/src/traversal/bfs_impl.cuh:133-870, sssp_impl.cuh:169-566 and of
  * prims/transform_reduce_if_v_frontier_outgoing_e_by_dst.cuh:617-1127 (the (dst, payload) shuffle to the dst owner is the

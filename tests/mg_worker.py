@@ -78,6 +78,63 @@ class OracleEngine(mg.LocalEngine):
         return torch.from_numpy(self.pr.copy())
 
 
+class OracleEngine2D(mg.LocalEngine2D):
+    """CPU engine of the 2-D layout (same contract as HipLocalEngine2D): scipy block SpMV in fp64, fp32 storage."""
+
+    def __init__(self, part, local_col, local_row, weights, outw_own, alpha, initial_own=None):
+        import scipy.sparse as sp
+
+        self.part, self.alpha = part, float(alpha)
+        L, R, Cc = part.L, part.R, part.C
+        w = np.ones(local_col.numel()) if weights is None else weights.numpy().astype(np.float64)
+        self.A = sp.csr_matrix((w, (local_row.numpy().astype(np.int64), local_col.numpy().astype(np.int64))), shape=(Cc * L, R * L))
+        self.outw = np.zeros(L, np.float32)
+        self.outw[: part.n_rows] = outw_own.numpy().astype(np.float32)
+        self.pr = np.zeros(L, np.float32)
+        self.pr[: part.n_rows] = 1.0 / part.nv if initial_own is None else initial_own.numpy().astype(np.float32)
+        self.x_own = torch.zeros(L, dtype=torch.float32)
+        self.x_cols = torch.zeros(R * L, dtype=torch.float32)
+        self.y_part = torch.zeros(Cc * L, dtype=torch.float32)
+        self.y_own = torch.zeros(L, dtype=torch.float32)
+        self.triple = torch.zeros(4, dtype=torch.float64)
+        self.base = np.float32(0)
+
+    def _x_and_scalars(self, diff):
+        n = self.part.n_rows
+        div = np.where(self.outw == 0, np.float32(1), self.outw)
+        x = (self.pr / div).astype(np.float32)
+        x[n:] = 0  # padding rows of the last partitions
+        self.x_own.numpy()[:] = x
+        owned = np.arange(self.part.L) < n
+        self.triple[0] = diff
+        self.triple[1] = float(self.pr[owned & (self.outw == 0)].astype(np.float64).sum())
+        self.triple[2] = float(np.abs(x).max()) if x.size else 0.0
+
+    def start(self):
+        self._x_and_scalars(0.0)
+
+    def set_scalars(self, gathered, read_back):
+        t = gathered.numpy().reshape(-1, 4)
+        diff, dang = float(t[:, 0].sum()), np.float32(t[:, 1].sum())
+        self.base = np.float32((dang * np.float32(self.alpha) + np.float32(1.0 - self.alpha)) / np.float32(self.part.nv))
+        return diff, float(dang)
+
+    def spmv(self):
+        x = self.x_cols.numpy().astype(np.float64) * np.float64(np.float32(self.alpha))
+        self.y_part.numpy()[:] = (self.A @ x).astype(np.float32)
+
+    def epilogue(self):
+        n = self.part.n_rows
+        new = self.pr.copy()
+        new[:n] = (self.base + self.y_own.numpy()[:n]).astype(np.float32)
+        diff = float(np.abs(new[:n] - self.pr[:n]).astype(np.float64).sum())
+        self.pr = new
+        self._x_and_scalars(diff)
+
+    def values(self):
+        return torch.from_numpy(self.pr[: self.part.n_rows].copy())
+
+
 def main():
     mode, scale, out_dir = sys.argv[1], int(sys.argv[2]), Path(sys.argv[3])
     eps, max_iter = float(sys.argv[4]), int(sys.argv[5])
@@ -86,17 +143,22 @@ def main():
     nv, ne = 1 << scale, 16 << scale
     per = (ne + world - 1) // world
     s, d = orc.rmat(scale, min(per, ne - rank * per), first_edge=rank * per)
-    weighted = mode.endswith("w")
+    weighted = mode.endswith("w")  # (modes: oracle / hip, optional "2d", optional trailing "w" = weighted, "_rounds")
     if mode.endswith("_rounds"):  # exercise the multi-round path of mg._a2a: every message of more than 64 bytes is cut
         mg._A2A_MAX_BYTES = 64
     w = None
     if weighted:
         w = torch.from_numpy(np.random.default_rng(1).integers(1, 9, size=ne).astype(np.float32)[rank * per: rank * per + s.size].copy())
-    factory = OracleEngine if mode.startswith("oracle") else None
+    two_d = "2d" in mode  # the reference's R x C layout (mg.MGPageRank2D) instead of the 1-D sparse all-to-all
+    factory = (OracleEngine2D if two_d else OracleEngine) if mode.startswith("oracle") else None
     if factory is None:
         torch.cuda.set_device(0)
-    v, x, iters, conv = mg.pagerank(torch.from_numpy(s), torch.from_numpy(d), nv, weights=w, alpha=0.85, epsilon=eps, max_iterations=max_iter,
-                                    engine_factory=factory)
+    if two_d:
+        v, x, iters, conv = mg.pagerank_2d(torch.from_numpy(s), torch.from_numpy(d), nv, weights=w, alpha=0.85, epsilon=eps, max_iterations=max_iter,
+                                           engine_factory=factory)
+    else:
+        v, x, iters, conv = mg.pagerank(torch.from_numpy(s), torch.from_numpy(d), nv, weights=w, alpha=0.85, epsilon=eps, max_iterations=max_iter,
+                                        engine_factory=factory)
     np.savez(out_dir / f"rank{rank}.npz", v=v.cpu().numpy(), x=x.cpu().numpy(), iters=iters, conv=conv)
     dist.barrier()
     dist.destroy_process_group()

@@ -1039,6 +1039,36 @@ def test_louvain_scale_vs_oracle(cg, handle, orc, scale):
     assert abs(q - orc.louvain_modularity(src, dst, w, c, 1.0)) <= 1e-9
 
 
+@pytest.mark.parametrize("scale,weights", [(14, "int"), (16, "real")])
+def test_louvain_hash_path_equals_sorted_path(cg, handle, orc, monkeypatch, scale, weights):
+    """Round 3: rows of at most 512 edges take the LDS hash path (k_lv_hash_chunks), hubs the sorted path.  Both accumulate the same
+    fixed-point integers, so the whole run -- clusters, modularity, hierarchy -- must not depend on which path a row takes: compare
+    the default split with CUGRAPH_AMD_LOUVAIN_HASH=0 (every row sorted), on a graph with hubs, isolated vertices, self-loops and
+    multi-edges, and with the numpy / C oracle."""
+    src, dst, w = louvain_rmat_input(orc, scale)
+    nv = 1 << scale
+    rng = np.random.default_rng(3)
+    loops = rng.integers(0, nv, 500).astype(np.int32)           # self-loops (cluster_subtract path)
+    dup = rng.integers(0, src.size, 2000)                       # repeated edges, both directions
+    src, dst = np.concatenate([src, loops, src[dup], dst[dup]]), np.concatenate([dst, loops, dst[dup], src[dup]])
+    wl = np.full(500, 2.0, np.float32)
+    w = np.concatenate([w, wl, w[dup], w[dup]])
+    if weights == "real":
+        w = (w * np.float32(0.37) + np.float32(0.25)).astype(np.float32)
+    o = np.lexsort((dst, src))
+    src, dst, w = src[o], dst[o], w[o]
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CUGRAPH_AMD_LOUVAIN_HASH", mode)
+        g = cg.SGGraph(handle, cg.GraphProperties(is_symmetric=True, is_multigraph=True), T(src, np.int32), T(dst, np.int32), T(w, np.float32), renumber=False,
+                       vertices_array=T(np.arange(nv), np.int32))
+        v, c, q = cg.louvain(handle, g, 100, 1e-7, 1.0, False)
+        res[mode] = (by_vertex(v, c)[0], q)
+    assert np.array_equal(res["1"][0], res["0"][0]) and res["1"][1] == res["0"][1]
+    oc, oq, _, _ = orc.louvain_c(nv, src, dst, w, 100, 1e-7, 1.0)
+    assert np.array_equal(res["1"][0], oc) and abs(res["1"][1] - oq) <= 1e-9
+
+
 def test_capi_generators_edge_columns_and_decompress(cg, handle):
     """cugraph_generate_rmat_edgelists / _edge_ids / _edge_types (graph_generators.h), cugraph_data_type_id_from_dlpack,
     cugraph_graph_create_mg on a one-rank handle and cugraph_decompress_to_edgelist (external ids, by-source order)."""

@@ -120,6 +120,56 @@ def test_mg_pagerank_gloo_cpu(orc, tmp_path, world, mode):
     assert np.max(np.abs(pr - t) / t) <= 2e-5
 
 
+def test_partition_2d_arithmetic(orc):
+    """partition_t of the reference (graph_view.hpp:63-230, partition_manager.hpp:42-51): P = R x C, rank = c * R + r; every edge is
+    stored on exactly one rank, its local column / row ids address the gathered x / the partial rows as the collectives lay them out."""
+    import torch
+
+    from cugraph_amd.mg import Partition2D, grid_shape
+
+    assert [grid_shape(p) for p in (1, 2, 3, 4, 6, 8, 16)] == [(1, 1), (1, 2), (1, 3), (2, 2), (2, 3), (2, 4), (4, 4)]
+    s, d = rmat_graph(orc, 11)
+    nv = 1 << 11
+    indeg = torch.from_numpy(np.bincount(d, minlength=nv))
+    for world in (2, 4, 8):
+        parts = [Partition2D(indeg, world, r) for r in range(world)]
+        R, C, L = parts[0].R, parts[0].C, parts[0].L
+        owned = torch.cat([p.local_vertices for p in parts])
+        assert sorted(owned.tolist()) == list(range(nv))
+        p0 = parts[0]
+        ps, pd = p0.pos[torch.from_numpy(s).long()], p0.pos[torch.from_numpy(d).long()]
+        owner = p0.edge_owner(ps, pd)
+        lc, lr = p0.local_col(ps), p0.local_row(pd)
+        assert int(owner.min()) >= 0 and int(owner.max()) < world and int(lc.max()) < R * L and int(lr.max()) < C * L
+        for rank, p in enumerate(parts):
+            assert (p.r, p.c) == (rank % R, rank // R) and p.col_group == [p.c * R + rr for rr in range(R)] and p.row_group == [cc * R + p.r for cc in range(C)]
+            mine = owner == rank
+            # the source of a stored edge is owned by member (local_col // L) of the column group, at row local_col % L ...
+            src_owner = torch.tensor(p.col_group)[(lc[mine] // L)]
+            assert torch.equal(src_owner, ps[mine] % world) and torch.equal(lc[mine] % L, ps[mine] // world)
+            # ... and its destination by member (local_row // L) of the row group
+            dst_owner = torch.tensor(p.row_group)[(lr[mine] // L)]
+            assert torch.equal(dst_owner, pd[mine] % world) and torch.equal(lr[mine] % L, pd[mine] // world)
+
+
+@pytest.mark.parametrize("world,mode", [(2, "oracle2d"), (4, "oracle2d"), (8, "oracle2d"), (4, "oracle2dw"), (6, "oracle2d")])
+def test_mg_pagerank_2d_gloo_cpu(orc, tmp_path, world, mode):
+    """The 2-D layout (column all-gather of x, block SpMV, row reduce-scatter of the partial rows, scalar all-gather) with the
+    oracle as the per-rank engine: 1x2, 2x2, 2x4 and 2x3 grids against the single-process oracle."""
+    scale = 10
+    pr, iters, conv = run_world(mode, world, scale, tmp_path, eps=0.0, max_iter=12)
+    t, it, _ = truth(orc, scale, 0.0, 12, weighted=mode.endswith("w"))
+    assert iters == 12 and not conv
+    assert np.max(np.abs(pr - t) / t) <= 2e-5
+
+
+def test_mg_pagerank_2d_converges_like_single_gpu(orc, tmp_path):
+    pr, iters, conv = run_world("oracle2d", 4, 9, tmp_path, eps=1e-5, max_iter=200)
+    t, it, tconv = truth(orc, 9, 1e-5, 200)
+    assert conv and tconv and abs(iters - it) <= 1
+    np.testing.assert_allclose(pr, t, rtol=1e-4)
+
+
 def test_mg_pagerank_gloo_cpu_converges_like_single_gpu(orc, tmp_path):
     scale = 9
     pr, iters, conv = run_world("oracle", 2, scale, tmp_path, eps=1e-5, max_iter=200)
@@ -133,6 +183,18 @@ def test_mg_pagerank_gloo_cpu_converges_like_single_gpu(orc, tmp_path):
 def test_mg_pagerank_hip_engine(orc, tmp_path, world, mode):
     """The partitioned HIP path (edge-balanced kernel with the rank-interleaved column ids, piggybacked scalars),
     ranks sharing one GPU and exchanging through gloo."""
+    scale = 12
+    pr, iters, conv = run_world(mode, world, scale, tmp_path, eps=0.0, max_iter=12)
+    t, _, _ = truth(orc, scale, 0.0, 12, weighted=mode.endswith("w"))
+    assert np.max(np.abs(pr - t)) <= 1e-6
+    assert np.max(np.abs(pr - t) / t) <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,mode", [(1, "hip2d"), (2, "hip2d"), (4, "hip2d"), (4, "hip2dw"), (8, "hip2d")])
+def test_mg_pagerank_2d_hip_engine(orc, tmp_path, world, mode):
+    """The 2-D layout on the HIP engine (cugraph_amd_pagerank_mg2d_plan_*: tiled SpMV of the local block in raw mode + owned-row
+    epilogue), ranks sharing one GPU and exchanging through gloo."""
     scale = 12
     pr, iters, conv = run_world(mode, world, scale, tmp_path, eps=0.0, max_iter=12)
     t, _, _ = truth(orc, scale, 0.0, 12, weighted=mode.endswith("w"))
