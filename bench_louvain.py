@@ -75,12 +75,21 @@ def louvain_bench(cg, h, scale=22, edge_factor=8, repeats=3, cpu_scale=18):
                      "kernel": "whole call (all levels: sort + segment passes + contraction); 16 B x edge-sweeps + 28 B x vertex-sweeps + 32 B x contracted edges"},
     }
     # the returned clustering's modularity, recomputed from the edge list with torch (fp64), must be the reported one
-    cl = torch.empty(1 << scale, dtype=torch.int64, device="cuda")
+    # (prefix sums over the source-sorted edge list and over the cluster-sorted vertices: fp64 atomics -- index_add_ -- take seconds here)
+    nvv = 1 << scale
+    cl = torch.empty(nvv, dtype=torch.int64, device="cuda")
     cl[v.to(torch.int64)] = c.to(torch.int64)
     wd = w.double()
     m = wd.sum()
-    k = torch.zeros(1 << scale, dtype=torch.float64, device="cuda").index_add_(0, src.long(), wd)
-    a = torch.zeros(1 << scale, dtype=torch.float64, device="cuda").index_add_(0, cl, k)
+    zero = torch.zeros(1, dtype=torch.float64, device="cuda")
+    c0 = torch.cat([zero, torch.cumsum(wd, 0)])
+    off = torch.searchsorted(src.long().contiguous(), torch.arange(nvv + 1, device="cuda"))
+    k = c0[off[1:]] - c0[off[:-1]]                      # vertex weights (edges are sorted by source)
+    order = torch.argsort(cl)
+    _, counts = torch.unique_consecutive(cl[order], return_counts=True)
+    ends = torch.cumsum(counts, 0)
+    c1 = torch.cat([zero, torch.cumsum(k[order], 0)])
+    a = c1[ends] - c1[ends - counts]                     # cluster weights
     internal = wd[cl[src.long()] == cl[dst.long()]].sum()
     q_torch = float(internal / m - (a * a).sum() / (m * m))
     out["check"] = {"modularity_recomputed_abs_err": abs(q_torch - q), "ok": abs(q_torch - q) <= 1e-9,

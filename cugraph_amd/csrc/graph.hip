@@ -165,8 +165,8 @@ __global__ void k_expand_rows(int32_t const* offsets, int64_t nv, int32_t* rows)
   int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   int lane       = threadIdx.x & 63;
   for (int64_t v = wave; v < nv; v += nwaves) {
-    int32_t b = offsets[v], e = offsets[v + 1];
-    for (int32_t p = b + lane; p < e; p += 64) rows[p] = (int32_t)v;
+    uint32_t const b = (uint32_t)offsets[v], len = (uint32_t)offsets[v + 1] - b;  // unsigned positions: up to 2^32 - 1 edges
+    for (uint32_t p = lane; p < len; p += 64) rows[b + p] = (int32_t)v;
   }
 }
 
@@ -291,17 +291,17 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
                 "Invalid input arguments: src size != edge type prop size");
     // type rules (graph_sg.cpp:745-779): vertex columns are INT32 or INT64; a mix promotes the graph to INT64.  INT64 ids and
     // INT32 ids too sparse for the dense external->internal table are translated at the API boundary (outer_ids.hip); the
-    // kernels keep 32-bit internal ids, so the vertex and edge COUNTS stay below 2^31 either way.
+    // kernels keep 32-bit internal ids (fewer than 2^31 vertices) and UNSIGNED 32-bit edge positions: up to kMaxGraphEdges edges.
+    // (The reference caps an INT32 graph at 2^31 - 1 edges because its edge_t is the vertex type, graph_sg.cpp:766-770, and
+    // switches to int64 offsets beyond; here graphs of 2^31 .. 2^32 - 4097 edges -- symmetrised RMAT-26, the Graph500 input of
+    // scale 26 -- are built and traversed with the same 32-bit arrays; the algorithms that address edges through signed or
+    // 16-bit-tiled positions, PageRank and Louvain, refuse such a graph with CUGRAPH_UNSUPPORTED_TYPE_COMBINATION.)
     auto is_id_type = [](device_array_view_t const* v) { return v == nullptr || v->type == INT32 || v->type == INT64; };
     CGA_EXPECTS(is_id_type(src) && is_id_type(dst) && is_id_type(vertices), CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
                 "vertex ids must be INT32 or INT64");
     bool const any64 = src->type == INT64 || dst->type == INT64 || (vertices && vertices->type == INT64);
-    if (!any64)
-      CGA_EXPECTS(src->size < (size_t)INT32_MAX, CUGRAPH_INVALID_INPUT,
-                  "Number of edges won't fit in 32-bit integer, using 32-bit type");
-    else
-      CGA_EXPECTS(src->size < (size_t)INT32_MAX, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
-                  "INT64 graphs with 2^31 or more edges need 64-bit edge offsets, which this build does not have");
+    CGA_EXPECTS((int64_t)src->size <= kMaxGraphEdges, any64 ? CUGRAPH_UNSUPPORTED_TYPE_COMBINATION : CUGRAPH_INVALID_INPUT,
+                "Number of edges won't fit the 32-bit unsigned edge positions of this build (at most 2^32 - 4097 edges)");
     check_view(src, "src"); check_view(dst, "dst"); check_view(vertices, "vertices");
     outer_ids_t outer;
     dvec<int32_t> c_src, c_dst, c_vtx;  // compact ids when the external ids are translated
@@ -403,7 +403,7 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
       if (drop_self_loops == TRUE) edgelist_drop_self_loops(h, el);
       if (drop_multi_edges == TRUE) edgelist_drop_multi_edges(h, el, vmin, vrange);
       if (symmetrize == TRUE) edgelist_symmetrize(h, el, vmin, vrange);
-      CGA_EXPECTS(el.n < (int64_t)INT32_MAX, CUGRAPH_INVALID_INPUT, "Number of edges won't fit in 32-bit integer, using 32-bit type");
+      CGA_EXPECTS(el.n <= kMaxGraphEdges, CUGRAPH_INVALID_INPUT, "Number of edges won't fit the 32-bit unsigned edge positions of this build");
     }
     int64_t const ne_in = ne;
     if (do_expensive_check == TRUE) {  // create_graph_from_edgelist_impl.cuh:72-126, 1466-1494

@@ -37,7 +37,7 @@ __global__ void k_offsets_to_degrees(int32_t const* offsets, int64_t nv, int32_t
 {
   int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < nv; i += stride) deg[i] = offsets[i + 1] - offsets[i];
+  for (; i < nv; i += stride) deg[i] = (int32_t)((uint32_t)offsets[i + 1] - (uint32_t)offsets[i]);
 }
 
 __global__ void k_gather_degrees(int32_t const* deg, int32_t const* internal_ids, int64_t n, int32_t* out)
@@ -276,8 +276,10 @@ __global__ void k_rows_of_edges(int32_t const* offsets, int64_t nv, int32_t* row
   int64_t wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   int lane       = threadIdx.x & 63;
-  for (int64_t v = wave; v < nv; v += nwaves)
-    for (int32_t p = offsets[v] + lane; p < offsets[v + 1]; p += 64) rows[p] = (int32_t)v;
+  for (int64_t v = wave; v < nv; v += nwaves) {
+    uint32_t const b = (uint32_t)offsets[v], len = (uint32_t)offsets[v + 1] - b;
+    for (uint32_t p = lane; p < len; p += 64) rows[b + p] = (int32_t)v;
+  }
 }
 }  // namespace
 }  // namespace cga

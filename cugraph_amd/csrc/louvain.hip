@@ -651,6 +651,7 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
     graph_t& g        = G(graph);
     CGA_EXPECTS(result != nullptr, CUGRAPH_INVALID_INPUT, "result is NULL");
     HIP_TRY(hipSetDevice(h.device));
+    CGA_EXPECTS(g.ne <= kMaxSignedEdges, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "Louvain: graphs of 2^31 or more edges are not supported");
     ensure_orientation(h, g, false);  // louvain expects store_transposed == false (louvain.cpp:60-66)
     orientation_t const& o = g.csr;
     int64_t const nv0 = g.nv;

@@ -858,6 +858,8 @@ struct pagerank_plan : pagerank_plan_base {
               device_array_view_t const* ig_s, device_array_view_t const* p_v, device_array_view_t const* p_s)
   {
     HIP_TRY(hipSetDevice(h.device));
+    CGA_EXPECTS(g.ne <= kMaxSignedEdges, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
+                "PageRank addresses edges through 16-bit tiled / signed 32-bit positions: graphs of 2^31 or more edges are not supported");
     ensure_orientation(h, g, true);  // PageRank pulls over CSC
     int64_t const nv = g.nv;
     size_t const n1  = (size_t)(nv > 0 ? nv : 1);

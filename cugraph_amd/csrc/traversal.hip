@@ -63,7 +63,7 @@ struct bfs_visit {
   bfs_state s;
   wave_queue wq;
   unsigned long long acc_out{0}, acc_in{0};
-  __device__ __forceinline__ void operator()(int32_t u, int32_t v, int32_t)
+  __device__ __forceinline__ void operator()(int32_t u, int32_t v, eoff_t)
   {
     uint32_t bit = 1u << (v & 31);
     bool fresh   = false;
@@ -77,8 +77,8 @@ struct bfs_visit {
       }
       if (fresh) {
         s.dist[v] = s.next_depth;
-        acc_out += (unsigned long long)(s.out_offsets[v + 1] - s.out_offsets[v]);
-        acc_in += (unsigned long long)(s.in_offsets[v + 1] - s.in_offsets[v]);
+        acc_out += (unsigned long long)(eoff(s.out_offsets, v + 1) - eoff(s.out_offsets, v));
+        acc_in += (unsigned long long)(eoff(s.in_offsets, v + 1) - eoff(s.in_offsets, v));
       }
       if (s.pred && u < __builtin_nontemporal_load(&s.pred[v])) atomicMin(&s.pred[v], u);  // minimum internal id among the frontier parents
     }
@@ -126,7 +126,7 @@ constexpr int BU_LANE_MAX   = 64;  // neighbours a lane scans on its own; the re
 // those, not bytes, bound a bottom-up level (~65 G random accesses/s beyond the Infinity Cache, tools/ubench/gather_bench.hip).
 // Entries past `left` (the row's remaining length; the index array is padded) come back as -1.
 typedef int32_t bu_i32x4 __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ void bu_load_chunk(int32_t const* indices, int32_t pos, int32_t left, int32_t (&u)[BU_CHUNK])
+__device__ __forceinline__ void bu_load_chunk(int32_t const* indices, eoff_t pos, int32_t left, int32_t (&u)[BU_CHUNK])
 {
   static_assert(BU_CHUNK == 4, "one dwordx4 load per chunk");
   bu_i32x4 v = {-1, -1, -1, -1};
@@ -158,7 +158,8 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_of
   for (int64_t grp0 = gwave * BU_GROUPS; grp0 < ngroup; grp0 += nwaves * BU_GROUPS) {
     unsigned long long const tk0 = PROF ? wall_clock64() : 0;
     bool unvisited[BU_GROUPS], found[BU_GROUPS], open_row[BU_GROUPS];
-    int32_t b[BU_GROUPS], e[BU_GROUPS], parent[BU_GROUPS], scanned[BU_GROUPS];
+    eoff_t b[BU_GROUPS];  // first in-edge of the lane's vertex (unsigned 32-bit position)
+    int32_t e[BU_GROUPS], parent[BU_GROUPS], scanned[BU_GROUPS];  // e = the row's LENGTH (a row has fewer than 2^31 edges)
     int32_t u[BU_GROUPS][BU_CHUNK];
     uint32_t word[BU_GROUPS];
 #pragma unroll
@@ -166,21 +167,21 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_of
       int64_t const grp = grp0 + g, v = grp * 64 + lane;  // too: 64 consecutive offsets are one cheap coalesced load, a dependent step is not)
       word[g] = grp < ngroup ? vis[(grp * 2) + (lane >> 5)] : 0xFFFFFFFFu;
       b[g] = 0; e[g] = 0; parent[g] = -1; found[g] = false; scanned[g] = 0;
-      if (v < nv) { b[g] = in_offsets[v]; e[g] = in_offsets[v + 1]; }
+      if (v < nv) { b[g] = eoff(in_offsets, v); e[g] = (int32_t)(eoff(in_offsets, v + 1) - b[g]); }
     }
 #pragma unroll
     for (int g = 0; g < BU_GROUPS; ++g) {
       int64_t const v = (grp0 + g) * 64 + lane;
       unvisited[g] = v < nv && !((word[g] >> (lane & 31)) & 1u);
-      acc_out += (unsigned long long)(od1[g] - od0[g]);  // requested an iteration ago: complete by the time `word` is (loads retire in order)
+      acc_out += (unsigned long long)(uint32_t)(od1[g] - od0[g]);  // requested an iteration ago: complete by the time `word` is (loads retire in order)
     }
 #pragma unroll
     for (int g = 0; g < BU_GROUPS; ++g) {
-      open_row[g] = unvisited[g] && e[g] > b[g];
+      open_row[g] = unvisited[g] && e[g] > 0;
 #if defined(CGA_BU_ABL) && CGA_BU_ABL == 2  // timing experiment: no neighbour load either
       u[g][0] = open_row[g] ? 0 : -1; u[g][1] = u[g][2] = u[g][3] = -1;
 #else
-      bu_load_chunk(in_indices, b[g], open_row[g] ? e[g] - b[g] : 0, u[g]);
+      bu_load_chunk(in_indices, b[g], open_row[g] ? e[g] : 0, u[g]);
 #endif
     }
 #pragma unroll
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_of
         if (u[g][k] >= 0 && ((front[u[g][k] >> 5] >> (u[g][k] & 31)) & 1u)) first = k;  // ascending ids: the first hit is the minimum
 #endif
       if (open_row[g]) {
-        int32_t const deg = e[g] - b[g];
+        int32_t const deg = e[g];
         if (first < BU_CHUNK) {
 #pragma unroll
           for (int k = 0; k < BU_CHUNK; ++k) if (k == first) parent[g] = u[g][k];
@@ -220,10 +221,10 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_of
       int32_t w[BU_GROUPS][2 * BU_CHUNK];
 #pragma unroll
       for (int g = 0; g < BU_GROUPS; ++g) {
-        int32_t const left = act[g] ? (e[g] - b[g]) - scanned[g] : 0;
+        int32_t const left = act[g] ? e[g] - scanned[g] : 0;
         int32_t lo[BU_CHUNK], hi[BU_CHUNK];
-        bu_load_chunk(in_indices, b[g] + scanned[g], left, lo);
-        bu_load_chunk(in_indices, b[g] + scanned[g] + BU_CHUNK, left - BU_CHUNK, hi);
+        bu_load_chunk(in_indices, b[g] + (eoff_t)scanned[g], left, lo);
+        bu_load_chunk(in_indices, b[g] + (eoff_t)scanned[g] + BU_CHUNK, left - BU_CHUNK, hi);
 #pragma unroll
         for (int k = 0; k < BU_CHUNK; ++k) { w[g][k] = lo[k]; w[g][BU_CHUNK + k] = hi[k]; }
       }
@@ -234,7 +235,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_of
         for (int k = 2 * BU_CHUNK - 1; k >= 0; --k)
           if (w[g][k] >= 0 && ((front[w[g][k] >> 5] >> (w[g][k] & 31)) & 1u)) first = k;
         if (act[g]) {
-          int32_t const deg = e[g] - b[g];
+          int32_t const deg = e[g];
           if (first < 2 * BU_CHUNK) {
 #pragma unroll
             for (int k = 0; k < 2 * BU_CHUNK; ++k) if (k == first) parent[g] = w[g][k];
@@ -253,24 +254,24 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_of
     for (int g = 0; g < BU_GROUPS; ++g) {
       inspected += (unsigned long long)scanned[g];
       uint64_t cm = __ballot(open_row[g]);
-      int32_t const rest = b[g] + scanned[g];
       while (cm) {
         int src = __ffsll((unsigned long long)cm) - 1;
         cm &= cm - 1;
         if (PROF) ++pn[1];
-        int32_t bb = __shfl(rest, src), ee = __shfl(e[g], src);
+        eoff_t const row = (eoff_t)__shfl((int)b[g], src);                       // the row's first edge
+        int32_t const first = __shfl(scanned[g], src), len = __shfl(e[g], src);  // scan positions [first, len) of the row
         bool hit = false;
-        int32_t p = bb, par = -1;
-        for (; p < ee && !hit; p += 64) {
+        int32_t p = first, par = -1;
+        for (; p < len && !hit; p += 64) {
           if (PROF) ++pn[2];
           int32_t q = p + lane, x = -1;
           bool h    = false;
-          if (q < ee) { x = in_indices[q]; h = ((front[x >> 5] >> (x & 31)) & 1u) != 0; }
+          if (q < len) { x = in_indices[row + (eoff_t)q]; h = ((front[x >> 5] >> (x & 31)) & 1u) != 0; }
           uint64_t hm = __ballot(h);
           hit         = hm != 0;
           if (hit) par = __shfl(x, __ffsll((unsigned long long)hm) - 1);  // lowest lane = smallest position = smallest id
         }
-        if (lane == src) { found[g] = hit; parent[g] = par; inspected += (unsigned long long)(min(p, ee) - bb); }
+        if (lane == src) { found[g] = hit; parent[g] = par; inspected += (unsigned long long)(min(p, len) - first); }
       }
     }
     // results: nothing below waits for memory (the visited words are still in registers; the out-degrees of the discovered
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_of
     for (int g = 0; g < BU_GROUPS; ++g) {
       int64_t const v = (grp0 + g) * 64 + lane;
       od0[g] = 0; od1[g] = 0;
-      if (found[g]) { od0[g] = out_offsets[v]; od1[g] = out_offsets[v + 1]; }
+      if (found[g]) { od0[g] = out_offsets[v]; od1[g] = out_offsets[v + 1]; }  // (differences of the words are taken modulo 2^32: a degree fits)
     }
 #pragma unroll
     for (int g = 0; g < BU_GROUPS; ++g) {
@@ -293,7 +294,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_of
       if (found[g]) {
         dist[v] = next_depth;
         if (pred) pred[v] = parent[g];
-        acc_in += (unsigned long long)(e[g] - b[g]);
+        acc_in += (unsigned long long)e[g];
       }
       found_total += (uint32_t)__popcll(fm);
     }
@@ -305,7 +306,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_of
     atomicMax(prof + 7, pt[2]);
   }
 #pragma unroll
-  for (int g = 0; g < BU_GROUPS; ++g) acc_out += (unsigned long long)(od1[g] - od0[g]);
+  for (int g = 0; g < BU_GROUPS; ++g) acc_out += (unsigned long long)(uint32_t)(od1[g] - od0[g]);
   for (int o = 32; o > 0; o >>= 1) { inspected += __shfl_xor(inspected, o); acc_out += __shfl_xor(acc_out, o); acc_in += __shfl_xor(acc_in, o); }
   if (lane == 0) {
     counter_sums_t* r = cnt_replica(cnt);
@@ -376,8 +377,8 @@ __global__ void k_bfs_init_sources(int32_t const* src, int64_t n, int32_t* dist,
     atomicOr(&vis_prev[v >> 5], bit);
     dist[v] = 0;
     q[atomicAdd(&cnt->n_next, 1u)] = v;
-    atomicAdd(&cnt->out_edges, (unsigned long long)(out_offsets[v + 1] - out_offsets[v]));
-    atomicAdd(&cnt->in_edges, (unsigned long long)(in_offsets[v + 1] - in_offsets[v]));
+    atomicAdd(&cnt->out_edges, (unsigned long long)(eoff(out_offsets, v + 1) - eoff(out_offsets, v)));
+    atomicAdd(&cnt->in_edges, (unsigned long long)(eoff(in_offsets, v + 1) - eoff(in_offsets, v)));
   }
 }
 
@@ -418,7 +419,7 @@ struct sssp_relax {
   sssp_state<WT> s;
   wave_queue wq_near, wq_far, wq_set;
   __device__ __forceinline__ void flush() { wq_near.flush(); wq_far.flush(); wq_set.flush(); }
-  __device__ __forceinline__ void operator()(int32_t u, int32_t v, int32_t p)
+  __device__ __forceinline__ void operator()(int32_t u, int32_t v, eoff_t p)
   {
     using B  = dist_bits<WT>;
     WT du    = B::from(s.dist[u]);
@@ -515,7 +516,7 @@ struct sssp_parent {
   int32_t* pred;  // INT32_MAX = none
   int32_t const* labels;
   int32_t source;
-  __device__ __forceinline__ void operator()(int32_t u, int32_t v, int32_t p) const
+  __device__ __forceinline__ void operator()(int32_t u, int32_t v, eoff_t p) const
   {
     using B = dist_bits<WT>;
     if (v != source && B::to(B::from(dist[u]) + weights[p]) == dist[v]) atomicMin(&pred[v], labels ? labels[u] : u);
@@ -573,7 +574,7 @@ __global__ void k_bfs_edges_of_reached(int32_t const* dist, int32_t const* out_o
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   unsigned long long c = 0;
   for (; i < nv; i += stride)
-    if (dist[i] != INT32_MAX) c += (unsigned long long)(out_offsets[i + 1] - out_offsets[i]);
+    if (dist[i] != INT32_MAX) c += (unsigned long long)(eoff(out_offsets, i + 1) - eoff(out_offsets, i));
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
@@ -906,7 +907,7 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   // delta / 2: 14.9, delta / 8: 15.9): what a round costs is the SUCCESSFUL updates (atomicMin + mark exchange + queue append, and
   // the far pile that every bucket re-splits), not the failed relaxations this scheme removes.  So the path is opt-in
   // (CUGRAPH_AMD_SSSP_LH=1) and covered by test_sssp_light_heavy_buckets_vs_oracle; wide buckets stay the default.
-  bool const use_lh  = g.ne > 0 && env_lh && atoi(env_lh) != 0;
+  bool const use_lh  = g.ne > 0 && g.ne <= kMaxSignedEdges && env_lh && atoi(env_lh) != 0;  // (the light / heavy copy keeps signed positions)
   if (use_lh) {
     char const* env_s = getenv("CUGRAPH_AMD_SSSP_LH_SCALE");
     delta *= env_s ? atof(env_s) : 0.25;

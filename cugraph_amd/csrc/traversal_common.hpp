@@ -153,6 +153,11 @@ struct wave_queue {
   }
 };
 
+// Edge positions are UNSIGNED 32-bit (eoff_t): the offsets arrays hold values up to 2^32 - 1 in their int32 words (a graph of
+// 2^31 .. 2^32 - 1 edges -- symmetrised RMAT-26 -- is addressable; a row has fewer than 2^31 edges).
+using eoff_t = uint32_t;
+__device__ __forceinline__ eoff_t eoff(int32_t const* offsets, int64_t v) { return (eoff_t)offsets[v]; }
+
 // Expands the frontier `q[0..n)` (q == nullptr: vertices 0..n-1): calls f(u, v, edge_position) for every
 // out-edge of every frontier vertex for which keep(u) is true.  Vertices of degree >= BIG_DEG are pushed to
 // bigq for k_expand_big.
@@ -162,7 +167,7 @@ __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int
                                                 int32_t const* row_end = nullptr)  // row u = [offsets[u], row_end ? row_end[u] : offsets[u + 1])
 {
   __shared__ uint32_t s_scan[TV_WAVES][64];
-  __shared__ int32_t s_beg[TV_WAVES][64];
+  __shared__ eoff_t s_beg[TV_WAVES][64];
   __shared__ int32_t s_u[TV_WAVES][64];
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int64_t const gwave  = (int64_t)blockIdx.x * TV_WAVES + wave;
@@ -170,10 +175,11 @@ __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int
   unsigned long long inspected = 0;
   for (int64_t base = gwave * 64; base < n; base += nwaves * 64) {
     int64_t i = base + lane;
-    int32_t u = -1, beg = 0, deg = 0;
+    int32_t u = -1, deg = 0;
+    eoff_t beg = 0;
     if (i < n) {
       u = q ? q[i] : (int32_t)i;
-      if (keep(u)) { beg = offsets[u]; deg = (row_end ? row_end[u] : offsets[u + 1]) - beg; } else { u = -1; }
+      if (keep(u)) { beg = eoff(offsets, u); deg = (int32_t)((row_end ? eoff(row_end, u) : eoff(offsets, u + 1)) - beg); } else { u = -1; }
     }
     // deferred: huge rows, cut into BIG_SEG-edge segments (one workgroup of k_*_big each)
     bool big = deg >= big_deg;
@@ -187,8 +193,9 @@ __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int
     while (mid) {
       int src     = __ffsll((unsigned long long)mid) - 1;
       mid &= mid - 1;
-      int32_t uu = __shfl(u, src), b = __shfl(beg, src), d = __shfl(deg, src);
-      for (int32_t p = lane; p < d; p += 64) f(uu, indices[b + p], b + p);
+      int32_t uu = __shfl(u, src), d = __shfl(deg, src);
+      eoff_t const b = (eoff_t)__shfl((int)beg, src);
+      for (int32_t p = lane; p < d; p += 64) f(uu, indices[b + (eoff_t)p], b + (eoff_t)p);
       inspected += (lane == 0) ? (unsigned long long)d : 0ull;
     }
     // flattened small rows
@@ -207,7 +214,7 @@ __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int
         int m = (lo + hi + 1) >> 1;
         if (s_scan[wave][m] <= t) lo = m; else hi = m - 1;
       }
-      int32_t p = s_beg[wave][lo] + (int32_t)(t - s_scan[wave][lo]);
+      eoff_t const p = s_beg[wave][lo] + (t - s_scan[wave][lo]);
       f(s_u[wave][lo], indices[p], p);
     }
     __builtin_amdgcn_wave_barrier();
@@ -224,16 +231,19 @@ __device__ __forceinline__ void expand_big(int32_t const* bigq, int32_t const* o
   unsigned long long inspected = 0;
   for (uint32_t k = blockIdx.x; k < nseg; k += gridDim.x) {
     int32_t const u = bigq[2 * k], sgm = bigq[2 * k + 1];
-    int32_t const b = offsets[u] + sgm * BIG_SEG;
-    int32_t const e = min(row_end ? row_end[u] : offsets[u + 1], b + BIG_SEG);
-    for (int32_t p = b + (int32_t)threadIdx.x; p < e; p += (int32_t)blockDim.x) f(u, indices[p], p);
-    if (threadIdx.x == 0) inspected += (unsigned long long)(e - b);
+    eoff_t const row_b = eoff(offsets, u), row_e = row_end ? eoff(row_end, u) : eoff(offsets, u + 1);
+    eoff_t const b = row_b + (eoff_t)sgm * (eoff_t)BIG_SEG;             // (b <= row_e: the segment exists)
+    eoff_t const len = min(row_e - b, (eoff_t)BIG_SEG);
+    for (eoff_t p = threadIdx.x; p < len; p += blockDim.x) f(u, indices[b + p], b + p);
+    if (threadIdx.x == 0) inspected += (unsigned long long)len;
   }
   if (threadIdx.x == 0 && inspected) atomicAdd(&cnt_replica(cnt)->edges, inspected);
 }
 
 
 inline size_t big_queue_entries(int64_t ne) { return (size_t)(2 * (ne / BIG_DEG_NARROW + ne / BIG_SEG + 64)); }
+// largest edge count the traversal kernels address (32-bit unsigned positions, 2048 words of tail padding)
+constexpr int64_t kMaxTraversalEdges = ((int64_t)1 << 32) - 4096;
 
 // narrow frontier (fewer vertices than the chip has wavefront slots): defer every row a wavefront would otherwise walk alone
 inline int32_t big_deg_for(handle_t const& h, int64_t n) { return n < (int64_t)h.num_cus * 64 ? BIG_DEG_NARROW : BIG_DEG; }

@@ -57,7 +57,7 @@ struct mg_bfs_state {
 struct mg_bfs_visit {
   mg_bfs_state s;
   wave_queue wq;
-  __device__ __forceinline__ void operator()(int32_t u, int32_t g, int32_t)
+  __device__ __forceinline__ void operator()(int32_t u, int32_t g, eoff_t)
   {
     uint32_t const bit = 1u << (g & 31);
     bool fresh = false;
@@ -86,7 +86,7 @@ struct mg_sssp_state {
 struct mg_sssp_relax {
   mg_sssp_state s;
   wave_queue wq;
-  __device__ __forceinline__ void operator()(int32_t u, int32_t g, int32_t p)
+  __device__ __forceinline__ void operator()(int32_t u, int32_t g, eoff_t p)
   {
     float const du = __uint_as_float((uint32_t)(s.st[u] >> 32));
     float const nd = du + s.weights[p];
