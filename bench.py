@@ -271,8 +271,6 @@ def extras(args):
 
     res = {}
     h = cg.ResourceHandle()
-    cg.pylib.capi.lib().cugraph_amd_memory_pool_trim()
-    torch.cuda.empty_cache()
     try:
         t = traversal_bench(cg, h, 24, 16, args.extra_roots, "int", False, False, True, 20, not args.no_cpu_baseline, not args.no_check)
         res["bfs"] = dict(t["bfs"], workload=t["workload"], metric="bfs_mteps_rmat24", unit="MTEPS", value=t["bfs"]["harmonic_mean_mteps"],
@@ -281,15 +279,11 @@ def extras(args):
         res["sssp"] = dict(t["sssp"], workload=t["workload"], metric="sssp_mteps_rmat24_int_weights", unit="MTEPS", value=t["sssp"]["harmonic_mean_mteps"],
                            cpu_baseline=None if cb is None else dict({k: v for k, v in cb.items() if k not in ("value", "sssp_value")}, value=cb["sssp_value"]))
         del t
-        cg.pylib.capi.lib().cugraph_amd_memory_pool_trim()
-        torch.cuda.empty_cache()
         u = traversal_bench(cg, h, 24, 16, args.extra_roots, "unit", False, False, True, 20, False, not args.no_check)
         res["sssp_unit"] = dict(u["sssp"], workload=u["workload"], metric="sssp_mteps_rmat24_unit_weights", unit="MTEPS", value=u["sssp"]["harmonic_mean_mteps"])
         del u
     except Exception as e:  # an extra must never cost the headline line
         res["traversal_error"] = repr(e)
-    cg.pylib.capi.lib().cugraph_amd_memory_pool_trim()
-    torch.cuda.empty_cache()
     try:
         res["louvain"] = louvain_bench(cg, h, 22, 8, 2, 0 if args.no_cpu_baseline else 18)
     except Exception as e:

@@ -202,19 +202,23 @@ def traversal_bench(cg, h, scale=24, edge_factor=16, n_roots=64, weights="unit",
         d[u] + w (w = 1 for BFS; fp32 addition is monotone, so the fixed point is unique and equals Dijkstra's):
         recomputed here with one torch scatter-min over the edge list, compared bit for bit."""
         root = int(roots[-1])
+        step = 1 << 27  # edges per pass (bounded temporaries; torch kernels stay below 2^31 elements)
         if kind == "bfs":
             dist = torch.empty(nv, dtype=torch.int64, device="cuda")
             dist[v.to(torch.int64)] = d.to(torch.int64)
             INF = 2147483647
-            cand = torch.where(dist[src.long()] == INF, torch.full_like(dist[:1], INF).expand(ne), dist[src.long()] + 1)
-            best = torch.full((nv,), INF, dtype=torch.int64, device="cuda").scatter_reduce(0, dst.long(), cand, "amin", include_self=True)
+            best = torch.full((nv,), INF, dtype=torch.int64, device="cuda")
+            for b0 in range(0, ne, step):
+                du = dist[src[b0:b0 + step].long()]
+                best.scatter_reduce_(0, dst[b0:b0 + step].long(), torch.where(du == INF, du, du + 1), "amin", include_self=True)
         else:
             dist = torch.empty(nv, dtype=torch.float32, device="cuda")
             dist[v.to(torch.int64)] = d
             INF = torch.finfo(torch.float32).max
-            du = dist[src.long()]
-            cand = torch.where(du == INF, du, du + w)
-            best = torch.full((nv,), INF, dtype=torch.float32, device="cuda").scatter_reduce(0, dst.long(), cand, "amin", include_self=True)
+            best = torch.full((nv,), INF, dtype=torch.float32, device="cuda")
+            for b0 in range(0, ne, step):
+                du = dist[src[b0:b0 + step].long()]
+                best.scatter_reduce_(0, dst[b0:b0 + step].long(), torch.where(du == INF, du, du + w[b0:b0 + step]), "amin", include_self=True)
         best[root] = 0
         bad = int((best != dist).sum())
         return {"what": "d[v] == min over in-edges (d[u] + w), d[root] == 0, recomputed with torch on the last root's result (bit for bit)",

@@ -121,6 +121,7 @@ PROTOTYPES = {
     "cugraph_generate_edge_types": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _PP]),
     "cugraph_data_type_id_from_dlpack": (C.c_int, [_P, C.POINTER(C.c_int), _PP]),
     "cugraph_amd_memory_pool_trim": (C.c_size_t, []),
+    "cugraph_amd_memory_pool_trim_large": (C.c_size_t, [C.c_size_t]),
     "cugraph_amd_memory_pool_cached_bytes": (C.c_size_t, []),
     "cugraph_louvain": (C.c_int, [_P, _P, C.c_size_t, C.c_double, C.c_double, C.c_int, _PP, _PP]),
     "cugraph_hierarchical_clustering_result_get_vertices": (_P, [_P]),

@@ -101,9 +101,9 @@ inline size_t dtype_size(cugraph_data_type_id_t t)
 // synchronous and slow for the sizes of this library (a BFS call used to spend more time in its dozen hipMalloc / hipFree
 // pairs than in two of its levels; a PageRank plan build waited seconds for the driver after 60 GB of temporaries had just
 // been freed), so freed blocks are kept and handed out again: best fit within 25 % slack, at most CUGRAPH_AMD_POOL_MAX_GB
-// (default 32) cached, everything is released and the request retried when hipMalloc fails; graph and plan construction hand
-// their large temporaries back to the driver when they end (pool_release_large_blocks), so other allocators of the process
-// (torch, cupy, RMM) find the memory.  Stream order: every API entry point names its handle's stream (H() -> pool_set_stream);
+// (default 128, at most 45 % of the device) cached, everything is released and the request retried when hipMalloc fails;
+// cugraph_amd_memory_pool_trim / _trim_large hand cached blocks back for other allocators of the process (torch, cupy, RMM).
+// Stream order: every API entry point names its handle's stream (H() -> pool_set_stream);
 // a freed block records an event on that stream, and a reuse from a different stream waits for it (a reuse on the same stream
 // is ordered by the stream).  CUGRAPH_AMD_POOL=0 turns the pool off; CUGRAPH_AMD_POOL_DEBUG=1 reports blocks that are freed
 // while their stream still has work queued.

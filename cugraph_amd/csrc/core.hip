@@ -388,13 +388,21 @@ struct pool_t {
   std::multimap<std::pair<int, size_t>, free_block_t> free_blocks;  // (device, size) -> block
   std::vector<hipEvent_t> spare_events;
   size_t cached{0};
-  size_t max_cached{(size_t)32 << 30};
+  size_t max_cached{(size_t)128 << 30};  // a Louvain sweep at RMAT-26 recycles ~40 GB of sort buffers: a 32 GB cap made every sweep hipFree /
+                                        // hipMalloc them (9.0 s instead of 2.3 s per run; 3.9 s with 96 GB: round 3); what other allocators of the process
+                                        // need can be returned with cugraph_amd_memory_pool_trim (an eager trim at the end of every
+                                        // graph / plan construction was tried: the hipFree of tens of GB stalls for seconds now and then)
   bool enabled{true};
   bool debug{false};
   pool_t()
   {
     if (char const* e = getenv("CUGRAPH_AMD_POOL")) enabled = atoi(e) != 0;
     if (char const* e = getenv("CUGRAPH_AMD_POOL_MAX_GB")) max_cached = (size_t)std::max(0.0, atof(e)) << 30;
+    else {  // never more than 45 % of the device
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) max_cached = std::min(max_cached, total_b / 20 * 9);
+      else (void)hipGetLastError();
+    }
     debug = getenv("CUGRAPH_AMD_POOL_DEBUG") != nullptr;
   }
   hipEvent_t get_event()
@@ -520,9 +528,10 @@ void pool_free(void* ptr, size_t granted) noexcept
   if (p.cached > p.max_cached) p.trim_locked(p.max_cached / 2);
 }
 
-// Graph and plan construction free tens of GB of temporaries (sort buffers): those go back to the driver when the build ends,
-// so that torch / cupy / RMM allocations of the same process do not find the memory held by this library's cache; the small and
-// medium blocks the per-call paths (BFS / SSSP state, result columns) recycle stay cached.
+// Returns the cached blocks above `block_bytes` to the driver (cugraph_amd_memory_pool_trim_large): for callers that share the
+// device with another allocator and want the sort buffers of a finished graph / plan construction back without losing the small
+// and medium blocks the per-call paths (BFS / SSSP state, result columns) recycle.  Not done eagerly: hipFree of tens of GB takes
+// seconds now and then (graph build 0.18 s -> 5.4 s in one of five runs when every build ended with it).
 size_t pool_release_large_blocks(size_t block_bytes) noexcept
 {
   pool_t& p = pool();
@@ -540,6 +549,7 @@ extern "C" size_t cugraph_amd_memory_pool_trim(void)
   p.trim_locked(0);
   return had;
 }
+extern "C" size_t cugraph_amd_memory_pool_trim_large(size_t block_bytes) { return cga::pool_release_large_blocks(block_bytes); }
 extern "C" size_t cugraph_amd_memory_pool_cached_bytes(void)
 {
   cga::pool_t& p = cga::pool();

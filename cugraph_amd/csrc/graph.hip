@@ -273,7 +273,6 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
                                bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error)
 {
   if (graph) *graph = nullptr;
-  struct release_temporaries { ~release_temporaries() { pool_release_large_blocks(); } } on_exit;  // after the lambda's locals are gone
   return guarded(error, [&] {
     handle_t const& h = H(handle);
     CGA_EXPECTS(graph != nullptr && properties != nullptr && src != nullptr && dst != nullptr, CUGRAPH_INVALID_INPUT,

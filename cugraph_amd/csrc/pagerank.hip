@@ -1497,7 +1497,6 @@ pagerank_plan_base* make_plan(cugraph_resource_handle_t const* handle, cugraph_g
   device_array_view_t const* ow = c_ow.get(h, g, V(ow_v), "precomputed_vertex_out_weight_vertices");
   device_array_view_t const* ig = c_ig.get(h, g, V(ig_v), "initial_guess_vertices");
   device_array_view_t const* pv = c_p.get(h, g, V(p_v), "personalization_vector");
-  struct release_temporaries { ~release_temporaries() { pool_release_large_blocks(); } } on_exit;  // the plan build's sort buffers
   if (g.weight_type == FLOAT64) {
     auto p = std::make_unique<pagerank_plan<double>>(h, g, alpha);
     p->create(ow, V(ow_s), ig, V(ig_s), pv, V(p_s));
@@ -1698,7 +1697,6 @@ extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_create(
     graph_t& g        = G(graph);
     CGA_EXPECTS(plan != nullptr, CUGRAPH_INVALID_INPUT, "plan is NULL");
     CGA_EXPECTS(alpha >= 0.0 && alpha <= 1.0, CUGRAPH_INVALID_INPUT, "Invalid input argument: alpha should be in [0.0, 1.0].");
-    struct release_temporaries { ~release_temporaries() { pool_release_large_blocks(); } } on_exit;
     if (g.weight_type == FLOAT64) {
       auto p = std::make_unique<pagerank_mg2d_plan<double>>(h, g, alpha, (int64_t)rows_per_partition, (int64_t)block_rows, (int64_t)block_cols, (int64_t)global_num_vertices);
       p->create(V(out_weight_sums_own), V(initial_own), V(x_own), V(x_cols), V(y_part), V(y_own), V(triple));

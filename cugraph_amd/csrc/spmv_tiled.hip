@@ -531,7 +531,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     char const* env_tf = getenv("CUGRAPH_AMD_TP_TAIL_FRAC");
     char const* env_tc = getenv("CUGRAPH_AMD_TP_TAIL_CHUNK");
     double const tail_frac = env_tf ? atof(env_tf) : TP_TAIL_FRAC;
-    int const tail_chunk   = std::max(1, std::min(chunk, env_tc ? atoi(env_tc) : TP_TAIL_CHUNK));
+    int tail_chunk         = std::max(1, std::min(chunk, env_tc ? atoi(env_tc) : TP_TAIL_CHUNK));
     int const tail_first   = t.n_items / (max_wg * 4) >= TP_CHUNK ? (int)((1.0 - tail_frac) * t.n_items) : t.n_items;
     // STATIC PREFIX (sticky tiles): every workgroup first walks a private, contiguous range of work items -- equal shares, by
     // estimated cost, of the first `static_frac` of the total cost -- so that it loads a hot source tile ONCE (a 126 KiB tile
@@ -542,12 +542,17 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     // takes about twice as long).
     char const* env_sf = getenv("CUGRAPH_AMD_TP_STATIC_FRAC");
     char const* env_rc = getenv("CUGRAPH_AMD_TP_RUN_COST");
-    double const static_frac = env_sf ? atof(env_sf) : 0.0;  // off by default: see DESIGN.md section 3.1 (round 3) for the measurements
+    // Default by the number of work items per workgroup (measured): RMAT-26 (257 items per workgroup):
+    // the x-tile reloads are a small share and the dynamic queue balances better -- off (0.85: +8 %, 0.5: neutral); RMAT-24 (64):
+    // 0.7 -> phase 1 -17 %; RMAT-22 (16): 0.85-0.95 with 2-item dynamic chunks -> -13 %.
+    double const items_per_wg = (double)t.n_items / (double)max_wg;
+    double const static_frac  = env_sf ? atof(env_sf) : (items_per_wg >= 160.0 ? 0.0 : items_per_wg >= 24.0 ? 0.7 : 0.9);
     double const run_cost    = env_rc ? atof(env_rc) : 1.3;
     std::vector<int32_t> cb;              // [4 * n_chunks]: (unused, first item, end item, source tile); static chunks first, grouped by workgroup
     std::vector<int32_t> wg_static;       // [2 * n_wg]: (first static chunk, end static chunk) of every workgroup
     int static_items = 0;
-    bool const use_static = static_frac > 0.0 && ne > 0 && (t.n_items / (max_wg * 4) >= TP_CHUNK || getenv("CUGRAPH_AMD_TP_STATIC_FORCE") != nullptr);
+    bool const use_static = static_frac > 0.0 && ne > 0 && (items_per_wg >= 2.0 || getenv("CUGRAPH_AMD_TP_STATIC_FORCE") != nullptr);
+    if (use_static && !env_tc && !env_chunk && items_per_wg < 24.0) tail_chunk = std::max(1, tail_chunk / 2);  // few items per workgroup: finer dynamic tail
     t.n_wg = use_static ? max_wg : 0;
     if (use_static) {
       dvec<uint32_t> d_item_end, d_item_runs((size_t)t.n_items);

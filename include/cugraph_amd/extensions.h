@@ -198,10 +198,11 @@ CUGRAPH_EXPORT void cugraph_amd_last_traversal_stats(const cugraph_resource_hand
                                                      cugraph_amd_traversal_stats_t* out);
 /* Device memory of the library comes from a process-wide caching pool (csrc/common.hpp: dev_buf): freed blocks are kept and
  * reused (hipMalloc / hipFree are synchronous and slow at graph sizes).  _trim returns every cached block to the driver and
- * reports how many bytes that were; environment: CUGRAPH_AMD_POOL=0 (off), CUGRAPH_AMD_POOL_MAX_GB (cache cap, default 32).
- * Graph and plan construction return their large temporaries (blocks above 256 MiB) to the driver before they return, so other
- * allocators of the process see the memory; a cached block is reused across streams only behind an event recorded at its free. */
+ * reports how many bytes that were; environment: CUGRAPH_AMD_POOL=0 (off), CUGRAPH_AMD_POOL_MAX_GB (cache cap, default 128 GB and at most 45 % of the device).
+ * _trim_large returns only the cached blocks above block_bytes (the sort buffers of a finished graph / plan construction) and keeps
+ * the small blocks the per-call paths recycle.  A cached block is reused across streams only behind an event recorded at its free. */
 CUGRAPH_EXPORT size_t cugraph_amd_memory_pool_trim(void);
+CUGRAPH_EXPORT size_t cugraph_amd_memory_pool_trim_large(size_t block_bytes);
 CUGRAPH_EXPORT size_t cugraph_amd_memory_pool_cached_bytes(void);
 
 #ifdef __cplusplus
