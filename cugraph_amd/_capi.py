@@ -167,6 +167,8 @@ PROTOTYPES = {
     "cugraph_amd_pagerank_mg_plan_local_step": (C.c_int, [_P, _PP]),
     "cugraph_amd_pagerank_mg_plan_values": (C.c_int, [_P, _P, _PP]),
     "cugraph_amd_pagerank_mg_plan_free": (None, [_P]),
+    "cugraph_amd_sort_pairs_u64_u32": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.c_int, _PP]),
+    "cugraph_amd_exclusive_scan_u32": (C.c_int, [_P, _P, _P, C.c_size_t, _PP]),
     "cugraph_amd_pagerank_mg2d_plan_create": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _P, _P, _P, _P, _P, _P, _P, C.c_double, _PP, _PP]),
     "cugraph_amd_pagerank_mg2d_plan_start": (C.c_int, [_P, _PP]),
     "cugraph_amd_pagerank_mg2d_plan_set_scalars": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _PP]),

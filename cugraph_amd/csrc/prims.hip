@@ -495,3 +495,33 @@ int64_t count_negative_f32(handle_t const& h, float const* v, int64_t n) { retur
 int64_t count_negative_f64(handle_t const& h, double const* v, int64_t n) { return count_negative_fp<double>(h, v, n); }
 
 }  // namespace cga
+
+// ---- the two primitives the host layer's multi-GPU plan construction is built from (cugraph_amd/mg.py): the library's own
+// stable LSD radix sort and its exclusive scan behind the C ABI, so that no rocPRIM / Thrust kernel (torch.sort, torch.unique,
+// torch.argsort, torch.cumsum) sits on the product's path.  Device pointers; blocking at return.
+extern "C" cugraph_error_code_t cugraph_amd_sort_pairs_u64_u32(const cugraph_resource_handle_t* handle, uint64_t* keys, uint32_t* vals, size_t n, int bit_lo,
+                                                              int bit_hi, cugraph_error_t** error)
+{
+  return cga::guarded(error, [&] {
+    cga::handle_t const& h = cga::H(handle);
+    CGA_EXPECTS(keys != nullptr || n == 0, CUGRAPH_INVALID_INPUT, "sort_pairs: keys is NULL");
+    CGA_EXPECTS(n < ((size_t)1 << 32) && bit_lo >= 0 && bit_hi <= 64 && bit_lo <= bit_hi, CUGRAPH_INVALID_INPUT, "sort_pairs: at most 2^32 - 1 pairs, bits in [0, 64]");
+    if (n <= 1 || bit_hi == bit_lo) return;
+    HIP_TRY(hipSetDevice(h.device));
+    cga::dvec<uint64_t> kt(n);
+    cga::dvec<uint32_t> vt(vals ? n : 0);
+    cga::radix_sort_u64_u32(h, keys, vals, kt.data(), vals ? vt.data() : nullptr, (int64_t)n, bit_lo, bit_hi);
+    h.sync();
+  });
+}
+extern "C" cugraph_error_code_t cugraph_amd_exclusive_scan_u32(const cugraph_resource_handle_t* handle, const uint32_t* in, uint32_t* out, size_t n,
+                                                              cugraph_error_t** error)
+{
+  return cga::guarded(error, [&] {
+    cga::handle_t const& h = cga::H(handle);
+    CGA_EXPECTS((in != nullptr && out != nullptr) || n == 0, CUGRAPH_INVALID_INPUT, "exclusive_scan: in / out is NULL");
+    HIP_TRY(hipSetDevice(h.device));
+    cga::exclusive_scan_u32(h, in, out, (int64_t)n);
+    h.sync();
+  });
+}

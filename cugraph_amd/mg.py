@@ -31,6 +31,106 @@ import torch.distributed as dist
 TAIL_BYTES = 32  # (L1 change, dangling mass, max |x|) as 3 doubles + padding, behind every message
 
 
+# ------------------------------------------------------------------------------- device primitives
+# Plan construction on the GPU uses the LIBRARY's stable radix sort and exclusive scan through the C ABI
+# (cugraph_amd_sort_pairs_u64_u32 / cugraph_amd_exclusive_scan_u32), not torch.sort / argsort / unique / cumsum (rocPRIM under
+# the hood): the product's multi-GPU path runs no Thrust / CUB / rocPRIM kernel.  Host tensors (the CPU engines of the gloo
+# tests) take the torch functions.
+_PRIM = {}
+
+
+def _prim_handle():
+    h = _PRIM.get("handle")
+    if h is None:
+        from .pylib import ResourceHandle
+
+        h = _PRIM["handle"] = ResourceHandle()
+    return h
+
+
+def _bits_for(max_value: int) -> int:
+    return max(1, int(max_value).bit_length())
+
+
+def _lib_sort_pairs(keys: torch.Tensor, vals: torch.Tensor, bits: int):
+    """in place: keys (int64, non-negative) ascending on their low `bits` bits, stable; vals (int32) follow"""
+    from . import _capi as capi
+    from .pylib import assert_success
+
+    assert keys.is_cuda and keys.dtype == torch.int64 and keys.is_contiguous() and vals.dtype == torch.int32 and vals.is_contiguous()
+    torch.cuda.current_stream().synchronize()  # the library sorts on its own stream
+    err = C.c_void_p()
+    code = capi.lib().cugraph_amd_sort_pairs_u64_u32(_prim_handle().c_resource_handle_ptr, C.c_void_p(keys.data_ptr()), C.c_void_p(vals.data_ptr()),
+                                                     keys.numel(), 0, int(bits), C.byref(err))
+    assert_success(code, err, "cugraph_amd_sort_pairs_u64_u32")
+
+
+def _lib_exclusive_scan(flags: torch.Tensor) -> torch.Tensor:
+    from . import _capi as capi
+    from .pylib import assert_success
+
+    assert flags.is_cuda and flags.dtype == torch.int32 and flags.is_contiguous()
+    out = torch.empty_like(flags)
+    torch.cuda.current_stream().synchronize()
+    err = C.c_void_p()
+    code = capi.lib().cugraph_amd_exclusive_scan_u32(_prim_handle().c_resource_handle_ptr, C.c_void_p(flags.data_ptr()), C.c_void_p(out.data_ptr()), flags.numel(),
+                                                     C.byref(err))
+    assert_success(code, err, "cugraph_amd_exclusive_scan_u32")
+    return out
+
+
+def stable_argsort(x: torch.Tensor, max_value=None) -> torch.Tensor:
+    """positions that sort the non-negative integers x ascending, ties in input order (int64 positions)"""
+    if not x.is_cuda:
+        return torch.argsort(x, stable=True)
+    n = x.numel()
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=x.device)
+    keys = x.to(torch.int64).contiguous().clone()
+    vals = torch.arange(n, dtype=torch.int32, device=x.device)
+    _lib_sort_pairs(keys, vals, _bits_for(int(x.max()) if max_value is None else max_value))
+    return vals.to(torch.int64)
+
+
+def inclusive_counts(rows: torch.Tensor, n_rows: int) -> torch.Tensor:
+    """out[r] = number of entries of `rows` that are <= r (the CSR offsets of a row-sorted list, without their leading 0)"""
+    cnt = torch.bincount(rows, minlength=n_rows)
+    if not rows.is_cuda:
+        return torch.cumsum(cnt, 0)
+    c32 = torch.cat([cnt.to(torch.int32), torch.zeros(1, dtype=torch.int32, device=rows.device)]).contiguous()
+    return _lib_exclusive_scan(c32)[1:].to(torch.int64)
+
+
+def degree_order(deg: torch.Tensor) -> torch.Tensor:
+    """vertices by descending degree, ties by ascending id (= torch.sort(deg, descending=True, stable=True).indices)"""
+    if not deg.is_cuda:
+        return torch.sort(deg, descending=True, stable=True)[1]
+    mx = int(deg.max()) if deg.numel() else 0
+    return stable_argsort(mx - deg.to(torch.int64), mx)
+
+
+def unique_inverse(x: torch.Tensor):
+    """(sorted distinct values of the non-negative integers x, index of every element's value in that list)
+    = torch.unique(x, sorted=True, return_inverse=True)"""
+    if not x.is_cuda:
+        return torch.unique(x, sorted=True, return_inverse=True)
+    n = x.numel()
+    if n == 0:
+        return x.clone(), torch.empty(0, dtype=torch.int64, device=x.device)
+    keys = x.to(torch.int64).contiguous().clone()
+    vals = torch.arange(n, dtype=torch.int32, device=x.device)
+    _lib_sort_pairs(keys, vals, _bits_for(int(x.max())))
+    head = torch.ones(n, dtype=torch.int32, device=x.device)
+    head[1:] = (keys[1:] != keys[:-1]).to(torch.int32)
+    rank = (_lib_exclusive_scan(head) + head - 1).to(torch.int64)  # index of the element's value among the distinct values
+    n_unique = int(rank[-1]) + 1
+    uniq = torch.empty(n_unique, dtype=x.dtype, device=x.device)
+    uniq[rank] = keys.to(x.dtype)            # every member of a group stores the group's value
+    inverse = torch.empty(n, dtype=torch.int64, device=x.device)
+    inverse[vals.to(torch.int64)] = rank
+    return uniq, inverse
+
+
 # ------------------------------------------------------------------------------------------ partition
 class Partition:
     """Global degree-order numbering dealt round-robin over the ranks."""
@@ -39,7 +139,7 @@ class Partition:
         self.nv = int(in_degree.numel())
         self.world, self.rank = world, rank
         # stable descending sort: ties keep ascending vertex id
-        _, order = torch.sort(in_degree, descending=True, stable=True)
+        order = degree_order(in_degree)
         self.order = order                                   # position -> vertex
         self.pos = torch.empty_like(order)
         self.pos[order] = torch.arange(self.nv, dtype=order.dtype, device=order.device)  # vertex -> position
@@ -94,7 +194,7 @@ def _a2a(t, send_counts, recv_counts, group):
 def _exchange_edges(col_src, local_dst, owner_dst, weights, world, group):
     """Routes every edge to the owner of its destination (all-to-all-v), like shuffle_ext_edges in the reference
     (cpp/src/c_api/graph_mg.cpp:140) but keyed on the degree-order owner instead of a hash."""
-    order = torch.argsort(owner_dst, stable=True)
+    order = stable_argsort(owner_dst, world - 1)
     col_src, local_dst = col_src[order].contiguous(), local_dst[order].contiguous()
     if weights is not None:
         weights = weights[order].contiguous()
@@ -117,10 +217,10 @@ class Exchange:
     def __init__(self, src_pos: torch.Tensor, world: int, rank: int, itemsize: int, group):
         self.world, self.rank = world, rank
         self.tail = TAIL_BYTES // itemsize
-        need, self.col_of_edge = torch.unique(src_pos, sorted=True, return_inverse=True)
+        need, self.col_of_edge = unique_inverse(src_pos)
         self.ncols = int(need.numel())
         owner = need % world
-        order = torch.argsort(owner, stable=True)            # requests grouped by owner, ascending position inside
+        order = stable_argsort(owner, world - 1)             # requests grouped by owner, ascending position inside
         req = (need // world)[order].to(torch.int32)
         counts = _count_owners(owner, world).tolist()
         # fp32 tails hold doubles: keep every message 8-byte aligned by padding odd requests with a repeat of local row 0
@@ -364,7 +464,7 @@ class Partition2D:
         self.R, self.C = shape or grid_shape(world)
         assert self.R * self.C == world
         self.r, self.c = rank % self.R, rank // self.R
-        _, order = torch.sort(in_degree, descending=True, stable=True)
+        order = degree_order(in_degree)
         self.order = order
         self.pos = torch.empty_like(order)
         self.pos[order] = torch.arange(self.nv, dtype=order.dtype, device=order.device)

@@ -32,7 +32,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .mg import Partition, _a2a, _count_owners
+from .mg import Partition, _a2a, _count_owners, inclusive_counts, stable_argsort
 
 INT32_MAX = 2**31 - 1
 FLT_MAX = float(np.finfo(np.float32).max)
@@ -179,7 +179,7 @@ class MGTraversal:
         pos_s, pos_d = part.pos[src64], part.pos[dst64]
         g_dst = (pos_d % world) * L + pos_d // world                 # compact global id of the destination
         owner = pos_s % world
-        order = torch.argsort(owner, stable=True)
+        order = stable_argsort(owner, world - 1)  # the library's radix sort on device tensors (mg.py)
         send_counts = _count_owners(owner, world)
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts, group=group)
@@ -190,12 +190,12 @@ class MGTraversal:
         # local CSR (rows ascending, destinations ascending inside a row)
         n_rows = part.n_rows
         key = rows * (L * world) + cols
-        o2 = torch.argsort(key, stable=True)
+        o2 = stable_argsort(key, n_rows * L * world)
         rows, cols = rows[o2], cols[o2]
         w = None if w is None else w[o2].contiguous()
         offsets = torch.zeros(n_rows + 1, dtype=torch.int64, device=rows.device)
         if rows.numel():
-            offsets[1:] = torch.cumsum(torch.bincount(rows, minlength=n_rows), 0)
+            offsets[1:] = inclusive_counts(rows, n_rows)
         self.num_local_edges = int(cols.numel())
         assert self.num_local_edges < 2**31 and L * world < 2**31
         factory = engine_factory or HipTraversalEngine

@@ -82,6 +82,15 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg_plan_values(cugraph_
                                                                         cugraph_error_t** error);
 CUGRAPH_EXPORT void cugraph_amd_pagerank_mg_plan_free(cugraph_amd_pagerank_mg_plan_t* plan);
 
+/* Device primitives of the library behind the C ABI: the multi-GPU host layer (cugraph_amd/mg.py) builds its partition and its
+ * exchange plan from these two instead of torch.sort / torch.unique / torch.argsort / torch.cumsum (rocPRIM).
+ * sort_pairs: stable LSD radix sort of n (key, value) pairs in place on the bits [bit_lo, bit_hi) of the keys (vals may be NULL);
+ * exclusive_scan: out[i] = sum of in[0 .. i) (in == out allowed).  Device pointers, n < 2^32; both block until done. */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_sort_pairs_u64_u32(const cugraph_resource_handle_t* handle, uint64_t* keys, uint32_t* vals, size_t n,
+                                                                   int bit_lo, int bit_hi, cugraph_error_t** error);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_exclusive_scan_u32(const cugraph_resource_handle_t* handle, const uint32_t* in, uint32_t* out, size_t n,
+                                                                   cugraph_error_t** error);
+
 /* 2-D layout of the same iteration (the reference's scheme: cpp/include/cugraph/graph_view.hpp:159-216, partition_manager.hpp:42-51,
  * prims/update_edge_src_dst_property.cuh:550-579, prims/detail/per_v_transform_reduce_e.cuh:3390-3406): P = R x C ranks, rank = c * R + r;
  * vertex partitions of rows_per_partition rows (position p of the global degree order -> partition p % P, row p / P); rank (r, c) owns

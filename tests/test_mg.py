@@ -208,3 +208,31 @@ def test_mg_pagerank_hip_engine_convergence(orc, tmp_path):
     t, it, tconv = truth(orc, 11, 1e-5, 200)
     assert conv and abs(iters - it) <= 1
     np.testing.assert_allclose(pr, t, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_plan_construction_primitives_on_device():
+    """The device versions of the plan-construction helpers (the library's radix sort / scan through the C ABI:
+    cugraph_amd_sort_pairs_u64_u32, cugraph_amd_exclusive_scan_u32) against their torch definitions."""
+    import torch
+
+    from cugraph_amd import mg
+
+    g = torch.Generator().manual_seed(7)
+    for n, hi in ((1, 5), (1000, 7), (300001, 1 << 20), (2_000_003, (1 << 40) + 17)):
+        x = torch.randint(0, hi, (n,), generator=g, dtype=torch.int64)
+        xd = x.cuda()
+        assert torch.equal(mg.stable_argsort(xd).cpu(), torch.argsort(x, stable=True))
+        u, inv = mg.unique_inverse(xd)
+        tu, tinv = torch.unique(x, sorted=True, return_inverse=True)
+        assert torch.equal(u.cpu(), tu) and torch.equal(inv.cpu(), tinv)
+    deg = torch.randint(0, 50, (100003,), generator=g, dtype=torch.int64)
+    assert torch.equal(mg.degree_order(deg.cuda()).cpu(), torch.sort(deg, descending=True, stable=True)[1])
+    rows = torch.sort(torch.randint(0, 5000, (70001,), generator=g, dtype=torch.int64))[0]
+    assert torch.equal(mg.inclusive_counts(rows.cuda(), 5000).cpu(), torch.cumsum(torch.bincount(rows, minlength=5000), 0))
+    # a partition and an exchange plan built from device tensors equal the ones built on the host
+    indeg = torch.randint(0, 30, (4096,), generator=g, dtype=torch.int64)
+    ph, pd = mg.Partition(indeg, 4, 1), mg.Partition(indeg.cuda(), 4, 1)
+    assert torch.equal(ph.order, pd.order.cpu()) and torch.equal(ph.local_vertices, pd.local_vertices.cpu())
+    p2h, p2d = mg.Partition2D(indeg, 8, 3), mg.Partition2D(indeg.cuda(), 8, 3)
+    assert torch.equal(p2h.pos, p2d.pos.cpu()) and (p2h.R, p2h.C, p2h.L) == (p2d.R, p2d.C, p2d.L)
