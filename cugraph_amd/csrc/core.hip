@@ -473,7 +473,11 @@ void* pool_alloc(size_t n_bytes, size_t* granted)
     {
       std::lock_guard<std::mutex> lock(p.m);
       auto it = p.free_blocks.lower_bound({dev, want});
-      if (it != p.free_blocks.end() && it->first.first == dev && it->first.second <= want + want / 4) {
+      // best fit within 25 % slack; large requests (>= 256 MiB) take a cached block of up to twice their size: the levels of a
+      // Louvain run and the passes of a graph build ask for a sequence of shrinking multi-GB buffers, and a miss there means a
+      // synchronous hipMalloc of gigabytes (and, once the cache is over its cap, hipFrees) in the middle of the algorithm
+      size_t const slack = want >= ((size_t)256 << 20) ? want : want / 4;
+      if (it != p.free_blocks.end() && it->first.first == dev && it->first.second <= want + slack) {
         blk      = it->second;
         *granted = it->first.second;
         p.cached -= it->first.second;

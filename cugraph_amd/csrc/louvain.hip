@@ -32,6 +32,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "cugraph_c/community_algorithms.h"
@@ -350,15 +351,110 @@ __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
     }
   }
 }
+// OPT-IN (CUGRAPH_AMD_LOUVAIN_HUB=hash; the default keeps the sorted path for hubs, see run_level): hub rows (more than LVH_B
+// edges -- 36 % of the edges of RMAT-22, 56 % of RMAT-26) WITHOUT sorting either: their edges are
+// compacted once per level (hub list, grouped by row); row v with deg edges owns the table region [2 * first, 2 * first + 2 * deg)
+// of a global open-addressing table (first = position of the row's first edge in the hub list), keyed by the destination's cluster
+// inside the region.  k_lv_hub_insert adds the fixed-point weights (runs of equal (row, cluster) on neighbouring lanes are summed
+// in the wavefront first: a hub whose neighbours sit in one giant cluster would otherwise serialise its atomics on one address),
+// k_lv_hub_eval<0/1> walks the table slots flat -- slot t belongs to the row of hub edge t / 2 -- and reduces the best gain / the
+// smallest cluster among the best per row exactly as the sorted path's k_segment_best does.  Same integers, same gains, same ties.
+struct lv_hub_args {
+  int32_t const* hs; int32_t const* hd; double const* hw; uint32_t const* hrow0; int32_t const* off;  // hub list + first hub position of the edge's row
+  int32_t const* c; double const* k; double const* a; double m, resolution, scale, inv_scale; int64_t n_h;
+  unsigned long long* keys; unsigned long long* sums;  // [2 * n_h]: keys = cluster id, ~0 = empty (set by the caller), sums = 0
+  unsigned long long* selffix; unsigned long long* subfix; unsigned long long* best_bits; int32_t* best_c;  // [nv]
+};
+__global__ void k_lv_hub_insert(lv_hub_args A)
+{
+  int const lane       = threadIdx.x & 63;
+  int64_t const wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t const nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t q0 = wave * 64; q0 < A.n_h; q0 += nwaves * 64) {
+    int64_t const q  = q0 + lane;
+    bool const valid = q < A.n_h;
+    int32_t v = -1, cl = -1, cv = -2;
+    long long wf = 0;
+    uint32_t r0 = 0, size = 2;
+    if (valid) {
+      v            = A.hs[q];
+      int32_t const u = A.hd[q];
+      cl           = A.c[u];
+      cv           = A.c[v];
+      wf           = __double2ll_rn(A.hw[q] * A.scale);
+      r0           = A.hrow0[q];
+      size         = 2u * (uint32_t)(A.off[v + 1] - A.off[v]);
+      if (u == v) atomicAdd(&A.subfix[v], (unsigned long long)wf);  // self-loop
+    }
+    // runs of equal (row, cluster) on neighbouring lanes: one table update per run
+    int32_t const vp = __shfl_up(v, 1), cp = __shfl_up(cl, 1), vn = __shfl_down(v, 1), cn = __shfl_down(cl, 1);
+    bool const head = lane == 0 || v != vp || cl != cp;
+    bool const end  = lane == 63 || v != vn || cl != cn;
+    bool open;
+    long long const sum = seg_scan64(wf, head, lane, open);
+    if (valid && end) {
+      uint64_t const base = 2ull * (uint64_t)r0;
+      uint32_t i          = (uint32_t)(((uint64_t)((uint32_t)cl * 0x9E3779B1u) * (uint64_t)size) >> 32);
+      unsigned long long const key = (unsigned long long)(uint32_t)cl;
+      for (;;) {
+        unsigned long long const old = atomicCAS(&A.keys[base + i], ~0ull, key);
+        if (old == ~0ull || old == key) break;
+        if (++i == size) i = 0;
+      }
+      atomicAdd(&A.sums[base + i], (unsigned long long)sum);
+      if (cl == cv) atomicAdd(&A.selffix[v], (unsigned long long)sum);
+    }
+  }
+}
+template <int PHASE>
+__global__ void k_lv_hub_eval(lv_hub_args A)
+{
+  int const lane       = threadIdx.x & 63;
+  int64_t const wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t const nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int64_t const nslots = 2 * A.n_h;
+  for (int64_t t0 = wave * 64; t0 < nslots; t0 += nwaves * 64) {
+    int64_t const t  = t0 + lane;
+    bool const valid = t < nslots;
+    unsigned long long const key = valid ? A.keys[t] : ~0ull;
+    int32_t const v = valid ? A.hs[t >> 1] : -1;  // the slot lies in the region of this row
+    unsigned long long bits = 0;
+    int32_t const cl = (int32_t)(uint32_t)key;
+    if (key != ~0ull) {
+      int32_t const cv     = A.c[v];
+      double const s       = (double)(long long)A.sums[t] * A.inv_scale;
+      double const sub     = (double)(long long)A.subfix[v] * A.inv_scale;
+      double const old_sum = (double)(long long)(A.selffix[v] - A.subfix[v]) * A.inv_scale;
+      double const new_sum = cl == cv ? s - sub : s;
+      double const delta   = lv_delta(new_sum, old_sum, A.a[cl], A.a[cv], A.k[v], A.m, A.resolution);
+      if (delta > 0.0) bits = (unsigned long long)__double_as_longlong(delta);
+    }
+    if (PHASE == 0) {  // maximum over the lanes of one row (consecutive lanes), then one atomic per (wavefront, row)
+      int32_t const vprev = __shfl_up(v, 1), vnext = __shfl_down(v, 1);
+      bool vhead = lane == 0 || v != vprev;
+      unsigned long long mx = bits;
+      unsigned f = vhead ? 1u : 0u;
+      for (int o = 1; o < 64; o <<= 1) {
+        unsigned long long const tm = __shfl_up(mx, o);
+        unsigned const tf           = __shfl_up(f, o);
+        if (lane >= o && !f) { mx = tm > mx ? tm : mx; f |= tf; }
+      }
+      bool const vend = lane == 63 || v != vnext;
+      if (valid && vend && mx) atomicMax(&A.best_bits[v], mx);
+    } else {
+      if (bits && bits == A.best_bits[v]) atomicMin(&A.best_c[v], cl);
+    }
+  }
+}
 // hub rows (more than LVH_B edges): their edges, compacted once per level, go through the sorted path
 __global__ void k_lv_hub_flags(int32_t const* src, int32_t const* off, int64_t ne, uint32_t* flag)
 {
   LV_LOOP(e, ne) { int32_t const v = src[e]; flag[e] = (off[v + 1] - off[v] > LVH_B) ? 1u : 0u; }
 }
-__global__ void k_lv_hub_compact(int32_t const* src, int32_t const* dst, double const* w, uint32_t const* flag, uint32_t const* pos, int64_t ne, int32_t* hs,
-                                 int32_t* hd, double* hw)
+__global__ void k_lv_hub_compact(int32_t const* src, int32_t const* dst, double const* w, int32_t const* off, uint32_t const* flag, uint32_t const* pos, int64_t ne,
+                                 int32_t* hs, int32_t* hd, double* hw, uint32_t* hrow0)
 {
-  LV_LOOP(e, ne) if (flag[e]) { uint32_t const q = pos[e]; hs[q] = src[e]; hd[q] = dst[e]; hw[q] = w[e]; }
+  LV_LOOP(e, ne) if (flag[e]) { uint32_t const q = pos[e]; hs[q] = src[e]; hd[q] = dst[e]; hw[q] = w[e]; hrow0[q] = pos[off[src[e]]]; }
 }
 __global__ void k_best_finalize(unsigned long long const* best_bits, int32_t* best_c, double* best_d, int64_t nv)
 {
@@ -542,6 +638,7 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   // and take the sorted path.  CUGRAPH_AMD_LOUVAIN_HASH=0: every row takes the sorted path (round 2's behaviour).
   bool const use_hash = ne > 0 && !(getenv("CUGRAPH_AMD_LOUVAIN_HASH") && atoi(getenv("CUGRAPH_AMD_LOUVAIN_HASH")) == 0);
   level_t Lh;  // the hub rows' edges (use_hash) -- src / dst / w only
+  dvec<uint32_t> hrow0;  // position in the hub list of the first edge of every hub edge's row
   int64_t n_sorted = ne;
   if (use_hash) {
     dvec<uint32_t> flag((size_t)ne + 1), pos((size_t)ne + 1);
@@ -553,18 +650,27 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     n_sorted = nh;
     size_t const h1 = (size_t)std::max<int64_t>(n_sorted, 1);
     Lh.src.resize_discard(h1); Lh.dst.resize_discard(h1); Lh.w.resize_discard(h1);
+    hrow0.resize_discard(h1);
     if (n_sorted > 0)
       hipLaunchKernelGGL(k_lv_hub_compact, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.dst.data(), (double const*)L.w.data(),
-                         (uint32_t const*)flag.data(), (uint32_t const*)pos.data(), ne, Lh.src.data(), Lh.dst.data(), Lh.w.data());
+                         (int32_t const*)L.off.data(), (uint32_t const*)flag.data(), (uint32_t const*)pos.data(), ne, Lh.src.data(), Lh.dst.data(), Lh.w.data(),
+                         hrow0.data());
     h.sync();
   }
+  // hub rows: the sorted path (default), or a global hash table (CUGRAPH_AMD_LOUVAIN_HUB=hash; measured SLOWER -- 0.129 s against
+  // 0.114 s at RMAT-22, 2.43 s against 2.10 s at RMAT-26: an insertion is two device-scope atomics per run of equal clusters and
+  // k_lv_hub_insert manages 7 G edges/s, where the radix passes stream)
+  bool const hub_hash = use_hash && n_sorted > 0 && getenv("CUGRAPH_AMD_LOUVAIN_HUB") && std::string(getenv("CUGRAPH_AMD_LOUVAIN_HUB")) == "hash";
+  dvec<unsigned long long> hub_keys, hub_sums;
+  if (hub_hash) { hub_keys.resize_discard((size_t)2 * n_sorted); hub_sums.resize_discard((size_t)2 * n_sorted); }
   int32_t const* const s_src = use_hash ? Lh.src.data() : L.src.data();
   int32_t const* const s_dst = use_hash ? Lh.dst.data() : L.dst.data();
   double const* const s_w    = use_hash ? Lh.w.data() : L.w.data();
   int const g_s = grid_for(n_sorted, kBlock, 8192);
-  dvec<uint32_t> count(2), eperm((size_t)std::max<int64_t>(n_sorted, 1));
-  dvec<uint64_t> ekeys((size_t)std::max<int64_t>(n_sorted, 1));
-  segfix.resize_discard((size_t)std::max<int64_t>(n_sorted, 1));
+  size_t const n_keys = (size_t)std::max<int64_t>(hub_hash ? 1 : n_sorted, 1);  // buffers of the sorted path
+  dvec<uint32_t> count(2), eperm(n_keys);
+  dvec<uint64_t> ekeys(n_keys);
+  segfix.resize_discard(n_keys);
   accepted.resize_discard((size_t)nv);
   HIP_TRY(hipMemsetAsync(kfix.data(), 0, (size_t)nv * sizeof(long long), h.stream));
   if (ne > 0) hipLaunchKernelGGL(k_vertex_weights, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (double const*)L.w.data(), ne, scale,
@@ -595,7 +701,7 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     ++st.sweeps;
     ++st.sweeps_in_level;
     // update_clustering_by_delta_modularity (common_methods.cuh:259-447)
-    if (n_sorted > 0) {
+    if (n_sorted > 0 && !hub_hash) {
       hipLaunchKernelGGL(k_pair_keys, g_s, kBlock, 0, h.stream, s_src, (int32_t const*)nullptr, s_dst, (int32_t const*)c.data(), n_sorted, vb, ekeys.data(),
                          eperm.data());
       // first sweep of a level: every vertex is its own cluster, so the key is (source, destination) -- the order the level's
@@ -604,7 +710,17 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     }
     HIP_TRY(hipMemsetAsync(vfix.data(), 0, (size_t)nv * 3 * sizeof(unsigned long long), h.stream));  // selffix, subfix, best_bits
     HIP_TRY(hipMemsetAsync(best_c.data(), 0x7f, (size_t)nv * sizeof(int32_t), h.stream));
-    if (n_sorted > 0) {
+    if (hub_hash) {
+      HIP_TRY(hipMemsetAsync(hub_keys.data(), 0xFF, (size_t)2 * n_sorted * sizeof(unsigned long long), h.stream));
+      HIP_TRY(hipMemsetAsync(hub_sums.data(), 0, (size_t)2 * n_sorted * sizeof(unsigned long long), h.stream));
+      lv_hub_args HB{s_src, s_dst, s_w, hrow0.data(), L.off.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, n_sorted,
+                     hub_keys.data(), hub_sums.data(), vfix.data(), vfix.data() + nv, vfix.data() + 2 * nv, best_c.data()};
+      int const g_t = grid_for(2 * n_sorted, kBlock, 16384);
+      hipLaunchKernelGGL(k_lv_hub_insert, g_s, kBlock, 0, h.stream, HB);
+      hipLaunchKernelGGL(k_lv_hub_eval<0>, g_t, kBlock, 0, h.stream, HB);
+      hipLaunchKernelGGL(k_lv_hub_eval<1>, g_t, kBlock, 0, h.stream, HB);
+    }
+    if (n_sorted > 0 && !hub_hash) {
       HIP_TRY(hipMemsetAsync(segfix.data(), 0, (size_t)n_sorted * sizeof(unsigned long long), h.stream));
       lv_flat_args A{ekeys.data(), eperm.data(), s_dst, s_w, c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, n_sorted, vb,
                      segfix.data(), vfix.data(), vfix.data() + nv, vfix.data() + 2 * nv, best_c.data()};

@@ -1041,10 +1041,10 @@ def test_louvain_scale_vs_oracle(cg, handle, orc, scale):
 
 @pytest.mark.parametrize("scale,weights", [(14, "int"), (16, "real")])
 def test_louvain_hash_path_equals_sorted_path(cg, handle, orc, monkeypatch, scale, weights):
-    """Round 3: rows of at most 512 edges take the LDS hash path (k_lv_hash_chunks), hubs the sorted path.  Both accumulate the same
-    fixed-point integers, so the whole run -- clusters, modularity, hierarchy -- must not depend on which path a row takes: compare
-    the default split with CUGRAPH_AMD_LOUVAIN_HASH=0 (every row sorted), on a graph with hubs, isolated vertices, self-loops and
-    multi-edges, and with the numpy / C oracle."""
+    """Round 3: rows of at most 512 edges take the LDS hash path (k_lv_hash_chunks), hubs a global hash table (k_lv_hub_*) or the
+    sorted path.  All accumulate the same fixed-point integers, so the whole run -- clusters, modularity, hierarchy -- must not depend
+    on which path a row takes: the default against hubs-sorted (CUGRAPH_AMD_LOUVAIN_HUB=sort) and everything-sorted
+    (CUGRAPH_AMD_LOUVAIN_HASH=0), on a graph with hubs, isolated vertices, self-loops and multi-edges, and against the C oracle."""
     src, dst, w = louvain_rmat_input(orc, scale)
     nv = 1 << scale
     rng = np.random.default_rng(3)
@@ -1058,15 +1058,44 @@ def test_louvain_hash_path_equals_sorted_path(cg, handle, orc, monkeypatch, scal
     o = np.lexsort((dst, src))
     src, dst, w = src[o], dst[o], w[o]
     res = {}
-    for mode in ("1", "0"):
+    for mode, hub in (("1", "hash"), ("1", "sort"), ("0", "sort")):  # default (LDS hash + global hub hash); hubs sorted; everything sorted
         monkeypatch.setenv("CUGRAPH_AMD_LOUVAIN_HASH", mode)
+        monkeypatch.setenv("CUGRAPH_AMD_LOUVAIN_HUB", hub)
         g = cg.SGGraph(handle, cg.GraphProperties(is_symmetric=True, is_multigraph=True), T(src, np.int32), T(dst, np.int32), T(w, np.float32), renumber=False,
                        vertices_array=T(np.arange(nv), np.int32))
         v, c, q = cg.louvain(handle, g, 100, 1e-7, 1.0, False)
-        res[mode] = (by_vertex(v, c)[0], q)
-    assert np.array_equal(res["1"][0], res["0"][0]) and res["1"][1] == res["0"][1]
+        res[mode + hub] = (by_vertex(v, c)[0], q)
+    for k in ("1sort", "0sort"):
+        assert np.array_equal(res["1hash"][0], res[k][0]) and res["1hash"][1] == res[k][1], k
     oc, oq, _, _ = orc.louvain_c(nv, src, dst, w, 100, 1e-7, 1.0)
-    assert np.array_equal(res["1"][0], oc) and abs(res["1"][1] - oq) <= 1e-9
+    assert np.array_equal(res["1hash"][0], oc) and abs(res["1hash"][1] - oq) <= 1e-9
+
+
+def test_louvain_rmat22_golden(cg, handle):
+    """Louvain at the size its timing is quoted on (RMAT-22, 65 M directed edges): clusters (sha256 of the column), modularity (exact),
+    against the fixture the C oracle produced (tests/golden/make_louvain_rmat22.py: ~2.5 CPU-minutes, hence a fixture)."""
+    import hashlib
+    import json
+    import sys
+    from pathlib import Path
+
+    import torch
+
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    from bench_louvain import undirected_rmat
+
+    gold = json.loads((root / "tests" / "golden" / "louvain_rmat22.json").read_text())
+    scale = gold["scale"]
+    src, dst, w = undirected_rmat(cg, handle, scale, gold["edge_factor"], seed=gold["seed"])
+    assert int(src.numel()) == gold["directed_edges"]
+    nv = 1 << scale
+    g = cg.SGGraph(handle, cg.GraphProperties(is_symmetric=True), src, dst, w, renumber=False, vertices_array=torch.arange(nv, dtype=torch.int32, device="cuda"))
+    v, c, q = cg.louvain(handle, g, 100, 1e-7, 1.0, False)
+    (c,) = by_vertex(v, c)
+    assert q == gold["modularity"]
+    assert int(np.unique(c).size) == gold["clusters"]
+    assert hashlib.sha256(np.ascontiguousarray(c, np.int32).tobytes()).hexdigest() == gold["clusters_sha256"]
 
 
 def test_capi_generators_edge_columns_and_decompress(cg, handle):
