@@ -508,6 +508,220 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split(int32_t const* far_in, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// SSSP, round 3: the near set of a bucket is kept in SSSP_K distance-ordered sub-queues (delta-stepping INSIDE the near-far
+// window; sssp_impl.cuh:376-561 has one near bucket).  With one near queue every vertex of [lower, upper) is expanded as soon as
+// it is reached and again whenever its distance improves inside the window -- 2.2-2.3 relaxations per edge at RMAT-24 with
+// weights 1..255, a Bellman-Ford inside the first window.  Here a successful relaxation with nd < upper appends v to sub-queue
+// k = floor((nd - lower) / (delta / K)); the sub-queues are drained in order (k == current: the next round of the same sub-queue),
+// so a vertex is expanded when the vertices that can still improve it by more than delta / K have been expanded already.  No far
+// pile is rescanned between sub-queues (that is what made a narrower delta slower in round 2), stale entries are dropped when they
+// are popped: an entry is expanded iff the vertex's CURRENT distance falls into the sub-queue being drained and it has not been
+// expanded at that distance (done[v]).  Distances are the same fixed point as before (bit-identical to Dijkstra).
+constexpr int SSSP_K = 8;
+template <typename WT>
+struct sssp_multi_state {
+  using bits_t = typename dist_bits<WT>::type;
+  bits_t* dist;
+  WT const* weights;
+  bits_t* done;                 // distance bits at which the vertex was expanded last (unreached pattern = never)
+  int32_t* q[SSSP_K];           // sub-queues of the current window (q[k], k > j, receive entries while sub-queue j is drained)
+  int32_t* q_same;              // next round of sub-queue j
+  int32_t* far;
+  uint32_t* mark;               // per vertex: tag of its last insertion into a near queue (dedup within a round / a sub-queue)
+  uint32_t* mark_far;
+  counters_t* cnt;              // n_next = entries of q_same, n_far = far pile, edges = relaxations
+  uint32_t* qn;                 // [SSSP_K] fill of the sub-queues (persist across the rounds of a window)
+  WT lower, upper, inv_sub, cutoff;
+  int j;
+  uint32_t round_tag, sub_tag0, far_epoch;  // tag of an insertion into q_same / base tag of the window's sub-queues (+ k)
+};
+template <typename WT>
+__device__ __forceinline__ int sssp_sub_of(WT d, WT lower, WT inv_sub)
+{
+  WT const x = (d - lower) * inv_sub;
+  int k      = x > WT(0) ? (int)x : 0;
+  return k < SSSP_K - 1 ? k : SSSP_K - 1;
+}
+// per-wavefront LDS staging for SSSP_K + 2 output queues (the wave_queue scheme with the queue picked per call, wave-uniform)
+struct multi_queue_storage {
+  int32_t buf[SSSP_K + 2][TV_WAVES][WQ_CAP / 2];
+  uint32_t fill[SSSP_K + 2][TV_WAVES];
+  int32_t* q[SSSP_K + 2];
+  uint32_t* counter[SSSP_K + 2];
+};
+constexpr int MQ_CAP = WQ_CAP / 2;
+__device__ __forceinline__ void mq_push(multi_queue_storage& st, int k, bool flag, int32_t value)
+{  // k wave-uniform
+  uint64_t const m = __ballot(flag);
+  if (m == 0) return;
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int32_t* const buf   = st.buf[k][wave];
+  uint32_t* const fill = &st.fill[k][wave];
+  uint32_t const c     = (uint32_t)__popcll(m);
+  int const leader     = __ffsll((unsigned long long)m) - 1;
+  uint32_t const rank  = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  uint32_t base        = 0;
+  if (lane == leader) base = atomicAdd(fill, c);
+  base = __shfl(base, leader);
+  if (base + c <= (uint32_t)MQ_CAP) {
+    if (flag) buf[base + rank] = value;
+    return;
+  }
+  uint32_t g = 0;
+  if (lane == leader) { g = atomicAdd(st.counter[k], base + c); *fill = 0; }
+  g = __shfl(g, leader);
+  uint64_t const act = __ballot(true);
+  uint32_t const na = (uint32_t)__popcll(act), ar = (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
+  int32_t* const q = st.q[k];
+  for (uint32_t i = ar; i < base; i += na) q[g + i] = buf[i];
+  if (flag) q[g + base + rank] = value;
+}
+__device__ __forceinline__ void mq_flush(multi_queue_storage& st)
+{
+  __builtin_amdgcn_wave_barrier();
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < SSSP_K + 2; ++k) {
+    uint32_t const n = st.fill[k][wave];
+    if (n == 0) continue;
+    uint32_t g = 0;
+    if (lane == 0) g = atomicAdd(st.counter[k], n);
+    g = __shfl(g, 0);
+    int32_t* const q = st.q[k];
+    for (uint32_t i = lane; i < n; i += 64) q[g + i] = st.buf[k][wave][i];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) st.fill[k][wave] = 0;
+  }
+}
+template <typename WT>
+__device__ __forceinline__ void mq_init(multi_queue_storage& st, sssp_multi_state<WT> const& s)
+{
+  if (threadIdx.x < (SSSP_K + 2) * TV_WAVES) (&st.fill[0][0])[threadIdx.x] = 0;
+  if (threadIdx.x < SSSP_K) { st.q[threadIdx.x] = s.q[threadIdx.x]; st.counter[threadIdx.x] = &s.qn[threadIdx.x]; }
+  if (threadIdx.x == SSSP_K) { st.q[SSSP_K] = s.q_same; st.counter[SSSP_K] = &s.cnt->n_next; }
+  if (threadIdx.x == SSSP_K + 1) { st.q[SSSP_K + 1] = s.far; st.counter[SSSP_K + 1] = &s.cnt->n_far; }
+  __syncthreads();
+}
+template <typename WT>
+struct sssp_relax_multi {
+  sssp_multi_state<WT> s;
+  multi_queue_storage* st;
+  __device__ __forceinline__ void operator()(int32_t u, int32_t v, eoff_t p)
+  {
+    using B  = dist_bits<WT>;
+    WT const nd = B::from(s.dist[u]) + s.weights[p];
+    bool near = false, far = false;
+    int k = 0;
+    if (nd < s.cutoff && nd < B::from(__hip_atomic_load(&s.dist[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+      auto old = atomicMin(&s.dist[v], B::to(nd));
+      if (B::to(nd) < old) {
+        if (nd < s.upper) {
+          k = sssp_sub_of<WT>(nd, s.lower, s.inv_sub);
+          if (k < s.j) k = s.j;  // (cannot happen for a monotone sub_of; keeps the queue order safe)
+          uint32_t const tag = k == s.j ? s.round_tag : s.sub_tag0 + (uint32_t)k;
+          near = atomicExch(&s.mark[v], tag) != tag;
+        } else {
+          far = atomicExch(&s.mark_far[v], s.far_epoch) != s.far_epoch;
+        }
+      }
+    }
+    uint64_t m = __ballot(near);
+    while (m) {  // one staged append per distinct sub-queue among the lanes
+      int const l  = __ffsll((unsigned long long)m) - 1;
+      int const k0 = __shfl(k, l);
+      bool const mine = near && k == k0;
+      mq_push(*st, k0 == s.j ? SSSP_K : k0, mine, v);
+      m &= ~__ballot(mine);
+    }
+    mq_push(*st, SSSP_K + 1, far, v);
+  }
+};
+// pop filter: expand u iff its current distance lies in the sub-queue being drained and it was not expanded at that distance
+template <typename WT>
+struct sssp_pop {
+  typename dist_bits<WT>::type const* dist;
+  typename dist_bits<WT>::type* done;
+  WT lower, upper, inv_sub;
+  int j;
+  __device__ __forceinline__ bool operator()(int32_t u) const
+  {
+    using B = dist_bits<WT>;
+    auto const b = dist[u];
+    WT const d   = B::from(b);
+    if (!(d >= lower && d < upper) || sssp_sub_of<WT>(d, lower, inv_sub) != j) return false;
+    return atomicExch(&done[u], b) != b;
+  }
+};
+template <typename WT>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_multi(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices, int32_t* bigq,
+                                                                sssp_multi_state<WT> s, int32_t big_deg)
+{
+  __shared__ multi_queue_storage st;
+  mq_init<WT>(st, s);
+  sssp_relax_multi<WT> f{s, &st};
+  sssp_pop<WT> keep{s.dist, s.done, s.lower, s.upper, s.inv_sub, s.j};
+  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep, f, big_deg);
+  mq_flush(st);
+}
+template <typename WT>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_big_multi(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, sssp_multi_state<WT> s)
+{
+  __shared__ multi_queue_storage st;
+  mq_init<WT>(st, s);
+  sssp_relax_multi<WT> f{s, &st};
+  expand_big(bigq, offsets, indices, s.cnt, f);
+  mq_flush(st);
+}
+// far pile -> the sub-queues of the new window [lower, upper) | far pile'
+template <typename WT>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_split_multi(int32_t const* far_in, int64_t n, sssp_multi_state<WT> s, int32_t* far_out, uint32_t new_epoch)
+{
+  using B = dist_bits<WT>;
+  __shared__ multi_queue_storage st;
+  mq_init<WT>(st, s);
+  if (threadIdx.x == 0) st.q[SSSP_K + 1] = far_out;  // the kept entries go to the other far buffer
+  __syncthreads();
+  int const lane = threadIdx.x & 63;
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t n_pad  = (n + 63) & ~(int64_t)63;
+  unsigned long long kept_min = ~0ull;
+  for (; i < n_pad; i += stride) {
+    bool near = false, keep = false;
+    int32_t v = 0;
+    int k = 0;
+    if (i < n) {
+      v    = far_in[i];
+      WT d = B::from(s.dist[v]);
+      if (d >= s.lower) {
+        if (d < s.upper) {
+          k = sssp_sub_of<WT>(d, s.lower, s.inv_sub);
+          uint32_t const tag = s.sub_tag0 + (uint32_t)k;
+          near = atomicExch(&s.mark[v], tag) != tag;
+        } else {
+          keep = atomicExch(&s.mark_far[v], new_epoch) != new_epoch;
+          if (keep) kept_min = min(kept_min, (unsigned long long)B::to(d));
+        }
+      }
+    }
+    uint64_t m = __ballot(near);
+    while (m) {
+      int const l  = __ffsll((unsigned long long)m) - 1;
+      int const k0 = __shfl(k, l);
+      bool const mine = near && k == k0;
+      mq_push(st, k0, mine, v);
+      m &= ~__ballot(mine);
+    }
+    mq_push(st, SSSP_K + 1, keep, v);
+  }
+  mq_flush(st);
+  for (int o = 32; o > 0; o >>= 1) kept_min = min(kept_min, (unsigned long long)__shfl_xor(kept_min, o));
+  if (lane == 0 && kept_min != ~0ull) {
+    if constexpr (sizeof(WT) == 4) atomicMin(&s.cnt->far_min_bits_lo, (uint32_t)kept_min);
+    else atomicMin(&s.cnt->far_min_bits64, kept_min);
+  }
+}
+
 // canonical parents: pred[v] = min EXTERNAL id u with d[u] + w(u,v) == d[v]
 template <typename WT>
 struct sssp_parent {
@@ -923,6 +1137,120 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   dvec<uint32_t> mark_set(use_lh ? n1 : 1);
   if (use_lh) HIP_TRY(hipMemsetAsync(mark_set.data(), 0, n1 * 4, h.stream));
 
+  // CUGRAPH_AMD_SSSP_MODE=multi: distance-ordered sub-queues inside the window (k_sssp_expand_multi above).  Measured at RMAT-24,
+  // weights 1..255, 16 roots (profiles/r3_sssp_subqueues.txt): 8 sub-queues 1.64 relaxations per edge instead of 2.25 -- and 49.6
+  // rounds instead of 18.4, 12.8 ms instead of 11.6; 4 sub-queues 1.88 / 34.8 rounds / 11.6 ms; with delta / 2: 1.35 / 77.6 rounds /
+  // 13.4 ms.  A round costs ~100 us whatever it relaxes (two launches over the whole chip, counter upload and read-back), which
+  // eats what the saved relaxations buy -- the same outcome as the light / heavy buckets of round 2.  The single near queue
+  // therefore stays the default; the sub-queue path is kept, tested (test_sssp_subqueues_vs_oracle), for the day the rounds are
+  // driven from the device.
+  char const* env_mode = getenv("CUGRAPH_AMD_SSSP_MODE");
+  bool const use_multi = !use_lh && env_mode && std::string(env_mode) == "multi";
+  uint64_t steps = 0, relaxed = 0;
+  counters_t c;
+  if (use_multi) {
+    std::vector<dvec<int32_t>> subq(SSSP_K);
+    for (auto& q : subq) q.resize_discard(n1);
+    dvec<bits_t> done(n1);
+    hipLaunchKernelGGL(k_fill_t<bits_t>, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, done.data(), nv, unreached_bits);
+    {
+      bits_t zero_bits = 0;
+      HIP_TRY(hipMemcpyAsync(d + source, &zero_bits, sizeof(bits_t), hipMemcpyHostToDevice, h.stream));
+      HIP_TRY(hipMemcpyAsync(subq[0].data(), &source, 4, hipMemcpyHostToDevice, h.stream));
+      h.sync();
+    }
+    char const* env_k = getenv("CUGRAPH_AMD_SSSP_SUBQ");  // sub-queues actually used (1 .. SSSP_K; 1 = the single near queue through the new kernels)
+    int const kk = env_k ? std::max(1, std::min(SSSP_K, atoi(env_k))) : SSSP_K;
+    double lower = 0.0, upper = delta;
+    auto inv_sub_of = [&]() { return (double)kk / (upper - lower); };
+    uint32_t qn_h[SSSP_K] = {1u, 0, 0, 0, 0, 0, 0, 0};
+    int32_t* same_nxt = qa.data();
+    int32_t* same_oth = qb.data();
+    int32_t* far_cur  = fa.data();
+    int32_t* far_nxt  = fb.data();
+    int32_t const* front = nullptr;
+    int64_t n_front = 0, n_far = 0;
+    uint32_t round = 0, window = 0, far_epoch = 1;
+    int j = 0;
+    auto state = [&](int jj) {
+      sssp_multi_state<WT> s;
+      s.dist = d; s.weights = w; s.done = done.data();
+      for (int k = 0; k < SSSP_K; ++k) s.q[k] = subq[k].data();
+      s.q_same = same_nxt; s.far = far_cur; s.mark = mark_near.data(); s.mark_far = mark_far.data(); s.cnt = cnt.data();
+      s.qn = &cnt.data()->padl0[0];  // the sub-queue fills live in the padding behind n_next: one read-back per round brings everything
+      s.lower = (WT)std::min(lower, (double)wmax); s.upper = (WT)std::min(upper, (double)wmax); s.inv_sub = (WT)inv_sub_of(); s.cutoff = cutoff;
+      s.j = jj; s.round_tag = round; s.sub_tag0 = 0x80000000u | (window << 4); s.far_epoch = far_epoch;
+      return s;
+    };
+    auto upload_counters = [&]() {
+      counters_t z{};
+      z.n_far = (uint32_t)n_far;
+      for (int k = 0; k < SSSP_K; ++k) z.padl0[k] = qn_h[k];
+      z.far_min_bits_lo = 0xFFFFFFFFu;
+      z.far_min_bits64  = ~0ull;
+      std::memcpy(h.pinned, &z, sizeof(z));
+      HIP_TRY(hipMemcpyAsync(cnt.data(), h.pinned, sizeof(z), hipMemcpyHostToDevice, h.stream));
+    };
+    auto download_counters = [&]() {
+      h.read_back(&c, cnt.data(), 1);
+      for (int k = 0; k < SSSP_K; ++k) { qn_h[k] = c.padl0[k]; CGA_EXPECTS((int64_t)qn_h[k] <= nv, CUGRAPH_UNKNOWN_ERROR, "sssp: sub-queue overflow"); }
+      c.fold();
+      n_far = c.n_far;
+      CGA_EXPECTS(n_far <= nv && (int64_t)c.n_next <= nv, CUGRAPH_UNKNOWN_ERROR, "sssp: queue overflow");
+    };
+    for (;;) {
+      if (n_front == 0) {
+        while (j < SSSP_K && qn_h[j] == 0) ++j;
+        if (j < SSSP_K) {  // drain the next non-empty sub-queue
+          front   = subq[j].data();
+          n_front = qn_h[j];
+          qn_h[j] = 0;
+        } else {
+          if (n_far == 0) break;
+          // the window is exhausted: advance it until the far pile yields near entries
+          lower = upper;
+          upper = upper + delta;
+          ++window;
+          ++far_epoch;
+          ++round;
+          int64_t const n_in = n_far;
+          n_far = 0;
+          upload_counters();
+          sssp_multi_state<WT> s = state(0);
+          s.far = far_nxt;  // (unused by the split: it appends the kept entries to its far_out argument)
+          hipLaunchKernelGGL(k_sssp_split_multi<WT>, grid_for(n_in, TV_BLOCK, 2048), TV_BLOCK, 0, h.stream, (int32_t const*)far_cur, n_in, s, far_nxt, far_epoch);
+          download_counters();
+          std::swap(far_cur, far_nxt);
+          j = 0;
+          bool any = false;
+          for (int k = 0; k < SSSP_K; ++k) any |= qn_h[k] != 0;
+          if (!any && n_far > 0) {  // empty windows: jump to the one holding the smallest far distance
+            double dmin;
+            if constexpr (sizeof(WT) == 4) { float f; uint32_t b = c.far_min_bits_lo; std::memcpy(&f, &b, 4); dmin = f; }
+            else { double f; unsigned long long b = c.far_min_bits64; std::memcpy(&f, &b, 8); dmin = f; }
+            double kq = std::floor(dmin / delta);
+            while (kq > 0.0 && kq * delta > dmin) kq -= 1.0;
+            if (kq * delta > upper) upper = kq * delta;  // the next advance opens [kq * delta, (kq + 1) * delta)
+          }
+          continue;
+        }
+      }
+      ++round;
+      ++steps;
+      upload_counters();
+      sssp_multi_state<WT> s = state(j);
+      {
+        timed_launch t(h, "sssp_relax");
+        hipLaunchKernelGGL(k_sssp_expand_multi<WT>, expand_grid(h, n_front), TV_BLOCK, 0, h.stream, front, n_front, row_beg, adj, bigq.data(), s, big_deg_for(h, n_front));
+        hipLaunchKernelGGL(k_sssp_expand_big_multi<WT>, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), row_beg, adj, s);
+      }
+      download_counters();
+      relaxed += c.edges;
+      front   = same_nxt;
+      n_front = c.n_next;
+      std::swap(same_nxt, same_oth);
+    }
+  } else {
   {  // d[source] = 0, near = {source}
     bits_t zero_bits = 0;
     HIP_TRY(hipMemcpyAsync(d + source, &zero_bits, sizeof(bits_t), hipMemcpyHostToDevice, h.stream));
@@ -943,8 +1271,6 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   int32_t* set_nxt = sb.data();
   uint32_t round = 0, far_epoch = 1, set_epoch = 1;
   double lower = 0.0, upper = delta;
-  uint64_t steps = 0, relaxed = 0;
-  counters_t c;
   // one relaxation round over the rows [beg[u], end[u]) of the vertices in `front`; near / far / bucket-member appends continue
   // at n_far / n_set_in (they persist across the rounds of a bucket), n_next / n_big / edges start from zero
   auto relax_round = [&](int32_t const* front, int64_t n_front, int32_t const* beg, int32_t const* end, int32_t* set_out, int64_t n_set_in) {
@@ -1018,6 +1344,8 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
         if (k * delta > upper) upper = k * delta;
       }
     }
+  }
+
   }
 
   if (compute_predecessors) {

@@ -366,6 +366,36 @@ def test_sssp_rmat_vs_oracle(cg, handle, orc, scale, kind, dtype):
     assert np.array_equal(dist, oc)
 
 
+@pytest.mark.parametrize("scale,kind,dtype,subq", [(12, "int", np.float32, 8), (14, "real", np.float32, 8), (16, "int", np.float32, 4), (14, "int", np.float64, 8),
+                                                   (13, "unit", np.float32, 2)])
+def test_sssp_subqueues_vs_oracle(cg, handle, orc, monkeypatch, scale, kind, dtype, subq):
+    """The opt-in distance-ordered sub-queue schedule of SSSP (CUGRAPH_AMD_SSSP_MODE=multi, round 3): same fixed point, so
+    distances bit-identical to Dijkstra and the canonical parents, for integer / real / unit weights, fp32 / fp64, with a cutoff."""
+    monkeypatch.setenv("CUGRAPH_AMD_SSSP_MODE", "multi")
+    monkeypatch.setenv("CUGRAPH_AMD_SSSP_SUBQ", str(subq))
+    s, d = rmat_graph(orc, scale)
+    nv = 1 << scale
+    if kind == "unit":
+        w = np.ones(s.size, dtype)
+    elif kind == "int":
+        w = int_weights(s.size).astype(dtype)
+    else:
+        w = np.random.default_rng(3).random(s.size).astype(dtype) + dtype(0.01)
+    g = make_graph(cg, handle, s, d, w, transposed=False, renumber=True, vertices=np.arange(nv), wdtype=dtype)
+    off, idx, ww = orc.coo_to_cs(nv, s, d, w)
+    src = int(np.nonzero(np.diff(off) > 0)[0][3])
+    v, dist, pred = cg.sssp(handle, g, src, float(np.finfo(dtype).max), True, False)
+    dist, pred = by_vertex(v, dist, pred)
+    od, _ = orc.sssp(nv, off, idx, ww, src)
+    assert np.array_equal(dist, od)
+    assert np.array_equal(pred, orc.sssp_min_pred(nv, off, idx, ww, src, od))
+    cut = float(np.median(od[od < np.finfo(dtype).max]))
+    v, dist, _ = cg.sssp(handle, g, src, cut, False, False)
+    (dist,) = by_vertex(v, dist)
+    oc, _ = orc.sssp(nv, off, idx, ww, src, cutoff=cut)
+    assert np.array_equal(dist, oc)
+
+
 @pytest.mark.parametrize("scale,kind,dtype,lh_scale", [(12, "int", np.float32, 0.25), (14, "int", np.float32, 0.25), (14, "int", np.float32, 0.05),
                                                        (14, "real", np.float32, 0.25), (14, "int", np.float64, 0.5), (14, "unit", np.float32, 0.25),
                                                        (16, "int", np.float32, 1.0)])
