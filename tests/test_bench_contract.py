@@ -36,13 +36,39 @@ def test_bench_line_contract():
     assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1
 
 
-def test_traffic_file_matches_profile_summary():
+def test_extras_carry_configs_3_and_5():
+    """Round 3: BASELINE configs 3 (BFS + SSSP at RMAT-24) and 5's graph size for one GPU (Louvain at RMAT-22) ride in the driver's line
+    as sub-objects of the same shape: value / unit, roofline (bound, achieved, peak, frac, traffic), check, cpu_baseline."""
+    d, name = latest_bench_line()
+    if "extra" not in d:  # lines of rounds 1-2
+        return
+    e = d["extra"]
+    for key in ("bfs", "sssp", "sssp_unit", "louvain"):
+        assert key in e, (name, key, [k for k in e if k.endswith("_error")])
+        x = e[key]
+        for f in ("value", "unit", "roofline", "check"):
+            assert f in x, (key, f)
+        r = x["roofline"]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+        assert x["check"]["ok"] is True
+    for key in ("bfs", "sssp", "louvain"):
+        c = e[key]["cpu_baseline"]
+        assert c["kind"] == "port" and c["cores"] >= 1 and "sample" in c
+    assert e["bfs"]["metric"] == "bfs_mteps_rmat24" and e["sssp"]["unit"] == "MTEPS" and e["louvain"]["unit"] == "s"
+    assert e["sssp_unit"].get("unit_weight_distances_equal_bfs") is True  # integer hops == BFS distances, bit for bit
+
+
+def test_traffic_file_matches_bench_line():
+    """profiles/traffic_latest.json (tools/traffic_collect.py): hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 per unit of work, keyed by
+    the hash of the kernels' sources; the committed bench line quotes exactly that figure (or null with a reason when the sources moved on)."""
     t = json.loads((ROOT / "profiles" / "traffic_latest.json").read_text())
-    src = t["source"].split(" ")[0]
-    assert (ROOT / src).exists(), src
-    p = t["per_iteration"]
-    total = 2 * (p["k_tiled_phase1"]["FETCH_SIZE_KB"] + p["k_tiled_phase2"]["FETCH_SIZE_KB"]) + p["k_tiled_phase1"]["WRITE_SIZE_KB"] + \
-        p["k_tiled_phase2"]["WRITE_SIZE_KB"]
-    assert abs(t["hbm_bytes_per_launch"] - total * 1000) <= 1000
+    assert "source_hash" in t and "entries" in t
+    pr = t["entries"]["pagerank_s26"]
+    assert abs(pr["hbm_bytes"] - (2 * pr["fetch_kib"] + pr["write_kib"]) * 1024) <= 2048
     d, _ = latest_bench_line()
-    assert d["roofline"]["traffic"] == t["hbm_bytes_per_launch"]
+    r = d["roofline"]
+    if r["traffic"] is not None:
+        assert r["traffic"] == pr["hbm_bytes"] and "same source hash" in r["traffic_source"]
+        assert r["traffic"] >= r["algorithmic_bytes_per_launch"]
+    else:
+        assert "STALE" in r["traffic_source"] or "absent" in r["traffic_source"] or "no entry" in r["traffic_source"]

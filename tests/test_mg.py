@@ -94,9 +94,10 @@ def test_exchange_plan_is_sparse_and_consistent(tmp_path):
         dist.destroy_process_group()
 
 
-def test_a2a_rounds_match_one_shot(tmp_path, monkeypatch):
-    """_a2a cuts messages above its per-round limit into rounds (a single multi-GB message came back truncated on the GPU box):
-    with a tiny limit the result must equal the one-shot exchange; one rank needs no collective."""
+def test_a2a_single_rank_needs_no_collective(tmp_path):
+    """One rank: _a2a returns a copy without touching the process group (the one-rank all_to_all_single of an 8.6 GB message came back
+    truncated on the GPU box).  The multi-round path -- messages cut at _A2A_MAX_BYTES -- runs with three ranks and a 64-byte limit in
+    test_mg_pagerank_gloo_cpu[3-oracle_rounds] below, and directly in test_a2a_rounds_two_ranks."""
     import torch
     import torch.distributed as dist
 
@@ -106,9 +107,36 @@ def test_a2a_rounds_match_one_shot(tmp_path, monkeypatch):
         dist.init_process_group("gloo", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1)
     try:
         t = torch.arange(1000, dtype=torch.int64)
-        assert torch.equal(mg._a2a(t, [1000], [1000], None), t)
+        out = mg._a2a(t, [1000], [1000], None)
+        assert torch.equal(out, t) and out.data_ptr() != t.data_ptr()
     finally:
         dist.destroy_process_group()
+
+
+def test_a2a_rounds_two_ranks(tmp_path):
+    """_a2a with a 40-byte round limit between two gloo ranks: ragged messages (one of them empty) arrive whole and in order."""
+    script = tmp_path / "a2a_worker.py"
+    script.write_text(f"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {str(ROOT)!r})
+from cugraph_amd import mg
+dist.init_process_group("gloo")
+r = dist.get_rank()
+mg._A2A_MAX_BYTES = 40                                   # 5 int64 per message and round
+send_counts = [[0, 23], [17, 4]][r]                      # rank 0 sends nothing to itself, 23 to rank 1; rank 1 sends 17 / 4
+recv_counts = [[0, 17], [23, 4]][r]
+t = torch.arange(sum(send_counts), dtype=torch.int64) + 1000 * r
+out = mg._a2a(t, send_counts, recv_counts, None)
+expect = [torch.arange(0, 17) + 1000, torch.cat([torch.arange(0, 23), torch.arange(17, 21) + 1000])][r]
+assert torch.equal(out, expect), (r, out.tolist())
+dist.barrier()
+""")
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-2000:]
 
 
 @pytest.mark.parametrize("world,mode", [(2, "oracle"), (4, "oracle"), (8, "oracle"), (2, "oraclew"), (3, "oracle_rounds")])
