@@ -21,6 +21,7 @@ CPU engine built on the oracle into the same orchestration to exercise partition
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import time
@@ -129,6 +130,38 @@ def unique_inverse(x: torch.Tensor):
     inverse = torch.empty(n, dtype=torch.int64, device=x.device)
     inverse[vals.to(torch.int64)] = rank
     return uniq, inverse
+
+
+def _share_stream(handle, dev):
+    """A stream of torch's that the library borrows (cugraph_amd_handle_set_stream): the collectives of an iteration are ordered on
+    torch's CURRENT stream, so stepping runs with this stream current (on_engine_stream) and the kernels that consume / produce the
+    exchange buffers need no host synchronisation.  Never torch's default stream: its handle is the null stream, which
+    cugraph_amd_handle_set_stream reads as "back to the handle's own stream" (the library would then race the collectives)."""
+    s = torch.cuda.Stream(device=dev)
+    assert s.cuda_stream != 0
+    s.wait_stream(torch.cuda.current_stream())
+    handle.set_stream(s.cuda_stream)
+    return s
+
+
+@contextlib.contextmanager
+def on_engine_stream(engine):
+    """Makes the engine's borrowed stream torch's current one (ordered behind / ahead of the caller's stream at entry / exit)."""
+    s = getattr(engine, "stream", None)
+    if s is None:
+        yield
+        return
+    outer = torch.cuda.current_stream()
+    s.wait_stream(outer)
+    with torch.cuda.stream(s):
+        yield
+    outer.wait_stream(s)
+
+
+def _order_engine_stream_behind_caller(engine):
+    s = getattr(engine, "stream", None)
+    if s is not None:
+        s.wait_stream(torch.cuda.current_stream())
 
 
 # ------------------------------------------------------------------------------------------ partition
@@ -323,8 +356,7 @@ class HipLocalEngine(LocalEngine):
         # from here on the library works on torch's current stream, the one the collectives are ordered on: the exchange and
         # the kernels that consume / produce its buffers need no host synchronisation between them
         self.shared_stream = os.environ.get("CUGRAPH_AMD_MG_OWN_STREAM") != "1"
-        if self.shared_stream:
-            self.handle.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.stream = _share_stream(self.handle, dev) if self.shared_stream else None
 
     def _call(self, name, *args):
         err = C.c_void_p()
@@ -389,7 +421,8 @@ class MGPageRank:
         factory = engine_factory or HipLocalEngine
         self.engine = factory(part, ex, local_dst, w, outw_local, alpha, init_local)
         self.iterations = 0
-        self.engine.start()
+        with on_engine_stream(self.engine):
+            self.engine.start()
 
     def _exchange(self):
         e, ex = self.engine, self.ex
@@ -406,23 +439,25 @@ class MGPageRank:
     def step(self, n_iterations, epsilon=0.0):
         """Runs up to n_iterations power iterations; stops when the global L1 change drops below epsilon
         (pagerank_impl.cuh:320-326).  Returns (iterations_done, converged)."""
-        done = 0
-        while done < n_iterations:
-            self._exchange()
-            diff, _ = self.engine.reduce_scalars(epsilon > 0.0)
-            if epsilon > 0.0 and self.iterations > 0 and diff < epsilon:
-                return done, True
-            self.engine.local_step()
-            self.iterations += 1
-            done += 1
-        if epsilon > 0.0:  # did the last allowed iteration converge?
-            self._exchange()
-            diff, _ = self.engine.reduce_scalars(True)
-            return done, diff < epsilon
-        return done, False
+        with on_engine_stream(self.engine):
+            done = 0
+            while done < n_iterations:
+                self._exchange()
+                diff, _ = self.engine.reduce_scalars(epsilon > 0.0)
+                if epsilon > 0.0 and self.iterations > 0 and diff < epsilon:
+                    return done, True
+                self.engine.local_step()
+                self.iterations += 1
+                done += 1
+            if epsilon > 0.0:  # did the last allowed iteration converge?
+                self._exchange()
+                diff, _ = self.engine.reduce_scalars(True)
+                return done, diff < epsilon
+            return done, False
 
     def result(self):
         """(external vertex ids, pagerank values) of the vertices this rank owns."""
+        _order_engine_stream_behind_caller(self.engine)  # the result tensor belongs to the caller's stream; the library fills it (blocking)
         return self.part.local_vertices, self.engine.values()
 
 
@@ -546,8 +581,7 @@ class HipLocalEngine2D(LocalEngine2D):
         assert_success(code, err, "cugraph_amd_pagerank_mg2d_plan_create")
         self.plan = plan
         self.shared_stream = os.environ.get("CUGRAPH_AMD_MG_OWN_STREAM") != "1"
-        if self.shared_stream:
-            self.handle.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.stream = _share_stream(self.handle, dev) if self.shared_stream else None
 
     def _call(self, name, *args):
         err = C.c_void_p()
@@ -623,7 +657,8 @@ class MGPageRank2D:
         factory = engine_factory or HipLocalEngine2D
         self.engine = factory(part, lcol, lrow, w, outw_own, alpha, init_own)
         self.iterations = 0
-        self.engine.start()
+        with on_engine_stream(self.engine):
+            self.engine.start()
         self.bytes_per_iteration = {"all_gather_in": (part.R - 1) * part.L * self.engine.x_own.element_size(),
                                     "reduce_scatter_out": (part.C - 1) * part.L * self.engine.x_own.element_size()}
 
@@ -667,25 +702,27 @@ class MGPageRank2D:
             torch.cuda.current_stream().synchronize()  # the library computes on its own HIP stream
 
     def step(self, n_iterations, epsilon=0.0):
-        done = 0
-        while done < n_iterations:
-            diff, _ = self._gather_scalars(epsilon > 0.0)
-            if epsilon > 0.0 and self.iterations > 0 and diff < epsilon:
-                return done, True
-            self._gather_x()
-            self._sync_for_library()
-            self.engine.spmv()
-            self._reduce_y()
-            self._sync_for_library()
-            self.engine.epilogue()
-            self.iterations += 1
-            done += 1
-        if epsilon > 0.0:
-            diff, _ = self._gather_scalars(True)
-            return done, diff < epsilon
-        return done, False
+        with on_engine_stream(self.engine):
+            done = 0
+            while done < n_iterations:
+                diff, _ = self._gather_scalars(epsilon > 0.0)
+                if epsilon > 0.0 and self.iterations > 0 and diff < epsilon:
+                    return done, True
+                self._gather_x()
+                self._sync_for_library()
+                self.engine.spmv()
+                self._reduce_y()
+                self._sync_for_library()
+                self.engine.epilogue()
+                self.iterations += 1
+                done += 1
+            if epsilon > 0.0:
+                diff, _ = self._gather_scalars(True)
+                return done, diff < epsilon
+            return done, False
 
     def result(self):
+        _order_engine_stream_behind_caller(self.engine)  # the result tensor belongs to the caller's stream; the library fills it (blocking)
         return self.part.local_vertices, self.engine.values()
 
 
@@ -761,14 +798,15 @@ def bench_main(args):
     else:
         phases = (("exchange", pr._exchange), ("reduce_scalars", lambda: pr.engine.reduce_scalars(False)), ("local_step", pr.engine.local_step))
     split = torch.zeros(len(phases), dtype=torch.float64)
-    for _ in range(3):
-        for k, (_, fn) in enumerate(phases):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            fn()
-            torch.cuda.synchronize()
-            split[k] += (time.perf_counter() - t1) / 3
-        pr.iterations += 1
+    with on_engine_stream(pr.engine):
+        for _ in range(3):
+            for k, (_, fn) in enumerate(phases):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                split[k] += (time.perf_counter() - t1) / 3
+            pr.iterations += 1
     split = split if single else split.cuda()
     dist.all_reduce(split, op=dist.ReduceOp.MAX)
     split = split.cpu().tolist()

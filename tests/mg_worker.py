@@ -135,11 +135,32 @@ class OracleEngine2D(mg.LocalEngine2D):
         return torch.from_numpy(self.pr[: self.part.n_rows].copy())
 
 
+def _delay_collectives():
+    """Every data collective starts ~10 ms late on the stream it is issued from (a spin kernel in front of it): a consumer that is not
+    ordered behind the collective -- the library computing on a stream of its own without a synchronisation -- then reads the previous
+    iteration's buffer, every time instead of once in a few runs."""
+    def late(fn):
+        def call(*a, **k):
+            torch.cuda._sleep(20_000_000)
+            return fn(*a, **k)
+        return call
+
+    for name in ("all_to_all_single", "all_gather_into_tensor", "reduce_scatter_tensor"):
+        setattr(dist, name, late(getattr(dist, name)))
+
+
 def main():
     mode, scale, out_dir = sys.argv[1], int(sys.argv[2]), Path(sys.argv[3])
     eps, max_iter = float(sys.argv[4]), int(sys.argv[5])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nccl = mode.endswith("_nccl")  # RCCL with device tensors (one rank per GPU; world 1 on the one-GPU box), every collective delayed
+    if nccl:
+        mode = mode[: -len("_nccl")]
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        _delay_collectives()
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     nv, ne = 1 << scale, 16 << scale
     per = (ne + world - 1) // world
     s, d = orc.rmat(scale, min(per, ne - rank * per), first_edge=rank * per)
@@ -153,12 +174,13 @@ def main():
     factory = (OracleEngine2D if two_d else OracleEngine) if mode.startswith("oracle") else None
     if factory is None:
         torch.cuda.set_device(0)
+    ts, td = torch.from_numpy(s), torch.from_numpy(d)
+    if nccl:
+        ts, td, w = ts.cuda(), td.cuda(), (None if w is None else w.cuda())
     if two_d:
-        v, x, iters, conv = mg.pagerank_2d(torch.from_numpy(s), torch.from_numpy(d), nv, weights=w, alpha=0.85, epsilon=eps, max_iterations=max_iter,
-                                           engine_factory=factory)
+        v, x, iters, conv = mg.pagerank_2d(ts, td, nv, weights=w, alpha=0.85, epsilon=eps, max_iterations=max_iter, engine_factory=factory)
     else:
-        v, x, iters, conv = mg.pagerank(torch.from_numpy(s), torch.from_numpy(d), nv, weights=w, alpha=0.85, epsilon=eps, max_iterations=max_iter,
-                                        engine_factory=factory)
+        v, x, iters, conv = mg.pagerank(ts, td, nv, weights=w, alpha=0.85, epsilon=eps, max_iterations=max_iter, engine_factory=factory)
     np.savez(out_dir / f"rank{rank}.npz", v=v.cpu().numpy(), x=x.cpu().numpy(), iters=iters, conv=conv)
     dist.barrier()
     dist.destroy_process_group()

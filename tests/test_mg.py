@@ -231,6 +231,20 @@ def test_mg_pagerank_2d_hip_engine(orc, tmp_path, world, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["hip_nccl", "hip2d_nccl", "hipw_nccl"])
+def test_mg_pagerank_rccl_one_rank_with_late_collectives(orc, tmp_path, mode):
+    """One rank over RCCL with device tensors (the configuration bench.py --gpus N runs per GPU): the library borrows a stream of torch's
+    and the iteration has no host synchronisation, so every kernel must be ordered behind the collective that feeds it.  The worker
+    delays each collective by ~10 ms; round 3 found the engines borrowing torch's DEFAULT stream, whose null handle the library reads
+    as 'use your own stream' -- results then were wrong in one run out of a few (mass off by up to 17 % at RMAT-22)."""
+    scale = 14
+    pr, iters, conv = run_world(mode, 1, scale, tmp_path, eps=0.0, max_iter=12)
+    t, _, _ = truth(orc, scale, 0.0, 12, weighted=mode.startswith("hipw") or mode.startswith("hip2dw"))
+    assert np.max(np.abs(pr - t)) <= 1e-6
+    assert np.max(np.abs(pr - t) / t) <= 2e-5
+
+
+@pytest.mark.gpu
 def test_mg_pagerank_hip_engine_convergence(orc, tmp_path):
     pr, iters, conv = run_world("hip", 2, 11, tmp_path, eps=1e-5, max_iter=200)
     t, it, tconv = truth(orc, 11, 1e-5, 200)
