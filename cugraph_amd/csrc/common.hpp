@@ -335,6 +335,7 @@ struct graph_t {  // behind cugraph_graph_t (cpp/src/c_api/graph.hpp:61-77)
   bool out_weight_sums_valid{false};
   double weight_sum{0};  // sum of the edge weights (SSSP bucket width), cached
   bool weight_sum_valid{false};
+  int64_t sssp_heavy_cut{-1};  // SSSP (radix sub-queues): ids below this have at least average out-degree (ids are degree-sorted); -1 = not counted yet
   int bfs_calls{0};  // the CSC (bottom-up BFS levels) is built from the second traversal of a non-symmetric graph on
 };
 

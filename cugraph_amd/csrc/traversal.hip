@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand(int32_t const* q, int64
   __shared__ wave_queue_storage<1> wqs;
   wqs.init();
   bfs_visit f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next)};
-  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f, big_deg);
+  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f, big_deg);  // (EX_U edges in flight per lane, as SSSP does: no gain here)
   f.flush();
 }
 __global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, bfs_state s)
@@ -443,6 +443,41 @@ struct sssp_relax {
     wq_far.push(far, v);
     if (s.q_set) wq_set.push(fresh, v);  // (wave-uniform condition)
   }
+  // the phased form of the same relaxation (expand_*_mlp: EX_U edges in flight per lane)
+  struct cand_t { WT nd; bool pass; };
+  using tok_t = typename dist_bits<WT>::type;
+  __device__ __forceinline__ cand_t pre(int32_t u, int32_t v, eoff_t p) const
+  {  // branch-free: the loads of the EX_U edges of a step go out together.  d[v] is read with an agent-scope load: L2-served, so once a
+     // hub has been lowered the other relaxations of this round see it and skip the atomic (a non-temporal load is L2-served too, but
+     // its lines are not retained: 14.0 ms instead of 10.4 per SSSP at RMAT-24)
+    using B = dist_bits<WT>;
+    WT const nd = B::from(s.dist[u < 0 ? 0 : u]) + s.weights[p];
+    WT const dv = B::from(__hip_atomic_load(&s.dist[v < 0 ? 0 : v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    bool const pass = (v >= 0) & (nd < s.cutoff) & (nd < dv);
+    return cand_t{nd, pass};
+  }
+  __device__ __forceinline__ tok_t mid(int32_t v, cand_t c) const
+  {
+    using B = dist_bits<WT>;
+    return c.pass ? atomicMin(&s.dist[v], B::to(c.nd)) : (tok_t)0;
+  }
+  using tok2_t = uint32_t;
+  __device__ __forceinline__ tok2_t mid2(int32_t v, cand_t c, tok_t old) const
+  {  // the relaxation lowered d[v]: claim the vertex for this round's near queue / this epoch's far pile
+    using B = dist_bits<WT>;
+    if (!(c.pass && B::to(c.nd) < old)) return 0u;
+    bool const won = c.nd < s.threshold ? atomicExch(&s.mark_near[v], s.round) != s.round : atomicExch(&s.mark_far[v], s.far_epoch) != s.far_epoch;
+    return won ? (c.nd < s.threshold ? 1u : 2u) : 0u;
+  }
+  __device__ __forceinline__ void post(int32_t, int32_t v, cand_t, tok_t, tok2_t won)
+  {
+    bool const near = won == 1u, far = won == 2u;
+    bool fresh = false;
+    if (s.q_set && near) fresh = atomicExch(&s.mark_set[v], s.set_epoch) != s.set_epoch;
+    wq_near.push(near, v);
+    wq_far.push(far, v);
+    if (s.q_set) wq_set.push(fresh, v);
+  }
 };
 
 template <typename WT>
@@ -452,7 +487,11 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand(int32_t const* q, int6
   __shared__ wave_queue_storage<3> wqs;
   wqs.init();
   sssp_relax<WT> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far), wave_queue(wqs, 2, s.q_set, &s.cnt->n_set)};
+#ifdef CGA_SSSP_NO_MLP
   expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f, big_deg, row_end);
+#else
+  expand_frontier_mlp(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f, big_deg, row_end);
+#endif
   f.flush();
 }
 template <typename WT>
@@ -462,7 +501,11 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_big(int32_t const* big
   __shared__ wave_queue_storage<3> wqs;
   wqs.init();
   sssp_relax<WT> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far), wave_queue(wqs, 2, s.q_set, &s.cnt->n_set)};
+#ifdef CGA_SSSP_NO_MLP
   expand_big(bigq, offsets, indices, s.cnt, f, row_end);
+#else
+  expand_big_mlp(bigq, offsets, indices, s.cnt, f, row_end);
+#endif
   f.flush();
 }
 
@@ -518,7 +561,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split(int32_t const* far_in, 
 // pile is rescanned between sub-queues (that is what made a narrower delta slower in round 2), stale entries are dropped when they
 // are popped: an entry is expanded iff the vertex's CURRENT distance falls into the sub-queue being drained and it has not been
 // expanded at that distance (done[v]).  Distances are the same fixed point as before (bit-identical to Dijkstra).
-constexpr int SSSP_K = 8;
+constexpr int SSSP_K = 12;
 template <typename WT>
 struct sssp_multi_state {
   using bits_t = typename dist_bits<WT>::type;
@@ -532,25 +575,37 @@ struct sssp_multi_state {
   uint32_t* mark_far;
   counters_t* cnt;              // n_next = entries of q_same, n_far = far pile, edges = relaxations
   uint32_t* qn;                 // [SSSP_K] fill of the sub-queues (persist across the rounds of a window)
-  WT lower, upper, inv_sub, cutoff;
+  uint32_t* qh;                 // [SSSP_K] how many of those entries are vertices below heavy_cut (ids are degree-sorted: the bucket's work)
+  WT lower;                     // distances below are settled
+  WT ub[SSSP_K];                // absolute, non-decreasing upper bounds: sub-queue k holds [k ? ub[k - 1] : lower, ub[k]); ub[SSSP_K - 1] = the window's end
+  WT cutoff;
+  int32_t heavy_cut;
+  __host__ __device__ WT upper() const { return ub[SSSP_K - 1]; }
   int j;
-  uint32_t round_tag, sub_tag0, far_epoch;  // tag of an insertion into q_same / base tag of the window's sub-queues (+ k)
+  uint32_t round_tag, far_epoch;  // tag of an insertion into q_same (one per round) / epoch of the far pile
+  uint32_t tag[SSSP_K];           // tag of an insertion into sub-queue k: one per INCARNATION of the sub-queue (a new one whenever its range is
+                                  // redefined), so a vertex enters an incarnation at most once and a queue never holds more than V entries
 };
 template <typename WT>
-__device__ __forceinline__ int sssp_sub_of(WT d, WT lower, WT inv_sub)
-{
-  WT const x = (d - lower) * inv_sub;
-  int k      = x > WT(0) ? (int)x : 0;
-  return k < SSSP_K - 1 ? k : SSSP_K - 1;
+__device__ __forceinline__ int sssp_sub_of(WT d, sssp_multi_state<WT> const& s)
+{  // first k with d < ub[k] (callers have checked d < ub[SSSP_K - 1])
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < SSSP_K - 1; ++i) k += d >= s.ub[i] ? 1 : 0;
+  return k;
 }
 // per-wavefront LDS staging for SSSP_K + 2 output queues (the wave_queue scheme with the queue picked per call, wave-uniform)
 struct multi_queue_storage {
-  int32_t buf[SSSP_K + 2][TV_WAVES][WQ_CAP / 2];
+  int32_t buf[SSSP_K + 2][TV_WAVES][WQ_CAP / 4];
   uint32_t fill[SSSP_K + 2][TV_WAVES];
+  uint32_t heavy[SSSP_K][TV_WAVES];  // staged entries below heavy_cut, per sub-queue
   int32_t* q[SSSP_K + 2];
   uint32_t* counter[SSSP_K + 2];
+  uint32_t* hcounter[SSSP_K];
+  uint32_t tag[SSSP_K];
+  int32_t heavy_cut;
 };
-constexpr int MQ_CAP = WQ_CAP / 2;
+constexpr int MQ_CAP = WQ_CAP / 4;
 __device__ __forceinline__ void mq_push(multi_queue_storage& st, int k, bool flag, int32_t value)
 {  // k wave-uniform
   uint64_t const m = __ballot(flag);
@@ -562,6 +617,10 @@ __device__ __forceinline__ void mq_push(multi_queue_storage& st, int k, bool fla
   int const leader     = __ffsll((unsigned long long)m) - 1;
   uint32_t const rank  = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
   uint32_t base        = 0;
+  if (k < SSSP_K) {  // (k is wave-uniform)
+    uint32_t const hc = (uint32_t)__popcll(__ballot(flag && value < st.heavy_cut));
+    if (lane == leader && hc) st.heavy[k][wave] += hc;  // this wavefront's own word
+  }
   if (lane == leader) base = atomicAdd(fill, c);
   base = __shfl(base, leader);
   if (base + c <= (uint32_t)MQ_CAP) {
@@ -581,6 +640,10 @@ __device__ __forceinline__ void mq_flush(multi_queue_storage& st)
 {
   __builtin_amdgcn_wave_barrier();
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < SSSP_K) {
+    uint32_t const hc = st.heavy[lane][wave];
+    if (hc) { atomicAdd(st.hcounter[lane], hc); st.heavy[lane][wave] = 0; }
+  }
   for (int k = 0; k < SSSP_K + 2; ++k) {
     uint32_t const n = st.fill[k][wave];
     if (n == 0) continue;
@@ -597,7 +660,22 @@ template <typename WT>
 __device__ __forceinline__ void mq_init(multi_queue_storage& st, sssp_multi_state<WT> const& s)
 {
   if (threadIdx.x < (SSSP_K + 2) * TV_WAVES) (&st.fill[0][0])[threadIdx.x] = 0;
-  if (threadIdx.x < SSSP_K) { st.q[threadIdx.x] = s.q[threadIdx.x]; st.counter[threadIdx.x] = &s.qn[threadIdx.x]; }
+  if (threadIdx.x < SSSP_K * TV_WAVES) (&st.heavy[0][0])[threadIdx.x] = 0;
+  if (threadIdx.x == 0) st.heavy_cut = s.heavy_cut;
+  if (threadIdx.x < SSSP_K) { st.q[threadIdx.x] = s.q[threadIdx.x]; st.counter[threadIdx.x] = &s.qn[threadIdx.x]; st.hcounter[threadIdx.x] = &s.qh[threadIdx.x]; st.tag[threadIdx.x] = s.tag[threadIdx.x]; }
+  if (threadIdx.x == SSSP_K) { st.q[SSSP_K] = s.q_same; st.counter[SSSP_K] = &s.cnt->n_next; }
+  if (threadIdx.x == SSSP_K + 1) { st.q[SSSP_K + 1] = s.far; st.counter[SSSP_K + 1] = &s.cnt->n_far; }
+  __syncthreads();
+}
+// (the sub-queue pointers are read from `src` -- the kernel-argument copy when `s` is a modified local one: a runtime-indexed read of a
+// local struct would go through scratch memory)
+template <typename WT>
+__device__ __forceinline__ void mq_init_from(multi_queue_storage& st, sssp_multi_state<WT> const& src, sssp_multi_state<WT> const& s)
+{
+  if (threadIdx.x < (SSSP_K + 2) * TV_WAVES) (&st.fill[0][0])[threadIdx.x] = 0;
+  if (threadIdx.x < SSSP_K * TV_WAVES) (&st.heavy[0][0])[threadIdx.x] = 0;
+  if (threadIdx.x == 0) st.heavy_cut = s.heavy_cut;
+  if (threadIdx.x < SSSP_K) { st.q[threadIdx.x] = src.q[threadIdx.x]; st.counter[threadIdx.x] = &src.qn[threadIdx.x]; st.hcounter[threadIdx.x] = &src.qh[threadIdx.x]; st.tag[threadIdx.x] = src.tag[threadIdx.x]; }
   if (threadIdx.x == SSSP_K) { st.q[SSSP_K] = s.q_same; st.counter[SSSP_K] = &s.cnt->n_next; }
   if (threadIdx.x == SSSP_K + 1) { st.q[SSSP_K + 1] = s.far; st.counter[SSSP_K + 1] = &s.cnt->n_far; }
   __syncthreads();
@@ -615,10 +693,10 @@ struct sssp_relax_multi {
     if (nd < s.cutoff && nd < B::from(__hip_atomic_load(&s.dist[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
       auto old = atomicMin(&s.dist[v], B::to(nd));
       if (B::to(nd) < old) {
-        if (nd < s.upper) {
-          k = sssp_sub_of<WT>(nd, s.lower, s.inv_sub);
+        if (nd < s.upper()) {
+          k = sssp_sub_of<WT>(nd, s);
           if (k < s.j) k = s.j;  // (cannot happen for a monotone sub_of; keeps the queue order safe)
-          uint32_t const tag = k == s.j ? s.round_tag : s.sub_tag0 + (uint32_t)k;
+          uint32_t const tag = k == s.j ? s.round_tag : st->tag[k];
           near = atomicExch(&s.mark[v], tag) != tag;
         } else {
           far = atomicExch(&s.mark_far[v], s.far_epoch) != s.far_epoch;
@@ -641,17 +719,25 @@ template <typename WT>
 struct sssp_pop {
   typename dist_bits<WT>::type const* dist;
   typename dist_bits<WT>::type* done;
-  WT lower, upper, inv_sub;
-  int j;
+  WT lb, ub;  // the range of the sub-queue being drained
   __device__ __forceinline__ bool operator()(int32_t u) const
   {
     using B = dist_bits<WT>;
     auto const b = dist[u];
     WT const d   = B::from(b);
-    if (!(d >= lower && d < upper) || sssp_sub_of<WT>(d, lower, inv_sub) != j) return false;
+    if (!(d >= lb && d < ub)) return false;
     return atomicExch(&done[u], b) != b;
   }
 };
+template <typename WT>
+__device__ __forceinline__ sssp_pop<WT> sssp_pop_of(sssp_multi_state<WT> const& s)
+{
+  WT lb = s.lower, ub = s.ub[0];
+#pragma unroll
+  for (int k = 1; k < SSSP_K; ++k)
+    if (k == s.j) { lb = s.ub[k - 1]; ub = s.ub[k]; }
+  return sssp_pop<WT>{s.dist, s.done, lb, ub};
+}
 template <typename WT>
 __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_multi(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices, int32_t* bigq,
                                                                 sssp_multi_state<WT> s, int32_t big_deg)
@@ -659,7 +745,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_multi(int32_t const* q
   __shared__ multi_queue_storage st;
   mq_init<WT>(st, s);
   sssp_relax_multi<WT> f{s, &st};
-  sssp_pop<WT> keep{s.dist, s.done, s.lower, s.upper, s.inv_sub, s.j};
+  sssp_pop<WT> keep = sssp_pop_of<WT>(s);
   expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep, f, big_deg);
   mq_flush(st);
 }
@@ -672,6 +758,117 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_big_multi(int32_t cons
   expand_big(bigq, offsets, indices, s.cnt, f);
   mq_flush(st);
 }
+// ---- device-driven rounds (CUGRAPH_AMD_SSSP_MODE=dev): the host enqueues a BATCH of rounds -- expand, deferred rows, control -- and
+// synchronises once per batch; which queue a round drains, how long it is and its dedup tag come from a control block in device
+// memory that a one-wavefront control kernel advances after every round (next round of the same sub-queue while it yields entries,
+// then the next non-empty sub-queue; `done` once the window is exhausted: the remaining kernels of the batch return at once).  A
+// host-driven round costs ~100 us of launches, counter upload and read-back whatever it relaxes; here it costs three back-to-back
+// launches.  The control block lives in the padding of counters_t (the n_set line, unused by this path): one read-back brings
+// the cursors and the control state.
+struct sssp_ctl_t {
+  unsigned long long relaxed;  // edges inspected by the rounds of this batch sequence
+  uint32_t done;
+  uint32_t j;              // sub-queue being drained
+  uint32_t n_front;        // entries of the current frontier
+  uint32_t front_is_same;  // 0: the frontier is sub-queue j itself, 1: q_same[cur] (a later round of sub-queue j)
+  uint32_t cur;
+  uint32_t round;          // dedup tag of the running round
+  uint32_t rounds;         // rounds run
+};
+static_assert(sizeof(sssp_ctl_t) <= 14 * 4, "sssp_ctl_t lives in counters_t::padl2[1..14]");
+__host__ __device__ inline sssp_ctl_t* sssp_ctl_of(counters_t* cnt) { return reinterpret_cast<sssp_ctl_t*>(&cnt->padl2[1]); }
+
+template <typename WT>
+struct sssp_dev_args {
+  sssp_multi_state<WT> s;  // the fields of the window; j / round_tag / q_same are taken from the control block by every kernel
+  int32_t* qsame[2];
+  int32_t narrow_limit;    // frontiers shorter than this defer every row a wavefront would walk alone (big_deg_for)
+  int kk;                  // sub-queues in use
+};
+template <typename WT>
+__device__ __forceinline__ bool sssp_dev_round(sssp_dev_args<WT> const& a, sssp_multi_state<WT>& s, int32_t const*& front, int64_t& n)
+{
+  sssp_ctl_t const c = *sssp_ctl_of(a.s.cnt);
+  if (c.done) return false;
+  s           = a.s;
+  s.j         = (int)c.j;
+  s.round_tag = c.round;
+  s.q_same    = a.qsame[(c.cur ^ 1u) & 1u];
+  int32_t const* f = a.qsame[c.cur & 1u];
+  if (!c.front_is_same) {
+#pragma unroll
+    for (int k = 0; k < SSSP_K; ++k)
+      if (k == (int)c.j) f = a.s.q[k];
+  }
+  front = f;
+  n     = (int64_t)c.n_front;
+  return true;
+}
+template <typename WT>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_dev(int32_t const* offsets, int32_t const* indices, int32_t* bigq, sssp_dev_args<WT> a)
+{
+  __shared__ multi_queue_storage st;
+  sssp_multi_state<WT> s;
+  int32_t const* front;
+  int64_t n;
+  if (!sssp_dev_round<WT>(a, s, front, n)) return;
+  mq_init_from<WT>(st, a.s, s);
+  sssp_relax_multi<WT> f{s, &st};
+  sssp_pop<WT> keep = sssp_pop_of<WT>(s);
+  expand_frontier(front, n, offsets, indices, bigq, s.cnt, keep, f, n < (int64_t)a.narrow_limit ? BIG_DEG_NARROW : BIG_DEG);
+  mq_flush(st);
+}
+template <typename WT>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_big_dev(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, sssp_dev_args<WT> a)
+{
+  __shared__ multi_queue_storage st;
+  sssp_multi_state<WT> s;
+  int32_t const* front;
+  int64_t n;
+  if (!sssp_dev_round<WT>(a, s, front, n)) return;
+  if (s.cnt->n_big == 0) return;
+  mq_init_from<WT>(st, a.s, s);
+  sssp_relax_multi<WT> f{s, &st};
+  expand_big(bigq, offsets, indices, s.cnt, f);
+  mq_flush(st);
+}
+// one wavefront, after the two kernels of a round
+__global__ void k_sssp_ctl(counters_t* cnt, int kk)
+{
+  sssp_ctl_t* const ctl = sssp_ctl_of(cnt);
+  if (ctl->done) return;
+  int const lane = threadIdx.x & 63;
+  unsigned long long e = 0;
+  if (lane < CNT_REPLICAS) { e = cnt->rep[lane].edges; cnt->rep[lane].edges = 0; }
+  for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+  if (lane != 0) return;
+  sssp_ctl_t c = *ctl;
+  c.relaxed += e + cnt->edges;
+  cnt->edges = 0;
+  c.rounds += 1;
+  c.round += 1;
+  uint32_t const n_next = cnt->n_next;
+  cnt->n_next = 0;
+  cnt->n_big  = 0;
+  if (n_next > 0) {
+    c.front_is_same = 1;
+    c.cur ^= 1u;
+    c.n_front = n_next;
+  } else {
+    uint32_t j = c.j + 1;  // sub-queue c.j is exhausted (entries for it went to q_same while it was drained)
+    while (j < (uint32_t)kk && cnt->padl0[j] == 0) ++j;
+    if (j >= (uint32_t)kk) {
+      c.done = 1;
+    } else {
+      c.j             = j;
+      c.front_is_same = 0;
+      c.n_front       = cnt->padl0[j];
+      cnt->padl0[j]   = 0;
+    }
+  }
+  *ctl = c;
+}
+
 // far pile -> the sub-queues of the new window [lower, upper) | far pile'
 template <typename WT>
 __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split_multi(int32_t const* far_in, int64_t n, sssp_multi_state<WT> s, int32_t* far_out, uint32_t new_epoch)
@@ -694,9 +891,9 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split_multi(int32_t const* fa
       v    = far_in[i];
       WT d = B::from(s.dist[v]);
       if (d >= s.lower) {
-        if (d < s.upper) {
-          k = sssp_sub_of<WT>(d, s.lower, s.inv_sub);
-          uint32_t const tag = s.sub_tag0 + (uint32_t)k;
+        if (d < s.upper()) {
+          k = sssp_sub_of<WT>(d, s);
+          uint32_t const tag = st.tag[k];
           near = atomicExch(&s.mark[v], tag) != tag;
         } else {
           keep = atomicExch(&s.mark_far[v], new_epoch) != new_epoch;
@@ -772,6 +969,16 @@ __global__ void k_fix_pred(int32_t* pred, int64_t n)
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride)
     if (pred[i] == INT32_MAX) pred[i] = -1;  // invalid_vertex_id
+}
+
+__global__ void k_count_degree_at_least(int32_t const* offsets, int64_t nv, uint32_t deg, unsigned long long* out)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned c     = 0;
+  for (; i < nv; i += stride) c += (eoff(offsets, i + 1) - eoff(offsets, i)) >= deg;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
 }
 
 template <typename T>
@@ -1137,15 +1344,22 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   dvec<uint32_t> mark_set(use_lh ? n1 : 1);
   if (use_lh) HIP_TRY(hipMemsetAsync(mark_set.data(), 0, n1 * 4, h.stream));
 
-  // CUGRAPH_AMD_SSSP_MODE=multi: distance-ordered sub-queues inside the window (k_sssp_expand_multi above).  Measured at RMAT-24,
-  // weights 1..255, 16 roots (profiles/r3_sssp_subqueues.txt): 8 sub-queues 1.64 relaxations per edge instead of 2.25 -- and 49.6
-  // rounds instead of 18.4, 12.8 ms instead of 11.6; 4 sub-queues 1.88 / 34.8 rounds / 11.6 ms; with delta / 2: 1.35 / 77.6 rounds /
-  // 13.4 ms.  A round costs ~100 us whatever it relaxes (two launches over the whole chip, counter upload and read-back), which
-  // eats what the saved relaxations buy -- the same outcome as the light / heavy buckets of round 2.  The single near queue
-  // therefore stays the default; the sub-queue path is kept, tested (test_sssp_subqueues_vs_oracle), for the day the rounds are
-  // driven from the device.
+  // Opt-in schedules (CUGRAPH_AMD_SSSP_MODE; same fixed point, tested bit for bit against Dijkstra by test_sssp_subqueues_vs_oracle):
+  //   multi  distance-ordered sub-queues inside the window (k_sssp_expand_multi): 8 sub-queues 1.64 relaxations per edge instead of 2.2,
+  //          49.6 rounds instead of 18.4 -- and 12.7 ms instead of 11.5 at RMAT-24, weights 1..255 (profiles/r3_sssp_subqueues.txt)
+  //   dev    the same with the rounds of a window driven from the device (k_sssp_ctl; one host synchronisation per batch of rounds): 12.1 ms
+  //   radix  radix-heap sub-queues (below): 0.99-1.4 relaxations per edge, 108 rounds, 21.8 ms
+  // What CUGRAPH_AMD_SSSP_TRACE shows (profiles/r3_sssp_rounds.txt): an empty round costs 23 us, not the 100 us assumed in round 2; of the
+  // 11 ms of a traversal 9 are FOUR rounds -- the hubs right after the source (66 K vertices, 79 M edges, most relaxations succeed:
+  // 24 G edges/s), the sweep over nearly every edge (259 M, 73 G/s) and its two echoes (140 M, 33 M).  Ordering the work more finely
+  // moves edges from the efficient sweep into rounds of the first kind and adds a pass over the bucket per cut; it removes relaxations,
+  // not time.  What did help the wide rounds is more edges in flight per lane (expand_*_mlp: 11.3 -> 10.4 ms).  The single near queue
+  // stays the default.
   char const* env_mode = getenv("CUGRAPH_AMD_SSSP_MODE");
-  bool const use_multi = !use_lh && env_mode && std::string(env_mode) == "multi";
+  bool const use_dev   = !use_lh && env_mode && std::string(env_mode) == "dev";    // uniform sub-queues + device-driven rounds (k_sssp_ctl)
+  bool const use_radix = !use_lh && env_mode && std::string(env_mode) == "radix";  // radix-heap sub-queues (see below)
+  bool const use_multi = !use_lh && env_mode && (std::string(env_mode) == "multi" || use_dev || use_radix);
+  static bool const sssp_trace_multi = getenv("CUGRAPH_AMD_SSSP_TRACE") != nullptr;
   uint64_t steps = 0, relaxed = 0;
   counters_t c;
   if (use_multi) {
@@ -1159,33 +1373,64 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
       HIP_TRY(hipMemcpyAsync(subq[0].data(), &source, 4, hipMemcpyHostToDevice, h.stream));
       h.sync();
     }
-    char const* env_k = getenv("CUGRAPH_AMD_SSSP_SUBQ");  // sub-queues actually used (1 .. SSSP_K; 1 = the single near queue through the new kernels)
-    int const kk = env_k ? std::max(1, std::min(SSSP_K, atoi(env_k))) : SSSP_K;
-    double lower = 0.0, upper = delta;
-    auto inv_sub_of = [&]() { return (double)kk / (upper - lower); };
-    uint32_t qn_h[SSSP_K] = {1u, 0, 0, 0, 0, 0, 0, 0};
+    char const* env_k = getenv("CUGRAPH_AMD_SSSP_SUBQ");  // uniform modes: sub-queues actually used (1 .. SSSP_K; 1 = the single near queue through these kernels)
+    int const kk = use_radix ? SSSP_K : (env_k ? std::max(1, std::min(SSSP_K, atoi(env_k))) : 8);
+    // the "work" of a sub-queue = its entries with at least average out-degree: ids are degree-sorted (renumbered graphs), so that is
+    // "ids below heavy_cut"; counted once per graph
+    if (g.sssp_heavy_cut < 0) {
+      int64_t cut = nv;
+      if (g.renumbered && nv > 0 && use_radix) {
+        dvec<unsigned long long> n_ge(1);
+        HIP_TRY(hipMemsetAsync(n_ge.data(), 0, 8, h.stream));
+        hipLaunchKernelGGL(k_count_degree_at_least, grid_for(nv, kBlock, 2048), kBlock, 0, h.stream, row_beg, nv, (uint32_t)std::max(1.0, std::ceil(avg_deg)), n_ge.data());
+        unsigned long long r = 0;
+        h.read_back(&r, (unsigned long long const*)n_ge.data(), 1);
+        cut = (int64_t)r;
+      }
+      g.sssp_heavy_cut = cut;
+    }
+    int32_t const heavy_cut = (int32_t)std::min<int64_t>(g.sssp_heavy_cut, INT32_MAX);
+    double lower = 0.0;
+    double ubh[SSSP_K];
+    uint32_t tagh[SSSP_K], next_tag = 0x80000000u;
+    // bucket 0 of the radix layout is delta / radix_div wide (delta = the reference's near / far width); the layout covers 2^(K-1) of those
+    char const* env_div = getenv("CUGRAPH_AMD_SSSP_RADIX_DIV");
+    double const delta0 = delta / (env_div ? std::max(1.0, atof(env_div)) : 256.0);
+    char const* env_sm = getenv("CUGRAPH_AMD_SSSP_SPLIT_MIN");
+    uint32_t const split_min = env_sm ? (uint32_t)std::max(1, atoi(env_sm)) : 2048u;
+    auto set_uniform = [&](double lo, double hi) {
+      lower = lo;
+      for (int k = 0; k < SSSP_K; ++k) { ubh[k] = k < kk - 1 ? lo + (hi - lo) * (double)(k + 1) / (double)kk : hi; tagh[k] = next_tag++; }
+    };
+    auto set_radix = [&](double lo) {  // widths d0, d0, 2 d0, 4 d0, ...
+      lower = lo;
+      for (int k = 0; k < SSSP_K; ++k) { ubh[k] = lo + delta0 * std::ldexp(1.0, k); tagh[k] = next_tag++; }
+    };
+    if (use_radix) set_radix(0.0); else set_uniform(0.0, delta);
+    uint32_t qn_h[SSSP_K] = {1u}, qh_h[SSSP_K] = {1u};
     int32_t* same_nxt = qa.data();
     int32_t* same_oth = qb.data();
     int32_t* far_cur  = fa.data();
     int32_t* far_nxt  = fb.data();
     int32_t const* front = nullptr;
     int64_t n_front = 0, n_far = 0;
-    uint32_t round = 0, window = 0, far_epoch = 1;
+    uint32_t round = 0, far_epoch = 1;
     int j = 0;
     auto state = [&](int jj) {
       sssp_multi_state<WT> s;
       s.dist = d; s.weights = w; s.done = done.data();
-      for (int k = 0; k < SSSP_K; ++k) s.q[k] = subq[k].data();
+      for (int k = 0; k < SSSP_K; ++k) { s.q[k] = subq[k].data(); s.ub[k] = (WT)std::min(ubh[k], (double)wmax); s.tag[k] = tagh[k]; }
       s.q_same = same_nxt; s.far = far_cur; s.mark = mark_near.data(); s.mark_far = mark_far.data(); s.cnt = cnt.data();
       s.qn = &cnt.data()->padl0[0];  // the sub-queue fills live in the padding behind n_next: one read-back per round brings everything
-      s.lower = (WT)std::min(lower, (double)wmax); s.upper = (WT)std::min(upper, (double)wmax); s.inv_sub = (WT)inv_sub_of(); s.cutoff = cutoff;
-      s.j = jj; s.round_tag = round; s.sub_tag0 = 0x80000000u | (window << 4); s.far_epoch = far_epoch;
+      s.qh = &cnt.data()->padl1[0];  // ... their heavy counts behind n_far
+      s.lower = (WT)std::min(lower, (double)wmax); s.cutoff = cutoff; s.heavy_cut = heavy_cut;
+      s.j = jj; s.round_tag = round; s.far_epoch = far_epoch;
       return s;
     };
     auto upload_counters = [&]() {
       counters_t z{};
       z.n_far = (uint32_t)n_far;
-      for (int k = 0; k < SSSP_K; ++k) z.padl0[k] = qn_h[k];
+      for (int k = 0; k < SSSP_K; ++k) { z.padl0[k] = qn_h[k]; z.padl1[k] = qh_h[k]; }
       z.far_min_bits_lo = 0xFFFFFFFFu;
       z.far_min_bits64  = ~0ull;
       std::memcpy(h.pinned, &z, sizeof(z));
@@ -1193,62 +1438,180 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
     };
     auto download_counters = [&]() {
       h.read_back(&c, cnt.data(), 1);
-      for (int k = 0; k < SSSP_K; ++k) { qn_h[k] = c.padl0[k]; CGA_EXPECTS((int64_t)qn_h[k] <= nv, CUGRAPH_UNKNOWN_ERROR, "sssp: sub-queue overflow"); }
+      for (int k = 0; k < SSSP_K; ++k) {
+        qn_h[k] = c.padl0[k]; qh_h[k] = c.padl1[k];
+        CGA_EXPECTS((int64_t)qn_h[k] <= nv, CUGRAPH_UNKNOWN_ERROR, "sssp: sub-queue overflow");
+      }
       c.fold();
       n_far = c.n_far;
       CGA_EXPECTS(n_far <= nv && (int64_t)c.n_next <= nv, CUGRAPH_UNKNOWN_ERROR, "sssp: queue overflow");
     };
-    for (;;) {
-      if (n_front == 0) {
-        while (j < SSSP_K && qn_h[j] == 0) ++j;
-        if (j < SSSP_K) {  // drain the next non-empty sub-queue
-          front   = subq[j].data();
-          n_front = qn_h[j];
-          qn_h[j] = 0;
-        } else {
-          if (n_far == 0) break;
-          // the window is exhausted: advance it until the far pile yields near entries
-          lower = upper;
-          upper = upper + delta;
-          ++window;
-          ++far_epoch;
-          ++round;
-          int64_t const n_in = n_far;
-          n_far = 0;
-          upload_counters();
-          sssp_multi_state<WT> s = state(0);
-          s.far = far_nxt;  // (unused by the split: it appends the kept entries to its far_out argument)
-          hipLaunchKernelGGL(k_sssp_split_multi<WT>, grid_for(n_in, TV_BLOCK, 2048), TV_BLOCK, 0, h.stream, (int32_t const*)far_cur, n_in, s, far_nxt, far_epoch);
-          download_counters();
-          std::swap(far_cur, far_nxt);
-          j = 0;
-          bool any = false;
-          for (int k = 0; k < SSSP_K; ++k) any |= qn_h[k] != 0;
-          if (!any && n_far > 0) {  // empty windows: jump to the one holding the smallest far distance
-            double dmin;
-            if constexpr (sizeof(WT) == 4) { float f; uint32_t b = c.far_min_bits_lo; std::memcpy(&f, &b, 4); dmin = f; }
-            else { double f; unsigned long long b = c.far_min_bits64; std::memcpy(&f, &b, 8); dmin = f; }
-            double kq = std::floor(dmin / delta);
-            while (kq > 0.0 && kq * delta > dmin) kq -= 1.0;
-            if (kq * delta > upper) upper = kq * delta;  // the next advance opens [kq * delta, (kq + 1) * delta)
-          }
-          continue;
-        }
+    double far_min = 0.0;  // smallest distance the last split kept in the far pile
+    auto read_far_min = [&]() {
+      if constexpr (sizeof(WT) == 4) { float f; uint32_t b = c.far_min_bits_lo; std::memcpy(&f, &b, 4); far_min = f; }
+      else { double f; unsigned long long b = c.far_min_bits64; std::memcpy(&f, &b, 8); far_min = f; }
+    };
+    // entries of `in` -> the sub-queues of the current bounds (distances below `lower`: stale, dropped; at or beyond the last bound: far pile)
+    auto split_into_subqueues = [&](int32_t const* in, int64_t n_in, int32_t* far_out) {
+      ++round;
+      upload_counters();
+      sssp_multi_state<WT> s = state(0);
+      hipLaunchKernelGGL(k_sssp_split_multi<WT>, grid_for(n_in, TV_BLOCK, 2048), TV_BLOCK, 0, h.stream, in, n_in, s, far_out, far_epoch);
+      download_counters();
+      read_far_min();
+    };
+    // the sub-queues are exhausted: open the next window on the far pile
+    auto advance_window = [&]() {
+      double const upper = ubh[SSSP_K - 1];
+      if (use_radix) set_radix(upper); else set_uniform(upper, upper + delta);
+      for (;;) {
+        ++far_epoch;
+        int64_t const n_in = n_far;
+        n_far = 0;
+        split_into_subqueues(far_cur, n_in, far_nxt);
+        std::swap(far_cur, far_nxt);
+        bool any = false;
+        for (int k = 0; k < SSSP_K; ++k) any |= qn_h[k] != 0;
+        if (any || n_far == 0) break;
+        // empty window: jump to the one holding the smallest far distance (never past it: fl(dmin / step) may round up to an integer)
+        double const step = use_radix ? delta0 : delta;
+        double kq = std::floor(far_min / step);
+        while (kq > 0.0 && kq * step > far_min) kq -= 1.0;
+        double const lo = std::max(kq * step, ubh[SSSP_K - 1]);
+        if (use_radix) set_radix(lo); else set_uniform(lo, lo + delta);
       }
+      j = 0;
+    };
+    auto one_round = [&](int jj) {
       ++round;
       ++steps;
       upload_counters();
-      sssp_multi_state<WT> s = state(j);
+      sssp_multi_state<WT> s = state(jj);
       {
         timed_launch t(h, "sssp_relax");
         hipLaunchKernelGGL(k_sssp_expand_multi<WT>, expand_grid(h, n_front), TV_BLOCK, 0, h.stream, front, n_front, row_beg, adj, bigq.data(), s, big_deg_for(h, n_front));
         hipLaunchKernelGGL(k_sssp_expand_big_multi<WT>, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), row_beg, adj, s);
       }
       download_counters();
+      if (sssp_trace_multi) {
+        static auto t_prev = std::chrono::steady_clock::now();
+        auto const now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sssp multi] round %3u  sub-queue %2d [%g, %g)  frontier %9lld  edges %11llu  same %9u  far %9u  %8.1f us\n", round, jj,
+                jj ? ubh[jj - 1] : lower, ubh[jj], (long long)n_front, (unsigned long long)c.edges, c.n_next, c.n_far,
+                std::chrono::duration<double, std::micro>(now - t_prev).count());
+        t_prev = now;
+      }
       relaxed += c.edges;
       front   = same_nxt;
       n_front = c.n_next;
       std::swap(same_nxt, same_oth);
+    };
+    if (use_radix) {
+      // Radix-heap buckets (monotone: distances only ever enter sub-queues at or above the one being drained).  The first non-empty
+      // sub-queue k is either drained as it is -- a frontier Bellman-Ford inside its range, cheap when it holds little work -- or, when
+      // it holds at least split_min heavy vertices and is wider than delta0, cut into the k empty sub-queues below it (widths w / 2^(k-1),
+      // w / 2^(k-1), w / 2^(k-2), ..., w / 2) by one pass over ITS entries only: the dense part of the distance range ends up in
+      // sub-queues one delta0 wide (a vertex is expanded once, with its final distance), the sparse tail in a handful of wide ones.
+      for (;;) {
+        int k = 0;
+        while (k < SSSP_K && qn_h[k] == 0) ++k;
+        if (k == SSSP_K) {
+          if (n_far == 0) break;
+          advance_window();
+          continue;
+        }
+        double const lb = k ? ubh[k - 1] : lower, wd = ubh[k] - lb;
+        if (k > 0 && qh_h[k] >= split_min && wd > delta0 * 1.5) {
+          int m = 1 + (int)std::floor(std::log2(wd / delta0) + 1e-6);  // finest sub-queue no narrower than delta0
+          m     = std::max(2, std::min(m, k));
+          lower = lb;
+          for (int i = 0; i < k; ++i) {
+            ubh[i]  = i < m - 1 ? lb + wd * std::ldexp(1.0, i - (m - 1)) : ubh[k];
+            tagh[i] = next_tag++;
+          }
+          int64_t const n_in = qn_h[k];
+          qn_h[k] = 0; qh_h[k] = 0;
+          tagh[k] = next_tag++;  // (its range is empty now)
+          split_into_subqueues(subq[k].data(), n_in, far_cur);
+          if (sssp_trace_multi)
+            fprintf(stderr, "[sssp multi] sub-queue %d [%g, %g): %lld entries cut into %d sub-queues\n", k, lb, ubh[k], (long long)n_in, m);
+          continue;
+        }
+        front   = subq[k].data();
+        n_front = qn_h[k];
+        qn_h[k] = 0; qh_h[k] = 0;
+        while (n_front > 0) one_round(k);
+        lower = ubh[k];
+      }
+    } else if (use_dev) {
+      char const* env_b = getenv("CUGRAPH_AMD_SSSP_BATCH");  // rounds enqueued per host synchronisation
+      int const batch   = env_b ? std::max(1, atoi(env_b)) : 8;
+      int const grid    = h.num_cus * 8;
+      for (;;) {
+        int j0 = 0;
+        while (j0 < SSSP_K && qn_h[j0] == 0) ++j0;
+        if (j0 == SSSP_K) {
+          if (n_far == 0) break;
+          advance_window();
+          continue;
+        }
+        ++round;
+        sssp_dev_args<WT> a;
+        a.s            = state(j0);
+        a.qsame[0]     = qa.data();
+        a.qsame[1]     = qb.data();
+        a.narrow_limit = (int32_t)std::min<int64_t>((int64_t)h.num_cus * 64, INT32_MAX);
+        a.kk           = kk;
+        {
+          counters_t z{};
+          z.n_far = (uint32_t)n_far;
+          for (int k = 0; k < SSSP_K; ++k) z.padl0[k] = k == j0 ? 0u : qn_h[k];
+          z.far_min_bits_lo = 0xFFFFFFFFu;
+          z.far_min_bits64  = ~0ull;
+          sssp_ctl_t c0{};
+          c0.j = (uint32_t)j0; c0.n_front = qn_h[j0]; c0.round = round;
+          *sssp_ctl_of(&z) = c0;
+          std::memcpy(h.pinned, &z, sizeof(z));
+          HIP_TRY(hipMemcpyAsync(cnt.data(), h.pinned, sizeof(z), hipMemcpyHostToDevice, h.stream));
+        }
+        sssp_ctl_t ctl{};
+        for (;;) {
+          {
+            timed_launch t(h, "sssp_relax");
+            for (int b = 0; b < batch; ++b) {
+              hipLaunchKernelGGL(k_sssp_expand_dev<WT>, grid, TV_BLOCK, 0, h.stream, row_beg, adj, bigq.data(), a);
+              hipLaunchKernelGGL(k_sssp_expand_big_dev<WT>, grid, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), row_beg, adj, a);
+              hipLaunchKernelGGL(k_sssp_ctl, 1, 64, 0, h.stream, cnt.data(), SSSP_K);
+            }
+          }
+          h.read_back(&c, cnt.data(), 1);
+          ctl = *sssp_ctl_of(&c);
+          CGA_EXPECTS((int64_t)c.n_far <= nv && (int64_t)c.n_next <= nv, CUGRAPH_UNKNOWN_ERROR, "sssp: queue overflow");
+          for (int k = 0; k < SSSP_K; ++k) CGA_EXPECTS((int64_t)c.padl0[k] <= nv, CUGRAPH_UNKNOWN_ERROR, "sssp: sub-queue overflow");
+          if (ctl.done) break;
+        }
+        steps += ctl.rounds;
+        relaxed += ctl.relaxed;
+        round = ctl.round;
+        n_far = c.n_far;
+        for (int k = 0; k < SSSP_K; ++k) { qn_h[k] = 0; qh_h[k] = 0; }
+      }
+    } else {
+      for (;;) {
+        if (n_front == 0) {
+          while (j < SSSP_K && qn_h[j] == 0) ++j;
+          if (j < SSSP_K) {  // drain the next non-empty sub-queue
+            front   = subq[j].data();
+            n_front = qn_h[j];
+            qn_h[j] = 0; qh_h[j] = 0;
+          } else {
+            if (n_far == 0) break;
+            advance_window();
+            continue;
+          }
+        }
+        one_round(j);
+      }
     }
   } else {
   {  // d[source] = 0, near = {source}
@@ -1273,6 +1636,8 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   double lower = 0.0, upper = delta;
   // one relaxation round over the rows [beg[u], end[u]) of the vertices in `front`; near / far / bucket-member appends continue
   // at n_far / n_set_in (they persist across the rounds of a bucket), n_next / n_big / edges start from zero
+  static bool const sssp_trace = getenv("CUGRAPH_AMD_SSSP_TRACE") != nullptr;  // per round: sizes and wall time since the previous line (stderr)
+  auto t_trace = std::chrono::steady_clock::now();
   auto relax_round = [&](int32_t const* front, int64_t n_front, int32_t const* beg, int32_t const* end, int32_t* set_out, int64_t n_set_in) {
     ++round;
     ++steps;
@@ -1292,6 +1657,12 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
     }
     h.read_back(&c, cnt.data(), 1);
     c.fold();
+    if (sssp_trace) {
+      auto const now = std::chrono::steady_clock::now();
+      fprintf(stderr, "[sssp] round %3u  window [%g, %g)  frontier %9lld  edges %11llu  next %9u  far %9u  deferred segments %7u  %8.1f us\n", round, lower, upper,
+              (long long)n_front, (unsigned long long)c.edges, c.n_next, c.n_far, c.n_big, std::chrono::duration<double, std::micro>(now - t_trace).count());
+      t_trace = now;
+    }
     relaxed += c.edges;
     n_cur = c.n_next;
     n_far = c.n_far;

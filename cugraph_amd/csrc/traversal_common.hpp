@@ -241,6 +241,145 @@ __device__ __forceinline__ void expand_big(int32_t const* bigq, int32_t const* o
 }
 
 
+// ---- the same two walks with EX_U edges in flight per lane.  A relaxation is a chain of dependent memory round trips (neighbour
+// id -> its distance / visited word -> atomic): with one edge per lane and step a wavefront has 64 requests outstanding and spends
+// the round trip waiting (measured: adding ONE more cached load to the chain made an SSSP round 15 % slower; removing the returned
+// atomic did not help -- latency, not bytes or atomics, bounded the wide rounds).  The functor is therefore split in two:
+//   cand_t pre(u, v, p)          loads and tests only, BRANCH-FREE (v < 0: no edge; u, v, p are then clamped to loadable positions by
+//                                the caller / the functor): the loads of the EX_U pre() calls of a step are issued back to back
+//   tok_t  mid(v, cand_t)        the first returned atomic, if any (issued for the EX_U edges before any result is waited for)
+//   tok2_t mid2(v, cand, tok)    the second one (the dedup mark of a successful relaxation), likewise
+//   void   post(u, v, cand, tok, tok2)  the queue appends (wave-convergent: every lane that entered the step calls it EX_U times)
+#ifndef CGA_EX_U
+#define CGA_EX_U 4
+#endif
+constexpr int EX_U = CGA_EX_U;
+template <typename Keep, typename F>
+__device__ __forceinline__ void expand_frontier_mlp(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices, int32_t* bigq,
+                                                    counters_t* cnt, Keep keep, F& f, int32_t big_deg = BIG_DEG, int32_t const* row_end = nullptr)
+{
+  __shared__ uint32_t s_scan[TV_WAVES][64];
+  __shared__ eoff_t s_beg[TV_WAVES][64];
+  __shared__ int32_t s_u[TV_WAVES][64];
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t const gwave  = (int64_t)blockIdx.x * TV_WAVES + wave;
+  int64_t const nwaves = (int64_t)gridDim.x * TV_WAVES;
+  unsigned long long inspected = 0;
+  for (int64_t base = gwave * 64; base < n; base += nwaves * 64) {
+    int64_t i = base + lane;
+    int32_t u = -1, deg = 0;
+    eoff_t beg = 0;
+    if (i < n) {
+      u = q ? q[i] : (int32_t)i;
+      if (keep(u)) { beg = eoff(offsets, u); deg = (int32_t)((row_end ? eoff(row_end, u) : eoff(offsets, u + 1)) - beg); } else { u = -1; }
+    }
+    bool big = deg >= big_deg;
+    if (big) {
+      uint32_t nseg = ((uint32_t)deg + BIG_SEG - 1) / BIG_SEG;
+      uint32_t at   = atomicAdd(&cnt->n_big, nseg);
+      for (uint32_t sgm = 0; sgm < nseg; ++sgm) { bigq[2 * (at + sgm)] = u; bigq[2 * (at + sgm) + 1] = (int32_t)sgm; }
+    }
+    // whole-wave rows
+    uint64_t mid = __ballot(deg >= 64 && !big);
+    while (mid) {
+      int src     = __ffsll((unsigned long long)mid) - 1;
+      mid &= mid - 1;
+      int32_t uu = __shfl(u, src), d = __shfl(deg, src);
+      eoff_t const b = (eoff_t)__shfl((int)beg, src);
+      for (int32_t p0 = lane; p0 < d; p0 += 64 * EX_U) {
+        int32_t v[EX_U];
+        typename F::cand_t c[EX_U];
+        typename F::tok_t tk[EX_U];
+        typename F::tok2_t tk2[EX_U];
+#pragma unroll
+        for (int k = 0; k < EX_U; ++k) { int32_t const p = p0 + 64 * k; v[k] = p < d ? indices[b + (eoff_t)p] : -1; }
+#pragma unroll
+        for (int k = 0; k < EX_U; ++k) { int32_t const p = p0 + 64 * k; c[k] = f.pre(uu, v[k], b + (eoff_t)(p < d ? p : 0)); }
+#pragma unroll
+        for (int k = 0; k < EX_U; ++k) tk[k] = f.mid(v[k], c[k]);
+#pragma unroll
+        for (int k = 0; k < EX_U; ++k) tk2[k] = f.mid2(v[k], c[k], tk[k]);
+#pragma unroll
+        for (int k = 0; k < EX_U; ++k) f.post(uu, v[k], c[k], tk[k], tk2[k]);
+      }
+      inspected += (lane == 0) ? (unsigned long long)d : 0ull;
+    }
+    // flattened small rows
+    uint32_t sd = (deg < 64) ? (uint32_t)deg : 0u, total;
+    uint32_t ex = wave_excl_scan(sd, lane, &total);
+    s_scan[wave][lane] = ex;
+    s_beg[wave][lane]  = beg;
+    s_u[wave][lane]    = u;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t t0 = lane; t0 < total; t0 += 64 * EX_U) {
+      int32_t v[EX_U], uu[EX_U];
+      eoff_t pp[EX_U];
+      typename F::cand_t c[EX_U];
+      typename F::tok_t tk[EX_U];
+      typename F::tok2_t tk2[EX_U];
+#pragma unroll
+      for (int k = 0; k < EX_U; ++k) {
+        uint32_t const t = t0 + 64u * (uint32_t)k;
+        v[k] = -1; uu[k] = s_u[wave][0] < 0 ? 0 : s_u[wave][0]; pp[k] = s_beg[wave][0];  // (loadable stand-ins for "no edge")
+        if (t < total) {
+          int lo = 0, hi = 63;
+#pragma unroll
+          for (int st = 0; st < 6; ++st) {
+            int m = (lo + hi + 1) >> 1;
+            if (s_scan[wave][m] <= t) lo = m; else hi = m - 1;
+          }
+          pp[k] = s_beg[wave][lo] + (t - s_scan[wave][lo]);
+          uu[k] = s_u[wave][lo];
+          v[k]  = indices[pp[k]];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < EX_U; ++k) c[k] = f.pre(uu[k], v[k], pp[k]);
+#pragma unroll
+      for (int k = 0; k < EX_U; ++k) tk[k] = f.mid(v[k], c[k]);
+#pragma unroll
+      for (int k = 0; k < EX_U; ++k) tk2[k] = f.mid2(v[k], c[k], tk[k]);
+#pragma unroll
+      for (int k = 0; k < EX_U; ++k) f.post(uu[k], v[k], c[k], tk[k], tk2[k]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    inspected += (lane == 0) ? (unsigned long long)total : 0ull;
+  }
+  if (lane == 0 && inspected) atomicAdd(&cnt_replica(cnt)->edges, inspected);
+}
+
+template <typename F>
+__device__ __forceinline__ void expand_big_mlp(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, counters_t* cnt, F& f,
+                                               int32_t const* row_end = nullptr)
+{
+  uint32_t const nseg = cnt->n_big;
+  unsigned long long inspected = 0;
+  for (uint32_t k = blockIdx.x; k < nseg; k += gridDim.x) {
+    int32_t const u = bigq[2 * k], sgm = bigq[2 * k + 1];
+    eoff_t const row_b = eoff(offsets, u), row_e = row_end ? eoff(row_end, u) : eoff(offsets, u + 1);
+    eoff_t const b = row_b + (eoff_t)sgm * (eoff_t)BIG_SEG;
+    eoff_t const len = min(row_e - b, (eoff_t)BIG_SEG);
+    for (eoff_t p0 = threadIdx.x; p0 < len; p0 += (eoff_t)blockDim.x * EX_U) {
+      int32_t v[EX_U];
+      typename F::cand_t c[EX_U];
+      typename F::tok_t tk[EX_U];
+      typename F::tok2_t tk2[EX_U];
+#pragma unroll
+      for (int i = 0; i < EX_U; ++i) { eoff_t const p = p0 + (eoff_t)i * blockDim.x; v[i] = p < len ? indices[b + p] : -1; }
+#pragma unroll
+      for (int i = 0; i < EX_U; ++i) { eoff_t const p = p0 + (eoff_t)i * blockDim.x; c[i] = f.pre(u, v[i], b + (p < len ? p : 0)); }
+#pragma unroll
+      for (int i = 0; i < EX_U; ++i) tk[i] = f.mid(v[i], c[i]);
+#pragma unroll
+      for (int i = 0; i < EX_U; ++i) tk2[i] = f.mid2(v[i], c[i], tk[i]);
+#pragma unroll
+      for (int i = 0; i < EX_U; ++i) f.post(u, v[i], c[i], tk[i], tk2[i]);
+    }
+    if (threadIdx.x == 0) inspected += (unsigned long long)len;
+  }
+  if (threadIdx.x == 0 && inspected) atomicAdd(&cnt_replica(cnt)->edges, inspected);
+}
+
 inline size_t big_queue_entries(int64_t ne) { return (size_t)(2 * (ne / BIG_DEG_NARROW + ne / BIG_SEG + 64)); }
 // largest edge count the traversal kernels address (32-bit unsigned positions, 2048 words of tail padding)
 constexpr int64_t kMaxTraversalEdges = ((int64_t)1 << 32) - 4096;

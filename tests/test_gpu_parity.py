@@ -366,13 +366,25 @@ def test_sssp_rmat_vs_oracle(cg, handle, orc, scale, kind, dtype):
     assert np.array_equal(dist, oc)
 
 
+@pytest.mark.parametrize("mode,batch", [("multi", 0), ("dev", 8), ("dev", 1), ("dev", 3), ("radix", -1), ("radix", -64), ("radix", -100000)])
 @pytest.mark.parametrize("scale,kind,dtype,subq", [(12, "int", np.float32, 8), (14, "real", np.float32, 8), (16, "int", np.float32, 4), (14, "int", np.float64, 8),
-                                                   (13, "unit", np.float32, 2)])
-def test_sssp_subqueues_vs_oracle(cg, handle, orc, monkeypatch, scale, kind, dtype, subq):
-    """The opt-in distance-ordered sub-queue schedule of SSSP (CUGRAPH_AMD_SSSP_MODE=multi, round 3): same fixed point, so
-    distances bit-identical to Dijkstra and the canonical parents, for integer / real / unit weights, fp32 / fp64, with a cutoff."""
-    monkeypatch.setenv("CUGRAPH_AMD_SSSP_MODE", "multi")
+                                                   (13, "unit", np.float32, 2), (15, "int", np.float32, 1)])
+def test_sssp_subqueues_vs_oracle(cg, handle, orc, monkeypatch, scale, kind, dtype, subq, mode, batch):
+    """The distance-ordered sub-queue schedule of SSSP (CUGRAPH_AMD_SSSP_MODE=multi, round 3), its device-driven form (=dev: batches
+    of rounds advanced by k_sssp_ctl, one host synchronisation per batch) and the radix-heap form (=radix: sub-queues of doubling width,
+    the first non-empty one either drained or cut into the empty ones below it): same fixed point, so distances bit-identical to Dijkstra and
+    the canonical parents, for integer / real / unit weights, fp32 / fp64, with a cutoff; batch sizes that end inside, at and past the
+    end of a window."""
+    monkeypatch.setenv("CUGRAPH_AMD_SSSP_MODE", mode)
     monkeypatch.setenv("CUGRAPH_AMD_SSSP_SUBQ", str(subq))
+    if batch > 0:
+        monkeypatch.setenv("CUGRAPH_AMD_SSSP_BATCH", str(batch))
+    if batch < 0:  # radix sub-queues: a sub-queue is cut into finer ones from this many heavy entries on (1: always, 100000: never at these sizes)
+        monkeypatch.setenv("CUGRAPH_AMD_SSSP_SPLIT_MIN", str(-batch))
+    _sssp_parity(cg, handle, orc, scale, kind, dtype)
+
+
+def _sssp_parity(cg, handle, orc, scale, kind, dtype):
     s, d = rmat_graph(orc, scale)
     nv = 1 << scale
     if kind == "unit":
