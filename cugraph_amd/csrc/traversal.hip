@@ -68,9 +68,11 @@ struct bfs_visit {
     uint32_t bit = 1u << (v & 31);
     bool fresh   = false;
     if (!(s.vis_prev[v >> 5] & bit)) {
-      // plain pre-test of the cumulative word: hub destinations are claimed once and then skipped without an atomic
+      // pre-test of the cumulative word: hub destinations are claimed once and then skipped without an atomic
       // (a stale read only costs a redundant atomicOr)
-      bool claimed = (__builtin_nontemporal_load(&s.vis_new[v >> 5]) & bit) != 0;
+      // (agent-scope load: L2-served AND retained.  A non-temporal load is L2-served too but its lines are evicted first -- the 2 MB
+      // bitmap then keeps missing: a push-only BFS at RMAT-24 takes 5.5 ms with it, 4.55 ms with this: profiles/r3_sssp_rounds.txt)
+      bool claimed = (__hip_atomic_load(&s.vis_new[v >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) != 0;
       if (!claimed) {
         uint32_t old = atomicOr(&s.vis_new[v >> 5], bit);
         fresh        = !(old & bit);
@@ -80,7 +82,7 @@ struct bfs_visit {
         acc_out += (unsigned long long)(eoff(s.out_offsets, v + 1) - eoff(s.out_offsets, v));
         acc_in += (unsigned long long)(eoff(s.in_offsets, v + 1) - eoff(s.in_offsets, v));
       }
-      if (s.pred && u < __builtin_nontemporal_load(&s.pred[v])) atomicMin(&s.pred[v], u);  // minimum internal id among the frontier parents
+      if (s.pred && u < __hip_atomic_load(&s.pred[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&s.pred[v], u);  // minimum internal id among the frontier parents
     }
     wq.push(fresh, v);
   }

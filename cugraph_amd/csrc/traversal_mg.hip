@@ -64,9 +64,9 @@ struct mg_bfs_visit {
     if (!(s.seen[g >> 5] & bit)) {
       if (s.with_pred) {
         int32_t const pu = s.row_vertex[u];
-        if (pu < __builtin_nontemporal_load(&s.cand_parent[g])) atomicMin(&s.cand_parent[g], pu);
+        if (pu < __hip_atomic_load(&s.cand_parent[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&s.cand_parent[g], pu);
       }
-      if (!(__builtin_nontemporal_load(&s.touched[g >> 5]) & bit)) fresh = !(atomicOr(&s.touched[g >> 5], bit) & bit);
+      if (!(__hip_atomic_load(&s.touched[g >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) fresh = !(atomicOr(&s.touched[g >> 5], bit) & bit);
     }
     wq.push(fresh, g);
   }
@@ -96,7 +96,7 @@ struct mg_sssp_relax {
       if (packed < __hip_atomic_load(&s.cand_best[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         atomicMin(&s.cand_best[g], packed);
         uint32_t const bit = 1u << (g & 31);
-        if (!(__builtin_nontemporal_load(&s.touched[g >> 5]) & bit)) fresh = !(atomicOr(&s.touched[g >> 5], bit) & bit);
+        if (!(__hip_atomic_load(&s.touched[g >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) fresh = !(atomicOr(&s.touched[g >> 5], bit) & bit);
       }
     }
     wq.push(fresh, g);
@@ -219,7 +219,7 @@ __global__ void k_mg_bfs_apply(int32_t const* in, size_t n, int32_t level, int32
     int32_t const old  = atomicCAS(&dist[row], INT32_MAX, level);
     fresh              = old == INT32_MAX;
     if (fresh) atomicOr(&newfront[row >> 5], 1u << (row & 31));
-    if (pred && (fresh || old == level) && par < __builtin_nontemporal_load(&pred[row])) atomicMin(&pred[row], par);
+    if (pred && (fresh || old == level) && par < __hip_atomic_load(&pred[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&pred[row], par);
   }
   wave_push(fresh, row, q_next, &cnt->n_next, threadIdx.x & 63);
 }
