@@ -67,7 +67,7 @@ def main_partitioned(args):
     def run(kind):
         e = engines[kind]
         times, teps, levels = [], [], []
-        for i, r in enumerate([roots[0], roots[0]] + roots):  # two warm-ups
+        for i, r in enumerate([roots[0], roots[-1]] + roots):  # two warm-ups (different roots: the collectives size their buffers on first use)
             torch.cuda.synchronize()
             dist.barrier()
             t0 = time.perf_counter()
@@ -84,7 +84,9 @@ def main_partitioned(args):
                 teps.append(float(er.item()) / dt)
                 levels.append(e.levels)
         hm = len(teps) / sum(1.0 / t for t in teps)
-        return {"ms_mean": round(1e3 * sum(times) / len(times), 3), "ms_min": round(1e3 * min(times), 3), "ms_max": round(1e3 * max(times), 3),
+        return {"ms_mean": round(1e3 * sum(times) / len(times), 3), "ms_median": round(1e3 * sorted(times)[len(times) // 2], 3),
+                "ms_all": [round(1e3 * t, 2) for t in times], "bottom_up_levels_last": getattr(e, "bottom_up_levels", 0),
+                "ms_min": round(1e3 * min(times), 3), "ms_max": round(1e3 * max(times), 3),
                 "mteps_harmonic_mean": round(hm / 1e6, 1), "rounds_mean": round(sum(levels) / len(levels), 1)}
 
     out = {"workload": f"partitioned BFS/SSSP, RMAT scale {args.scale} edge factor {args.edge_factor}, weights {args.weights}, {world} rank(s)",

@@ -183,6 +183,9 @@ PROTOTYPES = {
     "cugraph_amd_traversal_mg_plan_apply": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.POINTER(C.c_size_t), _PP]),
     "cugraph_amd_traversal_mg_plan_frontier_bits": (C.c_int, [_P, _PP, _PP]),
     "cugraph_amd_traversal_mg_plan_merge_visited": (C.c_int, [_P, _P, _PP]),
+    "cugraph_amd_traversal_mg_plan_set_bottom_up": (C.c_int, [_P, _P, _P, _P, _PP]),
+    "cugraph_amd_traversal_mg_plan_bottom_up": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(C.c_size_t), _PP]),
+    "cugraph_amd_traversal_mg_plan_last_degree_sums": (C.c_int, [_P, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), _PP]),
     "cugraph_amd_traversal_mg_plan_results": (C.c_int, [_P, _P, _P, _PP]),
     "cugraph_amd_traversal_mg_plan_free": (None, [_P]),
     "cugraph_amd_read_matrix_market": (C.c_int, [_P, C.c_char_p, _PP, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int), _PP]),

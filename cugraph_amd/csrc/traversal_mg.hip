@@ -28,6 +28,7 @@
 // deterministic and independent of P and of the numbering.
 #include "common.hpp"
 #include "traversal_common.hpp"
+#include "traversal_bottom_up.hpp"
 
 #include <cfloat>
 #include <climits>
@@ -208,20 +209,32 @@ __global__ void __launch_bounds__(256) k_mg_bucket_scatter(int32_t const* cand, 
 }
 
 // ---- owner side
-__global__ void k_mg_bfs_apply(int32_t const* in, size_t n, int32_t level, int32_t* dist, int32_t* pred, int32_t* q_next, uint32_t* newfront, counters_t* cnt)
+__global__ void k_mg_bfs_apply(int32_t const* in, size_t n, int32_t level, int32_t* dist, int32_t* pred, int32_t* q_next, uint32_t* newfront, counters_t* cnt,
+                               int32_t const* out_offsets, int32_t const* in_offsets /* nullptr: no degree sums (no bottom-up levels) */)
 {
   size_t i      = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   bool fresh    = false;
   int32_t row   = 0;
+  unsigned long long acc_out = 0, acc_in = 0;
   if (i < n) {
     row                = in[2 * i];
     int32_t const par  = in[2 * i + 1];
     int32_t const old  = atomicCAS(&dist[row], INT32_MAX, level);
     fresh              = old == INT32_MAX;
-    if (fresh) atomicOr(&newfront[row >> 5], 1u << (row & 31));
+    if (fresh) {
+      atomicOr(&newfront[row >> 5], 1u << (row & 31));
+      if (in_offsets) {  // the direction heuristic's sums (bfs_impl.cuh:598-607 counts the same two quantities)
+        acc_out = (unsigned long long)(eoff(out_offsets, row + 1) - eoff(out_offsets, row));
+        acc_in  = (unsigned long long)(eoff(in_offsets, row + 1) - eoff(in_offsets, row));
+      }
+    }
     if (pred && (fresh || old == level) && par < __hip_atomic_load(&pred[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&pred[row], par);
   }
   wave_push(fresh, row, q_next, &cnt->n_next, threadIdx.x & 63);
+  if (in_offsets) {
+    for (int o = 32; o > 0; o >>= 1) { acc_out += __shfl_xor(acc_out, o); acc_in += __shfl_xor(acc_in, o); }
+    if ((threadIdx.x & 63) == 0 && (acc_out | acc_in)) { counter_sums_t* r = cnt_replica(cnt); atomicAdd(&r->out_edges, acc_out); atomicAdd(&r->in_edges, acc_in); }
+  }
 }
 
 __global__ void k_mg_sssp_apply(int32_t const* in, size_t n, uint32_t round, unsigned long long* st, uint32_t* mark, int32_t* q_next, counters_t* cnt)
@@ -312,6 +325,12 @@ struct traversal_mg_plan {
   int32_t* q_cur{nullptr};
   int32_t* q_next{nullptr};
   size_t n_frontier{0};
+  // bottom-up levels (BFS): the in-edges of the local rows (neighbours = compact global ids, ascending EXTERNAL id inside a row) and the
+  // external id of every compact global id; degree sums of the last level's discoveries for the direction heuristic
+  int32_t const* in_offsets{nullptr};
+  int32_t const* in_indices{nullptr};
+  int32_t const* ext_of_g{nullptr};
+  unsigned long long last_out{0}, last_in{0};
   int tuple_words() const { return mode == 0 ? 2 : 3; }
 };
 
@@ -484,7 +503,7 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_apply(cugraph_amd_
       int const g = (int)((n_tuples + 255) / 256);
       if (p.mode == 0)
         hipLaunchKernelGGL(k_mg_bfs_apply, g, 256, 0, h.stream, recv, n_tuples, (int32_t)level, p.dist.data(), p.with_pred ? p.pred.data() : (int32_t*)nullptr,
-                           p.q_next, p.newfront.data(), p.cnt.data());
+                           p.q_next, p.newfront.data(), p.cnt.data(), p.offsets, p.in_offsets);
       else
         hipLaunchKernelGGL(k_mg_sssp_apply, g, 256, 0, h.stream, recv, n_tuples, level, p.st.data(), p.mark.data(), p.q_next, p.cnt.data());
     }
@@ -493,7 +512,75 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_apply(cugraph_amd_
     c.fold();
     std::swap(p.q_cur, p.q_next);
     p.n_frontier = c.n_next;
+    p.last_out   = c.out_edges;
+    p.last_in    = c.in_edges;
     *n_next      = c.n_next;
+  });
+}
+
+/* BFS: enables bottom-up levels.  in_offsets [n_rows + 1] / in_indices: the in-edges of the local rows, neighbours as compact global ids in
+   ascending order of their EXTERNAL id (the first frontier member of a row is then the minimum-external-id parent -- the rule of the
+   top-down levels), in_indices over-allocated by at least 8 entries; ext_of_g [comm_size * rows_per_rank]: external id of a compact id.
+   The arrays stay owned by the caller.  Replaces the bottom-up branch of bfs_impl.cuh:587-805 for the partitioned case. */
+extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_set_bottom_up(cugraph_amd_traversal_mg_plan_t* plan, const int32_t* in_offsets,
+                                                                            const int32_t* in_indices, const int32_t* ext_of_g, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr && TP(plan).mode == 0, CUGRAPH_INVALID_INPUT, "BFS plan expected");
+    CGA_EXPECTS(in_offsets != nullptr && in_indices != nullptr && ext_of_g != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
+    traversal_mg_plan& p = TP(plan);
+    p.in_offsets = in_offsets;
+    p.in_indices = in_indices;
+    p.ext_of_g   = ext_of_g;
+  });
+}
+
+/* BFS, one bottom-up level: every unvisited local row scans its in-neighbours against `front` (the all-gathered frontier bitmap,
+   comm_size * rows_per_rank bits) and stops at the first member.  No candidate exchange: the discoveries are local; their bits are
+   shared by the same all-gather as after a top-down level (frontier_bits / merge_visited).  n_found = size of the next local frontier. */
+extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_bottom_up(cugraph_amd_traversal_mg_plan_t* plan, const uint32_t* front, uint32_t level,
+                                                                        size_t* n_found, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr && front != nullptr && n_found != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
+    traversal_mg_plan& p = TP(plan);
+    CGA_EXPECTS(p.mode == 0 && p.in_offsets != nullptr, CUGRAPH_INVALID_INPUT, "bottom-up levels were not enabled (cugraph_amd_traversal_mg_plan_set_bottom_up)");
+    handle_t const& h = *p.h;
+    HIP_TRY(hipSetDevice(h.device));
+    HIP_TRY(hipMemsetAsync(p.cnt.data(), 0, sizeof(counters_t), h.stream));
+    HIP_TRY(hipMemsetAsync(p.newfront.data(), 0, p.L / 8, h.stream));
+    int64_t const nv = (int64_t)p.n_rows;
+    if (nv > 0) {
+      int const grid = (int)std::max<int64_t>(1, std::min<int64_t>(((nv + 63) / 64 + TV_WAVES * BU_GROUPS - 1) / (TV_WAVES * BU_GROUPS), (int64_t)h.num_cus * 16));
+      timed_launch tl(h, "bfs_bottom_up");
+      hipLaunchKernelGGL(k_bfs_bottom_up<false>, grid, TV_BLOCK, 0, h.stream, p.in_offsets, p.in_indices, p.offsets, nv, p.seen.data() + (size_t)p.rank * (p.L / 32),
+                         front, p.newfront.data(), p.dist.data(), p.with_pred ? p.pred.data() : (int32_t*)nullptr, (int32_t)level, p.cnt.data(),
+                         (unsigned long long*)nullptr, p.ext_of_g);
+      // the next level may run top-down: its queue
+      hipLaunchKernelGGL(k_bfs_bitmap_to_queue, grid_for((int64_t)(p.L / 32), TV_BLOCK, 2048), TV_BLOCK, 0, h.stream, (uint32_t const*)p.newfront.data(), (int64_t)(p.L / 32),
+                         p.q_next, p.cnt.data());
+    }
+    counters_t c{};
+    h.read_back(&c, p.cnt.data(), 1);
+    c.fold();  // (the kernel counts its discoveries in the replica lines: folded into n_next)
+    CGA_EXPECTS(c.n_next == c.n_big, CUGRAPH_UNKNOWN_ERROR, "bottom-up level: discoveries and queue length differ");
+    std::swap(p.q_cur, p.q_next);
+    p.n_frontier = c.n_next;
+    p.last_out   = c.out_edges;
+    p.last_in    = c.in_edges;
+    *n_found     = c.n_next;
+  });
+}
+
+/* BFS: sums of the out- and in-degrees of the vertices the last apply / bottom_up call discovered on this rank (zero unless bottom-up
+   levels are enabled) */
+extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_last_degree_sums(cugraph_amd_traversal_mg_plan_t* plan, unsigned long long* out_edges,
+                                                                               unsigned long long* in_edges, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr && out_edges != nullptr && in_edges != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
+    *out_edges = TP(plan).last_out;
+    *in_edges  = TP(plan).last_in;
   });
 }
 

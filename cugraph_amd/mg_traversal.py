@@ -27,6 +27,7 @@ kernels of csrc/traversal_mg.hip) -- there is no CPU engine here.  The tests plu
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -59,6 +60,18 @@ class TraversalEngine:
 
     def merge_visited(self, gathered: torch.Tensor):
         raise NotImplementedError
+
+    # BFS, bottom-up levels (optional: an engine without them returns False and the search stays top-down)
+    def enable_bottom_up(self, in_offsets: torch.Tensor, in_indices: torch.Tensor, ext_of_g: torch.Tensor) -> bool:
+        return False
+
+    def bottom_up(self, front_bits: torch.Tensor, level: int) -> int:
+        """every unvisited local row scans its in-neighbours against the all-gathered frontier bitmap -> discoveries"""
+        raise NotImplementedError
+
+    def degree_sums(self):
+        """(out-degree sum, in-degree sum) of the vertices the last apply / bottom_up discovered on this rank"""
+        return 0, 0
 
     def results(self):
         raise NotImplementedError
@@ -132,6 +145,28 @@ class HipTraversalEngine(TraversalEngine):
         torch.cuda.current_stream().synchronize()
         self._call("cugraph_amd_traversal_mg_plan_merge_visited", g.data_ptr())
 
+    def enable_bottom_up(self, in_offsets, in_indices, ext_of_g):
+        dev = self.device
+        self._in_off = in_offsets.to(dev).to(torch.int32).contiguous()
+        # (the kernel reads 16-byte chunks of neighbour ids: over-allocate)
+        self._in_idx = torch.cat([in_indices.to(dev).to(torch.int32), torch.zeros(64, dtype=torch.int32, device=dev)]).contiguous()
+        self._ext_of_g = ext_of_g.to(dev).to(torch.int32).contiguous()
+        torch.cuda.current_stream().synchronize()
+        self._call("cugraph_amd_traversal_mg_plan_set_bottom_up", self._in_off.data_ptr(), self._in_idx.data_ptr(), self._ext_of_g.data_ptr())
+        return True
+
+    def bottom_up(self, front_bits, level):
+        n = C.c_size_t(0)
+        f = front_bits.to(self.device).contiguous()
+        torch.cuda.current_stream().synchronize()
+        self._call("cugraph_amd_traversal_mg_plan_bottom_up", f.data_ptr(), int(level), C.byref(n))
+        return int(n.value)
+
+    def degree_sums(self):
+        o, i = C.c_ulonglong(0), C.c_ulonglong(0)
+        self._call("cugraph_amd_traversal_mg_plan_last_degree_sums", C.byref(o), C.byref(i))
+        return int(o.value), int(i.value)
+
     def results(self):
         n = max(self.n_rows, 1)
         d = torch.empty(n, dtype=(torch.int32 if self.mode == 0 else torch.float32), device=self.device)
@@ -201,6 +236,36 @@ class MGTraversal:
         factory = engine_factory or HipTraversalEngine
         self.engine = factory(self.mode, offsets.to(torch.int32), cols.to(torch.int32), w, n_rows, L, rank, world, part.local_vertices.to(torch.int32))
         self.levels = 0
+        self.bottom_up_levels = 0
+        # BFS: bottom-up levels need the in-edges of the owned vertices -- a second copy of the edge list, routed by the owner of the
+        # DESTINATION, neighbours as compact global ids in ascending order of their external id (first frontier member of a row = the
+        # minimum-external-id parent, the rule of the top-down levels) -- and the external id of every compact global id
+        self.can_bottom_up = False
+        if self.mode == 0 and os.environ.get("CUGRAPH_AMD_MG_BFS_BOTTOM_UP", "1") != "0":
+            owner_d = pos_d % world
+            od = stable_argsort(owner_d, world - 1)
+            sc_d = _count_owners(owner_d, world)
+            rc_d = torch.empty_like(sc_d)
+            dist.all_to_all_single(rc_d, sc_d, group=group)
+            sc_d, rc_d = sc_d.tolist(), rc_d.tolist()
+            in_rows = _a2a((pos_d // world)[od].contiguous(), sc_d, rc_d, group)
+            in_g = _a2a(((pos_s % world) * L + pos_s // world)[od].contiguous(), sc_d, rc_d, group)
+            in_ext = _a2a(src64[od].contiguous(), sc_d, rc_d, group)
+            o3 = stable_argsort(in_rows * nv + in_ext, max(n_rows, 1) * nv)
+            in_rows, in_g = in_rows[o3], in_g[o3]
+            in_off = torch.zeros(n_rows + 1, dtype=torch.int64, device=in_rows.device)
+            if in_rows.numel():
+                in_off[1:] = inclusive_counts(in_rows, n_rows)
+            mine = torch.full((L,), -1, dtype=torch.int32, device=part.local_vertices.device)
+            mine[:n_rows] = part.local_vertices.to(torch.int32)
+            mine_c = self._to_comm(mine)
+            ext_of_g = torch.empty(world * L, dtype=torch.int32, device=mine_c.device)
+            dist.all_gather_into_tensor(ext_of_g, mine_c, group=group)
+            self.can_bottom_up = bool(self.engine.enable_bottom_up(in_off.to(torch.int32), in_g.to(torch.int32), ext_of_g))
+            ne_t = torch.tensor([int(src64.numel())], dtype=torch.int64, device=mine_c.device)
+            dist.all_reduce(ne_t, group=group)
+            self.ne_global = int(ne_t.item())
+            self._out_deg = out_deg
 
     # -- collectives on device tensors (nccl) or through the host (gloo moves host memory)
     def _to_comm(self, t):
@@ -221,11 +286,20 @@ class MGTraversal:
         dist.all_to_all_single(r, s, output_split_sizes=[c * tw for c in rc], input_split_sizes=[c * tw for c in counts], group=self.group)
         return r.reshape(-1, tw).to(dev)
 
-    def _share_frontier_bits(self):
+    def _share_frontier_bits(self, stats=(0, 0, 0)):
+        """All-gather of the ranks' new-frontier bits; three int64 per rank (discoveries, their out- and in-degree sums) ride behind the
+        bits, so the level needs no separate all-reduce.  Returns the three sums over all ranks."""
         bits = self._to_comm(self.engine.frontier_bits())
-        out = torch.empty(self.world * bits.numel(), dtype=bits.dtype, device=bits.device)
-        dist.all_gather_into_tensor(out, bits, group=self.group)
-        self.engine.merge_visited(out)
+        W = bits.numel()
+        tail = torch.tensor([int(x) for x in stats], dtype=torch.int64).view(torch.int32).to(bits.device)
+        msg = torch.cat([bits, tail])
+        out = torch.empty(self.world * msg.numel(), dtype=msg.dtype, device=msg.device)
+        dist.all_gather_into_tensor(out, msg, group=self.group)
+        out = out.view(self.world, W + 6)
+        gathered = out[:, :W].contiguous().view(-1)
+        self.engine.merge_visited(gathered)
+        self._front_bits = gathered  # the frontier of the next level (what a bottom-up level tests against)
+        return out[:, W:].contiguous().view(torch.int64).view(self.world, 3).sum(0).tolist()
 
     def run(self, sources, cutoff=FLT_MAX, compute_predecessors=True, depth_limit=None):
         """sources: external vertex ids (the same list on every rank).  Returns (vertices, distances, predecessors) of the
@@ -239,19 +313,46 @@ class MGTraversal:
         e.reset(mine.to(torch.int32), cutoff, compute_predecessors)
         if self.mode == 0:
             self._share_frontier_bits()
+        # Beamer's direction heuristic on GLOBAL sums (every rank takes the same decision): bottom-up when the frontier's out-edges exceed
+        # 1 / alpha of the unvisited vertices' in-edges, top-down again when the frontier has shrunk below V / beta (the single-GPU
+        # driver's constants: traversal.hip run_bfs)
+        bu_ok = self.mode == 0 and self.can_bottom_up
+        alpha, beta = float(os.environ.get("CUGRAPH_AMD_BFS_ALPHA", "60")), float(os.environ.get("CUGRAPH_AMD_BFS_BETA", "24"))
+        force = os.environ.get("CUGRAPH_AMD_MG_BFS", "")  # "bottomup" / "topdown": pin the direction (tests)
+        n_front = int(sources.numel())
+        frontier_out = int(self._out_deg[sources.to(self._out_deg.device)].sum()) if bu_ok else 0
+        unvisited_in = self.ne_global if bu_ok else 0
+        bottom_up = False
+        comm_dev = "cpu" if dist.get_backend(self.group) == "gloo" else e.device
         level = 0
+        self.bottom_up_levels = 0
         while True:
             level += 1
             if self.mode == 0 and depth_limit is not None and level > depth_limit:
                 break
-            send, counts = e.expand()
-            recv = self._exchange(send, counts)
-            n_next = e.apply(recv, level)
+            if bu_ok:
+                if not bottom_up:
+                    bottom_up = frontier_out > unvisited_in / alpha and n_front > 1024
+                else:
+                    bottom_up = not (n_front < self.nv / beta)
+                if force:
+                    bottom_up = force == "bottomup"
+            if bottom_up:
+                n_next = e.bottom_up(self._front_bits, level)
+                self.bottom_up_levels += 1
+            else:
+                send, counts = e.expand()
+                recv = self._exchange(send, counts)
+                n_next = e.apply(recv, level)
+            o_sum, i_sum = e.degree_sums() if bu_ok else (0, 0)
             if self.mode == 0:
-                self._share_frontier_bits()
-            tot = torch.tensor([n_next], dtype=torch.int64, device=(send.device if dist.get_backend(self.group) != "gloo" else "cpu"))
-            dist.all_reduce(tot, group=self.group)
-            if int(tot.item()) == 0:
+                n_front, frontier_out, i_tot = self._share_frontier_bits((n_next, o_sum, i_sum))
+                unvisited_in = max(0, unvisited_in - int(i_tot))
+            else:
+                tot = torch.tensor([n_next], dtype=torch.int64, device=comm_dev)
+                dist.all_reduce(tot, group=self.group)
+                n_front = int(tot.item())
+            if n_front == 0:
                 break
         self.levels = level
         d, p = e.results()

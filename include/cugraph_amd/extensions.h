@@ -153,6 +153,21 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_frontier_bits(
                                                                                 cugraph_error_t** error);
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_merge_visited(cugraph_amd_traversal_mg_plan_t* plan, const uint32_t* gathered,
                                                                                 cugraph_error_t** error);
+/* BFS, direction-optimising (replaces the bottom-up branch of bfs_impl.cuh:587-805 for the partitioned case): set_bottom_up hands over the
+ * in-edges of the local rows -- in_offsets [n_rows + 1], in_indices = in-neighbours as compact global ids in ascending order of their
+ * EXTERNAL id (the first frontier member of a row is then the minimum-external-id parent, the rule of the top-down levels), over-allocated
+ * by at least 8 entries -- and ext_of_g [comm_size * rows_per_rank] = external id of a compact global id (device, borrowed).  A bottom_up
+ * level scans the unvisited local rows against `front`, the all-gathered frontier bitmap of the previous level (comm_size * rows_per_rank
+ * bits): no candidate exchange, the discoveries are local; frontier_bits / merge_visited follow as after apply.  last_degree_sums: out- and
+ * in-degree sums of the vertices the last apply / bottom_up discovered on this rank (the two quantities of the direction heuristic). */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_set_bottom_up(cugraph_amd_traversal_mg_plan_t* plan, const int32_t* in_offsets,
+                                                                                const int32_t* in_indices, const int32_t* ext_of_g,
+                                                                                cugraph_error_t** error);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_bottom_up(cugraph_amd_traversal_mg_plan_t* plan, const uint32_t* front,
+                                                                            uint32_t level, size_t* n_found, cugraph_error_t** error);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_last_degree_sums(cugraph_amd_traversal_mg_plan_t* plan,
+                                                                                   unsigned long long* out_edges, unsigned long long* in_edges,
+                                                                                   cugraph_error_t** error);
 /* distances of the local rows (BFS: int32, INT32_MAX unreached; SSSP: float, FLT_MAX unreached) and predecessors (external ids, -1) */
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_results(cugraph_amd_traversal_mg_plan_t* plan, void* distances,
                                                                           int32_t* predecessors, cugraph_error_t** error);

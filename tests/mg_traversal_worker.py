@@ -30,14 +30,16 @@ def main():
     factory = NumpyTraversalEngine if engine == "numpy" else None
     if factory is None:
         torch.cuda.set_device(0)
+    levels = bu_levels = 0
     if algo == "bfs":
-        v, dd, pp = mt.bfs(torch.from_numpy(s), torch.from_numpy(d), nv, sources, depth_limit=(None if limit < 0 else int(limit)),
-                           engine_factory=factory)
+        t = mt.MGTraversal(torch.from_numpy(s), torch.from_numpy(d), nv, None, "bfs", None, factory)
+        v, dd, pp = t.run(sources, depth_limit=(None if limit < 0 else int(limit)))
+        levels, bu_levels = t.levels, t.bottom_up_levels
     else:
         w = np.random.default_rng(1).integers(1, 256, size=ne).astype(np.float32)[rank * per: rank * per + s.size].copy()
         v, dd, pp = mt.sssp(torch.from_numpy(s), torch.from_numpy(d), torch.from_numpy(w), nv, sources[0],
                             cutoff=(mt.FLT_MAX if limit < 0 else limit), engine_factory=factory)
-    np.savez(out_dir / f"rank{rank}.npz", v=v.cpu().numpy(), d=dd.cpu().numpy(), p=pp.cpu().numpy())
+    np.savez(out_dir / f"rank{rank}.npz", v=v.cpu().numpy(), d=dd.cpu().numpy(), p=pp.cpu().numpy(), levels=levels, bottom_up_levels=bu_levels)
     dist.barrier()
     dist.destroy_process_group()
 

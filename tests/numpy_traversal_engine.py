@@ -18,6 +18,46 @@ class NumpyTraversalEngine(TraversalEngine):
         self.row_vertex = row_vertex.numpy().astype(np.int64)
         self.tuple_words = 2 if mode == 0 else 3
         self.device = torch.device("cpu")
+        self.in_off = None
+        self.sums = (0, 0)
+
+    def enable_bottom_up(self, in_offsets, in_indices, ext_of_g):
+        self.in_off = in_offsets.numpy().astype(np.int64)
+        self.in_idx = in_indices.numpy().astype(np.int64)
+        self.ext_of_g = ext_of_g.numpy().astype(np.int64)
+        return True
+
+    def _degree_sums(self, rows):
+        if self.in_off is None:
+            return 0, 0
+        return int((self.off[rows + 1] - self.off[rows]).sum()), int((self.in_off[rows + 1] - self.in_off[rows]).sum())
+
+    def degree_sums(self):
+        return self.sums
+
+    def bottom_up(self, front_bits, level):
+        front = np.unpackbits(front_bits.numpy().view(np.uint8), bitorder="little").astype(bool)
+        mine = self.seen[self.rank * self.L: self.rank * self.L + self.n_rows]
+        rows = np.flatnonzero(~mine)
+        deg = self.in_off[rows + 1] - self.in_off[rows]
+        r = np.repeat(rows, deg)
+        pos = np.repeat(self.in_off[rows], deg) + (np.arange(int(deg.sum())) - np.repeat(np.cumsum(deg) - deg, deg))
+        g = self.in_idx[pos]
+        hit = front[g]
+        r, par = r[hit], self.ext_of_g[g[hit]]
+        self.new[:] = False
+        if r.size:
+            order = np.lexsort((par, r))
+            r, par = r[order], par[order]
+            first = np.ones(r.size, bool)
+            first[1:] = r[1:] != r[:-1]
+            r, par = r[first], par[first]  # the minimum external id among the frontier parents
+            self.dist[r] = level
+            self.pred[r] = par
+            self.new[r] = True
+        self.frontier = np.flatnonzero(self.new[: self.n_rows])
+        self.sums = self._degree_sums(self.frontier)
+        return int(self.frontier.size)
 
     def reset(self, source_rows, cutoff, with_pred):
         src = np.unique(source_rows.numpy().astype(np.int64))
@@ -83,6 +123,7 @@ class NumpyTraversalEngine(TraversalEngine):
                 np.minimum.at(self.pred, rows, par)
                 self.new[rows] = True
             self.frontier = np.flatnonzero(self.new[: self.n_rows])
+            self.sums = self._degree_sums(self.frontier)
         else:
             nxt = np.zeros(self.n_rows, bool)
             if r.size:

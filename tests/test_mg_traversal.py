@@ -23,12 +23,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_world(engine, algo, world, scale, tmp_path, sources, limit=-1.0):
+def run_world(engine, algo, world, scale, tmp_path, sources, limit=-1.0, direction="", stats=None):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", CUGRAPH_AMD_MG_BFS=direction)
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "mg_traversal_worker.py"), engine, algo, str(scale), str(tmp_path),
                                        ",".join(str(x) for x in sources), str(limit)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -44,6 +44,8 @@ def run_world(engine, algo, world, scale, tmp_path, sources, limit=-1.0):
         dist[r["v"]] = r["d"]
         pred[r["v"]] = r["p"]
     assert (seen == 1).all(), "every vertex must be owned by exactly one rank"
+    if stats is not None:
+        stats.update(levels=int(res[0]["levels"]), bottom_up_levels=int(res[0]["bottom_up_levels"]))
     return dist, pred
 
 
@@ -99,6 +101,24 @@ def test_mg_bfs_gloo_cpu(orc, tmp_path, world):
     check_bfs(orc, scale, src, dist, pred)
 
 
+@pytest.mark.parametrize("world,direction", [(2, "bottomup"), (3, "bottomup"), (2, "topdown"), (4, "")])
+def test_mg_bfs_gloo_cpu_directions(orc, tmp_path, world, direction):
+    """Direction-optimising partitioned BFS: every level bottom-up (each unvisited owned row scans its in-edges against the all-gathered
+    frontier bitmap; no candidate exchange), every level top-down, and the heuristic's mix -- same distances, same minimum-external-id
+    parents."""
+    scale = 12
+    src = pick_sources(orc, scale, 2)
+    st = {}
+    dist, pred = run_world("numpy", "bfs", world, scale, tmp_path, src, direction=direction, stats=st)
+    check_bfs(orc, scale, src, dist, pred)
+    if direction == "bottomup":
+        assert st["bottom_up_levels"] == st["levels"]
+    if direction == "topdown":
+        assert st["bottom_up_levels"] == 0
+    if direction == "":
+        assert 0 < st["bottom_up_levels"] < st["levels"]  # RMAT-12: the two widest levels run bottom-up
+
+
 def test_mg_bfs_gloo_cpu_depth_limit(orc, tmp_path):
     scale = 10
     src = pick_sources(orc, scale, 1)
@@ -128,6 +148,21 @@ def test_mg_bfs_hip_engine(orc, tmp_path, world):
     src = pick_sources(orc, scale, 3)
     dist, pred = run_world("hip", "bfs", world, scale, tmp_path, src)
     check_bfs(orc, scale, src, dist, pred)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,direction", [(1, "bottomup"), (2, "bottomup"), (4, "bottomup"), (2, "topdown"), (2, ""), (4, "")])
+def test_mg_bfs_hip_engine_directions(orc, tmp_path, world, direction):
+    """the bottom-up level of the partitioned HIP engine (k_bfs_bottom_up on the local in-edges, frontier = the all-gathered bitmap)"""
+    scale = 14
+    src = pick_sources(orc, scale, 2)
+    st = {}
+    dist, pred = run_world("hip", "bfs", world, scale, tmp_path, src, direction=direction, stats=st)
+    check_bfs(orc, scale, src, dist, pred)
+    if direction == "bottomup":
+        assert st["bottom_up_levels"] == st["levels"]
+    if direction == "":
+        assert 0 < st["bottom_up_levels"] < st["levels"]
 
 
 @pytest.mark.gpu
