@@ -102,6 +102,31 @@ struct mg_sssp_relax {
     }
     wq.push(fresh, g);
   }
+  // the phased form (expand_*_mlp of traversal_common.hpp: EX_U edges in flight per lane)
+  struct cand_t { unsigned long long packed; uint32_t bit; bool pass, claimed; };
+  using tok_t  = uint32_t;
+  using tok2_t = uint32_t;
+  __device__ __forceinline__ cand_t pre(int32_t u, int32_t g, eoff_t p) const
+  {  // branch-free
+    int32_t const us = u < 0 ? 0 : u, gs = g < 0 ? 0 : g;
+    float const nd   = __uint_as_float((uint32_t)(s.st[us] >> 32)) + s.weights[p];
+    unsigned long long const packed = ((unsigned long long)__float_as_uint(nd) << 32) | (uint32_t)(s.row_vertex[us] + 1);
+    unsigned long long const best   = __hip_atomic_load(&s.cand_best[gs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t const bit = 1u << (gs & 31);
+    bool const claimed = (__hip_atomic_load(&s.touched[gs >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) != 0;
+    bool const pass    = (g >= 0) & (nd < s.cutoff) & (packed < best);
+    return cand_t{packed, bit, pass, claimed};
+  }
+  __device__ __forceinline__ tok_t mid(int32_t g, cand_t c) const
+  {
+    if (c.pass) atomicMin(&s.cand_best[g], c.packed);
+    return 0u;
+  }
+  __device__ __forceinline__ tok2_t mid2(int32_t g, cand_t c, tok_t) const
+  {
+    return (c.pass && !c.claimed) ? (uint32_t)!(atomicOr(&s.touched[g >> 5], c.bit) & c.bit) : 0u;
+  }
+  __device__ __forceinline__ void post(int32_t, int32_t g, cand_t, tok_t, tok2_t fresh) { wq.push(fresh != 0u, g); }
 };
 
 struct keep_all_mg { __device__ __forceinline__ bool operator()(int32_t) const { return true; } };
@@ -129,7 +154,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_mg_sssp_expand(int32_t const* q, i
   __shared__ wave_queue_storage<1> wqs;
   wqs.init();
   mg_sssp_relax f{s, wave_queue(wqs, 0, s.cand, &s.cnt->n_next)};
-  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all_mg{}, f);
+  expand_frontier_mlp(q, n, offsets, indices, bigq, s.cnt, keep_all_mg{}, f);
   f.wq.flush();
 }
 __global__ void __launch_bounds__(TV_BLOCK) k_mg_sssp_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, mg_sssp_state s)
@@ -137,7 +162,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_mg_sssp_expand_big(int32_t const* 
   __shared__ wave_queue_storage<1> wqs;
   wqs.init();
   mg_sssp_relax f{s, wave_queue(wqs, 0, s.cand, &s.cnt->n_next)};
-  expand_big(bigq, offsets, indices, s.cnt, f);
+  expand_big_mlp(bigq, offsets, indices, s.cnt, f);
   f.wq.flush();
 }
 

@@ -28,6 +28,10 @@ cd "$R"
 for lay in 1d 2d; do
   timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus 2 --layout $lay --scale 24 --steps 10 --warmup 2 --cpu-scale 18 2>"$O/${TAG}_nccl1_$lay.err" > "$O/${TAG}_nccl1_$lay.json"; echo "nccl world-1 layout $lay rc=$?"; cut -c1-260 "$O/${TAG}_nccl1_$lay.json"; tail -2 "$O/${TAG}_nccl1_$lay.err" | cut -c1-200
 done
+# the partitioned traversals with one rank over RCCL (BFS direction-optimising; SSSP)
+timeout 600 python bench_traversal.py --partitioned --scale 24 --weights int --roots 16 2>/dev/null | grep "^{" > "$O/${TAG}_partitioned_s24.json"; cut -c1-400 "$O/${TAG}_partitioned_s24.json"
+# the N > 1 line at the full size with one rank (plan construction through the library primitives at 2^30 edges)
+timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29578 bench.py --gpus 2 --layout 1d --scale 26 --steps 10 --warmup 2 --cpu-scale 18 2>"$O/${TAG}_nccl1_1d_s26.err" > "$O/${TAG}_nccl1_1d_s26.json"; echo "nccl world-1 scale 26 rc=$?"; cut -c1-200 "$O/${TAG}_nccl1_1d_s26.json"
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob("gpurun_out/r3z_*.json")):
