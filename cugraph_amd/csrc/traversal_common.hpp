@@ -320,7 +320,7 @@ __device__ __forceinline__ void expand_frontier_mlp(int32_t const* q, int64_t n,
 #pragma unroll
       for (int k = 0; k < EX_U; ++k) {
         uint32_t const t = t0 + 64u * (uint32_t)k;
-        v[k] = -1; uu[k] = s_u[wave][0] < 0 ? 0 : s_u[wave][0]; pp[k] = s_beg[wave][0];  // (loadable stand-ins for "no edge")
+        v[k] = -1; uu[k] = 0; pp[k] = 0;  // (loadable stand-ins for "no edge": vertex 0, edge position 0 -- this loop runs only when edges exist)
         if (t < total) {
           int lo = 0, hi = 63;
 #pragma unroll
