@@ -10,6 +10,7 @@ Layout (only what the hot path needs):
 from .pylib import (  # noqa: F401
     FailedToConvergeError,
     GraphProperties,
+    MGGraph,
     PageRankPlan,
     ResourceHandle,
     SGGraph,

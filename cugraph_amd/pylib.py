@@ -227,6 +227,55 @@ class SGGraph:
         return int(capi.lib().cugraph_amd_graph_num_edges(self.c_graph_ptr))
 
 
+class MGGraph(SGGraph):
+    """graphs.pyx:357-700 MGGraph: this rank's slice of the edge list, as one array per column or as `num_arrays` lists of arrays
+    (cugraph_graph_create_with_times_mg concatenates them).  The library has no communicator: the call serves one-rank handles -- the
+    graph is built as SGGraph builds it, always renumbered (graph_mg.cpp:214) -- and a multi-rank job drives the per-rank plans of
+    cugraph_amd.mg / cugraph_amd.mg_traversal instead."""
+
+    def __init__(self, resource_handle, graph_properties, src_array, dst_array, weight_array=None, store_transposed=False,
+                 do_expensive_check=False, edge_id_array=None, edge_type_array=None, edge_start_time_array=None, edge_end_time_array=None,
+                 vertices_array=None, num_arrays=1, drop_self_loops=False, drop_multi_edges=False, symmetrize=False):
+        self.c_graph_ptr = None
+        l = capi.lib()
+        self.resource_handle = resource_handle
+
+        def as_list(a, name):
+            if a is None:
+                return None
+            seq = list(a) if isinstance(a, (list, tuple)) else [a]
+            if len(seq) != num_arrays:
+                raise ValueError(f"{name}: {len(seq)} arrays given, num_arrays = {num_arrays}")
+            for x in seq:
+                _describe(x)  # TypeError like assert_CAI_type
+            return seq
+
+        cols = [as_list(a, n) for a, n in ((vertices_array, "vertices_array"), (src_array, "src_array"), (dst_array, "dst_array"),
+                                           (weight_array, "weight_array"), (edge_id_array, "edge_id_array"), (edge_type_array, "edge_type_array"),
+                                           (edge_start_time_array, "edge_start_time_array"), (edge_end_time_array, "edge_end_time_array"))]
+        if cols[1] is None or cols[2] is None:
+            raise TypeError("src_array and dst_array are required")
+        views, ptr_arrays = [], []
+        for seq in cols:
+            if seq is None:
+                ptr_arrays.append(None)
+                continue
+            vs = [_View(x) for x in seq]
+            views += vs
+            ptr_arrays.append((C.c_void_p * num_arrays)(*[v.ptr for v in vs]))
+        g, err = C.c_void_p(), C.c_void_p()
+        _sync_torch()
+        try:
+            code = l.cugraph_graph_create_with_times_mg(
+                resource_handle.c_resource_handle_ptr, C.byref(graph_properties.c_graph_properties), *ptr_arrays, int(store_transposed),
+                int(num_arrays), int(drop_self_loops), int(drop_multi_edges), int(symmetrize), int(do_expensive_check), C.byref(g), C.byref(err))
+            assert_success(code, err, "cugraph_graph_create_with_times_mg()")
+        finally:
+            for v in views:
+                v.free()
+        self.c_graph_ptr = g
+
+
 def has_vertex(resource_handle, graph, vertices, do_expensive_check=False):
     """has_vertex.pyx:43"""
     l = capi.lib()

@@ -257,6 +257,36 @@ def test_pagerank_rmat_vs_oracle(cg, handle, orc, scale, weighted, renumber, tra
     assert abs(float(pr.astype(np.float64).sum()) - 1.0) < 1e-4  # mass conservation (dangling mass redistributed)
 
 
+def test_mggraph_one_rank_equals_sggraph(cg, handle, orc):
+    """pylibcugraph's MGGraph (graphs.pyx:357-700) on a one-rank handle: the rank's slice as three arrays per column
+    (cugraph_graph_create_with_times_mg concatenates them, always renumbers): PageRank, BFS and SSSP equal the oracle's."""
+    scale = 12
+    s, d = rmat_graph(orc, scale)
+    nv = 1 << scale
+    w = int_weights(s.size)
+    cut = [0, s.size // 3, s.size // 2, s.size]
+    parts = lambda a, t: [T(a[cut[i]: cut[i + 1]], t) for i in range(3)]  # noqa: E731
+    props = cg.GraphProperties(is_multigraph=True)
+    with pytest.raises(ValueError):
+        cg.MGGraph(handle, props, parts(s, np.int32), parts(d, np.int32)[:2], num_arrays=3)
+    g = cg.MGGraph(handle, props, parts(s, np.int32), parts(d, np.int32), parts(w, np.float32), store_transposed=False, num_arrays=3,
+                   vertices_array=[T(np.arange(nv), np.int32), T(np.zeros(0), np.int32), T(np.zeros(0), np.int32)])
+    assert g.num_vertices == nv and g.num_edges == s.size
+    v, pr, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 20, False, fail_on_nonconvergence=False)
+    (pr,) = by_vertex(v, pr)
+    off, idx, ww = orc.coo_to_cs(nv, d, s, w)
+    truth, _, _ = orc.pagerank(nv, off, idx, ww, 0.85, 0.0, 20, acc64=True)
+    assert np.max(np.abs(pr - truth)) <= 1e-6
+    off, idx, ww = orc.coo_to_cs(nv, s, d, w)
+    src = int(np.nonzero(np.diff(off) > 0)[0][1])
+    v, dist, _ = cg.sssp(handle, g, src, float(np.finfo(np.float32).max), False, False)
+    (dist,) = by_vertex(v, dist)
+    assert np.array_equal(dist, orc.sssp(nv, off, idx, ww, src)[0])
+    dist, _, v = cg.bfs(handle, g, T(np.array([src]), np.int32), False, 0, False, False)
+    (dist,) = by_vertex(v, dist)
+    assert np.array_equal(dist, orc.bfs(nv, off, idx, np.array([src], np.int32))[0])
+
+
 def test_pagerank_converged_iterations_and_initial_guess(cg, handle, orc):
     scale = 13
     s, d = rmat_graph(orc, scale, seed=5)
