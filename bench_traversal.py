@@ -100,19 +100,37 @@ def main_partitioned(args):
     dist.destroy_process_group()
 
 
-def kernel_source_hash():
-    """sha256 over the HIP sources of the library: profiles/traffic_latest.json is only believed when it was measured on this code."""
+# Which sources a counter figure depends on.  The collector differences two amounts of work, so graph construction cancels: a workload's
+# bytes per unit come from its own kernels, the headers they include and the handle / memory pool (core.hip).  Files outside a group
+# (graph build, generators, file readers, other algorithms) cannot change that workload's traffic.
+TRAFFIC_GROUPS = {
+    "pagerank": ["common.hpp", "core.hip", "wave_ops.hpp", "spmv_tiled.hpp", "spmv_tiled.hip", "pagerank.hip"],
+    "traversal": ["common.hpp", "core.hip", "traversal_common.hpp", "traversal_bottom_up.hpp", "traversal.hip", "graph.hip", "outer_ids.hip", "prims.hip"],
+    "louvain": ["common.hpp", "core.hip", "louvain.hip", "prims.hip"],
+}
+TRAFFIC_UNMEASURED = ["edgelist.hip", "graph_functions.hip", "mtx.hip", "rmat.hip", "traversal_mg.hip"]  # no entry of the counter file runs them per unit of work
+
+
+def traffic_group_of(key):
+    return "pagerank" if key.startswith("pagerank") else "louvain" if key.startswith("louvain") else "traversal"
+
+
+def kernel_source_hash(group=None):
+    """sha256 over the HIP sources of the library (group = None: all of csrc/; else the files of TRAFFIC_GROUPS[group]):
+    profiles/traffic_latest.json is only believed when it was measured on this code."""
     import hashlib
 
     hsh = hashlib.sha256()
-    for f in sorted((ROOT / "cugraph_amd" / "csrc").glob("*.h*")):
+    d = ROOT / "cugraph_amd" / "csrc"
+    files = sorted(d.glob("*.h*")) if group is None else [d / f for f in sorted(TRAFFIC_GROUPS[group])]
+    for f in files:
         hsh.update(f.name.encode())
         hsh.update(f.read_bytes())
     return hsh.hexdigest()[:16]
 
 
 def counter_traffic(key):
-    """(bytes, source) of a workload from profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/gpu_traffic.sh;
+    """(bytes, source) of a workload from profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/traffic_collect.py;
     FETCH_SIZE doubled per the gfx950 note of the guide).  The file names the source hash it was measured on: a stale file gives
     (None, reason) -- never a number from other kernels."""
     f = ROOT / "profiles" / "traffic_latest.json"
@@ -122,8 +140,12 @@ def counter_traffic(key):
         t = json.loads(f.read_text())
     except Exception as e:
         return None, f"profiles/traffic_latest.json unreadable: {e!r}"
-    if t.get("source_hash") != kernel_source_hash():
-        return None, f"STALE: profiles/traffic_latest.json was measured on source hash {t.get('source_hash')}, this build is {kernel_source_hash()} (re-run tools/gpu_traffic.sh)"
+    grp = traffic_group_of(key)
+    have, want = (t.get("group_hashes") or {}).get(grp), kernel_source_hash(grp)
+    if have is None:  # a file without per-workload hashes: the hash over all of csrc/ decides
+        have, want = t.get("source_hash"), kernel_source_hash()
+    if have != want:
+        return None, f"STALE: profiles/traffic_latest.json was measured on source hash {have} ({grp}), this build is {want} (re-run tools/traffic_collect.py)"
     e = t.get("entries", {}).get(key)
     if e is None:
         return None, f"profiles/traffic_latest.json has no entry {key}"

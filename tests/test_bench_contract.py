@@ -72,3 +72,37 @@ def test_traffic_file_matches_bench_line():
         assert r["traffic"] >= r["algorithmic_bytes_per_launch"]
     else:
         assert "STALE" in r["traffic_source"] or "absent" in r["traffic_source"] or "no entry" in r["traffic_source"]
+
+
+def test_traffic_hash_groups_cover_the_sources(tmp_path, monkeypatch):
+    """The counter file is keyed per workload by a hash over the sources that workload's kernels come from (bench_traversal.TRAFFIC_GROUPS).
+    Every file of csrc/ must be in a group or on the explicit list of files no measured unit of work runs -- a new source file cannot
+    silently escape the staleness check -- and an edit inside a group must turn exactly that group's figures stale."""
+    import sys
+
+    sys.path.insert(0, str(ROOT))
+    import bench_traversal as bt
+
+    files = {f.name for f in (ROOT / "cugraph_amd" / "csrc").glob("*.h*")}
+    grouped = set().union(*bt.TRAFFIC_GROUPS.values())
+    assert grouped <= files and set(bt.TRAFFIC_UNMEASURED) <= files
+    assert files == grouped | set(bt.TRAFFIC_UNMEASURED), files ^ (grouped | set(bt.TRAFFIC_UNMEASURED))
+    assert not (grouped & set(bt.TRAFFIC_UNMEASURED))
+    t = json.loads((ROOT / "profiles" / "traffic_latest.json").read_text())
+    assert set(t["group_hashes"]) == set(bt.TRAFFIC_GROUPS)
+    # a copy of the tree with one traversal source edited: PageRank's figure stays valid, the traversal figures go stale
+    import shutil
+
+    root2 = tmp_path / "repo"
+    (root2 / "cugraph_amd").mkdir(parents=True)
+    shutil.copytree(ROOT / "cugraph_amd" / "csrc", root2 / "cugraph_amd" / "csrc")
+    (root2 / "profiles").mkdir()
+    shutil.copy(ROOT / "profiles" / "traffic_latest.json", root2 / "profiles" / "traffic_latest.json")
+    monkeypatch.setattr(bt, "ROOT", root2)
+    fresh = t["group_hashes"]["pagerank"] == bt.kernel_source_hash("pagerank")  # (false while the sources are ahead of the committed collection)
+    with open(root2 / "cugraph_amd" / "csrc" / "traversal.hip", "a") as f:
+        f.write("// edited\n")
+    pr, why_pr = bt.counter_traffic("pagerank_s26")
+    bfs, why_bfs = bt.counter_traffic("bfs_s24_int")
+    assert bfs is None and "STALE" in why_bfs
+    assert (pr is not None) == fresh

@@ -20,12 +20,12 @@ ROOT = Path(__file__).resolve().parent.parent
 OUT = ROOT / "gpurun_out"
 
 
+sys.path.insert(0, str(ROOT))
+from bench_traversal import TRAFFIC_GROUPS, kernel_source_hash  # noqa: E402  (one definition of the hashes for collector and readers)
+
+
 def source_hash():
-    h = hashlib.sha256()
-    for f in sorted((ROOT / "cugraph_amd" / "csrc").glob("*.h*")):
-        h.update(f.name.encode())
-        h.update(f.read_bytes())
-    return h.hexdigest()[:16]
+    return kernel_source_hash()
 
 
 def counter_total(cmd, counter, tag):
@@ -87,7 +87,7 @@ def main():
             b = entries["bfs_s24_int"]
             entries[k] = dict(entries[k], hbm_bytes=entries[k]["hbm_bytes"] - b["hbm_bytes"], fetch_kib=round(entries[k]["fetch_kib"] - b["fetch_kib"], 1),
                               write_kib=round(entries[k]["write_kib"] - b["write_kib"], 1), unit="one SSSP (all rounds)")
-    out = {"source_hash": source_hash(), "source": "tools/traffic_collect.py on the GPU box: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs), totals over all dispatches, "
+    out = {"source_hash": source_hash(), "group_hashes": {g: kernel_source_hash(g) for g in TRAFFIC_GROUPS}, "groups": TRAFFIC_GROUPS, "source": "tools/traffic_collect.py on the GPU box: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs), totals over all dispatches, "
                                                    "differenced between two amounts of work; KiB x 1024; FETCH_SIZE x 2 per MI355X_MICROARCH.md (gfx950)",
            "entries": entries}
     (OUT / "traffic_latest.json").write_text(json.dumps(out, indent=1) + "\n")
