@@ -119,6 +119,14 @@ def test_mg_bfs_gloo_cpu_directions(orc, tmp_path, world, direction):
         assert 0 < st["bottom_up_levels"] < st["levels"]  # RMAT-12: the two widest levels run bottom-up
 
 
+@pytest.mark.parametrize("direction", ["bottomup", ""])
+def test_mg_bfs_gloo_cpu_tiny_graph_many_ranks(orc, tmp_path, direction):
+    """8 vertices over 5 ranks (partitions of one or two rows, padded to 64): the in-edge copy, the external-id table and the bitmaps hold."""
+    src = pick_sources(orc, 3, 1)
+    dist, pred = run_world("numpy", "bfs", 5, 3, tmp_path, src, direction=direction)
+    check_bfs(orc, 3, src, dist, pred)
+
+
 def test_mg_bfs_gloo_cpu_depth_limit(orc, tmp_path):
     scale = 10
     src = pick_sources(orc, scale, 1)
