@@ -74,7 +74,7 @@ struct mg_bfs_visit {
 };
 
 struct mg_sssp_state {
-  unsigned long long const* st;  // [n_rows] (distance bits << 32) | (parent external id + 1)
+  unsigned long long* st;        // [n_rows] (distance bits << 32) | (parent external id + 1)
   unsigned long long* cand_best; // [P * L] best candidate of this round per destination
   uint32_t* touched;
   float const* weights;
@@ -82,28 +82,24 @@ struct mg_sssp_state {
   int32_t* cand;
   counters_t* cnt;
   float cutoff;
+  // destinations this rank owns are relaxed IN PLACE (see mg_sssp_relax::pre): their range of compact ids, the round's dedup mark and the
+  // next local frontier (appends counted in cnt->n_far; apply continues behind them)
+  uint32_t own_lo, own_n;        // compact ids [own_lo, own_lo + own_n) = this rank's rows (own_n = 0: no shortcut)
+  uint32_t* mark;
+  int32_t* q_next;
+  uint32_t round;
 };
 
 struct mg_sssp_relax {
   mg_sssp_state s;
-  wave_queue wq;
-  __device__ __forceinline__ void operator()(int32_t u, int32_t g, eoff_t p)
-  {
-    float const du = __uint_as_float((uint32_t)(s.st[u] >> 32));
-    float const nd = du + s.weights[p];
-    bool fresh = false;
-    if (nd < s.cutoff) {  // strict, as sssp_impl.cuh:58-71
-      unsigned long long const packed = ((unsigned long long)__float_as_uint(nd) << 32) | (uint32_t)(s.row_vertex[u] + 1);  // parent + 1: 0 = none
-      if (packed < __hip_atomic_load(&s.cand_best[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        atomicMin(&s.cand_best[g], packed);
-        uint32_t const bit = 1u << (g & 31);
-        if (!(__hip_atomic_load(&s.touched[g >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) fresh = !(atomicOr(&s.touched[g >> 5], bit) & bit);
-      }
-    }
-    wq.push(fresh, g);
-  }
-  // the phased form (expand_*_mlp of traversal_common.hpp: EX_U edges in flight per lane)
-  struct cand_t { unsigned long long packed; uint32_t bit; bool pass, claimed; };
+  wave_queue wq, wq_own;
+  // the phased form (expand_*_mlp of traversal_common.hpp: EX_U edges in flight per lane).  A candidate whose destination THIS rank owns
+  // is applied in place -- atomicMin on st[row], round mark, append to the next local frontier -- instead of going through the candidate
+  // table, the bucket sort, the (self-)exchange and apply: an improvement is then visible to the rest of the round (Gauss-Seidel) where the
+  // exchanged ones become visible a round later (Jacobi).  With one rank that is every candidate: six sweeps over the edges become
+  // three (profiles/r3s_mgsssp_debug.log); with P ranks it is 1 / P of them.  The fixed point -- and the minimum-external-id parent
+  // among the tight in-edges -- does not depend on the schedule.
+  struct cand_t { unsigned long long packed; uint32_t bit; bool pass, claimed, own; };
   using tok_t  = uint32_t;
   using tok2_t = uint32_t;
   __device__ __forceinline__ cand_t pre(int32_t u, int32_t g, eoff_t p) const
@@ -111,22 +107,35 @@ struct mg_sssp_relax {
     int32_t const us = u < 0 ? 0 : u, gs = g < 0 ? 0 : g;
     float const nd   = __uint_as_float((uint32_t)(s.st[us] >> 32)) + s.weights[p];
     unsigned long long const packed = ((unsigned long long)__float_as_uint(nd) << 32) | (uint32_t)(s.row_vertex[us] + 1);
-    unsigned long long const best   = __hip_atomic_load(&s.cand_best[gs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool const own = ((uint32_t)gs - s.own_lo) < s.own_n;
+    unsigned long long const* const cur = own ? &s.st[(uint32_t)gs - s.own_lo] : &s.cand_best[gs];
+    unsigned long long const best = __hip_atomic_load(cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t const bit = 1u << (gs & 31);
     bool const claimed = (__hip_atomic_load(&s.touched[gs >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) != 0;
     bool const pass    = (g >= 0) & (nd < s.cutoff) & (packed < best);
-    return cand_t{packed, bit, pass, claimed};
+    return cand_t{packed, bit, pass, claimed, own};
   }
   __device__ __forceinline__ tok_t mid(int32_t g, cand_t c) const
-  {
-    if (c.pass) atomicMin(&s.cand_best[g], c.packed);
+  {  // -> 1: an owned destination's DISTANCE dropped (it must be expanded again)
+    if (!c.pass) return 0u;
+    if (c.own) {
+      unsigned long long const old = atomicMin(&s.st[(uint32_t)g - s.own_lo], c.packed);
+      return (uint32_t)(c.packed >> 32) < (uint32_t)(old >> 32) ? 1u : 0u;
+    }
+    atomicMin(&s.cand_best[g], c.packed);
     return 0u;
   }
-  __device__ __forceinline__ tok2_t mid2(int32_t g, cand_t c, tok_t) const
-  {
-    return (c.pass && !c.claimed) ? (uint32_t)!(atomicOr(&s.touched[g >> 5], c.bit) & c.bit) : 0u;
+  __device__ __forceinline__ tok2_t mid2(int32_t g, cand_t c, tok_t dropped) const
+  {  // -> 1: list g as a candidate for its owner; 2: append the owned row to the next local frontier
+    if (!c.pass) return 0u;
+    if (c.own) return (dropped && atomicExch(&s.mark[(uint32_t)g - s.own_lo], s.round) != s.round) ? 2u : 0u;
+    return !c.claimed ? (uint32_t)!(atomicOr(&s.touched[g >> 5], c.bit) & c.bit) : 0u;
   }
-  __device__ __forceinline__ void post(int32_t, int32_t g, cand_t, tok_t, tok2_t fresh) { wq.push(fresh != 0u, g); }
+  __device__ __forceinline__ void post(int32_t, int32_t g, cand_t, tok_t, tok2_t what)
+  {
+    wq.push(what == 1u, g);
+    wq_own.push(what == 2u, (int32_t)((uint32_t)g - s.own_lo));
+  }
 };
 
 struct keep_all_mg { __device__ __forceinline__ bool operator()(int32_t) const { return true; } };
@@ -151,19 +160,21 @@ __global__ void __launch_bounds__(TV_BLOCK) k_mg_bfs_expand_big(int32_t const* b
 __global__ void __launch_bounds__(TV_BLOCK) k_mg_sssp_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices, int32_t* bigq,
                                                              mg_sssp_state s)
 {
-  __shared__ wave_queue_storage<1> wqs;
+  __shared__ wave_queue_storage<2> wqs;
   wqs.init();
-  mg_sssp_relax f{s, wave_queue(wqs, 0, s.cand, &s.cnt->n_next)};
+  mg_sssp_relax f{s, wave_queue(wqs, 0, s.cand, &s.cnt->n_next), wave_queue(wqs, 1, s.q_next, &s.cnt->n_far)};
   expand_frontier_mlp(q, n, offsets, indices, bigq, s.cnt, keep_all_mg{}, f);
   f.wq.flush();
+  f.wq_own.flush();
 }
 __global__ void __launch_bounds__(TV_BLOCK) k_mg_sssp_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, mg_sssp_state s)
 {
-  __shared__ wave_queue_storage<1> wqs;
+  __shared__ wave_queue_storage<2> wqs;
   wqs.init();
-  mg_sssp_relax f{s, wave_queue(wqs, 0, s.cand, &s.cnt->n_next)};
+  mg_sssp_relax f{s, wave_queue(wqs, 0, s.cand, &s.cnt->n_next), wave_queue(wqs, 1, s.q_next, &s.cnt->n_far)};
   expand_big_mlp(bigq, offsets, indices, s.cnt, f);
   f.wq.flush();
+  f.wq_own.flush();
 }
 
 // ---- bucketing by owner: counting sort of the candidate list.  Workgroup b owns the contiguous slice
@@ -356,6 +367,11 @@ struct traversal_mg_plan {
   int32_t const* in_indices{nullptr};
   int32_t const* ext_of_g{nullptr};
   unsigned long long last_out{0}, last_in{0};
+  // SSSP: the relaxation round (dedup mark of expand's in-place relaxations and of apply) and the length of the next local frontier
+  // that expand has already written
+  uint32_t round{0};
+  size_t n_local{0};
+  bool own_in_place{true};
   int tuple_words() const { return mode == 0 ? 2 : 3; }
 };
 
@@ -437,6 +453,12 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_reset(cugraph_amd_
     size_t const G = p.L * (size_t)p.P, n1 = std::max<size_t>(p.n_rows, 1);
     p.with_pred = compute_predecessors == TRUE;
     p.cutoff    = cutoff >= (double)FLT_MAX ? FLT_MAX : (float)cutoff;
+    p.round     = 0;
+    p.n_local   = 0;
+    {
+      char const* e  = getenv("CUGRAPH_AMD_MG_SSSP_INPLACE");  // 0: every candidate through the exchange (A/B, tests)
+      p.own_in_place = !(e && atoi(e) == 0);
+    }
     HIP_TRY(hipMemsetAsync(p.touched.data(), 0, G / 8, h.stream));
     HIP_TRY(hipMemsetAsync(p.cnt.data(), 0, sizeof(counters_t), h.stream));
     p.q_cur  = p.q_a.data();
@@ -472,6 +494,7 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_expand(cugraph_amd
     HIP_TRY(hipSetDevice(h.device));
     HIP_TRY(hipMemsetAsync(p.cnt.data(), 0, sizeof(counters_t), h.stream));
     int64_t const n = (int64_t)p.n_frontier;
+    if (p.mode == 1) { ++p.round; p.n_local = 0; }
     if (n > 0) {
       int const g = expand_grid(h, n);
       timed_launch tl(h, p.mode == 0 ? "bfs_expand" : "sssp_relax");
@@ -480,7 +503,8 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_expand(cugraph_amd
         hipLaunchKernelGGL(k_mg_bfs_expand, g, TV_BLOCK, 0, h.stream, (int32_t const*)p.q_cur, n, p.offsets, p.indices, p.bigq.data(), s);
         hipLaunchKernelGGL(k_mg_bfs_expand_big, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)p.bigq.data(), p.offsets, p.indices, s);
       } else {
-        mg_sssp_state s{p.st.data(), p.cand_best.data(), p.touched.data(), p.weights, p.row_vertex, p.cand.data(), p.cnt.data(), p.cutoff};
+        mg_sssp_state s{p.st.data(), p.cand_best.data(), p.touched.data(), p.weights, p.row_vertex, p.cand.data(), p.cnt.data(), p.cutoff,
+                        (uint32_t)((size_t)p.rank * p.L), p.own_in_place ? (uint32_t)p.n_rows : 0u, p.mark.data(), p.q_next, p.round};
         hipLaunchKernelGGL(k_mg_sssp_expand, g, TV_BLOCK, 0, h.stream, (int32_t const*)p.q_cur, n, p.offsets, p.indices, p.bigq.data(), s);
         hipLaunchKernelGGL(k_mg_sssp_expand_big, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)p.bigq.data(), p.offsets, p.indices, s);
       }
@@ -505,6 +529,10 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_expand(cugraph_amd
     std::memcpy(&c, static_cast<char*>(h.pinned) + 1024, sizeof(c));
     c.fold();
     CGA_EXPECTS((size_t)c.n_next <= p.capacity, CUGRAPH_UNKNOWN_ERROR, "candidate list overflowed the send capacity");
+    if (p.mode == 1) {
+      p.n_local = c.n_far;  // owned destinations relaxed in place: the head of the next local frontier is written already
+      CGA_EXPECTS(p.n_local <= p.n_rows, CUGRAPH_UNKNOWN_ERROR, "next local frontier overflowed");
+    }
     for (int r = 0; r < p.P; ++r) {
       uint32_t const first = (uint32_t)tot.t[r];
       uint32_t const next  = r + 1 < p.P ? (uint32_t)(tot.t[r] >> 32) : c.n_next;
@@ -522,7 +550,14 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_apply(cugraph_amd_
     traversal_mg_plan& p = TP(plan);
     handle_t const& h    = *p.h;
     HIP_TRY(hipSetDevice(h.device));
-    HIP_TRY(hipMemsetAsync(p.cnt.data(), 0, sizeof(counters_t), h.stream));
+    if (p.mode == 1 && p.n_local > 0) {  // apply appends behind what expand put there
+      counters_t z{};
+      z.n_next = (uint32_t)p.n_local;
+      std::memcpy(h.pinned, &z, sizeof(z));
+      HIP_TRY(hipMemcpyAsync(p.cnt.data(), h.pinned, sizeof(z), hipMemcpyHostToDevice, h.stream));
+    } else {
+      HIP_TRY(hipMemsetAsync(p.cnt.data(), 0, sizeof(counters_t), h.stream));
+    }
     if (p.mode == 0) HIP_TRY(hipMemsetAsync(p.newfront.data(), 0, p.L / 8, h.stream));
     if (n_tuples) {
       int const g = (int)((n_tuples + 255) / 256);
@@ -530,13 +565,14 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_apply(cugraph_amd_
         hipLaunchKernelGGL(k_mg_bfs_apply, g, 256, 0, h.stream, recv, n_tuples, (int32_t)level, p.dist.data(), p.with_pred ? p.pred.data() : (int32_t*)nullptr,
                            p.q_next, p.newfront.data(), p.cnt.data(), p.offsets, p.in_offsets);
       else
-        hipLaunchKernelGGL(k_mg_sssp_apply, g, 256, 0, h.stream, recv, n_tuples, level, p.st.data(), p.mark.data(), p.q_next, p.cnt.data());
+        hipLaunchKernelGGL(k_mg_sssp_apply, g, 256, 0, h.stream, recv, n_tuples, p.round, p.st.data(), p.mark.data(), p.q_next, p.cnt.data());
     }
     counters_t c{};
     h.read_back(&c, p.cnt.data(), 1);
     c.fold();
     std::swap(p.q_cur, p.q_next);
     p.n_frontier = c.n_next;
+    p.n_local    = 0;
     p.last_out   = c.out_edges;
     p.last_in    = c.in_edges;
     *n_next      = c.n_next;

@@ -23,12 +23,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_world(engine, algo, world, scale, tmp_path, sources, limit=-1.0, direction="", stats=None):
+def run_world(engine, algo, world, scale, tmp_path, sources, limit=-1.0, direction="", stats=None, extra_env=None):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", CUGRAPH_AMD_MG_BFS=direction)
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", CUGRAPH_AMD_MG_BFS=direction, **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "mg_traversal_worker.py"), engine, algo, str(scale), str(tmp_path),
                                        ",".join(str(x) for x in sources), str(limit)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -182,11 +182,14 @@ def test_mg_bfs_hip_engine_depth_limit(orc, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [1, 2, 4])
-def test_mg_sssp_hip_engine(orc, tmp_path, world):
+@pytest.mark.parametrize("world,in_place", [(1, "1"), (2, "1"), (4, "1"), (3, "1"), (1, "0"), (2, "0")])
+def test_mg_sssp_hip_engine(orc, tmp_path, world, in_place):
+    """in_place = 1 (default): candidates whose destination the expanding rank owns are relaxed in place during expand (with one rank:
+    all of them -- nothing is exchanged); 0: every candidate goes through the sender-side table, the exchange and apply.  Same fixed point:
+    distances bit-identical to Dijkstra, minimum-external-id parents among the tight in-edges."""
     scale = 13
     src = pick_sources(orc, scale, 1)
-    dist, pred = run_world("hip", "sssp", world, scale, tmp_path, src)
+    dist, pred = run_world("hip", "sssp", world, scale, tmp_path, src, extra_env={"CUGRAPH_AMD_MG_SSSP_INPLACE": in_place})
     check_sssp(orc, scale, src[0], dist, pred)
 
 
