@@ -169,7 +169,7 @@ PROTOTYPES = {
     "cugraph_amd_pagerank_mg_plan_free": (None, [_P]),
     "cugraph_amd_sort_pairs_u64_u32": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.c_int, _PP]),
     "cugraph_amd_exclusive_scan_u32": (C.c_int, [_P, _P, _P, C.c_size_t, _PP]),
-    "cugraph_amd_pagerank_mg2d_plan_create": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _P, _P, _P, _P, _P, _P, _P, C.c_double, _PP, _PP]),
+    "cugraph_amd_pagerank_mg2d_plan_create": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _P, _P, _P, _P, _P, _P, _P, C.c_double, _PP, _PP]),
     "cugraph_amd_pagerank_mg2d_plan_start": (C.c_int, [_P, _PP]),
     "cugraph_amd_pagerank_mg2d_plan_set_scalars": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _PP]),
     "cugraph_amd_pagerank_mg2d_plan_spmv": (C.c_int, [_P, _PP]),
@@ -188,6 +188,12 @@ PROTOTYPES = {
     "cugraph_amd_traversal_mg_plan_last_degree_sums": (C.c_int, [_P, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), _PP]),
     "cugraph_amd_traversal_mg_plan_results": (C.c_int, [_P, _P, _P, _PP]),
     "cugraph_amd_traversal_mg_plan_free": (None, [_P]),
+    "cugraph_amd_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _PP, _PP]),
+    "cugraph_amd_comm_free": (None, [_P]),
+    "cugraph_amd_comm_host_selftest": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, _PP]),
+    "cugraph_amd_comm_rank": (C.c_int, [_P]),
+    "cugraph_amd_comm_size": (C.c_int, [_P]),
+    "cugraph_amd_comm_selftest": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_double), _PP]),
     "cugraph_amd_read_matrix_market": (C.c_int, [_P, C.c_char_p, _PP, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int), _PP]),
     "cugraph_amd_handle_set_stream": (C.c_int, [_P, _P, _PP]),
     "cugraph_amd_handle_sync": (C.c_int, [_P, _PP]),

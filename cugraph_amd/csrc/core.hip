@@ -1,6 +1,7 @@
 // Handle, error and type-erased array entry points of the drop-in libcugraph_c.so.
 // Replaces cpp/src/c_api/resource_handle.cpp:11-39, cpp/src/c_api/error.cpp, cpp/src/c_api/array.cpp.
 #include "common.hpp"
+#include "comm.hpp"
 
 using namespace cga;
 
@@ -16,11 +17,17 @@ extern "C" void cugraph_error_free(cugraph_error_t* error) { delete reinterpret_
 // ------------------------------------------------------------------------------------------ handle
 extern "C" cugraph_resource_handle_t* cugraph_create_resource_handle(void* raft_handle)
 {
-  // A non-NULL argument is a raft::handle_t* in the reference (resource_handle.hpp:12-25); RAFT does not
-  // exist on this platform, so only the library-owned context (NULL) is supported.
-  if (raft_handle != nullptr) return nullptr;
+  // A non-NULL argument is a raft::handle_t* in the reference (resource_handle.hpp:12-25), i.e. the object that carries the
+  // communicator.  RAFT does not exist on this platform; the library's own communicator (cugraph_amd_comm_create, comm.hpp) takes
+  // its place: the handle then reports that communicator's rank / size and the MG entry points become collective.
+  comm_t* comm = nullptr;
+  if (raft_handle != nullptr) {
+    comm = static_cast<comm_t*>(raft_handle);
+    if (comm->magic != kCommMagic) return nullptr;
+  }
   try {
     auto h = std::make_unique<handle_t>();
+    if (comm) { h->comm = comm; h->rank = comm->rank; h->comm_size = comm->size; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { (void)hipGetLastError(); return nullptr; }
     HIP_TRY(hipGetDevice(&h->device));

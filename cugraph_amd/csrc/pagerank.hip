@@ -1083,6 +1083,7 @@ __global__ void k_mg_fold_tails(WT const* recv, int64_t const* tail_off /*[P] el
 }
 
 struct pagerank_mg_plan_base {
+  handle_t const* hp{nullptr};  // the entry points name its stream to the memory pool (frees / reuses are ordered on it)
   virtual ~pagerank_mg_plan_base() = default;
   virtual void start()                                           = 0;
   virtual void reduce_scalars(bool read_back, double* diff, double* dangling) = 0;
@@ -1112,6 +1113,7 @@ struct pagerank_mg_plan : pagerank_mg_plan_base {
   pagerank_mg_plan(handle_t const& h_, graph_t& g_, double alpha_, int64_t n_rows_, int64_t nv_global_, int rank_, int size_)
     : h(h_), g(g_), alpha((WT)alpha_), n_rows(n_rows_), nv_global(nv_global_), rank(rank_), size(size_)
   {
+    hp = &h_;
   }
 
   void create(device_array_view_t const* outw_local, device_array_view_t const* init_local, device_array_view_t const* send_index_v,
@@ -1321,6 +1323,7 @@ __global__ void __launch_bounds__(256) k_mg2d_epilogue(WT const* y_own, WT const
 }
 
 struct pagerank_mg2d_plan_base {
+  handle_t const* hp{nullptr};
   virtual ~pagerank_mg2d_plan_base() = default;
   virtual void start()                                                          = 0;
   virtual void set_scalars(void const* gathered, int nranks, bool read_back, double* diff, double* dangling) = 0;
@@ -1334,7 +1337,7 @@ struct pagerank_mg2d_plan : pagerank_mg2d_plan_base {
   handle_t const& h;
   graph_t& g;
   WT alpha;
-  int64_t L, n_block_rows, n_block_cols, nv_global;
+  int64_t L, n_own, n_block_rows, n_block_cols, nv_global;  // n_own <= L: owned rows that are vertices (the last partitions are padded)
   dvec<WT> pr, outw, part, x_pad;
   WT* x_own{nullptr};    // [L]        caller-owned: this rank's x = pr / out_w (input of the column all-gather)
   WT const* x_cols{nullptr};  // [R * L]  caller-owned: the gathered x of the column group
@@ -1347,15 +1350,17 @@ struct pagerank_mg2d_plan : pagerank_mg2d_plan_base {
   std::shared_ptr<tiled_csc_t> tc;
   int epi_grid{1};
 
-  pagerank_mg2d_plan(handle_t const& h_, graph_t& g_, double alpha_, int64_t L_, int64_t rows_, int64_t cols_, int64_t nv_global_)
-    : h(h_), g(g_), alpha((WT)alpha_), L(L_), n_block_rows(rows_), n_block_cols(cols_), nv_global(nv_global_)
+  pagerank_mg2d_plan(handle_t const& h_, graph_t& g_, double alpha_, int64_t L_, int64_t n_own_, int64_t rows_, int64_t cols_, int64_t nv_global_)
+    : h(h_), g(g_), alpha((WT)alpha_), L(L_), n_own(n_own_), n_block_rows(rows_), n_block_cols(cols_), nv_global(nv_global_)
   {
+    hp = &h_;
   }
 
   void create(device_array_view_t const* outw_own, device_array_view_t const* init_own, device_array_view_t const* x_own_v, device_array_view_t const* x_cols_v,
               device_array_view_t const* y_part_v, device_array_view_t const* y_own_v, device_array_view_t const* triple_v)
   {
     HIP_TRY(hipSetDevice(h.device));
+    CGA_EXPECTS(n_own >= 0 && n_own <= L, CUGRAPH_INVALID_INPUT, "2-D multi-GPU PageRank: owned rows must not exceed rows_per_partition");
     auto typed = [&](device_array_view_t const* v, int64_t n) { return v != nullptr && v->type == g.weight_type && (int64_t)v->size == n; };
     CGA_EXPECTS(typed(outw_own, L) && typed(x_own_v, L) && typed(y_own_v, L) && typed(x_cols_v, n_block_cols) && typed(y_part_v, n_block_rows), CUGRAPH_INVALID_INPUT,
                 "2-D multi-GPU PageRank: out_weight_sums / x_own / y_own need L values, x_cols R * L, y_part C * L, all of the weight type");
@@ -1376,7 +1381,13 @@ struct pagerank_mg2d_plan : pagerank_mg2d_plan_base {
       CGA_EXPECTS(typed(init_own, L), CUGRAPH_INVALID_INPUT, "initial guess: one value per owned row");
       if (L > 0) HIP_TRY(hipMemcpyAsync(pr.data(), init_own->data, L * sizeof(WT), hipMemcpyDeviceToDevice, h.stream));
     } else {
-      fill_wt<WT>(h, pr.data(), L, WT(1) / (WT)nv_global);
+      fill_wt<WT>(h, pr.data(), n_own, WT(1) / (WT)nv_global);
+    }
+    // padded rows [n_own, L) are not vertices: they hold 0 and stay out of the dangling mass / L1 change (their x_own is 0 as well, so
+    // the all-gathered column block reads 0 where no vertex is)
+    if (L > n_own) {
+      HIP_TRY(hipMemsetAsync(pr.data() + n_own, 0, (size_t)(L - n_own) * sizeof(WT), h.stream));
+      HIP_TRY(hipMemsetAsync(x_own + n_own, 0, (size_t)(L - n_own) * sizeof(WT), h.stream));
     }
     int const T = tiled_default_T(h, sizeof(WT), std::max<int64_t>(n_block_cols, 1));
     if (!o.tiled || o.tiled->T != T || o.tiled->nv != n_block_rows) {
@@ -1392,7 +1403,7 @@ struct pagerank_mg2d_plan : pagerank_mg2d_plan_base {
     HIP_TRY(hipMemsetAsync(x_pad.data(), 0, nx * sizeof(WT), h.stream));
     counters.resize_discard(4);
     HIP_TRY(hipMemsetAsync(counters.data(), 0, 4 * sizeof(uint32_t), h.stream));
-    epi_grid = std::max(1, std::min(grid_for(L, 256, 1024), 1024));
+    epi_grid = std::max(1, std::min(grid_for(n_own, 256, 1024), 1024));
     tpartials.resize_discard((size_t)3 * std::max({tc->nI, 1024, epi_grid}));
     h.sync();
   }
@@ -1409,8 +1420,8 @@ struct pagerank_mg2d_plan : pagerank_mg2d_plan_base {
   void start() override
   {  // x_own <- x of the initial vector, triple <- (0, partial dangling mass, max |x|)
     HIP_TRY(hipSetDevice(h.device));
-    int const grid = std::max(1, std::min(grid_for(L, 256, 1024), 1024));
-    hipLaunchKernelGGL(k_tiled_prologue_plain<WT>, grid, 256, 0, h.stream, (WT const*)pr.data(), (WT const*)outw.data(), x_own, L, tpartials.data());
+    int const grid = std::max(1, std::min(grid_for(n_own, 256, 1024), 1024));
+    hipLaunchKernelGGL(k_tiled_prologue_plain<WT>, grid, 256, 0, h.stream, (WT const*)pr.data(), (WT const*)outw.data(), x_own, n_own, tpartials.data());
     tiled_finish<WT>(h, epi(), grid);
     h.sync();
   }
@@ -1437,7 +1448,7 @@ struct pagerank_mg2d_plan : pagerank_mg2d_plan_base {
   }
   void epilogue() override
   {
-    hipLaunchKernelGGL(k_mg2d_epilogue<WT>, epi_grid, 256, 0, h.stream, y_own, (WT const*)outw.data(), pr.data(), x_own, L, (pr_scalars<WT> const*)scal.data(),
+    hipLaunchKernelGGL(k_mg2d_epilogue<WT>, epi_grid, 256, 0, h.stream, y_own, (WT const*)outw.data(), pr.data(), x_own, n_own, (pr_scalars<WT> const*)scal.data(),
                        tpartials.data());
     tiled_finish<WT>(h, epi(), epi_grid);  // this rank's (L1 change, dangling, max |x|) -> triple
     done();
@@ -1635,6 +1646,25 @@ extern "C" cugraph_error_code_t cugraph_amd_pagerank_plan_result(cugraph_amd_pag
 extern "C" void cugraph_amd_pagerank_plan_free(cugraph_amd_pagerank_plan_t* plan) { delete reinterpret_cast<pagerank_plan_base*>(plan); }
 
 // ---- multi-GPU plan API (include/cugraph_amd/extensions.h) ---------------------------------------
+namespace {
+// a stepping / free entry point of a multi-GPU plan: NULL is reported, and the plan's stream is named to the memory pool (the handle may
+// have borrowed another stream since the plan was created; blocks freed by this call must be ordered on the stream the kernels ran on)
+pagerank_mg_plan_base* P1D(cugraph_amd_pagerank_mg_plan_t* plan)
+{
+  CGA_EXPECTS(plan != nullptr, CUGRAPH_INVALID_INPUT, "plan is NULL");
+  auto* p = reinterpret_cast<pagerank_mg_plan_base*>(plan);
+  pool_set_stream(p->hp->stream);
+  return p;
+}
+pagerank_mg2d_plan_base* P2D(cugraph_amd_pagerank_mg2d_plan_t* plan)
+{
+  CGA_EXPECTS(plan != nullptr, CUGRAPH_INVALID_INPUT, "plan is NULL");
+  auto* p = reinterpret_cast<pagerank_mg2d_plan_base*>(plan);
+  pool_set_stream(p->hp->stream);
+  return p;
+}
+}  // namespace
+
 extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg_plan_create(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
                                                                     size_t n_local_rows, size_t global_num_vertices, int comm_rank, int comm_size,
                                                                     const cugraph_type_erased_device_array_view_t* out_weight_sums_local,
@@ -1662,31 +1692,36 @@ extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg_plan_create(const cugrap
 }
 extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg_plan_start(cugraph_amd_pagerank_mg_plan_t* plan, cugraph_error_t** error)
 {
-  return guarded(error, [&] { CGA_EXPECTS(plan, CUGRAPH_INVALID_INPUT, "plan is NULL"); reinterpret_cast<pagerank_mg_plan_base*>(plan)->start(); });
+  return guarded(error, [&] { P1D(plan)->start(); });
 }
 extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg_plan_reduce_scalars(cugraph_amd_pagerank_mg_plan_t* plan, bool_t read_back, double* diff,
                                                                             double* dangling, cugraph_error_t** error)
 {
   return guarded(error, [&] {
-    CGA_EXPECTS(plan, CUGRAPH_INVALID_INPUT, "plan is NULL");
-    reinterpret_cast<pagerank_mg_plan_base*>(plan)->reduce_scalars(read_back == TRUE, diff, dangling);
+    P1D(plan)->reduce_scalars(read_back == TRUE, diff, dangling);
   });
 }
 extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg_plan_local_step(cugraph_amd_pagerank_mg_plan_t* plan, cugraph_error_t** error)
 {
-  return guarded(error, [&] { CGA_EXPECTS(plan, CUGRAPH_INVALID_INPUT, "plan is NULL"); reinterpret_cast<pagerank_mg_plan_base*>(plan)->local_step(); });
+  return guarded(error, [&] { P1D(plan)->local_step(); });
 }
 extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg_plan_values(cugraph_amd_pagerank_mg_plan_t* plan,
                                                                     cugraph_type_erased_device_array_view_t* out_local, cugraph_error_t** error)
 {
-  return guarded(error, [&] { CGA_EXPECTS(plan, CUGRAPH_INVALID_INPUT, "plan is NULL"); reinterpret_cast<pagerank_mg_plan_base*>(plan)->values(V(out_local)); });
+  return guarded(error, [&] { P1D(plan)->values(V(out_local)); });
 }
-extern "C" void cugraph_amd_pagerank_mg_plan_free(cugraph_amd_pagerank_mg_plan_t* plan) { delete reinterpret_cast<pagerank_mg_plan_base*>(plan); }
+extern "C" void cugraph_amd_pagerank_mg_plan_free(cugraph_amd_pagerank_mg_plan_t* plan)
+{
+  if (!plan) return;
+  auto* p = reinterpret_cast<pagerank_mg_plan_base*>(plan);
+  pool_set_stream(p->hp->stream);
+  delete p;
+}
 
 // ---- 2-D layout (see pagerank_mg2d_plan)
 extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_create(
-  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, size_t rows_per_partition, size_t block_rows, size_t block_cols, size_t global_num_vertices,
-  const cugraph_type_erased_device_array_view_t* out_weight_sums_own, const cugraph_type_erased_device_array_view_t* initial_own,
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, size_t rows_per_partition, size_t owned_rows, size_t block_rows, size_t block_cols,
+  size_t global_num_vertices, const cugraph_type_erased_device_array_view_t* out_weight_sums_own, const cugraph_type_erased_device_array_view_t* initial_own,
   cugraph_type_erased_device_array_view_t* x_own, const cugraph_type_erased_device_array_view_t* x_cols, cugraph_type_erased_device_array_view_t* y_part,
   const cugraph_type_erased_device_array_view_t* y_own, cugraph_type_erased_device_array_view_t* triple, double alpha, cugraph_amd_pagerank_mg2d_plan_t** plan,
   cugraph_error_t** error)
@@ -1698,11 +1733,11 @@ extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_create(
     CGA_EXPECTS(plan != nullptr, CUGRAPH_INVALID_INPUT, "plan is NULL");
     CGA_EXPECTS(alpha >= 0.0 && alpha <= 1.0, CUGRAPH_INVALID_INPUT, "Invalid input argument: alpha should be in [0.0, 1.0].");
     if (g.weight_type == FLOAT64) {
-      auto p = std::make_unique<pagerank_mg2d_plan<double>>(h, g, alpha, (int64_t)rows_per_partition, (int64_t)block_rows, (int64_t)block_cols, (int64_t)global_num_vertices);
+      auto p = std::make_unique<pagerank_mg2d_plan<double>>(h, g, alpha, (int64_t)rows_per_partition, (int64_t)owned_rows, (int64_t)block_rows, (int64_t)block_cols, (int64_t)global_num_vertices);
       p->create(V(out_weight_sums_own), V(initial_own), V(x_own), V(x_cols), V(y_part), V(y_own), V(triple));
       *plan = reinterpret_cast<cugraph_amd_pagerank_mg2d_plan_t*>(static_cast<pagerank_mg2d_plan_base*>(p.release()));
     } else {
-      auto p = std::make_unique<pagerank_mg2d_plan<float>>(h, g, alpha, (int64_t)rows_per_partition, (int64_t)block_rows, (int64_t)block_cols, (int64_t)global_num_vertices);
+      auto p = std::make_unique<pagerank_mg2d_plan<float>>(h, g, alpha, (int64_t)rows_per_partition, (int64_t)owned_rows, (int64_t)block_rows, (int64_t)block_cols, (int64_t)global_num_vertices);
       p->create(V(out_weight_sums_own), V(initial_own), V(x_own), V(x_cols), V(y_part), V(y_own), V(triple));
       *plan = reinterpret_cast<cugraph_amd_pagerank_mg2d_plan_t*>(static_cast<pagerank_mg2d_plan_base*>(p.release()));
     }
@@ -1710,24 +1745,33 @@ extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_create(
 }
 extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_start(cugraph_amd_pagerank_mg2d_plan_t* plan, cugraph_error_t** error)
 {
-  return guarded(error, [&] { reinterpret_cast<pagerank_mg2d_plan_base*>(plan)->start(); });
+  return guarded(error, [&] { P2D(plan)->start(); });
 }
 extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_set_scalars(cugraph_amd_pagerank_mg2d_plan_t* plan, const void* gathered_triples, int comm_size,
                                                                           bool_t read_back, double* diff, double* dangling, cugraph_error_t** error)
 {
-  return guarded(error, [&] { reinterpret_cast<pagerank_mg2d_plan_base*>(plan)->set_scalars(gathered_triples, comm_size, read_back == TRUE, diff, dangling); });
+  return guarded(error, [&] {
+    CGA_EXPECTS(gathered_triples != nullptr && comm_size >= 1, CUGRAPH_INVALID_INPUT, "set_scalars: gathered triples / comm_size");
+    P2D(plan)->set_scalars(gathered_triples, comm_size, read_back == TRUE, diff, dangling);
+  });
 }
 extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_spmv(cugraph_amd_pagerank_mg2d_plan_t* plan, cugraph_error_t** error)
 {
-  return guarded(error, [&] { reinterpret_cast<pagerank_mg2d_plan_base*>(plan)->spmv(); });
+  return guarded(error, [&] { P2D(plan)->spmv(); });
 }
 extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_epilogue(cugraph_amd_pagerank_mg2d_plan_t* plan, cugraph_error_t** error)
 {
-  return guarded(error, [&] { reinterpret_cast<pagerank_mg2d_plan_base*>(plan)->epilogue(); });
+  return guarded(error, [&] { P2D(plan)->epilogue(); });
 }
 extern "C" cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_values(cugraph_amd_pagerank_mg2d_plan_t* plan, cugraph_type_erased_device_array_view_t* out_own,
                                                                      cugraph_error_t** error)
 {
-  return guarded(error, [&] { reinterpret_cast<pagerank_mg2d_plan_base*>(plan)->values(V(out_own)); });
+  return guarded(error, [&] { P2D(plan)->values(V(out_own)); });
 }
-extern "C" void cugraph_amd_pagerank_mg2d_plan_free(cugraph_amd_pagerank_mg2d_plan_t* plan) { delete reinterpret_cast<pagerank_mg2d_plan_base*>(plan); }
+extern "C" void cugraph_amd_pagerank_mg2d_plan_free(cugraph_amd_pagerank_mg2d_plan_t* plan)
+{
+  if (!plan) return;
+  auto* p = reinterpret_cast<pagerank_mg2d_plan_base*>(plan);
+  pool_set_stream(p->hp->stream);
+  delete p;
+}

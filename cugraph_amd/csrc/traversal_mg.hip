@@ -380,7 +380,14 @@ struct traversal_mg_plan {
 
 using namespace cga;
 
-static traversal_mg_plan& TP(cugraph_amd_traversal_mg_plan_t* p) { return *reinterpret_cast<traversal_mg_plan*>(p); }
+// every entry point goes through here: the plan's stream is named to the memory pool, so blocks freed / reused by the call are ordered on the
+// stream its kernels run on (the handle may have borrowed another stream since the plan was created)
+static traversal_mg_plan& TP(cugraph_amd_traversal_mg_plan_t* p)
+{
+  auto& plan = *reinterpret_cast<traversal_mg_plan*>(p);
+  if (plan.h) pool_set_stream(plan.h->stream);
+  return plan;
+}
 
 extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_create(const cugraph_resource_handle_t* handle, const int32_t* offsets,
                                                                      const int32_t* indices, const float* weights, size_t n_rows, size_t n_edges,
@@ -439,7 +446,10 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_create(const cugra
   });
 }
 
-extern "C" void cugraph_amd_traversal_mg_plan_free(cugraph_amd_traversal_mg_plan_t* plan) { delete reinterpret_cast<traversal_mg_plan*>(plan); }
+extern "C" void cugraph_amd_traversal_mg_plan_free(cugraph_amd_traversal_mg_plan_t* plan)
+{
+  if (plan) delete &TP(plan);
+}
 
 extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_reset(cugraph_amd_traversal_mg_plan_t* plan, const int32_t* source_rows,
                                                                     size_t n_sources, double cutoff, bool_t compute_predecessors,

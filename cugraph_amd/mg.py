@@ -574,7 +574,7 @@ class HipLocalEngine2D(LocalEngine2D):
         plan, err = C.c_void_p(), C.c_void_p()
         torch.cuda.current_stream().synchronize()
         code = capi.lib().cugraph_amd_pagerank_mg2d_plan_create(
-            self.handle.c_resource_handle_ptr, self.graph.c_graph_ptr, L, Cc * L, R * L, part.nv, views[0].ptr, views[1].ptr, views[2].ptr, views[3].ptr,
+            self.handle.c_resource_handle_ptr, self.graph.c_graph_ptr, L, part.n_rows, Cc * L, R * L, part.nv, views[0].ptr, views[1].ptr, views[2].ptr, views[3].ptr,
             views[4].ptr, views[5].ptr, views[6].ptr, float(alpha), C.byref(plan), C.byref(err))
         for v in views:
             v.free()

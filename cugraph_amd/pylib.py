@@ -107,19 +107,53 @@ def copy_to_torch(handle_ptr, view_ptr):
     return out
 
 
+class Comm:
+    """The library's one-node communicator (include/cugraph_amd/extensions.h: cugraph_amd_comm_create; csrc/comm.hpp): one process per
+    rank, HIP IPC windows, direct peer writes.  Collective constructor: every rank passes the same session name and size."""
+
+    def __init__(self, session: str, rank: int, size: int):
+        if not torch.cuda.is_available():
+            raise RuntimeError("cugraph_amd needs a HIP device; there is no CPU fallback")
+        torch.cuda.init()
+        torch.cuda.current_device()
+        ptr, err = C.c_void_p(), C.c_void_p()
+        assert_success(capi.lib().cugraph_amd_comm_create(session.encode(), int(rank), int(size), C.byref(ptr), C.byref(err)), err, "cugraph_amd_comm_create")
+        self.c_comm_ptr = ptr
+        self.rank, self.size = int(rank), int(size)
+
+    def close(self):
+        p = getattr(self, "c_comm_ptr", None)
+        if p:
+            capi.lib().cugraph_amd_comm_free(p)
+            self.c_comm_ptr = None
+
+    def __del__(self):
+        self.close()
+
+
 class ResourceHandle:
     """resource_handle.pyx: RAII wrapper of cugraph_resource_handle_t (SG: library-owned context)."""
 
     def __init__(self, handle=None):
-        if handle is not None:
-            raise NotImplementedError("a raft handle cannot be consumed on this platform; pass None")
+        """handle: None (library-owned single-GPU context) or a Comm (the multi-GPU communicator; the reference passes the address of a
+        raft::handle_t that carries NCCL comms here, resource_handle.pyx:47-66) -- an integer is taken as that pointer."""
         l = capi.lib()
         if not torch.cuda.is_available():
             raise RuntimeError("cugraph_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
         torch.cuda.init()
-        self.c_resource_handle_ptr = l.cugraph_create_resource_handle(None)
+        self.comm = handle if isinstance(handle, Comm) else None
+        ptr = None if handle is None else C.c_void_p(handle.c_comm_ptr.value if isinstance(handle, Comm) else int(handle))
+        self.c_resource_handle_ptr = l.cugraph_create_resource_handle(ptr)
         if not self.c_resource_handle_ptr:
             raise RuntimeError("cugraph_create_resource_handle failed")
+
+    @property
+    def rank(self):
+        return capi.lib().cugraph_resource_handle_get_rank(self.c_resource_handle_ptr)
+
+    @property
+    def comm_size(self):
+        return capi.lib().cugraph_resource_handle_get_comm_size(self.c_resource_handle_ptr)
 
     def __del__(self):
         p = getattr(self, "c_resource_handle_ptr", None)

@@ -99,12 +99,13 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_exclusive_scan_u32(const cugraph
  * max(block_rows, block_cols) vertices).  Caller-owned device buffers (weight type): x_own [L] (out: this rank's x = pr / out_w,
  * the input of the column group's all-gather), x_cols [block_cols = R * L] (in: the gathered x), y_part [block_rows = C * L]
  * (out: partial row sums, the input of the row group's reduce-scatter), y_own [L] (in: the reduced owned rows), triple [4 doubles]
- * (out: this rank's L1 change, dangling mass, max |x|).  One iteration = all-gather(x_own -> x_cols), spmv, reduce-scatter(y_part ->
+ * (out: this rank's L1 change, dangling mass, max |x|).  owned_rows <= L = the rows of this rank's partition that are vertices (the last
+ * partitions are padded when V is not a multiple of P): padded rows hold 0 and stay out of the dangling mass and the L1 change.  One iteration = all-gather(x_own -> x_cols), spmv, reduce-scatter(y_part ->
  * y_own), epilogue, all-gather(triple) + set_scalars.  cugraph_amd/mg.py: MGPageRank2D is the host layer. */
 typedef struct { int32_t align_; } cugraph_amd_pagerank_mg2d_plan_t;
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_mg2d_plan_create(
-  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, size_t rows_per_partition, size_t block_rows, size_t block_cols, size_t global_num_vertices,
-  const cugraph_type_erased_device_array_view_t* out_weight_sums_own, const cugraph_type_erased_device_array_view_t* initial_own,
+  const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, size_t rows_per_partition, size_t owned_rows, size_t block_rows, size_t block_cols,
+  size_t global_num_vertices, const cugraph_type_erased_device_array_view_t* out_weight_sums_own, const cugraph_type_erased_device_array_view_t* initial_own,
   cugraph_type_erased_device_array_view_t* x_own, const cugraph_type_erased_device_array_view_t* x_cols, cugraph_type_erased_device_array_view_t* y_part,
   const cugraph_type_erased_device_array_view_t* y_own, cugraph_type_erased_device_array_view_t* triple, double alpha, cugraph_amd_pagerank_mg2d_plan_t** plan,
   cugraph_error_t** error);
@@ -172,6 +173,30 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_last_degree_su
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_results(cugraph_amd_traversal_mg_plan_t* plan, void* distances,
                                                                           int32_t* predecessors, cugraph_error_t** error);
 CUGRAPH_EXPORT void cugraph_amd_traversal_mg_plan_free(cugraph_amd_traversal_mg_plan_t* plan);
+
+/* One-node communicator of the library (cugraph_amd/csrc/comm.hpp): one process per GPU, every rank's device windows mapped into every
+ * rank through HIP IPC, data moved by direct peer writes over xGMI, completion by sequence-number flags -- no collective launches on
+ * the per-iteration paths.  It plays the part of the raft::handle_t with NCCL comms that the reference's
+ * cugraph_create_resource_handle(void* raft_handle) takes (cpp/src/c_api/resource_handle.cpp:11-39): pass the communicator as that
+ * pointer and the handle reports its rank / size; cugraph_graph_create_mg, cugraph_pagerank, cugraph_bfs, cugraph_sssp and
+ * cugraph_louvain on such a handle are COLLECTIVE (every rank calls them in the same order with its slice, as in the reference).
+ *   session   names the job on this node (a POSIX shared-memory segment carries the bootstrap): unique per job, the same on all ranks
+ *   rank/size one process per rank; several ranks may share one GPU (tests), at most 64 ranks
+ * The calling thread's current HIP device is the rank's GPU.  Free the communicator after the handles / graphs that use it. */
+typedef struct { int32_t align_; } cugraph_amd_comm_t;
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_comm_create(const char* session, int rank, int size, cugraph_amd_comm_t** comm,
+                                                            cugraph_error_t** error);
+CUGRAPH_EXPORT void cugraph_amd_comm_free(cugraph_amd_comm_t* comm);
+/* the host half of the bootstrap alone (shared-memory session, barrier, all-gather of small host payloads); needs no GPU */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_comm_host_selftest(const char* session, int rank, int size, int rounds, cugraph_error_t** error);
+CUGRAPH_EXPORT int cugraph_amd_comm_rank(const cugraph_amd_comm_t* comm);
+CUGRAPH_EXPORT int cugraph_amd_comm_size(const cugraph_amd_comm_t* comm);
+/* Collective self-check of every primitive (all-gather, all-to-all-v, integer / double all-reduce against closed forms) and timing of
+ * the two on the per-iteration path: out[0] = microseconds per device barrier, out[1] = GB/s of peer pushes issued by this rank
+ * (n_words 4-byte words to every peer per iteration), out[2] = 1 when the ranks sit on different GPUs.  `handle` must have been
+ * created on a communicator. */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_comm_selftest(const cugraph_resource_handle_t* handle, size_t n_words, int iterations,
+                                                              double* out, cugraph_error_t** error);
 
 /* MatrixMarket coordinate file -> device edge list (the format of the reference's datasets/karate.mtx etc.; conventions of
  * cpp/tests/utilities/matrix_market_file_utilities.cu: 0-based ids, `pattern` -> weight 1, a `symmetric` file's off-diagonal

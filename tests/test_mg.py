@@ -219,10 +219,11 @@ def test_mg_pagerank_hip_engine(orc, tmp_path, world, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,mode", [(1, "hip2d"), (2, "hip2d"), (4, "hip2d"), (4, "hip2dw"), (8, "hip2d")])
+@pytest.mark.parametrize("world,mode", [(1, "hip2d"), (2, "hip2d"), (4, "hip2d"), (4, "hip2dw"), (8, "hip2d"), (3, "hip2d"), (6, "hip2d")])
 def test_mg_pagerank_2d_hip_engine(orc, tmp_path, world, mode):
     """The 2-D layout on the HIP engine (cugraph_amd_pagerank_mg2d_plan_*: tiled SpMV of the local block in raw mode + owned-row
-    epilogue), ranks sharing one GPU and exchanging through gloo."""
+    epilogue), ranks sharing one GPU and exchanging through gloo.  Worlds 3 and 6 do not divide V = 4096: the last partitions are padded,
+    and the padded rows must stay out of the dangling mass and the L1 change (a round-3 review finding: they were counted)."""
     scale = 12
     pr, iters, conv = run_world(mode, world, scale, tmp_path, eps=0.0, max_iter=12)
     t, _, _ = truth(orc, scale, 0.0, 12, weighted=mode.endswith("w"))

@@ -1,0 +1,62 @@
+"""Multi-GPU behind the reference's own entry points (cugraph_create_resource_handle on a communicator -> cugraph_graph_create_mg ->
+cugraph_pagerank / cugraph_bfs / cugraph_sssp / cugraph_louvain; SURVEY.md section 8e, c_api/graph_mg.cpp:140,326,
+c_api/resource_handle.cpp:11-39): 2 / 3 / 4 processes share cuda:0 of the GPU box, the library's communicator (HIP IPC windows + peer
+writes) carries the exchanges -- the same code path as one process per GPU on an xGMI node."""
+import json
+import os
+import subprocess
+import sys
+import uuid
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def run_ranks(what, world, tmp_path, *args, timeout=600, env_extra=None):
+    session = f"t{uuid.uuid4().hex[:12]}"
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CUGRAPH_AMD_COMM_TIMEOUT_S="60", **(env_extra or {}))
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "ipc_worker.py"), what, session, str(rank), str(world), str(tmp_path)] + [str(a) for a in args],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=timeout)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}:\n{o[-4000:]}"
+    return [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(world)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_comm_selftest(world, tmp_path):
+    """every primitive of the communicator against closed forms (all-gather, all-to-all-v, integer / double all-reduce in rank order),
+    several ranks sharing one GPU"""
+    res = run_ranks("selftest", world, tmp_path, 1 << 16, 20)
+    assert len(res) == world
+    for r in res:
+        assert r["barrier_us"] > 0 and r["push_gbps"] > 0
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_comm_host_bootstrap(world):
+    """the shared-memory bootstrap of the communicator (session attach, sense-reversing barrier, host all-gather) with real processes;
+    no GPU involved"""
+    session = f"h{uuid.uuid4().hex[:12]}"
+    code = ("import ctypes as C, sys; from cugraph_amd import _capi as capi; l = capi.lib(); e = C.c_void_p(); "
+            "rc = l.cugraph_amd_comm_host_selftest(sys.argv[1].encode(), int(sys.argv[2]), int(sys.argv[3]), 200, C.byref(e)); "
+            "print(l.cugraph_error_message(e) if rc else 'ok'); sys.exit(rc)")
+    procs = [subprocess.Popen([sys.executable, "-c", code, session, str(r), str(world)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-2000:]
+    assert not Path("/dev/shm/cga_" + session).exists()
