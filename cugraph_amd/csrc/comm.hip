@@ -156,7 +156,15 @@ comm_window_t* comm_t::window_create(size_t bytes)
   w->bytes[rank] = b;
   if (size == 1) return w.release();
   win_slot_t mine{};
-  HIP_TRY(hipIpcGetMemHandle(&mine.handle, w->local));
+  {
+    hipError_t const e = hipIpcGetMemHandle(&mine.handle, w->local);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      shm->abort_flag.store(1, std::memory_order_relaxed);  // the peers are waiting in a barrier: fail them now, not after the timeout
+      throw api_error(CUGRAPH_UNKNOWN_ERROR, std::string("communicator: hipIpcGetMemHandle failed (") + hipGetErrorString(e) + ") for a window of " + std::to_string(b) +
+                                               " bytes at " + std::to_string((uintptr_t)w->local) + " on rank " + std::to_string(rank));
+    }
+  }
   mine.bytes = b;
   mine.pid   = (uint64_t)getpid();
   std::vector<win_slot_t> all(size);
@@ -165,7 +173,13 @@ comm_window_t* comm_t::window_create(size_t bytes)
     if (r == rank) continue;
     CGA_EXPECTS(all[r].pid != mine.pid, CUGRAPH_INVALID_INPUT, "communicator: two ranks in one process (one process per rank is required: HIP IPC maps ANOTHER process's memory)");
     void* p = nullptr;
-    HIP_TRY(hipIpcOpenMemHandle(&p, all[r].handle, hipIpcMemLazyEnablePeerAccess));
+    hipError_t const e = hipIpcOpenMemHandle(&p, all[r].handle, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      shm->abort_flag.store(1, std::memory_order_relaxed);
+      throw api_error(CUGRAPH_UNKNOWN_ERROR, std::string("communicator: hipIpcOpenMemHandle failed (") + hipGetErrorString(e) + ") for rank " + std::to_string(r) + "'s window of " +
+                                               std::to_string(all[r].bytes) + " bytes on rank " + std::to_string(rank));
+    }
     w->peer[r]  = p;
     w->bytes[r] = all[r].bytes;
   }
@@ -460,10 +474,17 @@ __global__ void k_selftest_fill(uint32_t* p, int64_t n, uint32_t tag)
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   for (; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = tag * 1000003u + (uint32_t)i;
 }
+// exactly representable, and their sum depends on the order: +2^60, 1, -2^60, 1, ... (in rank order: 2^60 + 1 rounds to 2^60)
+__host__ __device__ inline double selftest_value(int rank, int64_t i)
+{
+  double const big = 1152921504606846976.0;
+  int const k      = (rank + (int)(i % 4)) % 4;
+  return k == 0 ? big : k == 2 ? -big : 1.0;
+}
 __global__ void k_selftest_fill_f64(double* p, int64_t n, int rank)
 {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 1.0 / (double)(1 + rank) + (double)(i % 97) * 1e-3;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = selftest_value(rank, i);
 }
 }  // namespace
 
@@ -529,8 +550,8 @@ extern "C" cugraph_error_code_t cugraph_amd_comm_selftest(const cugraph_resource
       HIP_TRY(hipMemcpy(hd.data(), d.data(), hd.size() * 8, hipMemcpyDeviceToHost));
       for (int64_t i = 0; i < m; i += std::max<int64_t>(1, m / 509)) {
         CGA_EXPECTS(ha[i] == (uint32_t)i * (uint32_t)P, CUGRAPH_UNKNOWN_ERROR, "selftest: integer all_reduce is wrong");
-        double want = 0.0;
-        for (int r = 0; r < P; ++r) want += 1.0 / (double)(1 + r) + (double)(i % 97) * 1e-3;  // the library's fold order
+        double want = selftest_value(0, i);
+        for (int r = 1; r < P; ++r) want += selftest_value(r, i);  // the library's fold order
         CGA_EXPECTS(hd[i] == want, CUGRAPH_UNKNOWN_ERROR, "selftest: double all_reduce is not the rank-order fold");
       }
     }
