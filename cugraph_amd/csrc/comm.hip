@@ -87,12 +87,20 @@ void push_words(hipStream_t s, void* dst, void const* src, int64_t n_words)
   hipLaunchKernelGGL(k_push_u32, grid_for((n_words + 3) / 4, 256, 4096), 256, 0, s, static_cast<uint32_t*>(dst), static_cast<uint32_t const*>(src), n_words);
 }
 
+// Windows are written by OTHER processes (peers on other GPUs over xGMI; in the one-GPU tests, kernels of another process) and then read
+// by local kernels.  Peers on other GPUs: fine-grained memory (coherent with remote writes).  All ranks on ONE GPU: ordinary device memory
+// (same physical L2s; kernel boundaries write back / invalidate them).  CUGRAPH_AMD_COMM_WINDOWS = cached | finegrained | uncached overrides.
 void* raw_alloc(comm_t const& c, size_t bytes)
 {
   void* p = nullptr;
+  static int const forced = [] {
+    char const* e = getenv("CUGRAPH_AMD_COMM_WINDOWS");
+    std::string const k = e ? e : "";
+    return k == "cached" ? 0 : k == "finegrained" ? 1 : k == "uncached" ? 2 : -1;
+  }();
+  int const kind = forced >= 0 ? forced : (c.multi_device ? 1 : 0);
   auto alloc = [&]() {
-    // peers on other GPUs write into this block while local kernels poll / read it: fine-grained memory keeps that coherent
-    return c.multi_device ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) : hipMalloc(&p, bytes);
+    return kind == 0 ? hipMalloc(&p, bytes) : hipExtMallocWithFlags(&p, bytes, kind == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached);
   };
   hipError_t e = alloc();
   if (e == hipErrorOutOfMemory) {
@@ -144,59 +152,86 @@ void comm_t::host_allgather(void const* in, size_t bytes, void* out)
   host_barrier();  // nobody overwrites a slot before everybody has read it
 }
 
+namespace {
+// exports `local` (a fresh allocation of `bytes`) and maps every peer's counterpart; collective
+void exchange_mappings(comm_t& c, void* local, size_t bytes, std::vector<void*>& peer)
+{
+  peer.assign(c.size, nullptr);
+  peer[c.rank] = local;
+  if (c.size == 1) return;
+  win_slot_t mine{};
+  hipError_t e = hipIpcGetMemHandle(&mine.handle, local);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    c.shm->abort_flag.store(1, std::memory_order_relaxed);  // the peers are waiting in a barrier: fail them now, not after the timeout
+    throw api_error(CUGRAPH_UNKNOWN_ERROR, std::string("communicator: hipIpcGetMemHandle failed (") + hipGetErrorString(e) + ") for " + std::to_string(bytes) +
+                                             " bytes at " + std::to_string((uintptr_t)local) + " on rank " + std::to_string(c.rank));
+  }
+  mine.bytes = bytes;
+  mine.pid   = (uint64_t)getpid();
+  std::vector<win_slot_t> all(c.size);
+  c.host_allgather(&mine, sizeof(mine), all.data());
+  for (int r = 0; r < c.size; ++r) {
+    if (r == c.rank) continue;
+    CGA_EXPECTS(all[r].pid != mine.pid, CUGRAPH_INVALID_INPUT, "communicator: two ranks in one process (one process per rank is required: HIP IPC maps ANOTHER process's memory)");
+    void* p = nullptr;
+    e       = hipIpcOpenMemHandle(&p, all[r].handle, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      c.shm->abort_flag.store(1, std::memory_order_relaxed);
+      throw api_error(CUGRAPH_UNKNOWN_ERROR, std::string("communicator: hipIpcOpenMemHandle failed (") + hipGetErrorString(e) + ") for rank " + std::to_string(r) + "'s block of " +
+                                               std::to_string(all[r].bytes) + " bytes on rank " + std::to_string(c.rank));
+    }
+    peer[r] = p;
+  }
+  c.host_barrier();
+}
+}  // namespace
+
 comm_window_t* comm_t::window_create(size_t bytes)
 {
   HIP_TRY(hipSetDevice(device));
-  auto w = std::make_unique<comm_window_t>();
-  size_t const b = (std::max<size_t>(bytes, 256) + 255) / 256 * 256;
-  w->local = raw_alloc(*this, b);
-  w->peer.assign(size, nullptr);
-  w->bytes.assign(size, 0);
-  w->peer[rank]  = w->local;
-  w->bytes[rank] = b;
-  if (size == 1) return w.release();
-  win_slot_t mine{};
-  {
-    hipError_t const e = hipIpcGetMemHandle(&mine.handle, w->local);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      shm->abort_flag.store(1, std::memory_order_relaxed);  // the peers are waiting in a barrier: fail them now, not after the timeout
-      throw api_error(CUGRAPH_UNKNOWN_ERROR, std::string("communicator: hipIpcGetMemHandle failed (") + hipGetErrorString(e) + ") for a window of " + std::to_string(b) +
-                                               " bytes at " + std::to_string((uintptr_t)w->local) + " on rank " + std::to_string(rank));
-    }
-  }
-  mine.bytes = b;
-  mine.pid   = (uint64_t)getpid();
-  std::vector<win_slot_t> all(size);
+  // every rank carves the LARGEST request out of the same place: the arenas look the same everywhere
+  uint64_t mine = (std::max<size_t>(bytes, 256) + 4095) / 4096 * 4096;
+  std::vector<uint64_t> all(size);
   host_allgather(&mine, sizeof(mine), all.data());
-  for (int r = 0; r < size; ++r) {
-    if (r == rank) continue;
-    CGA_EXPECTS(all[r].pid != mine.pid, CUGRAPH_INVALID_INPUT, "communicator: two ranks in one process (one process per rank is required: HIP IPC maps ANOTHER process's memory)");
-    void* p = nullptr;
-    hipError_t const e = hipIpcOpenMemHandle(&p, all[r].handle, hipIpcMemLazyEnablePeerAccess);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      shm->abort_flag.store(1, std::memory_order_relaxed);
-      throw api_error(CUGRAPH_UNKNOWN_ERROR, std::string("communicator: hipIpcOpenMemHandle failed (") + hipGetErrorString(e) + ") for rank " + std::to_string(r) + "'s window of " +
-                                               std::to_string(all[r].bytes) + " bytes on rank " + std::to_string(rank));
-    }
-    w->peer[r]  = p;
-    w->bytes[r] = all[r].bytes;
+  size_t b = 0;
+  for (auto x : all) b = std::max<size_t>(b, (size_t)x);
+  int a = -1;
+  for (size_t k = 0; k < arenas.size(); ++k)
+    if (arenas[k].top + b <= arenas[k].bytes) { a = (int)k; break; }
+  if (a < 0) {
+    comm_arena_t ar;
+    ar.bytes = std::max<size_t>(b, (size_t)256 << 20);
+    ar.local = raw_alloc(*this, ar.bytes);
+    exchange_mappings(*this, ar.local, ar.bytes, ar.peer);
+    arenas.push_back(std::move(ar));
+    a = (int)arenas.size() - 1;
   }
-  host_barrier();
+  comm_arena_t& ar = arenas[a];
+  auto w    = std::make_unique<comm_window_t>();
+  w->arena  = a;
+  w->offset = ar.top;
+  w->peer.assign(size, nullptr);
+  w->bytes.assign(size, b);
+  for (int r = 0; r < size; ++r) w->peer[r] = static_cast<char*>(ar.peer[r]) + ar.top;
+  w->local = w->peer[rank];
+  ar.live.emplace_back(ar.top, b);
+  ar.top += b;
   return w.release();
 }
 
 void comm_t::window_free(comm_window_t* w)
 {
   if (!w) return;
-  if (size > 1) {
-    host_barrier();  // nobody is still writing into a block that is about to go
-    for (int r = 0; r < size; ++r)
-      if (r != rank && w->peer[r]) (void)hipIpcCloseMemHandle(w->peer[r]);
-    host_barrier();  // every mapping is closed before the owner frees
+  host_barrier();  // nobody is still writing into a block that is about to be handed out again
+  comm_arena_t& ar = arenas[w->arena];
+  for (auto& lv : ar.live)
+    if (lv.first == w->offset && lv.second != 0) { lv.second = 0; break; }
+  while (!ar.live.empty() && ar.live.back().second == 0) {  // give back what is on top of the stack
+    ar.top = ar.live.back().first;
+    ar.live.pop_back();
   }
-  (void)hipFree(w->local);
   delete w;
 }
 
@@ -314,6 +349,11 @@ comm_t::~comm_t()
     (void)hipFree(flags->local);
     delete flags;
   }
+  for (auto& ar : arenas) {
+    for (int r = 0; r < size; ++r)
+      if (r != rank && ar.peer[r]) (void)hipIpcCloseMemHandle(ar.peer[r]);
+    (void)hipFree(ar.local);
+  }
   if (d_peer_flags) (void)hipFree(d_peer_flags);
   if (err_word) (void)hipHostFree(err_word);
   if (shm) {
@@ -395,29 +435,12 @@ comm_t* comm_create(char const* session, int rank, int size, double timeout_s)
   // the flag words: zeroed BEFORE anybody can map them
   size_t const fbytes = (size_t)kCommChannels * kCommMaxRanks * sizeof(uint64_t);
   {
-    auto w       = std::make_unique<comm_window_t>();
-    w->local     = raw_alloc(*c, fbytes);
+    auto w   = std::make_unique<comm_window_t>();
+    w->local = raw_alloc(*c, fbytes);
     HIP_TRY(hipMemset(w->local, 0, fbytes));
     HIP_TRY(hipDeviceSynchronize());
-    w->peer.assign(size, nullptr);
     w->bytes.assign(size, fbytes);
-    w->peer[rank] = w->local;
-    if (size > 1) {
-      win_slot_t mine{};
-      HIP_TRY(hipIpcGetMemHandle(&mine.handle, w->local));
-      mine.bytes = fbytes;
-      mine.pid   = (uint64_t)getpid();
-      std::vector<win_slot_t> slots(size);
-      c->host_allgather(&mine, sizeof(mine), slots.data());
-      for (int r = 0; r < size; ++r) {
-        if (r == rank) continue;
-        CGA_EXPECTS(slots[r].pid != mine.pid, CUGRAPH_INVALID_INPUT, "communicator: one process per rank is required");
-        void* p = nullptr;
-        HIP_TRY(hipIpcOpenMemHandle(&p, slots[r].handle, hipIpcMemLazyEnablePeerAccess));
-        w->peer[r] = p;
-      }
-      c->host_barrier();
-    }
+    exchange_mappings(*c, w->local, fbytes, w->peer);
     c->flags = w.release();
   }
   HIP_TRY(hipMalloc((void**)&c->d_peer_flags, (size_t)size * sizeof(uint64_t*)));
@@ -535,12 +558,13 @@ extern "C" cugraph_error_code_t cugraph_amd_comm_selftest(const cugraph_resource
         for (int64_t i = 0; i < rc[s]; ++i, ++at)
           CGA_EXPECTS(host[at] == (uint32_t)(100 * s + me) * 1000003u + (uint32_t)i, CUGRAPH_UNKNOWN_ERROR, "selftest: all_to_all_v delivered wrong data");
     }
-    // all_reduce (integer and double; a length that is not a multiple of the rank count)
+    // all_reduce (integer and double; a length that is not a multiple of the rank count).  Integer: rank r contributes 1 << r everywhere,
+    // so a wrong sum names the ranks whose contribution is missing or stale
     {
       int64_t const m = n + 3;
       dvec<uint32_t> a((size_t)m);
       dvec<double> d((size_t)m);
-      hipLaunchKernelGGL(k_selftest_fill, grid_for(m), 256, 0, h.stream, a.data(), m, 0u);  // value = i on every rank
+      fill_u32(h, a.data(), m, 1u << (me % 31));
       hipLaunchKernelGGL(k_selftest_fill_f64, grid_for(m), 256, 0, h.stream, d.data(), m, me);
       c.all_reduce_sum_u32(h, a.data(), m);
       c.all_reduce_sum_f64(h, d.data(), m);
@@ -548,11 +572,20 @@ extern "C" cugraph_error_code_t cugraph_amd_comm_selftest(const cugraph_resource
       std::vector<double> hd((size_t)m);
       HIP_TRY(hipMemcpy(ha.data(), a.data(), ha.size() * 4, hipMemcpyDeviceToHost));
       HIP_TRY(hipMemcpy(hd.data(), d.data(), hd.size() * 8, hipMemcpyDeviceToHost));
-      for (int64_t i = 0; i < m; i += std::max<int64_t>(1, m / 509)) {
-        CGA_EXPECTS(ha[i] == (uint32_t)i * (uint32_t)P, CUGRAPH_UNKNOWN_ERROR, "selftest: integer all_reduce is wrong");
+      uint32_t want_u = 0;
+      for (int r = 0; r < P; ++r) want_u += 1u << (r % 31);
+      int64_t bad_u = 0, bad_d = 0, first_u = -1, first_d = -1;
+      for (int64_t i = 0; i < m; ++i) {
+        if (ha[i] != want_u) { if (bad_u++ == 0) first_u = i; }
         double want = selftest_value(0, i);
         for (int r = 1; r < P; ++r) want += selftest_value(r, i);  // the library's fold order
-        CGA_EXPECTS(hd[i] == want, CUGRAPH_UNKNOWN_ERROR, "selftest: double all_reduce is not the rank-order fold");
+        if (hd[i] != want) { if (bad_d++ == 0) first_d = i; }
+      }
+      if (bad_u || bad_d) {
+        char msg[512];
+        snprintf(msg, sizeof(msg), "selftest: all_reduce wrong on rank %d of %d (n = %lld): integer %lld wrong, first at %lld (got 0x%x, want 0x%x); double %lld wrong, first at %lld (got %.17g)",
+                 me, P, (long long)m, (long long)bad_u, (long long)first_u, first_u >= 0 ? ha[first_u] : 0u, want_u, (long long)bad_d, (long long)first_d, first_d >= 0 ? hd[first_d] : 0.0);
+        throw api_error(CUGRAPH_UNKNOWN_ERROR, msg);
       }
     }
     // timing: device barriers back to back; pushes of n words to every peer

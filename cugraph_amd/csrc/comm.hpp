@@ -41,12 +41,26 @@ struct comm_shm_t {  // lives in the POSIX shm segment
   unsigned char slots[kCommMaxRanks][kCommSlotBytes];
 };
 
-// A symmetric allocation: one device block per rank (sizes may differ), every block mapped into every process.
+// A symmetric allocation: one device block per rank at the same offset of a symmetric ARENA, every block mapped into every process.
 struct comm_window_t {
   std::vector<void*> peer;    // peer[r]: address of rank r's block in THIS process (peer[rank] = local block)
-  std::vector<size_t> bytes;  // bytes[r]
+  std::vector<size_t> bytes;  // bytes[r] (the same on every rank: the largest request)
   void* local{nullptr};
+  int arena{-1};
+  size_t offset{0};
   template <typename T> T* at(int r) const { return static_cast<T*>(peer[r]); }
+};
+
+// Device memory is exported / imported through HIP IPC ONCE per arena and never handed back while the communicator lives: on this
+// driver (ROCm 7.2, dmabuf IPC) exporting a fresh allocation that reuses the virtual address of a freed, previously exported one fails
+// with "invalid argument" or -- for uncached memory -- silently yields the handle of the FREED memory (round 4: the second large window
+// of a process received its peers' pushes nowhere; tools/gpu_r4c.sh).  Windows are carved out of the arenas stack-wise; every rank
+// allocates the same (largest) size at the same offset, so all ranks take the same decisions without talking.
+struct comm_arena_t {
+  void* local{nullptr};
+  size_t bytes{0}, top{0};
+  std::vector<void*> peer;
+  std::vector<std::pair<size_t, size_t>> live;  // (offset, size) of the windows carved out, in order; size 0 = freed, waiting for the ones above it
 };
 
 struct comm_t {
@@ -59,6 +73,7 @@ struct comm_t {
   int shm_fd{-1};
   double timeout_s{60.0};
   // device-side signalling
+  std::vector<comm_arena_t> arenas;
   comm_window_t* flags{nullptr};        // per rank: uint64 flags[kCommChannels][kCommMaxRanks]
   uint64_t** d_peer_flags{nullptr};     // device array [size] of the peers' flag blocks
   uint32_t* err_word{nullptr};          // host-mapped: bit 0 = a wait timed out

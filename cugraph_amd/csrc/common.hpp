@@ -262,6 +262,7 @@ struct timed_launch {  // RAII bracket: records start/stop events when timing is
 };
 
 struct tiled_csc_t;  // spmv_tiled.hpp
+struct mg_graph_t;   // mg_graph.hpp
 
 // ------------------------------------------------------------------------------------------- graph
 // One compressed-sparse orientation.  `major` = row vertex: source for CSR (store_transposed = false),
@@ -338,6 +339,9 @@ struct graph_t {  // behind cugraph_graph_t (cpp/src/c_api/graph.hpp:61-77)
   bool weight_sum_valid{false};
   int64_t sssp_heavy_cut{-1};  // SSSP (radix sub-queues): ids below this have at least average out-degree (ids are degree-sorted); -1 = not counted yet
   int bfs_calls{0};  // the CSC (bottom-up BFS levels) is built from the second traversal of a non-symmetric graph on
+  // cugraph_graph_create_mg on a communicator handle: this rank's slice + the partitions built from it (mg_graph.hpp); the single-GPU
+  // members above (orientations, number_map) stay empty, nv / ne are the GLOBAL counts
+  std::shared_ptr<mg_graph_t> mg;
 };
 
 inline handle_t const& H(cugraph_resource_handle_t const* h)
@@ -347,10 +351,16 @@ inline handle_t const& H(cugraph_resource_handle_t const* h)
   pool_set_stream(hh.stream);  // frees and reuses of device blocks made by this call are ordered on this stream
   return hh;
 }
-inline graph_t& G(cugraph_graph_t* g)
+inline graph_t& GM(cugraph_graph_t* g)  // entry points that also take multi-GPU graphs
 {
   CGA_EXPECTS(g != nullptr, CUGRAPH_INVALID_INPUT, "graph is NULL");
   return *reinterpret_cast<graph_t*>(g);
+}
+inline graph_t& G(cugraph_graph_t* g)
+{
+  graph_t& gg = GM(g);
+  CGA_EXPECTS(!gg.mg, CUGRAPH_NOT_IMPLEMENTED, "this entry point does not take a multi-GPU graph in this build (PageRank, BFS, SSSP, Louvain, has_vertex do)");
+  return gg;
 }
 inline device_array_view_t const* V(cugraph_type_erased_device_array_view_t const* v)
 {

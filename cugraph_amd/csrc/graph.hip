@@ -17,6 +17,7 @@
 // is one stable LSD radix sort of packed (major << 32 | minor) keys with the edge position as payload;
 // CSR and CSC coexist under one numbering.
 #include "common.hpp"
+#include "mg_graph.hpp"
 
 namespace cga {
 
@@ -565,10 +566,10 @@ extern "C" cugraph_error_code_t cugraph_graph_create_with_times_sg(
 
 // cugraph_graph_create_mg / _with_times_mg (cpp/src/c_api/graph_mg.cpp:326-560; pylibcugraph MGGraph, graphs.pyx:357-700): every
 // rank passes ITS slice of the edge list as `num_arrays` arrays of views and the reference shuffles edges to their owners
-// (graph_mg.cpp:140).  Here the multi-rank exchange lives in the host layer (torch.distributed over RCCL, cugraph_amd/mg.py +
-// the plan API of include/cugraph_amd/extensions.h), so this entry point serves one-rank handles -- the arrays are
-// concatenated and the graph is built as cugraph_graph_create_sg does, always renumbered as an MG graph is
-// (graph_mg.cpp:214) -- and returns CUGRAPH_NOT_IMPLEMENTED on a multi-rank handle.
+// (graph_mg.cpp:140).  On a handle created on a communicator (cugraph_amd_comm_create, the stand-in for the reference's raft::handle_t with
+// NCCL comms) the call is COLLECTIVE and yields one graph partitioned over the ranks (mg_graph.hip); on a plain one-rank handle --
+// what the reference's single-process C tests and pylibcugraph's MGGraph with a one-rank communicator use -- the arrays are concatenated
+// and the graph is built as cugraph_graph_create_sg does, always renumbered as an MG graph is (graph_mg.cpp:214).
 namespace cga {
 namespace {
 struct concat_t {
@@ -613,10 +614,11 @@ cugraph_error_code_t create_mg(const cugraph_resource_handle_t* handle, const cu
 {
   if (graph) *graph = nullptr;
   concat_t cv, cs, cd, cw, ci, ct, c0, c1;
+  bool multi = false;
   cugraph_error_code_t rc = guarded(error, [&] {
     handle_t const& h = H(handle);
-    CGA_EXPECTS(h.comm_size == 1, CUGRAPH_NOT_IMPLEMENTED,
-                "cugraph_graph_create_mg on a multi-rank handle: the multi-GPU graph lives behind cugraph_amd_pagerank_mg_plan_* / cugraph_amd_traversal_mg_plan_* (include/cugraph_amd/extensions.h)");
+    multi             = h.comm != nullptr;  // a handle created on a communicator (extensions.h): the collective path, also with one rank
+    CGA_EXPECTS(multi || h.comm_size == 1, CUGRAPH_INVALID_HANDLE, "cugraph_graph_create_mg: a multi-rank handle without a communicator");
     CGA_EXPECTS(src != nullptr && dst != nullptr && num_arrays >= 1, CUGRAPH_INVALID_INPUT, "Invalid input arguments: src / dst arrays.");
     HIP_TRY(hipSetDevice(h.device));
     concat_views(h, vertices, num_arrays, "vertices", cv);
@@ -628,8 +630,26 @@ cugraph_error_code_t create_mg(const cugraph_resource_handle_t* handle, const cu
     concat_views(h, t0, num_arrays, "edge_start_time_ids", c0);
     concat_views(h, t1, num_arrays, "edge_end_time_ids", c1);
     CGA_EXPECTS(cs.present && cd.present, CUGRAPH_INVALID_INPUT, "Invalid input arguments: src / dst arrays.");
+    if (multi) {
+      // collective: this rank's slice becomes part of ONE graph partitioned over the communicator (graph_mg.cpp:140 shuffles the edges
+      // to their owners at this point; here the owners depend on the algorithm family and are chosen on first use: mg_graph.hpp)
+      CGA_EXPECTS(graph != nullptr && properties != nullptr, CUGRAPH_INVALID_INPUT, "Invalid input arguments: NULL graph / properties.");
+      CGA_EXPECTS(cs.view.size == cd.view.size && (!cw.present || cw.view.size == cs.view.size), CUGRAPH_INVALID_INPUT, "Invalid input arguments: src size != dst / weights size.");
+      CGA_EXPECTS(drop_multi_edges != TRUE && symmetrize != TRUE, CUGRAPH_NOT_IMPLEMENTED,
+                  "cugraph_graph_create_mg: drop_multi_edges / symmetrize are not available on a multi-GPU graph in this build (drop_self_loops is)");
+      auto g              = std::make_unique<graph_t>();
+      g->vertex_type      = INT32;
+      g->edge_type        = INT32;
+      g->weight_type      = cw.present ? cw.view.type : FLOAT32;
+      g->has_weights      = cw.present;
+      g->store_transposed = store_transposed == TRUE;
+      g->renumbered       = true;  // graph_mg.cpp:214
+      g->props            = *properties;
+      mg_graph_create(h, *g, cv.present ? &cv.view : nullptr, &cs.view, &cd.view, cw.present ? &cw.view : nullptr, drop_self_loops == TRUE);
+      *graph = reinterpret_cast<cugraph_graph_t*>(g.release());
+    }
   });
-  if (rc != CUGRAPH_SUCCESS) return rc;
+  if (rc != CUGRAPH_SUCCESS || multi) return rc;
   auto opt = [](concat_t& c) -> device_array_view_t const* { return c.present ? &c.view : nullptr; };
   return create_sg(handle, properties, opt(cv), &cs.view, &cd.view, opt(cw), opt(ci), opt(ct), opt(c0), opt(c1), store_transposed, TRUE,
                    drop_self_loops, drop_multi_edges, symmetrize, do_expensive_check, graph, error);
@@ -714,9 +734,17 @@ extern "C" cugraph_error_code_t cugraph_has_vertex(const cugraph_resource_handle
   if (result) *result = nullptr;
   return guarded(error, [&] {
     handle_t const& h = H(handle);
-    graph_t& g        = G(graph);
+    graph_t& g        = GM(graph);
     auto v            = V(vertices);
     CGA_EXPECTS(v != nullptr && result != nullptr, CUGRAPH_INVALID_INPUT, "vertices / result is NULL");
+    if (g.mg) {  // multi-GPU graph: the id is a vertex if ANY rank knows it (graph_functions.cpp:391 answers per rank for the local range)
+      CGA_EXPECTS(v->type == INT32, CUGRAPH_INVALID_INPUT, "vertex type of graph and vertices must match");
+      auto out = std::make_unique<device_array_t>(v->size, BOOL);
+      mg_has_vertex(h, g, v->as<int32_t>(), (int64_t)v->size, out->buf.as<uint8_t>());
+      h.sync();
+      *result = reinterpret_cast<cugraph_type_erased_device_array_t*>(out.release());
+      return;
+    }
     vertex_column_in c_v;  // INT64 / sparse external ids: compact int32 ids (absent ones -1) from here on (outer_ids.hip)
     v = c_v.get(h, g, v, "vertices");
     auto out = std::make_unique<device_array_t>(v->size, BOOL);

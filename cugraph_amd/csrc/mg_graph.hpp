@@ -1,0 +1,69 @@
+// The multi-GPU graph behind cugraph_graph_create_mg on a communicator handle (replaces cpp/src/c_api/graph_mg.cpp:140-560 and the
+// multi_gpu = true halves of cpp/src/structure/create_graph_from_edgelist_impl.cuh:473-955 / renumber_edgelist_impl.cuh:425-829).
+//
+// Every rank hands over ITS slice of the edge list (external ids).  The graph object keeps that slice and builds, on the first call
+// that needs it, the partition an algorithm family runs on -- both deal the vertices of a global degree order round-robin over the
+// P ranks (position p -> rank p % P, local row p / P: every rank gets the same hub / tail mix):
+//   * PageRank: 1-D by DESTINATION in descending global in-degree order (the owner holds all in-edges of its rows: no partial-sum
+//     reduction); columns are numbered so that the receive window of the per-iteration x exchange IS the gather vector
+//     (grouped by the owning peer, hottest first inside a group: no unpack pass);
+//   * BFS / SSSP: 1-D by SOURCE in descending global out-degree order, destinations as compact global ids g = owner * L + row.
+// The reference hashes vertices to ranks and keeps a 2-D edge partition (partition_manager.hpp:42-51); DESIGN.md section 5 has the
+// byte counts that decide for 1-D on one xGMI node.
+#pragma once
+
+#include "common.hpp"
+
+namespace cga {
+
+struct comm_t;
+struct comm_window_t;
+
+struct mg_pagerank_part_t {
+  int P{1}, rank{0};
+  int64_t nv_global{0}, n_rows{0}, ncols{0}, n_send{0}, ne_local{0};
+  dvec<int32_t> local_vertices;      // [n_rows] external id of local row r
+  dvec<int32_t> send_index;          // [n_send] local row whose x is the k-th value this rank sends, grouped by receiving peer
+  std::vector<int64_t> send_first;   // [P + 1] k-range per receiving peer
+  std::vector<int64_t> dst_off;      // [P] element offset in peer r's x window where this rank's values for r start
+  std::vector<int64_t> seg_start;    // [P + 1] layout of this rank's own window: values of owner s at [seg_start[s], seg_start[s + 1])
+  dev_buf outw_local;                // [n_rows] out-weight sums of the owned vertices (weight type)
+  cugraph_graph_t* local{nullptr};   // CSC of the owned rows over the window columns (renumber = FALSE); owned
+  ~mg_pagerank_part_t();
+};
+
+struct mg_traversal_part_t {
+  int P{1}, rank{0};
+  int64_t nv_global{0}, n_rows{0}, L{0}, ne_local{0}, ne_global{0};
+  dvec<int32_t> local_vertices;  // [max(n_rows, 1)] external ids
+  dvec<int32_t> offsets, indices;  // CSR of the owned rows' out-edges, destinations as compact global ids, ascending inside a row
+  dvec<float> weights;             // optional
+  bool has_weights{false};
+  dvec<int32_t> pos;               // [vrange] external id - vmin -> position in the out-degree order (-1: not a vertex)
+  dvec<uint32_t> out_deg;          // [vrange] global out-degrees (the direction heuristic needs the sources' sum)
+  // bottom-up BFS levels: in-edges of the owned rows, neighbours as compact global ids in ascending order of their external id
+  bool has_in{false};
+  dvec<int32_t> in_offsets, in_indices, ext_of_g;
+};
+
+struct mg_graph_t {
+  comm_t* comm{nullptr};
+  edge_list_t el;             // this rank's slice (external ids), after the local part of the creation flags
+  dvec<int32_t> listed;       // vertices this rank listed explicitly (isolated vertices exist only through such a list)
+  int64_t n_listed{0};
+  int64_t vmin{0}, vrange{0};  // dense external id range over all ranks
+  int64_t nv_global{0}, ne_global{0};
+  dvec<uint32_t> present;     // [vrange] 1 = the id is a vertex of the graph
+  std::unique_ptr<mg_pagerank_part_t> pr;
+  std::unique_ptr<mg_traversal_part_t> tr[2];  // [0] = without weights (BFS), [1] = with float weights (SSSP)
+};
+
+// cugraph_graph_create_mg / _with_times_mg on a handle with more than one rank (collective)
+void mg_graph_create(handle_t const& h, graph_t& g, device_array_view_t const* vertices, device_array_view_t const* src, device_array_view_t const* dst,
+                     device_array_view_t const* weights, bool drop_self_loops);
+void mg_has_vertex(handle_t const& h, graph_t const& g, int32_t const* v, int64_t n, uint8_t* out);
+mg_pagerank_part_t& mg_pagerank_part(handle_t const& h, graph_t& g);                   // collective on first use
+mg_traversal_part_t& mg_traversal_part(handle_t const& h, graph_t& g, bool weighted);  // collective on first use
+void mg_traversal_in_edges(handle_t const& h, graph_t& g, mg_traversal_part_t& t);     // collective: the in-edge copy for bottom-up BFS levels
+
+}  // namespace cga

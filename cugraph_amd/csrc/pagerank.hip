@@ -27,6 +27,8 @@
 // Loop order and stopping rule follow pagerank_impl.cuh:224-329 exactly (see oracle/oracle.c).
 #include "common.hpp"
 #include "spmv_tiled.hpp"
+#include "comm.hpp"
+#include "mg_graph.hpp"
 #include "wave_ops.hpp"
 
 #include <type_traits>
@@ -1461,6 +1463,256 @@ struct pagerank_mg2d_plan : pagerank_mg2d_plan_base {
   }
 };
 
+// =================================================================================================
+// Multi-GPU PageRank behind the reference's own entry points: cugraph_pagerank on a graph from cugraph_graph_create_mg (a handle on the
+// library's communicator, comm.hpp).  Same 1-D partition and the same tiled kernels as pagerank_mg_plan above; what changes is the exchange:
+//   * the epilogue's x' is PUSHED: one kernel gathers x_own[send_index[k]] and stores it straight into each peer's receive window
+//     through the peer-mapped pointers (xGMI stores; all links at once), the three scalars go into a [P][4] window the same way, then ONE
+//     signal; the consumer waits on the sequence number.  No pack into a send buffer, no collective launch, no host in the loop;
+//   * the receive window IS the gather vector: columns are numbered (owner, position) at partition time (mg_graph.hip), so there is no
+//     unpack pass.  (Measured on the partition itself, RMAT-24 / 8 ranks: the owner-grouped numbering costs 16 % more partial sums,
+//     +10 MB of the 138 MB a rank moves per iteration; the unpack pass it removes moved 42 MB: DESIGN.md section 5.)
+//   * windows are double-buffered by iteration parity: a rank can be at most one push ahead of the slowest peer (its next iteration
+//     waits for every peer's signal), so the buffer it overwrites has been consumed everywhere;
+//   * the single-GPU plan's shortcuts apply: rows without in-edges stay out of the epilogue (their share of the scalars is analytic and
+//     added to this rank's triple), fixed-count iterations neither read the previous iterate nor write pr.
+// The iteration loop is this file's step(): Python is not in it.  Replaces the multi_gpu = true path of detail::pagerank
+// (cpp/src/link_analysis/pagerank_impl.cuh:224-329) with update_edge_src_property's row broadcast (prims/update_edge_src_dst_property.cuh:550-579).
+// =================================================================================================
+template <typename WT>
+__global__ void __launch_bounds__(256) k_mgc_push(WT const* x_own, int32_t const* send_index, int64_t const* first /*[P + 1]*/, WT* const* peer_x /*[P]*/,
+                                                  int64_t const* dst_off /*[P]*/)
+{
+  int const r      = blockIdx.y;
+  int64_t const k0 = first[r], n = first[r + 1] - k0;
+  WT* dst          = peer_x[r] + dst_off[r];
+  int32_t const* idx = send_index + k0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = x_own[idx[i]];
+}
+
+__global__ void k_mgc_push_scalars(double const* totals, double* const* peer_s /*[P]: each [P][4]*/, int rank, int P)
+{
+  int const r = threadIdx.x;
+  if (r < P) {
+    double* d = peer_s[r] + 4 * rank;
+    d[0] = totals[0]; d[1] = totals[1]; d[2] = totals[2]; d[3] = 0.0;
+  }
+}
+
+template <typename WT>
+__global__ void k_mgc_fold(double const* triples /*[P][4]*/, int P, pr_scalars<WT>* scal, WT alpha, int64_t nv_global, double wmax)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double diff = 0, dang = 0, xmax = 0;
+  for (int r = 0; r < P; ++r) { diff += triples[4 * r]; dang += triples[4 * r + 1]; xmax = fmax(xmax, triples[4 * r + 2]); }  // rank order: every rank folds the same bits
+  tiled_write_scalars<WT>(scal, diff, dang, xmax, alpha, nv_global, 0, wmax);
+}
+
+template <typename WT>
+__global__ void k_fill_from_scal(WT* out, int64_t n, pr_scalars<WT> const* scal, int use_prev)
+{
+  WT const v     = use_prev ? scal->base_prev : scal->base;
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = v;
+}
+
+template <typename WT>
+struct pagerank_mgc_plan : pagerank_plan_base {
+  handle_t const& h;
+  graph_t& g;
+  comm_t& c;
+  mg_pagerank_part_t* part{nullptr};
+  WT alpha;
+  int P, me;
+  int64_t n_rows{0}, nv_global{0};
+  dvec<WT> pr, x_own, partial;
+  WT const* outw{nullptr};
+  dvec<pr_scalars<WT>> scal;
+  dvec<double> tpartials, totals;
+  dvec<uint32_t> counters;
+  std::shared_ptr<tiled_csc_t> tc;
+  tiled_const_rows<WT> crows;
+  comm_window_t* xwin[2]{nullptr, nullptr};  // the gather vector of an iteration = what the peers pushed (double-buffered)
+  comm_window_t* swin[2]{nullptr, nullptr};  // [P][4] doubles: every rank's (L1 change, dangling mass, max |x|)
+  dvec<WT*> d_peer_x[2];
+  dvec<double*> d_peer_s[2];
+  dvec<int64_t> d_first, d_dst_off;
+  int channel{0};
+  uint64_t pushes{0}, folds{0};  // push #n fills buffer (n - 1) & 1 everywhere; fold #n waits for it
+  size_t iterations{0};
+  double last_diff{0};
+
+  pagerank_mgc_plan(handle_t const& h_, graph_t& g_, double alpha_) : h(h_), g(g_), c(*g_.mg->comm), alpha((WT)alpha_), P(g_.mg->comm->size), me(g_.mg->comm->rank) {}
+
+  ~pagerank_mgc_plan() override
+  {  // collective, like the constructor: every rank frees its plans in the same order
+    try {
+      (void)hipStreamSynchronize(h.stream);
+      for (int b = 0; b < 2; ++b) { if (xwin[b]) c.window_free(xwin[b]); if (swin[b]) c.window_free(swin[b]); }
+    } catch (...) {
+    }
+  }
+
+  tiled_epilogue<WT> epi()
+  {
+    tiled_epilogue<WT> e;
+    e.nv = n_rows; e.pr = pr.data(); e.x_next = x_own.data(); e.outw = outw; e.pers = nullptr; e.scal = scal.data();
+    e.partials = tpartials.data(); e.totals = totals.data(); e.alpha = alpha; e.nv_global = nv_global; e.wmax = tc->wmax;
+    e.cr = crows;
+    return e;
+  }
+
+  void create()
+  {
+    HIP_TRY(hipSetDevice(h.device));
+    part      = &mg_pagerank_part(h, g);  // collective on first use
+    n_rows    = part->n_rows;
+    nv_global = part->nv_global;
+    graph_t& lg      = *reinterpret_cast<graph_t*>(part->local);
+    CGA_EXPECTS(lg.weight_type == g.weight_type, CUGRAPH_UNKNOWN_ERROR, "multi-GPU PageRank: local graph of another weight type");
+    ensure_orientation(h, lg, true);
+    orientation_t& o = lg.csc;
+    CGA_EXPECTS(o.seg[4] <= n_rows, CUGRAPH_UNKNOWN_ERROR, "multi-GPU PageRank: edges point to rows outside the local range");
+    int const T = tiled_default_T(h, sizeof(WT), std::max<int64_t>(part->ncols, 1));
+    if (!o.tiled || o.tiled->T != T || o.tiled->nv != n_rows) {
+      auto t = std::make_shared<tiled_csc_t>();
+      build_tiled_csc(h, lg.nv, n_rows, lg.ne, o, lg.has_weights, sizeof(WT), T, *t);
+      o.tiled = t;
+    }
+    tc = o.tiled;
+    size_t const n1 = (size_t)std::max<int64_t>(n_rows, 1);
+    pr.resize_discard(n1); x_own.resize_discard(n1);
+    outw = part->outw_local.template as<WT const>();
+    scal.resize_discard(1); totals.resize_discard(4); counters.resize_discard(4);
+    partial.resize_discard((size_t)tc->n_slots + 64);
+    tpartials.resize_discard((size_t)3 * std::max(tc->nI, 1024));
+    HIP_TRY(hipMemsetAsync(partial.data(), 0, ((size_t)tc->n_slots + 64) * sizeof(WT), h.stream));
+    HIP_TRY(hipMemsetAsync(counters.data(), 0, 4 * sizeof(uint32_t), h.stream));
+    HIP_TRY(hipMemsetAsync(totals.data(), 0, 4 * sizeof(double), h.stream));
+    HIP_TRY(hipMemsetAsync(x_own.data(), 0, n1 * sizeof(WT), h.stream));
+    fill_wt<WT>(h, pr.data(), n_rows, nv_global > 0 ? WT(1) / (WT)nv_global : WT(0));  // pagerank_impl.cuh:422-426
+    pr_scalars<WT> s0{};
+    s0.base = nv_global > 0 ? WT(1) / (WT)nv_global : WT(0);  // the first fold makes it base_prev: what the rows hold before iteration 1
+    HIP_TRY(hipMemcpyAsync(scal.data(), &s0, sizeof(s0), hipMemcpyHostToDevice, h.stream));
+    h.sync();
+    // rows without in-edges leave the per-iteration epilogue (spmv_tiled.hpp: tiled_const_rows); columns are the rows themselves here
+    if (!getenv("CUGRAPH_AMD_PAGERANK_ALL_ROWS") && tc->n_act < n_rows && tc->nI_act > 0) {
+      int64_t const n = n_rows - tc->n_act;
+      crows.n_rows = n; crows.c0 = tc->n_act; crows.n_cols = n; crows.outw_c = outw + tc->n_act; crows.nI_act = tc->nI_act;
+      dvec<unsigned long long> red(2);
+      dvec<WT> scratch((size_t)n);
+      HIP_TRY(hipMemsetAsync(red.data(), 0, 2 * sizeof(unsigned long long), h.stream));
+      hipLaunchKernelGGL(k_const_rows_setup<WT>, grid_for(n, kBlock, 4096), kBlock, 0, h.stream, outw + tc->n_act, (int32_t const*)nullptr, n, (int64_t)tc->n_act, (int64_t)tc->n_act,
+                         scratch.data(), red.data());
+      unsigned long long r[2];
+      h.read_back(r, red.data(), 2);
+      crows.n_dangling = (int64_t)r[0];
+      std::memcpy(&crows.max_inv_outw, &r[1], sizeof(double));
+    }
+    // windows (collective): zeroed before anybody may push into them
+    channel         = c.channel_alloc();
+    size_t const nx = (size_t)tc->nJ * tc->T + 8;  // the gather vector is read tile-wise
+    for (int b = 0; b < 2; ++b) {
+      xwin[b] = c.window_create(nx * sizeof(WT));
+      swin[b] = c.window_create((size_t)P * 4 * sizeof(double));
+      HIP_TRY(hipMemsetAsync(xwin[b]->local, 0, nx * sizeof(WT), h.stream));
+      HIP_TRY(hipMemsetAsync(swin[b]->local, 0, (size_t)P * 4 * sizeof(double), h.stream));
+      d_peer_x[b].resize_discard(P); d_peer_s[b].resize_discard(P);
+      HIP_TRY(hipMemcpyAsync(d_peer_x[b].data(), xwin[b]->peer.data(), (size_t)P * sizeof(void*), hipMemcpyHostToDevice, h.stream));
+      HIP_TRY(hipMemcpyAsync(d_peer_s[b].data(), swin[b]->peer.data(), (size_t)P * sizeof(void*), hipMemcpyHostToDevice, h.stream));
+    }
+    d_first.resize_discard(P + 1); d_dst_off.resize_discard(P);
+    HIP_TRY(hipMemcpyAsync(d_first.data(), part->send_first.data(), (size_t)(P + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h.stream));
+    HIP_TRY(hipMemcpyAsync(d_dst_off.data(), part->dst_off.data(), (size_t)P * sizeof(int64_t), hipMemcpyHostToDevice, h.stream));
+    h.sync();
+    c.host_barrier();
+    // iteration-0 state: x = pr / out_w of every owned row, this rank's (0, dangling mass, max |x|); first push
+    int const n = tiled_prologue<WT>(h, *tc, (WT const*)pr.data(), outw, x_own.data(), n_rows, tpartials.data());
+    tiled_finish<WT>(h, epi(), n, (double)s0.base);
+    push();
+    h.sync();
+    c.check("multi-GPU PageRank: first exchange");
+  }
+
+  void push()
+  {
+    int const b = (int)(pushes & 1);
+    int64_t biggest = 0;
+    for (int r = 0; r < P; ++r) biggest = std::max(biggest, part->send_first[r + 1] - part->send_first[r]);
+    if (biggest > 0) {
+      dim3 const grid((unsigned)std::max(1, std::min(grid_for(biggest, 256, 512), 512)), (unsigned)P);
+      hipLaunchKernelGGL(k_mgc_push<WT>, grid, dim3(256), 0, h.stream, (WT const*)x_own.data(), (int32_t const*)part->send_index.data(), (int64_t const*)d_first.data(),
+                         (WT* const*)d_peer_x[b].data(), (int64_t const*)d_dst_off.data());
+    }
+    hipLaunchKernelGGL(k_mgc_push_scalars, 1, 64, 0, h.stream, (double const*)totals.data(), (double* const*)d_peer_s[b].data(), me, P);
+    c.signal(h.stream, channel);
+    ++pushes;
+  }
+
+  // waits for the latest push of every rank and folds the P scalar triples into the constants of the next iteration
+  void fold(bool read_back)
+  {
+    if (folds < pushes) {
+      c.wait(h.stream, channel, folds + 1);
+      int const b = (int)(folds & 1);
+      hipLaunchKernelGGL(k_mgc_fold<WT>, 1, 64, 0, h.stream, (double const*)swin[b]->local, P, scal.data(), alpha, nv_global, tc->wmax);
+      ++folds;
+    }
+    if (read_back) {
+      pr_scalars<WT> sc;
+      h.read_back(&sc, scal.data(), 1);
+      c.check("multi-GPU PageRank");
+      last_diff = (double)sc.diff;
+    }
+  }
+
+  void iterate(bool need_diff, bool last_of_call)
+  {
+    int const b          = (int)((folds - 1) & 1);
+    tiled_epilogue<WT> e = epi();
+    e.need_diff          = need_diff;
+    e.write_pr           = need_diff || last_of_call;
+    tiled_phase1<WT>(h, *tc, (WT const*)xwin[b]->local, alpha, partial.data(), counters.data(), tiled_x_map<WT>{}, nullptr);
+    tiled_phase2<WT>(h, *tc, (WT const*)partial.data(), e, counters.data());
+    tiled_finish<WT>(h, e, tiled_fold_count(*tc, e));  // this rank's triple (with the analytic share of the rows left out)
+    push();
+  }
+
+  void step(double epsilon, size_t max_iterations, size_t* done, bool* converged) override
+  {
+    HIP_TRY(hipSetDevice(h.device));
+    bool const track = epsilon > 0.0;
+    size_t it = 0;
+    bool conv = false;
+    while (it < max_iterations) {
+      fold(track);
+      if (track && iterations > 0 && last_diff < epsilon) { conv = true; break; }  // pagerank_impl.cuh:320-326, on the GLOBAL L1 change
+      iterate(track, it + 1 == max_iterations);
+      ++iterations; ++it;
+    }
+    if (track && !conv) { fold(true); conv = last_diff < epsilon; }  // did the last allowed iteration converge?
+    *done      = it;
+    *converged = conv;
+  }
+
+  centrality_result_t* result(size_t total_iterations, bool converged) override
+  {
+    auto ids  = std::make_unique<device_array_t>((size_t)n_rows, INT32);
+    auto vals = std::make_unique<device_array_t>((size_t)n_rows, g.weight_type);
+    if (crows.nI_act > 0)  // the rows without in-edges hold the base of the last iteration (base_prev once its scalars have been folded)
+      hipLaunchKernelGGL(k_fill_from_scal<WT>, grid_for(crows.n_rows, kBlock, 4096), kBlock, 0, h.stream, pr.data() + tc->n_act, crows.n_rows,
+                         (pr_scalars<WT> const*)scal.data(), (folds == pushes && iterations > 0) ? 1 : 0);
+    if (n_rows > 0) {
+      HIP_TRY(hipMemcpyAsync(ids->buf.ptr, part->local_vertices.data(), (size_t)n_rows * 4, hipMemcpyDeviceToDevice, h.stream));
+      HIP_TRY(hipMemcpyAsync(vals->buf.ptr, pr.data(), (size_t)n_rows * sizeof(WT), hipMemcpyDeviceToDevice, h.stream));
+    }
+    h.sync();
+    c.check("multi-GPU PageRank result");
+    return new centrality_result_t{ids.release(), vals.release(), total_iterations, converged};
+  }
+};
+
 namespace {
 
 void check_pair_types(graph_t const& g, device_array_view_t const* v, device_array_view_t const* s, char const* vmsg, char const* smsg)
@@ -1478,9 +1730,22 @@ pagerank_plan_base* make_plan(cugraph_resource_handle_t const* handle, cugraph_g
                               bool do_expensive_check = false)
 {
   handle_t const& h = H(handle);
-  graph_t& g        = G(graph);
+  graph_t& g        = GM(graph);
   // pagerank_impl.cuh:78-88
   CGA_EXPECTS(alpha >= 0.0 && alpha <= 1.0, CUGRAPH_INVALID_INPUT, "Invalid input argument: alpha should be in [0.0, 1.0].");
+  if (g.mg) {  // a graph from cugraph_graph_create_mg on a communicator handle: collective, every rank gets its owned vertices back
+    CGA_EXPECTS(ow_v == nullptr && ow_s == nullptr && ig_v == nullptr && ig_s == nullptr && p_v == nullptr && p_s == nullptr, CUGRAPH_NOT_IMPLEMENTED,
+                "multi-GPU PageRank: precomputed out-weights, initial guess and personalization are not available in this build");
+    CGA_EXPECTS(handle_comm(h) == g.mg->comm, CUGRAPH_INVALID_HANDLE, "multi-GPU PageRank: the handle is not on the communicator the graph was created on");
+    if (g.weight_type == FLOAT64) {
+      auto p = std::make_unique<pagerank_mgc_plan<double>>(h, g, alpha);
+      p->create();
+      return p.release();
+    }
+    auto p = std::make_unique<pagerank_mgc_plan<float>>(h, g, alpha);
+    p->create();
+    return p.release();
+  }
   CGA_EXPECTS(p_v == nullptr || V(p_v)->size > 0, CUGRAPH_INVALID_INPUT,
               "Invalid input argument: if personalizations.has_value() is true, the input personalization vector size should not be 0.");
   if (do_expensive_check) {  // pagerank_impl.cuh:90-117

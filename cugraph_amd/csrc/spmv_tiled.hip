@@ -751,18 +751,16 @@ __device__ __forceinline__ void finish_scalars(fin_args<WT> const& f, double* sc
     __syncthreads();
   }
   if (tid == 0) {
-    if (f.totals) { f.totals[0] = r0[0]; f.totals[1] = r1[0]; f.totals[2] = r2[0]; }
-    else {
-      double diff = r0[0], dang = r1[0], xmax = r2[0];
-      if (f.cr_rows > 0 && f.init_prev < 0) {  // the rows without in-edges were not visited: pr' = base for each of them
-        WT const b = f.scal->base, bp = f.scal->base_prev;
-        diff += f.cr_rows * (double)fabs(b - bp);
-        dang += f.cr_dangling * (double)b;
-        xmax = fmax(xmax, fabs((double)b) * f.cr_max_inv_outw);
-      }
-      if (f.init_prev >= 0) f.scal->base = (WT)f.init_prev;  // becomes base_prev: the rows' value before the first iteration
-      tiled_write_scalars<WT>(f.scal, diff, dang, xmax, f.alpha, f.nv_global, f.personalized, f.wmax);
+    double diff = r0[0], dang = r1[0], xmax = r2[0];
+    if (f.cr_rows > 0 && f.init_prev < 0) {  // the rows without in-edges were not visited: pr' = base for each of them
+      WT const b = f.scal->base, bp = f.scal->base_prev;
+      diff += f.cr_rows * (double)fabs(b - bp);
+      dang += f.cr_dangling * (double)b;
+      xmax = fmax(xmax, fabs((double)b) * f.cr_max_inv_outw);
     }
+    if (f.init_prev >= 0) f.scal->base = (WT)f.init_prev;  // becomes base_prev: the rows' value before the first iteration
+    if (f.totals) { f.totals[0] = diff; f.totals[1] = dang; f.totals[2] = xmax; }  // multi-GPU: this rank's share, folded with the peers' later
+    else tiled_write_scalars<WT>(f.scal, diff, dang, xmax, f.alpha, f.nv_global, f.personalized, f.wmax);
   }
   __syncthreads();
 }

@@ -1,0 +1,43 @@
+"""What a rank of tests/test_mg_capi.py runs through the reference's own entry points on a communicator handle
+(cugraph_graph_create_mg -> cugraph_pagerank / cugraph_bfs / cugraph_sssp / cugraph_louvain).  Every rank builds ITS slice of the same
+seeded RMAT edge list, saves (vertices, values) of the vertices it gets back; the test assembles them and compares with the oracle."""
+import numpy as np
+import torch
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t if dtype is None else t.to(dtype)).cuda()
+
+
+def rmat_slice(scale, rank, size, edge_factor=16, seed=0):
+    from oracle import oracle as orc  # the checker's generator = the library's (smoke() compares them); input only
+
+    ne = edge_factor << scale
+    per = (ne + size - 1) // size
+    first = min(rank * per, ne)
+    return orc.rmat(scale, max(0, min(per, ne - first)), seed=seed, first_edge=first), first
+
+
+def run(what, cg, h, comm, rank, size, outdir, args):
+    out = {}
+    if what == "pagerank":
+        scale, max_iter, eps, weighted = int(args[0]), int(args[1]), float(args[2]), args[3] == "w"
+        (s, d), first = rmat_slice(scale, rank, size)
+        w = None
+        if weighted:
+            w = np.random.default_rng(1).integers(1, 9, size=16 << scale).astype(np.float32)[first: first + s.size].copy()
+        # isolated ids are vertices only when somebody lists them (graph_mg.cpp:326: vertices are optional): every rank lists a slice
+        verts = np.arange(rank, 1 << scale, size, dtype=np.int32)
+        g = cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [T(s)], [T(d)], None if w is None else [T(w)], store_transposed=True, vertices_array=[T(verts)])
+        v, x, conv = cg.pagerank(h, g, None, None, None, None, 0.85, eps, max_iter, False, fail_on_nonconvergence=False)
+        np.savez(outdir / f"rank{rank}.npz", v=v.cpu().numpy(), x=x.cpu().numpy())
+        out["rows"] = int(v.numel())
+        out["converged"] = bool(conv) if conv is not None else None
+        # a second call on the same graph reuses the partition and must give the same answer
+        v2, x2, _ = cg.pagerank(h, g, None, None, None, None, 0.85, eps, max_iter, False, fail_on_nonconvergence=False)
+        out["repeat_equal"] = bool(torch.equal(v, v2) and torch.equal(x, x2))
+        del g
+    else:
+        raise ValueError(what)
+    return out

@@ -60,3 +60,41 @@ def test_comm_host_bootstrap(world):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-2000:]
     assert not Path("/dev/shm/cga_" + session).exists()
+
+
+def _assemble(tmp_path, world, nv):
+    out = np.full(nv, np.nan, np.float64)
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        assert np.isnan(out[z["v"]]).all(), "a vertex came back from two ranks"
+        out[z["v"]] = z["x"]
+    assert not np.isnan(out).any(), "every vertex must come back from exactly one rank"
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,weighted", [(1, "-"), (2, "-"), (3, "-"), (4, "w"), (8, "-")])
+def test_mg_capi_pagerank(orc, tmp_path, world, weighted):
+    """cugraph_graph_create_mg + cugraph_pagerank_allow_nonconvergence on a communicator handle, 1 .. 8 ranks sharing one GPU, against the
+    single-process oracle at a fixed iteration count (1e-6 absolute, 2e-5 relative: the tolerance of the single-GPU parity tests)."""
+    from test_mg import truth
+
+    scale, iters = 12, 12
+    res = run_ranks("pagerank", world, tmp_path, scale, iters, 0.0, weighted)
+    assert sum(r["rows"] for r in res) == 1 << scale and all(r["repeat_equal"] for r in res)
+    pr = _assemble(tmp_path, world, 1 << scale)
+    t, _, _ = truth(orc, scale, 0.0, iters, weighted=weighted == "w")
+    assert np.max(np.abs(pr - t)) <= 1e-6
+    assert np.max(np.abs(pr - t) / t) <= 2e-5
+
+
+@pytest.mark.gpu
+def test_mg_capi_pagerank_converges_like_single_gpu(orc, tmp_path):
+    from test_mg import truth
+
+    res = run_ranks("pagerank", 2, tmp_path, 11, 200, 1e-5, "-")
+    assert all(r["converged"] for r in res)
+    pr = _assemble(tmp_path, 2, 1 << 11)
+    t, it, tconv = truth(orc, 11, 1e-5, 200)
+    assert tconv
+    np.testing.assert_allclose(pr, t, rtol=1e-4)
