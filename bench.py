@@ -9,8 +9,10 @@ resident in HBM.  W untimed steps, then exactly K timed steps bracketed by barri
 ranks is reported.  value = E * K / t / 1e6 (MTEPS, whole job).  Workload = RMAT scale 26, edge factor 16,
 (a,b,c) = (0.57,0.19,0.19), seed 0, int32 ids, fp32 ranks, alpha 0.85 -- the graph BASELINE.json quotes the metric on;
 with N > 1 the SAME graph is partitioned over the ranks ("strong" scaling).
-rank 0 prints one JSON line with `roofline` (dominant kernel k_spmv, HIP events on the library's stream) and
-`cpu_baseline` (the C oracle with OpenMP on the host cores, bounded sample).
+rank 0 prints one JSON line with `roofline` (dominant kernels k_tiled_phase1 + k_tiled_phase2 -- one launch of each per iteration --
+timed with HIP events on the library's stream) and `cpu_baseline` (the C oracle with OpenMP on the host cores, bounded sample).
+N > 1 (`--transport ipc`, default): cugraph_graph_create_mg + cugraph_pagerank on the library's own communicator (cugraph_amd/mg_capi.py);
+`--transport rccl`: the torch.distributed / RCCL orchestration of cugraph_amd/mg.py.
 """
 import argparse
 import json
@@ -179,6 +181,9 @@ def main():
     ap.add_argument("--extra-roots", type=int, default=16)
     ap.add_argument("--layout", choices=["1d", "2d"], default=os.environ.get("CUGRAPH_AMD_MG_LAYOUT", "1d"),
                     help="N > 1: 1d = destination partition + sparse all-to-all (default), 2d = the reference's R x C layout (all-gather + reduce-scatter)")
+    ap.add_argument("--transport", choices=["ipc", "rccl"], default=os.environ.get("CUGRAPH_AMD_MG_TRANSPORT", "ipc"),
+                    help="N > 1: ipc = cugraph_graph_create_mg + cugraph_pagerank on the library's communicator (HIP IPC peer writes over xGMI, loop inside the "
+                         "library; default), rccl = the torch.distributed orchestration of cugraph_amd/mg.py (RCCL collectives; --layout applies)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -198,7 +203,7 @@ def main():
             if torch.cuda.device_count() < args.gpus:  # fewer devices than ranks: refuse, unless the plumbing switch is set
                 if env.get("CUGRAPH_AMD_MG_TEST_SINGLE_GPU") != "1":
                     print(json.dumps({"error": f"--gpus {args.gpus} needs {args.gpus} devices, torch sees {torch.cuda.device_count()} "
-                                               "(CUGRAPH_AMD_MG_TEST_SINGLE_GPU=1 runs all ranks on cuda:0 over gloo as a plumbing check)"}), flush=True)
+                                               "(CUGRAPH_AMD_MG_TEST_SINGLE_GPU=1 runs all ranks on cuda:0 as a plumbing check)"}), flush=True)
                     sys.exit(2)
         except ImportError:
             pass
@@ -206,7 +211,10 @@ def main():
                "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=env))
     if args.gpus > 1 or world > 1:
-        from cugraph_amd import mg
+        if args.transport == "ipc" and args.layout == "1d":
+            from cugraph_amd import mg_capi as mg
+        else:
+            from cugraph_amd import mg
 
         out = mg.bench_main(args)
         if rank == 0 and out is not None:

@@ -191,6 +191,8 @@ PROTOTYPES = {
     "cugraph_amd_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _PP, _PP]),
     "cugraph_amd_comm_free": (None, [_P]),
     "cugraph_amd_comm_host_selftest": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, _PP]),
+    "cugraph_amd_comm_host_barrier": (C.c_int, [_P, _PP]),
+    "cugraph_amd_comm_host_allgather": (C.c_int, [_P, _P, C.c_size_t, _P, _PP]),
     "cugraph_amd_comm_rank": (C.c_int, [_P]),
     "cugraph_amd_comm_size": (C.c_int, [_P]),
     "cugraph_amd_comm_selftest": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_double), _PP]),
@@ -202,6 +204,7 @@ PROTOTYPES = {
     "cugraph_amd_kernel_timing_reset": (None, [_P]),
     "cugraph_amd_graph_num_vertices": (C.c_size_t, [_P]),
     "cugraph_amd_graph_num_edges": (C.c_size_t, [_P]),
+    "cugraph_amd_graph_num_local_edges": (C.c_size_t, [_P]),
     "cugraph_amd_set_pagerank_hot_tile": (C.c_int, [_P, C.c_int]),
     "cugraph_amd_last_traversal_stats": (None, [_P, C.POINTER(TraversalStats)]),
 }

@@ -488,6 +488,24 @@ extern "C" cugraph_error_code_t cugraph_amd_comm_host_selftest(const char* sessi
   });
 }
 
+extern "C" cugraph_error_code_t cugraph_amd_comm_host_barrier(cugraph_amd_comm_t* comm, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    auto* c = reinterpret_cast<comm_t*>(comm);
+    CGA_EXPECTS(c != nullptr && c->magic == kCommMagic, CUGRAPH_INVALID_INPUT, "not a communicator");
+    c->host_barrier();
+  });
+}
+
+extern "C" cugraph_error_code_t cugraph_amd_comm_host_allgather(cugraph_amd_comm_t* comm, const void* in, size_t bytes, void* out, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    auto* c = reinterpret_cast<comm_t*>(comm);
+    CGA_EXPECTS(c != nullptr && c->magic == kCommMagic && in != nullptr && out != nullptr, CUGRAPH_INVALID_INPUT, "not a communicator / NULL buffer");
+    c->host_allgather(in, bytes, out);
+  });
+}
+
 extern "C" int cugraph_amd_comm_rank(const cugraph_amd_comm_t* comm) { return comm ? reinterpret_cast<comm_t const*>(comm)->rank : 0; }
 extern "C" int cugraph_amd_comm_size(const cugraph_amd_comm_t* comm) { return comm ? reinterpret_cast<comm_t const*>(comm)->size : 0; }
 

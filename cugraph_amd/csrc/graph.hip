@@ -765,3 +765,11 @@ extern "C" size_t cugraph_amd_graph_num_edges(const cugraph_graph_t* graph)
 {
   return graph ? (size_t) reinterpret_cast<graph_t const*>(graph)->ne : 0;
 }
+// multi-GPU graph: the edges of THIS rank's PageRank partition (0 before the first PageRank call builds it); otherwise all edges
+extern "C" size_t cugraph_amd_graph_num_local_edges(const cugraph_graph_t* graph)
+{
+  if (!graph) return 0;
+  graph_t const& g = *reinterpret_cast<graph_t const*>(graph);
+  if (!g.mg) return (size_t)g.ne;
+  return g.mg->pr ? (size_t)g.mg->pr->ne_local : 0;
+}

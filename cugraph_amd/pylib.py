@@ -121,6 +121,20 @@ class Comm:
         self.c_comm_ptr = ptr
         self.rank, self.size = int(rank), int(size)
 
+    def barrier(self):
+        """host barrier over all ranks (timing harness; the algorithms synchronise on the device)"""
+        err = C.c_void_p()
+        assert_success(capi.lib().cugraph_amd_comm_host_barrier(self.c_comm_ptr, C.byref(err)), err, "cugraph_amd_comm_host_barrier")
+
+    def allgather_f64(self, values):
+        """every rank's list of doubles (same length everywhere, at most 512) -> list of lists, in rank order"""
+        n = len(values)
+        mine = (C.c_double * n)(*[float(v) for v in values])
+        out = (C.c_double * (n * self.size))()
+        err = C.c_void_p()
+        assert_success(capi.lib().cugraph_amd_comm_host_allgather(self.c_comm_ptr, mine, 8 * n, out, C.byref(err)), err, "cugraph_amd_comm_host_allgather")
+        return [[out[r * n + k] for k in range(n)] for r in range(self.size)]
+
     def close(self):
         p = getattr(self, "c_comm_ptr", None)
         if p:
@@ -260,12 +274,17 @@ class SGGraph:
     def num_edges(self):
         return int(capi.lib().cugraph_amd_graph_num_edges(self.c_graph_ptr))
 
+    def num_local_edges(self):
+        """multi-GPU graph: edges of this rank's PageRank partition (0 before the first PageRank call); otherwise all edges"""
+        return int(capi.lib().cugraph_amd_graph_num_local_edges(self.c_graph_ptr))
+
 
 class MGGraph(SGGraph):
     """graphs.pyx:357-700 MGGraph: this rank's slice of the edge list, as one array per column or as `num_arrays` lists of arrays
-    (cugraph_graph_create_with_times_mg concatenates them).  The library has no communicator: the call serves one-rank handles -- the
-    graph is built as SGGraph builds it, always renumbered (graph_mg.cpp:214) -- and a multi-rank job drives the per-rank plans of
-    cugraph_amd.mg / cugraph_amd.mg_traversal instead."""
+    (cugraph_graph_create_with_times_mg concatenates them).  On a ResourceHandle created on a Comm the call is COLLECTIVE: the slices of
+    all ranks become one partitioned graph (csrc/mg_graph.hip) that pagerank / bfs / sssp / louvain accept, each rank getting its owned
+    vertices back.  On a plain handle (one rank, no communicator) the graph is built as SGGraph builds it, always renumbered
+    (graph_mg.cpp:214)."""
 
     def __init__(self, resource_handle, graph_properties, src_array, dst_array, weight_array=None, store_transposed=False,
                  do_expensive_check=False, edge_id_array=None, edge_type_array=None, edge_start_time_array=None, edge_end_time_array=None,

@@ -189,6 +189,11 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_comm_create(const char* session,
 CUGRAPH_EXPORT void cugraph_amd_comm_free(cugraph_amd_comm_t* comm);
 /* the host half of the bootstrap alone (shared-memory session, barrier, all-gather of small host payloads); needs no GPU */
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_comm_host_selftest(const char* session, int rank, int size, int rounds, cugraph_error_t** error);
+/* host-side collectives of the bootstrap segment for the harness (timing barriers, max-over-ranks): a barrier, and an all-gather of at
+ * most 4096 bytes per rank (out holds size * bytes) */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_comm_host_barrier(cugraph_amd_comm_t* comm, cugraph_error_t** error);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_comm_host_allgather(cugraph_amd_comm_t* comm, const void* in, size_t bytes, void* out,
+                                                                    cugraph_error_t** error);
 CUGRAPH_EXPORT int cugraph_amd_comm_rank(const cugraph_amd_comm_t* comm);
 CUGRAPH_EXPORT int cugraph_amd_comm_size(const cugraph_amd_comm_t* comm);
 /* Collective self-check of every primitive (all-gather, all-to-all-v, integer / double all-reduce against closed forms) and timing of
@@ -228,6 +233,8 @@ CUGRAPH_EXPORT void cugraph_amd_kernel_timing_reset(const cugraph_resource_handl
 /* Graph introspection used by the tests (sizes, degree-class boundaries of the CSC/CSR row schedule). */
 CUGRAPH_EXPORT size_t cugraph_amd_graph_num_vertices(const cugraph_graph_t* graph);
 CUGRAPH_EXPORT size_t cugraph_amd_graph_num_edges(const cugraph_graph_t* graph);
+/* multi-GPU graph: edges of this rank's PageRank partition (0 before the first PageRank call has built it); otherwise all edges */
+CUGRAPH_EXPORT size_t cugraph_amd_graph_num_local_edges(const cugraph_graph_t* graph);
 
 /* Tuning knob for the PageRank SpMV: number of x entries staged in LDS per workgroup (0 = off).
  * Default is chosen from the graph size; set before plan creation.  Returns the previous value. */
