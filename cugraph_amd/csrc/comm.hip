@@ -69,6 +69,21 @@ __global__ void __launch_bounds__(256) k_push_u32(uint32_t* __restrict__ dst, ui
   for (; i < n; i += stride) dst[i] = src[i];
 }
 
+__global__ void __launch_bounds__(256) k_push_multi(comm_push_desc_t d)
+{
+  int const k          = blockIdx.y;
+  uint32_t* dst        = static_cast<uint32_t*>(d.dst[k]);
+  uint32_t const* src  = static_cast<uint32_t const*>(d.src[k]);
+  int64_t const n      = d.words[k];
+  int64_t i            = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t const stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    uint32_t const a = src[i], b = src[i + stride], c = src[i + 2 * stride], e = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = e;
+  }
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_fold_chunks(T const* staged /*[size][chunk]*/, int size, int64_t chunk, int64_t count, T* out)
 {
@@ -233,6 +248,15 @@ void comm_t::window_free(comm_window_t* w)
     ar.live.pop_back();
   }
   delete w;
+}
+
+void comm_t::push_multi(hipStream_t s, comm_push_desc_t const& d)
+{
+  int64_t biggest = 0;
+  for (int k = 0; k < d.n; ++k) biggest = std::max(biggest, d.words[k]);
+  if (biggest <= 0 || d.n <= 0) return;
+  dim3 const grid((unsigned)grid_for((biggest + 3) / 4, 256, 2048), (unsigned)d.n);
+  hipLaunchKernelGGL(k_push_multi, grid, dim3(256), 0, s, d);
 }
 
 uint64_t comm_t::signal(hipStream_t s, int channel)

@@ -63,6 +63,14 @@ struct comm_arena_t {
   std::vector<std::pair<size_t, size_t>> live;  // (offset, size) of the windows carved out, in order; size 0 = freed, waiting for the ones above it
 };
 
+// one launch that copies words[k] 4-byte words from src[k] to dst[k] (usually a peer's window) for k < n
+struct comm_push_desc_t {
+  void* dst[kCommMaxRanks];
+  void const* src[kCommMaxRanks];
+  int64_t words[kCommMaxRanks];
+  int n;
+};
+
 struct comm_t {
   uint32_t magic{kCommMagic};  // first member: cugraph_create_resource_handle recognises a communicator by it
   int rank{0}, size{1}, device{0};
@@ -91,6 +99,7 @@ struct comm_t {
   uint64_t signal(hipStream_t s, int channel);           // returns the sequence number it stored
   void wait(hipStream_t s, int channel, uint64_t seq);   // until every rank's word on `channel` is >= seq
   void device_barrier(hipStream_t s) { wait(s, 0, signal(s, 0)); }
+  void push_multi(hipStream_t s, comm_push_desc_t const& d);
   void check(char const* where) const;                   // throws when a wait timed out (call after a stream synchronisation)
   // ---- build-time data collectives on device buffers (each ends with a stream synchronisation)
   // every rank sends send[off[r] .. off[r] + counts[r]) (elements of elem bytes) to rank r; returns what it received, grouped by sender

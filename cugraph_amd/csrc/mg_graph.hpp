@@ -18,6 +18,8 @@ namespace cga {
 
 struct comm_t;
 struct comm_window_t;
+struct mg_traversal_run_t;  // traversal_mg_driver.hip: the per-rank plan + exchange windows of one traversal family
+struct paths_result_t;
 
 struct mg_pagerank_part_t {
   int P{1}, rank{0};
@@ -44,6 +46,7 @@ struct mg_traversal_part_t {
   // bottom-up BFS levels: in-edges of the owned rows, neighbours as compact global ids in ascending order of their external id
   bool has_in{false};
   dvec<int32_t> in_offsets, in_indices, ext_of_g;
+  std::shared_ptr<mg_traversal_run_t> run;  // created by the first traversal, freed with the graph (collective)
 };
 
 struct mg_graph_t {
@@ -65,5 +68,8 @@ void mg_has_vertex(handle_t const& h, graph_t const& g, int32_t const* v, int64_
 mg_pagerank_part_t& mg_pagerank_part(handle_t const& h, graph_t& g);                   // collective on first use
 mg_traversal_part_t& mg_traversal_part(handle_t const& h, graph_t& g, bool weighted);  // collective on first use
 void mg_traversal_in_edges(handle_t const& h, graph_t& g, mg_traversal_part_t& t);     // collective: the in-edge copy for bottom-up BFS levels
+// cugraph_bfs / cugraph_sssp on a multi-GPU graph (traversal_mg_driver.hip): collective; every rank gets its owned vertices back
+paths_result_t* mg_run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sources, bool direction_optimizing, size_t depth_limit, bool with_pred);
+paths_result_t* mg_run_sssp(handle_t& h, graph_t& g, size_t source, double cutoff, bool with_pred);
 
 }  // namespace cga

@@ -1479,6 +1479,8 @@ struct pagerank_mg2d_plan : pagerank_mg2d_plan_base {
 // The iteration loop is this file's step(): Python is not in it.  Replaces the multi_gpu = true path of detail::pagerank
 // (cpp/src/link_analysis/pagerank_impl.cuh:224-329) with update_edge_src_property's row broadcast (prims/update_edge_src_dst_property.cuh:550-579).
 // =================================================================================================
+// dst[i] = x_own[idx[i]] for the k-range of peer blockIdx.y: four independent gathers per thread (the index lists are ascending, so the
+// gathers walk x_own forwards), coalesced stores into the peer's window
 template <typename WT>
 __global__ void __launch_bounds__(256) k_mgc_push(WT const* x_own, int32_t const* send_index, int64_t const* first /*[P + 1]*/, WT* const* peer_x /*[P]*/,
                                                   int64_t const* dst_off /*[P]*/)
@@ -1487,25 +1489,56 @@ __global__ void __launch_bounds__(256) k_mgc_push(WT const* x_own, int32_t const
   int64_t const k0 = first[r], n = first[r + 1] - k0;
   WT* dst          = peer_x[r] + dst_off[r];
   int32_t const* idx = send_index + k0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = x_own[idx[i]];
+  int64_t const stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    int32_t const a = idx[i], b = idx[i + stride], c = idx[i + 2 * stride], d = idx[i + 3 * stride];
+    WT const va = x_own[a], vb = x_own[b], vc = x_own[c], vd = x_own[d];
+    dst[i] = va; dst[i + stride] = vb; dst[i + 2 * stride] = vc; dst[i + 3 * stride] = vd;
+  }
+  for (; i < n; i += stride) dst[i] = x_own[idx[i]];
 }
 
-__global__ void k_mgc_push_scalars(double const* totals, double* const* peer_s /*[P]: each [P][4]*/, int rank, int P)
+// this rank's (L1 change, dangling mass, max |x|) -> slot `rank` of every peer's [P][4] window, then the iteration's signal: everything
+// this stream wrote before (the pushed x) is released with it (comm.hpp: k-th signal = sequence number k in flags[channel][rank])
+__global__ void k_mgc_scalars_signal(double const* totals, double* const* peer_s, int rank, int P, uint64_t* const* peer_flags, int channel, uint64_t seq)
 {
   int const r = threadIdx.x;
   if (r < P) {
     double* d = peer_s[r] + 4 * rank;
     d[0] = totals[0]; d[1] = totals[1]; d[2] = totals[2]; d[3] = 0.0;
   }
+  __threadfence_system();
+  if (r < P) __hip_atomic_store(peer_flags[r] + (size_t)channel * kCommMaxRanks + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// waits until every rank's k-th push has landed (one lane per peer, bounded by the wall clock), then folds the P triples in rank order
+// into the constants of the next iteration
 template <typename WT>
-__global__ void k_mgc_fold(double const* triples /*[P][4]*/, int P, pr_scalars<WT>* scal, WT alpha, int64_t nv_global, double wmax)
+__global__ void k_mgc_wait_fold(uint64_t const* my_flags, int channel, uint64_t seq, long long timeout_ticks, uint32_t* err, double const* triples /*[P][4]*/, int P,
+                                pr_scalars<WT>* scal, WT alpha, int64_t nv_global, double wmax)
 {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double diff = 0, dang = 0, xmax = 0;
-  for (int r = 0; r < P; ++r) { diff += triples[4 * r]; dang += triples[4 * r + 1]; xmax = fmax(xmax, triples[4 * r + 2]); }  // rank order: every rank folds the same bits
-  tiled_write_scalars<WT>(scal, diff, dang, xmax, alpha, nv_global, 0, wmax);
+  int const r = threadIdx.x;
+  if (r < P) {
+    uint64_t const* f  = my_flags + (size_t)channel * kCommMaxRanks + r;
+    long long const t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > timeout_ticks) { __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (r == 0) {
+    double diff = 0, dang = 0, xmax = 0;
+    for (int k = 0; k < P; ++k) {
+      double const* t = triples + 4 * k;
+      diff += __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      dang += __hip_atomic_load(t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      xmax = fmax(xmax, __hip_atomic_load(t + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    }
+    tiled_write_scalars<WT>(scal, diff, dang, xmax, alpha, nv_global, 0, wmax);
+  }
 }
 
 template <typename WT>
@@ -1517,6 +1550,30 @@ __global__ void k_fill_from_scal(WT* out, int64_t n, pr_scalars<WT> const* scal,
   for (; i < n; i += stride) out[i] = v;
 }
 
+__global__ void k_mark_rows(int32_t const* rows, int64_t n, uint32_t* flags)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) flags[rows[i]] = 1u;
+}
+// one rank: row r's value goes straight to where the rank's own window wants it
+__global__ void k_self_columns(int32_t const* rows, int64_t n, int64_t first_col, int32_t* xcol)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) xcol[rows[i]] = (int32_t)(first_col + i);
+}
+// the referenced rows >= n_act, compacted: where their value goes (the row itself, or its window column when xcol is given) and their out-weight
+template <typename WT>
+__global__ void k_live_const_rows(uint32_t const* flags, uint32_t const* rank, int64_t n_act, int64_t n_rows, int32_t const* xcol, WT const* outw, int32_t* col_idx, WT* outw_c)
+{
+  int64_t r = n_act + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; r < n_rows; r += (int64_t)gridDim.x * blockDim.x)
+    if (flags[r]) {
+      uint32_t const j = rank[r] - rank[n_act];
+      col_idx[j] = xcol ? xcol[r] : (int32_t)r;
+      outw_c[j]  = outw[r];
+    }
+}
+
 template <typename WT>
 struct pagerank_mgc_plan : pagerank_plan_base {
   handle_t const& h;
@@ -1526,7 +1583,9 @@ struct pagerank_mgc_plan : pagerank_plan_base {
   WT alpha;
   int P, me;
   int64_t n_rows{0}, nv_global{0};
-  dvec<WT> pr, x_own, partial;
+  dvec<WT> pr, x_own, partial, outw_live;
+  dvec<int32_t> xcol_self, live_idx;
+  bool direct{false};  // one rank: the epilogue writes x straight into the (own) gather window -- nothing to push
   WT const* outw{nullptr};
   dvec<pr_scalars<WT>> scal;
   dvec<double> tpartials, totals;
@@ -1549,17 +1608,20 @@ struct pagerank_mgc_plan : pagerank_plan_base {
   {  // collective, like the constructor: every rank frees its plans in the same order
     try {
       (void)hipStreamSynchronize(h.stream);
-      for (int b = 0; b < 2; ++b) { if (xwin[b]) c.window_free(xwin[b]); if (swin[b]) c.window_free(swin[b]); }
+      for (int b = 1; b >= 0; --b) { if (swin[b]) c.window_free(swin[b]); if (xwin[b]) c.window_free(xwin[b]); }
     } catch (...) {
     }
   }
 
+  // where iteration results go: next = the buffer the NEXT push fills
   tiled_epilogue<WT> epi()
   {
     tiled_epilogue<WT> e;
-    e.nv = n_rows; e.pr = pr.data(); e.x_next = x_own.data(); e.outw = outw; e.pers = nullptr; e.scal = scal.data();
+    e.nv = n_rows; e.pr = pr.data(); e.outw = outw; e.pers = nullptr; e.scal = scal.data();
     e.partials = tpartials.data(); e.totals = totals.data(); e.alpha = alpha; e.nv_global = nv_global; e.wmax = tc->wmax;
     e.cr = crows;
+    if (direct) { e.x_next = static_cast<WT*>(xwin[pushes & 1]->local); e.xcol = xcol_self.data(); }
+    else e.x_next = x_own.data();
     return e;
   }
 
@@ -1569,6 +1631,7 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     part      = &mg_pagerank_part(h, g);  // collective on first use
     n_rows    = part->n_rows;
     nv_global = part->nv_global;
+    direct    = P == 1 && getenv("CUGRAPH_AMD_MG_PUSH_SELF") == nullptr;
     graph_t& lg      = *reinterpret_cast<graph_t*>(part->local);
     CGA_EXPECTS(lg.weight_type == g.weight_type, CUGRAPH_UNKNOWN_ERROR, "multi-GPU PageRank: local graph of another weight type");
     ensure_orientation(h, lg, true);
@@ -1596,10 +1659,17 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     s0.base = nv_global > 0 ? WT(1) / (WT)nv_global : WT(0);  // the first fold makes it base_prev: what the rows hold before iteration 1
     HIP_TRY(hipMemcpyAsync(scal.data(), &s0, sizeof(s0), hipMemcpyHostToDevice, h.stream));
     h.sync();
-    // rows without in-edges leave the per-iteration epilogue (spmv_tiled.hpp: tiled_const_rows); columns are the rows themselves here
+    if (direct) {  // the row -> window column map of the rank's own segment
+      xcol_self.resize_discard(n1);
+      fill_i32(h, xcol_self.data(), (int64_t)n1, -1);
+      if (part->n_send > 0)
+        hipLaunchKernelGGL(k_self_columns, grid_for(part->n_send, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)part->send_index.data(), part->n_send, part->dst_off[0], xcol_self.data());
+    }
+    // rows without in-edges leave the per-iteration epilogue (spmv_tiled.hpp: tiled_const_rows): their share of the scalars is analytic, and
+    // only those of them that SOME rank references (an entry of send_index) get their x = base / out_w written at all
     if (!getenv("CUGRAPH_AMD_PAGERANK_ALL_ROWS") && tc->n_act < n_rows && tc->nI_act > 0) {
       int64_t const n = n_rows - tc->n_act;
-      crows.n_rows = n; crows.c0 = tc->n_act; crows.n_cols = n; crows.outw_c = outw + tc->n_act; crows.nI_act = tc->nI_act;
+      crows.n_rows = n; crows.c0 = 0; crows.nI_act = tc->nI_act;
       dvec<unsigned long long> red(2);
       dvec<WT> scratch((size_t)n);
       HIP_TRY(hipMemsetAsync(red.data(), 0, 2 * sizeof(unsigned long long), h.stream));
@@ -1609,6 +1679,24 @@ struct pagerank_mgc_plan : pagerank_plan_base {
       h.read_back(r, red.data(), 2);
       crows.n_dangling = (int64_t)r[0];
       std::memcpy(&crows.max_inv_outw, &r[1], sizeof(double));
+      dvec<uint32_t> flags((size_t)n_rows + 1), rank((size_t)n_rows + 1);
+      HIP_TRY(hipMemsetAsync(flags.data(), 0, ((size_t)n_rows + 1) * 4, h.stream));
+      if (part->n_send > 0) hipLaunchKernelGGL(k_mark_rows, grid_for(part->n_send, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)part->send_index.data(), part->n_send, flags.data());
+      exclusive_scan_u32(h, flags.data(), rank.data(), n_rows + 1);
+      uint32_t ends[2];
+      HIP_TRY(hipMemcpyAsync(&ends[0], rank.data() + tc->n_act, 4, hipMemcpyDeviceToHost, h.stream));
+      HIP_TRY(hipMemcpyAsync(&ends[1], rank.data() + n_rows, 4, hipMemcpyDeviceToHost, h.stream));
+      h.sync();
+      int64_t const n_live = (int64_t)ends[1] - (int64_t)ends[0];
+      live_idx.resize_discard((size_t)std::max<int64_t>(n_live, 1));
+      outw_live.resize_discard((size_t)std::max<int64_t>(n_live, 1));
+      if (n_live > 0)
+        hipLaunchKernelGGL(k_live_const_rows<WT>, grid_for(n, kBlock, 4096), kBlock, 0, h.stream, (uint32_t const*)flags.data(), (uint32_t const*)rank.data(), (int64_t)tc->n_act, n_rows,
+                           direct ? (int32_t const*)xcol_self.data() : (int32_t const*)nullptr, outw, live_idx.data(), outw_live.data());
+      h.sync();
+      crows.n_cols  = n_live;
+      crows.col_idx = live_idx.data();
+      crows.outw_c  = outw_live.data();
     }
     // windows (collective): zeroed before anybody may push into them
     channel         = c.channel_alloc();
@@ -1628,8 +1716,9 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     h.sync();
     c.host_barrier();
     // iteration-0 state: x = pr / out_w of every owned row, this rank's (0, dangling mass, max |x|); first push
-    int const n = tiled_prologue<WT>(h, *tc, (WT const*)pr.data(), outw, x_own.data(), n_rows, tpartials.data());
-    tiled_finish<WT>(h, epi(), n, (double)s0.base);
+    tiled_epilogue<WT> const e0 = epi();
+    int const n = tiled_prologue<WT>(h, *tc, (WT const*)pr.data(), outw, e0.x_next, n_rows, tpartials.data(), direct ? (int32_t const*)xcol_self.data() : (int32_t const*)nullptr);
+    tiled_finish<WT>(h, e0, n, (double)s0.base);
     push();
     h.sync();
     c.check("multi-GPU PageRank: first exchange");
@@ -1638,15 +1727,17 @@ struct pagerank_mgc_plan : pagerank_plan_base {
   void push()
   {
     int const b = (int)(pushes & 1);
-    int64_t biggest = 0;
-    for (int r = 0; r < P; ++r) biggest = std::max(biggest, part->send_first[r + 1] - part->send_first[r]);
-    if (biggest > 0) {
-      dim3 const grid((unsigned)std::max(1, std::min(grid_for(biggest, 256, 512), 512)), (unsigned)P);
-      hipLaunchKernelGGL(k_mgc_push<WT>, grid, dim3(256), 0, h.stream, (WT const*)x_own.data(), (int32_t const*)part->send_index.data(), (int64_t const*)d_first.data(),
-                         (WT* const*)d_peer_x[b].data(), (int64_t const*)d_dst_off.data());
+    if (!direct) {
+      int64_t biggest = 0;
+      for (int r = 0; r < P; ++r) biggest = std::max(biggest, part->send_first[r + 1] - part->send_first[r]);
+      if (biggest > 0) {
+        dim3 const grid((unsigned)std::max(1, std::min(grid_for((biggest + 3) / 4, 256, 4096), 4096)), (unsigned)P);
+        hipLaunchKernelGGL(k_mgc_push<WT>, grid, dim3(256), 0, h.stream, (WT const*)x_own.data(), (int32_t const*)part->send_index.data(), (int64_t const*)d_first.data(),
+                           (WT* const*)d_peer_x[b].data(), (int64_t const*)d_dst_off.data());
+      }
     }
-    hipLaunchKernelGGL(k_mgc_push_scalars, 1, 64, 0, h.stream, (double const*)totals.data(), (double* const*)d_peer_s[b].data(), me, P);
-    c.signal(h.stream, channel);
+    uint64_t const k = ++c.seq[channel];
+    hipLaunchKernelGGL(k_mgc_scalars_signal, 1, 64, 0, h.stream, (double const*)totals.data(), (double* const*)d_peer_s[b].data(), me, P, (uint64_t* const*)c.d_peer_flags, channel, k);
     ++pushes;
   }
 
@@ -1654,9 +1745,10 @@ struct pagerank_mgc_plan : pagerank_plan_base {
   void fold(bool read_back)
   {
     if (folds < pushes) {
-      c.wait(h.stream, channel, folds + 1);
       int const b = (int)(folds & 1);
-      hipLaunchKernelGGL(k_mgc_fold<WT>, 1, 64, 0, h.stream, (double const*)swin[b]->local, P, scal.data(), alpha, nv_global, tc->wmax);
+      long long const ticks = (long long)(c.timeout_s * (double)c.wall_ticks_per_s);
+      hipLaunchKernelGGL(k_mgc_wait_fold<WT>, 1, 64, 0, h.stream, (uint64_t const*)c.flags->local, channel, folds + 1, ticks, c.err_word, (double const*)swin[b]->local, P, scal.data(),
+                         alpha, nv_global, tc->wmax);
       ++folds;
     }
     if (read_back) {

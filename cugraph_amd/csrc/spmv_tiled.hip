@@ -1333,10 +1333,12 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
   if (a.e.cr.nI_act > 0 && I >= a.e.cr.nI_act) {  // tiled_const_rows: x of the live columns whose rows have no in-edge
     WT const b       = a.e.scal->base;
     int64_t const n  = a.e.cr.n_cols;
-    WT* const xo     = a.e.x_next + a.e.cr.c0;
+    WT* const xo           = a.e.x_next + a.e.cr.c0;
+    int32_t const* const ci = a.e.cr.col_idx;
     for (int64_t j = (int64_t)(I - a.e.cr.nI_act) * (TP2_BLOCK * 8) + tid, k = 0; k < 8 && j < n; ++k, j += TP2_BLOCK) {
       WT const ow = a.e.cr.outw_c[j];
-      xo[j]       = b / (ow == WT(0) ? WT(1) : ow);
+      WT const xv = b / (ow == WT(0) ? WT(1) : ow);
+      if (ci) a.e.x_next[ci[j]] = xv; else xo[j] = xv;
     }
     return;
   }
@@ -1558,10 +1560,11 @@ void tiled_finish(handle_t const& h, tiled_epilogue<WT> const& e, int n_partials
 }
 
 template <typename WT>
-int tiled_prologue(handle_t const& h, tiled_csc_t const& t, WT const* pr, WT const* outw, WT* x, int64_t nv, double* partials)
+int tiled_prologue(handle_t const& h, tiled_csc_t const& t, WT const* pr, WT const* outw, WT* x, int64_t nv, double* partials, int32_t const* xcol_override)
 {
   int const grid = std::max(1, std::min(t.nI, grid_for(nv, 256, 1024)));
-  hipLaunchKernelGGL(k_tiled_prologue<WT>, grid, 256, 0, h.stream, pr, outw, t.xcol.size() ? (int32_t const*)t.xcol.data() : (int32_t const*)nullptr, x, nv, partials);
+  int32_t const* xc = xcol_override ? xcol_override : (t.xcol.size() ? (int32_t const*)t.xcol.data() : (int32_t const*)nullptr);
+  hipLaunchKernelGGL(k_tiled_prologue<WT>, grid, 256, 0, h.stream, pr, outw, xc, x, nv, partials);
   return grid;
 }
 
@@ -1576,7 +1579,7 @@ void tiled_scalars_from_ranks(handle_t const& h, tiled_epilogue<WT> const& e, vo
   template void tiled_phase1<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT, WT*, uint32_t*, tiled_x_map<WT> const&, tiled_epilogue<WT> const*); \
   template void tiled_phase2<WT>(handle_t const&, tiled_csc_t const&, WT const*, tiled_epilogue<WT> const&, uint32_t*);                                  \
   template void tiled_finish<WT>(handle_t const&, tiled_epilogue<WT> const&, int, double);                                                           \
-  template int tiled_prologue<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT const*, WT*, int64_t, double*);                          \
+  template int tiled_prologue<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT const*, WT*, int64_t, double*, int32_t const*);          \
   template void tiled_scalars_from_ranks<WT>(handle_t const&, tiled_epilogue<WT> const&, void const*, size_t, size_t, int);
 CGA_INSTANTIATE_TILED(float)
 CGA_INSTANTIATE_TILED(double)

@@ -56,6 +56,8 @@ struct tiled_const_rows {
   double max_inv_outw{0};    // max over those rows of 1 / (outw == 0 ? 1 : outw)
   WT const* outw_c{nullptr}; // out-weight sums of the live columns >= c0, in column order
   int64_t c0{0}, n_cols{0};
+  int32_t const* col_idx{nullptr};  // non-null: the j-th live column is written to x_next[col_idx[j]] instead of x_next[c0 + j] (multi-GPU
+                                    // plans: only the rows some rank references get a value, wherever the exchange wants it)
 };
 
 constexpr int TP_BLOCK = 1024;               // phase-1 workgroup: 16 wavefronts sharing one LDS tile
@@ -195,7 +197,8 @@ inline int tiled_fold_count(tiled_csc_t const& t, tiled_epilogue<WT> const& e) {
 
 // iteration-0 state: x = pr / out_w plus per-block (0, dangling, max |x|) partials; returns the number of partial triples
 template <typename WT>
-int tiled_prologue(handle_t const& h, tiled_csc_t const& t, WT const* pr, WT const* outw, WT* x, int64_t nv, double* partials);  // honours t.xcol
+int tiled_prologue(handle_t const& h, tiled_csc_t const& t, WT const* pr, WT const* outw, WT* x, int64_t nv, double* partials,
+                   int32_t const* xcol_override = nullptr);  // honours t.xcol (or the given row -> column map, -1 = no column)
 
 // multi-GPU: e.scal <- fold of the per-rank (diff, dangling, xmax) triples at recv + first_off + r * stride_bytes
 template <typename WT>

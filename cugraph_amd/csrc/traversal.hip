@@ -25,6 +25,7 @@
 // consecutive adjacency words; degree >= 64 rows are walked by the whole wave; degree >= 2048 rows are
 // deferred to a second kernel in which the whole grid strides the adjacency list.
 #include "common.hpp"
+#include "mg_graph.hpp"
 
 #include <chrono>
 #include "traversal_common.hpp"
@@ -1541,8 +1542,13 @@ extern "C" cugraph_error_code_t cugraph_bfs(const cugraph_resource_handle_t* han
   return guarded(error, [&] {
     CGA_EXPECTS(result != nullptr, CUGRAPH_INVALID_INPUT, "result is NULL");
     handle_t& h = const_cast<handle_t&>(H(handle));
+    graph_t& g  = GM(graph);
+    if (g.mg) {  // a graph from cugraph_graph_create_mg on a communicator handle: collective (traversal_mg_driver.hip)
+      *result = reinterpret_cast<cugraph_paths_result_t*>(mg_run_bfs(h, g, V(sources), direction_optimizing == TRUE, depth_limit, compute_predecessors == TRUE));
+      return;
+    }
     *result     = reinterpret_cast<cugraph_paths_result_t*>(
-      run_bfs(h, G(graph), V(sources), direction_optimizing == TRUE, depth_limit, compute_predecessors == TRUE));
+      run_bfs(h, g, V(sources), direction_optimizing == TRUE, depth_limit, compute_predecessors == TRUE));
   });
 }
 
@@ -1554,7 +1560,11 @@ extern "C" cugraph_error_code_t cugraph_sssp(const cugraph_resource_handle_t* ha
   return guarded(error, [&] {
     CGA_EXPECTS(result != nullptr, CUGRAPH_INVALID_INPUT, "result is NULL");
     handle_t& h = const_cast<handle_t&>(H(handle));
-    graph_t& g  = G(graph);
+    graph_t& g  = GM(graph);
+    if (g.mg) {
+      *result = reinterpret_cast<cugraph_paths_result_t*>(mg_run_sssp(h, g, source, cutoff, compute_predecessors == TRUE));
+      return;
+    }
     // sssp.cpp:72-73,105 dereferences the edge weights unconditionally: an unweighted graph is an error
     CGA_EXPECTS(g.has_weights, CUGRAPH_INVALID_INPUT, "cugraph_sssp requires a weighted graph");
     paths_result_t* r = g.weight_type == FLOAT64 ? run_sssp<double>(h, g, source, cutoff, compute_predecessors == TRUE)

@@ -1,0 +1,340 @@
+// cugraph_bfs / cugraph_sssp on a graph from cugraph_graph_create_mg (a handle on the library's communicator): the level loop of the
+// partitioned traversals inside the library.  Per-rank compute = the plan of traversal_mg.hip (sender-side reduction of candidates,
+// counting sort by owner, owner-side apply, bottom-up BFS levels on the in-edge copy); exchange = peer pushes into persistent windows
+// (comm.hpp): the candidate tuples go straight into every owner's receive window at the offset the count matrix assigns (one host
+// all-gather of P counts per level through the bootstrap segment), the L-bit new-frontier bitmaps and three statistics per rank into a
+// [P][L/32] / [P][4] window double-buffered by level parity -- one signal per exchange, no collective launch.
+// Replaces the multi_gpu = true halves of cpp/src/traversal/bfs_impl.cuh:133-870, sssp_impl.cuh:169-566 and the shuffle of
+// prims/transform_reduce_if_v_frontier_outgoing_e_by_dst.cuh:981-1074 (what cugraph_amd/mg_traversal.py does over torch.distributed).
+#include "comm.hpp"
+#include "mg_graph.hpp"
+
+#include <algorithm>
+#include <cfloat>
+
+namespace cga {
+
+namespace {
+
+void ck(cugraph_error_code_t rc, cugraph_error_t* err, char const* what)
+{
+  if (rc == CUGRAPH_SUCCESS) return;
+  std::string msg = err ? cugraph_error_message(err) : "?";
+  cugraph_error_free(err);
+  throw api_error(rc, std::string(what) + ": " + msg);
+}
+
+__global__ void k_lookup_pos(int32_t const* ids, int64_t n, int64_t vmin, int64_t vrange, int32_t const* pos, uint32_t const* out_deg, int32_t* out_pos, unsigned long long* deg_sum)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t const k = (int64_t)ids[i] - vmin;
+    int32_t const p = (k >= 0 && k < vrange) ? pos[k] : -1;
+    out_pos[i]      = p;
+    if (p >= 0 && deg_sum) atomicAdd(deg_sum, (unsigned long long)out_deg[k]);
+  }
+}
+
+__global__ void k_put_stats(unsigned long long* const* peer_s, int rank, int P, unsigned long long a, unsigned long long b, unsigned long long c)
+{
+  int const r = threadIdx.x;
+  if (r < P) {
+    unsigned long long* d = peer_s[r] + 4 * rank;
+    d[0] = a; d[1] = b; d[2] = c; d[3] = 0;
+  }
+}
+
+}  // namespace
+
+// the plan of one traversal family on one graph + its exchange windows (created on first use, freed with the graph: collective)
+struct mg_traversal_run_t {
+  comm_t* c{nullptr};
+  handle_t const* h{nullptr};
+  int mode{0}, tw{2};
+  cugraph_amd_traversal_mg_plan_t* plan{nullptr};
+  dvec<int32_t> send;
+  size_t capacity{0};
+  comm_window_t* twin{nullptr};                  // received candidate tuples, grouped by sender
+  comm_window_t* bwin[2]{nullptr, nullptr};      // BFS: [P][L / 32] gathered new-frontier bits, by level parity
+  comm_window_t* swin[2]{nullptr, nullptr};      // BFS: [P][4] (discoveries, their out- and in-degree sums)
+  dvec<unsigned long long*> d_peer_s[2];
+  int channel{0};
+  bool bottom_up_set{false};
+  ~mg_traversal_run_t()
+  {
+    try {
+      if (h) (void)hipStreamSynchronize(h->stream);
+      if (plan) cugraph_amd_traversal_mg_plan_free(plan);
+      for (int b = 1; b >= 0; --b) { if (swin[b]) c->window_free(swin[b]); if (bwin[b]) c->window_free(bwin[b]); }
+      if (twin) c->window_free(twin);
+    } catch (...) {
+    }
+  }
+};
+
+namespace {
+
+mg_traversal_run_t& ensure_run(handle_t const& h, graph_t& g, mg_traversal_part_t& t, int mode)
+{
+  if (t.run) return *t.run;
+  comm_t& c = *g.mg->comm;
+  auto r    = std::make_shared<mg_traversal_run_t>();
+  r->c = &c; r->h = &h; r->mode = mode; r->tw = mode == 0 ? 2 : 3;
+  int const P = t.P;
+  r->capacity = (size_t)std::max<int64_t>(std::min<int64_t>(t.L * P, std::max<int64_t>(t.ne_local, 1)), 1);
+  r->send.resize_discard(r->capacity * r->tw + 64);
+  cugraph_error_t* err = nullptr;
+  auto hh = reinterpret_cast<cugraph_resource_handle_t const*>(&h);
+  ck(cugraph_amd_traversal_mg_plan_create(hh, t.offsets.data(), t.indices.data(), t.has_weights ? t.weights.data() : nullptr, (size_t)t.n_rows, (size_t)t.ne_local, (size_t)t.L,
+                                          t.rank, P, t.local_vertices.data(), mode, r->send.data(), r->capacity, &r->plan, &err),
+     err, "multi-GPU traversal plan");
+  // every sender sends a destination at most once per level: at most L tuples per (sender, owner) pair
+  r->channel = c.channel_alloc();
+  r->twin    = c.window_create((size_t)P * (size_t)t.L * r->tw * 4);
+  if (mode == 0)
+    for (int b = 0; b < 2; ++b) {
+      r->bwin[b] = c.window_create((size_t)P * (size_t)(t.L / 32) * 4);
+      r->swin[b] = c.window_create((size_t)P * 4 * sizeof(unsigned long long));
+      HIP_TRY(hipMemsetAsync(r->bwin[b]->local, 0, (size_t)P * (size_t)(t.L / 32) * 4, h.stream));
+      HIP_TRY(hipMemsetAsync(r->swin[b]->local, 0, (size_t)P * 4 * sizeof(unsigned long long), h.stream));
+      r->d_peer_s[b].resize_discard(P);
+      HIP_TRY(hipMemcpyAsync(r->d_peer_s[b].data(), r->swin[b]->peer.data(), (size_t)P * sizeof(void*), hipMemcpyHostToDevice, h.stream));
+    }
+  h.sync();
+  c.host_barrier();
+  t.run = r;
+  return *t.run;
+}
+
+// all-to-all-v of the candidate tuples `send` holds grouped by owner: returns the number of tuples now in the local receive window
+size_t exchange_tuples(handle_t const& h, mg_traversal_run_t& r, int P, int me, size_t const* send_counts)
+{
+  comm_t& c = *r.c;
+  std::vector<int64_t> mine(P), M((size_t)P * P);
+  for (int k = 0; k < P; ++k) mine[k] = (int64_t)send_counts[k];
+  c.host_allgather(mine.data(), (size_t)P * sizeof(int64_t), M.data());
+  comm_push_desc_t d{};
+  int64_t soff = 0, total = 0;
+  for (int s = 0; s < P; ++s) total += M[(size_t)s * P + me];
+  CGA_EXPECTS((size_t)total * r.tw * 4 <= r.twin->bytes[me], CUGRAPH_UNKNOWN_ERROR, "multi-GPU traversal: more candidates than the receive window holds");
+  for (int k = 0; k < P; ++k) {
+    int64_t roff = 0;  // where this rank's tuples start in owner k's window: behind the lower ranks'
+    for (int s = 0; s < me; ++s) roff += M[(size_t)s * P + k];
+    d.dst[k]   = r.twin->at<int32_t>(k) + roff * r.tw;
+    d.src[k]   = r.send.data() + soff * r.tw;
+    d.words[k] = mine[k] * r.tw;
+    soff += mine[k];
+  }
+  d.n = P;
+  c.push_multi(h.stream, d);
+  c.wait(h.stream, r.channel, c.signal(h.stream, r.channel));
+  return (size_t)total;
+}
+
+struct level_stats_t { unsigned long long n, out_sum, in_sum; };
+
+// BFS: every rank's new-frontier bits + (discoveries, out-degree sum, in-degree sum) -> every rank; merges the bits into the visited set
+level_stats_t share_frontier(handle_t const& h, mg_traversal_run_t& r, mg_traversal_part_t const& t, int b, level_stats_t mine)
+{
+  comm_t& c   = *r.c;
+  int const P = t.P, me = t.rank;
+  cugraph_error_t* err = nullptr;
+  uint32_t const* bits = nullptr;
+  ck(cugraph_amd_traversal_mg_plan_frontier_bits(r.plan, &bits, &err), err, "frontier bits");
+  int64_t const W = t.L / 32;
+  comm_push_desc_t d{};
+  for (int k = 0; k < P; ++k) { d.dst[k] = r.bwin[b]->at<uint32_t>(k) + (int64_t)me * W; d.src[k] = bits; d.words[k] = W; }
+  d.n = P;
+  c.push_multi(h.stream, d);
+  hipLaunchKernelGGL(k_put_stats, 1, 64, 0, h.stream, (unsigned long long* const*)r.d_peer_s[b].data(), me, P, mine.n, mine.out_sum, mine.in_sum);
+  c.wait(h.stream, r.channel, c.signal(h.stream, r.channel));
+  ck(cugraph_amd_traversal_mg_plan_merge_visited(r.plan, static_cast<uint32_t const*>(r.bwin[b]->local), &err), err, "merge visited");  // synchronises
+  std::vector<unsigned long long> all((size_t)P * 4);
+  HIP_TRY(hipMemcpy(all.data(), r.swin[b]->local, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  c.check("multi-GPU BFS level");
+  level_stats_t tot{0, 0, 0};
+  for (int k = 0; k < P; ++k) { tot.n += all[4 * k]; tot.out_sum += all[4 * k + 1]; tot.in_sum += all[4 * k + 2]; }
+  return tot;
+}
+
+// the union of the ranks' source lists (external ids), sorted, without duplicates: every rank ends with the same list
+std::vector<int32_t> gather_sources(handle_t const& h, comm_t& c, device_array_view_t const* sources)
+{
+  int64_t const ns = sources ? (int64_t)sources->size : 0;
+  std::vector<int32_t> mine((size_t)ns);
+  if (ns > 0) HIP_TRY(hipMemcpyAsync(mine.data(), sources->data, (size_t)ns * 4, hipMemcpyDeviceToHost, h.stream));
+  h.sync();
+  std::vector<int64_t> counts(c.size);
+  int64_t n64 = ns;
+  c.host_allgather(&n64, sizeof(n64), counts.data());
+  int64_t biggest = 0;
+  for (auto x : counts) biggest = std::max(biggest, x);
+  std::vector<int32_t> all;
+  int64_t const chunk = (int64_t)(kCommSlotBytes / 4);
+  std::vector<int32_t> buf((size_t)chunk), got((size_t)chunk * c.size);
+  for (int64_t first = 0; first < biggest; first += chunk) {
+    std::fill(buf.begin(), buf.end(), 0);
+    for (int64_t k = 0; k < chunk && first + k < ns; ++k) buf[k] = mine[first + k];
+    c.host_allgather(buf.data(), (size_t)chunk * 4, got.data());
+    for (int r = 0; r < c.size; ++r)
+      for (int64_t k = 0; k < chunk && first + k < counts[r]; ++k) all.push_back(got[(size_t)r * chunk + k]);
+  }
+  std::sort(all.begin(), all.end());
+  all.erase(std::unique(all.begin(), all.end()), all.end());
+  return all;
+}
+
+struct located_t {
+  std::vector<int32_t> rows;  // local rows of the sources this rank owns
+  unsigned long long out_deg_sum{0};
+  int64_t n_sources{0};
+};
+
+located_t locate_sources(handle_t const& h, graph_t& g, mg_traversal_part_t const& t, std::vector<int32_t> const& ext, char const* api)
+{
+  mg_graph_t const& mg = *g.mg;
+  located_t out;
+  out.n_sources = (int64_t)ext.size();
+  if (ext.empty()) return out;
+  dvec<int32_t> d_ids(ext.size()), d_pos(ext.size());
+  dvec<unsigned long long> d_sum(1);
+  HIP_TRY(hipMemcpyAsync(d_ids.data(), ext.data(), ext.size() * 4, hipMemcpyHostToDevice, h.stream));
+  HIP_TRY(hipMemsetAsync(d_sum.data(), 0, 8, h.stream));
+  hipLaunchKernelGGL(k_lookup_pos, grid_for((int64_t)ext.size(), kBlock, 1024), kBlock, 0, h.stream, (int32_t const*)d_ids.data(), (int64_t)ext.size(), mg.vmin, mg.vrange,
+                     (int32_t const*)t.pos.data(), (uint32_t const*)t.out_deg.data(), d_pos.data(), d_sum.data());
+  std::vector<int32_t> pos(ext.size());
+  HIP_TRY(hipMemcpyAsync(pos.data(), d_pos.data(), ext.size() * 4, hipMemcpyDeviceToHost, h.stream));
+  h.read_back(&out.out_deg_sum, d_sum.data(), 1);
+  for (size_t i = 0; i < pos.size(); ++i) {
+    CGA_EXPECTS(pos[i] >= 0, CUGRAPH_INVALID_INPUT, std::string(api) + ": found a source that is not a vertex of the graph");  // bfs.cpp:106-119
+    if (pos[i] % t.P == t.rank) out.rows.push_back(pos[i] / t.P);
+  }
+  return out;
+}
+
+paths_result_t* collect(handle_t const& h, mg_traversal_run_t& r, mg_traversal_part_t const& t, bool with_pred, cugraph_data_type_id_t dist_type)
+{
+  auto ids   = std::make_unique<device_array_t>((size_t)t.n_rows, INT32);
+  auto dist  = std::make_unique<device_array_t>((size_t)t.n_rows, dist_type);
+  auto preds = std::make_unique<device_array_t>(with_pred ? (size_t)t.n_rows : 0, INT32);
+  if (t.n_rows > 0) {
+    HIP_TRY(hipMemcpyAsync(ids->buf.ptr, t.local_vertices.data(), (size_t)t.n_rows * 4, hipMemcpyDeviceToDevice, h.stream));
+    cugraph_error_t* err = nullptr;
+    ck(cugraph_amd_traversal_mg_plan_results(r.plan, dist->buf.ptr, with_pred ? preds->buf.as<int32_t>() : nullptr, &err), err, "results");
+  }
+  h.sync();
+  r.c->check("multi-GPU traversal result");
+  return new paths_result_t{ids.release(), dist.release(), preds.release()};
+}
+
+}  // namespace
+
+paths_result_t* mg_run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sources, bool direction_optimizing, size_t depth_limit, bool with_pred)
+{
+  HIP_TRY(hipSetDevice(h.device));
+  CGA_EXPECTS(handle_comm(h) == g.mg->comm, CUGRAPH_INVALID_HANDLE, "multi-GPU BFS: the handle is not on the communicator the graph was created on");
+  CGA_EXPECTS(sources == nullptr || sources->type == INT32, CUGRAPH_INVALID_INPUT, "vertex type of graph and sources must match");
+  if (direction_optimizing)  // bfs_impl.cuh:202-204
+    CGA_EXPECTS(g.props.is_symmetric == TRUE, CUGRAPH_INVALID_INPUT, "Invalid input argument: input graph should be symmetric for direction optimizing BFS.");
+  comm_t& c = *g.mg->comm;
+  mg_traversal_part_t& t = mg_traversal_part(h, g, false);
+  mg_traversal_run_t& r  = ensure_run(h, g, t, 0);
+  int const P = t.P, me = t.rank;
+  cugraph_error_t* err = nullptr;
+  // bottom-up levels (the direction never changes distances or the minimum-external-id parents): needs the in-edge copy
+  static bool const allow_bu = !(getenv("CUGRAPH_AMD_MG_BFS_BOTTOM_UP") && std::string(getenv("CUGRAPH_AMD_MG_BFS_BOTTOM_UP")) == "0");
+  if (allow_bu && !r.bottom_up_set) {
+    mg_traversal_in_edges(h, g, t);
+    ck(cugraph_amd_traversal_mg_plan_set_bottom_up(r.plan, t.in_offsets.data(), t.in_indices.data(), t.ext_of_g.data(), &err), err, "set_bottom_up");
+    r.bottom_up_set = true;
+  }
+  bool const bu_ok = r.bottom_up_set;
+  std::vector<int32_t> const ext = gather_sources(h, c, sources);
+  located_t const loc            = locate_sources(h, g, t, ext, "cugraph_bfs");
+  dvec<int32_t> d_rows(std::max<size_t>(loc.rows.size(), 1));
+  if (!loc.rows.empty()) HIP_TRY(hipMemcpyAsync(d_rows.data(), loc.rows.data(), loc.rows.size() * 4, hipMemcpyHostToDevice, h.stream));
+  h.sync();
+  ck(cugraph_amd_traversal_mg_plan_reset(r.plan, loc.rows.empty() ? nullptr : d_rows.data(), loc.rows.size(), (double)FLT_MAX, with_pred ? TRUE : FALSE, &err), err, "reset");
+  (void)share_frontier(h, r, t, 0, level_stats_t{0, 0, 0});
+  // Beamer's direction rule on GLOBAL sums, the single-GPU driver's constants (traversal.hip: run_bfs)
+  double const alpha = getenv("CUGRAPH_AMD_BFS_ALPHA") ? atof(getenv("CUGRAPH_AMD_BFS_ALPHA")) : 60.0;
+  double const beta  = getenv("CUGRAPH_AMD_BFS_BETA") ? atof(getenv("CUGRAPH_AMD_BFS_BETA")) : 24.0;
+  char const* force  = getenv("CUGRAPH_AMD_MG_BFS");  // "bottomup" / "topdown": pin the direction (tests)
+  unsigned long long n_front = (unsigned long long)loc.n_sources, frontier_out = loc.out_deg_sum, unvisited_in = (unsigned long long)t.ne_global;
+  uint64_t const limit = depth_limit > (size_t)INT32_MAX ? (uint64_t)INT32_MAX : (uint64_t)depth_limit;
+  bool bottom_up = false;
+  uint64_t level = 0;
+  uint64_t steps = 0, bu_levels = 0;
+  while (n_front > 0) {
+    ++level;
+    if (level > limit) break;  // depth_limit is compared after incrementing (bfs_impl.cuh:867-868)
+    if (bu_ok) {
+      if (!bottom_up) bottom_up = (double)frontier_out > (double)unvisited_in / alpha && n_front > 1024;
+      else bottom_up = !((double)n_front < (double)t.nv_global / beta);
+      if (force && std::string(force) == "bottomup") bottom_up = true;
+      if (force && std::string(force) == "topdown") bottom_up = false;
+    }
+    size_t n_next = 0;
+    if (bottom_up) {
+      ck(cugraph_amd_traversal_mg_plan_bottom_up(r.plan, static_cast<uint32_t const*>(r.bwin[(level - 1) & 1]->local), (uint32_t)level, &n_next, &err), err, "bottom_up");
+      ++bu_levels;
+    } else {
+      size_t counts[kCommMaxRanks];
+      ck(cugraph_amd_traversal_mg_plan_expand(r.plan, counts, &err), err, "expand");
+      size_t const got = exchange_tuples(h, r, P, me, counts);
+      ck(cugraph_amd_traversal_mg_plan_apply(r.plan, static_cast<int32_t const*>(r.twin->local), got, (uint32_t)level, &n_next, &err), err, "apply");
+    }
+    unsigned long long o_sum = 0, i_sum = 0;
+    if (bu_ok) ck(cugraph_amd_traversal_mg_plan_last_degree_sums(r.plan, &o_sum, &i_sum, &err), err, "degree sums");
+    level_stats_t const tot = share_frontier(h, r, t, (int)(level & 1), level_stats_t{(unsigned long long)n_next, o_sum, i_sum});
+    n_front      = tot.n;
+    frontier_out = tot.out_sum;
+    unvisited_in = unvisited_in > tot.in_sum ? unvisited_in - tot.in_sum : 0;
+    ++steps;
+  }
+  h.last_stats       = cugraph_amd_traversal_stats_t{};
+  h.last_stats.steps = steps;
+  h.last_stats.edges_inspected = bu_levels;  // (bottom-up levels taken: what the direction tests look at)
+  return collect(h, r, t, with_pred, INT32);
+}
+
+paths_result_t* mg_run_sssp(handle_t& h, graph_t& g, size_t source, double cutoff, bool with_pred)
+{
+  HIP_TRY(hipSetDevice(h.device));
+  CGA_EXPECTS(handle_comm(h) == g.mg->comm, CUGRAPH_INVALID_HANDLE, "multi-GPU SSSP: the handle is not on the communicator the graph was created on");
+  CGA_EXPECTS(g.has_weights, CUGRAPH_INVALID_INPUT, "cugraph_sssp requires a weighted graph");  // sssp.cpp:72-73,105
+  CGA_EXPECTS(g.weight_type == FLOAT32, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "multi-GPU SSSP takes FLOAT32 weights in this build");
+  comm_t& c = *g.mg->comm;
+  mg_traversal_part_t& t = mg_traversal_part(h, g, true);
+  mg_traversal_run_t& r  = ensure_run(h, g, t, 1);
+  int const P = t.P, me = t.rank;
+  cugraph_error_t* err = nullptr;
+  CGA_EXPECTS(source <= (size_t)INT32_MAX, CUGRAPH_INVALID_INPUT, "cugraph_sssp: source is not a vertex of the graph");
+  std::vector<int32_t> const ext{(int32_t)source};
+  located_t const loc = locate_sources(h, g, t, ext, "cugraph_sssp");
+  dvec<int32_t> d_rows(1);
+  if (!loc.rows.empty()) HIP_TRY(hipMemcpyAsync(d_rows.data(), loc.rows.data(), 4, hipMemcpyHostToDevice, h.stream));
+  h.sync();
+  ck(cugraph_amd_traversal_mg_plan_reset(r.plan, loc.rows.empty() ? nullptr : d_rows.data(), loc.rows.size(), cutoff, with_pred ? TRUE : FALSE, &err), err, "reset");
+  uint64_t rounds = 0;
+  for (;;) {
+    ++rounds;
+    size_t counts[kCommMaxRanks];
+    size_t n_next = 0;
+    ck(cugraph_amd_traversal_mg_plan_expand(r.plan, counts, &err), err, "expand");
+    size_t const got = exchange_tuples(h, r, P, me, counts);
+    ck(cugraph_amd_traversal_mg_plan_apply(r.plan, static_cast<int32_t const*>(r.twin->local), got, (uint32_t)rounds, &n_next, &err), err, "apply");
+    c.check("multi-GPU SSSP round");
+    int64_t mine = (int64_t)n_next;
+    std::vector<int64_t> all(P);
+    c.host_allgather(&mine, sizeof(mine), all.data());  // the search ends when the global frontier is empty
+    int64_t tot = 0;
+    for (auto x : all) tot += x;
+    if (tot == 0) break;
+  }
+  h.last_stats       = cugraph_amd_traversal_stats_t{};
+  h.last_stats.steps = rounds;
+  return collect(h, r, t, with_pred, FLOAT32);
+}
+
+}  // namespace cga

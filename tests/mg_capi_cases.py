@@ -38,6 +38,44 @@ def run(what, cg, h, comm, rank, size, outdir, args):
         v2, x2, _ = cg.pagerank(h, g, None, None, None, None, 0.85, eps, max_iter, False, fail_on_nonconvergence=False)
         out["repeat_equal"] = bool(torch.equal(v, v2) and torch.equal(x, x2))
         del g
+    elif what in ("bfs", "sssp"):
+        scale, n_roots, with_pred = int(args[0]), int(args[1]), args[2] == "p"
+        (s, d), first = rmat_slice(scale, rank, size)
+        nv = 1 << scale
+        verts = np.arange(rank, nv, size, dtype=np.int32)
+        w = None
+        if what == "sssp":
+            kind = args[3]
+            wall = (np.random.default_rng(1).integers(1, 256, size=16 << scale).astype(np.float32) if kind == "int" else np.ones(16 << scale, np.float32))
+            w = wall[first: first + s.size].copy()
+        g = cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [T(s)], [T(d)], None if w is None else [T(w)], store_transposed=False, vertices_array=[T(verts)])
+        # roots: the same list on every rank (vertices with out-edges, fixed seed); BFS hands every rank a SLICE of it (the union is the source set)
+        all_s, _ = rmat_slice(scale, 0, 1)
+        cand = np.unique(all_s[0])
+        roots = np.random.default_rng(7).choice(cand, size=n_roots, replace=False).astype(np.int32)
+        res = {}
+        if what == "bfs":
+            depth = int(args[3]) if len(args) > 3 else 0
+            for k, root in enumerate(roots):
+                mine = np.array([root], np.int32) if k % size == rank else np.zeros(0, np.int32)  # one rank names the source
+                dist, pred, v = cg.bfs(h, g, T(mine), False, depth, with_pred, False)
+                res[f"v{k}"], res[f"d{k}"] = v.cpu().numpy(), dist.cpu().numpy()
+                if with_pred:
+                    res[f"p{k}"] = pred.cpu().numpy()
+            stats = h.last_traversal_stats()
+            out["levels"], out["bottom_up_levels"] = int(stats["steps"]), int(stats["edges_inspected"])
+            # multi-source: all roots at once, every rank passing the whole list
+            dist, pred, v = cg.bfs(h, g, T(roots), False, depth, False, False)
+            res["vm"], res["dm"] = v.cpu().numpy(), dist.cpu().numpy()
+        else:
+            cutoff = float(args[4]) if len(args) > 4 else 3.0e38
+            for k, root in enumerate(roots):
+                v, dist, pred = cg.sssp(h, g, int(root), cutoff, with_pred, False)
+                res[f"v{k}"], res[f"d{k}"] = v.cpu().numpy(), dist.cpu().numpy()
+                if with_pred:
+                    res[f"p{k}"] = pred.cpu().numpy()
+        np.savez(outdir / f"rank{rank}.npz", roots=roots, **res)
+        del g
     else:
         raise ValueError(what)
     return out

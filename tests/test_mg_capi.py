@@ -98,3 +98,69 @@ def test_mg_capi_pagerank_converges_like_single_gpu(orc, tmp_path):
     t, it, tconv = truth(orc, 11, 1e-5, 200)
     assert tconv
     np.testing.assert_allclose(pr, t, rtol=1e-4)
+
+
+def _assemble_paths(tmp_path, world, nv, k):
+    res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    seen = np.zeros(nv, np.int32)
+    dist = np.zeros(nv, res[0][f"d{k}"].dtype)
+    pred = np.full(nv, -2, np.int32)
+    for r in res:
+        seen[r[f"v{k}"]] += 1
+        dist[r[f"v{k}"]] = r[f"d{k}"]
+        if f"p{k}" in r:
+            pred[r[f"v{k}"]] = r[f"p{k}"]
+    assert (seen == 1).all(), "every vertex must come back from exactly one rank"
+    return res[0]["roots"], dist, pred
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,direction", [(1, ""), (2, ""), (3, "topdown"), (4, "bottomup"), (4, "")])
+def test_mg_capi_bfs(orc, tmp_path, world, direction):
+    """cugraph_graph_create_mg + cugraph_bfs on a communicator handle (ranks sharing one GPU): distances bit-exact against the oracle,
+    parents = minimum external id among the valid ones whatever directions the levels took; one rank names each source (the union of
+    the ranks' lists is the source set), and one multi-source call with the whole list on every rank."""
+    from test_mg_traversal import check_bfs
+
+    scale, n_roots = 12, 3
+    res = run_ranks("bfs", world, tmp_path, scale, n_roots, "p", env_extra={"CUGRAPH_AMD_MG_BFS": direction})
+    for k in range(n_roots):
+        roots, dist, pred = _assemble_paths(tmp_path, world, 1 << scale, k)
+        check_bfs(orc, scale, [int(roots[k])], dist, pred)
+    if direction == "bottomup":
+        assert res[0]["bottom_up_levels"] == res[0]["levels"]
+    if direction == "topdown":
+        assert res[0]["bottom_up_levels"] == 0
+    roots, dist, _ = _assemble_paths(tmp_path, world, 1 << scale, "m")
+    nv, s, d, _, off, idx, _ = __import__("test_mg_traversal").graph(orc, scale)
+    od, _ = orc.bfs(nv, off, idx, np.asarray(roots, np.int32), 2**31 - 1)
+    assert np.array_equal(dist, od)
+
+
+@pytest.mark.gpu
+def test_mg_capi_bfs_depth_limit(orc, tmp_path):
+    from test_mg_traversal import check_bfs
+
+    scale = 12
+    run_ranks("bfs", 2, tmp_path, scale, 1, "p", 2)
+    roots, dist, pred = _assemble_paths(tmp_path, 2, 1 << scale, 0)
+    check_bfs(orc, scale, [int(roots[0])], dist, pred, depth_limit=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,kind", [(1, "int"), (2, "int"), (3, "int"), (4, "unit")])
+def test_mg_capi_sssp(orc, tmp_path, world, kind):
+    """cugraph_sssp on a multi-GPU graph: distances bit-identical to Dijkstra (integer and unit weights), minimum-external-id parents"""
+    from test_mg_traversal import check_sssp, graph, min_ext_parent
+
+    scale, n_roots = 12, 2
+    run_ranks("sssp", world, tmp_path, scale, n_roots, "p", kind)
+    for k in range(n_roots):
+        roots, dist, pred = _assemble_paths(tmp_path, world, 1 << scale, k)
+        if kind == "int":
+            check_sssp(orc, scale, int(roots[k]), dist, pred)
+        else:
+            nv, s, d, _, off, idx, _ = graph(orc, scale)
+            od, _ = orc.bfs(nv, off, idx, np.asarray([roots[k]], np.int32), 2**31 - 1)
+            want = np.where(od == 2**31 - 1, np.finfo(np.float32).max, od.astype(np.float32)).astype(np.float32)
+            assert np.array_equal(dist.view(np.uint32), want.view(np.uint32))  # unit weights: the BFS distances, bit for bit
