@@ -108,7 +108,8 @@ TRAFFIC_GROUPS = {
     "traversal": ["common.hpp", "core.hip", "traversal_common.hpp", "traversal_bottom_up.hpp", "traversal.hip", "graph.hip", "outer_ids.hip", "prims.hip"],
     "louvain": ["common.hpp", "core.hip", "louvain.hip", "prims.hip"],
 }
-TRAFFIC_UNMEASURED = ["edgelist.hip", "graph_functions.hip", "mtx.hip", "rmat.hip", "traversal_mg.hip"]  # no entry of the counter file runs them per unit of work
+TRAFFIC_UNMEASURED = ["edgelist.hip", "graph_functions.hip", "mtx.hip", "rmat.hip", "traversal_mg.hip", "traversal_mg_driver.hip", "comm.hpp", "comm.hip",
+                      "mg_graph.hpp", "mg_graph.hip"]  # no entry of the counter file runs them per unit of work
 
 
 def traffic_group_of(key):

@@ -346,6 +346,11 @@ extern "C" cugraph_error_code_t cugraph_type_erased_device_array_view_copy(const
     CGA_EXPECTS(d->size == s->size, CUGRAPH_INVALID_INPUT, "size of src and dst must match");
     size_t bytes = s->size * dtype_size(s->type);
     if (bytes == 0) return;
+    // `dst` is the caller's array (pylibcugraph: a cupy array it has just created -- and zero-filled -- on ITS stream, the legacy default
+    // stream; utils.pyx:162-196).  The reference orders its copy behind that work implicitly (RAFT's stream is a blocking stream); this
+    // library's stream is non-blocking, so the order is made explicit: whatever the caller queued on the default stream runs first.
+    // Found with two ranks sharing one GPU: the zero-fill of the result array landed AFTER the copy once in a few calls (round 4).
+    HIP_TRY(hipStreamSynchronize(nullptr));
     HIP_TRY(hipMemcpyAsync(d->data, s->data, bytes, hipMemcpyDeviceToDevice, h.stream));
     h.sync();  // callers free the source right after (pylibcugraph utils.pyx:162-196); see SURVEY section 9.8
   });

@@ -38,3 +38,46 @@ def test_pylibcugraph_goldens_through_the_reference_binding():
     r = subprocess.run([sys.executable, str(ROOT / "tests" / "pylibcugraph_run" / "run_goldens.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                        timeout=600, cwd="/tmp")
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-4000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_pylibcugraph_mggraph_on_ranks_sharing_one_gpu(world, tmp_path):
+    """The reference's MGGraph + pagerank / bfs / sssp -- unchanged Cython modules -- on several ranks of the library's communicator
+    (ResourceHandle(handle=<communicator>), graphs.pyx:357): the single-GPU goldens come back, every vertex from exactly one rank."""
+    import json
+    import uuid
+
+    import numpy as np
+
+    if not any(PKG.glob("pagerank*.so")):
+        pytest.skip("tests/pylibcugraph_run/_pkg missing: built only where the reference tree is available")
+    session = f"plc{uuid.uuid4().hex[:10]}"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CUGRAPH_AMD_COMM_TIMEOUT_S="60")
+    procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "pylibcugraph_run" / "run_mg.py"), session, str(r), str(world), str(tmp_path)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True, env=env, cwd="/tmp") for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "RANK OK" in o, o[-4000:]
+    res = [json.loads((tmp_path / f"plc_rank{r}.json").read_text()) for r in range(world)]
+
+    def merged(key, col):
+        got = {}
+        for r in res:
+            for v, x in zip(r[key]["v"], r[key][col]):
+                assert v not in got, "a vertex came back from two ranks"
+                got[v] = x
+        return got
+
+    pr = merged("capi_pagerank", "x")
+    want = res[0]["capi_pagerank"]["want"]
+    assert sorted(pr) == list(range(len(want))) and np.allclose([pr[v] for v in range(len(want))], want, rtol=1e-3)
+    k = res[0]["karate_pagerank"]
+    pr = merged("karate_pagerank", "x")
+    for vid, val in zip(k["want_v"], k["want"]):
+        assert abs(pr[vid] - val) <= k["rel_tol"] * abs(val) + 5e-7
+    d, p = merged("bfs", "d"), merged("bfs", "p")
+    assert [d[v] for v in sorted(d)] == res[0]["bfs"]["want_d"] and [p[v] for v in sorted(p)] == res[0]["bfs"]["want_p"]
+    d = merged("karate_sssp", "d")
+    k = res[0]["karate_sssp"]
+    np.testing.assert_allclose([d[v] for v in k["want_v"]], np.array(k["want_d"], np.float32), rtol=1e-4)
