@@ -26,6 +26,8 @@
 // rows whose neighbours moved is the next step).
 #pragma clang fp contract(off)
 #include "common.hpp"
+#include "comm.hpp"
+#include "mg_graph.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -553,9 +555,11 @@ __global__ void k_copy_i32(int32_t* dst, int32_t const* src, int64_t n) { LV_LOO
 // contraction: edges sorted by (cluster of src, cluster of dst); segment number = pos[i] (exclusive scan of the heads).  The head
 // of a segment emits the coarse edge's endpoints; the weights are summed in fixed point: a wavefront reduces its 64 sorted
 // entries by segment and adds one value per (wavefront, segment) with an integer atomic
+// (wfix_in != nullptr: the entries carry fixed-point weights already -- the second stage of the partitioned contraction, which adds up
+// what the ranks aggregated locally; the total is the same integer as the single-GPU sum)
 __global__ void k_coarse_edges(uint64_t const* keys, uint32_t const* perm, uint32_t const* head, uint32_t const* pos, double const* w, int64_t ne,
                                int shift,
-                               double scale, int32_t* csrc, int32_t* cdst, unsigned long long* cwfix)
+                               double scale, int32_t* csrc, int32_t* cdst, unsigned long long* cwfix, unsigned long long const* wfix_in = nullptr)
 {
   int const lane       = threadIdx.x & 63;
   int64_t const wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
@@ -569,7 +573,7 @@ __global__ void k_coarse_edges(uint64_t const* keys, uint32_t const* perm, uint3
     if (valid) {
       hd  = head[i] != 0;
       seg = pos[i] - (hd ? 0u : 1u);  // pos = exclusive scan of the heads: a segment's later entries already count their own head
-      wf  = __double2ll_rn(w[perm[i]] * scale);
+      wf  = wfix_in ? (long long)wfix_in[perm[i]] : __double2ll_rn(w[perm[i]] * scale);
       if (hd) { csrc[seg] = (int32_t)(keys[i] >> shift); cdst[seg] = (int32_t)(keys[i] & ((1ull << shift) - 1ull)); }
     }
     bool open;
@@ -577,6 +581,91 @@ __global__ void k_coarse_edges(uint64_t const* keys, uint32_t const* perm, uint3
     bool const end = valid && (i + 1 >= ne || lane == 63 || head[i + 1] != 0);
     if (end) atomicAdd(&cwfix[seg], (unsigned long long)sum);
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Partitioned Louvain (cugraph_louvain on a graph from cugraph_graph_create_mg; BASELINE config 5).  Replaces the multi_gpu = true
+// path of detail::louvain (cpp/src/community/louvain_impl.cuh:78-262): update_clustering_by_delta_modularity's collect_values_for_keys /
+// host_scalar_allreduce (detail/common_methods.cuh:200, 259-447) and the MG coarsen_graph (cpp/src/structure/coarsen_graph_impl.cuh).
+// A level's vertices v = 0 .. nv - 1 are dealt cyclically (owner v % P); a rank holds the out-edges of its vertices (sorted by source,
+// destination) and FULL copies of the per-vertex / per-cluster vectors (labels c, vertex weights k, cluster weights a: 20 bytes per vertex).
+// A sweep runs the single-GPU kernels on the local edges -- every per-vertex quantity they produce depends only on that vertex's edges and
+// the full vectors -- then the owners' new labels are merged into every rank's c (one push of nv / P labels per rank), and the cluster
+// weights are rebuilt from c and k with integer atomics.  All sums that decide a move are 64-bit fixed point, so the partitioned run takes
+// the same moves as the single-GPU run, vertex for vertex, whatever the number of ranks.  The modularity of a sweep = (sum over ranks, in rank
+// order, of the local intra-cluster weight) / m - resolution * sum a^2 / m^2 with the second sum formed by every rank over the full vector in
+// the single-GPU chunk order: bit-equal to the single-GPU value whenever the edge weights are integers (any fp64 sum of them is exact).
+// Contraction: local (cluster, cluster) aggregation in fixed point, one all-to-all of the coarse edges to the owner of the source cluster,
+// a second integer aggregation there.
+struct lv_mg_t {
+  comm_t* c{nullptr};
+  handle_t const* h{nullptr};
+  int P{1}, rank{0}, channel{1};
+  comm_window_t* stage{nullptr};  // [P][Lc] 8-byte slots: the owners' values of one merge
+  int64_t Lc{0};
+  void level_begin(int64_t nv)
+  {
+    Lc    = std::max<int64_t>((nv + P - 1) / P, 1);
+    stage = c->window_create((size_t)P * (size_t)Lc * 8);
+  }
+  void level_end()
+  {
+    h->sync();
+    if (stage) c->window_free(stage);
+    stage = nullptr;
+  }
+  double sum_f64(double x)
+  {
+    std::vector<double> all(P);
+    c->host_allgather(&x, sizeof(x), all.data());
+    double s = 0.0;
+    for (double y : all) s += y;  // rank order
+    return s;
+  }
+  void sum_u32x2(uint32_t* v)
+  {
+    uint64_t mine[2] = {v[0], v[1]};
+    std::vector<uint64_t> all((size_t)2 * P);
+    c->host_allgather(mine, sizeof(mine), all.data());
+    uint64_t a = 0, b = 0;
+    for (int r = 0; r < P; ++r) { a += all[2 * r]; b += all[2 * r + 1]; }
+    v[0] = (uint32_t)std::min<uint64_t>(a, 0xffffffffu); v[1] = (uint32_t)std::min<uint64_t>(b, 0xffffffffu);
+  }
+  template <typename T> void merge_owned(T* full, int64_t nv);  // full[v] <- the value rank v % P holds, on every rank
+};
+
+template <typename T>
+__global__ void k_take_owned(T const* full, int64_t nv, int P, int rank, T* out)
+{
+  LV_LOOP(i, (nv - rank + P - 1) / P) out[i] = full[i * P + rank];
+}
+template <typename T>
+__global__ void k_interleave(T const* stage, int64_t nv, int P, int64_t Lc, T* full)
+{
+  LV_LOOP(v, nv) full[v] = stage[(v % P) * Lc + v / P];
+}
+template <typename T>
+void lv_mg_t::merge_owned(T* full, int64_t nv)
+{
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte values");
+  int64_t const mine = nv > rank ? (nv - rank + P - 1) / P : 0;
+  dvec<T> own((size_t)std::max<int64_t>(mine, 1));
+  if (mine > 0) hipLaunchKernelGGL(k_take_owned<T>, grid_for(mine, kBlock, 8192), kBlock, 0, h->stream, (T const*)full, nv, P, rank, own.data());
+  comm_push_desc_t d{};
+  for (int r = 0; r < P; ++r) { d.dst[r] = static_cast<T*>(stage->peer[r]) + (int64_t)rank * Lc; d.src[r] = own.data(); d.words[r] = mine * (int64_t)(sizeof(T) / 4); }
+  d.n = P;
+  c->push_multi(h->stream, d);
+  c->wait(h->stream, channel, c->signal(h->stream, channel));
+  if (nv > 0) hipLaunchKernelGGL(k_interleave<T>, grid_for(nv, kBlock, 8192), kBlock, 0, h->stream, (T const*)stage->local, nv, P, Lc, full);
+  // the next merge overwrites the staging rows: every rank must have consumed them first
+  c->wait(h->stream, channel, c->signal(h->stream, channel));
+  h->sync();  // (`own` is released here)
+}
+
+__global__ void k_cluster_weights(int32_t const* c, long long const* kfix, int64_t nv, unsigned long long* afix)
+{
+  LV_LOOP(v, nv) { unsigned long long const kv = (unsigned long long)kfix[v]; if (kv) atomicAdd(&afix[c[v]], kv); }
 }
 
 struct level_t {
@@ -625,7 +714,7 @@ struct louvain_stats_t { int sweeps{0}, sweeps_in_level{0}; };
 
 // one level (the body of the while loop of detail::louvain, louvain_impl.cuh:78-262): accepted clustering and its modularity
 double run_level(handle_t const& h, level_t const& L, double m, double threshold, double resolution, double noise_floor, dvec<int32_t>& accepted,
-                 louvain_stats_t& st)
+                 louvain_stats_t& st, lv_mg_t* mg = nullptr)
 {
   int64_t const nv = L.nv, ne = L.ne;
   int const g_v = grid_for(nv, kBlock, 8192), g_e = grid_for(ne, kBlock, 8192);
@@ -675,6 +764,7 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   HIP_TRY(hipMemsetAsync(kfix.data(), 0, (size_t)nv * sizeof(long long), h.stream));
   if (ne > 0) hipLaunchKernelGGL(k_vertex_weights, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (double const*)L.w.data(), ne, scale,
                                  reinterpret_cast<unsigned long long*>(kfix.data()));
+  if (mg) mg->merge_owned<long long>(kfix.data(), nv);  // a vertex's weight comes from its owner's edges
   hipLaunchKernelGGL(k_fix_to_double, g_v, kBlock, 0, h.stream, reinterpret_cast<unsigned long long const*>(kfix.data()), nv, 1.0 / scale, k.data());
   iota_i32(h, c.data(), nv, 0);
   iota_i32(h, accepted.data(), nv, 0);
@@ -689,6 +779,7 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     chunked_sum(h, nv, parts, scal.data() + 1, [&](int np, double* p) { hipLaunchKernelGGL(k_part_squares, np, 1024, 0, h.stream, (double const*)a.data(), nv, p); });
     double s[2];
     h.read_back(s, scal.data(), 2);
+    if (mg) s[0] = mg->sum_f64(s[0]);  // the ranks' intra-cluster weights, added in rank order
     return s[0] / m - (resolution * s[1]) / (m * m);
   };
   double new_q = modularity();
@@ -739,10 +830,17 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
                        (int32_t const*)best_c.data(), (double const*)best_d.data(), min_gain, nv, count.data());
     uint32_t nr_moves[2] = {0, 0};
     h.read_back(nr_moves, count.data(), 2);
+    if (mg) mg->sum_u32x2(nr_moves);
     if (nr_moves[up_down ? 1 : 0] == 0) up_down = !up_down;
     // the moves + compute_cluster_keys_and_values: cluster weights of the new clustering
     hipLaunchKernelGGL(k_apply_moves, g_v, kBlock, 0, h.stream, c.data(), (int32_t const*)best_c.data(), (double const*)best_d.data(), min_gain, up_down ? 1 : 0, nv,
                        (long long const*)kfix.data(), afix.data());
+    if (mg) {  // every rank moved ITS vertices: merge the labels, rebuild the cluster weights from them (integers: the same values the
+               // single-GPU run reaches by adding and subtracting)
+      mg->merge_owned<int32_t>(c.data(), nv);
+      HIP_TRY(hipMemsetAsync(afix.data(), 0, (size_t)nv * sizeof(unsigned long long), h.stream));
+      hipLaunchKernelGGL(k_cluster_weights, g_v, kBlock, 0, h.stream, (int32_t const*)c.data(), (long long const*)kfix.data(), nv, afix.data());
+    }
     hipLaunchKernelGGL(k_fix_to_double, g_v, kBlock, 0, h.stream, (unsigned long long const*)afix.data(), nv, 1.0 / scale, a.data());
     up_down = !up_down;
     new_q   = modularity();
@@ -752,6 +850,202 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   return cur_q;
 }
 
+
+// ---- the partitioned driver: level 0 from this rank's slice, levels, contraction with one all-to-all per level
+__global__ void k_lv_route(int32_t const* s, int32_t const* d, int64_t m, int64_t vmin, uint32_t const* vrank, int P, int32_t* owner, int32_t* vs, int32_t* vd)
+{
+  LV_LOOP(i, m)
+  {
+    int32_t const a = (int32_t)vrank[(int64_t)s[i] - vmin], b = (int32_t)vrank[(int64_t)d[i] - vmin];
+    vs[i] = a; vd[i] = b; owner[i] = a % P;
+  }
+}
+__global__ void k_lv_owner_of(int32_t const* src, int64_t n, int P, int32_t* owner) { LV_LOOP(i, n) owner[i] = src[i] % P; }
+__global__ void k_lv_ext_of(uint32_t const* present, uint32_t const* vrank, int64_t vrange, int64_t vmin, int P, int rank, int32_t* ext_own)
+{
+  LV_LOOP(r, vrange) if (present[r]) { uint32_t const v = vrank[r]; if ((int)(v % (uint32_t)P) == rank) ext_own[v / (uint32_t)P] = (int32_t)(r + vmin); }
+}
+__global__ void k_lv_own_iota(int32_t* part, int64_t n, int P, int rank) { LV_LOOP(i, n) part[i] = (int32_t)(i * P + rank); }
+template <typename T>
+__global__ void k_lv_gather(T const* in, uint32_t const* perm, int64_t n, T* out) { LV_LOOP(i, n) out[i] = in[perm[i]]; }
+
+// (src, dst, w) in any order -> sorted by (src, dst): the order the single-GPU level stores its edges in
+void lv_sort_edges(handle_t const& h, int32_t const* src, int32_t const* dst, double const* w, int64_t n, int64_t nv, level_t& L)
+{
+  size_t const n1 = (size_t)std::max<int64_t>(n, 1);
+  L.ne = n;
+  L.src.resize_discard(n1); L.dst.resize_discard(n1); L.w.resize_discard(n1);
+  if (n <= 0) return;
+  int const vb = bits_of_u((uint64_t)std::max<int64_t>(nv - 1, 1));
+  dvec<uint64_t> keys(n1);
+  dvec<uint32_t> perm(n1);
+  int const g = grid_for(n, kBlock, 8192);
+  hipLaunchKernelGGL(k_pair_keys, g, kBlock, 0, h.stream, src, (int32_t const*)nullptr, dst, (int32_t const*)nullptr, n, vb, keys.data(), perm.data());
+  sort_pairs(h, keys, perm, n, 2 * vb);
+  hipLaunchKernelGGL(k_lv_gather<int32_t>, g, kBlock, 0, h.stream, src, (uint32_t const*)perm.data(), n, L.src.data());
+  hipLaunchKernelGGL(k_lv_gather<int32_t>, g, kBlock, 0, h.stream, dst, (uint32_t const*)perm.data(), n, L.dst.data());
+  hipLaunchKernelGGL(k_lv_gather<double>, g, kBlock, 0, h.stream, w, (uint32_t const*)perm.data(), n, L.w.data());
+  h.sync();
+}
+
+}  // namespace
+
+clustering_result_t* mg_run_louvain(handle_t const& h, graph_t& g, size_t max_level, double threshold, double resolution)
+{
+  HIP_TRY(hipSetDevice(h.device));
+  mg_graph_t& mg = *g.mg;
+  comm_t& c      = *mg.comm;
+  CGA_EXPECTS(handle_comm(h) == mg.comm, CUGRAPH_INVALID_HANDLE, "multi-GPU Louvain: the handle is not on the communicator the graph was created on");
+  int const P = c.size, me = c.rank;
+  lv_mg_t M;
+  M.c = &c; M.h = &h; M.P = P; M.rank = me; M.channel = 1;
+  // level 0: vertex ids = rank of the external id among the graph's vertices (ascending): what a single-GPU graph created with
+  // renumber = FALSE on dense ids runs on -- the partitioned clustering equals that run's vertex for vertex
+  int64_t const nv0 = mg.nv_global;
+  dvec<uint32_t> vrank((size_t)mg.vrange + 1);
+  {
+    dvec<uint32_t> pr((size_t)mg.vrange + 1);
+    HIP_TRY(hipMemcpyAsync(pr.data(), mg.present.data(), (size_t)mg.vrange * 4, hipMemcpyDeviceToDevice, h.stream));
+    HIP_TRY(hipMemsetAsync(pr.data() + mg.vrange, 0, 4, h.stream));
+    exclusive_scan_u32(h, pr.data(), vrank.data(), mg.vrange + 1);
+    h.sync();
+  }
+  int64_t const n_own = nv0 > me ? (nv0 - me + P - 1) / P : 0;
+  level_t L;
+  L.nv = nv0;
+  {
+    int64_t const m  = mg.el.n;
+    size_t const m1  = (size_t)std::max<int64_t>(m, 1);
+    dvec<int32_t> owner(m1), vs(m1), vd(m1);
+    dvec<double> wd(m1);
+    if (m > 0) {
+      int const ge = grid_for(m, kBlock, 8192);
+      hipLaunchKernelGGL(k_lv_route, ge, kBlock, 0, h.stream, (int32_t const*)mg.el.s.data(), (int32_t const*)mg.el.d.data(), m, mg.vmin, (uint32_t const*)vrank.data(), P, owner.data(),
+                         vs.data(), vd.data());
+      if (mg.el.wsize == 0) hipLaunchKernelGGL(k_to_double<float>, ge, kBlock, 0, h.stream, (float const*)nullptr, m, wd.data());  // constant weight 1 (louvain.cpp:86-92)
+      else if (mg.el.wsize == 8) hipLaunchKernelGGL(k_to_double<double>, ge, kBlock, 0, h.stream, mg.el.w.as<double const>(), m, wd.data());
+      else hipLaunchKernelGGL(k_to_double<float>, ge, kBlock, 0, h.stream, mg.el.w.as<float const>(), m, wd.data());
+    }
+    std::vector<dev_buf> got;
+    int64_t const e_loc = mg_shuffle_by_owner(h, c, owner.data(), m, {{vs.data(), 4}, {vd.data(), 4}, {wd.data(), 8}}, got);
+    CGA_EXPECTS(e_loc <= kMaxSignedEdges, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "multi-GPU Louvain: a rank's share must hold fewer than 2^31 edges");
+    lv_sort_edges(h, got[0].as<int32_t const>(), got[1].as<int32_t const>(), got[2].as<double const>(), e_loc, nv0, L);
+  }
+  dvec<double> scal(1), parts;
+  chunked_sum(h, L.ne, parts, scal.data(), [&](int np, double* p) { hipLaunchKernelGGL(k_part_sum, np, 1024, 0, h.stream, (double const*)L.w.data(), L.ne, p); });
+  double m_loc = 0.0;
+  h.read_back(&m_loc, (double const*)scal.data(), 1);
+  double const m     = M.sum_f64(m_loc);  // compute_total_edge_weight over all ranks
+  double const scale = fixed_scale(m);
+  bool const trace   = getenv("CUGRAPH_AMD_LOUVAIN_TRACE") != nullptr;
+  size_t const o1    = (size_t)std::max<int64_t>(n_own, 1);
+  auto part          = std::make_unique<device_array_t>((size_t)n_own, INT32);
+  dvec<int32_t> part_own(o1);
+  hipLaunchKernelGGL(k_lv_own_iota, grid_for((int64_t)o1, kBlock, 8192), kBlock, 0, h.stream, part_own.data(), n_own, P, me);
+  double best   = -1.0;
+  size_t levels = 0;
+  cugraph_amd_traversal_stats_t work{0, 0, 0, 0};
+  while (levels < max_level && L.nv > 0 && m > 0.0) {
+    ++levels;
+    build_offsets(h, L);
+    dvec<int32_t> cl;
+    louvain_stats_t st;
+    M.level_begin(L.nv);
+    double const q = run_level(h, L, m, threshold, resolution, g.weight_type == FLOAT64 ? 1e-15 : 1e-12, cl, st, &M);
+    M.level_end();
+    if (trace && me == 0) fprintf(stderr, "[louvain mg] level %zu: %lld vertices, %lld local edges, %d sweeps, Q = %.9f\n", levels, (long long)L.nv, (long long)L.ne, st.sweeps, q);
+    work.steps += (uint64_t)st.sweeps;
+    work.edges_inspected += (uint64_t)st.sweeps * (uint64_t)L.ne;
+    work.vertices_reached += (uint64_t)st.sweeps * (uint64_t)L.nv;
+    work.edges_of_reached += (uint64_t)L.ne;
+    if (q <= best) break;
+    best = q;
+    // graph_contraction: dense labels (every rank holds the full label vector: the same ranks everywhere), flattening of the owned vertices
+    dvec<uint32_t> used((size_t)L.nv + 1), rank((size_t)L.nv + 1);
+    HIP_TRY(hipMemsetAsync(used.data(), 0, ((size_t)L.nv + 1) * sizeof(uint32_t), h.stream));
+    hipLaunchKernelGGL(k_mark_labels, grid_for(L.nv, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)cl.data(), L.nv, used.data());
+    exclusive_scan_u32(h, used.data(), rank.data(), L.nv + 1);
+    uint32_t ncl = 0;
+    h.read_back(&ncl, rank.data() + L.nv, 1);
+    hipLaunchKernelGGL(k_relabel, grid_for(L.nv, kBlock, 8192), kBlock, 0, h.stream, cl.data(), (uint32_t const*)rank.data(), L.nv);
+    if (n_own > 0) hipLaunchKernelGGL(k_compose, grid_for(n_own, kBlock, 8192), kBlock, 0, h.stream, part_own.data(), (int32_t const*)cl.data(), n_own);
+    // coarse edges: local aggregation, all-to-all to the owner of the source cluster, second aggregation (integers: the single-GPU sums)
+    int const cb = bits_of_u((uint64_t)std::max<int64_t>((int64_t)ncl - 1, 1));
+    dvec<int32_t> lsrc, ldst;
+    dvec<unsigned long long> lwfix;
+    int64_t n_loc = 0;
+    if (L.ne > 0) {
+      dvec<uint64_t> keys((size_t)L.ne);
+      dvec<uint32_t> perm((size_t)L.ne), head((size_t)L.ne + 1), pos((size_t)L.ne + 1);
+      hipLaunchKernelGGL(k_pair_keys, grid_for(L.ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)cl.data(), (int32_t const*)L.dst.data(),
+                         (int32_t const*)cl.data(), L.ne, cb, keys.data(), perm.data());
+      sort_pairs(h, keys, perm, L.ne, 2 * cb);
+      hipLaunchKernelGGL(k_heads, grid_for(L.ne, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), L.ne, head.data());
+      HIP_TRY(hipMemsetAsync(head.data() + L.ne, 0, sizeof(uint32_t), h.stream));
+      exclusive_scan_u32(h, head.data(), pos.data(), L.ne + 1);
+      uint32_t nce = 0;
+      h.read_back(&nce, pos.data() + L.ne, 1);
+      n_loc = nce;
+      size_t const n1 = (size_t)std::max<uint32_t>(nce, 1);
+      lsrc.resize_discard(n1); ldst.resize_discard(n1); lwfix.resize_discard(n1);
+      HIP_TRY(hipMemsetAsync(lwfix.data(), 0, n1 * sizeof(unsigned long long), h.stream));
+      hipLaunchKernelGGL(k_coarse_edges, grid_for(L.ne, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)perm.data(), (uint32_t const*)head.data(),
+                         (uint32_t const*)pos.data(), (double const*)L.w.data(), L.ne, cb, scale, lsrc.data(), ldst.data(), lwfix.data(), (unsigned long long const*)nullptr);
+      h.sync();
+    } else {
+      lsrc.resize_discard(1); ldst.resize_discard(1); lwfix.resize_discard(1);
+    }
+    level_t N;
+    N.nv = ncl;
+    {
+      dvec<int32_t> owner((size_t)std::max<int64_t>(n_loc, 1));
+      if (n_loc > 0) hipLaunchKernelGGL(k_lv_owner_of, grid_for(n_loc, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)lsrc.data(), n_loc, P, owner.data());
+      std::vector<dev_buf> got;
+      int64_t const n_r = mg_shuffle_by_owner(h, c, owner.data(), n_loc, {{lsrc.data(), 4}, {ldst.data(), 4}, {lwfix.data(), 8}}, got);
+      CGA_EXPECTS(n_r <= kMaxSignedEdges, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "multi-GPU Louvain: a rank's coarse share must hold fewer than 2^31 edges");
+      if (n_r > 0) {
+        dvec<uint64_t> keys((size_t)n_r);
+        dvec<uint32_t> perm((size_t)n_r), head((size_t)n_r + 1), pos((size_t)n_r + 1);
+        hipLaunchKernelGGL(k_pair_keys, grid_for(n_r, kBlock, 8192), kBlock, 0, h.stream, got[0].as<int32_t const>(), (int32_t const*)nullptr, got[1].as<int32_t const>(),
+                           (int32_t const*)nullptr, n_r, cb, keys.data(), perm.data());
+        sort_pairs(h, keys, perm, n_r, 2 * cb);
+        hipLaunchKernelGGL(k_heads, grid_for(n_r, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), n_r, head.data());
+        HIP_TRY(hipMemsetAsync(head.data() + n_r, 0, sizeof(uint32_t), h.stream));
+        exclusive_scan_u32(h, head.data(), pos.data(), n_r + 1);
+        uint32_t nce = 0;
+        h.read_back(&nce, pos.data() + n_r, 1);
+        N.ne = nce;
+        size_t const n1 = (size_t)std::max<uint32_t>(nce, 1);
+        N.src.resize_discard(n1); N.dst.resize_discard(n1); N.w.resize_discard(n1);
+        dvec<unsigned long long> cwfix(n1);
+        HIP_TRY(hipMemsetAsync(cwfix.data(), 0, n1 * sizeof(unsigned long long), h.stream));
+        hipLaunchKernelGGL(k_coarse_edges, grid_for(n_r, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)perm.data(), (uint32_t const*)head.data(),
+                           (uint32_t const*)pos.data(), (double const*)nullptr, n_r, cb, scale, N.src.data(), N.dst.data(), cwfix.data(), got[2].as<unsigned long long const>());
+        hipLaunchKernelGGL(k_fix_to_double, grid_for((int64_t)n1, kBlock, 8192), kBlock, 0, h.stream, (unsigned long long const*)cwfix.data(), (int64_t)n1, 1.0 / scale, N.w.data());
+        h.sync();
+      } else {
+        N.ne = 0;
+        N.src.resize_discard(1); N.dst.resize_discard(1); N.w.resize_discard(1);
+      }
+    }
+    L = std::move(N);
+  }
+  const_cast<handle_t&>(h).last_stats = work;
+  auto res        = std::make_unique<clustering_result_t>();
+  res->modularity = best;
+  res->vertices   = new device_array_t((size_t)n_own, INT32);
+  if (n_own > 0) {
+    hipLaunchKernelGGL(k_lv_ext_of, grid_for(mg.vrange, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)mg.present.data(), (uint32_t const*)vrank.data(), mg.vrange, mg.vmin, P, me,
+                       res->vertices->buf.as<int32_t>());
+    HIP_TRY(hipMemcpyAsync(part->buf.ptr, part_own.data(), (size_t)n_own * 4, hipMemcpyDeviceToDevice, h.stream));
+  }
+  res->clusters = part.release();
+  h.sync();
+  c.check("multi-GPU Louvain");
+  return res.release();
+}
+
+namespace {
 }  // namespace
 }  // namespace cga
 
@@ -764,9 +1058,13 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
   if (result) *result = nullptr;
   return guarded(error, [&] {
     handle_t const& h = H(handle);
-    graph_t& g        = G(graph);
+    graph_t& g        = GM(graph);
     CGA_EXPECTS(result != nullptr, CUGRAPH_INVALID_INPUT, "result is NULL");
     HIP_TRY(hipSetDevice(h.device));
+    if (g.mg) {  // a graph from cugraph_graph_create_mg on a communicator handle: collective
+      *result = reinterpret_cast<cugraph_hierarchical_clustering_result_t*>(mg_run_louvain(h, g, max_level, threshold, resolution));
+      return;
+    }
     CGA_EXPECTS(g.ne <= kMaxSignedEdges, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "Louvain: graphs of 2^31 or more edges are not supported");
     ensure_orientation(h, g, false);  // louvain expects store_transposed == false (louvain.cpp:60-66)
     orientation_t const& o = g.csr;

@@ -169,13 +169,12 @@ std::vector<int64_t> count_owners(handle_t const& h, int32_t const* owner, int64
   return out;
 }
 
-struct column_t {
-  void const* ptr;
-  size_t elem;  // 4 or 8 bytes
-};
+using column_t = mg_column_t;
+
+}  // namespace
 
 // Sends every element i of the columns to rank owner[i]; returns the received columns (grouped by sender) and their length.
-int64_t shuffle_by_owner(handle_t const& h, comm_t& c, int32_t const* owner, int64_t m, std::vector<column_t> const& cols, std::vector<dev_buf>& out)
+int64_t mg_shuffle_by_owner(handle_t const& h, comm_t& c, int32_t const* owner, int64_t m, std::vector<mg_column_t> const& cols, std::vector<dev_buf>& out)
 {
   int const P = c.size;
   out.clear();
@@ -202,6 +201,12 @@ int64_t shuffle_by_owner(handle_t const& h, comm_t& c, int32_t const* owner, int
     for (auto x : rc) received += x;
   }
   return received;
+}
+
+namespace {
+int64_t shuffle_by_owner(handle_t const& h, comm_t& c, int32_t const* owner, int64_t m, std::vector<mg_column_t> const& cols, std::vector<dev_buf>& out)
+{
+  return mg_shuffle_by_owner(h, c, owner, m, cols, out);
 }
 
 struct vertex_order_t {

@@ -61,6 +61,16 @@ struct mg_graph_t {
   std::unique_ptr<mg_traversal_part_t> tr[2];  // [0] = without weights (BFS), [1] = with float weights (SSSP)
 };
 
+struct mg_column_t {
+  void const* ptr;
+  size_t elem;  // 4 or 8 bytes
+};
+// all-to-all-v of whole columns: element i of every column goes to rank owner[i]; returns the received columns (grouped by sender)
+int64_t mg_shuffle_by_owner(handle_t const& h, comm_t& c, int32_t const* owner, int64_t m, std::vector<mg_column_t> const& cols, std::vector<dev_buf>& out);
+struct clustering_result_t;
+// cugraph_louvain on a multi-GPU graph (louvain.hip): collective; every rank gets the clusters of the vertices it owns (v % P == rank in ascending id order)
+clustering_result_t* mg_run_louvain(handle_t const& h, graph_t& g, size_t max_level, double threshold, double resolution);
+
 // cugraph_graph_create_mg / _with_times_mg on a handle with more than one rank (collective)
 void mg_graph_create(handle_t const& h, graph_t& g, device_array_view_t const* vertices, device_array_view_t const* src, device_array_view_t const* dst,
                      device_array_view_t const* weights, bool drop_self_loops);

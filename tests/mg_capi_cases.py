@@ -76,6 +76,23 @@ def run(what, cg, h, comm, rank, size, outdir, args):
                     res[f"p{k}"] = pred.cpu().numpy()
         np.savez(outdir / f"rank{rank}.npz", roots=roots, **res)
         del g
+    elif what == "louvain":
+        scale = int(args[0])
+        from oracle import oracle as orc
+        from test_gpu_parity import louvain_rmat_input
+
+        src, dst, w = louvain_rmat_input(orc, scale)  # undirected simple RMAT, integer weights 1..8, both directions, sorted by (src, dst)
+        nv = 1 << scale
+        mine = np.arange(src.size) % size == rank      # an arbitrary slice: the library routes the edges to their owners
+        verts = np.arange(rank, nv, size, dtype=np.int32)
+        g = cg.MGGraph(h, cg.GraphProperties(is_symmetric=True), [T(src[mine])], [T(dst[mine])], [T(w[mine])], store_transposed=False, vertices_array=[T(verts)])
+        v, c, q = cg.louvain(h, g, 100, 1e-7, 1.0, False)
+        np.savez(outdir / f"rank{rank}.npz", v=v.cpu().numpy(), c=c.cpu().numpy())
+        out["modularity_hex"] = float(q).hex()
+        out["rows"] = int(v.numel())
+        st = h.last_traversal_stats()
+        out["sweeps"] = int(st["steps"])
+        del g
     else:
         raise ValueError(what)
     return out

@@ -164,3 +164,47 @@ def test_mg_capi_sssp(orc, tmp_path, world, kind):
             od, _ = orc.bfs(nv, off, idx, np.asarray([roots[k]], np.int32), 2**31 - 1)
             want = np.where(od == 2**31 - 1, np.finfo(np.float32).max, od.astype(np.float32)).astype(np.float32)
             assert np.array_equal(dist.view(np.uint32), want.view(np.uint32))  # unit weights: the BFS distances, bit for bit
+
+
+def _assemble_clusters(tmp_path, world, nv):
+    c = np.full(nv, -1, np.int64)
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        assert (c[z["v"]] == -1).all(), "a vertex came back from two ranks"
+        c[z["v"]] = z["c"]
+    assert (c >= 0).all(), "every vertex must come back from exactly one rank"
+    return c.astype(np.int32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,scale", [(1, 14), (2, 14), (3, 14), (4, 16)])
+def test_mg_capi_louvain(orc, tmp_path, world, scale):
+    """cugraph_louvain on a multi-GPU graph (BASELINE config 5's algorithm partitioned over ranks sharing one GPU): the clustering equals the C
+    oracle's -- and therefore the single-GPU library's, which the parity suite pins to the same oracle -- vertex for vertex, the modularity is
+    the same double on every rank and within 1e-9 of the oracle's."""
+    from test_gpu_parity import louvain_rmat_input
+
+    res = run_ranks("louvain", world, tmp_path, scale)
+    nv = 1 << scale
+    assert sum(r["rows"] for r in res) == nv and len({r["modularity_hex"] for r in res}) == 1
+    c = _assemble_clusters(tmp_path, world, nv)
+    src, dst, w = louvain_rmat_input(orc, scale)
+    oc, oq, _, osweeps = orc.louvain_c(nv, src, dst, w, 100, 1e-7, 1.0)
+    q = float.fromhex(res[0]["modularity_hex"])
+    assert abs(q - oq) <= 1e-9
+    assert np.array_equal(c, oc)
+    assert res[0]["sweeps"] == osweeps
+
+
+@pytest.mark.gpu
+def test_mg_capi_louvain_rmat22_golden(tmp_path):
+    """the partitioned run at the size the single-GPU timing is quoted on, two ranks, against the committed fixture of the C oracle
+    (tests/golden/louvain_rmat22.json): cluster column (sha256), modularity (the exact double: integer weights)"""
+    import hashlib
+
+    gold = json.loads((ROOT / "tests" / "golden" / "louvain_rmat22.json").read_text())
+    res = run_ranks("louvain", 2, tmp_path, gold["scale"], timeout=900)
+    c = _assemble_clusters(tmp_path, 2, 1 << gold["scale"])
+    assert float.fromhex(res[0]["modularity_hex"]) == gold["modularity"]
+    assert int(np.unique(c).size) == gold["clusters"]
+    assert hashlib.sha256(np.ascontiguousarray(c, np.int32).tobytes()).hexdigest() == gold["clusters_sha256"]
