@@ -338,6 +338,12 @@ ORC_SSSP_MIN_PRED(orc_sssp_min_pred_f64, double, DBL_MAX)
  * (graph_contraction, :230-257).  Per vertex the weights are accumulated per neighbouring cluster in STORED EDGE ORDER (a
  * marker array instead of the numpy version's lexsort: same sums in the same order), clusters are then visited in ascending
  * order.  Edges must be grouped by source (any order inside a source).
+ * DEVIATION from the reference, on purpose: every sum and every gain here is fp64 whatever the graph's weight type; the reference computes
+ * them in weight_t (float for FLOAT32 graphs: common_methods.cuh:71-97, its thrust / cub reduction order unpinned).  fp64 is the wider,
+ * order-independent choice the library makes too (64-bit fixed point: exact for the integer-weight graphs the fixtures use), so the
+ * restatement and the library agree to the bit; against the reference itself the parity claim rests on its own goldens
+ * (cpp/tests/c_api/louvain_test.c, tests/test_oracle.py) -- on float graphs whose best moves are decided by less than float rounding the
+ * reference may take other moves.
  * ---------------------------------------------------------------------------------------------- */
 /* louvain_delta_modularity_noise_floor (common_methods.cuh:52-58): 1e-12 for float graphs, 1e-15 for double */
 static double lv_noise_floor = 1e-15;
