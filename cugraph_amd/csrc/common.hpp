@@ -199,7 +199,7 @@ struct handle_t {  // behind cugraph_resource_handle_t
   int rank{0};
   int comm_size{1};
   void* comm{nullptr};    // cga::comm_t (comm.hpp) when the handle was created on a communicator; borrowed, not owned
-  void* pinned{nullptr};  // 4 KiB pinned scratch for scalar read-backs
+  void* pinned{nullptr};  // 64 KiB pinned scratch for scalar read-backs
   bool timing{false};
   std::map<std::string, kernel_timer> timers;
   int pagerank_hot_tile{-1};  // -1 = auto

@@ -37,7 +37,7 @@ extern "C" cugraph_resource_handle_t* cugraph_create_resource_handle(void* raft_
     h->lds_per_block = prop.sharedMemPerBlock;
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = h->stream;
-    HIP_TRY(hipHostMalloc(&h->pinned, 4096, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&h->pinned, 65536, hipHostMallocDefault));
     return reinterpret_cast<cugraph_resource_handle_t*>(h.release());
   } catch (...) {
     return nullptr;

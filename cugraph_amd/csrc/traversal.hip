@@ -144,6 +144,40 @@ __global__ void k_bfs_finish_pred(int32_t* pred, int64_t n, int32_t const* label
   }
 }
 
+// result columns in one pass: ids <- the numbering; parents (when kept): internal ids -> external ids, INT32_MAX (none) -> -1
+__global__ void __launch_bounds__(256) k_bfs_result_columns(int32_t const* number_map, int32_t* ids, int32_t* pred, int64_t n, int32_t const* labels)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    ids[i] = number_map[i];
+    if (pred) {
+      int32_t const p = pred[i];
+      pred[i]         = p == INT32_MAX ? -1 : (labels ? labels[p] : p);
+    }
+  }
+}
+
+// dist / pred <- "unreached", the bitmaps and the counters <- 0
+__global__ void __launch_bounds__(256) k_bfs_init_state(int32_t* dist, int32_t* pred, int64_t nv, uint32_t* vis_prev, uint32_t* vis_new, uint32_t* front, uint32_t* next,
+                                                        int64_t nwords, counters_t* cnt)
+{
+  int64_t const t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t const n4 = nv / 4;
+  int4 const big{INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX};
+  for (int64_t i = t; i < n4; i += stride) {
+    reinterpret_cast<int4*>(dist)[i] = big;
+    if (pred) reinterpret_cast<int4*>(pred)[i] = big;
+  }
+  for (int64_t i = n4 * 4 + t; i < nv; i += stride) { dist[i] = INT32_MAX; if (pred) pred[i] = INT32_MAX; }
+  for (int64_t i = t; i < nwords; i += stride) {
+    vis_prev[i] = 0u; vis_new[i] = 0u;
+    if (front) { front[i] = 0u; next[i] = 0u; }
+  }
+  uint32_t* c = reinterpret_cast<uint32_t*>(cnt);
+  for (int64_t i = t; i < (int64_t)(sizeof(counters_t) / 4); i += stride) c[i] = 0u;
+}
+
 __global__ void k_bfs_init_sources(int32_t const* src, int64_t n, int32_t* dist, uint32_t* vis_prev, uint32_t* vis_new, int32_t* q,
                                    counters_t* cnt, int32_t const* out_offsets, int32_t const* in_offsets)
 {
@@ -854,17 +888,12 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   dvec<uint32_t> vis_prev(nwords), vis_new(nwords), front(in ? nwords : 1), next(in ? nwords : 1);
   dvec<int32_t> qa(n1), qb(n1), bigq(big_queue_entries(g.ne));
   dvec<counters_t> cnt(1);
-  fill_i32(h, dist->buf.as<int32_t>(), nv, INT32_MAX);
-  if (compute_predecessors) fill_i32(h, preds->buf.as<int32_t>(), nv, INT32_MAX);
   int32_t* const pred_p = compute_predecessors ? preds->buf.as<int32_t>() : nullptr;
   int32_t const* labels = g.renumbered ? g.number_map.data() : nullptr;
-  HIP_TRY(hipMemsetAsync(vis_prev.data(), 0, nwords * 4, h.stream));
-  HIP_TRY(hipMemsetAsync(vis_new.data(), 0, nwords * 4, h.stream));
-  if (in) {  // the bottom-up kernel rewrites whole 64-vertex groups only: the two slack words must read as "no vertex"
-    HIP_TRY(hipMemsetAsync(front.data(), 0, nwords * 4, h.stream));
-    HIP_TRY(hipMemsetAsync(next.data(), 0, nwords * 4, h.stream));
-  }
-  HIP_TRY(hipMemsetAsync(cnt.data(), 0, sizeof(counters_t), h.stream));
+  // one launch for the whole initial state (it used to be two fills and five memsets: 50 us of a 1.2 ms search at RMAT-24).  With in-edges
+  // the bottom-up kernel rewrites whole 64-vertex groups only: the two slack words of front / next must read as "no vertex"
+  hipLaunchKernelGGL(k_bfs_init_state, grid_for(std::max<int64_t>(nv / 4, nwords), kBlock, 4096), kBlock, 0, h.stream, dist->buf.as<int32_t>(), pred_p, nv, vis_prev.data(),
+                     vis_new.data(), in ? front.data() : (uint32_t*)nullptr, in ? next.data() : (uint32_t*)nullptr, nwords, cnt.data());
   if (ns > 0)
     hipLaunchKernelGGL(k_bfs_init_sources, grid_for(ns, kBlock), kBlock, 0, h.stream, (int32_t const*)src.data(), ns, dist->buf.as<int32_t>(),
                        vis_prev.data(), vis_new.data(), qa.data(), cnt.data(), out_off, in_off);
@@ -929,7 +958,7 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
       ++bu_levels;
     } else {
       if (front_is_bitmap) {  // the last level ran bottom-up: materialise its discoveries as a queue
-        hipLaunchKernelGGL(k_bfs_bitmap_to_queue, grid_for(nwords, TV_BLOCK, 2048), TV_BLOCK, 0, h.stream, (uint32_t const*)front.data(), nwords, q_cur,
+        hipLaunchKernelGGL(k_bfs_bitmap_to_queue, grid_for(nwords, TV_BLOCK, 512), TV_BLOCK, 0, h.stream, (uint32_t const*)front.data(), nwords, q_cur,
                            cnt.data());
         HIP_TRY(hipMemsetAsync(cnt.data(), 0, sizeof(counters_t), h.stream));
         HIP_TRY(hipMemcpyAsync(vis_prev.data(), vis_new.data(), nwords * 4, hipMemcpyDeviceToDevice, h.stream));
@@ -970,9 +999,9 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   // statistics: every discovered vertex was counted (with its out-degree) by the level that found it -- no extra pass
   h.last_stats = cugraph_amd_traversal_stats_t{levels, edges, reached_total, edges_of_reached};
   (void)bu_levels;
-  if (nv > 0) HIP_TRY(hipMemcpyAsync(ids->buf.ptr, g.number_map.data(), nv * 4, hipMemcpyDeviceToDevice, h.stream));
-  if (compute_predecessors && nv > 0)  // bfs.cpp:131-138 unrenumbers the predecessors the same way
-    hipLaunchKernelGGL(k_bfs_finish_pred, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, pred_p, nv, labels);
+  // the vertex column (a copy of the numbering: the result owns its columns) and, bfs.cpp:131-138, the predecessors back in external ids:
+  // one kernel (the 64 MB device-to-device copy of the runtime took 80 us at RMAT-24, a streaming kernel takes 30)
+  if (nv > 0) hipLaunchKernelGGL(k_bfs_result_columns, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)g.number_map.data(), ids->buf.as<int32_t>(), pred_p, nv, labels);
   mark("finish_pred");
   h.sync();
   auto* r = new paths_result_t{ids.release(), dist.release(), preds.release()};

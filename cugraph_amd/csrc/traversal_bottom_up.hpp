@@ -209,26 +209,45 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bottom_up(int32_t const* in_of
   }
 }
 
-// set bits of `bits` -> a list of their positions (n_big doubles as the queue cursor of this kernel)
+// set bits of `bits` -> a list of their positions (n_big doubles as the queue cursor of this kernel).  Every workgroup owns one contiguous
+// range of words, counts its bits, reserves its piece of the queue with ONE atomic and fills it: with one atomic per wavefront-chunk the
+// 8 Ki same-address atomics of a 16 M-vertex bitmap took 100 us whatever the bitmap held (round 4).
 __global__ void __launch_bounds__(TV_BLOCK) k_bfs_bitmap_to_queue(uint32_t const* bits, int64_t nwords, int32_t* q, counters_t* cnt)
 {
-  int const lane = threadIdx.x & 63;
-  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t n_pad  = (nwords + 63) & ~(int64_t)63;
-  for (; i < n_pad; i += stride) {
-    uint32_t w = i < nwords ? bits[i] : 0u;
-    uint32_t c = __popc(w), total;
-    uint32_t ex = wave_excl_scan(c, lane, &total);
-    if (total == 0) continue;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&cnt->n_big, total);
-    base = __shfl(base, 0) + ex;
+  __shared__ uint32_t s_wave[TV_BLOCK / 64];
+  __shared__ uint32_t s_base;
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t const per = ((nwords + gridDim.x - 1) / gridDim.x + TV_BLOCK - 1) / TV_BLOCK * TV_BLOCK;  // words per workgroup, whole rounds
+  int64_t const w0 = (int64_t)blockIdx.x * per, w1 = w0 + per < nwords ? w0 + per : nwords;
+  uint32_t mine = 0;
+  for (int64_t i = w0 + threadIdx.x; i < w1; i += TV_BLOCK) mine += __popc(bits[i]);
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+  if (lane == 0) s_wave[wave] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int k = 0; k < TV_BLOCK / 64; ++k) t += s_wave[k];
+    s_base = t ? atomicAdd(&cnt->n_big, t) : 0u;
+  }
+  __syncthreads();
+  uint32_t base = s_base;  // running cursor of the workgroup (uniform)
+  for (int64_t r0 = w0; r0 < w1; r0 += TV_BLOCK) {  // one round = TV_BLOCK words; the waves of a round take consecutive pieces
+    int64_t const i = r0 + threadIdx.x;
+    uint32_t w      = i < w1 ? bits[i] : 0u;
+    uint32_t c      = __popc(w), total;
+    uint32_t ex     = wave_excl_scan(c, lane, &total);
+    __syncthreads();
+    if (lane == 0) s_wave[wave] = total;
+    __syncthreads();
+    uint32_t before = 0, round_total = 0;
+    for (int k = 0; k < TV_BLOCK / 64; ++k) { before += k < wave ? s_wave[k] : 0u; round_total += s_wave[k]; }
+    uint32_t at = base + before + ex;
     while (w) {
       int b = __ffs((int)w) - 1;
       w &= w - 1;
-      q[base++] = (int32_t)(i * 32 + b);
+      q[at++] = (int32_t)(i * 32 + b);
     }
+    base += round_total;
   }
 }
 

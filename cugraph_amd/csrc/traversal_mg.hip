@@ -628,7 +628,7 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_bottom_up(cugraph_
                          front, p.newfront.data(), p.dist.data(), p.with_pred ? p.pred.data() : (int32_t*)nullptr, (int32_t)level, p.cnt.data(),
                          (unsigned long long*)nullptr, p.ext_of_g);
       // the next level may run top-down: its queue
-      hipLaunchKernelGGL(k_bfs_bitmap_to_queue, grid_for((int64_t)(p.L / 32), TV_BLOCK, 2048), TV_BLOCK, 0, h.stream, (uint32_t const*)p.newfront.data(), (int64_t)(p.L / 32),
+      hipLaunchKernelGGL(k_bfs_bitmap_to_queue, grid_for((int64_t)(p.L / 32), TV_BLOCK, 512), TV_BLOCK, 0, h.stream, (uint32_t const*)p.newfront.data(), (int64_t)(p.L / 32),
                          p.q_next, p.cnt.data());
     }
     counters_t c{};
