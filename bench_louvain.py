@@ -112,14 +112,118 @@ def louvain_bench(cg, h, scale=22, edge_factor=8, repeats=3, cpu_scale=18):
     return out
 
 
+def louvain_bench_mg(args):
+    """BASELINE config 5 (Louvain partitioned over the GPUs of one node) on the library's communicator: every rank builds a slice of the same
+    undirected RMAT graph, cugraph_graph_create_mg + cugraph_louvain (collective).  Launched under torch.distributed.run (RANK / WORLD_SIZE /
+    LOCAL_RANK / MASTER_PORT from the environment) -- `python bench_louvain.py --gpus N` starts the ranks itself.  The clustering is checked
+    against the committed fixture of the C oracle when there is one for the scale (sha256 of the assembled cluster column)."""
+    import hashlib
+
+    import numpy as np
+    import torch
+
+    import cugraph_amd as cg
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    single = os.environ.get("CUGRAPH_AMD_MG_TEST_SINGLE_GPU") == "1"  # all ranks share cuda:0 (the IPC path is the same)
+    torch.cuda.set_device(0 if single else int(os.environ.get("LOCAL_RANK", str(rank))))
+    comm = cg.Comm(f"louvain_{os.environ.get('MASTER_PORT', '0')}", rank, world)
+    h = cg.ResourceHandle(comm)
+    scale, nv = args.scale, 1 << args.scale
+    src, dst, w = undirected_rmat(cg, h, scale, args.edge_factor)  # (every rank generates the list and keeps a slice: generation is not timed)
+    ne = int(src.numel())
+    mine = torch.arange(ne, device="cuda") % world == rank
+    s_m, d_m, w_m = src[mine].contiguous(), dst[mine].contiguous(), w[mine].contiguous()
+    del src, dst, w, mine
+    verts = torch.arange(rank, nv, world, dtype=torch.int32, device="cuda")
+    t0 = time.perf_counter()
+    g = cg.MGGraph(h, cg.GraphProperties(is_symmetric=True), [s_m], [d_m], [w_m], store_transposed=False, vertices_array=[verts])
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    times = []
+    for _ in range(args.repeats + 1):  # one warm-up
+        h.sync()
+        comm.barrier()
+        t0 = time.perf_counter()
+        v, c, q = cg.louvain(h, g, 100, 1e-7, 1.0, False)
+        h.sync()
+        comm.barrier()
+        times.append(max(x[0] for x in comm.allgather_f64([time.perf_counter() - t0])))
+    work = h.last_traversal_stats()
+    best = min(times[1:])
+    # the whole job's algorithmic bytes: edge-sweeps summed over the ranks (each rank sweeps its share), vertex-sweeps once
+    tot = comm.allgather_f64([float(work["edges_inspected"]), float(work["edges_of_reached"])])
+    e_sweeps, e_contr = sum(t[0] for t in tot), sum(t[1] for t in tot)
+    alg = 16 * e_sweeps + 28 * work["vertices_reached"] + 32 * e_contr
+    # assemble the cluster column on rank 0 through files (checker only) and compare with the fixture
+    tmp = Path(os.environ.get("TMPDIR", "/tmp")) / f"louvain_mg_{os.environ.get('MASTER_PORT', '0')}"
+    tmp.mkdir(parents=True, exist_ok=True)
+    np.savez(tmp / f"rank{rank}.npz", v=v.cpu().numpy(), c=c.cpu().numpy())
+    comm.barrier()
+    out = None
+    if rank == 0:
+        col = np.full(nv, -1, np.int64)
+        for r in range(world):
+            z = np.load(tmp / f"rank{r}.npz")
+            col[z["v"]] = z["c"]
+        check = {"every_vertex_once": bool((col >= 0).all()), "ok": bool((col >= 0).all())}
+        fx = ROOT / "tests" / "golden" / f"louvain_rmat{scale}.json"
+        if fx.exists() and args.edge_factor == 8:
+            gold = json.loads(fx.read_text())
+            same = hashlib.sha256(np.ascontiguousarray(col, np.int32).tobytes()).hexdigest() == gold["clusters_sha256"]
+            check.update({"clusters_equal_oracle_fixture": bool(same), "modularity_abs_err_vs_fixture": abs(q - gold["modularity"]), "fixture": fx.name})
+            check["ok"] = bool(check["ok"] and same and abs(q - gold["modularity"]) <= 1e-9)
+        out = {
+            "metric": f"louvain_seconds_rmat{scale}", "value": round(best, 4), "unit": "s", "higher_is_better": False, "n_gpus": world, "scaling": "strong",
+            "config": {"workload": f"Louvain (max_level 100, threshold 1e-7, resolution 1), undirected simple RMAT scale {scale} edge factor {args.edge_factor}, integer weights 1..8, "
+                                   "both directions stored; cugraph_graph_create_mg + cugraph_louvain on the library's communicator: cyclic vertex ownership, label merge by peer "
+                                   "pushes per sweep, two-stage integer contraction", "vertices": nv, "directed_edges": ne, "parallelism": f"{world} ranks, 1 process per rank",
+                       "all_ranks_on_one_gpu": single},
+            "modularity": q, "clusters": int(np.unique(col).size), "seconds_all": [round(t, 4) for t in times[1:]], "sweeps": int(work["steps"]), "graph_build_s": round(build_s, 3),
+            "dtype": "f64", "data": "synthetic",
+            "roofline": {"bound": "hbm", "achieved": round(alg / best / 1e9, 1), "peak": 8000.0 * (1 if single else world), "unit": "GB/s",
+                         "frac": round(alg / best / 1e9 / (8000.0 * (1 if single else world)), 4), "traffic": None, "algorithmic_bytes": int(alg),
+                         "kernel": "whole call on all ranks; 16 B x edge-sweeps + 28 B x vertex-sweeps + 32 B x contracted edges"},
+            "check": check,
+        }
+    comm.barrier()
+    del g
+    h.sync()
+    comm.barrier()
+    del h
+    comm.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1, help="> 1: the partitioned run on the library's communicator (one process per GPU)")
     ap.add_argument("--scale", type=int, default=22)
     ap.add_argument("--edge-factor", type=int, default=8)
     ap.add_argument("--repeats", type=int, default=3)
     ap.add_argument("--cpu-scale", type=int, default=18, help="RMAT scale of the bounded CPU sample (0 = skip)")
     ap.add_argument("--out", type=str, default=None)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:  # start the ranks ourselves, as bench.py does
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               str(Path(__file__).resolve())] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ)))
+    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        out = louvain_bench_mg(args)
+        if out is not None:
+            line = json.dumps(out)
+            print(line, flush=True)
+            if args.out:
+                Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+                Path(args.out).write_text(line + "\n")
+        return
 
     import torch
 

@@ -1146,7 +1146,8 @@ def test_louvain_hash_path_equals_sorted_path(cg, handle, orc, monkeypatch, scal
 @pytest.mark.parametrize("scale", [22, 24, 26])
 def test_louvain_rmat_golden(cg, handle, scale):
     """Louvain at the sizes its timings are quoted on (RMAT-22: 65 M directed edges, the single-GPU bench line; RMAT-24; RMAT-26: 1.06 G, BASELINE
-    config 5's graph): clusters (sha256 of the column), modularity (the exact double: integer weights), against the fixtures the C oracle
+    config 5's graph): clusters (sha256 of the column: every vertex in the oracle's cluster), modularity to 1e-9 (the sum of squared cluster
+    weights exceeds 2^53, so its last bits follow the summation order: the oracle adds sequentially, the library in 64 Ki chunks), against the fixtures the C oracle
     produced (tests/golden/make_louvain_fixture.py: 2.5 CPU-minutes / 10 minutes / hours of one core, hence fixtures)."""
     import hashlib
     import json
@@ -1170,7 +1171,7 @@ def test_louvain_rmat_golden(cg, handle, scale):
     del src, dst, w
     v, c, q = cg.louvain(handle, g, 100, 1e-7, 1.0, False)
     (c,) = by_vertex(v, c)
-    assert q == gold["modularity"]
+    assert abs(q - gold["modularity"]) <= 1e-9
     assert int(np.unique(c).size) == gold["clusters"]
     assert hashlib.sha256(np.ascontiguousarray(c, np.int32).tobytes()).hexdigest() == gold["clusters_sha256"]
 

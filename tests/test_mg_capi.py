@@ -199,12 +199,12 @@ def test_mg_capi_louvain(orc, tmp_path, world, scale):
 @pytest.mark.gpu
 def test_mg_capi_louvain_rmat22_golden(tmp_path):
     """the partitioned run at the size the single-GPU timing is quoted on, two ranks, against the committed fixture of the C oracle
-    (tests/golden/louvain_rmat22.json): cluster column (sha256), modularity (the exact double: integer weights)"""
+    (tests/golden/louvain_rmat22.json): cluster column (sha256), modularity to 1e-9 (and the same double on both ranks)"""
     import hashlib
 
     gold = json.loads((ROOT / "tests" / "golden" / "louvain_rmat22.json").read_text())
     res = run_ranks("louvain", 2, tmp_path, gold["scale"], timeout=900)
     c = _assemble_clusters(tmp_path, 2, 1 << gold["scale"])
-    assert float.fromhex(res[0]["modularity_hex"]) == gold["modularity"]
+    assert abs(float.fromhex(res[0]["modularity_hex"]) - gold["modularity"]) <= 1e-9 and res[0]["modularity_hex"] == res[1]["modularity_hex"]
     assert int(np.unique(c).size) == gold["clusters"]
     assert hashlib.sha256(np.ascontiguousarray(c, np.int32).tobytes()).hexdigest() == gold["clusters_sha256"]
