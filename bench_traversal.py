@@ -18,6 +18,93 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+def main_partitioned_ipc(args):
+    """Partitioned BFS / SSSP through the reference's own entry points on the library's communicator (cugraph_graph_create_mg + cugraph_bfs /
+    cugraph_sssp; csrc/traversal_mg_driver.hip): the SAME RMAT graph over all ranks (strong scaling).  Launched under torch.distributed.run
+    (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT); no process group is created."""
+    import torch
+
+    import cugraph_amd as cg
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    single = os.environ.get("CUGRAPH_AMD_MG_TEST_SINGLE_GPU") == "1"  # all ranks share cuda:0 (the IPC path is the same)
+    torch.cuda.set_device(0 if single else int(os.environ.get("LOCAL_RANK", str(rank))))
+    comm = cg.Comm(f"trav_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}", rank, world)
+    h = cg.ResourceHandle(comm)
+    nv, ne = 1 << args.scale, args.edge_factor << args.scale
+    per = (ne + world - 1) // world
+    first = min(rank * per, ne)
+    count = max(0, min(per, ne - first))
+    # global out-degrees (TEPS denominators, root choice): every rank walks the whole generator stream once, in pieces
+    outdeg = torch.zeros(nv, dtype=torch.int64, device="cuda")
+    piece = 1 << 26
+    for f in range(0, ne, piece):
+        s_all, _ = cg.generate_rmat_edgelist(h, args.scale, min(piece, ne - f), first_edge=f)
+        outdeg += torch.bincount(s_all.to(torch.int64), minlength=nv)
+        del s_all
+    src, dst = cg.generate_rmat_edgelist(h, args.scale, count, first_edge=first)
+    if args.weights == "unit":
+        w = torch.ones(count, dtype=torch.float32, device="cuda")
+    else:
+        w = torch.randint(1, 256, (count,), generator=torch.Generator(device="cuda").manual_seed(1 + rank), device="cuda").to(torch.float32)
+    verts = torch.arange(rank, nv, world, dtype=torch.int32, device="cuda")
+    t0 = time.perf_counter()
+    g = cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [src], [dst], [w], store_transposed=False, vertices_array=[verts])
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    del src, dst, w, verts
+    cand = torch.nonzero(outdeg > 0).flatten().cpu()
+    perm = torch.randperm(cand.numel(), generator=torch.Generator().manual_seed(0))[: args.roots]
+    roots = cand[perm].tolist()
+    outdeg_f = outdeg.to(torch.float64)
+    empty = torch.zeros(0, dtype=torch.int32, device="cuda")
+
+    def run(kind):
+        times, teps, levels = [], [], []
+        for i, r in enumerate([roots[0], roots[-1]] + roots):  # two warm-ups (the first call builds the partition and its windows)
+            h.sync()
+            comm.barrier()
+            t0 = time.perf_counter()
+            if kind == "bfs":
+                d, _, v = cg.bfs(h, g, torch.tensor([r], dtype=torch.int32, device="cuda") if rank == 0 else empty, False, 0, args.predecessors, False)
+                unreached = 2**31 - 1
+            else:
+                v, d, _ = cg.sssp(h, g, int(r), 3.0e38, args.predecessors, False)
+                unreached = float(torch.finfo(torch.float32).max)
+            h.sync()
+            comm.barrier()
+            dt = max(x[0] for x in comm.allgather_f64([time.perf_counter() - t0]))
+            er = float((outdeg_f[v.long()] * (d != unreached)).sum())
+            er = sum(x[0] for x in comm.allgather_f64([er]))
+            if i >= 2:
+                times.append(dt)
+                teps.append(er / dt)
+                levels.append(h.last_traversal_stats()["steps"])
+        hm = len(teps) / sum(1.0 / t for t in teps)
+        return {"ms_mean": round(1e3 * sum(times) / len(times), 3), "ms_median": round(1e3 * sorted(times)[len(times) // 2], 3),
+                "ms_all": [round(1e3 * t, 2) for t in times], "ms_min": round(1e3 * min(times), 3), "ms_max": round(1e3 * max(times), 3),
+                "mteps_harmonic_mean": round(hm / 1e6, 1), "rounds_mean": round(sum(levels) / len(levels), 1)}
+
+    out = {"workload": f"partitioned BFS/SSSP through cugraph_graph_create_mg + cugraph_bfs / cugraph_sssp on the library's communicator, RMAT scale {args.scale} "
+                       f"edge factor {args.edge_factor}, weights {args.weights}, {world} rank(s)" + (" sharing one GPU" if single and world > 1 else ""),
+           "n_gpus": world, "vertices": nv, "edges": ne, "roots": len(roots), "graph_build_s": round(build_s, 3), "scaling": "strong", "transport": "ipc",
+           "bfs": run("bfs")}
+    if not args.no_sssp:
+        out["sssp"] = run("sssp")
+    if rank == 0:
+        line = json.dumps(out)
+        print(line, flush=True)
+        if args.out:
+            Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+            Path(args.out).write_text(line + "\n")
+    comm.barrier()
+    del g
+    h.sync()
+    comm.barrier()
+    del h
+    comm.close()
+
+
 def main_partitioned(args):
     """Partitioned BFS / SSSP (cugraph_amd/mg_traversal.py): the SAME RMAT graph over all ranks (strong scaling)."""
     import torch
@@ -305,9 +392,11 @@ def main():
     ap.add_argument("--predecessors", action="store_true")
     ap.add_argument("--gpus", type=int, default=1, help="> 1 (under torch.distributed.run): the partitioned engine, one rank per GPU")
     ap.add_argument("--partitioned", action="store_true", help="run the partitioned engine even with one rank (comparison with the single-GPU path)")
+    ap.add_argument("--transport", choices=["ipc", "rccl"], default=os.environ.get("CUGRAPH_AMD_MG_TRANSPORT", "ipc"),
+                    help="partitioned runs: ipc = cugraph_graph_create_mg + cugraph_bfs / cugraph_sssp on the library's communicator (default), rccl = cugraph_amd/mg_traversal.py over torch.distributed")
     args = ap.parse_args()
     if args.gpus > 1 or args.partitioned:
-        return main_partitioned(args)
+        return main_partitioned_ipc(args) if args.transport == "ipc" else main_partitioned(args)
 
     torch.cuda.set_device(0)
     h = cg.ResourceHandle()

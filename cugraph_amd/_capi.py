@@ -187,6 +187,7 @@ PROTOTYPES = {
     "cugraph_amd_traversal_mg_plan_bottom_up": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(C.c_size_t), _PP]),
     "cugraph_amd_traversal_mg_plan_last_degree_sums": (C.c_int, [_P, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), _PP]),
     "cugraph_amd_traversal_mg_plan_results": (C.c_int, [_P, _P, _P, _PP]),
+    "cugraph_amd_traversal_mg_plan_keep_buffers": (None, [_P, C.c_int]),
     "cugraph_amd_traversal_mg_plan_free": (None, [_P]),
     "cugraph_amd_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _PP, _PP]),
     "cugraph_amd_comm_free": (None, [_P]),

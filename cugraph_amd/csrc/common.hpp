@@ -284,6 +284,8 @@ struct orientation_t {
   dvec<int32_t> offsets;    // V + 1
   dvec<int32_t> indices;    // E (minor ids)
   dev_buf weights;          // E * sizeof(weight) or empty
+  dev_buf edge_ids;         // E * (4 or 8) bytes or empty: the caller's edge ids in this orientation's edge order (graph_t::edge_id_type)
+  dvec<int32_t> edge_types; // E or empty: the caller's edge type ids in this orientation's edge order
   dvec<int32_t> row_order;  // V (permutation, degree descending) or empty = identity
   // seg[k] = number of scheduled rows with degree >= seg_threshold[k]; seg[4] = number of non-empty rows
   static constexpr int n_seg = 5;
@@ -321,6 +323,8 @@ struct graph_t {  // behind cugraph_graph_t (cpp/src/c_api/graph.hpp:61-77)
   cugraph_data_type_id_t weight_type{FLOAT32};
   bool store_transposed{false};  // orientation requested at creation (primary)
   bool has_weights{false};
+  bool has_edge_ids{false}, has_edge_types{false};  // edge properties carried for cugraph_decompress_to_edgelist (graph_sg.cpp:781-830)
+  cugraph_data_type_id_t edge_id_type{INT32};
   bool renumbered{false};
   cugraph_graph_properties_t props{FALSE, FALSE};
   int64_t nv{0};

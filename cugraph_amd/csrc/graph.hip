@@ -196,8 +196,13 @@ int bits_for(uint64_t max_value)
 }
 
 // Builds one orientation from an internal-id COO list.  major/minor/weights are left untouched.
+struct edge_props_in {  // optional per-edge columns that travel with the edges (same order as major / minor)
+  void const* ids{nullptr};
+  size_t ids_size{0};  // 4 or 8
+  int32_t const* types{nullptr};
+};
 void build_orientation(handle_t const& h, int64_t nv, int64_t ne, int32_t const* major, int32_t const* minor,
-                       void const* weights, size_t wsize, orientation_t& o)
+                       void const* weights, size_t wsize, orientation_t& o, edge_props_in const& props = edge_props_in{})
 {
   build_trace tr(h, "orientation");
   o.offsets.resize_discard(nv + 1);
@@ -206,9 +211,10 @@ void build_orientation(handle_t const& h, int64_t nv, int64_t ne, int32_t const*
   fill_i32(h, o.offsets.data(), nv + 1, (int32_t)ne);
   if (ne > 0) {
     dvec<uint64_t> keys(ne), keys_tmp(ne);
-    dvec<uint32_t> vals(weights ? ne : 0), vals_tmp(weights ? ne : 0);
-    uint32_t* const vp  = weights ? vals.data() : nullptr;
-    uint32_t* const vtp = weights ? vals_tmp.data() : nullptr;
+    bool const payload = weights != nullptr || props.ids != nullptr || props.types != nullptr;  // the sort carries the edge's input position
+    dvec<uint32_t> vals(payload ? ne : 0), vals_tmp(payload ? ne : 0);
+    uint32_t* const vp  = payload ? vals.data() : nullptr;
+    uint32_t* const vtp = payload ? vals_tmp.data() : nullptr;
     int const vb = bits_for(nv > 0 ? (uint64_t)(nv - 1) : 0);  // <= 31
     hipLaunchKernelGGL(k_pack_keys, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, major, minor, ne, vb, keys.data(), vp);
     tr.step("pack keys");
@@ -221,6 +227,15 @@ void build_orientation(handle_t const& h, int64_t nv, int64_t ne, int32_t const*
       HIP_TRY(hipMemsetAsync(static_cast<char*>(o.weights.ptr) + ne * wsize, 0, kEdgePad * wsize, h.stream));
       if (wsize == 4) gather_b32(h, (uint32_t const*)weights, vals.data(), o.weights.as<uint32_t>(), ne);
       else            gather_b64(h, (uint64_t const*)weights, vals.data(), o.weights.as<uint64_t>(), ne);
+    }
+    if (props.ids) {  // edge ids / types follow the same permutation (graph_sg.cpp:803-830 keeps them as edge properties)
+      o.edge_ids.alloc((size_t)ne * props.ids_size);
+      if (props.ids_size == 4) gather_b32(h, (uint32_t const*)props.ids, vals.data(), o.edge_ids.as<uint32_t>(), ne);
+      else                     gather_b64(h, (uint64_t const*)props.ids, vals.data(), o.edge_ids.as<uint64_t>(), ne);
+    }
+    if (props.types) {
+      o.edge_types.resize_discard((size_t)ne);
+      gather_b32(h, (uint32_t const*)props.types, vals.data(), reinterpret_cast<uint32_t*>(o.edge_types.data()), ne);
     }
     h.sync();  // temporaries die here
   }
@@ -343,9 +358,11 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
     CGA_EXPECTS(weights == nullptr || weights->type == FLOAT32 || weights->type == FLOAT64,
                 CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "weights must be FLOAT32 or FLOAT64");
     // Edge ids / types / start and end times are edge PROPERTIES that only the sampling and lookup families read
-    // (graph_sg.cpp:803-830 stores them next to the weights).  None of the algorithms of this library reads them: the columns
-    // are validated (sizes above, types here: graph_sg.cpp:781-801) and then not kept -- cugraph_decompress_to_edgelist returns
-    // NULL for them.
+    // (graph_sg.cpp:803-830 stores them next to the weights).  None of the algorithms of this library reads them; edge ids and edge
+    // type ids are CARRIED through the build's sort permutation (round 4: they used to be dropped silently) and come back from
+    // cugraph_decompress_to_edgelist; start / end times are validated (graph_sg.cpp:781-801) and not kept (no accessor of this
+    // library returns them).  Together with a flag that rewrites the edge list (drop_self_loops / drop_multi_edges / symmetrize) they
+    // are refused: the rewritten list has no one-to-one relation to the input columns.
     CGA_EXPECTS(edge_type_ids == nullptr || edge_type_ids->type == INT32, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "edge type ids must be INT32");
     CGA_EXPECTS(edge_ids == nullptr || edge_ids->type == INT32 || edge_ids->type == INT64, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
                 "edge ids must be INT32 or INT64");
@@ -497,7 +514,14 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
     orientation_t& primary = g->store_transposed ? g->csc : g->csr;
     int32_t const* major   = g->store_transposed ? d.data() : s.data();
     int32_t const* minor   = g->store_transposed ? s.data() : d.data();
-    build_orientation(h, g->nv, ne2, major, minor, wptr, wsize, primary);
+    edge_props_in props;
+    if (edge_ids || edge_type_ids) {
+      CGA_EXPECTS(!preprocess, CUGRAPH_NOT_IMPLEMENTED,
+                  "edge ids / edge type ids together with drop_self_loops / drop_multi_edges / symmetrize are not supported: the rewritten edge list has no one-to-one relation to them");
+      if (edge_ids) { props.ids = edge_ids->data; props.ids_size = dtype_size(edge_ids->type); g->has_edge_ids = true; g->edge_id_type = edge_ids->type; }
+      if (edge_type_ids) { props.types = edge_type_ids->as<int32_t const>(); g->has_edge_types = true; }
+    }
+    build_orientation(h, g->nv, ne2, major, minor, wptr, wsize, primary, props);
     *graph = reinterpret_cast<cugraph_graph_t*>(g.release());
   });
 }
@@ -517,7 +541,10 @@ void ensure_orientation(handle_t const& h, graph_t& g, bool transposed)
     hipLaunchKernelGGL(k_expand_rows, grid_for(g.nv * 16, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)have.offsets.data(), g.nv, rows.data());
   size_t wsize = g.has_weights ? dtype_size(g.weight_type) : 0;
   // new major = old minor (indices), new minor = old major (rows)
-  build_orientation(h, g.nv, g.ne, have.indices.data(), rows.data(), g.has_weights ? have.weights.ptr : nullptr, wsize, want);
+  edge_props_in props;
+  if (g.has_edge_ids) { props.ids = have.edge_ids.ptr; props.ids_size = dtype_size(g.edge_id_type); }
+  if (g.has_edge_types) props.types = have.edge_types.data();
+  build_orientation(h, g.nv, g.ne, have.indices.data(), rows.data(), g.has_weights ? have.weights.ptr : nullptr, wsize, want, props);
 }
 
 void renumber_ext_to_int(handle_t const& h, graph_t const& g, int32_t* ids, int64_t n)

@@ -261,14 +261,16 @@ extern "C" void cugraph_extract_paths_result_free(cugraph_extract_paths_result_t
 // cpp/src/c_api/decompress_to_edgelist.cpp:24-125 -> cugraph::decompress_to_edgelist, cpp/src/structure/
 // decompress_to_edgelist_impl.cuh): the graph back as (sources, destinations[, weights]) with EXTERNAL ids, in the order of
 // the by-source storage (the reference flips a transposed graph first, decompress_to_edgelist.cpp:53-58; here the CSR
-// orientation is built next to the CSC under the same numbering).  Edge ids / types were never stored: their accessors
-// and the offsets accessor return NULL.
+// orientation is built next to the CSC under the same numbering).  Edge ids / edge type ids given at graph creation travel with
+// their edges (graph.hip: build_orientation) and come back here; the offsets accessor (a temporal-graph feature) returns NULL.
 namespace cga {
 struct edgelist_result_t {
   device_array_t* src{nullptr};
   device_array_t* dst{nullptr};
   device_array_t* wgt{nullptr};
-  ~edgelist_result_t() { delete src; delete dst; delete wgt; }
+  device_array_t* ids{nullptr};
+  device_array_t* types{nullptr};
+  ~edgelist_result_t() { delete src; delete dst; delete wgt; delete ids; delete types; }
 };
 namespace {
 __global__ void k_rows_of_edges(int32_t const* offsets, int64_t nv, int32_t* rows)
@@ -292,7 +294,7 @@ extern "C" cugraph_error_code_t cugraph_decompress_to_edgelist(const cugraph_res
   return guarded(error, [&] {
     handle_t const& h = H(handle);
     CGA_EXPECTS(graph != nullptr && result != nullptr, CUGRAPH_INVALID_INPUT, "graph / result is NULL");
-    graph_t& g = *reinterpret_cast<graph_t*>(graph);
+    graph_t& g = G(graph);
     HIP_TRY(hipSetDevice(h.device));
     ensure_orientation(h, g, false);
     auto out = std::make_unique<edgelist_result_t>();
@@ -310,6 +312,14 @@ extern "C" cugraph_error_code_t cugraph_decompress_to_edgelist(const cugraph_res
     } else if (g.has_weights) {
       out->wgt = new device_array_t(0, g.weight_type);
     }
+    if (g.has_edge_ids) {
+      out->ids = new device_array_t((size_t)g.ne, g.edge_id_type);
+      if (g.ne > 0) HIP_TRY(hipMemcpyAsync(out->ids->buf.ptr, g.csr.edge_ids.ptr, (size_t)g.ne * dtype_size(g.edge_id_type), hipMemcpyDeviceToDevice, h.stream));
+    }
+    if (g.has_edge_types) {
+      out->types = new device_array_t((size_t)g.ne, INT32);
+      if (g.ne > 0) HIP_TRY(hipMemcpyAsync(out->types->buf.ptr, g.csr.edge_types.data(), (size_t)g.ne * 4, hipMemcpyDeviceToDevice, h.stream));
+    }
     h.sync();
     outer_replace_ids(h, g, out->src);
     outer_replace_ids(h, g, out->dst);
@@ -323,7 +333,7 @@ static cugraph_type_erased_device_array_view_t* el_view(device_array_t* a)
 extern "C" cugraph_type_erased_device_array_view_t* cugraph_edgelist_get_sources(cugraph_edgelist_t* e) { return el_view(reinterpret_cast<edgelist_result_t*>(e)->src); }
 extern "C" cugraph_type_erased_device_array_view_t* cugraph_edgelist_get_destinations(cugraph_edgelist_t* e) { return el_view(reinterpret_cast<edgelist_result_t*>(e)->dst); }
 extern "C" cugraph_type_erased_device_array_view_t* cugraph_edgelist_get_edge_weights(cugraph_edgelist_t* e) { return el_view(reinterpret_cast<edgelist_result_t*>(e)->wgt); }
-extern "C" cugraph_type_erased_device_array_view_t* cugraph_edgelist_get_edge_ids(cugraph_edgelist_t*) { return nullptr; }
-extern "C" cugraph_type_erased_device_array_view_t* cugraph_edgelist_get_edge_type_ids(cugraph_edgelist_t*) { return nullptr; }
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_edgelist_get_edge_ids(cugraph_edgelist_t* e) { return el_view(reinterpret_cast<edgelist_result_t*>(e)->ids); }
+extern "C" cugraph_type_erased_device_array_view_t* cugraph_edgelist_get_edge_type_ids(cugraph_edgelist_t* e) { return el_view(reinterpret_cast<edgelist_result_t*>(e)->types); }
 extern "C" cugraph_type_erased_device_array_view_t* cugraph_edgelist_get_edge_offsets(cugraph_edgelist_t*) { return nullptr; }
 extern "C" void cugraph_edgelist_free(cugraph_edgelist_t* e) { delete reinterpret_cast<edgelist_result_t*>(e); }

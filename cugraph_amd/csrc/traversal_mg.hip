@@ -344,6 +344,7 @@ void fill(handle_t const& h, T* p, size_t n, T v)
 
 struct traversal_mg_plan {
   handle_t const* h{nullptr};
+  bool caller_keeps_buffers{false};  // the buffers handed to merge_visited / apply outlive the call (the library's own driver: persistent windows)
   int mode{0}, rank{0}, P{1};
   size_t n_rows{0}, n_edges{0}, L{0}, capacity{0};
   int32_t const* offsets{nullptr};
@@ -444,6 +445,11 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_create(const cugra
     h.sync();
     *plan = reinterpret_cast<cugraph_amd_traversal_mg_plan_t*>(p.release());
   });
+}
+
+extern "C" void cugraph_amd_traversal_mg_plan_keep_buffers(cugraph_amd_traversal_mg_plan_t* plan, bool_t on)
+{
+  if (plan) TP(plan).caller_keeps_buffers = on == TRUE;
 }
 
 extern "C" void cugraph_amd_traversal_mg_plan_free(cugraph_amd_traversal_mg_plan_t* plan)
@@ -676,7 +682,7 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_merge_visited(cugr
     HIP_TRY(hipSetDevice(h.device));
     size_t const n = p.L * (size_t)p.P / 32;
     hipLaunchKernelGGL(k_mg_or, (int)((n + 255) / 256), 256, 0, h.stream, p.seen.data(), gathered, n);
-    h.sync();
+    if (!p.caller_keeps_buffers) h.sync();  // (`gathered` may be the caller's temporary)
   });
 }
 

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstring>
 
 namespace cga {
 
@@ -88,6 +89,7 @@ mg_traversal_run_t& ensure_run(handle_t const& h, graph_t& g, mg_traversal_part_
   ck(cugraph_amd_traversal_mg_plan_create(hh, t.offsets.data(), t.indices.data(), t.has_weights ? t.weights.data() : nullptr, (size_t)t.n_rows, (size_t)t.ne_local, (size_t)t.L,
                                           t.rank, P, t.local_vertices.data(), mode, r->send.data(), r->capacity, &r->plan, &err),
      err, "multi-GPU traversal plan");
+  cugraph_amd_traversal_mg_plan_keep_buffers(r->plan, TRUE);  // the gathered bitmaps live in persistent windows: no synchronisation per merge
   // every sender sends a destination at most once per level: at most L tuples per (sender, owner) pair
   r->channel = c.channel_alloc();
   r->twin    = c.window_create((size_t)P * (size_t)t.L * r->tw * 4);
@@ -148,9 +150,11 @@ level_stats_t share_frontier(handle_t const& h, mg_traversal_run_t& r, mg_traver
   c.push_multi(h.stream, d);
   hipLaunchKernelGGL(k_put_stats, 1, 64, 0, h.stream, (unsigned long long* const*)r.d_peer_s[b].data(), me, P, mine.n, mine.out_sum, mine.in_sum);
   c.wait(h.stream, r.channel, c.signal(h.stream, r.channel));
-  ck(cugraph_amd_traversal_mg_plan_merge_visited(r.plan, static_cast<uint32_t const*>(r.bwin[b]->local), &err), err, "merge visited");  // synchronises
+  ck(cugraph_amd_traversal_mg_plan_merge_visited(r.plan, static_cast<uint32_t const*>(r.bwin[b]->local), &err), err, "merge visited");  // (no synchronisation: keep_buffers)
   std::vector<unsigned long long> all((size_t)P * 4);
-  HIP_TRY(hipMemcpy(all.data(), r.swin[b]->local, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(h.pinned, r.swin[b]->local, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h.stream));
+  h.sync();  // the level's one wait for the exchange: the statistics of all ranks are here, the bits are merged
+  std::memcpy(all.data(), h.pinned, all.size() * sizeof(unsigned long long));
   c.check("multi-GPU BFS level");
   level_stats_t tot{0, 0, 0};
   for (int k = 0; k < P; ++k) { tot.n += all[4 * k]; tot.out_sum += all[4 * k + 1]; tot.in_sum += all[4 * k + 2]; }

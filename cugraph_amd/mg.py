@@ -49,6 +49,15 @@ def _prim_handle():
     return h
 
 
+def release_build_temporaries():
+    """After a partition / plan has been built: hand the library's large cached blocks (sort buffers of the construction) back to the
+    driver.  torch and RCCL allocate from the same device (exchange buffers, a second edge-list copy for the bottom-up BFS) and could hit
+    out-of-memory while the library's pool sits on tens of GB of idle cache (round-3 review)."""
+    from . import _capi as capi
+
+    return int(capi.lib().cugraph_amd_memory_pool_trim_large(256 << 20))
+
+
 def _bits_for(max_value: int) -> int:
     return max(1, int(max_value).bit_length())
 
@@ -421,6 +430,8 @@ class MGPageRank:
         factory = engine_factory or HipLocalEngine
         self.engine = factory(part, ex, local_dst, w, outw_local, alpha, init_local)
         self.iterations = 0
+        if getattr(self.engine, "plan", None) is not None:
+            release_build_temporaries()
         with on_engine_stream(self.engine):
             self.engine.start()
 
@@ -657,6 +668,8 @@ class MGPageRank2D:
         factory = engine_factory or HipLocalEngine2D
         self.engine = factory(part, lcol, lrow, w, outw_own, alpha, init_own)
         self.iterations = 0
+        if getattr(self.engine, "plan", None) is not None:
+            release_build_temporaries()
         with on_engine_stream(self.engine):
             self.engine.start()
         self.bytes_per_iteration = {"all_gather_in": (part.R - 1) * part.L * self.engine.x_own.element_size(),

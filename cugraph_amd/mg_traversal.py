@@ -33,7 +33,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .mg import Partition, _a2a, _count_owners, inclusive_counts, stable_argsort
+from .mg import Partition, _a2a, _count_owners, inclusive_counts, release_build_temporaries, stable_argsort
 
 INT32_MAX = 2**31 - 1
 FLT_MAX = float(np.finfo(np.float32).max)
@@ -266,6 +266,8 @@ class MGTraversal:
             dist.all_reduce(ne_t, group=group)
             self.ne_global = int(ne_t.item())
             self._out_deg = out_deg
+        if getattr(self.engine, "plan", None) is not None:
+            release_build_temporaries()  # (the library's cache of construction temporaries: torch / RCCL share the device)
 
     # -- collectives on device tensors (nccl) or through the host (gloo moves host memory)
     def _to_comm(self, t):

@@ -172,6 +172,8 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_last_degree_su
 /* distances of the local rows (BFS: int32, INT32_MAX unreached; SSSP: float, FLT_MAX unreached) and predecessors (external ids, -1) */
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_results(cugraph_amd_traversal_mg_plan_t* plan, void* distances,
                                                                           int32_t* predecessors, cugraph_error_t** error);
+/* the buffers handed to merge_visited outlive the call (persistent exchange windows): it then returns without synchronising */
+CUGRAPH_EXPORT void cugraph_amd_traversal_mg_plan_keep_buffers(cugraph_amd_traversal_mg_plan_t* plan, bool_t on);
 CUGRAPH_EXPORT void cugraph_amd_traversal_mg_plan_free(cugraph_amd_traversal_mg_plan_t* plan);
 
 /* One-node communicator of the library (cugraph_amd/csrc/comm.hpp): one process per GPU, every rank's device windows mapped into every

@@ -8,9 +8,11 @@
  * else is CUGRAPH_UNSUPPORTED_TYPE_COMBINATION.  INT64 ids and INT32 ids spread over a sparse range are translated to compact
  * 32-bit internal ids at this boundary (csrc/outer_ids.hip) and translated back in every result; limits, named in the error
  * message: fewer than 2^31 distinct vertex ids per graph (edge counts: see DESIGN.md section 6).
- * edge_ids (INT32 / INT64), edge_type_ids (INT32) and edge start / end times are VALIDATED (sizes and types as
- * graph_sg.cpp:781-830) and then NOT STORED: no algorithm behind this library reads edge properties, and
- * cugraph_decompress_to_edgelist returns NULL for those columns -- a caller that needs them back must keep its own copy.
+ * edge_ids (INT32 / INT64) and edge_type_ids (INT32) are validated (sizes and types as graph_sg.cpp:781-830) and STORED with their
+ * edges (they travel through the build's sort permutation); cugraph_decompress_to_edgelist returns them.  No algorithm behind this
+ * library reads them.  Combined with drop_self_loops / drop_multi_edges / symmetrize they are refused with CUGRAPH_NOT_IMPLEMENTED (the
+ * rewritten edge list has no one-to-one relation to the columns); multi-GPU graphs (cugraph_graph_create_mg on a communicator handle)
+ * and edge start / end times are validated and not kept.
  * drop_self_loops / drop_multi_edges / symmetrize are applied in the reference's order before renumbering
  * (graph_sg.cpp:185-248; csrc/edgelist.hip) and do_expensive_check runs the reference's input checks.
  *

@@ -1243,6 +1243,44 @@ def test_capi_generators_edge_columns_and_decompress(cg, handle):
             v.free()
 
 
+@pytest.mark.parametrize("transposed,id_dtype", [(False, np.int32), (True, np.int64)])
+def test_edge_ids_and_types_travel_with_their_edges(cg, handle, orc, transposed, id_dtype):
+    """Edge ids / edge type ids given at graph creation are stored with their edges and come back from cugraph_decompress_to_edgelist
+    (graph_sg.cpp:781-830; c_api/decompress_to_edgelist.cpp): the id returned next to an edge names exactly that input edge -- also when the
+    by-source storage is derived from a transposed graph (a second sort) and after renumbering.  With a flag that rewrites the edge list the
+    combination is refused, not silently dropped."""
+    import ctypes as C
+
+    from cugraph_amd import _capi
+    from cugraph_amd.pylib import assert_success, copy_to_torch
+
+    s, d = rmat_graph(orc, 10)
+    ne = s.size
+    w = np.random.default_rng(3).random(ne).astype(np.float32)
+    ids = (np.random.default_rng(4).permutation(ne) + 1000).astype(id_dtype)   # arbitrary distinct ids
+    types = (np.arange(ne) % 5).astype(np.int32)
+    g = cg.SGGraph(handle, cg.GraphProperties(is_multigraph=True), T(s), T(d), T(w), store_transposed=transposed, renumber=True, edge_id_array=T(ids),
+                   edge_type_array=T(types))
+    if transposed:  # exercise the derived orientation once more through an algorithm that flips it
+        cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 2, False, fail_on_nonconvergence=False)
+    l, hp = _capi.lib(), handle.c_resource_handle_ptr
+    el, err = C.c_void_p(), C.c_void_p()
+    assert_success(l.cugraph_decompress_to_edgelist(hp, g.c_graph_ptr, 0, C.byref(el), C.byref(err)), err, "decompress")
+    es = copy_to_torch(hp, l.cugraph_edgelist_get_sources(el)).cpu().numpy()
+    ed = copy_to_torch(hp, l.cugraph_edgelist_get_destinations(el)).cpu().numpy()
+    ew = copy_to_torch(hp, l.cugraph_edgelist_get_edge_weights(el)).cpu().numpy()
+    ei = copy_to_torch(hp, l.cugraph_edgelist_get_edge_ids(el)).cpu().numpy()
+    et = copy_to_torch(hp, l.cugraph_edgelist_get_edge_type_ids(el)).cpu().numpy()
+    l.cugraph_edgelist_free(el)
+    assert ei.dtype == id_dtype and sorted(ei.tolist()) == sorted(ids.tolist())
+    where = np.empty(ne + 1000, np.int64)
+    where[ids] = np.arange(ne)
+    k = where[ei]   # the input edge every returned row claims to be
+    assert np.array_equal(es, s[k]) and np.array_equal(ed, d[k]) and np.array_equal(ew, w[k]) and np.array_equal(et, types[k])
+    with pytest.raises(Exception, match="NOT_IMPLEMENTED|not supported"):
+        cg.SGGraph(handle, cg.GraphProperties(), T(s), T(d), T(w), renumber=True, edge_id_array=T(ids), drop_self_loops=True)
+
+
 # ----------------------------------------------------------------------- INT64 ids, sparse ids (outer_ids.hip)
 def _ext(ids, mapping, dtype):
     return T(np.asarray([mapping[i] for i in ids]), dtype)
