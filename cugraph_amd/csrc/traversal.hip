@@ -226,13 +226,26 @@ struct sssp_state {
   WT cutoff;
   uint32_t round;
   uint32_t far_epoch;
+  int32_t const* out_offsets;  // CSR offsets: the out-degrees of the vertices that enter the near frontier are summed (counters_t::out_edges):
+                               // the host knows the next round's edge count without a pass over the queue (pull rounds are chosen by it)
 };
 
 template <typename WT>
 struct sssp_relax {
   sssp_state<WT> s;
   wave_queue wq_near, wq_far, wq_set;
-  __device__ __forceinline__ void flush() { wq_near.flush(); wq_far.flush(); wq_set.flush(); }
+  unsigned long long deg_acc{0};
+  __device__ __forceinline__ void count_near(bool near, int32_t v)
+  {
+    if (near && s.out_offsets) deg_acc += (unsigned long long)(eoff(s.out_offsets, v + 1) - eoff(s.out_offsets, v));
+  }
+  __device__ __forceinline__ void flush()
+  {
+    wq_near.flush(); wq_far.flush(); wq_set.flush();
+    unsigned long long a = deg_acc;
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if ((threadIdx.x & 63) == 0 && a) atomicAdd(&cnt_replica(s.cnt)->out_edges, a);
+  }
   __device__ __forceinline__ void operator()(int32_t u, int32_t v, eoff_t p)
   {
     using B  = dist_bits<WT>;
@@ -253,6 +266,7 @@ struct sssp_relax {
         }
       }
     }
+    count_near(near, v);
     wq_near.push(near, v);
     wq_far.push(far, v);
     if (s.q_set) wq_set.push(fresh, v);  // (wave-uniform condition)
@@ -288,11 +302,116 @@ struct sssp_relax {
     bool const near = won == 1u, far = won == 2u;
     bool fresh = false;
     if (s.q_set && near) fresh = atomicExch(&s.mark_set[v], s.set_epoch) != s.set_epoch;
+    count_near(near, v);
     wq_near.push(near, v);
     wq_far.push(far, v);
     if (s.q_set) wq_set.push(fresh, v);
   }
 };
+
+// A PULL relaxation round: every row of the CSC scans its in-edges and relaxes the ones whose source sits in the frontier bitmap
+// (sssp_impl.cuh:412-561 always pushes).  For the round right after the source -- a few ten thousand hubs whose out-edges are a third of the
+// graph -- a push round is 79 M relaxations at 24-31 G/s (RMAT-24; most of them SUCCEED: an atomicMin, a mark exchange and a queue append
+// each, on random lines); the pull round streams the in-edges once (8 bytes each), tests a bitmap that sits in L2, reads d[u] of the few
+// frontier members from L2 and updates d[row] next to where its neighbours on the other lanes update it.  Same fixed point: relaxation
+// order does not matter.  The adapter swaps the roles for sssp_relax: relax(u = in-neighbour, v = row, position in the CSC).
+template <typename WT>
+struct sssp_pull_fn {
+  sssp_relax<WT> inner;
+  uint32_t const* fbits;
+  __device__ __forceinline__ void operator()(int32_t row, int32_t nbr, eoff_t p)
+  {
+    if ((fbits[(uint32_t)nbr >> 5] >> ((uint32_t)nbr & 31u)) & 1u) inner(nbr, row, p);
+  }
+  __device__ __forceinline__ void flush() { inner.flush(); }
+};
+
+__global__ void k_queue_to_bits(int32_t const* q, int64_t n, uint32_t* bits)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) { int32_t const v = q[i]; atomicOr(&bits[(uint32_t)v >> 5], 1u << ((uint32_t)v & 31u)); }
+}
+
+// The rows of fewer than big_deg in-edges: a wavefront takes 64 consecutive vertices; a lane scans its own row when it is shorter than 64
+// (16-byte index loads, four probes of the frontier bitmap per step), longer rows are walked by the whole wavefront; a row's candidate
+// distances are reduced in registers and the vertex is updated ONCE, by its only writer in this kernel -- no atomic on d[]: the edges stream
+// at the rate of the bottom-up BFS levels instead of the 40-70 G edges/s of the frontier expansion.  Rows of big_deg or more in-edges go to
+// bigq in BIG_SEG-edge segments for k_sssp_pull_big (which relaxes through sssp_relax: several workgroups share such a row).
+template <typename WT>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_pull_rows(int32_t const* in_offsets, int32_t const* in_indices, WT const* in_weights, int64_t nv, uint32_t const* fbits,
+                                                             int32_t* bigq, sssp_state<WT> s, int32_t big_deg)
+{
+  __shared__ wave_queue_storage<2> wqs;
+  wqs.init();
+  wave_queue wq_near(wqs, 0, s.q_next, &s.cnt->n_next), wq_far(wqs, 1, s.far, &s.cnt->n_far);
+  using B              = dist_bits<WT>;
+  int const lane       = threadIdx.x & 63;
+  int64_t const gwave  = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t const nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int64_t const ngroup = (nv + 63) >> 6;
+  WT const inf         = std::numeric_limits<WT>::max();
+  unsigned long long deg_acc = 0;
+  auto in_front = [&](int32_t u) { return ((fbits[(uint32_t)u >> 5] >> ((uint32_t)u & 31u)) & 1u) != 0; };
+  for (int64_t grp = gwave; grp < ngroup; grp += nwaves) {
+    int64_t const v = grp * 64 + lane;
+    eoff_t b    = 0;
+    int32_t len = 0;
+    if (v < nv) { b = eoff(in_offsets, v); len = (int32_t)(eoff(in_offsets, v + 1) - b); }
+    bool const big = len >= big_deg;
+    if (big) {
+      uint32_t const nseg = ((uint32_t)len + BIG_SEG - 1) / BIG_SEG;
+      uint32_t const at   = atomicAdd(&s.cnt->n_big, nseg);
+      for (uint32_t sgm = 0; sgm < nseg; ++sgm) { bigq[2 * (at + sgm)] = (int32_t)v; bigq[2 * (at + sgm) + 1] = (int32_t)sgm; }
+    }
+    WT best = inf;
+    bool const own = len > 0 && len < 64;
+    int32_t longest = own ? len : 0;
+    for (int o = 32; o > 0; o >>= 1) longest = max(longest, __shfl_xor(longest, o));
+    for (int32_t k = 0; k < longest; k += BU_CHUNK) {
+      int32_t u[BU_CHUNK];
+      bu_load_chunk(in_indices, b + (eoff_t)k, own ? len - k : 0, u);
+#pragma unroll
+      for (int j = 0; j < BU_CHUNK; ++j)
+        if (u[j] >= 0 && in_front(u[j])) best = min(best, B::from(s.dist[u[j]]) + in_weights[b + (eoff_t)(k + j)]);
+    }
+    uint64_t mid = __ballot(len >= 64 && !big);
+    while (mid) {
+      int const src = __ffsll((unsigned long long)mid) - 1;
+      mid &= mid - 1;
+      eoff_t const rb  = (eoff_t)__shfl((int)b, src);
+      int32_t const rl = __shfl(len, src);
+      WT m = inf;
+      for (int32_t p = lane; p < rl; p += 64) {
+        int32_t const u = in_indices[rb + (eoff_t)p];
+        if (in_front(u)) m = min(m, B::from(s.dist[u]) + in_weights[rb + (eoff_t)p]);
+      }
+      for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+      if (lane == src) best = m;
+    }
+    bool near = false, far = false;
+    if (v < nv && best < s.cutoff && best < B::from(s.dist[v])) {
+      s.dist[v] = B::to(best);
+      if (best < s.threshold) { near = atomicExch(&s.mark_near[v], s.round) != s.round; }
+      else { far = atomicExch(&s.mark_far[v], s.far_epoch) != s.far_epoch; }
+    }
+    if (near && s.out_offsets) deg_acc += (unsigned long long)(eoff(s.out_offsets, v + 1) - eoff(s.out_offsets, v));
+    wq_near.push(near, (int32_t)v);
+    wq_far.push(far, (int32_t)v);
+  }
+  wq_near.flush();
+  wq_far.flush();
+  for (int o = 32; o > 0; o >>= 1) deg_acc += __shfl_xor(deg_acc, o);
+  if (lane == 0 && deg_acc) atomicAdd(&cnt_replica(s.cnt)->out_edges, deg_acc);
+}
+template <typename WT>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_pull_big(int32_t const* bigq, int32_t const* in_offsets, int32_t const* in_indices, sssp_state<WT> s, uint32_t const* fbits)
+{
+  __shared__ wave_queue_storage<3> wqs;
+  wqs.init();
+  sssp_pull_fn<WT> f{sssp_relax<WT>{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far), wave_queue(wqs, 2, s.q_set, &s.cnt->n_set)}, fbits};
+  expand_big(bigq, in_offsets, in_indices, s.cnt, f);
+  f.flush();
+}
 
 template <typename WT>
 __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* row_end,
@@ -328,7 +447,7 @@ template <typename WT>
 __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split(int32_t const* far_in, int64_t n, typename dist_bits<WT>::type const* dist, WT lower,
                                                          WT upper, int32_t* near_out, int32_t* far_out, uint32_t* mark_near,
                                                          uint32_t* mark_far, uint32_t round, uint32_t new_epoch, counters_t* cnt,
-                                                         int32_t* set_out, uint32_t* mark_set, uint32_t set_epoch)
+                                                         int32_t* set_out, uint32_t* mark_set, uint32_t set_epoch, int32_t const* out_offsets)
 {
   using B        = dist_bits<WT>;
   int const lane = threadIdx.x & 63;
@@ -336,6 +455,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split(int32_t const* far_in, 
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t n_pad  = (n + 63) & ~(int64_t)63;
   unsigned long long kept_min = ~0ull;  // smallest distance bits this lane kept in the far pile
+  unsigned long long deg_acc = 0;       // out-degrees of the vertices that enter the near frontier (the next round's edge count)
   for (; i < n_pad; i += stride) {
     bool near = false, keep = false;
     int32_t v = 0;
@@ -350,6 +470,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split(int32_t const* far_in, 
         }
       }
     }
+    if (near && out_offsets) deg_acc += (unsigned long long)(eoff(out_offsets, v + 1) - eoff(out_offsets, v));
     wave_push(near, v, near_out, &cnt->n_next, lane);
     wave_push(keep, v, far_out, &cnt->n_far, lane);
     if (set_out) {  // (uniform) the bucket's members, once each
@@ -357,6 +478,8 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split(int32_t const* far_in, 
       wave_push(fresh, v, set_out, &cnt->n_set, lane);
     }
   }
+  for (int o = 32; o > 0; o >>= 1) deg_acc += __shfl_xor(deg_acc, o);
+  if (lane == 0 && deg_acc) atomicAdd(&cnt_replica(cnt)->out_edges, deg_acc);
   // one atomicMin per wavefront (per kept vertex they would all hit the same word)
   for (int o = 32; o > 0; o >>= 1) kept_min = min(kept_min, (unsigned long long)__shfl_xor(kept_min, o));
   if (lane == 0 && kept_min != ~0ull) {
@@ -1445,6 +1568,16 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   double lower = 0.0, upper = delta;
   // one relaxation round over the rows [beg[u], end[u]) of the vertices in `front`; near / far / bucket-member appends continue
   // at n_far / n_set_in (they persist across the rounds of a bucket), n_next / n_big / edges start from zero
+  // pull rounds (sssp_pull_fn): chosen from the frontier's out-edge count, which the round that built the frontier summed on the device
+  // OPT-IN (CUGRAPH_AMD_SSSP_PULL=1; "force": every round, the parity test): measured at RMAT-24, weights 1..255 (profiles/r4o_sssp_pull.txt): the
+  // round of the 66 K hubs right after the source takes 2.7 ms pulled (268 M in-edges streamed, 82 M of them relaxed; the rows of 2048 or
+  // more in-edges -- 82 M edges -- still go through the atomic path) against 2.5 ms pushed, and a traversal 12.1 ms against 11.0: no gain.
+  char const* env_pull     = getenv("CUGRAPH_AMD_SSSP_PULL");
+  bool const pull_allowed  = !use_lh && g.ne <= kMaxSignedEdges && env_pull && std::string(env_pull) != "0";
+  bool const pull_force    = pull_allowed && env_pull && std::string(env_pull) == "force";
+  uint64_t const pull_min_edges = std::max<uint64_t>((uint64_t)g.ne / 10, (uint64_t)1 << 22);
+  uint64_t front_edges = 0, pull_rounds = 0;  // out-edges of the current near frontier (0 for the source: its round is a push)
+  dvec<uint32_t> fbits;
   static bool const sssp_trace = getenv("CUGRAPH_AMD_SSSP_TRACE") != nullptr;  // per round: sizes and wall time since the previous line (stderr)
   auto t_trace = std::chrono::steady_clock::now();
   auto relax_round = [&](int32_t const* front, int64_t n_front, int32_t const* beg, int32_t const* end, int32_t* set_out, int64_t n_set_in) {
@@ -1458,18 +1591,41 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
     std::memcpy(h.pinned, &z, sizeof(z));
     HIP_TRY(hipMemcpyAsync(cnt.data(), h.pinned, sizeof(z), hipMemcpyHostToDevice, h.stream));
     sssp_state<WT> s{d, wrel, q_nxt, far_cur, mark_near.data(), mark_far.data(), use_lh ? set_out : nullptr, mark_set.data(), set_epoch, cnt.data(),
-                     (WT)std::min(upper, (double)wmax), cutoff, round, far_epoch};
-    {
+                     (WT)std::min(upper, (double)wmax), cutoff, round, far_epoch, (int32_t const*)o.offsets.data()};
+    // few vertices with a large share of the graph's edges (the hubs right after the source): a pull round over the in-edges (sssp_pull_fn)
+    bool const pull = pull_allowed && (pull_force || (front_edges >= pull_min_edges && n_front * 16 <= nv));
+    if (pull) {
+      ensure_orientation(h, g, true);  // in-edges + their weights: built once per graph, next to the CSR under the same numbering
+      orientation_t const& ci = g.csc;
+      size_t const fw = (size_t)((nv + 31) / 32 + 1);
+      if (fbits.size() < fw) fbits.resize_discard(fw);
+      HIP_TRY(hipMemsetAsync(fbits.data(), 0, fw * 4, h.stream));
+      hipLaunchKernelGGL(k_queue_to_bits, grid_for(n_front, kBlock, 2048), kBlock, 0, h.stream, front, n_front, fbits.data());
+      s.weights = ci.weights.template as<WT const>();
+      {
+        timed_launch t(h, "sssp_relax");
+        int64_t const ngroup = (nv + 63) / 64;
+        int const grid       = (int)std::max<int64_t>(1, std::min<int64_t>((ngroup + TV_WAVES - 1) / TV_WAVES, (int64_t)h.num_cus * 16));
+        hipLaunchKernelGGL(k_sssp_pull_rows<WT>, grid, TV_BLOCK, 0, h.stream, (int32_t const*)ci.offsets.data(), (int32_t const*)ci.indices.data(), ci.weights.template as<WT const>(), nv,
+                           (uint32_t const*)fbits.data(), bigq.data(), s, (int32_t)BIG_DEG);
+        hipLaunchKernelGGL(k_sssp_pull_big<WT>, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)ci.offsets.data(), (int32_t const*)ci.indices.data(), s,
+                           (uint32_t const*)fbits.data());
+      }
+      ++pull_rounds;
+    } else {
       timed_launch t(h, "sssp_relax");
       hipLaunchKernelGGL(k_sssp_expand<WT>, expand_grid(h, n_front), TV_BLOCK, 0, h.stream, front, n_front, beg, end, adj, bigq.data(), s, big_deg_for(h, n_front));
       hipLaunchKernelGGL(k_sssp_expand_big<WT>, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), beg, end, adj, s);
     }
     h.read_back(&c, cnt.data(), 1);
     c.fold();
+    if (pull) c.edges = front_edges;  // relaxations = the frontier's out-edges (the kernel walked every in-edge of the graph to find them)
+    front_edges = c.out_edges;
     if (sssp_trace) {
       auto const now = std::chrono::steady_clock::now();
-      fprintf(stderr, "[sssp] round %3u  window [%g, %g)  frontier %9lld  edges %11llu  next %9u  far %9u  deferred segments %7u  %8.1f us\n", round, lower, upper,
-              (long long)n_front, (unsigned long long)c.edges, c.n_next, c.n_far, c.n_big, std::chrono::duration<double, std::micro>(now - t_trace).count());
+      fprintf(stderr, "[sssp] round %3u %s window [%g, %g)  frontier %9lld  edges %11llu  next %9u (%llu out-edges)  far %9u  deferred segments %7u  %8.1f us\n", round,
+              pull ? "PULL" : "push", lower, upper, (long long)n_front, (unsigned long long)c.edges, c.n_next, (unsigned long long)c.out_edges, c.n_far, c.n_big,
+              std::chrono::duration<double, std::micro>(now - t_trace).count());
       t_trace = now;
     }
     relaxed += c.edges;
@@ -1508,9 +1664,11 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
       HIP_TRY(hipMemcpyAsync(cnt.data(), h.pinned, sizeof(z), hipMemcpyHostToDevice, h.stream));
       hipLaunchKernelGGL(k_sssp_split<WT>, grid_for(n_far, TV_BLOCK, 2048), TV_BLOCK, 0, h.stream, (int32_t const*)far_cur, n_far,
                          (bits_t const*)d, (WT)std::min(lower, (double)wmax), (WT)std::min(upper, (double)wmax), q_cur, far_nxt,
-                         mark_near.data(), mark_far.data(), round, far_epoch, cnt.data(), use_lh ? set_cur : (int32_t*)nullptr, mark_set.data(), set_epoch);
+                         mark_near.data(), mark_far.data(), round, far_epoch, cnt.data(), use_lh ? set_cur : (int32_t*)nullptr, mark_set.data(), set_epoch,
+                         (int32_t const*)o.offsets.data());
       h.read_back(&c, cnt.data(), 1);
       c.fold();
+      front_edges = c.out_edges;
       n_cur = c.n_next;
       n_far = c.n_far;
       n_set = use_lh ? c.n_set : 0;

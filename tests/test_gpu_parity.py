@@ -414,6 +414,15 @@ def test_sssp_subqueues_vs_oracle(cg, handle, orc, monkeypatch, scale, kind, dty
     _sssp_parity(cg, handle, orc, scale, kind, dtype)
 
 
+@pytest.mark.parametrize("scale,kind,dtype", [(12, "int", np.float32), (14, "real", np.float32), (16, "int", np.float32), (14, "int", np.float64), (13, "unit", np.float32)])
+def test_sssp_pull_rounds_vs_oracle(cg, handle, orc, monkeypatch, scale, kind, dtype):
+    """SSSP with EVERY relaxation round pulled over the in-edges (CUGRAPH_AMD_SSSP_PULL=force; by default only the round of the hubs right
+    after the source is: sssp_pull_fn): the fixed point does not depend on the direction of a round -- distances bit-identical to Dijkstra,
+    canonical parents, cutoff honoured -- for integer / real / unit weights, fp32 / fp64."""
+    monkeypatch.setenv("CUGRAPH_AMD_SSSP_PULL", "force")
+    _sssp_parity(cg, handle, orc, scale, kind, dtype)
+
+
 def _sssp_parity(cg, handle, orc, scale, kind, dtype):
     s, d = rmat_graph(orc, scale)
     nv = 1 << scale
