@@ -216,7 +216,18 @@ def main():
         else:
             from cugraph_amd import mg
 
-        out = mg.bench_main(args)
+        try:
+            out = mg.bench_main(args)
+        except getattr(mg, "IpcUnavailable", ()) as e:
+            # every rank raises this together (the ranks agree on the self-check over the bootstrap segment) before any graph exists:
+            # the node cannot run the library's communicator; the RCCL orchestration is the other product path of the same kernels
+            if rank == 0:
+                print(f"bench.py: communicator bring-up failed ({e}); taking --transport rccl", file=sys.stderr, flush=True)
+            from cugraph_amd import mg as mg_rccl
+
+            out = mg_rccl.bench_main(args)
+            if out is not None:
+                out.setdefault("config", {})["transport_note"] = f"--transport ipc failed its bring-up self-check: {e}"[:400]
         if rank == 0 and out is not None:
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(min(args.cpu_scale, args.scale), 10)

@@ -9,6 +9,42 @@ import time
 import torch
 
 
+class IpcUnavailable(RuntimeError):
+    """the communicator could not be brought up on this node (every rank raises it together: bench.py then takes --transport rccl)"""
+
+
+def _bring_up(Comm, ResourceHandle, session, rank, world):
+    """Collective: communicator + handle + the library's self-check of every primitive (all-gather, all-to-all-v, all-reduces against
+    closed forms; include/cugraph_amd/extensions.h: cugraph_amd_comm_selftest), which also times the two primitives of the iteration
+    path.  The ranks agree on the outcome over the host-side bootstrap segment, so a node where HIP IPC between the GPUs does not work
+    fails HERE, on every rank, before any graph is built."""
+    import ctypes as C
+
+    from . import _capi as capi
+    from .pylib import assert_success
+
+    comm = h = None
+    link, why = {}, ""
+    try:
+        comm = Comm(session, rank, world)
+        h = ResourceHandle(comm)
+        res, err = (C.c_double * 4)(), C.c_void_p()
+        assert_success(capi.lib().cugraph_amd_comm_selftest(h.c_resource_handle_ptr, 1 << 20, 8, res, C.byref(err)), err, "cugraph_amd_comm_selftest")
+        link = {"device_barrier_us": round(res[0], 2), "peer_push_GBps_per_rank": round(res[1], 1), "ranks_on_distinct_gpus": bool(res[2])}
+        ok = 1.0
+    except Exception as e:  # noqa: BLE001 -- any failure of the bring-up means "not on this node"
+        ok, why = 0.0, f"{type(e).__name__}: {e}"
+    try:
+        if comm is None:
+            raise RuntimeError(why)
+        ok = min(x[0] for x in comm.allgather_f64([ok]))
+    except Exception as e:  # noqa: BLE001
+        ok, why = 0.0, why or f"{type(e).__name__}: {e}"
+    if ok != 1.0:
+        raise IpcUnavailable(why or "a peer rank failed the communicator self-check")
+    return comm, h, link
+
+
 def bench_main(args):
     """bench.py --gpus N: strong scaling of the SAME RMAT graph over N ranks.  Launched under torch.distributed.run (RANK / WORLD_SIZE /
     LOCAL_RANK / MASTER_PORT from the environment); no process group is created -- the session name of the communicator comes from
@@ -23,8 +59,7 @@ def bench_main(args):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     session = f"bench_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}"
-    comm = Comm(session, rank, world)
-    h = ResourceHandle(comm)
+    comm, h, link = _bring_up(Comm, ResourceHandle, session, rank, world)
     if args.hot_tile is not None:
         h.set_pagerank_hot_tile(args.hot_tile)
     nv, ne = 1 << args.scale, args.edge_factor << args.scale
@@ -83,7 +118,8 @@ def bench_main(args):
                                    "partition in global degree order, x pushed into the peers' gather windows over xGMI (HIP IPC), scalars in a [P][4] window, "
                                    "one signal per iteration, iteration loop inside the library",
                        "vertices": nv, "edges": ne, "parallelism": f"{world} GPUs, 1 process per GPU", "layout": "1d", "transport": "ipc",
-                       "backend": "cugraph_amd communicator (HIP IPC peer writes)", "all_ranks_on_one_gpu": single},
+                       "backend": "cugraph_amd communicator (HIP IPC peer writes)", "all_ranks_on_one_gpu": single,
+                       "link_selftest": link},
             "iters_per_sec": round(args.steps / dt, 2), "graph_build_s": round(build_s, 3), "plan_build_s": round(plan_s, 3),
             "check": check,
             "phase_split_ms": {"phase1": round(p1m, 4), "phase2": round(p2m, 4), "exchange_and_gaps": round(ms_iter - p1m - p2m, 4),
