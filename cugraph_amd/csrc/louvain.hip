@@ -353,6 +353,99 @@ __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
     }
   }
 }
+// Round 4: rows of LVH_B < degree <= LVM_MAX edges ("mid rows": a quarter of the edges of RMAT-22 that used to take the sorted path with
+// the hubs): ONE workgroup per row, the row's (cluster -> weight) sums in an LDS open-addressing table keyed by the cluster alone (at most
+// degree distinct keys in a table of at least twice as many slots), fixed-point integer atomics -- the same integers whatever the order --,
+// then the table's slots are walked once: gain per occupied slot with the same expression and the same operands as the other two paths,
+// maximum gain and smallest cluster among the maxima reduced over the workgroup.  One pass over (destination, weight, cluster) per edge.
+constexpr int LVM_MAX = 4096, LVM_THREADS = 512;
+struct lv_mid_args {
+  int32_t const* rows; int32_t n_rows;  // vertices with LVH_B < degree <= max_deg of this launch, any order
+  int32_t const* dst; int32_t const* off; double const* w; int32_t const* c; double const* k; double const* a;
+  double m, resolution, scale, inv_scale;
+  unsigned long long* best_bits; int32_t* best_c;
+};
+template <int SLOTS>
+__global__ void __launch_bounds__(LVM_THREADS) k_lv_hash_rows(lv_mid_args A)
+{
+  extern __shared__ unsigned long long lvm_smem[];
+  unsigned long long* const s_sum = lvm_smem;                                  // [SLOTS]
+  uint32_t* const s_key           = reinterpret_cast<uint32_t*>(s_sum + SLOTS);  // [SLOTS]
+  __shared__ unsigned long long s_sub, s_red_bits[LVM_THREADS / 64];
+  __shared__ int32_t s_red_c[LVM_THREADS / 64];
+  int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto slot_of = [](uint32_t cl) { return ((cl * 0x9E3779B1u) ^ (cl >> 15)) & (uint32_t)(SLOTS - 1); };
+  for (int r = blockIdx.x; r < A.n_rows; r += gridDim.x) {
+    int32_t const v = A.rows[r];
+    int32_t const b = A.off[v], d = A.off[v + 1] - b;
+    for (int i = tid; i < SLOTS; i += LVM_THREADS) { s_key[i] = 0xFFFFFFFFu; s_sum[i] = 0; }
+    if (tid == 0) s_sub = 0;
+    __syncthreads();
+    unsigned long long sub = 0;
+    for (int i = tid; i < d; i += LVM_THREADS) {
+      int32_t const u   = A.dst[b + i];
+      uint32_t const cl = (uint32_t)A.c[u];
+      unsigned long long const wf = (unsigned long long)__double2ll_rn(A.w[b + i] * A.scale);
+      uint32_t slot = slot_of(cl);
+      for (;;) {
+        uint32_t const old = atomicCAS(&s_key[slot], 0xFFFFFFFFu, cl);
+        if (old == 0xFFFFFFFFu || old == cl) break;
+        slot = (slot + 1) & (uint32_t)(SLOTS - 1);
+      }
+      atomicAdd(&s_sum[slot], wf);
+      if (u == v) sub += wf;
+    }
+    if (sub) atomicAdd(&s_sub, sub);
+    __syncthreads();
+    int32_t const cv = A.c[v];
+    unsigned long long self = 0;
+    {
+      uint32_t slot = slot_of((uint32_t)cv);
+      for (;;) {
+        uint32_t const k2 = s_key[slot];
+        if (k2 == (uint32_t)cv) { self = s_sum[slot]; break; }
+        if (k2 == 0xFFFFFFFFu) break;
+        slot = (slot + 1) & (uint32_t)(SLOTS - 1);
+      }
+    }
+    unsigned long long const subf = s_sub;
+    double const sub_d = (double)(long long)subf * A.inv_scale, old_sum = (double)(long long)(self - subf) * A.inv_scale;
+    double const a_old = A.a[cv], kk = A.k[v];
+    unsigned long long best = 0;
+    int32_t best_c = 0x7f7f7f7f;
+    for (int i = tid; i < SLOTS; i += LVM_THREADS) {
+      uint32_t const cl = s_key[i];
+      if (cl == 0xFFFFFFFFu) continue;
+      double const sd      = (double)(long long)s_sum[i] * A.inv_scale;
+      double const new_sum = (int32_t)cl == cv ? sd - sub_d : sd;
+      double const delta   = lv_delta(new_sum, old_sum, A.a[cl], a_old, kk, A.m, A.resolution);
+      unsigned long long const bits = delta > 0.0 ? (unsigned long long)__double_as_longlong(delta) : 0ull;
+      if (bits > best || (bits == best && bits && (int32_t)cl < best_c)) { best = bits; best_c = (int32_t)cl; }
+    }
+    for (int o = 32; o; o >>= 1) {
+      unsigned long long const ob = __shfl_xor(best, o);
+      int32_t const oc            = __shfl_xor(best_c, o);
+      if (ob > best || (ob == best && oc < best_c)) { best = ob; best_c = oc; }
+    }
+    if (lane == 0) { s_red_bits[wave] = best; s_red_c[wave] = best_c; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int k2 = 1; k2 < LVM_THREADS / 64; ++k2)
+        if (s_red_bits[k2] > best || (s_red_bits[k2] == best && s_red_c[k2] < best_c)) { best = s_red_bits[k2]; best_c = s_red_c[k2]; }
+      A.best_bits[v] = best;
+      A.best_c[v]    = best ? best_c : 0x7f7f7f7f;
+    }
+    __syncthreads();
+  }
+}
+__global__ void k_lv_mid_rows(int32_t const* off, int64_t nv, int lo, int hi, int32_t* rows, uint32_t* count)
+{
+  LV_LOOP(v, nv)
+  {
+    int32_t const d = off[v + 1] - off[v];
+    if (d > lo && d <= hi) rows[atomicAdd(count, 1u)] = (int32_t)v;
+  }
+}
 // OPT-IN (CUGRAPH_AMD_LOUVAIN_HUB=hash; the default keeps the sorted path for hubs, see run_level): hub rows (more than LVH_B
 // edges -- 36 % of the edges of RMAT-22, 56 % of RMAT-26) WITHOUT sorting either: their edges are
 // compacted once per level (hub list, grouped by row); row v with deg edges owns the table region [2 * first, 2 * first + 2 * deg)
@@ -449,9 +542,9 @@ __global__ void k_lv_hub_eval(lv_hub_args A)
   }
 }
 // hub rows (more than LVH_B edges): their edges, compacted once per level, go through the sorted path
-__global__ void k_lv_hub_flags(int32_t const* src, int32_t const* off, int64_t ne, uint32_t* flag)
+__global__ void k_lv_hub_flags(int32_t const* src, int32_t const* off, int64_t ne, int32_t longer_than, uint32_t* flag)
 {
-  LV_LOOP(e, ne) { int32_t const v = src[e]; flag[e] = (off[v + 1] - off[v] > LVH_B) ? 1u : 0u; }
+  LV_LOOP(e, ne) { int32_t const v = src[e]; flag[e] = (off[v + 1] - off[v] > longer_than) ? 1u : 0u; }
 }
 __global__ void k_lv_hub_compact(int32_t const* src, int32_t const* dst, double const* w, int32_t const* off, uint32_t const* flag, uint32_t const* pos, int64_t ne,
                                  int32_t* hs, int32_t* hd, double* hw, uint32_t* hrow0)
@@ -729,11 +822,26 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   level_t Lh;  // the hub rows' edges (use_hash) -- src / dst / w only
   dvec<uint32_t> hrow0;  // position in the hub list of the first edge of every hub edge's row
   int64_t n_sorted = ne;
+  // rows of LVH_B < degree <= LVM_MAX edges: one workgroup per row (k_lv_hash_rows; two table sizes).  CUGRAPH_AMD_LOUVAIN_MID=0: they
+  // stay with the hubs (round 3's behaviour)
+  bool const use_mid = use_hash && !(getenv("CUGRAPH_AMD_LOUVAIN_MID") && atoi(getenv("CUGRAPH_AMD_LOUVAIN_MID")) == 0);
+  dvec<int32_t> mid_rows[2];
+  dvec<uint32_t> mid_count(2);
+  uint32_t n_mid[2] = {0, 0};
   if (use_hash) {
     dvec<uint32_t> flag((size_t)ne + 1), pos((size_t)ne + 1);
-    hipLaunchKernelGGL(k_lv_hub_flags, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.off.data(), ne, flag.data());
+    hipLaunchKernelGGL(k_lv_hub_flags, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.off.data(), ne, (int32_t)(use_mid ? LVM_MAX : LVH_B),
+                       flag.data());
     HIP_TRY(hipMemsetAsync(flag.data() + ne, 0, sizeof(uint32_t), h.stream));
     exclusive_scan_u32(h, flag.data(), pos.data(), ne + 1);
+    if (use_mid) {
+      size_t const cap = (size_t)(ne / LVH_B + 2);  // rows of more than LVH_B edges
+      mid_rows[0].resize_discard(cap); mid_rows[1].resize_discard(cap);
+      HIP_TRY(hipMemsetAsync(mid_count.data(), 0, 2 * sizeof(uint32_t), h.stream));
+      hipLaunchKernelGGL(k_lv_mid_rows, g_v, kBlock, 0, h.stream, (int32_t const*)L.off.data(), nv, LVH_B, LVM_MAX / 2, mid_rows[0].data(), mid_count.data());
+      hipLaunchKernelGGL(k_lv_mid_rows, g_v, kBlock, 0, h.stream, (int32_t const*)L.off.data(), nv, LVM_MAX / 2, LVM_MAX, mid_rows[1].data(), mid_count.data() + 1);
+      h.read_back(n_mid, mid_count.data(), 2);
+    }
     uint32_t nh = 0;
     h.read_back(&nh, pos.data() + ne, 1);
     n_sorted = nh;
@@ -823,6 +931,23 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
       lv_hash_args HA{L.src.data(), L.dst.data(), L.off.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, ne,
                       vfix.data() + 2 * nv, best_c.data()};
       hipLaunchKernelGGL(k_lv_hash_chunks, (int)((ne + LVH_B - 1) / LVH_B), LVH_THREADS, 0, h.stream, HA);
+    }
+    if (n_mid[0] + n_mid[1] > 0) {
+      static bool attr_done = false;
+      if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_lv_hash_rows<LVM_MAX * 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LVM_MAX * 2 * 12));
+        attr_done = true;
+      }
+      lv_mid_args MA{nullptr, 0, L.dst.data(), L.off.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale,
+                     vfix.data() + 2 * nv, best_c.data()};
+      if (n_mid[0]) {
+        MA.rows = mid_rows[0].data(); MA.n_rows = (int32_t)n_mid[0];
+        hipLaunchKernelGGL(k_lv_hash_rows<LVM_MAX>, (int)std::min<uint32_t>(n_mid[0], (uint32_t)h.num_cus * 12), LVM_THREADS, LVM_MAX * 12, h.stream, MA);
+      }
+      if (n_mid[1]) {
+        MA.rows = mid_rows[1].data(); MA.n_rows = (int32_t)n_mid[1];
+        hipLaunchKernelGGL(k_lv_hash_rows<LVM_MAX * 2>, (int)std::min<uint32_t>(n_mid[1], (uint32_t)h.num_cus * 8), LVM_THREADS, LVM_MAX * 2 * 12, h.stream, MA);
+      }
     }
     hipLaunchKernelGGL(k_best_finalize, g_v, kBlock, 0, h.stream, (unsigned long long const*)(vfix.data() + 2 * nv), best_c.data(), best_d.data(), nv);
     HIP_TRY(hipMemsetAsync(count.data(), 0, 2 * sizeof(uint32_t), h.stream));
