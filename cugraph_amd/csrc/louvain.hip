@@ -252,7 +252,10 @@ __global__ void k_segment_best(lv_flat_args A)
 // (common_methods.cuh:70-125) and the row's maximum / smallest cluster among the maxima are reduced in LDS.  One pass over
 // (destination, weight, cluster of destination) per edge instead of key construction + 6 radix passes + three segment passes.
 // The row slot of a vertex is the position of its first edge relative to the window (unique per non-empty row, < LVH_B).
-constexpr int LVH_B = 512, LVH_CAP = 2 * LVH_B, LVH_SLOTS = 2048, LVH_THREADS = 256;
+#ifndef LVH_THREADS_N
+#define LVH_THREADS_N 1024  // 256 -> 1024 threads per workgroup (two workgroups of 56 KB LDS per CU either way): 0.0844 -> 0.078 s at RMAT-22 (round 4)
+#endif
+constexpr int LVH_B = 512, LVH_CAP = 2 * LVH_B, LVH_SLOTS = 2048, LVH_THREADS = LVH_THREADS_N;
 constexpr unsigned long long LVH_EMPTY = ~0ull;
 struct lv_hash_args {
   int32_t const* src; int32_t const* dst; int32_t const* off; double const* w; int32_t const* c; double const* k; double const* a;
@@ -438,6 +441,144 @@ __global__ void __launch_bounds__(LVM_THREADS) k_lv_hash_rows(lv_mid_args A)
     __syncthreads();
   }
 }
+// Rows of more than LVM_MAX edges ("big rows"): R = ceil(degree / LVB_SHARE) work items per row; item r scans the WHOLE row and keeps the
+// clusters whose range hash is r (a 1 / R share of the distinct clusters: <= LVB_SHARE expected in a table of LVB_SLOTS), so the table of
+// a row of any length lives in LDS, at the price of reading the row R times (the items of a row run next to each other: the re-reads are
+// L2 hits; 2.3 x the big rows' edges at RMAT-22).  Every item also accumulates the row's self-loop weight and the weight into the row's
+// own cluster while it scans (each item needs both for the gains).  An item reduces its slots to (best gain, smallest cluster among
+// them), raises best_bits[v] with an atomic maximum and keeps its pair; k_lv_big_ties then lets the items whose gain IS the row's maximum
+// lower best_c[v] -- the same maximum and the same tie rule as the sorted path's k_segment_best<0/1>.
+// A table that fills up (keys that defeat the range hash) raises *overflow and the item gives up: the caller repeats the sweep's
+// evaluation with the sorted path for these rows.
+#ifndef LVB_SLOTS_N
+#define LVB_SLOTS_N 8192
+#endif
+#ifndef LVB_THREADS_N
+#define LVB_THREADS_N 512
+#endif
+constexpr int LVB_SLOTS = LVB_SLOTS_N, LVB_SHARE = LVB_SLOTS * 3 / 8, LVB_THREADS = LVB_THREADS_N;
+struct lv_big_args {
+  int4 const* items; int32_t n_items;  // (row, r, R, position of the row's first edge in the big rows' edge list)
+  uint32_t const* ecl; unsigned long long const* ewf;  // per edge of that list: cluster of the destination (this sweep), fixed-point weight (this level)
+  unsigned long long const* rowsub;                    // [nv] self-loop weight of a row (this level)
+  int32_t const* off; int32_t const* c; double const* k; double const* a;
+  double m, resolution, scale, inv_scale;
+  unsigned long long* best_bits; int32_t* best_c;
+  unsigned long long* item_bits; int32_t* item_c;  // [n_items]
+  uint32_t* overflow;
+  uint32_t max_used;  // slots an item may occupy (an eighth stays free: probes stay short)
+};
+__device__ __forceinline__ uint32_t lvb_range(uint32_t cl, uint32_t R) { return (uint32_t)(((unsigned long long)(cl * 0x85EBCA6Bu + 0x27D4EB2Fu) * R) >> 32); }
+__global__ void __launch_bounds__(LVB_THREADS) k_lv_hash_big(lv_big_args A)
+{
+  extern __shared__ unsigned long long lvm_smem[];
+  unsigned long long* const s_sum = lvm_smem;                                      // [LVB_SLOTS]
+  uint32_t* const s_key           = reinterpret_cast<uint32_t*>(s_sum + LVB_SLOTS);  // [LVB_SLOTS]
+  __shared__ unsigned long long s_self, s_red_bits[LVB_THREADS / 64];
+  __shared__ int32_t s_red_c[LVB_THREADS / 64];
+  __shared__ uint32_t s_used, s_full;
+  int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto slot_of = [](uint32_t cl) { return ((cl * 0x9E3779B1u) ^ (cl >> 15)) & (uint32_t)(LVB_SLOTS - 1); };
+  for (int it = blockIdx.x; it < A.n_items; it += gridDim.x) {
+    int4 const item = A.items[it];
+    int32_t const v = item.x;
+    uint32_t const r = (uint32_t)item.y, R = (uint32_t)item.z;
+    int32_t const d = A.off[v + 1] - A.off[v];
+    for (int i = tid; i < LVB_SLOTS; i += LVB_THREADS) { s_key[i] = 0xFFFFFFFFu; s_sum[i] = 0; }
+    if (tid == 0) { s_self = 0; s_used = 0; s_full = 0; }
+    __syncthreads();
+    int32_t const cv = A.c[v];
+    unsigned long long self = 0;
+    uint32_t const* const ecl           = A.ecl + (uint32_t)item.w;
+    unsigned long long const* const ewf = A.ewf + (uint32_t)item.w;
+    for (int i = tid; i < d; i += LVB_THREADS) {
+      uint32_t const cl           = ecl[i];
+      unsigned long long const wf = ewf[i];
+      if ((int32_t)cl == cv) self += wf;
+      if (lvb_range(cl, R) != r) continue;
+      uint32_t slot = slot_of(cl);
+      bool placed   = false;
+      for (int probes = 0; probes < LVB_SLOTS; ++probes) {
+        uint32_t const old = atomicCAS(&s_key[slot], 0xFFFFFFFFu, cl);
+        if (old == 0xFFFFFFFFu) { placed = atomicAdd(&s_used, 1u) < A.max_used; if (!placed) s_full = 1; break; }
+        if (old == cl) { placed = true; break; }
+        if (*(volatile uint32_t*)&s_full) break;
+        slot = (slot + 1) & (uint32_t)(LVB_SLOTS - 1);
+      }
+      if (placed) atomicAdd(&s_sum[slot], wf);
+      else s_full = 1;
+    }
+    if (self) atomicAdd(&s_self, self);
+    __syncthreads();
+    if (s_full) {  // (uniform: read after the barrier)
+      if (tid == 0) { atomicOr(A.overflow, 1u); A.item_bits[it] = 0; A.item_c[it] = 0x7f7f7f7f; }
+      __syncthreads();
+      continue;
+    }
+    unsigned long long const subf = A.rowsub[v], selff = s_self;
+    double const sub_d = (double)(long long)subf * A.inv_scale, old_sum = (double)(long long)(selff - subf) * A.inv_scale;
+    double const a_old = A.a[cv], kk = A.k[v];
+    unsigned long long best = 0;
+    int32_t best_c = 0x7f7f7f7f;
+    for (int i = tid; i < LVB_SLOTS; i += LVB_THREADS) {
+      uint32_t const cl = s_key[i];
+      if (cl == 0xFFFFFFFFu) continue;
+      double const sd      = (double)(long long)s_sum[i] * A.inv_scale;
+      double const new_sum = (int32_t)cl == cv ? sd - sub_d : sd;
+      double const delta   = lv_delta(new_sum, old_sum, A.a[cl], a_old, kk, A.m, A.resolution);
+      unsigned long long const bits = delta > 0.0 ? (unsigned long long)__double_as_longlong(delta) : 0ull;
+      if (bits > best || (bits == best && bits && (int32_t)cl < best_c)) { best = bits; best_c = (int32_t)cl; }
+    }
+    for (int o = 32; o; o >>= 1) {
+      unsigned long long const ob = __shfl_xor(best, o);
+      int32_t const oc            = __shfl_xor(best_c, o);
+      if (ob > best || (ob == best && oc < best_c)) { best = ob; best_c = oc; }
+    }
+    if (lane == 0) { s_red_bits[wave] = best; s_red_c[wave] = best_c; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int k2 = 1; k2 < LVB_THREADS / 64; ++k2)
+        if (s_red_bits[k2] > best || (s_red_bits[k2] == best && s_red_c[k2] < best_c)) { best = s_red_bits[k2]; best_c = s_red_c[k2]; }
+      A.item_bits[it] = best;
+      A.item_c[it]    = best ? best_c : 0x7f7f7f7f;
+      if (best) atomicMax(&A.best_bits[v], best);
+    }
+    __syncthreads();
+  }
+}
+__global__ void k_lv_big_ties(lv_big_args A)
+{
+  LV_LOOP(i, (int64_t)A.n_items)
+  {
+    unsigned long long const bits = A.item_bits[i];
+    int32_t const v = A.items[i].x;
+    if (bits && bits == A.best_bits[v]) atomicMin(&A.best_c[v], A.item_c[i]);
+  }
+}
+__global__ void k_lv_big_items(int32_t const* off, uint32_t const* pos, int64_t nv, int longer_than, int4* items, uint32_t* count)
+{
+  LV_LOOP(v, nv)
+  {
+    int32_t const d = off[v + 1] - off[v];
+    if (d > longer_than) {
+      int32_t const R   = (d + LVB_SHARE - 1) / LVB_SHARE;
+      uint32_t const at = atomicAdd(count, (uint32_t)R);
+      for (int32_t r = 0; r < R; ++r) items[at + r] = make_int4((int32_t)v, r, R, (int32_t)pos[off[v]]);
+    }
+  }
+}
+// once per level: fixed-point weights of the big rows' edges, self-loop weight per row
+__global__ void k_lv_big_prep(int32_t const* hs, int32_t const* hd, double const* hw, int64_t n, double scale, unsigned long long* ewf, unsigned long long* rowsub)
+{
+  LV_LOOP(q, n)
+  {
+    unsigned long long const wf = (unsigned long long)__double2ll_rn(hw[q] * scale);
+    ewf[q] = wf;
+    if (hs[q] == hd[q]) atomicAdd(&rowsub[hs[q]], wf);
+  }
+}
+// once per sweep: the cluster of every big-row edge's destination (the items of a row then re-read 12 sequential bytes per edge)
+__global__ void k_lv_big_gather(int32_t const* hd, int32_t const* c, int64_t n, uint32_t* ecl) { LV_LOOP(q, n) ecl[q] = (uint32_t)c[hd[q]]; }
 __global__ void k_lv_mid_rows(int32_t const* off, int64_t nv, int lo, int hi, int32_t* rows, uint32_t* count)
 {
   LV_LOOP(v, nv)
@@ -825,9 +966,15 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   // rows of LVH_B < degree <= LVM_MAX edges: one workgroup per row (k_lv_hash_rows; two table sizes).  CUGRAPH_AMD_LOUVAIN_MID=0: they
   // stay with the hubs (round 3's behaviour)
   bool const use_mid = use_hash && !(getenv("CUGRAPH_AMD_LOUVAIN_MID") && atoi(getenv("CUGRAPH_AMD_LOUVAIN_MID")) == 0);
+  // rows of more than LVM_MAX edges: LDS tables too, several work items per row (k_lv_hash_big); CUGRAPH_AMD_LOUVAIN_BIG=0: sorted path
+  bool const use_big = use_mid && !(getenv("CUGRAPH_AMD_LOUVAIN_BIG") && atoi(getenv("CUGRAPH_AMD_LOUVAIN_BIG")) == 0);
   dvec<int32_t> mid_rows[2];
-  dvec<uint32_t> mid_count(2);
-  uint32_t n_mid[2] = {0, 0};
+  dvec<uint32_t> mid_count(3);
+  uint32_t n_mid[3] = {0, 0, 0};  // [2] = work items of the big rows
+  dvec<int4> big_items;
+  dvec<unsigned long long> big_bits, big_ewf, big_rowsub;
+  dvec<uint32_t> big_ecl;
+  dvec<int32_t> big_c;
   if (use_hash) {
     dvec<uint32_t> flag((size_t)ne + 1), pos((size_t)ne + 1);
     hipLaunchKernelGGL(k_lv_hub_flags, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.off.data(), ne, (int32_t)(use_mid ? LVM_MAX : LVH_B),
@@ -837,10 +984,16 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     if (use_mid) {
       size_t const cap = (size_t)(ne / LVH_B + 2);  // rows of more than LVH_B edges
       mid_rows[0].resize_discard(cap); mid_rows[1].resize_discard(cap);
-      HIP_TRY(hipMemsetAsync(mid_count.data(), 0, 2 * sizeof(uint32_t), h.stream));
+      HIP_TRY(hipMemsetAsync(mid_count.data(), 0, 3 * sizeof(uint32_t), h.stream));
       hipLaunchKernelGGL(k_lv_mid_rows, g_v, kBlock, 0, h.stream, (int32_t const*)L.off.data(), nv, LVH_B, LVM_MAX / 2, mid_rows[0].data(), mid_count.data());
       hipLaunchKernelGGL(k_lv_mid_rows, g_v, kBlock, 0, h.stream, (int32_t const*)L.off.data(), nv, LVM_MAX / 2, LVM_MAX, mid_rows[1].data(), mid_count.data() + 1);
-      h.read_back(n_mid, mid_count.data(), 2);
+      if (use_big) {
+        big_items.resize_discard((size_t)(ne / LVB_SHARE + ne / LVM_MAX + 2));  // sum over the big rows of ceil(degree / LVB_SHARE)
+        hipLaunchKernelGGL(k_lv_big_items, g_v, kBlock, 0, h.stream, (int32_t const*)L.off.data(), (uint32_t const*)pos.data(), nv, LVM_MAX, big_items.data(),
+                           mid_count.data() + 2);
+      }
+      h.read_back(n_mid, mid_count.data(), 3);
+      if (n_mid[2]) { big_bits.resize_discard(n_mid[2]); big_c.resize_discard(n_mid[2]); }
     }
     uint32_t nh = 0;
     h.read_back(&nh, pos.data() + ne, 1);
@@ -864,8 +1017,17 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   int32_t const* const s_dst = use_hash ? Lh.dst.data() : L.dst.data();
   double const* const s_w    = use_hash ? Lh.w.data() : L.w.data();
   int const g_s = grid_for(n_sorted, kBlock, 8192);
-  size_t const n_keys = (size_t)std::max<int64_t>(hub_hash ? 1 : n_sorted, 1);  // buffers of the sorted path
-  dvec<uint32_t> count(2), eperm(n_keys);
+  bool big_hash = use_big && !hub_hash && n_mid[2] > 0;  // (cleared for the rest of the level if a table ever fills up)
+  if (big_hash) {
+    big_ewf.resize_discard((size_t)n_sorted); big_ecl.resize_discard((size_t)n_sorted); big_rowsub.resize_discard((size_t)nv);
+    HIP_TRY(hipMemsetAsync(big_rowsub.data(), 0, (size_t)nv * sizeof(unsigned long long), h.stream));
+    hipLaunchKernelGGL(k_lv_big_prep, grid_for(n_sorted, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)Lh.src.data(), (int32_t const*)Lh.dst.data(),
+                       (double const*)Lh.w.data(), n_sorted, scale, big_ewf.data(), big_rowsub.data());
+  }
+  // CUGRAPH_AMD_LOUVAIN_BIG_SLOTS=n (tests): an item gives up after n distinct clusters -- exercises the fall-back to the sorted path
+  uint32_t const big_max_used = getenv("CUGRAPH_AMD_LOUVAIN_BIG_SLOTS") ? (uint32_t)std::max(1, atoi(getenv("CUGRAPH_AMD_LOUVAIN_BIG_SLOTS"))) : (uint32_t)(LVB_SLOTS - LVB_SLOTS / 8);
+  size_t const n_keys = (size_t)std::max<int64_t>((hub_hash || big_hash) ? 1 : n_sorted, 1);  // buffers of the sorted path
+  dvec<uint32_t> count(3), eperm(n_keys);  // count[2] = a big row's table filled up
   dvec<uint64_t> ekeys(n_keys);
   segfix.resize_discard(n_keys);
   accepted.resize_discard((size_t)nv);
@@ -900,61 +1062,80 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     ++st.sweeps;
     ++st.sweeps_in_level;
     // update_clustering_by_delta_modularity (common_methods.cuh:259-447)
-    if (n_sorted > 0 && !hub_hash) {
-      hipLaunchKernelGGL(k_pair_keys, g_s, kBlock, 0, h.stream, s_src, (int32_t const*)nullptr, s_dst, (int32_t const*)c.data(), n_sorted, vb, ekeys.data(),
-                         eperm.data());
-      // first sweep of a level: every vertex is its own cluster, so the key is (source, destination) -- the order the level's
-      // edges are stored in (CSR order / the contraction's output): nothing to sort
-      if (st.sweeps_in_level > 1) sort_pairs(h, ekeys, eperm, n_sorted, 2 * vb);
-    }
-    HIP_TRY(hipMemsetAsync(vfix.data(), 0, (size_t)nv * 3 * sizeof(unsigned long long), h.stream));  // selffix, subfix, best_bits
-    HIP_TRY(hipMemsetAsync(best_c.data(), 0x7f, (size_t)nv * sizeof(int32_t), h.stream));
-    if (hub_hash) {
-      HIP_TRY(hipMemsetAsync(hub_keys.data(), 0xFF, (size_t)2 * n_sorted * sizeof(unsigned long long), h.stream));
-      HIP_TRY(hipMemsetAsync(hub_sums.data(), 0, (size_t)2 * n_sorted * sizeof(unsigned long long), h.stream));
-      lv_hub_args HB{s_src, s_dst, s_w, hrow0.data(), L.off.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, n_sorted,
-                     hub_keys.data(), hub_sums.data(), vfix.data(), vfix.data() + nv, vfix.data() + 2 * nv, best_c.data()};
-      int const g_t = grid_for(2 * n_sorted, kBlock, 16384);
-      hipLaunchKernelGGL(k_lv_hub_insert, g_s, kBlock, 0, h.stream, HB);
-      hipLaunchKernelGGL(k_lv_hub_eval<0>, g_t, kBlock, 0, h.stream, HB);
-      hipLaunchKernelGGL(k_lv_hub_eval<1>, g_t, kBlock, 0, h.stream, HB);
-    }
-    if (n_sorted > 0 && !hub_hash) {
-      HIP_TRY(hipMemsetAsync(segfix.data(), 0, (size_t)n_sorted * sizeof(unsigned long long), h.stream));
-      lv_flat_args A{ekeys.data(), eperm.data(), s_dst, s_w, c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, n_sorted, vb,
-                     segfix.data(), vfix.data(), vfix.data() + nv, vfix.data() + 2 * nv, best_c.data()};
-      hipLaunchKernelGGL(k_segment_sums, g_s, kBlock, 0, h.stream, A);
-      hipLaunchKernelGGL(k_segment_best<0>, g_s, kBlock, 0, h.stream, A);
-      hipLaunchKernelGGL(k_segment_best<1>, g_s, kBlock, 0, h.stream, A);
-    }
-    if (use_hash && n_sorted < ne) {
-      lv_hash_args HA{L.src.data(), L.dst.data(), L.off.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, ne,
-                      vfix.data() + 2 * nv, best_c.data()};
-      hipLaunchKernelGGL(k_lv_hash_chunks, (int)((ne + LVH_B - 1) / LVH_B), LVH_THREADS, 0, h.stream, HA);
-    }
-    if (n_mid[0] + n_mid[1] > 0) {
-      static bool attr_done = false;
-      if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_lv_hash_rows<LVM_MAX * 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LVM_MAX * 2 * 12));
-        attr_done = true;
+    auto evaluate = [&]() {
+      bool const sorted = n_sorted > 0 && !hub_hash && !big_hash;
+      if (sorted) {
+        hipLaunchKernelGGL(k_pair_keys, g_s, kBlock, 0, h.stream, s_src, (int32_t const*)nullptr, s_dst, (int32_t const*)c.data(), n_sorted, vb, ekeys.data(),
+                           eperm.data());
+        // first sweep of a level: every vertex is its own cluster, so the key is (source, destination) -- the order the level's
+        // edges are stored in (CSR order / the contraction's output): nothing to sort
+        if (st.sweeps_in_level > 1) sort_pairs(h, ekeys, eperm, n_sorted, 2 * vb);
       }
-      lv_mid_args MA{nullptr, 0, L.dst.data(), L.off.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale,
-                     vfix.data() + 2 * nv, best_c.data()};
-      if (n_mid[0]) {
-        MA.rows = mid_rows[0].data(); MA.n_rows = (int32_t)n_mid[0];
-        hipLaunchKernelGGL(k_lv_hash_rows<LVM_MAX>, (int)std::min<uint32_t>(n_mid[0], (uint32_t)h.num_cus * 12), LVM_THREADS, LVM_MAX * 12, h.stream, MA);
+      HIP_TRY(hipMemsetAsync(vfix.data(), 0, (size_t)nv * 3 * sizeof(unsigned long long), h.stream));  // selffix, subfix, best_bits
+      HIP_TRY(hipMemsetAsync(best_c.data(), 0x7f, (size_t)nv * sizeof(int32_t), h.stream));
+      HIP_TRY(hipMemsetAsync(count.data(), 0, 3 * sizeof(uint32_t), h.stream));
+      if (hub_hash) {
+        HIP_TRY(hipMemsetAsync(hub_keys.data(), 0xFF, (size_t)2 * n_sorted * sizeof(unsigned long long), h.stream));
+        HIP_TRY(hipMemsetAsync(hub_sums.data(), 0, (size_t)2 * n_sorted * sizeof(unsigned long long), h.stream));
+        lv_hub_args HB{s_src, s_dst, s_w, hrow0.data(), L.off.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, n_sorted,
+                       hub_keys.data(), hub_sums.data(), vfix.data(), vfix.data() + nv, vfix.data() + 2 * nv, best_c.data()};
+        int const g_t = grid_for(2 * n_sorted, kBlock, 16384);
+        hipLaunchKernelGGL(k_lv_hub_insert, g_s, kBlock, 0, h.stream, HB);
+        hipLaunchKernelGGL(k_lv_hub_eval<0>, g_t, kBlock, 0, h.stream, HB);
+        hipLaunchKernelGGL(k_lv_hub_eval<1>, g_t, kBlock, 0, h.stream, HB);
       }
-      if (n_mid[1]) {
-        MA.rows = mid_rows[1].data(); MA.n_rows = (int32_t)n_mid[1];
-        hipLaunchKernelGGL(k_lv_hash_rows<LVM_MAX * 2>, (int)std::min<uint32_t>(n_mid[1], (uint32_t)h.num_cus * 8), LVM_THREADS, LVM_MAX * 2 * 12, h.stream, MA);
+      if (sorted) {
+        HIP_TRY(hipMemsetAsync(segfix.data(), 0, (size_t)n_sorted * sizeof(unsigned long long), h.stream));
+        lv_flat_args A{ekeys.data(), eperm.data(), s_dst, s_w, c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, n_sorted, vb,
+                       segfix.data(), vfix.data(), vfix.data() + nv, vfix.data() + 2 * nv, best_c.data()};
+        hipLaunchKernelGGL(k_segment_sums, g_s, kBlock, 0, h.stream, A);
+        hipLaunchKernelGGL(k_segment_best<0>, g_s, kBlock, 0, h.stream, A);
+        hipLaunchKernelGGL(k_segment_best<1>, g_s, kBlock, 0, h.stream, A);
       }
+      if (use_hash && n_sorted < ne) {
+        lv_hash_args HA{L.src.data(), L.dst.data(), L.off.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, ne,
+                        vfix.data() + 2 * nv, best_c.data()};
+        hipLaunchKernelGGL(k_lv_hash_chunks, (int)((ne + LVH_B - 1) / LVH_B), LVH_THREADS, 0, h.stream, HA);
+      }
+      if (n_mid[0] + n_mid[1] > 0 || big_hash) {
+        static bool attr_done = false;
+        if (!attr_done) {
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_lv_hash_rows<LVM_MAX * 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LVM_MAX * 2 * 12));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_lv_hash_big), hipFuncAttributeMaxDynamicSharedMemorySize, LVB_SLOTS * 12));
+          attr_done = true;
+        }
+        lv_mid_args MA{nullptr, 0, L.dst.data(), L.off.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale,
+                       vfix.data() + 2 * nv, best_c.data()};
+        if (n_mid[0]) {
+          MA.rows = mid_rows[0].data(); MA.n_rows = (int32_t)n_mid[0];
+          hipLaunchKernelGGL(k_lv_hash_rows<LVM_MAX>, (int)std::min<uint32_t>(n_mid[0], (uint32_t)h.num_cus * 12), LVM_THREADS, LVM_MAX * 12, h.stream, MA);
+        }
+        if (n_mid[1]) {
+          MA.rows = mid_rows[1].data(); MA.n_rows = (int32_t)n_mid[1];
+          hipLaunchKernelGGL(k_lv_hash_rows<LVM_MAX * 2>, (int)std::min<uint32_t>(n_mid[1], (uint32_t)h.num_cus * 8), LVM_THREADS, LVM_MAX * 2 * 12, h.stream, MA);
+        }
+        if (big_hash) {
+          lv_big_args BA{big_items.data(), (int32_t)n_mid[2], big_ecl.data(), big_ewf.data(), big_rowsub.data(), L.off.data(), c.data(), k.data(), a.data(), m, resolution,
+                         scale, 1.0 / scale, vfix.data() + 2 * nv, best_c.data(), big_bits.data(), big_c.data(), count.data() + 2, big_max_used};
+          hipLaunchKernelGGL(k_lv_big_gather, g_s, kBlock, 0, h.stream, s_dst, (int32_t const*)c.data(), n_sorted, big_ecl.data());
+          hipLaunchKernelGGL(k_lv_hash_big, (int)std::min<uint32_t>(n_mid[2], (uint32_t)h.num_cus * 8), LVB_THREADS, LVB_SLOTS * 12, h.stream, BA);
+          hipLaunchKernelGGL(k_lv_big_ties, grid_for((int64_t)n_mid[2], kBlock, 1024), kBlock, 0, h.stream, BA);
+        }
+      }
+      hipLaunchKernelGGL(k_best_finalize, g_v, kBlock, 0, h.stream, (unsigned long long const*)(vfix.data() + 2 * nv), best_c.data(), best_d.data(), nv);
+      hipLaunchKernelGGL(k_count_moves, (int)std::max<int64_t>(1, std::min<int64_t>((nv + 1023) / 1024, 512)), 1024, 0, h.stream, (int32_t const*)c.data(),
+                         (int32_t const*)best_c.data(), (double const*)best_d.data(), min_gain, nv, count.data());
+    };
+    evaluate();
+    uint32_t nr_moves[3] = {0, 0, 0};
+    h.read_back(nr_moves, count.data(), 3);
+    if (nr_moves[2]) {  // a big row's LDS table filled up: the sorted path takes the big rows for the rest of this level
+      big_hash = false;
+      size_t const nk = (size_t)std::max<int64_t>(n_sorted, 1);
+      eperm.resize_discard(nk); ekeys.resize_discard(nk); segfix.resize_discard(nk);
+      evaluate();
+      h.read_back(nr_moves, count.data(), 3);
     }
-    hipLaunchKernelGGL(k_best_finalize, g_v, kBlock, 0, h.stream, (unsigned long long const*)(vfix.data() + 2 * nv), best_c.data(), best_d.data(), nv);
-    HIP_TRY(hipMemsetAsync(count.data(), 0, 2 * sizeof(uint32_t), h.stream));
-    hipLaunchKernelGGL(k_count_moves, (int)std::max<int64_t>(1, std::min<int64_t>((nv + 1023) / 1024, 512)), 1024, 0, h.stream, (int32_t const*)c.data(),
-                       (int32_t const*)best_c.data(), (double const*)best_d.data(), min_gain, nv, count.data());
-    uint32_t nr_moves[2] = {0, 0};
-    h.read_back(nr_moves, count.data(), 2);
     if (mg) mg->sum_u32x2(nr_moves);
     if (nr_moves[up_down ? 1 : 0] == 0) up_down = !up_down;
     // the moves + compute_cluster_keys_and_values: cluster weights of the new clustering

@@ -1131,22 +1131,33 @@ def test_louvain_hash_path_equals_sorted_path(cg, handle, orc, monkeypatch, scal
     rng = np.random.default_rng(3)
     loops = rng.integers(0, nv, 500).astype(np.int32)           # self-loops (cluster_subtract path)
     dup = rng.integers(0, src.size, 2000)                       # repeated edges, both directions
-    src, dst = np.concatenate([src, loops, src[dup], dst[dup]]), np.concatenate([dst, loops, dst[dup], src[dup]])
+    # two stars, so that there are rows of more than 4096 edges (several LDS work items per row) at these sizes: 9 000 and 5 000 spokes
+    hub_a, hub_b = np.full(9000, 7, np.int32), np.full(5000, 11, np.int32)
+    spoke_a, spoke_b = rng.permutation(nv)[:9000].astype(np.int32), rng.permutation(nv)[:5000].astype(np.int32)
+    star_s, star_d = np.concatenate([hub_a, spoke_a, hub_b, spoke_b]), np.concatenate([spoke_a, hub_a, spoke_b, hub_b])
+    src, dst = np.concatenate([src, loops, src[dup], dst[dup], star_s]), np.concatenate([dst, loops, dst[dup], src[dup], star_d])
     wl = np.full(500, 2.0, np.float32)
-    w = np.concatenate([w, wl, w[dup], w[dup]])
+    w = np.concatenate([w, wl, w[dup], w[dup], np.full(star_s.size, 3.0, np.float32)])
     if weights == "real":
         w = (w * np.float32(0.37) + np.float32(0.25)).astype(np.float32)
     o = np.lexsort((dst, src))
     src, dst, w = src[o], dst[o], w[o]
     res = {}
-    for mode, hub in (("1", "hash"), ("1", "sort"), ("0", "sort")):  # default (LDS hash + global hub hash); hubs sorted; everything sorted
-        monkeypatch.setenv("CUGRAPH_AMD_LOUVAIN_HASH", mode)
-        monkeypatch.setenv("CUGRAPH_AMD_LOUVAIN_HUB", hub)
+    # default of round 3 (LDS hash + global hub hash); hubs sorted; everything sorted; round 4: the default (mid rows and big rows in LDS
+    # tables too), mid rows back on the sorted path, big rows back on it, and big rows whose table "fills up" after 16 clusters (the fall-back
+    # to the sorted path in the middle of a level)
+    variants = {"1hash": {"HASH": "1", "HUB": "hash"}, "1sort": {"HASH": "1", "HUB": "sort", "MID": "0"}, "0sort": {"HASH": "0", "HUB": "sort"},
+                "default": {}, "mid0": {"MID": "0"}, "big0": {"BIG": "0"}, "overflow": {"BIG_SLOTS": "16"}}
+    for name, env in variants.items():
+        for k in ("HASH", "HUB", "MID", "BIG", "BIG_SLOTS"):
+            monkeypatch.delenv("CUGRAPH_AMD_LOUVAIN_" + k, raising=False)
+        for k, val in env.items():
+            monkeypatch.setenv("CUGRAPH_AMD_LOUVAIN_" + k, val)
         g = cg.SGGraph(handle, cg.GraphProperties(is_symmetric=True, is_multigraph=True), T(src, np.int32), T(dst, np.int32), T(w, np.float32), renumber=False,
                        vertices_array=T(np.arange(nv), np.int32))
         v, c, q = cg.louvain(handle, g, 100, 1e-7, 1.0, False)
-        res[mode + hub] = (by_vertex(v, c)[0], q)
-    for k in ("1sort", "0sort"):
+        res[name] = (by_vertex(v, c)[0], q)
+    for k in res:
         assert np.array_equal(res["1hash"][0], res[k][0]) and res["1hash"][1] == res[k][1], k
     oc, oq, _, _ = orc.louvain_c(nv, src, dst, w, 100, 1e-7, 1.0)
     assert np.array_equal(res["1hash"][0], oc) and abs(res["1hash"][1] - oq) <= 1e-9
