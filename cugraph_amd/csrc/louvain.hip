@@ -248,6 +248,7 @@ __global__ void k_segment_best(lv_flat_args A)
 // through the sorted path below -- can only be the LAST row that starts in a window, so the edges of a chunk are contiguous).
 // The weight from a vertex into every neighbouring cluster is accumulated in an LDS hash table keyed by (row slot, cluster) with
 // 64-bit fixed-point integer atomics -- the same sums as the sorted path, bit for bit, whatever order the edges arrive in --,
+// (round 4 measured the gains formed per occupied slot -- per distinct pair -- instead of per edge: 0.0757 against 0.0745 s at RMAT-22, no gain;)
 // then every edge looks its (row, cluster) sum up, forms the modularity gain with the reference's expression
 // (common_methods.cuh:70-125) and the row's maximum / smallest cluster among the maxima are reduced in LDS.  One pass over
 // (destination, weight, cluster of destination) per edge instead of key construction + 6 radix passes + three segment passes.
@@ -454,7 +455,7 @@ __global__ void __launch_bounds__(LVM_THREADS) k_lv_hash_rows(lv_mid_args A)
 #define LVB_SLOTS_N 8192
 #endif
 #ifndef LVB_THREADS_N
-#define LVB_THREADS_N 512
+#define LVB_THREADS_N 1024  // one workgroup of 96 KB LDS per CU: 16 waves instead of 8 (RMAT-26 1.45 -> 1.33 s; 4096 slots x 512 threads: 1.36 s)
 #endif
 constexpr int LVB_SLOTS = LVB_SLOTS_N, LVB_SHARE = LVB_SLOTS * 3 / 8, LVB_THREADS = LVB_THREADS_N;
 struct lv_big_args {

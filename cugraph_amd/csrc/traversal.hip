@@ -1576,7 +1576,7 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   bool const pull_allowed  = !use_lh && g.ne <= kMaxSignedEdges && env_pull && std::string(env_pull) != "0";
   bool const pull_force    = pull_allowed && env_pull && std::string(env_pull) == "force";
   uint64_t const pull_min_edges = std::max<uint64_t>((uint64_t)g.ne / 10, (uint64_t)1 << 22);
-  uint64_t front_edges = 0, pull_rounds = 0;  // out-edges of the current near frontier (0 for the source: its round is a push)
+  uint64_t front_edges = 0;  // out-edges of the current near frontier (0 for the source: its round is a push)
   dvec<uint32_t> fbits;
   static bool const sssp_trace = getenv("CUGRAPH_AMD_SSSP_TRACE") != nullptr;  // per round: sizes and wall time since the previous line (stderr)
   auto t_trace = std::chrono::steady_clock::now();
@@ -1611,7 +1611,6 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
         hipLaunchKernelGGL(k_sssp_pull_big<WT>, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)ci.offsets.data(), (int32_t const*)ci.indices.data(), s,
                            (uint32_t const*)fbits.data());
       }
-      ++pull_rounds;
     } else {
       timed_launch t(h, "sssp_relax");
       hipLaunchKernelGGL(k_sssp_expand<WT>, expand_grid(h, n_front), TV_BLOCK, 0, h.stream, front, n_front, beg, end, adj, bigq.data(), s, big_deg_for(h, n_front));
