@@ -263,6 +263,7 @@ struct lv_hash_args {
   double m, resolution, scale, inv_scale; int64_t ne;
   unsigned long long* best_bits;  // [nv]
   int32_t* best_c;                // [nv]
+  unsigned long long* ifix;       // += weight of the rows' edges that stay inside their cluster (fixed point): the modularity's first term
 };
 __device__ __forceinline__ uint32_t lvh_slot(uint32_t rs, uint32_t cl) { return ((rs * 0x9E3779B1u) ^ (cl * 0x85EBCA6Bu) ^ (cl >> 15)) & (LVH_SLOTS - 1); }
 __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
@@ -274,9 +275,11 @@ __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
   __shared__ uint32_t s_cl[LVH_CAP];
   __shared__ uint16_t s_rs[LVH_CAP];
   __shared__ long long s_range[2];
+  __shared__ unsigned long long s_int;
   int const tid = threadIdx.x;
   int64_t const e_lo = blockIdx.x * (int64_t)LVH_B, e_hi = e_lo + LVH_B < A.ne ? e_lo + LVH_B : A.ne;
   if (tid == 0) {
+    s_int = 0;
     int64_t p0 = e_lo, p1 = e_lo;
     if (e_lo > 0 && A.src[e_lo - 1] == A.src[e_lo]) p0 = A.off[A.src[e_lo] + 1];  // the window opens inside a row of an earlier chunk (or a hub)
     if (p0 < e_hi) {
@@ -354,8 +357,12 @@ __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
       uint32_t const rs = s_rs[i];
       A.best_bits[v] = s_best[rs];
       A.best_c[v]    = s_best[rs] ? s_bestc[rs] : 0x7f7f7f7f;
+      unsigned long long const self = lookup(rs, (uint32_t)A.c[v]);
+      if (self) atomicAdd(&s_int, self);
     }
   }
+  __syncthreads();
+  if (tid == 0 && s_int) atomicAdd(A.ifix, s_int);
 }
 // Round 4: rows of LVH_B < degree <= LVM_MAX edges ("mid rows": a quarter of the edges of RMAT-22 that used to take the sorted path with
 // the hubs): ONE workgroup per row, the row's (cluster -> weight) sums in an LDS open-addressing table keyed by the cluster alone (at most
@@ -368,6 +375,7 @@ struct lv_mid_args {
   int32_t const* dst; int32_t const* off; double const* w; int32_t const* c; double const* k; double const* a;
   double m, resolution, scale, inv_scale;
   unsigned long long* best_bits; int32_t* best_c;
+  unsigned long long* ifix;  // += the rows' weight into their own clusters
 };
 template <int SLOTS>
 __global__ void __launch_bounds__(LVM_THREADS) k_lv_hash_rows(lv_mid_args A)
@@ -379,6 +387,7 @@ __global__ void __launch_bounds__(LVM_THREADS) k_lv_hash_rows(lv_mid_args A)
   __shared__ int32_t s_red_c[LVM_THREADS / 64];
   int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto slot_of = [](uint32_t cl) { return ((cl * 0x9E3779B1u) ^ (cl >> 15)) & (uint32_t)(SLOTS - 1); };
+  unsigned long long internal = 0;  // (the same value in every thread)
   for (int r = blockIdx.x; r < A.n_rows; r += gridDim.x) {
     int32_t const v = A.rows[r];
     int32_t const b = A.off[v], d = A.off[v + 1] - b;
@@ -412,6 +421,7 @@ __global__ void __launch_bounds__(LVM_THREADS) k_lv_hash_rows(lv_mid_args A)
         slot = (slot + 1) & (uint32_t)(SLOTS - 1);
       }
     }
+    internal += self;
     unsigned long long const subf = s_sub;
     double const sub_d = (double)(long long)subf * A.inv_scale, old_sum = (double)(long long)(self - subf) * A.inv_scale;
     double const a_old = A.a[cv], kk = A.k[v];
@@ -441,6 +451,7 @@ __global__ void __launch_bounds__(LVM_THREADS) k_lv_hash_rows(lv_mid_args A)
     }
     __syncthreads();
   }
+  if (tid == 0 && internal) atomicAdd(A.ifix, internal);
 }
 // Rows of more than LVM_MAX edges ("big rows"): R = ceil(degree / LVB_SHARE) work items per row; item r scans the WHOLE row and keeps the
 // clusters whose range hash is r (a 1 / R share of the distinct clusters: <= LVB_SHARE expected in a table of LVB_SLOTS), so the table of
@@ -467,6 +478,7 @@ struct lv_big_args {
   unsigned long long* best_bits; int32_t* best_c;
   unsigned long long* item_bits; int32_t* item_c;  // [n_items]
   uint32_t* overflow;
+  unsigned long long* ifix;  // += the rows' weight into their own clusters (by a row's first item)
   uint32_t max_used;  // slots an item may occupy (an eighth stays free: probes stay short)
 };
 __device__ __forceinline__ uint32_t lvb_range(uint32_t cl, uint32_t R) { return (uint32_t)(((unsigned long long)(cl * 0x85EBCA6Bu + 0x27D4EB2Fu) * R) >> 32); }
@@ -517,6 +529,7 @@ __global__ void __launch_bounds__(LVB_THREADS) k_lv_hash_big(lv_big_args A)
       continue;
     }
     unsigned long long const subf = A.rowsub[v], selff = s_self;
+    if (r == 0 && tid == 0 && selff) atomicAdd(A.ifix, selff);
     double const sub_d = (double)(long long)subf * A.inv_scale, old_sum = (double)(long long)(selff - subf) * A.inv_scale;
     double const a_old = A.a[cv], kk = A.k[v];
     unsigned long long best = 0;
@@ -754,12 +767,18 @@ __device__ __forceinline__ void lv_block_fold(double s, double* out)
   for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) *out = red[0];
 }
-__global__ void __launch_bounds__(1024) k_part_internal(int32_t const* src, int32_t const* dst, double const* w, int32_t const* c, int64_t ne, double* part)
+// sum of an array of fixed-point values into *out (the sorted / global-table paths leave the rows' own-cluster weights in selffix[])
+__global__ void __launch_bounds__(1024) k_lv_sum_u64(unsigned long long const* x, int64_t n, unsigned long long* out)
 {
-  int64_t const b = (int64_t)blockIdx.x * LV_RCHUNK, e = b + LV_RCHUNK < ne ? b + LV_RCHUNK : ne;
-  double s = 0.0;
-  for (int64_t i = b + threadIdx.x; i < e; i += 1024) s += c[src[i]] == c[dst[i]] ? w[i] : 0.0;
-  lv_block_fold(s, part + blockIdx.x);
+  __shared__ unsigned long long s_acc;
+  if (threadIdx.x == 0) s_acc = 0;
+  __syncthreads();
+  unsigned long long s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) s += x[i];
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(&s_acc, s);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_acc) atomicAdd(out, s_acc);
 }
 __global__ void __launch_bounds__(1024) k_part_squares(double const* a, int64_t n, double* part)
 {
@@ -857,6 +876,14 @@ struct lv_mg_t {
     double s = 0.0;
     for (double y : all) s += y;  // rank order
     return s;
+  }
+  unsigned long long sum_u64(unsigned long long x)
+  {
+    std::vector<unsigned long long> all(P);
+    c->host_allgather(&x, sizeof(x), all.data());
+    unsigned long long t = 0;
+    for (auto y : all) t += y;
+    return t;
   }
   void sum_u32x2(uint32_t* v)
   {
@@ -1028,7 +1055,7 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   // CUGRAPH_AMD_LOUVAIN_BIG_SLOTS=n (tests): an item gives up after n distinct clusters -- exercises the fall-back to the sorted path
   uint32_t const big_max_used = getenv("CUGRAPH_AMD_LOUVAIN_BIG_SLOTS") ? (uint32_t)std::max(1, atoi(getenv("CUGRAPH_AMD_LOUVAIN_BIG_SLOTS"))) : (uint32_t)(LVB_SLOTS - LVB_SLOTS / 8);
   size_t const n_keys = (size_t)std::max<int64_t>((hub_hash || big_hash) ? 1 : n_sorted, 1);  // buffers of the sorted path
-  dvec<uint32_t> count(3), eperm(n_keys);  // count[2] = a big row's table filled up
+  dvec<uint32_t> eperm(n_keys);
   dvec<uint64_t> ekeys(n_keys);
   segfix.resize_discard(n_keys);
   accepted.resize_discard((size_t)nv);
@@ -1042,103 +1069,119 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   HIP_TRY(hipMemcpyAsync(afix.data(), kfix.data(), nv * sizeof(long long), hipMemcpyDeviceToDevice, h.stream));
   hipLaunchKernelGGL(k_fix_to_double, g_v, kBlock, 0, h.stream, (unsigned long long const*)afix.data(), nv, 1.0 / scale, a.data());
   int const vb = bits_of_u((uint64_t)std::max<int64_t>(nv - 1, 1));
-  auto modularity = [&]() {  // detail::compute_modularity (common_methods.cuh:176-228)
-    chunked_sum(h, ne, parts, scal.data(), [&](int np, double* p) {
-      hipLaunchKernelGGL(k_part_internal, np, 1024, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.dst.data(), (double const*)L.w.data(),
-                         (int32_t const*)c.data(), ne, p);
-    });
-    chunked_sum(h, nv, parts, scal.data() + 1, [&](int np, double* p) { hipLaunchKernelGGL(k_part_squares, np, 1024, 0, h.stream, (double const*)a.data(), nv, p); });
-    double s[2];
-    h.read_back(s, scal.data(), 2);
-    if (mg) s[0] = mg->sum_f64(s[0]);  // the ranks' intra-cluster weights, added in rank order
-    return s[0] / m - (resolution * s[1]) / (m * m);
-  };
-  double new_q = modularity();
-  double cur_q = new_q - 1.0;
-  bool up_down = true;
+  // One evaluation of the clustering c (update_clustering_by_delta_modularity, common_methods.cuh:259-447, up to the moves): the best move
+  // of every vertex, the number of moves wanted in each direction, and -- as a by-product of the same tables: every row's weight into its own
+  // cluster is in them -- the modularity of c itself (detail::compute_modularity, common_methods.cuh:176-228): the intra-cluster weight
+  // as an exact fixed-point integer (order-free: the same bits on every path and with any number of ranks), the squared cluster weights
+  // summed in 64 Ki chunks.  Round 4: the loop below therefore evaluates the clustering AFTER a sweep's moves before it decides whether
+  // the sweep improved the modularity -- one evaluation per level is thrown away, and the separate pass over all edges after every sweep
+  // (17 % of a call at RMAT-26: its gathers of c[dst] miss every cache) is gone.
+  dvec<unsigned long long> stat(4);  // [0..1] three uint32: moves wanted down / up, "a big row's table filled up"; [2] intra-cluster weight; [3] sum of squares (double)
+  uint32_t* const count           = reinterpret_cast<uint32_t*>(stat.data());
+  unsigned long long* const ifix  = stat.data() + 2;
+  int evals_in_level              = 0;
   // compute_louvain_min_vertex_move_gain with the reference's noise floor per weight type (common_methods.cuh:52-66)
   double const min_gain = std::max(threshold / (double)std::max<int64_t>(nv, 1), noise_floor);
-  while (new_q > cur_q + threshold) {
-    cur_q = new_q;
-    ++st.sweeps;
-    ++st.sweeps_in_level;
-    // update_clustering_by_delta_modularity (common_methods.cuh:259-447)
-    auto evaluate = [&]() {
-      bool const sorted = n_sorted > 0 && !hub_hash && !big_hash;
-      if (sorted) {
-        hipLaunchKernelGGL(k_pair_keys, g_s, kBlock, 0, h.stream, s_src, (int32_t const*)nullptr, s_dst, (int32_t const*)c.data(), n_sorted, vb, ekeys.data(),
-                           eperm.data());
-        // first sweep of a level: every vertex is its own cluster, so the key is (source, destination) -- the order the level's
-        // edges are stored in (CSR order / the contraction's output): nothing to sort
-        if (st.sweeps_in_level > 1) sort_pairs(h, ekeys, eperm, n_sorted, 2 * vb);
+  auto evaluate = [&]() {
+    bool const sorted = n_sorted > 0 && !hub_hash && !big_hash;
+    if (sorted) {
+      hipLaunchKernelGGL(k_pair_keys, g_s, kBlock, 0, h.stream, s_src, (int32_t const*)nullptr, s_dst, (int32_t const*)c.data(), n_sorted, vb, ekeys.data(),
+                         eperm.data());
+      // first evaluation of a level: every vertex is its own cluster, so the key is (source, destination) -- the order the level's
+      // edges are stored in (CSR order / the contraction's output): nothing to sort
+      if (evals_in_level > 1) sort_pairs(h, ekeys, eperm, n_sorted, 2 * vb);
+    }
+    HIP_TRY(hipMemsetAsync(vfix.data(), 0, (size_t)nv * 3 * sizeof(unsigned long long), h.stream));  // selffix, subfix, best_bits
+    HIP_TRY(hipMemsetAsync(best_c.data(), 0x7f, (size_t)nv * sizeof(int32_t), h.stream));
+    HIP_TRY(hipMemsetAsync(stat.data(), 0, 3 * sizeof(unsigned long long), h.stream));  // counts, overflow flag, intra-cluster weight
+    if (hub_hash) {
+      HIP_TRY(hipMemsetAsync(hub_keys.data(), 0xFF, (size_t)2 * n_sorted * sizeof(unsigned long long), h.stream));
+      HIP_TRY(hipMemsetAsync(hub_sums.data(), 0, (size_t)2 * n_sorted * sizeof(unsigned long long), h.stream));
+      lv_hub_args HB{s_src, s_dst, s_w, hrow0.data(), L.off.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, n_sorted,
+                     hub_keys.data(), hub_sums.data(), vfix.data(), vfix.data() + nv, vfix.data() + 2 * nv, best_c.data()};
+      int const g_t = grid_for(2 * n_sorted, kBlock, 16384);
+      hipLaunchKernelGGL(k_lv_hub_insert, g_s, kBlock, 0, h.stream, HB);
+      hipLaunchKernelGGL(k_lv_hub_eval<0>, g_t, kBlock, 0, h.stream, HB);
+      hipLaunchKernelGGL(k_lv_hub_eval<1>, g_t, kBlock, 0, h.stream, HB);
+    }
+    if (sorted) {
+      HIP_TRY(hipMemsetAsync(segfix.data(), 0, (size_t)n_sorted * sizeof(unsigned long long), h.stream));
+      lv_flat_args A{ekeys.data(), eperm.data(), s_dst, s_w, c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, n_sorted, vb,
+                     segfix.data(), vfix.data(), vfix.data() + nv, vfix.data() + 2 * nv, best_c.data()};
+      hipLaunchKernelGGL(k_segment_sums, g_s, kBlock, 0, h.stream, A);
+      hipLaunchKernelGGL(k_segment_best<0>, g_s, kBlock, 0, h.stream, A);
+      hipLaunchKernelGGL(k_segment_best<1>, g_s, kBlock, 0, h.stream, A);
+    }
+    if (use_hash && n_sorted < ne) {
+      lv_hash_args HA{L.src.data(), L.dst.data(), L.off.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, ne,
+                      vfix.data() + 2 * nv, best_c.data(), ifix};
+      hipLaunchKernelGGL(k_lv_hash_chunks, (int)((ne + LVH_B - 1) / LVH_B), LVH_THREADS, 0, h.stream, HA);
+    }
+    if (n_mid[0] + n_mid[1] > 0 || big_hash) {
+      static bool attr_done = false;
+      if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_lv_hash_rows<LVM_MAX * 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LVM_MAX * 2 * 12));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_lv_hash_big), hipFuncAttributeMaxDynamicSharedMemorySize, LVB_SLOTS * 12));
+        attr_done = true;
       }
-      HIP_TRY(hipMemsetAsync(vfix.data(), 0, (size_t)nv * 3 * sizeof(unsigned long long), h.stream));  // selffix, subfix, best_bits
-      HIP_TRY(hipMemsetAsync(best_c.data(), 0x7f, (size_t)nv * sizeof(int32_t), h.stream));
-      HIP_TRY(hipMemsetAsync(count.data(), 0, 3 * sizeof(uint32_t), h.stream));
-      if (hub_hash) {
-        HIP_TRY(hipMemsetAsync(hub_keys.data(), 0xFF, (size_t)2 * n_sorted * sizeof(unsigned long long), h.stream));
-        HIP_TRY(hipMemsetAsync(hub_sums.data(), 0, (size_t)2 * n_sorted * sizeof(unsigned long long), h.stream));
-        lv_hub_args HB{s_src, s_dst, s_w, hrow0.data(), L.off.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, n_sorted,
-                       hub_keys.data(), hub_sums.data(), vfix.data(), vfix.data() + nv, vfix.data() + 2 * nv, best_c.data()};
-        int const g_t = grid_for(2 * n_sorted, kBlock, 16384);
-        hipLaunchKernelGGL(k_lv_hub_insert, g_s, kBlock, 0, h.stream, HB);
-        hipLaunchKernelGGL(k_lv_hub_eval<0>, g_t, kBlock, 0, h.stream, HB);
-        hipLaunchKernelGGL(k_lv_hub_eval<1>, g_t, kBlock, 0, h.stream, HB);
+      lv_mid_args MA{nullptr, 0, L.dst.data(), L.off.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale,
+                     vfix.data() + 2 * nv, best_c.data(), ifix};
+      if (n_mid[0]) {
+        MA.rows = mid_rows[0].data(); MA.n_rows = (int32_t)n_mid[0];
+        hipLaunchKernelGGL(k_lv_hash_rows<LVM_MAX>, (int)std::min<uint32_t>(n_mid[0], (uint32_t)h.num_cus * 12), LVM_THREADS, LVM_MAX * 12, h.stream, MA);
       }
-      if (sorted) {
-        HIP_TRY(hipMemsetAsync(segfix.data(), 0, (size_t)n_sorted * sizeof(unsigned long long), h.stream));
-        lv_flat_args A{ekeys.data(), eperm.data(), s_dst, s_w, c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, n_sorted, vb,
-                       segfix.data(), vfix.data(), vfix.data() + nv, vfix.data() + 2 * nv, best_c.data()};
-        hipLaunchKernelGGL(k_segment_sums, g_s, kBlock, 0, h.stream, A);
-        hipLaunchKernelGGL(k_segment_best<0>, g_s, kBlock, 0, h.stream, A);
-        hipLaunchKernelGGL(k_segment_best<1>, g_s, kBlock, 0, h.stream, A);
+      if (n_mid[1]) {
+        MA.rows = mid_rows[1].data(); MA.n_rows = (int32_t)n_mid[1];
+        hipLaunchKernelGGL(k_lv_hash_rows<LVM_MAX * 2>, (int)std::min<uint32_t>(n_mid[1], (uint32_t)h.num_cus * 8), LVM_THREADS, LVM_MAX * 2 * 12, h.stream, MA);
       }
-      if (use_hash && n_sorted < ne) {
-        lv_hash_args HA{L.src.data(), L.dst.data(), L.off.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, ne,
-                        vfix.data() + 2 * nv, best_c.data()};
-        hipLaunchKernelGGL(k_lv_hash_chunks, (int)((ne + LVH_B - 1) / LVH_B), LVH_THREADS, 0, h.stream, HA);
+      if (big_hash) {
+        lv_big_args BA{big_items.data(), (int32_t)n_mid[2], big_ecl.data(), big_ewf.data(), big_rowsub.data(), L.off.data(), c.data(), k.data(), a.data(), m, resolution,
+                       scale, 1.0 / scale, vfix.data() + 2 * nv, best_c.data(), big_bits.data(), big_c.data(), count + 2, ifix, big_max_used};
+        hipLaunchKernelGGL(k_lv_big_gather, g_s, kBlock, 0, h.stream, s_dst, (int32_t const*)c.data(), n_sorted, big_ecl.data());
+        hipLaunchKernelGGL(k_lv_hash_big, (int)std::min<uint32_t>(n_mid[2], (uint32_t)h.num_cus * 8), LVB_THREADS, LVB_SLOTS * 12, h.stream, BA);
+        hipLaunchKernelGGL(k_lv_big_ties, grid_for((int64_t)n_mid[2], kBlock, 1024), kBlock, 0, h.stream, BA);
       }
-      if (n_mid[0] + n_mid[1] > 0 || big_hash) {
-        static bool attr_done = false;
-        if (!attr_done) {
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_lv_hash_rows<LVM_MAX * 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LVM_MAX * 2 * 12));
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_lv_hash_big), hipFuncAttributeMaxDynamicSharedMemorySize, LVB_SLOTS * 12));
-          attr_done = true;
-        }
-        lv_mid_args MA{nullptr, 0, L.dst.data(), L.off.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale,
-                       vfix.data() + 2 * nv, best_c.data()};
-        if (n_mid[0]) {
-          MA.rows = mid_rows[0].data(); MA.n_rows = (int32_t)n_mid[0];
-          hipLaunchKernelGGL(k_lv_hash_rows<LVM_MAX>, (int)std::min<uint32_t>(n_mid[0], (uint32_t)h.num_cus * 12), LVM_THREADS, LVM_MAX * 12, h.stream, MA);
-        }
-        if (n_mid[1]) {
-          MA.rows = mid_rows[1].data(); MA.n_rows = (int32_t)n_mid[1];
-          hipLaunchKernelGGL(k_lv_hash_rows<LVM_MAX * 2>, (int)std::min<uint32_t>(n_mid[1], (uint32_t)h.num_cus * 8), LVM_THREADS, LVM_MAX * 2 * 12, h.stream, MA);
-        }
-        if (big_hash) {
-          lv_big_args BA{big_items.data(), (int32_t)n_mid[2], big_ecl.data(), big_ewf.data(), big_rowsub.data(), L.off.data(), c.data(), k.data(), a.data(), m, resolution,
-                         scale, 1.0 / scale, vfix.data() + 2 * nv, best_c.data(), big_bits.data(), big_c.data(), count.data() + 2, big_max_used};
-          hipLaunchKernelGGL(k_lv_big_gather, g_s, kBlock, 0, h.stream, s_dst, (int32_t const*)c.data(), n_sorted, big_ecl.data());
-          hipLaunchKernelGGL(k_lv_hash_big, (int)std::min<uint32_t>(n_mid[2], (uint32_t)h.num_cus * 8), LVB_THREADS, LVB_SLOTS * 12, h.stream, BA);
-          hipLaunchKernelGGL(k_lv_big_ties, grid_for((int64_t)n_mid[2], kBlock, 1024), kBlock, 0, h.stream, BA);
-        }
-      }
-      hipLaunchKernelGGL(k_best_finalize, g_v, kBlock, 0, h.stream, (unsigned long long const*)(vfix.data() + 2 * nv), best_c.data(), best_d.data(), nv);
-      hipLaunchKernelGGL(k_count_moves, (int)std::max<int64_t>(1, std::min<int64_t>((nv + 1023) / 1024, 512)), 1024, 0, h.stream, (int32_t const*)c.data(),
-                         (int32_t const*)best_c.data(), (double const*)best_d.data(), min_gain, nv, count.data());
-    };
+    }
+    if (sorted || hub_hash)  // these paths leave the rows' own-cluster weights in selffix[] (zero for the rows of the LDS paths)
+      hipLaunchKernelGGL(k_lv_sum_u64, (int)std::max<int64_t>(1, std::min<int64_t>((nv + 1023) / 1024, 1024)), 1024, 0, h.stream, (unsigned long long const*)vfix.data(), nv, ifix);
+    chunked_sum(h, nv, parts, reinterpret_cast<double*>(stat.data() + 3), [&](int np, double* p) { hipLaunchKernelGGL(k_part_squares, np, 1024, 0, h.stream, (double const*)a.data(), nv, p); });
+    hipLaunchKernelGGL(k_best_finalize, g_v, kBlock, 0, h.stream, (unsigned long long const*)(vfix.data() + 2 * nv), best_c.data(), best_d.data(), nv);
+    hipLaunchKernelGGL(k_count_moves, (int)std::max<int64_t>(1, std::min<int64_t>((nv + 1023) / 1024, 512)), 1024, 0, h.stream, (int32_t const*)c.data(),
+                       (int32_t const*)best_c.data(), (double const*)best_d.data(), min_gain, nv, count);
+  };
+  struct eval_t { uint32_t moves[2]; double q; };
+  auto run_eval = [&]() {
+    ++evals_in_level;
     evaluate();
-    uint32_t nr_moves[3] = {0, 0, 0};
-    h.read_back(nr_moves, count.data(), 3);
-    if (nr_moves[2]) {  // a big row's LDS table filled up: the sorted path takes the big rows for the rest of this level
+    unsigned long long got[4];
+    h.read_back(got, stat.data(), 4);
+    uint32_t cnt[4];
+    std::memcpy(cnt, got, sizeof(cnt));
+    if (cnt[2]) {  // a big row's LDS table filled up: the sorted path takes the big rows for the rest of this level
       big_hash = false;
       size_t const nk = (size_t)std::max<int64_t>(n_sorted, 1);
       eperm.resize_discard(nk); ekeys.resize_discard(nk); segfix.resize_discard(nk);
       evaluate();
-      h.read_back(nr_moves, count.data(), 3);
+      h.read_back(got, stat.data(), 4);
+      std::memcpy(cnt, got, sizeof(cnt));
     }
-    if (mg) mg->sum_u32x2(nr_moves);
-    if (nr_moves[up_down ? 1 : 0] == 0) up_down = !up_down;
+    eval_t r{{cnt[0], cnt[1]}, 0.0};
+    unsigned long long internal = got[2];
+    if (mg) { mg->sum_u32x2(r.moves); internal = mg->sum_u64(internal); }  // (the cluster weights are complete on every rank)
+    double squares;
+    std::memcpy(&squares, &got[3], sizeof(squares));
+    r.q = ((double)(long long)internal * (1.0 / scale)) / m - (resolution * squares) / (m * m);
+    return r;
+  };
+  eval_t ev    = run_eval();
+  double new_q = ev.q;
+  double cur_q = new_q - 1.0;
+  bool up_down = true;
+  while (new_q > cur_q + threshold) {
+    cur_q = new_q;
+    ++st.sweeps;
+    ++st.sweeps_in_level;
+    if (ev.moves[up_down ? 1 : 0] == 0) up_down = !up_down;
     // the moves + compute_cluster_keys_and_values: cluster weights of the new clustering
     hipLaunchKernelGGL(k_apply_moves, g_v, kBlock, 0, h.stream, c.data(), (int32_t const*)best_c.data(), (double const*)best_d.data(), min_gain, up_down ? 1 : 0, nv,
                        (long long const*)kfix.data(), afix.data());
@@ -1150,7 +1193,8 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     }
     hipLaunchKernelGGL(k_fix_to_double, g_v, kBlock, 0, h.stream, (unsigned long long const*)afix.data(), nv, 1.0 / scale, a.data());
     up_down = !up_down;
-    new_q   = modularity();
+    ev      = run_eval();
+    new_q   = ev.q;
     if (new_q > cur_q + threshold) HIP_TRY(hipMemcpyAsync(accepted.data(), c.data(), nv * sizeof(int32_t), hipMemcpyDeviceToDevice, h.stream));
   }
   h.sync();

@@ -3,7 +3,7 @@
 set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"; O="$R/gpurun_out"; mkdir -p "$O"; cd "$R"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_mg_capi.py -m gpu -x -q -k "louvain or Louvain" 2>&1 | tail -3 | tee "$O/r4v_louvain_tests.log"
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_mg_capi.py tests/test_c_conformance.py tests/test_pylibcugraph_on_gpu.py -m gpu -x -q -k "louvain or Louvain" 2>&1 | tail -3 | tee "$O/r4v_louvain_tests.log"
 cp cugraph_amd/lib/libcugraph_c.so /tmp/orig.so
 for lib in ${LIBS:-prev new}; do
   cp "gpurun_libs/$lib.so" cugraph_amd/lib/libcugraph_c.so
