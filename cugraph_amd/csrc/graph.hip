@@ -662,8 +662,9 @@ cugraph_error_code_t create_mg(const cugraph_resource_handle_t* handle, const cu
       // to their owners at this point; here the owners depend on the algorithm family and are chosen on first use: mg_graph.hpp)
       CGA_EXPECTS(graph != nullptr && properties != nullptr, CUGRAPH_INVALID_INPUT, "Invalid input arguments: NULL graph / properties.");
       CGA_EXPECTS(cs.view.size == cd.view.size && (!cw.present || cw.view.size == cs.view.size), CUGRAPH_INVALID_INPUT, "Invalid input arguments: src size != dst / weights size.");
-      CGA_EXPECTS(drop_multi_edges != TRUE && symmetrize != TRUE, CUGRAPH_NOT_IMPLEMENTED,
-                  "cugraph_graph_create_mg: drop_multi_edges / symmetrize are not available on a multi-GPU graph in this build (drop_self_loops is)");
+      if (symmetrize == TRUE)  // graph_mg.cpp:117-121
+        CGA_EXPECTS(properties->is_symmetric == TRUE, CUGRAPH_INVALID_INPUT,
+                    "Invalid input arguments: The graph property must be symmetric if 'symmetrize' is set to True.");
       auto g              = std::make_unique<graph_t>();
       g->vertex_type      = INT32;
       g->edge_type        = INT32;
@@ -672,7 +673,8 @@ cugraph_error_code_t create_mg(const cugraph_resource_handle_t* handle, const cu
       g->store_transposed = store_transposed == TRUE;
       g->renumbered       = true;  // graph_mg.cpp:214
       g->props            = *properties;
-      mg_graph_create(h, *g, cv.present ? &cv.view : nullptr, &cs.view, &cd.view, cw.present ? &cw.view : nullptr, drop_self_loops == TRUE);
+      mg_graph_create(h, *g, cv.present ? &cv.view : nullptr, &cs.view, &cd.view, cw.present ? &cw.view : nullptr, drop_self_loops == TRUE, drop_multi_edges == TRUE,
+                      symmetrize == TRUE);
       *graph = reinterpret_cast<cugraph_graph_t*>(g.release());
     }
   });

@@ -9,6 +9,7 @@
 // Degrees come straight from the offsets of the orientation whose rows are the wanted endpoint; when only the other
 // orientation exists they are a histogram of its minor ids (no transposition of the storage is forced).
 #include "common.hpp"
+#include "mg_graph.hpp"
 
 #include <climits>
 
@@ -70,10 +71,31 @@ cugraph_error_code_t degrees_impl(const cugraph_resource_handle_t* handle, cugra
   if (result) *result = nullptr;
   return guarded(error, [&] {
     handle_t const& h = H(handle);
-    graph_t& g        = G(graph);
     CGA_EXPECTS(result != nullptr, CUGRAPH_INVALID_INPUT, "result is NULL");
     HIP_TRY(hipSetDevice(h.device));
     auto const sv_user = reinterpret_cast<device_array_view_t const*>(source_vertices);
+    if (GM(graph).mg) {  // a graph from cugraph_graph_create_mg on a communicator handle: collective, every rank answers for its share of the vertices
+      graph_t& mgg = GM(graph);
+      CGA_EXPECTS(sv_user == nullptr || sv_user->type == INT32, CUGRAPH_INVALID_INPUT, "vertex type of graph and source_vertices must match");
+      bool const msym   = mgg.props.is_symmetric == TRUE;
+      bool const mshare = want_in && want_out && msym;  // degrees.cu:84-88
+      dvec<int32_t> ids, din, dout;
+      int64_t const n = mg_degrees(h, mgg, sv_user, want_in, want_out && !mshare, ids, din, dout);
+      auto res          = std::make_unique<degrees_result_t>();
+      res->is_symmetric = msym;
+      auto take = [&](dvec<int32_t> const& d, cugraph_data_type_id_t t) {
+        auto* a = new device_array_t((size_t)n, t);
+        if (n > 0) HIP_TRY(hipMemcpyAsync(a->buf.ptr, d.data(), (size_t)n * 4, hipMemcpyDeviceToDevice, h.stream));
+        return a;
+      };
+      res->vertex_ids = take(ids, INT32);
+      if (want_in) res->in_degrees = take(din, mgg.edge_type);
+      if (want_out && !mshare) res->out_degrees = take(dout, mgg.edge_type);
+      h.sync();
+      *result = reinterpret_cast<cugraph_degrees_result_t*>(res.release());
+      return;
+    }
+    graph_t& g = G(graph);
     vertex_column_in c_sv;  // INT64 / sparse external ids: compact int32 ids from here on (outer_ids.hip)
     device_array_view_t const* sv = c_sv.get(h, g, sv_user, "source_vertices");
     int64_t const nv = g.nv, n1 = nv > 0 ? nv : 1;

@@ -25,6 +25,18 @@ __global__ void k_present(uint32_t const* a, uint32_t const* b, uint32_t const* 
   for (; i < n; i += (int64_t)gridDim.x * blockDim.x) present[i] = (a[i] | b[i] | (listed ? listed[i] : 0u)) != 0u ? 1u : 0u;
 }
 
+// owner of the unordered endpoint pair of an edge (all edges between two vertices, either direction, land on one rank)
+__global__ void k_pair_owner(int32_t const* s, int32_t const* d, int64_t n, int P, int32_t* owner)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t const a = (uint32_t)min(s[i], d[i]), b = (uint32_t)max(s[i], d[i]);
+    uint32_t x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA6Bu;
+    x ^= x >> 16;
+    owner[i] = (int32_t)(x % (uint32_t)P);
+  }
+}
+
 __global__ void k_mark_listed(int32_t const* v, int64_t n, int64_t vmin, uint32_t* flags)
 {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -247,7 +259,7 @@ mg_pagerank_part_t::~mg_pagerank_part_t()
 
 // ------------------------------------------------------------------------------------------------ graph creation
 void mg_graph_create(handle_t const& h, graph_t& g, device_array_view_t const* vertices, device_array_view_t const* src, device_array_view_t const* dst,
-                     device_array_view_t const* weights, bool drop_self_loops)
+                     device_array_view_t const* weights, bool drop_self_loops, bool drop_multi_edges, bool symmetrize)
 {
   comm_t* cp = handle_comm(h);
   CGA_EXPECTS(cp != nullptr, CUGRAPH_INVALID_HANDLE, "multi-GPU graph: the handle carries no communicator");
@@ -300,6 +312,40 @@ void mg_graph_create(handle_t const& h, graph_t& g, device_array_view_t const* v
   CGA_EXPECTS(hi >= lo, CUGRAPH_INVALID_INPUT, "multi-GPU graph: no edges and no vertices on any rank");
   CGA_EXPECTS(hi - lo + 1 < ((int64_t)1 << 31) - 2, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "multi-GPU graph: the external id range must fit 31 bits");
   mg->vmin = lo; mg->vrange = hi - lo + 1; mg->ne_global = ne;
+  if ((drop_multi_edges || symmetrize) && ne > 0) {
+    // graph_mg.cpp:165-230 (remove_multi_edges / symmetrize_edgelist on the shuffled list).  Both decisions concern the edges between ONE
+    // unordered pair of endpoints: those are brought together on one rank (owner = a hash of the pair), where the single-GPU routines
+    // (edgelist.hip) decide as they would on the whole list.  Which rank holds an edge afterwards does not matter: the partitions
+    // re-shuffle the slices on first use.
+    size_t const m1 = (size_t)std::max<int64_t>(el.n, 1);
+    dvec<int32_t> owner(m1);
+    if (el.n > 0) hipLaunchKernelGGL(k_pair_owner, grid_for(el.n, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)el.s.data(), (int32_t const*)el.d.data(), el.n, c.size, owner.data());
+    std::vector<mg_column_t> cols{{el.s.data(), 4}, {el.d.data(), 4}};
+    if (el.wsize) cols.push_back({el.w.ptr, el.wsize});
+    std::vector<dev_buf> got;
+    int64_t const n_in = mg_shuffle_by_owner(h, c, owner.data(), el.n, cols, got);
+    CGA_EXPECTS(n_in <= kMaxSignedEdges, CUGRAPH_INVALID_INPUT, "multi-GPU graph: a rank's share of the edge pairs must hold fewer than 2^31 edges");
+    size_t const n1 = (size_t)std::max<int64_t>(n_in, 1);
+    el.n = n_in;
+    el.s.resize_discard(n1); el.d.resize_discard(n1);
+    if (n_in > 0) {
+      HIP_TRY(hipMemcpyAsync(el.s.data(), got[0].ptr, (size_t)n_in * 4, hipMemcpyDeviceToDevice, h.stream));
+      HIP_TRY(hipMemcpyAsync(el.d.data(), got[1].ptr, (size_t)n_in * 4, hipMemcpyDeviceToDevice, h.stream));
+      if (el.wsize) {
+        el.w.alloc((size_t)n_in * el.wsize);
+        HIP_TRY(hipMemcpyAsync(el.w.ptr, got[2].ptr, (size_t)n_in * el.wsize, hipMemcpyDeviceToDevice, h.stream));
+      }
+    }
+    h.sync();
+    if (el.n > 0 && drop_multi_edges) edgelist_drop_multi_edges(h, el, mg->vmin, mg->vrange);
+    if (el.n > 0 && symmetrize) edgelist_symmetrize(h, el, mg->vmin, mg->vrange);
+    std::vector<int64_t> counts(c.size);
+    int64_t const mine_n = el.n;
+    c.host_allgather(&mine_n, sizeof(mine_n), counts.data());
+    ne = 0;
+    for (auto x : counts) ne += x;
+    mg->ne_global = ne;
+  }
   // which ids are vertices: an endpoint of an edge anywhere, or listed anywhere
   dvec<uint32_t> din, dout, lst;
   global_degree(h, c, *mg, el.d.data(), din);
@@ -334,6 +380,102 @@ __global__ void k_mg_has_vertex(int32_t const* v, int64_t n, int64_t vmin, int64
   }
 }
 }  // namespace
+
+namespace {
+// flag[i] = 1 when ids[i] (or, ids == nullptr, the id vmin + i) is a vertex this rank answers for: (id - vmin) % P == rank; *bad counts listed ids that are no vertices
+__global__ void k_mg_mine(int32_t const* ids, int64_t n, int64_t vmin, int64_t vrange, uint32_t const* present, int P, int rank, uint32_t* flag, unsigned long long* bad)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t const k = ids ? (int64_t)ids[i] - vmin : i;
+    bool const ok   = k >= 0 && k < vrange && present[k] != 0u;
+    if (ids && !ok) atomicAdd(bad, 1ull);
+    flag[i] = ok && (int)(k % P) == rank ? 1u : 0u;
+  }
+}
+__global__ void k_mg_take(int32_t const* ids, uint32_t const* flag, uint32_t const* pos, int64_t n, int64_t vmin, uint32_t const* din, uint32_t const* dout, int32_t* out_ids,
+                          int32_t* out_in, int32_t* out_out)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (flag[i]) {
+      int64_t const k  = ids ? (int64_t)ids[i] - vmin : i;
+      uint32_t const q = pos[i];
+      out_ids[q] = (int32_t)(k + vmin);
+      if (out_in) out_in[q] = (int32_t)din[k];
+      if (out_out) out_out[q] = (int32_t)dout[k];
+    }
+}
+}  // namespace
+
+// cugraph_degrees / _in_degrees / _out_degrees on a multi-GPU graph (degrees.cu:24-213 with multi_gpu = true): collective.  Every rank
+// answers for the vertices with (id - vmin) % P == rank -- all of them, or those of them ANY rank listed (the reference shuffles the listed
+// vertices to their owners).  Degrees = all-reduced endpoint counts of the ranks' slices.
+int64_t mg_degrees(handle_t const& h, graph_t& g, device_array_view_t const* listed, bool want_in, bool want_out, dvec<int32_t>& ids, dvec<int32_t>& in_deg, dvec<int32_t>& out_deg)
+{
+  mg_graph_t& mg = *g.mg;
+  comm_t& c      = *mg.comm;
+  int const P    = c.size;
+  dvec<uint32_t> din, dout;
+  if (want_in) global_degree(h, c, mg, mg.el.d.data(), din);
+  if (want_out) global_degree(h, c, mg, mg.el.s.data(), dout);
+  dvec<int32_t> all;
+  int64_t n = mg.vrange;
+  bool const any_list = [&] {
+    int64_t const has = listed != nullptr ? 1 : 0;
+    std::vector<int64_t> v(P);
+    c.host_allgather(&has, sizeof(has), v.data());
+    int64_t s = 0;
+    for (auto x : v) s += x;
+    return s > 0;
+  }();
+  if (any_list) {  // every rank's list, padded to the longest, in rank order
+    int64_t const mine = listed ? (int64_t)listed->size : 0;
+    std::vector<int64_t> counts(P);
+    c.host_allgather(&mine, sizeof(mine), counts.data());
+    int64_t stride = 1;
+    for (auto x : counts) stride = std::max(stride, x);
+    dvec<int32_t> in((size_t)stride);
+    fill_i32(h, in.data(), stride, INT32_MIN);  // padding: outside every id range, never "mine"
+    if (mine > 0) HIP_TRY(hipMemcpyAsync(in.data(), listed->data, (size_t)mine * 4, hipMemcpyDeviceToDevice, h.stream));
+    dvec<int32_t> padded((size_t)stride * P);
+    c.all_gather(h, in.data(), (size_t)stride * 4, padded.data());
+    int64_t total = 0;
+    for (auto x : counts) total += x;
+    all.resize_discard((size_t)std::max<int64_t>(total, 1));
+    int64_t at = 0;
+    for (int r = 0; r < P; ++r) {
+      if (counts[r] > 0) HIP_TRY(hipMemcpyAsync(all.data() + at, padded.data() + (size_t)r * stride, (size_t)counts[r] * 4, hipMemcpyDeviceToDevice, h.stream));
+      at += counts[r];
+    }
+    h.sync();
+    n = total;
+  }
+  size_t const n1 = (size_t)std::max<int64_t>(n, 1);
+  dvec<uint32_t> flag(n1 + 1), pos(n1 + 1);
+  dvec<unsigned long long> bad(1);
+  HIP_TRY(hipMemsetAsync(bad.data(), 0, 8, h.stream));
+  HIP_TRY(hipMemsetAsync(flag.data(), 0, (n1 + 1) * 4, h.stream));
+  if (n > 0)
+    hipLaunchKernelGGL(k_mg_mine, grid_for(n, kBlock, 8192), kBlock, 0, h.stream, any_list ? (int32_t const*)all.data() : (int32_t const*)nullptr, n, mg.vmin, mg.vrange,
+                       (uint32_t const*)mg.present.data(), P, c.rank, flag.data(), bad.data());
+  exclusive_scan_u32(h, flag.data(), pos.data(), n + 1);
+  uint32_t n_mine = 0;
+  unsigned long long n_bad = 0;
+  h.read_back(&n_mine, pos.data() + n, 1);
+  h.read_back(&n_bad, bad.data(), 1);
+  CGA_EXPECTS(n_bad == 0, CUGRAPH_INVALID_INPUT, "Invalid input argument: source_vertices contains a vertex that is not in the graph");
+  size_t const m1 = (size_t)std::max<uint32_t>(n_mine, 1);
+  ids.resize_discard(m1);
+  if (want_in) in_deg.resize_discard(m1);
+  if (want_out) out_deg.resize_discard(m1);
+  if (n > 0)
+    hipLaunchKernelGGL(k_mg_take, grid_for(n, kBlock, 8192), kBlock, 0, h.stream, any_list ? (int32_t const*)all.data() : (int32_t const*)nullptr, (uint32_t const*)flag.data(),
+                       (uint32_t const*)pos.data(), n, mg.vmin, want_in ? (uint32_t const*)din.data() : nullptr, want_out ? (uint32_t const*)dout.data() : nullptr, ids.data(),
+                       want_in ? in_deg.data() : nullptr, want_out ? out_deg.data() : nullptr);
+  h.sync();
+  return (int64_t)n_mine;
+}
 
 // cugraph_has_vertex on a multi-GPU graph: is the id a vertex ANYWHERE (every rank holds the presence table)
 void mg_has_vertex(handle_t const& h, graph_t const& g, int32_t const* v, int64_t n, uint8_t* out)
@@ -479,13 +621,14 @@ namespace {
 // sorts the received (row, minor[, extra key]) tuples into a CSR: rows ascending, inside a row ascending `sort_minor`; returns offsets and
 // the `take` column in that order (+ weights)
 void build_local_csr(handle_t const& h, int32_t const* row, int32_t const* sort_minor, int32_t const* take, float const* w, int64_t m, int64_t n_rows,
-                     dvec<int32_t>& offsets, dvec<int32_t>& indices, dvec<float>* weights)
+                     dvec<int32_t>& offsets, dvec<int32_t>& indices, dvec<float>* weights, double const* w64 = nullptr, dvec<double>* weights64 = nullptr)
 {
   size_t const m1 = (size_t)std::max<int64_t>(m, 1);
   offsets.resize_discard((size_t)n_rows + 2);
   indices.resize_discard(m1 + (size_t)kEdgePad);
   HIP_TRY(hipMemsetAsync(indices.data(), 0, (m1 + (size_t)kEdgePad) * 4, h.stream));
   if (weights) { weights->resize_discard(m1 + (size_t)kEdgePad); HIP_TRY(hipMemsetAsync(weights->data(), 0, (m1 + (size_t)kEdgePad) * 4, h.stream)); }
+  if (weights64) { weights64->resize_discard(m1 + (size_t)kEdgePad); HIP_TRY(hipMemsetAsync(weights64->data(), 0, (m1 + (size_t)kEdgePad) * 8, h.stream)); }
   dvec<uint32_t> cnt((size_t)n_rows + 2);
   HIP_TRY(hipMemsetAsync(cnt.data(), 0, ((size_t)n_rows + 2) * 4, h.stream));
   if (m > 0) {
@@ -496,6 +639,7 @@ void build_local_csr(handle_t const& h, int32_t const* row, int32_t const* sort_
     radix_sort_u64_u32(h, keys.data(), perm.data(), keys_tmp.data(), perm_tmp.data(), m, 0, 32 + bits_for((uint64_t)std::max<int64_t>(n_rows, 1)));
     gather_b32(h, reinterpret_cast<uint32_t const*>(take), perm.data(), reinterpret_cast<uint32_t*>(indices.data()), m);
     if (weights) gather_b32(h, reinterpret_cast<uint32_t const*>(w), perm.data(), reinterpret_cast<uint32_t*>(weights->data()), m);
+    if (weights64) gather_b64(h, reinterpret_cast<uint64_t const*>(w64), perm.data(), reinterpret_cast<uint64_t*>(weights64->data()), m);
     h.sync();
   }
   exclusive_scan_u32(h, cnt.data(), reinterpret_cast<uint32_t*>(offsets.data()), n_rows + 1);
@@ -510,8 +654,8 @@ mg_traversal_part_t& mg_traversal_part(handle_t const& h, graph_t& g, bool weigh
   if (slot) return *slot;
   comm_t& c   = *mg.comm;
   int const P = c.size, me = c.rank;
-  CGA_EXPECTS(!weighted || mg.el.wsize == 4, weighted && mg.el.wsize == 0 ? CUGRAPH_INVALID_INPUT : CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
-              weighted && mg.el.wsize == 0 ? "Graph must be weighted" : "multi-GPU SSSP takes FLOAT32 weights in this build");
+  CGA_EXPECTS(!weighted || mg.el.wsize != 0, CUGRAPH_INVALID_INPUT, "Graph must be weighted");
+  bool const w64 = weighted && mg.el.wsize == 8;
   auto t       = std::make_unique<mg_traversal_part_t>();
   t->P         = P;
   t->rank      = me;
@@ -536,13 +680,13 @@ mg_traversal_part_t& mg_traversal_part(handle_t const& h, graph_t& g, bool weigh
     dvec<int32_t> owner(m1), a(m1), b(m1);
     if (m > 0) hipLaunchKernelGGL(k_route, grid_for(m, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)mg.el.s.data(), (int32_t const*)mg.el.d.data(), m, mg.vmin, (int32_t const*)vo.pos.data(), P, t->L, 1, owner.data(), a.data(), b.data(), (int32_t*)nullptr);
     std::vector<column_t> cols{{a.data(), 4}, {b.data(), 4}};
-    if (weighted) cols.push_back({mg.el.w.ptr, 4});
+    if (weighted) cols.push_back({mg.el.w.ptr, mg.el.wsize});
     e_loc = shuffle_by_owner(h, c, owner.data(), m, cols, got);
   }
   CGA_EXPECTS(e_loc <= kMaxSignedEdges, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "multi-GPU traversal: a rank's share must hold fewer than 2^31 edges");
   t->ne_local = e_loc;
-  build_local_csr(h, got[0].as<int32_t const>(), got[1].as<int32_t const>(), got[1].as<int32_t const>(), weighted ? got[2].as<float const>() : nullptr, e_loc, t->n_rows,
-                  t->offsets, t->indices, weighted ? &t->weights : nullptr);
+  build_local_csr(h, got[0].as<int32_t const>(), got[1].as<int32_t const>(), got[1].as<int32_t const>(), weighted && !w64 ? got[2].as<float const>() : nullptr, e_loc, t->n_rows,
+                  t->offsets, t->indices, weighted && !w64 ? &t->weights : nullptr, w64 ? got[2].as<double const>() : nullptr, w64 ? &t->weights64 : nullptr);
   t->pos = std::move(vo.pos);
   // (order is needed once more by the in-edge copy: keep the external ids of all compact global ids instead -- built there)
   slot = std::move(t);

@@ -39,7 +39,8 @@ struct mg_traversal_part_t {
   int64_t nv_global{0}, n_rows{0}, L{0}, ne_local{0}, ne_global{0};
   dvec<int32_t> local_vertices;  // [max(n_rows, 1)] external ids
   dvec<int32_t> offsets, indices;  // CSR of the owned rows' out-edges, destinations as compact global ids, ascending inside a row
-  dvec<float> weights;             // optional
+  dvec<float> weights;             // optional (FLOAT32 graphs)
+  dvec<double> weights64;          // optional (FLOAT64 graphs: the plain exchange loop of traversal_mg_driver.hip)
   bool has_weights{false};
   dvec<int32_t> pos;               // [vrange] external id - vmin -> position in the out-degree order (-1: not a vertex)
   dvec<uint32_t> out_deg;          // [vrange] global out-degrees (the direction heuristic needs the sources' sum)
@@ -58,7 +59,7 @@ struct mg_graph_t {
   int64_t nv_global{0}, ne_global{0};
   dvec<uint32_t> present;     // [vrange] 1 = the id is a vertex of the graph
   std::unique_ptr<mg_pagerank_part_t> pr;
-  std::unique_ptr<mg_traversal_part_t> tr[2];  // [0] = without weights (BFS), [1] = with float weights (SSSP)
+  std::unique_ptr<mg_traversal_part_t> tr[2];  // [0] = without weights (BFS), [1] = with the graph's weights (SSSP)
 };
 
 struct mg_column_t {
@@ -73,8 +74,10 @@ clustering_result_t* mg_run_louvain(handle_t const& h, graph_t& g, size_t max_le
 
 // cugraph_graph_create_mg / _with_times_mg on a handle with more than one rank (collective)
 void mg_graph_create(handle_t const& h, graph_t& g, device_array_view_t const* vertices, device_array_view_t const* src, device_array_view_t const* dst,
-                     device_array_view_t const* weights, bool drop_self_loops);
+                     device_array_view_t const* weights, bool drop_self_loops, bool drop_multi_edges, bool symmetrize);
 void mg_has_vertex(handle_t const& h, graph_t const& g, int32_t const* v, int64_t n, uint8_t* out);
+// cugraph_degrees family on a multi-GPU graph (collective): this rank's share of the vertices (all, or those any rank listed) and their degrees
+int64_t mg_degrees(handle_t const& h, graph_t& g, device_array_view_t const* listed, bool want_in, bool want_out, dvec<int32_t>& ids, dvec<int32_t>& in_deg, dvec<int32_t>& out_deg);
 mg_pagerank_part_t& mg_pagerank_part(handle_t const& h, graph_t& g);                   // collective on first use
 mg_traversal_part_t& mg_traversal_part(handle_t const& h, graph_t& g, bool weighted);  // collective on first use
 void mg_traversal_in_edges(handle_t const& h, graph_t& g, mg_traversal_part_t& t);     // collective: the in-edge copy for bottom-up BFS levels

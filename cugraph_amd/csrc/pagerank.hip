@@ -1516,7 +1516,7 @@ __global__ void k_mgc_scalars_signal(double const* totals, double* const* peer_s
 // into the constants of the next iteration
 template <typename WT>
 __global__ void k_mgc_wait_fold(uint64_t const* my_flags, int channel, uint64_t seq, long long timeout_ticks, uint32_t* err, double const* triples /*[P][4]*/, int P,
-                                pr_scalars<WT>* scal, WT alpha, int64_t nv_global, double wmax)
+                                pr_scalars<WT>* scal, WT alpha, int64_t nv_global, double wmax, int personalized)
 {
   int const r = threadIdx.x;
   if (r < P) {
@@ -1537,7 +1537,7 @@ __global__ void k_mgc_wait_fold(uint64_t const* my_flags, int channel, uint64_t 
       dang += __hip_atomic_load(t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       xmax = fmax(xmax, __hip_atomic_load(t + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
     }
-    tiled_write_scalars<WT>(scal, diff, dang, xmax, alpha, nv_global, 0, wmax);
+    tiled_write_scalars<WT>(scal, diff, dang, xmax, alpha, nv_global, personalized, wmax);
   }
 }
 
@@ -1550,6 +1550,32 @@ __global__ void k_fill_from_scal(WT* out, int64_t n, pr_scalars<WT> const* scal,
   for (; i < n; i += stride) out[i] = v;
 }
 
+// external id -> local row of the ids this rank owns (-1 elsewhere)
+__global__ void k_mgc_row_of(int32_t const* local_vertices, int64_t n_rows, int64_t vmin, int32_t* rowof)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n_rows; i += (int64_t)gridDim.x * blockDim.x) rowof[(int64_t)local_vertices[i] - vmin] = (int32_t)i;
+}
+// the (vertex, value) pairs of ALL ranks ([P][stride], counts[r] valid entries each): the pairs of the rows this rank owns go into `dense`
+// (ADD: accumulated, scaled); *matched counts them -- over all ranks every pair must have found its owner
+template <typename WT, bool ADD>
+__global__ void k_mgc_pairs_to_rows(int32_t const* ids, WT const* vals, int64_t stride, int64_t const* counts, int P, int64_t vmin, int64_t vrange, int32_t const* rowof,
+                                    WT* dense, WT scale, unsigned long long* matched)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < stride * P; i += (int64_t)gridDim.x * blockDim.x) {
+    int const r     = (int)(i / stride);
+    int64_t const k = i - (int64_t)r * stride;
+    if (k >= counts[r]) continue;
+    int64_t const x = (int64_t)ids[i] - vmin;
+    if (x < 0 || x >= vrange) continue;
+    int32_t const row = rowof[x];
+    if (row < 0) continue;
+    if constexpr (ADD) atomicAdd(&dense[row], vals[i] * scale);
+    else dense[row] = vals[i];
+    atomicAdd(matched, 1ull);
+  }
+}
 __global__ void k_mark_rows(int32_t const* rows, int64_t n, uint32_t* flags)
 {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1583,8 +1609,9 @@ struct pagerank_mgc_plan : pagerank_plan_base {
   WT alpha;
   int P, me;
   int64_t n_rows{0}, nv_global{0};
-  dvec<WT> pr, x_own, partial, outw_live;
+  dvec<WT> pr, x_own, partial, outw_live, pers, outw_own;
   dvec<int32_t> xcol_self, live_idx;
+  bool personalized{false}, has_guess{false};
   bool direct{false};  // one rank: the epilogue writes x straight into the (own) gather window -- nothing to push
   WT const* outw{nullptr};
   dvec<pr_scalars<WT>> scal;
@@ -1617,7 +1644,7 @@ struct pagerank_mgc_plan : pagerank_plan_base {
   tiled_epilogue<WT> epi()
   {
     tiled_epilogue<WT> e;
-    e.nv = n_rows; e.pr = pr.data(); e.outw = outw; e.pers = nullptr; e.scal = scal.data();
+    e.nv = n_rows; e.pr = pr.data(); e.outw = outw; e.pers = personalized ? pers.data() : nullptr; e.scal = scal.data();
     e.partials = tpartials.data(); e.totals = totals.data(); e.alpha = alpha; e.nv_global = nv_global; e.wmax = tc->wmax;
     e.cr = crows;
     if (direct) { e.x_next = static_cast<WT*>(xwin[pushes & 1]->local); e.xcol = xcol_self.data(); }
@@ -1625,7 +1652,66 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     return e;
   }
 
-  void create()
+  // Collective.  Any rank may name any vertex (the reference shuffles such pairs to the owning GPU by vertex partition,
+  // cpp/src/c_api/pagerank.cpp:140-196 shuffle_ext_vertex_value_pairs_to_local_gpu_by_vertex_partitioning): every rank's pairs are
+  // all-gathered (padded to the longest list) and each rank keeps the pairs of the rows it owns.  ADD: duplicates accumulate; normalise:
+  // values are divided by the sum of all values (which must be positive: the personalization vector, pagerank_impl.cuh:136-146).  A pair nobody owns is not a vertex of the graph: INVALID_INPUT on every rank.  Returns the sum of ALL values, added
+  // in rank order (the same bits everywhere).
+  template <bool ADD>
+  double pairs_to_rows(device_array_view_t const* ids, device_array_view_t const* vals, WT* dense, WT fill, bool normalise, char const* what)
+  {
+    CGA_EXPECTS(ids->size == vals->size, CUGRAPH_INVALID_INPUT, std::string(what) + ": vertices and values differ in size");
+    mg_graph_t& mg = *g.mg;
+    fill_wt<WT>(h, dense, n_rows, fill);
+    int64_t const mine = (int64_t)ids->size;
+    std::vector<int64_t> counts(P);
+    c.host_allgather(&mine, sizeof(mine), counts.data());
+    int64_t stride = 0, total = 0;
+    for (auto x : counts) { stride = std::max(stride, x); total += x; }
+    dvec<double> dsum(1);
+    HIP_TRY(hipMemsetAsync(dsum.data(), 0, sizeof(double), h.stream));
+    if (mine > 0) hipLaunchKernelGGL(k_sum<WT>, grid_for(mine, kBlock, 1024), kBlock, 0, h.stream, vals->as<WT const>(), mine, dsum.data());
+    double my_sum = 0;
+    h.read_back(&my_sum, dsum.data(), 1);
+    std::vector<double> sums(P);
+    c.host_allgather(&my_sum, sizeof(my_sum), sums.data());
+    double all_sum = 0;
+    for (double x : sums) all_sum += x;
+    if (normalise) CGA_EXPECTS((WT)all_sum > WT(0), CUGRAPH_INVALID_INPUT, "Invalid input argument: sum of personalization values should be positive.");
+    WT const scale = normalise ? WT(1) / (WT)all_sum : WT(1);
+    if (total == 0) return all_sum;
+    size_t const w = (size_t)stride;
+    dvec<int32_t> ids_in(w), ids_all(w * P);
+    dvec<WT> vals_in(w), vals_all(w * P);
+    HIP_TRY(hipMemsetAsync(ids_in.data(), 0, w * 4, h.stream));
+    HIP_TRY(hipMemsetAsync(vals_in.data(), 0, w * sizeof(WT), h.stream));
+    if (mine > 0) {
+      HIP_TRY(hipMemcpyAsync(ids_in.data(), ids->data, (size_t)mine * 4, hipMemcpyDeviceToDevice, h.stream));
+      HIP_TRY(hipMemcpyAsync(vals_in.data(), vals->data, (size_t)mine * sizeof(WT), hipMemcpyDeviceToDevice, h.stream));
+    }
+    c.all_gather(h, ids_in.data(), w * 4, ids_all.data());
+    c.all_gather(h, vals_in.data(), w * sizeof(WT), vals_all.data());
+    dvec<int32_t> rowof((size_t)std::max<int64_t>(mg.vrange, 1));
+    fill_i32(h, rowof.data(), std::max<int64_t>(mg.vrange, 1), -1);
+    if (n_rows > 0) hipLaunchKernelGGL(k_mgc_row_of, grid_for(n_rows, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)part->local_vertices.data(), n_rows, mg.vmin, rowof.data());
+    dvec<int64_t> d_counts(P);
+    dvec<unsigned long long> d_matched(1);
+    HIP_TRY(hipMemcpyAsync(d_counts.data(), counts.data(), (size_t)P * sizeof(int64_t), hipMemcpyHostToDevice, h.stream));
+    HIP_TRY(hipMemsetAsync(d_matched.data(), 0, sizeof(unsigned long long), h.stream));
+    hipLaunchKernelGGL((k_mgc_pairs_to_rows<WT, ADD>), grid_for(stride * P, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)ids_all.data(), (WT const*)vals_all.data(), stride,
+                       (int64_t const*)d_counts.data(), P, mg.vmin, mg.vrange, (int32_t const*)rowof.data(), dense, scale, d_matched.data());
+    unsigned long long matched = 0;
+    h.read_back(&matched, d_matched.data(), 1);
+    std::vector<unsigned long long> all_matched(P);
+    c.host_allgather(&matched, sizeof(matched), all_matched.data());
+    unsigned long long found = 0;
+    for (auto x : all_matched) found += x;
+    CGA_EXPECTS(found == (unsigned long long)total, CUGRAPH_INVALID_INPUT, std::string(what) + ": found a vertex id that is not in the graph");
+    return all_sum;
+  }
+
+  void create(device_array_view_t const* ow_v = nullptr, device_array_view_t const* ow_s = nullptr, device_array_view_t const* ig_v = nullptr,
+              device_array_view_t const* ig_s = nullptr, device_array_view_t const* p_v = nullptr, device_array_view_t const* p_s = nullptr)
   {
     HIP_TRY(hipSetDevice(h.device));
     part      = &mg_pagerank_part(h, g);  // collective on first use
@@ -1655,6 +1741,21 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     HIP_TRY(hipMemsetAsync(totals.data(), 0, 4 * sizeof(double), h.stream));
     HIP_TRY(hipMemsetAsync(x_own.data(), 0, n1 * sizeof(WT), h.stream));
     fill_wt<WT>(h, pr.data(), n_rows, nv_global > 0 ? WT(1) / (WT)nv_global : WT(0));  // pagerank_impl.cuh:422-426
+    // the optional (vertices, values) arguments, as in the single-GPU plan (pagerank_plan::create); collective: every rank passes all or none
+    if (ow_s) {
+      outw_own.resize_discard(n1);
+      (void)pairs_to_rows<false>(ow_v, ow_s, outw_own.data(), WT(0), false, "precomputed_vertex_out_weight");
+      outw = outw_own.data();
+    }
+    if (ig_s) {
+      has_guess = true;
+      (void)pairs_to_rows<false>(ig_v, ig_s, pr.data(), WT(0), false, "initial_guess");  // not renormalised: pagerank_impl.cuh:427-432
+    }
+    if (p_s) {
+      personalized = true;
+      pers.resize_discard(n1);
+      (void)pairs_to_rows<true>(p_v, p_s, pers.data(), WT(0), true, "personalization");
+    }
     pr_scalars<WT> s0{};
     s0.base = nv_global > 0 ? WT(1) / (WT)nv_global : WT(0);  // the first fold makes it base_prev: what the rows hold before iteration 1
     HIP_TRY(hipMemcpyAsync(scal.data(), &s0, sizeof(s0), hipMemcpyHostToDevice, h.stream));
@@ -1667,7 +1768,7 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     }
     // rows without in-edges leave the per-iteration epilogue (spmv_tiled.hpp: tiled_const_rows): their share of the scalars is analytic, and
     // only those of them that SOME rank references (an entry of send_index) get their x = base / out_w written at all
-    if (!getenv("CUGRAPH_AMD_PAGERANK_ALL_ROWS") && tc->n_act < n_rows && tc->nI_act > 0) {
+    if (!getenv("CUGRAPH_AMD_PAGERANK_ALL_ROWS") && !personalized && !has_guess && tc->n_act < n_rows && tc->nI_act > 0) {
       int64_t const n = n_rows - tc->n_act;
       crows.n_rows = n; crows.c0 = 0; crows.nI_act = tc->nI_act;
       dvec<unsigned long long> red(2);
@@ -1748,7 +1849,7 @@ struct pagerank_mgc_plan : pagerank_plan_base {
       int const b = (int)(folds & 1);
       long long const ticks = (long long)(c.timeout_s * (double)c.wall_ticks_per_s);
       hipLaunchKernelGGL(k_mgc_wait_fold<WT>, 1, 64, 0, h.stream, (uint64_t const*)c.flags->local, channel, folds + 1, ticks, c.err_word, (double const*)swin[b]->local, P, scal.data(),
-                         alpha, nv_global, tc->wmax);
+                         alpha, nv_global, tc->wmax, personalized ? 1 : 0);
       ++folds;
     }
     if (read_back) {
@@ -1826,16 +1927,18 @@ pagerank_plan_base* make_plan(cugraph_resource_handle_t const* handle, cugraph_g
   // pagerank_impl.cuh:78-88
   CGA_EXPECTS(alpha >= 0.0 && alpha <= 1.0, CUGRAPH_INVALID_INPUT, "Invalid input argument: alpha should be in [0.0, 1.0].");
   if (g.mg) {  // a graph from cugraph_graph_create_mg on a communicator handle: collective, every rank gets its owned vertices back
-    CGA_EXPECTS(ow_v == nullptr && ow_s == nullptr && ig_v == nullptr && ig_s == nullptr && p_v == nullptr && p_s == nullptr, CUGRAPH_NOT_IMPLEMENTED,
-                "multi-GPU PageRank: precomputed out-weights, initial guess and personalization are not available in this build");
     CGA_EXPECTS(handle_comm(h) == g.mg->comm, CUGRAPH_INVALID_HANDLE, "multi-GPU PageRank: the handle is not on the communicator the graph was created on");
+    check_pair_types(g, V(ow_v), V(ow_s), "vertex type of graph and precomputed_vertex_out_weight_vertices must match",
+                     "vertex type of graph and precomputed_vertex_out_weight_sums must match");
+    check_pair_types(g, V(ig_v), V(ig_s), "vertex type of graph and initial_guess_vertices must match", "vertex type of graph and initial_guess_values must match");
+    check_pair_types(g, V(p_v), V(p_s), "vertex type of graph and personalization_vector must match", "vertex type of graph and personalization_vector must match");
     if (g.weight_type == FLOAT64) {
       auto p = std::make_unique<pagerank_mgc_plan<double>>(h, g, alpha);
-      p->create();
+      p->create(V(ow_v), V(ow_s), V(ig_v), V(ig_s), V(p_v), V(p_s));
       return p.release();
     }
     auto p = std::make_unique<pagerank_mgc_plan<float>>(h, g, alpha);
-    p->create();
+    p->create(V(ow_v), V(ow_s), V(ig_v), V(ig_s), V(p_v), V(p_s));
     return p.release();
   }
   CGA_EXPECTS(p_v == nullptr || V(p_v)->size > 0, CUGRAPH_INVALID_INPUT,

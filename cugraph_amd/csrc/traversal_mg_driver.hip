@@ -302,12 +302,194 @@ paths_result_t* mg_run_bfs(handle_t& h, graph_t& g, device_array_view_t const* s
   return collect(h, r, t, with_pred, INT32);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// FLOAT64 weights: the plain exchange loop.  The fast engine packs (float distance, parent) into ONE 64-bit word per vertex, which a double
+// distance does not fit; double-weight graphs therefore take this frontier Bellman-Ford, exact in double, written for correctness
+// (sssp_impl.cuh:169-566 with weight_t = double): every round the rows whose distance dropped relax their out-edges, the candidates
+// (row at the owner, distance, external id of the parent: four words) go to the owners' window, the owner lowers the distance (64-bit
+// atomic minimum on the bits of a non-negative double), and the parent is the minimum external id among the candidates that attain the
+// vertex's distance -- at the end: among all tight in-edges, the same rule as the float engine and the single-GPU path.
+namespace {
+
+__global__ void k_d64_count(int32_t const* front, int64_t n, int32_t const* off, int32_t const* idx, double const* w, unsigned long long const* dist, double cutoff, int64_t L, int P,
+                            unsigned long long* counts)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t const u = front[i];
+    double const du = __longlong_as_double((long long)dist[u]);
+    for (int32_t p = off[u]; p < off[u + 1]; ++p)
+      if (du + w[p] < cutoff) atomicAdd(&counts[idx[p] / L], 1ull);
+  }
+}
+__global__ void k_d64_scatter(int32_t const* front, int64_t n, int32_t const* off, int32_t const* idx, double const* w, unsigned long long const* dist, double cutoff, int64_t L,
+                              int32_t const* local_vertices, unsigned long long* cursor /*[P]: start of every owner's bucket, advanced*/, int32_t* send)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t const u = front[i];
+    double const du = __longlong_as_double((long long)dist[u]);
+    for (int32_t p = off[u]; p < off[u + 1]; ++p) {
+      double const nd = du + w[p];
+      if (!(nd < cutoff)) continue;
+      int32_t const g = idx[p];
+      unsigned long long const at = atomicAdd(&cursor[g / L], 1ull);
+      unsigned long long const b  = (unsigned long long)__double_as_longlong(nd);
+      int32_t* t = send + 4 * at;
+      t[0] = (int32_t)(g % L); t[1] = (int32_t)(uint32_t)b; t[2] = (int32_t)(uint32_t)(b >> 32); t[3] = local_vertices[u];
+    }
+  }
+}
+__global__ void k_d64_lower(int32_t const* recv, int64_t n, unsigned long long* dist, uint32_t* improved)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t const* t = recv + 4 * i;
+    unsigned long long const b = (unsigned long long)(uint32_t)t[1] | ((unsigned long long)(uint32_t)t[2] << 32);
+    if (b < dist[t[0]] && atomicMin(&dist[t[0]], b) > b) improved[t[0]] = 1u;
+  }
+}
+__global__ void k_d64_reset_pred(uint32_t const* improved, int64_t n_rows, int32_t* pred)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n_rows; i += (int64_t)gridDim.x * blockDim.x) if (improved[i]) pred[i] = INT32_MAX;
+}
+__global__ void k_d64_parents(int32_t const* recv, int64_t n, unsigned long long const* dist, int32_t source_row, int32_t* pred)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t const* t = recv + 4 * i;
+    unsigned long long const b = (unsigned long long)(uint32_t)t[1] | ((unsigned long long)(uint32_t)t[2] << 32);
+    if (t[0] != source_row && b == dist[t[0]]) atomicMin(&pred[t[0]], t[3]);
+  }
+}
+__global__ void k_d64_next(uint32_t* improved, int64_t n_rows, int32_t* front, unsigned long long* n_front)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n_rows; i += (int64_t)gridDim.x * blockDim.x)
+    if (improved[i]) { improved[i] = 0u; front[atomicAdd(n_front, 1ull)] = (int32_t)i; }
+}
+__global__ void k_d64_results(unsigned long long const* dist, int32_t const* pred, int64_t n_rows, double* out_d, int32_t* out_p)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n_rows; i += (int64_t)gridDim.x * blockDim.x) {
+    out_d[i] = __longlong_as_double((long long)dist[i]);  // unreached: DBL_MAX (sssp_impl.cuh: the weight type's maximum)
+    if (out_p) out_p[i] = pred[i] == INT32_MAX ? -1 : pred[i];
+  }
+}
+
+paths_result_t* mg_run_sssp_f64(handle_t& h, graph_t& g, size_t source, double cutoff, bool with_pred)
+{
+  comm_t& c              = *g.mg->comm;
+  mg_traversal_part_t& t = mg_traversal_part(h, g, true);
+  int const P = t.P, me = t.rank;
+  CGA_EXPECTS(source <= (size_t)INT32_MAX, CUGRAPH_INVALID_INPUT, "cugraph_sssp: source is not a vertex of the graph");
+  std::vector<int32_t> const ext{(int32_t)source};
+  located_t const loc = locate_sources(h, g, t, ext, "cugraph_sssp");
+  size_t const n1     = (size_t)std::max<int64_t>(t.n_rows, 1);
+  dvec<unsigned long long> dist(n1), counts((size_t)P), cursor((size_t)P), n_front(1);
+  dvec<int32_t> pred(n1), front(n1), send;
+  dvec<uint32_t> improved(n1);
+  fill_f64(h, reinterpret_cast<double*>(dist.data()), (int64_t)n1, DBL_MAX);
+  fill_i32(h, pred.data(), (int64_t)n1, INT32_MAX);
+  HIP_TRY(hipMemsetAsync(improved.data(), 0, n1 * 4, h.stream));
+  int32_t const source_row = loc.rows.empty() ? -1 : loc.rows[0];
+  int64_t nf               = 0;
+  if (source_row >= 0) {
+    unsigned long long const zero = 0ull;
+    HIP_TRY(hipMemcpyAsync(dist.data() + source_row, &zero, 8, hipMemcpyHostToDevice, h.stream));
+    HIP_TRY(hipMemcpyAsync(front.data(), &source_row, 4, hipMemcpyHostToDevice, h.stream));
+    nf = 1;
+  }
+  h.sync();
+  comm_window_t* win = nullptr;
+  size_t win_tuples  = 0;
+  int const channel  = 1;  // (build-time channel: every exchange below is followed by a stream synchronisation)
+  uint64_t rounds    = 0;
+  double const cut   = cutoff;
+  for (;;) {
+    ++rounds;
+    // candidates per owner, buckets, scatter
+    HIP_TRY(hipMemsetAsync(counts.data(), 0, (size_t)P * 8, h.stream));
+    if (nf > 0)
+      hipLaunchKernelGGL(k_d64_count, grid_for(nf, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)front.data(), nf, (int32_t const*)t.offsets.data(), (int32_t const*)t.indices.data(),
+                         (double const*)t.weights64.data(), (unsigned long long const*)dist.data(), cut, t.L, P, counts.data());
+    std::vector<unsigned long long> mine(P);
+    h.read_back(mine.data(), counts.data(), (size_t)P);
+    std::vector<int64_t> row(P), M((size_t)P * P);
+    for (int k = 0; k < P; ++k) row[k] = (int64_t)mine[k];
+    c.host_allgather(row.data(), (size_t)P * sizeof(int64_t), M.data());
+    int64_t any = 0, need = 1, n_send = 0;
+    for (int s = 0; s < P; ++s) {
+      int64_t in = 0;
+      for (int k = 0; k < P; ++k) { any += M[(size_t)s * P + k]; in += M[(size_t)k * P + s]; }
+      need = std::max(need, in);
+    }
+    if (any == 0) break;  // nobody has a candidate left: every distance is final
+    for (int k = 0; k < P; ++k) n_send += row[k];
+    if ((size_t)need > win_tuples) {  // collective: every rank sees the same count matrix
+      if (win) c.window_free(win);
+      win_tuples = (size_t)need * 2;
+      win        = c.window_create(win_tuples * 16);
+    }
+    send.resize_discard((size_t)std::max<int64_t>(n_send, 1) * 4);
+    std::vector<unsigned long long> start(P);
+    int64_t acc = 0;
+    for (int k = 0; k < P; ++k) { start[k] = (unsigned long long)acc; acc += row[k]; }
+    HIP_TRY(hipMemcpyAsync(cursor.data(), start.data(), (size_t)P * 8, hipMemcpyHostToDevice, h.stream));
+    if (nf > 0)
+      hipLaunchKernelGGL(k_d64_scatter, grid_for(nf, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)front.data(), nf, (int32_t const*)t.offsets.data(), (int32_t const*)t.indices.data(),
+                         (double const*)t.weights64.data(), (unsigned long long const*)dist.data(), cut, t.L, (int32_t const*)t.local_vertices.data(), cursor.data(), send.data());
+    comm_push_desc_t d{};
+    int64_t total = 0;
+    for (int s = 0; s < P; ++s) total += M[(size_t)s * P + me];
+    for (int k = 0; k < P; ++k) {
+      int64_t roff = 0;
+      for (int s = 0; s < me; ++s) roff += M[(size_t)s * P + k];
+      d.dst[k]   = win->at<int32_t>(k) + roff * 4;
+      d.src[k]   = send.data() + (int64_t)start[k] * 4;
+      d.words[k] = row[k] * 4;
+    }
+    d.n = P;
+    c.push_multi(h.stream, d);
+    c.wait(h.stream, channel, c.signal(h.stream, channel));
+    // owner side: lower the distances, then the parents of the distances that stand
+    int32_t const* recv = static_cast<int32_t const*>(win->local);
+    if (total > 0) {
+      hipLaunchKernelGGL(k_d64_lower, grid_for(total, kBlock, 4096), kBlock, 0, h.stream, recv, total, dist.data(), improved.data());
+      hipLaunchKernelGGL(k_d64_reset_pred, grid_for(t.n_rows, kBlock, 4096), kBlock, 0, h.stream, (uint32_t const*)improved.data(), t.n_rows, pred.data());
+      hipLaunchKernelGGL(k_d64_parents, grid_for(total, kBlock, 4096), kBlock, 0, h.stream, recv, total, (unsigned long long const*)dist.data(), source_row, pred.data());
+    }
+    HIP_TRY(hipMemsetAsync(n_front.data(), 0, 8, h.stream));
+    if (t.n_rows > 0) hipLaunchKernelGGL(k_d64_next, grid_for(t.n_rows, kBlock, 4096), kBlock, 0, h.stream, improved.data(), t.n_rows, front.data(), n_front.data());
+    unsigned long long got = 0;
+    h.read_back(&got, n_front.data(), 1);
+    c.check("multi-GPU SSSP (FLOAT64) round");
+    nf = (int64_t)got;
+    c.host_barrier();  // nobody overwrites a window before every rank has consumed this round's tuples
+  }
+  if (win) c.window_free(win);
+  auto ids   = std::make_unique<device_array_t>((size_t)t.n_rows, INT32);
+  auto dst   = std::make_unique<device_array_t>((size_t)t.n_rows, FLOAT64);
+  auto preds = std::make_unique<device_array_t>(with_pred ? (size_t)t.n_rows : 0, INT32);
+  if (t.n_rows > 0) {
+    HIP_TRY(hipMemcpyAsync(ids->buf.ptr, t.local_vertices.data(), (size_t)t.n_rows * 4, hipMemcpyDeviceToDevice, h.stream));
+    hipLaunchKernelGGL(k_d64_results, grid_for(t.n_rows, kBlock, 4096), kBlock, 0, h.stream, (unsigned long long const*)dist.data(), (int32_t const*)pred.data(), t.n_rows,
+                       dst->buf.as<double>(), with_pred ? preds->buf.as<int32_t>() : (int32_t*)nullptr);
+  }
+  h.sync();
+  h.last_stats       = cugraph_amd_traversal_stats_t{};
+  h.last_stats.steps = rounds;
+  return new paths_result_t{ids.release(), dst.release(), preds.release()};
+}
+}  // namespace
+
 paths_result_t* mg_run_sssp(handle_t& h, graph_t& g, size_t source, double cutoff, bool with_pred)
 {
   HIP_TRY(hipSetDevice(h.device));
   CGA_EXPECTS(handle_comm(h) == g.mg->comm, CUGRAPH_INVALID_HANDLE, "multi-GPU SSSP: the handle is not on the communicator the graph was created on");
   CGA_EXPECTS(g.has_weights, CUGRAPH_INVALID_INPUT, "cugraph_sssp requires a weighted graph");  // sssp.cpp:72-73,105
-  CGA_EXPECTS(g.weight_type == FLOAT32, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "multi-GPU SSSP takes FLOAT32 weights in this build");
+  if (g.weight_type == FLOAT64) return mg_run_sssp_f64(h, g, source, cutoff, with_pred);
   comm_t& c = *g.mg->comm;
   mg_traversal_part_t& t = mg_traversal_part(h, g, true);
   mg_traversal_run_t& r  = ensure_run(h, g, t, 1);

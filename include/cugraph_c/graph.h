@@ -63,10 +63,13 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_graph_create_sg_from_csr(
   bool_t symmetrize, bool_t do_expensive_check, cugraph_graph_t** graph, cugraph_error_t** error);
 
 /* Per-rank collective creation (cpp/include/cugraph_c/graph.h:238-327, impl cpp/src/c_api/graph_mg.cpp:326-560; called by
- * pylibcugraph.MGGraph, graphs.pyx:648): `num_arrays` arrays of views per column.  Served on one-rank handles (the arrays are
- * concatenated; the graph is renumbered as every MG graph is); a multi-rank handle gets CUGRAPH_NOT_IMPLEMENTED -- the
- * multi-GPU graph of this library sits behind the plan API of include/cugraph_amd/extensions.h (one process per GPU,
- * torch.distributed over RCCL in the host layer). */
+ * pylibcugraph.MGGraph, graphs.pyx:648): `num_arrays` arrays of views per column, concatenated.  On a handle created with NULL the
+ * graph is a single-GPU graph (renumbered as every MG graph is).  On a handle created on the library's communicator
+ * (include/cugraph_amd/extensions.h: cugraph_amd_comm_create; one process per GPU) the call is COLLECTIVE: every rank passes its slice of
+ * the edges (and, optionally, of the vertex list) of ONE graph partitioned over the ranks; INT32 ids, FLOAT32 / FLOAT64 weights;
+ * drop_self_loops / drop_multi_edges / symmetrize act on the whole graph.  cugraph_pagerank / _personalized_pagerank (all optional
+ * arguments), cugraph_bfs, cugraph_sssp, cugraph_louvain, cugraph_degrees / _in_degrees / _out_degrees and cugraph_has_vertex run on
+ * such a graph; the other entry points answer CUGRAPH_NOT_IMPLEMENTED for it.  edge ids / types / times are validated and not kept. */
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_graph_create_mg(
   cugraph_resource_handle_t const* handle, cugraph_graph_properties_t const* properties,
   cugraph_type_erased_device_array_view_t const* const* vertices, cugraph_type_erased_device_array_view_t const* const* src,

@@ -17,4 +17,9 @@ done
 gcc $CFLAGS -Dmain=reference_main "$T/create_graph_test.c" -c -o "$O/create_graph_test.o"
 gcc $CFLAGS -DCGA_CREATE_GRAPH_MAIN "$R/tests/c_api/ref_test_shim.c" "$O/create_graph_test.o" -o "$O/create_graph_test" $LDFLAGS
 rm -f "$O/create_graph_test.o"
+# the reference's multi-GPU tests: the same sources a maintainer runs under mpirun; here the helper library forks the ranks
+# (tests/c_api/ref_mg_test_shim.c) on this library's own communicator
+for name in mg_pagerank_test mg_bfs_test mg_sssp_test mg_louvain_test mg_create_graph_test mg_degrees_test mg_generate_rmat_test; do
+  gcc $CFLAGS "$T/$name.c" "$R/tests/c_api/ref_mg_test_shim.c" -o "$O/$name" $LDFLAGS
+done
 ls "$O"

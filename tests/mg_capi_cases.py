@@ -19,6 +19,20 @@ def rmat_slice(scale, rank, size, edge_factor=16, seed=0):
     return orc.rmat(scale, max(0, min(per, ne - first)), seed=seed, first_edge=first), first
 
 
+def ppr_inputs(scale):
+    """personalization pairs (with a repeated vertex), an initial guess and precomputed out-weight sums (= the true out-degrees: the result
+    must equal the run without them) for the RMAT graph of `scale`; the same on every rank and in the checker"""
+    nv = 1 << scale
+    rng = np.random.default_rng(11)
+    pv = rng.choice(nv, size=97, replace=False).astype(np.int32)
+    pv = np.concatenate([pv, pv[:3]])
+    pval = rng.random(pv.size).astype(np.float32) + np.float32(0.1)
+    guess = (rng.random(nv).astype(np.float32) + np.float32(0.5)) / np.float32(nv)
+    (s, _), _ = rmat_slice(scale, 0, 1)
+    outw = np.bincount(s, minlength=nv).astype(np.float32)
+    return pv, pval, guess, outw
+
+
 def run(what, cg, h, comm, rank, size, outdir, args):
     out = {}
     if what == "pagerank":
@@ -38,6 +52,29 @@ def run(what, cg, h, comm, rank, size, outdir, args):
         v2, x2, _ = cg.pagerank(h, g, None, None, None, None, 0.85, eps, max_iter, False, fail_on_nonconvergence=False)
         out["repeat_equal"] = bool(torch.equal(v, v2) and torch.equal(x, x2))
         del g
+    elif what == "ppr":
+        # the optional arguments of cugraph_personalized_pagerank on a multi-GPU graph: every rank hands over a SLICE of each (vertices, values)
+        # list, naming vertices other ranks own (the library routes the pairs)
+        scale, max_iter = int(args[0]), int(args[1])
+        (s, d), first = rmat_slice(scale, rank, size)
+        nv = 1 << scale
+        verts = np.arange(rank, nv, size, dtype=np.int32)
+        g = cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [T(s)], [T(d)], None, store_transposed=True, vertices_array=[T(verts)])
+        pv, pval, guess, outw = ppr_inputs(scale)
+        cut = lambda a: a[(rank * a.size) // size: ((rank + 1) * a.size) // size].copy()  # noqa: E731
+        allv = np.arange(nv, dtype=np.int32)[::-1].copy()  # (descending: a rank's slice names mostly other ranks' vertices)
+        v, x, _ = cg.personalized_pagerank(h, g, T(cut(allv)), T(cut(outw[allv])), T(cut(allv)), T(cut(guess[allv])), T(cut(pv)), T(cut(pval)), 0.85, 0.0, max_iter,
+                                           False, fail_on_nonconvergence=False)
+        np.savez(outdir / f"rank{rank}.npz", v=v.cpu().numpy(), x=x.cpu().numpy())
+        out["rows"] = int(v.numel())
+        # a vertex that is not in the graph: INVALID_INPUT on every rank
+        try:
+            cg.personalized_pagerank(h, g, None, None, None, None, T(np.array([nv + 5], np.int32) if rank == 0 else np.zeros(0, np.int32)),
+                                     T(np.array([1.0], np.float32) if rank == 0 else np.zeros(0, np.float32)), 0.85, 0.0, 2, False, fail_on_nonconvergence=False)
+            out["bad_vertex"] = "accepted"
+        except Exception as e:  # noqa: BLE001
+            out["bad_vertex"] = str(e)
+        del g
     elif what in ("bfs", "sssp"):
         scale, n_roots, with_pred = int(args[0]), int(args[1]), args[2] == "p"
         (s, d), first = rmat_slice(scale, rank, size)
@@ -46,7 +83,9 @@ def run(what, cg, h, comm, rank, size, outdir, args):
         w = None
         if what == "sssp":
             kind = args[3]
-            wall = (np.random.default_rng(1).integers(1, 256, size=16 << scale).astype(np.float32) if kind == "int" else np.ones(16 << scale, np.float32))
+            wall = (np.ones(16 << scale, np.float32) if kind == "unit" else np.random.default_rng(1).integers(1, 256, size=16 << scale).astype(np.float32))
+            if kind == "f64":  # FLOAT64 weights (the plain exchange loop): the integer weights + a fraction that float32 cannot hold
+                wall = wall.astype(np.float64) + 1.0 / 3.0
             w = wall[first: first + s.size].copy()
         g = cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [T(s)], [T(d)], None if w is None else [T(w)], store_transposed=False, vertices_array=[T(verts)])
         # roots: the same list on every rank (vertices with out-edges, fixed seed); BFS hands every rank a SLICE of it (the union is the source set)

@@ -100,6 +100,30 @@ def test_mg_capi_pagerank_converges_like_single_gpu(orc, tmp_path):
     np.testing.assert_allclose(pr, t, rtol=1e-4)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_mg_capi_personalized_pagerank_with_guess_and_out_weights(orc, tmp_path, world):
+    """cugraph_personalized_pagerank on a multi-GPU graph with all three optional (vertices, values) arguments, each rank passing a slice that
+    names other ranks' vertices: against the oracle (personalization with a repeated vertex, un-normalised initial guess, precomputed
+    out-weight sums) at a fixed iteration count; an id that is no vertex is refused on every rank."""
+    from mg_capi_cases import ppr_inputs
+    from test_mg import rmat_graph
+
+    scale, iters = 11, 10
+    res = run_ranks("ppr", world, tmp_path, scale, iters)
+    nv = 1 << scale
+    assert sum(r["rows"] for r in res) == nv
+    assert all("not in the graph" in r["bad_vertex"] for r in res), [r["bad_vertex"] for r in res]
+    pr = _assemble(tmp_path, world, nv)
+    s, d = rmat_graph(orc, scale)
+    off, idx, ww = orc.coo_to_cs(nv, d, s, None)
+    pv, pval, guess, outw = ppr_inputs(scale)
+    t, _, _ = orc.pagerank(nv, off, idx, ww, 0.85, 0.0, iters, personalization=(pv, pval), initial_guess=guess, precomputed_outw=outw, acc64=True)
+    assert np.max(np.abs(pr - t)) <= 1e-6
+    nz = t > 1e-9
+    assert np.max(np.abs(pr[nz] - t[nz]) / t[nz]) <= 5e-5
+
+
 def _assemble_paths(tmp_path, world, nv, k):
     res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     seen = np.zeros(nv, np.int32)
@@ -164,6 +188,50 @@ def test_mg_capi_sssp(orc, tmp_path, world, kind):
             od, _ = orc.bfs(nv, off, idx, np.asarray([roots[k]], np.int32), 2**31 - 1)
             want = np.where(od == 2**31 - 1, np.finfo(np.float32).max, od.astype(np.float32)).astype(np.float32)
             assert np.array_equal(dist.view(np.uint32), want.view(np.uint32))  # unit weights: the BFS distances, bit for bit
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_mg_capi_sssp_float64(orc, tmp_path, world):
+    """cugraph_sssp on a multi-GPU graph with FLOAT64 weights (integer + 1/3: not float32 values): distances equal Dijkstra's in double to the last
+    bit, DBL_MAX where unreached, minimum-external-id parents among the tight in-edges"""
+    from test_mg_traversal import graph, min_ext_parent
+
+    scale, n_roots = 11, 2
+    run_ranks("sssp", world, tmp_path, scale, n_roots, "p", "f64")
+    nv, s, d, w, off, idx, ww = graph(orc, scale, weighted=True)
+    w64, ww64 = w.astype(np.float64) + 1.0 / 3.0, ww.astype(np.float64) + 1.0 / 3.0
+    for k in range(n_roots):
+        roots, dist, pred = _assemble_paths(tmp_path, world, nv, k)
+        assert dist.dtype == np.float64
+        od = dijkstra_f64(nv, off, idx, ww64, int(roots[k]))
+        assert np.array_equal(dist, od)
+        dmax = np.finfo(np.float64).max
+        ok = (od[s] != dmax) & (od[d] != dmax) & (od[s] + w64 == od[d])
+        want = min_ext_parent(nv, s, d, ok)
+        want[int(roots[k])] = -1
+        assert np.array_equal(pred, want)
+
+
+def dijkstra_f64(nv, off, idx, w, source):
+    """plain binary-heap Dijkstra in double (checker for the FLOAT64 case; the distances of a shortest-path tree do not depend on the order
+    relaxations are tried in: min over paths of left-to-right sums along the path -- every algorithm that only ever forms dist[u] + w(u, v) agrees)"""
+    import heapq
+
+    dist = np.full(nv, np.finfo(np.float64).max)
+    dist[source] = 0.0
+    heap = [(0.0, source)]
+    while heap:
+        du, u = heapq.heappop(heap)
+        if du > dist[u]:
+            continue
+        for p in range(off[u], off[u + 1]):
+            nd = du + w[p]
+            v = idx[p]
+            if nd < dist[v]:
+                dist[v] = nd
+                heapq.heappush(heap, (nd, v))
+    return dist
 
 
 def _assemble_clusters(tmp_path, world, nv):
