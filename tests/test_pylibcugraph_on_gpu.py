@@ -81,3 +81,14 @@ def test_pylibcugraph_mggraph_on_ranks_sharing_one_gpu(world, tmp_path):
     d = merged("karate_sssp", "d")
     k = res[0]["karate_sssp"]
     np.testing.assert_allclose([d[v] for v in k["want_v"]], np.array(k["want_d"], np.float32), rtol=1e-4)
+    pr = merged("capi_ppr", "x")
+    want = res[0]["capi_ppr"]["want"]
+    assert sorted(pr) == list(range(len(want))) and np.allclose([pr[v] for v in range(len(want))], want, rtol=1e-3)
+    d, p = merged("sssp_f64", "d"), merged("sssp_f64", "p")
+    k = res[0]["sssp_f64"]
+    np.testing.assert_allclose([d[v] for v in sorted(d)], k["want_d"], rtol=1e-12)
+    assert [p[v] for v in sorted(p)] == k["want_p"]
+    din, dout = merged("degrees", "in"), merged("degrees", "out")
+    k = res[0]["degrees"]
+    nv = max(max(k["src"]), max(k["dst"])) + 1
+    assert [din[v] for v in range(nv)] == np.bincount(k["dst"], minlength=nv).tolist() and [dout[v] for v in range(nv)] == np.bincount(k["src"], minlength=nv).tolist()
