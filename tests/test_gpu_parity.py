@@ -1163,6 +1163,37 @@ def test_louvain_hash_path_equals_sorted_path(cg, handle, orc, monkeypatch, scal
     assert np.array_equal(res["1hash"][0], oc) and abs(res["1hash"][1] - oq) <= 1e-9
 
 
+@pytest.mark.parametrize("scale", [22, 26])
+def test_pagerank_rmat_golden(cg, handle, scale):
+    """PageRank at the size the headline number is quoted on (RMAT-26, 1.07 G edges: bench.py's graph, built here by the library's generator)
+    against the C oracle's result after 20 fixed iterations -- the fixture holds the oracle's values at 4096 vertices (the 64 of highest
+    in-degree, random ones with and without in-edges: tests/golden/make_pagerank_fixture.py) and the sum: 1e-6 absolute and 2e-5 relative
+    at every one of them, as the full-vector comparison at RMAT-22 (test_pagerank_config2_rmat22_vs_oracle).  RMAT-22 checks the fixture
+    mechanism against that test's graph."""
+    import json
+    from pathlib import Path
+
+    import torch
+
+    f = Path(__file__).resolve().parent / "golden" / f"pagerank_rmat{scale}.json"
+    if not f.exists():
+        pytest.skip(f"{f.name} not committed")
+    gold = json.loads(f.read_text())
+    nv, ne = 1 << scale, gold["edge_factor"] << scale
+    src, dst = cg.generate_rmat_edgelist(handle, scale, ne)
+    g = cg.SGGraph(handle, cg.GraphProperties(is_multigraph=True), src, dst, None, store_transposed=True, renumber=True,
+                   vertices_array=torch.arange(nv, dtype=torch.int32, device="cuda"))
+    del src, dst
+    v, pr, _ = cg.pagerank(handle, g, None, None, None, None, gold["alpha"], 0.0, gold["iterations"], False, fail_on_nonconvergence=False)
+    full = torch.empty(nv, dtype=torch.float32, device="cuda")
+    full[v.long()] = pr
+    assert abs(float(full.double().sum()) - gold["sum"]) <= 1e-5
+    got = full[torch.tensor(gold["vertices"], device="cuda")].double().cpu().numpy()
+    want = np.asarray(gold["values"])
+    assert np.max(np.abs(got - want)) <= 1e-6
+    assert np.max(np.abs(got - want) / np.maximum(want, 1e-30)) <= 2e-5
+
+
 @pytest.mark.parametrize("scale", [22, 24, 26])
 def test_louvain_rmat_golden(cg, handle, scale):
     """Louvain at the sizes its timings are quoted on (RMAT-22: 65 M directed edges, the single-GPU bench line; RMAT-24; RMAT-26: 1.06 G, BASELINE
