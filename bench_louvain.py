@@ -72,7 +72,7 @@ def louvain_bench(cg, h, scale=22, edge_factor=8, repeats=3, cpu_scale=18):
         "directed_edges_per_second": round(ne / best, 1), "edge_sweeps_per_second": round(work["edges_inspected"] / best, 1), "dtype": "f64", "data": "synthetic",
         "roofline": {"bound": "hbm", "achieved": round(alg / best / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / best / 1e9 / 8000.0, 4),
                      "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes": int(alg),
-                     "kernel": "whole call (all levels: sort + segment passes + contraction); 16 B x edge-sweeps + 28 B x vertex-sweeps + 32 B x contracted edges"},
+                     "kernel": "whole call (all levels: evaluation sweeps over LDS tables, moves, contraction by radix sort); 16 B x edge-sweeps + 28 B x vertex-sweeps + 32 B x contracted edges"},
     }
     # the returned clustering's modularity, recomputed from the edge list with torch (fp64), must be the reported one
     # (prefix sums over the source-sorted edge list and over the cluster-sorted vertices: fp64 atomics -- index_add_ -- take seconds here)
