@@ -128,6 +128,19 @@ def run_single(args):
             del plan2
         finally:
             os.environ.pop("CUGRAPH_AMD_PAGERANK_DIFF", None)
+        # besides the fixed-count run, the run a user makes -- the ordinary entry point (plan + iterations + result, one
+        # call) with epsilon = 1e-6: iterations to converge and end-to-end time of the call (graph construction excluded, as above)
+        h.sync()
+        t0 = time.perf_counter()
+        _, _, conv = cg.pagerank(h, g, None, None, None, None, 0.85, 1e-6, 500, False, fail_on_nonconvergence=False)
+        torch.cuda.synchronize()
+        api_s = time.perf_counter() - t0
+        plan3 = cg.PageRankPlan(h, g, 0.85)
+        n_it, conv3 = plan3.step(500, epsilon=1e-6)
+        del plan3
+        check["converging_run"] = {"epsilon": 1e-6, "iterations": int(n_it), "converged": bool(conv3) and (conv is None or bool(conv)),
+                                   "api_call_seconds": round(api_s, 4), "what": "cugraph_pagerank_allow_nonconvergence(alpha 0.85, epsilon 1e-6, max 500): plan "
+                                   "construction + iterations (L1 change read back every iteration) + result columns, one call on the built graph"}
     return nv, ne, dt, launches, kernel_ms, build_s, launches2, kernel2_ms, plan_s, check
 
 
