@@ -52,6 +52,7 @@ def main_partitioned_ipc(args):
     g = cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [src], [dst], [w], store_transposed=False, vertices_array=[verts])
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
+    src_k, dst_k, w_k = src, dst, w  # (kept: the check tests this rank's slice of the edges)
     del src, dst, w, verts
     cand = torch.nonzero(outdeg > 0).flatten().cpu()
     perm = torch.randperm(cand.numel(), generator=torch.Generator().manual_seed(0))[: args.roots]
@@ -59,8 +60,54 @@ def main_partitioned_ipc(args):
     outdeg_f = outdeg.to(torch.float64)
     empty = torch.zeros(0, dtype=torch.int32, device="cuda")
 
+    import tempfile
+
+    import numpy as np
+
+    share = Path(tempfile.gettempdir()) / f"cugraph_amd_part_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}"
+    share.mkdir(parents=True, exist_ok=True)
+
+    def fixed_point_check(kind, v, d, root):
+        """OUTSIDE the timed region, on the last root's result: the distances must be THE fixed point of d[v] = min over in-edges (d[u] + w).  Every
+        rank saves the (vertex, distance) pairs it got back; the vector is assembled from the files (one node: a shared directory), and every
+        rank tests ITS slice of the edge list: no edge may offer less than its destination holds (<=), and over all ranks every reached vertex
+        but the root must be ATTAINED by some edge (the ranks' per-vertex minima are merged by rank 0)."""
+        np.save(share / f"{kind}_v{rank}.npy", v.cpu().numpy())
+        np.save(share / f"{kind}_d{rank}.npy", d.cpu().numpy())
+        comm.barrier()
+        full = torch.empty(nv, dtype=d.dtype, device="cuda")
+        seen = torch.zeros(nv, dtype=torch.int32, device="cuda")
+        for r in range(world):
+            vv = torch.from_numpy(np.load(share / f"{kind}_v{r}.npy")).cuda().long()
+            full[vv] = torch.from_numpy(np.load(share / f"{kind}_d{r}.npy")).cuda()
+            seen[vv] += 1
+        inf = 2**31 - 1 if kind == "bfs" else float(torch.finfo(torch.float32).max)
+        if kind == "bfs":
+            full = full.to(torch.int64)
+        du = full[src_k.long()]
+        cand = torch.where(du == inf, du, du + (1 if kind == "bfs" else w_k))
+        too_low = int((cand < full[dst_k.long()]).sum())  # an edge that offers less than its destination holds
+        best = torch.full((nv,), inf, dtype=full.dtype, device="cuda")
+        best.scatter_reduce_(0, dst_k.long(), cand, "amin", include_self=True)
+        np.save(share / f"{kind}_b{rank}.npy", best.cpu().numpy())
+        comm.barrier()
+        res = None
+        if rank == 0:
+            for r in range(1, world):
+                best = torch.minimum(best, torch.from_numpy(np.load(share / f"{kind}_b{r}.npy")).cuda())
+            best[root] = 0
+            res = {"not_attained": int((best != full).sum()), "every_vertex_once": bool((seen == 1).all()), "reached": int((full != inf).sum())}
+        lows = sum(int(x[0]) for x in comm.allgather_f64([float(too_low)]))
+        if rank == 0:
+            res.update({"edges_offering_less": lows, "root": int(root), "ok": lows == 0 and res["not_attained"] == 0 and res["every_vertex_once"],
+                        "what": "d[v] == min over in-edges (d[u] + w), d[root] == 0 on the last root's result: every rank tests its slice of the edges against the "
+                                "assembled distance vector (bit for bit)"})
+        comm.barrier()
+        return res
+
     def run(kind):
         times, teps, levels = [], [], []
+        last = None
         for i, r in enumerate([roots[0], roots[-1]] + roots):  # two warm-ups (the first call builds the partition and its windows)
             h.sync()
             comm.barrier()
@@ -80,10 +127,16 @@ def main_partitioned_ipc(args):
                 times.append(dt)
                 teps.append(er / dt)
                 levels.append(h.last_traversal_stats()["steps"])
+            last = (v, d, r)
         hm = len(teps) / sum(1.0 / t for t in teps)
-        return {"ms_mean": round(1e3 * sum(times) / len(times), 3), "ms_median": round(1e3 * sorted(times)[len(times) // 2], 3),
-                "ms_all": [round(1e3 * t, 2) for t in times], "ms_min": round(1e3 * min(times), 3), "ms_max": round(1e3 * max(times), 3),
-                "mteps_harmonic_mean": round(hm / 1e6, 1), "rounds_mean": round(sum(levels) / len(levels), 1)}
+        res = {"ms_mean": round(1e3 * sum(times) / len(times), 3), "ms_median": round(1e3 * sorted(times)[len(times) // 2], 3),
+               "ms_all": [round(1e3 * t, 2) for t in times], "ms_min": round(1e3 * min(times), 3), "ms_max": round(1e3 * max(times), 3),
+               "mteps_harmonic_mean": round(hm / 1e6, 1), "rounds_mean": round(sum(levels) / len(levels), 1)}
+        if not args.no_check:
+            chk = fixed_point_check(kind, *last)
+            if rank == 0:
+                res["check"] = chk
+        return res
 
     out = {"workload": f"partitioned BFS/SSSP through cugraph_graph_create_mg + cugraph_bfs / cugraph_sssp on the library's communicator, RMAT scale {args.scale} "
                        f"edge factor {args.edge_factor}, weights {args.weights}, {world} rank(s)" + (" sharing one GPU" if single and world > 1 else ""),

@@ -1,12 +1,11 @@
 #!/usr/bin/env bash
-# round 4, session ag: plumbing lines of the partitioned traversals and of Louvain on several ranks sharing the GPU (RMAT-24 / RMAT-22; every line carries its check)
+# round 4, session ag: plumbing lines of the partitioned traversals (with the distributed fixed-point check) and of Louvain on several ranks sharing the GPU
 set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"; O="$R/gpurun_out"; mkdir -p "$O"; cd "$R"
 export HSA_ENABLE_IPC_MODE_LEGACY=0 CUGRAPH_AMD_MG_TEST_SINGLE_GPU=1
 for w in 2 4; do
   timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $w --master-addr 127.0.0.1 --master-port $((29600 + RANDOM % 300)) bench_traversal.py --gpus $w --transport ipc --scale 24 --weights int --roots 8 2>"$O/r4ag_part_ipc${w}.err" | grep "^{" > "$O/r4ag_part_ipc${w}_s24.json"; echo "traversal ranks $w rc=$?"; tail -1 "$O/r4ag_part_ipc${w}.err" | cut -c1-200
 done
-timeout 900 python bench_louvain.py --gpus 4 --scale 22 --repeats 2 --out "$O/r4ag_louvain_s22_ranks4.json" > /dev/null 2>&1; echo "louvain ranks 4 rc=$?"
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob("gpurun_out/r4ag_*.json")):
