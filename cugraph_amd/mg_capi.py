@@ -45,6 +45,50 @@ def _bring_up(Comm, ResourceHandle, session, rank, world):
     return comm, h, link
 
 
+def _against_single_gpu(args, comm, rank, world, v, x, iterations, nv, ne):
+    """OUTSIDE the timed region: the distributed vector after `iterations` iterations against the single-GPU entry point run for the same number
+    of iterations on the whole graph by rank 0 (whose result the parity suite pins to the oracle, and bench.py's N = 1 line to an explicit fp64
+    step): the ranks' (vertices, values) are assembled through files (one node), every vertex must come back exactly once."""
+    import tempfile
+    from pathlib import Path
+
+    import numpy as np
+
+    from .pylib import GraphProperties, PageRankPlan, ResourceHandle, SGGraph, generate_rmat_edgelist
+
+    share = Path(tempfile.gettempdir()) / f"cugraph_amd_pr_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}"
+    share.mkdir(parents=True, exist_ok=True)
+    np.save(share / f"v{rank}.npy", v.cpu().numpy())
+    np.save(share / f"x{rank}.npy", x.cpu().numpy())
+    comm.barrier()
+    res = {"vs_single_gpu": {"ok": True}}
+    if rank == 0:
+        full = torch.empty(nv, dtype=x.dtype, device="cuda")
+        seen = torch.zeros(nv, dtype=torch.int32, device="cuda")
+        for r in range(world):
+            vv = torch.from_numpy(np.load(share / f"v{r}.npy")).cuda().long()
+            full[vv] = torch.from_numpy(np.load(share / f"x{r}.npy")).cuda()
+            seen[vv] += 1
+        h1 = ResourceHandle()
+        src, dst = generate_rmat_edgelist(h1, args.scale, ne)
+        g1 = SGGraph(h1, GraphProperties(is_multigraph=True), src, dst, None, store_transposed=True, renumber=True,
+                     vertices_array=torch.arange(nv, dtype=torch.int32, device="cuda"))
+        del src, dst
+        p1 = PageRankPlan(h1, g1, 0.85)
+        p1.step(iterations)
+        v1, x1, _ = p1.result()
+        want = torch.empty(nv, dtype=x1.dtype, device="cuda")
+        want[v1.long()] = x1
+        diff = (full.double() - want.double()).abs()
+        rel = float((diff / want.double().clamp_min(1e-30)).max())
+        res["vs_single_gpu"] = {"iterations": int(iterations), "max_abs": float(diff.max()), "max_rel": rel, "every_vertex_once": bool((seen == 1).all()),
+                                "ok": bool(float(diff.max()) <= 1e-6 and rel <= 2e-5 and bool((seen == 1).all())),
+                                "what": "the assembled distributed vector against cugraph's single-GPU entry point after the same number of iterations on the whole graph"}
+        del p1, g1, h1
+    comm.barrier()
+    return res
+
+
 def bench_main(args):
     """bench.py --gpus N: strong scaling of the SAME RMAT graph over N ranks.  Launched under torch.distributed.run (RANK / WORLD_SIZE /
     LOCAL_RANK / MASTER_PORT from the environment); no process group is created -- the session name of the communicator comes from
@@ -102,6 +146,9 @@ def bench_main(args):
     check = {"mass_err": abs(mass_all - 1.0), "rows": rows_all, "ok": abs(mass_all - 1.0) <= 1e-4 and rows_all == nv,
              "what": "sum of the distributed PageRank vector and number of owned rows over all ranks (the kernels are the single-GPU ones, checked "
                      "against an explicit fp64 step by bench.py at N = 1; tests/test_mg_capi.py checks this path against the oracle)"}
+    if not getattr(args, "no_check", False):
+        check.update(_against_single_gpu(args, comm, rank, world, v, x, args.warmup + args.steps + 3, nv, ne))
+        check["ok"] = bool(check["ok"] and check["vs_single_gpu"]["ok"])
     n_rows = int(v.numel())
     local_edges = int(g.num_local_edges()) if hasattr(g, "num_local_edges") else None
     local_bytes = 4 * (local_edges if local_edges is not None else ne // world) + 16 * n_rows + 4  # this rank's share of 4E + 16V + 4
