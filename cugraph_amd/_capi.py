@@ -183,6 +183,9 @@ PROTOTYPES = {
     "cugraph_amd_traversal_mg_plan_apply": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.POINTER(C.c_size_t), _PP]),
     "cugraph_amd_traversal_mg_plan_frontier_bits": (C.c_int, [_P, _PP, _PP]),
     "cugraph_amd_traversal_mg_plan_merge_visited": (C.c_int, [_P, _P, _PP]),
+    "cugraph_amd_traversal_mg_plan_sssp_set_window": (C.c_int, [_P, C.c_double, _PP]),
+    "cugraph_amd_traversal_mg_plan_sssp_far_stats": (C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_double), _PP]),
+    "cugraph_amd_traversal_mg_plan_sssp_advance": (C.c_int, [_P, C.c_double, C.POINTER(C.c_size_t), _PP]),
     "cugraph_amd_traversal_mg_plan_set_bottom_up": (C.c_int, [_P, _P, _P, _P, _PP]),
     "cugraph_amd_traversal_mg_plan_bottom_up": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(C.c_size_t), _PP]),
     "cugraph_amd_traversal_mg_plan_last_degree_sums": (C.c_int, [_P, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), _PP]),

@@ -88,11 +88,18 @@ struct mg_sssp_state {
   uint32_t* mark;
   int32_t* q_next;
   uint32_t round;
+  // near / far (round 4): an improved row whose distance is below the window's upper bound joins the next frontier, one beyond it the
+  // FAR pile (once per window: far_mark), which cugraph_amd_traversal_mg_plan_sssp_advance splits when the window moves on.  hi_bits =
+  // the bound's float bits (non-negative floats order like their bit patterns); 0x7f7fffff (FLT_MAX): no window, everything is near
+  uint32_t hi_bits, win;
+  uint32_t* far_mark;
+  int32_t* q_far;
+  uint32_t* far_count;
 };
 
 struct mg_sssp_relax {
   mg_sssp_state s;
-  wave_queue wq, wq_own;
+  wave_queue wq, wq_own, wq_far;
   // the phased form (expand_*_mlp of traversal_common.hpp: EX_U edges in flight per lane).  A candidate whose destination THIS rank owns
   // is applied in place -- atomicMin on st[row], round mark, append to the next local frontier -- instead of going through the candidate
   // table, the bucket sort, the (self-)exchange and apply: an improvement is then visible to the rest of the round (Gauss-Seidel) where the
@@ -126,15 +133,21 @@ struct mg_sssp_relax {
     return 0u;
   }
   __device__ __forceinline__ tok2_t mid2(int32_t g, cand_t c, tok_t dropped) const
-  {  // -> 1: list g as a candidate for its owner; 2: append the owned row to the next local frontier
+  {  // -> 1: list g as a candidate for its owner; 2: append the owned row to the next local frontier; 3: to the far pile
     if (!c.pass) return 0u;
-    if (c.own) return (dropped && atomicExch(&s.mark[(uint32_t)g - s.own_lo], s.round) != s.round) ? 2u : 0u;
+    if (c.own) {
+      if (!dropped) return 0u;
+      uint32_t const row = (uint32_t)g - s.own_lo;
+      if ((uint32_t)(c.packed >> 32) < s.hi_bits) return atomicExch(&s.mark[row], s.round) != s.round ? 2u : 0u;
+      return atomicExch(&s.far_mark[row], s.win) != s.win ? 3u : 0u;
+    }
     return !c.claimed ? (uint32_t)!(atomicOr(&s.touched[g >> 5], c.bit) & c.bit) : 0u;
   }
   __device__ __forceinline__ void post(int32_t, int32_t g, cand_t, tok_t, tok2_t what)
   {
     wq.push(what == 1u, g);
     wq_own.push(what == 2u, (int32_t)((uint32_t)g - s.own_lo));
+    wq_far.push(what == 3u, (int32_t)((uint32_t)g - s.own_lo));
   }
 };
 
@@ -160,21 +173,23 @@ __global__ void __launch_bounds__(TV_BLOCK) k_mg_bfs_expand_big(int32_t const* b
 __global__ void __launch_bounds__(TV_BLOCK) k_mg_sssp_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices, int32_t* bigq,
                                                              mg_sssp_state s)
 {
-  __shared__ wave_queue_storage<2> wqs;
+  __shared__ wave_queue_storage<3> wqs;
   wqs.init();
-  mg_sssp_relax f{s, wave_queue(wqs, 0, s.cand, &s.cnt->n_next), wave_queue(wqs, 1, s.q_next, &s.cnt->n_far)};
+  mg_sssp_relax f{s, wave_queue(wqs, 0, s.cand, &s.cnt->n_next), wave_queue(wqs, 1, s.q_next, &s.cnt->n_far), wave_queue(wqs, 2, s.q_far, s.far_count)};
   expand_frontier_mlp(q, n, offsets, indices, bigq, s.cnt, keep_all_mg{}, f);
   f.wq.flush();
   f.wq_own.flush();
+  f.wq_far.flush();
 }
 __global__ void __launch_bounds__(TV_BLOCK) k_mg_sssp_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, mg_sssp_state s)
 {
-  __shared__ wave_queue_storage<2> wqs;
+  __shared__ wave_queue_storage<3> wqs;
   wqs.init();
-  mg_sssp_relax f{s, wave_queue(wqs, 0, s.cand, &s.cnt->n_next), wave_queue(wqs, 1, s.q_next, &s.cnt->n_far)};
+  mg_sssp_relax f{s, wave_queue(wqs, 0, s.cand, &s.cnt->n_next), wave_queue(wqs, 1, s.q_next, &s.cnt->n_far), wave_queue(wqs, 2, s.q_far, s.far_count)};
   expand_big_mlp(bigq, offsets, indices, s.cnt, f);
   f.wq.flush();
   f.wq_own.flush();
+  f.wq_far.flush();
 }
 
 // ---- bucketing by owner: counting sort of the candidate list.  Workgroup b owns the contiguous slice
@@ -273,20 +288,54 @@ __global__ void k_mg_bfs_apply(int32_t const* in, size_t n, int32_t level, int32
   }
 }
 
-__global__ void k_mg_sssp_apply(int32_t const* in, size_t n, uint32_t round, unsigned long long* st, uint32_t* mark, int32_t* q_next, counters_t* cnt)
+__global__ void k_mg_sssp_apply(int32_t const* in, size_t n, uint32_t round, unsigned long long* st, uint32_t* mark, int32_t* q_next, counters_t* cnt,
+                                uint32_t hi_bits, uint32_t win, uint32_t* far_mark, int32_t* q_far, uint32_t* far_count)
 {
   size_t i    = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  bool push   = false;
+  bool push = false, far = false;
   int32_t row = 0;
   if (i < n) {
     row = in[3 * i];
     unsigned long long const packed = ((unsigned long long)(uint32_t)in[3 * i + 1] << 32) | (uint32_t)in[3 * i + 2];
     if (packed < __hip_atomic_load(&st[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
       unsigned long long const old = atomicMin(&st[row], packed);
-      if ((uint32_t)(packed >> 32) < (uint32_t)(old >> 32)) push = atomicExch(&mark[row], round) != round;  // the DISTANCE dropped: expand again
+      if ((uint32_t)(packed >> 32) < (uint32_t)(old >> 32)) {  // the DISTANCE dropped: expand again -- in this window, or when the window reaches it
+        if ((uint32_t)(packed >> 32) < hi_bits) push = atomicExch(&mark[row], round) != round;
+        else far = atomicExch(&far_mark[row], win) != win;
+      }
     }
   }
   wave_push(push, row, q_next, &cnt->n_next, threadIdx.x & 63);
+  wave_push(far, row, q_far, far_count, threadIdx.x & 63);
+}
+
+// the far pile when the window moves from [.., hi_old) to [.., hi_new): rows whose distance has dropped below hi_old were expanded already;
+// rows below hi_new form the next frontier; the rest stay (marked with the new window).  *dmin: smallest distance bits left in the pile.
+__global__ void k_mg_sssp_split(int32_t const* far, uint32_t n, unsigned long long const* st, uint32_t hi_old, uint32_t hi_new, uint32_t round, uint32_t win_new,
+                                uint32_t* mark, uint32_t* far_mark, int32_t* q_front, uint32_t* n_front, int32_t* far_out, uint32_t* n_far_out)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool near = false, keep = false;
+  int32_t row = 0;
+  if (i < n) {
+    row = far[i];
+    uint32_t const d = (uint32_t)(st[row] >> 32);
+    if (d >= hi_old) {
+      if (d < hi_new) near = atomicExch(&mark[row], round) != round;
+      else keep = atomicExch(&far_mark[row], win_new) != win_new;
+    }
+  }
+  wave_push(near, row, q_front, n_front, threadIdx.x & 63);
+  wave_push(keep, row, far_out, n_far_out, threadIdx.x & 63);
+}
+__global__ void k_mg_sssp_far_min(int32_t const* far, uint32_t n, unsigned long long const* st, uint32_t hi, uint32_t* out /*[0] live entries, [1] min bits*/)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t d = 0xFFFFFFFFu;
+  if (i < n) { uint32_t const x = (uint32_t)(st[far[i]] >> 32); if (x >= hi) d = x; }
+  uint32_t live = d != 0xFFFFFFFFu ? 1u : 0u;
+  for (int o = 32; o; o >>= 1) { d = min(d, (uint32_t)__shfl_xor((int)d, o)); live += (uint32_t)__shfl_xor((int)live, o); }
+  if ((threadIdx.x & 63) == 0 && live) { atomicAdd(&out[0], live); atomicMin(&out[1], d); }
 }
 
 __global__ void k_mg_bfs_sources(int32_t const* rows, size_t n, int32_t* dist, int32_t* q, uint32_t* newfront, counters_t* cnt)
@@ -336,6 +385,13 @@ __global__ void k_mg_sssp_results(unsigned long long const* st, size_t n, float*
   if (pred_out) pred_out[i] = reached ? (int32_t)(uint32_t)v - 1 : -1;  // low word = parent + 1; 0 (-> -1) for the sources
 }
 
+inline uint32_t float_bits(float f)
+{
+  uint32_t b;
+  std::memcpy(&b, &f, 4);
+  return b;
+}
+
 template <typename T>
 void fill(handle_t const& h, T* p, size_t n, T v)
 {
@@ -373,6 +429,11 @@ struct traversal_mg_plan {
   uint32_t round{0};
   size_t n_local{0};
   bool own_in_place{true};
+  // SSSP near / far window (cugraph_amd_traversal_mg_plan_sssp_set_window / _far_stats / _advance); hi = FLT_MAX: no window
+  float hi{FLT_MAX};
+  uint32_t win{1};
+  dvec<uint32_t> far_mark, far_count;
+  dvec<int32_t> q_far, q_far2;
   int tuple_words() const { return mode == 0 ? 2 : 3; }
 };
 
@@ -441,6 +502,10 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_create(const cugra
       p->st.resize_discard(n1);
       p->cand_best.resize_discard(G);
       p->mark.resize_discard(n1);
+      p->far_mark.resize_discard(n1);
+      p->q_far.resize_discard(n1);
+      p->q_far2.resize_discard(n1);
+      p->far_count.resize_discard(2);
     }
     h.sync();
     *plan = reinterpret_cast<cugraph_amd_traversal_mg_plan_t*>(p.release());
@@ -491,6 +556,10 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_reset(cugraph_amd_
       fill<unsigned long long>(h, p.st.data(), n1, MG_NONE64);
       fill<unsigned long long>(h, p.cand_best.data(), G, MG_NONE64);
       HIP_TRY(hipMemsetAsync(p.mark.data(), 0, n1 * 4, h.stream));
+      HIP_TRY(hipMemsetAsync(p.far_mark.data(), 0, n1 * 4, h.stream));
+      HIP_TRY(hipMemsetAsync(p.far_count.data(), 0, 2 * sizeof(uint32_t), h.stream));
+      p.hi  = FLT_MAX;  // no window until the driver sets one (cugraph_amd/mg_traversal.py never does)
+      p.win = 1;
       if (n_sources) hipLaunchKernelGGL(k_mg_sssp_sources, g, 256, 0, h.stream, source_rows, n_sources, p.st.data(), p.q_cur, p.cnt.data());
     }
     counters_t c{};
@@ -520,7 +589,8 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_expand(cugraph_amd
         hipLaunchKernelGGL(k_mg_bfs_expand_big, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)p.bigq.data(), p.offsets, p.indices, s);
       } else {
         mg_sssp_state s{p.st.data(), p.cand_best.data(), p.touched.data(), p.weights, p.row_vertex, p.cand.data(), p.cnt.data(), p.cutoff,
-                        (uint32_t)((size_t)p.rank * p.L), p.own_in_place ? (uint32_t)p.n_rows : 0u, p.mark.data(), p.q_next, p.round};
+                        (uint32_t)((size_t)p.rank * p.L), p.own_in_place ? (uint32_t)p.n_rows : 0u, p.mark.data(), p.q_next, p.round,
+                        float_bits(p.hi), p.win, p.far_mark.data(), p.q_far.data(), p.far_count.data()};
         hipLaunchKernelGGL(k_mg_sssp_expand, g, TV_BLOCK, 0, h.stream, (int32_t const*)p.q_cur, n, p.offsets, p.indices, p.bigq.data(), s);
         hipLaunchKernelGGL(k_mg_sssp_expand_big, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)p.bigq.data(), p.offsets, p.indices, s);
       }
@@ -581,7 +651,8 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_apply(cugraph_amd_
         hipLaunchKernelGGL(k_mg_bfs_apply, g, 256, 0, h.stream, recv, n_tuples, (int32_t)level, p.dist.data(), p.with_pred ? p.pred.data() : (int32_t*)nullptr,
                            p.q_next, p.newfront.data(), p.cnt.data(), p.offsets, p.in_offsets);
       else
-        hipLaunchKernelGGL(k_mg_sssp_apply, g, 256, 0, h.stream, recv, n_tuples, p.round, p.st.data(), p.mark.data(), p.q_next, p.cnt.data());
+        hipLaunchKernelGGL(k_mg_sssp_apply, g, 256, 0, h.stream, recv, n_tuples, p.round, p.st.data(), p.mark.data(), p.q_next, p.cnt.data(), float_bits(p.hi), p.win,
+                           p.far_mark.data(), p.q_far.data(), p.far_count.data());
     }
     counters_t c{};
     h.read_back(&c, p.cnt.data(), 1);
@@ -592,6 +663,69 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_apply(cugraph_amd_
     p.last_out   = c.out_edges;
     p.last_in    = c.in_edges;
     *n_next      = c.n_next;
+  });
+}
+
+/* SSSP near / far (sssp_impl.cuh:376-561 partitioned): rows whose distance drops to a value at or beyond `hi` wait in a per-rank far pile instead
+   of joining the next frontier.  The caller -- all ranks together -- runs rounds until the frontier is empty everywhere, asks every rank for
+   (entries still beyond the window, their smallest distance), picks the next window from the global minimum and calls advance, which splits
+   the pile: the rows below the new bound become the frontier.  The fixed point and the parents do not depend on the windows. */
+extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_sssp_set_window(cugraph_amd_traversal_mg_plan_t* plan, double hi, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr && TP(plan).mode == 1, CUGRAPH_INVALID_INPUT, "SSSP plan expected");
+    TP(plan).hi = hi >= (double)FLT_MAX ? FLT_MAX : (float)hi;
+  });
+}
+extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_sssp_far_stats(cugraph_amd_traversal_mg_plan_t* plan, size_t* n_far, double* min_distance,
+                                                                             cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr && n_far != nullptr && min_distance != nullptr && TP(plan).mode == 1, CUGRAPH_INVALID_INPUT, "SSSP plan / NULL argument");
+    traversal_mg_plan& p = TP(plan);
+    handle_t const& h    = *p.h;
+    HIP_TRY(hipSetDevice(h.device));
+    uint32_t n = 0;
+    h.read_back(&n, p.far_count.data(), 1);
+    CGA_EXPECTS(n <= p.n_rows, CUGRAPH_UNKNOWN_ERROR, "far pile overflowed");
+    dvec<uint32_t> out(2);
+    uint32_t const init[2] = {0u, 0xFFFFFFFFu};
+    std::memcpy(h.pinned, init, sizeof(init));
+    HIP_TRY(hipMemcpyAsync(out.data(), h.pinned, sizeof(init), hipMemcpyHostToDevice, h.stream));
+    if (n) hipLaunchKernelGGL(k_mg_sssp_far_min, (int)((n + 255) / 256), 256, 0, h.stream, (int32_t const*)p.q_far.data(), n, (unsigned long long const*)p.st.data(), float_bits(p.hi), out.data());
+    uint32_t got[2];
+    h.read_back(got, out.data(), 2);
+    *n_far = got[0];
+    float f;
+    std::memcpy(&f, &got[1], 4);
+    *min_distance = got[0] ? (double)f : (double)FLT_MAX;
+  });
+}
+extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_sssp_advance(cugraph_amd_traversal_mg_plan_t* plan, double hi_new, size_t* n_frontier,
+                                                                           cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr && n_frontier != nullptr && TP(plan).mode == 1, CUGRAPH_INVALID_INPUT, "SSSP plan / NULL argument");
+    traversal_mg_plan& p = TP(plan);
+    handle_t const& h    = *p.h;
+    HIP_TRY(hipSetDevice(h.device));
+    CGA_EXPECTS(p.n_frontier == 0, CUGRAPH_INVALID_INPUT, "the window may move only when the local frontier is empty");
+    uint32_t n = 0;
+    h.read_back(&n, p.far_count.data(), 1);
+    float const hi_old = p.hi;
+    p.hi               = hi_new >= (double)FLT_MAX ? FLT_MAX : (float)hi_new;
+    ++p.win;
+    ++p.round;
+    HIP_TRY(hipMemsetAsync(p.far_count.data(), 0, 2 * sizeof(uint32_t), h.stream));  // [0]: the new pile, [1]: the new frontier
+    if (n)
+      hipLaunchKernelGGL(k_mg_sssp_split, (int)((n + 255) / 256), 256, 0, h.stream, (int32_t const*)p.q_far.data(), n, (unsigned long long const*)p.st.data(), float_bits(hi_old),
+                         float_bits(p.hi), p.round, p.win, p.mark.data(), p.far_mark.data(), p.q_cur, p.far_count.data() + 1, p.q_far2.data(), p.far_count.data());
+    uint32_t got[2];
+    h.read_back(got, p.far_count.data(), 2);
+    std::swap(p.q_far, p.q_far2);
+    HIP_TRY(hipMemsetAsync(p.far_count.data() + 1, 0, sizeof(uint32_t), h.stream));
+    p.n_frontier = got[1];
+    *n_frontier  = got[1];
   });
 }
 

@@ -154,6 +154,15 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_frontier_bits(
                                                                                 cugraph_error_t** error);
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_merge_visited(cugraph_amd_traversal_mg_plan_t* plan, const uint32_t* gathered,
                                                                                 cugraph_error_t** error);
+/* SSSP near / far windows on a partitioned plan (sssp_impl.cuh:376-561): rows whose distance drops to a value at or beyond `hi` wait in a
+ * per-rank far pile instead of joining the next frontier (reset sets hi = +inf: no window).  All ranks together: rounds until the frontier is
+ * empty everywhere, far_stats on every rank (entries still beyond the window, their smallest distance), the next bound from the global
+ * minimum, advance (splits the pile: the rows below the new bound become the frontier).  The result does not depend on the windows. */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_sssp_set_window(cugraph_amd_traversal_mg_plan_t* plan, double hi, cugraph_error_t** error);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_sssp_far_stats(cugraph_amd_traversal_mg_plan_t* plan, size_t* n_far, double* min_distance,
+                                                                                 cugraph_error_t** error);
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_sssp_advance(cugraph_amd_traversal_mg_plan_t* plan, double hi_new, size_t* n_frontier,
+                                                                               cugraph_error_t** error);
 /* BFS, direction-optimising (replaces the bottom-up branch of bfs_impl.cuh:587-805 for the partitioned case): set_bottom_up hands over the
  * in-edges of the local rows -- in_offsets [n_rows + 1], in_indices = in-neighbours as compact global ids in ascending order of their
  * EXTERNAL id (the first frontier member of a row is then the minimum-external-id parent, the rule of the top-down levels), over-allocated

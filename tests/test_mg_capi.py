@@ -191,6 +191,23 @@ def test_mg_capi_sssp(orc, tmp_path, world, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,env", [(2, {"CUGRAPH_AMD_MG_SSSP_WINDOW": "1"}), (3, {"CUGRAPH_AMD_MG_SSSP_WINDOW": "1", "CUGRAPH_AMD_SSSP_DELTA_SCALE": "0.1"}),
+                                       (2, {"CUGRAPH_AMD_MG_SSSP_WINDOW": "1", "CUGRAPH_AMD_MG_SSSP_INPLACE": "0"})])
+def test_mg_capi_sssp_schedules(orc, tmp_path, world, env):
+    """the opt-in near / far windows of the partitioned SSSP do not change the result: windows of the reference's width, windows a tenth as
+    wide (many window moves, far piles split again and again), every candidate through the exchange (owner-side near / far decision only) --
+    distances bit-identical to Dijkstra, minimum-external-id parents, with a cut-off (the default -- one unbounded window -- runs under every
+    other SSSP test of this file)"""
+    from test_mg_traversal import check_sssp
+
+    scale, n_roots = 12, 2
+    run_ranks("sssp", world, tmp_path, scale, n_roots, "p", "int", 900.0, env_extra=env)
+    for k in range(n_roots):
+        roots, dist, pred = _assemble_paths(tmp_path, world, 1 << scale, k)
+        check_sssp(orc, scale, int(roots[k]), dist, pred, cutoff=900.0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_mg_capi_sssp_float64(orc, tmp_path, world):
     """cugraph_sssp on a multi-GPU graph with FLOAT64 weights (integer + 1/3: not float32 values): distances equal Dijkstra's in double to the last
