@@ -245,19 +245,20 @@ struct timed_launch {  // RAII bracket: records start/stop events when timing is
   handle_t* h;
   kernel_timer* t{nullptr};
   hipEvent_t stop{nullptr};
-  timed_launch(handle_t const& hc, char const* family) : h(const_cast<handle_t*>(&hc))
+  hipStream_t s{nullptr};  // the stream the bracketed launch goes to (default: the handle's)
+  timed_launch(handle_t const& hc, char const* family, hipStream_t stream = nullptr) : h(const_cast<handle_t*>(&hc)), s(stream ? stream : hc.stream)
   {
     if (!h->timing) return;
     t = &h->timers[family];
     hipEvent_t start;
     (void)hipEventCreate(&start);
     (void)hipEventCreate(&stop);
-    (void)hipEventRecord(start, h->stream);
+    (void)hipEventRecord(start, s);
     t->events.emplace_back(start, stop);
   }
   ~timed_launch()
   {
-    if (t) (void)hipEventRecord(stop, h->stream);
+    if (t) (void)hipEventRecord(stop, s);
   }
 };
 

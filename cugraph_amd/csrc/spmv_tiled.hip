@@ -45,6 +45,12 @@ __global__ void k_xcol(uint32_t const* live, uint32_t const* rank, int64_t nv, i
   for (; i < nv; i += stride) xcol[i] = live[i] ? (int32_t)rank[i] : -1;
 }
 
+__global__ void k_gather_u32(uint32_t const* src, uint32_t const* idx, int64_t n, uint32_t* out)
+{
+  int64_t const i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = src[idx[i]];
+}
+
 // first[key] = first position holding that key in a sorted key array (entries of absent keys keep the pre-filled value)
 __global__ void k_first_of_key(uint64_t const* keys, int64_t n, int shift, uint32_t* first)
 {
@@ -312,6 +318,20 @@ std::vector<uint32_t> key_starts(handle_t const& h, uint64_t const* keys, int64_
 
 }  // namespace
 
+std::vector<uint32_t> tiled_overlap_need(tiled_csc_t const& t, bool const_rows, int64_t c0, int64_t n_cols)
+{
+  std::vector<uint32_t> need((size_t)std::max(t.nJ, 1), 0u);
+  auto add = [&](int64_t lo, int64_t hi) {  // a producer of columns [lo, hi)
+    if (hi <= lo) return;
+    for (int64_t J = lo / t.T; J <= (hi - 1) / t.T && J < t.nJ; ++J) ++need[(size_t)J];
+  };
+  int const n_tiles = const_rows ? t.nI_act : t.nI;
+  for (int I = 0; I < n_tiles; ++I) add(t.tile_col0_host[(size_t)I], t.tile_col0_host[(size_t)I + 1]);
+  if (const_rows)
+    for (int64_t b = 0; b * TP2_CONST_COLS < n_cols; ++b) add(c0 + b * TP2_CONST_COLS, c0 + std::min<int64_t>(n_cols, (b + 1) * TP2_CONST_COLS));
+  return need;
+}
+
 int tiled_default_T(handle_t const& h, size_t vsize, int64_t nv)
 {
   // LDS = tile (T values) + one TP_SUB-entry staging row per wavefront + a few static words
@@ -484,12 +504,19 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   t.nI = (int)row0.size() - 1;
   to_device(h, t.tile_row0, row0);
   t.c0 = t.n_act;  // first column of a row >= n_act (identity columns: the row itself)
+  t.tile_col0_host = row0;
   if (live_rank.size()) {
     uint32_t c0 = 0;
     h.read_back(&c0, live_rank.data() + t.n_act, 1);
     t.c0 = c0;
+    // first column of every destination tile (columns are monotone in the row id): which source tiles a phase-2 workgroup feeds
+    dvec<uint32_t> col0(row0.size());
+    hipLaunchKernelGGL(k_gather_u32, grid_for((int64_t)row0.size(), kBlock), kBlock, 0, h.stream, (uint32_t const*)live_rank.data(), (uint32_t const*)t.tile_row0.data(),
+                       (int64_t)row0.size(), col0.data());
+    t.tile_col0_host = to_host(h, col0.data(), row0.size());
     live_rank = dvec<uint32_t>();
   }
+  to_device(h, t.tile_col0, t.tile_col0_host);
 
   tr.step("destination tiles");
   // ---- phase-1 work items (source tile order = hottest tiles first)
@@ -834,6 +861,12 @@ struct p1_args {
   uint32_t pmask, plog, chunk, ncols;
   fin_args<WT> fin;  // scalars of the PREVIOUS iteration, folded by workgroup 0 before it starts streaming
   unsigned long long* dbg{nullptr};  // CUGRAPH_AMD_TILED_DEBUG: per-workgroup (cycles, tile loads)
+  // overlapped iterations (spmv_tiled.hpp, tiled_ovl): x of source tile J is complete when ready[J] has reached need[J] * ovl_launches
+  uint32_t const* ready{nullptr};
+  uint32_t const* need{nullptr};
+  uint32_t ovl_launches{0};
+  uint32_t* counter_next{nullptr};  // the next launch's chunk cursor: rewound by workgroup 0
+  uint32_t* ovl_error{nullptr};
 };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -1140,7 +1173,7 @@ struct p1_iter {  // position in this workgroup's item sequence (all fields wave
   int item, end, pos, tile;
 };
 
-template <typename WT, bool WEIGHTED, bool DBG = false>
+template <typename WT, bool WEIGHTED, bool DBG = false, bool OVL = false>
 __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1151,7 +1184,11 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
   int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   WT* stage = xs + a.T + wave * TP_STAGE;
 
-  if (blockIdx.x == 0 && a.fin.partials) finish_scalars<WT>(a.fin, reinterpret_cast<double*>(smem), tid, TP_BLOCK);
+  if constexpr (OVL) {
+    if (blockIdx.x == 0 && tid == 0) *a.counter_next = 0u;  // nobody uses it before this launch has ended (stream order)
+  } else {
+    if (blockIdx.x == 0 && a.fin.partials) finish_scalars<WT>(a.fin, reinterpret_cast<double*>(smem), tid, TP_BLOCK);
+  }
 
   // Work is handed out dynamically in CHUNKS (a few consecutive work items of one source tile; hottest tiles first, the
   // small cold tiles last); chunk ids are fetched three chunks ahead so the item sequence is known two items ahead.
@@ -1198,6 +1235,22 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
   auto compute_item = [&](p1_regs& rg, p1_runs& q) {
     int const J = I.tile;
     if (J != curJ) {
+      if constexpr (OVL) {
+        // the phase 2 that produces this tile's x may still be running on the other CUs: ONE lane polls the tile's counter (relaxed,
+        // agent scope = an sc1 load that bypasses this CU's L1), then ONE agent-scope acquire (buffer_inv sc1: this CU's L1 holds the
+        // tile's previous contents at most), then the barrier; the tile loads below stay plain.  The producers stored x write-through.
+        uint32_t const target      = a.need[J] * a.ovl_launches;  // wave-uniform: scalar loads
+        uint32_t const* const flag = a.ready + J;
+        if (wave == 0) {  // (wave-uniform branch, every lane reads the same word: the loop lives in scalar registers)
+          uint32_t spins = 0;
+          while ((int32_t)(rfl(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - target) < 0) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > 4000000u) { *a.ovl_error = 1u; break; }  // seconds: a lost producer must not hang the GPU
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+      }
       // x is allocated (and zero-filled) up to nJ * T elements; indices are clamped instead of guarded so that the loads
       // stay straight-line (8 in flight per thread)
       using vec4 = typename std::conditional<sizeof(WT) == 4, float4, double4>::type;
@@ -1252,7 +1305,11 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
     bool const have_next = Jt.item >= 0;
     if (have_next) p1_counts(lane, nxt, qn);
     if (busy) {
-      if (pend.count) p1_writeout<WT>(a, stage, lane, cur.rec, qc, pend.base_c, pend.base_c + pend.count);
+      if (pend.count) {
+        int wl = lane;
+        if constexpr (OVL) asm volatile("" : "+v"(wl));  // (this variant sits one register over the budget: keep lane-derived LDS addresses of the
+        p1_writeout<WT>(a, stage, wl, cur.rec, qc, pend.base_c, pend.base_c + pend.count);  // write-out from being hoisted out of the item loop and spilled)
+      }
 #ifndef CGA_ABL_NOSTORE
       if (lane == 63) vm_st(a.part, qc.slot_tail * (uint32_t)sizeof(WT), tail);  // slot_tail = head slot when no run starts in the range
 #endif
@@ -1301,7 +1358,25 @@ struct p2_args {
   int nI;
   tiled_epilogue<WT> e;
   uint32_t* counters;
+  // overlapped iterations (tiled_ovl): the workgroup counts itself into ready[J] of every source tile J its columns fall into
+  uint32_t const* tile_col0{nullptr};
+  uint32_t* ready{nullptr};
+  int T{0};
+  int n_const{0};  // blocks [0, n_const) are the tiled_const_rows blocks (first: they are cheap and the coldest source tiles wait for them)
 };
+
+// x[c] = v so that a workgroup on another XCD that polls ready[] afterwards reads it: write-through (sc1) store
+template <typename WT>
+__device__ __forceinline__ void store_x_through(WT* p, WT v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// after every wavefront has drained its write-through stores (s_waitcnt vmcnt(0) + barrier): one lane publishes columns [c_lo, c_hi)
+__device__ __forceinline__ void publish_columns(uint32_t* ready, int T, int64_t c_lo, int64_t c_hi)
+{
+  if (c_hi <= c_lo) return;
+  for (int64_t J = c_lo / T; J <= (c_hi - 1) / T; ++J) __hip_atomic_fetch_add(&ready[J], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // fp32 partials are accumulated as signed 64-bit fixed point (value * 2^k, truncated): LDS integer atomics run at
 // full rate on gfx950 while ds_add_f32 is ~5x slower (tools/ubench/lds_update_bench.hip), and integer addition is
@@ -1320,7 +1395,7 @@ __device__ __forceinline__ unsigned long long to_fixed(float v, int k)
 template <typename WT> struct p2_acc { using type = WT; };
 template <> struct p2_acc<float> { using type = unsigned long long; };
 
-template <typename WT, bool PERS>
+template <typename WT, bool PERS, bool OVL = false>
 __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
 {
   using ACC = typename p2_acc<WT>::type;
@@ -1329,16 +1404,27 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
   ACC* acc = reinterpret_cast<ACC*>(smem2);  // [TP2_ROWS]
   __shared__ double red[3 * (TP2_BLOCK / 64)];
   int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int const I   = blockIdx.x;
-  if (a.e.cr.nI_act > 0 && I >= a.e.cr.nI_act) {  // tiled_const_rows: x of the live columns whose rows have no in-edge
+  int I = blockIdx.x, cblock = -1;  // destination tile, or block of tiled_const_rows
+  if constexpr (OVL) {
+    if (I < a.n_const) cblock = I; else I -= a.n_const;
+  } else {
+    if (a.e.cr.nI_act > 0 && I >= a.e.cr.nI_act) cblock = I - a.e.cr.nI_act;
+  }
+  if (cblock >= 0) {  // tiled_const_rows: x of the live columns whose rows have no in-edge
     WT const b       = a.e.scal->base;
     int64_t const n  = a.e.cr.n_cols;
     WT* const xo           = a.e.x_next + a.e.cr.c0;
     int32_t const* const ci = a.e.cr.col_idx;
-    for (int64_t j = (int64_t)(I - a.e.cr.nI_act) * (TP2_BLOCK * 8) + tid, k = 0; k < 8 && j < n; ++k, j += TP2_BLOCK) {
+    for (int64_t j = (int64_t)cblock * TP2_CONST_COLS + tid, k = 0; k < 8 && j < n; ++k, j += TP2_BLOCK) {
       WT const ow = a.e.cr.outw_c[j];
       WT const xv = b / (ow == WT(0) ? WT(1) : ow);
-      if (ci) a.e.x_next[ci[j]] = xv; else xo[j] = xv;
+      if constexpr (OVL) store_x_through<WT>(xo + j, xv);
+      else if (ci) a.e.x_next[ci[j]] = xv; else xo[j] = xv;
+    }
+    if constexpr (OVL) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wavefront drains its write-through stores ...
+      __syncthreads();
+      if (tid == 0) publish_columns(a.ready, a.T, a.e.cr.c0 + (int64_t)cblock * TP2_CONST_COLS, a.e.cr.c0 + min(n, (int64_t)(cblock + 1) * TP2_CONST_COLS));  // ... then one lane counts the block in
     }
     return;
   }
@@ -1430,7 +1516,10 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
       if constexpr (PERS) val += sc.pers_factor * e.pers[v];
       WT const xn = val / (ow[j] == WT(0) ? WT(1) : ow[j]);
       if (e.write_pr) e.pr[v] = val;
-      if (col[j] >= 0) e.x_next[col[j]] = xn;  // sources without out-edges have no column
+      if (col[j] >= 0) {  // sources without out-edges have no column
+        if constexpr (OVL) store_x_through<WT>(e.x_next + col[j], xn);
+        else e.x_next[col[j]] = xn;
+      }
       if (e.need_diff) diff += (double)fabs(val - old[j]);
       xmax = fmax(xmax, fabs((double)xn));
       if (ow[j] == WT(0)) dang += (double)val;
@@ -1440,9 +1529,13 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
   dang = group_sum(dang, 64);
   for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_xor(xmax, o));
   if (lane == 0) { red[3 * wave] = diff; red[3 * wave + 1] = dang; red[3 * wave + 2] = xmax; }
+  if constexpr (OVL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's write-through x stores have left (before the barrier)
   __syncthreads();
+  if constexpr (OVL) {
+    if (tid == 0) publish_columns(a.ready, a.T, (int64_t)a.tile_col0[I], (int64_t)a.tile_col0[I + 1]);
+  }
   if (tid == 0) {  // folded by the next phase-1 launch (or k_tiled_finish): no device-scope fence per workgroup here
-    if (I == 0) a.counters[0] = 0;  // phase 1 is over: rewind its chunk cursor for the next iteration
+    if (!OVL && I == 0) a.counters[0] = 0;  // phase 1 is over: rewind its chunk cursor for the next iteration
     double d0 = 0, d1 = 0, d2 = 0;
 #pragma unroll
     for (int k = 0; k < TP2_BLOCK / 64; ++k) { d0 += red[3 * k]; d1 += red[3 * k + 1]; d2 = fmax(d2, red[3 * k + 2]); }
@@ -1473,8 +1566,27 @@ fin_args<WT> make_fin(tiled_epilogue<WT> const& e, int n)
 
 template <typename WT>
 void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha, WT* part, uint32_t* counters, tiled_x_map<WT> const& map,
-                  tiled_epilogue<WT> const* pending)
+                  tiled_epilogue<WT> const* pending, tiled_ovl const* ovl)
 {
+  if (ovl) {  // overlapped with the previous iteration's phase 2 (tiled_ovl): fewer workgroups than CUs, own stream, polls before tile loads
+    CGA_EXPECTS(t.n_items > 0 && t.n_static_chunks == 0 && pending == nullptr, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: overlapped phase 1 needs a dynamic-only schedule");
+    p1_args<WT> a;
+    a.src16 = t.src16.data(); a.bits = reinterpret_cast<uint8_t const*>(t.bits.data()); a.weights = t.weights.ptr ? t.weights.as<WT const>() : nullptr;
+    a.delta1 = t.delta1.data(); a.wrec = t.wrec.data(); a.chunk_begin = t.chunk_begin.data(); a.n_chunks = t.n_chunks; a.n_static_chunks = 0;
+    a.wg_static = t.wg_static.data();  // all zero: no private chunks
+    a.counter = ovl->cursor; a.counter_next = ovl->cursor_next; a.T = t.T; a.x = x; a.part = part; a.alpha = alpha;
+    a.pmask = map.pmask; a.plog = map.plog; a.chunk = map.chunk; a.ncols = map.ncols;
+    a.ready = ovl->ready; a.need = ovl->need; a.ovl_launches = ovl->launches; a.ovl_error = ovl->error;
+    size_t const lds = ((size_t)t.T + (size_t)TP_WAVES * TP_STAGE) * sizeof(WT) + 64;
+    static bool attr_ovl[2] = {false, false};
+    auto launch = [&](auto kernel, int slot) {
+      if (!attr_ovl[slot]) { ensure_max_lds(kernel, (int)h.lds_per_block); attr_ovl[slot] = true; }
+      timed_launch tl(h, "pagerank_spmv", ovl->stream);
+      hipLaunchKernelGGL(kernel, std::max(1, std::min(ovl->grid, t.n_wg)), TP_BLOCK, lds, ovl->stream, a);
+    };
+    if (a.weights) launch(k_tiled_phase1<WT, true, false, true>, 0); else launch(k_tiled_phase1<WT, false, false, true>, 1);
+    return;
+  }
   if (t.n_items == 0) {
     if (pending) tiled_finish<WT>(h, *pending, tiled_fold_count(t, *pending));
     return;
@@ -1525,7 +1637,7 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
 }
 
 template <typename WT>
-void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters)
+void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters, tiled_ovl const* ovl)
 {
   p2_args<WT> a;
   a.part       = part;
@@ -1542,21 +1654,32 @@ void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled
   if (!attr_done && lds > 48 * 1024) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_tiled_phase2<WT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_tiled_phase2<WT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_tiled_phase2<WT, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_tiled_phase2<WT, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   int grid = t.nI;
-  if (e.cr.nI_act > 0) grid = e.cr.nI_act + (int)((e.cr.n_cols + TP2_BLOCK * 8 - 1) / (TP2_BLOCK * 8));
+  int const n_const = e.cr.nI_act > 0 ? (int)((e.cr.n_cols + TP2_CONST_COLS - 1) / TP2_CONST_COLS) : 0;
+  if (e.cr.nI_act > 0) grid = e.cr.nI_act + n_const;
+  if (ovl) {  // beside the next iteration's phase 1 (tiled_ovl): x stored write-through, every workgroup counts itself into ready[]
+    CGA_EXPECTS(e.raw_y == nullptr && e.cr.col_idx == nullptr, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: overlapped phase 2 is the single-GPU PageRank epilogue");
+    a.tile_col0 = t.tile_col0.data(); a.ready = ovl->ready; a.T = t.T; a.n_const = n_const;
+    timed_launch tl(h, "pagerank_reduce", ovl->stream);
+    if (e.pers) hipLaunchKernelGGL((k_tiled_phase2<WT, true, true>), grid, TP2_BLOCK, lds, ovl->stream, a);
+    else        hipLaunchKernelGGL((k_tiled_phase2<WT, false, true>), grid, TP2_BLOCK, lds, ovl->stream, a);
+    return;
+  }
   timed_launch tl(h, "pagerank_reduce");
   if (e.pers) hipLaunchKernelGGL((k_tiled_phase2<WT, true>), grid, TP2_BLOCK, lds, h.stream, a);
   else        hipLaunchKernelGGL((k_tiled_phase2<WT, false>), grid, TP2_BLOCK, lds, h.stream, a);
 }
 
 template <typename WT>
-void tiled_finish(handle_t const& h, tiled_epilogue<WT> const& e, int n_partials, double init_prev)
+void tiled_finish(handle_t const& h, tiled_epilogue<WT> const& e, int n_partials, double init_prev, hipStream_t stream)
 {
   fin_args<WT> f = make_fin<WT>(e, n_partials);
   f.init_prev    = init_prev;
-  hipLaunchKernelGGL(k_tiled_finish<WT>, 1, TP2_BLOCK, 0, h.stream, f);
+  hipLaunchKernelGGL(k_tiled_finish<WT>, 1, TP2_BLOCK, 0, stream ? stream : h.stream, f);
 }
 
 template <typename WT>
@@ -1576,9 +1699,9 @@ void tiled_scalars_from_ranks(handle_t const& h, tiled_epilogue<WT> const& e, vo
 }
 
 #define CGA_INSTANTIATE_TILED(WT)                                                                                                          \
-  template void tiled_phase1<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT, WT*, uint32_t*, tiled_x_map<WT> const&, tiled_epilogue<WT> const*); \
-  template void tiled_phase2<WT>(handle_t const&, tiled_csc_t const&, WT const*, tiled_epilogue<WT> const&, uint32_t*);                                  \
-  template void tiled_finish<WT>(handle_t const&, tiled_epilogue<WT> const&, int, double);                                                           \
+  template void tiled_phase1<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT, WT*, uint32_t*, tiled_x_map<WT> const&, tiled_epilogue<WT> const*, tiled_ovl const*); \
+  template void tiled_phase2<WT>(handle_t const&, tiled_csc_t const&, WT const*, tiled_epilogue<WT> const&, uint32_t*, tiled_ovl const*);                                  \
+  template void tiled_finish<WT>(handle_t const&, tiled_epilogue<WT> const&, int, double, hipStream_t);                                                           \
   template int tiled_prologue<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT const*, WT*, int64_t, double*, int32_t const*);          \
   template void tiled_scalars_from_ranks<WT>(handle_t const&, tiled_epilogue<WT> const&, void const*, size_t, size_t, int);
 CGA_INSTANTIATE_TILED(float)

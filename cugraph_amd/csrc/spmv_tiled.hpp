@@ -85,6 +85,7 @@ constexpr int TP_CHUNK_BIG = 32;             // chunk length for the first part 
 #endif
 constexpr int TP2_BLOCK = CGA_TP2_BLOCK;     // phase-2 workgroup
 constexpr int TP2_ROWS  = CGA_TP2_ROWS;      // max destination rows per phase-2 tile (64-bit LDS accumulators: 32 KiB at 4096)
+constexpr int TP2_CONST_COLS = TP2_BLOCK * 8;  // columns per tiled_const_rows block of phase 2
 
 struct tiled_wave_t {  // build-time description of one wavefront's share of a work item
   uint32_t es, ee;     // padded edge positions [es, ee); es = item * TP_ITEM + wave * TP_WLEN
@@ -125,6 +126,8 @@ struct tiled_csc_t {
   dvec<int32_t> chunk_begin;  // [n_chunks][4] (unused, first item, end item, source tile) of each chunk (<= TP_CHUNK items of one source tile), largest first
   dvec<int32_t> wg_static;    // [n_wg][2] (first, end) static chunk of each phase-1 workgroup
   dvec<uint32_t> tile_row0;   // [nI + 1] destination tile boundaries
+  dvec<uint32_t> tile_col0;   // [nI + 1] first column (xcol rank) of each destination tile's rows: phase 2 of tile I writes x[tile_col0[I] .. tile_col0[I + 1])
+  std::vector<uint32_t> tile_col0_host;  // the same on the host (tiled_overlap_need)
   dvec<uint32_t> region_off;  // [nI + 2] slot range of region I (multiples of 8); region nI = dummy
   dvec<uint16_t> dstl16;      // [n_slots + pad] tile-local destination of slot (16 bits per slot: tiles of more than 4096 rows)
   dvec<uint32_t> dstl12;      // [n_slots / 8 * 3 + pad] the same packed to 12 bits per slot, 8 slots = 3 dwords (tiles of <= 4096 rows:
@@ -175,21 +178,45 @@ struct tiled_epilogue {
   tiled_const_rows<WT> cr;    // nI_act == 0: off
 };
 
+// Overlap of consecutive iterations: phase 2 of iteration k and phase 1 of iteration k + 1 run at the same time
+// on two streams.  Phase 1 is bound by the CUs (LDS gathers, run scans: the memory system idles through a third of it), phase 2 by the
+// memory system (the CUs idle), and phase 1 of iteration k + 1 needs, for source tile J, only the x entries of that tile -- which the
+// phase-2 workgroups of the few destination tiles whose rows carry those columns wrote.  So: phase 1 is launched with FEWER workgroups
+// than CUs (one workgroup owns a whole CU: its tile fills the LDS), phase 2 of the previous iteration fills the CUs left over, its
+// workgroups store x write-through (sc1), drain, and count themselves into ready[J] of the source tiles they fed; a phase-1 workgroup
+// polls ready[J] (one lane, relaxed) before it loads tile J, then one agent-scope acquire (MI355X_MICROARCH.md, hand-off recipe).
+// The partial buffer is double-buffered (phase 1 of k + 1 writes while phase 2 of k reads), the scalars of an iteration are folded by a
+// one-workgroup launch in phase 2's stream.  Replaces the reference's overlap of communication and compute across
+// num_concurrent_loops streams (prims/detail/per_v_transform_reduce_e.cuh:1845-1906) with an overlap of the two halves of the SpMV.
+struct tiled_ovl {
+  hipStream_t stream{nullptr};     // the stream this launch goes to
+  uint32_t* ready{nullptr};        // [nJ] producers (phase-2 workgroups) that have published into source tile J, monotone over launches
+  uint32_t const* need{nullptr};   // [nJ] producers per launch of phase 2 (tiled_overlap_need)
+  uint32_t launches{0};            // phase 1: overlapped phase-2 launches issued so far: tile J is ready at ready[J] >= need[J] * launches
+  uint32_t* cursor{nullptr};       // phase 1: this launch's chunk cursor (0 on entry) ...
+  uint32_t* cursor_next{nullptr};  // ... and the next launch's, which workgroup 0 rewinds
+  uint32_t* error{nullptr};        // set to 1 when a poll ran into its bound (a bug, not a state: the launch then finishes with stale x)
+  int grid{0};                     // phase 1: workgroups (< CUs: the rest of the chip runs phase 2)
+};
+
+// need[J] = number of phase-2 workgroups (destination tiles, plus the blocks of tiled_const_rows when `const_rows`) whose columns fall into source tile J
+std::vector<uint32_t> tiled_overlap_need(tiled_csc_t const& t, bool const_rows, int64_t c0, int64_t n_cols);
+
 // phase 1: part[slot of run] = sum over the run's edges of alpha * x[src] (* w).  counters[0] = chunk cursor (0 on entry;
 // phase 2 rewinds it).  `pending` != nullptr: the scalars of the
 // previous phase 2 have not been folded yet -- workgroup 0 does it first (saves a launch per iteration).
 template <typename WT>
 void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha, WT* part, uint32_t* counters, tiled_x_map<WT> const& map,
-                  tiled_epilogue<WT> const* pending);
+                  tiled_epilogue<WT> const* pending, tiled_ovl const* ovl = nullptr);
 
 // phase 2 + fused PageRank epilogue; leaves per-tile scalar partials in e.partials (fold them with the next phase 1 or tiled_finish)
 template <typename WT>
-void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters);
+void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters, tiled_ovl const* ovl = nullptr);
 
 // folds e.partials[0 .. n_partials) in a fixed order into e.scal (or e.totals).  init_prev >= 0: this is the fold of the
 // iteration-0 state (tiled_prologue visited every row); scal->base_prev becomes init_prev, the rows' initial value
 template <typename WT>
-void tiled_finish(handle_t const& h, tiled_epilogue<WT> const& e, int n_partials, double init_prev = -1.0);
+void tiled_finish(handle_t const& h, tiled_epilogue<WT> const& e, int n_partials, double init_prev = -1.0, hipStream_t stream = nullptr);
 
 // number of per-tile scalar triples phase 2 leaves for the fold
 template <typename WT>

@@ -612,6 +612,10 @@ class PageRankPlan:
         self.iterations += int(done.value)
         return int(done.value), bool(conv.value)
 
+    def overlap(self):
+        """phase-1 workgroups of an overlapped fixed-count step (0: the iterations run one after the other)"""
+        return int(capi.lib().cugraph_amd_pagerank_plan_overlap(self.ptr))
+
     def result(self, converged=False):
         l = capi.lib()
         res, err = C.c_void_p(), C.c_void_p()

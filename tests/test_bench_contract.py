@@ -27,7 +27,14 @@ def test_bench_line_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     ne, nv = d["config"]["edges"], d["config"]["vertices"]
     assert r["algorithmic_bytes_per_launch"] == 4 * ne + 16 * nv + 4
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
+    if "frac_basis" in r:  # round 5: priced on the wall clock of the timed region (the two kernels of consecutive iterations may overlap)
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
+        if r.get("frac_kernels") is not None:  # serial iterations: the kernels' own time cannot exceed the step
+            assert r["frac_kernels"] >= r["frac"] - 1e-3 and r["avg_kernel_ms"] <= d["ms_per_step"] * 1.001
+        else:
+            assert r.get("overlap")
+    else:
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
     assert abs(d["value"] - ne / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3   # MTEPS = E * iterations / time
     assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]   # real HBM bytes cannot undercut the algorithmic ones
     c = d["cpu_baseline"]

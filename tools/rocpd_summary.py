@@ -75,7 +75,57 @@ def per_dispatch(db, regex):
         print(f"{d:>8} {dur.get(d, 0) / 1e3:>7.1f} " + " ".join(f"{table[d].get(cn, 0):>22,.0f}" for cn in cn_all))
 
 
+def overlap(db, rx_a, rx_b, show=12):
+    """Concurrency of two kernel families in a kernel trace: total time of A, of B, and the time during which a dispatch of A and a
+    dispatch of B were both running (start / end timestamps of the `kernels` view); plus the first `show` dispatches as a timeline."""
+    import re
+
+    c = sqlite3.connect(db)
+    cur = c.cursor()
+    kcols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    st = next((x for x in ("start", "start_timestamp", "begin") if x in kcols), None)
+    en = next((x for x in ("end", "end_timestamp") if x in kcols), None)
+    if st is None or en is None:
+        print("overlap: no start/end columns in", kcols)
+        return
+    rows = cur.execute(f"select name, {st}, {en} from kernels order by {st}").fetchall()
+    a = [(s0, e0) for n, s0, e0 in rows if re.search(rx_a, n)]
+    b = [(s0, e0) for n, s0, e0 in rows if re.search(rx_b, n)]
+    if not a or not b:
+        print(f"overlap: {len(a)} dispatches of /{rx_a}/, {len(b)} of /{rx_b}/ in {db}")
+        return
+    both, j = 0, 0
+    for s0, e0 in a:  # both lists are sorted by start; dispatches of one family do not overlap each other (one stream each)
+        while j < len(b) and b[j][1] <= s0:
+            j += 1
+        k = j
+        while k < len(b) and b[k][0] < e0:
+            both += max(0, min(e0, b[k][1]) - max(s0, b[k][0]))
+            k += 1
+    ta, tb = sum(e0 - s0 for s0, e0 in a), sum(e0 - s0 for s0, e0 in b)
+    span = max(a[-1][1], b[-1][1]) - min(a[0][0], b[0][0])
+    print(f"# overlap {db}")
+    print(f"/{rx_a}/: {len(a)} dispatches, {ta / 1e6:.3f} ms   /{rx_b}/: {len(b)} dispatches, {tb / 1e6:.3f} ms   both running: {both / 1e6:.3f} ms "
+          f"({100 * both / max(tb, 1):.1f} % of B)   first start -> last end: {span / 1e6:.3f} ms   sum A + B: {(ta + tb) / 1e6:.3f} ms")
+    t0 = min(a[0][0], b[0][0])
+    ev = sorted([(s0, e0, "A") for s0, e0 in a[:show]] + [(s0, e0, "B") for s0, e0 in b[:show]])
+    for s0, e0, w in ev:
+        print(f"   {w}  start {(s0 - t0) / 1e3:>10.1f} us  end {(e0 - t0) / 1e3:>10.1f} us  dur {(e0 - s0) / 1e3:>8.1f} us")
+
+
 if __name__ == "__main__":
+    if "--overlap" in sys.argv:
+        i = sys.argv.index("--overlap")
+        rx_a, rx_b = sys.argv[i + 1], sys.argv[i + 2]
+        del sys.argv[i:i + 3]
+        for a in sys.argv[1:]:
+            dbs = [a] if a.endswith(".db") else sorted(glob.glob(os.path.join(a, "**", "*.db"), recursive=True))
+            for d in dbs:
+                try:
+                    overlap(d, rx_a, rx_b)
+                except Exception as e:
+                    print("overlap:", d, e)
+        sys.exit(0)
     if "--per-dispatch" in sys.argv:
         i = sys.argv.index("--per-dispatch")
         rx = sys.argv[i + 1]
