@@ -293,8 +293,8 @@ def counter_traffic(key):
     return e.get("hbm_bytes"), f"profiles/traffic_latest.json[{key}] ({t.get('source', 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes')}; same source hash; not measured by this run)"
 
 
-def traversal_bench(cg, h, scale=24, edge_factor=16, n_roots=64, weights="unit", symmetric=False, predecessors=False, do_sssp=True, cpu_scale=20,
-                    cpu=True, check=True):
+def traversal_bench(cg, h, scale=24, edge_factor=16, n_roots=64, weights="unit", symmetric=False, predecessors=True, do_sssp=True, cpu_scale=20,
+                    cpu=True, check=True, both=True):
     """One Graph500-protocol measurement (see the module docstring); returns the dict of the JSON line."""
     import numpy as np
     import torch
@@ -326,15 +326,16 @@ def traversal_bench(cg, h, scale=24, edge_factor=16, n_roots=64, weights="unit",
     perm = torch.randperm(cand.numel(), generator=torch.Generator().manual_seed(0))[: n_roots]
     roots = cand[perm.to(cand.device)].to(torch.int32)
 
-    def run(kind):
+    def run(kind, pred=None):
+        pred = predecessors if pred is None else pred
         times, edges, steps, inspected = [], [], [], []
         for i, r in enumerate([roots[0], roots[0]] + list(roots)):  # two warm-ups (the second BFS of a directed graph builds its CSC)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             if kind == "bfs":
-                d, p, v = cg.bfs(h, g, r.reshape(1).clone(), False, 0, predecessors, False)
+                d, p, v = cg.bfs(h, g, r.reshape(1).clone(), False, 0, pred, False)
             else:
-                v, d, p = cg.sssp(h, g, int(r), 3.0e38, predecessors, False)
+                v, d, p = cg.sssp(h, g, int(r), 3.0e38, pred, False)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             st = h.last_traversal_stats()
@@ -405,6 +406,17 @@ def traversal_bench(cg, h, scale=24, edge_factor=16, n_roots=64, weights="unit",
     if check:
         out["bfs"]["check"] = bellman_check("bfs", bv, bd)
     out["value"] = out["bfs"]["harmonic_mean_mteps"]
+
+    def other_variant(kind, e_list):
+        """the same roots with the predecessor request flipped (the headline carries `predecessors`; the other figure rides beside it)"""
+        ot, _, _, _ = run(kind, not predecessors)
+        tp = [e / t for e, t in zip(e_list, ot)]
+        ohm = len(tp) / sum(1.0 / x for x in tp)
+        return {"predecessors": not predecessors, "mean_ms": round(1e3 * float(np.mean(ot)), 3), "harmonic_mean_mteps": round(ohm / 1e6, 1),
+                "roofline_frac": roofline(kind, float(np.mean(e_list)), reached[0], float(np.mean(e_list)) / ohm, not predecessors)["frac"]}
+
+    if both:
+        out["bfs"]["distance_only" if predecessors else "with_predecessors"] = other_variant("bfs", be)
     if do_sssp:
         st, _, ss, (sv, sd) = run("sssp")
         teps = [e / t for e, t in zip(be, st)]  # same roots: same reached set, scored on the same edge count
@@ -415,6 +427,8 @@ def traversal_bench(cg, h, scale=24, edge_factor=16, n_roots=64, weights="unit",
                        "roofline": roofline("sssp", float(np.mean(be)), reached[0], t_hm, predecessors)}
         if check:
             out["sssp"]["check"] = bellman_check("sssp", sv, sd)
+        if both:
+            out["sssp"]["distance_only" if predecessors else "with_predecessors"] = other_variant("sssp", be)
         if weights == "unit":  # integer hops: bit-exact against BFS (last root)
             a = torch.empty(nv, dtype=torch.int64, device="cuda"); a[bv.to(torch.int64)] = bd.to(torch.int64)
             b = torch.empty(nv, dtype=torch.float32, device="cuda"); b[sv.to(torch.int64)] = sd
@@ -442,7 +456,10 @@ def main():
     ap.add_argument("--weights", choices=["unit", "int"], default="unit")
     ap.add_argument("--symmetric", action="store_true", help="add the reverse of every edge (Graph500 input)")
     ap.add_argument("--no-sssp", action="store_true")
-    ap.add_argument("--predecessors", action="store_true")
+    ap.add_argument("--predecessors", action="store_true", help="(the default since round 5) the headline figures are WITH predecessors, as python-cugraph asks for "
+                                                                  "them and the Graph500 protocol validates them; the distance-only time rides beside")
+    ap.add_argument("--single-variant", action="store_true", help="measure only the headline variant (counter collection: one traversal per root and kind)")
+    ap.add_argument("--distance-only", action="store_true", help="headline without predecessors (the figures of rounds 1-4); the with-predecessors time rides beside")
     ap.add_argument("--gpus", type=int, default=1, help="> 1 (under torch.distributed.run): the partitioned engine, one rank per GPU")
     ap.add_argument("--partitioned", action="store_true", help="run the partitioned engine even with one rank (comparison with the single-GPU path)")
     ap.add_argument("--transport", choices=["ipc", "rccl"], default=os.environ.get("CUGRAPH_AMD_MG_TRANSPORT", "ipc"),
@@ -453,8 +470,8 @@ def main():
 
     torch.cuda.set_device(0)
     h = cg.ResourceHandle()
-    out = traversal_bench(cg, h, args.scale, args.edge_factor, args.roots, args.weights, args.symmetric, args.predecessors, not args.no_sssp,
-                          args.cpu_scale, not args.no_cpu_baseline, not args.no_check)
+    out = traversal_bench(cg, h, args.scale, args.edge_factor, args.roots, args.weights, args.symmetric, not args.distance_only, not args.no_sssp,
+                          args.cpu_scale, not args.no_cpu_baseline, not args.no_check, not args.single_variant)
     line = json.dumps(out)
     print(line, flush=True)
     if args.out:

@@ -224,6 +224,18 @@ comm_window_t* comm_t::window_create(size_t bytes)
     a = (int)arenas.size() - 1;
   }
   comm_arena_t& ar = arenas[a];
+  {  // the arenas must look the same on every rank: a rank that created or freed windows in another order (a destructor that ran at another
+     // time, an error path taken on one rank only) would carve this one out of another place and its peers would push into the wrong
+     // memory -- silently.  The place is agreed on here, where a host all-gather runs anyway.
+    uint64_t const place[2] = {(uint64_t)a, (uint64_t)ar.top};
+    std::vector<uint64_t> places((size_t)2 * size);
+    host_allgather(place, sizeof(place), places.data());
+    for (int r = 0; r < size; ++r)
+      CGA_EXPECTS(places[2 * r] == place[0] && places[2 * r + 1] == place[1], CUGRAPH_UNKNOWN_ERROR,
+                  "communicator: the ranks' window stacks differ (rank " + std::to_string(r) + " would place this window at arena " + std::to_string(places[2 * r]) + " + " +
+                    std::to_string(places[2 * r + 1]) + ", rank " + std::to_string(rank) + " at arena " + std::to_string(place[0]) + " + " + std::to_string(place[1]) +
+                    "): windows, plans and graphs must be created and freed in the same order on every rank");
+  }
   auto w    = std::make_unique<comm_window_t>();
   w->arena  = a;
   w->offset = ar.top;
@@ -239,7 +251,19 @@ comm_window_t* comm_t::window_create(size_t bytes)
 void comm_t::window_free(comm_window_t* w)
 {
   if (!w) return;
-  host_barrier();  // nobody is still writing into a block that is about to be handed out again
+  {  // every rank frees the SAME window (the all-gather is also the barrier: nobody is still writing into a block that is about to be handed
+     // out again); a mismatch is reported, not repaired -- the arenas of the ranks no longer agree
+    uint64_t const place[2] = {(uint64_t)w->arena, (uint64_t)w->offset};
+    std::vector<uint64_t> places((size_t)2 * size);
+    host_allgather(place, sizeof(place), places.data());
+    bool same = true;
+    for (int r = 0; r < size; ++r) same = same && places[2 * r] == place[0] && places[2 * r + 1] == place[1];
+    if (!same) {
+      if (shm) shm->abort_flag.store(1, std::memory_order_relaxed);
+      fprintf(stderr, "cugraph_amd communicator: rank %d frees the window at arena %d + %zu while a peer frees another one: windows must be freed in the same order on every rank\n",
+              rank, w->arena, w->offset);
+    }
+  }
   comm_arena_t& ar = arenas[w->arena];
   for (auto& lv : ar.live)
     if (lv.first == w->offset && lv.second != 0) { lv.second = 0; break; }

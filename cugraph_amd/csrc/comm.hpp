@@ -87,6 +87,7 @@ struct comm_t {
   uint32_t* err_word{nullptr};          // host-mapped: bit 0 = a wait timed out
   uint64_t seq[kCommChannels]{};        // next sequence number per channel (all ranks advance in lockstep)
   int next_channel{2};                  // 0 = barrier, 1 = build-time collectives; plans allocate from 2
+  std::vector<int> free_channels;       // returned by channel_free: seq[channel] stays monotone, so a channel can be handed out again
   uint64_t wall_ticks_per_s{100000000ull};
 
   // ---- host side (construction time)
@@ -94,7 +95,14 @@ struct comm_t {
   void host_allgather(void const* in, size_t bytes, void* out);  // bytes <= kCommSlotBytes per rank
   comm_window_t* window_create(size_t bytes);                    // collective
   void window_free(comm_window_t* w);                            // collective
-  int channel_alloc() { CGA_EXPECTS(next_channel < kCommChannels, CUGRAPH_UNKNOWN_ERROR, "communicator: out of signal channels"); return next_channel++; }
+  // (collective like everything here: every rank allocates and returns channels in the same order, so all ranks draw the same numbers)
+  int channel_alloc()
+  {
+    if (!free_channels.empty()) { int const c = free_channels.back(); free_channels.pop_back(); return c; }
+    CGA_EXPECTS(next_channel < kCommChannels, CUGRAPH_UNKNOWN_ERROR, "communicator: out of signal channels");
+    return next_channel++;
+  }
+  void channel_free(int channel) { if (channel >= 2) free_channels.push_back(channel); }
   // ---- device side (stream-ordered)
   uint64_t signal(hipStream_t s, int channel);           // returns the sequence number it stored
   void wait(hipStream_t s, int channel, uint64_t seq);   // until every rank's word on `channel` is >= seq

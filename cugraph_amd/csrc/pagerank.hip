@@ -627,6 +627,7 @@ struct pagerank_plan : pagerank_plan_base {
   dvec<WT> part_b;                 // second partial buffer: phase 1 of k + 1 writes while phase 2 of k reads
   dvec<uint32_t> ovl_ready, ovl_need;
   uint32_t ovl_launches{0};        // overlapped phase-2 launches issued by this plan
+  bool const ovl_const_first{getenv("CUGRAPH_AMD_PR_OVERLAP_ORDER") == nullptr || atoi(getenv("CUGRAPH_AMD_PR_OVERLAP_ORDER")) != 0};  // (=0: the serial launch's chunk order)
 
   pagerank_plan(handle_t const& h_, graph_t& g_, double alpha_) : h(h_), g(g_), alpha((WT)alpha_) {}
   ~pagerank_plan() override
@@ -649,7 +650,7 @@ struct pagerank_plan : pagerank_plan_base {
     char const* env = getenv("CUGRAPH_AMD_PR_OVERLAP");
     int want = env ? atoi(env) : kOverlapDefaultGrid;
     if (want <= 0) return;
-    want = std::max(1, std::min({want, tc->n_wg, h.num_cus - 8}));
+    want = std::max(1, std::min({want, tc->n_wg, h.num_cus - 32}));  // (232 and more of 256 hung in round 5's first sweep -- not understood; phase 2 needs its CUs anyway)
     int const n_p2_cus = h.num_cus - want;
     bool const masked = getenv("CUGRAPH_AMD_PR_OVERLAP_MASK") != nullptr;
     auto make_stream = [&](hipStream_t* s, bool phase2_side) {
@@ -697,6 +698,7 @@ struct pagerank_plan : pagerank_plan_base {
       WT* const pbuf = b == 0 ? part.data() : part_b.data();
       tiled_ovl o;
       o.ready = ovl_ready.data(); o.need = ovl_need.data(); o.error = counters.data() + 3; o.grid = ovl_grid;
+      o.const_first = crows.nI_act > 0 && ovl_const_first;
       // phase 1 of iteration k
       if (k >= 2) HIP_TRY(hipStreamWaitEvent(ovl_s1, ovl_e2[b], 0));  // P2(k - 2) has read this partial buffer
       o.stream = ovl_s1; o.launches = ovl_launches; o.cursor = counters.data() + 1 + b; o.cursor_next = counters.data() + 1 + (b ^ 1);
@@ -1753,6 +1755,7 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     try {
       (void)hipStreamSynchronize(h.stream);
       for (int b = 1; b >= 0; --b) { if (swin[b]) c.window_free(swin[b]); if (xwin[b]) c.window_free(xwin[b]); }
+      if (channel >= 2) c.channel_free(channel);  // (64 channels per communicator: a loop of personalized PageRanks used to run out after ~60 calls)
     } catch (...) {
     }
   }

@@ -332,6 +332,33 @@ std::vector<uint32_t> tiled_overlap_need(tiled_csc_t const& t, bool const_rows, 
   return need;
 }
 
+namespace {
+// wmax[I] = max over the rows of destination tile I of sum |w| of the row's in-edges (w == nullptr: the in-degree); one workgroup per tile,
+// one wavefront per row at a time
+template <typename WB>
+__global__ void __launch_bounds__(256) k_tile_wmax(int32_t const* offsets, WB const* w, uint32_t const* tile_row0, double* wmax)
+{
+  __shared__ double red[4];
+  int const I = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t const r0 = tile_row0[I], r1 = tile_row0[I + 1];
+  double best = 0.0;
+  if (w == nullptr) {
+    for (uint32_t r = r0 + threadIdx.x; r < r1; r += 256) best = fmax(best, (double)(offsets[r + 1] - offsets[r]));
+  } else {
+    for (uint32_t r = r0 + wave; r < r1; r += 4) {
+      double s = 0.0;
+      for (int32_t p = offsets[r] + lane; p < offsets[r + 1]; p += 64) s += fabs((double)w[p]);
+      s    = group_sum(s, 64);
+      best = fmax(best, s);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) best = fmax(best, __shfl_xor(best, o));
+  if (lane == 0) red[wave] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) wmax[I] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+}  // namespace
+
 int tiled_default_T(handle_t const& h, size_t vsize, int64_t nv)
 {
   // LDS = tile (T values) + one TP_SUB-entry staging row per wavefront + a few static words
@@ -517,6 +544,13 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     live_rank = dvec<uint32_t>();
   }
   to_device(h, t.tile_col0, t.tile_col0_host);
+  t.tile_wmax.resize_discard((size_t)std::max(t.nI, 1));
+  HIP_TRY(hipMemsetAsync(t.tile_wmax.data(), 0, (size_t)std::max(t.nI, 1) * sizeof(double), h.stream));
+  if (ne > 0 && t.nI > 0) {
+    if (!has_weights) hipLaunchKernelGGL(k_tile_wmax<uint32_t>, t.nI, 256, 0, h.stream, (int32_t const*)csc.offsets.data(), (uint32_t const*)nullptr, (uint32_t const*)t.tile_row0.data(), t.tile_wmax.data());
+    else if (wsize == 4) hipLaunchKernelGGL(k_tile_wmax<float>, t.nI, 256, 0, h.stream, (int32_t const*)csc.offsets.data(), csc.weights.as<float const>(), (uint32_t const*)t.tile_row0.data(), t.tile_wmax.data());
+    else hipLaunchKernelGGL(k_tile_wmax<double>, t.nI, 256, 0, h.stream, (int32_t const*)csc.offsets.data(), csc.weights.as<double const>(), (uint32_t const*)t.tile_row0.data(), t.tile_wmax.data());
+  }
 
   tr.step("destination tiles");
   // ---- phase-1 work items (source tile order = hottest tiles first)
@@ -633,6 +667,19 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     }
     for (auto const& c : ch) { cb.push_back(0); cb.push_back(c.first); cb.push_back(c.first + c.second); cb.push_back(item_tile[c.first]); }
     t.n_chunks = (int)(cb.size() / 4);
+    // Overlapped iterations (tiled_ovl): the source tiles whose columns all belong to rows WITHOUT in-edges (columns >= c0) get their x from the
+    // few cheap tiled_const_rows blocks that phase 2 runs first, i.e. microseconds into the previous iteration's phase 2 -- while tile 0 waits
+    // for the ~4 % of phase 2 that reduce the hottest rows.  A second order of the same chunks puts those tiles first (largest first among
+    // them), then the others as above: phase 1 has work from its first microsecond, and the small chunks of the remaining cold tiles still
+    // balance the finish.
+    t.ovl_first_const_tile = (int)std::min<int64_t>((t.c0 + T - 1) / T, nJ);
+    if (!use_static && !ch.empty()) {
+      std::vector<std::pair<int32_t, int32_t>> ord = ch;
+      std::stable_partition(ord.begin(), ord.end(), [&](auto const& c) { return item_tile[c.first] >= t.ovl_first_const_tile; });
+      std::vector<int32_t> cbo;
+      for (auto const& c : ord) { cbo.push_back(0); cbo.push_back(c.first); cbo.push_back(c.first + c.second); cbo.push_back(item_tile[c.first]); }
+      to_device(h, t.chunk_begin_ovl, cbo);
+    }
     if (cb.empty()) cb.assign(4, 0);
     if (!use_static) t.n_wg = std::max(1, std::min<int>(t.n_chunks, max_wg));
     if (wg_static.empty()) wg_static.assign((size_t)2 * std::max(t.n_wg, 1), 0);
@@ -1244,8 +1291,13 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
         if (wave == 0) {  // (wave-uniform branch, every lane reads the same word: the loop lives in scalar registers)
           uint32_t spins = 0;
           while ((int32_t)(rfl(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - target) < 0) {
-            __builtin_amdgcn_s_sleep(16);
-            if (++spins > 4000000u) { *a.ovl_error = 1u; break; }  // seconds: a lost producer must not hang the GPU
+            __builtin_amdgcn_s_sleep(32);  // ~1 us between polls: 200 pollers on one line must not eat the producers' fabric
+            // a producer that never comes must not hang the GPU: after ~0.3 s the launch gives up (error word; the host throws when the result
+            // is read) and every later poll of the launch -- and of the launches queued behind it -- returns at once
+            if (++spins > 150000u || ((spins & 1023u) == 0u && rfl(__hip_atomic_load(a.ovl_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)) {
+              *a.ovl_error = 1u;
+              break;
+            }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
@@ -1359,6 +1411,7 @@ struct p2_args {
   tiled_epilogue<WT> e;
   uint32_t* counters;
   // overlapped iterations (tiled_ovl): the workgroup counts itself into ready[J] of every source tile J its columns fall into
+  double const* tile_wmax{nullptr};  // tiled_csc_t::tile_wmax (fp32: the fixed-point scale of the tile)
   uint32_t const* tile_col0{nullptr};
   uint32_t* ready{nullptr};
   int T{0};
@@ -1378,24 +1431,13 @@ __device__ __forceinline__ void publish_columns(uint32_t* ready, int T, int64_t 
   for (int64_t J = c_lo / T; J <= (c_hi - 1) / T; ++J) __hip_atomic_fetch_add(&ready[J], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// fp32 partials are accumulated as signed 64-bit fixed point (value * 2^k, truncated): LDS integer atomics run at
-// full rate on gfx950 while ds_add_f32 is ~5x slower (tools/ubench/lds_update_bench.hip), and integer addition is
+// fp32 partials are accumulated as signed 64-bit fixed point (value * 2^k of the tile, rounded to nearest: tiled_to_fixed in spmv_tiled.hpp):
+// LDS integer atomics run at full rate on gfx950 while ds_add_f32 is ~5x slower (tools/ubench/lds_update_bench.hip), and integer addition is
 // associative, so the result does not depend on the order in which wavefronts reach a row (bit-reproducible).
-__device__ __forceinline__ unsigned long long to_fixed(float v, int k)
-{
-  uint32_t const b = __float_as_uint(v);
-  int const e      = (int)((b >> 23) & 0xFFu);
-  unsigned long long m = (unsigned long long)((b & 0x7FFFFFu) | 0x800000u);
-  int const sh     = e - 150 + k;  // v = m * 2^(e - 150)
-  unsigned long long fx = sh >= 0 ? m << min(sh, 63) : m >> min(-sh, 63);
-  fx = e == 0 ? 0ull : fx;         // zero / denormal
-  return (b >> 31) ? (0ull - fx) : fx;
-}
-
 template <typename WT> struct p2_acc { using type = WT; };
 template <> struct p2_acc<float> { using type = unsigned long long; };
 
-template <typename WT, bool PERS, bool OVL = false>
+template <typename WT, bool PERS, bool OVL = false, int NB = 1>
 __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
 {
   using ACC = typename p2_acc<WT>::type;
@@ -1445,46 +1487,69 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
     col[j] = (e.xcol && in) ? e.xcol[(size_t)row0 + i] : (int32_t)(row0 + i);
   }
   for (uint32_t i = tid; i < nrows; i += TP2_BLOCK) acc[i] = ACC(0);
+  // fp32: the tile's fixed-point scale (spmv_tiled.hpp, tiled_to_fixed): its partials and row sums are bounded by fx_unit * tile_wmax[I]
+  double fx_scale = 1.0, fx_inv = 1.0;
+  if constexpr (sizeof(WT) == 4) tiled_tile_scale(sc.fx_unit * a.tile_wmax[I], &fx_scale, &fx_inv);
   __syncthreads();
-  for (uint32_t s = s0 + 8 * tid; s < s1; s += 8 * TP2_BLOCK) {
-    uint32_t idx8[8];
-    if (a.dstl12) {  // wave-uniform: 8 slots = 3 dwords of 12-bit tile-local rows
-      uint32_t const* p12 = a.dstl12 + 3u * (s >> 3);
+  // NB batches of 8 slots in flight per thread: every load of a step is issued before the first partial of the step is added (one batch
+  // keeps 44 bytes per lane in flight -- enough when the whole chip streams; beside a phase 1 that owns most CUs two are needed)
+  for (uint32_t sb = s0 + 8 * tid; sb < s1; sb += 8 * TP2_BLOCK * NB) {
+    uint32_t w12[NB][3], idx16w[NB];
+    WT v[NB][8];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      uint32_t const s = sb + (uint32_t)b * (8 * TP2_BLOCK);
+      bool const live  = b == 0 || s < s1;  // (a batch past the region adds zeros to row 0)
+      if (a.dstl12) {  // wave-uniform: 8 slots = 3 dwords of 12-bit tile-local rows
+        uint32_t const* p12 = a.dstl12 + 3u * (s >> 3);
 #ifndef CGA_P2_PLAIN_LOAD  // streamed once per iteration: non-temporal loads (phase 2 0.457 -> 0.442 ms at RMAT-26)
-      uint32_t const w0 = __builtin_nontemporal_load(p12), w1 = __builtin_nontemporal_load(p12 + 1), w2 = __builtin_nontemporal_load(p12 + 2);
+        w12[b][0] = live ? __builtin_nontemporal_load(p12) : 0u; w12[b][1] = live ? __builtin_nontemporal_load(p12 + 1) : 0u; w12[b][2] = live ? __builtin_nontemporal_load(p12 + 2) : 0u;
 #else
-      uint32_t const w0 = p12[0], w1 = p12[1], w2 = p12[2];
+        w12[b][0] = live ? p12[0] : 0u; w12[b][1] = live ? p12[1] : 0u; w12[b][2] = live ? p12[2] : 0u;
 #endif
-      idx8[0] = w0 & 0xFFFu; idx8[1] = (w0 >> 12) & 0xFFFu; idx8[2] = (w0 >> 24) | ((w1 & 0xFu) << 8); idx8[3] = (w1 >> 4) & 0xFFFu;
-      idx8[4] = (w1 >> 16) & 0xFFFu; idx8[5] = (w1 >> 28) | ((w2 & 0xFFu) << 4); idx8[6] = (w2 >> 8) & 0xFFFu; idx8[7] = w2 >> 20;
-    } else {
-      uint4 const d = *reinterpret_cast<uint4 const*>(a.dstl16 + s);
-      uint32_t const w4[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-      for (int k = 0; k < 8; ++k) idx8[k] = (k & 1) ? (w4[k >> 1] >> 16) : (w4[k >> 1] & 0xFFFFu);
-    }
-    WT v[8];
-    if constexpr (sizeof(WT) == 4) {
+      } else {  // 16-bit destinations: 8 slots = 16 bytes, repacked to the 12-bit layout's three dwords (tiles of <= 4096 rows only reach here with CUGRAPH_AMD_TILED_DSTL16)
+        uint4 d{0u, 0u, 0u, 0u};
+        if (live) d = *reinterpret_cast<uint4 const*>(a.dstl16 + s);
+        w12[b][0] = d.x; w12[b][1] = d.y; w12[b][2] = d.z; idx16w[b] = d.w;  // four dwords of two 16-bit rows each
+      }
+      if constexpr (sizeof(WT) == 4) {
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        f32x4_t q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
 #ifndef CGA_P2_PLAIN_LOAD
-      typedef float f32x4_t __attribute__((ext_vector_type(4)));
-      f32x4_t const q0 = __builtin_nontemporal_load(reinterpret_cast<f32x4_t const*>(a.part + s)), q1 = __builtin_nontemporal_load(reinterpret_cast<f32x4_t const*>(a.part + s + 4));
-      float4 const p0 = {q0.x, q0.y, q0.z, q0.w}, p1 = {q1.x, q1.y, q1.z, q1.w};
+          q0 = __builtin_nontemporal_load(reinterpret_cast<f32x4_t const*>(a.part + s)); q1 = __builtin_nontemporal_load(reinterpret_cast<f32x4_t const*>(a.part + s + 4));
 #else
-      float4 const p0 = *reinterpret_cast<float4 const*>(a.part + s), p1 = *reinterpret_cast<float4 const*>(a.part + s + 4);
+          q0 = *reinterpret_cast<f32x4_t const*>(a.part + s); q1 = *reinterpret_cast<f32x4_t const*>(a.part + s + 4);
 #endif
-      v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
-    } else {
+        }
+        v[b][0] = q0.x; v[b][1] = q0.y; v[b][2] = q0.z; v[b][3] = q0.w; v[b][4] = q1.x; v[b][5] = q1.y; v[b][6] = q1.z; v[b][7] = q1.w;
+      } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        double2 const p = *reinterpret_cast<double2 const*>(a.part + s + 2 * k);
-        v[2 * k] = p.x; v[2 * k + 1] = p.y;
+        for (int k = 0; k < 4; ++k) {
+          double2 p{0.0, 0.0};
+          if (live) p = *reinterpret_cast<double2 const*>(a.part + s + 2 * k);
+          v[b][2 * k] = p.x; v[b][2 * k + 1] = p.y;
+        }
       }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      uint32_t const i = idx8[k];
-      if constexpr (sizeof(WT) == 4) atomicAdd(&acc[i], to_fixed(v[k], sc.fx_k));  // ds_add_u64; padding slots hold 0
-      else atomicAdd(&acc[i], v[k]);                                              // ds_add_f64
+    for (int b = 0; b < NB; ++b) {
+      uint32_t idx8[8];
+      if (a.dstl12) {
+        uint32_t const w0 = w12[b][0], w1 = w12[b][1], w2 = w12[b][2];
+        idx8[0] = w0 & 0xFFFu; idx8[1] = (w0 >> 12) & 0xFFFu; idx8[2] = (w0 >> 24) | ((w1 & 0xFu) << 8); idx8[3] = (w1 >> 4) & 0xFFFu;
+        idx8[4] = (w1 >> 16) & 0xFFFu; idx8[5] = (w1 >> 28) | ((w2 & 0xFFu) << 4); idx8[6] = (w2 >> 8) & 0xFFFu; idx8[7] = w2 >> 20;
+      } else {
+        uint32_t const w4[4] = {w12[b][0], w12[b][1], w12[b][2], idx16w[b]};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) idx8[k] = (k & 1) ? (w4[k >> 1] >> 16) : (w4[k >> 1] & 0xFFFFu);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        uint32_t const i = idx8[k];
+        if constexpr (sizeof(WT) == 4) atomicAdd(&acc[i], tiled_to_fixed(v[b][k], fx_scale));  // ds_add_u64; padding slots hold 0
+        else atomicAdd(&acc[i], v[b][k]);                                                      // ds_add_f64
+      }
     }
   }
   __syncthreads();
@@ -1494,7 +1559,7 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
       uint32_t i = tid + j * TP2_BLOCK;
       if (i < nrows) {
         WT sum;
-        if constexpr (sizeof(WT) == 4) sum = (WT)((double)(long long)acc[i] * sc.fx_inv);
+        if constexpr (sizeof(WT) == 4) sum = (WT)((double)(long long)acc[i] * fx_inv);
         else sum = acc[i];
         e.raw_y[(size_t)row0 + i] = sum;
       }
@@ -1510,7 +1575,7 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
     if (i < nrows) {
       size_t const v = (size_t)row0 + i;
       WT sum;
-      if constexpr (sizeof(WT) == 4) sum = (WT)((double)(long long)acc[i] * sc.fx_inv);
+      if constexpr (sizeof(WT) == 4) sum = (WT)((double)(long long)acc[i] * fx_inv);
       else sum = acc[i];
       WT val = sc.base + sum;
       if constexpr (PERS) val += sc.pers_factor * e.pers[v];
@@ -1572,7 +1637,8 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
     CGA_EXPECTS(t.n_items > 0 && t.n_static_chunks == 0 && pending == nullptr, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: overlapped phase 1 needs a dynamic-only schedule");
     p1_args<WT> a;
     a.src16 = t.src16.data(); a.bits = reinterpret_cast<uint8_t const*>(t.bits.data()); a.weights = t.weights.ptr ? t.weights.as<WT const>() : nullptr;
-    a.delta1 = t.delta1.data(); a.wrec = t.wrec.data(); a.chunk_begin = t.chunk_begin.data(); a.n_chunks = t.n_chunks; a.n_static_chunks = 0;
+    a.delta1 = t.delta1.data(); a.wrec = t.wrec.data(); a.n_chunks = t.n_chunks; a.n_static_chunks = 0;
+    a.chunk_begin = ovl->const_first && t.chunk_begin_ovl.size() ? t.chunk_begin_ovl.data() : t.chunk_begin.data();
     a.wg_static = t.wg_static.data();  // all zero: no private chunks
     a.counter = ovl->cursor; a.counter_next = ovl->cursor_next; a.T = t.T; a.x = x; a.part = part; a.alpha = alpha;
     a.pmask = map.pmask; a.plog = map.plog; a.chunk = map.chunk; a.ncols = map.ncols;
@@ -1650,28 +1716,32 @@ void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled
   a.counters   = counters;
   using ACC = typename p2_acc<WT>::type;
   size_t const lds = (size_t)TP2_ROWS * sizeof(ACC);
-  static bool attr_done = false;
-  if (!attr_done && lds > 48 * 1024) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_tiled_phase2<WT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_tiled_phase2<WT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_tiled_phase2<WT, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_tiled_phase2<WT, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  a.tile_wmax = t.tile_wmax.data();
   int grid = t.nI;
   int const n_const = e.cr.nI_act > 0 ? (int)((e.cr.n_cols + TP2_CONST_COLS - 1) / TP2_CONST_COLS) : 0;
   if (e.cr.nI_act > 0) grid = e.cr.nI_act + n_const;
+  // batches of 8 slots in flight per thread: 1 when the kernel has the chip to itself (HBM-bound either way), 2 beside a phase 1
+  static int const nb_env = getenv("CUGRAPH_AMD_P2_BATCHES") ? atoi(getenv("CUGRAPH_AMD_P2_BATCHES")) : 0;
+  int const nb = nb_env == 1 || nb_env == 2 ? nb_env : (ovl ? 2 : 1);
+  hipStream_t const stream = ovl ? ovl->stream : h.stream;
   if (ovl) {  // beside the next iteration's phase 1 (tiled_ovl): x stored write-through, every workgroup counts itself into ready[]
     CGA_EXPECTS(e.raw_y == nullptr && e.cr.col_idx == nullptr, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: overlapped phase 2 is the single-GPU PageRank epilogue");
     a.tile_col0 = t.tile_col0.data(); a.ready = ovl->ready; a.T = t.T; a.n_const = n_const;
-    timed_launch tl(h, "pagerank_reduce", ovl->stream);
-    if (e.pers) hipLaunchKernelGGL((k_tiled_phase2<WT, true, true>), grid, TP2_BLOCK, lds, ovl->stream, a);
-    else        hipLaunchKernelGGL((k_tiled_phase2<WT, false, true>), grid, TP2_BLOCK, lds, ovl->stream, a);
-    return;
   }
-  timed_launch tl(h, "pagerank_reduce");
-  if (e.pers) hipLaunchKernelGGL((k_tiled_phase2<WT, true>), grid, TP2_BLOCK, lds, h.stream, a);
-  else        hipLaunchKernelGGL((k_tiled_phase2<WT, false>), grid, TP2_BLOCK, lds, h.stream, a);
+  auto launch = [&](auto kernel) {
+    static bool attr_done = false;  // (one flag per instantiation of this lambda = per kernel)
+    if (!attr_done && lds > 48 * 1024) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_done = true; }
+    timed_launch tl(h, "pagerank_reduce", stream);
+    hipLaunchKernelGGL(kernel, grid, TP2_BLOCK, lds, stream, a);
+  };
+  bool const pers = e.pers != nullptr;
+  if (ovl) {
+    if (nb == 2) { if (pers) launch(k_tiled_phase2<WT, true, true, 2>); else launch(k_tiled_phase2<WT, false, true, 2>); }
+    else         { if (pers) launch(k_tiled_phase2<WT, true, true, 1>); else launch(k_tiled_phase2<WT, false, true, 1>); }
+  } else {
+    if (nb == 2) { if (pers) launch(k_tiled_phase2<WT, true, false, 2>); else launch(k_tiled_phase2<WT, false, false, 2>); }
+    else         { if (pers) launch(k_tiled_phase2<WT, true, false, 1>); else launch(k_tiled_phase2<WT, false, false, 1>); }
+  }
 }
 
 template <typename WT>

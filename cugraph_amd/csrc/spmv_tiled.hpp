@@ -38,8 +38,9 @@ struct pr_scalars {  // device-resident PageRank loop state
   WT pers_factor;  // alpha * dangling + (1 - alpha)
   WT dangling;
   WT diff;
-  int32_t fx_k;   // tiled path, fp32: phase 2 accumulates value * 2^fx_k in 64-bit fixed point
+  int32_t fx_k;   // (round 1-4 layout: one global fixed-point scale; kept for the record, phase 2 now derives a scale per destination tile)
   double fx_inv;  // 2^-fx_k
+  double fx_unit; // alpha * max|x|: a partial or a row sum of destination tile I is bounded by fx_unit * tile_wmax[I] (phase 2's fixed-point scale)
   WT base_prev;   // tiled_const_rows: the value the rows without in-edges hold BEFORE the iteration that uses `base`
 };
 
@@ -124,8 +125,11 @@ struct tiled_csc_t {
   dvec<int32_t> item_tile;    // [n_items] source tile of work item
   dvec<uint32_t> wrec;        // [n_items * TP_WAVES][TP_REC_DWORDS] per-wavefront records (see above)
   dvec<int32_t> chunk_begin;  // [n_chunks][4] (unused, first item, end item, source tile) of each chunk (<= TP_CHUNK items of one source tile), largest first
+  dvec<int32_t> chunk_begin_ovl;  // the same chunks in the order of an overlapped launch (tiles >= ovl_first_const_tile first); empty with a static prefix
+  int ovl_first_const_tile{0};    // first source tile whose columns all belong to rows without in-edges (x written by the tiled_const_rows blocks)
   dvec<int32_t> wg_static;    // [n_wg][2] (first, end) static chunk of each phase-1 workgroup
   dvec<uint32_t> tile_row0;   // [nI + 1] destination tile boundaries
+  dvec<double> tile_wmax;     // [nI] max over the tile's rows of sum |w| of the row's in-edges (in-degree when unweighted): bounds the tile's partials and row sums
   dvec<uint32_t> tile_col0;   // [nI + 1] first column (xcol rank) of each destination tile's rows: phase 2 of tile I writes x[tile_col0[I] .. tile_col0[I + 1])
   std::vector<uint32_t> tile_col0_host;  // the same on the host (tiled_overlap_need)
   dvec<uint32_t> region_off;  // [nI + 2] slot range of region I (multiples of 8); region nI = dummy
@@ -197,6 +201,8 @@ struct tiled_ovl {
   uint32_t* cursor_next{nullptr};  // ... and the next launch's, which workgroup 0 rewinds
   uint32_t* error{nullptr};        // set to 1 when a poll ran into its bound (a bug, not a state: the launch then finishes with stale x)
   int grid{0};                     // phase 1: workgroups (< CUs: the rest of the chip runs phase 2)
+  bool const_first{false};         // phase 1: take the chunks in tiled_csc_t::chunk_begin_ovl order (the plan leaves the rows without in-edges to
+                                   // tiled_const_rows, so the x of the coldest source tiles is ready first)
 };
 
 // need[J] = number of phase-2 workgroups (destination tiles, plus the blocks of tiled_const_rows when `const_rows`) whose columns fall into source tile J
@@ -260,6 +266,34 @@ __device__ __forceinline__ void tiled_write_scalars(pr_scalars<WT>* scal, double
   scal->pers_factor = factor;
   scal->base        = personalized ? WT(0) : factor / (WT)nv_global;
   tiled_fixed_point_scale((double)alpha * xmax * wmax, &scal->fx_k, &scal->fx_inv);
+  scal->fx_unit = (double)alpha * xmax;
+}
+
+// Phase 2's fixed point, round 5.  A partial v of destination tile I satisfies |v| <= B = alpha * max|x| * (max over the tile's rows of sum |w|),
+// and so does every row sum.  With 2^k chosen so that B * 2^k < 2^50, n = round(v * 2^k) is an integer below 2^50 in magnitude and
+//     t = fma((double)v, 2^k, 1.5 * 2^52)
+// is exactly 1.5 * 2^52 + n (one rounding, to nearest even, at unit 1): the integer is the difference of the BIT PATTERNS of t and of
+// 1.5 * 2^52 -- whose low dword is zero, so the conversion is v_cvt_f64_f32 + v_fma_f64 + one 32-bit subtract instead of the 32 VALU
+// instructions of the shift-based conversion of rounds 1-4 (a CU then reduced 22 GB/s of partials, i.e. phase 2 needed the whole chip to keep
+// up with the HBM; profiles/r5a_overlap_first_sweep.txt).  Integer accumulation stays order-independent (bit-reproducible); the scale is per
+// destination tile, so the cold tiles (small in-degrees) keep more fraction bits than the single global scale gave them.
+constexpr double kFxMagic          = 6755399441055744.0;       // 1.5 * 2^52
+constexpr unsigned long long kFxMagicBits = 0x4338000000000000ull;
+__device__ __forceinline__ void tiled_tile_scale(double bound, double* scale, double* inv)
+{
+  int kk = 0;
+  if (bound > 0.0 && bound < 1.0e300) {
+    int e;
+    (void)frexp(bound, &e);  // bound < 2^e
+    kk = 50 - e;
+  }
+  kk     = max(-900, min(900, kk));
+  *scale = ldexp(1.0, kk);
+  *inv   = ldexp(1.0, -kk);
+}
+__device__ __forceinline__ unsigned long long tiled_to_fixed(float v, double scale)
+{
+  return (unsigned long long)__double_as_longlong(fma((double)v, scale, kFxMagic)) - kFxMagicBits;
 }
 
 }  // namespace cga

@@ -869,6 +869,25 @@ struct sssp_parent {
     using B = dist_bits<WT>;
     if (v != source && B::to(B::from(dist[u]) + weights[p]) == dist[v]) atomicMin(&pred[v], labels ? labels[u] : u);
   }
+  // the phased form (expand_*_mlp: EX_U edges in flight per lane; the sweep is one random read of d[v] per settled edge, nearly all of
+  // which fail the test -- the kind of round that gained most from several loads in flight, section 3.4 of DESIGN.md)
+  struct cand_t { int32_t label; bool pass; };
+  using tok_t  = int32_t;
+  using tok2_t = int32_t;
+  __device__ __forceinline__ cand_t pre(int32_t u, int32_t v, eoff_t p) const
+  {
+    using B = dist_bits<WT>;
+    int32_t const uu = u < 0 ? 0 : u, vv = v < 0 ? 0 : v;
+    bool const tight = (v >= 0) & (v != source) & (B::to(B::from(dist[uu]) + weights[p]) == dist[vv]);
+    return cand_t{labels ? labels[uu] : uu, tight};
+  }
+  __device__ __forceinline__ tok_t mid(int32_t v, cand_t c) const
+  {
+    if (c.pass && c.label < pred[v]) atomicMin(&pred[v], c.label);  // (plain pre-test: pred only ever decreases)
+    return 0;
+  }
+  __device__ __forceinline__ tok2_t mid2(int32_t, cand_t, tok_t) const { return 0; }
+  __device__ __forceinline__ void post(int32_t, int32_t, cand_t, tok_t, tok2_t) const {}
 };
 template <typename WT>
 struct keep_reached {
@@ -880,13 +899,13 @@ template <typename WT>
 __global__ void __launch_bounds__(TV_BLOCK) k_sssp_parents(int64_t nv, int32_t const* offsets, int32_t const* indices, int32_t* bigq,
                                                            counters_t* cnt, sssp_parent<WT> f, keep_reached<WT> keep)
 {
-  expand_frontier((int32_t const*)nullptr, nv, offsets, indices, bigq, cnt, keep, f);
+  expand_frontier_mlp((int32_t const*)nullptr, nv, offsets, indices, bigq, cnt, keep, f);
 }
 template <typename WT>
 __global__ void __launch_bounds__(TV_BLOCK) k_sssp_parents_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices,
                                                                counters_t* cnt, sssp_parent<WT> f)
 {
-  expand_big(bigq, offsets, indices, cnt, f);
+  expand_big_mlp(bigq, offsets, indices, cnt, f);
 }
 
 template <typename WT>

@@ -78,6 +78,7 @@ struct mg_traversal_run_t {
       if (plan) cugraph_amd_traversal_mg_plan_free(plan);
       for (int b = 1; b >= 0; --b) { if (swin[b]) c->window_free(swin[b]); if (bwin[b]) c->window_free(bwin[b]); }
       if (twin) c->window_free(twin);
+      if (channel >= 2) c->channel_free(channel);
     } catch (...) {
     }
   }

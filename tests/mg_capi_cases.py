@@ -51,6 +51,15 @@ def run(what, cg, h, comm, rank, size, outdir, args):
         # a second call on the same graph reuses the partition and must give the same answer
         v2, x2, _ = cg.pagerank(h, g, None, None, None, None, 0.85, eps, max_iter, False, fail_on_nonconvergence=False)
         out["repeat_equal"] = bool(torch.equal(v, v2) and torch.equal(x, x2))
+        if len(args) > 4 and int(args[4]) > 0:
+            # many calls on one communicator: every call builds and frees a plan; the plan's signal channel goes back to the communicator
+            # (64 channels per communicator -- a loop of PageRanks / traversals used to fail after ~60 calls)
+            ok = True
+            for i in range(int(args[4])):
+                v3, x3, _ = cg.pagerank(h, g, None, None, None, None, 0.85, eps, 2, False, fail_on_nonconvergence=False)
+                ok = ok and v3.numel() == v.numel()
+            v3, x3, _ = cg.pagerank(h, g, None, None, None, None, 0.85, eps, max_iter, False, fail_on_nonconvergence=False)
+            out["many_calls_equal"] = bool(ok and torch.equal(x, x3))
         del g
     elif what == "ppr":
         # the optional arguments of cugraph_personalized_pagerank on a multi-GPU graph: every rank hands over a SLICE of each (vertices, values)

@@ -89,6 +89,13 @@ def test_mg_capi_pagerank(orc, tmp_path, world, weighted):
 
 
 @pytest.mark.gpu
+def test_mg_capi_pagerank_many_calls_reuse_channels(tmp_path):
+    """Round 5 (advisor finding): 80 cugraph_pagerank calls on one communicator -- more than its 64 signal channels; the plans return theirs."""
+    res = run_ranks("pagerank", 2, tmp_path, 10, 6, 0.0, "-", 80)
+    assert all(r["repeat_equal"] and r["many_calls_equal"] for r in res)
+
+
+@pytest.mark.gpu
 def test_mg_capi_pagerank_converges_like_single_gpu(orc, tmp_path):
     from test_mg import truth
 

@@ -64,13 +64,13 @@ def main():
     py = sys.executable
     only = set(sys.argv[1:])
     bench = [py, str(ROOT / "bench.py"), "--scale", "26", "--warmup", "1", "--no-check", "--no-cpu-baseline", "--no-extras"]
-    trav = [py, str(ROOT / "bench_traversal.py"), "--scale", "24", "--no-cpu-baseline", "--no-check"]
+    trav = [py, str(ROOT / "bench_traversal.py"), "--scale", "24", "--no-cpu-baseline", "--no-check", "--single-variant"]  # with predecessors (the headline since round 5)
     louv = [py, str(ROOT / "bench_louvain.py"), "--scale", "22", "--cpu-scale", "0"]
     work = {
         "pagerank_s26": (bench + ["--steps", "4"], bench + ["--steps", "24"], 4, 24, "one power iteration (k_tiled_phase1 + k_tiled_phase2)"),
-        "bfs_s24_int": (trav + ["--weights", "int", "--no-sssp", "--roots", "2"], trav + ["--weights", "int", "--no-sssp", "--roots", "10"], 2, 10, "one BFS (all levels)"),
-        "sssp_s24_int": (trav + ["--weights", "int", "--roots", "2"], trav + ["--weights", "int", "--roots", "6"], 2, 6, "one BFS + one SSSP (subtract bfs_s24_int)"),
-        "sssp_s24_unit": (trav + ["--weights", "unit", "--roots", "2"], trav + ["--weights", "unit", "--roots", "6"], 2, 6, "one BFS + one SSSP (subtract bfs_s24_int)"),
+        "bfs_s24_int_pred": (trav + ["--weights", "int", "--no-sssp", "--roots", "2"], trav + ["--weights", "int", "--no-sssp", "--roots", "10"], 2, 10, "one BFS with predecessors (all levels)"),
+        "sssp_s24_int_pred": (trav + ["--weights", "int", "--roots", "2"], trav + ["--weights", "int", "--roots", "6"], 2, 6, "one BFS + one SSSP (subtract bfs_s24_int_pred)"),
+        "sssp_s24_unit_pred": (trav + ["--weights", "unit", "--roots", "2"], trav + ["--weights", "unit", "--roots", "6"], 2, 6, "one BFS + one SSSP (subtract bfs_s24_int_pred)"),
         "louvain_s22": (louv + ["--repeats", "1"], louv + ["--repeats", "4"], 1, 4, "one cugraph_louvain call (all levels)"),
     }
     entries = {}
@@ -82,11 +82,11 @@ def main():
         except Exception as e:
             entries[key] = {"error": repr(e)[:400]}
         print(key, entries[key], flush=True)
-    for k in ("sssp_s24_int", "sssp_s24_unit"):  # the traversal bench runs one BFS and one SSSP per root: isolate the SSSP
-        if k in entries and "hbm_bytes" in entries[k] and "hbm_bytes" in entries.get("bfs_s24_int", {}):
-            b = entries["bfs_s24_int"]
+    for k in ("sssp_s24_int_pred", "sssp_s24_unit_pred"):  # the traversal bench runs one BFS and one SSSP per root: isolate the SSSP
+        if k in entries and "hbm_bytes" in entries[k] and "hbm_bytes" in entries.get("bfs_s24_int_pred", {}):
+            b = entries["bfs_s24_int_pred"]
             entries[k] = dict(entries[k], hbm_bytes=entries[k]["hbm_bytes"] - b["hbm_bytes"], fetch_kib=round(entries[k]["fetch_kib"] - b["fetch_kib"], 1),
-                              write_kib=round(entries[k]["write_kib"] - b["write_kib"], 1), unit="one SSSP (all rounds)")
+                              write_kib=round(entries[k]["write_kib"] - b["write_kib"], 1), unit="one SSSP with predecessors (all rounds)")
     out = {"source_hash": source_hash(), "group_hashes": {g: kernel_source_hash(g) for g in TRAFFIC_GROUPS}, "groups": TRAFFIC_GROUPS, "source": "tools/traffic_collect.py on the GPU box: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs), totals over all dispatches, "
                                                    "differenced between two amounts of work; KiB x 1024; FETCH_SIZE x 2 per MI355X_MICROARCH.md (gfx950)",
            "entries": entries}
