@@ -1744,6 +1744,7 @@ struct pagerank_mgc_plan : pagerank_plan_base {
   dvec<double*> d_peer_s[2];
   dvec<int64_t> d_first, d_dst_off;
   int channel{0};
+  uint64_t seq_base{0};  // c.seq[channel] when the plan took the channel: its k-th push carries sequence number seq_base + k
   uint64_t pushes{0}, folds{0};  // push #n fills buffer (n - 1) & 1 everywhere; fold #n waits for it
   size_t iterations{0};
   double last_diff{0};
@@ -1921,6 +1922,7 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     }
     // windows (collective): zeroed before anybody may push into them
     channel         = c.channel_alloc();
+    seq_base        = c.seq[channel];
     size_t const nx = (size_t)tc->nJ * tc->T + 8;  // the gather vector is read tile-wise
     for (int b = 0; b < 2; ++b) {
       xwin[b] = c.window_create(nx * sizeof(WT));
@@ -1968,7 +1970,8 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     if (folds < pushes) {
       int const b = (int)(folds & 1);
       long long const ticks = (long long)(c.timeout_s * (double)c.wall_ticks_per_s);
-      hipLaunchKernelGGL(k_mgc_wait_fold<WT>, 1, 64, 0, h.stream, (uint64_t const*)c.flags->local, channel, folds + 1, ticks, c.err_word, (double const*)swin[b]->local, P, scal.data(),
+      // (the channel's sequence numbers continue where its previous owner stopped: channels are handed out again, comm_t::channel_free)
+      hipLaunchKernelGGL(k_mgc_wait_fold<WT>, 1, 64, 0, h.stream, (uint64_t const*)c.flags->local, channel, seq_base + folds + 1, ticks, c.err_word, (double const*)swin[b]->local, P, scal.data(),
                          alpha, nv_global, tc->wmax, personalized ? 1 : 0);
       ++folds;
     }

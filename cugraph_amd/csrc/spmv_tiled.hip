@@ -1434,10 +1434,23 @@ __device__ __forceinline__ void publish_columns(uint32_t* ready, int T, int64_t 
 // fp32 partials are accumulated as signed 64-bit fixed point (value * 2^k of the tile, rounded to nearest: tiled_to_fixed in spmv_tiled.hpp):
 // LDS integer atomics run at full rate on gfx950 while ds_add_f32 is ~5x slower (tools/ubench/lds_update_bench.hip), and integer addition is
 // associative, so the result does not depend on the order in which wavefronts reach a row (bit-reproducible).
+// the shift-based conversion of rounds 1-4 (value * 2^k truncated, 32 VALU instructions), kept selectable for same-session comparisons
+// (CUGRAPH_AMD_P2_FIXED=shift): phase 2 alone is HBM-bound either way
+__device__ __forceinline__ unsigned long long to_fixed_shift(float v, int k)
+{
+  uint32_t const b = __float_as_uint(v);
+  int const e      = (int)((b >> 23) & 0xFFu);
+  unsigned long long m = (unsigned long long)((b & 0x7FFFFFu) | 0x800000u);
+  int const sh     = e - 150 + k;  // v = m * 2^(e - 150)
+  unsigned long long fx = sh >= 0 ? m << min(sh, 63) : m >> min(-sh, 63);
+  fx = e == 0 ? 0ull : fx;         // zero / denormal
+  return (b >> 31) ? (0ull - fx) : fx;
+}
+
 template <typename WT> struct p2_acc { using type = WT; };
 template <> struct p2_acc<float> { using type = unsigned long long; };
 
-template <typename WT, bool PERS, bool OVL = false, int NB = 1>
+template <typename WT, bool PERS, bool OVL = false, int NB = 1, bool SHIFTFX = false>
 __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
 {
   using ACC = typename p2_acc<WT>::type;
@@ -1489,7 +1502,11 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
   for (uint32_t i = tid; i < nrows; i += TP2_BLOCK) acc[i] = ACC(0);
   // fp32: the tile's fixed-point scale (spmv_tiled.hpp, tiled_to_fixed): its partials and row sums are bounded by fx_unit * tile_wmax[I]
   double fx_scale = 1.0, fx_inv = 1.0;
-  if constexpr (sizeof(WT) == 4) tiled_tile_scale(sc.fx_unit * a.tile_wmax[I], &fx_scale, &fx_inv);
+  int fx_k = 0;
+  if constexpr (sizeof(WT) == 4) {
+    tiled_tile_scale(sc.fx_unit * a.tile_wmax[I], &fx_scale, &fx_inv);
+    if constexpr (SHIFTFX) { (void)frexp(fx_scale, &fx_k); fx_k -= 1; }  // fx_scale = 2^fx_k
+  }
   __syncthreads();
   // NB batches of 8 slots in flight per thread: every load of a step is issued before the first partial of the step is added (one batch
   // keeps 44 bytes per lane in flight -- enough when the whole chip streams; beside a phase 1 that owns most CUs two are needed)
@@ -1547,7 +1564,7 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         uint32_t const i = idx8[k];
-        if constexpr (sizeof(WT) == 4) atomicAdd(&acc[i], tiled_to_fixed(v[b][k], fx_scale));  // ds_add_u64; padding slots hold 0
+        if constexpr (sizeof(WT) == 4) atomicAdd(&acc[i], SHIFTFX ? to_fixed_shift(v[b][k], fx_k) : tiled_to_fixed(v[b][k], fx_scale));  // ds_add_u64; padding slots hold 0
         else atomicAdd(&acc[i], v[b][k]);                                                      // ds_add_f64
       }
     }
@@ -1721,7 +1738,8 @@ void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled
   int const n_const = e.cr.nI_act > 0 ? (int)((e.cr.n_cols + TP2_CONST_COLS - 1) / TP2_CONST_COLS) : 0;
   if (e.cr.nI_act > 0) grid = e.cr.nI_act + n_const;
   // batches of 8 slots in flight per thread: 1 when the kernel has the chip to itself (HBM-bound either way), 2 beside a phase 1
-  static int const nb_env = getenv("CUGRAPH_AMD_P2_BATCHES") ? atoi(getenv("CUGRAPH_AMD_P2_BATCHES")) : 0;
+  char const* const env_nb = getenv("CUGRAPH_AMD_P2_BATCHES");  // (read per launch: tools/plan_sweep.py switches variants inside one process)
+  int const nb_env = env_nb ? atoi(env_nb) : 0;
   int const nb = nb_env == 1 || nb_env == 2 ? nb_env : (ovl ? 2 : 1);
   hipStream_t const stream = ovl ? ovl->stream : h.stream;
   if (ovl) {  // beside the next iteration's phase 1 (tiled_ovl): x stored write-through, every workgroup counts itself into ready[]
@@ -1735,6 +1753,9 @@ void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled
     hipLaunchKernelGGL(kernel, grid, TP2_BLOCK, lds, stream, a);
   };
   bool const pers = e.pers != nullptr;
+  char const* const env_fx = getenv("CUGRAPH_AMD_P2_FIXED");
+  bool const shift_fx = env_fx != nullptr && std::string(env_fx) == "shift";
+  if (shift_fx && !ovl && !pers && nb == 1) { launch(k_tiled_phase2<WT, false, false, 1, true>); return; }
   if (ovl) {
     if (nb == 2) { if (pers) launch(k_tiled_phase2<WT, true, true, 2>); else launch(k_tiled_phase2<WT, false, true, 2>); }
     else         { if (pers) launch(k_tiled_phase2<WT, true, true, 1>); else launch(k_tiled_phase2<WT, false, true, 1>); }

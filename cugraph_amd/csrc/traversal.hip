@@ -117,6 +117,60 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand_big(int32_t const* bigq
   f.flush();
 }
 
+// Parents of the vertices a TOP-DOWN level has just discovered, pulled from their in-edges (round 5): the first in-neighbour -- ascending
+// internal id -- that was visited before the level started.  Such a neighbour sits exactly one level up (a shallower one would have given
+// the vertex a smaller depth), so this is the rule of the push with atomicMin (smallest internal id among the frontier parents) and of the
+// bottom-up levels, evaluated per DISCOVERED vertex (10^4-10^5 in the levels that run top-down) instead of per inspected edge: the push
+// then does nothing for the parents (it used to read pred[v] for every edge into a not yet visited vertex and atomicMin most of them:
+// +0.29 ms per BFS at RMAT-24).  One wavefront per vertex, 64 neighbours per step, ballot early exit; rows above BFS_PULL_LONG in-edges go to
+// a list that k_bfs_pull_parents_long scans with every wavefront of its grid (no single wavefront walks a 10^6-entry row).
+constexpr int32_t BFS_PULL_LONG = 8192;
+__global__ void __launch_bounds__(TV_BLOCK) k_bfs_pull_parents(int32_t const* q, counters_t* cnt, int32_t const* in_off, int32_t const* in_idx, uint32_t const* vis_prev,
+                                                               int32_t* pred, int32_t* longq)
+{
+  uint32_t const n = cnt->n_next;  // the level's expansion kernels have completed (stream order): the queue's final size
+  int const lane = threadIdx.x & 63;
+  uint32_t const gwave = (uint32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (uint32_t)(((int64_t)gridDim.x * blockDim.x) >> 6);
+  for (uint32_t i = gwave; i < n; i += nwaves) {
+    int32_t const v = q[i];
+    eoff_t const b = eoff(in_off, v), e = eoff(in_off, v + 1);
+    if (e - b > (eoff_t)BFS_PULL_LONG) {
+      if (lane == 0) longq[atomicAdd(&cnt->n_set, 1u)] = v;
+      continue;
+    }
+    int32_t best = INT32_MAX;
+    for (eoff_t p0 = b; p0 < e; p0 += 64) {
+      eoff_t const p = p0 + lane;
+      int32_t const u = p < e ? in_idx[p] : -1;
+      bool const hit  = u >= 0 && ((vis_prev[(uint32_t)u >> 5] >> ((uint32_t)u & 31u)) & 1u);
+      uint64_t const m = __ballot(hit);
+      if (m) { best = __shfl(u, __ffsll((unsigned long long)m) - 1); break; }
+    }
+    if (lane == 0) pred[v] = best;
+  }
+}
+__global__ void __launch_bounds__(TV_BLOCK) k_bfs_pull_parents_long(int32_t const* longq, counters_t const* cnt, int32_t const* in_off, int32_t const* in_idx,
+                                                                    uint32_t const* vis_prev, int32_t* pred)
+{
+  uint32_t const n = cnt->n_set;
+  int const lane = threadIdx.x & 63;
+  eoff_t const gwave = ((eoff_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((eoff_t)gridDim.x * blockDim.x) >> 6;
+  for (uint32_t k = 0; k < n; ++k) {
+    int32_t const v = longq[k];
+    eoff_t const b = eoff(in_off, v), e = eoff(in_off, v + 1);
+    for (eoff_t p0 = b + gwave * 64; p0 < e; p0 += nwaves * 64) {  // this wavefront's chunks ascend: its first hit is its smallest
+      eoff_t const p = p0 + lane;
+      int32_t const u = p < e ? in_idx[p] : -1;
+      bool const hit  = u >= 0 && ((vis_prev[(uint32_t)u >> 5] >> ((uint32_t)u & 31u)) & 1u);
+      uint64_t const m = __ballot(hit);
+      if (m) {
+        if (lane == 0) atomicMin(&pred[v], __shfl(u, __ffsll((unsigned long long)m) - 1));
+        break;
+      }
+    }
+  }
+}
+
 // front <- snapshot of the visited set (an unvisited vertex cannot have an in-neighbour that was visited before the
 // latest level, so testing against everything visited so far is the same as testing against the frontier);
 // vis_prev <- vis_new
@@ -228,10 +282,18 @@ struct sssp_state {
   uint32_t far_epoch;
   int32_t const* out_offsets;  // CSR offsets: the out-degrees of the vertices that enter the near frontier are summed (counters_t::out_edges):
                                // the host knows the next round's edge count without a pass over the queue (pull rounds are chosen by it)
+  // fp32 with predecessors (sssp_relax<WT, true>): (distance bits << 32 | external id of the parent) per vertex, lowered by ONE 64-bit
+  // atomicMin -- the reference's reduction, a lexicographic minimum over (distance, predecessor) (sssp_impl.cuh:334), in the relaxation itself
+  // instead of a sweep over the settled edges afterwards; `dist` is not used then
+  unsigned long long* pk{nullptr};
+  int32_t const* labels{nullptr};  // internal -> external id (nullptr: identity)
+  int32_t source{-1};              // keeps its parent -1 whatever reaches it at distance 0
 };
+__device__ __forceinline__ uint32_t pk_dist_bits(unsigned long long const* pk, int32_t v) { return reinterpret_cast<uint32_t const*>(pk)[2 * (size_t)v + 1]; }
 
-template <typename WT>
+template <typename WT, bool PK = false>
 struct sssp_relax {
+  static_assert(!PK || sizeof(WT) == 4, "the packed (distance, parent) word holds an fp32 distance");
   sssp_state<WT> s;
   wave_queue wq_near, wq_far, wq_set;
   unsigned long long deg_acc{0};
@@ -248,6 +310,12 @@ struct sssp_relax {
   }
   __device__ __forceinline__ void operator()(int32_t u, int32_t v, eoff_t p)
   {
+    if constexpr (PK) {  // (the one-edge-at-a-time expansion: the phased form below, called in sequence)
+      cand_t const c = pre(u, v, p);
+      tok_t const t  = mid(v, c);
+      post(u, v, c, t, mid2(v, c, t));
+      return;
+    }
     using B  = dist_bits<WT>;
     WT du    = B::from(s.dist[u]);
     WT nd    = du + s.weights[p];
@@ -272,28 +340,43 @@ struct sssp_relax {
     if (s.q_set) wq_set.push(fresh, v);  // (wave-uniform condition)
   }
   // the phased form of the same relaxation (expand_*_mlp: EX_U edges in flight per lane)
-  struct cand_t { WT nd; bool pass; };
-  using tok_t = typename dist_bits<WT>::type;
+  struct cand_t { WT nd; bool pass; unsigned long long word; };  // word: the packed candidate (PK only)
+  using tok_t = typename std::conditional<PK, unsigned long long, typename dist_bits<WT>::type>::type;
   __device__ __forceinline__ cand_t pre(int32_t u, int32_t v, eoff_t p) const
   {  // branch-free: the loads of the EX_U edges of a step go out together.  d[v] is read with an agent-scope load: L2-served, so once a
      // hub has been lowered the other relaxations of this round see it and skip the atomic (a non-temporal load is L2-served too, but
      // its lines are not retained: 14.0 ms instead of 10.4 per SSSP at RMAT-24)
     using B = dist_bits<WT>;
-    WT const nd = B::from(s.dist[u < 0 ? 0 : u]) + s.weights[p];
-    WT const dv = B::from(__hip_atomic_load(&s.dist[v < 0 ? 0 : v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    bool const pass = (v >= 0) & (nd < s.cutoff) & (nd < dv);
-    return cand_t{nd, pass};
+    if constexpr (PK) {
+      int32_t const uu = u < 0 ? 0 : u, vv = v < 0 ? 0 : v;
+      WT const nd = B::from(pk_dist_bits(s.pk, uu)) + s.weights[p];
+      unsigned long long const word = ((unsigned long long)B::to(nd) << 32) | (uint32_t)(s.labels ? s.labels[uu] : uu);
+      unsigned long long const cur  = __hip_atomic_load(&s.pk[vv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // strictly smaller (distance, parent): a shorter distance, or the same distance through a parent with a smaller external id
+      bool const pass = (v >= 0) & (v != s.source) & (nd < s.cutoff) & (word < cur);
+      return cand_t{nd, pass, word};
+    } else {
+      WT const nd = B::from(s.dist[u < 0 ? 0 : u]) + s.weights[p];
+      WT const dv = B::from(__hip_atomic_load(&s.dist[v < 0 ? 0 : v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      bool const pass = (v >= 0) & (nd < s.cutoff) & (nd < dv);
+      return cand_t{nd, pass, 0ull};
+    }
   }
   __device__ __forceinline__ tok_t mid(int32_t v, cand_t c) const
   {
     using B = dist_bits<WT>;
-    return c.pass ? atomicMin(&s.dist[v], B::to(c.nd)) : (tok_t)0;
+    if constexpr (PK) return c.pass ? atomicMin(&s.pk[v], c.word) : ~0ull;
+    else return c.pass ? atomicMin(&s.dist[v], B::to(c.nd)) : (tok_t)0;
   }
   using tok2_t = uint32_t;
   __device__ __forceinline__ tok2_t mid2(int32_t v, cand_t c, tok_t old) const
   {  // the relaxation lowered d[v]: claim the vertex for this round's near queue / this epoch's far pile
     using B = dist_bits<WT>;
-    if (!(c.pass && B::to(c.nd) < old)) return 0u;
+    if constexpr (PK) {
+      if (!(c.pass && (uint32_t)B::to(c.nd) < (uint32_t)(old >> 32))) return 0u;  // (a better parent at the same distance moves no queue)
+    } else {
+      if (!(c.pass && B::to(c.nd) < old)) return 0u;
+    }
     bool const won = c.nd < s.threshold ? atomicExch(&s.mark_near[v], s.round) != s.round : atomicExch(&s.mark_far[v], s.far_epoch) != s.far_epoch;
     return won ? (c.nd < s.threshold ? 1u : 2u) : 0u;
   }
@@ -413,13 +496,13 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_pull_big(int32_t const* bigq,
   f.flush();
 }
 
-template <typename WT>
+template <typename WT, bool PK = false>
 __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* row_end,
                                                           int32_t const* indices, int32_t* bigq, sssp_state<WT> s, int32_t big_deg)
 {
   __shared__ wave_queue_storage<3> wqs;
   wqs.init();
-  sssp_relax<WT> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far), wave_queue(wqs, 2, s.q_set, &s.cnt->n_set)};
+  sssp_relax<WT, PK> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far), wave_queue(wqs, 2, s.q_set, &s.cnt->n_set)};
 #ifdef CGA_SSSP_NO_MLP
   expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f, big_deg, row_end);
 #else
@@ -427,13 +510,13 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand(int32_t const* q, int6
 #endif
   f.flush();
 }
-template <typename WT>
+template <typename WT, bool PK = false>
 __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* row_end,
                                                               int32_t const* indices, sssp_state<WT> s)
 {
   __shared__ wave_queue_storage<3> wqs;
   wqs.init();
-  sssp_relax<WT> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far), wave_queue(wqs, 2, s.q_set, &s.cnt->n_set)};
+  sssp_relax<WT, PK> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far), wave_queue(wqs, 2, s.q_set, &s.cnt->n_set)};
 #ifdef CGA_SSSP_NO_MLP
   expand_big(bigq, offsets, indices, s.cnt, f, row_end);
 #else
@@ -443,7 +526,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_big(int32_t const* big
 }
 
 // far pile -> (near frontier | far pile'): d < lower: settled meanwhile, drop; d < upper: near; else keep
-template <typename WT>
+template <typename WT, bool PK = false>  // PK: `dist` points at the packed (distance, parent) words
 __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split(int32_t const* far_in, int64_t n, typename dist_bits<WT>::type const* dist, WT lower,
                                                          WT upper, int32_t* near_out, int32_t* far_out, uint32_t* mark_near,
                                                          uint32_t* mark_far, uint32_t round, uint32_t new_epoch, counters_t* cnt,
@@ -461,7 +544,9 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split(int32_t const* far_in, 
     int32_t v = 0;
     if (i < n) {
       v    = far_in[i];
-      WT d = B::from(dist[v]);
+      WT d;
+      if constexpr (PK) d = B::from(pk_dist_bits(reinterpret_cast<unsigned long long const*>(dist), v));
+      else d = B::from(dist[v]);
       if (d >= lower) {
         if (d < upper) near = atomicExch(&mark_near[v], round) != round;
         else {
@@ -908,6 +993,19 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_parents_big(int32_t const* bi
   expand_big_mlp(bigq, offsets, indices, cnt, f);
 }
 
+// packed (distance, parent) words -> the two result columns; parent INT32_MAX (none: unreached, or the source) -> -1
+__global__ void k_sssp_unpack(unsigned long long const* pk, int64_t n, uint32_t* dist_bits_out, int32_t* pred)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    unsigned long long const w = pk[i];
+    dist_bits_out[i] = (uint32_t)(w >> 32);
+    int32_t const p  = (int32_t)(uint32_t)w;
+    pred[i]          = p == INT32_MAX ? -1 : p;
+  }
+}
+
 template <typename WT>
 __global__ void k_sum_weights(WT const* w, int64_t n, double* out)
 {
@@ -1062,6 +1160,7 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   // depth_limit is compared after incrementing (bfs_impl.cuh:867-868)
   uint64_t const limit = depth_limit > (size_t)INT32_MAX ? (uint64_t)INT32_MAX : (uint64_t)depth_limit;
   bool const bu_profile = getenv("CUGRAPH_AMD_BFS_PROFILE") != nullptr;
+  bool const pull_parents_on = getenv("CUGRAPH_AMD_BFS_PULL_PARENTS") == nullptr || atoi(getenv("CUGRAPH_AMD_BFS_PULL_PARENTS")) != 0;  // (=0: the push claims parents with atomicMin)
   char const* env_bug = getenv("CUGRAPH_AMD_BU_GRID");  // workgroups per CU of the bottom-up kernel (experiments)
   int const bu_grid = (int)std::max<int64_t>(1, std::min<int64_t>(((nv + 63) / 64 + TV_WAVES * BU_GROUPS - 1) / (TV_WAVES * BU_GROUPS),
                                                                   (int64_t)h.num_cus * (env_bug ? atoi(env_bug) : 16)));
@@ -1107,7 +1206,9 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
         front_is_bitmap = false;
         mark("bitmap_to_queue", (long long)depth, n_cur);
       }
-      bfs_state s{dist->buf.as<int32_t>(), pred_p, vis_prev.data(), vis_new.data(), q_nxt,
+      // with in-edges at hand the parents of this level's discoveries are pulled afterwards (k_bfs_pull_parents); the push leaves pred alone
+      bool const pull_parents = pred_p != nullptr && in != nullptr && pull_parents_on;
+      bfs_state s{dist->buf.as<int32_t>(), pull_parents ? (int32_t*)nullptr : pred_p, vis_prev.data(), vis_new.data(), q_nxt,
                   cnt.data(), out_off, in_off, (int32_t)(depth + 1)};
       {
         timed_launch t(h, "bfs_expand");
@@ -1115,6 +1216,13 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
                            (int32_t const*)o.indices.data(), bigq.data(), s, big_deg_for(h, n_cur));
         hipLaunchKernelGGL(k_bfs_expand_big, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
                            (int32_t const*)o.indices.data(), s);
+        if (pull_parents) {  // (vis_prev still is the visited set of the level's start; bigq is free again)
+          hipLaunchKernelGGL(k_bfs_pull_parents, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)q_nxt, cnt.data(), in_off, in_idx, (uint32_t const*)vis_prev.data(), pred_p,
+                             bigq.data());
+          if (in->max_degree > BFS_PULL_LONG)
+            hipLaunchKernelGGL(k_bfs_pull_parents_long, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (counters_t const*)cnt.data(), in_off, in_idx,
+                               (uint32_t const*)vis_prev.data(), pred_p);
+        }
       }
       if (!in) HIP_TRY(hipMemcpyAsync(vis_prev.data(), vis_new.data(), nwords * 4, hipMemcpyDeviceToDevice, h.stream));
       mark("top_down", (long long)depth, n_cur);
@@ -1313,6 +1421,10 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   static bool const sssp_trace_multi = getenv("CUGRAPH_AMD_SSSP_TRACE") != nullptr;
   uint64_t steps = 0, relaxed = 0;
   counters_t c;
+  // fp32 + predecessors: (distance, parent) packed into one 64-bit word per vertex, lowered by one atomicMin per successful relaxation
+  // (sssp_relax<WT, true>): no sweep over the settled edges afterwards.  Default schedule only; CUGRAPH_AMD_SSSP_PACKED=0 keeps the sweep.
+  bool packed = false;
+  dvec<unsigned long long> pk;
   if (use_multi) {
     std::vector<dvec<int32_t>> subq(SSSP_K);
     for (auto& q : subq) q.resize_discard(n1);
@@ -1597,6 +1709,18 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   uint64_t const pull_min_edges = std::max<uint64_t>((uint64_t)g.ne / 10, (uint64_t)1 << 22);
   uint64_t front_edges = 0;  // out-edges of the current near frontier (0 for the source: its round is a push)
   dvec<uint32_t> fbits;
+  {
+    char const* env_pk = getenv("CUGRAPH_AMD_SSSP_PACKED");
+    packed = compute_predecessors && sizeof(WT) == 4 && !use_lh && !pull_allowed && !(env_pk && std::string(env_pk) == "0");
+    if (packed) {
+      pk.resize_discard(n1);
+      unsigned long long const none = ((unsigned long long)(uint32_t)unreached_bits << 32) | 0x7FFFFFFFull;
+      hipLaunchKernelGGL(k_fill_t<unsigned long long>, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, pk.data(), nv, none);
+      unsigned long long const at_source = 0x7FFFFFFFull;  // distance 0, no parent
+      HIP_TRY(hipMemcpyAsync(pk.data() + source, &at_source, 8, hipMemcpyHostToDevice, h.stream));
+      h.sync();  // (at_source is a local)
+    }
+  }
   static bool const sssp_trace = getenv("CUGRAPH_AMD_SSSP_TRACE") != nullptr;  // per round: sizes and wall time since the previous line (stderr)
   auto t_trace = std::chrono::steady_clock::now();
   auto relax_round = [&](int32_t const* front, int64_t n_front, int32_t const* beg, int32_t const* end, int32_t* set_out, int64_t n_set_in) {
@@ -1611,6 +1735,7 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
     HIP_TRY(hipMemcpyAsync(cnt.data(), h.pinned, sizeof(z), hipMemcpyHostToDevice, h.stream));
     sssp_state<WT> s{d, wrel, q_nxt, far_cur, mark_near.data(), mark_far.data(), use_lh ? set_out : nullptr, mark_set.data(), set_epoch, cnt.data(),
                      (WT)std::min(upper, (double)wmax), cutoff, round, far_epoch, (int32_t const*)o.offsets.data()};
+    if (packed) { s.pk = pk.data(); s.labels = g.renumbered ? g.number_map.data() : nullptr; s.source = source; }
     // few vertices with a large share of the graph's edges (the hubs right after the source): a pull round over the in-edges (sssp_pull_fn)
     bool const pull = pull_allowed && (pull_force || (front_edges >= pull_min_edges && n_front * 16 <= nv));
     if (pull) {
@@ -1632,8 +1757,18 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
       }
     } else {
       timed_launch t(h, "sssp_relax");
-      hipLaunchKernelGGL(k_sssp_expand<WT>, expand_grid(h, n_front), TV_BLOCK, 0, h.stream, front, n_front, beg, end, adj, bigq.data(), s, big_deg_for(h, n_front));
-      hipLaunchKernelGGL(k_sssp_expand_big<WT>, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), beg, end, adj, s);
+      bool launched = false;
+      if constexpr (sizeof(WT) == 4) {
+        if (packed) {
+          hipLaunchKernelGGL((k_sssp_expand<WT, true>), expand_grid(h, n_front), TV_BLOCK, 0, h.stream, front, n_front, beg, end, adj, bigq.data(), s, big_deg_for(h, n_front));
+          hipLaunchKernelGGL((k_sssp_expand_big<WT, true>), h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), beg, end, adj, s);
+          launched = true;
+        }
+      }
+      if (!launched) {
+        hipLaunchKernelGGL(k_sssp_expand<WT>, expand_grid(h, n_front), TV_BLOCK, 0, h.stream, front, n_front, beg, end, adj, bigq.data(), s, big_deg_for(h, n_front));
+        hipLaunchKernelGGL(k_sssp_expand_big<WT>, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), beg, end, adj, s);
+      }
     }
     h.read_back(&c, cnt.data(), 1);
     c.fold();
@@ -1680,6 +1815,17 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
       z.far_min_bits64  = ~0ull;
       std::memcpy(h.pinned, &z, sizeof(z));
       HIP_TRY(hipMemcpyAsync(cnt.data(), h.pinned, sizeof(z), hipMemcpyHostToDevice, h.stream));
+      bool split_done = false;
+      if constexpr (sizeof(WT) == 4) {
+        if (packed) {
+          hipLaunchKernelGGL((k_sssp_split<WT, true>), grid_for(n_far, TV_BLOCK, 2048), TV_BLOCK, 0, h.stream, (int32_t const*)far_cur, n_far,
+                             reinterpret_cast<bits_t const*>(pk.data()), (WT)std::min(lower, (double)wmax), (WT)std::min(upper, (double)wmax), q_cur, far_nxt,
+                             mark_near.data(), mark_far.data(), round, far_epoch, cnt.data(), (int32_t*)nullptr, mark_set.data(), set_epoch,
+                             (int32_t const*)o.offsets.data());
+          split_done = true;
+        }
+      }
+      if (!split_done)
       hipLaunchKernelGGL(k_sssp_split<WT>, grid_for(n_far, TV_BLOCK, 2048), TV_BLOCK, 0, h.stream, (int32_t const*)far_cur, n_far,
                          (bits_t const*)d, (WT)std::min(lower, (double)wmax), (WT)std::min(upper, (double)wmax), q_cur, far_nxt,
                          mark_near.data(), mark_far.data(), round, far_epoch, cnt.data(), use_lh ? set_cur : (int32_t*)nullptr, mark_set.data(), set_epoch,
@@ -1704,7 +1850,12 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
 
   }
 
-  if (compute_predecessors) {
+  if (packed) {  // the two result columns out of the packed words; nothing else to do for the parents
+    if constexpr (sizeof(WT) == 4) {
+      if (nv > 0) hipLaunchKernelGGL(k_sssp_unpack, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, (unsigned long long const*)pk.data(), nv, reinterpret_cast<uint32_t*>(d), preds->buf.as<int32_t>());
+    }
+    c = counters_t{};
+  } else if (compute_predecessors) {
     fill_i32(h, preds->buf.as<int32_t>(), nv, INT32_MAX);
     HIP_TRY(hipMemsetAsync(cnt.data(), 0, sizeof(counters_t), h.stream));
     sssp_parent<WT> f{(bits_t const*)d, w, preds->buf.as<int32_t>(), g.renumbered ? g.number_map.data() : nullptr, source};

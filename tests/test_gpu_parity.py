@@ -388,12 +388,55 @@ def test_sssp_rmat_vs_oracle(cg, handle, orc, scale, kind, dtype):
         (bd,) = by_vertex(bv, bd)
         reach = bd != orc.INT32_MAX
         assert np.array_equal(dist[reach], bd[reach].astype(dtype)) and np.all(dist[~reach] == np.finfo(dtype).max)
-    # cutoff
+    # cutoff (with predecessors: the packed path honours it too -- a vertex beyond the cutoff has no parent)
     cut = float(np.median(od[od < np.finfo(dtype).max]))
-    v, dist, _ = cg.sssp(handle, g, src, cut, False, False)
-    (dist,) = by_vertex(v, dist)
+    v, dist, predc = cg.sssp(handle, g, src, cut, True, False)
+    dist, predc = by_vertex(v, dist, predc)
     oc, _ = orc.sssp(nv, off, idx, ww, src, cutoff=cut)
     assert np.array_equal(dist, oc)
+    assert np.array_equal(predc, orc.sssp_min_pred(nv, off, idx, ww, src, oc))
+
+
+@pytest.mark.parametrize("scale,kind", [(13, "int"), (15, "real"), (14, "zero")])
+def test_sssp_packed_parents_equal_the_sweep(cg, handle, orc, monkeypatch, scale, kind):
+    """Round 5: fp32 SSSP with predecessors lowers (distance, external parent id) with one 64-bit atomicMin per successful relaxation -- the
+    reference's lexicographic minimum (sssp_impl.cuh:334) -- instead of sweeping the settled edges afterwards.  Both ways must name the same
+    parents (smallest external id over the tight in-edges) and the oracle's; "zero": zero-weight edges and cycles of them (the source keeps -1)."""
+    s, d = rmat_graph(orc, scale, seed=11)
+    nv = 1 << scale
+    rng = np.random.default_rng(2)
+    if kind == "int":
+        w = int_weights(s.size, seed=6).astype(np.float32)
+    elif kind == "real":
+        w = (rng.random(s.size) + 0.01).astype(np.float32)
+    else:
+        w = rng.integers(0, 3, s.size).astype(np.float32)  # a third of the edges weigh nothing
+    g = make_graph(cg, handle, s, d, w, transposed=False, renumber=True, vertices=np.arange(nv))
+    off, idx, ww = orc.coo_to_cs(nv, s, d, w)
+    src = int(np.nonzero(np.diff(off) > 0)[0][5])
+    res = {}
+    for packed in ("1", "0"):
+        monkeypatch.setenv("CUGRAPH_AMD_SSSP_PACKED", packed)
+        v, dist, pred = cg.sssp(handle, g, src, float(np.finfo(np.float32).max), True, False)
+        res[packed] = by_vertex(v, dist, pred)
+    od, _ = orc.sssp(nv, off, idx, ww, src)
+    for packed in ("1", "0"):
+        assert np.array_equal(res[packed][0], od), packed
+        assert res[packed][1][src] == -1
+    assert np.array_equal(res["1"][1], res["0"][1])  # the same rule evaluated two ways
+    if kind != "zero":
+        assert np.array_equal(res["1"][1], orc.sssp_min_pred(nv, off, idx, ww, src, od))
+    else:  # zero-weight cycles: "tight in-edge" no longer implies "on a shortest path tree"; every named parent must still be a tight in-neighbour
+        for packed in ("1", "0"):
+            pred = res[packed][1]
+            has = pred >= 0
+            assert np.array_equal(has, (od < np.finfo(np.float32).max) & (np.arange(nv) != src))
+            key = set(zip(s.tolist(), d.tolist(), w.tolist()))
+            vs = np.nonzero(has)[0]
+            pick = vs[:: max(1, vs.size // 2000)]
+            for vtx in pick:
+                pu = int(pred[vtx])
+                assert any((pu, int(vtx), float(x)) in key and np.float32(od[pu]) + np.float32(x) == od[vtx] for x in (0.0, 1.0, 2.0))
 
 
 @pytest.mark.parametrize("mode,batch", [("multi", 0), ("dev", 8), ("dev", 1), ("dev", 3), ("radix", -1), ("radix", -64), ("radix", -100000)])
