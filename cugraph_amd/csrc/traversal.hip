@@ -121,9 +121,9 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand_big(int32_t const* bigq
 // internal id -- that was visited before the level started.  Such a neighbour sits exactly one level up (a shallower one would have given
 // the vertex a smaller depth), so this is the rule of the push with atomicMin (smallest internal id among the frontier parents) and of the
 // bottom-up levels, evaluated per DISCOVERED vertex (10^4-10^5 in the levels that run top-down) instead of per inspected edge: the push
-// then does nothing for the parents (it used to read pred[v] for every edge into a not yet visited vertex and atomicMin most of them:
-// +0.29 ms per BFS at RMAT-24).  One wavefront per vertex, 64 neighbours per step, ballot early exit; rows above BFS_PULL_LONG in-edges go to
-// a list that k_bfs_pull_parents_long scans with every wavefront of its grid (no single wavefront walks a 10^6-entry row).
+// then does nothing for the parents (it reads pred[v] for every edge into a not yet visited vertex and atomicMins most of them:
+// +0.2 ms per BFS at RMAT-24).  Measured slower than that (see run_bfs) and therefore opt-in; kept under test.  One wavefront per vertex, 64 neighbours per step, ballot early exit; rows above BFS_PULL_LONG in-edges go to
+// a list that k_bfs_pull_parents_long scans with a workgroup per row (no single wavefront walks a 10^6-entry row).
 constexpr int32_t BFS_PULL_LONG = 8192;
 __global__ void __launch_bounds__(TV_BLOCK) k_bfs_pull_parents(int32_t const* q, counters_t* cnt, int32_t const* in_off, int32_t const* in_idx, uint32_t const* vis_prev,
                                                                int32_t* pred, int32_t* longq)
@@ -151,23 +151,30 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_pull_parents(int32_t const* q,
 }
 __global__ void __launch_bounds__(TV_BLOCK) k_bfs_pull_parents_long(int32_t const* longq, counters_t const* cnt, int32_t const* in_off, int32_t const* in_idx,
                                                                     uint32_t const* vis_prev, int32_t* pred)
-{
+{  // one workgroup per long row at a time: its wavefronts take the row's 64-entry chunks round-robin (ascending), the position of the
+   // earliest hit is kept in LDS and ends the scan of every wavefront that has passed it
+  __shared__ uint32_t s_best;
   uint32_t const n = cnt->n_set;
-  int const lane = threadIdx.x & 63;
-  eoff_t const gwave = ((eoff_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((eoff_t)gridDim.x * blockDim.x) >> 6;
-  for (uint32_t k = 0; k < n; ++k) {
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
     int32_t const v = longq[k];
     eoff_t const b = eoff(in_off, v), e = eoff(in_off, v + 1);
-    for (eoff_t p0 = b + gwave * 64; p0 < e; p0 += nwaves * 64) {  // this wavefront's chunks ascend: its first hit is its smallest
+    if (threadIdx.x == 0) s_best = 0xFFFFFFFFu;
+    __syncthreads();
+    for (eoff_t p0 = b + (eoff_t)wave * 64; p0 < e; p0 += (eoff_t)TV_WAVES * 64) {
+      if (p0 - b > *reinterpret_cast<volatile uint32_t*>(&s_best)) break;  // (wave-uniform: an LDS word)
       eoff_t const p = p0 + lane;
       int32_t const u = p < e ? in_idx[p] : -1;
       bool const hit  = u >= 0 && ((vis_prev[(uint32_t)u >> 5] >> ((uint32_t)u & 31u)) & 1u);
       uint64_t const m = __ballot(hit);
       if (m) {
-        if (lane == 0) atomicMin(&pred[v], __shfl(u, __ffsll((unsigned long long)m) - 1));
+        if (lane == 0) atomicMin(&s_best, (uint32_t)(p0 - b) + (uint32_t)(__ffsll((unsigned long long)m) - 1));
         break;
       }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) pred[v] = s_best != 0xFFFFFFFFu ? in_idx[b + s_best] : INT32_MAX;
+    __syncthreads();
   }
 }
 
@@ -1160,7 +1167,10 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   // depth_limit is compared after incrementing (bfs_impl.cuh:867-868)
   uint64_t const limit = depth_limit > (size_t)INT32_MAX ? (uint64_t)INT32_MAX : (uint64_t)depth_limit;
   bool const bu_profile = getenv("CUGRAPH_AMD_BFS_PROFILE") != nullptr;
-  bool const pull_parents_on = getenv("CUGRAPH_AMD_BFS_PULL_PARENTS") == nullptr || atoi(getenv("CUGRAPH_AMD_BFS_PULL_PARENTS")) != 0;  // (=0: the push claims parents with atomicMin)
+  // OPT-IN (CUGRAPH_AMD_BFS_PULL_PARENTS=1), measured at RMAT-24 (32 roots, profiles/r5d_bfs_ab.txt): 1.74 ms against 1.37 ms with the
+  // atomicMin in the push.  The levels that run top-down are the ones whose discoveries are HUBS (one frontier vertex discovering 1 141 vertices
+  // of 10^4-10^5 in-edges each): a pull scans half of every such row to find the one frontier member, the push reads the frontier's out-edges once.
+  bool const pull_parents_on = getenv("CUGRAPH_AMD_BFS_PULL_PARENTS") != nullptr && atoi(getenv("CUGRAPH_AMD_BFS_PULL_PARENTS")) != 0;
   char const* env_bug = getenv("CUGRAPH_AMD_BU_GRID");  // workgroups per CU of the bottom-up kernel (experiments)
   int const bu_grid = (int)std::max<int64_t>(1, std::min<int64_t>(((nv + 63) / 64 + TV_WAVES * BU_GROUPS - 1) / (TV_WAVES * BU_GROUPS),
                                                                   (int64_t)h.num_cus * (env_bug ? atoi(env_bug) : 16)));

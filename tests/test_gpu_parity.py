@@ -439,6 +439,27 @@ def test_sssp_packed_parents_equal_the_sweep(cg, handle, orc, monkeypatch, scale
                 assert any((pu, int(vtx), float(x)) in key and np.float32(od[pu]) + np.float32(x) == od[vtx] for x in (0.0, 1.0, 2.0))
 
 
+@pytest.mark.parametrize("scale,transposed", [(16, True), (18, False)])
+def test_bfs_pulled_parents_equal_pushed_parents(cg, handle, orc, monkeypatch, scale, transposed):
+    """Round 5 (opt-in schedule): the parents of a top-down level's discoveries pulled from their in-edges -- first in-neighbour, ascending
+    internal id, visited before the level -- instead of claimed with atomicMin by the push.  Same rule, same parents; rows above 8192 in-edges
+    take the workgroup-per-row kernel (RMAT-16's top vertices have 12 863)."""
+    s, d = rmat_graph(orc, scale)
+    nv = 1 << scale
+    g = make_graph(cg, handle, s, d, None, transposed=transposed, renumber=True, vertices=np.arange(nv))
+    off, idx, _ = orc.coo_to_cs(nv, s, d)
+    for src in [int(x) for x in np.nonzero(np.diff(off) > 0)[0][[0, 7, 100]]]:
+        got = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("CUGRAPH_AMD_BFS_PULL_PARENTS", mode)
+            dist, pred, v = cg.bfs(handle, g, T([src], np.int32), False, 0, True, False)
+            got[mode] = by_vertex(v, dist, pred)
+        od, _ = orc.bfs(nv, off, idx, [src])
+        for mode in ("0", "1"):
+            assert np.array_equal(got[mode][0], od)
+            assert np.array_equal(got[mode][1], bfs_expected_parents(s, d, od, v)), mode
+
+
 @pytest.mark.parametrize("mode,batch", [("multi", 0), ("dev", 8), ("dev", 1), ("dev", 3), ("radix", -1), ("radix", -64), ("radix", -100000)])
 @pytest.mark.parametrize("scale,kind,dtype,subq", [(12, "int", np.float32, 8), (14, "real", np.float32, 8), (16, "int", np.float32, 4), (14, "int", np.float64, 8),
                                                    (13, "unit", np.float32, 2), (15, "int", np.float32, 1)])
