@@ -246,14 +246,14 @@ __global__ void k_wave_records(tiled_wave_t const* waves, uint32_t const* call, 
 
 __global__ void k_assign_slots(uint64_t const* keys, uint32_t const* vals, int64_t n, int64_t n_runs, uint32_t const* shift,
                                uint32_t const* run_dst, uint32_t const* tile_row0, int nI, uint32_t* rpos, tiled_wave_t* waves,
-                               uint16_t* dstl16)
+                               uint16_t* dstl16, uint32_t const* slot_of = nullptr)
 {
   int64_t s      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; s < n; s += stride) {
     uint32_t I    = (uint32_t)keys[s];
     uint32_t idx  = vals[s];
-    uint32_t slot = (uint32_t)s + shift[I];  // modulo 2^32
+    uint32_t slot = slot_of ? slot_of[s] : (uint32_t)s + shift[I];  // modulo 2^32
     if ((int64_t)idx < n_runs) {
       rpos[idx + 1] = slot;
       dstl16[slot] = (uint16_t)(run_dst[idx] - tile_row0[I]);
@@ -262,6 +262,69 @@ __global__ void k_assign_slots(uint64_t const* keys, uint32_t const* vals, int64
       wd.head_slot     = slot;
       if ((int)I < nI) dstl16[slot] = (uint16_t)(run_dst[wd.rank - 1] - tile_row0[I]);
     }
+  }
+}
+
+// ---- slot blocks aligned to whole cache lines (CUGRAPH_AMD_TILED_BLOCK_ALIGN = slots): the runs of ONE source tile that fall into ONE
+// destination tile are a BLOCK of consecutive slots, written by the one workgroup that streams that piece of the source tile; two blocks
+// that share a 128-byte line are written at different times by different workgroups, i.e. twice as a partial line -- and scattered pieces that
+// start off a line boundary reach a third to a half of the write rate of aligned ones (tools/ubench/scatter_store_bench.hip:
+// 64 floats per piece 4.25 TB/s aligned, 1.74 TB/s 12 bytes off).  With the option every block starts on a multiple of A slots and is padded
+// to a multiple of A (the padding is never written -- it stays zero -- and phase 2 adds those zeros to row 0).
+// source tile of every run (runs are numbered by (source tile, destination): tile J owns the run ordinals [tile_run0[J], tile_run0[J + 1]))
+__global__ void k_run_tile(uint32_t const* tile_run0, int nJ, int64_t n_runs, uint32_t* run_J)
+{
+  int64_t q      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; q < n_runs; q += stride) {
+    int lo = 0, hi = nJ;  // tile_run0[lo] <= q < tile_run0[hi]
+    while (hi - lo > 1) {
+      int const mid = (lo + hi) >> 1;
+      if (tile_run0[mid] <= (uint32_t)q) lo = mid; else hi = mid;
+    }
+    run_J[q] = (uint32_t)lo;
+  }
+}
+// element s of the (destination tile)-sorted list starts a block: first of its region, or another source tile than its predecessor, or the
+// first wavefront-head slot of the region (the heads sit behind the region's runs: ids >= n_runs)
+__global__ void k_aligned_block_flags(uint64_t const* keys, uint32_t const* vals, int64_t n, int64_t n_runs, uint32_t const* run_J, uint32_t* flag)
+{
+  int64_t s      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; s < n; s += stride) {
+    bool f = s == 0 || keys[s] != keys[s - 1];
+    if (!f) {
+      uint32_t const a = vals[s - 1], b = vals[s];
+      bool const ha = (int64_t)a >= n_runs, hb = (int64_t)b >= n_runs;
+      f = ha != hb || (!ha && run_J[a] != run_J[b]);
+    }
+    flag[s] = f ? 1u : 0u;
+  }
+}
+__global__ void k_aligned_block_starts(uint32_t const* flag, uint32_t const* bid, int64_t n, uint32_t* bstart)
+{
+  int64_t s      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; s < n; s += stride)
+    if (flag[s]) bstart[bid[s]] = (uint32_t)s;
+}
+__global__ void k_aligned_block_lengths(uint32_t const* bstart, int64_t nb, int64_t n, uint32_t align, uint32_t* padded)
+{
+  int64_t b      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; b < nb; b += stride) {
+    uint32_t const len = (b + 1 < nb ? bstart[b + 1] : (uint32_t)n) - bstart[b];
+    padded[b] = (len + align - 1) / align * align;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) padded[nb] = 0;
+}
+__global__ void k_aligned_slots(uint32_t const* flag, uint32_t const* bid, uint32_t const* bstart, uint32_t const* pad_off, int64_t n, uint32_t* slot_of)
+{
+  int64_t s      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; s < n; s += stride) {
+    uint32_t const b = flag[s] ? bid[s] : bid[s] - 1u;  // bid = exclusive scan of the flags: an element that starts a block has its own id there
+    slot_of[s] = pad_off[b] + ((uint32_t)s - bstart[b]);
   }
 }
 
@@ -708,9 +771,54 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     radix_sort_u64_u32(h, keys.data(), vals.data(), keys_tmp.data(), vals_tmp.data(), n_el, 0, bits_for_u((uint64_t)t.nI));
     std::vector<uint32_t> first = key_starts(h, keys.data(), n_el, (int64_t)t.nI + 1);  // regions 0..nI (nI = dummy)
     std::vector<uint32_t> shift(t.nI + 1);
+    char const* env_align = getenv("CUGRAPH_AMD_TILED_BLOCK_ALIGN");
+    uint32_t const align  = env_align ? (uint32_t)std::max(0, atoi(env_align)) / 8u * 8u : (uint32_t)kTiledBlockAlign;
+    dvec<uint32_t> slot_of;
+    if (align >= 8 && t.n_runs > 0) {  // every (destination tile, source tile) block on its own cache lines (see k_run_tile)
+      std::vector<uint32_t> tile_run0((size_t)nJ + 1);
+      {
+        dvec<uint32_t> d_pos, d_r0((size_t)nJ + 1);
+        to_device(h, d_pos, tile_off);  // (tile_off[J] = first tiled edge position of tile J; ord[] = run ordinal at an edge position)
+        hipLaunchKernelGGL(k_gather_u32, grid_for((int64_t)nJ + 1, kBlock), kBlock, 0, h.stream, (uint32_t const*)ord.data(), (uint32_t const*)d_pos.data(), (int64_t)nJ + 1, d_r0.data());
+        dvec<uint32_t> run_J((size_t)t.n_runs), flag((size_t)n_el + 1), bid((size_t)n_el + 1);
+        hipLaunchKernelGGL(k_run_tile, grid_for(t.n_runs, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)d_r0.data(), nJ, t.n_runs, run_J.data());
+        hipLaunchKernelGGL(k_aligned_block_flags, grid_for(n_el, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), n_el, t.n_runs,
+                           (uint32_t const*)run_J.data(), flag.data());
+        HIP_TRY(hipMemsetAsync(flag.data() + n_el, 0, sizeof(uint32_t), h.stream));
+        exclusive_scan_u32(h, flag.data(), bid.data(), n_el + 1);
+        uint32_t nb = 0;
+        h.read_back(&nb, bid.data() + n_el, 1);
+        dvec<uint32_t> bstart((size_t)nb + 1), padded((size_t)nb + 1), pad_off((size_t)nb + 1);
+        hipLaunchKernelGGL(k_aligned_block_starts, grid_for(n_el, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)flag.data(), (uint32_t const*)bid.data(), n_el, bstart.data());
+        hipLaunchKernelGGL(k_aligned_block_lengths, grid_for((int64_t)nb, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)bstart.data(), (int64_t)nb, n_el, align, padded.data());
+        exclusive_scan_u32(h, padded.data(), pad_off.data(), (int64_t)nb + 1);
+        uint32_t total = 0;
+        h.read_back(&total, pad_off.data() + nb, 1);
+        CGA_EXPECTS((uint64_t)total + 64 < ((uint64_t)1 << 32) / vsize, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: the padded partial buffer exceeds the 32-bit byte-offset addressing of phase 1");
+        slot_of.resize_discard((size_t)n_el);
+        hipLaunchKernelGGL(k_aligned_slots, grid_for(n_el, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)flag.data(), (uint32_t const*)bid.data(), (uint32_t const*)bstart.data(),
+                           (uint32_t const*)pad_off.data(), n_el, slot_of.data());
+        // region I starts at the slot of its first element (an empty region at the next one's; the dummy region nI holds the unused head slots)
+        dvec<uint32_t> d_first, d_roff((size_t)t.nI + 2);
+        std::vector<uint32_t> fidx(first.begin(), first.end());
+        for (auto& x : fidx) x = std::min<uint32_t>(x, (uint32_t)n_el);  // (n_el = "one past the last element")
+        fidx.push_back((uint32_t)n_el);
+        // slot_of has n_el entries: append the total so that index n_el reads it
+        dvec<uint32_t> slot_ext((size_t)n_el + 1);
+        HIP_TRY(hipMemcpyAsync(slot_ext.data(), slot_of.data(), (size_t)n_el * sizeof(uint32_t), hipMemcpyDeviceToDevice, h.stream));
+        HIP_TRY(hipMemcpyAsync(slot_ext.data() + n_el, &total, sizeof(uint32_t), hipMemcpyHostToDevice, h.stream));
+        to_device(h, d_first, fidx);
+        hipLaunchKernelGGL(k_gather_u32, grid_for((int64_t)t.nI + 2, kBlock), kBlock, 0, h.stream, (uint32_t const*)slot_ext.data(), (uint32_t const*)d_first.data(), (int64_t)t.nI + 2, d_roff.data());
+        std::vector<uint32_t> roff = to_host(h, d_roff.data(), (size_t)t.nI + 2);
+        for (int I = 0; I <= t.nI + 1; ++I) region_off[I] = roff[I];
+        region_off[0] = 0;
+      }
+      for (int I = 0; I <= t.nI; ++I) shift[I] = 0;  // unused: slots come from slot_of
+    } else {
     for (int I = 0; I <= t.nI; ++I) {
       region_off[I + 1] = region_off[I] + ((first[I + 1] - first[I] + 7u) & ~7u);
       shift[I]          = region_off[I] - first[I];
+    }
     }
     t.n_slots = region_off[t.nI + 1];
     size_t const spad = (size_t)t.n_slots + 64;
@@ -726,7 +834,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     to_device(h, d_shift, shift);
     hipLaunchKernelGGL(k_assign_slots, grid_for(n_el, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), n_el,
                        t.n_runs, (uint32_t const*)d_shift.data(), (uint32_t const*)run_dst.data(), (uint32_t const*)t.tile_row0.data(), t.nI, rpos.data(),
-                       waves.data(), t.dstl16.data());
+                       waves.data(), t.dstl16.data(), slot_of.size() ? (uint32_t const*)slot_of.data() : (uint32_t const*)nullptr);
     h.sync();
     keys = dvec<uint64_t>(); keys_tmp = dvec<uint64_t>(); vals = dvec<uint32_t>(); vals_tmp = dvec<uint32_t>();
     // ---- slot blocks: inside one (destination tile, source tile) block the slots follow the run order, so phase 1 needs
