@@ -342,6 +342,7 @@ struct graph_t {  // behind cugraph_graph_t (cpp/src/c_api/graph.hpp:61-77)
   bool out_weight_sums_valid{false};
   double weight_sum{0};  // sum of the edge weights (SSSP bucket width), cached
   bool weight_sum_valid{false};
+  bool weights_uniform{false};  // every edge weight is the same value (found with the sum): distance order inside a round carries no information
   int64_t sssp_heavy_cut{-1};  // SSSP (radix sub-queues): ids below this have at least average out-degree (ids are degree-sorted); -1 = not counted yet
   int bfs_calls{0};  // the CSC (bottom-up BFS levels) is built from the second traversal of a non-symmetric graph on
   // cugraph_graph_create_mg on a communicator handle: this rank's slice + the partitions built from it (mg_graph.hpp); the single-GPU
@@ -428,6 +429,10 @@ void histogram_i32_mapped(handle_t const& h, int32_t const* keys, int64_t n, int
 // keys/vals are sorted in place; tmp buffers of the same size are required.
 void radix_sort_u64_u32(handle_t const& h, uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp,
                         uint32_t* vals_tmp, int64_t n, int bit_lo, int bit_hi);
+// one stable 8-bit pass without synchronisation or copy-back: the result is in (keys_out, vals_out); hist = caller's scratch of radix_pass_scratch(n) words
+size_t radix_pass_scratch(int64_t n);
+void radix_pass_u64_u32(handle_t const& h, uint64_t const* keys_in, uint32_t const* vals_in, uint64_t* keys_out, uint32_t* vals_out, int64_t n, int shift, int bits,
+                        uint32_t* hist);
 // out[i] = src[idx[i]] for 4- / 8-byte elements
 void gather_b32(handle_t const& h, uint32_t const* src, uint32_t const* idx, uint32_t* out, int64_t n);
 void gather_b64(handle_t const& h, uint64_t const* src, uint32_t const* idx, uint64_t* out, int64_t n);

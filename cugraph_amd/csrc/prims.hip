@@ -460,6 +460,20 @@ void radix_sort_u64_u32(handle_t const& h, uint64_t* keys, uint32_t* vals, uint6
   h.sync();  // `hist` is freed on return
 }
 
+// ONE stable 8-bit pass, stream-ordered: no synchronisation, no copy back -- (keys_out, vals_out) hold the result; `hist` is the caller's
+// scratch of radix_pass_scratch(n) words (it must outlive the launches).  For callers inside a latency-sensitive loop (the SSSP hub round).
+size_t radix_pass_scratch(int64_t n) { return (size_t)((n + RS_TILE - 1) / RS_TILE) * RS_BINS + 1; }
+void radix_pass_u64_u32(handle_t const& h, uint64_t const* keys_in, uint32_t const* vals_in, uint64_t* keys_out, uint32_t* vals_out, int64_t n, int shift, int bits,
+                        uint32_t* hist)
+{
+  if (n <= 0) return;
+  int const nblocks   = (int)((n + RS_TILE - 1) / RS_TILE);
+  uint32_t const mask = (1u << bits) - 1u;
+  hipLaunchKernelGGL(k_rs_hist, nblocks, RS_THREADS, 0, h.stream, keys_in, n, shift, mask, hist, nblocks);
+  exclusive_scan_u32(h, hist, hist, (int64_t)nblocks * RS_BINS);
+  hipLaunchKernelGGL(k_rs_scatter, nblocks, RS_THREADS, 0, h.stream, keys_in, vals_in, keys_out, vals_out, n, shift, mask, (uint32_t const*)hist, nblocks);
+}
+
 void gather_b32(handle_t const& h, uint32_t const* src, uint32_t const* idx, uint32_t* out, int64_t n)
 {
   if (n > 0) hipLaunchKernelGGL(k_gather<uint32_t>, grid_for(n, kBlock, 8192), kBlock, 0, h.stream, src, idx, out, n);
