@@ -264,48 +264,67 @@ struct lv_hash_args {
   unsigned long long* best_bits;  // [nv]
   int32_t* best_c;                // [nv]
   unsigned long long* ifix;       // += weight of the rows' edges that stay inside their cluster (fixed point): the modularity's first term
+  // what depends on the level's graph only (round 5: computed once per level by k_lv_chunk_prep instead of by every sweep's workgroups --
+  // a chain of four dependent loads on ONE thread before a workgroup could start, and src -> off per edge)
+  long long const* range;         // [chunks][2] edge range [p0, p1) of every chunk (p1 <= p0: nothing)
+  uint16_t const* rs;             // [ne] row slot of every edge = position of its row's first edge inside that row's window (off[src] mod LVH_B)
 };
 __device__ __forceinline__ uint32_t lvh_slot(uint32_t rs, uint32_t cl) { return ((rs * 0x9E3779B1u) ^ (cl * 0x85EBCA6Bu) ^ (cl >> 15)) & (LVH_SLOTS - 1); }
+static_assert((LVH_B & (LVH_B - 1)) == 0, "the row slot is off[v] mod LVH_B");
+// once per level: the edge range of every chunk (the rule of round 3, see above) and the row slot of every edge
+__global__ void k_lv_chunk_prep(int32_t const* src, int32_t const* off, int64_t ne, long long* range, uint16_t* rs)
+{
+  int64_t const t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t const n_chunks = (ne + LVH_B - 1) / LVH_B;
+  for (int64_t b = t; b < n_chunks; b += stride) {
+    int64_t const e_lo = b * (int64_t)LVH_B, e_hi = e_lo + LVH_B < ne ? e_lo + LVH_B : ne;
+    int64_t p0 = e_lo, p1 = e_lo;
+    if (e_lo > 0 && src[e_lo - 1] == src[e_lo]) p0 = off[src[e_lo] + 1];  // the window opens inside a row of an earlier chunk (or a hub)
+    if (p0 < e_hi) {
+      int32_t const vl = src[e_hi - 1];  // the last row that starts in the window
+      int64_t const bb = off[vl], ee = off[vl + 1];
+      p1 = ee - bb > LVH_B ? bb : ee;    // a hub can only be the last row of a window
+    }
+    range[2 * b]     = p0;
+    range[2 * b + 1] = p1 > p0 ? p1 : p0;
+  }
+  for (int64_t e = t; e < ne; e += stride) rs[e] = (uint16_t)((uint32_t)off[src[e]] & (uint32_t)(LVH_B - 1));
+}
 __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
 {
   __shared__ unsigned long long s_key[LVH_SLOTS], s_sum[LVH_SLOTS];
   __shared__ unsigned long long s_bits[LVH_CAP];
   __shared__ unsigned long long s_sub[LVH_B], s_best[LVH_B];
-  __shared__ int32_t s_bestc[LVH_B];
+  __shared__ double s_k[LVH_B], s_acv[LVH_B];  // per row: the vertex's weight, the weight of its cluster (gathered once per row, by the row's first edge)
+  __shared__ int32_t s_bestc[LVH_B], s_cv[LVH_B];
   __shared__ uint32_t s_cl[LVH_CAP];
   __shared__ uint16_t s_rs[LVH_CAP];
-  __shared__ long long s_range[2];
   __shared__ unsigned long long s_int;
   int const tid = threadIdx.x;
-  int64_t const e_lo = blockIdx.x * (int64_t)LVH_B, e_hi = e_lo + LVH_B < A.ne ? e_lo + LVH_B : A.ne;
-  if (tid == 0) {
-    s_int = 0;
-    int64_t p0 = e_lo, p1 = e_lo;
-    if (e_lo > 0 && A.src[e_lo - 1] == A.src[e_lo]) p0 = A.off[A.src[e_lo] + 1];  // the window opens inside a row of an earlier chunk (or a hub)
-    if (p0 < e_hi) {
-      int32_t const vl = A.src[e_hi - 1];  // the last row that starts in the window
-      int64_t const b = A.off[vl], e = A.off[vl + 1];
-      p1 = e - b > LVH_B ? b : e;          // a hub can only be the last row of a window
-    }
-    s_range[0] = p0;
-    s_range[1] = p1 > p0 ? p1 : p0;
-  }
+  int64_t const e_lo = blockIdx.x * (int64_t)LVH_B;
+  int64_t const p0   = A.range[2 * (int64_t)blockIdx.x];
+  int const n        = (int)(A.range[2 * (int64_t)blockIdx.x + 1] - p0);  // < 2 * LVH_B
+  if (n <= 0) return;
+  if (tid == 0) s_int = 0;
   for (int i = tid; i < LVH_SLOTS; i += LVH_THREADS) { s_key[i] = LVH_EMPTY; s_sum[i] = 0; }
   for (int i = tid; i < LVH_B; i += LVH_THREADS) { s_sub[i] = 0; s_best[i] = 0; s_bestc[i] = 0x7f7f7f7f; }
   __syncthreads();
-  int64_t const p0 = s_range[0];
-  int const n      = (int)(s_range[1] - p0);  // < 2 * LVH_B
-  if (n <= 0) return;
-  // pass 1: (row slot, cluster of destination) -> sum of weights; self-loops per row
+  // pass 1: (row slot, cluster of destination) -> sum of weights; self-loops per row; the row's own operands of the gain
   for (int i = tid; i < n; i += LVH_THREADS) {
     int64_t const e  = p0 + i;
     int32_t const v  = A.src[e], u = A.dst[e];
+    uint32_t const rs = A.rs[e];
     uint32_t const cl = (uint32_t)A.c[u];
-    uint32_t const rs = (uint32_t)((int64_t)A.off[v] - e_lo);
     unsigned long long const wf  = (unsigned long long)__double2ll_rn(A.w[e] * A.scale);
     unsigned long long const key = ((unsigned long long)rs << 32) | cl;
     s_cl[i] = cl;
     s_rs[i] = (uint16_t)rs;
+    if ((uint32_t)(e - e_lo) == rs) {  // the row's first edge (rows of a chunk start inside its window)
+      int32_t const cv = A.c[v];
+      s_cv[rs]  = cv;
+      s_k[rs]   = A.k[v];
+      s_acv[rs] = A.a[cv];
+    }
     uint32_t slot = lvh_slot(rs, cl);
     for (;;) {
       unsigned long long const old = atomicCAS(&s_key[slot], LVH_EMPTY, key);
@@ -326,11 +345,11 @@ __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
       slot = (slot + 1) & (LVH_SLOTS - 1);
     }
   };
-  // pass 2: the gain of every edge's (row, cluster) pair (pairs that occur on several edges are evaluated as often: same value)
+  // pass 2: the gain of every edge's (row, cluster) pair (pairs that occur on several edges are evaluated as often: same value); the only
+  // global access left here is the weight of the destination's cluster
   for (int i = tid; i < n; i += LVH_THREADS) {
-    int32_t const v   = A.src[p0 + i];
     uint32_t const rs = s_rs[i], cl = s_cl[i];
-    int32_t const cv  = A.c[v];
+    int32_t const cv  = s_cv[rs];
     unsigned long long const sfix = lookup(rs, cl);
     unsigned long long const self = (int32_t)cl == cv ? sfix : lookup(rs, (uint32_t)cv);
     unsigned long long const subf = s_sub[rs];
@@ -338,7 +357,7 @@ __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
     double const sub     = (double)(long long)subf * A.inv_scale;
     double const old_sum = (double)(long long)(self - subf) * A.inv_scale;
     double const new_sum = (int32_t)cl == cv ? s - sub : s;
-    double const delta   = lv_delta(new_sum, old_sum, A.a[cl], A.a[cv], A.k[v], A.m, A.resolution);
+    double const delta   = lv_delta(new_sum, old_sum, A.a[cl], s_acv[rs], s_k[rs], A.m, A.resolution);
     unsigned long long const bits = delta > 0.0 ? (unsigned long long)__double_as_longlong(delta) : 0ull;
     s_bits[i] = bits;
     if (bits) atomicMax(&s_best[rs], bits);  // positive doubles order like their bit patterns
@@ -351,13 +370,13 @@ __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
   }
   __syncthreads();
   for (int i = tid; i < n; i += LVH_THREADS) {
-    int64_t const e = p0 + i;
-    int32_t const v = A.src[e];
-    if (i == 0 || A.src[e - 1] != v) {  // first edge of a row
-      uint32_t const rs = s_rs[i];
+    int64_t const e   = p0 + i;
+    uint32_t const rs = s_rs[i];
+    if ((uint32_t)(e - e_lo) == rs) {  // first edge of a row
+      int32_t const v = A.src[e];
       A.best_bits[v] = s_best[rs];
       A.best_c[v]    = s_best[rs] ? s_bestc[rs] : 0x7f7f7f7f;
-      unsigned long long const self = lookup(rs, (uint32_t)A.c[v]);
+      unsigned long long const self = lookup(rs, (uint32_t)s_cv[rs]);
       if (self) atomicAdd(&s_int, self);
     }
   }
@@ -1003,7 +1022,12 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   dvec<unsigned long long> big_bits, big_ewf, big_rowsub;
   dvec<uint32_t> big_ecl;
   dvec<int32_t> big_c;
+  dvec<long long> chunk_range;
+  dvec<uint16_t> chunk_rs;
   if (use_hash) {
+    chunk_range.resize_discard((size_t)((ne + LVH_B - 1) / LVH_B) * 2);
+    chunk_rs.resize_discard((size_t)ne);
+    hipLaunchKernelGGL(k_lv_chunk_prep, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.off.data(), ne, chunk_range.data(), chunk_rs.data());
     dvec<uint32_t> flag((size_t)ne + 1), pos((size_t)ne + 1);
     hipLaunchKernelGGL(k_lv_hub_flags, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.off.data(), ne, (int32_t)(use_mid ? LVM_MAX : LVH_B),
                        flag.data());
@@ -1114,7 +1138,7 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     }
     if (use_hash && n_sorted < ne) {
       lv_hash_args HA{L.src.data(), L.dst.data(), L.off.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, ne,
-                      vfix.data() + 2 * nv, best_c.data(), ifix};
+                      vfix.data() + 2 * nv, best_c.data(), ifix, chunk_range.data(), chunk_rs.data()};
       hipLaunchKernelGGL(k_lv_hash_chunks, (int)((ne + LVH_B - 1) / LVH_B), LVH_THREADS, 0, h.stream, HA);
     }
     if (n_mid[0] + n_mid[1] > 0 || big_hash) {
