@@ -789,6 +789,7 @@ struct pagerank_plan : pagerank_plan_base {
     char const* env  = getenv("CUGRAPH_AMD_PAGERANK_KERNEL");  // "flat" / "rows" select the single-pass kernels (testing / profiling)
     std::string const kern = env ? env : "tiled";
     tiled = g.ne > 0 && kern != "flat" && kern != "rows";
+    CGA_EXPECTS(tiled || g.ne <= kMaxSignedEdges, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "PageRank: the single-pass kernels address edges with signed 32-bit positions (fewer than 2^31 edges)");
     if (tiled) {
       int const T = tiled_default_T(h, sizeof(WT), g.nv);
       if (!o.tiled || o.tiled->T != T || getenv("CUGRAPH_AMD_TILED_REBUILD")) {  // (the env: parameter sweeps on one graph, tools/plan_sweep.py)
@@ -806,6 +807,7 @@ struct pagerank_plan : pagerank_plan_base {
         } catch (api_error const& e) {
           // the re-blocked arrays are addressed with 32-bit byte offsets; a graph that outgrows them (or the memory for
           // the build temporaries) still gets an answer from the single-pass kernels
+          if (g.ne > kMaxSignedEdges) throw;  // (the single-pass kernels keep signed 32-bit edge positions: no answer from them here)
           if (e.code == CUGRAPH_ALLOC_ERROR || std::string(e.what()).find("tiled SpMV") != std::string::npos) tiled = false;
           else throw;
         }
@@ -974,8 +976,9 @@ struct pagerank_plan : pagerank_plan_base {
               device_array_view_t const* ig_s, device_array_view_t const* p_v, device_array_view_t const* p_s)
   {
     HIP_TRY(hipSetDevice(h.device));
-    CGA_EXPECTS(g.ne <= kMaxSignedEdges, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION,
-                "PageRank addresses edges through 16-bit tiled / signed 32-bit positions: graphs of 2^31 or more edges are not supported");
+    // (round 5: the column-tiled plan addresses its edge arrays from 64-bit per-wavefront bases, so it takes graphs of 2^31 edges and more --
+    // RMAT-27 on one 288 GB GPU; the single-pass comparison kernels keep signed 32-bit positions and are not offered there)
+    CGA_EXPECTS(g.ne <= kMaxGraphEdges, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "PageRank: graphs of more than 2^32 - 4097 edges are not supported");
     ensure_orientation(h, g, true);  // PageRank pulls over CSC
     int64_t const nv = g.nv;
     size_t const n1  = (size_t)(nv > 0 ? nv : 1);

@@ -22,8 +22,8 @@ __global__ void k_tile_keys(int32_t const* offsets, int32_t const* indices, int3
   int64_t const wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   int const lane = threadIdx.x & 63;
   for (int64_t v = wave; v < nv; v += nwaves) {
-    int32_t const b = offsets[v], e = offsets[v + 1];
-    for (int32_t p = b + lane; p < e; p += 64) {
+    uint32_t const b = (uint32_t)offsets[v], e = (uint32_t)offsets[v + 1];  // (edge positions are unsigned 32-bit words: graphs of 2^31 edges and more)
+    for (uint64_t p = (uint64_t)b + lane; p < e; p += 64) {
       uint32_t const c = xcol ? (uint32_t)xcol[indices[p]] : (uint32_t)indices[p];
       uint32_t const J = c / T;
       keys[p] = ((uint64_t)J << TK_TILE_SHIFT) | ((uint64_t)(uint32_t)v << TK_ROW_SHIFT) | (uint64_t)(c - J * T);
@@ -406,11 +406,11 @@ __global__ void __launch_bounds__(256) k_tile_wmax(int32_t const* offsets, WB co
   uint32_t const r0 = tile_row0[I], r1 = tile_row0[I + 1];
   double best = 0.0;
   if (w == nullptr) {
-    for (uint32_t r = r0 + threadIdx.x; r < r1; r += 256) best = fmax(best, (double)(offsets[r + 1] - offsets[r]));
+    for (uint32_t r = r0 + threadIdx.x; r < r1; r += 256) best = fmax(best, (double)((uint32_t)offsets[r + 1] - (uint32_t)offsets[r]));
   } else {
     for (uint32_t r = r0 + wave; r < r1; r += 4) {
       double s = 0.0;
-      for (int32_t p = offsets[r] + lane; p < offsets[r + 1]; p += 64) s += fabs((double)w[p]);
+      for (uint64_t p = (uint64_t)(uint32_t)offsets[r] + lane; p < (uint32_t)offsets[r + 1]; p += 64) s += fabs((double)w[p]);
       s    = group_sum(s, 64);
       best = fmax(best, s);
     }
@@ -443,7 +443,7 @@ __global__ void k_row_abs_max(int32_t const* offsets, WB const* w, int64_t nv, u
   double best    = 0;
   for (int64_t v = wave; v < nv; v += nwaves) {
     double s = 0;
-    for (int32_t p = offsets[v] + lane; p < offsets[v + 1]; p += 64) s += fabs((double)w[p]);
+    for (uint64_t p = (uint64_t)(uint32_t)offsets[v] + lane; p < (uint32_t)offsets[v + 1]; p += 64) s += fabs((double)w[p]);
     s    = group_sum(s, 64);
     best = fmax(best, s);
   }
@@ -456,7 +456,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   // nv = number of column (source) ids and of CSC rows; n_dst <= nv = rows that can have in-edges and get an epilogue
   // (single GPU: n_dst = nv; multi-GPU: the local rows, while the columns span the whole graph)
   size_t const wsize = has_weights ? vsize : 0;
-  CGA_EXPECTS(nv < ((int64_t)1 << 31) && ne < ((int64_t)1 << 31), CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: graph too large for 32-bit positions");
+  CGA_EXPECTS(nv < ((int64_t)1 << 31) && ne <= kMaxGraphEdges - 2 * (int64_t)TP_ITEM * 1024, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: graph too large for 32-bit positions");
   t       = tiled_csc_t{};
   build_trace tr(h, "tiled");
   dvec<uint32_t> live_rank;  // compact columns: live_rank[r] = number of live sources with an id < r
@@ -824,7 +824,8 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     size_t const spad = (size_t)t.n_slots + 64;
     t.dstl16.resize_discard(spad);
     HIP_TRY(hipMemsetAsync(t.dstl16.data(), 0, spad * sizeof(uint16_t), h.stream));
-    CGA_EXPECTS((uint64_t)t.ne_pad * 2 + 65536 < ((uint64_t)1 << 32) && ((uint64_t)t.n_runs + 512) * 4 < ((uint64_t)1 << 32) &&
+    // (the edge arrays -- src16, weights -- are addressed from a 64-bit per-wavefront base: only their POSITIONS must fit 32 bits, checked above)
+    CGA_EXPECTS(((uint64_t)t.n_runs + 512) * 4 < ((uint64_t)1 << 32) &&
                   ((uint64_t)t.n_slots + 64) * vsize < ((uint64_t)1 << 32) && (uint64_t)(n_waves + 2) * TP_REC_DWORDS * 4 < ((uint64_t)1 << 32),
                 CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: an array exceeds the 32-bit byte-offset addressing of phase 1");
     // slot of every run (build-time only): [0] = dummy (the "run" before run 0), run q at [q + 1], zero padding behind
@@ -1130,10 +1131,19 @@ __device__ __forceinline__ void p1_load(p1_args<WT> const& a, int item, int wave
 {  // arrays are over-allocated and zero padded: no bounds checks
   r.es = (uint32_t)item * (uint32_t)TP_ITEM + (uint32_t)wave * TP_WLEN;
   uint32_t const e = r.es + (uint32_t)TP_EPL * (uint32_t)lane;
-  vm_ld128(r.id[0], a.src16, 2u * e);
-  vm_ld128_o16(r.id[1], a.src16, 2u * e);
+  // (the base is the wavefront's share -- wave-uniform, a 64-bit scalar add -- and the lane offset a constant: byte offsets of the whole
+  // array would pass 2^32 from 2^31 edges on)
+  uint16_t const* const wbase = a.src16 + r.es;
+  vm_ld128(r.id[0], wbase, (uint32_t)(2 * TP_EPL) * (uint32_t)lane);
+  vm_ld128_o16(r.id[1], wbase, (uint32_t)(2 * TP_EPL) * (uint32_t)lane);
+#ifndef CGA_P1_OLD_ADDR
+  (void)e;
+  vm_ld16u(r.fl, a.bits + (r.es >> 3), (uint32_t)(TP_EPL / 8) * (uint32_t)lane);  // (TP_EPL consecutive edges per lane = TP_EPL / 8 bytes of the bitmap)
+  vm_ld32(r.rec, a.wrec + ((size_t)item * TP_WAVES + (size_t)wave) * TP_REC_DWORDS, 4u * (uint32_t)min(lane, TP_REC_DWORDS - 1));
+#else
   vm_ld16u(r.fl, a.bits, e >> 3);
   vm_ld32(r.rec, a.wrec, ((uint32_t)item * TP_WAVES + (uint32_t)wave) * (uint32_t)(TP_REC_DWORDS * 4) + 4u * (uint32_t)min(lane, TP_REC_DWORDS - 1));
+#endif
 }
 __device__ __forceinline__ void p1_fence(p1_regs& r) { vm_fence(r.id[0]); vm_fence(r.id[1]); vm_fence(r.fl); vm_fence(r.rec); }
 
@@ -1175,7 +1185,11 @@ __device__ __forceinline__ void p1_issue_slots(p1_args<WT> const& a, int lane, p
   for (int k = 0; k < TP_NDREG; ++k) {
     q.dreg[k] = 0;
 #ifndef CGA_ABL_NODELTA
+#ifndef CGA_P1_OLD_ADDR
+    if (k == 0 || q.c_all > (uint32_t)(64 * k)) vm_ld32(q.dreg[k], a.delta1 + q.blk, 4u * ((uint32_t)(64 * k) + (uint32_t)lane));  // (block starts <= run starts)
+#else
     if (k == 0 || q.c_all > (uint32_t)(64 * k)) vm_ld32(q.dreg[k], a.delta1, 4u * (q.blk + (uint32_t)(64 * k) + (uint32_t)lane));  // (block starts <= run starts)
+#endif
 #endif
   }
 }
@@ -1279,7 +1293,7 @@ __device__ __forceinline__ WT p1_compute(p1_args<WT> const& a, WT const* xs, WT*
   });
   if constexpr (WEIGHTED) {
 #pragma unroll
-    for (int k = 0; k < TP_EPL; ++k) r[k] *= ld32<WT>(a.weights, (e + (uint32_t)k) * (uint32_t)sizeof(WT));
+    for (int k = 0; k < TP_EPL; ++k) r[k] *= ld32<WT>(a.weights + q.es, ((uint32_t)TP_EPL * (uint32_t)lane + (uint32_t)k) * (uint32_t)sizeof(WT));
   }
   if (e + TP_EPL > q.ee) {
     uint32_t const nval = q.ee > e ? q.ee - e : 0u;
@@ -1467,8 +1481,8 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
     if (busy) {
       if (pend.count) {
         int wl = lane;
-        if constexpr (OVL) asm volatile("" : "+v"(wl));  // (this variant sits one register over the budget: keep lane-derived LDS addresses of the
-        p1_writeout<WT>(a, stage, wl, cur.rec, qc, pend.base_c, pend.base_c + pend.count);  // write-out from being hoisted out of the item loop and spilled)
+        asm volatile("" : "+v"(wl));  // (the kernel sits AT its 128-register budget: keep the lane-derived LDS addresses of the write-out from
+        p1_writeout<WT>(a, stage, wl, cur.rec, qc, pend.base_c, pend.base_c + pend.count);  // being hoisted out of the item loop and spilled)
       }
 #ifndef CGA_ABL_NOSTORE
       if (lane == 63) vm_st(a.part, qc.slot_tail * (uint32_t)sizeof(WT), tail);  // slot_tail = head slot when no run starts in the range

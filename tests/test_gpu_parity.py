@@ -1732,3 +1732,30 @@ def test_pagerank_aligned_slot_blocks_give_the_same_bits(cg, handle, orc, monkey
     truth, _, _ = orc.pagerank(nv, off, idx, ww, 0.85, 0.0, 9, acc64=True)
     got = by_vertex(vb, b)[0]
     assert np.max(np.abs(got - truth)) <= 1e-6 and np.max(np.abs(got - truth) / truth) <= 2e-5
+
+
+def test_pagerank_two_to_the_31_edges(cg, handle):
+    """Round 5: RMAT-27 (2^31 directed edges, 134 M vertices) on one GPU through the column-tiled plan -- its edge arrays are addressed from
+    64-bit per-wavefront bases, so only edge POSITIONS have to fit 32 bits (the reference needs 64-bit vertex / edge types for such a graph:
+    cpp/src/c_api/graph_sg.cpp:745-779).  The oracle cannot run at this size; the vector is checked the way bench.py checks the timed one:
+    mass, and one more library iteration against one explicit fp64 power iteration in torch on the regenerated edge list."""
+    import sys
+    from pathlib import Path
+
+    import torch
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+
+    scale = 27
+    nv, ne = 1 << scale, 16 << scale
+    src, dst = cg.generate_rmat_edgelist(handle, scale, ne)
+    g = cg.SGGraph(handle, cg.GraphProperties(is_multigraph=True), src, dst, None, store_transposed=True, renumber=True,
+                   vertices_array=torch.arange(nv, dtype=torch.int32, device="cuda"))
+    del src, dst
+    plan = cg.PageRankPlan(handle, g, 0.85)
+    plan.step(6)
+    chk = bench.check_result(cg, handle, plan, scale, ne, nv)
+    assert chk["ok"], chk
+    del plan, g
+    torch.cuda.empty_cache()
