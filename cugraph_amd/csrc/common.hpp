@@ -303,8 +303,8 @@ struct orientation_t {
 constexpr int32_t kSegThreshold[orientation_t::n_seg] = {4096, 64, 16, 4, 1};
 constexpr int64_t kEdgePad = 2048;  // indices / weights are over-allocated so 16-byte tail loads stay in bounds
 // Edge positions are unsigned 32-bit words (the offsets arrays are declared int32_t and read as uint32_t where a graph may have
-// 2^31 or more edges: graph construction, degrees, BFS / SSSP).  PageRank (16-bit tiled positions, signed offsets in the
-// single-pass kernels) and Louvain keep the signed limit: kMaxSignedEdges.
+// 2^31 or more edges: graph construction, degrees, BFS / SSSP, and -- round 5 -- the column-tiled PageRank plan).  PageRank's single-pass
+// comparison kernels (signed offsets) and Louvain keep the signed limit: kMaxSignedEdges.
 constexpr int64_t kMaxGraphEdges  = ((int64_t)1 << 32) - 4097;
 constexpr int64_t kMaxSignedEdges = ((int64_t)1 << 31) - 1;
 
