@@ -1263,7 +1263,13 @@ __device__ __forceinline__ void p1_writeout(p1_args<WT> const& a, WT const* stag
       uint32_t slot    = d + (rm1 + 64u * (uint32_t)jj) + (uint32_t)lane;
       if (jj == 0) slot = lane == 0 ? q.head_slot : slot;
 #ifndef CGA_ABL_NOSTORE
+#if defined(CGA_ABL_STORE_LOCAL)  // timing experiments (WRONG results): every partial store lands in one 16 MiB window (issued and acknowledged, nothing reaches HBM) ...
+      if (n >= n_lo && n < n_hi) vm_st(a.part, (slot & 0x3FFFFFu) * (uint32_t)sizeof(WT), stage[n - n_lo]);
+#elif defined(CGA_ABL_STORE_ADDR_ONLY)  // ... or the slot and the value are computed and the store is not issued
+      if (n >= n_lo && n < n_hi) { WT const val = stage[n - n_lo]; asm volatile("" : : "v"(slot), "v"(val)); }
+#else
       if (n >= n_lo && n < n_hi) vm_st(a.part, slot * (uint32_t)sizeof(WT), stage[n - n_lo]);
+#endif
 #endif
     }
   }
@@ -1485,7 +1491,13 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
         p1_writeout<WT>(a, stage, wl, cur.rec, qc, pend.base_c, pend.base_c + pend.count);  // being hoisted out of the item loop and spilled)
       }
 #ifndef CGA_ABL_NOSTORE
+#if defined(CGA_ABL_STORE_LOCAL)
+      if (lane == 63) vm_st(a.part, (qc.slot_tail & 0x3FFFFFu) * (uint32_t)sizeof(WT), tail);
+#elif defined(CGA_ABL_STORE_ADDR_ONLY)
+      if (lane == 63) asm volatile("" : : "v"(qc.slot_tail), "v"(tail));
+#else
       if (lane == 63) vm_st(a.part, qc.slot_tail * (uint32_t)sizeof(WT), tail);  // slot_tail = head slot when no run starts in the range
+#endif
 #endif
     }
     if (have_next) p1_issue_slots<WT>(a, lane, nxt, qn);
