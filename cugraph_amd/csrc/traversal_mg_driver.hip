@@ -74,7 +74,8 @@ struct mg_traversal_run_t {
   ~mg_traversal_run_t()
   {
     try {
-      if (h) (void)hipStreamSynchronize(h->stream);
+      // (not h->stream: the resource handle of the first traversal may be gone by the time the graph is freed -- advisor finding, round 4)
+      if (c) { (void)hipSetDevice(c->device); (void)hipDeviceSynchronize(); }
       if (plan) cugraph_amd_traversal_mg_plan_free(plan);
       for (int b = 1; b >= 0; --b) { if (swin[b]) c->window_free(swin[b]); if (bwin[b]) c->window_free(bwin[b]); }
       if (twin) c->window_free(twin);
@@ -88,7 +89,12 @@ namespace {
 
 mg_traversal_run_t& ensure_run(handle_t const& h, graph_t& g, mg_traversal_part_t& t, int mode)
 {
-  if (t.run) return *t.run;
+  if (t.run) {
+    // the cached plan and its windows were built on the first traversal's resource handle (its stream orders every later call)
+    CGA_EXPECTS(t.run->h == &h, CUGRAPH_INVALID_HANDLE,
+                "multi-GPU traversal: the graph's traversal plan belongs to the resource handle of its first BFS / SSSP; later calls must pass the same handle");
+    return *t.run;
+  }
   comm_t& c = *g.mg->comm;
   auto r    = std::make_shared<mg_traversal_run_t>();
   r->c = &c; r->h = &h; r->mode = mode; r->tw = mode == 0 ? 2 : 3;
