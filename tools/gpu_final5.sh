@@ -45,5 +45,5 @@ for f in sorted(glob.glob(f"gpurun_out/{tag}_*.json")):
     r=d.get("roofline") or {}
     print(f.split("/")[-1], d.get("value"), d.get("ms_per_step"), "frac", r.get("frac"), "traffic", r.get("traffic"), "check", (d.get("check") or {}).get("ok"),
           {k: (v.get("value"), (v.get("roofline") or {}).get("frac"), (v.get("roofline") or {}).get("traffic"), (v.get("check") or {}).get("ok")) for k, v in (d.get("extra") or {}).items() if isinstance(v, dict)},
-          {k: (d[k].get("mean_ms"), d[k]["roofline"]["frac"], d[k]["roofline"].get("traffic"), (d[k].get("check") or {}).get("ok")) for k in ("bfs","sssp") if k in d})
+          {k: (d[k].get("mean_ms"), (d[k].get("roofline") or {}).get("frac"), (d[k].get("roofline") or {}).get("traffic"), (d[k].get("check") or {}).get("ok")) for k in ("bfs","sssp") if k in d})
 PY
