@@ -1089,6 +1089,13 @@ __device__ __forceinline__ void vm_fence(uint32_t&) {}
 __device__ __forceinline__ void vm_fence(u32x4_t&) {}
 #endif
 
+// LDS access by ABSOLUTE byte address (address space 3): `ds_read_b32 v, vaddr` with nothing added.  Through a generic pointer
+// (`xs + offset`) the compiler adds the symbol's address first -- a link-time constant that happens to be 0: the dynamic LDS of these kernels
+// starts at LDS address 0, they declare no static LDS; k_tiled_phase1 traps if that ever changes -- which costs a `v_add_u32 v, 0, v` per
+// access: 16 per lane and work item in the gathers of phase 1.
+template <typename T> __device__ __forceinline__ T lds_ld(uint32_t a) { return *reinterpret_cast<__attribute__((address_space(3))) T const*>((uintptr_t)a); }
+template <typename T> __device__ __forceinline__ void lds_st(uint32_t a, T v) { *reinterpret_cast<__attribute__((address_space(3))) T*>((uintptr_t)a) = v; }
+
 // LDS byte offset of 16-bit tile-local index number HALF of w, scaled by the element size, in ONE VALU op (SDWA word select
 // + shift); the x tile starts at LDS address 0
 template <int HALF, int SHIFT>
@@ -1294,7 +1301,11 @@ __device__ __forceinline__ WT p1_compute(p1_args<WT> const& a, WT const* xs, WT*
 #ifdef CGA_ABL_NOGATHER
     r[k] = (WT)__uint_as_float(0x3f800000u | (idx_offset<(k & 1), sh>(w) >> 2));
 #else
+#ifdef CGA_P1_GENERIC_LDS
     r[k] = *reinterpret_cast<WT const*>(reinterpret_cast<unsigned char const*>(xs) + idx_offset<(k & 1), sh>(w));
+#else
+    r[k] = lds_ld<WT>(idx_offset<(k & 1), sh>(w));  // (the tile sits at LDS address 0)
+#endif
 #endif
   });
   if constexpr (WEIGHTED) {
@@ -1357,6 +1368,7 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
   int4* s_chunk = reinterpret_cast<int4*>(smem + ((size_t)a.T + (size_t)TP_WAVES * TP_STAGE) * sizeof(WT));
   int const tid = threadIdx.x, lane = tid & 63;
   int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();  // lds_ld / lds_st / idx_offset address the tile from LDS address 0
   WT* stage = xs + a.T + wave * TP_STAGE;
 
   if constexpr (OVL) {
