@@ -100,20 +100,20 @@ struct bfs_visit {
 struct keep_all { __device__ __forceinline__ bool operator()(int32_t) const { return true; } };
 
 __global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices,
-                                                         int32_t* bigq, bfs_state s, int32_t big_deg)
+                                                         int32_t* bigq, bfs_state s, int32_t big_deg, int32_t seg)
 {
   __shared__ wave_queue_storage<1> wqs;
   wqs.init();
   bfs_visit f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next)};
-  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f, big_deg);  // (EX_U edges in flight per lane, as SSSP does: no gain here)
+  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f, big_deg, nullptr, seg);  // (EX_U edges in flight per lane, as SSSP does: no gain here)
   f.flush();
 }
-__global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, bfs_state s)
+__global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, bfs_state s, int32_t seg)
 {
   __shared__ wave_queue_storage<1> wqs;
   wqs.init();
   bfs_visit f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next)};
-  expand_big(bigq, offsets, indices, s.cnt, f);
+  expand_big(bigq, offsets, indices, s.cnt, f, nullptr, seg);
   f.flush();
 }
 
@@ -1187,6 +1187,8 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   // depth_limit is compared after incrementing (bfs_impl.cuh:867-868)
   uint64_t const limit = depth_limit > (size_t)INT32_MAX ? (uint64_t)INT32_MAX : (uint64_t)depth_limit;
   bool const bu_profile = getenv("CUGRAPH_AMD_BFS_PROFILE") != nullptr;
+  // edges per deferred work unit of a NARROW frontier (CUGRAPH_AMD_BFS_NARROW_SEG: 64 ... 4096, power of two not required)
+  int32_t const narrow_seg = getenv("CUGRAPH_AMD_BFS_NARROW_SEG") ? std::max(64, std::min(4096, atoi(getenv("CUGRAPH_AMD_BFS_NARROW_SEG")))) : BIG_SEG_NARROW;
   // OPT-IN (CUGRAPH_AMD_BFS_PULL_PARENTS=1), measured at RMAT-24 (32 roots, profiles/r5d_bfs_ab.txt): 1.74 ms against 1.37 ms with the
   // atomicMin in the push.  The levels that run top-down are the ones whose discoveries are HUBS (one frontier vertex discovering 1 141 vertices
   // of 10^4-10^5 in-edges each): a pull scans half of every such row to find the one frontier member, the push reads the frontier's out-edges once.
@@ -1242,10 +1244,11 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
                   cnt.data(), out_off, in_off, (int32_t)(depth + 1)};
       {
         timed_launch t(h, "bfs_expand");
+        int32_t const seg = big_seg_for_deg(big_deg_for(h, n_cur), narrow_seg);
         hipLaunchKernelGGL(k_bfs_expand, expand_grid(h, n_cur), TV_BLOCK, 0, h.stream, (int32_t const*)q_cur, n_cur, (int32_t const*)o.offsets.data(),
-                           (int32_t const*)o.indices.data(), bigq.data(), s, big_deg_for(h, n_cur));
+                           (int32_t const*)o.indices.data(), bigq.data(), s, big_deg_for(h, n_cur), seg);
         hipLaunchKernelGGL(k_bfs_expand_big, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
-                           (int32_t const*)o.indices.data(), s);
+                           (int32_t const*)o.indices.data(), s, seg);
         if (pull_parents) {  // (vis_prev still is the visited set of the level's start; bigq is free again)
           hipLaunchKernelGGL(k_bfs_pull_parents, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)q_nxt, cnt.data(), in_off, in_idx, (uint32_t const*)vis_prev.data(), pred_p,
                              bigq.data());

@@ -15,6 +15,11 @@ constexpr int32_t BIG_DEG_NARROW = 64; // ... and rows at least THIS long when i
                                        // relaxation round right after the source) ran on a handful of wavefronts: 3.6 ms for one BFS level
                                        // of 1141 vertices at RMAT-24, 0.5 ms for one of 30.  Deferred rows get one workgroup per 4096 edges.
 constexpr int32_t BIG_SEG = 4096;  // edges per deferred (row, segment) work unit
+// ... of a NARROW frontier (round 5, BFS): one frontier vertex with 10^5 out-edges is 25 work units of 4096 edges -- 25 workgroups of 256
+// threads walking 16 dependent probes each while 2 000 workgroup slots idle.  Measured at RMAT-24 (32 roots, same session,
+// profiles/r5p_bfs_seg.txt): 4096 -> 1.347 / 1.346 ms, 1024 -> 1.324, 512 -> 1.339 / 1.334, 256 -> 1.359: a per cent; 1024 it is.
+constexpr int32_t BIG_SEG_NARROW = 1024;
+__host__ __device__ inline int32_t big_seg_for_deg(int32_t big_deg, int32_t narrow_seg) { return big_deg == 64 ? narrow_seg : 4096; }
 
 // Plain sums (edges inspected, degree sums of the discoveries, discoveries of the bottom-up kernel) are added once per wavefront
 // at kernel exit.  With one counter per quantity that is 10^4..10^5 atomics on ONE 64-byte line per launch, and same-line atomics
@@ -164,7 +169,8 @@ __device__ __forceinline__ eoff_t eoff(int32_t const* offsets, int64_t v) { retu
 template <typename Keep, typename F>
 __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices,
                                                 int32_t* bigq, counters_t* cnt, Keep keep, F& f, int32_t big_deg = BIG_DEG,
-                                                int32_t const* row_end = nullptr)  // row u = [offsets[u], row_end ? row_end[u] : offsets[u + 1])
+                                                int32_t const* row_end = nullptr,  // row u = [offsets[u], row_end ? row_end[u] : offsets[u + 1])
+                                                int32_t seg = BIG_SEG)             // edges per deferred work unit (the same value goes to expand_big)
 {
   __shared__ uint32_t s_scan[TV_WAVES][64];
   __shared__ eoff_t s_beg[TV_WAVES][64];
@@ -184,7 +190,7 @@ __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int
     // deferred: huge rows, cut into BIG_SEG-edge segments (one workgroup of k_*_big each)
     bool big = deg >= big_deg;
     if (big) {
-      uint32_t nseg = ((uint32_t)deg + BIG_SEG - 1) / BIG_SEG;
+      uint32_t nseg = ((uint32_t)deg + (uint32_t)seg - 1) / (uint32_t)seg;
       uint32_t at   = atomicAdd(&cnt->n_big, nseg);
       for (uint32_t sgm = 0; sgm < nseg; ++sgm) { bigq[2 * (at + sgm)] = u; bigq[2 * (at + sgm) + 1] = (int32_t)sgm; }
     }
@@ -225,15 +231,15 @@ __device__ __forceinline__ void expand_frontier(int32_t const* q, int64_t n, int
 
 template <typename F>
 __device__ __forceinline__ void expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, counters_t* cnt, F& f,
-                                           int32_t const* row_end = nullptr)
+                                           int32_t const* row_end = nullptr, int32_t seg = BIG_SEG)
 {  // one workgroup per (row, segment) pair: rows of 10^3..10^6 edges all get parallelism proportional to their length
   uint32_t const nseg = cnt->n_big;
   unsigned long long inspected = 0;
   for (uint32_t k = blockIdx.x; k < nseg; k += gridDim.x) {
     int32_t const u = bigq[2 * k], sgm = bigq[2 * k + 1];
     eoff_t const row_b = eoff(offsets, u), row_e = row_end ? eoff(row_end, u) : eoff(offsets, u + 1);
-    eoff_t const b = row_b + (eoff_t)sgm * (eoff_t)BIG_SEG;             // (b <= row_e: the segment exists)
-    eoff_t const len = min(row_e - b, (eoff_t)BIG_SEG);
+    eoff_t const b = row_b + (eoff_t)sgm * (eoff_t)seg;                 // (b <= row_e: the segment exists)
+    eoff_t const len = min(row_e - b, (eoff_t)seg);
     for (eoff_t p = threadIdx.x; p < len; p += blockDim.x) f(u, indices[b + p], b + p);
     if (threadIdx.x == 0) inspected += (unsigned long long)len;
   }
