@@ -18,6 +18,7 @@ from .pylib import (  # noqa: F401
     SGGraph,
     bfs,
     bfs_extract_paths,
+    decompress_to_edgelist,
     degrees,
     generate_rmat_edgelist,
     has_vertex,

@@ -665,7 +665,26 @@ cugraph_error_code_t create_mg(const cugraph_resource_handle_t* handle, const cu
       if (symmetrize == TRUE)  // graph_mg.cpp:117-121
         CGA_EXPECTS(properties->is_symmetric == TRUE, CUGRAPH_INVALID_INPUT,
                     "Invalid input arguments: The graph property must be symmetric if 'symmetrize' is set to True.");
+      // INT64 vertex ids (graph_mg.cpp:127-151 instantiates vertex_t = int64_t; python-cugraph hands over int64 columns by default): the ranks
+      // agree on ONE ascending list of the distinct ids (mg_graph.hip: mg_outer_ids, collective), the columns become compact int32 ids
+      // (position in that list: monotone in the external id, so every minimum-external-id tie-break is unchanged) and every vertex column
+      // that leaves the library goes back through outer_ids.hip -- the same boundary translation as on one GPU.
+      outer_ids_t outer;
+      dvec<int32_t> s32, d32, v32;
+      device_array_view_t sview = cs.view, dview = cd.view, vview = cv.view;
+      if (mg_outer_ids(h, cv.present ? &cv.view : nullptr, &cs.view, &cd.view, outer)) {
+        auto narrow = [&](device_array_view_t& v, dvec<int32_t>& owned) {
+          owned.resize_discard(std::max<size_t>(v.size, 1));
+          outer_to_compact(h, outer, v.data, v.type, (int64_t)v.size, owned.data());
+          v = device_array_view_t{owned.data(), v.size, INT32};
+        };
+        narrow(sview, s32);
+        narrow(dview, d32);
+        if (cv.present) narrow(vview, v32);
+        h.sync();
+      }
       auto g              = std::make_unique<graph_t>();
+      g->outer            = std::move(outer);
       g->vertex_type      = INT32;
       g->edge_type        = INT32;
       g->weight_type      = cw.present ? cw.view.type : FLOAT32;
@@ -673,8 +692,8 @@ cugraph_error_code_t create_mg(const cugraph_resource_handle_t* handle, const cu
       g->store_transposed = store_transposed == TRUE;
       g->renumbered       = true;  // graph_mg.cpp:214
       g->props            = *properties;
-      mg_graph_create(h, *g, cv.present ? &cv.view : nullptr, &cs.view, &cd.view, cw.present ? &cw.view : nullptr, drop_self_loops == TRUE, drop_multi_edges == TRUE,
-                      symmetrize == TRUE);
+      mg_graph_create(h, *g, cv.present ? &vview : nullptr, &sview, &dview, cw.present ? &cw.view : nullptr, ci.present ? &ci.view : nullptr,
+                      ct.present ? &ct.view : nullptr, drop_self_loops == TRUE, drop_multi_edges == TRUE, symmetrize == TRUE);
       *graph = reinterpret_cast<cugraph_graph_t*>(g.release());
     }
   });
@@ -767,6 +786,8 @@ extern "C" cugraph_error_code_t cugraph_has_vertex(const cugraph_resource_handle
     auto v            = V(vertices);
     CGA_EXPECTS(v != nullptr && result != nullptr, CUGRAPH_INVALID_INPUT, "vertices / result is NULL");
     if (g.mg) {  // multi-GPU graph: the id is a vertex if ANY rank knows it (graph_functions.cpp:391 answers per rank for the local range)
+      vertex_column_in c_mv;  // INT64 ids of a multi-GPU graph: compact int32 ids, -1 (never a vertex) when unknown
+      v = c_mv.get(h, g, v, "vertices");
       CGA_EXPECTS(v->type == INT32, CUGRAPH_INVALID_INPUT, "vertex type of graph and vertices must match");
       auto out = std::make_unique<device_array_t>(v->size, BOOL);
       mg_has_vertex(h, g, v->as<int32_t>(), (int64_t)v->size, out->buf.as<uint8_t>());

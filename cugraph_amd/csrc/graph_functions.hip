@@ -76,11 +76,13 @@ cugraph_error_code_t degrees_impl(const cugraph_resource_handle_t* handle, cugra
     auto const sv_user = reinterpret_cast<device_array_view_t const*>(source_vertices);
     if (GM(graph).mg) {  // a graph from cugraph_graph_create_mg on a communicator handle: collective, every rank answers for its share of the vertices
       graph_t& mgg = GM(graph);
-      CGA_EXPECTS(sv_user == nullptr || sv_user->type == INT32, CUGRAPH_INVALID_INPUT, "vertex type of graph and source_vertices must match");
+      vertex_column_in c_msv;  // INT64 ids: compact int32 ids from here on (unknown ids -1: refused below like any id that is no vertex)
+      device_array_view_t const* msv = c_msv.get(h, mgg, sv_user, "source_vertices");
+      CGA_EXPECTS(msv == nullptr || msv->type == INT32, CUGRAPH_INVALID_INPUT, "vertex type of graph and source_vertices must match");
       bool const msym   = mgg.props.is_symmetric == TRUE;
       bool const mshare = want_in && want_out && msym;  // degrees.cu:84-88
       dvec<int32_t> ids, din, dout;
-      int64_t const n = mg_degrees(h, mgg, sv_user, want_in, want_out && !mshare, ids, din, dout);
+      int64_t const n = mg_degrees(h, mgg, msv, want_in, want_out && !mshare, ids, din, dout);
       auto res          = std::make_unique<degrees_result_t>();
       res->is_symmetric = msym;
       auto take = [&](dvec<int32_t> const& d, cugraph_data_type_id_t t) {
@@ -92,6 +94,7 @@ cugraph_error_code_t degrees_impl(const cugraph_resource_handle_t* handle, cugra
       if (want_in) res->in_degrees = take(din, mgg.edge_type);
       if (want_out && !mshare) res->out_degrees = take(dout, mgg.edge_type);
       h.sync();
+      outer_replace_ids(h, mgg, res->vertex_ids);
       *result = reinterpret_cast<cugraph_degrees_result_t*>(res.release());
       return;
     }
@@ -174,6 +177,32 @@ __global__ void k_walk_paths(int32_t const* dest, int64_t n, int32_t const* dist
   }
 }
 
+// the same two steps on a multi-GPU graph: the tables cover the dense external id range and hold hop count + 1 / predecessor + 2 (mg_gather_paths)
+__global__ void k_mg_max_path(int32_t const* dest, int64_t n, int64_t vmin, int64_t vrange, uint32_t const* dist1, uint32_t const* pred2, int32_t* out_max, int32_t* bad)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t const k = (int64_t)dest[i] - vmin;
+  if (k < 0 || k >= vrange || dist1[k] == 0u) { *bad = 1; return; }
+  uint32_t const d = dist1[k] - 1u;
+  if (pred2[k] >= 2u && d != (uint32_t)INT32_MAX) atomicMax(out_max, (int32_t)d);
+}
+__global__ void k_mg_walk_paths(int32_t const* dest, int64_t n, int64_t vmin, int64_t vrange, uint32_t const* dist1, uint32_t const* pred2, int64_t L, int32_t* paths)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t k = (int64_t)dest[i] - vmin;
+  uint32_t const d = dist1[k] - 1u;
+  if (d == (uint32_t)INT32_MAX || (int64_t)d >= L) return;  // unreached destination: the row stays invalid (-1)
+  for (int64_t pos = d; pos >= 0; --pos) {
+    paths[i * L + pos] = (int32_t)(k + vmin);
+    int64_t const p = (int64_t)pred2[k] - 2;
+    if (p < 0) break;
+    k = p - vmin;
+    if (k < 0 || k >= vrange) break;
+  }
+}
+
 }  // namespace
 }  // namespace cga
 
@@ -221,12 +250,65 @@ extern "C" cugraph_error_code_t cugraph_extract_paths(const cugraph_resource_han
   if (result) *result = nullptr;
   return guarded(error, [&] {
     handle_t const& h = H(handle);
-    graph_t& g        = G(graph);
+    graph_t& g        = GM(graph);
     auto pr           = reinterpret_cast<paths_result_t const*>(paths_result);
     auto dv           = reinterpret_cast<device_array_view_t const*>(destinations);
     CGA_EXPECTS(result != nullptr && pr != nullptr && dv != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
     CGA_EXPECTS(pr->distances != nullptr && pr->distances->type == g.api_vertex_type(), CUGRAPH_INVALID_INPUT,
                 "Invalid input argument: distances must come from cugraph_bfs (vertex-typed hop counts)");
+    if (g.mg) {
+      // A graph from cugraph_graph_create_mg (extract_paths.cpp:57-119 with multi_gpu = true; extract_bfs_paths_impl.cuh:130-240 looks the
+      // predecessors of vertices other ranks own up through a distributed key-value store, one hop per round).  COLLECTIVE: the BFS
+      // result holds this rank's share of the vertices; the (hop count, predecessor) columns of all ranks are folded into two tables over
+      // the dense id range that every rank holds (8 bytes per id: what the graph's presence table and degree arrays cost already), and
+      // each rank then walks its own destinations locally -- any destination, whoever owns it.  The matrix is as wide on every rank
+      // (the longest path over all ranks' destinations), as the reference's host_scalar_allreduce makes it.
+      mg_graph_t& mg    = *g.mg;
+      int64_t const n   = (int64_t)pr->vertex_ids->size;
+      bool const bad_in = pr->predecessors == nullptr || (int64_t)pr->predecessors->size != n || (int64_t)pr->distances->size != n;
+      HIP_TRY(hipSetDevice(h.device));
+      vertex_column_in c_mdv;
+      dv = c_mdv.get(h, g, dv, "destinations");
+      int64_t const nd = (int64_t)dv->size, n1 = std::max<int64_t>(n, 1);
+      dvec<int32_t> vert((size_t)n1), pred((size_t)n1), dist32((size_t)n1), scal(2);
+      if (!bad_in && n > 0) {
+        if (g.outer.active) {  // the BFS result carries outer ids / widened hop counts: back to compact ids and int32 hops
+          outer_to_compact(h, g.outer, pr->vertex_ids->buf.ptr, pr->vertex_ids->type, n, vert.data());
+          outer_to_compact(h, g.outer, pr->predecessors->buf.ptr, pr->predecessors->type, n, pred.data());  // -1 stays -1
+          if (g.outer.type == INT64) outer_narrow_dist(h, pr->distances->buf.as<int64_t const>(), n, dist32.data());
+          else HIP_TRY(hipMemcpyAsync(dist32.data(), pr->distances->buf.ptr, (size_t)n * 4, hipMemcpyDeviceToDevice, h.stream));
+        } else {
+          HIP_TRY(hipMemcpyAsync(vert.data(), pr->vertex_ids->buf.ptr, (size_t)n * 4, hipMemcpyDeviceToDevice, h.stream));
+          HIP_TRY(hipMemcpyAsync(pred.data(), pr->predecessors->buf.ptr, (size_t)n * 4, hipMemcpyDeviceToDevice, h.stream));
+          HIP_TRY(hipMemcpyAsync(dist32.data(), pr->distances->buf.ptr, (size_t)n * 4, hipMemcpyDeviceToDevice, h.stream));
+        }
+      }
+      dvec<uint32_t> dist1, pred2;
+      mg_gather_paths(h, g, vert.data(), dist32.data(), pred.data(), bad_in ? 0 : n, dist1, pred2);
+      HIP_TRY(hipMemsetAsync(scal.data(), 0, 2 * sizeof(int32_t), h.stream));
+      if (nd > 0)
+        hipLaunchKernelGGL(k_mg_max_path, grid_for(nd), kBlock, 0, h.stream, dv->as<int32_t>(), nd, mg.vmin, mg.vrange, (uint32_t const*)dist1.data(), (uint32_t const*)pred2.data(),
+                           scal.data(), scal.data() + 1);
+      int32_t hs[2] = {0, 0};
+      h.read_back(hs, scal.data(), 2);
+      // one exchange carries the width and the verdicts, so that every rank throws or none does
+      int64_t const agreed = mg_host_max(g, bad_in ? ((int64_t)1 << 41) : hs[1] != 0 ? ((int64_t)1 << 40) : (int64_t)hs[0]);
+      CGA_EXPECTS(agreed < ((int64_t)1 << 41), CUGRAPH_INVALID_INPUT, "Invalid input argument: predecessors cannot be null");  // extract_bfs_paths_impl.cuh:140-142
+      CGA_EXPECTS(agreed < ((int64_t)1 << 40), CUGRAPH_INVALID_INPUT, "Invalid input argument: destinations contains a vertex that is not in the graph");
+      int64_t const L = agreed + 1;
+      auto res        = std::make_unique<extract_paths_result_t>();
+      res->max_path_length = (size_t)L;
+      res->paths      = new device_array_t((size_t)(nd * L), INT32);
+      if (nd > 0) {
+        HIP_TRY(hipMemsetAsync(res->paths->buf.ptr, 0xFF, (size_t)(nd * L) * 4, h.stream));  // invalid_vertex_id = -1
+        hipLaunchKernelGGL(k_mg_walk_paths, grid_for(nd), kBlock, 0, h.stream, dv->as<int32_t>(), nd, mg.vmin, mg.vrange, (uint32_t const*)dist1.data(), (uint32_t const*)pred2.data(), L,
+                           res->paths->buf.as<int32_t>());
+      }
+      h.sync();
+      outer_replace_ids(h, g, res->paths);  // -1 padding passes through
+      *result = reinterpret_cast<cugraph_extract_paths_result_t*>(res.release());
+      return;
+    }
     CGA_EXPECTS(pr->predecessors != nullptr && (int64_t)pr->predecessors->size == g.nv, CUGRAPH_INVALID_INPUT,
                 "Invalid input argument: predecessors cannot be null");  // extract_bfs_paths_impl.cuh:140-142
     HIP_TRY(hipSetDevice(h.device));
@@ -316,8 +398,31 @@ extern "C" cugraph_error_code_t cugraph_decompress_to_edgelist(const cugraph_res
   return guarded(error, [&] {
     handle_t const& h = H(handle);
     CGA_EXPECTS(graph != nullptr && result != nullptr, CUGRAPH_INVALID_INPUT, "graph / result is NULL");
-    graph_t& g = G(graph);
+    graph_t& g = GM(graph);
     HIP_TRY(hipSetDevice(h.device));
+    if (g.mg) {
+      // A graph from cugraph_graph_create_mg: every rank returns ITS part of the edge list (decompress_to_edgelist.cpp:60-103 with multi_gpu =
+      // true returns the rank's local partition) -- here the slice the rank holds after the creation flags, external ids, with the weights and
+      // the edge ids / edge type ids that came with it.  Not collective.  The union over the ranks is the graph's edge multiset.
+      mg_graph_t const& mg = *g.mg;
+      edge_list_t const& el = mg.el;
+      auto out = std::make_unique<edgelist_result_t>();
+      auto take = [&](void const* p, size_t elem, cugraph_data_type_id_t t) {
+        auto* a = new device_array_t((size_t)el.n, t);
+        if (el.n > 0) HIP_TRY(hipMemcpyAsync(a->buf.ptr, p, (size_t)el.n * elem, hipMemcpyDeviceToDevice, h.stream));
+        return a;
+      };
+      out->src = take(el.s.data(), 4, INT32);
+      out->dst = take(el.d.data(), 4, INT32);
+      if (g.has_weights) out->wgt = take(el.w.ptr, el.wsize, g.weight_type);
+      if (g.has_edge_ids) out->ids = take(mg.edge_ids.ptr, mg.ids_size, g.edge_id_type);
+      if (g.has_edge_types) out->types = take(mg.edge_types.data(), 4, INT32);
+      h.sync();
+      outer_replace_ids(h, g, out->src);
+      outer_replace_ids(h, g, out->dst);
+      *result = reinterpret_cast<cugraph_edgelist_t*>(out.release());
+      return;
+    }
     ensure_orientation(h, g, false);
     auto out = std::make_unique<edgelist_result_t>();
     out->src = new device_array_t((size_t)g.ne, g.vertex_type);

@@ -1437,7 +1437,9 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
     CGA_EXPECTS(result != nullptr, CUGRAPH_INVALID_INPUT, "result is NULL");
     HIP_TRY(hipSetDevice(h.device));
     if (g.mg) {  // a graph from cugraph_graph_create_mg on a communicator handle: collective
-      *result = reinterpret_cast<cugraph_hierarchical_clustering_result_t*>(mg_run_louvain(h, g, max_level, threshold, resolution));
+      clustering_result_t* r = mg_run_louvain(h, g, max_level, threshold, resolution);
+      outer_replace_ids(h, g, r->vertices);  // INT64 ids of a multi-GPU graph: back in the caller's id space (no-op otherwise)
+      *result = reinterpret_cast<cugraph_hierarchical_clustering_result_t*>(r);
       return;
     }
     CGA_EXPECTS(g.ne <= kMaxSignedEdges, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "Louvain: graphs of 2^31 or more edges are not supported");

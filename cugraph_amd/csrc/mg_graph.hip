@@ -258,8 +258,104 @@ mg_pagerank_part_t::~mg_pagerank_part_t()
 }
 
 // ------------------------------------------------------------------------------------------------ graph creation
+namespace {
+__global__ void k_scatter_paths(int32_t const* v, int32_t const* dist, int32_t const* pred, int64_t n, int64_t vmin, int64_t vrange, uint32_t* dist1, uint32_t* pred2)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t const k = (int64_t)v[i] - vmin;
+    if (k < 0 || k >= vrange) continue;
+    dist1[k] = (uint32_t)dist[i] + 1u;                 // hop counts are 0 .. INT32_MAX (unreached)
+    pred2[k] = (uint32_t)(pred[i] < 0 ? -1 : pred[i]) + 2u;  // -1 = no predecessor
+  }
+}
+
+// every rank's `mine` elements of `elem` bytes (a multiple of 4), concatenated in rank order, on every rank (collective)
+int64_t all_gather_v(handle_t const& h, comm_t& c, void const* in, int64_t mine, size_t elem, dev_buf& all)
+{
+  int const P = c.size;
+  std::vector<int64_t> counts(P);
+  c.host_allgather(&mine, sizeof(mine), counts.data());
+  int64_t stride = 1, total = 0;
+  for (auto x : counts) { stride = std::max(stride, x); total += x; }
+  dev_buf padded_in((size_t)stride * elem), padded((size_t)stride * elem * P);
+  HIP_TRY(hipMemsetAsync(padded_in.ptr, 0, (size_t)stride * elem, h.stream));
+  if (mine > 0) HIP_TRY(hipMemcpyAsync(padded_in.ptr, in, (size_t)mine * elem, hipMemcpyDeviceToDevice, h.stream));
+  c.all_gather(h, padded_in.ptr, (size_t)stride * elem, padded.ptr);
+  all.alloc((size_t)std::max<int64_t>(total, 1) * elem);
+  int64_t at = 0;
+  for (int r = 0; r < P; ++r) {
+    if (counts[r] > 0)
+      HIP_TRY(hipMemcpyAsync(static_cast<char*>(all.ptr) + (size_t)at * elem, static_cast<char const*>(padded.ptr) + (size_t)r * stride * elem, (size_t)counts[r] * elem,
+                             hipMemcpyDeviceToDevice, h.stream));
+    at += counts[r];
+  }
+  h.sync();
+  return total;
+}
+}  // namespace
+
+bool mg_outer_ids(handle_t const& h, device_array_view_t const* vertices, device_array_view_t const* src, device_array_view_t const* dst, outer_ids_t& outer)
+{
+  comm_t* cp = handle_comm(h);
+  CGA_EXPECTS(cp != nullptr, CUGRAPH_INVALID_HANDLE, "multi-GPU graph: the handle carries no communicator");
+  comm_t& c = *cp;
+  device_array_view_t const* cols[3] = {src, dst, vertices};
+  struct info_t { int64_t wide, bad; } mine{0, 0};
+  for (auto v : cols) {
+    if (v == nullptr) continue;
+    if (v->type == INT64) mine.wide = 1;
+    else if (v->type != INT32) mine.bad = 1;
+  }
+  std::vector<info_t> all(c.size);
+  c.host_allgather(&mine, sizeof(mine), all.data());  // (the ranks decide together: nobody is left waiting in a collective)
+  int64_t wide = 0, bad = 0;
+  for (auto const& i : all) { wide += i.wide; bad += i.bad; }
+  CGA_EXPECTS(bad == 0, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "multi-GPU graph: vertex ids must be INT32 or INT64");
+  if (wide == 0) return false;
+  // a mix of INT32 and INT64 columns (on one rank or between ranks) promotes the graph to INT64 (graph_sg.cpp:745-779 does the same for one rank)
+  dvec<int64_t> local;
+  outer_collect(h, cols, 3, local);  // this rank's distinct ids, ascending
+  dev_buf gathered;
+  int64_t const total = all_gather_v(h, c, local.data(), (int64_t)local.size(), sizeof(int64_t), gathered);
+  local = dvec<int64_t>();
+  device_array_view_t const gv{gathered.ptr, (size_t)total, INT64};
+  device_array_view_t const* one[1] = {&gv};
+  outer_collect(h, one, 1, outer.ext);  // the same list on every rank
+  outer.active   = true;
+  outer.identity = false;
+  outer.type     = INT64;
+  return true;
+}
+
+int64_t mg_host_max(graph_t& g, int64_t mine)
+{
+  comm_t& c = *g.mg->comm;
+  std::vector<int64_t> all(c.size);
+  c.host_allgather(&mine, sizeof(mine), all.data());
+  int64_t m = mine;
+  for (auto x : all) m = std::max(m, x);
+  return m;
+}
+
+void mg_gather_paths(handle_t const& h, graph_t& g, int32_t const* vertices, int32_t const* dist, int32_t const* pred, int64_t n, dvec<uint32_t>& dist1,
+                     dvec<uint32_t>& pred2)
+{
+  mg_graph_t& mg = *g.mg;
+  comm_t& c      = *mg.comm;
+  dist1.resize_discard((size_t)mg.vrange);
+  pred2.resize_discard((size_t)mg.vrange);
+  HIP_TRY(hipMemsetAsync(dist1.data(), 0, (size_t)mg.vrange * 4, h.stream));
+  HIP_TRY(hipMemsetAsync(pred2.data(), 0, (size_t)mg.vrange * 4, h.stream));
+  if (n > 0) hipLaunchKernelGGL(k_scatter_paths, grid_for(n, kBlock, 8192), kBlock, 0, h.stream, vertices, dist, pred, n, mg.vmin, mg.vrange, dist1.data(), pred2.data());
+  // every id is reported by exactly one rank (its owner), the others contribute 0: the sum IS the gather
+  c.all_reduce_sum_u32(h, dist1.data(), mg.vrange);
+  c.all_reduce_sum_u32(h, pred2.data(), mg.vrange);
+}
+
 void mg_graph_create(handle_t const& h, graph_t& g, device_array_view_t const* vertices, device_array_view_t const* src, device_array_view_t const* dst,
-                     device_array_view_t const* weights, bool drop_self_loops, bool drop_multi_edges, bool symmetrize)
+                     device_array_view_t const* weights, device_array_view_t const* edge_ids, device_array_view_t const* edge_type_ids, bool drop_self_loops,
+                     bool drop_multi_edges, bool symmetrize)
 {
   comm_t* cp = handle_comm(h);
   CGA_EXPECTS(cp != nullptr, CUGRAPH_INVALID_HANDLE, "multi-GPU graph: the handle carries no communicator");
@@ -270,6 +366,16 @@ void mg_graph_create(handle_t const& h, graph_t& g, device_array_view_t const* v
   auto mg  = std::make_shared<mg_graph_t>();
   mg->comm = cp;
   int64_t const m = (int64_t)src->size;
+  // Edge ids / edge type ids: edge PROPERTIES that the sampling and lookup families read (graph_mg.cpp:127-151 shuffles them with their edges);
+  // none of the algorithms of this library does.  They stay with this rank's slice and come back from cugraph_decompress_to_edgelist.  As
+  // on one GPU (graph.hip: create_sg) they are refused together with a flag that rewrites the edge list.
+  int64_t const props_state = [&]() -> int64_t {
+    if (edge_ids == nullptr && edge_type_ids == nullptr) return 0;
+    if (drop_self_loops || drop_multi_edges || symmetrize) return -1;
+    if ((edge_ids && edge_ids->size != src->size) || (edge_type_ids && edge_type_ids->size != src->size)) return -2;
+    if ((edge_ids && edge_ids->type != INT32 && edge_ids->type != INT64) || (edge_type_ids && edge_type_ids->type != INT32)) return -3;
+    return (edge_ids ? (edge_ids->type == INT64 ? 2 : 1) : 0) + (edge_type_ids ? 4 : 0);
+  }();
   CGA_EXPECTS(m <= kMaxSignedEdges, CUGRAPH_INVALID_INPUT, "multi-GPU graph: a rank's slice must hold fewer than 2^31 edges");
   edge_list_t& el = mg->el;
   el.n     = m;
@@ -293,7 +399,7 @@ void mg_graph_create(handle_t const& h, graph_t& g, device_array_view_t const* v
     h.sync();
   }
   // the dense id range over all ranks, edge total, does anybody list vertices, do all ranks agree on the weights
-  struct info_t { int64_t lo, hi, ne, listed, weighted, wsize; } mine{INT64_MAX, INT64_MIN, el.n, mg->n_listed, weights ? 1 : 0, (int64_t)el.wsize};
+  struct info_t { int64_t lo, hi, ne, listed, weighted, wsize, props; } mine{INT64_MAX, INT64_MIN, el.n, mg->n_listed, weights ? 1 : 0, (int64_t)el.wsize, props_state};
   auto upd = [&](int32_t const* p, int64_t n) {
     if (n <= 0) return;
     int32_t a, b;
@@ -309,6 +415,28 @@ void mg_graph_create(handle_t const& h, graph_t& g, device_array_view_t const* v
     lo = std::min(lo, i.lo); hi = std::max(hi, i.hi); ne += i.ne; any_listed += i.listed;
     CGA_EXPECTS(i.weighted == mine.weighted && i.wsize == mine.wsize, CUGRAPH_INVALID_INPUT, "multi-GPU graph: the ranks disagree on the edge weights (present / type)");
   }
+  // (decided on the gathered states, so that every rank throws or none does)
+  for (auto const& i : all) {
+    CGA_EXPECTS(i.props != -1, CUGRAPH_NOT_IMPLEMENTED,
+                "edge ids / edge type ids together with drop_self_loops / drop_multi_edges / symmetrize are not supported: the rewritten edge list has no one-to-one relation to them");
+    CGA_EXPECTS(i.props != -2, CUGRAPH_INVALID_INPUT, "Invalid input arguments: src size != edge id / edge type prop size");
+    CGA_EXPECTS(i.props != -3, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "edge ids must be INT32 or INT64, edge type ids INT32");
+    CGA_EXPECTS(i.props == mine.props, CUGRAPH_INVALID_INPUT, "multi-GPU graph: the ranks disagree on the edge ids / edge type ids (present / type)");
+  }
+  if (edge_ids) {
+    mg->ids_size = dtype_size(edge_ids->type);
+    mg->edge_ids.alloc((size_t)std::max<int64_t>(m, 1) * mg->ids_size);
+    if (m > 0) HIP_TRY(hipMemcpyAsync(mg->edge_ids.ptr, edge_ids->data, (size_t)m * mg->ids_size, hipMemcpyDeviceToDevice, h.stream));
+    g.has_edge_ids = true;
+    g.edge_id_type = edge_ids->type;
+  }
+  if (edge_type_ids) {
+    mg->has_edge_types = true;
+    mg->edge_types.resize_discard((size_t)std::max<int64_t>(m, 1));
+    if (m > 0) HIP_TRY(hipMemcpyAsync(mg->edge_types.data(), edge_type_ids->data, (size_t)m * 4, hipMemcpyDeviceToDevice, h.stream));
+    g.has_edge_types = true;
+  }
+  h.sync();
   CGA_EXPECTS(hi >= lo, CUGRAPH_INVALID_INPUT, "multi-GPU graph: no edges and no vertices on any rank");
   CGA_EXPECTS(hi - lo + 1 < ((int64_t)1 << 31) - 2, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "multi-GPU graph: the external id range must fit 31 bits");
   mg->vmin = lo; mg->vrange = hi - lo + 1; mg->ne_global = ne;

@@ -53,6 +53,10 @@ struct mg_traversal_part_t {
 struct mg_graph_t {
   comm_t* comm{nullptr};
   edge_list_t el;             // this rank's slice (external ids), after the local part of the creation flags
+  dev_buf edge_ids;           // optional edge ids of the slice, in slice order (ids_size bytes each; graph_mg.cpp:127-151 keeps them as edge properties);
+  size_t ids_size{0};         // no algorithm of this library reads them: they come back from cugraph_decompress_to_edgelist
+  dvec<int32_t> edge_types;   // optional edge type ids of the slice
+  bool has_edge_types{false};
   dvec<int32_t> listed;       // vertices this rank listed explicitly (isolated vertices exist only through such a list)
   int64_t n_listed{0};
   int64_t vmin{0}, vrange{0};  // dense external id range over all ranks
@@ -72,9 +76,21 @@ struct clustering_result_t;
 // cugraph_louvain on a multi-GPU graph (louvain.hip): collective; every rank gets the clusters of the vertices it owns (v % P == rank in ascending id order)
 clustering_result_t* mg_run_louvain(handle_t const& h, graph_t& g, size_t max_level, double threshold, double resolution);
 
+// INT64 vertex ids on a multi-GPU graph (collective; graph_mg.cpp:127-151 instantiates vertex_t = int64_t): when ANY rank hands over an INT64
+// column, every rank gets the same ascending list of the distinct ids of all ranks in `outer` (outer_ids.hip: compact id = position) and
+// returns true; the caller then replaces its columns by compact int32 ids and results leave through outer_replace_ids
+bool mg_outer_ids(handle_t const& h, device_array_view_t const* vertices, device_array_view_t const* src, device_array_view_t const* dst, outer_ids_t& outer);
 // cugraph_graph_create_mg / _with_times_mg on a handle with more than one rank (collective)
 void mg_graph_create(handle_t const& h, graph_t& g, device_array_view_t const* vertices, device_array_view_t const* src, device_array_view_t const* dst,
-                     device_array_view_t const* weights, bool drop_self_loops, bool drop_multi_edges, bool symmetrize);
+                     device_array_view_t const* weights, device_array_view_t const* edge_ids, device_array_view_t const* edge_type_ids, bool drop_self_loops,
+                     bool drop_multi_edges, bool symmetrize);
+// cugraph_extract_paths on a multi-GPU graph (collective): every rank's (vertex, hop count, predecessor) triples -- external int32 ids -- folded into
+// two tables over the dense id range that every rank holds afterwards: dist1[id - vmin] = hop count + 1, pred2[id - vmin] = predecessor + 2
+// (0 = no rank reported the id)
+void mg_gather_paths(handle_t const& h, graph_t& g, int32_t const* vertices, int32_t const* dist, int32_t const* pred, int64_t n, dvec<uint32_t>& dist1,
+                     dvec<uint32_t>& pred2);
+// max over the ranks of a host value (collective)
+int64_t mg_host_max(graph_t& g, int64_t mine);
 void mg_has_vertex(handle_t const& h, graph_t const& g, int32_t const* v, int64_t n, uint8_t* out);
 // cugraph_degrees family on a multi-GPU graph (collective): this rank's share of the vertices (all, or those any rank listed) and their degrees
 int64_t mg_degrees(handle_t const& h, graph_t& g, device_array_view_t const* listed, bool want_in, bool want_out, dvec<int32_t>& ids, dvec<int32_t>& in_deg, dvec<int32_t>& out_deg);

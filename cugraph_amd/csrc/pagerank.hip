@@ -2028,7 +2028,9 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     }
     h.sync();
     c.check("multi-GPU PageRank result");
-    return new centrality_result_t{ids.release(), vals.release(), total_iterations, converged};
+    device_array_t* idp = ids.release();
+    outer_replace_ids(h, g, idp);  // INT64 ids: the caller's id space (no-op otherwise)
+    return new centrality_result_t{idp, vals.release(), total_iterations, converged};
   }
 };
 
@@ -2058,13 +2060,19 @@ pagerank_plan_base* make_plan(cugraph_resource_handle_t const* handle, cugraph_g
                      "vertex type of graph and precomputed_vertex_out_weight_sums must match");
     check_pair_types(g, V(ig_v), V(ig_s), "vertex type of graph and initial_guess_vertices must match", "vertex type of graph and initial_guess_values must match");
     check_pair_types(g, V(p_v), V(p_s), "vertex type of graph and personalization_vector must match", "vertex type of graph and personalization_vector must match");
+    // INT64 ids of a multi-GPU graph: the vertex columns become compact int32 ids (outer_ids.hip); ids that are no vertices map to -1 and are
+    // rejected by create() exactly as unknown int32 ids are; the result's vertex column goes back through outer_replace_ids (pagerank_mgc_plan::result)
+    vertex_column_in mc_ow, mc_ig, mc_p;
+    device_array_view_t const* mow = mc_ow.get(h, g, V(ow_v), "precomputed_vertex_out_weight_vertices");
+    device_array_view_t const* mig = mc_ig.get(h, g, V(ig_v), "initial_guess_vertices");
+    device_array_view_t const* mpv = mc_p.get(h, g, V(p_v), "personalization_vector");
     if (g.weight_type == FLOAT64) {
       auto p = std::make_unique<pagerank_mgc_plan<double>>(h, g, alpha);
-      p->create(V(ow_v), V(ow_s), V(ig_v), V(ig_s), V(p_v), V(p_s));
+      p->create(mow, V(ow_s), mig, V(ig_s), mpv, V(p_s));
       return p.release();
     }
     auto p = std::make_unique<pagerank_mgc_plan<float>>(h, g, alpha);
-    p->create(V(ow_v), V(ow_s), V(ig_v), V(ig_s), V(p_v), V(p_s));
+    p->create(mow, V(ow_s), mig, V(ig_s), mpv, V(p_s));
     return p.release();
   }
   CGA_EXPECTS(p_v == nullptr || V(p_v)->size > 0, CUGRAPH_INVALID_INPUT,

@@ -1965,7 +1965,13 @@ extern "C" cugraph_error_code_t cugraph_bfs(const cugraph_resource_handle_t* han
     handle_t& h = const_cast<handle_t&>(H(handle));
     graph_t& g  = GM(graph);
     if (g.mg) {  // a graph from cugraph_graph_create_mg on a communicator handle: collective (traversal_mg_driver.hip)
-      *result = reinterpret_cast<cugraph_paths_result_t*>(mg_run_bfs(h, g, V(sources), direction_optimizing == TRUE, depth_limit, compute_predecessors == TRUE));
+      vertex_column_in c_msources;  // INT64 ids of a multi-GPU graph: compact int32 ids in, the caller's ids out (outer_ids.hip)
+      device_array_view_t const* msv = c_msources.get(h, g, V(sources), "sources");
+      paths_result_t* r = mg_run_bfs(h, g, msv, direction_optimizing == TRUE, depth_limit, compute_predecessors == TRUE);
+      outer_replace_ids(h, g, r->vertex_ids);
+      outer_replace_dist(h, g, r->distances);  // BFS distances carry the vertex type (bfs.cpp:156-187)
+      outer_replace_ids(h, g, r->predecessors);
+      *result = reinterpret_cast<cugraph_paths_result_t*>(r);
       return;
     }
     *result     = reinterpret_cast<cugraph_paths_result_t*>(
@@ -1983,7 +1989,23 @@ extern "C" cugraph_error_code_t cugraph_sssp(const cugraph_resource_handle_t* ha
     handle_t& h = const_cast<handle_t&>(H(handle));
     graph_t& g  = GM(graph);
     if (g.mg) {
-      *result = reinterpret_cast<cugraph_paths_result_t*>(mg_run_sssp(h, g, source, cutoff, compute_predecessors == TRUE));
+      size_t msource = source;
+      if (g.outer.active) {  // INT64 ids: the source's position in the sorted id list every rank holds (no collective: all ranks get the same answer)
+        dvec<int64_t> one(1);
+        dvec<int32_t> compact(1);
+        int64_t const sv = (int64_t)source;
+        HIP_TRY(hipSetDevice(h.device));
+        HIP_TRY(hipMemcpyAsync(one.data(), &sv, 8, hipMemcpyHostToDevice, h.stream));
+        outer_to_compact(h, g.outer, one.data(), INT64, 1, compact.data());
+        int32_t c = -1;
+        h.read_back(&c, compact.data(), 1);
+        CGA_EXPECTS(c >= 0, CUGRAPH_INVALID_INPUT, "Invalid input argument: source vertex is not a vertex of the graph.");
+        msource = (size_t)c;
+      }
+      paths_result_t* r = mg_run_sssp(h, g, msource, cutoff, compute_predecessors == TRUE);
+      outer_replace_ids(h, g, r->vertex_ids);
+      outer_replace_ids(h, g, r->predecessors);
+      *result = reinterpret_cast<cugraph_paths_result_t*>(r);
       return;
     }
     // sssp.cpp:72-73,105 dereferences the edge weights unconditionally: an unweighted graph is an error

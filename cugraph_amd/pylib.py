@@ -452,6 +452,25 @@ def bfs_extract_paths(handle, graph, sources, destinations, direction_optimizing
     return (distances, predecessors, vertices, paths)
 
 
+def decompress_to_edgelist(resource_handle, graph, do_expensive_check=False):
+    """decompress_to_edgelist.pyx: the graph back as (sources, destinations, weights, edge_ids, edge_type_ids) with the caller's vertex ids (missing
+    columns None).  On a multi-GPU graph every rank gets ITS part of the edge list (not collective)."""
+    l = capi.lib()
+    h = resource_handle.c_resource_handle_ptr
+    el, err = C.c_void_p(), C.c_void_p()
+    _sync_torch()
+    assert_success(l.cugraph_decompress_to_edgelist(h, graph.c_graph_ptr, int(do_expensive_check), C.byref(el), C.byref(err)), err, "cugraph_decompress_to_edgelist")
+    try:
+        cols = []
+        for get in (l.cugraph_edgelist_get_sources, l.cugraph_edgelist_get_destinations, l.cugraph_edgelist_get_edge_weights, l.cugraph_edgelist_get_edge_ids,
+                    l.cugraph_edgelist_get_edge_type_ids):
+            view = get(el)
+            cols.append(copy_to_torch(h, view) if view else None)
+    finally:
+        l.cugraph_edgelist_free(el)
+    return tuple(cols)
+
+
 def louvain(resource_handle, graph, max_level, threshold, resolution, do_expensive_check):
     """louvain.pyx: returns (vertices, clusters, modularity)."""
     l = capi.lib()

@@ -1,13 +1,53 @@
 """What a rank of tests/test_mg_capi.py runs through the reference's own entry points on a communicator handle
 (cugraph_graph_create_mg -> cugraph_pagerank / cugraph_bfs / cugraph_sssp / cugraph_louvain).  Every rank builds ITS slice of the same
 seeded RMAT edge list, saves (vertices, values) of the vertices it gets back; the test assembles them and compares with the oracle."""
+import os
+
 import numpy as np
 import torch
+
+# CUGRAPH_AMD_TEST_WIDE_IDS=1: every vertex id crosses the C API as INT64, spread out and shifted past 2^40 (v -> v * WIDE_MUL + WIDE_OFF, monotone:
+# minimum-external-id tie-breaks are unchanged); what comes back is mapped home before it is saved, so the checks of the int32 cases apply as they are
+WIDE = os.environ.get("CUGRAPH_AMD_TEST_WIDE_IDS") == "1"
+WIDE_MUL, WIDE_OFF = 1000003, 1 << 40
 
 
 def T(a, dtype=None):
     t = torch.from_numpy(np.ascontiguousarray(a))
     return (t if dtype is None else t.to(dtype)).cuda()
+
+
+def wide_of(a):
+    return np.asarray(a).astype(np.int64) * WIDE_MUL + WIDE_OFF
+
+
+def X(a):
+    """a column of vertex ids on its way into the library"""
+    return T(wide_of(a)) if WIDE else T(a)
+
+
+def xid(v):
+    return int(v) * WIDE_MUL + WIDE_OFF if WIDE else int(v)
+
+
+def U(t):
+    """a column of vertex ids that came out of the library (negative markers -- no predecessor, path padding -- stay as they are), as int32"""
+    a = t.cpu().numpy()
+    if not WIDE:
+        return a
+    assert a.dtype == np.int64, a.dtype
+    ok = a >= 0
+    assert ((a[ok] - WIDE_OFF) % WIDE_MUL == 0).all(), "an id that is not one of the graph's came back"
+    return np.where(ok, (a - WIDE_OFF) // WIDE_MUL, a).astype(np.int32)
+
+
+def UD(t):
+    """BFS hop counts (typed like the vertices: INT64 with INT64_MAX = unreached in the wide case) as the int32 column the checks expect"""
+    a = t.cpu().numpy()
+    if not WIDE:
+        return a
+    assert a.dtype == np.int64, a.dtype
+    return np.where(a == np.iinfo(np.int64).max, np.iinfo(np.int32).max, a).astype(np.int32)
 
 
 def rmat_slice(scale, rank, size, edge_factor=16, seed=0):
@@ -43,9 +83,9 @@ def run(what, cg, h, comm, rank, size, outdir, args):
             w = np.random.default_rng(1).integers(1, 9, size=16 << scale).astype(np.float32)[first: first + s.size].copy()
         # isolated ids are vertices only when somebody lists them (graph_mg.cpp:326: vertices are optional): every rank lists a slice
         verts = np.arange(rank, 1 << scale, size, dtype=np.int32)
-        g = cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [T(s)], [T(d)], None if w is None else [T(w)], store_transposed=True, vertices_array=[T(verts)])
+        g = cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [X(s)], [X(d)], None if w is None else [T(w)], store_transposed=True, vertices_array=[X(verts)])
         v, x, conv = cg.pagerank(h, g, None, None, None, None, 0.85, eps, max_iter, False, fail_on_nonconvergence=False)
-        np.savez(outdir / f"rank{rank}.npz", v=v.cpu().numpy(), x=x.cpu().numpy())
+        np.savez(outdir / f"rank{rank}.npz", v=U(v), x=x.cpu().numpy())
         out["rows"] = int(v.numel())
         out["converged"] = bool(conv) if conv is not None else None
         # a second call on the same graph reuses the partition and must give the same answer
@@ -68,17 +108,17 @@ def run(what, cg, h, comm, rank, size, outdir, args):
         (s, d), first = rmat_slice(scale, rank, size)
         nv = 1 << scale
         verts = np.arange(rank, nv, size, dtype=np.int32)
-        g = cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [T(s)], [T(d)], None, store_transposed=True, vertices_array=[T(verts)])
+        g = cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [X(s)], [X(d)], None, store_transposed=True, vertices_array=[X(verts)])
         pv, pval, guess, outw = ppr_inputs(scale)
         cut = lambda a: a[(rank * a.size) // size: ((rank + 1) * a.size) // size].copy()  # noqa: E731
         allv = np.arange(nv, dtype=np.int32)[::-1].copy()  # (descending: a rank's slice names mostly other ranks' vertices)
-        v, x, _ = cg.personalized_pagerank(h, g, T(cut(allv)), T(cut(outw[allv])), T(cut(allv)), T(cut(guess[allv])), T(cut(pv)), T(cut(pval)), 0.85, 0.0, max_iter,
+        v, x, _ = cg.personalized_pagerank(h, g, X(cut(allv)), T(cut(outw[allv])), X(cut(allv)), T(cut(guess[allv])), X(cut(pv)), T(cut(pval)), 0.85, 0.0, max_iter,
                                            False, fail_on_nonconvergence=False)
-        np.savez(outdir / f"rank{rank}.npz", v=v.cpu().numpy(), x=x.cpu().numpy())
+        np.savez(outdir / f"rank{rank}.npz", v=U(v), x=x.cpu().numpy())
         out["rows"] = int(v.numel())
         # a vertex that is not in the graph: INVALID_INPUT on every rank
         try:
-            cg.personalized_pagerank(h, g, None, None, None, None, T(np.array([nv + 5], np.int32) if rank == 0 else np.zeros(0, np.int32)),
+            cg.personalized_pagerank(h, g, None, None, None, None, X(np.array([nv + 5], np.int32) if rank == 0 else np.zeros(0, np.int32)),
                                      T(np.array([1.0], np.float32) if rank == 0 else np.zeros(0, np.float32)), 0.85, 0.0, 2, False, fail_on_nonconvergence=False)
             out["bad_vertex"] = "accepted"
         except Exception as e:  # noqa: BLE001
@@ -96,7 +136,7 @@ def run(what, cg, h, comm, rank, size, outdir, args):
             if kind == "f64":  # FLOAT64 weights (the plain exchange loop): the integer weights + a fraction that float32 cannot hold
                 wall = wall.astype(np.float64) + 1.0 / 3.0
             w = wall[first: first + s.size].copy()
-        g = cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [T(s)], [T(d)], None if w is None else [T(w)], store_transposed=False, vertices_array=[T(verts)])
+        g = cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [X(s)], [X(d)], None if w is None else [T(w)], store_transposed=False, vertices_array=[X(verts)])
         # roots: the same list on every rank (vertices with out-edges, fixed seed); BFS hands every rank a SLICE of it (the union is the source set)
         all_s, _ = rmat_slice(scale, 0, 1)
         cand = np.unique(all_s[0])
@@ -106,22 +146,22 @@ def run(what, cg, h, comm, rank, size, outdir, args):
             depth = int(args[3]) if len(args) > 3 else 0
             for k, root in enumerate(roots):
                 mine = np.array([root], np.int32) if k % size == rank else np.zeros(0, np.int32)  # one rank names the source
-                dist, pred, v = cg.bfs(h, g, T(mine), False, depth, with_pred, False)
-                res[f"v{k}"], res[f"d{k}"] = v.cpu().numpy(), dist.cpu().numpy()
+                dist, pred, v = cg.bfs(h, g, X(mine), False, depth, with_pred, False)
+                res[f"v{k}"], res[f"d{k}"] = U(v), UD(dist)
                 if with_pred:
-                    res[f"p{k}"] = pred.cpu().numpy()
+                    res[f"p{k}"] = U(pred)
             stats = h.last_traversal_stats()
             out["levels"], out["bottom_up_levels"] = int(stats["steps"]), int(stats["edges_inspected"])
             # multi-source: all roots at once, every rank passing the whole list
-            dist, pred, v = cg.bfs(h, g, T(roots), False, depth, False, False)
-            res["vm"], res["dm"] = v.cpu().numpy(), dist.cpu().numpy()
+            dist, pred, v = cg.bfs(h, g, X(roots), False, depth, False, False)
+            res["vm"], res["dm"] = U(v), UD(dist)
         else:
             cutoff = float(args[4]) if len(args) > 4 else 3.0e38
             for k, root in enumerate(roots):
-                v, dist, pred = cg.sssp(h, g, int(root), cutoff, with_pred, False)
-                res[f"v{k}"], res[f"d{k}"] = v.cpu().numpy(), dist.cpu().numpy()
+                v, dist, pred = cg.sssp(h, g, xid(root), cutoff, with_pred, False)
+                res[f"v{k}"], res[f"d{k}"] = U(v), dist.cpu().numpy()
                 if with_pred:
-                    res[f"p{k}"] = pred.cpu().numpy()
+                    res[f"p{k}"] = U(pred)
         np.savez(outdir / f"rank{rank}.npz", roots=roots, **res)
         del g
     elif what == "louvain":
@@ -133,13 +173,60 @@ def run(what, cg, h, comm, rank, size, outdir, args):
         nv = 1 << scale
         mine = np.arange(src.size) % size == rank      # an arbitrary slice: the library routes the edges to their owners
         verts = np.arange(rank, nv, size, dtype=np.int32)
-        g = cg.MGGraph(h, cg.GraphProperties(is_symmetric=True), [T(src[mine])], [T(dst[mine])], [T(w[mine])], store_transposed=False, vertices_array=[T(verts)])
+        g = cg.MGGraph(h, cg.GraphProperties(is_symmetric=True), [X(src[mine])], [X(dst[mine])], [T(w[mine])], store_transposed=False, vertices_array=[X(verts)])
         v, c, q = cg.louvain(h, g, 100, 1e-7, 1.0, False)
-        np.savez(outdir / f"rank{rank}.npz", v=v.cpu().numpy(), c=c.cpu().numpy())
+        np.savez(outdir / f"rank{rank}.npz", v=U(v), c=c.cpu().numpy())
         out["modularity_hex"] = float(q).hex()
         out["rows"] = int(v.numel())
         st = h.last_traversal_stats()
         out["sweeps"] = int(st["steps"])
+        del g
+    elif what == "props":
+        # edge ids / edge type ids on a multi-GPU graph: kept with the rank's slice, back from cugraph_decompress_to_edgelist (graph_mg.cpp:127-151);
+        # degrees / has_vertex on the same graph (the wide case sends their id columns through the INT64 translation too)
+        scale, id_kind = int(args[0]), args[1]
+        (s, d), first = rmat_slice(scale, rank, size)
+        nv, ne = 1 << scale, 16 << scale
+        w = np.random.default_rng(1).integers(1, 9, size=ne).astype(np.float32)[first: first + s.size].copy()
+        ids = ((np.random.default_rng(4).permutation(ne) + 1000).astype(np.int64 if id_kind == "i64" else np.int32))[first: first + s.size].copy()
+        types = (np.arange(first, first + s.size) % 5).astype(np.int32)
+        verts = np.arange(rank, nv, size, dtype=np.int32)
+        g = cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [X(s)], [X(d)], [T(w)], store_transposed=False, vertices_array=[X(verts)],
+                       edge_id_array=[T(ids)], edge_type_array=[T(types)])
+        es, ed, ew, ei, et = cg.decompress_to_edgelist(h, g)
+        v, din, dout = cg.degrees(h, g, None)
+        some = np.arange(rank, nv, 7 * size + 1, dtype=np.int32)  # every rank lists its own few; the owners answer
+        v2, din2, dout2 = cg.degrees(h, g, X(some))
+        hv = cg.has_vertex(h, g, X(np.array([0, nv - 1, nv + 3], np.int32)))
+        np.savez(outdir / f"rank{rank}.npz", s=U(es), d=U(ed), w=ew.cpu().numpy(), ids=ei.cpu().numpy(), types=et.cpu().numpy(), v=U(v), din=din.cpu().numpy(),
+                 dout=dout.cpu().numpy(), v2=U(v2), din2=din2.cpu().numpy(), dout2=dout2.cpu().numpy(), listed=some)
+        out["has_vertex"] = [bool(x) for x in hv.cpu().numpy()]
+        try:  # together with a flag that rewrites the edge list the properties are refused on every rank, as on one GPU
+            cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [X(s)], [X(d)], [T(w)], edge_id_array=[T(ids)], drop_self_loops=True)
+            out["refused"] = "accepted"
+        except Exception as e:  # noqa: BLE001
+            out["refused"] = str(e)
+        del g
+    elif what == "paths":
+        # cugraph_bfs with predecessors + cugraph_extract_paths on a multi-GPU graph: every rank asks for its own destinations, most of them
+        # vertices other ranks own
+        scale = int(args[0])
+        (s, d), first = rmat_slice(scale, rank, size)
+        nv = 1 << scale
+        verts = np.arange(rank, nv, size, dtype=np.int32)
+        g = cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [X(s)], [X(d)], None, store_transposed=False, vertices_array=[X(verts)])
+        all_s, _ = rmat_slice(scale, 0, 1)
+        root = int(np.random.default_rng(7).choice(np.unique(all_s[0]), size=1)[0])
+        dests = np.random.default_rng(100 + rank).choice(nv, size=40 + 5 * rank, replace=False).astype(np.int32)
+        mine = np.array([root], np.int32) if rank == 0 else np.zeros(0, np.int32)
+        dist, pred, v, paths = cg.bfs_extract_paths(h, g, X(mine), X(dests))
+        np.savez(outdir / f"rank{rank}.npz", root=root, dests=dests, v=U(v), dist=UD(dist), pred=U(pred), paths=U(paths.reshape(-1)).reshape(paths.shape))
+        out["width"] = int(paths.shape[1])
+        try:  # a destination that is no vertex: INVALID_INPUT on every rank
+            cg.bfs_extract_paths(h, g, X(mine), X(np.array([nv + 9], np.int32) if rank == size - 1 else dests[:2]))
+            out["bad_destination"] = "accepted"
+        except Exception as e:  # noqa: BLE001
+            out["bad_destination"] = str(e)
         del g
     else:
         raise ValueError(what)

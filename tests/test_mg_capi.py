@@ -77,10 +77,14 @@ def _assemble(tmp_path, world, nv):
 def test_mg_capi_pagerank(orc, tmp_path, world, weighted):
     """cugraph_graph_create_mg + cugraph_pagerank_allow_nonconvergence on a communicator handle, 1 .. 8 ranks sharing one GPU, against the
     single-process oracle at a fixed iteration count (1e-6 absolute, 2e-5 relative: the tolerance of the single-GPU parity tests)."""
+    _pagerank_case(orc, tmp_path, world, weighted)
+
+
+def _pagerank_case(orc, tmp_path, world, weighted, env=None):
     from test_mg import truth
 
     scale, iters = 12, 12
-    res = run_ranks("pagerank", world, tmp_path, scale, iters, 0.0, weighted)
+    res = run_ranks("pagerank", world, tmp_path, scale, iters, 0.0, weighted, env_extra=env)
     assert sum(r["rows"] for r in res) == 1 << scale and all(r["repeat_equal"] for r in res)
     pr = _assemble(tmp_path, world, 1 << scale)
     t, _, _ = truth(orc, scale, 0.0, iters, weighted=weighted == "w")
@@ -113,11 +117,15 @@ def test_mg_capi_personalized_pagerank_with_guess_and_out_weights(orc, tmp_path,
     """cugraph_personalized_pagerank on a multi-GPU graph with all three optional (vertices, values) arguments, each rank passing a slice that
     names other ranks' vertices: against the oracle (personalization with a repeated vertex, un-normalised initial guess, precomputed
     out-weight sums) at a fixed iteration count; an id that is no vertex is refused on every rank."""
+    _ppr_case(orc, tmp_path, world)
+
+
+def _ppr_case(orc, tmp_path, world, env=None):
     from mg_capi_cases import ppr_inputs
     from test_mg import rmat_graph
 
     scale, iters = 11, 10
-    res = run_ranks("ppr", world, tmp_path, scale, iters)
+    res = run_ranks("ppr", world, tmp_path, scale, iters, env_extra=env)
     nv = 1 << scale
     assert sum(r["rows"] for r in res) == nv
     assert all("not in the graph" in r["bad_vertex"] for r in res), [r["bad_vertex"] for r in res]
@@ -151,10 +159,14 @@ def test_mg_capi_bfs(orc, tmp_path, world, direction):
     """cugraph_graph_create_mg + cugraph_bfs on a communicator handle (ranks sharing one GPU): distances bit-exact against the oracle,
     parents = minimum external id among the valid ones whatever directions the levels took; one rank names each source (the union of
     the ranks' lists is the source set), and one multi-source call with the whole list on every rank."""
+    _bfs_case(orc, tmp_path, world, direction)
+
+
+def _bfs_case(orc, tmp_path, world, direction, env=None):
     from test_mg_traversal import check_bfs
 
     scale, n_roots = 12, 3
-    res = run_ranks("bfs", world, tmp_path, scale, n_roots, "p", env_extra={"CUGRAPH_AMD_MG_BFS": direction})
+    res = run_ranks("bfs", world, tmp_path, scale, n_roots, "p", env_extra=dict(env or {}, CUGRAPH_AMD_MG_BFS=direction))
     for k in range(n_roots):
         roots, dist, pred = _assemble_paths(tmp_path, world, 1 << scale, k)
         check_bfs(orc, scale, [int(roots[k])], dist, pred)
@@ -182,10 +194,14 @@ def test_mg_capi_bfs_depth_limit(orc, tmp_path):
 @pytest.mark.parametrize("world,kind", [(1, "int"), (2, "int"), (3, "int"), (4, "unit")])
 def test_mg_capi_sssp(orc, tmp_path, world, kind):
     """cugraph_sssp on a multi-GPU graph: distances bit-identical to Dijkstra (integer and unit weights), minimum-external-id parents"""
-    from test_mg_traversal import check_sssp, graph, min_ext_parent
+    _sssp_case(orc, tmp_path, world, kind)
+
+
+def _sssp_case(orc, tmp_path, world, kind, env=None):
+    from test_mg_traversal import check_sssp, graph
 
     scale, n_roots = 12, 2
-    run_ranks("sssp", world, tmp_path, scale, n_roots, "p", kind)
+    run_ranks("sssp", world, tmp_path, scale, n_roots, "p", kind, env_extra=env)
     for k in range(n_roots):
         roots, dist, pred = _assemble_paths(tmp_path, world, 1 << scale, k)
         if kind == "int":
@@ -274,9 +290,13 @@ def test_mg_capi_louvain(orc, tmp_path, world, scale):
     """cugraph_louvain on a multi-GPU graph (BASELINE config 5's algorithm partitioned over ranks sharing one GPU): the clustering equals the C
     oracle's -- and therefore the single-GPU library's, which the parity suite pins to the same oracle -- vertex for vertex, the modularity is
     the same double on every rank and within 1e-9 of the oracle's."""
+    _louvain_case(orc, tmp_path, world, scale)
+
+
+def _louvain_case(orc, tmp_path, world, scale, env=None):
     from test_gpu_parity import louvain_rmat_input
 
-    res = run_ranks("louvain", world, tmp_path, scale)
+    res = run_ranks("louvain", world, tmp_path, scale, env_extra=env)
     nv = 1 << scale
     assert sum(r["rows"] for r in res) == nv and len({r["modularity_hex"] for r in res}) == 1
     c = _assemble_clusters(tmp_path, world, nv)
@@ -300,3 +320,95 @@ def test_mg_capi_louvain_rmat22_golden(tmp_path):
     assert abs(float.fromhex(res[0]["modularity_hex"]) - gold["modularity"]) <= 1e-9 and res[0]["modularity_hex"] == res[1]["modularity_hex"]
     assert int(np.unique(c).size) == gold["clusters"]
     assert hashlib.sha256(np.ascontiguousarray(c, np.int32).tobytes()).hexdigest() == gold["clusters_sha256"]
+
+
+# ----------------------------------------------------------------------- round 5: the multi-GPU graph at the width of the single-GPU one
+WIDE = {"CUGRAPH_AMD_TEST_WIDE_IDS": "1"}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what,world", [("pagerank", 2), ("ppr", 3), ("bfs", 2), ("sssp", 3), ("sssp", 1), ("louvain", 2)])
+def test_mg_capi_int64_vertex_ids(orc, tmp_path, what, world):
+    """INT64 vertex ids on a graph from cugraph_graph_create_mg (graph_mg.cpp:127-151 instantiates vertex_t = int64_t; python-cugraph's default):
+    every id crosses the C API as v * 1000003 + 2^40.  The ranks agree on one sorted id list (mg_graph.hip: mg_outer_ids), the engines run on
+    compact int32 ids, and every vertex column that comes back -- result vertices, predecessors, BFS hop counts typed like the vertices -- is in
+    the caller's id space: mapped home by the worker, the results pass the very checks of the int32 cases (oracle parity, minimum-external-id
+    parents: the mapping is monotone)."""
+    if what == "pagerank":
+        _pagerank_case(orc, tmp_path, world, "-", env=WIDE)
+    elif what == "ppr":
+        _ppr_case(orc, tmp_path, world, env=WIDE)
+    elif what == "bfs":
+        _bfs_case(orc, tmp_path, world, "", env=WIDE)
+    elif what == "sssp":
+        _sssp_case(orc, tmp_path, world, "int", env=WIDE)
+    else:
+        _louvain_case(orc, tmp_path, world, 14, env=WIDE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,id_kind,wide", [(1, "i32", False), (2, "i64", False), (3, "i32", True)])
+def test_mg_capi_edge_properties_and_decompress(orc, tmp_path, world, id_kind, wide):
+    """Edge ids / edge type ids handed to cugraph_graph_create_mg stay with their edges and come back from cugraph_decompress_to_edgelist, every
+    rank returning its part: the union over the ranks is the input edge list, and the id next to an edge names exactly that input edge
+    (graph_mg.cpp:127-151, decompress_to_edgelist.cpp:60-103).  On the same graph: cugraph_degrees (all vertices / a listed few) against bincounts,
+    cugraph_has_vertex; with drop_self_loops the properties are refused on every rank (as cugraph_graph_create_sg refuses them)."""
+    from test_mg import rmat_graph
+
+    scale = 10
+    res = run_ranks("props", world, tmp_path, scale, id_kind, env_extra=WIDE if wide else None)
+    nv, ne = 1 << scale, 16 << scale
+    s, d = rmat_graph(orc, scale)
+    w = np.random.default_rng(1).integers(1, 9, size=ne).astype(np.float32)
+    ids = (np.random.default_rng(4).permutation(ne) + 1000).astype(np.int64 if id_kind == "i64" else np.int32)
+    types = (np.arange(ne) % 5).astype(np.int32)
+    z = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    es, ed, ew, ei, et = (np.concatenate([x[k] for x in z]) for k in ("s", "d", "w", "ids", "types"))
+    assert ei.dtype == ids.dtype and es.size == ne and sorted(ei.tolist()) == sorted(ids.tolist())
+    where = np.empty(ne + 1000, np.int64)
+    where[ids] = np.arange(ne)
+    k = where[ei]  # the input edge every returned row claims to be
+    assert np.array_equal(es, s[k]) and np.array_equal(ed, d[k]) and np.array_equal(ew, w[k]) and np.array_equal(et, types[k])
+    din, dout = np.bincount(d, minlength=nv), np.bincount(s, minlength=nv)
+    v = np.concatenate([x["v"] for x in z])
+    assert np.array_equal(np.sort(v), np.arange(nv))
+    assert np.array_equal(np.concatenate([x["din"] for x in z]), din[v]) and np.array_equal(np.concatenate([x["dout"] for x in z]), dout[v])
+    v2 = np.concatenate([x["v2"] for x in z])
+    assert np.array_equal(np.sort(v2), np.sort(np.concatenate([x["listed"] for x in z])))
+    assert np.array_equal(np.concatenate([x["din2"] for x in z]), din[v2]) and np.array_equal(np.concatenate([x["dout2"] for x in z]), dout[v2])
+    assert all(r["has_vertex"] == [True, True, False] for r in res)
+    assert all("not supported" in r["refused"] or "NOT_IMPLEMENTED" in r["refused"] for r in res), [r["refused"] for r in res]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,wide", [(1, False), (2, False), (3, True)])
+def test_mg_capi_extract_paths(orc, tmp_path, world, wide):
+    """cugraph_bfs (with predecessors) + cugraph_extract_paths on a multi-GPU graph (extract_paths.cpp:57-119, extract_bfs_paths_impl.cuh:130-240
+    with multi_gpu = true): every rank asks for its own destinations, most of them owned by other ranks.  Row i is the root ... destination i along
+    edges of the graph in exactly dist + 1 entries, -1 beyond; a destination the BFS did not reach gives a row of -1; the matrix is as wide on
+    every rank (the longest path over all ranks' destinations + 1); a destination that is no vertex is INVALID_INPUT on every rank."""
+    from test_mg_traversal import graph
+
+    scale = 11
+    res = run_ranks("paths", world, tmp_path, scale, env_extra=WIDE if wide else None)
+    nv, s, d, _, off, idx, _ = graph(orc, scale)
+    z = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    root = int(z[0]["root"])
+    od, _ = orc.bfs(nv, off, idx, np.asarray([root], np.int32), 2**31 - 1)
+    edges = set(zip(s.tolist(), d.tolist()))
+    unreached = 2**31 - 1
+    longest = max((int(od[x["dests"]][od[x["dests"]] != unreached].max()) if (od[x["dests"]] != unreached).any() else 0) for x in z)
+    assert all(r["width"] == longest + 1 for r in res), ([r["width"] for r in res], longest)
+    n_unreached = 0
+    for x in z:
+        assert x["paths"].shape == (x["dests"].size, longest + 1)
+        for dest, row in zip(x["dests"].tolist(), x["paths"].tolist()):
+            if od[dest] == unreached:
+                assert all(p == -1 for p in row)
+                n_unreached += 1
+                continue
+            n = int(od[dest]) + 1
+            assert row[0] == root and row[n - 1] == dest and all(p == -1 for p in row[n:])
+            assert all((a, b) in edges for a, b in zip(row[:n - 1], row[1:n]))
+    assert n_unreached > 0  # (RMAT: a third of the ids have no in-edge)
+    assert all("not in the graph" in r["bad_destination"] for r in res), [r["bad_destination"] for r in res]
