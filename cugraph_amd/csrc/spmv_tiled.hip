@@ -1562,6 +1562,7 @@ struct p2_args {
   uint32_t* ready{nullptr};
   int T{0};
   int n_const{0};  // blocks [0, n_const) are the tiled_const_rows blocks (first: they are cheap and the coldest source tiles wait for them)
+  int I0{0};       // first block of this launch (tiled_range: a launch over a part of the destination tiles)
 };
 
 // x[c] = v so that a workgroup on another XCD that polls ready[] afterwards reads it: write-through (sc1) store
@@ -1605,7 +1606,7 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
   ACC* acc = reinterpret_cast<ACC*>(smem2);  // [TP2_ROWS]
   __shared__ double red[3 * (TP2_BLOCK / 64)];
   int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int I = blockIdx.x, cblock = -1;  // destination tile, or block of tiled_const_rows
+  int I = (int)blockIdx.x + a.I0, cblock = -1;  // destination tile, or block of tiled_const_rows
   if constexpr (OVL) {
     if (I < a.n_const) cblock = I; else I -= a.n_const;
   } else {
@@ -1794,7 +1795,7 @@ fin_args<WT> make_fin(tiled_epilogue<WT> const& e, int n)
 
 template <typename WT>
 void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha, WT* part, uint32_t* counters, tiled_x_map<WT> const& map,
-                  tiled_epilogue<WT> const* pending, tiled_ovl const* ovl)
+                  tiled_epilogue<WT> const* pending, tiled_ovl const* ovl, tiled_chunks const* chunks)
 {
   if (ovl) {  // overlapped with the previous iteration's phase 2 (tiled_ovl): fewer workgroups than CUs, own stream, polls before tile loads
     CGA_EXPECTS(t.n_items > 0 && t.n_static_chunks == 0 && pending == nullptr, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: overlapped phase 1 needs a dynamic-only schedule");
@@ -1836,6 +1837,11 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
   a.part      = part;
   a.alpha     = alpha;
   a.pmask = map.pmask; a.plog = map.plog; a.chunk = map.chunk; a.ncols = map.ncols;
+  if (chunks) {  // a launch over a subset of the plan's chunks (tiled_chunks): everything drawn dynamically from the caller's cursor
+    CGA_EXPECTS(pending == nullptr && chunks->cursor != nullptr && chunks->no_static != nullptr, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: phase-1 chunk subset");
+    if (chunks->n_chunks == 0) return;
+    a.chunk_begin = chunks->chunk_begin; a.n_chunks = chunks->n_chunks; a.n_static_chunks = 0; a.wg_static = chunks->no_static; a.counter = chunks->cursor;
+  }
   if (pending) a.fin = make_fin<WT>(*pending, tiled_fold_count(t, *pending));
   size_t const lds = std::max<size_t>(((size_t)t.T + (size_t)TP_WAVES * TP_STAGE) * sizeof(WT) + 64, 3 * TP_BLOCK * sizeof(double));
   bool const w     = a.weights != nullptr;
@@ -1844,9 +1850,9 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
   auto launch = [&](auto kernel, int slot) {
     if (!attr_done[slot]) { ensure_max_lds(kernel, (int)h.lds_per_block); attr_done[slot] = true; }
     timed_launch tl(h, "pagerank_spmv");
-    hipLaunchKernelGGL(kernel, t.n_wg, TP_BLOCK, lds, h.stream, a);
+    hipLaunchKernelGGL(kernel, chunks ? std::max(1, std::min(t.n_wg, chunks->n_chunks)) : t.n_wg, TP_BLOCK, lds, h.stream, a);
   };
-  if (dbg_calls > 0 && !w && sizeof(WT) == 4) {  // instrumented variant: per-workgroup wall time / tile loads to stderr
+  if (dbg_calls > 0 && !w && sizeof(WT) == 4 && !chunks) {  // instrumented variant: per-workgroup wall time / tile loads to stderr
     --dbg_calls;
     size_t const n = (size_t)t.n_wg * 2;
     dvec<unsigned long long> dbg(n);
@@ -1866,7 +1872,7 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
 }
 
 template <typename WT>
-void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters, tiled_ovl const* ovl)
+void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters, tiled_ovl const* ovl, tiled_range const* range)
 {
   p2_args<WT> a;
   a.part       = part;
@@ -1883,6 +1889,12 @@ void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled
   int grid = t.nI;
   int const n_const = e.cr.nI_act > 0 ? (int)((e.cr.n_cols + TP2_CONST_COLS - 1) / TP2_CONST_COLS) : 0;
   if (e.cr.nI_act > 0) grid = e.cr.nI_act + n_const;
+  if (range) {  // a part of the blocks (destination tiles first, then the tiled_const_rows blocks): [first, first + count)
+    CGA_EXPECTS(ovl == nullptr && range->first >= 0 && range->count >= 0 && range->first + range->count <= grid, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: phase-2 block range");
+    if (range->count == 0) return;
+    a.I0 = range->first;
+    grid = range->count;
+  }
   // batches of 8 slots in flight per thread: 1 when the kernel has the chip to itself (HBM-bound either way), 2 beside a phase 1
   char const* const env_nb = getenv("CUGRAPH_AMD_P2_BATCHES");  // (read per launch: tools/plan_sweep.py switches variants inside one process)
   int const nb_env = env_nb ? atoi(env_nb) : 0;
@@ -1936,8 +1948,8 @@ void tiled_scalars_from_ranks(handle_t const& h, tiled_epilogue<WT> const& e, vo
 }
 
 #define CGA_INSTANTIATE_TILED(WT)                                                                                                          \
-  template void tiled_phase1<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT, WT*, uint32_t*, tiled_x_map<WT> const&, tiled_epilogue<WT> const*, tiled_ovl const*); \
-  template void tiled_phase2<WT>(handle_t const&, tiled_csc_t const&, WT const*, tiled_epilogue<WT> const&, uint32_t*, tiled_ovl const*);                                  \
+  template void tiled_phase1<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT, WT*, uint32_t*, tiled_x_map<WT> const&, tiled_epilogue<WT> const*, tiled_ovl const*, tiled_chunks const*); \
+  template void tiled_phase2<WT>(handle_t const&, tiled_csc_t const&, WT const*, tiled_epilogue<WT> const&, uint32_t*, tiled_ovl const*, tiled_range const*);                                  \
   template void tiled_finish<WT>(handle_t const&, tiled_epilogue<WT> const&, int, double, hipStream_t);                                                           \
   template int tiled_prologue<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT const*, WT*, int64_t, double*, int32_t const*);          \
   template void tiled_scalars_from_ranks<WT>(handle_t const&, tiled_epilogue<WT> const&, void const*, size_t, size_t, int);

@@ -207,6 +207,20 @@ struct tiled_ovl {
                                    // tiled_const_rows, so the x of the coldest source tiles is ready first)
 };
 
+// Launches over a PART of the work (multi-GPU PageRank, DESIGN.md section 5: the x exchange in two chunks).  Phase 1's schedule is data -- a list
+// of chunks drawn through a cursor -- so a launch over any subset of the plan's chunks is the same kernel with another list; its partial sums
+// land in the slots they always land in.  Phase 2's workgroup = destination tile, so a launch over a block range is the same kernel with an
+// offset.  The results are those of the undivided launches, bit for bit.
+struct tiled_chunks {
+  int32_t const* chunk_begin{nullptr};  // [n_chunks][4] rows of tiled_csc_t::chunk_begin, any subset in any order
+  int n_chunks{0};
+  uint32_t* cursor{nullptr};            // 0 on entry (the caller rewinds it)
+  int32_t const* no_static{nullptr};    // [2 * n_wg] zeros: no workgroup owns a private chunk
+};
+struct tiled_range {
+  int first{0}, count{0};  // phase-2 blocks: destination tiles [0, nI or nI_act), then the tiled_const_rows blocks
+};
+
 // need[J] = number of phase-2 workgroups (destination tiles, plus the blocks of tiled_const_rows when `const_rows`) whose columns fall into source tile J
 std::vector<uint32_t> tiled_overlap_need(tiled_csc_t const& t, bool const_rows, int64_t c0, int64_t n_cols);
 
@@ -215,11 +229,12 @@ std::vector<uint32_t> tiled_overlap_need(tiled_csc_t const& t, bool const_rows, 
 // previous phase 2 have not been folded yet -- workgroup 0 does it first (saves a launch per iteration).
 template <typename WT>
 void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha, WT* part, uint32_t* counters, tiled_x_map<WT> const& map,
-                  tiled_epilogue<WT> const* pending, tiled_ovl const* ovl = nullptr);
+                  tiled_epilogue<WT> const* pending, tiled_ovl const* ovl = nullptr, tiled_chunks const* chunks = nullptr);
 
 // phase 2 + fused PageRank epilogue; leaves per-tile scalar partials in e.partials (fold them with the next phase 1 or tiled_finish)
 template <typename WT>
-void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters, tiled_ovl const* ovl = nullptr);
+void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters, tiled_ovl const* ovl = nullptr,
+                  tiled_range const* range = nullptr);
 
 // folds e.partials[0 .. n_partials) in a fixed order into e.scal (or e.totals).  init_prev >= 0: this is the fold of the
 // iteration-0 state (tiled_prologue visited every row); scal->base_prev becomes init_prev, the rows' initial value

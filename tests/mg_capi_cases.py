@@ -75,6 +75,8 @@ def ppr_inputs(scale):
 
 def run(what, cg, h, comm, rank, size, outdir, args):
     out = {}
+    if os.environ.get("CUGRAPH_AMD_TEST_HOT_TILE"):  # small source tiles: a rank's gather window then spans many of them (the two-chunk exchange splits phase 1 by source tile)
+        h.set_pagerank_hot_tile(int(os.environ["CUGRAPH_AMD_TEST_HOT_TILE"]))
     if what == "pagerank":
         scale, max_iter, eps, weighted = int(args[0]), int(args[1]), float(args[2]), args[3] == "w"
         (s, d), first = rmat_slice(scale, rank, size)
