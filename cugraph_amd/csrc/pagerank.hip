@@ -2015,8 +2015,8 @@ struct pagerank_mgc_plan : pagerank_plan_base {
   void setup_overlap()
   {
     for (int r = 0; r < P; ++r) biggest_all = std::max(biggest_all, part->send_first[r + 1] - part->send_first[r]);
-    char const* const env = getenv("CUGRAPH_AMD_MG_OVERLAP");  // per cent of the destination tiles that count as hot; 0 = one-chunk exchange
-    int64_t pct = direct ? 0 : (env ? atoi(env) : 30);
+    char const* const env = getenv("CUGRAPH_AMD_MG_OVERLAP");  // per cent of the destination tiles that count as hot (30 = the split DESIGN.md section 5 works through); 0 / unset = one-chunk exchange
+    int64_t pct = direct ? 0 : (env ? atoi(env) : 0);  // default: one chunk (measured, ranks on one GPU: the two launches per phase cost more than there is wire to hide)
     if (pct < 0 || pct >= 100) pct = 0;
     std::vector<int64_t> all((size_t)P);
     c.host_allgather(&pct, sizeof(pct), all.data());
@@ -2064,6 +2064,26 @@ struct pagerank_mgc_plan : pagerank_plan_base {
       std::vector<int32_t>& dst = hot[cb[(size_t)4 * k + 3]] ? ca : cbb;
       dst.insert(dst.end(), cb.begin() + (size_t)4 * k, cb.begin() + (size_t)4 * k + 4);
     }
+    // Each of the two launches ends on its own: the plan's list closes with small chunks of the coldest tiles so that the workgroups finish
+    // together (spmv_tiled.hpp: TP_TAIL_FRAC), and all of those land in part B.  The last quarter of each list's work items is therefore
+    // handed out in pieces of four items (a chunk is a range of items of one source tile: any cut is a valid chunk).
+    auto smooth_tail = [](std::vector<int32_t>& list) {
+      int64_t items = 0, seen = 0;
+      for (size_t k = 0; k + 3 < list.size(); k += 4) items += list[k + 2] - list[k + 1];
+      std::vector<int32_t> out;
+      for (size_t k = 0; k + 3 < list.size(); k += 4) {
+        int32_t const first = list[k + 1], end = list[k + 2], tile = list[k + 3];
+        for (int32_t i = first; i < end;) {
+          int32_t const piece = seen + (i - first) >= items - items / 4 ? 4 : end - i;
+          int32_t const e2    = std::min(end, i + piece);
+          out.insert(out.end(), {0, i, e2, tile});
+          i = e2;
+        }
+        seen += end - first;
+      }
+      list.swap(out);
+    };
+    if (!getenv("CUGRAPH_AMD_MG_OVERLAP_PLAIN_TAIL")) { smooth_tail(ca); smooth_tail(cbb); }
     n_chunksA = (int)(ca.size() / 4);
     n_chunksB = (int)(cbb.size() / 4);
     if (ca.empty()) ca.assign(4, 0);

@@ -418,10 +418,10 @@ def test_mg_capi_extract_paths(orc, tmp_path, world, wide):
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,weighted,eps", [(1, "-", 0.0), (2, "-", 0.0), (3, "w", 0.0), (4, "-", 1e-7)])
 def test_mg_capi_pagerank_two_chunk_exchange_is_bit_identical(orc, tmp_path, world, weighted, eps):
-    """The x exchange of the multi-GPU PageRank in two chunks (default): phase 2 over the hot destination tiles, their x
+    """The x exchange of the multi-GPU PageRank in two chunks (CUGRAPH_AMD_MG_OVERLAP=<per cent of hot tiles>): phase 2 over the hot destination tiles, their x
     pushed on a side stream while the cold tiles are reduced, phase 1 of the receiver over the source tiles the first chunk filled while the
     second is on the wire.  Same kernels over parts of the same work lists: the vector must equal the one-chunk exchange's
-    (CUGRAPH_AMD_MG_OVERLAP=0) BIT FOR BIT, with every split position (10 / 30 / 70 per cent of the destination tiles), weighted, with the
+    (the default) BIT FOR BIT, with every split position (10 / 30 / 70 per cent of the destination tiles), weighted, with the
     convergence test on (a fold + read-back between the two phase-1 launches), and for one rank pushing to itself.  1024-column source tiles so
     that a rank's window spans dozens of them; the graph is large enough for several destination tiles per rank."""
     from test_mg import truth
@@ -445,7 +445,7 @@ def test_mg_capi_pagerank_two_chunk_exchange_is_bit_identical(orc, tmp_path, wor
             assert all(split), run_ranks.last_outputs[0][-2000:]
             for m in split:
                 ia, nt, sa, sn, ca, cb = (int(x) for x in m.groups())
-                assert 0 < ia < nt and 0 < sa < sn and ca > 0 and cb > 0, m.group(0)
+                assert 0 < ia < nt and 0 < sa < sn and cb > 0 and (ca > 0 or pct == "10"), m.group(0)  # (10 %: the hot prefix may be shorter than a source tile)
     for pct in pcts[1:]:
         for a, b in zip(got["0"], got[pct]):
             assert np.array_equal(a["v"], b["v"]) and np.array_equal(a["x"].view(np.uint32), b["x"].view(np.uint32)), pct
