@@ -5,6 +5,7 @@
 
 #include <fcntl.h>
 #include <sched.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -426,40 +427,86 @@ static std::unique_ptr<comm_t> attach_session(char const* session, int rank, int
   if (char const* e = getenv("CUGRAPH_AMD_COMM_TIMEOUT_S")) c->timeout_s = std::max(1.0, atof(e));
   std::string const name = shm_name(session);
   double const t0        = now_s();
+  // A crashed job may have left a segment of this name behind.  Rank 0 unlinks and re-creates it; a rank that starts BEFORE rank 0 must not
+  // settle on the old one: it trusts a segment only while the process that created it is alive (pid0), and while it waits in the first
+  // barrier it keeps checking that the name still leads to the file it mapped -- if rank 0 has re-created the session meanwhile, it moves over.
+  auto still_linked = [&](int fd) {
+    struct stat a, b;
+    std::string const path = "/dev/shm" + name;
+    return fstat(fd, &a) == 0 && stat(path.c_str(), &b) == 0 && a.st_ino == b.st_ino && a.st_dev == b.st_dev;
+  };
   if (rank == 0) {
     shm_unlink(name.c_str());  // a stale segment of a crashed job with the same session name
     c->shm_fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
     CGA_EXPECTS(c->shm_fd >= 0, CUGRAPH_UNKNOWN_ERROR, "communicator: shm_open(" + name + ") failed: " + strerror(errno));
     CGA_EXPECTS(ftruncate(c->shm_fd, sizeof(comm_shm_t)) == 0, CUGRAPH_UNKNOWN_ERROR, "communicator: ftruncate failed");
-  } else {
-    for (;;) {
-      c->shm_fd = shm_open(name.c_str(), O_RDWR, 0600);
-      if (c->shm_fd >= 0) {
-        struct stat st;
-        if (fstat(c->shm_fd, &st) == 0 && (size_t)st.st_size >= sizeof(comm_shm_t)) break;
-        close(c->shm_fd);
-        c->shm_fd = -1;
-      }
-      CGA_EXPECTS(now_s() - t0 < c->timeout_s, CUGRAPH_UNKNOWN_ERROR, "communicator: rank 0 never created the session " + name);
-      usleep(2000);
-    }
-  }
-  void* m = mmap(nullptr, sizeof(comm_shm_t), PROT_READ | PROT_WRITE, MAP_SHARED, c->shm_fd, 0);
-  CGA_EXPECTS(m != MAP_FAILED, CUGRAPH_UNKNOWN_ERROR, "communicator: mmap failed");
-  c->shm = static_cast<comm_shm_t*>(m);
-  if (rank == 0) {
+    void* m = mmap(nullptr, sizeof(comm_shm_t), PROT_READ | PROT_WRITE, MAP_SHARED, c->shm_fd, 0);
+    CGA_EXPECTS(m != MAP_FAILED, CUGRAPH_UNKNOWN_ERROR, "communicator: mmap failed");
+    c->shm = static_cast<comm_shm_t*>(m);
     std::memset(m, 0, sizeof(comm_shm_t));
     c->shm->size = (uint32_t)size;
+    c->shm->pid0 = (uint32_t)getpid();
     c->shm->ready.store(kCommMagic, std::memory_order_release);
-  } else {
+    c->shm->attached.fetch_add(1);
+    c->host_barrier();
+    return c;
+  }
+  for (;;) {
+    auto expired = [&] { return now_s() - t0 >= c->timeout_s; };
+    c->shm_fd = shm_open(name.c_str(), O_RDWR, 0600);
+    if (c->shm_fd >= 0) {
+      struct stat st;
+      if (!(fstat(c->shm_fd, &st) == 0 && (size_t)st.st_size >= sizeof(comm_shm_t))) { close(c->shm_fd); c->shm_fd = -1; }
+    }
+    if (c->shm_fd < 0) {
+      CGA_EXPECTS(!expired(), CUGRAPH_UNKNOWN_ERROR, "communicator: rank 0 never created the session " + name);
+      usleep(2000);
+      continue;
+    }
+    void* m = mmap(nullptr, sizeof(comm_shm_t), PROT_READ | PROT_WRITE, MAP_SHARED, c->shm_fd, 0);
+    CGA_EXPECTS(m != MAP_FAILED, CUGRAPH_UNKNOWN_ERROR, "communicator: mmap failed");
+    c->shm = static_cast<comm_shm_t*>(m);
+    auto drop = [&] { munmap(c->shm, sizeof(comm_shm_t)); c->shm = nullptr; close(c->shm_fd); c->shm_fd = -1; };
+    bool stale = false;
     while (c->shm->ready.load(std::memory_order_acquire) != kCommMagic) {
-      CGA_EXPECTS(now_s() - t0 < c->timeout_s, CUGRAPH_UNKNOWN_ERROR, "communicator: session " + name + " was never initialised");
+      if (!still_linked(c->shm_fd)) { stale = true; break; }
+      CGA_EXPECTS(!expired(), CUGRAPH_UNKNOWN_ERROR, "communicator: session " + name + " was never initialised");
       usleep(1000);
     }
+    if (!stale) {
+      uint32_t const creator = c->shm->pid0;
+      stale = creator == 0 || (kill((pid_t)creator, 0) != 0 && errno == ESRCH);  // the creator is gone: a crashed job's segment
+    }
+    if (stale) {
+      drop();
+      CGA_EXPECTS(!expired(), CUGRAPH_UNKNOWN_ERROR, "communicator: only a stale segment of the session " + name + " was found (rank 0 never re-created it)");
+      usleep(5000);
+      continue;
+    }
     CGA_EXPECTS(c->shm->size == (uint32_t)size, CUGRAPH_INVALID_INPUT, "communicator: ranks disagree on the communicator size");
+    c->shm->attached.fetch_add(1);
+    // the first barrier, with the freshness check inside its wait
+    uint32_t const gen = c->shm->bar_gen.load(std::memory_order_acquire);
+    if (c->shm->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)size) {
+      c->shm->bar_count.store(0, std::memory_order_relaxed);
+      c->shm->bar_gen.fetch_add(1, std::memory_order_release);
+      return c;
+    }
+    int spins = 0;
+    while (c->shm->bar_gen.load(std::memory_order_acquire) == gen) {
+      if (c->shm->abort_flag.load(std::memory_order_relaxed)) throw api_error(CUGRAPH_UNKNOWN_ERROR, "communicator: a peer aborted");
+      if (++spins > 200) sched_yield();
+      if ((spins & 1023) == 0) {
+        if (!still_linked(c->shm_fd)) { stale = true; break; }  // rank 0 has re-created the session under our feet
+        if (expired()) {
+          c->shm->abort_flag.store(1, std::memory_order_relaxed);
+          throw api_error(CUGRAPH_UNKNOWN_ERROR, "communicator: host barrier timed out on rank " + std::to_string(rank) + " (a peer is missing or has failed)");
+        }
+      }
+    }
+    if (!stale) return c;
+    drop();
   }
-  c->shm->attached.fetch_add(1);
-  c->host_barrier();
   return c;
 }
 

@@ -37,7 +37,8 @@ struct comm_shm_t {  // lives in the POSIX shm segment
   std::atomic<uint32_t> bar_gen;
   std::atomic<uint32_t> abort_flag;
   std::atomic<uint32_t> attached;
-  uint32_t pad_[10];
+  uint32_t pid0;  // process id of the rank 0 that created the segment: a segment whose creator is gone is a crashed job's (comm.hip: attach_session)
+  uint32_t pad_[9];
   unsigned char slots[kCommMaxRanks][kCommSlotBytes];
 };
 

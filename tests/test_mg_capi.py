@@ -63,6 +63,43 @@ def test_comm_host_bootstrap(world):
     assert not Path("/dev/shm/cga_" + session).exists()
 
 
+@pytest.mark.parametrize("creator", ["dead", "alive"])
+def test_comm_host_bootstrap_survives_a_stale_segment(creator):
+    """A crashed job left a segment of the same session name behind (ready, one arrival short of a full barrier), and this time the other ranks
+    start BEFORE rank 0 (advisor finding, round 4).  They must not settle on the old segment: its creator is gone (dead pid), or -- the pid
+    has been recycled and looks alive -- rank 0 re-creates the session under their feet and they move over when the name no longer leads to
+    the file they mapped.  No GPU involved."""
+    import struct
+    import time
+
+    world = 3
+    session = f"s{uuid.uuid4().hex[:12]}"
+    path = Path("/dev/shm/cga_" + session)
+    if creator == "dead":
+        p = subprocess.Popen([sys.executable, "-c", "pass"])
+        p.wait()
+        pid0, arrived = p.pid, world - 1
+    else:
+        pid0, arrived = os.getpid(), 0
+    header = struct.pack("<16I", 0x43474331, world, arrived, 0, 0, world - 1, pid0, *([0] * 9))  # comm_shm_t: ready, size, bar_count, bar_gen, abort, attached, pid0
+    path.write_bytes(header + bytes(64 * 4096))
+    code = ("import ctypes as C, sys; from cugraph_amd import _capi as capi; l = capi.lib(); e = C.c_void_p(); "
+            "rc = l.cugraph_amd_comm_host_selftest(sys.argv[1].encode(), int(sys.argv[2]), int(sys.argv[3]), 50, C.byref(e)); "
+            "print(l.cugraph_error_message(e) if rc else 'ok'); sys.exit(rc)")
+    env = dict(os.environ, CUGRAPH_AMD_COMM_TIMEOUT_S="30")
+    start = lambda r: subprocess.Popen([sys.executable, "-c", code, session, str(r), str(world)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)  # noqa: E731
+    try:
+        procs = {r: start(r) for r in range(1, world)}
+        time.sleep(1.5)  # the late rank 0
+        procs[0] = start(0)
+        outs = {r: p.communicate(timeout=120)[0] for r, p in procs.items()}
+        for r, p in procs.items():
+            assert p.returncode == 0, (r, outs[r][-2000:])
+    finally:
+        if path.exists():
+            path.unlink()
+
+
 def _assemble(tmp_path, world, nv):
     out = np.full(nv, np.nan, np.float64)
     for r in range(world):
