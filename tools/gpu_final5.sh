@@ -34,6 +34,16 @@ one bench.py --gpus 2 --scale 24 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/
 one bench.py --gpus 2 --scale 26 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null > "$O/${TAG}_ipc1_s26.json"
 for w in 2 8; do CUGRAPH_AMD_MG_TEST_SINGLE_GPU=1 timeout 600 python bench.py --gpus $w --scale 24 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null > "$O/${TAG}_ipc${w}_s24.json"; done
 timeout 600 python bench_traversal.py --partitioned --transport ipc --scale 24 --weights int --roots 16 2>/dev/null | grep "^{" > "$O/${TAG}_part_ipc1_s24.json"
+# the x exchange in two chunks (opt-in, CUGRAPH_AMD_MG_OVERLAP): one rank pushing to ITSELF at RMAT-26, one chunk against two; then a kernel trace of
+# the two-chunk run (one process, no launcher) with the push kernels set against phase 2
+for ov in 0 30; do CUGRAPH_AMD_MG_OVERLAP=$ov CUGRAPH_AMD_MG_PUSH_SELF=1 one bench.py --gpus 2 --scale 26 --steps 20 --warmup 3 --no-cpu-baseline --no-check 2>/dev/null > "$O/${TAG}_ipc1self_s26_ov$ov.json"; done
+( cd /tmp && export TMPDIR=/tmp
+RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29917 CUGRAPH_AMD_MG_OVERLAP=30 CUGRAPH_AMD_MG_PUSH_SELF=1 timeout 300 rocprofv3 --kernel-trace --stats -d "$O/prof_$TAG/mgovl" -o run -- \
+  python "$R/bench.py" --gpus 2 --scale 24 --steps 10 --warmup 2 --no-cpu-baseline --no-check > "$O/prof_${TAG}_mgovl.log" 2>&1
+python "$R/tools/rocpd_summary.py" "$O/prof_$TAG/mgovl" 2>&1 | head -14 > "$O/${TAG}_mg_two_chunk_rocprofv3_summary.txt"
+python "$R/tools/rocpd_summary.py" --overlap "k_mgc_push" "k_tiled_phase2" "$O/prof_$TAG/mgovl" 2>&1 | head -14 >> "$O/${TAG}_mg_two_chunk_rocprofv3_summary.txt"
+find "$O/prof_$TAG" -name "*.db" -delete
+tail -6 "$O/${TAG}_mg_two_chunk_rocprofv3_summary.txt" | cut -c1-160 )
 CUGRAPH_AMD_MG_TEST_SINGLE_GPU=1 timeout 900 python bench_louvain.py --gpus 2 --scale 22 --repeats 2 --out "$O/${TAG}_louvain_s22_ranks2.json" > /dev/null 2>&1
 timeout 900 python bench_traversal.py --scale 26 --symmetric --roots 16 --no-sssp --no-cpu-baseline --out "$O/${TAG}_traversal_s26_sym.json" > /dev/null 2>&1
 python - <<'PY'
