@@ -283,7 +283,8 @@ class MGGraph(SGGraph):
     """graphs.pyx:357-700 MGGraph: this rank's slice of the edge list, as one array per column or as `num_arrays` lists of arrays
     (cugraph_graph_create_with_times_mg concatenates them).  On a ResourceHandle created on a Comm the call is COLLECTIVE: the slices of
     all ranks become one partitioned graph (csrc/mg_graph.hip) that pagerank / personalized_pagerank / bfs / sssp / louvain / degrees /
-    has_vertex accept, each rank getting its share of the vertices back.  On a plain handle (one rank, no communicator) the graph is built as SGGraph builds it, always renumbered
+    has_vertex / bfs_extract_paths / decompress_to_edgelist accept, each rank getting its share of the vertices (or of the edge list) back; vertex
+    ids may be int32 or int64 (the ranks agree on one sorted id list), edge ids / edge type ids stay with the rank's slice.  On a plain handle (one rank, no communicator) the graph is built as SGGraph builds it, always renumbered
     (graph_mg.cpp:214)."""
 
     def __init__(self, resource_handle, graph_properties, src_array, dst_array, weight_array=None, store_transposed=False,
