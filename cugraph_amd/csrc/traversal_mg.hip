@@ -627,42 +627,81 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_expand(cugraph_amd
   });
 }
 
+// ---- the launch half and the host half of apply / bottom_up.  The exported calls below run one after the other with a read-back in
+// between; the library's own BFS driver (traversal_mg_driver.hip) ships the level's counters to every rank FROM THE DEVICE between the two
+// halves (mg_plan_counters) and adopts what came back, so a level costs one host synchronisation less.
+namespace cga {
+void mg_plan_apply_launch(cugraph_amd_traversal_mg_plan_t* plan, int32_t const* recv, size_t n_tuples, uint32_t level)
+{
+  traversal_mg_plan& p = TP(plan);
+  handle_t const& h    = *p.h;
+  HIP_TRY(hipSetDevice(h.device));
+  if (p.mode == 1 && p.n_local > 0) {  // apply appends behind what expand put there
+    counters_t z{};
+    z.n_next = (uint32_t)p.n_local;
+    std::memcpy(h.pinned, &z, sizeof(z));
+    HIP_TRY(hipMemcpyAsync(p.cnt.data(), h.pinned, sizeof(z), hipMemcpyHostToDevice, h.stream));
+  } else {
+    HIP_TRY(hipMemsetAsync(p.cnt.data(), 0, sizeof(counters_t), h.stream));
+  }
+  if (p.mode == 0) HIP_TRY(hipMemsetAsync(p.newfront.data(), 0, p.L / 8, h.stream));
+  if (n_tuples) {
+    int const g = (int)((n_tuples + 255) / 256);
+    if (p.mode == 0)
+      hipLaunchKernelGGL(k_mg_bfs_apply, g, 256, 0, h.stream, recv, n_tuples, (int32_t)level, p.dist.data(), p.with_pred ? p.pred.data() : (int32_t*)nullptr,
+                         p.q_next, p.newfront.data(), p.cnt.data(), p.offsets, p.in_offsets);
+    else
+      hipLaunchKernelGGL(k_mg_sssp_apply, g, 256, 0, h.stream, recv, n_tuples, p.round, p.st.data(), p.mark.data(), p.q_next, p.cnt.data(), float_bits(p.hi), p.win,
+                         p.far_mark.data(), p.q_far.data(), p.far_count.data());
+  }
+}
+void mg_plan_bottom_up_launch(cugraph_amd_traversal_mg_plan_t* plan, uint32_t const* front, uint32_t level)
+{
+  traversal_mg_plan& p = TP(plan);
+  CGA_EXPECTS(p.mode == 0 && p.in_offsets != nullptr, CUGRAPH_INVALID_INPUT, "bottom-up levels were not enabled (cugraph_amd_traversal_mg_plan_set_bottom_up)");
+  handle_t const& h = *p.h;
+  HIP_TRY(hipSetDevice(h.device));
+  HIP_TRY(hipMemsetAsync(p.cnt.data(), 0, sizeof(counters_t), h.stream));
+  HIP_TRY(hipMemsetAsync(p.newfront.data(), 0, p.L / 8, h.stream));
+  int64_t const nv = (int64_t)p.n_rows;
+  if (nv > 0) {
+    int const grid = (int)std::max<int64_t>(1, std::min<int64_t>(((nv + 63) / 64 + TV_WAVES * BU_GROUPS - 1) / (TV_WAVES * BU_GROUPS), (int64_t)h.num_cus * 16));
+    timed_launch tl(h, "bfs_bottom_up");
+    hipLaunchKernelGGL(k_bfs_bottom_up<false>, grid, TV_BLOCK, 0, h.stream, p.in_offsets, p.in_indices, p.offsets, nv, p.seen.data() + (size_t)p.rank * (p.L / 32),
+                       front, p.newfront.data(), p.dist.data(), p.with_pred ? p.pred.data() : (int32_t*)nullptr, (int32_t)level, p.cnt.data(),
+                       (unsigned long long*)nullptr, p.ext_of_g);
+    // the next level may run top-down: its queue
+    hipLaunchKernelGGL(k_bfs_bitmap_to_queue, grid_for((int64_t)(p.L / 32), TV_BLOCK, 512), TV_BLOCK, 0, h.stream, (uint32_t const*)p.newfront.data(), (int64_t)(p.L / 32),
+                       p.q_next, p.cnt.data());
+  }
+}
+// the level's counters on the device (counters_t: cursors + replica lines, not folded)
+void const* mg_plan_counters(cugraph_amd_traversal_mg_plan_t* plan) { return TP(plan).cnt.data(); }
+// the host half: the next local frontier is what the launch half queued (n_next rows), with these degree sums
+void mg_plan_adopt_level(cugraph_amd_traversal_mg_plan_t* plan, size_t n_next, unsigned long long out_edges, unsigned long long in_edges)
+{
+  traversal_mg_plan& p = TP(plan);
+  std::swap(p.q_cur, p.q_next);
+  p.n_frontier = n_next;
+  p.n_local    = 0;
+  p.last_out   = out_edges;
+  p.last_in    = in_edges;
+}
+}  // namespace cga
+
 /* Folds n_tuples received candidates into the local rows; n_next = size of the next local frontier. */
 extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_apply(cugraph_amd_traversal_mg_plan_t* plan, const int32_t* recv, size_t n_tuples,
                                                                     uint32_t level, size_t* n_next, cugraph_error_t** error)
 {
   return guarded(error, [&] {
     CGA_EXPECTS(plan != nullptr && n_next != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
+    mg_plan_apply_launch(plan, recv, n_tuples, level);
     traversal_mg_plan& p = TP(plan);
-    handle_t const& h    = *p.h;
-    HIP_TRY(hipSetDevice(h.device));
-    if (p.mode == 1 && p.n_local > 0) {  // apply appends behind what expand put there
-      counters_t z{};
-      z.n_next = (uint32_t)p.n_local;
-      std::memcpy(h.pinned, &z, sizeof(z));
-      HIP_TRY(hipMemcpyAsync(p.cnt.data(), h.pinned, sizeof(z), hipMemcpyHostToDevice, h.stream));
-    } else {
-      HIP_TRY(hipMemsetAsync(p.cnt.data(), 0, sizeof(counters_t), h.stream));
-    }
-    if (p.mode == 0) HIP_TRY(hipMemsetAsync(p.newfront.data(), 0, p.L / 8, h.stream));
-    if (n_tuples) {
-      int const g = (int)((n_tuples + 255) / 256);
-      if (p.mode == 0)
-        hipLaunchKernelGGL(k_mg_bfs_apply, g, 256, 0, h.stream, recv, n_tuples, (int32_t)level, p.dist.data(), p.with_pred ? p.pred.data() : (int32_t*)nullptr,
-                           p.q_next, p.newfront.data(), p.cnt.data(), p.offsets, p.in_offsets);
-      else
-        hipLaunchKernelGGL(k_mg_sssp_apply, g, 256, 0, h.stream, recv, n_tuples, p.round, p.st.data(), p.mark.data(), p.q_next, p.cnt.data(), float_bits(p.hi), p.win,
-                           p.far_mark.data(), p.q_far.data(), p.far_count.data());
-    }
     counters_t c{};
-    h.read_back(&c, p.cnt.data(), 1);
+    p.h->read_back(&c, p.cnt.data(), 1);
     c.fold();
-    std::swap(p.q_cur, p.q_next);
-    p.n_frontier = c.n_next;
-    p.n_local    = 0;
-    p.last_out   = c.out_edges;
-    p.last_in    = c.in_edges;
-    *n_next      = c.n_next;
+    mg_plan_adopt_level(plan, c.n_next, c.out_edges, c.in_edges);
+    *n_next = c.n_next;
   });
 }
 
@@ -754,32 +793,14 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_bottom_up(cugraph_
 {
   return guarded(error, [&] {
     CGA_EXPECTS(plan != nullptr && front != nullptr && n_found != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
+    mg_plan_bottom_up_launch(plan, front, level);
     traversal_mg_plan& p = TP(plan);
-    CGA_EXPECTS(p.mode == 0 && p.in_offsets != nullptr, CUGRAPH_INVALID_INPUT, "bottom-up levels were not enabled (cugraph_amd_traversal_mg_plan_set_bottom_up)");
-    handle_t const& h = *p.h;
-    HIP_TRY(hipSetDevice(h.device));
-    HIP_TRY(hipMemsetAsync(p.cnt.data(), 0, sizeof(counters_t), h.stream));
-    HIP_TRY(hipMemsetAsync(p.newfront.data(), 0, p.L / 8, h.stream));
-    int64_t const nv = (int64_t)p.n_rows;
-    if (nv > 0) {
-      int const grid = (int)std::max<int64_t>(1, std::min<int64_t>(((nv + 63) / 64 + TV_WAVES * BU_GROUPS - 1) / (TV_WAVES * BU_GROUPS), (int64_t)h.num_cus * 16));
-      timed_launch tl(h, "bfs_bottom_up");
-      hipLaunchKernelGGL(k_bfs_bottom_up<false>, grid, TV_BLOCK, 0, h.stream, p.in_offsets, p.in_indices, p.offsets, nv, p.seen.data() + (size_t)p.rank * (p.L / 32),
-                         front, p.newfront.data(), p.dist.data(), p.with_pred ? p.pred.data() : (int32_t*)nullptr, (int32_t)level, p.cnt.data(),
-                         (unsigned long long*)nullptr, p.ext_of_g);
-      // the next level may run top-down: its queue
-      hipLaunchKernelGGL(k_bfs_bitmap_to_queue, grid_for((int64_t)(p.L / 32), TV_BLOCK, 512), TV_BLOCK, 0, h.stream, (uint32_t const*)p.newfront.data(), (int64_t)(p.L / 32),
-                         p.q_next, p.cnt.data());
-    }
     counters_t c{};
-    h.read_back(&c, p.cnt.data(), 1);
+    p.h->read_back(&c, p.cnt.data(), 1);
     c.fold();  // (the kernel counts its discoveries in the replica lines: folded into n_next)
     CGA_EXPECTS(c.n_next == c.n_big, CUGRAPH_UNKNOWN_ERROR, "bottom-up level: discoveries and queue length differ");
-    std::swap(p.q_cur, p.q_next);
-    p.n_frontier = c.n_next;
-    p.last_out   = c.out_edges;
-    p.last_in    = c.in_edges;
-    *n_found     = c.n_next;
+    mg_plan_adopt_level(plan, c.n_next, c.out_edges, c.in_edges);
+    *n_found = c.n_next;
   });
 }
 

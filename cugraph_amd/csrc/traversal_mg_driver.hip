@@ -8,12 +8,19 @@
 // prims/transform_reduce_if_v_frontier_outgoing_e_by_dst.cuh:981-1074 (what cugraph_amd/mg_traversal.py does over torch.distributed).
 #include "comm.hpp"
 #include "mg_graph.hpp"
+#include "traversal_common.hpp"
 
 #include <algorithm>
 #include <cfloat>
 #include <cstring>
 
 namespace cga {
+
+// traversal_mg.hip: the launch half and the host half of the plan's apply / bottom_up (the exported calls synchronise in between)
+void mg_plan_apply_launch(cugraph_amd_traversal_mg_plan_t* plan, int32_t const* recv, size_t n_tuples, uint32_t level);
+void mg_plan_bottom_up_launch(cugraph_amd_traversal_mg_plan_t* plan, uint32_t const* front, uint32_t level);
+void const* mg_plan_counters(cugraph_amd_traversal_mg_plan_t* plan);
+void mg_plan_adopt_level(cugraph_amd_traversal_mg_plan_t* plan, size_t n_next, unsigned long long out_edges, unsigned long long in_edges);
 
 namespace {
 
@@ -51,6 +58,24 @@ __global__ void k_put_stats(unsigned long long* const* peer_s, int rank, int P, 
   if (r < P) {
     unsigned long long* d = peer_s[r] + 4 * rank;
     d[0] = a; d[1] = b; d[2] = c; d[3] = 0;
+  }
+}
+// the same from the level's device counters (one wavefront folds the replica lines: counters_t::fold without the trip to the host);
+// the fourth word carries the length of the queue the level wrote (a bottom-up level's cross-check)
+__global__ void k_put_stats_dev(unsigned long long* const* peer_s, int rank, int P, counters_t const* cnt)
+{
+  int const lane = threadIdx.x;
+  unsigned long long found = 0, out = 0, in = 0;
+  if (lane < CNT_REPLICAS) { found = cnt->rep[lane].n_found; out = cnt->rep[lane].out_edges; in = cnt->rep[lane].in_edges; }
+  for (int o = 32; o; o >>= 1) {
+    found += (unsigned long long)__shfl_xor((long long)found, o);
+    out   += (unsigned long long)__shfl_xor((long long)out, o);
+    in    += (unsigned long long)__shfl_xor((long long)in, o);
+  }
+  found += cnt->n_next; out += cnt->out_edges; in += cnt->in_edges;
+  if (lane < P) {
+    unsigned long long* d = peer_s[lane] + 4 * rank;
+    d[0] = found; d[1] = out; d[2] = in; d[3] = cnt->n_big;
   }
 }
 
@@ -153,7 +178,8 @@ size_t exchange_tuples(handle_t const& h, mg_traversal_run_t& r, int P, int me, 
 struct level_stats_t { unsigned long long n, out_sum, in_sum; };
 
 // BFS: every rank's new-frontier bits + (discoveries, out-degree sum, in-degree sum) -> every rank; merges the bits into the visited set
-level_stats_t share_frontier(handle_t const& h, mg_traversal_run_t& r, mg_traversal_part_t const& t, int b, level_stats_t mine)
+level_stats_t share_frontier(handle_t const& h, mg_traversal_run_t& r, mg_traversal_part_t const& t, int b, level_stats_t mine, counters_t const* dev_counters = nullptr,
+                             unsigned long long* own = nullptr /*[4]: this rank's (discoveries, out sum, in sum, queue length) as shipped*/)
 {
   comm_t& c   = *r.c;
   int const P = t.P, me = t.rank;
@@ -165,7 +191,8 @@ level_stats_t share_frontier(handle_t const& h, mg_traversal_run_t& r, mg_traver
   for (int k = 0; k < P; ++k) { d.dst[k] = r.bwin[b]->at<uint32_t>(k) + (int64_t)me * W; d.src[k] = bits; d.words[k] = W; }
   d.n = P;
   c.push_multi(h.stream, d);
-  hipLaunchKernelGGL(k_put_stats, 1, 64, 0, h.stream, (unsigned long long* const*)r.d_peer_s[b].data(), me, P, mine.n, mine.out_sum, mine.in_sum);
+  if (dev_counters) hipLaunchKernelGGL(k_put_stats_dev, 1, 64, 0, h.stream, (unsigned long long* const*)r.d_peer_s[b].data(), me, P, dev_counters);
+  else hipLaunchKernelGGL(k_put_stats, 1, 64, 0, h.stream, (unsigned long long* const*)r.d_peer_s[b].data(), me, P, mine.n, mine.out_sum, mine.in_sum);
   c.wait(h.stream, r.channel, c.signal(h.stream, r.channel));
   ck(cugraph_amd_traversal_mg_plan_merge_visited(r.plan, static_cast<uint32_t const*>(r.bwin[b]->local), &err), err, "merge visited");  // (no synchronisation: keep_buffers)
   std::vector<unsigned long long> all((size_t)P * 4);
@@ -175,6 +202,7 @@ level_stats_t share_frontier(handle_t const& h, mg_traversal_run_t& r, mg_traver
   c.check("multi-GPU BFS level");
   level_stats_t tot{0, 0, 0};
   for (int k = 0; k < P; ++k) { tot.n += all[4 * k]; tot.out_sum += all[4 * k + 1]; tot.in_sum += all[4 * k + 2]; }
+  if (own) std::memcpy(own, all.data() + (size_t)4 * me, 4 * sizeof(unsigned long long));
   return tot;
 }
 
@@ -295,19 +323,22 @@ paths_result_t* mg_run_bfs(handle_t& h, graph_t& g, device_array_view_t const* s
       if (force && std::string(force) == "bottomup") bottom_up = true;
       if (force && std::string(force) == "topdown") bottom_up = false;
     }
-    size_t n_next = 0;
+    // the level's kernels are launched, its counters travel to every rank from the device together with the frontier bits, and the ONE host
+    // synchronisation of share_frontier brings back everybody's -- this rank's own included (round 5: the plan's exported apply / bottom_up
+    // read them back first, a second synchronisation per level)
     if (bottom_up) {
-      ck(cugraph_amd_traversal_mg_plan_bottom_up(r.plan, static_cast<uint32_t const*>(r.bwin[(level - 1) & 1]->local), (uint32_t)level, &n_next, &err), err, "bottom_up");
+      mg_plan_bottom_up_launch(r.plan, static_cast<uint32_t const*>(r.bwin[(level - 1) & 1]->local), (uint32_t)level);
       ++bu_levels;
     } else {
       size_t counts[kCommMaxRanks];
       ck(cugraph_amd_traversal_mg_plan_expand(r.plan, counts, &err), err, "expand");
       size_t const got = exchange_tuples(h, r, P, me, counts);
-      ck(cugraph_amd_traversal_mg_plan_apply(r.plan, static_cast<int32_t const*>(r.twin->local), got, (uint32_t)level, &n_next, &err), err, "apply");
+      mg_plan_apply_launch(r.plan, static_cast<int32_t const*>(r.twin->local), got, (uint32_t)level);
     }
-    unsigned long long o_sum = 0, i_sum = 0;
-    if (bu_ok) ck(cugraph_amd_traversal_mg_plan_last_degree_sums(r.plan, &o_sum, &i_sum, &err), err, "degree sums");
-    level_stats_t const tot = share_frontier(h, r, t, (int)(level & 1), level_stats_t{(unsigned long long)n_next, o_sum, i_sum});
+    unsigned long long own[4] = {0, 0, 0, 0};
+    level_stats_t const tot = share_frontier(h, r, t, (int)(level & 1), level_stats_t{0, 0, 0}, static_cast<counters_t const*>(mg_plan_counters(r.plan)), own);
+    if (bottom_up) CGA_EXPECTS(own[0] == own[3], CUGRAPH_UNKNOWN_ERROR, "bottom-up level: discoveries and queue length differ");
+    mg_plan_adopt_level(r.plan, (size_t)own[0], own[1], own[2]);
     n_front      = tot.n;
     frontier_out = tot.out_sum;
     unvisited_in = unvisited_in > tot.in_sum ? unvisited_in - tot.in_sum : 0;
