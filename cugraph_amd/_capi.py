@@ -160,7 +160,6 @@ PROTOTYPES = {
     "cugraph_amd_pagerank_plan_step": (C.c_int, [_P, C.c_double, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int), _PP]),
     "cugraph_amd_pagerank_plan_result": (C.c_int, [_P, C.c_size_t, C.c_int, _PP, _PP]),
     "cugraph_amd_pagerank_plan_free": (None, [_P]),
-    "cugraph_amd_pagerank_plan_overlap": (C.c_int32, [_P]),
     "cugraph_amd_pagerank_mg_plan_create": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _P, _P, _P, C.POINTER(C.c_size_t),
                                                     C.POINTER(C.c_size_t), _P, _P, _P, C.c_double, _PP, _PP]),
     "cugraph_amd_pagerank_mg_plan_start": (C.c_int, [_P, _PP]),
@@ -207,6 +206,8 @@ PROTOTYPES = {
     "cugraph_amd_kernel_timing_enable": (None, [_P, C.c_int]),
     "cugraph_amd_kernel_timing_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_double), _PP]),
     "cugraph_amd_kernel_timing_reset": (None, [_P]),
+    "cugraph_amd_kernel_timing_region_begin": (None, [_P, C.c_char_p]),
+    "cugraph_amd_kernel_timing_region_end": (None, [_P, C.c_char_p]),
     "cugraph_amd_graph_num_vertices": (C.c_size_t, [_P]),
     "cugraph_amd_graph_num_edges": (C.c_size_t, [_P]),
     "cugraph_amd_graph_num_local_edges": (C.c_size_t, [_P]),

@@ -96,6 +96,25 @@ extern "C" void cugraph_amd_kernel_timing_enable(const cugraph_resource_handle_t
 {
   if (handle) const_cast<handle_t*>(reinterpret_cast<handle_t const*>(handle))->timing = on == TRUE;
 }
+// One event pair around a whole REGION of work on the handle's stream (bench.py: the timed iterations with the per-launch events off,
+// so that no hipEventCreate / hipEventRecord sits between the launches the wall clock measures).  get(family) then returns 1 and the region's ms.
+extern "C" void cugraph_amd_kernel_timing_region_begin(const cugraph_resource_handle_t* handle, const char* family)
+{
+  if (!handle || !family) return;
+  auto* h = const_cast<handle_t*>(reinterpret_cast<handle_t const*>(handle));
+  hipEvent_t start = nullptr, stop = nullptr;
+  if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) return;
+  (void)hipEventRecord(start, h->stream);
+  h->timers[family].events.emplace_back(start, stop);
+}
+extern "C" void cugraph_amd_kernel_timing_region_end(const cugraph_resource_handle_t* handle, const char* family)
+{
+  if (!handle || !family) return;
+  auto* h = const_cast<handle_t*>(reinterpret_cast<handle_t const*>(handle));
+  auto it = h->timers.find(family);
+  if (it == h->timers.end() || it->second.events.empty()) return;
+  (void)hipEventRecord(it->second.events.back().second, h->stream);
+}
 extern "C" void cugraph_amd_kernel_timing_reset(const cugraph_resource_handle_t* handle)
 {
   if (!handle) return;

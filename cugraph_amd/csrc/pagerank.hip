@@ -580,13 +580,10 @@ __global__ void k_fill_from_base_prev(WT* out, int64_t n, pr_scalars<WT> const* 
 }  // namespace
 
 // ----------------------------------------------------------------------------------------- plan
-constexpr int kOverlapDefaultGrid = 0;  // phase-1 workgroups of an overlapped iteration (0 = serial iterations)
-
 struct pagerank_plan_base {
   virtual ~pagerank_plan_base() = default;
   virtual void step(double epsilon, size_t max_iterations, size_t* done, bool* converged) = 0;
   virtual centrality_result_t* result(size_t total_iterations, bool converged)          = 0;
-  virtual int overlap_grid() const { return 0; }
 };
 
 template <typename WT>
@@ -620,118 +617,7 @@ struct pagerank_plan : pagerank_plan_base {
   dvec<double> tpartials;  // [max(nI, 1024)][3]
   dvec<uint32_t> counters;
 
-  // overlapped iterations (spmv_tiled.hpp, tiled_ovl): phase 2 of iteration k runs beside phase 1 of iteration k + 1
-  int ovl_grid{0};                 // phase-1 workgroups of an overlapped launch; 0 = off
-  int overlap_grid() const override { return ovl_grid; }
-  hipStream_t ovl_s1{nullptr}, ovl_s2{nullptr};
-  hipEvent_t ovl_fork{nullptr}, ovl_e1[2]{nullptr, nullptr}, ovl_e2[2]{nullptr, nullptr};
-  dvec<WT> part_b;                 // second partial buffer: phase 1 of k + 1 writes while phase 2 of k reads
-  dvec<uint32_t> ovl_ready, ovl_need;
-  uint32_t ovl_launches{0};        // overlapped phase-2 launches issued by this plan
-  bool const ovl_const_first{getenv("CUGRAPH_AMD_PR_OVERLAP_ORDER") == nullptr || atoi(getenv("CUGRAPH_AMD_PR_OVERLAP_ORDER")) != 0};  // (=0: the serial launch's chunk order)
-
   pagerank_plan(handle_t const& h_, graph_t& g_, double alpha_) : h(h_), g(g_), alpha((WT)alpha_) {}
-  ~pagerank_plan() override
-  {
-    if (ovl_s1) {
-      (void)hipStreamSynchronize(ovl_s1); (void)hipStreamSynchronize(ovl_s2);
-      (void)hipStreamDestroy(ovl_s1); (void)hipStreamDestroy(ovl_s2);
-      (void)hipEventDestroy(ovl_fork);
-      for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(ovl_e1[i]); (void)hipEventDestroy(ovl_e2[i]); }
-    }
-  }
-
-  // Overlap is worth it when phase 1 keeps every CU busy for many chunks (RMAT-24 and up: see DESIGN.md section 3.1, round 5); the schedule
-  // must be the dynamic queue (a static chunk prefix is cut for one workgroup per CU).  CUGRAPH_AMD_PR_OVERLAP=0 switches it off, =N sets
-  // the number of phase-1 workgroups (the other CUs run phase 2), CUGRAPH_AMD_PR_OVERLAP_MASK=1 pins the two streams to disjoint CU sets.
-  void setup_overlap()
-  {
-    ovl_grid = 0;
-    if (!tiled || tc->n_items == 0 || tc->n_static_chunks != 0) return;
-    char const* env = getenv("CUGRAPH_AMD_PR_OVERLAP");
-    int want = env ? atoi(env) : kOverlapDefaultGrid;
-    if (want <= 0) return;
-    want = std::max(1, std::min({want, tc->n_wg, h.num_cus - 32}));  // (232 and more of 256 hung in round 5's first sweep -- not understood; phase 2 needs its CUs anyway)
-    int const n_p2_cus = h.num_cus - want;
-    bool const masked = getenv("CUGRAPH_AMD_PR_OVERLAP_MASK") != nullptr;
-    auto make_stream = [&](hipStream_t* s, bool phase2_side) {
-      if (masked) {  // CU mask bits interleave the XCDs (bit i -> XCD i % 8): the first n_p2_cus bits are an even share of every XCD
-        std::vector<uint32_t> mask((size_t)(h.num_cus + 31) / 32, 0u);
-        for (int i = 0; i < h.num_cus; ++i)
-          if ((i < n_p2_cus) == phase2_side) mask[(size_t)i / 32] |= 1u << (i % 32);
-        if (hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data()) == hipSuccess) return;
-        (void)hipGetLastError();
-      }
-      HIP_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
-    };
-    make_stream(&ovl_s1, false);
-    make_stream(&ovl_s2, true);
-    HIP_TRY(hipEventCreateWithFlags(&ovl_fork, hipEventDisableTiming));
-    for (int i = 0; i < 2; ++i) { HIP_TRY(hipEventCreateWithFlags(&ovl_e1[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ovl_e2[i], hipEventDisableTiming)); }
-    part_b.resize_discard((size_t)tc->n_slots + 64);
-    HIP_TRY(hipMemsetAsync(part_b.data(), 0, ((size_t)tc->n_slots + 64) * sizeof(WT), h.stream));
-    std::vector<uint32_t> const need = tiled_overlap_need(*tc, crows.nI_act > 0, crows.c0, crows.n_cols);
-    ovl_need.resize_discard(need.size());
-    ovl_ready.resize_discard(need.size());
-    HIP_TRY(hipMemcpyAsync(ovl_need.data(), need.data(), need.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h.stream));
-    HIP_TRY(hipMemsetAsync(ovl_ready.data(), 0, need.size() * sizeof(uint32_t), h.stream));
-    h.sync();  // `need` is a local
-    ovl_launches = 0;
-    ovl_grid     = want;
-  }
-
-  // epsilon == 0, n >= 2 iterations: phase 1 on ovl_s1 (ovl_grid workgroups), phase 2 + the fold of its scalars on ovl_s2.
-  //   s1:  P1(0) ------ P1(1) [waits ready[] per tile] ------ P1(2) [after P2(0): it reuses P2(0)'s partial buffer] ...
-  //   s2:        fold, P2(0) [after P1(0)] ------ fold, P2(1) [after P1(1)] ...
-  // Same kernels' arithmetic as the serial path (the fixed-point accumulation makes the row sums order-independent): results are
-  // bit-identical to it.
-  void step_overlapped(size_t n)
-  {
-    flush_tiled_scalars();  // the first phase 2 reads `scal`
-    HIP_TRY(hipMemsetAsync(counters.data() + 1, 0, 3 * sizeof(uint32_t), h.stream));  // the two chunk cursors and the error word
-    HIP_TRY(hipEventRecord(ovl_fork, h.stream));
-    HIP_TRY(hipStreamWaitEvent(ovl_s1, ovl_fork, 0));
-    HIP_TRY(hipStreamWaitEvent(ovl_s2, ovl_fork, 0));
-    for (size_t k = 0; k < n; ++k) {
-      int const b    = (int)(k & 1);
-      WT const* xcur = cur == 0 ? x0.data() : x1.data();
-      WT* xnext      = cur == 0 ? x1.data() : x0.data();
-      WT* const pbuf = b == 0 ? part.data() : part_b.data();
-      tiled_ovl o;
-      o.ready = ovl_ready.data(); o.need = ovl_need.data(); o.error = counters.data() + 3; o.grid = ovl_grid;
-      o.const_first = crows.nI_act > 0 && ovl_const_first;
-      // phase 1 of iteration k
-      if (k >= 2) HIP_TRY(hipStreamWaitEvent(ovl_s1, ovl_e2[b], 0));  // P2(k - 2) has read this partial buffer
-      o.stream = ovl_s1; o.launches = ovl_launches; o.cursor = counters.data() + 1 + b; o.cursor_next = counters.data() + 1 + (b ^ 1);
-      tiled_phase1<WT>(h, *tc, xcur, alpha, pbuf, nullptr, tiled_x_map<WT>{}, nullptr, &o);
-      HIP_TRY(hipEventRecord(ovl_e1[b], ovl_s1));
-      // phase 2 of iteration k
-      tiled_epilogue<WT> e = tiled_epi(xnext);
-      e.need_diff = force_diff;
-      e.write_pr  = e.need_diff || k + 1 == n || force_write_pr;
-      HIP_TRY(hipStreamWaitEvent(ovl_s2, ovl_e1[b], 0));
-      if (k > 0) tiled_finish<WT>(h, e, tiled_fold_count(*tc, e), -1.0, ovl_s2);  // the scalars of P2(k - 1)
-      o.stream = ovl_s2;
-      tiled_phase2<WT>(h, *tc, (WT const*)pbuf, e, nullptr, &o);
-      ++ovl_launches;
-      HIP_TRY(hipEventRecord(ovl_e2[b], ovl_s2));
-      cur ^= 1;
-    }
-    HIP_TRY(hipStreamWaitEvent(h.stream, ovl_e1[(n - 1) & 1], 0));
-    HIP_TRY(hipStreamWaitEvent(h.stream, ovl_e2[(n - 1) & 1], 0));
-    pending_finish   = true;
-    const_rows_stale = crows.nI_act > 0;
-    ovl_used         = true;
-  }
-  bool ovl_used{false};
-  void check_overlap_error()
-  {
-    if (!ovl_used) return;
-    uint32_t err = 0;
-    h.read_back(&err, (uint32_t const*)counters.data() + 3, 1);
-    ovl_used = false;
-    CGA_EXPECTS(err == 0, CUGRAPH_UNKNOWN_ERROR, "PageRank: an overlapped phase 1 gave up waiting for its source tile (internal error)");
-  }
 
   // (ext ids, values) -> dense vector with `fill` elsewhere; INVALID_INPUT on ids that are not vertices
   void pairs_to_dense(device_array_view_t const* ids, device_array_view_t const* vals, WT* dense, WT fill, char const* what)
@@ -1040,7 +926,6 @@ struct pagerank_plan : pagerank_plan_base {
     // iteration-0 state: x = pr / out_w, dangling mass, base
     if (tiled) {
       setup_const_rows(!personalized && !ig_s);
-      setup_overlap();
       int n = tiled_prologue<WT>(h, *tc, (WT const*)pr.data(), outw, x0.data(), nv, tpartials.data());
       // the rows without in-edges start from the uniform value (there is no user vector when they are left out)
       tiled_finish<WT>(h, tiled_epi(nullptr), n, crows.nI_act > 0 ? (double)(WT(1) / (WT)nv) : -1.0);
@@ -1085,10 +970,6 @@ struct pagerank_plan : pagerank_plan_base {
     if (flat) {
       if (!flat_attr[0]) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_spmv_flat<WT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_per_block)); flat_attr[0] = true; }
       if (!flat_attr[1]) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_spmv_flat<WT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_per_block)); flat_attr[1] = true; }
-    }
-    if (tiled && ovl_grid > 0 && epsilon == 0.0 && max_iterations >= 2) {  // fixed count: nothing is read back between the iterations
-      step_overlapped(max_iterations);
-      it = max_iterations;
     }
     while (it < max_iterations) {
       if (tiled || flat) {
@@ -1139,7 +1020,7 @@ struct pagerank_plan : pagerank_plan_base {
   {
     auto ids  = std::make_unique<device_array_t>((size_t)g.nv, g.vertex_type);
     auto vals = std::make_unique<device_array_t>((size_t)g.nv, g.weight_type);
-    if (tiled) { flush_tiled_scalars(); materialize_const_rows(); check_overlap_error(); }
+    if (tiled) { flush_tiled_scalars(); materialize_const_rows(); }
     if (g.nv > 0) {
       HIP_TRY(hipMemcpyAsync(ids->buf.ptr, g.number_map.data(), g.nv * 4, hipMemcpyDeviceToDevice, h.stream));
       HIP_TRY(hipMemcpyAsync(vals->buf.ptr, pr.data(), g.nv * sizeof(WT), hipMemcpyDeviceToDevice, h.stream));
@@ -2160,7 +2041,7 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     HIP_TRY(hipMemsetAsync(cursors.data(), 0, 2 * sizeof(uint32_t), h.stream));
     c.wait(h.stream, channelA, seqA_base + n);
     tiled_chunks const ch{chunksA.data(), n_chunksA, cursors.data(), no_static.data()};
-    tiled_phase1<WT>(h, *tc, (WT const*)xwin[b]->local, alpha, partial.data(), counters.data(), tiled_x_map<WT>{}, nullptr, nullptr, &ch);
+    tiled_phase1<WT>(h, *tc, (WT const*)xwin[b]->local, alpha, partial.data(), counters.data(), tiled_x_map<WT>{}, nullptr, &ch);
   }
 
   // waits for the latest push of every rank and folds the P scalar triples into the constants of the next iteration
@@ -2190,11 +2071,11 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     e.write_pr           = need_diff || last_of_call;
     if (ovl) {  // (phase 1 over the hot source tiles went out before the fold: step())
       tiled_chunks const ch{chunksB.data(), n_chunksB, cursors.data() + 1, no_static.data()};
-      tiled_phase1<WT>(h, *tc, (WT const*)xwin[b]->local, alpha, partial.data(), counters.data(), tiled_x_map<WT>{}, nullptr, nullptr, &ch);
+      tiled_phase1<WT>(h, *tc, (WT const*)xwin[b]->local, alpha, partial.data(), counters.data(), tiled_x_map<WT>{}, nullptr, &ch);
       tiled_range const ra{0, ovl_IA}, rb{ovl_IA, ovl_blocks - ovl_IA};
-      tiled_phase2<WT>(h, *tc, (WT const*)partial.data(), e, counters.data(), nullptr, &ra);
+      tiled_phase2<WT>(h, *tc, (WT const*)partial.data(), e, counters.data(), &ra);
       push_hot();
-      tiled_phase2<WT>(h, *tc, (WT const*)partial.data(), e, counters.data(), nullptr, &rb);
+      tiled_phase2<WT>(h, *tc, (WT const*)partial.data(), e, counters.data(), &rb);
     } else {
       tiled_phase1<WT>(h, *tc, (WT const*)xwin[b]->local, alpha, partial.data(), counters.data(), tiled_x_map<WT>{}, nullptr);
       tiled_phase2<WT>(h, *tc, (WT const*)partial.data(), e, counters.data());
@@ -2444,10 +2325,6 @@ extern "C" cugraph_error_code_t cugraph_amd_pagerank_plan_result(cugraph_amd_pag
   });
 }
 extern "C" void cugraph_amd_pagerank_plan_free(cugraph_amd_pagerank_plan_t* plan) { delete reinterpret_cast<pagerank_plan_base*>(plan); }
-extern "C" int32_t cugraph_amd_pagerank_plan_overlap(cugraph_amd_pagerank_plan_t const* plan)
-{
-  return plan ? (int32_t)reinterpret_cast<pagerank_plan_base const*>(plan)->overlap_grid() : 0;
-}
 
 // ---- multi-GPU plan API (include/cugraph_amd/extensions.h) ---------------------------------------
 namespace {

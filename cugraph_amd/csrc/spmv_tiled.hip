@@ -381,20 +381,6 @@ std::vector<uint32_t> key_starts(handle_t const& h, uint64_t const* keys, int64_
 
 }  // namespace
 
-std::vector<uint32_t> tiled_overlap_need(tiled_csc_t const& t, bool const_rows, int64_t c0, int64_t n_cols)
-{
-  std::vector<uint32_t> need((size_t)std::max(t.nJ, 1), 0u);
-  auto add = [&](int64_t lo, int64_t hi) {  // a producer of columns [lo, hi)
-    if (hi <= lo) return;
-    for (int64_t J = lo / t.T; J <= (hi - 1) / t.T && J < t.nJ; ++J) ++need[(size_t)J];
-  };
-  int const n_tiles = const_rows ? t.nI_act : t.nI;
-  for (int I = 0; I < n_tiles; ++I) add(t.tile_col0_host[(size_t)I], t.tile_col0_host[(size_t)I + 1]);
-  if (const_rows)
-    for (int64_t b = 0; b * TP2_CONST_COLS < n_cols; ++b) add(c0 + b * TP2_CONST_COLS, c0 + std::min<int64_t>(n_cols, (b + 1) * TP2_CONST_COLS));
-  return need;
-}
-
 namespace {
 // wmax[I] = max over the rows of destination tile I of sum |w| of the row's in-edges (w == nullptr: the in-degree); one workgroup per tile,
 // one wavefront per row at a time
@@ -594,19 +580,12 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   t.nI = (int)row0.size() - 1;
   to_device(h, t.tile_row0, row0);
   t.c0 = t.n_act;  // first column of a row >= n_act (identity columns: the row itself)
-  t.tile_col0_host = row0;
   if (live_rank.size()) {
     uint32_t c0 = 0;
     h.read_back(&c0, live_rank.data() + t.n_act, 1);
     t.c0 = c0;
-    // first column of every destination tile (columns are monotone in the row id): which source tiles a phase-2 workgroup feeds
-    dvec<uint32_t> col0(row0.size());
-    hipLaunchKernelGGL(k_gather_u32, grid_for((int64_t)row0.size(), kBlock), kBlock, 0, h.stream, (uint32_t const*)live_rank.data(), (uint32_t const*)t.tile_row0.data(),
-                       (int64_t)row0.size(), col0.data());
-    t.tile_col0_host = to_host(h, col0.data(), row0.size());
     live_rank = dvec<uint32_t>();
   }
-  to_device(h, t.tile_col0, t.tile_col0_host);
   t.tile_wmax.resize_discard((size_t)std::max(t.nI, 1));
   HIP_TRY(hipMemsetAsync(t.tile_wmax.data(), 0, (size_t)std::max(t.nI, 1) * sizeof(double), h.stream));
   if (ne > 0 && t.nI > 0) {
@@ -730,19 +709,6 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     }
     for (auto const& c : ch) { cb.push_back(0); cb.push_back(c.first); cb.push_back(c.first + c.second); cb.push_back(item_tile[c.first]); }
     t.n_chunks = (int)(cb.size() / 4);
-    // Overlapped iterations (tiled_ovl): the source tiles whose columns all belong to rows WITHOUT in-edges (columns >= c0) get their x from the
-    // few cheap tiled_const_rows blocks that phase 2 runs first, i.e. microseconds into the previous iteration's phase 2 -- while tile 0 waits
-    // for the ~4 % of phase 2 that reduce the hottest rows.  A second order of the same chunks puts those tiles first (largest first among
-    // them), then the others as above: phase 1 has work from its first microsecond, and the small chunks of the remaining cold tiles still
-    // balance the finish.
-    t.ovl_first_const_tile = (int)std::min<int64_t>((t.c0 + T - 1) / T, nJ);
-    if (!use_static && !ch.empty()) {
-      std::vector<std::pair<int32_t, int32_t>> ord = ch;
-      std::stable_partition(ord.begin(), ord.end(), [&](auto const& c) { return item_tile[c.first] >= t.ovl_first_const_tile; });
-      std::vector<int32_t> cbo;
-      for (auto const& c : ord) { cbo.push_back(0); cbo.push_back(c.first); cbo.push_back(c.first + c.second); cbo.push_back(item_tile[c.first]); }
-      to_device(h, t.chunk_begin_ovl, cbo);
-    }
     if (cb.empty()) cb.assign(4, 0);
     if (!use_static) t.n_wg = std::max(1, std::min<int>(t.n_chunks, max_wg));
     if (wg_static.empty()) wg_static.assign((size_t)2 * std::max(t.n_wg, 1), 0);
@@ -1017,12 +983,6 @@ struct p1_args {
   uint32_t pmask, plog, chunk, ncols;
   fin_args<WT> fin;  // scalars of the PREVIOUS iteration, folded by workgroup 0 before it starts streaming
   unsigned long long* dbg{nullptr};  // CUGRAPH_AMD_TILED_DEBUG: per-workgroup (cycles, tile loads)
-  // overlapped iterations (spmv_tiled.hpp, tiled_ovl): x of source tile J is complete when ready[J] has reached need[J] * ovl_launches
-  uint32_t const* ready{nullptr};
-  uint32_t const* need{nullptr};
-  uint32_t ovl_launches{0};
-  uint32_t* counter_next{nullptr};  // the next launch's chunk cursor: rewound by workgroup 0
-  uint32_t* ovl_error{nullptr};
 };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -1359,7 +1319,7 @@ struct p1_iter {  // position in this workgroup's item sequence (all fields wave
   int item, end, pos, tile;
 };
 
-template <typename WT, bool WEIGHTED, bool DBG = false, bool OVL = false>
+template <typename WT, bool WEIGHTED, bool DBG = false>
 __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1371,11 +1331,7 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();  // lds_ld / lds_st / idx_offset address the tile from LDS address 0
   WT* stage = xs + a.T + wave * TP_STAGE;
 
-  if constexpr (OVL) {
-    if (blockIdx.x == 0 && tid == 0) *a.counter_next = 0u;  // nobody uses it before this launch has ended (stream order)
-  } else {
-    if (blockIdx.x == 0 && a.fin.partials) finish_scalars<WT>(a.fin, reinterpret_cast<double*>(smem), tid, TP_BLOCK);
-  }
+  if (blockIdx.x == 0 && a.fin.partials) finish_scalars<WT>(a.fin, reinterpret_cast<double*>(smem), tid, TP_BLOCK);
 
   // Work is handed out dynamically in CHUNKS (a few consecutive work items of one source tile; hottest tiles first, the
   // small cold tiles last); chunk ids are fetched three chunks ahead so the item sequence is known two items ahead.
@@ -1422,27 +1378,6 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
   auto compute_item = [&](p1_regs& rg, p1_runs& q) {
     int const J = I.tile;
     if (J != curJ) {
-      if constexpr (OVL) {
-        // the phase 2 that produces this tile's x may still be running on the other CUs: ONE lane polls the tile's counter (relaxed,
-        // agent scope = an sc1 load that bypasses this CU's L1), then ONE agent-scope acquire (buffer_inv sc1: this CU's L1 holds the
-        // tile's previous contents at most), then the barrier; the tile loads below stay plain.  The producers stored x write-through.
-        uint32_t const target      = a.need[J] * a.ovl_launches;  // wave-uniform: scalar loads
-        uint32_t const* const flag = a.ready + J;
-        if (wave == 0) {  // (wave-uniform branch, every lane reads the same word: the loop lives in scalar registers)
-          uint32_t spins = 0;
-          while ((int32_t)(rfl(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - target) < 0) {
-            __builtin_amdgcn_s_sleep(32);  // ~1 us between polls: 200 pollers on one line must not eat the producers' fabric
-            // a producer that never comes must not hang the GPU: after ~0.3 s the launch gives up (error word; the host throws when the result
-            // is read) and every later poll of the launch -- and of the launches queued behind it -- returns at once
-            if (++spins > 150000u || ((spins & 1023u) == 0u && rfl(__hip_atomic_load(a.ovl_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)) {
-              *a.ovl_error = 1u;
-              break;
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-      }
       // x is allocated (and zero-filled) up to nJ * T elements; indices are clamped instead of guarded so that the loads
       // stay straight-line (8 in flight per thread)
       using vec4 = typename std::conditional<sizeof(WT) == 4, float4, double4>::type;
@@ -1556,48 +1491,17 @@ struct p2_args {
   int nI;
   tiled_epilogue<WT> e;
   uint32_t* counters;
-  // overlapped iterations (tiled_ovl): the workgroup counts itself into ready[J] of every source tile J its columns fall into
   double const* tile_wmax{nullptr};  // tiled_csc_t::tile_wmax (fp32: the fixed-point scale of the tile)
-  uint32_t const* tile_col0{nullptr};
-  uint32_t* ready{nullptr};
-  int T{0};
-  int n_const{0};  // blocks [0, n_const) are the tiled_const_rows blocks (first: they are cheap and the coldest source tiles wait for them)
   int I0{0};       // first block of this launch (tiled_range: a launch over a part of the destination tiles)
 };
-
-// x[c] = v so that a workgroup on another XCD that polls ready[] afterwards reads it: write-through (sc1) store
-template <typename WT>
-__device__ __forceinline__ void store_x_through(WT* p, WT v)
-{
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// after every wavefront has drained its write-through stores (s_waitcnt vmcnt(0) + barrier): one lane publishes columns [c_lo, c_hi)
-__device__ __forceinline__ void publish_columns(uint32_t* ready, int T, int64_t c_lo, int64_t c_hi)
-{
-  if (c_hi <= c_lo) return;
-  for (int64_t J = c_lo / T; J <= (c_hi - 1) / T; ++J) __hip_atomic_fetch_add(&ready[J], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // fp32 partials are accumulated as signed 64-bit fixed point (value * 2^k of the tile, rounded to nearest: tiled_to_fixed in spmv_tiled.hpp):
 // LDS integer atomics run at full rate on gfx950 while ds_add_f32 is ~5x slower (tools/ubench/lds_update_bench.hip), and integer addition is
 // associative, so the result does not depend on the order in which wavefronts reach a row (bit-reproducible).
-// the shift-based conversion of rounds 1-4 (value * 2^k truncated, 32 VALU instructions), kept selectable for same-session comparisons
-// (CUGRAPH_AMD_P2_FIXED=shift): phase 2 alone is HBM-bound either way
-__device__ __forceinline__ unsigned long long to_fixed_shift(float v, int k)
-{
-  uint32_t const b = __float_as_uint(v);
-  int const e      = (int)((b >> 23) & 0xFFu);
-  unsigned long long m = (unsigned long long)((b & 0x7FFFFFu) | 0x800000u);
-  int const sh     = e - 150 + k;  // v = m * 2^(e - 150)
-  unsigned long long fx = sh >= 0 ? m << min(sh, 63) : m >> min(-sh, 63);
-  fx = e == 0 ? 0ull : fx;         // zero / denormal
-  return (b >> 31) ? (0ull - fx) : fx;
-}
-
 template <typename WT> struct p2_acc { using type = WT; };
 template <> struct p2_acc<float> { using type = unsigned long long; };
 
-template <typename WT, bool PERS, bool OVL = false, int NB = 1, bool SHIFTFX = false>
+template <typename WT, bool PERS>
 __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
 {
   using ACC = typename p2_acc<WT>::type;
@@ -1606,13 +1510,9 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
   ACC* acc = reinterpret_cast<ACC*>(smem2);  // [TP2_ROWS]
   __shared__ double red[3 * (TP2_BLOCK / 64)];
   int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int I = (int)blockIdx.x + a.I0, cblock = -1;  // destination tile, or block of tiled_const_rows
-  if constexpr (OVL) {
-    if (I < a.n_const) cblock = I; else I -= a.n_const;
-  } else {
-    if (a.e.cr.nI_act > 0 && I >= a.e.cr.nI_act) cblock = I - a.e.cr.nI_act;
-  }
-  if (cblock >= 0) {  // tiled_const_rows: x of the live columns whose rows have no in-edge
+  int const I = (int)blockIdx.x + a.I0;  // destination tile, or (I >= nI_act) block of tiled_const_rows
+  if (a.e.cr.nI_act > 0 && I >= a.e.cr.nI_act) {  // tiled_const_rows: x of the live columns whose rows have no in-edge
+    int const cblock = I - a.e.cr.nI_act;
     WT const b       = a.e.scal->base;
     int64_t const n  = a.e.cr.n_cols;
     WT* const xo           = a.e.x_next + a.e.cr.c0;
@@ -1620,13 +1520,7 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
     for (int64_t j = (int64_t)cblock * TP2_CONST_COLS + tid, k = 0; k < 8 && j < n; ++k, j += TP2_BLOCK) {
       WT const ow = a.e.cr.outw_c[j];
       WT const xv = b / (ow == WT(0) ? WT(1) : ow);
-      if constexpr (OVL) store_x_through<WT>(xo + j, xv);
-      else if (ci) a.e.x_next[ci[j]] = xv; else xo[j] = xv;
-    }
-    if constexpr (OVL) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wavefront drains its write-through stores ...
-      __syncthreads();
-      if (tid == 0) publish_columns(a.ready, a.T, a.e.cr.c0 + (int64_t)cblock * TP2_CONST_COLS, a.e.cr.c0 + min(n, (int64_t)(cblock + 1) * TP2_CONST_COLS));  // ... then one lane counts the block in
+      if (ci) a.e.x_next[ci[j]] = xv; else xo[j] = xv;
     }
     return;
   }
@@ -1649,71 +1543,45 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
   for (uint32_t i = tid; i < nrows; i += TP2_BLOCK) acc[i] = ACC(0);
   // fp32: the tile's fixed-point scale (spmv_tiled.hpp, tiled_to_fixed): its partials and row sums are bounded by fx_unit * tile_wmax[I]
   double fx_scale = 1.0, fx_inv = 1.0;
-  int fx_k = 0;
-  if constexpr (sizeof(WT) == 4) {
-    tiled_tile_scale(sc.fx_unit * a.tile_wmax[I], &fx_scale, &fx_inv);
-    if constexpr (SHIFTFX) { (void)frexp(fx_scale, &fx_k); fx_k -= 1; }  // fx_scale = 2^fx_k
-  }
+  if constexpr (sizeof(WT) == 4) tiled_tile_scale(sc.fx_unit * a.tile_wmax[I], &fx_scale, &fx_inv);
   __syncthreads();
-  // NB batches of 8 slots in flight per thread: every load of a step is issued before the first partial of the step is added (one batch
-  // keeps 44 bytes per lane in flight -- enough when the whole chip streams; beside a phase 1 that owns most CUs two are needed)
-  for (uint32_t sb = s0 + 8 * tid; sb < s1; sb += 8 * TP2_BLOCK * NB) {
-    uint32_t w12[NB][3], idx16w[NB];
-    WT v[NB][8];
+  // 8 slots per thread and step: every load of a step is issued before the first partial of the step is added (44 bytes per lane in flight,
+  // 32 wavefronts per CU)
+  for (uint32_t s = s0 + 8 * tid; s < s1; s += 8 * TP2_BLOCK) {
+    uint32_t idx8[8];
+    WT v[8];
+    uint32_t w0, w1, w2, w3 = 0;
+    if (a.dstl12) {  // wave-uniform: 8 slots = 3 dwords of 12-bit tile-local rows
+      typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+      u32x3_t const w = __builtin_nontemporal_load(reinterpret_cast<u32x3_t const*>(a.dstl12 + 3u * (s >> 3)));  // streamed once per iteration
+      w0 = w.x; w1 = w.y; w2 = w.z;
+    } else {  // 16-bit destinations: 8 slots = 16 bytes (tiles of <= 4096 rows only reach here with CUGRAPH_AMD_TILED_DSTL16)
+      uint4 const d = *reinterpret_cast<uint4 const*>(a.dstl16 + s);
+      w0 = d.x; w1 = d.y; w2 = d.z; w3 = d.w;
+    }
+    if constexpr (sizeof(WT) == 4) {
+      typedef float f32x4_t __attribute__((ext_vector_type(4)));
+      f32x4_t const q0 = __builtin_nontemporal_load(reinterpret_cast<f32x4_t const*>(a.part + s)), q1 = __builtin_nontemporal_load(reinterpret_cast<f32x4_t const*>(a.part + s + 4));
+      v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+    } else {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      uint32_t const s = sb + (uint32_t)b * (8 * TP2_BLOCK);
-      bool const live  = b == 0 || s < s1;  // (a batch past the region adds zeros to row 0)
-      if (a.dstl12) {  // wave-uniform: 8 slots = 3 dwords of 12-bit tile-local rows
-        uint32_t const* p12 = a.dstl12 + 3u * (s >> 3);
-#ifndef CGA_P2_PLAIN_LOAD  // streamed once per iteration: non-temporal loads (phase 2 0.457 -> 0.442 ms at RMAT-26)
-        w12[b][0] = live ? __builtin_nontemporal_load(p12) : 0u; w12[b][1] = live ? __builtin_nontemporal_load(p12 + 1) : 0u; w12[b][2] = live ? __builtin_nontemporal_load(p12 + 2) : 0u;
-#else
-        w12[b][0] = live ? p12[0] : 0u; w12[b][1] = live ? p12[1] : 0u; w12[b][2] = live ? p12[2] : 0u;
-#endif
-      } else {  // 16-bit destinations: 8 slots = 16 bytes, repacked to the 12-bit layout's three dwords (tiles of <= 4096 rows only reach here with CUGRAPH_AMD_TILED_DSTL16)
-        uint4 d{0u, 0u, 0u, 0u};
-        if (live) d = *reinterpret_cast<uint4 const*>(a.dstl16 + s);
-        w12[b][0] = d.x; w12[b][1] = d.y; w12[b][2] = d.z; idx16w[b] = d.w;  // four dwords of two 16-bit rows each
-      }
-      if constexpr (sizeof(WT) == 4) {
-        typedef float f32x4_t __attribute__((ext_vector_type(4)));
-        f32x4_t q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
-        if (live) {
-#ifndef CGA_P2_PLAIN_LOAD
-          q0 = __builtin_nontemporal_load(reinterpret_cast<f32x4_t const*>(a.part + s)); q1 = __builtin_nontemporal_load(reinterpret_cast<f32x4_t const*>(a.part + s + 4));
-#else
-          q0 = *reinterpret_cast<f32x4_t const*>(a.part + s); q1 = *reinterpret_cast<f32x4_t const*>(a.part + s + 4);
-#endif
-        }
-        v[b][0] = q0.x; v[b][1] = q0.y; v[b][2] = q0.z; v[b][3] = q0.w; v[b][4] = q1.x; v[b][5] = q1.y; v[b][6] = q1.z; v[b][7] = q1.w;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          double2 p{0.0, 0.0};
-          if (live) p = *reinterpret_cast<double2 const*>(a.part + s + 2 * k);
-          v[b][2 * k] = p.x; v[b][2 * k + 1] = p.y;
-        }
+      for (int k = 0; k < 4; ++k) {
+        double2 const p = *reinterpret_cast<double2 const*>(a.part + s + 2 * k);
+        v[2 * k] = p.x; v[2 * k + 1] = p.y;
       }
     }
+    if (a.dstl12) {
+      idx8[0] = w0 & 0xFFFu; idx8[1] = (w0 >> 12) & 0xFFFu; idx8[2] = (w0 >> 24) | ((w1 & 0xFu) << 8); idx8[3] = (w1 >> 4) & 0xFFFu;
+      idx8[4] = (w1 >> 16) & 0xFFFu; idx8[5] = (w1 >> 28) | ((w2 & 0xFFu) << 4); idx8[6] = (w2 >> 8) & 0xFFFu; idx8[7] = w2 >> 20;
+    } else {
+      uint32_t const w4[4] = {w0, w1, w2, w3};
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      uint32_t idx8[8];
-      if (a.dstl12) {
-        uint32_t const w0 = w12[b][0], w1 = w12[b][1], w2 = w12[b][2];
-        idx8[0] = w0 & 0xFFFu; idx8[1] = (w0 >> 12) & 0xFFFu; idx8[2] = (w0 >> 24) | ((w1 & 0xFu) << 8); idx8[3] = (w1 >> 4) & 0xFFFu;
-        idx8[4] = (w1 >> 16) & 0xFFFu; idx8[5] = (w1 >> 28) | ((w2 & 0xFFu) << 4); idx8[6] = (w2 >> 8) & 0xFFFu; idx8[7] = w2 >> 20;
-      } else {
-        uint32_t const w4[4] = {w12[b][0], w12[b][1], w12[b][2], idx16w[b]};
+      for (int k = 0; k < 8; ++k) idx8[k] = (k & 1) ? (w4[k >> 1] >> 16) : (w4[k >> 1] & 0xFFFFu);
+    }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) idx8[k] = (k & 1) ? (w4[k >> 1] >> 16) : (w4[k >> 1] & 0xFFFFu);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        uint32_t const i = idx8[k];
-        if constexpr (sizeof(WT) == 4) atomicAdd(&acc[i], SHIFTFX ? to_fixed_shift(v[b][k], fx_k) : tiled_to_fixed(v[b][k], fx_scale));  // ds_add_u64; padding slots hold 0
-        else atomicAdd(&acc[i], v[b][k]);                                                      // ds_add_f64
-      }
+    for (int k = 0; k < 8; ++k) {
+      if constexpr (sizeof(WT) == 4) atomicAdd(&acc[idx8[k]], tiled_to_fixed(v[k], fx_scale));  // ds_add_u64; padding slots hold 0
+      else atomicAdd(&acc[idx8[k]], v[k]);                                                      // ds_add_f64
     }
   }
   __syncthreads();
@@ -1732,39 +1600,43 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
     return;
   }
 
+  // Every row's values first, every store afterwards: a store between the rows makes the compiler drain the memory counter (vmcnt(0)) in front of
+  // the next row's first use of a register loaded at the top of the kernel -- one store round trip per row, eight in a row per thread (ISA of
+  // round 5).  With the stores at the end the only wait of the epilogue is the one for its inputs, which arrived long ago.
   double diff = 0.0, dang = 0.0, xmax = 0.0;
+  WT val[RPT], xn[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    uint32_t i = tid + j * TP2_BLOCK;
+    val[j] = WT(0); xn[j] = WT(0);
+    if (i < nrows) {
+      WT sum;
+      if constexpr (sizeof(WT) == 4) sum = (WT)((double)(long long)acc[i] * fx_inv);
+      else sum = acc[i];
+      WT vv = sc.base + sum;
+      if constexpr (PERS) vv += sc.pers_factor * e.pers[(size_t)row0 + i];
+      val[j] = vv;
+      xn[j]  = vv / (ow[j] == WT(0) ? WT(1) : ow[j]);
+      if (e.need_diff) diff += (double)fabs(vv - old[j]);
+      xmax = fmax(xmax, fabs((double)xn[j]));
+      if (ow[j] == WT(0)) dang += (double)vv;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     uint32_t i = tid + j * TP2_BLOCK;
     if (i < nrows) {
-      size_t const v = (size_t)row0 + i;
-      WT sum;
-      if constexpr (sizeof(WT) == 4) sum = (WT)((double)(long long)acc[i] * fx_inv);
-      else sum = acc[i];
-      WT val = sc.base + sum;
-      if constexpr (PERS) val += sc.pers_factor * e.pers[v];
-      WT const xn = val / (ow[j] == WT(0) ? WT(1) : ow[j]);
-      if (e.write_pr) e.pr[v] = val;
-      if (col[j] >= 0) {  // sources without out-edges have no column
-        if constexpr (OVL) store_x_through<WT>(e.x_next + col[j], xn);
-        else e.x_next[col[j]] = xn;
-      }
-      if (e.need_diff) diff += (double)fabs(val - old[j]);
-      xmax = fmax(xmax, fabs((double)xn));
-      if (ow[j] == WT(0)) dang += (double)val;
+      if (e.write_pr) e.pr[(size_t)row0 + i] = val[j];
+      if (col[j] >= 0) e.x_next[col[j]] = xn[j];  // sources without out-edges have no column
     }
   }
   diff = group_sum(diff, 64);
   dang = group_sum(dang, 64);
   for (int o = 32; o > 0; o >>= 1) xmax = fmax(xmax, __shfl_xor(xmax, o));
   if (lane == 0) { red[3 * wave] = diff; red[3 * wave + 1] = dang; red[3 * wave + 2] = xmax; }
-  if constexpr (OVL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's write-through x stores have left (before the barrier)
   __syncthreads();
-  if constexpr (OVL) {
-    if (tid == 0) publish_columns(a.ready, a.T, (int64_t)a.tile_col0[I], (int64_t)a.tile_col0[I + 1]);
-  }
   if (tid == 0) {  // folded by the next phase-1 launch (or k_tiled_finish): no device-scope fence per workgroup here
-    if (!OVL && I == 0) a.counters[0] = 0;  // phase 1 is over: rewind its chunk cursor for the next iteration
+    if (I == 0) a.counters[0] = 0;  // phase 1 is over: rewind its chunk cursor for the next iteration
     double d0 = 0, d1 = 0, d2 = 0;
 #pragma unroll
     for (int k = 0; k < TP2_BLOCK / 64; ++k) { d0 += red[3 * k]; d1 += red[3 * k + 1]; d2 = fmax(d2, red[3 * k + 2]); }
@@ -1795,28 +1667,8 @@ fin_args<WT> make_fin(tiled_epilogue<WT> const& e, int n)
 
 template <typename WT>
 void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha, WT* part, uint32_t* counters, tiled_x_map<WT> const& map,
-                  tiled_epilogue<WT> const* pending, tiled_ovl const* ovl, tiled_chunks const* chunks)
+                  tiled_epilogue<WT> const* pending, tiled_chunks const* chunks)
 {
-  if (ovl) {  // overlapped with the previous iteration's phase 2 (tiled_ovl): fewer workgroups than CUs, own stream, polls before tile loads
-    CGA_EXPECTS(t.n_items > 0 && t.n_static_chunks == 0 && pending == nullptr, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: overlapped phase 1 needs a dynamic-only schedule");
-    p1_args<WT> a;
-    a.src16 = t.src16.data(); a.bits = reinterpret_cast<uint8_t const*>(t.bits.data()); a.weights = t.weights.ptr ? t.weights.as<WT const>() : nullptr;
-    a.delta1 = t.delta1.data(); a.wrec = t.wrec.data(); a.n_chunks = t.n_chunks; a.n_static_chunks = 0;
-    a.chunk_begin = ovl->const_first && t.chunk_begin_ovl.size() ? t.chunk_begin_ovl.data() : t.chunk_begin.data();
-    a.wg_static = t.wg_static.data();  // all zero: no private chunks
-    a.counter = ovl->cursor; a.counter_next = ovl->cursor_next; a.T = t.T; a.x = x; a.part = part; a.alpha = alpha;
-    a.pmask = map.pmask; a.plog = map.plog; a.chunk = map.chunk; a.ncols = map.ncols;
-    a.ready = ovl->ready; a.need = ovl->need; a.ovl_launches = ovl->launches; a.ovl_error = ovl->error;
-    size_t const lds = ((size_t)t.T + (size_t)TP_WAVES * TP_STAGE) * sizeof(WT) + 64;
-    static bool attr_ovl[2] = {false, false};
-    auto launch = [&](auto kernel, int slot) {
-      if (!attr_ovl[slot]) { ensure_max_lds(kernel, (int)h.lds_per_block); attr_ovl[slot] = true; }
-      timed_launch tl(h, "pagerank_spmv", ovl->stream);
-      hipLaunchKernelGGL(kernel, std::max(1, std::min(ovl->grid, t.n_wg)), TP_BLOCK, lds, ovl->stream, a);
-    };
-    if (a.weights) launch(k_tiled_phase1<WT, true, false, true>, 0); else launch(k_tiled_phase1<WT, false, false, true>, 1);
-    return;
-  }
   if (t.n_items == 0) {
     if (pending) tiled_finish<WT>(h, *pending, tiled_fold_count(t, *pending));
     return;
@@ -1872,7 +1724,7 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
 }
 
 template <typename WT>
-void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters, tiled_ovl const* ovl, tiled_range const* range)
+void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters, tiled_range const* range)
 {
   p2_args<WT> a;
   a.part       = part;
@@ -1890,37 +1742,18 @@ void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled
   int const n_const = e.cr.nI_act > 0 ? (int)((e.cr.n_cols + TP2_CONST_COLS - 1) / TP2_CONST_COLS) : 0;
   if (e.cr.nI_act > 0) grid = e.cr.nI_act + n_const;
   if (range) {  // a part of the blocks (destination tiles first, then the tiled_const_rows blocks): [first, first + count)
-    CGA_EXPECTS(ovl == nullptr && range->first >= 0 && range->count >= 0 && range->first + range->count <= grid, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: phase-2 block range");
+    CGA_EXPECTS(range->first >= 0 && range->count >= 0 && range->first + range->count <= grid, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: phase-2 block range");
     if (range->count == 0) return;
     a.I0 = range->first;
     grid = range->count;
   }
-  // batches of 8 slots in flight per thread: 1 when the kernel has the chip to itself (HBM-bound either way), 2 beside a phase 1
-  char const* const env_nb = getenv("CUGRAPH_AMD_P2_BATCHES");  // (read per launch: tools/plan_sweep.py switches variants inside one process)
-  int const nb_env = env_nb ? atoi(env_nb) : 0;
-  int const nb = nb_env == 1 || nb_env == 2 ? nb_env : (ovl ? 2 : 1);
-  hipStream_t const stream = ovl ? ovl->stream : h.stream;
-  if (ovl) {  // beside the next iteration's phase 1 (tiled_ovl): x stored write-through, every workgroup counts itself into ready[]
-    CGA_EXPECTS(e.raw_y == nullptr && e.cr.col_idx == nullptr, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: overlapped phase 2 is the single-GPU PageRank epilogue");
-    a.tile_col0 = t.tile_col0.data(); a.ready = ovl->ready; a.T = t.T; a.n_const = n_const;
-  }
   auto launch = [&](auto kernel) {
     static bool attr_done = false;  // (one flag per instantiation of this lambda = per kernel)
     if (!attr_done && lds > 48 * 1024) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_done = true; }
-    timed_launch tl(h, "pagerank_reduce", stream);
-    hipLaunchKernelGGL(kernel, grid, TP2_BLOCK, lds, stream, a);
+    timed_launch tl(h, "pagerank_reduce");
+    hipLaunchKernelGGL(kernel, grid, TP2_BLOCK, lds, h.stream, a);
   };
-  bool const pers = e.pers != nullptr;
-  char const* const env_fx = getenv("CUGRAPH_AMD_P2_FIXED");
-  bool const shift_fx = env_fx != nullptr && std::string(env_fx) == "shift";
-  if (shift_fx && !ovl && !pers && nb == 1) { launch(k_tiled_phase2<WT, false, false, 1, true>); return; }
-  if (ovl) {
-    if (nb == 2) { if (pers) launch(k_tiled_phase2<WT, true, true, 2>); else launch(k_tiled_phase2<WT, false, true, 2>); }
-    else         { if (pers) launch(k_tiled_phase2<WT, true, true, 1>); else launch(k_tiled_phase2<WT, false, true, 1>); }
-  } else {
-    if (nb == 2) { if (pers) launch(k_tiled_phase2<WT, true, false, 2>); else launch(k_tiled_phase2<WT, false, false, 2>); }
-    else         { if (pers) launch(k_tiled_phase2<WT, true, false, 1>); else launch(k_tiled_phase2<WT, false, false, 1>); }
-  }
+  if (e.pers != nullptr) launch(k_tiled_phase2<WT, true>); else launch(k_tiled_phase2<WT, false>);
 }
 
 template <typename WT>
@@ -1948,8 +1781,8 @@ void tiled_scalars_from_ranks(handle_t const& h, tiled_epilogue<WT> const& e, vo
 }
 
 #define CGA_INSTANTIATE_TILED(WT)                                                                                                          \
-  template void tiled_phase1<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT, WT*, uint32_t*, tiled_x_map<WT> const&, tiled_epilogue<WT> const*, tiled_ovl const*, tiled_chunks const*); \
-  template void tiled_phase2<WT>(handle_t const&, tiled_csc_t const&, WT const*, tiled_epilogue<WT> const&, uint32_t*, tiled_ovl const*, tiled_range const*);                                  \
+  template void tiled_phase1<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT, WT*, uint32_t*, tiled_x_map<WT> const&, tiled_epilogue<WT> const*, tiled_chunks const*); \
+  template void tiled_phase2<WT>(handle_t const&, tiled_csc_t const&, WT const*, tiled_epilogue<WT> const&, uint32_t*, tiled_range const*);                                  \
   template void tiled_finish<WT>(handle_t const&, tiled_epilogue<WT> const&, int, double, hipStream_t);                                                           \
   template int tiled_prologue<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT const*, WT*, int64_t, double*, int32_t const*);          \
   template void tiled_scalars_from_ranks<WT>(handle_t const&, tiled_epilogue<WT> const&, void const*, size_t, size_t, int);

@@ -127,13 +127,9 @@ struct tiled_csc_t {
   dvec<int32_t> item_tile;    // [n_items] source tile of work item
   dvec<uint32_t> wrec;        // [n_items * TP_WAVES][TP_REC_DWORDS] per-wavefront records (see above)
   dvec<int32_t> chunk_begin;  // [n_chunks][4] (unused, first item, end item, source tile) of each chunk (<= TP_CHUNK items of one source tile), largest first
-  dvec<int32_t> chunk_begin_ovl;  // the same chunks in the order of an overlapped launch (tiles >= ovl_first_const_tile first); empty with a static prefix
-  int ovl_first_const_tile{0};    // first source tile whose columns all belong to rows without in-edges (x written by the tiled_const_rows blocks)
   dvec<int32_t> wg_static;    // [n_wg][2] (first, end) static chunk of each phase-1 workgroup
   dvec<uint32_t> tile_row0;   // [nI + 1] destination tile boundaries
   dvec<double> tile_wmax;     // [nI] max over the tile's rows of sum |w| of the row's in-edges (in-degree when unweighted): bounds the tile's partials and row sums
-  dvec<uint32_t> tile_col0;   // [nI + 1] first column (xcol rank) of each destination tile's rows: phase 2 of tile I writes x[tile_col0[I] .. tile_col0[I + 1])
-  std::vector<uint32_t> tile_col0_host;  // the same on the host (tiled_overlap_need)
   dvec<uint32_t> region_off;  // [nI + 2] slot range of region I (multiples of 8); region nI = dummy
   dvec<uint16_t> dstl16;      // [n_slots + pad] tile-local destination of slot (16 bits per slot: tiles of more than 4096 rows)
   dvec<uint32_t> dstl12;      // [n_slots / 8 * 3 + pad] the same packed to 12 bits per slot, 8 slots = 3 dwords (tiles of <= 4096 rows:
@@ -184,29 +180,6 @@ struct tiled_epilogue {
   tiled_const_rows<WT> cr;    // nI_act == 0: off
 };
 
-// Overlap of consecutive iterations: phase 2 of iteration k and phase 1 of iteration k + 1 run at the same time
-// on two streams.  Phase 1 is bound by the CUs (LDS gathers, run scans: the memory system idles through a third of it), phase 2 by the
-// memory system (the CUs idle), and phase 1 of iteration k + 1 needs, for source tile J, only the x entries of that tile -- which the
-// phase-2 workgroups of the few destination tiles whose rows carry those columns wrote.  So: phase 1 is launched with FEWER workgroups
-// than CUs (one workgroup owns a whole CU: its tile fills the LDS), phase 2 of the previous iteration fills the CUs left over, its
-// workgroups store x write-through (sc1), drain, and count themselves into ready[J] of the source tiles they fed; a phase-1 workgroup
-// polls ready[J] (one lane, relaxed) before it loads tile J, then one agent-scope acquire (MI355X_MICROARCH.md, hand-off recipe).
-// The partial buffer is double-buffered (phase 1 of k + 1 writes while phase 2 of k reads), the scalars of an iteration are folded by a
-// one-workgroup launch in phase 2's stream.  Replaces the reference's overlap of communication and compute across
-// num_concurrent_loops streams (prims/detail/per_v_transform_reduce_e.cuh:1845-1906) with an overlap of the two halves of the SpMV.
-struct tiled_ovl {
-  hipStream_t stream{nullptr};     // the stream this launch goes to
-  uint32_t* ready{nullptr};        // [nJ] producers (phase-2 workgroups) that have published into source tile J, monotone over launches
-  uint32_t const* need{nullptr};   // [nJ] producers per launch of phase 2 (tiled_overlap_need)
-  uint32_t launches{0};            // phase 1: overlapped phase-2 launches issued so far: tile J is ready at ready[J] >= need[J] * launches
-  uint32_t* cursor{nullptr};       // phase 1: this launch's chunk cursor (0 on entry) ...
-  uint32_t* cursor_next{nullptr};  // ... and the next launch's, which workgroup 0 rewinds
-  uint32_t* error{nullptr};        // set to 1 when a poll ran into its bound (a bug, not a state: the launch then finishes with stale x)
-  int grid{0};                     // phase 1: workgroups (< CUs: the rest of the chip runs phase 2)
-  bool const_first{false};         // phase 1: take the chunks in tiled_csc_t::chunk_begin_ovl order (the plan leaves the rows without in-edges to
-                                   // tiled_const_rows, so the x of the coldest source tiles is ready first)
-};
-
 // Launches over a PART of the work (multi-GPU PageRank, DESIGN.md section 5: the x exchange in two chunks).  Phase 1's schedule is data -- a list
 // of chunks drawn through a cursor -- so a launch over any subset of the plan's chunks is the same kernel with another list; its partial sums
 // land in the slots they always land in.  Phase 2's workgroup = destination tile, so a launch over a block range is the same kernel with an
@@ -221,20 +194,16 @@ struct tiled_range {
   int first{0}, count{0};  // phase-2 blocks: destination tiles [0, nI or nI_act), then the tiled_const_rows blocks
 };
 
-// need[J] = number of phase-2 workgroups (destination tiles, plus the blocks of tiled_const_rows when `const_rows`) whose columns fall into source tile J
-std::vector<uint32_t> tiled_overlap_need(tiled_csc_t const& t, bool const_rows, int64_t c0, int64_t n_cols);
-
 // phase 1: part[slot of run] = sum over the run's edges of alpha * x[src] (* w).  counters[0] = chunk cursor (0 on entry;
 // phase 2 rewinds it).  `pending` != nullptr: the scalars of the
 // previous phase 2 have not been folded yet -- workgroup 0 does it first (saves a launch per iteration).
 template <typename WT>
 void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha, WT* part, uint32_t* counters, tiled_x_map<WT> const& map,
-                  tiled_epilogue<WT> const* pending, tiled_ovl const* ovl = nullptr, tiled_chunks const* chunks = nullptr);
+                  tiled_epilogue<WT> const* pending, tiled_chunks const* chunks = nullptr);
 
 // phase 2 + fused PageRank epilogue; leaves per-tile scalar partials in e.partials (fold them with the next phase 1 or tiled_finish)
 template <typename WT>
-void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters, tiled_ovl const* ovl = nullptr,
-                  tiled_range const* range = nullptr);
+void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters, tiled_range const* range = nullptr);
 
 // folds e.partials[0 .. n_partials) in a fixed order into e.scal (or e.totals).  init_prev >= 0: this is the fold of the
 // iteration-0 state (tiled_prologue visited every row); scal->base_prev becomes init_prev, the rows' initial value
@@ -298,15 +267,13 @@ constexpr double kFxMagic          = 6755399441055744.0;       // 1.5 * 2^52
 constexpr unsigned long long kFxMagicBits = 0x4338000000000000ull;
 __device__ __forceinline__ void tiled_tile_scale(double bound, double* scale, double* inv)
 {
+  // 2^kk, kk = 50 - e with bound = m * 2^e, 0.5 <= m < 1 (frexp), straight from the exponent field: every phase-2 workgroup starts with this
+  // (the frexp / ldexp library calls of round 5 sat on its critical path; same values bit for bit, denormal bounds clamp to 2^900 as before)
   int kk = 0;
-  if (bound > 0.0 && bound < 1.0e300) {
-    int e;
-    (void)frexp(bound, &e);  // bound < 2^e
-    kk = 50 - e;
-  }
+  if (bound > 0.0 && bound < 1.0e300) kk = 50 - ((int)((unsigned long long)__double_as_longlong(bound) >> 52) - 1022);
   kk     = max(-900, min(900, kk));
-  *scale = ldexp(1.0, kk);
-  *inv   = ldexp(1.0, -kk);
+  *scale = __longlong_as_double((long long)(1023 + kk) << 52);
+  *inv   = __longlong_as_double((long long)(1023 - kk) << 52);
 }
 __device__ __forceinline__ unsigned long long tiled_to_fixed(float v, double scale)
 {

@@ -189,6 +189,11 @@ class ResourceHandle:
     def kernel_timing(self, on: bool):
         capi.lib().cugraph_amd_kernel_timing_enable(self.c_resource_handle_ptr, 1 if on else 0)
 
+    def kernel_timing_region(self, family: str, begin: bool):
+        """one HIP-event pair around a region of work on the handle's stream (read it with kernel_timing_get(family))"""
+        l = capi.lib()
+        (l.cugraph_amd_kernel_timing_region_begin if begin else l.cugraph_amd_kernel_timing_region_end)(self.c_resource_handle_ptr, family.encode())
+
     def kernel_timing_reset(self):
         capi.lib().cugraph_amd_kernel_timing_reset(self.c_resource_handle_ptr)
 
@@ -631,10 +636,6 @@ class PageRankPlan:
         assert_success(code, err, "cugraph_amd_pagerank_plan_step")
         self.iterations += int(done.value)
         return int(done.value), bool(conv.value)
-
-    def overlap(self):
-        """phase-1 workgroups of an overlapped fixed-count step (0: the iterations run one after the other)"""
-        return int(capi.lib().cugraph_amd_pagerank_plan_overlap(self.ptr))
 
     def result(self, converged=False):
         l = capi.lib()

@@ -48,10 +48,6 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_plan_result(
   cugraph_amd_pagerank_plan_t* plan, size_t total_iterations, bool_t converged,
   cugraph_centrality_result_t** result, cugraph_error_t** error);
 CUGRAPH_EXPORT void cugraph_amd_pagerank_plan_free(cugraph_amd_pagerank_plan_t* plan);
-/* How the plan runs a fixed number of iterations (epsilon == 0, >= 2 iterations per step call): 0 = one after the other on the handle's
- * stream; n > 0 = overlapped -- the edge pass of iteration k + 1 runs on n workgroups beside the row reduction of iteration k on the other
- * CUs.  Chosen at plan creation from the graph's size (CUGRAPH_AMD_PR_OVERLAP overrides). */
-CUGRAPH_EXPORT int32_t cugraph_amd_pagerank_plan_overlap(const cugraph_amd_pagerank_plan_t* plan);
 
 
 /* Multi-GPU PageRank, one process per GPU (1-D partition by destination; design in DESIGN.md section 5).
@@ -244,6 +240,11 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_kernel_timing_get(
   const cugraph_resource_handle_t* handle, const char* family, size_t* launches, double* total_ms,
   cugraph_error_t** error);
 CUGRAPH_EXPORT void cugraph_amd_kernel_timing_reset(const cugraph_resource_handle_t* handle);
+/* One event pair around a whole region of work on the handle's stream, independent of kernel_timing_enable: begin() records the start event,
+ * end() the stop event; cugraph_amd_kernel_timing_get(family) then reports them like one launch.  bench.py brackets its timed iterations this
+ * way, with the per-launch events off: nothing but the kernels sits between the two events or inside the wall clock. */
+CUGRAPH_EXPORT void cugraph_amd_kernel_timing_region_begin(const cugraph_resource_handle_t* handle, const char* family);
+CUGRAPH_EXPORT void cugraph_amd_kernel_timing_region_end(const cugraph_resource_handle_t* handle, const char* family);
 
 /* Graph introspection used by the tests (sizes, degree-class boundaries of the CSC/CSR row schedule). */
 CUGRAPH_EXPORT size_t cugraph_amd_graph_num_vertices(const cugraph_graph_t* graph);

@@ -29,10 +29,11 @@ def test_bench_line_contract():
     assert r["algorithmic_bytes_per_launch"] == 4 * ne + 16 * nv + 4
     if "frac_basis" in r:  # round 5: priced on the wall clock of the timed region (the two kernels of consecutive iterations may overlap)
         assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
-        if r.get("frac_kernels") is not None:  # serial iterations: the kernels' own time cannot exceed the step
+        if r.get("region_event_ms_per_step") is not None:  # round 6: one event pair around the timed steps; the phase averages come from a second pass
+            assert r["region_event_ms_per_step"] <= d["ms_per_step"] * 1.001      # the stream's own clock cannot exceed the host's around it
+            assert r["avg_kernel_ms"] <= d["ms_per_step"] * 1.05                  # another pass of the same steps: run-to-run spread only
+        elif r.get("frac_kernels") is not None:  # round 5: events inside the timed pass: the kernels' own time cannot exceed the step
             assert r["frac_kernels"] >= r["frac"] - 1e-3 and r["avg_kernel_ms"] <= d["ms_per_step"] * 1.001
-        else:
-            assert r.get("overlap")
     else:
         assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
     assert abs(d["value"] - ne / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3   # MTEPS = E * iterations / time

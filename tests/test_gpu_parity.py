@@ -1663,50 +1663,6 @@ def test_pagerank_phase1_schedules_agree(cg, handle, orc, monkeypatch, chunk, st
     assert abs(float(got.sum()) - 1.0) <= 1e-5
 
 
-@pytest.mark.parametrize("scale,grid,mask,tile,chunk,weighted", [
-    (14, 200, False, 256, 1, False), (14, 248, True, 1024, 3, True), (16, 224, False, 0, 2, False), (18, 192, True, 4096, 4, False),
-    (20, 208, False, 0, 8, False), (20, 216, True, 8192, 16, True)])
-def test_pagerank_overlapped_iterations_are_bit_identical(cg, handle, orc, monkeypatch, scale, grid, mask, tile, chunk, weighted):
-    """Round 5: phase 2 of iteration k beside phase 1 of iteration k + 1 (two streams, per-source-tile ready counters, x stored
-    write-through, double-buffered partials).  The arithmetic is the serial path's (fixed-point row sums are order-independent), so
-    every vector must equal the serial plan's bit for bit -- also across several step() calls on one plan (the counters are monotone
-    over launches) -- and the oracle's within the PageRank tolerance."""
-    import torch
-
-    monkeypatch.setenv("CUGRAPH_AMD_PAGERANK_KERNEL", "tiled")
-    monkeypatch.setenv("CUGRAPH_AMD_TILED_REBUILD", "1")
-    monkeypatch.setenv("CUGRAPH_AMD_TP_CHUNK", str(chunk))
-    monkeypatch.setenv("CUGRAPH_AMD_TP_STATIC_FRAC", "0")  # the overlapped launch draws every chunk from the queue
-    nv = 1 << scale
-    s, d = rmat_graph(orc, scale, seed=3)
-    w = int_weights(s.size, seed=4) if weighted else None
-    prev = handle.set_pagerank_hot_tile(tile if tile else -1)
-    try:
-        g = make_graph(cg, handle, s, d, w, transposed=True, renumber=True, vertices=np.arange(nv))
-        monkeypatch.setenv("CUGRAPH_AMD_PR_OVERLAP", "0")
-        serial = cg.PageRankPlan(handle, g, 0.85)
-        monkeypatch.setenv("CUGRAPH_AMD_PR_OVERLAP", str(grid))
-        if mask:
-            monkeypatch.setenv("CUGRAPH_AMD_PR_OVERLAP_MASK", "1")
-        ovl = cg.PageRankPlan(handle, g, 0.85)
-        total = 0
-        for n in (5, 1, 2, 7):  # n = 1 takes the serial kernels on the overlapped plan: the two kinds of launches must interleave
-            serial.step(n)
-            ovl.step(n)
-            total += n
-            va, a, _ = serial.result()
-            vb, b, _ = ovl.result()
-            assert torch.equal(va, vb)
-            assert torch.equal(a, b), f"after {total} iterations"
-    finally:
-        handle.set_pagerank_hot_tile(prev)
-    off, idx, ww = orc.coo_to_cs(nv, d, s, None if w is None else w.astype(np.float32))
-    truth, _, _ = orc.pagerank(nv, off, idx, ww, 0.85, 0.0, total, acc64=True)
-    got = by_vertex(vb, b)[0]
-    assert np.max(np.abs(got - truth)) <= 1e-6
-    assert np.max(np.abs(got - truth) / truth) <= 2e-5
-
-
 @pytest.mark.parametrize("scale,align,tile,weighted", [(14, 16, 256, False), (16, 32, 1024, True), (18, 32, 0, False), (18, 64, 4096, False), (20, 16, 0, True)])
 def test_pagerank_aligned_slot_blocks_give_the_same_bits(cg, handle, orc, monkeypatch, scale, align, tile, weighted):
     """Round 5: every (destination tile, source tile) block of the partial buffer on its own cache lines (CUGRAPH_AMD_TILED_BLOCK_ALIGN slots,

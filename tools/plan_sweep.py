@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--scale", type=int, default=26)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--trim", action="store_true", help="hand the pool's cached blocks back to the driver before every plan build")
     ap.add_argument("variants", nargs="*", help='e.g. "base" "CUGRAPH_AMD_TP_TAIL_FRAC=0.1,CUGRAPH_AMD_TP_TAIL_CHUNK=2"')
     args = ap.parse_args()
     import torch
@@ -38,6 +39,10 @@ def main():
             sets = [kv.split("=", 1) for kv in v.split(",") if "=" in kv]
             for k, val in sets:
                 os.environ[k] = val
+            if args.trim:
+                from cugraph_amd import _capi as capi
+
+                capi.lib().cugraph_amd_memory_pool_trim()
             t0 = time.perf_counter()
             plan = cg.PageRankPlan(h, g, 0.85)
             h.sync()
