@@ -31,7 +31,7 @@ class GraphPropertiesStruct(C.Structure):
 
 class TraversalStats(C.Structure):
     _fields_ = [("steps", C.c_uint64), ("edges_inspected", C.c_uint64), ("vertices_reached", C.c_uint64),
-                ("edges_of_reached", C.c_uint64)]
+                ("edges_of_reached", C.c_uint64), ("probes", C.c_uint64)]
 
 
 def build(verbose: bool = False) -> Path:
@@ -191,6 +191,7 @@ PROTOTYPES = {
     "cugraph_amd_traversal_mg_plan_last_degree_sums": (C.c_int, [_P, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), _PP]),
     "cugraph_amd_traversal_mg_plan_results": (C.c_int, [_P, _P, _P, _PP]),
     "cugraph_amd_traversal_mg_plan_keep_buffers": (None, [_P, C.c_int]),
+    "cugraph_amd_traversal_mg_plan_rebind": (None, [_P, _P]),
     "cugraph_amd_traversal_mg_plan_free": (None, [_P]),
     "cugraph_amd_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _PP, _PP]),
     "cugraph_amd_comm_free": (None, [_P]),

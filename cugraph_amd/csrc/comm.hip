@@ -430,6 +430,10 @@ static std::unique_ptr<comm_t> attach_session(char const* session, int rank, int
   // A crashed job may have left a segment of this name behind.  Rank 0 unlinks and re-creates it; a rank that starts BEFORE rank 0 must not
   // settle on the old one: it trusts a segment only while the process that created it is alive (pid0), and while it waits in the first
   // barrier it keeps checking that the name still leads to the file it mapped -- if rank 0 has re-created the session meanwhile, it moves over.
+  auto pid_namespace = [] {  // inode of this process's PID namespace (0: not available)
+    struct stat st;
+    return stat("/proc/self/ns/pid", &st) == 0 ? (uint64_t)st.st_ino : (uint64_t)0;
+  };
   auto still_linked = [&](int fd) {
     struct stat a, b;
     std::string const path = "/dev/shm" + name;
@@ -446,6 +450,7 @@ static std::unique_ptr<comm_t> attach_session(char const* session, int rank, int
     std::memset(m, 0, sizeof(comm_shm_t));
     c->shm->size = (uint32_t)size;
     c->shm->pid0 = (uint32_t)getpid();
+    c->shm->pidns0 = pid_namespace();
     c->shm->ready.store(kCommMagic, std::memory_order_release);
     c->shm->attached.fetch_add(1);
     c->host_barrier();
@@ -474,8 +479,15 @@ static std::unique_ptr<comm_t> attach_session(char const* session, int rank, int
       usleep(1000);
     }
     if (!stale) {
+      // the creator is gone: a crashed job's segment.  "Gone" can only be read off the pid by a rank that shares the creator's PID namespace; across
+      // namespaces (a container per GPU over one /dev/shm) the pid is invisible although its process lives, and the segment is trusted as long as the
+      // name still leads to it (still_linked, re-checked inside the first barrier's wait): rank 0 unlinks a crashed job's segment before it creates its own
       uint32_t const creator = c->shm->pid0;
-      stale = creator == 0 || (kill((pid_t)creator, 0) != 0 && errno == ESRCH);  // the creator is gone: a crashed job's segment
+      uint64_t const ns = c->shm->pidns0, my_ns = pid_namespace();
+      bool const same_ns = ns != 0 && ns == my_ns;
+      stale = creator == 0 || (same_ns && kill((pid_t)creator, 0) != 0 && errno == ESRCH) || !still_linked(c->shm_fd);
+      // an abort flag that is set before this rank has even attached is a crashed job's (rank 0 creates a session with the flag clear)
+      stale = stale || c->shm->abort_flag.load(std::memory_order_relaxed) != 0;
     }
     if (stale) {
       drop();
@@ -494,7 +506,11 @@ static std::unique_ptr<comm_t> attach_session(char const* session, int rank, int
     }
     int spins = 0;
     while (c->shm->bar_gen.load(std::memory_order_acquire) == gen) {
-      if (c->shm->abort_flag.load(std::memory_order_relaxed)) throw api_error(CUGRAPH_UNKNOWN_ERROR, "communicator: a peer aborted");
+      if (c->shm->abort_flag.load(std::memory_order_relaxed)) {
+        // (a crashed job leaves its abort flag set: a segment the name no longer leads to is that job's, not a peer's verdict -- move over to rank 0's new one)
+        if (!still_linked(c->shm_fd)) { stale = true; break; }
+        throw api_error(CUGRAPH_UNKNOWN_ERROR, "communicator: a peer aborted");
+      }
       if (++spins > 200) sched_yield();
       if ((spins & 1023) == 0) {
         if (!still_linked(c->shm_fd)) { stale = true; break; }  // rank 0 has re-created the session under our feet

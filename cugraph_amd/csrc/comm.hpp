@@ -38,7 +38,10 @@ struct comm_shm_t {  // lives in the POSIX shm segment
   std::atomic<uint32_t> abort_flag;
   std::atomic<uint32_t> attached;
   uint32_t pid0;  // process id of the rank 0 that created the segment: a segment whose creator is gone is a crashed job's (comm.hip: attach_session)
-  uint32_t pad_[9];
+  uint32_t pad0_;
+  uint64_t pidns0;  // inode of the creator's PID namespace (/proc/self/ns/pid; 0: unknown): pid0 means something only to a rank in the SAME namespace
+                    // (one container per GPU sharing /dev/shm: the creator's pid is invisible there and must not be read as "gone")
+  uint32_t pad_[6];
   unsigned char slots[kCommMaxRanks][kCommSlotBytes];
 };
 

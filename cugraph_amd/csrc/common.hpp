@@ -270,16 +270,6 @@ struct mg_graph_t;   // mg_graph.hpp
 // destination for CSC (store_transposed = true).  Neighbour lists ascending, multi-edges kept.
 // Rows are processed through a degree-descending schedule: row_order == nullptr means rows are already
 // numbered by descending degree (renumber = TRUE, primary orientation).
-// Delta-stepping copy of an orientation for SSSP (traversal.hip): inside every row the LIGHT edges (w <= delta) come first.
-// indices / weights are permuted copies (stable inside the light and the heavy part), light_end[v] = position of row v's first
-// heavy edge.  Built on the first SSSP that asks for the light / heavy path (opt-in, see run_sssp), cached like the tiled structure.
-struct sssp_lh_t {
-  double delta{0};
-  dvec<int32_t> indices;
-  dev_buf weights;
-  dvec<int32_t> light_end;
-};
-
 struct orientation_t {
   bool built{false};
   dvec<int32_t> offsets;    // V + 1
@@ -297,7 +287,9 @@ struct orientation_t {
   dvec<uint32_t> rowstart_bits;
   // column-tiled re-blocking of this orientation (built lazily by the PageRank plan, cached for later calls)
   std::shared_ptr<tiled_csc_t> tiled;
-  std::shared_ptr<sssp_lh_t> lh;
+  // row (major id) of every edge position: built lazily by the first SSSP whose frontier holds a large share of the graph's edges
+  // (k_sssp_sweep streams the whole edge list then: 4 more bytes per edge position, no row gathers); E + pad or empty
+  dvec<int32_t> edge_rows;
 };
 
 constexpr int32_t kSegThreshold[orientation_t::n_seg] = {4096, 64, 16, 4, 1};

@@ -117,67 +117,6 @@ __global__ void __launch_bounds__(TV_BLOCK) k_bfs_expand_big(int32_t const* bigq
   f.flush();
 }
 
-// Parents of the vertices a TOP-DOWN level has just discovered, pulled from their in-edges (round 5): the first in-neighbour -- ascending
-// internal id -- that was visited before the level started.  Such a neighbour sits exactly one level up (a shallower one would have given
-// the vertex a smaller depth), so this is the rule of the push with atomicMin (smallest internal id among the frontier parents) and of the
-// bottom-up levels, evaluated per DISCOVERED vertex (10^4-10^5 in the levels that run top-down) instead of per inspected edge: the push
-// then does nothing for the parents (it reads pred[v] for every edge into a not yet visited vertex and atomicMins most of them:
-// +0.2 ms per BFS at RMAT-24).  Measured slower than that (see run_bfs) and therefore opt-in; kept under test.  One wavefront per vertex, 64 neighbours per step, ballot early exit; rows above BFS_PULL_LONG in-edges go to
-// a list that k_bfs_pull_parents_long scans with a workgroup per row (no single wavefront walks a 10^6-entry row).
-constexpr int32_t BFS_PULL_LONG = 8192;
-__global__ void __launch_bounds__(TV_BLOCK) k_bfs_pull_parents(int32_t const* q, counters_t* cnt, int32_t const* in_off, int32_t const* in_idx, uint32_t const* vis_prev,
-                                                               int32_t* pred, int32_t* longq)
-{
-  uint32_t const n = cnt->n_next;  // the level's expansion kernels have completed (stream order): the queue's final size
-  int const lane = threadIdx.x & 63;
-  uint32_t const gwave = (uint32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (uint32_t)(((int64_t)gridDim.x * blockDim.x) >> 6);
-  for (uint32_t i = gwave; i < n; i += nwaves) {
-    int32_t const v = q[i];
-    eoff_t const b = eoff(in_off, v), e = eoff(in_off, v + 1);
-    if (e - b > (eoff_t)BFS_PULL_LONG) {
-      if (lane == 0) longq[atomicAdd(&cnt->n_set, 1u)] = v;
-      continue;
-    }
-    int32_t best = INT32_MAX;
-    for (eoff_t p0 = b; p0 < e; p0 += 64) {
-      eoff_t const p = p0 + lane;
-      int32_t const u = p < e ? in_idx[p] : -1;
-      bool const hit  = u >= 0 && ((vis_prev[(uint32_t)u >> 5] >> ((uint32_t)u & 31u)) & 1u);
-      uint64_t const m = __ballot(hit);
-      if (m) { best = __shfl(u, __ffsll((unsigned long long)m) - 1); break; }
-    }
-    if (lane == 0) pred[v] = best;
-  }
-}
-__global__ void __launch_bounds__(TV_BLOCK) k_bfs_pull_parents_long(int32_t const* longq, counters_t const* cnt, int32_t const* in_off, int32_t const* in_idx,
-                                                                    uint32_t const* vis_prev, int32_t* pred)
-{  // one workgroup per long row at a time: its wavefronts take the row's 64-entry chunks round-robin (ascending), the position of the
-   // earliest hit is kept in LDS and ends the scan of every wavefront that has passed it
-  __shared__ uint32_t s_best;
-  uint32_t const n = cnt->n_set;
-  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
-    int32_t const v = longq[k];
-    eoff_t const b = eoff(in_off, v), e = eoff(in_off, v + 1);
-    if (threadIdx.x == 0) s_best = 0xFFFFFFFFu;
-    __syncthreads();
-    for (eoff_t p0 = b + (eoff_t)wave * 64; p0 < e; p0 += (eoff_t)TV_WAVES * 64) {
-      if (p0 - b > *reinterpret_cast<volatile uint32_t*>(&s_best)) break;  // (wave-uniform: an LDS word)
-      eoff_t const p = p0 + lane;
-      int32_t const u = p < e ? in_idx[p] : -1;
-      bool const hit  = u >= 0 && ((vis_prev[(uint32_t)u >> 5] >> ((uint32_t)u & 31u)) & 1u);
-      uint64_t const m = __ballot(hit);
-      if (m) {
-        if (lane == 0) atomicMin(&s_best, (uint32_t)(p0 - b) + (uint32_t)(__ffsll((unsigned long long)m) - 1));
-        break;
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) pred[v] = s_best != 0xFFFFFFFFu ? in_idx[b + s_best] : INT32_MAX;
-    __syncthreads();
-  }
-}
-
 // front <- snapshot of the visited set (an unvisited vertex cannot have an in-neighbour that was visited before the
 // latest level, so testing against everything visited so far is the same as testing against the frontier);
 // vis_prev <- vis_new
@@ -270,6 +209,18 @@ template <> struct dist_bits<double> {
   static __device__ __forceinline__ double from(unsigned long long b) { return __longlong_as_double((long long)b); }
 };
 
+// The distance filter of a wide relaxation round (round 6).  What bounds such a round is not bytes but REQUESTS: every edge probes the
+// tentative distance of its destination -- 4 or 8 bytes at a random place of a 64 / 128 MB array (RMAT-24) that the 4 MiB L2 of an XCD cannot
+// hold, so each probe is a request to the fabric (66-85 G probes/s whatever the schedule, profiles/r5*), and 2.26 of them per edge fail.  The filter is one BIT per vertex,
+// fbits[v] = (d[v] < T) for a threshold T chosen per round (sssp_filter_pick): 2 MB at RMAT-24, L2-resident.  A relaxation with candidate
+// nd >= T into a vertex whose bit is set cannot succeed (d only decreases, so d[v] < T <= nd still holds; strictly, so the lexicographic
+// (distance, parent) minimum cannot change either) and is dropped BEFORE the probe.  Exact for any T; T only decides how much is filtered.
+template <typename WT>
+struct sssp_filter {
+  uint32_t const* bits{nullptr};  // nullptr: no filter in this round
+  WT const* t{nullptr};           // the threshold the bits were built with (device-resident: chosen by a kernel, no host round trip)
+};
+
 template <typename WT>
 struct sssp_state {
   using bits_t = typename dist_bits<WT>::type;
@@ -279,94 +230,105 @@ struct sssp_state {
   int32_t* far;        // far pile
   uint32_t* mark_near; // last relax round in which the vertex entered q_next
   uint32_t* mark_far;  // last far epoch in which the vertex entered the far pile
-  int32_t* q_set;      // light / heavy buckets: every vertex that entered the near frontier of the current bucket, once (nullptr: off)
-  uint32_t* mark_set;  // ... its membership marks (set epoch)
-  uint32_t set_epoch;
   counters_t* cnt;
   WT threshold;        // near / far split
   WT cutoff;
   uint32_t round;
   uint32_t far_epoch;
   int32_t const* out_offsets;  // CSR offsets: the out-degrees of the vertices that enter the near frontier are summed (counters_t::out_edges):
-                               // the host knows the next round's edge count without a pass over the queue (pull rounds are chosen by it)
+                               // the host knows the next round's edge count without a pass over the queue
   // fp32 with predecessors (sssp_relax<WT, true>): (distance bits << 32 | external id of the parent) per vertex, lowered by ONE 64-bit
   // atomicMin -- the reference's reduction, a lexicographic minimum over (distance, predecessor) (sssp_impl.cuh:334), in the relaxation itself
   // instead of a sweep over the settled edges afterwards; `dist` is not used then
   unsigned long long* pk{nullptr};
   int32_t const* labels{nullptr};  // internal -> external id (nullptr: identity)
   int32_t source{-1};              // keeps its parent -1 whatever reaches it at distance 0
+  sssp_filter<WT> flt{};
+  void const* du_src{nullptr};  // k_sssp_sweep: where a row's own distance is read from (a snapshot taken before the round; nullptr: the live words)
+  int32_t hot_cache{1};  // the two-stage kernels keep a per-workgroup minimum per hot destination (sssp_two_stage::dominated); 0: off (A/B)
 };
 __device__ __forceinline__ uint32_t pk_dist_bits(unsigned long long const* pk, int32_t v) { return reinterpret_cast<uint32_t const*>(pk)[2 * (size_t)v + 1]; }
+// parent labels inside the packed word are biased so that the UNSIGNED order of the word is the signed order of the external ids (a negative
+// external id must not lose against every non-negative one: the sweep and the fp64 path take a signed minimum); k_sssp_unpack removes the bias
+__device__ __forceinline__ uint32_t pk_label(int32_t label) { return (uint32_t)label ^ 0x80000000u; }
+constexpr unsigned long long kPkNoParent = 0xFFFFFFFFull;  // low word of a vertex nobody has reached through an edge (the source keeps it)
 
 template <typename WT, bool PK = false>
 struct sssp_relax {
   static_assert(!PK || sizeof(WT) == 4, "the packed (distance, parent) word holds an fp32 distance");
   sssp_state<WT> s;
-  wave_queue wq_near, wq_far, wq_set;
+  wave_queue wq_near, wq_far;
+  WT ft{0};                      // filter threshold (read once per workgroup; meaningless without s.flt.bits)
   unsigned long long deg_acc{0};
+  unsigned long long probes{0};  // relaxations that went on to probe the destination's distance (reported as counters_t::in_edges)
+  __device__ __forceinline__ void begin() { if (s.flt.bits) ft = *s.flt.t; }
   __device__ __forceinline__ void count_near(bool near, int32_t v)
   {
     if (near && s.out_offsets) deg_acc += (unsigned long long)(eoff(s.out_offsets, v + 1) - eoff(s.out_offsets, v));
   }
   __device__ __forceinline__ void flush()
   {
-    wq_near.flush(); wq_far.flush(); wq_set.flush();
-    unsigned long long a = deg_acc;
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    wq_near.flush(); wq_far.flush();
+    unsigned long long a = deg_acc, b = probes;
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
     if ((threadIdx.x & 63) == 0 && a) atomicAdd(&cnt_replica(s.cnt)->out_edges, a);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&cnt_replica(s.cnt)->in_edges, b);
   }
   __device__ __forceinline__ void operator()(int32_t u, int32_t v, eoff_t p)
-  {
-    if constexpr (PK) {  // (the one-edge-at-a-time expansion: the phased form below, called in sequence)
-      cand_t const c = pre(u, v, p);
-      tok_t const t  = mid(v, c);
-      post(u, v, c, t, mid2(v, c, t));
-      return;
-    }
-    using B  = dist_bits<WT>;
-    WT du    = B::from(s.dist[u]);
-    WT nd    = du + s.weights[p];
-    bool near = false, far = false, fresh = false;
-    // agent-scope load: bypasses the per-CU vector cache, so once a hub has been lowered the other relaxations of this
-    // round see it and skip the atomic (a plain load keeps reading the stale value from L1 and every edge into the hub
-    // issues an atomicMin)
-    if (nd < s.cutoff && nd < B::from(__hip_atomic_load(&s.dist[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-      auto old = atomicMin(&s.dist[v], B::to(nd));
-      if (B::to(nd) < old) {  // this relaxation lowered d[v]
-        if (nd < s.threshold) {
-          near = atomicExch(&s.mark_near[v], s.round) != s.round;
-          if (s.q_set && near) fresh = atomicExch(&s.mark_set[v], s.set_epoch) != s.set_epoch;
-        } else {
-          far = atomicExch(&s.mark_far[v], s.far_epoch) != s.far_epoch;
-        }
-      }
-    }
-    count_near(near, v);
-    wq_near.push(near, v);
-    wq_far.push(far, v);
-    if (s.q_set) wq_set.push(fresh, v);  // (wave-uniform condition)
+  {  // the one-edge-at-a-time expansion: the phased form below, called in sequence
+    cand_t const c = pre(u, v, p);
+    tok_t const t  = mid(v, c);
+    post(u, v, c, t, mid2(v, c, t));
   }
-  // the phased form of the same relaxation (expand_*_mlp: EX_U edges in flight per lane)
+  // the phased form of the relaxation (expand_*_mlp: EX_U edges in flight per lane)
   struct cand_t { WT nd; bool pass; unsigned long long word; };  // word: the packed candidate (PK only)
   using tok_t = typename std::conditional<PK, unsigned long long, typename dist_bits<WT>::type>::type;
-  __device__ __forceinline__ cand_t pre(int32_t u, int32_t v, eoff_t p) const
-  {  // branch-free: the loads of the EX_U edges of a step go out together.  d[v] is read with an agent-scope load: L2-served, so once a
+  // true: the relaxation cannot succeed, decided from the L2-resident bit (sssp_filter)
+  __device__ __forceinline__ bool filtered(int32_t vv, WT nd) const
+  {
+    if (!s.flt.bits) return false;  // (wave-uniform)
+    uint32_t const w = s.flt.bits[(uint32_t)vv >> 5];
+    return ((w >> ((uint32_t)vv & 31u)) & 1u) != 0u && nd >= ft;
+  }
+  __device__ __forceinline__ cand_t pre(int32_t u, int32_t v, eoff_t p)
+  {  // the loads of the EX_U edges of a step go out together.  d[v] is read with an agent-scope load: L2-served, so once a
      // hub has been lowered the other relaxations of this round see it and skip the atomic (a non-temporal load is L2-served too, but
      // its lines are not retained: 14.0 ms instead of 10.4 per SSSP at RMAT-24)
     using B = dist_bits<WT>;
+    int32_t const uu = u < 0 ? 0 : u, vv = v < 0 ? 0 : v;
     if constexpr (PK) {
-      int32_t const uu = u < 0 ? 0 : u, vv = v < 0 ? 0 : v;
       WT const nd = B::from(pk_dist_bits(s.pk, uu)) + s.weights[p];
-      unsigned long long const word = ((unsigned long long)B::to(nd) << 32) | (uint32_t)(s.labels ? s.labels[uu] : uu);
-      unsigned long long const cur  = __hip_atomic_load(&s.pk[vv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long const word = ((unsigned long long)B::to(nd) << 32) | pk_label(s.labels ? s.labels[uu] : uu);
+      bool const go = (v >= 0) & (v != s.source) & (nd < s.cutoff) && !filtered(vv, nd);
+      unsigned long long cur = 0ull;
+      if (go) cur = __hip_atomic_load(&s.pk[vv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      probes += go ? 1ull : 0ull;
       // strictly smaller (distance, parent): a shorter distance, or the same distance through a parent with a smaller external id
-      bool const pass = (v >= 0) & (v != s.source) & (nd < s.cutoff) & (word < cur);
-      return cand_t{nd, pass, word};
+      return cand_t{nd, go && word < cur, word};
     } else {
-      WT const nd = B::from(s.dist[u < 0 ? 0 : u]) + s.weights[p];
-      WT const dv = B::from(__hip_atomic_load(&s.dist[v < 0 ? 0 : v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      bool const pass = (v >= 0) & (nd < s.cutoff) & (nd < dv);
-      return cand_t{nd, pass, 0ull};
+      WT const nd = B::from(s.dist[uu]) + s.weights[p];
+      bool const go = (v >= 0) & (nd < s.cutoff) && !filtered(vv, nd);
+      WT dv = WT(0);
+      if (go) dv = B::from(__hip_atomic_load(&s.dist[vv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      probes += go ? 1ull : 0ull;
+      return cand_t{nd, go && nd < dv, 0ull};
+    }
+  }
+  // the probe of a candidate that has passed the cheap tests already (sssp_two_stage::drain); v < 0: no candidate
+  __device__ __forceinline__ cand_t probe(int32_t v, WT nd, uint32_t biased_label)
+  {
+    using B       = dist_bits<WT>;
+    bool const go = v >= 0;
+    probes += go ? 1ull : 0ull;
+    if constexpr (PK) {
+      unsigned long long const word = ((unsigned long long)B::to(nd) << 32) | biased_label;
+      unsigned long long cur = 0ull;
+      if (go) cur = __hip_atomic_load(&s.pk[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return cand_t{nd, go && word < cur, word};
+    } else {
+      WT dv = WT(0);
+      if (go) dv = B::from(__hip_atomic_load(&s.dist[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      return cand_t{nd, go && nd < dv, 0ull};
     }
   }
   __device__ __forceinline__ tok_t mid(int32_t v, cand_t c) const
@@ -390,154 +352,517 @@ struct sssp_relax {
   __device__ __forceinline__ void post(int32_t, int32_t v, cand_t, tok_t, tok2_t won)
   {
     bool const near = won == 1u, far = won == 2u;
-    bool fresh = false;
-    if (s.q_set && near) fresh = atomicExch(&s.mark_set[v], s.set_epoch) != s.set_epoch;
     count_near(near, v);
     wq_near.push(near, v);
     wq_far.push(far, v);
-    if (s.q_set) wq_set.push(fresh, v);
   }
 };
 
-// A PULL relaxation round: every row of the CSC scans its in-edges and relaxes the ones whose source sits in the frontier bitmap
-// (sssp_impl.cuh:412-561 always pushes).  For the round right after the source -- a few ten thousand hubs whose out-edges are a third of the
-// graph -- a push round is 79 M relaxations at 24-31 G/s (RMAT-24; most of them SUCCEED: an atomicMin, a mark exchange and a queue append
-// each, on random lines); the pull round streams the in-edges once (8 bytes each), tests a bitmap that sits in L2, reads d[u] of the few
-// frontier members from L2 and updates d[row] next to where its neighbours on the other lanes update it.  Same fixed point: relaxation
-// order does not matter.  The adapter swaps the roles for sssp_relax: relax(u = in-neighbour, v = row, position in the CSC).
-template <typename WT>
-struct sssp_pull_fn {
-  sssp_relax<WT> inner;
-  uint32_t const* fbits;
-  __device__ __forceinline__ void operator()(int32_t row, int32_t nbr, eoff_t p)
-  {
-    if ((fbits[(uint32_t)nbr >> 5] >> ((uint32_t)nbr & 31u)) & 1u) inner(nbr, row, p);
-  }
-  __device__ __forceinline__ void flush() { inner.flush(); }
-};
-
-__global__ void k_queue_to_bits(int32_t const* q, int64_t n, uint32_t* bits)
-{
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) { int32_t const v = q[i]; atomicOr(&bits[(uint32_t)v >> 5], 1u << ((uint32_t)v & 31u)); }
-}
-
-// The rows of fewer than big_deg in-edges: a wavefront takes 64 consecutive vertices; a lane scans its own row when it is shorter than 64
-// (16-byte index loads, four probes of the frontier bitmap per step), longer rows are walked by the whole wavefront; a row's candidate
-// distances are reduced in registers and the vertex is updated ONCE, by its only writer in this kernel -- no atomic on d[]: the edges stream
-// at the rate of the bottom-up BFS levels instead of the 40-70 G edges/s of the frontier expansion.  Rows of big_deg or more in-edges go to
-// bigq in BIG_SEG-edge segments for k_sssp_pull_big (which relaxes through sssp_relax: several workgroups share such a row).
-template <typename WT>
-__global__ void __launch_bounds__(TV_BLOCK) k_sssp_pull_rows(int32_t const* in_offsets, int32_t const* in_indices, WT const* in_weights, int64_t nv, uint32_t const* fbits,
-                                                             int32_t* bigq, sssp_state<WT> s, int32_t big_deg)
+template <typename WT, bool PK = false>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices, int32_t* bigq, sssp_state<WT> s,
+                                                          int32_t big_deg)
 {
   __shared__ wave_queue_storage<2> wqs;
   wqs.init();
-  wave_queue wq_near(wqs, 0, s.q_next, &s.cnt->n_next), wq_far(wqs, 1, s.far, &s.cnt->n_far);
-  using B              = dist_bits<WT>;
-  int const lane       = threadIdx.x & 63;
-  int64_t const gwave  = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  int64_t const nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  int64_t const ngroup = (nv + 63) >> 6;
-  WT const inf         = std::numeric_limits<WT>::max();
-  unsigned long long deg_acc = 0;
-  auto in_front = [&](int32_t u) { return ((fbits[(uint32_t)u >> 5] >> ((uint32_t)u & 31u)) & 1u) != 0; };
-  for (int64_t grp = gwave; grp < ngroup; grp += nwaves) {
-    int64_t const v = grp * 64 + lane;
-    eoff_t b    = 0;
-    int32_t len = 0;
-    if (v < nv) { b = eoff(in_offsets, v); len = (int32_t)(eoff(in_offsets, v + 1) - b); }
-    bool const big = len >= big_deg;
-    if (big) {
-      uint32_t const nseg = ((uint32_t)len + BIG_SEG - 1) / BIG_SEG;
-      uint32_t const at   = atomicAdd(&s.cnt->n_big, nseg);
-      for (uint32_t sgm = 0; sgm < nseg; ++sgm) { bigq[2 * (at + sgm)] = (int32_t)v; bigq[2 * (at + sgm) + 1] = (int32_t)sgm; }
-    }
-    WT best = inf;
-    bool const own = len > 0 && len < 64;
-    int32_t longest = own ? len : 0;
-    for (int o = 32; o > 0; o >>= 1) longest = max(longest, __shfl_xor(longest, o));
-    for (int32_t k = 0; k < longest; k += BU_CHUNK) {
-      int32_t u[BU_CHUNK];
-      bu_load_chunk(in_indices, b + (eoff_t)k, own ? len - k : 0, u);
-#pragma unroll
-      for (int j = 0; j < BU_CHUNK; ++j)
-        if (u[j] >= 0 && in_front(u[j])) best = min(best, B::from(s.dist[u[j]]) + in_weights[b + (eoff_t)(k + j)]);
-    }
-    uint64_t mid = __ballot(len >= 64 && !big);
-    while (mid) {
-      int const src = __ffsll((unsigned long long)mid) - 1;
-      mid &= mid - 1;
-      eoff_t const rb  = (eoff_t)__shfl((int)b, src);
-      int32_t const rl = __shfl(len, src);
-      WT m = inf;
-      for (int32_t p = lane; p < rl; p += 64) {
-        int32_t const u = in_indices[rb + (eoff_t)p];
-        if (in_front(u)) m = min(m, B::from(s.dist[u]) + in_weights[rb + (eoff_t)p]);
-      }
-      for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
-      if (lane == src) best = m;
-    }
-    bool near = false, far = false;
-    if (v < nv && best < s.cutoff && best < B::from(s.dist[v])) {
-      s.dist[v] = B::to(best);
-      if (best < s.threshold) { near = atomicExch(&s.mark_near[v], s.round) != s.round; }
-      else { far = atomicExch(&s.mark_far[v], s.far_epoch) != s.far_epoch; }
-    }
-    if (near && s.out_offsets) deg_acc += (unsigned long long)(eoff(s.out_offsets, v + 1) - eoff(s.out_offsets, v));
-    wq_near.push(near, (int32_t)v);
-    wq_far.push(far, (int32_t)v);
-  }
-  wq_near.flush();
-  wq_far.flush();
-  for (int o = 32; o > 0; o >>= 1) deg_acc += __shfl_xor(deg_acc, o);
-  if (lane == 0 && deg_acc) atomicAdd(&cnt_replica(s.cnt)->out_edges, deg_acc);
+  sssp_relax<WT, PK> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far)};
+  f.begin();
+  expand_frontier_mlp(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f, big_deg);
+  f.flush();
 }
-template <typename WT>
-__global__ void __launch_bounds__(TV_BLOCK) k_sssp_pull_big(int32_t const* bigq, int32_t const* in_offsets, int32_t const* in_indices, sssp_state<WT> s, uint32_t const* fbits)
+template <typename WT, bool PK = false>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, sssp_state<WT> s)
 {
-  __shared__ wave_queue_storage<3> wqs;
+  __shared__ wave_queue_storage<2> wqs;
   wqs.init();
-  sssp_pull_fn<WT> f{sssp_relax<WT>{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far), wave_queue(wqs, 2, s.q_set, &s.cnt->n_set)}, fbits};
-  expand_big(bigq, in_offsets, in_indices, s.cnt, f);
+  sssp_relax<WT, PK> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far)};
+  f.begin();
+  expand_big_mlp(bigq, offsets, indices, s.cnt, f);
   f.flush();
 }
 
-template <typename WT, bool PK = false>
-__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* row_end,
-                                                          int32_t const* indices, int32_t* bigq, sssp_state<WT> s, int32_t big_deg)
-{
-  __shared__ wave_queue_storage<3> wqs;
-  wqs.init();
-  sssp_relax<WT, PK> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far), wave_queue(wqs, 2, s.q_set, &s.cnt->n_set)};
-#ifdef CGA_SSSP_NO_MLP
-  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f, big_deg, row_end);
+// ---- wide rounds with the filter: TWO STAGES per wavefront (round 6).
+// What a wide round waits for is not the number of probes but the CHAIN of a step: neighbour id -> distance probe -> atomicMin -> queue mark, four
+// dependent round trips of 1-2 us each, taken by the whole wavefront whenever ONE lane of the step needs them (PMC of k_sssp_expand at RMAT-24: waves
+// 76 % in SQ_WAIT_ANY, 1.3 TB/s moved; with the filter dropping 80 % of the probes the round took the same time, profiles/r6g_*).  So the survivors of
+// the cheap part (neighbour id, weight, filter bit: streamed or L2-resident) are COMPACTED into a per-wavefront LDS buffer, and the expensive chain runs
+// over dense groups of 64 x S2_DU candidates: its round trips are paid per surviving candidate, not per step.
+constexpr int S2_U     = 4;                      // edges per lane and step of the cheap stage
+constexpr int S2_DU    = 4;                      // candidates per lane and step of the drain
+constexpr int S2_DRAIN = 64 * S2_DU;             // buffered candidates that start a drain
+constexpr int S2_CAP   = S2_DRAIN + 64 * S2_U;   // (a cheap step adds at most 64 * S2_U)
+// Candidates for the SAME hot destination: in the round after the source every frontier row has an edge to each of the top hubs, the candidates of a
+// workgroup for one hub arrive within microseconds of each other, all pass the (stale) probe and all issue an atomicMin on ONE address -- and same-address
+// atomics retire one after the other in their L2 channel (~12 ns each: 60 K candidates for the top vertex = 0.7 ms whatever else the round does; the streamed
+// part of k_sssp_sweep alone takes 0.45 ms, the kernel 1.3-1.9 ms).  So a workgroup keeps, in LDS, the smallest candidate distance it has sent for each of the
+// first S2_HOT vertex ids (degree-descending numbering: the hubs) and drops a candidate that is strictly worse than one it sent already (ties go on: the parent
+// with the smaller id must still win).  Exact: a dropped candidate is dominated by one that does reach memory.  fp32 distances only (32-bit LDS minimum).
+constexpr int S2_HOT = 2048;
+template <typename WT, bool PK>
+struct sssp_cand_storage {
+  int32_t v[TV_WAVES][S2_CAP];
+  typename dist_bits<WT>::type nd[TV_WAVES][S2_CAP];
+  uint32_t lab[PK ? TV_WAVES : 1][PK ? S2_CAP : 1];  // biased parent label (packed words only)
+};
+template <typename WT, bool PK>
+struct sssp_two_stage {
+  using B      = dist_bits<WT>;
+  using bits_t = typename B::type;
+  using R      = sssp_relax<WT, PK>;
+  R& f;
+  int32_t* cv;
+  bits_t* cnd;
+  uint32_t* clab;
+  uint32_t* hot;  // [S2_HOT] smallest candidate distance bits this workgroup has sent per hot vertex id (nullptr: off)
+  uint32_t n{0};  // candidates buffered (wave-uniform)
+  // true: a strictly better candidate for v has been sent by this workgroup already
+  __device__ __forceinline__ bool dominated(int32_t v, bits_t nd_bits)
+  {
+    if constexpr (sizeof(bits_t) == 4) {
+      if (hot != nullptr && (uint32_t)v < (uint32_t)S2_HOT) return atomicMin(&hot[v], (uint32_t)nd_bits) < (uint32_t)nd_bits;
+    }
+    return false;
+  }
+  // cheap stage for S2_U edges of this lane: positions p[k] of rows whose vertex has distance bits du[k] / biased label lab[k]; live[k]: the edge exists
+  __device__ __forceinline__ void step(bool const (&live)[S2_U], eoff_t const (&p)[S2_U], bits_t const (&du)[S2_U], uint32_t const (&lab)[S2_U], int32_t const* indices)
+  {
+    int const lane = threadIdx.x & 63;
+    int32_t v[S2_U];
+    WT w[S2_U];
+    uint32_t bw[S2_U];
+#pragma unroll
+    for (int k = 0; k < S2_U; ++k) v[k] = indices[live[k] ? p[k] : 0];
+#pragma unroll
+    for (int k = 0; k < S2_U; ++k) w[k] = f.s.weights[live[k] ? p[k] : 0];
+#pragma unroll
+    for (int k = 0; k < S2_U; ++k) bw[k] = f.s.flt.bits ? f.s.flt.bits[(uint32_t)v[k] >> 5] : 0u;
+#pragma unroll
+    for (int k = 0; k < S2_U; ++k) {
+      WT const nd = B::from(du[k]) + w[k];
+      bool go     = live[k] & (nd < f.s.cutoff) & !((((bw[k] >> ((uint32_t)v[k] & 31u)) & 1u) != 0u) & (nd >= f.ft));
+      if constexpr (PK) go = go & (v[k] != f.s.source);
+      if (go) go = !dominated(v[k], B::to(nd));
+      uint64_t const m = __ballot(go);
+      if (go) {
+        uint32_t const at = n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        cv[at]  = v[k];
+        cnd[at] = B::to(nd);
+        if constexpr (PK) clab[at] = lab[k];
+      }
+      n += (uint32_t)__popcll(m);
+    }
+  }
+  // the expensive chain over the buffered candidates, newest first (the buffer stays a stack), while at least `min_n` of them wait
+  __device__ __forceinline__ void drain(uint32_t min_n)
+  {
+    int const lane = threadIdx.x & 63;
+    while (n > 0 && n >= min_n) {
+      uint32_t const cnt = min(n, (uint32_t)(64 * S2_DU)), base = n - cnt;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      int32_t v[S2_DU];
+      typename R::cand_t c[S2_DU];
+      typename R::tok_t tk[S2_DU];
+      typename R::tok2_t tk2[S2_DU];
+#pragma unroll
+      for (int k = 0; k < S2_DU; ++k) {
+        uint32_t const i = base + (uint32_t)lane + 64u * (uint32_t)k;
+        bool const has   = i < n;
+        v[k]             = has ? cv[i] : -1;
+        WT const nd      = B::from(has ? cnd[i] : bits_t(0));
+        uint32_t lb      = 0;
+        if constexpr (PK) lb = has ? clab[i] : 0u;
+        c[k] = f.probe(v[k], nd, lb);
+      }
+#if defined(CGA_ABL_DRAIN) && CGA_ABL_DRAIN == 1  // timing experiments (WRONG results): the probe only ...
+      for (int k = 0; k < S2_DU; ++k) asm volatile("" : : "v"(c[k].pass));
+#elif defined(CGA_ABL_DRAIN) && CGA_ABL_DRAIN == 2  // ... probe + atomicMin
+      for (int k = 0; k < S2_DU; ++k) tk[k] = f.mid(v[k], c[k]);
+      for (int k = 0; k < S2_DU; ++k) asm volatile("" : : "v"(tk[k]));
+#elif defined(CGA_ABL_DRAIN) && CGA_ABL_DRAIN == 3  // ... + the queue mark, no append
+      for (int k = 0; k < S2_DU; ++k) tk[k] = f.mid(v[k], c[k]);
+      for (int k = 0; k < S2_DU; ++k) tk2[k] = f.mid2(v[k], c[k], tk[k]);
+      for (int k = 0; k < S2_DU; ++k) asm volatile("" : : "v"(tk2[k]));
 #else
-  expand_frontier_mlp(q, n, offsets, indices, bigq, s.cnt, keep_all{}, f, big_deg, row_end);
+#pragma unroll
+      for (int k = 0; k < S2_DU; ++k) tk[k] = f.mid(v[k], c[k]);
+#pragma unroll
+      for (int k = 0; k < S2_DU; ++k) tk2[k] = f.mid2(v[k], c[k], tk[k]);
+#pragma unroll
+      for (int k = 0; k < S2_DU; ++k) f.post(0, v[k], c[k], tk[k], tk2[k]);
 #endif
+      n = base;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+};
+
+template <typename WT, bool PK>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand2(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices, int32_t* bigq, sssp_state<WT> s,
+                                                           int32_t big_deg)
+{
+  using B      = dist_bits<WT>;
+  using bits_t = typename B::type;
+  __shared__ wave_queue_storage<2> wqs;
+  __shared__ sssp_cand_storage<WT, PK> cs;
+  __shared__ uint32_t s_scan[TV_WAVES][64];
+  __shared__ eoff_t s_beg[TV_WAVES][64];
+  __shared__ bits_t s_du[TV_WAVES][64];
+  __shared__ uint32_t s_lab[TV_WAVES][64];
+  wqs.init();
+  sssp_relax<WT, PK> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far)};
+  f.begin();
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ uint32_t s_hot[S2_HOT];
+  for (int i = threadIdx.x; i < S2_HOT; i += TV_BLOCK) s_hot[i] = 0xFFFFFFFFu;
+  __syncthreads();
+  sssp_two_stage<WT, PK> ts{f, cs.v[wave], cs.nd[wave], PK ? cs.lab[wave] : cs.lab[0], s.hot_cache ? s_hot : nullptr};
+  int64_t const gwave  = (int64_t)blockIdx.x * TV_WAVES + wave;
+  int64_t const nwaves = (int64_t)gridDim.x * TV_WAVES;
+  unsigned long long inspected = 0;
+  for (int64_t base = gwave * 64; base < n; base += nwaves * 64) {
+    int64_t const i = base + lane;
+    int32_t u = -1, deg = 0;
+    eoff_t beg = 0;
+    bits_t du  = 0;
+    uint32_t lab = 0;
+    if (i < n) {
+      u   = q[i];
+      beg = eoff(offsets, u);
+      deg = (int32_t)(eoff(offsets, u + 1) - beg);
+      if constexpr (PK) { du = pk_dist_bits(s.pk, u); lab = pk_label(s.labels ? s.labels[u] : u); }
+      else du = s.dist[u];
+    }
+    bool const big = deg >= big_deg;
+    if (big) {
+      uint32_t const nseg = ((uint32_t)deg + BIG_SEG - 1) / BIG_SEG;
+      uint32_t const at   = atomicAdd(&s.cnt->n_big, nseg);
+      for (uint32_t sgm = 0; sgm < nseg; ++sgm) { bigq[2 * (at + sgm)] = u; bigq[2 * (at + sgm) + 1] = (int32_t)sgm; }
+    }
+    // whole-wave rows
+    uint64_t mid = __ballot(deg >= 64 && !big);
+    while (mid) {
+      int const src = __ffsll((unsigned long long)mid) - 1;
+      mid &= mid - 1;
+      int32_t const d  = __shfl(deg, src);
+      eoff_t const b   = (eoff_t)__shfl((int)beg, src);
+      bits_t duu;
+      if constexpr (sizeof(bits_t) == 4) duu = (bits_t)__shfl((int)du, src);
+      else duu = (bits_t)__shfl((unsigned long long)du, src);
+      uint32_t const labu = (uint32_t)__shfl((int)lab, src);
+      for (int32_t p0 = 0; p0 < d; p0 += 64 * S2_U) {
+        bool live[S2_U]; eoff_t pp[S2_U]; bits_t dd[S2_U]; uint32_t ll[S2_U];
+#pragma unroll
+        for (int k = 0; k < S2_U; ++k) { int32_t const p = p0 + lane + 64 * k; live[k] = p < d; pp[k] = b + (eoff_t)(p < d ? p : 0); dd[k] = duu; ll[k] = labu; }
+        ts.step(live, pp, dd, ll, indices);
+        ts.drain(S2_DRAIN);
+      }
+      inspected += (lane == 0) ? (unsigned long long)d : 0ull;
+    }
+    // flattened small rows
+    uint32_t const sd = (deg < 64) ? (uint32_t)deg : 0u;
+    uint32_t total;
+    uint32_t const ex = wave_excl_scan(sd, lane, &total);
+    s_scan[wave][lane] = ex;
+    s_beg[wave][lane]  = beg;
+    s_du[wave][lane]   = du;
+    s_lab[wave][lane]  = lab;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t t0 = 0; t0 < total; t0 += 64 * S2_U) {
+      bool live[S2_U]; eoff_t pp[S2_U]; bits_t dd[S2_U]; uint32_t ll[S2_U];
+#pragma unroll
+      for (int k = 0; k < S2_U; ++k) {
+        uint32_t const t = t0 + (uint32_t)lane + 64u * (uint32_t)k;
+        live[k] = t < total; pp[k] = 0; dd[k] = 0; ll[k] = 0;
+        if (t < total) {
+          int lo = 0, hi = 63;
+#pragma unroll
+          for (int st = 0; st < 6; ++st) {
+            int const m = (lo + hi + 1) >> 1;
+            if (s_scan[wave][m] <= t) lo = m; else hi = m - 1;
+          }
+          pp[k] = s_beg[wave][lo] + (t - s_scan[wave][lo]);
+          dd[k] = s_du[wave][lo];
+          ll[k] = s_lab[wave][lo];
+        }
+      }
+      ts.step(live, pp, dd, ll, indices);
+      ts.drain(S2_DRAIN);
+    }
+    __builtin_amdgcn_wave_barrier();
+    inspected += (lane == 0) ? (unsigned long long)total : 0ull;
+  }
+  ts.drain(1);
+  if (lane == 0 && inspected) atomicAdd(&cnt_replica(s.cnt)->edges, inspected);
   f.flush();
 }
-template <typename WT, bool PK = false>
-__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_big(int32_t const* bigq, int32_t const* offsets, int32_t const* row_end,
-                                                              int32_t const* indices, sssp_state<WT> s)
+template <typename WT, bool PK>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand2_big(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, sssp_state<WT> s)
 {
-  __shared__ wave_queue_storage<3> wqs;
+  using B      = dist_bits<WT>;
+  using bits_t = typename B::type;
+  __shared__ wave_queue_storage<2> wqs;
+  __shared__ sssp_cand_storage<WT, PK> cs;
   wqs.init();
-  sssp_relax<WT, PK> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far), wave_queue(wqs, 2, s.q_set, &s.cnt->n_set)};
-#ifdef CGA_SSSP_NO_MLP
-  expand_big(bigq, offsets, indices, s.cnt, f, row_end);
-#else
-  expand_big_mlp(bigq, offsets, indices, s.cnt, f, row_end);
-#endif
+  sssp_relax<WT, PK> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far)};
+  f.begin();
+  int const wave = threadIdx.x >> 6;
+  __shared__ uint32_t s_hot[S2_HOT];
+  for (int i = threadIdx.x; i < S2_HOT; i += TV_BLOCK) s_hot[i] = 0xFFFFFFFFu;
+  __syncthreads();
+  sssp_two_stage<WT, PK> ts{f, cs.v[wave], cs.nd[wave], PK ? cs.lab[wave] : cs.lab[0], s.hot_cache ? s_hot : nullptr};
+  uint32_t const nseg = s.cnt->n_big;
+  unsigned long long inspected = 0;
+  for (uint32_t k = blockIdx.x; k < nseg; k += gridDim.x) {
+    int32_t const u = bigq[2 * k], sgm = bigq[2 * k + 1];
+    eoff_t const row_b = eoff(offsets, u), row_e = eoff(offsets, u + 1);
+    eoff_t const b = row_b + (eoff_t)sgm * (eoff_t)BIG_SEG;
+    eoff_t const len = min(row_e - b, (eoff_t)BIG_SEG);
+    bits_t du;
+    uint32_t lab = 0;
+    if constexpr (PK) { du = pk_dist_bits(s.pk, u); lab = pk_label(s.labels ? s.labels[u] : u); }
+    else du = s.dist[u];
+    for (eoff_t p0 = 0; p0 < len; p0 += (eoff_t)TV_BLOCK * S2_U) {
+      bool live[S2_U]; eoff_t pp[S2_U]; bits_t dd[S2_U]; uint32_t ll[S2_U];
+#pragma unroll
+      for (int j = 0; j < S2_U; ++j) { eoff_t const p = p0 + threadIdx.x + (eoff_t)j * TV_BLOCK; live[j] = p < len; pp[j] = b + (p < len ? p : 0); dd[j] = du; ll[j] = lab; }
+      ts.step(live, pp, dd, ll, indices);
+      ts.drain(S2_DRAIN);
+    }
+    if (threadIdx.x == 0) inspected += (unsigned long long)len;
+  }
+  ts.drain(1);
+  if (threadIdx.x == 0 && inspected) atomicAdd(&cnt_replica(s.cnt)->edges, inspected);
   f.flush();
+}
+
+// A wide frontier in VERTEX ORDER (round 6): the near queue holds its vertices in the order the relaxations found them, so a wavefront's 64 rows are
+// 64 random places of the CSR (each ~200 bytes at RMAT-24).  Every member carries mark_near[v] == tag, so the same set is rebuilt by a sweep over the
+// marks -- every workgroup owns a contiguous vertex range, counts, reserves its piece with ONE atomic and fills it in order (the scheme of
+// k_bfs_bitmap_to_queue) -- and the expansion reads offsets, distances, labels and adjacency rows of consecutive vertices: streams instead of gathers.
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_front_in_vertex_order(uint32_t const* mark_near, int64_t nv, uint32_t tag, int32_t* q, uint32_t* cursor)
+{
+  __shared__ uint32_t s_wave[TV_BLOCK / 64];
+  __shared__ uint32_t s_base;
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t const per = ((nv + gridDim.x - 1) / gridDim.x + TV_BLOCK - 1) / TV_BLOCK * TV_BLOCK;  // vertices per workgroup, whole rounds
+  int64_t const v0 = (int64_t)blockIdx.x * per, v1 = v0 + per < nv ? v0 + per : nv;
+  uint32_t mine = 0;
+  for (int64_t i = v0 + threadIdx.x; i < v1; i += TV_BLOCK) mine += mark_near[i] == tag ? 1u : 0u;
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+  if (lane == 0) s_wave[wave] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int k = 0; k < TV_BLOCK / 64; ++k) t += s_wave[k];
+    s_base = t ? atomicAdd(cursor, t) : 0u;
+  }
+  __syncthreads();
+  uint32_t base = s_base;
+  for (int64_t r0 = v0; r0 < v1; r0 += TV_BLOCK) {
+    int64_t const i = r0 + threadIdx.x;
+    bool const in   = i < v1 && mark_near[i] == tag;
+    uint64_t const m = __ballot(in);
+    __syncthreads();
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0, round_total = 0;
+    for (int k = 0; k < TV_BLOCK / 64; ++k) { before += k < wave ? s_wave[k] : 0u; round_total += s_wave[k]; }
+    if (in) q[base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+    base += round_total;
+  }
+}
+
+// A round whose frontier holds a large share of ALL edges (RMAT-24: the two rounds after the hubs relax 259 M and 200 M of the graph's 268 M edges):
+// frontier-driven expansion gathers ~200-byte rows at 65-75 G edges/s (0.6 TB/s); the same edges are the whole CSR, so the round STREAMS it instead --
+// edge positions in order, 12 bytes each (row id, neighbour, weight: orientation_t::edge_rows is built once per graph), the row's membership
+// (mark_near[u] == tag), distance and label read from nearly consecutive places -- and feeds the survivors of the filter to the same two-stage
+// drain.  No row search, no deferred rows, no imbalance between rows.
+template <typename WT, bool PK>
+__global__ void __launch_bounds__(TV_BLOCK) k_sssp_sweep(int32_t const* edge_rows, int32_t const* indices, int64_t ne, uint32_t const* mark_near, uint32_t tag, sssp_state<WT> s,
+                                                         unsigned long long* prof)  // CUGRAPH_AMD_SSSP_TRACE=2: per wavefront (ticks, ticks inside drains, drains)
+{
+  unsigned long long const t_begin = wall_clock64();
+  unsigned long long t_drain = 0, n_drain = 0;
+  using B      = dist_bits<WT>;
+  using bits_t = typename B::type;
+  __shared__ wave_queue_storage<2> wqs;
+  __shared__ sssp_cand_storage<WT, PK> cs;
+  wqs.init();
+  sssp_relax<WT, PK> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far)};
+  f.begin();
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ uint32_t s_hot[S2_HOT];
+  for (int i = threadIdx.x; i < S2_HOT; i += TV_BLOCK) s_hot[i] = 0xFFFFFFFFu;
+  __syncthreads();
+  sssp_two_stage<WT, PK> ts{f, cs.v[wave], cs.nd[wave], PK ? cs.lab[wave] : cs.lab[0], s.hot_cache ? s_hot : nullptr};
+  int64_t const gwave  = (int64_t)blockIdx.x * TV_WAVES + wave;
+  int64_t const nwaves = (int64_t)gridDim.x * TV_WAVES;
+  constexpr int64_t STEP = 64 * S2_U;
+  unsigned long long inspected = 0;
+  for (int64_t p0 = gwave * STEP; p0 < ne; p0 += nwaves * STEP) {  // (indices / weights / edge_rows are padded: a step may read past ne, its lanes are not live)
+    int32_t u[S2_U], v[S2_U];
+    WT w[S2_U];
+    uint32_t mk[S2_U], bw[S2_U];
+    bits_t du[S2_U];
+    uint32_t lab[S2_U];
+    bool live[S2_U];
+#pragma unroll
+    for (int k = 0; k < S2_U; ++k) {  // streamed once per round: non-temporal, so that the distance words the probes hit stay in the Infinity Cache
+      int64_t const p = p0 + lane + 64 * k;
+      live[k] = p < ne;
+#ifndef CGA_SWEEP_PLAIN_LOADS
+      u[k] = __builtin_nontemporal_load(edge_rows + p); v[k] = __builtin_nontemporal_load(indices + p); w[k] = __builtin_nontemporal_load(s.weights + p);
+#else
+      u[k] = edge_rows[p]; v[k] = indices[p]; w[k] = s.weights[p];
+#endif
+    }
+#pragma unroll
+    for (int k = 0; k < S2_U; ++k) { u[k] = live[k] ? u[k] : 0; v[k] = live[k] ? v[k] : 0; mk[k] = mark_near[u[k]]; bw[k] = s.flt.bits ? s.flt.bits[(uint32_t)v[k] >> 5] : 0u; }
+#pragma unroll
+    for (int k = 0; k < S2_U; ++k) {
+      live[k] = live[k] & (mk[k] == tag);
+      du[k] = 0; lab[k] = 0;
+      if (live[k]) {  // (a row's edges are consecutive: most lanes of a step read the same few words)
+        if constexpr (PK) { du[k] = pk_dist_bits(s.du_src ? static_cast<unsigned long long const*>(s.du_src) : s.pk, u[k]); lab[k] = pk_label(s.labels ? s.labels[u[k]] : u[k]); }
+        else du[k] = (s.du_src ? static_cast<bits_t const*>(s.du_src) : s.dist)[u[k]];
+      }
+    }
+    uint32_t n_live = 0;
+#pragma unroll
+    for (int k = 0; k < S2_U; ++k) {
+      WT const nd = B::from(du[k]) + w[k];
+      bool go     = live[k] & (nd < s.cutoff) & !((((bw[k] >> ((uint32_t)v[k] & 31u)) & 1u) != 0u) & (nd >= f.ft));
+      if constexpr (PK) go = go & (v[k] != s.source);
+      n_live += live[k] ? 1u : 0u;
+      if (go) go = !ts.dominated(v[k], B::to(nd));
+      uint64_t const m = __ballot(go);
+      if (go) {
+        uint32_t const at = ts.n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        ts.cv[at]  = v[k];
+        ts.cnd[at] = B::to(nd);
+        if constexpr (PK) ts.clab[at] = lab[k];
+      }
+      ts.n += (uint32_t)__popcll(m);
+    }
+    inspected += n_live;
+#ifdef CGA_ABL_SWEEP_NODRAIN  // timing experiment (WRONG results): the streamed part alone
+    if (ts.n >= (uint32_t)S2_DRAIN) ts.n = 0;
+#else
+    if (prof && ts.n >= (uint32_t)S2_DRAIN) {
+      unsigned long long const t0 = wall_clock64();
+      ts.drain(S2_DRAIN);
+      t_drain += wall_clock64() - t0; ++n_drain;
+    } else ts.drain(S2_DRAIN);
+#endif
+  }
+#ifndef CGA_ABL_SWEEP_NODRAIN
+  ts.drain(1);
+#endif
+  if (prof && lane == 0) { prof[3 * gwave] = wall_clock64() - t_begin; prof[3 * gwave + 1] = t_drain; prof[3 * gwave + 2] = n_drain; }
+  for (int o = 32; o > 0; o >>= 1) inspected += __shfl_xor(inspected, o);
+  if (lane == 0 && inspected) atomicAdd(&cnt_replica(s.cnt)->edges, inspected);
+  f.flush();
+}
+__global__ void k_sssp_edge_rows(int32_t const* offsets, int64_t nv, int32_t* rows)
+{  // one wavefront per row chunk (rows[e] = v for offsets[v] <= e < offsets[v + 1]; unsigned positions)
+  int64_t const wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int const lane = threadIdx.x & 63;
+  for (int64_t v = wave; v < nv; v += nwaves) {
+    uint32_t const b = (uint32_t)offsets[v], len = (uint32_t)offsets[v + 1] - b;
+    for (uint32_t p = lane; p < len; p += 64) rows[b + p] = (int32_t)v;
+  }
+}
+
+// ---- the threshold and the bits of sssp_filter.  Distances are cut into SF_BANDS bands of the current window [lower, lower + SF_BANDS / inv_band):
+//   hist[0][b]  out-edges of the FRONTIER vertices whose distance lies in band b     (k_sssp_filter_hist_front)
+//   hist[1][b]  (1 + out-degree) of ALL vertices whose distance lies in band b       (k_sssp_filter_hist_all; the out-degree stands in for the
+//               in-degree: how many edges point at the vertex -- a heuristic, the filter is exact whatever T is)
+// sssp_filter_pick maximises, over the band boundaries T, (share of the frontier's relaxations with nd >= T) x (share of the destinations with
+// d < T), modelling a relaxation's weight as uniform on (0, 2 avg_w] (constant weights: exactly avg_w).
+constexpr int SF_BANDS = 256;
+template <typename WT, bool PK>
+__device__ __forceinline__ int sf_band(typename dist_bits<WT>::type const* dist, int32_t v, WT lower, WT inv_band)
+{
+  using B = dist_bits<WT>;
+  WT d;
+  if constexpr (PK) d = B::from(pk_dist_bits(reinterpret_cast<unsigned long long const*>(dist), v));
+  else d = B::from(dist[v]);
+  WT const r = (d - lower) * inv_band;
+  return r < WT(0) ? 0 : (r >= WT(SF_BANDS) ? SF_BANDS : (int)r);  // SF_BANDS = beyond the window (far pile, unreached): never below a threshold
+}
+template <typename WT, bool PK>
+__global__ void __launch_bounds__(256) k_sssp_filter_hist(int32_t const* front, int64_t n, typename dist_bits<WT>::type const* dist, int32_t const* out_offsets, WT lower,
+                                                          WT inv_band, unsigned long long* hist /* [SF_BANDS + 1] */, unsigned long long plus)
+{  // front == nullptr: all vertices 0 .. n - 1
+  __shared__ unsigned long long h[SF_BANDS + 1];
+  for (int i = threadIdx.x; i <= SF_BANDS; i += blockDim.x) h[i] = 0ull;
+  __syncthreads();
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t const v = front ? front[i] : (int32_t)i;
+    int const b     = sf_band<WT, PK>(dist, v, lower, inv_band);
+    if (b < SF_BANDS) atomicAdd(&h[b], plus + (unsigned long long)(eoff(out_offsets, v + 1) - eoff(out_offsets, v)));
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < SF_BANDS; i += blockDim.x)
+    if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+template <typename WT>
+__global__ void __launch_bounds__(SF_BANDS) k_sssp_filter_pick(unsigned long long* hist_front, unsigned long long* hist_all, WT lower, WT band, WT avg_w, int uniform_weights,
+                                                               WT* t_out)
+{
+  __shared__ double hf[SF_BANDS], ha[SF_BANDS], score[SF_BANDS];
+  int const b = threadIdx.x;
+  hf[b] = (double)hist_front[b]; ha[b] = (double)hist_all[b];
+  hist_front[b] = 0ull; hist_all[b] = 0ull;  // ready for the next round
+  __syncthreads();
+  // threshold T = lower + b * band: destinations below it = bands [0, b); a frontier vertex of band c relaxes with nd = (lower + (c + 0.5) band) + w
+  double below = 0.0;
+  for (int c = 0; c < b; ++c) below += ha[c];
+  double above = 0.0;
+  for (int c = 0; c < SF_BANDS; ++c) {
+    double const need = ((double)b - ((double)c + 0.5)) * (double)band;  // nd >= T  <=>  w >= need
+    double pw;
+    if (need <= 0.0) pw = 1.0;
+    else if (uniform_weights) pw = (double)avg_w >= need ? 1.0 : 0.0;
+    else pw = fmax(0.0, 1.0 - need / (2.0 * (double)avg_w));
+    above += hf[c] * pw;
+  }
+  score[b] = below * above;
+  __syncthreads();
+  if (b == 0) {
+    int best = 0;
+    for (int c = 1; c < SF_BANDS; ++c)
+      if (score[c] > score[best]) best = c;
+    *t_out = lower + (WT)best * band;  // (best == 0: T = lower, nothing is below it: the filter passes everything)
+  }
+}
+template <typename WT, bool PK>
+__global__ void __launch_bounds__(256) k_sssp_filter_bits(typename dist_bits<WT>::type const* dist, int64_t nv, WT const* t, uint32_t* bits)
+{
+  using B = dist_bits<WT>;
+  WT const T = *t;
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t const n_pad = (nv + 63) & ~(int64_t)63;
+  for (; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
+    bool below = false;
+    if (i < nv) {
+      WT d;
+      if constexpr (PK) d = B::from(pk_dist_bits(reinterpret_cast<unsigned long long const*>(dist), (int32_t)i));
+      else d = B::from(dist[i]);
+      below = d < T;
+    }
+    unsigned long long const m = __ballot(below);
+    if ((threadIdx.x & 63) == 0) { bits[i >> 5] = (uint32_t)m; bits[(i >> 5) + 1] = (uint32_t)(m >> 32); }
+  }
 }
 
 // far pile -> (near frontier | far pile'): d < lower: settled meanwhile, drop; d < upper: near; else keep
 template <typename WT, bool PK = false>  // PK: `dist` points at the packed (distance, parent) words
 __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split(int32_t const* far_in, int64_t n, typename dist_bits<WT>::type const* dist, WT lower,
                                                          WT upper, int32_t* near_out, int32_t* far_out, uint32_t* mark_near,
-                                                         uint32_t* mark_far, uint32_t round, uint32_t new_epoch, counters_t* cnt,
-                                                         int32_t* set_out, uint32_t* mark_set, uint32_t set_epoch, int32_t const* out_offsets)
+                                                         uint32_t* mark_far, uint32_t round, uint32_t new_epoch, counters_t* cnt, int32_t const* out_offsets)
 {
   using B        = dist_bits<WT>;
   int const lane = threadIdx.x & 63;
@@ -565,10 +890,6 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split(int32_t const* far_in, 
     if (near && out_offsets) deg_acc += (unsigned long long)(eoff(out_offsets, v + 1) - eoff(out_offsets, v));
     wave_push(near, v, near_out, &cnt->n_next, lane);
     wave_push(keep, v, far_out, &cnt->n_far, lane);
-    if (set_out) {  // (uniform) the bucket's members, once each
-      bool const fresh = near && atomicExch(&mark_set[v], set_epoch) != set_epoch;
-      wave_push(fresh, v, set_out, &cnt->n_set, lane);
-    }
   }
   for (int o = 32; o > 0; o >>= 1) deg_acc += __shfl_xor(deg_acc, o);
   if (lane == 0 && deg_acc) atomicAdd(&cnt_replica(cnt)->out_edges, deg_acc);
@@ -577,374 +898,6 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_split(int32_t const* far_in, 
   if (lane == 0 && kept_min != ~0ull) {
     if constexpr (sizeof(WT) == 4) atomicMin(&cnt->far_min_bits_lo, (uint32_t)kept_min);
     else atomicMin(&cnt->far_min_bits64, kept_min);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// SSSP, round 3: the near set of a bucket is kept in SSSP_K distance-ordered sub-queues (delta-stepping INSIDE the near-far
-// window; sssp_impl.cuh:376-561 has one near bucket).  With one near queue every vertex of [lower, upper) is expanded as soon as
-// it is reached and again whenever its distance improves inside the window -- 2.2-2.3 relaxations per edge at RMAT-24 with
-// weights 1..255, a Bellman-Ford inside the first window.  Here a successful relaxation with nd < upper appends v to sub-queue
-// k = floor((nd - lower) / (delta / K)); the sub-queues are drained in order (k == current: the next round of the same sub-queue),
-// so a vertex is expanded when the vertices that can still improve it by more than delta / K have been expanded already.  No far
-// pile is rescanned between sub-queues (that is what made a narrower delta slower in round 2), stale entries are dropped when they
-// are popped: an entry is expanded iff the vertex's CURRENT distance falls into the sub-queue being drained and it has not been
-// expanded at that distance (done[v]).  Distances are the same fixed point as before (bit-identical to Dijkstra).
-constexpr int SSSP_K = 12;
-template <typename WT>
-struct sssp_multi_state {
-  using bits_t = typename dist_bits<WT>::type;
-  bits_t* dist;
-  WT const* weights;
-  bits_t* done;                 // distance bits at which the vertex was expanded last (unreached pattern = never)
-  int32_t* q[SSSP_K];           // sub-queues of the current window (q[k], k > j, receive entries while sub-queue j is drained)
-  int32_t* q_same;              // next round of sub-queue j
-  int32_t* far;
-  uint32_t* mark;               // per vertex: tag of its last insertion into a near queue (dedup within a round / a sub-queue)
-  uint32_t* mark_far;
-  counters_t* cnt;              // n_next = entries of q_same, n_far = far pile, edges = relaxations
-  uint32_t* qn;                 // [SSSP_K] fill of the sub-queues (persist across the rounds of a window)
-  uint32_t* qh;                 // [SSSP_K] how many of those entries are vertices below heavy_cut (ids are degree-sorted: the bucket's work)
-  WT lower;                     // distances below are settled
-  WT ub[SSSP_K];                // absolute, non-decreasing upper bounds: sub-queue k holds [k ? ub[k - 1] : lower, ub[k]); ub[SSSP_K - 1] = the window's end
-  WT cutoff;
-  int32_t heavy_cut;
-  __host__ __device__ WT upper() const { return ub[SSSP_K - 1]; }
-  int j;
-  uint32_t round_tag, far_epoch;  // tag of an insertion into q_same (one per round) / epoch of the far pile
-  uint32_t tag[SSSP_K];           // tag of an insertion into sub-queue k: one per INCARNATION of the sub-queue (a new one whenever its range is
-                                  // redefined), so a vertex enters an incarnation at most once and a queue never holds more than V entries
-};
-template <typename WT>
-__device__ __forceinline__ int sssp_sub_of(WT d, sssp_multi_state<WT> const& s)
-{  // first k with d < ub[k] (callers have checked d < ub[SSSP_K - 1])
-  int k = 0;
-#pragma unroll
-  for (int i = 0; i < SSSP_K - 1; ++i) k += d >= s.ub[i] ? 1 : 0;
-  return k;
-}
-// per-wavefront LDS staging for SSSP_K + 2 output queues (the wave_queue scheme with the queue picked per call, wave-uniform)
-struct multi_queue_storage {
-  int32_t buf[SSSP_K + 2][TV_WAVES][WQ_CAP / 4];
-  uint32_t fill[SSSP_K + 2][TV_WAVES];
-  uint32_t heavy[SSSP_K][TV_WAVES];  // staged entries below heavy_cut, per sub-queue
-  int32_t* q[SSSP_K + 2];
-  uint32_t* counter[SSSP_K + 2];
-  uint32_t* hcounter[SSSP_K];
-  uint32_t tag[SSSP_K];
-  int32_t heavy_cut;
-};
-constexpr int MQ_CAP = WQ_CAP / 4;
-__device__ __forceinline__ void mq_push(multi_queue_storage& st, int k, bool flag, int32_t value)
-{  // k wave-uniform
-  uint64_t const m = __ballot(flag);
-  if (m == 0) return;
-  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int32_t* const buf   = st.buf[k][wave];
-  uint32_t* const fill = &st.fill[k][wave];
-  uint32_t const c     = (uint32_t)__popcll(m);
-  int const leader     = __ffsll((unsigned long long)m) - 1;
-  uint32_t const rank  = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-  uint32_t base        = 0;
-  if (k < SSSP_K) {  // (k is wave-uniform)
-    uint32_t const hc = (uint32_t)__popcll(__ballot(flag && value < st.heavy_cut));
-    if (lane == leader && hc) st.heavy[k][wave] += hc;  // this wavefront's own word
-  }
-  if (lane == leader) base = atomicAdd(fill, c);
-  base = __shfl(base, leader);
-  if (base + c <= (uint32_t)MQ_CAP) {
-    if (flag) buf[base + rank] = value;
-    return;
-  }
-  uint32_t g = 0;
-  if (lane == leader) { g = atomicAdd(st.counter[k], base + c); *fill = 0; }
-  g = __shfl(g, leader);
-  uint64_t const act = __ballot(true);
-  uint32_t const na = (uint32_t)__popcll(act), ar = (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
-  int32_t* const q = st.q[k];
-  for (uint32_t i = ar; i < base; i += na) q[g + i] = buf[i];
-  if (flag) q[g + base + rank] = value;
-}
-__device__ __forceinline__ void mq_flush(multi_queue_storage& st)
-{
-  __builtin_amdgcn_wave_barrier();
-  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane < SSSP_K) {
-    uint32_t const hc = st.heavy[lane][wave];
-    if (hc) { atomicAdd(st.hcounter[lane], hc); st.heavy[lane][wave] = 0; }
-  }
-  for (int k = 0; k < SSSP_K + 2; ++k) {
-    uint32_t const n = st.fill[k][wave];
-    if (n == 0) continue;
-    uint32_t g = 0;
-    if (lane == 0) g = atomicAdd(st.counter[k], n);
-    g = __shfl(g, 0);
-    int32_t* const q = st.q[k];
-    for (uint32_t i = lane; i < n; i += 64) q[g + i] = st.buf[k][wave][i];
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) st.fill[k][wave] = 0;
-  }
-}
-template <typename WT>
-__device__ __forceinline__ void mq_init(multi_queue_storage& st, sssp_multi_state<WT> const& s)
-{
-  if (threadIdx.x < (SSSP_K + 2) * TV_WAVES) (&st.fill[0][0])[threadIdx.x] = 0;
-  if (threadIdx.x < SSSP_K * TV_WAVES) (&st.heavy[0][0])[threadIdx.x] = 0;
-  if (threadIdx.x == 0) st.heavy_cut = s.heavy_cut;
-  if (threadIdx.x < SSSP_K) { st.q[threadIdx.x] = s.q[threadIdx.x]; st.counter[threadIdx.x] = &s.qn[threadIdx.x]; st.hcounter[threadIdx.x] = &s.qh[threadIdx.x]; st.tag[threadIdx.x] = s.tag[threadIdx.x]; }
-  if (threadIdx.x == SSSP_K) { st.q[SSSP_K] = s.q_same; st.counter[SSSP_K] = &s.cnt->n_next; }
-  if (threadIdx.x == SSSP_K + 1) { st.q[SSSP_K + 1] = s.far; st.counter[SSSP_K + 1] = &s.cnt->n_far; }
-  __syncthreads();
-}
-// (the sub-queue pointers are read from `src` -- the kernel-argument copy when `s` is a modified local one: a runtime-indexed read of a
-// local struct would go through scratch memory)
-template <typename WT>
-__device__ __forceinline__ void mq_init_from(multi_queue_storage& st, sssp_multi_state<WT> const& src, sssp_multi_state<WT> const& s)
-{
-  if (threadIdx.x < (SSSP_K + 2) * TV_WAVES) (&st.fill[0][0])[threadIdx.x] = 0;
-  if (threadIdx.x < SSSP_K * TV_WAVES) (&st.heavy[0][0])[threadIdx.x] = 0;
-  if (threadIdx.x == 0) st.heavy_cut = s.heavy_cut;
-  if (threadIdx.x < SSSP_K) { st.q[threadIdx.x] = src.q[threadIdx.x]; st.counter[threadIdx.x] = &src.qn[threadIdx.x]; st.hcounter[threadIdx.x] = &src.qh[threadIdx.x]; st.tag[threadIdx.x] = src.tag[threadIdx.x]; }
-  if (threadIdx.x == SSSP_K) { st.q[SSSP_K] = s.q_same; st.counter[SSSP_K] = &s.cnt->n_next; }
-  if (threadIdx.x == SSSP_K + 1) { st.q[SSSP_K + 1] = s.far; st.counter[SSSP_K + 1] = &s.cnt->n_far; }
-  __syncthreads();
-}
-template <typename WT>
-struct sssp_relax_multi {
-  sssp_multi_state<WT> s;
-  multi_queue_storage* st;
-  __device__ __forceinline__ void operator()(int32_t u, int32_t v, eoff_t p)
-  {
-    using B  = dist_bits<WT>;
-    WT const nd = B::from(s.dist[u]) + s.weights[p];
-    bool near = false, far = false;
-    int k = 0;
-    if (nd < s.cutoff && nd < B::from(__hip_atomic_load(&s.dist[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-      auto old = atomicMin(&s.dist[v], B::to(nd));
-      if (B::to(nd) < old) {
-        if (nd < s.upper()) {
-          k = sssp_sub_of<WT>(nd, s);
-          if (k < s.j) k = s.j;  // (cannot happen for a monotone sub_of; keeps the queue order safe)
-          uint32_t const tag = k == s.j ? s.round_tag : st->tag[k];
-          near = atomicExch(&s.mark[v], tag) != tag;
-        } else {
-          far = atomicExch(&s.mark_far[v], s.far_epoch) != s.far_epoch;
-        }
-      }
-    }
-    uint64_t m = __ballot(near);
-    while (m) {  // one staged append per distinct sub-queue among the lanes
-      int const l  = __ffsll((unsigned long long)m) - 1;
-      int const k0 = __shfl(k, l);
-      bool const mine = near && k == k0;
-      mq_push(*st, k0 == s.j ? SSSP_K : k0, mine, v);
-      m &= ~__ballot(mine);
-    }
-    mq_push(*st, SSSP_K + 1, far, v);
-  }
-};
-// pop filter: expand u iff its current distance lies in the sub-queue being drained and it was not expanded at that distance
-template <typename WT>
-struct sssp_pop {
-  typename dist_bits<WT>::type const* dist;
-  typename dist_bits<WT>::type* done;
-  WT lb, ub;  // the range of the sub-queue being drained
-  __device__ __forceinline__ bool operator()(int32_t u) const
-  {
-    using B = dist_bits<WT>;
-    auto const b = dist[u];
-    WT const d   = B::from(b);
-    if (!(d >= lb && d < ub)) return false;
-    return atomicExch(&done[u], b) != b;
-  }
-};
-template <typename WT>
-__device__ __forceinline__ sssp_pop<WT> sssp_pop_of(sssp_multi_state<WT> const& s)
-{
-  WT lb = s.lower, ub = s.ub[0];
-#pragma unroll
-  for (int k = 1; k < SSSP_K; ++k)
-    if (k == s.j) { lb = s.ub[k - 1]; ub = s.ub[k]; }
-  return sssp_pop<WT>{s.dist, s.done, lb, ub};
-}
-template <typename WT>
-__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_multi(int32_t const* q, int64_t n, int32_t const* offsets, int32_t const* indices, int32_t* bigq,
-                                                                sssp_multi_state<WT> s, int32_t big_deg)
-{
-  __shared__ multi_queue_storage st;
-  mq_init<WT>(st, s);
-  sssp_relax_multi<WT> f{s, &st};
-  sssp_pop<WT> keep = sssp_pop_of<WT>(s);
-  expand_frontier(q, n, offsets, indices, bigq, s.cnt, keep, f, big_deg);
-  mq_flush(st);
-}
-template <typename WT>
-__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_big_multi(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, sssp_multi_state<WT> s)
-{
-  __shared__ multi_queue_storage st;
-  mq_init<WT>(st, s);
-  sssp_relax_multi<WT> f{s, &st};
-  expand_big(bigq, offsets, indices, s.cnt, f);
-  mq_flush(st);
-}
-// ---- device-driven rounds (CUGRAPH_AMD_SSSP_MODE=dev): the host enqueues a BATCH of rounds -- expand, deferred rows, control -- and
-// synchronises once per batch; which queue a round drains, how long it is and its dedup tag come from a control block in device
-// memory that a one-wavefront control kernel advances after every round (next round of the same sub-queue while it yields entries,
-// then the next non-empty sub-queue; `done` once the window is exhausted: the remaining kernels of the batch return at once).  A
-// host-driven round costs ~100 us of launches, counter upload and read-back whatever it relaxes; here it costs three back-to-back
-// launches.  The control block lives in the padding of counters_t (the n_set line, unused by this path): one read-back brings
-// the cursors and the control state.
-struct sssp_ctl_t {
-  unsigned long long relaxed;  // edges inspected by the rounds of this batch sequence
-  uint32_t done;
-  uint32_t j;              // sub-queue being drained
-  uint32_t n_front;        // entries of the current frontier
-  uint32_t front_is_same;  // 0: the frontier is sub-queue j itself, 1: q_same[cur] (a later round of sub-queue j)
-  uint32_t cur;
-  uint32_t round;          // dedup tag of the running round
-  uint32_t rounds;         // rounds run
-};
-static_assert(sizeof(sssp_ctl_t) <= 14 * 4, "sssp_ctl_t lives in counters_t::padl2[1..14]");
-__host__ __device__ inline sssp_ctl_t* sssp_ctl_of(counters_t* cnt) { return reinterpret_cast<sssp_ctl_t*>(&cnt->padl2[1]); }
-
-template <typename WT>
-struct sssp_dev_args {
-  sssp_multi_state<WT> s;  // the fields of the window; j / round_tag / q_same are taken from the control block by every kernel
-  int32_t* qsame[2];
-  int32_t narrow_limit;    // frontiers shorter than this defer every row a wavefront would walk alone (big_deg_for)
-  int kk;                  // sub-queues in use
-};
-template <typename WT>
-__device__ __forceinline__ bool sssp_dev_round(sssp_dev_args<WT> const& a, sssp_multi_state<WT>& s, int32_t const*& front, int64_t& n)
-{
-  sssp_ctl_t const c = *sssp_ctl_of(a.s.cnt);
-  if (c.done) return false;
-  s           = a.s;
-  s.j         = (int)c.j;
-  s.round_tag = c.round;
-  s.q_same    = a.qsame[(c.cur ^ 1u) & 1u];
-  int32_t const* f = a.qsame[c.cur & 1u];
-  if (!c.front_is_same) {
-#pragma unroll
-    for (int k = 0; k < SSSP_K; ++k)
-      if (k == (int)c.j) f = a.s.q[k];
-  }
-  front = f;
-  n     = (int64_t)c.n_front;
-  return true;
-}
-template <typename WT>
-__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_dev(int32_t const* offsets, int32_t const* indices, int32_t* bigq, sssp_dev_args<WT> a)
-{
-  __shared__ multi_queue_storage st;
-  sssp_multi_state<WT> s;
-  int32_t const* front;
-  int64_t n;
-  if (!sssp_dev_round<WT>(a, s, front, n)) return;
-  mq_init_from<WT>(st, a.s, s);
-  sssp_relax_multi<WT> f{s, &st};
-  sssp_pop<WT> keep = sssp_pop_of<WT>(s);
-  expand_frontier(front, n, offsets, indices, bigq, s.cnt, keep, f, n < (int64_t)a.narrow_limit ? BIG_DEG_NARROW : BIG_DEG);
-  mq_flush(st);
-}
-template <typename WT>
-__global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_big_dev(int32_t const* bigq, int32_t const* offsets, int32_t const* indices, sssp_dev_args<WT> a)
-{
-  __shared__ multi_queue_storage st;
-  sssp_multi_state<WT> s;
-  int32_t const* front;
-  int64_t n;
-  if (!sssp_dev_round<WT>(a, s, front, n)) return;
-  if (s.cnt->n_big == 0) return;
-  mq_init_from<WT>(st, a.s, s);
-  sssp_relax_multi<WT> f{s, &st};
-  expand_big(bigq, offsets, indices, s.cnt, f);
-  mq_flush(st);
-}
-// one wavefront, after the two kernels of a round
-__global__ void k_sssp_ctl(counters_t* cnt, int kk)
-{
-  sssp_ctl_t* const ctl = sssp_ctl_of(cnt);
-  if (ctl->done) return;
-  int const lane = threadIdx.x & 63;
-  unsigned long long e = 0;
-  if (lane < CNT_REPLICAS) { e = cnt->rep[lane].edges; cnt->rep[lane].edges = 0; }
-  for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
-  if (lane != 0) return;
-  sssp_ctl_t c = *ctl;
-  c.relaxed += e + cnt->edges;
-  cnt->edges = 0;
-  c.rounds += 1;
-  c.round += 1;
-  uint32_t const n_next = cnt->n_next;
-  cnt->n_next = 0;
-  cnt->n_big  = 0;
-  if (n_next > 0) {
-    c.front_is_same = 1;
-    c.cur ^= 1u;
-    c.n_front = n_next;
-  } else {
-    uint32_t j = c.j + 1;  // sub-queue c.j is exhausted (entries for it went to q_same while it was drained)
-    while (j < (uint32_t)kk && cnt->padl0[j] == 0) ++j;
-    if (j >= (uint32_t)kk) {
-      c.done = 1;
-    } else {
-      c.j             = j;
-      c.front_is_same = 0;
-      c.n_front       = cnt->padl0[j];
-      cnt->padl0[j]   = 0;
-    }
-  }
-  *ctl = c;
-}
-
-// far pile -> the sub-queues of the new window [lower, upper) | far pile'
-template <typename WT>
-__global__ void __launch_bounds__(TV_BLOCK) k_sssp_split_multi(int32_t const* far_in, int64_t n, sssp_multi_state<WT> s, int32_t* far_out, uint32_t new_epoch)
-{
-  using B = dist_bits<WT>;
-  __shared__ multi_queue_storage st;
-  mq_init<WT>(st, s);
-  if (threadIdx.x == 0) st.q[SSSP_K + 1] = far_out;  // the kept entries go to the other far buffer
-  __syncthreads();
-  int const lane = threadIdx.x & 63;
-  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t n_pad  = (n + 63) & ~(int64_t)63;
-  unsigned long long kept_min = ~0ull;
-  for (; i < n_pad; i += stride) {
-    bool near = false, keep = false;
-    int32_t v = 0;
-    int k = 0;
-    if (i < n) {
-      v    = far_in[i];
-      WT d = B::from(s.dist[v]);
-      if (d >= s.lower) {
-        if (d < s.upper()) {
-          k = sssp_sub_of<WT>(d, s);
-          uint32_t const tag = st.tag[k];
-          near = atomicExch(&s.mark[v], tag) != tag;
-        } else {
-          keep = atomicExch(&s.mark_far[v], new_epoch) != new_epoch;
-          if (keep) kept_min = min(kept_min, (unsigned long long)B::to(d));
-        }
-      }
-    }
-    uint64_t m = __ballot(near);
-    while (m) {
-      int const l  = __ffsll((unsigned long long)m) - 1;
-      int const k0 = __shfl(k, l);
-      bool const mine = near && k == k0;
-      mq_push(st, k0, mine, v);
-      m &= ~__ballot(mine);
-    }
-    mq_push(st, SSSP_K + 1, keep, v);
-  }
-  mq_flush(st);
-  for (int o = 32; o > 0; o >>= 1) kept_min = min(kept_min, (unsigned long long)__shfl_xor(kept_min, o));
-  if (lane == 0 && kept_min != ~0ull) {
-    if constexpr (sizeof(WT) == 4) atomicMin(&s.cnt->far_min_bits_lo, (uint32_t)kept_min);
-    else atomicMin(&s.cnt->far_min_bits64, kept_min);
   }
 }
 
@@ -1019,7 +972,7 @@ __global__ void k_sssp_band_keys(int32_t const* front, int64_t n, typename dist_
   }
 }
 
-// packed (distance, parent) words -> the two result columns; parent INT32_MAX (none: unreached, or the source) -> -1
+// packed (distance, parent) words -> the two result columns; low word kPkNoParent (unreached, or the source) -> -1, else the label without its bias
 __global__ void k_sssp_unpack(unsigned long long const* pk, int64_t n, uint32_t* dist_bits_out, int32_t* pred)
 {
   int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1027,8 +980,8 @@ __global__ void k_sssp_unpack(unsigned long long const* pk, int64_t n, uint32_t*
   for (; i < n; i += stride) {
     unsigned long long const w = pk[i];
     dist_bits_out[i] = (uint32_t)(w >> 32);
-    int32_t const p  = (int32_t)(uint32_t)w;
-    pred[i]          = p == INT32_MAX ? -1 : p;
+    uint32_t const p = (uint32_t)w;
+    pred[i]          = p == (uint32_t)kPkNoParent ? -1 : (int32_t)(p ^ 0x80000000u);
   }
 }
 
@@ -1189,10 +1142,6 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   bool const bu_profile = getenv("CUGRAPH_AMD_BFS_PROFILE") != nullptr;
   // edges per deferred work unit of a NARROW frontier (CUGRAPH_AMD_BFS_NARROW_SEG: 64 ... 4096, power of two not required)
   int32_t const narrow_seg = getenv("CUGRAPH_AMD_BFS_NARROW_SEG") ? std::max(64, std::min(4096, atoi(getenv("CUGRAPH_AMD_BFS_NARROW_SEG")))) : BIG_SEG_NARROW;
-  // OPT-IN (CUGRAPH_AMD_BFS_PULL_PARENTS=1), measured at RMAT-24 (32 roots, profiles/r5d_bfs_ab.txt): 1.74 ms against 1.37 ms with the
-  // atomicMin in the push.  The levels that run top-down are the ones whose discoveries are HUBS (one frontier vertex discovering 1 141 vertices
-  // of 10^4-10^5 in-edges each): a pull scans half of every such row to find the one frontier member, the push reads the frontier's out-edges once.
-  bool const pull_parents_on = getenv("CUGRAPH_AMD_BFS_PULL_PARENTS") != nullptr && atoi(getenv("CUGRAPH_AMD_BFS_PULL_PARENTS")) != 0;
   char const* env_bug = getenv("CUGRAPH_AMD_BU_GRID");  // workgroups per CU of the bottom-up kernel (experiments)
   int const bu_grid = (int)std::max<int64_t>(1, std::min<int64_t>(((nv + 63) / 64 + TV_WAVES * BU_GROUPS - 1) / (TV_WAVES * BU_GROUPS),
                                                                   (int64_t)h.num_cus * (env_bug ? atoi(env_bug) : 16)));
@@ -1238,9 +1187,7 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
         front_is_bitmap = false;
         mark("bitmap_to_queue", (long long)depth, n_cur);
       }
-      // with in-edges at hand the parents of this level's discoveries are pulled afterwards (k_bfs_pull_parents); the push leaves pred alone
-      bool const pull_parents = pred_p != nullptr && in != nullptr && pull_parents_on;
-      bfs_state s{dist->buf.as<int32_t>(), pull_parents ? (int32_t*)nullptr : pred_p, vis_prev.data(), vis_new.data(), q_nxt,
+      bfs_state s{dist->buf.as<int32_t>(), pred_p, vis_prev.data(), vis_new.data(), q_nxt,
                   cnt.data(), out_off, in_off, (int32_t)(depth + 1)};
       {
         timed_launch t(h, "bfs_expand");
@@ -1249,13 +1196,6 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
                            (int32_t const*)o.indices.data(), bigq.data(), s, big_deg_for(h, n_cur), seg);
         hipLaunchKernelGGL(k_bfs_expand_big, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
                            (int32_t const*)o.indices.data(), s, seg);
-        if (pull_parents) {  // (vis_prev still is the visited set of the level's start; bigq is free again)
-          hipLaunchKernelGGL(k_bfs_pull_parents, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)q_nxt, cnt.data(), in_off, in_idx, (uint32_t const*)vis_prev.data(), pred_p,
-                             bigq.data());
-          if (in->max_degree > BFS_PULL_LONG)
-            hipLaunchKernelGGL(k_bfs_pull_parents_long, h.num_cus * 4, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (counters_t const*)cnt.data(), in_off, in_idx,
-                               (uint32_t const*)vis_prev.data(), pred_p);
-        }
       }
       if (!in) HIP_TRY(hipMemcpyAsync(vis_prev.data(), vis_new.data(), nwords * 4, hipMemcpyDeviceToDevice, h.stream));
       mark("top_down", (long long)depth, n_cur);
@@ -1280,7 +1220,7 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
     if (depth >= limit) break;
   }
   // statistics: every discovered vertex was counted (with its out-degree) by the level that found it -- no extra pass
-  h.last_stats = cugraph_amd_traversal_stats_t{levels, edges, reached_total, edges_of_reached};
+  h.last_stats = cugraph_amd_traversal_stats_t{levels, edges, reached_total, edges_of_reached, 0};
   (void)bu_levels;
   // the vertex column (a copy of the numbering: the result owns its columns) and, bfs.cpp:131-138, the predecessors back in external ids:
   // one kernel (the 64 MB device-to-device copy of the runtime took 80 us at RMAT-24, a streaming kernel takes 30)
@@ -1292,58 +1232,6 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   outer_replace_dist(h, g, r->distances);  // BFS distances carry the vertex type (bfs.cpp:156-187)
   outer_replace_ids(h, g, r->predecessors);
   return r;
-}
-
-// ---- light / heavy copy of the CSR (sssp_lh_t, common.hpp)
-template <typename WT>
-__global__ void k_lh_keys(int32_t const* offsets, WT const* w, int64_t nv, WT delta, uint64_t* keys, uint32_t* vals)
-{  // one wavefront per row: key = row << 1 | heavy, payload = edge position
-  int64_t const wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  int const lane = threadIdx.x & 63;
-  for (int64_t v = wave; v < nv; v += nwaves) {
-    int32_t const b = offsets[v], e = offsets[v + 1];
-    for (int32_t p = b + lane; p < e; p += 64) { keys[p] = ((uint64_t)v << 1) | (w[p] > delta ? 1u : 0u); vals[p] = (uint32_t)p; }
-  }
-}
-__global__ void k_lh_ends_init(int32_t const* offsets, int64_t nv, int32_t* light_end)
-{
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < nv; i += stride) light_end[i] = offsets[i + 1];
-}
-__global__ void k_lh_ends(uint64_t const* keys, int64_t ne, int32_t* light_end)
-{  // first position of every (row, heavy) group
-  int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
-  for (; p < ne; p += stride) {
-    uint64_t const k = keys[p];
-    if ((k & 1u) && (p == 0 || keys[p - 1] != k)) light_end[k >> 1] = (int32_t)p;
-  }
-}
-template <typename WT>
-std::shared_ptr<sssp_lh_t> build_sssp_lh(handle_t const& h, graph_t const& g, orientation_t const& o, double delta)
-{
-  build_trace tr(h, "sssp l/h");
-  auto lh   = std::make_shared<sssp_lh_t>();
-  lh->delta = delta;
-  int64_t const nv = g.nv, ne = g.ne;
-  lh->indices.resize_discard((size_t)ne + kEdgePad);
-  lh->weights.alloc(((size_t)ne + kEdgePad) * sizeof(WT));
-  lh->light_end.resize_discard((size_t)std::max<int64_t>(nv, 1));
-  HIP_TRY(hipMemsetAsync(lh->indices.data() + ne, 0, kEdgePad * sizeof(int32_t), h.stream));
-  HIP_TRY(hipMemsetAsync(static_cast<char*>(lh->weights.ptr) + ne * sizeof(WT), 0, kEdgePad * sizeof(WT), h.stream));
-  dvec<uint64_t> keys((size_t)ne), keys_tmp((size_t)ne);
-  dvec<uint32_t> vals((size_t)ne), vals_tmp((size_t)ne);
-  hipLaunchKernelGGL(k_lh_keys<WT>, grid_for(nv * 16, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)o.offsets.data(), o.weights.as<WT const>(), nv, (WT)delta,
-                     keys.data(), vals.data());
-  int vb = 1;
-  while (vb < 40 && (((uint64_t)std::max<int64_t>(nv - 1, 1)) >> vb) != 0) ++vb;
-  radix_sort_u64_u32(h, keys.data(), vals.data(), keys_tmp.data(), vals_tmp.data(), ne, 0, vb + 1);
-  gather_b32(h, reinterpret_cast<uint32_t const*>(o.indices.data()), vals.data(), reinterpret_cast<uint32_t*>(lh->indices.data()), ne);
-  if (sizeof(WT) == 4) gather_b32(h, o.weights.as<uint32_t const>(), vals.data(), lh->weights.as<uint32_t>(), ne);
-  else                 gather_b64(h, o.weights.as<uint64_t const>(), vals.data(), lh->weights.as<uint64_t>(), ne);
-  hipLaunchKernelGGL(k_lh_ends_init, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)o.offsets.data(), nv, lh->light_end.data());
-  hipLaunchKernelGGL(k_lh_ends, grid_for(ne, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), ne, lh->light_end.data());
-  h.sync();
-  return lh;
 }
 
 template <typename WT>
@@ -1414,460 +1302,200 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   double delta   = avg_w * 32.0 / std::max(avg_deg, 1.0);
   if (char const* e = getenv("CUGRAPH_AMD_SSSP_DELTA_SCALE")) delta *= atof(e);  // tuning knob (bucket width multiplier)
   if (!(delta > 0.0) || !std::isfinite(delta)) delta = 1.0;
-  // Light / heavy buckets (Meyer & Sanders' delta-stepping): with the wide buckets above a vertex is re-expanded every time its
-  // distance improves -- 2.4 relaxations per edge at RMAT-24 with weights 1..255.  Narrow buckets cure that only if the edges that
-  // cannot land in the current bucket (w > delta: "heavy") are relaxed ONCE, when the bucket closes and its members' distances are
-  // final; inside the bucket only the light edges are relaxed.  Needs every row's light edges first: sssp_lh_t, built once per graph.
-  char const* env_lh = getenv("CUGRAPH_AMD_SSSP_LH");
-  // Measured at RMAT-24, weights 1..255 (16 roots): relaxations per edge 2.25 -> 1.24, rounds 18 -> 46, time 11.5 -> 12.4 ms (delta / 4;
-  // delta / 2: 14.9, delta / 8: 15.9): what a round costs is the SUCCESSFUL updates (atomicMin + mark exchange + queue append, and
-  // the far pile that every bucket re-splits), not the failed relaxations this scheme removes.  So the path is opt-in
-  // (CUGRAPH_AMD_SSSP_LH=1) and covered by test_sssp_light_heavy_buckets_vs_oracle; wide buckets stay the default.
-  bool const use_lh  = g.ne > 0 && g.ne <= kMaxSignedEdges && env_lh && atoi(env_lh) != 0;  // (the light / heavy copy keeps signed positions)
-  if (use_lh) {
-    char const* env_s = getenv("CUGRAPH_AMD_SSSP_LH_SCALE");
-    delta *= env_s ? atof(env_s) : 0.25;
-    if (!(delta > 0.0) || !std::isfinite(delta)) delta = 1.0;
-    orientation_t& ow = g.csr;
-    if (!ow.lh || ow.lh->delta != delta) ow.lh = build_sssp_lh<WT>(h, g, o, delta);
-  }
-  int32_t const* row_beg  = o.offsets.data();
-  int32_t const* adj      = use_lh ? g.csr.lh->indices.data() : o.indices.data();
-  int32_t const* lend     = use_lh ? g.csr.lh->light_end.data() : nullptr;
-  WT const* wrel          = use_lh ? g.csr.lh->weights.template as<WT const>() : w;
-  dvec<int32_t> sa(use_lh ? n1 : 1), sb(use_lh ? n1 : 1);
-  dvec<uint32_t> mark_set(use_lh ? n1 : 1);
-  if (use_lh) HIP_TRY(hipMemsetAsync(mark_set.data(), 0, n1 * 4, h.stream));
-
-  // Opt-in schedules (CUGRAPH_AMD_SSSP_MODE; same fixed point, tested bit for bit against Dijkstra by test_sssp_subqueues_vs_oracle):
-  //   multi  distance-ordered sub-queues inside the window (k_sssp_expand_multi): 8 sub-queues 1.64 relaxations per edge instead of 2.2,
-  //          49.6 rounds instead of 18.4 -- and 12.7 ms instead of 11.5 at RMAT-24, weights 1..255 (profiles/r3_sssp_subqueues.txt)
-  //   dev    the same with the rounds of a window driven from the device (k_sssp_ctl; one host synchronisation per batch of rounds): 12.1 ms
-  //   radix  radix-heap sub-queues (below): 0.99-1.4 relaxations per edge, 108 rounds, 21.8 ms
-  // What CUGRAPH_AMD_SSSP_TRACE shows (profiles/r3_sssp_rounds.txt): an empty round costs 23 us, not the 100 us assumed in round 2; of the
-  // 11 ms of a traversal 9 are FOUR rounds -- the hubs right after the source (66 K vertices, 79 M edges, most relaxations succeed:
-  // 24 G edges/s), the sweep over nearly every edge (259 M, 73 G/s) and its two echoes (140 M, 33 M).  Ordering the work more finely
-  // moves edges from the efficient sweep into rounds of the first kind and adds a pass over the bucket per cut; it removes relaxations,
-  // not time.  What did help the wide rounds is more edges in flight per lane (expand_*_mlp: 11.3 -> 10.4 ms).  The single near queue
-  // stays the default.
-  char const* env_mode = getenv("CUGRAPH_AMD_SSSP_MODE");
-  bool const use_dev   = !use_lh && env_mode && std::string(env_mode) == "dev";    // uniform sub-queues + device-driven rounds (k_sssp_ctl)
-  bool const use_radix = !use_lh && env_mode && std::string(env_mode) == "radix";  // radix-heap sub-queues (see below)
-  bool const use_multi = !use_lh && env_mode && (std::string(env_mode) == "multi" || use_dev || use_radix);
-  static bool const sssp_trace_multi = getenv("CUGRAPH_AMD_SSSP_TRACE") != nullptr;
-  uint64_t steps = 0, relaxed = 0;
+  // Schedules that were built, tested bit for bit against Dijkstra and measured SLOWER than this one over rounds 2-5 are gone from the source
+  // (their numbers stay in profiles/ and DESIGN.md section 3.4): light / heavy buckets (1.24 relaxations per edge instead of 2.25 -- and 12.4 ms
+  // instead of 11.5: what a round costs is the successful updates and the far-pile re-splits, not the failed relaxations), distance-ordered /
+  // radix-heap sub-queues inside the window and device-driven rounds (12.1-21.8 ms), pull rounds over the in-edges for the hub round (12.1 against 11.0).
+  int32_t const* row_beg = o.offsets.data();
+  int32_t const* adj     = o.indices.data();
+  uint64_t steps = 0, relaxed = 0, probed = 0;
   counters_t c;
-  // fp32 + predecessors: (distance, parent) packed into one 64-bit word per vertex, lowered by one atomicMin per successful relaxation
-  // (sssp_relax<WT, true>): no sweep over the settled edges afterwards.  Default schedule only; CUGRAPH_AMD_SSSP_PACKED=0 keeps the sweep.
-  bool packed = false;
-  dvec<unsigned long long> pk;
-  if (use_multi) {
-    std::vector<dvec<int32_t>> subq(SSSP_K);
-    for (auto& q : subq) q.resize_discard(n1);
-    dvec<bits_t> done(n1);
-    hipLaunchKernelGGL(k_fill_t<bits_t>, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, done.data(), nv, unreached_bits);
-    {
-      bits_t zero_bits = 0;
-      HIP_TRY(hipMemcpyAsync(d + source, &zero_bits, sizeof(bits_t), hipMemcpyHostToDevice, h.stream));
-      HIP_TRY(hipMemcpyAsync(subq[0].data(), &source, 4, hipMemcpyHostToDevice, h.stream));
-      h.sync();
-    }
-    char const* env_k = getenv("CUGRAPH_AMD_SSSP_SUBQ");  // uniform modes: sub-queues actually used (1 .. SSSP_K; 1 = the single near queue through these kernels)
-    int const kk = use_radix ? SSSP_K : (env_k ? std::max(1, std::min(SSSP_K, atoi(env_k))) : 8);
-    // the "work" of a sub-queue = its entries with at least average out-degree: ids are degree-sorted (renumbered graphs), so that is
-    // "ids below heavy_cut"; counted once per graph
-    if (g.sssp_heavy_cut < 0) {
-      int64_t cut = nv;
-      if (g.renumbered && nv > 0 && use_radix) {
-        dvec<unsigned long long> n_ge(1);
-        HIP_TRY(hipMemsetAsync(n_ge.data(), 0, 8, h.stream));
-        hipLaunchKernelGGL(k_count_degree_at_least, grid_for(nv, kBlock, 2048), kBlock, 0, h.stream, row_beg, nv, (uint32_t)std::max(1.0, std::ceil(avg_deg)), n_ge.data());
-        unsigned long long r = 0;
-        h.read_back(&r, (unsigned long long const*)n_ge.data(), 1);
-        cut = (int64_t)r;
-      }
-      g.sssp_heavy_cut = cut;
-    }
-    int32_t const heavy_cut = (int32_t)std::min<int64_t>(g.sssp_heavy_cut, INT32_MAX);
-    double lower = 0.0;
-    double ubh[SSSP_K];
-    uint32_t tagh[SSSP_K], next_tag = 0x80000000u;
-    // bucket 0 of the radix layout is delta / radix_div wide (delta = the reference's near / far width); the layout covers 2^(K-1) of those
-    char const* env_div = getenv("CUGRAPH_AMD_SSSP_RADIX_DIV");
-    double const delta0 = delta / (env_div ? std::max(1.0, atof(env_div)) : 256.0);
-    char const* env_sm = getenv("CUGRAPH_AMD_SSSP_SPLIT_MIN");
-    uint32_t const split_min = env_sm ? (uint32_t)std::max(1, atoi(env_sm)) : 2048u;
-    auto set_uniform = [&](double lo, double hi) {
-      lower = lo;
-      for (int k = 0; k < SSSP_K; ++k) { ubh[k] = k < kk - 1 ? lo + (hi - lo) * (double)(k + 1) / (double)kk : hi; tagh[k] = next_tag++; }
-    };
-    auto set_radix = [&](double lo) {  // widths d0, d0, 2 d0, 4 d0, ...
-      lower = lo;
-      for (int k = 0; k < SSSP_K; ++k) { ubh[k] = lo + delta0 * std::ldexp(1.0, k); tagh[k] = next_tag++; }
-    };
-    if (use_radix) set_radix(0.0); else set_uniform(0.0, delta);
-    uint32_t qn_h[SSSP_K] = {1u}, qh_h[SSSP_K] = {1u};
-    int32_t* same_nxt = qa.data();
-    int32_t* same_oth = qb.data();
-    int32_t* far_cur  = fa.data();
-    int32_t* far_nxt  = fb.data();
-    int32_t const* front = nullptr;
-    int64_t n_front = 0, n_far = 0;
-    uint32_t round = 0, far_epoch = 1;
-    int j = 0;
-    auto state = [&](int jj) {
-      sssp_multi_state<WT> s;
-      s.dist = d; s.weights = w; s.done = done.data();
-      for (int k = 0; k < SSSP_K; ++k) { s.q[k] = subq[k].data(); s.ub[k] = (WT)std::min(ubh[k], (double)wmax); s.tag[k] = tagh[k]; }
-      s.q_same = same_nxt; s.far = far_cur; s.mark = mark_near.data(); s.mark_far = mark_far.data(); s.cnt = cnt.data();
-      s.qn = &cnt.data()->padl0[0];  // the sub-queue fills live in the padding behind n_next: one read-back per round brings everything
-      s.qh = &cnt.data()->padl1[0];  // ... their heavy counts behind n_far
-      s.lower = (WT)std::min(lower, (double)wmax); s.cutoff = cutoff; s.heavy_cut = heavy_cut;
-      s.j = jj; s.round_tag = round; s.far_epoch = far_epoch;
-      return s;
-    };
-    auto upload_counters = [&]() {
-      counters_t z{};
-      z.n_far = (uint32_t)n_far;
-      for (int k = 0; k < SSSP_K; ++k) { z.padl0[k] = qn_h[k]; z.padl1[k] = qh_h[k]; }
-      z.far_min_bits_lo = 0xFFFFFFFFu;
-      z.far_min_bits64  = ~0ull;
-      std::memcpy(h.pinned, &z, sizeof(z));
-      HIP_TRY(hipMemcpyAsync(cnt.data(), h.pinned, sizeof(z), hipMemcpyHostToDevice, h.stream));
-    };
-    auto download_counters = [&]() {
-      h.read_back(&c, cnt.data(), 1);
-      for (int k = 0; k < SSSP_K; ++k) {
-        qn_h[k] = c.padl0[k]; qh_h[k] = c.padl1[k];
-        CGA_EXPECTS((int64_t)qn_h[k] <= nv, CUGRAPH_UNKNOWN_ERROR, "sssp: sub-queue overflow");
-      }
-      c.fold();
-      n_far = c.n_far;
-      CGA_EXPECTS(n_far <= nv && (int64_t)c.n_next <= nv, CUGRAPH_UNKNOWN_ERROR, "sssp: queue overflow");
-    };
-    double far_min = 0.0;  // smallest distance the last split kept in the far pile
-    auto read_far_min = [&]() {
-      if constexpr (sizeof(WT) == 4) { float f; uint32_t b = c.far_min_bits_lo; std::memcpy(&f, &b, 4); far_min = f; }
-      else { double f; unsigned long long b = c.far_min_bits64; std::memcpy(&f, &b, 8); far_min = f; }
-    };
-    // entries of `in` -> the sub-queues of the current bounds (distances below `lower`: stale, dropped; at or beyond the last bound: far pile)
-    auto split_into_subqueues = [&](int32_t const* in, int64_t n_in, int32_t* far_out) {
-      ++round;
-      upload_counters();
-      sssp_multi_state<WT> s = state(0);
-      hipLaunchKernelGGL(k_sssp_split_multi<WT>, grid_for(n_in, TV_BLOCK, 2048), TV_BLOCK, 0, h.stream, in, n_in, s, far_out, far_epoch);
-      download_counters();
-      read_far_min();
-    };
-    // the sub-queues are exhausted: open the next window on the far pile
-    auto advance_window = [&]() {
-      double const upper = ubh[SSSP_K - 1];
-      if (use_radix) set_radix(upper); else set_uniform(upper, upper + delta);
-      for (;;) {
-        ++far_epoch;
-        int64_t const n_in = n_far;
-        n_far = 0;
-        split_into_subqueues(far_cur, n_in, far_nxt);
-        std::swap(far_cur, far_nxt);
-        bool any = false;
-        for (int k = 0; k < SSSP_K; ++k) any |= qn_h[k] != 0;
-        if (any || n_far == 0) break;
-        // empty window: jump to the one holding the smallest far distance (never past it: fl(dmin / step) may round up to an integer)
-        double const step = use_radix ? delta0 : delta;
-        double kq = std::floor(far_min / step);
-        while (kq > 0.0 && kq * step > far_min) kq -= 1.0;
-        double const lo = std::max(kq * step, ubh[SSSP_K - 1]);
-        if (use_radix) set_radix(lo); else set_uniform(lo, lo + delta);
-      }
-      j = 0;
-    };
-    auto one_round = [&](int jj) {
-      ++round;
-      ++steps;
-      upload_counters();
-      sssp_multi_state<WT> s = state(jj);
-      {
-        timed_launch t(h, "sssp_relax");
-        hipLaunchKernelGGL(k_sssp_expand_multi<WT>, expand_grid(h, n_front), TV_BLOCK, 0, h.stream, front, n_front, row_beg, adj, bigq.data(), s, big_deg_for(h, n_front));
-        hipLaunchKernelGGL(k_sssp_expand_big_multi<WT>, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), row_beg, adj, s);
-      }
-      download_counters();
-      if (sssp_trace_multi) {
-        static auto t_prev = std::chrono::steady_clock::now();
-        auto const now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[sssp multi] round %3u  sub-queue %2d [%g, %g)  frontier %9lld  edges %11llu  same %9u  far %9u  %8.1f us\n", round, jj,
-                jj ? ubh[jj - 1] : lower, ubh[jj], (long long)n_front, (unsigned long long)c.edges, c.n_next, c.n_far,
-                std::chrono::duration<double, std::micro>(now - t_prev).count());
-        t_prev = now;
-      }
-      relaxed += c.edges;
-      front   = same_nxt;
-      n_front = c.n_next;
-      std::swap(same_nxt, same_oth);
-    };
-    if (use_radix) {
-      // Radix-heap buckets (monotone: distances only ever enter sub-queues at or above the one being drained).  The first non-empty
-      // sub-queue k is either drained as it is -- a frontier Bellman-Ford inside its range, cheap when it holds little work -- or, when
-      // it holds at least split_min heavy vertices and is wider than delta0, cut into the k empty sub-queues below it (widths w / 2^(k-1),
-      // w / 2^(k-1), w / 2^(k-2), ..., w / 2) by one pass over ITS entries only: the dense part of the distance range ends up in
-      // sub-queues one delta0 wide (a vertex is expanded once, with its final distance), the sparse tail in a handful of wide ones.
-      for (;;) {
-        int k = 0;
-        while (k < SSSP_K && qn_h[k] == 0) ++k;
-        if (k == SSSP_K) {
-          if (n_far == 0) break;
-          advance_window();
-          continue;
-        }
-        double const lb = k ? ubh[k - 1] : lower, wd = ubh[k] - lb;
-        if (k > 0 && qh_h[k] >= split_min && wd > delta0 * 1.5) {
-          int m = 1 + (int)std::floor(std::log2(wd / delta0) + 1e-6);  // finest sub-queue no narrower than delta0
-          m     = std::max(2, std::min(m, k));
-          lower = lb;
-          for (int i = 0; i < k; ++i) {
-            ubh[i]  = i < m - 1 ? lb + wd * std::ldexp(1.0, i - (m - 1)) : ubh[k];
-            tagh[i] = next_tag++;
-          }
-          int64_t const n_in = qn_h[k];
-          qn_h[k] = 0; qh_h[k] = 0;
-          tagh[k] = next_tag++;  // (its range is empty now)
-          split_into_subqueues(subq[k].data(), n_in, far_cur);
-          if (sssp_trace_multi)
-            fprintf(stderr, "[sssp multi] sub-queue %d [%g, %g): %lld entries cut into %d sub-queues\n", k, lb, ubh[k], (long long)n_in, m);
-          continue;
-        }
-        front   = subq[k].data();
-        n_front = qn_h[k];
-        qn_h[k] = 0; qh_h[k] = 0;
-        while (n_front > 0) one_round(k);
-        lower = ubh[k];
-      }
-    } else if (use_dev) {
-      char const* env_b = getenv("CUGRAPH_AMD_SSSP_BATCH");  // rounds enqueued per host synchronisation
-      int const batch   = env_b ? std::max(1, atoi(env_b)) : 8;
-      int const grid    = h.num_cus * 8;
-      for (;;) {
-        int j0 = 0;
-        while (j0 < SSSP_K && qn_h[j0] == 0) ++j0;
-        if (j0 == SSSP_K) {
-          if (n_far == 0) break;
-          advance_window();
-          continue;
-        }
-        ++round;
-        sssp_dev_args<WT> a;
-        a.s            = state(j0);
-        a.qsame[0]     = qa.data();
-        a.qsame[1]     = qb.data();
-        a.narrow_limit = (int32_t)std::min<int64_t>((int64_t)h.num_cus * 64, INT32_MAX);
-        a.kk           = kk;
-        {
-          counters_t z{};
-          z.n_far = (uint32_t)n_far;
-          for (int k = 0; k < SSSP_K; ++k) z.padl0[k] = k == j0 ? 0u : qn_h[k];
-          z.far_min_bits_lo = 0xFFFFFFFFu;
-          z.far_min_bits64  = ~0ull;
-          sssp_ctl_t c0{};
-          c0.j = (uint32_t)j0; c0.n_front = qn_h[j0]; c0.round = round;
-          *sssp_ctl_of(&z) = c0;
-          std::memcpy(h.pinned, &z, sizeof(z));
-          HIP_TRY(hipMemcpyAsync(cnt.data(), h.pinned, sizeof(z), hipMemcpyHostToDevice, h.stream));
-        }
-        sssp_ctl_t ctl{};
-        for (;;) {
-          {
-            timed_launch t(h, "sssp_relax");
-            for (int b = 0; b < batch; ++b) {
-              hipLaunchKernelGGL(k_sssp_expand_dev<WT>, grid, TV_BLOCK, 0, h.stream, row_beg, adj, bigq.data(), a);
-              hipLaunchKernelGGL(k_sssp_expand_big_dev<WT>, grid, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), row_beg, adj, a);
-              hipLaunchKernelGGL(k_sssp_ctl, 1, 64, 0, h.stream, cnt.data(), SSSP_K);
-            }
-          }
-          h.read_back(&c, cnt.data(), 1);
-          ctl = *sssp_ctl_of(&c);
-          CGA_EXPECTS((int64_t)c.n_far <= nv && (int64_t)c.n_next <= nv, CUGRAPH_UNKNOWN_ERROR, "sssp: queue overflow");
-          for (int k = 0; k < SSSP_K; ++k) CGA_EXPECTS((int64_t)c.padl0[k] <= nv, CUGRAPH_UNKNOWN_ERROR, "sssp: sub-queue overflow");
-          if (ctl.done) break;
-        }
-        steps += ctl.rounds;
-        relaxed += ctl.relaxed;
-        round = ctl.round;
-        n_far = c.n_far;
-        for (int k = 0; k < SSSP_K; ++k) { qn_h[k] = 0; qh_h[k] = 0; }
-      }
-    } else {
-      for (;;) {
-        if (n_front == 0) {
-          while (j < SSSP_K && qn_h[j] == 0) ++j;
-          if (j < SSSP_K) {  // drain the next non-empty sub-queue
-            front   = subq[j].data();
-            n_front = qn_h[j];
-            qn_h[j] = 0; qh_h[j] = 0;
-          } else {
-            if (n_far == 0) break;
-            advance_window();
-            continue;
-          }
-        }
-        one_round(j);
-      }
-    }
-  } else {
   {  // d[source] = 0, near = {source}
     bits_t zero_bits = 0;
     HIP_TRY(hipMemcpyAsync(d + source, &zero_bits, sizeof(bits_t), hipMemcpyHostToDevice, h.stream));
     HIP_TRY(hipMemcpyAsync(qa.data(), &source, 4, hipMemcpyHostToDevice, h.stream));
-    if (use_lh) {  // the source is the first member of the first bucket
-      uint32_t const one = 1;
-      HIP_TRY(hipMemcpyAsync(sa.data(), &source, 4, hipMemcpyHostToDevice, h.stream));
-      HIP_TRY(hipMemcpyAsync(mark_set.data() + source, &one, 4, hipMemcpyHostToDevice, h.stream));
-    }
     h.sync();
   }
   int32_t* q_cur = qa.data();
   int32_t* q_nxt = qb.data();
   int32_t* far_cur = fa.data();
   int32_t* far_nxt = fb.data();
-  int64_t n_cur = 1, n_far = 0, n_set = use_lh ? 1 : 0;
-  int32_t* set_cur = sa.data();
-  int32_t* set_nxt = sb.data();
-  uint32_t round = 0, far_epoch = 1, set_epoch = 1;
+  int64_t n_cur = 1, n_far = 0;
+  uint32_t round = 0, far_epoch = 1;
   double lower = 0.0, upper = delta;
-  // one relaxation round over the rows [beg[u], end[u]) of the vertices in `front`; near / far / bucket-member appends continue
-  // at n_far / n_set_in (they persist across the rounds of a bucket), n_next / n_big / edges start from zero
-  // pull rounds (sssp_pull_fn): chosen from the frontier's out-edge count, which the round that built the frontier summed on the device
-  // OPT-IN (CUGRAPH_AMD_SSSP_PULL=1; "force": every round, the parity test): measured at RMAT-24, weights 1..255 (profiles/r4o_sssp_pull.txt): the
-  // round of the 66 K hubs right after the source takes 2.7 ms pulled (268 M in-edges streamed, 82 M of them relaxed; the rows of 2048 or
-  // more in-edges -- 82 M edges -- still go through the atomic path) against 2.5 ms pushed, and a traversal 12.1 ms against 11.0: no gain.
-  char const* env_pull     = getenv("CUGRAPH_AMD_SSSP_PULL");
-  bool const pull_allowed  = !use_lh && g.ne <= kMaxSignedEdges && env_pull && std::string(env_pull) != "0";
-  bool const pull_force    = pull_allowed && env_pull && std::string(env_pull) == "force";
-  uint64_t const pull_min_edges = std::max<uint64_t>((uint64_t)g.ne / 10, (uint64_t)1 << 22);
-  uint64_t front_edges = 0;  // out-edges of the current near frontier (0 for the source: its round is a push)
-  dvec<uint32_t> fbits;
+  uint64_t front_edges = 0;  // out-edges of the current near frontier (0 for the source)
+  // fp32 + predecessors: (distance, parent) packed into one 64-bit word per vertex, lowered by one atomicMin per successful relaxation
+  // (sssp_relax<WT, true>): no sweep over the settled edges afterwards.  CUGRAPH_AMD_SSSP_PACKED=0 keeps the sweep (what fp64 runs).
+  bool packed = false;
+  dvec<unsigned long long> pk;
   {
     char const* env_pk = getenv("CUGRAPH_AMD_SSSP_PACKED");
-    packed = compute_predecessors && sizeof(WT) == 4 && !use_lh && !pull_allowed && !(env_pk && std::string(env_pk) == "0");
+    packed = compute_predecessors && sizeof(WT) == 4 && !(env_pk && std::string(env_pk) == "0");
     if (packed) {
       pk.resize_discard(n1);
-      unsigned long long const none = ((unsigned long long)(uint32_t)unreached_bits << 32) | 0x7FFFFFFFull;
+      unsigned long long const none = ((unsigned long long)(uint32_t)unreached_bits << 32) | kPkNoParent;
       hipLaunchKernelGGL(k_fill_t<unsigned long long>, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, pk.data(), nv, none);
-      unsigned long long const at_source = 0x7FFFFFFFull;  // distance 0, no parent
+      unsigned long long const at_source = kPkNoParent;  // distance 0, no parent
       HIP_TRY(hipMemcpyAsync(pk.data() + source, &at_source, 8, hipMemcpyHostToDevice, h.stream));
       h.sync();  // (at_source is a local)
     }
   }
+  bits_t const* const dist_words = packed ? reinterpret_cast<bits_t const*>(pk.data()) : (bits_t const*)d;  // what the PK = packed kernels read distances from
   static bool const sssp_trace = getenv("CUGRAPH_AMD_SSSP_TRACE") != nullptr;  // per round: sizes and wall time since the previous line (stderr)
   auto t_trace = std::chrono::steady_clock::now();
   // The hub round -- the few ten thousand hubs right after the source, whose out-edges are a third of the graph and whose relaxations mostly
   // SUCCEED (a vertex reached from k hubs is lowered ~ln k times when they arrive in any order) -- takes its frontier ordered by tentative
   // distance (256 bands of the window, one 8-bit radix pass): the closest hubs go first, later candidates mostly fail the cheap pre-test.
   // RMAT-24, weights 1..255, 16 roots, same session: 12.19 -> 11.78 ms with predecessors, 11.04 -> 10.74 without (profiles/r5g_sssp_sort.txt);
-  // ordering EVERY wide round costs more (the sorts) than the 5 % of relaxations it saves (r5f_sssp_sort.txt).  CUGRAPH_AMD_SSSP_SORT=0: off,
-  // =n: every round of at least n vertices (the experiment).
+  // ordering EVERY wide round costs more (the sorts) than the 5 % of relaxations it saves (r5f_sssp_sort.txt).  CUGRAPH_AMD_SSSP_SORT=0: off.
   char const* env_sort = getenv("CUGRAPH_AMD_SSSP_SORT");
-  bool const sort_hub_only = env_sort == nullptr || std::string(env_sort) == "hub";
-  int64_t const sort_min = sort_hub_only ? 1024 : std::max<int64_t>(0, atoll(env_sort));  // 0 = off
+  bool const sort_hubs = !(env_sort && std::string(env_sort) == "0");
   dvec<uint64_t> sk, sk_out;
   dvec<uint32_t> sv, sv_out, sort_hist;
-  auto relax_round = [&](int32_t const* front, int64_t n_front, int32_t const* beg, int32_t const* end, int32_t* set_out, int64_t n_set_in) {
+  // the distance filter (sssp_filter): rounds of at least ne / 32 relaxations (a build costs two passes over the distances, ~60 us at RMAT-24)
+  char const* env_flt = getenv("CUGRAPH_AMD_SSSP_FILTER");  // 0: off (the A/B switch of the parity test and of the bench's comparison line)
+  bool const filter_force = env_flt && std::string(env_flt) == "force";  // every round, whatever its size (the parity test)
+  bool const filter_on = filter_force || (!(env_flt && std::string(env_flt) == "0") && nv >= 4096);
+  uint64_t const filter_min_edges = filter_force ? 0 : std::max<uint64_t>((uint64_t)g.ne / 32, (uint64_t)1 << 20);
+  char const* env_s2 = getenv("CUGRAPH_AMD_SSSP_TWO_STAGE");  // 0: filtered rounds keep the one-stage kernels (A/B)
+  bool const two_stage = !(env_s2 && std::string(env_s2) == "0");
+  char const* env_sw = getenv("CUGRAPH_AMD_SSSP_SWEEP");  // share of the graph's edges a frontier must hold for a streamed round (0: never)
+  double const sweep_frac = env_sw ? atof(env_sw) : 0.25;
+  bool const sweep_on = sweep_frac > 0.0 && g.ne > 0;
+  char const* env_hot = getenv("CUGRAPH_AMD_SSSP_HOT");
+  bool const hot_cache_on = !(env_hot && std::string(env_hot) == "0");
+  char const* env_s2g = getenv("CUGRAPH_AMD_SSSP_S2_GRID");
+  int const s2_wg_per_cu = env_s2g ? std::max(1, atoi(env_s2g)) : 4;  // workgroups per CU of the two-stage kernels (their LDS buffers allow ~4 residents)
+  dvec<uint32_t> fbits;
+  dvec<unsigned long long> fhist;
+  dvec<WT> ft;
+  if (filter_on) {
+    fbits.resize_discard((size_t)((nv + 63) / 64) * 2 + 2);
+    fhist.resize_discard(2 * (SF_BANDS + 1));
+    ft.resize_discard(1);
+    HIP_TRY(hipMemsetAsync(fhist.data(), 0, 2 * (SF_BANDS + 1) * sizeof(unsigned long long), h.stream));
+  }
+  auto with_words = [&](auto&& fn) {  // fn(std::bool_constant<PK>): the kernels that read distances exist for the packed and the plain layout
+    if constexpr (sizeof(WT) == 4) {
+      if (packed) { fn(std::true_type{}); return; }
+    }
+    fn(std::false_type{});
+  };
+  char const* env_ord = getenv("CUGRAPH_AMD_SSSP_ORDER");  // 1: wide frontiers rebuilt in vertex order (measured SLOWER, 11.4 -> 13.1 ms: consecutive vertices have
+  bool const order_wide = env_ord && std::string(env_ord) == "1";  // similar degrees, so a wavefront's 64 rows are all of the slow whole-wave kind at once; profiles/r6j_sssp_ab.txt)
+  dvec<int32_t> ordered;
+  dvec<uint32_t> order_cursor;
+  dev_buf snap;
+  auto relax_round = [&](int32_t const* front, int64_t n_front) {
+    uint32_t const front_tag = round;  // every member of `front` carries mark_near == the round (or window advance) that appended it
     ++round;
     ++steps;
+    WT const lo = (WT)std::min(lower, (double)wmax);
     bool const hub_round = front_edges >= std::max<uint64_t>((uint64_t)g.ne / 10, (uint64_t)1 << 22) && n_front * 16 <= nv;  // few vertices, a large share of the edges
-    if (sort_min > 0 && n_front >= sort_min && !use_lh && (sort_hub_only ? hub_round && !g.weights_uniform : true)) {
+    if (sort_hubs && hub_round && n_front >= 1024 && !g.weights_uniform) {
       if ((int64_t)sk.size() < n_front) {
         sk.resize_discard((size_t)n_front); sk_out.resize_discard((size_t)n_front); sv.resize_discard((size_t)n_front); sv_out.resize_discard((size_t)n_front);
         sort_hist.resize_discard(radix_pass_scratch(n_front));
       }
-      WT const lo = (WT)std::min(lower, (double)wmax), inv = (WT)(256.0 / delta);
-      bool done = false;
-      if constexpr (sizeof(WT) == 4) {
-        if (packed) {
-          hipLaunchKernelGGL((k_sssp_band_keys<WT, true>), grid_for(n_front, kBlock, 4096), kBlock, 0, h.stream, front, n_front, reinterpret_cast<bits_t const*>(pk.data()), lo, inv, sk.data(), sv.data());
-          done = true;
-        }
-      }
-      if (!done) hipLaunchKernelGGL((k_sssp_band_keys<WT, false>), grid_for(n_front, kBlock, 4096), kBlock, 0, h.stream, front, n_front, (bits_t const*)d, lo, inv, sk.data(), sv.data());
+      WT const inv = (WT)(256.0 / delta);
+      with_words([&](auto pkc) {
+        hipLaunchKernelGGL((k_sssp_band_keys<WT, decltype(pkc)::value>), grid_for(n_front, kBlock, 4096), kBlock, 0, h.stream, front, n_front, dist_words, lo, inv, sk.data(), sv.data());
+      });
       radix_pass_u64_u32(h, sk.data(), sv.data(), sk_out.data(), sv_out.data(), n_front, 0, 8, sort_hist.data());
       front = reinterpret_cast<int32_t const*>(sv_out.data());
     }
+    bool const filtered = filter_on && front_edges >= filter_min_edges;
+    if (order_wide && !hub_round && n_front >= std::max<int64_t>(nv / 64, 4096) && front_edges >= filter_min_edges) {  // a wide frontier: its vertices in vertex order
+      if ((int64_t)ordered.size() < nv) { ordered.resize_discard(n1); order_cursor.resize_discard(1); }
+      HIP_TRY(hipMemsetAsync(order_cursor.data(), 0, 4, h.stream));
+      hipLaunchKernelGGL(k_sssp_front_in_vertex_order, std::min(h.num_cus * 8, (int)((nv + TV_BLOCK - 1) / TV_BLOCK)), TV_BLOCK, 0, h.stream, (uint32_t const*)mark_near.data(), nv,
+                         front_tag, ordered.data(), order_cursor.data());
+      front = ordered.data();
+    }
+    if (filtered) {
+      WT const band = (WT)(delta / SF_BANDS), inv = (WT)(SF_BANDS / delta);
+      with_words([&](auto pkc) {
+        constexpr bool PKC = decltype(pkc)::value;
+        hipLaunchKernelGGL((k_sssp_filter_hist<WT, PKC>), grid_for(n_front, 256, 1024), 256, 0, h.stream, front, n_front, dist_words, row_beg, lo, inv, fhist.data(), 0ull);
+        hipLaunchKernelGGL((k_sssp_filter_hist<WT, PKC>), grid_for(nv, 256, 2048), 256, 0, h.stream, (int32_t const*)nullptr, nv, dist_words, row_beg, lo, inv,
+                           fhist.data() + (SF_BANDS + 1), 1ull);
+        hipLaunchKernelGGL(k_sssp_filter_pick<WT>, 1, SF_BANDS, 0, h.stream, fhist.data(), fhist.data() + (SF_BANDS + 1), lo, band, (WT)avg_w, g.weights_uniform ? 1 : 0, ft.data());
+        hipLaunchKernelGGL((k_sssp_filter_bits<WT, PKC>), grid_for(nv, 256, 2048), 256, 0, h.stream, dist_words, nv, (WT const*)ft.data(), fbits.data());
+      });
+    }
     counters_t z{};
     z.n_far           = (uint32_t)n_far;
-    z.n_set           = (uint32_t)n_set_in;
     z.far_min_bits_lo = 0xFFFFFFFFu;
     z.far_min_bits64  = ~0ull;
     std::memcpy(h.pinned, &z, sizeof(z));
     HIP_TRY(hipMemcpyAsync(cnt.data(), h.pinned, sizeof(z), hipMemcpyHostToDevice, h.stream));
-    sssp_state<WT> s{d, wrel, q_nxt, far_cur, mark_near.data(), mark_far.data(), use_lh ? set_out : nullptr, mark_set.data(), set_epoch, cnt.data(),
-                     (WT)std::min(upper, (double)wmax), cutoff, round, far_epoch, (int32_t const*)o.offsets.data()};
+    sssp_state<WT> s{d, w, q_nxt, far_cur, mark_near.data(), mark_far.data(), cnt.data(), (WT)std::min(upper, (double)wmax), cutoff, round, far_epoch, row_beg};
     if (packed) { s.pk = pk.data(); s.labels = g.renumbered ? g.number_map.data() : nullptr; s.source = source; }
-    // few vertices with a large share of the graph's edges (the hubs right after the source): a pull round over the in-edges (sssp_pull_fn)
-    bool const pull = pull_allowed && (pull_force || (front_edges >= pull_min_edges && n_front * 16 <= nv));
-    if (pull) {
-      ensure_orientation(h, g, true);  // in-edges + their weights: built once per graph, next to the CSR under the same numbering
-      orientation_t const& ci = g.csc;
-      size_t const fw = (size_t)((nv + 31) / 32 + 1);
-      if (fbits.size() < fw) fbits.resize_discard(fw);
-      HIP_TRY(hipMemsetAsync(fbits.data(), 0, fw * 4, h.stream));
-      hipLaunchKernelGGL(k_queue_to_bits, grid_for(n_front, kBlock, 2048), kBlock, 0, h.stream, front, n_front, fbits.data());
-      s.weights = ci.weights.template as<WT const>();
-      {
-        timed_launch t(h, "sssp_relax");
-        int64_t const ngroup = (nv + 63) / 64;
-        int const grid       = (int)std::max<int64_t>(1, std::min<int64_t>((ngroup + TV_WAVES - 1) / TV_WAVES, (int64_t)h.num_cus * 16));
-        hipLaunchKernelGGL(k_sssp_pull_rows<WT>, grid, TV_BLOCK, 0, h.stream, (int32_t const*)ci.offsets.data(), (int32_t const*)ci.indices.data(), ci.weights.template as<WT const>(), nv,
-                           (uint32_t const*)fbits.data(), bigq.data(), s, (int32_t)BIG_DEG);
-        hipLaunchKernelGGL(k_sssp_pull_big<WT>, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)ci.offsets.data(), (int32_t const*)ci.indices.data(), s,
-                           (uint32_t const*)fbits.data());
-      }
-    } else {
+    if (filtered) { s.flt.bits = fbits.data(); s.flt.t = ft.data(); }
+    s.hot_cache = hot_cache_on ? 1 : 0;
+    {
       timed_launch t(h, "sssp_relax");
-      bool launched = false;
-      if constexpr (sizeof(WT) == 4) {
-        if (packed) {
-          hipLaunchKernelGGL((k_sssp_expand<WT, true>), expand_grid(h, n_front), TV_BLOCK, 0, h.stream, front, n_front, beg, end, adj, bigq.data(), s, big_deg_for(h, n_front));
-          hipLaunchKernelGGL((k_sssp_expand_big<WT, true>), h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), beg, end, adj, s);
-          launched = true;
+      with_words([&](auto pkc) {
+        constexpr bool PKC = decltype(pkc)::value;
+        if (filtered && two_stage && sweep_on && (double)front_edges >= sweep_frac * (double)g.ne) {  // the frontier's edges are most of the graph: stream the edge list
+          orientation_t& ow = g.csr;
+          if (ow.edge_rows.size() == 0) {
+            ow.edge_rows.resize_discard((size_t)g.ne + kEdgePad);
+            HIP_TRY(hipMemsetAsync(ow.edge_rows.data() + g.ne, 0, kEdgePad * sizeof(int32_t), h.stream));
+            hipLaunchKernelGGL(k_sssp_edge_rows, grid_for(nv * 16, kBlock, 8192), kBlock, 0, h.stream, row_beg, nv, ow.edge_rows.data());
+          }
+          if (getenv("CUGRAPH_AMD_SSSP_SNAPSHOT")) {  // experiment: the rows' own distances from a copy made before the round
+            size_t const bytes = (size_t)nv * (packed ? 8 : sizeof(bits_t));
+            if (snap.bytes < bytes) snap.alloc(bytes);
+            HIP_TRY(hipMemcpyAsync(snap.ptr, packed ? (void const*)pk.data() : (void const*)d, bytes, hipMemcpyDeviceToDevice, h.stream));
+            s.du_src = snap.ptr;
+          }
+          static bool const prof_on = getenv("CUGRAPH_AMD_SSSP_TRACE") && atoi(getenv("CUGRAPH_AMD_SSSP_TRACE")) >= 2;
+          size_t const n_prof = (size_t)h.num_cus * s2_wg_per_cu * TV_WAVES;
+          dvec<unsigned long long> prof(prof_on ? 3 * n_prof : 1);
+          hipLaunchKernelGGL((k_sssp_sweep<WT, PKC>), h.num_cus * s2_wg_per_cu, TV_BLOCK, 0, h.stream, (int32_t const*)ow.edge_rows.data(), adj, g.ne, (uint32_t const*)mark_near.data(), front_tag, s,
+                             prof_on ? prof.data() : (unsigned long long*)nullptr);
+          if (prof_on) {
+            std::vector<unsigned long long> pv(3 * n_prof);
+            HIP_TRY(hipMemcpyAsync(pv.data(), prof.data(), 3 * n_prof * sizeof(unsigned long long), hipMemcpyDeviceToHost, h.stream));
+            h.sync();
+            std::vector<unsigned long long> tot, dr;
+            double nd = 0;
+            for (size_t i = 0; i < n_prof; ++i) { tot.push_back(pv[3 * i]); dr.push_back(pv[3 * i + 1]); nd += (double)pv[3 * i + 2]; }
+            std::sort(tot.begin(), tot.end()); std::sort(dr.begin(), dr.end());
+            fprintf(stderr, "[sssp sweep] %zu wavefronts: ticks (100 MHz) total min %llu p50 %llu p90 %llu max %llu; inside drains min %llu p50 %llu p90 %llu max %llu; drains per wavefront %.1f\n", n_prof,
+                    tot[0], tot[n_prof / 2], tot[n_prof * 9 / 10], tot[n_prof - 1], dr[0], dr[n_prof / 2], dr[n_prof * 9 / 10], dr[n_prof - 1], nd / (double)n_prof);
+          }
+        } else if (filtered && two_stage) {  // wide round: survivors of the filter compacted per wavefront, the atomic chain over dense groups (sssp_two_stage)
+          hipLaunchKernelGGL((k_sssp_expand2<WT, PKC>), std::min(expand_grid(h, n_front), h.num_cus * s2_wg_per_cu), TV_BLOCK, 0, h.stream, front, n_front, row_beg, adj, bigq.data(), s, big_deg_for(h, n_front));
+          hipLaunchKernelGGL((k_sssp_expand2_big<WT, PKC>), h.num_cus * s2_wg_per_cu, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), row_beg, adj, s);
+        } else {
+          hipLaunchKernelGGL((k_sssp_expand<WT, PKC>), expand_grid(h, n_front), TV_BLOCK, 0, h.stream, front, n_front, row_beg, adj, bigq.data(), s, big_deg_for(h, n_front));
+          hipLaunchKernelGGL((k_sssp_expand_big<WT, PKC>), h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), row_beg, adj, s);
         }
-      }
-      if (!launched) {
-        hipLaunchKernelGGL(k_sssp_expand<WT>, expand_grid(h, n_front), TV_BLOCK, 0, h.stream, front, n_front, beg, end, adj, bigq.data(), s, big_deg_for(h, n_front));
-        hipLaunchKernelGGL(k_sssp_expand_big<WT>, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), beg, end, adj, s);
-      }
+      });
     }
     h.read_back(&c, cnt.data(), 1);
     c.fold();
-    if (pull) c.edges = front_edges;  // relaxations = the frontier's out-edges (the kernel walked every in-edge of the graph to find them)
     front_edges = c.out_edges;
     if (sssp_trace) {
       auto const now = std::chrono::steady_clock::now();
-      fprintf(stderr, "[sssp] round %3u %s window [%g, %g)  frontier %9lld  edges %11llu  next %9u (%llu out-edges)  far %9u  deferred segments %7u  %8.1f us\n", round,
-              pull ? "PULL" : "push", lower, upper, (long long)n_front, (unsigned long long)c.edges, c.n_next, (unsigned long long)c.out_edges, c.n_far, c.n_big,
-              std::chrono::duration<double, std::micro>(now - t_trace).count());
-      t_trace = now;
+      WT t_h = WT(0);
+      if (filtered) h.read_back(&t_h, (WT const*)ft.data(), 1);
+      fprintf(stderr, "[sssp] round %3u window [%g, %g)  frontier %9lld  edges %11llu  probes %11llu%s  next %9u (%llu out-edges)  far %9u  deferred segments %7u  %8.1f us\n", round,
+              lower, upper, (long long)n_front, (unsigned long long)c.edges, (unsigned long long)c.in_edges, filtered ? (" (filter T = " + std::to_string((double)t_h) + ")").c_str() : "",
+              c.n_next, (unsigned long long)c.out_edges, c.n_far, c.n_big, std::chrono::duration<double, std::micro>(now - t_trace).count());
+      t_trace = std::chrono::steady_clock::now();
     }
     relaxed += c.edges;
+    probed += c.in_edges;
     n_cur = c.n_next;
     n_far = c.n_far;
     CGA_EXPECTS(n_far <= nv, CUGRAPH_UNKNOWN_ERROR, "sssp: far pile overflow");
     std::swap(q_cur, q_nxt);
   };
   for (;;) {
-    for (;;) {  // one bucket
-      while (n_cur > 0) {
-        relax_round(q_cur, n_cur, row_beg, lend, set_cur, n_set);  // lend == nullptr: all edges (wide buckets)
-        if (use_lh) n_set = c.n_set;
-      }
-      if (!use_lh || n_set == 0) break;
-      // the bucket is closed: its members' distances are final -- their heavy edges, once.  (A heavy edge cannot land inside the
-      // bucket: fl(d + w) >= fl(lower + delta) = upper; should it ever, the vertex goes to the next set and the loop runs again.)
-      ++set_epoch;
-      int64_t const n_members = n_set;
-      relax_round(set_cur, n_members, lend, row_beg + 1, set_nxt, 0);
-      n_set = c.n_set;
-      std::swap(set_cur, set_nxt);
-      if (n_cur == 0 && n_set == 0) break;
-    }
+    while (n_cur > 0) relax_round(q_cur, n_cur);  // one bucket
     if (n_far == 0) break;
     // advance the bucket window until the far pile yields a non-empty near frontier
     while (n_cur == 0 && n_far > 0) {
@@ -1880,27 +1508,15 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
       z.far_min_bits64  = ~0ull;
       std::memcpy(h.pinned, &z, sizeof(z));
       HIP_TRY(hipMemcpyAsync(cnt.data(), h.pinned, sizeof(z), hipMemcpyHostToDevice, h.stream));
-      bool split_done = false;
-      if constexpr (sizeof(WT) == 4) {
-        if (packed) {
-          hipLaunchKernelGGL((k_sssp_split<WT, true>), grid_for(n_far, TV_BLOCK, 2048), TV_BLOCK, 0, h.stream, (int32_t const*)far_cur, n_far,
-                             reinterpret_cast<bits_t const*>(pk.data()), (WT)std::min(lower, (double)wmax), (WT)std::min(upper, (double)wmax), q_cur, far_nxt,
-                             mark_near.data(), mark_far.data(), round, far_epoch, cnt.data(), (int32_t*)nullptr, mark_set.data(), set_epoch,
-                             (int32_t const*)o.offsets.data());
-          split_done = true;
-        }
-      }
-      if (!split_done)
-      hipLaunchKernelGGL(k_sssp_split<WT>, grid_for(n_far, TV_BLOCK, 2048), TV_BLOCK, 0, h.stream, (int32_t const*)far_cur, n_far,
-                         (bits_t const*)d, (WT)std::min(lower, (double)wmax), (WT)std::min(upper, (double)wmax), q_cur, far_nxt,
-                         mark_near.data(), mark_far.data(), round, far_epoch, cnt.data(), use_lh ? set_cur : (int32_t*)nullptr, mark_set.data(), set_epoch,
-                         (int32_t const*)o.offsets.data());
+      with_words([&](auto pkc) {
+        hipLaunchKernelGGL((k_sssp_split<WT, decltype(pkc)::value>), grid_for(n_far, TV_BLOCK, 2048), TV_BLOCK, 0, h.stream, (int32_t const*)far_cur, n_far, dist_words,
+                           (WT)std::min(lower, (double)wmax), (WT)std::min(upper, (double)wmax), q_cur, far_nxt, mark_near.data(), mark_far.data(), round, far_epoch, cnt.data(), row_beg);
+      });
       h.read_back(&c, cnt.data(), 1);
       c.fold();
       front_edges = c.out_edges;
       n_cur = c.n_next;
       n_far = c.n_far;
-      n_set = use_lh ? c.n_set : 0;
       std::swap(far_cur, far_nxt);
       if (n_cur == 0 && n_far > 0) {  // empty buckets: jump to the one holding the smallest far distance
         double dmin;
@@ -1911,8 +1527,6 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
         if (k * delta > upper) upper = k * delta;
       }
     }
-  }
-
   }
 
   if (packed) {  // the two result columns out of the packed words; nothing else to do for the parents
@@ -1940,7 +1554,7 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   if (nv > 0) hipLaunchKernelGGL(k_count_reached_dist<bits_t>, grid_for(nv, kBlock, 1024), kBlock, 0, h.stream, (bits_t const*)d, nv, unreached_bits, reached.data());
   unsigned long long nreached;
   h.read_back(&nreached, reached.data(), 1);
-  h.last_stats = cugraph_amd_traversal_stats_t{steps, relaxed, nreached, compute_predecessors ? c.edges : 0};
+  h.last_stats = cugraph_amd_traversal_stats_t{steps, relaxed, nreached, compute_predecessors ? c.edges : 0, probed};
   if (nv > 0) HIP_TRY(hipMemcpyAsync(ids->buf.ptr, g.number_map.data(), nv * 4, hipMemcpyDeviceToDevice, h.stream));
   h.sync();
   auto* r = new paths_result_t{ids.release(), dist.release(), preds.release()};

@@ -517,6 +517,19 @@ extern "C" void cugraph_amd_traversal_mg_plan_keep_buffers(cugraph_amd_traversal
   if (plan) TP(plan).caller_keeps_buffers = on == TRUE;
 }
 
+// The plan queues its work on -- and reads counters back through -- a resource handle; a caller that creates a handle per call (the reference accepts any
+// handle of the communicator) moves a cached plan to the handle of the current call.  Everything the previous handle queued has finished by then (every
+// stepping entry point that yields host-visible data ends synchronised), and the device is synchronised here in case a caller overlapped calls anyway.
+extern "C" void cugraph_amd_traversal_mg_plan_rebind(cugraph_amd_traversal_mg_plan_t* plan, const cugraph_resource_handle_t* handle)
+{
+  if (!plan || !handle) return;
+  handle_t const* h = reinterpret_cast<handle_t const*>(handle);
+  if (TP(plan).h == h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  TP(plan).h = h;
+}
+
 extern "C" void cugraph_amd_traversal_mg_plan_free(cugraph_amd_traversal_mg_plan_t* plan)
 {
   if (plan) delete &TP(plan);

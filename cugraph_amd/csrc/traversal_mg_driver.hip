@@ -115,9 +115,12 @@ namespace {
 mg_traversal_run_t& ensure_run(handle_t const& h, graph_t& g, mg_traversal_part_t& t, int mode)
 {
   if (t.run) {
-    // the cached plan and its windows were built on the first traversal's resource handle (its stream orders every later call)
-    CGA_EXPECTS(t.run->h == &h, CUGRAPH_INVALID_HANDLE,
-                "multi-GPU traversal: the graph's traversal plan belongs to the resource handle of its first BFS / SSSP; later calls must pass the same handle");
+    // the cached plan and its windows were built through the first traversal's resource handle; a later call may come with ANY handle of the same
+    // communicator (the reference's contract: callers that create a handle per call): the run and its plan move to the handle of this call
+    if (t.run->h != &h) {
+      cugraph_amd_traversal_mg_plan_rebind(t.run->plan, reinterpret_cast<cugraph_resource_handle_t const*>(&h));
+      t.run->h = &h;
+    }
     return *t.run;
   }
   comm_t& c = *g.mg->comm;

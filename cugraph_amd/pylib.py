@@ -210,7 +210,7 @@ class ResourceHandle:
         s = capi.TraversalStats()
         capi.lib().cugraph_amd_last_traversal_stats(self.c_resource_handle_ptr, C.byref(s))
         return {"steps": s.steps, "edges_inspected": s.edges_inspected, "vertices_reached": s.vertices_reached,
-                "edges_of_reached": s.edges_of_reached}
+                "edges_of_reached": s.edges_of_reached, "probes": s.probes}
 
 
 class GraphProperties:

@@ -183,6 +183,9 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_traversal_mg_plan_results(cugrap
                                                                           int32_t* predecessors, cugraph_error_t** error);
 /* the buffers handed to merge_visited outlive the call (persistent exchange windows): it then returns without synchronising */
 CUGRAPH_EXPORT void cugraph_amd_traversal_mg_plan_keep_buffers(cugraph_amd_traversal_mg_plan_t* plan, bool_t on);
+/* Moves a plan to another resource handle of the same device (later calls queue on that handle's stream and read back through its pinned page).  The
+ * library's own multi-GPU BFS / SSSP do this when a graph's cached plan is used through a different handle than the one that built it. */
+CUGRAPH_EXPORT void cugraph_amd_traversal_mg_plan_rebind(cugraph_amd_traversal_mg_plan_t* plan, const cugraph_resource_handle_t* handle);
 CUGRAPH_EXPORT void cugraph_amd_traversal_mg_plan_free(cugraph_amd_traversal_mg_plan_t* plan);
 
 /* One-node communicator of the library (cugraph_amd/csrc/comm.hpp): one process per GPU, every rank's device windows mapped into every
@@ -265,6 +268,8 @@ typedef struct {
   uint64_t edges_inspected;
   uint64_t vertices_reached;
   uint64_t edges_of_reached;
+  uint64_t probes;  /* cugraph_sssp: relaxations that went on to probe the destination's tentative distance (the others were dropped by the
+                     * L2-resident distance filter); 0 elsewhere */
 } cugraph_amd_traversal_stats_t;
 CUGRAPH_EXPORT void cugraph_amd_last_traversal_stats(const cugraph_resource_handle_t* handle,
                                                      cugraph_amd_traversal_stats_t* out);

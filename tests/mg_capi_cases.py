@@ -154,16 +154,24 @@ def run(what, cg, h, comm, rank, size, outdir, args):
                     res[f"p{k}"] = U(pred)
             stats = h.last_traversal_stats()
             out["levels"], out["bottom_up_levels"] = int(stats["steps"]), int(stats["edges_inspected"])
-            # multi-source: all roots at once, every rank passing the whole list
-            dist, pred, v = cg.bfs(h, g, X(roots), False, depth, False, False)
+            # multi-source: all roots at once, every rank passing the whole list -- through a SECOND resource handle of the same communicator
+            # (the reference accepts any handle: callers that create one per call; the graph's cached traversal plan moves to it)
+            h2 = cg.ResourceHandle(comm)
+            dist, pred, v = cg.bfs(h2, g, X(roots), False, depth, False, False)
             res["vm"], res["dm"] = U(v), UD(dist)
+            del h2
+            mine = np.array([roots[0]], np.int32) if rank == 0 else np.zeros(0, np.int32)  # ... and back on the first handle, after the second is gone
+            dist, _, v = cg.bfs(h, g, X(mine), False, depth, False, False)
+            out["first_handle_again"] = bool(np.array_equal(U(v), res["v0"]) and np.array_equal(UD(dist), res["d0"]))
         else:
             cutoff = float(args[4]) if len(args) > 4 else 3.0e38
             for k, root in enumerate(roots):
-                v, dist, pred = cg.sssp(h, g, xid(root), cutoff, with_pred, False)
+                hk = cg.ResourceHandle(comm) if k % 2 == 1 else h  # every other call through a fresh handle of the communicator
+                v, dist, pred = cg.sssp(hk, g, xid(root), cutoff, with_pred, False)
                 res[f"v{k}"], res[f"d{k}"] = U(v), dist.cpu().numpy()
                 if with_pred:
                     res[f"p{k}"] = U(pred)
+                del hk
         np.savez(outdir / f"rank{rank}.npz", roots=roots, **res)
         del g
     elif what == "louvain":

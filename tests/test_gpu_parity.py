@@ -439,52 +439,35 @@ def test_sssp_packed_parents_equal_the_sweep(cg, handle, orc, monkeypatch, scale
                 assert any((pu, int(vtx), float(x)) in key and np.float32(od[pu]) + np.float32(x) == od[vtx] for x in (0.0, 1.0, 2.0))
 
 
-@pytest.mark.parametrize("scale,transposed", [(16, True), (18, False)])
-def test_bfs_pulled_parents_equal_pushed_parents(cg, handle, orc, monkeypatch, scale, transposed):
-    """Round 5 (opt-in schedule): the parents of a top-down level's discoveries pulled from their in-edges -- first in-neighbour, ascending
-    internal id, visited before the level -- instead of claimed with atomicMin by the push.  Same rule, same parents; rows above 8192 in-edges
-    take the workgroup-per-row kernel (RMAT-16's top vertices have 12 863)."""
+@pytest.mark.parametrize("scale,kind,dtype", [(12, "int", np.float32), (14, "real", np.float32), (16, "int", np.float32), (14, "int", np.float64), (13, "unit", np.float32),
+                                              (14, "zero", np.float32), (17, "int", np.float32)])
+def test_sssp_distance_filter_vs_oracle(cg, handle, orc, monkeypatch, scale, kind, dtype):
+    """Round 6: the L2-resident distance filter of the wide relaxation rounds (one bit per vertex, d[v] < T; relaxations with nd >= T into such a
+    vertex are dropped before they probe its distance) forced onto EVERY round (by default only rounds of >= E / 32 relaxations build it): the
+    filter is exact for any threshold, so distances stay bit-identical to Dijkstra and the parents canonical -- integer / real / unit weights,
+    zero-weight edges (equal-distance parent ties must still resolve to the smallest id), fp32 packed words and fp64, with a cutoff."""
+    monkeypatch.setenv("CUGRAPH_AMD_SSSP_FILTER", "force")
+    if kind != "zero":
+        _sssp_parity(cg, handle, orc, scale, kind, dtype)
+        st = handle.last_traversal_stats()
+        assert 0 < st["probes"] <= st["edges_inspected"]
+        return
+    # zero-weight cycles: a tight in-edge need not lie on a shortest-path tree, so the oracle's parents are not the reference point;
+    # the filtered run must name exactly the parents of the unfiltered one (same lexicographic minimum, fewer probes)
     s, d = rmat_graph(orc, scale)
     nv = 1 << scale
-    g = make_graph(cg, handle, s, d, None, transposed=transposed, renumber=True, vertices=np.arange(nv))
-    off, idx, _ = orc.coo_to_cs(nv, s, d)
-    for src in [int(x) for x in np.nonzero(np.diff(off) > 0)[0][[0, 7, 100]]]:
-        got = {}
-        for mode in ("0", "1"):
-            monkeypatch.setenv("CUGRAPH_AMD_BFS_PULL_PARENTS", mode)
-            dist, pred, v = cg.bfs(handle, g, T([src], np.int32), False, 0, True, False)
-            got[mode] = by_vertex(v, dist, pred)
-        od, _ = orc.bfs(nv, off, idx, [src])
-        for mode in ("0", "1"):
-            assert np.array_equal(got[mode][0], od)
-            assert np.array_equal(got[mode][1], bfs_expected_parents(s, d, od, v)), mode
-
-
-@pytest.mark.parametrize("mode,batch", [("multi", 0), ("dev", 8), ("dev", 1), ("dev", 3), ("radix", -1), ("radix", -64), ("radix", -100000)])
-@pytest.mark.parametrize("scale,kind,dtype,subq", [(12, "int", np.float32, 8), (14, "real", np.float32, 8), (16, "int", np.float32, 4), (14, "int", np.float64, 8),
-                                                   (13, "unit", np.float32, 2), (15, "int", np.float32, 1)])
-def test_sssp_subqueues_vs_oracle(cg, handle, orc, monkeypatch, scale, kind, dtype, subq, mode, batch):
-    """The distance-ordered sub-queue schedule of SSSP (CUGRAPH_AMD_SSSP_MODE=multi, round 3), its device-driven form (=dev: batches
-    of rounds advanced by k_sssp_ctl, one host synchronisation per batch) and the radix-heap form (=radix: sub-queues of doubling width,
-    the first non-empty one either drained or cut into the empty ones below it): same fixed point, so distances bit-identical to Dijkstra and
-    the canonical parents, for integer / real / unit weights, fp32 / fp64, with a cutoff; batch sizes that end inside, at and past the
-    end of a window."""
-    monkeypatch.setenv("CUGRAPH_AMD_SSSP_MODE", mode)
-    monkeypatch.setenv("CUGRAPH_AMD_SSSP_SUBQ", str(subq))
-    if batch > 0:
-        monkeypatch.setenv("CUGRAPH_AMD_SSSP_BATCH", str(batch))
-    if batch < 0:  # radix sub-queues: a sub-queue is cut into finer ones from this many heavy entries on (1: always, 100000: never at these sizes)
-        monkeypatch.setenv("CUGRAPH_AMD_SSSP_SPLIT_MIN", str(-batch))
-    _sssp_parity(cg, handle, orc, scale, kind, dtype)
-
-
-@pytest.mark.parametrize("scale,kind,dtype", [(12, "int", np.float32), (14, "real", np.float32), (16, "int", np.float32), (14, "int", np.float64), (13, "unit", np.float32)])
-def test_sssp_pull_rounds_vs_oracle(cg, handle, orc, monkeypatch, scale, kind, dtype):
-    """SSSP with EVERY relaxation round pulled over the in-edges (CUGRAPH_AMD_SSSP_PULL=force; by default only the round of the hubs right
-    after the source is: sssp_pull_fn): the fixed point does not depend on the direction of a round -- distances bit-identical to Dijkstra,
-    canonical parents, cutoff honoured -- for integer / real / unit weights, fp32 / fp64."""
-    monkeypatch.setenv("CUGRAPH_AMD_SSSP_PULL", "force")
-    _sssp_parity(cg, handle, orc, scale, kind, dtype)
+    w = (int_weights(s.size) % 3).astype(dtype)
+    g = make_graph(cg, handle, s, d, w, transposed=False, renumber=True, vertices=np.arange(nv), wdtype=dtype)
+    off, idx, ww = orc.coo_to_cs(nv, s, d, w)
+    src = int(np.nonzero(np.diff(off) > 0)[0][3])
+    od, _ = orc.sssp(nv, off, idx, ww, src)
+    res = {}
+    for mode in ("force", "0"):
+        monkeypatch.setenv("CUGRAPH_AMD_SSSP_FILTER", mode)
+        v, dist, pred = cg.sssp(handle, g, src, float(np.finfo(dtype).max), True, False)
+        res[mode] = by_vertex(v, dist, pred)
+        assert np.array_equal(res[mode][0], od), mode
+    assert np.array_equal(res["force"][1], res["0"][1])
 
 
 def _sssp_parity(cg, handle, orc, scale, kind, dtype):
@@ -494,6 +477,8 @@ def _sssp_parity(cg, handle, orc, scale, kind, dtype):
         w = np.ones(s.size, dtype)
     elif kind == "int":
         w = int_weights(s.size).astype(dtype)
+    elif kind == "zero":  # a third of the edges weigh nothing: many equal-distance parent candidates
+        w = (int_weights(s.size) % 3).astype(dtype)
     else:
         w = np.random.default_rng(3).random(s.size).astype(dtype) + dtype(0.01)
     g = make_graph(cg, handle, s, d, w, transposed=False, renumber=True, vertices=np.arange(nv), wdtype=dtype)
@@ -509,43 +494,6 @@ def _sssp_parity(cg, handle, orc, scale, kind, dtype):
     (dist,) = by_vertex(v, dist)
     oc, _ = orc.sssp(nv, off, idx, ww, src, cutoff=cut)
     assert np.array_equal(dist, oc)
-
-
-@pytest.mark.parametrize("scale,kind,dtype,lh_scale", [(12, "int", np.float32, 0.25), (14, "int", np.float32, 0.25), (14, "int", np.float32, 0.05),
-                                                       (14, "real", np.float32, 0.25), (14, "int", np.float64, 0.5), (14, "unit", np.float32, 0.25),
-                                                       (16, "int", np.float32, 1.0)])
-def test_sssp_light_heavy_buckets_vs_oracle(cg, handle, orc, monkeypatch, scale, kind, dtype, lh_scale):
-    """the delta-stepping path of large graphs (light edges inside a bucket, heavy edges once when it closes; sssp_lh_t) forced at
-    sizes the oracle handles: distances bit-identical to Dijkstra, canonical parents, cutoff honoured -- for narrow buckets (many
-    empty windows, every edge heavy with unit weights) and wide ones (every edge light)"""
-    monkeypatch.setenv("CUGRAPH_AMD_SSSP_LH", "1")
-    monkeypatch.setenv("CUGRAPH_AMD_SSSP_LH_SCALE", str(lh_scale))
-    s, d = rmat_graph(orc, scale, seed=2)
-    nv = 1 << scale
-    if kind == "unit":
-        w = np.ones(s.size, dtype)
-    elif kind == "int":
-        w = int_weights(s.size).astype(dtype)
-    else:
-        w = np.random.default_rng(5).random(s.size).astype(dtype) + dtype(0.01)
-    g = make_graph(cg, handle, s, d, w, transposed=False, renumber=True, vertices=np.arange(nv), wdtype=dtype)
-    off, idx, ww = orc.coo_to_cs(nv, s, d, w)
-    for src in np.nonzero(np.diff(off) > 0)[0][[1, 7]]:
-        src = int(src)
-        v, dist, pred = cg.sssp(handle, g, src, float(np.finfo(dtype).max), True, False)
-        dist, pred = by_vertex(v, dist, pred)
-        od, _ = orc.sssp(nv, off, idx, ww, src)
-        assert np.array_equal(dist, od)
-        assert np.array_equal(pred, orc.sssp_min_pred(nv, off, idx, ww, src, od))
-    cut = float(np.median(od[od < np.finfo(dtype).max]))
-    v, dist, _ = cg.sssp(handle, g, src, cut, False, False)
-    (dist,) = by_vertex(v, dist)
-    oc, _ = orc.sssp(nv, off, idx, ww, src, cutoff=cut)
-    assert np.array_equal(dist, oc)
-    monkeypatch.setenv("CUGRAPH_AMD_SSSP_LH", "0")  # and the wide-bucket path on the same graph object (the cached copy is not used)
-    v, dist, _ = cg.sssp(handle, g, src, float(np.finfo(dtype).max), False, False)
-    (dist,) = by_vertex(v, dist)
-    assert np.array_equal(dist, od)
 
 
 def test_csr_input_and_orientation_flip_share_one_numbering(cg, handle, orc):
@@ -704,7 +652,14 @@ def test_sssp_full_size_properties(cg, handle):
         reached = dist != FMAX
         nonroot = reached.clone(); nonroot[root] = False
         assert bool(tight[nonroot].all())
-        assert bool((pred[nonroot] >= 0).all()) and bool((dist[pred[nonroot]] < dist[nonroot]).all() or kind == "unit")
+        assert bool((pred[nonroot] >= 0).all()) and bool((dist[pred[nonroot]] < dist[nonroot]).all())  # (weights >= 1: a parent is strictly closer)
+        # the parent is THE canonical one: the smallest id among the in-neighbours joined by a tight edge, d[u] + w(u, v) == d[v] (the reference's
+        # lexicographic minimum over (distance, predecessor), sssp_impl.cuh:334) -- which also proves that (pred[v], v) is an edge and that it is tight
+        te = ru & (dv == du + w)
+        want = torch.full((nv,), nv, dtype=torch.int64, device="cuda")
+        want.scatter_reduce_(0, dst[te].long(), src[te].long(), reduce="amin", include_self=True)
+        assert torch.equal(pred[nonroot], want[nonroot])
+        assert int(pred[root]) == -1 and bool((pred[~reached] == -1).all())
         if kind == "unit":
             bd, _, bv = cg.bfs(handle, g, torch.tensor([root], dtype=torch.int32, device="cuda"), False, 0, False, False)
             lev = torch.empty(nv, dtype=torch.int64, device="cuda"); lev[bv.long()] = bd.long()
@@ -799,6 +754,8 @@ def test_bfs_sssp_config3_rmat24_vs_oracle(cg, handle, orc):
     osd, _ = orc.sssp(nv, coff, cidx, cw, root)
     got_s, got_sp = by_vertex(sv, sd, sp)
     assert np.array_equal(got_s, osd), "SSSP (integer weights) distances differ"
+    # the parents of the packed 64-bit relaxation at the configuration's full size: the oracle's canonical ones (smallest id over the tight in-edges)
+    assert np.array_equal(got_sp, orc.sssp_min_pred(nv, coff, cidx, cw, root, osd)), "SSSP (integer weights) predecessors differ"
     del g
     ones = np.ones(ne, np.float32)
     g1 = make_graph(cg, handle, s, d, ones, transposed=False, renumber=True, vertices=np.arange(nv))

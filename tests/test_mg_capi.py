@@ -63,7 +63,7 @@ def test_comm_host_bootstrap(world):
     assert not Path("/dev/shm/cga_" + session).exists()
 
 
-@pytest.mark.parametrize("creator", ["dead", "alive"])
+@pytest.mark.parametrize("creator", ["dead", "alive", "aborted", "foreign"])
 def test_comm_host_bootstrap_survives_a_stale_segment(creator):
     """A crashed job left a segment of the same session name behind (ready, one arrival short of a full barrier), and this time the other ranks
     start BEFORE rank 0 (advisor finding, round 4).  They must not settle on the old segment: its creator is gone (dead pid), or -- the pid
@@ -75,13 +75,19 @@ def test_comm_host_bootstrap_survives_a_stale_segment(creator):
     world = 3
     session = f"s{uuid.uuid4().hex[:12]}"
     path = Path("/dev/shm/cga_" + session)
-    if creator == "dead":
+    my_ns = os.stat("/proc/self/ns/pid").st_ino
+    abort, ns = 0, my_ns
+    if creator in ("dead", "foreign"):
         p = subprocess.Popen([sys.executable, "-c", "pass"])
         p.wait()
         pid0, arrived = p.pid, world - 1
+        if creator == "foreign":  # round 6 (advisor): the creator lives in ANOTHER pid namespace (a container per GPU over one /dev/shm): its pid means
+            ns, arrived = my_ns + 1, 0  # nothing here and must not be read as "gone"; the segment is left only when the name stops leading to it
     else:
         pid0, arrived = os.getpid(), 0
-    header = struct.pack("<16I", 0x43474331, world, arrived, 0, 0, world - 1, pid0, *([0] * 9))  # comm_shm_t: ready, size, bar_count, bar_gen, abort, attached, pid0
+        abort = 1 if creator == "aborted" else 0  # a crashed job left its abort flag set (pid recycled): not "a peer aborted", a stale segment
+    # comm_shm_t: ready, size, bar_count, bar_gen, abort, attached, pid0, pad, pidns0 (64 bits), pad[6]
+    header = struct.pack("<8IQ6I", 0x43474331, world, arrived, 0, abort, world - 1, pid0, 0, ns, *([0] * 6))
     path.write_bytes(header + bytes(64 * 4096))
     code = ("import ctypes as C, sys; from cugraph_amd import _capi as capi; l = capi.lib(); e = C.c_void_p(); "
             "rc = l.cugraph_amd_comm_host_selftest(sys.argv[1].encode(), int(sys.argv[2]), int(sys.argv[3]), 50, C.byref(e)); "
@@ -212,6 +218,7 @@ def _bfs_case(orc, tmp_path, world, direction, env=None):
         assert res[0]["bottom_up_levels"] == res[0]["levels"]
     if direction == "topdown":
         assert res[0]["bottom_up_levels"] == 0
+    assert all(r["first_handle_again"] for r in res)  # the cached plan served a second handle of the communicator and then the first one again
     roots, dist, _ = _assemble_paths(tmp_path, world, 1 << scale, "m")
     nv, s, d, _, off, idx, _ = __import__("test_mg_traversal").graph(orc, scale)
     od, _ = orc.bfs(nv, off, idx, np.asarray(roots, np.int32), 2**31 - 1)
