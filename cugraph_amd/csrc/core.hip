@@ -489,8 +489,19 @@ size_t round_size(size_t n)
 
 void pool_set_stream(hipStream_t s) noexcept { tl_stream = s; tl_stream_known = true; }
 void pool_forget_stream(hipStream_t s) noexcept
-{  // the stream is about to be destroyed (it has been synchronised): later frees of this thread have no stream to order against
-  if (tl_stream_known && tl_stream == s) { tl_stream = nullptr; tl_stream_known = false; }
+{  // the stream is about to be destroyed (it has been synchronised): later frees of this thread have no stream to order against ...
+  if (s == nullptr || (tl_stream_known && tl_stream == s)) { tl_stream = nullptr; tl_stream_known = false; }  // (nullptr: "this thread's frees have no stream now")
+  if (s == nullptr) return;
+  // ... and the cached blocks that were freed on it are plainly free now: their events go back to the spare list (an event that outlives the stream it was
+  // recorded on made a later hipEventRecord on ANOTHER stream of the device fault inside the runtime's walk over the active streams -- round 6: a second
+  // resource handle of a communicator created, used and destroyed between two traversals)
+  pool_t& p = pool();
+  std::lock_guard<std::mutex> lock(p.m);
+  for (auto& kv : p.free_blocks)
+    if (kv.second.stream == s) {
+      if (kv.second.ev) { (void)hipEventSynchronize(kv.second.ev); p.put_event(kv.second.ev); kv.second.ev = nullptr; }
+      kv.second.stream = nullptr;
+    }
 }
 
 void* pool_alloc(size_t n_bytes, size_t* granted)

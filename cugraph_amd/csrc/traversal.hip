@@ -244,8 +244,6 @@ struct sssp_state {
   int32_t const* labels{nullptr};  // internal -> external id (nullptr: identity)
   int32_t source{-1};              // keeps its parent -1 whatever reaches it at distance 0
   sssp_filter<WT> flt{};
-  void const* du_src{nullptr};  // k_sssp_sweep: where a row's own distance is read from (a snapshot taken before the round; nullptr: the live words)
-  int32_t hot_cache{1};  // the two-stage kernels keep a per-workgroup minimum per hot destination (sssp_two_stage::dominated); 0: off (A/B)
 };
 __device__ __forceinline__ uint32_t pk_dist_bits(unsigned long long const* pk, int32_t v) { return reinterpret_cast<uint32_t const*>(pk)[2 * (size_t)v + 1]; }
 // parent labels inside the packed word are biased so that the UNSIGNED order of the word is the signed order of the external ids (a negative
@@ -386,17 +384,13 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand_big(int32_t const* big
 // 76 % in SQ_WAIT_ANY, 1.3 TB/s moved; with the filter dropping 80 % of the probes the round took the same time, profiles/r6g_*).  So the survivors of
 // the cheap part (neighbour id, weight, filter bit: streamed or L2-resident) are COMPACTED into a per-wavefront LDS buffer, and the expensive chain runs
 // over dense groups of 64 x S2_DU candidates: its round trips are paid per surviving candidate, not per step.
-constexpr int S2_U     = 4;                      // edges per lane and step of the cheap stage
+#ifndef CGA_S2_U
+#define CGA_S2_U 4
+#endif
+constexpr int S2_U     = CGA_S2_U;               // edges per lane and step of the cheap stage
 constexpr int S2_DU    = 4;                      // candidates per lane and step of the drain
 constexpr int S2_DRAIN = 64 * S2_DU;             // buffered candidates that start a drain
 constexpr int S2_CAP   = S2_DRAIN + 64 * S2_U;   // (a cheap step adds at most 64 * S2_U)
-// Candidates for the SAME hot destination: in the round after the source every frontier row has an edge to each of the top hubs, the candidates of a
-// workgroup for one hub arrive within microseconds of each other, all pass the (stale) probe and all issue an atomicMin on ONE address -- and same-address
-// atomics retire one after the other in their L2 channel (~12 ns each: 60 K candidates for the top vertex = 0.7 ms whatever else the round does; the streamed
-// part of k_sssp_sweep alone takes 0.45 ms, the kernel 1.3-1.9 ms).  So a workgroup keeps, in LDS, the smallest candidate distance it has sent for each of the
-// first S2_HOT vertex ids (degree-descending numbering: the hubs) and drops a candidate that is strictly worse than one it sent already (ties go on: the parent
-// with the smaller id must still win).  Exact: a dropped candidate is dominated by one that does reach memory.  fp32 distances only (32-bit LDS minimum).
-constexpr int S2_HOT = 2048;
 template <typename WT, bool PK>
 struct sssp_cand_storage {
   int32_t v[TV_WAVES][S2_CAP];
@@ -412,16 +406,7 @@ struct sssp_two_stage {
   int32_t* cv;
   bits_t* cnd;
   uint32_t* clab;
-  uint32_t* hot;  // [S2_HOT] smallest candidate distance bits this workgroup has sent per hot vertex id (nullptr: off)
   uint32_t n{0};  // candidates buffered (wave-uniform)
-  // true: a strictly better candidate for v has been sent by this workgroup already
-  __device__ __forceinline__ bool dominated(int32_t v, bits_t nd_bits)
-  {
-    if constexpr (sizeof(bits_t) == 4) {
-      if (hot != nullptr && (uint32_t)v < (uint32_t)S2_HOT) return atomicMin(&hot[v], (uint32_t)nd_bits) < (uint32_t)nd_bits;
-    }
-    return false;
-  }
   // cheap stage for S2_U edges of this lane: positions p[k] of rows whose vertex has distance bits du[k] / biased label lab[k]; live[k]: the edge exists
   __device__ __forceinline__ void step(bool const (&live)[S2_U], eoff_t const (&p)[S2_U], bits_t const (&du)[S2_U], uint32_t const (&lab)[S2_U], int32_t const* indices)
   {
@@ -440,7 +425,6 @@ struct sssp_two_stage {
       WT const nd = B::from(du[k]) + w[k];
       bool go     = live[k] & (nd < f.s.cutoff) & !((((bw[k] >> ((uint32_t)v[k] & 31u)) & 1u) != 0u) & (nd >= f.ft));
       if constexpr (PK) go = go & (v[k] != f.s.source);
-      if (go) go = !dominated(v[k], B::to(nd));
       uint64_t const m = __ballot(go);
       if (go) {
         uint32_t const at = n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -513,10 +497,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand2(int32_t const* q, int
   sssp_relax<WT, PK> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far)};
   f.begin();
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __shared__ uint32_t s_hot[S2_HOT];
-  for (int i = threadIdx.x; i < S2_HOT; i += TV_BLOCK) s_hot[i] = 0xFFFFFFFFu;
-  __syncthreads();
-  sssp_two_stage<WT, PK> ts{f, cs.v[wave], cs.nd[wave], PK ? cs.lab[wave] : cs.lab[0], s.hot_cache ? s_hot : nullptr};
+  sssp_two_stage<WT, PK> ts{f, cs.v[wave], cs.nd[wave], PK ? cs.lab[wave] : cs.lab[0]};
   int64_t const gwave  = (int64_t)blockIdx.x * TV_WAVES + wave;
   int64_t const nwaves = (int64_t)gridDim.x * TV_WAVES;
   unsigned long long inspected = 0;
@@ -607,10 +588,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand2_big(int32_t const* bi
   sssp_relax<WT, PK> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far)};
   f.begin();
   int const wave = threadIdx.x >> 6;
-  __shared__ uint32_t s_hot[S2_HOT];
-  for (int i = threadIdx.x; i < S2_HOT; i += TV_BLOCK) s_hot[i] = 0xFFFFFFFFu;
-  __syncthreads();
-  sssp_two_stage<WT, PK> ts{f, cs.v[wave], cs.nd[wave], PK ? cs.lab[wave] : cs.lab[0], s.hot_cache ? s_hot : nullptr};
+  sssp_two_stage<WT, PK> ts{f, cs.v[wave], cs.nd[wave], PK ? cs.lab[wave] : cs.lab[0]};
   uint32_t const nseg = s.cnt->n_big;
   unsigned long long inspected = 0;
   for (uint32_t k = blockIdx.x; k < nseg; k += gridDim.x) {
@@ -692,10 +670,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_sweep(int32_t const* edge_row
   sssp_relax<WT, PK> f{s, wave_queue(wqs, 0, s.q_next, &s.cnt->n_next), wave_queue(wqs, 1, s.far, &s.cnt->n_far)};
   f.begin();
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __shared__ uint32_t s_hot[S2_HOT];
-  for (int i = threadIdx.x; i < S2_HOT; i += TV_BLOCK) s_hot[i] = 0xFFFFFFFFu;
-  __syncthreads();
-  sssp_two_stage<WT, PK> ts{f, cs.v[wave], cs.nd[wave], PK ? cs.lab[wave] : cs.lab[0], s.hot_cache ? s_hot : nullptr};
+  sssp_two_stage<WT, PK> ts{f, cs.v[wave], cs.nd[wave], PK ? cs.lab[wave] : cs.lab[0]};
   int64_t const gwave  = (int64_t)blockIdx.x * TV_WAVES + wave;
   int64_t const nwaves = (int64_t)gridDim.x * TV_WAVES;
   constexpr int64_t STEP = 64 * S2_U;
@@ -718,14 +693,17 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_sweep(int32_t const* edge_row
 #endif
     }
 #pragma unroll
-    for (int k = 0; k < S2_U; ++k) { u[k] = live[k] ? u[k] : 0; v[k] = live[k] ? v[k] : 0; mk[k] = mark_near[u[k]]; bw[k] = s.flt.bits ? s.flt.bits[(uint32_t)v[k] >> 5] : 0u; }
+    for (int k = 0; k < S2_U; ++k) { u[k] = live[k] ? u[k] : 0; v[k] = live[k] ? v[k] : 0; mk[k] = mark_near[u[k]]; }  // (consecutive positions: a few distinct words per load)
 #pragma unroll
     for (int k = 0; k < S2_U; ++k) {
       live[k] = live[k] & (mk[k] == tag);
-      du[k] = 0; lab[k] = 0;
-      if (live[k]) {  // (a row's edges are consecutive: most lanes of a step read the same few words)
-        if constexpr (PK) { du[k] = pk_dist_bits(s.du_src ? static_cast<unsigned long long const*>(s.du_src) : s.pk, u[k]); lab[k] = pk_label(s.labels ? s.labels[u[k]] : u[k]); }
-        else du[k] = (s.du_src ? static_cast<bits_t const*>(s.du_src) : s.dist)[u[k]];
+      du[k] = 0; lab[k] = 0; bw[k] = 0u;
+      // everything per-DESTINATION only for the edges of frontier rows: a filter-bit probe is a random L2 access, and the L2 serves ~260 G of those per
+      // second -- probing all 268 M positions of an RMAT-24 sweep cost 1 ms of a 1.4 ms kernel whatever the frontier held (profiles/r6n_*)
+      if (live[k]) {  // (a row's edges are consecutive: most lanes of a step read the same few words of the row's own state)
+        if (s.flt.bits) bw[k] = s.flt.bits[(uint32_t)v[k] >> 5];
+        if constexpr (PK) { du[k] = pk_dist_bits(s.pk, u[k]); lab[k] = pk_label(s.labels ? s.labels[u[k]] : u[k]); }
+        else du[k] = s.dist[u[k]];
       }
     }
     uint32_t n_live = 0;
@@ -735,7 +713,6 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_sweep(int32_t const* edge_row
       bool go     = live[k] & (nd < s.cutoff) & !((((bw[k] >> ((uint32_t)v[k] & 31u)) & 1u) != 0u) & (nd >= f.ft));
       if constexpr (PK) go = go & (v[k] != s.source);
       n_live += live[k] ? 1u : 0u;
-      if (go) go = !ts.dominated(v[k], B::to(nd));
       uint64_t const m = __ballot(go);
       if (go) {
         uint32_t const at = ts.n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -1362,8 +1339,6 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   char const* env_sw = getenv("CUGRAPH_AMD_SSSP_SWEEP");  // share of the graph's edges a frontier must hold for a streamed round (0: never)
   double const sweep_frac = env_sw ? atof(env_sw) : 0.25;
   bool const sweep_on = sweep_frac > 0.0 && g.ne > 0;
-  char const* env_hot = getenv("CUGRAPH_AMD_SSSP_HOT");
-  bool const hot_cache_on = !(env_hot && std::string(env_hot) == "0");
   char const* env_s2g = getenv("CUGRAPH_AMD_SSSP_S2_GRID");
   int const s2_wg_per_cu = env_s2g ? std::max(1, atoi(env_s2g)) : 4;  // workgroups per CU of the two-stage kernels (their LDS buffers allow ~4 residents)
   dvec<uint32_t> fbits;
@@ -1385,7 +1360,6 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   bool const order_wide = env_ord && std::string(env_ord) == "1";  // similar degrees, so a wavefront's 64 rows are all of the slow whole-wave kind at once; profiles/r6j_sssp_ab.txt)
   dvec<int32_t> ordered;
   dvec<uint32_t> order_cursor;
-  dev_buf snap;
   auto relax_round = [&](int32_t const* front, int64_t n_front) {
     uint32_t const front_tag = round;  // every member of `front` carries mark_near == the round (or window advance) that appended it
     ++round;
@@ -1432,7 +1406,6 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
     sssp_state<WT> s{d, w, q_nxt, far_cur, mark_near.data(), mark_far.data(), cnt.data(), (WT)std::min(upper, (double)wmax), cutoff, round, far_epoch, row_beg};
     if (packed) { s.pk = pk.data(); s.labels = g.renumbered ? g.number_map.data() : nullptr; s.source = source; }
     if (filtered) { s.flt.bits = fbits.data(); s.flt.t = ft.data(); }
-    s.hot_cache = hot_cache_on ? 1 : 0;
     {
       timed_launch t(h, "sssp_relax");
       with_words([&](auto pkc) {
@@ -1443,12 +1416,6 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
             ow.edge_rows.resize_discard((size_t)g.ne + kEdgePad);
             HIP_TRY(hipMemsetAsync(ow.edge_rows.data() + g.ne, 0, kEdgePad * sizeof(int32_t), h.stream));
             hipLaunchKernelGGL(k_sssp_edge_rows, grid_for(nv * 16, kBlock, 8192), kBlock, 0, h.stream, row_beg, nv, ow.edge_rows.data());
-          }
-          if (getenv("CUGRAPH_AMD_SSSP_SNAPSHOT")) {  // experiment: the rows' own distances from a copy made before the round
-            size_t const bytes = (size_t)nv * (packed ? 8 : sizeof(bits_t));
-            if (snap.bytes < bytes) snap.alloc(bytes);
-            HIP_TRY(hipMemcpyAsync(snap.ptr, packed ? (void const*)pk.data() : (void const*)d, bytes, hipMemcpyDeviceToDevice, h.stream));
-            s.du_src = snap.ptr;
           }
           static bool const prof_on = getenv("CUGRAPH_AMD_SSSP_TRACE") && atoi(getenv("CUGRAPH_AMD_SSSP_TRACE")) >= 2;
           size_t const n_prof = (size_t)h.num_cus * s2_wg_per_cu * TV_WAVES;

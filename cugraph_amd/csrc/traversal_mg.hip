@@ -524,15 +524,22 @@ extern "C" void cugraph_amd_traversal_mg_plan_rebind(cugraph_amd_traversal_mg_pl
 {
   if (!plan || !handle) return;
   handle_t const* h = reinterpret_cast<handle_t const*>(handle);
-  if (TP(plan).h == h) return;
+  auto& pl = *reinterpret_cast<traversal_mg_plan*>(plan);  // (not TP(): that names the OLD handle's stream to the pool, and the old handle may be gone)
+  if (pl.h == h) return;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
-  TP(plan).h = h;
+  pl.h = h;
+  pool_set_stream(h->stream);
 }
 
 extern "C" void cugraph_amd_traversal_mg_plan_free(cugraph_amd_traversal_mg_plan_t* plan)
 {
-  if (plan) delete &TP(plan);
+  if (!plan) return;
+  // (not TP(): the handle of the plan's last call may be gone when the graph that caches the plan is freed.  The device is synchronised and the blocks go
+  // back to the pool without a stream to order against)
+  (void)hipDeviceSynchronize();
+  pool_forget_stream(nullptr);
+  delete reinterpret_cast<traversal_mg_plan*>(plan);
 }
 
 extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_reset(cugraph_amd_traversal_mg_plan_t* plan, const int32_t* source_rows,
