@@ -328,7 +328,7 @@ def traversal_bench(cg, h, scale=24, edge_factor=16, n_roots=64, weights="unit",
 
     def run(kind, pred=None):
         pred = predecessors if pred is None else pred
-        times, edges, steps, inspected = [], [], [], []
+        times, edges, steps, inspected, probes = [], [], [], [], []
         for i, r in enumerate([roots[0], roots[0]] + list(roots)):  # two warm-ups (the second BFS of a directed graph builds its CSC)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -344,8 +344,10 @@ def traversal_bench(cg, h, scale=24, edge_factor=16, n_roots=64, weights="unit",
                 edges.append(st["edges_of_reached"] if kind == "bfs" else None)
                 steps.append(st["steps"])
                 inspected.append(st["edges_inspected"])
+                probes.append(st.get("probes", 0))
             last = (v, d)
         run.inspected = inspected
+        run.probes = probes
         return times, edges, steps, last
 
     HBM_PEAK = 8000.0  # GB/s, /opt/skills/guides/MI355X_MICROARCH.md
@@ -423,7 +425,9 @@ def traversal_bench(cg, h, scale=24, edge_factor=16, n_roots=64, weights="unit",
         hm = len(teps) / sum(1.0 / x for x in teps)
         t_hm = float(np.mean(be)) / hm
         out["sssp"] = {"mean_ms": round(1e3 * float(np.mean(st)), 3), "min_ms": round(1e3 * float(np.min(st)), 3), "max_ms": round(1e3 * float(np.max(st)), 3),
-                       "harmonic_mean_mteps": round(hm / 1e6, 1), "mean_steps": float(np.mean(ss)), "mean_relaxations_per_edge": round(float(np.mean(run.inspected)) / ne, 3), "dtype": "f32",
+                       "harmonic_mean_mteps": round(hm / 1e6, 1), "mean_steps": float(np.mean(ss)), "mean_relaxations_per_edge": round(float(np.mean(run.inspected)) / ne, 3),
+                       "mean_distance_probes_per_edge": round(float(np.mean(run.probes)) / ne, 3),  # relaxations that went past the L2-resident distance filter to the distance words
+                       "dtype": "f32",
                        "roofline": roofline("sssp", float(np.mean(be)), reached[0], t_hm, predecessors)}
         if check:
             out["sssp"]["check"] = bellman_check("sssp", sv, sd)

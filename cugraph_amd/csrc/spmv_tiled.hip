@@ -1384,6 +1384,8 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
       vec4 const* src = reinterpret_cast<vec4 const*>(a.x + (size_t)J * a.T);
       vec4* dst       = reinterpret_cast<vec4*>(xs);
       int const n4    = a.T / 4;
+      // (round 6: the same fill through LDS-DMA -- global_load_lds_dwordx4, 1 KiB per wavefront instruction, alpha applied in place afterwards -- is
+      // bit-identical and NEUTRAL, 0.9211 against 0.9209 ms alternated on one plan, profiles/r6o_p1_dma_fill.txt: the fill is one round trip either way)
       for (int i0 = 0; i0 < n4; i0 += 8 * TP_BLOCK) {
         vec4 v[8];
 #pragma unroll
@@ -1697,7 +1699,7 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
   if (pending) a.fin = make_fin<WT>(*pending, tiled_fold_count(t, *pending));
   size_t const lds = std::max<size_t>(((size_t)t.T + (size_t)TP_WAVES * TP_STAGE) * sizeof(WT) + 64, 3 * TP_BLOCK * sizeof(double));
   bool const w     = a.weights != nullptr;
-  static bool attr_done[2] = {false, false};
+  static bool attr_done[4] = {false, false, false, false};
   static int dbg_calls = getenv("CUGRAPH_AMD_TILED_DEBUG") ? 2 : 0;
   auto launch = [&](auto kernel, int slot) {
     if (!attr_done[slot]) { ensure_max_lds(kernel, (int)h.lds_per_block); attr_done[slot] = true; }
