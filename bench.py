@@ -235,7 +235,8 @@ def main():
                "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=env))
     if args.gpus > 1 or world > 1:
-        if args.transport == "ipc" and args.layout == "1d":
+        if args.transport == "ipc":  # both layouts run behind cugraph_graph_create_mg + cugraph_pagerank on the library's communicator (round 6)
+            os.environ["CUGRAPH_AMD_MG_LAYOUT"] = args.layout
             from cugraph_amd import mg_capi as mg
         else:
             from cugraph_amd import mg

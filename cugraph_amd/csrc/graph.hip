@@ -821,5 +821,6 @@ extern "C" size_t cugraph_amd_graph_num_local_edges(const cugraph_graph_t* graph
   if (!graph) return 0;
   graph_t const& g = *reinterpret_cast<graph_t const*>(graph);
   if (!g.mg) return (size_t)g.ne;
+  if (g.mg->pr2d) return (size_t)g.mg->pr2d->ne_local;  // (the layout the last PageRank of this graph ran on)
   return g.mg->pr ? (size_t)g.mg->pr->ne_local : 0;
 }

@@ -744,6 +744,127 @@ mg_pagerank_part_t& mg_pagerank_part(handle_t const& h, graph_t& g)
   return *mg.pr;
 }
 
+// ------------------------------------------------------------------------------------------------ 2-D PageRank partition
+namespace {
+// edge (s, d) -> the rank of its block, its local column and its local row (mg_pagerank2d_part_t)
+__global__ void k_route2d(int32_t const* s, int32_t const* d, int64_t m, int64_t vmin, int32_t const* pos, int P, int R, int64_t L, int32_t* owner, int32_t* col, int32_t* row)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t const ps = pos[(int64_t)s[i] - vmin], pd = pos[(int64_t)d[i] - vmin];
+    int const qs = ps % P, qd = pd % P;
+    owner[i] = (qs / R) * R + qd % R;
+    col[i]   = (int32_t)((int64_t)(qs % R) * L + ps / P);
+    row[i]   = (int32_t)((int64_t)(qd / R) * L + pd / P);
+  }
+}
+}  // namespace
+
+void mg_grid_shape(int P, int* R, int* C)
+{
+  int r = 1;
+  while ((r + 1) * (r + 1) <= P) ++r;
+  while (P % r) --r;
+  *R = r; *C = P / r;
+}
+
+mg_pagerank2d_part_t::~mg_pagerank2d_part_t()
+{
+  if (local) cugraph_graph_free(local);
+}
+
+mg_pagerank2d_part_t& mg_pagerank2d_part(handle_t const& h, graph_t& g)
+{
+  mg_graph_t& mg = *g.mg;
+  if (mg.pr2d) return *mg.pr2d;
+  comm_t& c   = *mg.comm;
+  int const P = c.size, me = c.rank;
+  auto part   = std::make_unique<mg_pagerank2d_part_t>();
+  part->P = P; part->rank = me; part->nv_global = mg.nv_global;
+  mg_grid_shape(P, &part->R, &part->C);
+  part->r = me % part->R; part->c = me / part->R;
+  int const R = part->R, C = part->C;
+  build_trace tr(h, "mg pagerank 2d");
+  // global in-degrees (the vertex order) and out-weight sums (PageRank's divisor): as for the 1-D partition
+  dvec<uint32_t> din;
+  global_degree(h, c, mg, mg.el.d.data(), din);
+  dvec<double> outw((size_t)mg.vrange);
+  if (mg.el.wsize == 0) {
+    dvec<uint32_t> dout;
+    global_degree(h, c, mg, mg.el.s.data(), dout);
+    hipLaunchKernelGGL(k_u32_to_f64, grid_for(mg.vrange, kBlock, 4096), kBlock, 0, h.stream, (uint32_t const*)dout.data(), mg.vrange, outw.data());
+    h.sync();
+  } else {
+    HIP_TRY(hipMemsetAsync(outw.data(), 0, (size_t)mg.vrange * 8, h.stream));
+    if (mg.el.n > 0) {
+      if (mg.el.wsize == 4) hipLaunchKernelGGL(k_add_weights_f64<float>, grid_for(mg.el.n, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)mg.el.s.data(), mg.el.w.as<float const>(), mg.el.n, mg.vmin, outw.data());
+      else hipLaunchKernelGGL(k_add_weights_f64<double>, grid_for(mg.el.n, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)mg.el.s.data(), mg.el.w.as<double const>(), mg.el.n, mg.vmin, outw.data());
+    }
+    c.all_reduce_sum_f64(h, outw.data(), mg.vrange);
+  }
+  vertex_order_t vo;
+  degree_order(h, din.data(), mg.present.data(), mg.vrange, mg.nv_global, vo);
+  din = dvec<uint32_t>();
+  tr.step("degree order");
+  int64_t const nvg = mg.nv_global;
+  int64_t const L   = std::max<int64_t>((nvg + P - 1) / P, 1);
+  CGA_EXPECTS((int64_t)std::max(R, C) * L < ((int64_t)1 << 31), CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "2-D multi-GPU PageRank: a block's rows / columns must fit 31 bits");
+  part->L     = L;
+  part->n_own = nvg > me ? (nvg - me + P - 1) / P : 0;
+  size_t const n1 = (size_t)std::max<int64_t>(part->n_own, 1);
+  part->local_vertices.resize_discard(n1);
+  bool const f64 = mg.el.wsize == 8;
+  part->outw_own.alloc((size_t)L * (f64 ? 8 : 4));
+  HIP_TRY(hipMemsetAsync(part->outw_own.ptr, 0, (size_t)L * (f64 ? 8 : 4), h.stream));
+  if (part->n_own > 0) {
+    hipLaunchKernelGGL(k_owned_ids, grid_for(part->n_own, kBlock, 4096), kBlock, 0, h.stream, (uint32_t const*)vo.order.data(), part->n_own, P, me, mg.vmin, part->local_vertices.data());
+    if (f64) hipLaunchKernelGGL((k_take_owned<double, double>), grid_for(part->n_own, kBlock, 4096), kBlock, 0, h.stream, (double const*)outw.data(), (uint32_t const*)vo.order.data(), part->n_own, P, me, part->outw_own.as<double>());
+    else hipLaunchKernelGGL((k_take_owned<float, double>), grid_for(part->n_own, kBlock, 4096), kBlock, 0, h.stream, (double const*)outw.data(), (uint32_t const*)vo.order.data(), part->n_own, P, me, part->outw_own.as<float>());
+  }
+  h.sync();
+  outw = dvec<double>();
+  // every edge to the rank of its block
+  int64_t const m = mg.el.n;
+  size_t const m1 = (size_t)std::max<int64_t>(m, 1);
+  std::vector<dev_buf> got;
+  int64_t e_loc = 0;
+  {
+    dvec<int32_t> owner(m1), a(m1), b(m1);
+    if (m > 0) hipLaunchKernelGGL(k_route2d, grid_for(m, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)mg.el.s.data(), (int32_t const*)mg.el.d.data(), m, mg.vmin, (int32_t const*)vo.pos.data(), P, R, L,
+                                  owner.data(), a.data(), b.data());
+    std::vector<column_t> cols{{a.data(), 4}, {b.data(), 4}};
+    if (mg.el.wsize) cols.push_back({mg.el.w.ptr, mg.el.wsize});
+    e_loc = shuffle_by_owner(h, c, owner.data(), m, cols, got);
+  }
+  tr.step("edge shuffle");
+  CGA_EXPECTS(e_loc <= kMaxSignedEdges, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "multi-GPU PageRank: a rank's share must hold fewer than 2^31 edges");
+  part->ne_local = e_loc;
+  {
+    int64_t const nverts = (int64_t)std::max(R, C) * L;
+    dvec<int32_t> verts((size_t)nverts);
+    iota_i32(h, verts.data(), nverts, 0);
+    h.sync();
+    device_array_view_t vv{verts.data(), (size_t)nverts, INT32}, sv{got[0].ptr, (size_t)e_loc, INT32}, dv{got[1].ptr, (size_t)e_loc, INT32};
+    device_array_view_t wv{mg.el.wsize ? got[2].ptr : nullptr, (size_t)e_loc, f64 ? FLOAT64 : FLOAT32};
+    cugraph_graph_properties_t props{FALSE, TRUE};
+    cugraph_error_t* err = nullptr;
+    cugraph_resource_handle_t const* hh = reinterpret_cast<cugraph_resource_handle_t const*>(&h);
+    cugraph_error_code_t const rc = cugraph_graph_create_sg(hh, &props, reinterpret_cast<cugraph_type_erased_device_array_view_t const*>(&vv),
+                                                            reinterpret_cast<cugraph_type_erased_device_array_view_t const*>(&sv),
+                                                            reinterpret_cast<cugraph_type_erased_device_array_view_t const*>(&dv),
+                                                            mg.el.wsize ? reinterpret_cast<cugraph_type_erased_device_array_view_t const*>(&wv) : nullptr, nullptr, nullptr, TRUE, FALSE, FALSE,
+                                                            FALSE, FALSE, FALSE, &part->local, &err);
+    if (rc != CUGRAPH_SUCCESS) {
+      std::string msg = err ? cugraph_error_message(err) : "?";
+      cugraph_error_free(err);
+      throw api_error(rc, "2-D multi-GPU PageRank: building the local block failed: " + msg);
+    }
+  }
+  tr.step("local block");
+  mg.pr2d = std::move(part);
+  return *mg.pr2d;
+}
+
 // ------------------------------------------------------------------------------------------------ traversal partition
 namespace {
 // sorts the received (row, minor[, extra key]) tuples into a CSR: rows ascending, inside a row ascending `sort_minor`; returns offsets and

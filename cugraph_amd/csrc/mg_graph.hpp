@@ -34,6 +34,20 @@ struct mg_pagerank_part_t {
   ~mg_pagerank_part_t();
 };
 
+// The reference's 2-D layout (graph_view.hpp:64-230, partition_manager.hpp:40-51) behind the same entry points: P = R x C ranks, rank = c * R + r;
+// vertex partition q = position % P of the global descending in-degree order, L = ceil(V / P) rows each; rank (r, c) OWNS partition c * R + r and
+// STORES the edges whose source lies in the partitions [c * R, (c + 1) * R) (local column (q_src % R) * L + row) and whose destination lies in the
+// partitions {i * R + r} (local row (q_dst / R) * L + row).  PageRank: all-gather of x over the COLUMN group {c * R + r'}, SpMV of the block,
+// reduce of the partial rows over the ROW group {c' * R + r} to their owners.  Chosen with CUGRAPH_AMD_MG_LAYOUT=2d (every rank the same).
+struct mg_pagerank2d_part_t {
+  int P{1}, R{1}, C{1}, r{0}, c{0}, rank{0};
+  int64_t nv_global{0}, L{0}, n_own{0}, ne_local{0};
+  dvec<int32_t> local_vertices;      // [n_own] external ids of the owned rows
+  dev_buf outw_own;                  // [L] out-weight sums of the owned vertices (weight type; padded rows 0)
+  cugraph_graph_t* local{nullptr};   // the block: CSC over max(C, R) * L ids, rows = local rows, columns = local columns (renumber = FALSE); owned
+  ~mg_pagerank2d_part_t();
+};
+
 struct mg_traversal_part_t {
   int P{1}, rank{0};
   int64_t nv_global{0}, n_rows{0}, L{0}, ne_local{0}, ne_global{0};
@@ -63,6 +77,7 @@ struct mg_graph_t {
   int64_t nv_global{0}, ne_global{0};
   dvec<uint32_t> present;     // [vrange] 1 = the id is a vertex of the graph
   std::unique_ptr<mg_pagerank_part_t> pr;
+  std::unique_ptr<mg_pagerank2d_part_t> pr2d;
   std::unique_ptr<mg_traversal_part_t> tr[2];  // [0] = without weights (BFS), [1] = with the graph's weights (SSSP)
 };
 
@@ -95,6 +110,8 @@ void mg_has_vertex(handle_t const& h, graph_t const& g, int32_t const* v, int64_
 // cugraph_degrees family on a multi-GPU graph (collective): this rank's share of the vertices (all, or those any rank listed) and their degrees
 int64_t mg_degrees(handle_t const& h, graph_t& g, device_array_view_t const* listed, bool want_in, bool want_out, dvec<int32_t>& ids, dvec<int32_t>& in_deg, dvec<int32_t>& out_deg);
 mg_pagerank_part_t& mg_pagerank_part(handle_t const& h, graph_t& g);                   // collective on first use
+mg_pagerank2d_part_t& mg_pagerank2d_part(handle_t const& h, graph_t& g);               // collective on first use
+void mg_grid_shape(int P, int* R, int* C);  // R = the largest divisor of P that is <= sqrt(P) (cpp/tests/utilities/mg_utilities.cpp:48-52): 1x2, 2x2, 2x4 for 2, 4, 8 ranks
 mg_traversal_part_t& mg_traversal_part(handle_t const& h, graph_t& g, bool weighted);  // collective on first use
 void mg_traversal_in_edges(handle_t const& h, graph_t& g, mg_traversal_part_t& t);     // collective: the in-edge copy for bottom-up BFS levels
 // cugraph_bfs / cugraph_sssp on a multi-GPU graph (traversal_mg_driver.hip): collective; every rank gets its owned vertices back

@@ -1421,7 +1421,8 @@ struct pagerank_mg2d_plan : pagerank_mg2d_plan_base {
     e.partials = tpartials.data(); e.totals = triple; e.alpha = alpha; e.nv_global = nv_global; e.wmax = tc->wmax;
     return e;
   }
-  void done() { if (!h.stream_borrowed) h.sync(); }  // the host layer's collectives run on its own stream -- unless it shares ours
+  bool in_library_loop{false};  // pagerank_mgc2d_plan: exchange and compute share the handle's stream, nothing to synchronise between the phases
+  void done() { if (!h.stream_borrowed && !in_library_loop) h.sync(); }  // the host layer's collectives run on its own stream -- unless it shares ours
 
   void start() override
   {  // x_own <- x of the initial vector, triple <- (0, partial dangling mass, max |x|)
@@ -2121,6 +2122,191 @@ struct pagerank_mgc_plan : pagerank_plan_base {
   }
 };
 
+// =================================================================================================
+// The reference's 2-D layout behind cugraph_graph_create_mg + cugraph_pagerank (round 6; CUGRAPH_AMD_MG_LAYOUT=2d on every rank): the block of
+// mg_pagerank2d_part_t (mg_graph.hpp), the kernels of pagerank_mg2d_plan, and the exchange on the library's communicator --
+//   column group {c * R + r'}: every member PUSHES its x_own [L] into slot r of the members' x windows [R * L]      (the row broadcast of
+//                              update_edge_src_property, prims/update_edge_src_dst_property.cuh:550-579)
+//   row group {c' * R + r}:    every member pushes chunk c' of its partial rows [C * L] into slot c of member c''s y window [C * L]; the owner adds its C
+//                              slots in slot order (the column reduction of prims/detail/per_v_transform_reduce_e.cuh:3390-3406; fixed order = the same bits in every run)
+//   all ranks:                 the scalar triples, into slot `rank` of everybody's [P][4] window, folded in rank order
+// all as peer-mapped stores over xGMI (comm_t::push_multi), one signal + wait per exchange step, no host in the loop.  One buffer per window suffices: a
+// rank overwrites a peer's x / scalar slot only after its own epilogue, i.e. after every rank has signalled the y exchange of the iteration that read them,
+// and a y slot only after the x exchange of the next iteration, which every rank signals after its epilogue has consumed the y window.
+// Per rank and iteration (R - 1 + C - 1) * L values travel -- 4 * V / 8 * 4 B = 134 MB at RMAT-26 on 2 x 4 ranks against the 1-D
+// layout's sparse exchange (DESIGN.md section 5 has both byte counts).  Plain PageRank only: a call with precomputed out-weights, an initial guess or a
+// personalization vector runs on the 1-D partition.
+// =================================================================================================
+template <typename WT>
+__global__ void __launch_bounds__(256) k_mgc2d_reduce_rows(WT const* ywin, int C, int64_t L, WT* y_own)
+{
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < L; i += (int64_t)gridDim.x * blockDim.x) {
+    WT sum = ywin[i];
+    for (int cc = 1; cc < C; ++cc) sum += ywin[(int64_t)cc * L + i];
+    y_own[i] = sum;
+  }
+}
+
+template <typename WT>
+struct pagerank_mgc2d_plan : pagerank_plan_base {
+  handle_t const& h;
+  graph_t& g;
+  comm_t& c;
+  mg_pagerank2d_part_t* part{nullptr};
+  double alpha;
+  std::unique_ptr<pagerank_mg2d_plan<WT>> inner;
+  dvec<WT> x_own, y_part, y_own;
+  dvec<double> triple;
+  comm_window_t* xwin{nullptr};  // [R * L] the gathered x of the column group
+  comm_window_t* ywin{nullptr};  // [C * L] the row group's partial sums of the owned rows, one slot per sender
+  comm_window_t* swin{nullptr};  // [P][4] doubles
+  int channel{0};
+  uint64_t pending_seq{0};  // the signal of the latest x / scalar push (0: none outstanding)
+  bool folded{true};        // its scalars have been folded into the iteration constants
+  size_t iterations{0};
+  double last_diff{0};
+
+  pagerank_mgc2d_plan(handle_t const& h_, graph_t& g_, double alpha_) : h(h_), g(g_), c(*g_.mg->comm), alpha(alpha_) {}
+  ~pagerank_mgc2d_plan() override
+  {  // collective, like create(): every rank frees in the same order
+    try {
+      (void)hipStreamSynchronize(h.stream);
+      inner.reset();
+      if (swin) c.window_free(swin);
+      if (ywin) c.window_free(ywin);
+      if (xwin) c.window_free(xwin);
+      if (channel >= 2) c.channel_free(channel);
+    } catch (...) {
+    }
+  }
+
+  void create()
+  {
+    HIP_TRY(hipSetDevice(h.device));
+    part = &mg_pagerank2d_part(h, g);
+    int const R = part->R, C = part->C, P = part->P;
+    int64_t const L = part->L;
+    CGA_EXPECTS(R + P <= kCommMaxRanks, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "2-D multi-GPU PageRank: too many ranks for one push");
+    x_own.resize_discard((size_t)L); y_part.resize_discard((size_t)C * L); y_own.resize_discard((size_t)L); triple.resize_discard(4);
+    HIP_TRY(hipMemsetAsync(x_own.data(), 0, (size_t)L * sizeof(WT), h.stream));
+    HIP_TRY(hipMemsetAsync(y_part.data(), 0, (size_t)C * L * sizeof(WT), h.stream));
+    HIP_TRY(hipMemsetAsync(y_own.data(), 0, (size_t)L * sizeof(WT), h.stream));
+    channel = c.channel_alloc();
+    xwin    = c.window_create((size_t)R * L * sizeof(WT));
+    ywin    = c.window_create((size_t)C * L * sizeof(WT));
+    swin    = c.window_create((size_t)P * 4 * sizeof(double));
+    HIP_TRY(hipMemsetAsync(xwin->local, 0, (size_t)R * L * sizeof(WT), h.stream));
+    HIP_TRY(hipMemsetAsync(ywin->local, 0, (size_t)C * L * sizeof(WT), h.stream));
+    HIP_TRY(hipMemsetAsync(swin->local, 0, (size_t)P * 4 * sizeof(double), h.stream));
+    h.sync();
+    c.host_barrier();  // nobody pushes into a window that is still being cleared
+    graph_t& block = G(part->local);
+    cugraph_data_type_id_t const wt = sizeof(WT) == 8 ? FLOAT64 : FLOAT32;
+    inner = std::make_unique<pagerank_mg2d_plan<WT>>(h, block, alpha, L, part->n_own, (int64_t)C * L, (int64_t)R * L, part->nv_global);
+    inner->in_library_loop = true;
+    device_array_view_t ow{part->outw_own.ptr, (size_t)L, wt}, xo{x_own.data(), (size_t)L, wt}, xc{xwin->local, (size_t)R * L, wt}, yp{y_part.data(), (size_t)C * L, wt},
+      yo{y_own.data(), (size_t)L, wt}, tv{triple.data(), 4, FLOAT64};
+    // (an unweighted multi-GPU graph computes in fp32: its block is created without weights and reports FLOAT32)
+    inner->create(&ow, nullptr, &xo, &xc, &yp, &yo, &tv);
+    inner->start();  // x_own, triple of the initial vector
+    push_x_and_scalars();
+  }
+
+  void push_x_and_scalars()
+  {
+    comm_push_desc_t d{};
+    int const R = part->R, P = part->P;
+    int64_t const L = part->L;
+    int n = 0;
+    for (int rr = 0; rr < R; ++rr, ++n) {  // my x into slot r of every member of my column group (myself included)
+      int const peer = part->c * R + rr;
+      d.dst[n] = static_cast<char*>(xwin->peer[peer]) + (size_t)part->r * L * sizeof(WT);
+      d.src[n] = x_own.data();
+      d.words[n] = (int64_t)(L * sizeof(WT) / 4);
+    }
+    for (int p = 0; p < P; ++p, ++n) {
+      d.dst[n] = static_cast<char*>(swin->peer[p]) + (size_t)part->rank * 4 * sizeof(double);
+      d.src[n] = triple.data();
+      d.words[n] = 8;
+    }
+    d.n = n;
+    c.push_multi(h.stream, d);
+    pending_seq = c.signal(h.stream, channel);
+    folded      = false;
+  }
+  void fold(bool read_back)
+  {
+    if (!folded) {
+      c.wait(h.stream, channel, pending_seq);
+      double diff = 0, dang = 0;
+      inner->set_scalars(swin->local, part->P, read_back, &diff, &dang);
+      if (read_back) { c.check("2-D multi-GPU PageRank"); last_diff = diff; }
+      folded = true;
+    } else if (read_back) {  // (folded already: only the L1 change is wanted)
+      pr_scalars<WT> sc;
+      h.read_back(&sc, inner->scal.data(), 1);
+      last_diff = (double)sc.diff;
+    }
+  }
+  void iterate()
+  {
+    int const R = part->R, C = part->C;
+    int64_t const L = part->L;
+    inner->spmv();  // y_part <- block x (alpha * x window)
+    comm_push_desc_t d{};
+    for (int cc = 0; cc < C; ++cc) {  // chunk cc of my partial rows into slot c of the owner's y window
+      int const peer = cc * R + part->r;
+      d.dst[cc] = static_cast<char*>(ywin->peer[peer]) + (size_t)part->c * L * sizeof(WT);
+      d.src[cc] = y_part.data() + (size_t)cc * L;
+      d.words[cc] = (int64_t)(L * sizeof(WT) / 4);
+    }
+    d.n = C;
+    c.push_multi(h.stream, d);
+    c.wait(h.stream, channel, c.signal(h.stream, channel));
+    hipLaunchKernelGGL(k_mgc2d_reduce_rows<WT>, grid_for(L, 256, 2048), 256, 0, h.stream, (WT const*)ywin->local, C, L, y_own.data());
+    inner->epilogue();  // pr, x_own, triple
+    push_x_and_scalars();
+  }
+
+  void step(double epsilon, size_t max_iterations, size_t* done, bool* converged) override
+  {
+    HIP_TRY(hipSetDevice(h.device));
+    bool const track = epsilon > 0.0;
+    size_t it = 0;
+    bool conv = false;
+    while (it < max_iterations) {
+      fold(track);
+      if (track && iterations > 0 && last_diff < epsilon) { conv = true; break; }  // pagerank_impl.cuh:320-326, on the GLOBAL L1 change
+      iterate();
+      ++iterations; ++it;
+    }
+    if (track && !conv) { fold(true); conv = last_diff < epsilon; }
+    *done      = it;
+    *converged = conv;
+  }
+
+  centrality_result_t* result(size_t total_iterations, bool converged) override
+  {
+    int64_t const n = part->n_own, L = part->L;
+    auto ids  = std::make_unique<device_array_t>((size_t)n, INT32);
+    auto vals = std::make_unique<device_array_t>((size_t)n, g.weight_type);
+    dvec<WT> all((size_t)L);
+    cugraph_data_type_id_t const wt = sizeof(WT) == 8 ? FLOAT64 : FLOAT32;
+    device_array_view_t av{all.data(), (size_t)L, wt};
+    inner->values(&av);
+    if (n > 0) {
+      HIP_TRY(hipMemcpyAsync(ids->buf.ptr, part->local_vertices.data(), (size_t)n * 4, hipMemcpyDeviceToDevice, h.stream));
+      HIP_TRY(hipMemcpyAsync(vals->buf.ptr, all.data(), (size_t)n * sizeof(WT), hipMemcpyDeviceToDevice, h.stream));
+    }
+    h.sync();
+    c.check("2-D multi-GPU PageRank result");
+    device_array_t* idp = ids.release();
+    outer_replace_ids(h, g, idp);
+    return new centrality_result_t{idp, vals.release(), total_iterations, converged};
+  }
+};
+
 namespace {
 
 void check_pair_types(graph_t const& g, device_array_view_t const* v, device_array_view_t const* s, char const* vmsg, char const* smsg)
@@ -2153,6 +2339,23 @@ pagerank_plan_base* make_plan(cugraph_resource_handle_t const* handle, cugraph_g
     device_array_view_t const* mow = mc_ow.get(h, g, V(ow_v), "precomputed_vertex_out_weight_vertices");
     device_array_view_t const* mig = mc_ig.get(h, g, V(ig_v), "initial_guess_vertices");
     device_array_view_t const* mpv = mc_p.get(h, g, V(p_v), "personalization_vector");
+    {  // the layout: the ranks must agree (a collective call); the optional arguments run on the 1-D partition
+      char const* env_l = getenv("CUGRAPH_AMD_MG_LAYOUT");
+      int64_t const want2d = env_l != nullptr && std::string(env_l) == "2d" ? 1 : 0;
+      int64_t const plain  = (mow == nullptr && mig == nullptr && mpv == nullptr) ? 1 : 0;
+      int64_t const hi = mg_host_max(g, want2d * 2 + plain), lo = -mg_host_max(g, -(want2d * 2 + plain));
+      CGA_EXPECTS(hi == lo, CUGRAPH_INVALID_INPUT, "multi-GPU PageRank: the ranks disagree on CUGRAPH_AMD_MG_LAYOUT or on which optional arguments they pass");
+      if (want2d && plain) {
+        if (g.weight_type == FLOAT64) {
+          auto p = std::make_unique<pagerank_mgc2d_plan<double>>(h, g, alpha);
+          p->create();
+          return p.release();
+        }
+        auto p = std::make_unique<pagerank_mgc2d_plan<float>>(h, g, alpha);
+        p->create();
+        return p.release();
+      }
+    }
     if (g.weight_type == FLOAT64) {
       auto p = std::make_unique<pagerank_mgc_plan<double>>(h, g, alpha);
       p->create(mow, V(ow_s), mig, V(ig_s), mpv, V(p_s));

@@ -162,10 +162,13 @@ def bench_main(args):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_iter, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"PageRank power iteration, RMAT scale {args.scale} edge factor {args.edge_factor} (a,b,c)=(0.57,0.19,0.19) seed 0, int32 ids, "
-                                   "fp32 ranks, alpha 0.85; cugraph_graph_create_mg + cugraph_pagerank (plan form) on the library's communicator: 1-D destination "
-                                   "partition in global degree order, x pushed into the peers' gather windows over xGMI (HIP IPC), scalars in a [P][4] window, "
-                                   "one signal per iteration, iteration loop inside the library",
-                       "vertices": nv, "edges": ne, "parallelism": f"{world} GPUs, 1 process per GPU", "layout": "1d", "transport": "ipc",
+                                   "fp32 ranks, alpha 0.85; cugraph_graph_create_mg + cugraph_pagerank (plan form) on the library's communicator: " +
+                                   ("the reference's 2-D R x C layout (rank = c * R + r): x pushed into the column group's windows, partial rows pushed to their owners "
+                                    "in the row group and added in slot order, scalars in a [P][4] window, two signals per iteration, iteration loop inside the library"
+                                    if os.environ.get("CUGRAPH_AMD_MG_LAYOUT") == "2d" else
+                                    "1-D destination partition in global degree order, x pushed into the peers' gather windows over xGMI (HIP IPC), scalars in a [P][4] "
+                                    "window, one signal per iteration, iteration loop inside the library"),
+                       "vertices": nv, "edges": ne, "parallelism": f"{world} GPUs, 1 process per GPU", "layout": os.environ.get("CUGRAPH_AMD_MG_LAYOUT", "1d"), "transport": "ipc",
                        "backend": "cugraph_amd communicator (HIP IPC peer writes)", "all_ranks_on_one_gpu": single,
                        "link_selftest": link},
             "iters_per_sec": round(args.steps / dt, 2), "graph_build_s": round(build_s, 3), "plan_build_s": round(plan_s, 3),

@@ -137,6 +137,27 @@ def _pagerank_case(orc, tmp_path, world, weighted, env=None):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,weighted", [(1, "-"), (2, "w"), (3, "-"), (4, "-"), (6, "w"), (8, "-")])
+def test_mg_capi_pagerank_2d_layout(orc, tmp_path, world, weighted):
+    """Round 6: the reference's 2-D R x C layout (graph_view.hpp:64-230; 1x1, 1x2, 1x3, 2x2, 2x3, 2x4 for these worlds) behind the same two entry
+    points, chosen with CUGRAPH_AMD_MG_LAYOUT=2d: x all-gathered over the column group, partial rows reduced over the row group to their owners, all
+    as peer writes on the library's communicator.  Same oracle, same tolerance, every vertex from exactly one rank, two calls bit-identical."""
+    _pagerank_case(orc, tmp_path, world, weighted, env={"CUGRAPH_AMD_MG_LAYOUT": "2d"})
+
+
+@pytest.mark.gpu
+def test_mg_capi_pagerank_2d_layout_converges_like_single_gpu(orc, tmp_path):
+    from test_mg import truth
+
+    res = run_ranks("pagerank", 4, tmp_path, 11, 200, 1e-5, "-", env_extra={"CUGRAPH_AMD_MG_LAYOUT": "2d"})
+    assert all(r["converged"] for r in res)
+    pr = _assemble(tmp_path, 4, 1 << 11)
+    t, it, tconv = truth(orc, 11, 1e-5, 200)
+    assert tconv
+    np.testing.assert_allclose(pr, t, rtol=1e-4)
+
+
+@pytest.mark.gpu
 def test_mg_capi_pagerank_many_calls_reuse_channels(tmp_path):
     """Round 5 (advisor finding): 80 cugraph_pagerank calls on one communicator -- more than its 64 signal channels; the plans return theirs."""
     res = run_ranks("pagerank", 2, tmp_path, 10, 6, 0.0, "-", 80)

@@ -41,6 +41,20 @@ def test_reference_c_test_passes(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_reference_mg_pagerank_c_test_passes_on_the_2d_layout(ranks):
+    """Round 6: the reference's mg_pagerank_test.c, unchanged, with the library's multi-GPU PageRank on the reference's own 2-D layout
+    (CUGRAPH_AMD_MG_LAYOUT=2d: 1x2 and 2x2 ranks; its personalized cases take the 1-D partition, the plain ones the R x C blocks)."""
+    exe = BIN / "mg_pagerank_test"
+    if not exe.is_file():
+        pytest.skip(f"{exe} missing: built only where the reference tree is available (tests/c_api/build_ref_tests.sh)")
+    env = dict(os.environ, LD_LIBRARY_PATH=str(ROOT / "cugraph_amd" / "lib") + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""),
+               CUGRAPH_AMD_TEST_RANKS=str(ranks), HSA_ENABLE_IPC_MODE_LEGACY="0", CUGRAPH_AMD_MG_LAYOUT="2d")
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "FAILED" not in out.stdout and "passed" in out.stdout, out.stdout[-4000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ranks", [2, 3])
 @pytest.mark.parametrize("name", MG_NAMES)
 def test_reference_mg_c_test_passes(name, ranks):
