@@ -1601,23 +1601,6 @@ void mgc_to_device(handle_t const& h, dvec<T>& dev, std::vector<T> const& host)
   if (host.size()) HIP_TRY(hipMemcpyAsync(dev.data(), host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, h.stream));
   h.sync();
 }
-// the exchange in two chunks: per receiving peer, how many entries of its list name a row below `cut` (below[r]), and how many of those
-// do NOT sit in the first below[r] positions of the list (violations: the lists are ascending, so there should be none)
-__global__ void k_mgc_count_below(int32_t const* send_index, int64_t const* first /*[P + 1]*/, int32_t cut, unsigned long long* below /*[P]*/)
-{
-  int const r = blockIdx.y;
-  int64_t const k0 = first[r], n = first[r + 1] - k0;
-  unsigned long long mine = 0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) mine += send_index[k0 + i] < cut ? 1ull : 0ull;
-  if (mine) atomicAdd(&below[r], mine);
-}
-__global__ void k_mgc_check_prefix(int32_t const* send_index, int64_t const* first /*[P + 1]*/, int32_t cut, unsigned long long const* below /*[P]*/, unsigned long long* violations)
-{
-  int const r = blockIdx.y;
-  int64_t const k0 = first[r], n = first[r + 1] - k0, nb = (int64_t)below[r];
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    if ((send_index[k0 + i] < cut) != (i < nb)) atomicAdd(violations, 1ull);
-}
 // one rank: row r's value goes straight to where the rank's own window wants it
 __global__ void k_self_columns(int32_t const* rows, int64_t n, int64_t first_col, int32_t* xcol)
 {
@@ -1666,26 +1649,10 @@ struct pagerank_mgc_plan : pagerank_plan_base {
   uint64_t pushes{0}, folds{0};  // push #n fills buffer (n - 1) & 1 everywhere; fold #n waits for it
   size_t iterations{0};
   double last_diff{0};
-  // The exchange in two chunks ("a coarser form of the same overlap"; replaces the reference's overlap of communication
-  // and compute across num_concurrent_loops streams, prims/detail/per_v_transform_reduce_e.cuh:1845-1906).  Rows are in descending global
-  // in-degree order, a peer's send list is ascending in the row, a segment of the window is that list: so "hot" is a PREFIX everywhere.
-  //   main stream:  wait A -> phase 1 over the source tiles part A filled -> wait B + fold -> phase 1 over the rest
-  //                 -> phase 2 over the hot destination tiles [evA] -> phase 2 over the rest + scalars [evB]
-  //   side stream:  [evA] push A (the x of the hot rows) + signal A      [evB] push B + the scalars + signal B
-  // A push kernel's duration IS the wire time between GPUs, so it must not sit on the stream the compute is on; part A travels while the cold
-  // destination tiles are reduced, part B while the receiver already gathers from part A.  Same kernels, same partial slots, same fold order:
-  // the results are those of the one-chunk exchange bit for bit (test_mg_capi_pagerank_two_chunk_exchange_is_bit_identical).
-  bool ovl{false};
-  int ovl_IA{0}, ovl_blocks{0};          // phase-2 blocks [0, ovl_IA) = the hot destination tiles; all blocks (tiles + tiled_const_rows blocks)
-  hipStream_t side{nullptr};
-  hipEvent_t evA{nullptr}, evB{nullptr};
-  int channelA{0};
-  uint64_t seqA_base{0};
-  dvec<int64_t> d_rangeA, d_rangeB;      // [3][P]: begin, end (positions in send_index), destination offset in the peer's window
-  int64_t biggestA{0}, biggestB{0}, biggest_all{0};
-  dvec<int32_t> chunksA, chunksB, no_static;
-  int n_chunksA{0}, n_chunksB{0};
-  dvec<uint32_t> cursors;                // [2] chunk cursors of the two phase-1 launches
+  int64_t biggest_all{0};  // the longest per-peer send list
+  // (The exchange in two chunks on a side stream -- hot rows pushed behind phase 2 of the hot destination tiles, phase 1 of the receiver split by source
+  // tile -- was built in round 5, bit-identical, and cost more on one GPU (+4.5 %: two launches per phase over a third of a rank's share cannot fill the
+  // chip) than the 0.07 ms of wire it could hide on eight; removed in round 6, numbers in profiles/r5r_*, r5s_*)
 
   pagerank_mgc_plan(handle_t const& h_, graph_t& g_, double alpha_) : h(h_), g(g_), c(*g_.mg->comm), alpha((WT)alpha_), P(g_.mg->comm->size), me(g_.mg->comm->rank) {}
 
@@ -1693,15 +1660,10 @@ struct pagerank_mgc_plan : pagerank_plan_base {
   {  // collective, like the constructor: every rank frees its plans in the same order
     try {
       (void)hipStreamSynchronize(h.stream);
-      if (side) (void)hipStreamSynchronize(side);
       for (int b = 1; b >= 0; --b) { if (swin[b]) c.window_free(swin[b]); if (xwin[b]) c.window_free(xwin[b]); }
-      if (channelA >= 2) c.channel_free(channelA);
       if (channel >= 2) c.channel_free(channel);  // (64 channels per communicator: a loop of personalized PageRanks used to run out after ~60 calls)
     } catch (...) {
     }
-    if (evA) (void)hipEventDestroy(evA);
-    if (evB) (void)hipEventDestroy(evB);
-    if (side) (void)hipStreamDestroy(side);
   }
 
   // where iteration results go: next = the buffer the NEXT push fills
@@ -1880,122 +1842,15 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     HIP_TRY(hipMemcpyAsync(d_first.data(), part->send_first.data(), (size_t)(P + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h.stream));
     HIP_TRY(hipMemcpyAsync(d_dst_off.data(), part->dst_off.data(), (size_t)P * sizeof(int64_t), hipMemcpyHostToDevice, h.stream));
     h.sync();
-    setup_overlap();
+    for (int r = 0; r < P; ++r) biggest_all = std::max(biggest_all, part->send_first[r + 1] - part->send_first[r]);
     c.host_barrier();
     // iteration-0 state: x = pr / out_w of every owned row, this rank's (0, dangling mass, max |x|); first push
     tiled_epilogue<WT> const e0 = epi();
     int const n = tiled_prologue<WT>(h, *tc, (WT const*)pr.data(), outw, e0.x_next, n_rows, tpartials.data(), direct ? (int32_t const*)xcol_self.data() : (int32_t const*)nullptr);
     tiled_finish<WT>(h, e0, n, (double)s0.base);
-    if (ovl) push_hot();
     push();
     h.sync();
-    if (side) HIP_TRY(hipStreamSynchronize(side));
     c.check("multi-GPU PageRank: first exchange");
-  }
-
-  // Collective (every rank takes the same decision): splits the exchange and both phases into a hot and a cold part.
-  void setup_overlap()
-  {
-    for (int r = 0; r < P; ++r) biggest_all = std::max(biggest_all, part->send_first[r + 1] - part->send_first[r]);
-    char const* const env = getenv("CUGRAPH_AMD_MG_OVERLAP");  // per cent of the destination tiles that count as hot (30 = the split DESIGN.md section 5 works through); 0 / unset = one-chunk exchange
-    int64_t pct = direct ? 0 : (env ? atoi(env) : 0);  // default: one chunk (measured, ranks on one GPU: the two launches per phase cost more than there is wire to hide)
-    if (pct < 0 || pct >= 100) pct = 0;
-    std::vector<int64_t> all((size_t)P);
-    c.host_allgather(&pct, sizeof(pct), all.data());
-    for (auto x : all) pct = std::min(pct, x);
-    if (pct == 0) return;
-    int const n_tiles = crows.nI_act > 0 ? crows.nI_act : tc->nI;
-    int const n_const = crows.nI_act > 0 ? (int)((crows.n_cols + TP2_CONST_COLS - 1) / TP2_CONST_COLS) : 0;
-    ovl_blocks = n_tiles + n_const;
-    ovl_IA     = n_tiles >= 2 ? (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles - 1, ((int64_t)n_tiles * pct + 50) / 100)) : 0;
-    int32_t cut = 0;  // rows below it are hot: the first row of destination tile ovl_IA
-    if (ovl_IA > 0) {
-      uint32_t r0 = 0;
-      h.read_back(&r0, tc->tile_row0.data() + ovl_IA, 1);
-      cut = (int32_t)r0;
-    }
-    // this rank's send lists: the entries that name a hot row must be a prefix of every list
-    dvec<unsigned long long> d_below((size_t)P + 1);
-    HIP_TRY(hipMemsetAsync(d_below.data(), 0, ((size_t)P + 1) * sizeof(unsigned long long), h.stream));
-    if (biggest_all > 0) {
-      dim3 const grid((unsigned)std::max(1, std::min(grid_for(biggest_all, 256, 1024), 1024)), (unsigned)P);
-      hipLaunchKernelGGL(k_mgc_count_below, grid, dim3(256), 0, h.stream, (int32_t const*)part->send_index.data(), (int64_t const*)d_first.data(), cut, d_below.data());
-      hipLaunchKernelGGL(k_mgc_check_prefix, grid, dim3(256), 0, h.stream, (int32_t const*)part->send_index.data(), (int64_t const*)d_first.data(), cut,
-                         (unsigned long long const*)d_below.data(), d_below.data() + P);
-    }
-    std::vector<unsigned long long> below((size_t)P + 1);
-    h.read_back(below.data(), d_below.data(), (size_t)P + 1);
-    // what every sender counts for every receiver (and whether anybody's lists are not in hot-first order: then nobody splits)
-    std::vector<int64_t> mine((size_t)P + 1), M((size_t)(P + 1) * P);
-    for (int r = 0; r <= P; ++r) mine[r] = (int64_t)below[r];
-    c.host_allgather(mine.data(), (size_t)(P + 1) * sizeof(int64_t), M.data());
-    for (int s2 = 0; s2 < P; ++s2)
-      if (M[(size_t)s2 * (P + 1) + P] != 0) return;
-    // source tiles whose columns all arrive with part A: segment s of this rank's window is sender s's list for this rank
-    int const T = tc->T;
-    std::vector<char> hot((size_t)std::max(tc->nJ, 1), 1);
-    for (int J = 0; J < tc->nJ; ++J) {
-      int64_t const lo = (int64_t)J * T, hi = lo + T;
-      for (int s2 = 0; s2 < P; ++s2) {
-        int64_t const a = std::max(lo, part->seg_start[s2]), b = std::min(hi, part->seg_start[s2 + 1]);
-        if (a < b && b > part->seg_start[s2] + M[(size_t)s2 * (P + 1) + me]) hot[J] = 0;
-      }
-    }
-    std::vector<int32_t> cb = mgc_to_host(h, (int32_t const*)tc->chunk_begin.data(), (size_t)tc->n_chunks * 4), ca, cbb;
-    for (int k = 0; k < tc->n_chunks; ++k) {
-      std::vector<int32_t>& dst = hot[cb[(size_t)4 * k + 3]] ? ca : cbb;
-      dst.insert(dst.end(), cb.begin() + (size_t)4 * k, cb.begin() + (size_t)4 * k + 4);
-    }
-    // Each of the two launches ends on its own: the plan's list closes with small chunks of the coldest tiles so that the workgroups finish
-    // together (spmv_tiled.hpp: TP_TAIL_FRAC), and all of those land in part B.  The last quarter of each list's work items is therefore
-    // handed out in pieces of four items (a chunk is a range of items of one source tile: any cut is a valid chunk).
-    auto smooth_tail = [](std::vector<int32_t>& list) {
-      int64_t items = 0, seen = 0;
-      for (size_t k = 0; k + 3 < list.size(); k += 4) items += list[k + 2] - list[k + 1];
-      std::vector<int32_t> out;
-      for (size_t k = 0; k + 3 < list.size(); k += 4) {
-        int32_t const first = list[k + 1], end = list[k + 2], tile = list[k + 3];
-        for (int32_t i = first; i < end;) {
-          int32_t const piece = seen + (i - first) >= items - items / 4 ? 4 : end - i;
-          int32_t const e2    = std::min(end, i + piece);
-          out.insert(out.end(), {0, i, e2, tile});
-          i = e2;
-        }
-        seen += end - first;
-      }
-      list.swap(out);
-    };
-    if (!getenv("CUGRAPH_AMD_MG_OVERLAP_PLAIN_TAIL")) { smooth_tail(ca); smooth_tail(cbb); }
-    n_chunksA = (int)(ca.size() / 4);
-    n_chunksB = (int)(cbb.size() / 4);
-    if (ca.empty()) ca.assign(4, 0);
-    if (cbb.empty()) cbb.assign(4, 0);
-    mgc_to_device(h, chunksA, ca);
-    mgc_to_device(h, chunksB, cbb);
-    std::vector<int32_t> zeros((size_t)2 * std::max(tc->n_wg, 1), 0);
-    mgc_to_device(h, no_static, zeros);
-    cursors.resize_discard(2);
-    HIP_TRY(hipMemsetAsync(cursors.data(), 0, 2 * sizeof(uint32_t), h.stream));
-    std::vector<int64_t> ra((size_t)3 * P), rb((size_t)3 * P);
-    for (int r = 0; r < P; ++r) {
-      int64_t const f = part->send_first[r], l = part->send_first[r + 1], na = (int64_t)below[r];
-      ra[r] = f;      ra[P + r] = f + na; ra[2 * P + r] = part->dst_off[r];
-      rb[r] = f + na; rb[P + r] = l;      rb[2 * P + r] = part->dst_off[r] + na;
-      biggestA = std::max(biggestA, na);
-      biggestB = std::max(biggestB, l - f - na);
-    }
-    mgc_to_device(h, d_rangeA, ra);
-    mgc_to_device(h, d_rangeB, rb);
-    HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&evA, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&evB, hipEventDisableTiming));
-    channelA  = c.channel_alloc();
-    seqA_base = c.seq[channelA];
-    h.sync();
-    ovl = true;
-    if (getenv("CUGRAPH_AMD_MG_OVERLAP_DEBUG"))
-      fprintf(stderr, "[mg pagerank rank %d] two-chunk exchange: hot destination tiles %d of %d (+%d const blocks), rows below %d; send A %lld of %lld entries; phase-1 chunks A %d / B %d\n", me,
-              ovl_IA, n_tiles, n_const, (int)cut, (long long)std::accumulate(below.begin(), below.begin() + P, 0ull), (long long)part->n_send, n_chunksA, n_chunksB);
   }
 
   void push_part(hipStream_t s, int b, int64_t const* begin, int64_t const* end, int64_t const* dst, int64_t biggest)
@@ -2005,44 +1860,15 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     hipLaunchKernelGGL(k_mgc_push<WT>, grid, dim3(256), 0, s, (WT const*)x_own.data(), (int32_t const*)part->send_index.data(), begin, end, (WT* const*)d_peer_x[b].data(), dst);
   }
 
-  // two-chunk exchange: the x of the hot rows, on the side stream behind what the main stream has issued so far (phase 2 over the hot destination tiles)
-  void push_hot()
-  {
-    int const b = (int)(pushes & 1);
-    HIP_TRY(hipEventRecord(evA, h.stream));
-    HIP_TRY(hipStreamWaitEvent(side, evA, 0));
-    push_part(side, b, d_rangeA.data(), d_rangeA.data() + P, d_rangeA.data() + 2 * P, biggestA);
-    (void)c.signal(side, channelA);
-  }
-
-  // the whole x -- or, two-chunk exchange, the rest of it on the side stream -- then the scalars and the push's signal
+  // the whole x, then the scalars and the push's signal
   void push()
   {
-    int const b    = (int)(pushes & 1);
-    hipStream_t s  = h.stream;
-    if (ovl) {
-      HIP_TRY(hipEventRecord(evB, h.stream));
-      HIP_TRY(hipStreamWaitEvent(side, evB, 0));
-      s = side;
-      push_part(s, b, d_rangeB.data(), d_rangeB.data() + P, d_rangeB.data() + 2 * P, biggestB);
-    } else {
-      push_part(s, b, d_first.data(), d_first.data() + 1, d_dst_off.data(), biggest_all);
-    }
+    int const b         = (int)(pushes & 1);
+    hipStream_t const s = h.stream;
+    push_part(s, b, d_first.data(), d_first.data() + 1, d_dst_off.data(), biggest_all);
     uint64_t const k = ++c.seq[channel];
     hipLaunchKernelGGL(k_mgc_scalars_signal, 1, 64, 0, s, (double const*)totals.data(), (double* const*)d_peer_s[b].data(), me, P, (uint64_t* const*)c.d_peer_flags, channel, k);
     ++pushes;
-  }
-
-  // two-chunk exchange: as soon as part A of the latest push of every rank is here, phase 1 over the source tiles it filled (before the fold:
-  // phase 1 needs no scalar of the iteration)
-  void phase1_hot()
-  {
-    uint64_t const n = folds < pushes ? folds + 1 : folds;  // the push this iteration gathers from (already folded when a previous step() ended on a fold)
-    int const b      = (int)((n - 1) & 1);
-    HIP_TRY(hipMemsetAsync(cursors.data(), 0, 2 * sizeof(uint32_t), h.stream));
-    c.wait(h.stream, channelA, seqA_base + n);
-    tiled_chunks const ch{chunksA.data(), n_chunksA, cursors.data(), no_static.data()};
-    tiled_phase1<WT>(h, *tc, (WT const*)xwin[b]->local, alpha, partial.data(), counters.data(), tiled_x_map<WT>{}, nullptr, &ch);
   }
 
   // waits for the latest push of every rank and folds the P scalar triples into the constants of the next iteration
@@ -2070,17 +1896,8 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     tiled_epilogue<WT> e = epi();
     e.need_diff          = need_diff;
     e.write_pr           = need_diff || last_of_call;
-    if (ovl) {  // (phase 1 over the hot source tiles went out before the fold: step())
-      tiled_chunks const ch{chunksB.data(), n_chunksB, cursors.data() + 1, no_static.data()};
-      tiled_phase1<WT>(h, *tc, (WT const*)xwin[b]->local, alpha, partial.data(), counters.data(), tiled_x_map<WT>{}, nullptr, &ch);
-      tiled_range const ra{0, ovl_IA}, rb{ovl_IA, ovl_blocks - ovl_IA};
-      tiled_phase2<WT>(h, *tc, (WT const*)partial.data(), e, counters.data(), &ra);
-      push_hot();
-      tiled_phase2<WT>(h, *tc, (WT const*)partial.data(), e, counters.data(), &rb);
-    } else {
-      tiled_phase1<WT>(h, *tc, (WT const*)xwin[b]->local, alpha, partial.data(), counters.data(), tiled_x_map<WT>{}, nullptr);
-      tiled_phase2<WT>(h, *tc, (WT const*)partial.data(), e, counters.data());
-    }
+    tiled_phase1<WT>(h, *tc, (WT const*)xwin[b]->local, alpha, partial.data(), counters.data(), tiled_x_map<WT>{}, nullptr);
+    tiled_phase2<WT>(h, *tc, (WT const*)partial.data(), e, counters.data());
     tiled_finish<WT>(h, e, tiled_fold_count(*tc, e));  // this rank's triple (with the analytic share of the rows left out)
     push();
   }
@@ -2092,7 +1909,6 @@ struct pagerank_mgc_plan : pagerank_plan_base {
     size_t it = 0;
     bool conv = false;
     while (it < max_iterations) {
-      if (ovl) phase1_hot();  // (an iteration that turns out not to run -- converged -- has then gathered from the hot tiles for nothing: once per call)
       fold(track);
       if (track && iterations > 0 && last_diff < epsilon) { conv = true; break; }  // pagerank_impl.cuh:320-326, on the GLOBAL L1 change
       iterate(track, it + 1 == max_iterations);

@@ -246,14 +246,14 @@ __global__ void k_wave_records(tiled_wave_t const* waves, uint32_t const* call, 
 
 __global__ void k_assign_slots(uint64_t const* keys, uint32_t const* vals, int64_t n, int64_t n_runs, uint32_t const* shift,
                                uint32_t const* run_dst, uint32_t const* tile_row0, int nI, uint32_t* rpos, tiled_wave_t* waves,
-                               uint16_t* dstl16, uint32_t const* slot_of = nullptr)
+                               uint16_t* dstl16)
 {
   int64_t s      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; s < n; s += stride) {
     uint32_t I    = (uint32_t)keys[s];
     uint32_t idx  = vals[s];
-    uint32_t slot = slot_of ? slot_of[s] : (uint32_t)s + shift[I];  // modulo 2^32
+    uint32_t slot = (uint32_t)s + shift[I];  // modulo 2^32
     if ((int64_t)idx < n_runs) {
       rpos[idx + 1] = slot;
       dstl16[slot] = (uint16_t)(run_dst[idx] - tile_row0[I]);
@@ -265,68 +265,8 @@ __global__ void k_assign_slots(uint64_t const* keys, uint32_t const* vals, int64
   }
 }
 
-// ---- slot blocks aligned to whole cache lines (CUGRAPH_AMD_TILED_BLOCK_ALIGN = slots): the runs of ONE source tile that fall into ONE
-// destination tile are a BLOCK of consecutive slots, written by the one workgroup that streams that piece of the source tile; two blocks
-// that share a 128-byte line are written at different times by different workgroups, i.e. twice as a partial line -- and scattered pieces that
-// start off a line boundary reach a third to a half of the write rate of aligned ones (tools/ubench/scatter_store_bench.hip:
-// 64 floats per piece 4.25 TB/s aligned, 1.74 TB/s 12 bytes off).  With the option every block starts on a multiple of A slots and is padded
-// to a multiple of A (the padding is never written -- it stays zero -- and phase 2 adds those zeros to row 0).
-// source tile of every run (runs are numbered by (source tile, destination): tile J owns the run ordinals [tile_run0[J], tile_run0[J + 1]))
-__global__ void k_run_tile(uint32_t const* tile_run0, int nJ, int64_t n_runs, uint32_t* run_J)
-{
-  int64_t q      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; q < n_runs; q += stride) {
-    int lo = 0, hi = nJ;  // tile_run0[lo] <= q < tile_run0[hi]
-    while (hi - lo > 1) {
-      int const mid = (lo + hi) >> 1;
-      if (tile_run0[mid] <= (uint32_t)q) lo = mid; else hi = mid;
-    }
-    run_J[q] = (uint32_t)lo;
-  }
-}
-// element s of the (destination tile)-sorted list starts a block: first of its region, or another source tile than its predecessor, or the
-// first wavefront-head slot of the region (the heads sit behind the region's runs: ids >= n_runs)
-__global__ void k_aligned_block_flags(uint64_t const* keys, uint32_t const* vals, int64_t n, int64_t n_runs, uint32_t const* run_J, uint32_t* flag)
-{
-  int64_t s      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; s < n; s += stride) {
-    bool f = s == 0 || keys[s] != keys[s - 1];
-    if (!f) {
-      uint32_t const a = vals[s - 1], b = vals[s];
-      bool const ha = (int64_t)a >= n_runs, hb = (int64_t)b >= n_runs;
-      f = ha != hb || (!ha && run_J[a] != run_J[b]);
-    }
-    flag[s] = f ? 1u : 0u;
-  }
-}
-__global__ void k_aligned_block_starts(uint32_t const* flag, uint32_t const* bid, int64_t n, uint32_t* bstart)
-{
-  int64_t s      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; s < n; s += stride)
-    if (flag[s]) bstart[bid[s]] = (uint32_t)s;
-}
-__global__ void k_aligned_block_lengths(uint32_t const* bstart, int64_t nb, int64_t n, uint32_t align, uint32_t* padded)
-{
-  int64_t b      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; b < nb; b += stride) {
-    uint32_t const len = (b + 1 < nb ? bstart[b + 1] : (uint32_t)n) - bstart[b];
-    padded[b] = (len + align - 1) / align * align;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) padded[nb] = 0;
-}
-__global__ void k_aligned_slots(uint32_t const* flag, uint32_t const* bid, uint32_t const* bstart, uint32_t const* pad_off, int64_t n, uint32_t* slot_of)
-{
-  int64_t s      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; s < n; s += stride) {
-    uint32_t const b = flag[s] ? bid[s] : bid[s] - 1u;  // bid = exclusive scan of the flags: an element that starts a block has its own id there
-    slot_of[s] = pad_off[b] + ((uint32_t)s - bstart[b]);
-  }
-}
+// (Slot blocks aligned to whole cache lines -- every (destination tile, source tile) block of the partial buffer padded to 16 / 32 / 64 slots -- were built in
+// round 5: identical bits, phase 1 +4 %, phase 2 +23 ... +144 % for the padding; removed in round 6, numbers in profiles/r5e_block_align_s26.txt.)
 
 // 8 tile-local destinations (< 4096 each) -> 3 dwords; slot groups of 8 never straddle a region (regions are multiples of 8 slots)
 __global__ void k_pack_dstl12(uint16_t const* d16, int64_t n_groups, uint32_t* out)
@@ -737,54 +677,9 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     radix_sort_u64_u32(h, keys.data(), vals.data(), keys_tmp.data(), vals_tmp.data(), n_el, 0, bits_for_u((uint64_t)t.nI));
     std::vector<uint32_t> first = key_starts(h, keys.data(), n_el, (int64_t)t.nI + 1);  // regions 0..nI (nI = dummy)
     std::vector<uint32_t> shift(t.nI + 1);
-    char const* env_align = getenv("CUGRAPH_AMD_TILED_BLOCK_ALIGN");
-    uint32_t const align  = env_align ? (uint32_t)std::max(0, atoi(env_align)) / 8u * 8u : (uint32_t)kTiledBlockAlign;
-    dvec<uint32_t> slot_of;
-    if (align >= 8 && t.n_runs > 0) {  // every (destination tile, source tile) block on its own cache lines (see k_run_tile)
-      std::vector<uint32_t> tile_run0((size_t)nJ + 1);
-      {
-        dvec<uint32_t> d_pos, d_r0((size_t)nJ + 1);
-        to_device(h, d_pos, tile_off);  // (tile_off[J] = first tiled edge position of tile J; ord[] = run ordinal at an edge position)
-        hipLaunchKernelGGL(k_gather_u32, grid_for((int64_t)nJ + 1, kBlock), kBlock, 0, h.stream, (uint32_t const*)ord.data(), (uint32_t const*)d_pos.data(), (int64_t)nJ + 1, d_r0.data());
-        dvec<uint32_t> run_J((size_t)t.n_runs), flag((size_t)n_el + 1), bid((size_t)n_el + 1);
-        hipLaunchKernelGGL(k_run_tile, grid_for(t.n_runs, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)d_r0.data(), nJ, t.n_runs, run_J.data());
-        hipLaunchKernelGGL(k_aligned_block_flags, grid_for(n_el, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), n_el, t.n_runs,
-                           (uint32_t const*)run_J.data(), flag.data());
-        HIP_TRY(hipMemsetAsync(flag.data() + n_el, 0, sizeof(uint32_t), h.stream));
-        exclusive_scan_u32(h, flag.data(), bid.data(), n_el + 1);
-        uint32_t nb = 0;
-        h.read_back(&nb, bid.data() + n_el, 1);
-        dvec<uint32_t> bstart((size_t)nb + 1), padded((size_t)nb + 1), pad_off((size_t)nb + 1);
-        hipLaunchKernelGGL(k_aligned_block_starts, grid_for(n_el, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)flag.data(), (uint32_t const*)bid.data(), n_el, bstart.data());
-        hipLaunchKernelGGL(k_aligned_block_lengths, grid_for((int64_t)nb, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)bstart.data(), (int64_t)nb, n_el, align, padded.data());
-        exclusive_scan_u32(h, padded.data(), pad_off.data(), (int64_t)nb + 1);
-        uint32_t total = 0;
-        h.read_back(&total, pad_off.data() + nb, 1);
-        CGA_EXPECTS((uint64_t)total + 64 < ((uint64_t)1 << 32) / vsize, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: the padded partial buffer exceeds the 32-bit byte-offset addressing of phase 1");
-        slot_of.resize_discard((size_t)n_el);
-        hipLaunchKernelGGL(k_aligned_slots, grid_for(n_el, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)flag.data(), (uint32_t const*)bid.data(), (uint32_t const*)bstart.data(),
-                           (uint32_t const*)pad_off.data(), n_el, slot_of.data());
-        // region I starts at the slot of its first element (an empty region at the next one's; the dummy region nI holds the unused head slots)
-        dvec<uint32_t> d_first, d_roff((size_t)t.nI + 2);
-        std::vector<uint32_t> fidx(first.begin(), first.end());
-        for (auto& x : fidx) x = std::min<uint32_t>(x, (uint32_t)n_el);  // (n_el = "one past the last element")
-        fidx.push_back((uint32_t)n_el);
-        // slot_of has n_el entries: append the total so that index n_el reads it
-        dvec<uint32_t> slot_ext((size_t)n_el + 1);
-        HIP_TRY(hipMemcpyAsync(slot_ext.data(), slot_of.data(), (size_t)n_el * sizeof(uint32_t), hipMemcpyDeviceToDevice, h.stream));
-        HIP_TRY(hipMemcpyAsync(slot_ext.data() + n_el, &total, sizeof(uint32_t), hipMemcpyHostToDevice, h.stream));
-        to_device(h, d_first, fidx);
-        hipLaunchKernelGGL(k_gather_u32, grid_for((int64_t)t.nI + 2, kBlock), kBlock, 0, h.stream, (uint32_t const*)slot_ext.data(), (uint32_t const*)d_first.data(), (int64_t)t.nI + 2, d_roff.data());
-        std::vector<uint32_t> roff = to_host(h, d_roff.data(), (size_t)t.nI + 2);
-        for (int I = 0; I <= t.nI + 1; ++I) region_off[I] = roff[I];
-        region_off[0] = 0;
-      }
-      for (int I = 0; I <= t.nI; ++I) shift[I] = 0;  // unused: slots come from slot_of
-    } else {
     for (int I = 0; I <= t.nI; ++I) {
       region_off[I + 1] = region_off[I] + ((first[I + 1] - first[I] + 7u) & ~7u);
       shift[I]          = region_off[I] - first[I];
-    }
     }
     t.n_slots = region_off[t.nI + 1];
     size_t const spad = (size_t)t.n_slots + 64;
@@ -801,7 +696,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     to_device(h, d_shift, shift);
     hipLaunchKernelGGL(k_assign_slots, grid_for(n_el, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)vals.data(), n_el,
                        t.n_runs, (uint32_t const*)d_shift.data(), (uint32_t const*)run_dst.data(), (uint32_t const*)t.tile_row0.data(), t.nI, rpos.data(),
-                       waves.data(), t.dstl16.data(), slot_of.size() ? (uint32_t const*)slot_of.data() : (uint32_t const*)nullptr);
+                       waves.data(), t.dstl16.data());
     h.sync();
     keys = dvec<uint64_t>(); keys_tmp = dvec<uint64_t>(); vals = dvec<uint32_t>(); vals_tmp = dvec<uint32_t>();
     // ---- slot blocks: inside one (destination tile, source tile) block the slots follow the run order, so phase 1 needs
@@ -1008,46 +903,19 @@ __device__ __forceinline__ void st32(void* base, uint32_t byte_off, T v)
 // (which merges states conservatively at joins: it put vmcnt(1) in front of the first use of an item's edge data and
 // vmcnt(0) between the partial stores of the long-run path in the previous, un-rotated loop -- measured: the partial
 // stores cost 0.36 of phase 1's 1.04 ms at RMAT-26) finds nothing pending at the loop header and adds no wait of its own
-// in the steady state.  CGA_P1_ASM=1 issues the same operations through inline asm (invisible to that pass; then a
-// register written by vm_ld* is valid only after vm_wait + vm_fence on it) -- kept for experiments, NOT the default:
-// the compiler is free to copy a register whose asm load is still in flight.
-#ifndef CGA_P1_ASM
-#define CGA_P1_ASM 0
-#endif
+// in the steady state.  (An inline-asm form of the same operations, invisible to that pass, was built in round 2 and rejected: the compiler is free to
+// copy a register whose asm load is still in flight.)
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-#if CGA_P1_ASM
-__device__ __forceinline__ void vm_ld128(u32x4_t& d, void const* base, uint32_t off) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(off), "s"(base)); }
-__device__ __forceinline__ void vm_ld128_o16(u32x4_t& d, void const* base, uint32_t off) { asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(d) : "v"(off), "s"(base)); }
-__device__ __forceinline__ void vm_ld16u(uint32_t& d, void const* base, uint32_t off) { asm volatile("global_load_ushort %0, %1, %2" : "=v"(d) : "v"(off), "s"(base)); }
-__device__ __forceinline__ void vm_ld32(uint32_t& d, void const* base, uint32_t off) { asm volatile("global_load_dword %0, %1, %2" : "=v"(d) : "v"(off), "s"(base)); }
-__device__ __forceinline__ void vm_st(void* base, uint32_t off, float v) { asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory"); }
-__device__ __forceinline__ void vm_st(void* base, uint32_t off, double v) { asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory"); }
-__device__ __forceinline__ void vm_wait0() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
-__device__ __forceinline__ void vm_fence(uint32_t& r) { asm volatile("" : "+v"(r)); }
-__device__ __forceinline__ void vm_fence(u32x4_t& r) { asm volatile("" : "+v"(r)); }
-#else
-#ifdef CGA_P1_NT_LOAD  // experiment: the edge stream is read once per iteration
-__device__ __forceinline__ void vm_ld128(u32x4_t& d, void const* base, uint32_t off) { d = __builtin_nontemporal_load(reinterpret_cast<u32x4_t const*>(static_cast<char const*>(base) + off)); }
-__device__ __forceinline__ void vm_ld128_o16(u32x4_t& d, void const* base, uint32_t off) { d = __builtin_nontemporal_load(reinterpret_cast<u32x4_t const*>(static_cast<char const*>(base) + off + 16)); }
-#else
 __device__ __forceinline__ void vm_ld128(u32x4_t& d, void const* base, uint32_t off) { d = *reinterpret_cast<u32x4_t const*>(static_cast<char const*>(base) + off); }
 __device__ __forceinline__ void vm_ld128_o16(u32x4_t& d, void const* base, uint32_t off) { d = *reinterpret_cast<u32x4_t const*>(static_cast<char const*>(base) + off + 16); }
-#endif
 __device__ __forceinline__ void vm_ld16u(uint32_t& d, void const* base, uint32_t off) { d = *reinterpret_cast<uint16_t const*>(static_cast<char const*>(base) + off); }
 __device__ __forceinline__ void vm_ld32(uint32_t& d, void const* base, uint32_t off) { d = *reinterpret_cast<uint32_t const*>(static_cast<char const*>(base) + off); }
 template <typename V>
 __device__ __forceinline__ void vm_st(void* base, uint32_t off, V v)
 {
-#ifdef CGA_P1_NT_STORE  // experiment: the partials are not read again by this kernel
-  __builtin_nontemporal_store(v, reinterpret_cast<V*>(static_cast<char*>(base) + off));
-#else
   *reinterpret_cast<V*>(static_cast<char*>(base) + off) = v;
-#endif
 }
 __device__ __forceinline__ void vm_wait0() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0); lgkmcnt / expcnt untouched
-__device__ __forceinline__ void vm_fence(uint32_t&) {}
-__device__ __forceinline__ void vm_fence(u32x4_t&) {}
-#endif
 
 // LDS access by ABSOLUTE byte address (address space 3): `ds_read_b32 v, vaddr` with nothing added.  Through a generic pointer
 // (`xs + offset`) the compiler adds the symbol's address first -- a link-time constant that happens to be 0: the dynamic LDS of these kernels
@@ -1103,16 +971,10 @@ __device__ __forceinline__ void p1_load(p1_args<WT> const& a, int item, int wave
   uint16_t const* const wbase = a.src16 + r.es;
   vm_ld128(r.id[0], wbase, (uint32_t)(2 * TP_EPL) * (uint32_t)lane);
   vm_ld128_o16(r.id[1], wbase, (uint32_t)(2 * TP_EPL) * (uint32_t)lane);
-#ifndef CGA_P1_OLD_ADDR
   (void)e;
   vm_ld16u(r.fl, a.bits + (r.es >> 3), (uint32_t)(TP_EPL / 8) * (uint32_t)lane);  // (TP_EPL consecutive edges per lane = TP_EPL / 8 bytes of the bitmap)
   vm_ld32(r.rec, a.wrec + ((size_t)item * TP_WAVES + (size_t)wave) * TP_REC_DWORDS, 4u * (uint32_t)min(lane, TP_REC_DWORDS - 1));
-#else
-  vm_ld16u(r.fl, a.bits, e >> 3);
-  vm_ld32(r.rec, a.wrec, ((uint32_t)item * TP_WAVES + (uint32_t)wave) * (uint32_t)(TP_REC_DWORDS * 4) + 4u * (uint32_t)min(lane, TP_REC_DWORDS - 1));
-#endif
 }
-__device__ __forceinline__ void p1_fence(p1_regs& r) { vm_fence(r.id[0]); vm_fence(r.id[1]); vm_fence(r.fl); vm_fence(r.rec); }
 
 // Run ordinal n within the wavefront's range: n = 0 is the run that was already open at `es` (its partial goes to the
 // head slot), n >= 1 is run (rank - 1 + n), whose slot is (rank - 1 + n) + delta1[blk + #block starts among the first n runs
@@ -1135,9 +997,6 @@ __device__ __forceinline__ void p1_counts(int lane, p1_regs const& rg, p1_runs& 
   uint32_t const c_inc = wave_inclusive_sum_u32(nf);
   q.ex_c               = c_inc - nf;
   q.c_all              = (uint32_t)__builtin_amdgcn_readlane((int)c_inc, 63);
-#ifdef CGA_ABL_NOOVERFLOW  // timing experiment: drop the run starts of the lanes that would overflow the staging area (WRONG results)
-  if (q.c_all > (uint32_t)TP_STAGE) { q.f = q.ex_c + nf <= (uint32_t)TP_STAGE ? q.f : 0u; q.c_all = (uint32_t)TP_STAGE; }
-#endif
 }
 
 // The slot of run ordinal n >= 1 is (rank - 1 + n) + delta1[blk + B(n)], B(n) = number of block starts among the record bits
@@ -1151,19 +1010,8 @@ __device__ __forceinline__ void p1_issue_slots(p1_args<WT> const& a, int lane, p
 #pragma unroll
   for (int k = 0; k < TP_NDREG; ++k) {
     q.dreg[k] = 0;
-#ifndef CGA_ABL_NODELTA
-#ifndef CGA_P1_OLD_ADDR
     if (k == 0 || q.c_all > (uint32_t)(64 * k)) vm_ld32(q.dreg[k], a.delta1 + q.blk, 4u * ((uint32_t)(64 * k) + (uint32_t)lane));  // (block starts <= run starts)
-#else
-    if (k == 0 || q.c_all > (uint32_t)(64 * k)) vm_ld32(q.dreg[k], a.delta1, 4u * (q.blk + (uint32_t)(64 * k) + (uint32_t)lane));  // (block starts <= run starts)
-#endif
-#endif
   }
-}
-__device__ __forceinline__ void p1_fence_slots(p1_runs& q)
-{
-#pragma unroll
-  for (int k = 0; k < TP_NDREG; ++k) vm_fence(q.dreg[k]);
 }
 // delta of run ordinal n = 64 * j + lane (j wave-uniform); `base` = B(64 j) on entry, B(64 (j + 1)) on exit (scalar popcounts)
 template <typename WT>
@@ -1183,7 +1031,6 @@ __device__ __forceinline__ uint32_t p1_delta_of_group(p1_args<WT> const& a, p1_r
     uint32_t direct;
     vm_ld32(direct, a.delta1, 4u * (q.blk + b));
     vm_wait0();
-    vm_fence(direct);
     d = b >= (uint32_t)(64 * TP_NDREG) ? direct : d;
   }
   return d;
@@ -1229,15 +1076,7 @@ __device__ __forceinline__ void p1_writeout(p1_args<WT> const& a, WT const* stag
       uint32_t const n = (uint32_t)lane + 64u * (uint32_t)jj;
       uint32_t slot    = d + (rm1 + 64u * (uint32_t)jj) + (uint32_t)lane;
       if (jj == 0) slot = lane == 0 ? q.head_slot : slot;
-#ifndef CGA_ABL_NOSTORE
-#if defined(CGA_ABL_STORE_LOCAL)  // timing experiments (WRONG results): every partial store lands in one 16 MiB window (issued and acknowledged, nothing reaches HBM) ...
-      if (n >= n_lo && n < n_hi) vm_st(a.part, (slot & 0x3FFFFFu) * (uint32_t)sizeof(WT), stage[n - n_lo]);
-#elif defined(CGA_ABL_STORE_ADDR_ONLY)  // ... or the slot and the value are computed and the store is not issued
-      if (n >= n_lo && n < n_hi) { WT const val = stage[n - n_lo]; asm volatile("" : : "v"(slot), "v"(val)); }
-#else
       if (n >= n_lo && n < n_hi) vm_st(a.part, slot * (uint32_t)sizeof(WT), stage[n - n_lo]);
-#endif
-#endif
     }
   }
   __builtin_amdgcn_wave_barrier();  // the staging area is reused by the next item
@@ -1258,15 +1097,7 @@ __device__ __forceinline__ WT p1_compute(p1_args<WT> const& a, WT const* xs, WT*
     constexpr int k  = decltype(kc)::value;
     uint32_t const w = k % 8 < 2 ? rg.id[k / 8].x : k % 8 < 4 ? rg.id[k / 8].y : k % 8 < 6 ? rg.id[k / 8].z : rg.id[k / 8].w;
     constexpr int sh = sizeof(WT) == 4 ? 2 : 3;
-#ifdef CGA_ABL_NOGATHER
-    r[k] = (WT)__uint_as_float(0x3f800000u | (idx_offset<(k & 1), sh>(w) >> 2));
-#else
-#ifdef CGA_P1_GENERIC_LDS
-    r[k] = *reinterpret_cast<WT const*>(reinterpret_cast<unsigned char const*>(xs) + idx_offset<(k & 1), sh>(w));
-#else
     r[k] = lds_ld<WT>(idx_offset<(k & 1), sh>(w));  // (the tile sits at LDS address 0)
-#endif
-#endif
   });
   if constexpr (WEIGHTED) {
 #pragma unroll
@@ -1306,7 +1137,6 @@ __device__ __forceinline__ WT p1_compute(p1_args<WT> const& a, WT const* xs, WT*
     uint32_t const half = (uint32_t)__builtin_amdgcn_readlane((int)c, 31);
     p1_stage<WT>(stage, q, r, carry_in, 0u, lane < 32);
     vm_wait0();  // the delta entries of this item were requested just before this compute (rare path: a full stall)
-    p1_fence_slots(q);
     p1_writeout<WT>(a, stage, lane, rg.rec, q, 0u, half);
     p1_stage<WT>(stage, q, r, carry_in, half, lane >= 32);
     pend.base_c = half;
@@ -1403,11 +1233,7 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
     pend.base_c = 0; pend.count = 0;
     tail = WT(0);
     busy = q.es < q.ee;  // wave-uniform; an empty share (tail of a tile) has nothing to compute or store
-#ifdef CGA_ABL_LOADONLY
-    if (busy) tail = (WT)__uint_as_float((rg.id[0].x ^ rg.id[0].y ^ rg.id[0].z ^ rg.id[0].w ^ rg.id[1].x ^ rg.id[1].y ^ rg.id[1].z ^ rg.id[1].w ^ rg.fl ^ rg.rec) & 0x3fffffffu);
-#else
     if (busy) tail = p1_compute<WT, WEIGHTED>(a, xs, stage, lane, rg, q, pend);
-#endif
   };
 
   // Software pipeline around the ONE memory counter of gfx9 (vmcnt counts loads AND stores and retires in order).  Steady
@@ -1420,15 +1246,12 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
   if (I.item >= 0) {
     p1_load<WT>(a, I.item, wave, lane, rA);
     vm_wait0();
-    p1_fence(rA);
     p1_counts(lane, rA, qA);
     p1_issue_slots<WT>(a, lane, rA, qA);
     advance(Jt);
     p1_load<WT>(a, max(Jt.item, 0), wave, lane, rB);  // unconditional (a dummy re-read of item 0 when there is no next item)
     compute_item(rA, qA);
     vm_wait0();
-    p1_fence(rB);
-    p1_fence_slots(qA);
   }
   auto body = [&](p1_regs& cur, p1_runs& qc, p1_regs& nxt, p1_runs& qn) {
     bool const have_next = Jt.item >= 0;
@@ -1439,15 +1262,7 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
         asm volatile("" : "+v"(wl));  // (the kernel sits AT its 128-register budget: keep the lane-derived LDS addresses of the write-out from
         p1_writeout<WT>(a, stage, wl, cur.rec, qc, pend.base_c, pend.base_c + pend.count);  // being hoisted out of the item loop and spilled)
       }
-#ifndef CGA_ABL_NOSTORE
-#if defined(CGA_ABL_STORE_LOCAL)
-      if (lane == 63) vm_st(a.part, (qc.slot_tail & 0x3FFFFFu) * (uint32_t)sizeof(WT), tail);
-#elif defined(CGA_ABL_STORE_ADDR_ONLY)
-      if (lane == 63) asm volatile("" : : "v"(qc.slot_tail), "v"(tail));
-#else
       if (lane == 63) vm_st(a.part, qc.slot_tail * (uint32_t)sizeof(WT), tail);  // slot_tail = head slot when no run starts in the range
-#endif
-#endif
     }
     if (have_next) p1_issue_slots<WT>(a, lane, nxt, qn);
     p1_iter K = Jt;
@@ -1467,8 +1282,6 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
     // every path through an iteration ends here (no early exit: a loop exit that bypasses the wait would reach the loop
     // header's join with operations in flight, and the compiler would then guard every later use with its own vmcnt(0))
     vm_wait0();
-    p1_fence(cur);
-    p1_fence_slots(qn);
   };
   while (I.item >= 0) {  // (the second call is a no-op apart from a dummy load when the first one consumed the last item)
     body(rA, qA, rB, qB);
@@ -1494,7 +1307,6 @@ struct p2_args {
   tiled_epilogue<WT> e;
   uint32_t* counters;
   double const* tile_wmax{nullptr};  // tiled_csc_t::tile_wmax (fp32: the fixed-point scale of the tile)
-  int I0{0};       // first block of this launch (tiled_range: a launch over a part of the destination tiles)
 };
 
 // fp32 partials are accumulated as signed 64-bit fixed point (value * 2^k of the tile, rounded to nearest: tiled_to_fixed in spmv_tiled.hpp):
@@ -1512,7 +1324,7 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
   ACC* acc = reinterpret_cast<ACC*>(smem2);  // [TP2_ROWS]
   __shared__ double red[3 * (TP2_BLOCK / 64)];
   int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int const I = (int)blockIdx.x + a.I0;  // destination tile, or (I >= nI_act) block of tiled_const_rows
+  int const I = (int)blockIdx.x;  // destination tile, or (I >= nI_act) block of tiled_const_rows
   if (a.e.cr.nI_act > 0 && I >= a.e.cr.nI_act) {  // tiled_const_rows: x of the live columns whose rows have no in-edge
     int const cblock = I - a.e.cr.nI_act;
     WT const b       = a.e.scal->base;
@@ -1669,7 +1481,7 @@ fin_args<WT> make_fin(tiled_epilogue<WT> const& e, int n)
 
 template <typename WT>
 void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha, WT* part, uint32_t* counters, tiled_x_map<WT> const& map,
-                  tiled_epilogue<WT> const* pending, tiled_chunks const* chunks)
+                  tiled_epilogue<WT> const* pending)
 {
   if (t.n_items == 0) {
     if (pending) tiled_finish<WT>(h, *pending, tiled_fold_count(t, *pending));
@@ -1691,11 +1503,6 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
   a.part      = part;
   a.alpha     = alpha;
   a.pmask = map.pmask; a.plog = map.plog; a.chunk = map.chunk; a.ncols = map.ncols;
-  if (chunks) {  // a launch over a subset of the plan's chunks (tiled_chunks): everything drawn dynamically from the caller's cursor
-    CGA_EXPECTS(pending == nullptr && chunks->cursor != nullptr && chunks->no_static != nullptr, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: phase-1 chunk subset");
-    if (chunks->n_chunks == 0) return;
-    a.chunk_begin = chunks->chunk_begin; a.n_chunks = chunks->n_chunks; a.n_static_chunks = 0; a.wg_static = chunks->no_static; a.counter = chunks->cursor;
-  }
   if (pending) a.fin = make_fin<WT>(*pending, tiled_fold_count(t, *pending));
   size_t const lds = std::max<size_t>(((size_t)t.T + (size_t)TP_WAVES * TP_STAGE) * sizeof(WT) + 64, 3 * TP_BLOCK * sizeof(double));
   bool const w     = a.weights != nullptr;
@@ -1704,9 +1511,9 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
   auto launch = [&](auto kernel, int slot) {
     if (!attr_done[slot]) { ensure_max_lds(kernel, (int)h.lds_per_block); attr_done[slot] = true; }
     timed_launch tl(h, "pagerank_spmv");
-    hipLaunchKernelGGL(kernel, chunks ? std::max(1, std::min(t.n_wg, chunks->n_chunks)) : t.n_wg, TP_BLOCK, lds, h.stream, a);
+    hipLaunchKernelGGL(kernel, t.n_wg, TP_BLOCK, lds, h.stream, a);
   };
-  if (dbg_calls > 0 && !w && sizeof(WT) == 4 && !chunks) {  // instrumented variant: per-workgroup wall time / tile loads to stderr
+  if (dbg_calls > 0 && !w && sizeof(WT) == 4) {  // instrumented variant: per-workgroup wall time / tile loads to stderr
     --dbg_calls;
     size_t const n = (size_t)t.n_wg * 2;
     dvec<unsigned long long> dbg(n);
@@ -1726,7 +1533,7 @@ void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha
 }
 
 template <typename WT>
-void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters, tiled_range const* range)
+void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters)
 {
   p2_args<WT> a;
   a.part       = part;
@@ -1743,12 +1550,6 @@ void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled
   int grid = t.nI;
   int const n_const = e.cr.nI_act > 0 ? (int)((e.cr.n_cols + TP2_CONST_COLS - 1) / TP2_CONST_COLS) : 0;
   if (e.cr.nI_act > 0) grid = e.cr.nI_act + n_const;
-  if (range) {  // a part of the blocks (destination tiles first, then the tiled_const_rows blocks): [first, first + count)
-    CGA_EXPECTS(range->first >= 0 && range->count >= 0 && range->first + range->count <= grid, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: phase-2 block range");
-    if (range->count == 0) return;
-    a.I0 = range->first;
-    grid = range->count;
-  }
   auto launch = [&](auto kernel) {
     static bool attr_done = false;  // (one flag per instantiation of this lambda = per kernel)
     if (!attr_done && lds > 48 * 1024) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_done = true; }
@@ -1783,8 +1584,8 @@ void tiled_scalars_from_ranks(handle_t const& h, tiled_epilogue<WT> const& e, vo
 }
 
 #define CGA_INSTANTIATE_TILED(WT)                                                                                                          \
-  template void tiled_phase1<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT, WT*, uint32_t*, tiled_x_map<WT> const&, tiled_epilogue<WT> const*, tiled_chunks const*); \
-  template void tiled_phase2<WT>(handle_t const&, tiled_csc_t const&, WT const*, tiled_epilogue<WT> const&, uint32_t*, tiled_range const*);                                  \
+  template void tiled_phase1<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT, WT*, uint32_t*, tiled_x_map<WT> const&, tiled_epilogue<WT> const*); \
+  template void tiled_phase2<WT>(handle_t const&, tiled_csc_t const&, WT const*, tiled_epilogue<WT> const&, uint32_t*);                                  \
   template void tiled_finish<WT>(handle_t const&, tiled_epilogue<WT> const&, int, double, hipStream_t);                                                           \
   template int tiled_prologue<WT>(handle_t const&, tiled_csc_t const&, WT const*, WT const*, WT*, int64_t, double*, int32_t const*);          \
   template void tiled_scalars_from_ranks<WT>(handle_t const&, tiled_epilogue<WT> const&, void const*, size_t, size_t, int);

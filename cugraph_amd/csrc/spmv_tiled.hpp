@@ -87,8 +87,6 @@ constexpr int TP_CHUNK_BIG = 32;             // chunk length for the first part 
 constexpr int TP2_BLOCK = CGA_TP2_BLOCK;     // phase-2 workgroup
 constexpr int TP2_ROWS  = CGA_TP2_ROWS;      // max destination rows per phase-2 tile (64-bit LDS accumulators: 32 KiB at 4096)
 constexpr int TP2_CONST_COLS = TP2_BLOCK * 8;  // columns per tiled_const_rows block of phase 2
-constexpr int kTiledBlockAlign = 0;          // slots every (destination tile, source tile) block of the partial buffer is aligned and padded to (0: packed;
-                                             // CUGRAPH_AMD_TILED_BLOCK_ALIGN overrides; multiples of 8)
 
 struct tiled_wave_t {  // build-time description of one wavefront's share of a work item
   uint32_t es, ee;     // padded edge positions [es, ee); es = item * TP_ITEM + wave * TP_WLEN
@@ -180,30 +178,16 @@ struct tiled_epilogue {
   tiled_const_rows<WT> cr;    // nI_act == 0: off
 };
 
-// Launches over a PART of the work (multi-GPU PageRank, DESIGN.md section 5: the x exchange in two chunks).  Phase 1's schedule is data -- a list
-// of chunks drawn through a cursor -- so a launch over any subset of the plan's chunks is the same kernel with another list; its partial sums
-// land in the slots they always land in.  Phase 2's workgroup = destination tile, so a launch over a block range is the same kernel with an
-// offset.  The results are those of the undivided launches, bit for bit.
-struct tiled_chunks {
-  int32_t const* chunk_begin{nullptr};  // [n_chunks][4] rows of tiled_csc_t::chunk_begin, any subset in any order
-  int n_chunks{0};
-  uint32_t* cursor{nullptr};            // 0 on entry (the caller rewinds it)
-  int32_t const* no_static{nullptr};    // [2 * n_wg] zeros: no workgroup owns a private chunk
-};
-struct tiled_range {
-  int first{0}, count{0};  // phase-2 blocks: destination tiles [0, nI or nI_act), then the tiled_const_rows blocks
-};
-
 // phase 1: part[slot of run] = sum over the run's edges of alpha * x[src] (* w).  counters[0] = chunk cursor (0 on entry;
 // phase 2 rewinds it).  `pending` != nullptr: the scalars of the
 // previous phase 2 have not been folded yet -- workgroup 0 does it first (saves a launch per iteration).
 template <typename WT>
 void tiled_phase1(handle_t const& h, tiled_csc_t const& t, WT const* x, WT alpha, WT* part, uint32_t* counters, tiled_x_map<WT> const& map,
-                  tiled_epilogue<WT> const* pending, tiled_chunks const* chunks = nullptr);
+                  tiled_epilogue<WT> const* pending);
 
 // phase 2 + fused PageRank epilogue; leaves per-tile scalar partials in e.partials (fold them with the next phase 1 or tiled_finish)
 template <typename WT>
-void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters, tiled_range const* range = nullptr);
+void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled_epilogue<WT> const& e, uint32_t* counters);
 
 // folds e.partials[0 .. n_partials) in a fixed order into e.scal (or e.totals).  init_prev >= 0: this is the fold of the
 // iteration-0 state (tiled_prologue visited every row); scal->base_prev becomes init_prev, the rows' initial value

@@ -1117,8 +1117,7 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   // depth_limit is compared after incrementing (bfs_impl.cuh:867-868)
   uint64_t const limit = depth_limit > (size_t)INT32_MAX ? (uint64_t)INT32_MAX : (uint64_t)depth_limit;
   bool const bu_profile = getenv("CUGRAPH_AMD_BFS_PROFILE") != nullptr;
-  // edges per deferred work unit of a NARROW frontier (CUGRAPH_AMD_BFS_NARROW_SEG: 64 ... 4096, power of two not required)
-  int32_t const narrow_seg = getenv("CUGRAPH_AMD_BFS_NARROW_SEG") ? std::max(64, std::min(4096, atoi(getenv("CUGRAPH_AMD_BFS_NARROW_SEG")))) : BIG_SEG_NARROW;
+  int32_t const narrow_seg = BIG_SEG_NARROW;  // edges per deferred work unit of a NARROW frontier (bigq is sized for segments of >= 128 edges: big_queue_entries)
   char const* env_bug = getenv("CUGRAPH_AMD_BU_GRID");  // workgroups per CU of the bottom-up kernel (experiments)
   int const bu_grid = (int)std::max<int64_t>(1, std::min<int64_t>(((nv + 63) / 64 + TV_WAVES * BU_GROUPS - 1) / (TV_WAVES * BU_GROUPS),
                                                                   (int64_t)h.num_cus * (env_bug ? atoi(env_bug) : 16)));

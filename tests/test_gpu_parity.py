@@ -1620,33 +1620,6 @@ def test_pagerank_phase1_schedules_agree(cg, handle, orc, monkeypatch, chunk, st
     assert abs(float(got.sum()) - 1.0) <= 1e-5
 
 
-@pytest.mark.parametrize("scale,align,tile,weighted", [(14, 16, 256, False), (16, 32, 1024, True), (18, 32, 0, False), (18, 64, 4096, False), (20, 16, 0, True)])
-def test_pagerank_aligned_slot_blocks_give_the_same_bits(cg, handle, orc, monkeypatch, scale, align, tile, weighted):
-    """Round 5: every (destination tile, source tile) block of the partial buffer on its own cache lines (CUGRAPH_AMD_TILED_BLOCK_ALIGN slots,
-    padding never written, phase 2 adds its zeros).  The same partials reach the same rows: identical bits to the packed layout, and the oracle's vector."""
-    import torch
-
-    monkeypatch.setenv("CUGRAPH_AMD_PAGERANK_KERNEL", "tiled")
-    monkeypatch.setenv("CUGRAPH_AMD_TILED_REBUILD", "1")
-    nv = 1 << scale
-    s, d = rmat_graph(orc, scale, seed=5)
-    w = int_weights(s.size, seed=9) if weighted else None
-    prev = handle.set_pagerank_hot_tile(tile if tile else -1)
-    try:
-        g = make_graph(cg, handle, s, d, w, transposed=True, renumber=True, vertices=np.arange(nv))
-        monkeypatch.setenv("CUGRAPH_AMD_TILED_BLOCK_ALIGN", "0")
-        va, a, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 9, False, fail_on_nonconvergence=False)
-        monkeypatch.setenv("CUGRAPH_AMD_TILED_BLOCK_ALIGN", str(align))
-        vb, b, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 9, False, fail_on_nonconvergence=False)
-    finally:
-        handle.set_pagerank_hot_tile(prev)
-    assert torch.equal(va, vb) and torch.equal(a, b)
-    off, idx, ww = orc.coo_to_cs(nv, d, s, None if w is None else w.astype(np.float32))
-    truth, _, _ = orc.pagerank(nv, off, idx, ww, 0.85, 0.0, 9, acc64=True)
-    got = by_vertex(vb, b)[0]
-    assert np.max(np.abs(got - truth)) <= 1e-6 and np.max(np.abs(got - truth) / truth) <= 2e-5
-
-
 def test_pagerank_two_to_the_31_edges(cg, handle):
     """Round 5: RMAT-27 (2^31 directed edges, 134 M vertices) on one GPU through the column-tiled plan -- its edge arrays are addressed from
     64-bit per-wavefront bases, so only edge POSITIONS have to fit 32 bits (the reference needs 64-bit vertex / edge types for such a graph:

@@ -478,42 +478,3 @@ def test_mg_capi_extract_paths(orc, tmp_path, world, wide):
             assert all((a, b) in edges for a, b in zip(row[:n - 1], row[1:n]))
     assert n_unreached > 0  # (RMAT: a third of the ids have no in-edge)
     assert all("not in the graph" in r["bad_destination"] for r in res), [r["bad_destination"] for r in res]
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("world,weighted,eps", [(1, "-", 0.0), (2, "-", 0.0), (3, "w", 0.0), (4, "-", 1e-7)])
-def test_mg_capi_pagerank_two_chunk_exchange_is_bit_identical(orc, tmp_path, world, weighted, eps):
-    """The x exchange of the multi-GPU PageRank in two chunks (CUGRAPH_AMD_MG_OVERLAP=<per cent of hot tiles>): phase 2 over the hot destination tiles, their x
-    pushed on a side stream while the cold tiles are reduced, phase 1 of the receiver over the source tiles the first chunk filled while the
-    second is on the wire.  Same kernels over parts of the same work lists: the vector must equal the one-chunk exchange's
-    (the default) BIT FOR BIT, with every split position (10 / 30 / 70 per cent of the destination tiles), weighted, with the
-    convergence test on (a fold + read-back between the two phase-1 launches), and for one rank pushing to itself.  1024-column source tiles so
-    that a rank's window spans dozens of them; the graph is large enough for several destination tiles per rank."""
-    from test_mg import truth
-
-    scale, iters = 16, 8
-    env0 = {"CUGRAPH_AMD_TEST_HOT_TILE": "1024", "CUGRAPH_AMD_MG_PUSH_SELF": "1"}
-    import re
-
-    got = {}
-    pcts = ("0", "30", "10", "70") if world == 2 else ("0", "30")
-    for pct in pcts:
-        d = tmp_path / f"pct{pct}"
-        d.mkdir()
-        res = run_ranks("pagerank", world, d, scale, iters, eps, weighted, env_extra=dict(env0, CUGRAPH_AMD_MG_OVERLAP=pct, CUGRAPH_AMD_MG_OVERLAP_DEBUG="1"))
-        assert sum(r["rows"] for r in res) == 1 << scale and all(r["repeat_equal"] for r in res)
-        got[pct] = [np.load(d / f"rank{r}.npz") for r in range(world)]
-        split = [re.search(r"hot destination tiles (\d+) of (\d+).*send A (\d+) of (\d+) entries; phase-1 chunks A (\d+) / B (\d+)", o) for o in run_ranks.last_outputs]
-        if pct == "0":
-            assert not any(split)
-        else:  # the split is a real one on every rank: both parts of the tiles, of the send lists and of the phase-1 chunks are non-empty
-            assert all(split), run_ranks.last_outputs[0][-2000:]
-            for m in split:
-                ia, nt, sa, sn, ca, cb = (int(x) for x in m.groups())
-                assert 0 < ia < nt and 0 < sa < sn and cb > 0 and (ca > 0 or pct == "10"), m.group(0)  # (10 %: the hot prefix may be shorter than a source tile)
-    for pct in pcts[1:]:
-        for a, b in zip(got["0"], got[pct]):
-            assert np.array_equal(a["v"], b["v"]) and np.array_equal(a["x"].view(np.uint32), b["x"].view(np.uint32)), pct
-    pr = _assemble(tmp_path / "pct30", world, 1 << scale)
-    t, _, _ = truth(orc, scale, eps, iters, weighted=weighted == "w")
-    assert np.max(np.abs(pr - t)) <= 1e-6
