@@ -682,7 +682,7 @@ struct pagerank_plan : pagerank_plan_base {
       if (!o.tiled || o.tiled->T != T || getenv("CUGRAPH_AMD_TILED_REBUILD")) {  // (the env: parameter sweeps on one graph, tools/plan_sweep.py)
         auto t = std::make_shared<tiled_csc_t>();
         try {
-          bool const compact = getenv("CUGRAPH_AMD_PAGERANK_DENSE_COLUMNS") == nullptr;
+          bool const compact = true;  // sources without out-edges get no column (spmv_tiled.hpp: xcol)
           dvec<uint32_t> live;  // unweighted graph: a vertex has an out-edge <=> its out-degree (= out-weight sum, cached on the graph) is non-zero
           if (compact && !g.has_weights) {
             compute_out_weight_sums();

@@ -564,17 +564,13 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     int const chunk  = env_chunk ? std::max(1, atoi(env_chunk)) : std::max(1, std::min<int>(TP_CHUNK, t.n_items / (max_wg * 4)));  // small graphs: more, shorter chunks
     // the hottest tiles span thousands of items: their first items go out in LONG chunks (a workgroup reloads the 126 KiB
     // tile once per chunk, with nothing else in flight), the rest in `chunk`-item pieces that balance the tail
-    char const* env_big  = getenv("CUGRAPH_AMD_TP_CHUNK_BIG");
-    char const* env_frac = getenv("CUGRAPH_AMD_TP_CHUNK_BIG_FRAC");
-    int const big        = std::max(chunk, env_big ? atoi(env_big) : TP_CHUNK_BIG);
-    double const frac    = env_frac ? atof(env_frac) : 0.55;
+    int const big        = std::max(chunk, TP_CHUNK_BIG);
+    double const frac    = 0.55;
     int64_t big_budget   = t.n_items / (max_wg * 4) >= TP_CHUNK ? (int64_t)(frac * t.n_items) : 0;
     // the items of the coldest tiles (the last `tail_frac` of all items; an item there costs about twice a hot one: ten times the
     // runs and partial stores) go out in short chunks, so the workgroups finish within one short chunk of each other
-    char const* env_tf = getenv("CUGRAPH_AMD_TP_TAIL_FRAC");
-    char const* env_tc = getenv("CUGRAPH_AMD_TP_TAIL_CHUNK");
-    double const tail_frac = env_tf ? atof(env_tf) : TP_TAIL_FRAC;
-    int tail_chunk         = std::max(1, std::min(chunk, env_tc ? atoi(env_tc) : TP_TAIL_CHUNK));
+    double const tail_frac = TP_TAIL_FRAC;
+    int tail_chunk         = std::max(1, std::min(chunk, TP_TAIL_CHUNK));
     int const tail_first   = t.n_items / (max_wg * 4) >= TP_CHUNK ? (int)((1.0 - tail_frac) * t.n_items) : t.n_items;
     // STATIC PREFIX (sticky tiles): every workgroup first walks a private, contiguous range of work items -- equal shares, by
     // estimated cost, of the first `static_frac` of the total cost -- so that it loads a hot source tile ONCE (a 126 KiB tile
@@ -584,18 +580,17 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     // Cost of an item = its edges + TP_RUN_COST x its run starts (a cold item stores ten times the partials of a hot one and
     // takes about twice as long).
     char const* env_sf = getenv("CUGRAPH_AMD_TP_STATIC_FRAC");
-    char const* env_rc = getenv("CUGRAPH_AMD_TP_RUN_COST");
     // Default by the number of work items per workgroup (measured): RMAT-26 (257 items per workgroup):
     // the x-tile reloads are a small share and the dynamic queue balances better -- off (0.85: +8 %, 0.5: neutral); RMAT-24 (64):
     // 0.7 -> phase 1 -17 %; RMAT-22 (16): 0.85-0.95 with 2-item dynamic chunks -> -13 %.
     double const items_per_wg = (double)t.n_items / (double)max_wg;
     double const static_frac  = env_sf ? atof(env_sf) : (items_per_wg >= 160.0 ? 0.0 : items_per_wg >= 24.0 ? 0.7 : 0.9);
-    double const run_cost    = env_rc ? atof(env_rc) : 1.3;
+    double const run_cost    = 1.3;
     std::vector<int32_t> cb;              // [4 * n_chunks]: (unused, first item, end item, source tile); static chunks first, grouped by workgroup
     std::vector<int32_t> wg_static;       // [2 * n_wg]: (first static chunk, end static chunk) of every workgroup
     int static_items = 0;
     bool const use_static = static_frac > 0.0 && ne > 0 && (items_per_wg >= 2.0 || getenv("CUGRAPH_AMD_TP_STATIC_FORCE") != nullptr);
-    if (use_static && !env_tc && !env_chunk && items_per_wg < 24.0) tail_chunk = std::max(1, tail_chunk / 2);  // few items per workgroup: finer dynamic tail
+    if (use_static && !env_chunk && items_per_wg < 24.0) tail_chunk = std::max(1, tail_chunk / 2);  // few items per workgroup: finer dynamic tail
     t.n_wg = use_static ? max_wg : 0;
     if (use_static) {
       dvec<uint32_t> d_item_end, d_item_runs((size_t)t.n_items);
@@ -639,14 +634,6 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
       i = j;
     }
     std::stable_sort(ch.begin(), ch.end(), [](auto const& x, auto const& y) { return x.second > y.second; });
-    if (char const* env_ord = getenv("CUGRAPH_AMD_TP_ORDER")) {  // experiment: "mix" = hot (load-bound) and cold (store-bound) chunks alternate in time
-      if (env_ord[0] == 'm' && ch.size() >= 16) {
-        size_t const n = ch.size() * 4 / 5 / 2 * 2;  // the smallest fifth keeps its place: it evens out the finish
-        std::vector<std::pair<int32_t, int32_t>> mixed;
-        for (size_t k = 0; k < n / 2; ++k) { mixed.push_back(ch[k]); mixed.push_back(ch[n / 2 + k]); }
-        std::copy(mixed.begin(), mixed.end(), ch.begin());
-      }
-    }
     for (auto const& c : ch) { cb.push_back(0); cb.push_back(c.first); cb.push_back(c.first + c.second); cb.push_back(item_tile[c.first]); }
     t.n_chunks = (int)(cb.size() / 4);
     if (cb.empty()) cb.assign(4, 0);
@@ -720,7 +707,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
                        (uint32_t const*)call.data(), (uint32_t const*)rpos.data(), (uint32_t const*)bidx.data(), (uint32_t const*)gbits.data(), n_waves,
                        t.wrec.data());
     h.sync();
-    if (TP2_ROWS <= 4096 && getenv("CUGRAPH_AMD_TILED_DSTL16") == nullptr) {
+    if (TP2_ROWS <= 4096) {
       int64_t const n_groups = (int64_t)(spad + 7) / 8;
       t.dstl12.resize_discard((size_t)n_groups * 3 + 16);
       HIP_TRY(hipMemsetAsync(t.dstl12.data(), 0, ((size_t)n_groups * 3 + 16) * sizeof(uint32_t), h.stream));

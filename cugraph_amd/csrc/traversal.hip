@@ -614,42 +614,8 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand2_big(int32_t const* bi
   f.flush();
 }
 
-// A wide frontier in VERTEX ORDER (round 6): the near queue holds its vertices in the order the relaxations found them, so a wavefront's 64 rows are
-// 64 random places of the CSR (each ~200 bytes at RMAT-24).  Every member carries mark_near[v] == tag, so the same set is rebuilt by a sweep over the
-// marks -- every workgroup owns a contiguous vertex range, counts, reserves its piece with ONE atomic and fills it in order (the scheme of
-// k_bfs_bitmap_to_queue) -- and the expansion reads offsets, distances, labels and adjacency rows of consecutive vertices: streams instead of gathers.
-__global__ void __launch_bounds__(TV_BLOCK) k_sssp_front_in_vertex_order(uint32_t const* mark_near, int64_t nv, uint32_t tag, int32_t* q, uint32_t* cursor)
-{
-  __shared__ uint32_t s_wave[TV_BLOCK / 64];
-  __shared__ uint32_t s_base;
-  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int64_t const per = ((nv + gridDim.x - 1) / gridDim.x + TV_BLOCK - 1) / TV_BLOCK * TV_BLOCK;  // vertices per workgroup, whole rounds
-  int64_t const v0 = (int64_t)blockIdx.x * per, v1 = v0 + per < nv ? v0 + per : nv;
-  uint32_t mine = 0;
-  for (int64_t i = v0 + threadIdx.x; i < v1; i += TV_BLOCK) mine += mark_near[i] == tag ? 1u : 0u;
-  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-  if (lane == 0) s_wave[wave] = mine;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t t = 0;
-    for (int k = 0; k < TV_BLOCK / 64; ++k) t += s_wave[k];
-    s_base = t ? atomicAdd(cursor, t) : 0u;
-  }
-  __syncthreads();
-  uint32_t base = s_base;
-  for (int64_t r0 = v0; r0 < v1; r0 += TV_BLOCK) {
-    int64_t const i = r0 + threadIdx.x;
-    bool const in   = i < v1 && mark_near[i] == tag;
-    uint64_t const m = __ballot(in);
-    __syncthreads();
-    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t before = 0, round_total = 0;
-    for (int k = 0; k < TV_BLOCK / 64; ++k) { before += k < wave ? s_wave[k] : 0u; round_total += s_wave[k]; }
-    if (in) q[base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
-    base += round_total;
-  }
-}
+// (A wide frontier rebuilt in VERTEX order -- a sweep over the marks, so that a wavefront's 64 rows are consecutive -- was measured SLOWER, 11.4 -> 13.1 ms:
+// consecutive vertices have similar degrees, so a wavefront's rows are all of the slow whole-wave kind at once; profiles/r6j_sssp_ab.txt.)
 
 // A round whose frontier holds a large share of ALL edges (RMAT-24: the two rounds after the hubs relax 259 M and 200 M of the graph's 268 M edges):
 // frontier-driven expansion gathers ~200-byte rows at 65-75 G edges/s (0.6 TB/s); the same edges are the whole CSR, so the round STREAMS it instead --
@@ -675,7 +641,21 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_sweep(int32_t const* edge_row
   int64_t const nwaves = (int64_t)gridDim.x * TV_WAVES;
   constexpr int64_t STEP = 64 * S2_U;
   unsigned long long inspected = 0;
-  for (int64_t p0 = gwave * STEP; p0 < ne; p0 += nwaves * STEP) {  // (indices / weights / edge_rows are padded: a step may read past ne, its lanes are not live)
+  // The three streams of step i + 1 are requested while step i is still gathering: they are issued AFTER step i's dependent gathers (marks, then the
+  // per-destination words), so the counted waits for those do not wait for the streams behind them (one in-order memory counter), and the HBM round trip
+  // of the streams is hidden behind the two L2 round trips of the gathers (positions past ne are clamped to the padded tail: loadable, not live).
+  int32_t un[S2_U], vn[S2_U];
+  WT wn[S2_U];
+  auto request = [&](int64_t p0) {
+#pragma unroll
+    for (int k = 0; k < S2_U; ++k) {  // streamed once per round: non-temporal, so that the distance words the probes hit stay in the Infinity Cache
+      int64_t const p = min(p0 + lane + 64 * k, ne);
+      un[k] = __builtin_nontemporal_load(edge_rows + p); vn[k] = __builtin_nontemporal_load(indices + p); wn[k] = __builtin_nontemporal_load(s.weights + p);
+    }
+  };
+  int64_t p0 = gwave * STEP;
+  if (p0 < ne) request(p0);
+  for (; p0 < ne; p0 += nwaves * STEP) {
     int32_t u[S2_U], v[S2_U];
     WT w[S2_U];
     uint32_t mk[S2_U], bw[S2_U];
@@ -683,17 +663,9 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_sweep(int32_t const* edge_row
     uint32_t lab[S2_U];
     bool live[S2_U];
 #pragma unroll
-    for (int k = 0; k < S2_U; ++k) {  // streamed once per round: non-temporal, so that the distance words the probes hit stay in the Infinity Cache
-      int64_t const p = p0 + lane + 64 * k;
-      live[k] = p < ne;
-#ifndef CGA_SWEEP_PLAIN_LOADS
-      u[k] = __builtin_nontemporal_load(edge_rows + p); v[k] = __builtin_nontemporal_load(indices + p); w[k] = __builtin_nontemporal_load(s.weights + p);
-#else
-      u[k] = edge_rows[p]; v[k] = indices[p]; w[k] = s.weights[p];
-#endif
-    }
+    for (int k = 0; k < S2_U; ++k) { live[k] = p0 + lane + 64 * k < ne; u[k] = live[k] ? un[k] : 0; v[k] = live[k] ? vn[k] : 0; w[k] = wn[k]; }
 #pragma unroll
-    for (int k = 0; k < S2_U; ++k) { u[k] = live[k] ? u[k] : 0; v[k] = live[k] ? v[k] : 0; mk[k] = mark_near[u[k]]; }  // (consecutive positions: a few distinct words per load)
+    for (int k = 0; k < S2_U; ++k) mk[k] = mark_near[u[k]];  // (consecutive positions: a few distinct words per load)
 #pragma unroll
     for (int k = 0; k < S2_U; ++k) {
       live[k] = live[k] & (mk[k] == tag);
@@ -706,6 +678,7 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_sweep(int32_t const* edge_row
         else du[k] = s.dist[u[k]];
       }
     }
+    if (p0 + nwaves * STEP < ne) request(p0 + nwaves * STEP);
     uint32_t n_live = 0;
 #pragma unroll
     for (int k = 0; k < S2_U; ++k) {
@@ -723,19 +696,13 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_sweep(int32_t const* edge_row
       ts.n += (uint32_t)__popcll(m);
     }
     inspected += n_live;
-#ifdef CGA_ABL_SWEEP_NODRAIN  // timing experiment (WRONG results): the streamed part alone
-    if (ts.n >= (uint32_t)S2_DRAIN) ts.n = 0;
-#else
     if (prof && ts.n >= (uint32_t)S2_DRAIN) {
       unsigned long long const t0 = wall_clock64();
       ts.drain(S2_DRAIN);
       t_drain += wall_clock64() - t0; ++n_drain;
     } else ts.drain(S2_DRAIN);
-#endif
   }
-#ifndef CGA_ABL_SWEEP_NODRAIN
   ts.drain(1);
-#endif
   if (prof && lane == 0) { prof[3 * gwave] = wall_clock64() - t_begin; prof[3 * gwave + 1] = t_drain; prof[3 * gwave + 2] = n_drain; }
   for (int o = 32; o > 0; o >>= 1) inspected += __shfl_xor(inspected, o);
   if (lane == 0 && inspected) atomicAdd(&cnt_replica(s.cnt)->edges, inspected);
@@ -1118,9 +1085,8 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   uint64_t const limit = depth_limit > (size_t)INT32_MAX ? (uint64_t)INT32_MAX : (uint64_t)depth_limit;
   bool const bu_profile = getenv("CUGRAPH_AMD_BFS_PROFILE") != nullptr;
   int32_t const narrow_seg = BIG_SEG_NARROW;  // edges per deferred work unit of a NARROW frontier (bigq is sized for segments of >= 128 edges: big_queue_entries)
-  char const* env_bug = getenv("CUGRAPH_AMD_BU_GRID");  // workgroups per CU of the bottom-up kernel (experiments)
   int const bu_grid = (int)std::max<int64_t>(1, std::min<int64_t>(((nv + 63) / 64 + TV_WAVES * BU_GROUPS - 1) / (TV_WAVES * BU_GROUPS),
-                                                                  (int64_t)h.num_cus * (env_bug ? atoi(env_bug) : 16)));
+                                                                  (int64_t)h.num_cus * 16));
   while (n_cur > 0) {
     if (in) {
       if (!bottom_up) bottom_up = (double)frontier_out > (double)unvisited_in / alpha && n_cur > 1024;
@@ -1323,9 +1289,8 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   // SUCCEED (a vertex reached from k hubs is lowered ~ln k times when they arrive in any order) -- takes its frontier ordered by tentative
   // distance (256 bands of the window, one 8-bit radix pass): the closest hubs go first, later candidates mostly fail the cheap pre-test.
   // RMAT-24, weights 1..255, 16 roots, same session: 12.19 -> 11.78 ms with predecessors, 11.04 -> 10.74 without (profiles/r5g_sssp_sort.txt);
-  // ordering EVERY wide round costs more (the sorts) than the 5 % of relaxations it saves (r5f_sssp_sort.txt).  CUGRAPH_AMD_SSSP_SORT=0: off.
-  char const* env_sort = getenv("CUGRAPH_AMD_SSSP_SORT");
-  bool const sort_hubs = !(env_sort && std::string(env_sort) == "0");
+  // ordering EVERY wide round costs more (the sorts) than the 5 % of relaxations it saves (r5f_sssp_sort.txt).
+  bool const sort_hubs = true;
   dvec<uint64_t> sk, sk_out;
   dvec<uint32_t> sv, sv_out, sort_hist;
   // the distance filter (sssp_filter): rounds of at least ne / 32 relaxations (a build costs two passes over the distances, ~60 us at RMAT-24)
@@ -1333,13 +1298,10 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   bool const filter_force = env_flt && std::string(env_flt) == "force";  // every round, whatever its size (the parity test)
   bool const filter_on = filter_force || (!(env_flt && std::string(env_flt) == "0") && nv >= 4096);
   uint64_t const filter_min_edges = filter_force ? 0 : std::max<uint64_t>((uint64_t)g.ne / 32, (uint64_t)1 << 20);
-  char const* env_s2 = getenv("CUGRAPH_AMD_SSSP_TWO_STAGE");  // 0: filtered rounds keep the one-stage kernels (A/B)
-  bool const two_stage = !(env_s2 && std::string(env_s2) == "0");
   char const* env_sw = getenv("CUGRAPH_AMD_SSSP_SWEEP");  // share of the graph's edges a frontier must hold for a streamed round (0: never)
   double const sweep_frac = env_sw ? atof(env_sw) : 0.25;
   bool const sweep_on = sweep_frac > 0.0 && g.ne > 0;
-  char const* env_s2g = getenv("CUGRAPH_AMD_SSSP_S2_GRID");
-  int const s2_wg_per_cu = env_s2g ? std::max(1, atoi(env_s2g)) : 4;  // workgroups per CU of the two-stage kernels (their LDS buffers allow ~4 residents)
+  int const s2_wg_per_cu = 4;  // workgroups per CU of the two-stage kernels (their LDS buffers allow 4 residents; 3: 8.8 -> 9.1 ms, profiles/r6p_*)
   dvec<uint32_t> fbits;
   dvec<unsigned long long> fhist;
   dvec<WT> ft;
@@ -1355,10 +1317,6 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
     }
     fn(std::false_type{});
   };
-  char const* env_ord = getenv("CUGRAPH_AMD_SSSP_ORDER");  // 1: wide frontiers rebuilt in vertex order (measured SLOWER, 11.4 -> 13.1 ms: consecutive vertices have
-  bool const order_wide = env_ord && std::string(env_ord) == "1";  // similar degrees, so a wavefront's 64 rows are all of the slow whole-wave kind at once; profiles/r6j_sssp_ab.txt)
-  dvec<int32_t> ordered;
-  dvec<uint32_t> order_cursor;
   auto relax_round = [&](int32_t const* front, int64_t n_front) {
     uint32_t const front_tag = round;  // every member of `front` carries mark_near == the round (or window advance) that appended it
     ++round;
@@ -1378,13 +1336,6 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
       front = reinterpret_cast<int32_t const*>(sv_out.data());
     }
     bool const filtered = filter_on && front_edges >= filter_min_edges;
-    if (order_wide && !hub_round && n_front >= std::max<int64_t>(nv / 64, 4096) && front_edges >= filter_min_edges) {  // a wide frontier: its vertices in vertex order
-      if ((int64_t)ordered.size() < nv) { ordered.resize_discard(n1); order_cursor.resize_discard(1); }
-      HIP_TRY(hipMemsetAsync(order_cursor.data(), 0, 4, h.stream));
-      hipLaunchKernelGGL(k_sssp_front_in_vertex_order, std::min(h.num_cus * 8, (int)((nv + TV_BLOCK - 1) / TV_BLOCK)), TV_BLOCK, 0, h.stream, (uint32_t const*)mark_near.data(), nv,
-                         front_tag, ordered.data(), order_cursor.data());
-      front = ordered.data();
-    }
     if (filtered) {
       WT const band = (WT)(delta / SF_BANDS), inv = (WT)(SF_BANDS / delta);
       with_words([&](auto pkc) {
@@ -1409,7 +1360,7 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
       timed_launch t(h, "sssp_relax");
       with_words([&](auto pkc) {
         constexpr bool PKC = decltype(pkc)::value;
-        if (filtered && two_stage && sweep_on && (double)front_edges >= sweep_frac * (double)g.ne) {  // the frontier's edges are most of the graph: stream the edge list
+        if (filtered && sweep_on && (double)front_edges >= sweep_frac * (double)g.ne) {  // the frontier's edges are most of the graph: stream the edge list
           orientation_t& ow = g.csr;
           if (ow.edge_rows.size() == 0) {
             ow.edge_rows.resize_discard((size_t)g.ne + kEdgePad);
@@ -1432,7 +1383,7 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
             fprintf(stderr, "[sssp sweep] %zu wavefronts: ticks (100 MHz) total min %llu p50 %llu p90 %llu max %llu; inside drains min %llu p50 %llu p90 %llu max %llu; drains per wavefront %.1f\n", n_prof,
                     tot[0], tot[n_prof / 2], tot[n_prof * 9 / 10], tot[n_prof - 1], dr[0], dr[n_prof / 2], dr[n_prof * 9 / 10], dr[n_prof - 1], nd / (double)n_prof);
           }
-        } else if (filtered && two_stage) {  // wide round: survivors of the filter compacted per wavefront, the atomic chain over dense groups (sssp_two_stage)
+        } else if (filtered) {  // wide round: survivors of the filter compacted per wavefront, the atomic chain over dense groups (sssp_two_stage)
           hipLaunchKernelGGL((k_sssp_expand2<WT, PKC>), std::min(expand_grid(h, n_front), h.num_cus * s2_wg_per_cu), TV_BLOCK, 0, h.stream, front, n_front, row_beg, adj, bigq.data(), s, big_deg_for(h, n_front));
           hipLaunchKernelGGL((k_sssp_expand2_big<WT, PKC>), h.num_cus * s2_wg_per_cu, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), row_beg, adj, s);
         } else {

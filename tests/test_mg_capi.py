@@ -158,6 +158,23 @@ def test_mg_capi_pagerank_2d_layout_converges_like_single_gpu(orc, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("what", ["pagerank", "pagerank2d", "bfs", "sssp"])
+def test_mg_capi_on_the_windows_of_a_multi_gpu_node(orc, tmp_path, what):
+    """The exchange paths as they run when the ranks sit on DIFFERENT GPUs: the communicator then allocates its windows fine-grained (system-scope
+    coherent), which ranks sharing one GPU never do by themselves.  CUGRAPH_AMD_COMM_WINDOWS=finegrained forces that memory kind: 3 ranks, every algorithm
+    family, both PageRank layouts, the same oracles."""
+    env = {"CUGRAPH_AMD_COMM_WINDOWS": "finegrained"}
+    if what == "pagerank":
+        _pagerank_case(orc, tmp_path, 3, "w", env=env)
+    elif what == "pagerank2d":
+        _pagerank_case(orc, tmp_path, 4, "-", env=dict(env, CUGRAPH_AMD_MG_LAYOUT="2d"))
+    elif what == "bfs":
+        _bfs_case(orc, tmp_path, 3, "", env=env)
+    else:
+        _sssp_case(orc, tmp_path, 3, "int", env=env)
+
+
+@pytest.mark.gpu
 def test_mg_capi_pagerank_many_calls_reuse_channels(tmp_path):
     """Round 5 (advisor finding): 80 cugraph_pagerank calls on one communicator -- more than its 64 signal channels; the plans return theirs."""
     res = run_ranks("pagerank", 2, tmp_path, 10, 6, 0.0, "-", 80)
