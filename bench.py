@@ -113,11 +113,13 @@ def run_single(args):
     dt = time.perf_counter() - t0
     _, region_ms = h.kernel_timing_get("timed_region")
     # phase breakdown: a SECOND pass of the same K steps, outside the wall clock, with an event pair around every launch
+    # (--no-phase-pass: the counter collection of tools/traffic_collect.py differences runs of K and K' steps and wants exactly that many)
     h.kernel_timing(True)
     h.kernel_timing_reset()
-    plan.step(args.steps)
+    if not args.no_phase_pass:
+        plan.step(args.steps)
     h.sync()
-    launches, kernel_ms = h.kernel_timing_get("pagerank_spmv")
+    launches, kernel_ms = h.kernel_timing_get("pagerank_spmv") if not args.no_phase_pass else (0, 0.0)
     try:  # the tiled default runs two kernels per iteration: phase 1 (edge stream) + phase 2 (partials -> rows + epilogue)
         launches2, kernel2_ms = h.kernel_timing_get("pagerank_reduce")
     except Exception:
@@ -201,6 +203,7 @@ def main():
     ap.add_argument("--cpu-scale", type=int, default=22, help="RMAT scale of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-timing correctness check of the timed result")
+    ap.add_argument("--no-phase-pass", action="store_true", help="skip the second, per-launch-instrumented pass of the K steps (the phase averages are then absent)")
     ap.add_argument("--no-extras", action="store_true", help="skip the bounded BFS / SSSP (RMAT-24) and Louvain (RMAT-22) sub-lines appended at N = 1")
     ap.add_argument("--extra-roots", type=int, default=16)
     ap.add_argument("--layout", choices=["1d", "2d"], default=os.environ.get("CUGRAPH_AMD_MG_LAYOUT", "1d"),
