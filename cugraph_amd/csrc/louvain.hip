@@ -1271,6 +1271,12 @@ clustering_result_t* mg_run_louvain(handle_t const& h, graph_t& g, size_t max_le
   mg_graph_t& mg = *g.mg;
   comm_t& c      = *mg.comm;
   CGA_EXPECTS(handle_comm(h) == mg.comm, CUGRAPH_INVALID_HANDLE, "multi-GPU Louvain: the handle is not on the communicator the graph was created on");
+  {
+    uint64_t scalars[3] = {(uint64_t)max_level, 0, 0};
+    std::memcpy(&scalars[1], &threshold, sizeof(double));
+    std::memcpy(&scalars[2], &resolution, sizeof(double));
+    mg_agree_same(g, scalars, sizeof(scalars), "cugraph_louvain (max_level, threshold, resolution)");
+  }
   int const P = c.size, me = c.rank;
   lv_mg_t M;
   M.c = &c; M.h = &h; M.P = P; M.rank = me; M.channel = 1;

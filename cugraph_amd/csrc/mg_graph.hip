@@ -338,6 +338,37 @@ int64_t mg_host_max(graph_t& g, int64_t mine)
   return m;
 }
 
+void mg_agree(graph_t& g, std::function<void()> const& local_checks, char const* what)
+{
+  comm_t& c = *g.mg->comm;
+  int32_t mine = 0;
+  std::string msg;
+  cugraph_error_code_t code = CUGRAPH_SUCCESS;
+  try {
+    local_checks();
+  } catch (api_error const& e) {
+    mine = 1; code = e.code; msg = e.what();
+  }
+  std::vector<int32_t> all(c.size);
+  c.host_allgather(&mine, sizeof(mine), all.data());
+  if (mine) throw api_error(code, msg);
+  for (int r = 0; r < c.size; ++r)
+    if (all[r]) throw api_error(CUGRAPH_INVALID_INPUT, std::string(what) + ": rank " + std::to_string(r) + " rejected its arguments (a collective call fails on every rank)");
+}
+
+void mg_agree_same(graph_t& g, void const* blob, size_t bytes, char const* what)
+{
+  comm_t& c = *g.mg->comm;
+  CGA_EXPECTS(bytes <= 64, CUGRAPH_UNKNOWN_ERROR, "mg_agree_same: at most 64 bytes");
+  unsigned char mine[64] = {0};
+  std::memcpy(mine, blob, bytes);
+  std::vector<unsigned char> all((size_t)c.size * 64);
+  c.host_allgather(mine, 64, all.data());
+  for (int r = 0; r < c.size; ++r)
+    CGA_EXPECTS(std::memcmp(all.data() + (size_t)r * 64, all.data(), 64) == 0, CUGRAPH_INVALID_INPUT,
+                std::string(what) + ": the ranks pass different scalar arguments (rank " + std::to_string(r) + " differs from rank 0)");
+}
+
 void mg_gather_paths(handle_t const& h, graph_t& g, int32_t const* vertices, int32_t const* dist, int32_t const* pred, int64_t n, dvec<uint32_t>& dist1,
                      dvec<uint32_t>& pred2)
 {

@@ -12,6 +12,8 @@
 // byte counts that decide for 1-D on one xGMI node.
 #pragma once
 
+#include <functional>
+
 #include "common.hpp"
 
 namespace cga {
@@ -106,6 +108,13 @@ void mg_gather_paths(handle_t const& h, graph_t& g, int32_t const* vertices, int
                      dvec<uint32_t>& pred2);
 // max over the ranks of a host value (collective)
 int64_t mg_host_max(graph_t& g, int64_t mine);
+// Collective: the rank-local argument checks of a collective entry point.  Every rank runs `local_checks` (which throws api_error on a bad argument),
+// the verdicts are exchanged, and if ANY rank failed EVERY rank throws -- the failing ranks their own error, the others CUGRAPH_INVALID_INPUT naming the
+// first failing rank -- so that nobody enters the algorithm's first collective alone (a lone rank used to leave its peers in a barrier until the
+// communicator's timeout and poison the session).
+void mg_agree(graph_t& g, std::function<void()> const& local_checks, char const* what);
+// Collective: every rank must pass the same `bytes` (<= 64) of scalar arguments; CUGRAPH_INVALID_INPUT on every rank otherwise
+void mg_agree_same(graph_t& g, void const* blob, size_t bytes, char const* what);
 void mg_has_vertex(handle_t const& h, graph_t const& g, int32_t const* v, int64_t n, uint8_t* out);
 // cugraph_degrees family on a multi-GPU graph (collective): this rank's share of the vertices (all, or those any rank listed) and their degrees
 int64_t mg_degrees(handle_t const& h, graph_t& g, device_array_view_t const* listed, bool want_in, bool want_out, dvec<int32_t>& ids, dvec<int32_t>& in_deg, dvec<int32_t>& out_deg);

@@ -2141,14 +2141,18 @@ pagerank_plan_base* make_plan(cugraph_resource_handle_t const* handle, cugraph_g
 {
   handle_t const& h = H(handle);
   graph_t& g        = GM(graph);
-  // pagerank_impl.cuh:78-88
-  CGA_EXPECTS(alpha >= 0.0 && alpha <= 1.0, CUGRAPH_INVALID_INPUT, "Invalid input argument: alpha should be in [0.0, 1.0].");
+  // pagerank_impl.cuh:78-88 (a multi-GPU graph checks it with the other rank-local arguments below: every rank fails or none does)
+  if (!g.mg) CGA_EXPECTS(alpha >= 0.0 && alpha <= 1.0, CUGRAPH_INVALID_INPUT, "Invalid input argument: alpha should be in [0.0, 1.0].");
   if (g.mg) {  // a graph from cugraph_graph_create_mg on a communicator handle: collective, every rank gets its owned vertices back
     CGA_EXPECTS(handle_comm(h) == g.mg->comm, CUGRAPH_INVALID_HANDLE, "multi-GPU PageRank: the handle is not on the communicator the graph was created on");
-    check_pair_types(g, V(ow_v), V(ow_s), "vertex type of graph and precomputed_vertex_out_weight_vertices must match",
-                     "vertex type of graph and precomputed_vertex_out_weight_sums must match");
-    check_pair_types(g, V(ig_v), V(ig_s), "vertex type of graph and initial_guess_vertices must match", "vertex type of graph and initial_guess_values must match");
-    check_pair_types(g, V(p_v), V(p_s), "vertex type of graph and personalization_vector must match", "vertex type of graph and personalization_vector must match");
+    mg_agree(g, [&] {  // rank-local argument checks: every rank fails or none does
+      CGA_EXPECTS(alpha >= 0.0 && alpha <= 1.0, CUGRAPH_INVALID_INPUT, "Invalid input argument: alpha should be in [0.0, 1.0].");
+      check_pair_types(g, V(ow_v), V(ow_s), "vertex type of graph and precomputed_vertex_out_weight_vertices must match",
+                       "vertex type of graph and precomputed_vertex_out_weight_sums must match");
+      check_pair_types(g, V(ig_v), V(ig_s), "vertex type of graph and initial_guess_vertices must match", "vertex type of graph and initial_guess_values must match");
+      check_pair_types(g, V(p_v), V(p_s), "vertex type of graph and personalization_vector must match", "vertex type of graph and personalization_vector must match");
+    }, "cugraph_pagerank");
+    mg_agree_same(g, &alpha, sizeof(alpha), "cugraph_pagerank (alpha)");
     // INT64 ids of a multi-GPU graph: the vertex columns become compact int32 ids (outer_ids.hip); ids that are no vertices map to -1 and are
     // rejected by create() exactly as unknown int32 ids are; the result's vertex column goes back through outer_replace_ids (pagerank_mgc_plan::result)
     vertex_column_in mc_ow, mc_ig, mc_p;
@@ -2229,6 +2233,13 @@ cugraph_error_code_t run_pagerank(cugraph_resource_handle_t const* handle, cugra
   bool converged = false;
   cugraph_error_code_t rc = guarded(error, [&] {
     CGA_EXPECTS(result != nullptr, CUGRAPH_INVALID_INPUT, "result is NULL");
+    if (graph != nullptr && reinterpret_cast<graph_t*>(graph)->mg) {  // collective call: the scalar arguments are checked and compared on every rank together
+      graph_t& gm = *reinterpret_cast<graph_t*>(graph);
+      mg_agree(gm, [&] { CGA_EXPECTS(epsilon >= 0.0, CUGRAPH_INVALID_INPUT, "Invalid input argument: epsilon should be non-negative."); }, "cugraph_pagerank");
+      uint64_t scalars[2] = {0, (uint64_t)max_iterations};
+      std::memcpy(&scalars[0], &epsilon, sizeof(double));
+      mg_agree_same(gm, scalars, sizeof(scalars), "cugraph_pagerank (epsilon, max_iterations)");
+    }
     CGA_EXPECTS(epsilon >= 0.0, CUGRAPH_INVALID_INPUT, "Invalid input argument: epsilon should be non-negative.");  // pagerank_impl.cuh:88
     std::unique_ptr<pagerank_plan_base> plan(make_plan(handle, graph, ow_v, ow_s, ig_v, ig_s, p_v, p_s, alpha, do_expensive_check));
     size_t done = 0;

@@ -285,9 +285,15 @@ paths_result_t* mg_run_bfs(handle_t& h, graph_t& g, device_array_view_t const* s
 {
   HIP_TRY(hipSetDevice(h.device));
   CGA_EXPECTS(handle_comm(h) == g.mg->comm, CUGRAPH_INVALID_HANDLE, "multi-GPU BFS: the handle is not on the communicator the graph was created on");
-  CGA_EXPECTS(sources == nullptr || sources->type == INT32, CUGRAPH_INVALID_INPUT, "vertex type of graph and sources must match");
-  if (direction_optimizing)  // bfs_impl.cuh:202-204
-    CGA_EXPECTS(g.props.is_symmetric == TRUE, CUGRAPH_INVALID_INPUT, "Invalid input argument: input graph should be symmetric for direction optimizing BFS.");
+  mg_agree(g, [&] {  // rank-local argument checks: every rank fails or none does
+    CGA_EXPECTS(sources == nullptr || sources->type == INT32, CUGRAPH_INVALID_INPUT, "vertex type of graph and sources must match");
+    if (direction_optimizing)  // bfs_impl.cuh:202-204
+      CGA_EXPECTS(g.props.is_symmetric == TRUE, CUGRAPH_INVALID_INPUT, "Invalid input argument: input graph should be symmetric for direction optimizing BFS.");
+  }, "cugraph_bfs");
+  {
+    uint64_t const scalars[3] = {direction_optimizing ? 1ull : 0ull, (uint64_t)depth_limit, with_pred ? 1ull : 0ull};
+    mg_agree_same(g, scalars, sizeof(scalars), "cugraph_bfs (direction_optimizing, depth_limit, compute_predecessors)");
+  }
   comm_t& c = *g.mg->comm;
   mg_traversal_part_t& t = mg_traversal_part(h, g, false);
   mg_traversal_run_t& r  = ensure_run(h, g, t, 0);
@@ -539,7 +545,12 @@ paths_result_t* mg_run_sssp(handle_t& h, graph_t& g, size_t source, double cutof
 {
   HIP_TRY(hipSetDevice(h.device));
   CGA_EXPECTS(handle_comm(h) == g.mg->comm, CUGRAPH_INVALID_HANDLE, "multi-GPU SSSP: the handle is not on the communicator the graph was created on");
-  CGA_EXPECTS(g.has_weights, CUGRAPH_INVALID_INPUT, "cugraph_sssp requires a weighted graph");  // sssp.cpp:72-73,105
+  CGA_EXPECTS(g.has_weights, CUGRAPH_INVALID_INPUT, "cugraph_sssp requires a weighted graph");  // sssp.cpp:72-73,105 (a property of the graph: the same on every rank)
+  {
+    uint64_t scalars[3] = {(uint64_t)source, 0, with_pred ? 1ull : 0ull};
+    std::memcpy(&scalars[1], &cutoff, sizeof(double));
+    mg_agree_same(g, scalars, sizeof(scalars), "cugraph_sssp (source, cutoff, compute_predecessors)");
+  }
   if (g.weight_type == FLOAT64) return mg_run_sssp_f64(h, g, source, cutoff, with_pred);
   comm_t& c = *g.mg->comm;
   mg_traversal_part_t& t = mg_traversal_part(h, g, true);

@@ -126,6 +126,31 @@ def run(what, cg, h, comm, rank, size, outdir, args):
         except Exception as e:  # noqa: BLE001
             out["bad_vertex"] = str(e)
         del g
+    elif what == "agree":
+        # round 6: a bad or different argument on ONE rank of a collective call: every rank fails, at once, and the communicator stays usable
+        import time
+
+        scale = int(args[0])
+        (s, d), first = rmat_slice(scale, rank, size)
+        verts = np.arange(rank, 1 << scale, size, dtype=np.int32)
+        w = np.ones(s.size, np.float32)
+        g = cg.MGGraph(h, cg.GraphProperties(is_multigraph=True), [X(s)], [X(d)], [T(w)], store_transposed=False, vertices_array=[X(verts)])
+        msgs, t0 = {}, time.perf_counter()
+        for name, call in (("alpha", lambda: cg.pagerank(h, g, None, None, None, None, 2.0 if rank == 0 else 0.85, 0.0, 3, False, fail_on_nonconvergence=False)),
+                           ("epsilon", lambda: cg.pagerank(h, g, None, None, None, None, 0.85, -1.0 if rank == size - 1 else 0.0, 3, False, fail_on_nonconvergence=False)),
+                           ("iterations", lambda: cg.pagerank(h, g, None, None, None, None, 0.85, 0.0, 3 + (rank == 0), False, fail_on_nonconvergence=False)),
+                           ("source", lambda: cg.sssp(h, g, xid(int(s[0]) if rank == 0 else int(d[0])), 3.0e38, False, False)),
+                           ("depth", lambda: cg.bfs(h, g, X(np.array([int(s[0])], np.int32) if rank == 0 else np.zeros(0, np.int32)), False, 2 + rank, False, False))):
+            try:
+                call()
+                msgs[name] = "accepted"
+            except Exception as e:  # noqa: BLE001
+                msgs[name] = str(e)
+        out["seconds"] = time.perf_counter() - t0
+        out["messages"] = msgs
+        v, x, _ = cg.pagerank(h, g, None, None, None, None, 0.85, 0.0, 3, False, fail_on_nonconvergence=False)  # the session still works
+        out["rows_after"] = int(v.numel())
+        del g
     elif what in ("bfs", "sssp"):
         scale, n_roots, with_pred = int(args[0]), int(args[1]), args[2] == "p"
         (s, d), first = rmat_slice(scale, rank, size)

@@ -175,6 +175,22 @@ def test_mg_capi_on_the_windows_of_a_multi_gpu_node(orc, tmp_path, what):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_mg_capi_bad_argument_on_one_rank_fails_everywhere(tmp_path, world):
+    """Round 6 (review of round 5, advisor): the rank-local argument checks of the collective entry points exchange their verdicts -- and the scalar
+    arguments are compared -- BEFORE the first collective of the algorithm: alpha out of range on rank 0, a negative epsilon on the last rank, different
+    iteration counts, different SSSP sources, different BFS depth limits: every rank gets an error at once (a lone rank used to leave its peers in a
+    barrier for the communicator's 60 s timeout, which then poisoned the session), and the next valid call on the same communicator works."""
+    res = run_ranks("agree", world, tmp_path, 10, timeout=120)
+    for r in res:
+        assert r["seconds"] < 20.0, r
+        assert all(m != "accepted" for m in r["messages"].values()), r["messages"]
+        assert "alpha" in r["messages"]["alpha"] or "rejected its arguments" in r["messages"]["alpha"]
+        assert "different scalar arguments" in r["messages"]["iterations"] and "different scalar arguments" in r["messages"]["source"]
+    assert sum(r["rows_after"] for r in res) == 1 << 10
+
+
+@pytest.mark.gpu
 def test_mg_capi_pagerank_many_calls_reuse_channels(tmp_path):
     """Round 5 (advisor finding): 80 cugraph_pagerank calls on one communicator -- more than its 64 signal channels; the plans return theirs."""
     res = run_ranks("pagerank", 2, tmp_path, 10, 6, 0.0, "-", 80)
