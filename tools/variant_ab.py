@@ -46,19 +46,20 @@ def main():
     a = cg.PageRankPlan(h, g, 0.85)
     b = cg.PageRankPlan(h, g, 0.85)
     a.step(7)
-    os.environ[name] = value
+    os.environ[name] = value.split(",")[0]
     b.step(7)
     os.environ.pop(name, None)
     _, pa, _ = a.result()
     _, pb, _ = b.result()
     print("bit-identical after 7 iterations:", bool(torch.equal(pa, pb)), flush=True)
     del b
+    values = value.split(",")  # several values: every one of them against the default, on the same plan
     for rep in range(reps):
-        for mode in ("base", name + "=" + value):
+        for mode in ["base"] + [name + "=" + v for v in values]:
             if mode == "base":
                 os.environ.pop(name, None)
             else:
-                os.environ[name] = value
+                os.environ[name] = mode.split("=", 1)[1]
             print("rep %d %-28s ms/iter %.4f phase1 %.4f phase2 %.4f" % ((rep, mode) + timed(h, a, 20)), flush=True)
     os.environ.pop(name, None)
 
