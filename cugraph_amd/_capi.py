@@ -212,6 +212,8 @@ PROTOTYPES = {
     "cugraph_amd_graph_num_vertices": (C.c_size_t, [_P]),
     "cugraph_amd_graph_num_edges": (C.c_size_t, [_P]),
     "cugraph_amd_graph_num_local_edges": (C.c_size_t, [_P]),
+    "cugraph_amd_graph_compress_hypersparse": (C.c_int, [_P, _P, C.c_int, C.c_size_t, _PP]),
+    "cugraph_amd_graph_hypersparse_view": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _PP, _PP, _PP]),
     "cugraph_amd_set_pagerank_hot_tile": (C.c_int, [_P, C.c_int]),
     "cugraph_amd_last_traversal_stats": (None, [_P, C.POINTER(TraversalStats)]),
 }

@@ -270,9 +270,61 @@ struct mg_graph_t;   // mg_graph.hpp
 // destination for CSC (store_transposed = true).  Neighbour lists ascending, multi-edges kept.
 // Rows are processed through a degree-descending schedule: row_order == nullptr means rows are already
 // numbered by descending degree (renumber = TRUE, primary orientation).
+// CSR + DCSR hybrid row storage (DCSC for a transposed orientation): the reference's compress_hypersparse_offsets
+// (cpp/src/structure/detail/structure_utils.cuh:139-195) and the dcs_nzd_vertices / major_hypersparse_first half of
+// edge_partition_device_view_t (cpp/include/cugraph/edge_partition_device_view.cuh:43-58, 820-835).  Rows [0, first) keep one offset each; a row
+// >= first is stored only when it has an edge: nzd[] lists those rows in ascending order and offsets[] has first + n_nzd + 1 entries.
+// Where it pays here: orientations whose ids are NOT degree-sorted and whose rows are mostly empty -- the local block of the 2-D multi-GPU
+// PageRank layout (rows of C vertex partitions that see 1 / C of the sources each; mg_graph.hip) and renumber = FALSE graphs over a sparse id
+// range.  An orientation in this form has NO plain offsets array; consumers walk it through rows_view_t (below) or ask ensure_orientation for
+// the plain form (which re-inflates it).
+struct hypersparse_t {
+  int64_t first{-1};      // -1: the orientation is in plain form
+  int64_t n_nzd{0};
+  dvec<int32_t> nzd;      // [n_nzd] rows >= first with at least one edge, ascending
+  dvec<int32_t> offsets;  // [first + n_nzd + 1] edge positions (unsigned 32-bit words, as orientation_t::offsets)
+  bool active() const { return first >= 0; }
+  int64_t n_stored() const { return first + n_nzd; }
+};
+
+// What a kernel needs to walk the STORED rows of an orientation in either form: stored index k in [0, n_stored) <-> row row_of(k), edges
+// [offsets[k], offsets[k + 1]).  Plain form: nzd == nullptr, k == row.
+struct rows_view_t {
+  int32_t const* offsets{nullptr};
+  int32_t const* nzd{nullptr};
+  int64_t first{0};
+  int64_t n_stored{0};
+  __host__ __device__ bool plain() const { return nzd == nullptr; }
+  __device__ int32_t row_of(int64_t k) const { return (nzd == nullptr || k < first) ? (int32_t)k : nzd[k - first]; }
+  // stored index of the first stored row >= r (n_stored when there is none)
+  __device__ int64_t lower_bound(int64_t r) const
+  {
+    if (nzd == nullptr || r <= first) return r < n_stored ? r : n_stored;
+    int64_t lo = 0, hi = n_stored - first;
+    while (lo < hi) {
+      int64_t const mid = (lo + hi) >> 1;
+      if ((int64_t)nzd[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    return first + lo;
+  }
+  // stored index of row r, or -1 when the row is not stored (it has no edge): major_hypersparse_idx_from_major_nocheck
+  __device__ int64_t find(int64_t r) const
+  {
+    if (nzd == nullptr || r < first) return r < n_stored ? r : -1;
+    int64_t const k = lower_bound(r);
+    return (k < n_stored && (int64_t)nzd[k - first] == r) ? k : -1;
+  }
+  __device__ uint32_t degree_of_row(int64_t r) const
+  {
+    int64_t const k = find(r);
+    return k < 0 ? 0u : (uint32_t)offsets[k + 1] - (uint32_t)offsets[k];
+  }
+};
+
 struct orientation_t {
   bool built{false};
-  dvec<int32_t> offsets;    // V + 1
+  dvec<int32_t> offsets;    // V + 1 (empty while the orientation is in hypersparse form: dcs)
+  hypersparse_t dcs;        // CSR + DCSR hybrid form of the rows, see hypersparse_t
   dvec<int32_t> indices;    // E (minor ids)
   dev_buf weights;          // E * sizeof(weight) or empty
   dev_buf edge_ids;         // E * (4 or 8) bytes or empty: the caller's edge ids in this orientation's edge order (graph_t::edge_id_type)
@@ -445,7 +497,18 @@ bool edgelist_has_parallel_edges(handle_t const& h, edge_list_t const& el, int64
 bool vertex_list_has_duplicates(handle_t const& h, int32_t const* v, int64_t n, int64_t vmin, int64_t vrange);
 
 // graph construction (graph.hip)
-void ensure_orientation(handle_t const& h, graph_t& g, bool transposed);
+// dcs_aware = false: the caller reads orientation_t::offsets directly, so an orientation in hypersparse form is re-inflated first
+void ensure_orientation(handle_t const& h, graph_t& g, bool transposed, bool dcs_aware = false);
+// hypersparse rows (graph.hip): rows >= first that have no edge lose their offset (offsets is released); no-op on an orientation already in that form
+void compress_hypersparse(handle_t const& h, orientation_t& o, int64_t nv, int64_t first);
+void inflate_offsets(handle_t const& h, orientation_t& o, int64_t nv);  // back to the plain form (dcs is released)
+inline rows_view_t rows_view(orientation_t const& o, int64_t nv)
+{
+  rows_view_t v;
+  if (o.dcs.active()) { v.offsets = o.dcs.offsets.data(); v.nzd = o.dcs.nzd.data(); v.first = o.dcs.first; v.n_stored = o.dcs.n_stored(); }
+  else { v.offsets = o.offsets.data(); v.nzd = nullptr; v.first = nv; v.n_stored = nv; }
+  return v;
+}
 // external -> internal ids (in place); absent ids become -1
 void renumber_ext_to_int(handle_t const& h, graph_t const& g, int32_t* ids, int64_t n);
 // internal -> external (in place); negative ids stay as they are

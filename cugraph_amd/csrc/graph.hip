@@ -158,16 +158,52 @@ __global__ void k_schedule_stats(uint32_t const* deg, int32_t const* order, int6
   if (bad) atomicOr(not_sorted, 1u);
 }
 
-// major id of every edge position: rows[e] = v for offsets[v] <= e < offsets[v+1]
-__global__ void k_expand_rows(int32_t const* offsets, int64_t nv, int32_t* rows)
+// major id of every edge position: rows[e] = v for the edges of row v (either row form: the walk is over the STORED rows)
+__global__ void k_expand_rows(rows_view_t rv, int32_t* rows)
 {
   // one wave per row chunk: rows are short on average, long rows are striped across the wave
   int64_t wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   int lane       = threadIdx.x & 63;
-  for (int64_t v = wave; v < nv; v += nwaves) {
-    uint32_t const b = (uint32_t)offsets[v], len = (uint32_t)offsets[v + 1] - b;  // unsigned positions: up to 2^32 - 1 edges
-    for (uint32_t p = lane; p < len; p += 64) rows[b + p] = (int32_t)v;
+  for (int64_t k = wave; k < rv.n_stored; k += nwaves) {
+    uint32_t const b = (uint32_t)rv.offsets[k], len = (uint32_t)rv.offsets[k + 1] - b;  // unsigned positions: up to 2^32 - 1 edges
+    int32_t const v  = rv.row_of(k);
+    for (uint32_t p = lane; p < len; p += 64) rows[b + p] = v;
+  }
+}
+
+// ---- hypersparse rows (hypersparse_t, common.hpp; the reference's compress_hypersparse_offsets, structure_utils.cuh:139-195)
+// keep[i] = 1 when row first + i has an edge (i < nv - first); keep[nv - first] = 0 closes the scan
+__global__ void k_dcs_flags(int32_t const* offsets, int64_t first, int64_t nv, uint32_t* keep)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i <= nv - first; i += stride) keep[i] = (i < nv - first && offsets[first + i + 1] != offsets[first + i]) ? 1u : 0u;
+}
+// rows below `first` copy their offset; a kept row r writes (r, offsets[r]) at its rank; the thread of i == n - first writes the closing offset
+__global__ void k_dcs_compact(int32_t const* offsets, uint32_t const* keep, uint32_t const* rank, int64_t first, int64_t nv, int32_t* nzd, int32_t* out)
+{
+  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i <= nv; i += stride) {
+    if (i < first) { out[i] = offsets[i]; continue; }
+    int64_t const j = i - first;
+    if (i == nv) out[first + rank[j]] = offsets[nv];
+    else if (keep[j]) { nzd[rank[j]] = (int32_t)i; out[first + rank[j]] = offsets[i]; }
+  }
+}
+// plain offsets back from the hybrid: stored row k's range starts at offsets[k]; a row that is not stored is empty and starts where the next stored
+// row starts.  One thread per stored row fills its own entry and the entries of the unstored rows in front of it.
+__global__ void k_dcs_inflate(rows_view_t rv, int64_t nv, int32_t* out)
+{
+  int64_t k      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; k <= rv.n_stored; k += stride) {
+    int64_t const r    = k < rv.n_stored ? (int64_t)rv.row_of(k) : nv;
+    int64_t const prev = k > rv.first ? (int64_t)rv.row_of(k - 1) : rv.first - 1;  // (rows below first are all stored)
+    int32_t const off  = rv.offsets[k];
+    if (k < rv.first) { out[k] = off; continue; }
+    for (int64_t v = prev + 1; v <= r; ++v) out[v] = off;
   }
 }
 
@@ -530,15 +566,51 @@ cugraph_error_code_t create_sg(cugraph_resource_handle_t const* handle, cugraph_
 
 // Builds the missing orientation under the same numbering (the reference re-creates and re-numbers the
 // graph instead, cpp/src/c_api/graph.hpp:84-143).
-void ensure_orientation(handle_t const& h, graph_t& g, bool transposed)
+void compress_hypersparse(handle_t const& h, orientation_t& o, int64_t nv, int64_t first)
+{
+  CGA_EXPECTS(o.built, CUGRAPH_UNKNOWN_ERROR, "compress_hypersparse: the orientation is not built");
+  if (o.dcs.active()) return;
+  first = std::max<int64_t>(0, std::min(first, nv));
+  int64_t const m = nv - first;  // candidate rows
+  dvec<uint32_t> keep((size_t)m + 1), rank((size_t)m + 1);
+  hipLaunchKernelGGL(k_dcs_flags, grid_for(m + 1, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)o.offsets.data(), first, nv, keep.data());
+  exclusive_scan_u32(h, keep.data(), rank.data(), m + 1);
+  uint32_t n_nzd = 0;
+  h.read_back(&n_nzd, rank.data() + m, 1);
+  hypersparse_t d;
+  d.first = first;
+  d.n_nzd = (int64_t)n_nzd;
+  d.nzd.resize_discard((size_t)std::max<int64_t>(d.n_nzd, 1));
+  d.offsets.resize_discard((size_t)(first + d.n_nzd + 1));
+  hipLaunchKernelGGL(k_dcs_compact, grid_for(nv + 1, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)o.offsets.data(), (uint32_t const*)keep.data(),
+                     (uint32_t const*)rank.data(), first, nv, d.nzd.data(), d.offsets.data());
+  h.sync();
+  o.dcs     = std::move(d);
+  o.offsets = dvec<int32_t>();  // the hybrid form replaces the plain one
+}
+
+void inflate_offsets(handle_t const& h, orientation_t& o, int64_t nv)
+{
+  if (!o.dcs.active()) return;
+  o.offsets.resize_discard((size_t)nv + 1);
+  rows_view_t const rv = rows_view(o, nv);
+  hipLaunchKernelGGL(k_dcs_inflate, grid_for(rv.n_stored + 1, kBlock, 4096), kBlock, 0, h.stream, rv, nv, o.offsets.data());
+  h.sync();
+  o.dcs = hypersparse_t{};
+}
+
+void ensure_orientation(handle_t const& h, graph_t& g, bool transposed, bool dcs_aware)
 {
   orientation_t& want = transposed ? g.csc : g.csr;
-  if (want.built) return;
+  if (want.built) {
+    if (!dcs_aware) inflate_offsets(h, want, g.nv);
+    return;
+  }
   orientation_t& have = transposed ? g.csr : g.csc;
   CGA_EXPECTS(have.built, CUGRAPH_UNKNOWN_ERROR, "graph has no storage");
   dvec<int32_t> rows(g.ne > 0 ? g.ne : 1);
   if (g.nv > 0 && g.ne > 0)
-    hipLaunchKernelGGL(k_expand_rows, grid_for(g.nv * 16, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)have.offsets.data(), g.nv, rows.data());
+    hipLaunchKernelGGL(k_expand_rows, grid_for(g.nv * 16, kBlock, 8192), kBlock, 0, h.stream, rows_view(have, g.nv), rows.data());
   size_t wsize = g.has_weights ? dtype_size(g.weight_type) : 0;
   // new major = old minor (indices), new minor = old major (rows)
   edge_props_in props;
@@ -750,8 +822,11 @@ extern "C" cugraph_error_code_t cugraph_graph_create_sg_from_csr(
                 "this build supports INT32 offsets / indices only");
     int64_t nv = (int64_t)off->size - 1;
     rows.resize_discard(idx->size > 0 ? idx->size : 1);
-    if (nv > 0 && idx->size > 0)
-      hipLaunchKernelGGL(k_expand_rows, grid_for(nv * 16, kBlock, 8192), kBlock, 0, h.stream, off->as<int32_t>(), nv, rows.data());
+    if (nv > 0 && idx->size > 0) {
+      rows_view_t rv;  // the caller's CSR: plain rows
+      rv.offsets = off->as<int32_t>(); rv.first = nv; rv.n_stored = nv;
+      hipLaunchKernelGGL(k_expand_rows, grid_for(nv * 16, kBlock, 8192), kBlock, 0, h.stream, rv, rows.data());
+    }
     h.sync();
     rows_view = device_array_view_t{rows.data(), idx->size, INT32};
   });
@@ -815,6 +890,50 @@ extern "C" size_t cugraph_amd_graph_num_edges(const cugraph_graph_t* graph)
 {
   return graph ? (size_t) reinterpret_cast<graph_t const*>(graph)->ne : 0;
 }
+extern "C" cugraph_error_code_t cugraph_amd_graph_compress_hypersparse(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, bool_t transposed,
+                                                                       size_t first_row, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(handle != nullptr && graph != nullptr, CUGRAPH_INVALID_INPUT, "handle / graph is NULL");
+    handle_t const& h = H(handle);
+    graph_t& g        = GM(graph);
+    CGA_EXPECTS(!g.mg, CUGRAPH_NOT_IMPLEMENTED, "hypersparse rows: a multi-GPU graph chooses the form of its local partitions itself");
+    HIP_TRY(hipSetDevice(h.device));
+    ensure_orientation(h, g, transposed == TRUE, /*dcs_aware=*/true);
+    orientation_t& o = transposed == TRUE ? g.csc : g.csr;
+    CGA_EXPECTS((int64_t)first_row <= g.nv, CUGRAPH_INVALID_INPUT, "hypersparse rows: first_row is larger than the number of vertices");
+    if (o.dcs.active() && o.dcs.first != (int64_t)first_row) inflate_offsets(h, o, g.nv);  // another boundary: through the plain form
+    compress_hypersparse(h, o, g.nv, (int64_t)first_row);
+  });
+}
+
+extern "C" cugraph_error_code_t cugraph_amd_graph_hypersparse_view(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph, bool_t transposed,
+                                                                   bool_t* is_hypersparse, size_t* first_row, size_t* num_nzd,
+                                                                   cugraph_type_erased_device_array_view_t** nzd_rows,
+                                                                   cugraph_type_erased_device_array_view_t** offsets, cugraph_error_t** error)
+{
+  if (nzd_rows) *nzd_rows = nullptr;
+  if (offsets) *offsets = nullptr;
+  return guarded(error, [&] {
+    CGA_EXPECTS(handle != nullptr && graph != nullptr, CUGRAPH_INVALID_INPUT, "handle / graph is NULL");
+    handle_t const& h = H(handle);
+    graph_t& g        = GM(graph);
+    CGA_EXPECTS(!g.mg, CUGRAPH_NOT_IMPLEMENTED, "hypersparse rows: not offered on a multi-GPU graph");
+    HIP_TRY(hipSetDevice(h.device));
+    ensure_orientation(h, g, transposed == TRUE, /*dcs_aware=*/true);
+    orientation_t const& o = transposed == TRUE ? g.csc : g.csr;
+    rows_view_t const rv   = rows_view(o, g.nv);
+    if (is_hypersparse) *is_hypersparse = rv.plain() ? FALSE : TRUE;
+    if (first_row) *first_row = rv.plain() ? 0 : (size_t)rv.first;
+    if (num_nzd) *num_nzd = rv.plain() ? 0 : (size_t)(rv.n_stored - rv.first);
+    if (nzd_rows)
+      *nzd_rows = reinterpret_cast<cugraph_type_erased_device_array_view_t*>(
+        new device_array_view_t{const_cast<int32_t*>(rv.nzd), rv.plain() ? (size_t)0 : (size_t)(rv.n_stored - rv.first), INT32});
+    if (offsets)
+      *offsets = reinterpret_cast<cugraph_type_erased_device_array_view_t*>(new device_array_view_t{const_cast<int32_t*>(rv.offsets), (size_t)rv.n_stored + 1, INT32});
+  });
+}
+
 // multi-GPU graph: the edges of THIS rank's PageRank partition (0 before the first PageRank call builds it); otherwise all edges
 extern "C" size_t cugraph_amd_graph_num_local_edges(const cugraph_graph_t* graph)
 {

@@ -34,11 +34,12 @@ struct extract_paths_result_t {  // c_api/extract_paths.cpp:24-30
 
 namespace {
 
-__global__ void k_offsets_to_degrees(int32_t const* offsets, int64_t nv, int32_t* deg)
+// deg[row] of every STORED row (either row form; the rows a hypersparse orientation does not store keep the caller's 0)
+__global__ void k_offsets_to_degrees(rows_view_t rv, int32_t* deg)
 {
   int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < nv; i += stride) deg[i] = (int32_t)((uint32_t)offsets[i + 1] - (uint32_t)offsets[i]);
+  for (; i < rv.n_stored; i += stride) deg[rv.row_of(i)] = (int32_t)((uint32_t)rv.offsets[i + 1] - (uint32_t)rv.offsets[i]);
 }
 
 __global__ void k_gather_degrees(int32_t const* deg, int32_t const* internal_ids, int64_t n, int32_t* out)
@@ -56,7 +57,9 @@ void endpoint_degrees(handle_t const& h, graph_t const& g, bool as_source, int32
   orientation_t const& same  = as_source ? g.csr : g.csc;   // rows are the wanted endpoint
   orientation_t const& other = as_source ? g.csc : g.csr;
   if (same.built) {
-    hipLaunchKernelGGL(k_offsets_to_degrees, grid_for(nv, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)same.offsets.data(), nv, deg);
+    rows_view_t const rv = rows_view(same, nv);
+    if (!rv.plain()) HIP_TRY(hipMemsetAsync(deg, 0, nv * sizeof(int32_t), h.stream));
+    hipLaunchKernelGGL(k_offsets_to_degrees, grid_for(rv.n_stored, kBlock, 8192), kBlock, 0, h.stream, rv, deg);
   } else {
     CGA_EXPECTS(other.built, CUGRAPH_UNKNOWN_ERROR, "graph has no adjacency storage");
     HIP_TRY(hipMemsetAsync(deg, 0, nv * sizeof(int32_t), h.stream));
@@ -377,14 +380,15 @@ struct edgelist_result_t {
   ~edgelist_result_t() { delete src; delete dst; delete wgt; delete ids; delete types; }
 };
 namespace {
-__global__ void k_rows_of_edges(int32_t const* offsets, int64_t nv, int32_t* rows)
+__global__ void k_rows_of_edges(rows_view_t rv, int32_t* rows)  // (either row form: the walk is over the stored rows)
 {
   int64_t wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   int lane       = threadIdx.x & 63;
-  for (int64_t v = wave; v < nv; v += nwaves) {
-    uint32_t const b = (uint32_t)offsets[v], len = (uint32_t)offsets[v + 1] - b;
-    for (uint32_t p = lane; p < len; p += 64) rows[b + p] = (int32_t)v;
+  for (int64_t k = wave; k < rv.n_stored; k += nwaves) {
+    uint32_t const b = (uint32_t)rv.offsets[k], len = (uint32_t)rv.offsets[k + 1] - b;
+    int32_t const v  = rv.row_of(k);
+    for (uint32_t p = lane; p < len; p += 64) rows[b + p] = v;
   }
 }
 }  // namespace
@@ -423,12 +427,12 @@ extern "C" cugraph_error_code_t cugraph_decompress_to_edgelist(const cugraph_res
       *result = reinterpret_cast<cugraph_edgelist_t*>(out.release());
       return;
     }
-    ensure_orientation(h, g, false);
+    ensure_orientation(h, g, false, /*dcs_aware=*/true);
     auto out = std::make_unique<edgelist_result_t>();
     out->src = new device_array_t((size_t)g.ne, g.vertex_type);
     out->dst = new device_array_t((size_t)g.ne, g.vertex_type);
     if (g.ne > 0) {
-      hipLaunchKernelGGL(k_rows_of_edges, grid_for(g.nv * 16, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)g.csr.offsets.data(), g.nv, out->src->buf.as<int32_t>());
+      hipLaunchKernelGGL(k_rows_of_edges, grid_for(g.nv * 16, kBlock, 8192), kBlock, 0, h.stream, rows_view(g.csr, g.nv), out->src->buf.as<int32_t>());
       HIP_TRY(hipMemcpyAsync(out->dst->buf.ptr, g.csr.indices.data(), (size_t)g.ne * 4, hipMemcpyDeviceToDevice, h.stream));
       unrenumber_int_to_ext(h, g, out->src->buf.as<int32_t>(), g.ne);
       unrenumber_int_to_ext(h, g, out->dst->buf.as<int32_t>(), g.ne);

@@ -891,6 +891,21 @@ mg_pagerank2d_part_t& mg_pagerank2d_part(handle_t const& h, graph_t& g)
       throw api_error(rc, "2-D multi-GPU PageRank: building the local block failed: " + msg);
     }
   }
+  // Hypersparse rows: the block's rows are C vertex partitions that see the sources of ONE column group each, so a row of global in-degree d
+  // holds ~d / C edges here and most tail rows hold none.  The reference stores such partitions as CSR + DCSR when the hypersparse segment
+  // exists, i.e. when minor_comm_size * hypersparse_threshold_ratio (0.5) exceeds 1 (graph_view.hpp:245-247, renumber_edgelist_impl.cuh:746-757);
+  // here: from C >= 4 (CUGRAPH_AMD_MG_DCSR=1 / 0 forces / forbids it, every rank the same).  The block's rows are not in one degree order (C
+  // partitions, each degree-descending), so all rows are listed (first = 0); PageRank's re-blocking walks the form directly.
+  {
+    char const* env = getenv("CUGRAPH_AMD_MG_DCSR");
+    bool const dcs  = env ? atoi(env) != 0 : C >= 4;
+    if (dcs) {
+      graph_t& block = *reinterpret_cast<graph_t*>(part->local);
+      if (block.csc.built) compress_hypersparse(h, block.csc, block.nv, 0);
+      if (block.csr.built) compress_hypersparse(h, block.csr, block.nv, 0);
+      tr.step("hypersparse rows");
+    }
+  }
   tr.step("local block");
   mg.pr2d = std::move(part);
   return *mg.pr2d;

@@ -642,7 +642,7 @@ struct pagerank_plan : pagerank_plan_base {
       WT* ow = g.out_weight_sums.as<WT>();
       if (g.nv > 0) {
         if (!g.has_weights) {
-          if (g.csr.built) {
+          if (g.csr.built && !g.csr.dcs.active()) {
             hipLaunchKernelGGL(k_outdeg_from_offsets<WT>, grid_for(g.nv, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)g.csr.offsets.data(), g.nv, ow);
           } else {
             dvec<uint32_t> c(g.nv);
@@ -651,7 +651,7 @@ struct pagerank_plan : pagerank_plan_base {
             hipLaunchKernelGGL(k_u32_to_wt<WT>, grid_for(g.nv, kBlock, 4096), kBlock, 0, h.stream, (uint32_t const*)c.data(), g.nv, ow);
             h.sync();
           }
-        } else if (g.csr.built) {
+        } else if (g.csr.built && !g.csr.dcs.active()) {
           hipLaunchKernelGGL(k_rowsum_weights<WT>, grid_for(g.nv * 16, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)g.csr.offsets.data(),
                              g.csr.weights.as<WT const>(), g.nv, ow);
         } else {
@@ -718,6 +718,7 @@ struct pagerank_plan : pagerank_plan_base {
                 (void*)tc->wrec.data(), (void*)tc->delta1.data(), (void*)tc->dstl12.data(), (void*)part.data(), (void*)x0.data(), (void*)x1.data(), (void*)pr.data());
       return;
     }
+    inflate_offsets(h, o, g.nv);  // the single-pass kernels read plain offsets
     flat = o.row_order.size() == 0 && g.ne > 0 && kern != "rows";
     if (!flat) return;
     int64_t const nnz_rows = o.seg[4];
@@ -866,7 +867,7 @@ struct pagerank_plan : pagerank_plan_base {
     // (round 5: the column-tiled plan addresses its edge arrays from 64-bit per-wavefront bases, so it takes graphs of 2^31 edges and more --
     // RMAT-27 on one 288 GB GPU; the single-pass comparison kernels keep signed 32-bit positions and are not offered there)
     CGA_EXPECTS(g.ne <= kMaxGraphEdges, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "PageRank: graphs of more than 2^32 - 4097 edges are not supported");
-    ensure_orientation(h, g, true);  // PageRank pulls over CSC
+    ensure_orientation(h, g, true, /*dcs_aware=*/true);  // PageRank pulls over CSC (plain or hypersparse rows: the re-blocking walks either form)
     int64_t const nv = g.nv;
     size_t const n1  = (size_t)(nv > 0 ? nv : 1);
     pr.resize_discard(n1); x0.resize_discard(n1); x1.resize_discard(n1);
@@ -1374,7 +1375,7 @@ struct pagerank_mg2d_plan : pagerank_mg2d_plan_base {
     CGA_EXPECTS(n_block_rows <= g.nv && n_block_cols <= g.nv, CUGRAPH_INVALID_INPUT, "2-D multi-GPU PageRank: the local graph must have max(block rows, block columns) vertices");
     x_own = x_own_v->as<WT>(); x_cols = x_cols_v->as<WT const>(); y_part = y_part_v->as<WT>(); y_own = y_own_v->as<WT const>();
     triple = triple_v->as<double>();
-    ensure_orientation(h, g, true);
+    ensure_orientation(h, g, true, /*dcs_aware=*/true);  // (the block of the library's 2-D layout arrives in hypersparse form: mg_pagerank2d_part)
     orientation_t& o = g.csc;
     CGA_EXPECTS(o.seg[4] <= n_block_rows, CUGRAPH_INVALID_INPUT, "2-D multi-GPU PageRank: edges point to rows outside the local block");
     size_t const n1 = (size_t)(L > 0 ? L : 1);

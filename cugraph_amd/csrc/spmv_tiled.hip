@@ -17,12 +17,14 @@ namespace {
 // bits are sorted on (stable: the CSC order -- destination, then source -- survives inside a tile); everything k_tile_emit needs
 // travels in the key, so it gathers nothing (it used to chase positions -> rows / indices -> xcol: four random reads per edge).
 constexpr int TK_TILE_SHIFT = 47, TK_ROW_SHIFT = 16;
-__global__ void k_tile_keys(int32_t const* offsets, int32_t const* indices, int32_t const* xcol, int64_t nv, uint32_t T, uint64_t* keys, uint32_t* vals)
+// The walk is over the STORED rows of the orientation (rows_view_t, common.hpp): plain CSC, or the CSC + DCSC hybrid of the 2-D multi-GPU block.
+__global__ void k_tile_keys(rows_view_t rv, int32_t const* indices, int32_t const* xcol, uint32_t T, uint64_t* keys, uint32_t* vals)
 {
   int64_t const wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   int const lane = threadIdx.x & 63;
-  for (int64_t v = wave; v < nv; v += nwaves) {
-    uint32_t const b = (uint32_t)offsets[v], e = (uint32_t)offsets[v + 1];  // (edge positions are unsigned 32-bit words: graphs of 2^31 edges and more)
+  for (int64_t k = wave; k < rv.n_stored; k += nwaves) {
+    uint32_t const b = (uint32_t)rv.offsets[k], e = (uint32_t)rv.offsets[k + 1];  // (edge positions are unsigned 32-bit words: graphs of 2^31 edges and more)
+    int32_t const v  = rv.row_of(k);
     for (uint64_t p = (uint64_t)b + lane; p < e; p += 64) {
       uint32_t const c = xcol ? (uint32_t)xcol[indices[p]] : (uint32_t)indices[p];
       uint32_t const J = c / T;
@@ -325,11 +327,13 @@ namespace {
 // wmax[I] = max over the rows of destination tile I of sum |w| of the row's in-edges (w == nullptr: the in-degree); one workgroup per tile,
 // one wavefront per row at a time
 template <typename WB>
-__global__ void __launch_bounds__(256) k_tile_wmax(int32_t const* offsets, WB const* w, uint32_t const* tile_row0, double* wmax)
+__global__ void __launch_bounds__(256) k_tile_wmax(rows_view_t rv, WB const* w, uint32_t const* tile_row0, double* wmax)
 {
   __shared__ double red[4];
   int const I = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t const r0 = tile_row0[I], r1 = tile_row0[I + 1];
+  // the tile's rows as a range of STORED rows (a hypersparse orientation stores only the rows that have an edge; the others add nothing to a maximum)
+  uint32_t const r0 = (uint32_t)rv.lower_bound(tile_row0[I]), r1 = (uint32_t)rv.lower_bound(tile_row0[I + 1]);
+  int32_t const* const offsets = rv.offsets;
   double best = 0.0;
   if (w == nullptr) {
     for (uint32_t r = r0 + threadIdx.x; r < r1; r += 256) best = fmax(best, (double)((uint32_t)offsets[r + 1] - (uint32_t)offsets[r]));
@@ -361,7 +365,7 @@ int tiled_default_T(handle_t const& h, size_t vsize, int64_t nv)
 
 // max over rows of sum |w|
 template <typename WB>
-__global__ void k_row_abs_max(int32_t const* offsets, WB const* w, int64_t nv, unsigned long long* out)
+__global__ void k_row_abs_max(int32_t const* offsets, WB const* w, int64_t nv, unsigned long long* out)  // (nv = stored rows)
 {
   int64_t wave   = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -382,6 +386,7 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   // nv = number of column (source) ids and of CSC rows; n_dst <= nv = rows that can have in-edges and get an epilogue
   // (single GPU: n_dst = nv; multi-GPU: the local rows, while the columns span the whole graph)
   size_t const wsize = has_weights ? vsize : 0;
+  rows_view_t const rows = rows_view(csc, nv);  // plain CSC, or its hypersparse form (walked natively: no offsets array is rebuilt)
   CGA_EXPECTS(nv < ((int64_t)1 << 31) && ne <= kMaxGraphEdges - 2 * (int64_t)TP_ITEM * 1024, CUGRAPH_UNKNOWN_ERROR, "tiled SpMV: graph too large for 32-bit positions");
   t       = tiled_csc_t{};
   build_trace tr(h, "tiled");
@@ -423,8 +428,8 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     if (has_weights) { vals.resize_discard(ne); vals_tmp.resize_discard(ne); }  // the edge position only has to travel when weights follow it
     uint32_t* const vp  = has_weights ? vals.data() : nullptr;
     uint32_t* const vtp = has_weights ? vals_tmp.data() : nullptr;
-    hipLaunchKernelGGL(k_tile_keys, grid_for(nv * 16, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)csc.offsets.data(), (int32_t const*)csc.indices.data(), xcol,
-                       nv, (uint32_t)T, keys.data(), vp);
+    hipLaunchKernelGGL(k_tile_keys, grid_for(rows.n_stored * 16, kBlock, 8192), kBlock, 0, h.stream, rows, (int32_t const*)csc.indices.data(), xcol, (uint32_t)T,
+                       keys.data(), vp);
     radix_sort_u64_u32(h, keys.data(), vp, keys_tmp.data(), vtp, ne, TK_TILE_SHIFT, TK_TILE_SHIFT + bits_for_u((uint64_t)nJ - 1));
     keys_tmp = dvec<uint64_t>(); vals_tmp = dvec<uint32_t>();
     tile_off = key_starts(h, keys.data(), ne, nJ, TK_TILE_SHIFT);
@@ -529,9 +534,9 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
   t.tile_wmax.resize_discard((size_t)std::max(t.nI, 1));
   HIP_TRY(hipMemsetAsync(t.tile_wmax.data(), 0, (size_t)std::max(t.nI, 1) * sizeof(double), h.stream));
   if (ne > 0 && t.nI > 0) {
-    if (!has_weights) hipLaunchKernelGGL(k_tile_wmax<uint32_t>, t.nI, 256, 0, h.stream, (int32_t const*)csc.offsets.data(), (uint32_t const*)nullptr, (uint32_t const*)t.tile_row0.data(), t.tile_wmax.data());
-    else if (wsize == 4) hipLaunchKernelGGL(k_tile_wmax<float>, t.nI, 256, 0, h.stream, (int32_t const*)csc.offsets.data(), csc.weights.as<float const>(), (uint32_t const*)t.tile_row0.data(), t.tile_wmax.data());
-    else hipLaunchKernelGGL(k_tile_wmax<double>, t.nI, 256, 0, h.stream, (int32_t const*)csc.offsets.data(), csc.weights.as<double const>(), (uint32_t const*)t.tile_row0.data(), t.tile_wmax.data());
+    if (!has_weights) hipLaunchKernelGGL(k_tile_wmax<uint32_t>, t.nI, 256, 0, h.stream, rows, (uint32_t const*)nullptr, (uint32_t const*)t.tile_row0.data(), t.tile_wmax.data());
+    else if (wsize == 4) hipLaunchKernelGGL(k_tile_wmax<float>, t.nI, 256, 0, h.stream, rows, csc.weights.as<float const>(), (uint32_t const*)t.tile_row0.data(), t.tile_wmax.data());
+    else hipLaunchKernelGGL(k_tile_wmax<double>, t.nI, 256, 0, h.stream, rows, csc.weights.as<double const>(), (uint32_t const*)t.tile_row0.data(), t.tile_wmax.data());
   }
 
   tr.step("destination tiles");
@@ -730,8 +735,8 @@ void build_tiled_csc(handle_t const& h, int64_t nv, int64_t n_dst, int64_t ne, o
     dvec<unsigned long long> mx(1);
     HIP_TRY(hipMemsetAsync(mx.data(), 0, sizeof(unsigned long long), h.stream));
     int const g = grid_for(nv * 16, kBlock, 8192);
-    if (vsize == 4) hipLaunchKernelGGL(k_row_abs_max<float>, g, kBlock, 0, h.stream, (int32_t const*)csc.offsets.data(), csc.weights.as<float const>(), nv, mx.data());
-    else            hipLaunchKernelGGL(k_row_abs_max<double>, g, kBlock, 0, h.stream, (int32_t const*)csc.offsets.data(), csc.weights.as<double const>(), nv, mx.data());
+    if (vsize == 4) hipLaunchKernelGGL(k_row_abs_max<float>, g, kBlock, 0, h.stream, rows.offsets, csc.weights.as<float const>(), rows.n_stored, mx.data());
+    else            hipLaunchKernelGGL(k_row_abs_max<double>, g, kBlock, 0, h.stream, rows.offsets, csc.weights.as<double const>(), rows.n_stored, mx.data());
     unsigned long long bits = 0;
     h.read_back(&bits, mx.data(), 1);
     std::memcpy(&t.wmax, &bits, sizeof(double));
@@ -1294,6 +1299,7 @@ struct p2_args {
   tiled_epilogue<WT> e;
   uint32_t* counters;
   double const* tile_wmax{nullptr};  // tiled_csc_t::tile_wmax (fp32: the fixed-point scale of the tile)
+  int stagger{0};                    // start offset between the co-resident workgroups of the first generation (k_tiled_phase2)
 };
 
 // fp32 partials are accumulated as signed 64-bit fixed point (value * 2^k of the tile, rounded to nearest: tiled_to_fixed in spmv_tiled.hpp):
@@ -1324,6 +1330,14 @@ __global__ void __launch_bounds__(TP2_BLOCK) k_tiled_phase2(p2_args<WT> a)
       if (ci) a.e.x_next[ci[j]] = xv; else xo[j] = xv;
     }
     return;
+  }
+  // The first generation of workgroups (four per CU, dispatched together) starts a quarter of a workgroup's life apart: left in lockstep the
+  // four share their latency-bound prologue / epilogue (40 % of a workgroup's 52 us) instead of hiding it behind each other's streaming loop,
+  // and the lockstep survives for several generations because the tiles have equal cost.  a.stagger = units of s_sleep(127) (~3.4 us) per
+  // quarter; 0 on grids too small for it to pay (tiled_phase2).  Measured: profiles/r6q_phase2_stagger.txt.
+  if (a.stagger > 0 && blockIdx.x < 1024u) {
+    int const q = (int)((blockIdx.x >> 8) & 3u) * a.stagger;
+    for (int i = 0; i < q; ++i) __builtin_amdgcn_s_sleep(127);
   }
   uint32_t const row0 = a.tile_row0[I], nrows = a.tile_row0[I + 1] - row0;
   uint32_t const s0 = a.region_off[I], s1 = a.region_off[I + 1];
@@ -1543,6 +1557,8 @@ void tiled_phase2(handle_t const& h, tiled_csc_t const& t, WT const* part, tiled
     timed_launch tl(h, "pagerank_reduce");
     hipLaunchKernelGGL(kernel, grid, TP2_BLOCK, lds, h.stream, a);
   };
+  char const* const stag_env = getenv("CUGRAPH_AMD_P2_STAGGER");  // (read per launch: tools/variant_ab.py alternates it on one plan)
+  a.stagger = stag_env ? std::max(0, std::min(64, atoi(stag_env))) : (grid >= TP2_STAGGER_MIN_GRID ? 6 : 0);
   if (e.pers != nullptr) launch(k_tiled_phase2<WT, true>); else launch(k_tiled_phase2<WT, false>);
 }
 

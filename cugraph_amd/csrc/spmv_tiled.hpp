@@ -87,6 +87,7 @@ constexpr int TP_CHUNK_BIG = 32;             // chunk length for the first part 
 constexpr int TP2_BLOCK = CGA_TP2_BLOCK;     // phase-2 workgroup
 constexpr int TP2_ROWS  = CGA_TP2_ROWS;      // max destination rows per phase-2 tile (64-bit LDS accumulators: 32 KiB at 4096)
 constexpr int TP2_CONST_COLS = TP2_BLOCK * 8;  // columns per tiled_const_rows block of phase 2
+constexpr int TP2_STAGGER_MIN_GRID = 4096;    // phase 2 staggers its first generation of workgroups on grids of at least four generations
 
 struct tiled_wave_t {  // build-time description of one wavefront's share of a work item
   uint32_t es, ee;     // padded edge positions [es, ee); es = item * TP_ITEM + wave * TP_WLEN

@@ -279,6 +279,25 @@ class SGGraph:
     def num_edges(self):
         return int(capi.lib().cugraph_amd_graph_num_edges(self.c_graph_ptr))
 
+    def compress_hypersparse(self, transposed, first_row=0):
+        """extensions.h cugraph_amd_graph_compress_hypersparse: rows >= first_row of the orientation keep an offset only when they have an edge
+        (the reference's CSR + DCSR hybrid, structure_utils.cuh:139-195)"""
+        err = C.c_void_p()
+        _sync_torch()
+        assert_success(capi.lib().cugraph_amd_graph_compress_hypersparse(self.resource_handle.c_resource_handle_ptr, self.c_graph_ptr, int(transposed),
+                                                                         int(first_row), C.byref(err)), err, "cugraph_amd_graph_compress_hypersparse")
+
+    def hypersparse_view(self, transposed):
+        """(is_hypersparse, first_row, nzd_rows, offsets): the row storage of the orientation as it is now (copies of the device arrays)"""
+        l = capi.lib()
+        h = self.resource_handle.c_resource_handle_ptr
+        flag, first, n_nzd = C.c_int(0), C.c_size_t(0), C.c_size_t(0)
+        nzd, off, err = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _sync_torch()
+        assert_success(l.cugraph_amd_graph_hypersparse_view(h, self.c_graph_ptr, int(transposed), C.byref(flag), C.byref(first), C.byref(n_nzd), C.byref(nzd),
+                                                            C.byref(off), C.byref(err)), err, "cugraph_amd_graph_hypersparse_view")
+        return bool(flag.value), int(first.value), copy_to_torch(h, nzd), copy_to_torch(h, off)  # (copy_to_torch frees the borrowed views)
+
     def num_local_edges(self):
         """multi-GPU graph: edges of this rank's PageRank partition (0 before the first PageRank call); otherwise all edges"""
         return int(capi.lib().cugraph_amd_graph_num_local_edges(self.c_graph_ptr))

@@ -255,6 +255,23 @@ CUGRAPH_EXPORT size_t cugraph_amd_graph_num_edges(const cugraph_graph_t* graph);
 /* multi-GPU graph: edges of this rank's PageRank partition (0 before the first PageRank call has built it); otherwise all edges */
 CUGRAPH_EXPORT size_t cugraph_amd_graph_num_local_edges(const cugraph_graph_t* graph);
 
+/* Hypersparse rows (DCSR; DCSC for the transposed orientation): the CSR + DCSR hybrid the reference builds for edge partitions whose rows are mostly
+ * empty (compress_hypersparse_offsets, cpp/src/structure/detail/structure_utils.cuh:139-195; read through dcs_nzd_vertices / major_hypersparse_first,
+ * cpp/include/cugraph/edge_partition_device_view.cuh:43-58, 820-835).  Rows [0, first_row) keep one offset each; a row >= first_row is stored only
+ * when it has an edge.  The library puts the local block of its 2-D multi-GPU PageRank layout into this form by itself; this call does it to an
+ * orientation of a single-GPU graph (internal row ids; transposed = TRUE: the CSC orientation, built when missing) -- for graphs created with
+ * renumber = FALSE over a sparse id range, and for the tests.  PageRank's re-blocking, the degree calls and cugraph_decompress_to_edgelist walk the
+ * hybrid form directly; any other algorithm re-inflates the orientation to plain offsets on its first use. */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_graph_compress_hypersparse(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+                                                                           bool_t transposed, size_t first_row, cugraph_error_t** error);
+/* The row storage of an orientation as it is now: *first_row / *num_nzd (0 / 0 for a plain orientation), and borrowed device views (valid until the
+ * graph changes form or is freed; free them with cugraph_type_erased_device_array_view_free) of the INT32 nzd rows [num_nzd] and of the INT32 offsets
+ * [first_row + num_nzd + 1, or V + 1 for a plain orientation].  *is_hypersparse = FALSE for a plain orientation. */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_graph_hypersparse_view(const cugraph_resource_handle_t* handle, cugraph_graph_t* graph,
+                                                                       bool_t transposed, bool_t* is_hypersparse, size_t* first_row,
+                                                                       size_t* num_nzd, cugraph_type_erased_device_array_view_t** nzd_rows,
+                                                                       cugraph_type_erased_device_array_view_t** offsets, cugraph_error_t** error);
+
 /* Tuning knob for the PageRank SpMV: number of x entries staged in LDS per workgroup (0 = off).
  * Default is chosen from the graph size; set before plan creation.  Returns the previous value. */
 CUGRAPH_EXPORT int cugraph_amd_set_pagerank_hot_tile(const cugraph_resource_handle_t* handle, int n_entries);

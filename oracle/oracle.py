@@ -97,6 +97,40 @@ def coo_to_cs(nv: int, major, minor, weights=None):
     return offsets, indices, out_w
 
 
+# ----------------------------------------------------------------------------- hypersparse rows
+# Restatement of compress_hypersparse_offsets (cpp/src/structure/detail/structure_utils.cuh:139-195): the CSR + DCSR hybrid.  Rows below
+# `first` keep one offset each; of the rows >= first only those with an edge survive: `nzd` lists them in ascending order (the reference's
+# dcs_nzd_vertices) and the returned offsets have first + len(nzd) + 1 entries, the last one being the edge count.  Parity status: pinned by the
+# definition only (the reference's tests hold no vector for it) plus the known-answer case in tests/test_oracle.py; the lookup the device view
+# performs (edge_partition_device_view.cuh:43-58: lower_bound over dcs_nzd_vertices) is hypersparse_find below.
+def compress_hypersparse_offsets(offsets, first):
+    offsets = np.asarray(offsets, dtype=np.int64)
+    nv = len(offsets) - 1
+    first = max(0, min(int(first), nv))
+    deg = np.diff(offsets[first:])
+    nzd = (first + np.nonzero(deg > 0)[0]).astype(np.int32)
+    out = np.concatenate([offsets[:first], offsets[nzd], offsets[-1:]])
+    return out.astype(np.int64), nzd
+
+
+def hypersparse_find(nzd, first, n_stored, row):
+    """stored index of `row` in the hybrid form, or -1 when the row is not stored (major_hypersparse_idx_from_major_nocheck)"""
+    if row < first:
+        return row if row < n_stored else -1
+    k = int(np.searchsorted(nzd, row, side="left"))
+    return first + k if k < len(nzd) and nzd[k] == row else -1
+
+
+def inflate_hypersparse_offsets(offsets, nzd, first, nv):
+    """the plain offsets [nv + 1] back from the hybrid form"""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    deg = np.zeros(nv, np.int64)
+    stored_deg = np.diff(offsets)
+    deg[:first] = stored_deg[:first]
+    deg[np.asarray(nzd, dtype=np.int64)] = stored_deg[first:]
+    return np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+
+
 # -------------------------------------------------------------------------------------- PageRank
 def pagerank(nv, offsets, indices, weights=None, alpha=0.85, epsilon=1e-6, max_iter=100,
              personalization=None, initial_guess=None, precomputed_outw=None, acc64=True,

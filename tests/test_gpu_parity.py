@@ -257,6 +257,56 @@ def test_pagerank_rmat_vs_oracle(cg, handle, orc, scale, weighted, renumber, tra
     assert abs(float(pr.astype(np.float64).sum()) - 1.0) < 1e-4  # mass conservation (dangling mass redistributed)
 
 
+@pytest.mark.parametrize("transposed,first_frac,weighted", [(True, 0.0, False), (True, 0.4, True), (False, 0.0, True), (False, 1.0, False), (True, 0.07, False)])
+def test_hypersparse_rows_vs_oracle(cg, handle, orc, transposed, first_frac, weighted):
+    """DCSR / DCSC (the reference's compress_hypersparse_offsets, structure_utils.cuh:139-195): a renumber = FALSE graph over a
+    sparse id range is put into the CSR + DCSR hybrid form; (nzd rows, offsets) must equal the oracle's restatement bit for bit, the consumers that
+    walk the form directly (PageRank's re-blocking, the degree calls, decompress_to_edgelist) must give what the plain graph gives -- PageRank bit for
+    bit -- and an algorithm that needs plain offsets (BFS) must re-inflate it and agree as well."""
+    rng = np.random.default_rng(5)
+    nv, ne = 200_000, 40_000  # most rows are empty
+    hubs = rng.integers(0, nv, 300)
+    s = np.where(rng.random(ne) < 0.5, rng.choice(hubs, ne), rng.integers(0, nv, ne)).astype(np.int32)
+    d = np.where(rng.random(ne) < 0.3, rng.choice(hubs, ne), rng.integers(0, nv, ne)).astype(np.int32)
+    w = int_weights(ne) if weighted else None
+    first = int(first_frac * nv)
+    plain = make_graph(cg, handle, s, d, w, transposed=transposed, renumber=False, vertices=np.arange(nv))
+    g = make_graph(cg, handle, s, d, w, transposed=transposed, renumber=False, vertices=np.arange(nv))
+    g.compress_hypersparse(transposed, first)
+    is_h, got_first, nzd, off = g.hypersparse_view(transposed)
+    assert is_h and got_first == first
+    major, minor = (d, s) if transposed else (s, d)
+    p_off, _, _ = orc.coo_to_cs(nv, major, minor, w)
+    want_off, want_nzd = orc.compress_hypersparse_offsets(p_off, first)
+    assert np.array_equal(nzd.cpu().numpy(), want_nzd)
+    assert np.array_equal(off.cpu().numpy().astype(np.int64), want_off)
+    assert off.numel() < nv // 2 or first_frac >= 0.4  # the point of the form
+    assert np.array_equal(orc.inflate_hypersparse_offsets(want_off, want_nzd, first, nv), np.asarray(p_off, np.int64))
+    # consumers that walk the hybrid form
+    for a, b in zip(cg.degrees(handle, g), cg.degrees(handle, plain)):
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+    assert g.hypersparse_view(transposed)[0], "the degree calls must not re-inflate the orientation"
+    e1, e2 = cg.decompress_to_edgelist(handle, g), cg.decompress_to_edgelist(handle, plain)
+    key = lambda e: np.sort(e[0].cpu().numpy().astype(np.int64) * nv + e[1].cpu().numpy())  # noqa: E731
+    assert np.array_equal(key(e1), key(e2)) and np.array_equal(key(e1), np.sort(s.astype(np.int64) * nv + d))
+    v1, pr1, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 15, False, fail_on_nonconvergence=False)
+    v2, pr2, _ = cg.pagerank(handle, plain, None, None, None, None, 0.85, 0.0, 15, False, fail_on_nonconvergence=False)
+    assert np.array_equal(v1.cpu().numpy(), v2.cpu().numpy()) and np.array_equal(pr1.cpu().numpy(), pr2.cpu().numpy())
+    if transposed:
+        assert g.hypersparse_view(True)[0], "PageRank's re-blocking must walk the hybrid form, not re-inflate it"
+    (pr,) = by_vertex(v1, pr1)
+    c_off, c_idx, c_w = orc.coo_to_cs(nv, d, s, w)
+    truth, _, _ = orc.pagerank(nv, c_off, c_idx, c_w, 0.85, 0.0, 15, acc64=True)
+    assert np.max(np.abs(pr - truth)) <= 1e-6 and np.max(np.abs(pr - truth) / truth) <= 2e-5
+    # ... and one that reads plain offsets
+    src0 = int(s[0])
+    r1 = cg.bfs(handle, g, T([src0], np.int32), False, 0, True, False)
+    r2 = cg.bfs(handle, plain, T([src0], np.int32), False, 0, True, False)
+    for a, b in zip(r1, r2):
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+    assert not g.hypersparse_view(False)[0]
+
+
 def test_mggraph_one_rank_equals_sggraph(cg, handle, orc):
     """pylibcugraph's MGGraph (graphs.pyx:357-700) on a one-rank handle: the rank's slice as three arrays per column
     (cugraph_graph_create_with_times_mg concatenates them, always renumbers): PageRank, BFS and SSSP equal the oracle's."""

@@ -146,6 +146,25 @@ def test_mg_capi_pagerank_2d_layout(orc, tmp_path, world, weighted):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,weighted", [(2, "-"), (4, "w"), (6, "-")])
+def test_mg_capi_pagerank_2d_layout_hypersparse_blocks(orc, tmp_path, world, weighted):
+    """DCSR in the place the reference uses it (structure_utils.cuh:139-195): the local block of the 2-D layout stored as DCSC
+    (the library does so from C >= 4 column groups; forced here on smaller grids) must give the bits the plain block gives, and both the oracle's
+    values.  The 8-rank case of test_mg_capi_pagerank_2d_layout (2 x 4) runs the form by default."""
+    from test_mg import truth
+
+    scale, iters = 12, 12
+    prs = []
+    for dcsr in ("1", "0"):
+        res = run_ranks("pagerank", world, tmp_path, scale, iters, 0.0, weighted, env_extra={"CUGRAPH_AMD_MG_LAYOUT": "2d", "CUGRAPH_AMD_MG_DCSR": dcsr})
+        assert sum(r["rows"] for r in res) == 1 << scale and all(r["repeat_equal"] for r in res)
+        prs.append(_assemble(tmp_path, world, 1 << scale))
+    assert np.array_equal(prs[0], prs[1])
+    t, _, _ = truth(orc, scale, 0.0, iters, weighted=weighted == "w")
+    assert np.max(np.abs(prs[0] - t)) <= 1e-6 and np.max(np.abs(prs[0] - t) / t) <= 2e-5
+
+
+@pytest.mark.gpu
 def test_mg_capi_pagerank_2d_layout_converges_like_single_gpu(orc, tmp_path):
     from test_mg import truth
 

@@ -263,3 +263,22 @@ def test_louvain_c_equals_numpy_restatement(orc, scale, resolution, real_weights
     assert np.array_equal(c1, c2) and l1 == l2 and sweeps >= l2
     assert abs(q1 - q2) <= 1e-12
 
+
+
+def test_hypersparse_offsets_known_answer(orc):
+    """compress_hypersparse_offsets (structure_utils.cuh:139-195) on a case small enough to check by hand: rows 0..7 with degrees 3,0,2,0,0,1,0,4; with
+    the boundary at row 2 the rows 0 and 1 keep their offsets, of the rows 2..7 only 2, 5 and 7 are listed."""
+    off = np.array([0, 3, 3, 5, 5, 5, 6, 6, 10])
+    c, nzd = orc.compress_hypersparse_offsets(off, 2)
+    assert nzd.tolist() == [2, 5, 7] and c.tolist() == [0, 3, 3, 5, 6, 10]
+    c0, nzd0 = orc.compress_hypersparse_offsets(off, 0)
+    assert nzd0.tolist() == [0, 2, 5, 7] and c0.tolist() == [0, 3, 5, 6, 10]
+    c8, nzd8 = orc.compress_hypersparse_offsets(off, 8)
+    assert nzd8.size == 0 and c8.tolist() == off.tolist()
+    for first, cc, nn in ((2, c, nzd), (0, c0, nzd0), (8, c8, nzd8)):
+        assert orc.inflate_hypersparse_offsets(cc, nn, first, 8).tolist() == off.tolist()
+        n_stored = first + len(nn)
+        for row in range(8):
+            k = orc.hypersparse_find(nn, first, n_stored, row)
+            deg = int(off[row + 1] - off[row])
+            assert (k < 0 and deg == 0) or (k >= 0 and int(cc[k + 1] - cc[k]) == deg)
