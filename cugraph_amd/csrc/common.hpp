@@ -204,6 +204,28 @@ struct handle_t {  // behind cugraph_resource_handle_t
   std::map<std::string, kernel_timer> timers;
   int pagerank_hot_tile{-1};  // -1 = auto
   cugraph_amd_traversal_stats_t last_stats{};
+  // A second stream for work that has no place on an algorithm's critical path (e.g. the vertex column of a traversal result, copied while the
+  // traversal runs): side_fork() makes it wait for everything enqueued on `stream` so far and returns it, side_join() makes `stream` wait for it.
+  // Created on first use, destroyed with the handle.
+  mutable hipStream_t side_stream{nullptr};
+  mutable hipEvent_t side_ev[2]{nullptr, nullptr};
+  hipStream_t side_fork() const
+  {
+    if (!side_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&side_ev[0], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&side_ev[1], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(side_ev[0], stream));
+    HIP_TRY(hipStreamWaitEvent(side_stream, side_ev[0], 0));
+    return side_stream;
+  }
+  void side_join() const
+  {
+    if (!side_stream) return;
+    HIP_TRY(hipEventRecord(side_ev[1], side_stream));
+    HIP_TRY(hipStreamWaitEvent(stream, side_ev[1], 0));
+  }
 
   template <typename T> T* pinned_as() const { return static_cast<T*>(pinned); }
   void sync() const { HIP_TRY(hipStreamSynchronize(stream)); }

@@ -70,6 +70,13 @@ extern "C" void cugraph_free_resource_handle(cugraph_resource_handle_t* handle)
   pool_forget_stream(h->stream);
   pool_forget_stream(h->own_stream);
   free_timers(h);
+  if (h->side_stream) {
+    (void)hipStreamSynchronize(h->side_stream);
+    pool_forget_stream(h->side_stream);
+    (void)hipStreamDestroy(h->side_stream);
+    (void)hipEventDestroy(h->side_ev[0]);
+    (void)hipEventDestroy(h->side_ev[1]);
+  }
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;

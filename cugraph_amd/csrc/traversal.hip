@@ -51,7 +51,8 @@ namespace {
 // validates parents, bfs_test.cpp:217-233), deterministic, and identical whichever direction each level ran in.
 struct bfs_state {
   int32_t* dist;
-  int32_t* pred;               // INTERNAL id of the parent, INT32_MAX = none yet (mapped to external ids / -1 at the end); nullptr when not requested
+  int32_t* pred;               // parent, -1 = none; the vertices a top-down level discovers hold the parent's INTERNAL id until the level's
+                               // k_bfs_relabel_queue, everything else the caller's id already; nullptr when not requested
   uint32_t const* vis_prev;    // visited as of the start of the level
   uint32_t* vis_new;           // cumulative
   int32_t* q_next;
@@ -84,7 +85,9 @@ struct bfs_visit {
         acc_out += (unsigned long long)(eoff(s.out_offsets, v + 1) - eoff(s.out_offsets, v));
         acc_in += (unsigned long long)(eoff(s.in_offsets, v + 1) - eoff(s.in_offsets, v));
       }
-      if (s.pred && u < __hip_atomic_load(&s.pred[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&s.pred[v], u);  // minimum internal id among the frontier parents
+      // minimum internal id among the frontier parents; "none" is -1 = the largest unsigned word, so the array needs no other initial value
+      uint32_t* const pw = reinterpret_cast<uint32_t*>(&s.pred[v]);
+      if (s.pred && (uint32_t)u < __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(pw, (uint32_t)u);
     }
     wq.push(fresh, v);
   }
@@ -133,29 +136,27 @@ __global__ void k_bfs_front_from_vis(uint32_t* vis_prev, uint32_t const* vis_new
 
 // queue <- set bits of a bitmap (order within the queue is immaterial)
 
-// parents: internal ids -> external ids, INT32_MAX (none) -> -1 (invalid_vertex_id)
-__global__ void k_bfs_finish_pred(int32_t* pred, int64_t n, int32_t const* labels)
+// The parents of the vertices a top-down level has just discovered (the level's output queue): internal ids -> the caller's ids.  Runs right after
+// the level, on the queue while it is hot: the end of the traversal has no pass over all V parents any more (it took 110 us of a 1.3 ms search
+// at RMAT-24).  Bottom-up levels write the caller's id at the discovery (k_bfs_bottom_up: parent_label).  n comes from the device counter.
+__global__ void __launch_bounds__(256) k_bfs_relabel_queue(int32_t const* q, counters_t const* cnt, int32_t* pred, int32_t const* labels)
 {
-  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t const n = (int64_t)cnt->n_next;
+  int64_t i       = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t stride  = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    int32_t p = pred[i];
-    pred[i]   = p == INT32_MAX ? -1 : (labels ? labels[p] : p);
+    int32_t const v = q[i], p = pred[v];
+    if (p >= 0) pred[v] = labels[p];
   }
 }
 
-// result columns in one pass: ids <- the numbering; parents (when kept): internal ids -> external ids, INT32_MAX (none) -> -1
-__global__ void __launch_bounds__(256) k_bfs_result_columns(int32_t const* number_map, int32_t* ids, int32_t* pred, int64_t n, int32_t const* labels)
+// the vertex column of the result: a copy of the numbering (the result owns its columns).  Runs on the handle's side stream beside the traversal.
+__global__ void __launch_bounds__(256) k_copy_i32x4(int32_t const* in, int32_t* out, int64_t n)
 {
-  int64_t i      = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) {
-    ids[i] = number_map[i];
-    if (pred) {
-      int32_t const p = pred[i];
-      pred[i]         = p == INT32_MAX ? -1 : (labels ? labels[p] : p);
-    }
-  }
+  int64_t const t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t const n4 = n / 4;
+  for (int64_t i = t; i < n4; i += stride) reinterpret_cast<int4*>(out)[i] = reinterpret_cast<int4 const*>(in)[i];
+  for (int64_t i = n4 * 4 + t; i < n; i += stride) out[i] = in[i];
 }
 
 // dist / pred <- "unreached", the bitmaps and the counters <- 0
@@ -164,12 +165,12 @@ __global__ void __launch_bounds__(256) k_bfs_init_state(int32_t* dist, int32_t* 
 {
   int64_t const t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
   int64_t const n4 = nv / 4;
-  int4 const big{INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX};
+  int4 const big{INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX}, none{-1, -1, -1, -1};
   for (int64_t i = t; i < n4; i += stride) {
     reinterpret_cast<int4*>(dist)[i] = big;
-    if (pred) reinterpret_cast<int4*>(pred)[i] = big;
+    if (pred) reinterpret_cast<int4*>(pred)[i] = none;
   }
-  for (int64_t i = n4 * 4 + t; i < nv; i += stride) { dist[i] = INT32_MAX; if (pred) pred[i] = INT32_MAX; }
+  for (int64_t i = n4 * 4 + t; i < nv; i += stride) { dist[i] = INT32_MAX; if (pred) pred[i] = -1; }
   for (int64_t i = t; i < nwords; i += stride) {
     vis_prev[i] = 0u; vis_new[i] = 0u;
     if (front) { front[i] = 0u; next[i] = 0u; }
@@ -1058,6 +1059,9 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   // the bottom-up kernel rewrites whole 64-vertex groups only: the two slack words of front / next must read as "no vertex"
   hipLaunchKernelGGL(k_bfs_init_state, grid_for(std::max<int64_t>(nv / 4, nwords), kBlock, 4096), kBlock, 0, h.stream, dist->buf.as<int32_t>(), pred_p, nv, vis_prev.data(),
                      vis_new.data(), in ? front.data() : (uint32_t*)nullptr, in ? next.data() : (uint32_t*)nullptr, nwords, cnt.data());
+  // the result's vertex column is a copy of the numbering: 128 MB of traffic at RMAT-24 that nothing in the traversal waits for -- on the side stream
+  // (the levels are latency-bound, the copy rides beside them); joined before the result is handed out
+  if (nv > 0) hipLaunchKernelGGL(k_copy_i32x4, grid_for(nv / 4 + 1, 256, 1024), 256, 0, h.side_fork(), (int32_t const*)g.number_map.data(), ids->buf.as<int32_t>(), nv);
   if (ns > 0)
     hipLaunchKernelGGL(k_bfs_init_sources, grid_for(ns, kBlock), kBlock, 0, h.stream, (int32_t const*)src.data(), ns, dist->buf.as<int32_t>(),
                        vis_prev.data(), vis_new.data(), qa.data(), cnt.data(), out_off, in_off);
@@ -1104,7 +1108,7 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
           dvec<unsigned long long> prof(8);
           HIP_TRY(hipMemsetAsync(prof.data(), 0, 8 * sizeof(unsigned long long), h.stream));
           hipLaunchKernelGGL(k_bfs_bottom_up<true>, bu_grid, TV_BLOCK, 0, h.stream, in_off, in_idx, out_off, nv, vis_new.data(), (uint32_t const*)front.data(),
-                             next.data(), dist->buf.as<int32_t>(), pred_p, (int32_t)(depth + 1), cnt.data(), prof.data());
+                             next.data(), dist->buf.as<int32_t>(), pred_p, (int32_t)(depth + 1), cnt.data(), prof.data(), labels);
           unsigned long long pr[8];
           h.read_back(pr, (unsigned long long const*)prof.data(), 8);
           double const nw = (double)bu_grid * TV_WAVES;
@@ -1113,7 +1117,7 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
                   (long long)depth, pr[0] / nw, pr[1] / nw, pr[2] / nw, pr[6], pr[7], pr[3] / nw, pr[4] / nw, pr[5] / nw);
         } else {
           hipLaunchKernelGGL(k_bfs_bottom_up<false>, bu_grid, TV_BLOCK, 0, h.stream, in_off, in_idx, out_off, nv, vis_new.data(), (uint32_t const*)front.data(),
-                             next.data(), dist->buf.as<int32_t>(), pred_p, (int32_t)(depth + 1), cnt.data(), (unsigned long long*)nullptr);
+                             next.data(), dist->buf.as<int32_t>(), pred_p, (int32_t)(depth + 1), cnt.data(), (unsigned long long*)nullptr, labels);
         }
       }
       mark("bottom_up", (long long)depth, n_cur);
@@ -1139,6 +1143,8 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
         hipLaunchKernelGGL(k_bfs_expand_big, h.num_cus * 8, TV_BLOCK, 0, h.stream, (int32_t const*)bigq.data(), (int32_t const*)o.offsets.data(),
                            (int32_t const*)o.indices.data(), s, seg);
       }
+      if (pred_p && labels)  // this level's discoveries: parents as the caller's ids (see k_bfs_relabel_queue)
+        hipLaunchKernelGGL(k_bfs_relabel_queue, std::min(h.num_cus, 64), 256, 0, h.stream, (int32_t const*)q_nxt, (counters_t const*)cnt.data(), pred_p, labels);
       if (!in) HIP_TRY(hipMemcpyAsync(vis_prev.data(), vis_new.data(), nwords * 4, hipMemcpyDeviceToDevice, h.stream));
       mark("top_down", (long long)depth, n_cur);
       std::swap(q_cur, q_nxt);
@@ -1164,10 +1170,9 @@ paths_result_t* run_bfs(handle_t& h, graph_t& g, device_array_view_t const* sour
   // statistics: every discovered vertex was counted (with its out-degree) by the level that found it -- no extra pass
   h.last_stats = cugraph_amd_traversal_stats_t{levels, edges, reached_total, edges_of_reached, 0};
   (void)bu_levels;
-  // the vertex column (a copy of the numbering: the result owns its columns) and, bfs.cpp:131-138, the predecessors back in external ids:
-  // one kernel (the 64 MB device-to-device copy of the runtime took 80 us at RMAT-24, a streaming kernel takes 30)
-  if (nv > 0) hipLaunchKernelGGL(k_bfs_result_columns, grid_for(nv, kBlock, 4096), kBlock, 0, h.stream, (int32_t const*)g.number_map.data(), ids->buf.as<int32_t>(), pred_p, nv, labels);
-  mark("finish_pred");
+  // the predecessors are in the caller's ids already (bfs.cpp:131-138: per level here, not in a pass over V at the end); the vertex column arrives from the side stream
+  h.side_join();
+  mark("finish");
   h.sync();
   auto* r = new paths_result_t{ids.release(), dist.release(), preds.release()};
   outer_replace_ids(h, g, r->vertex_ids);

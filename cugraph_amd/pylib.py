@@ -10,6 +10,7 @@ Everything computes through the C ABI (cugraph_amd/_capi.py); PyTorch is used fo
 from __future__ import annotations
 
 import ctypes as C
+import time
 
 import numpy as np
 import torch
@@ -421,6 +422,11 @@ def personalized_pagerank(resource_handle, graph, precomputed_vertex_out_weight_
     return _centrality_result(resource_handle, res, fail_on_nonconvergence)
 
 
+# wall time of the latest blocking C call per entry point (seconds): what the C-ABI boundary itself took, without this mirror's pre-checks and result
+# copies (bench_traversal.py reports both)
+last_c_call_s = {}
+
+
 def bfs(handle, graph, sources, direction_optimizing, depth_limit, compute_predecessors, do_expensive_check):
     """bfs.pyx:50-196.  Returns (distances, predecessors, vertices)."""
     l = capi.lib()
@@ -432,8 +438,10 @@ def bfs(handle, graph, sources, direction_optimizing, depth_limit, compute_prede
     v = _View(sources)
     res, err = C.c_void_p(), C.c_void_p()
     _sync_torch()
+    t0 = time.perf_counter()
     code = l.cugraph_bfs(handle.c_resource_handle_ptr, graph.c_graph_ptr, v.ptr, int(direction_optimizing), int(depth_limit),
                          int(compute_predecessors), int(do_expensive_check), C.byref(res), C.byref(err))
+    last_c_call_s["cugraph_bfs"] = time.perf_counter() - t0  # (the call returns when its results are complete)
     v.free()
     assert_success(code, err, "cugraph_bfs")
     h = handle.c_resource_handle_ptr
@@ -555,8 +563,10 @@ def sssp(resource_handle, graph, source, cutoff, compute_predecessors, do_expens
     l = capi.lib()
     res, err = C.c_void_p(), C.c_void_p()
     _sync_torch()
+    t0 = time.perf_counter()
     code = l.cugraph_sssp(resource_handle.c_resource_handle_ptr, graph.c_graph_ptr, int(source), float(cutoff), int(compute_predecessors),
                           int(do_expensive_check), C.byref(res), C.byref(err))
+    last_c_call_s["cugraph_sssp"] = time.perf_counter() - t0
     assert_success(code, err, "cugraph_sssp")
     h = resource_handle.c_resource_handle_ptr
     vertices = copy_to_torch(h, l.cugraph_paths_result_get_vertices(res))
