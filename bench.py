@@ -205,7 +205,7 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the post-timing correctness check of the timed result")
     ap.add_argument("--no-phase-pass", action="store_true", help="skip the second, per-launch-instrumented pass of the K steps (the phase averages are then absent)")
     ap.add_argument("--no-extras", action="store_true", help="skip the bounded BFS / SSSP (RMAT-24) and Louvain (RMAT-22) sub-lines appended at N = 1")
-    ap.add_argument("--extra-roots", type=int, default=16)
+    ap.add_argument("--extra-roots", type=int, default=64, help="roots of the traversal sub-lines (64 = the Graph500 protocol of SURVEY section 8(d))")
     ap.add_argument("--layout", choices=["1d", "2d"], default=os.environ.get("CUGRAPH_AMD_MG_LAYOUT", "1d"),
                     help="N > 1: 1d = destination partition + sparse all-to-all (default), 2d = the reference's R x C layout (all-gather + reduce-scatter)")
     ap.add_argument("--transport", choices=["ipc", "rccl"], default=os.environ.get("CUGRAPH_AMD_MG_TRANSPORT", "ipc"),
@@ -327,7 +327,7 @@ def extras(args):
     res = {}
     h = cg.ResourceHandle()
     try:
-        bounded = f" [bench.py extra: {args.extra_roots} roots instead of the 64 of SURVEY section 8(d), to keep the default run within minutes; bench_traversal.py runs 64]"
+        bounded = "" if args.extra_roots >= 64 else f" [bench.py extra: {args.extra_roots} roots instead of the 64 of SURVEY section 8(d)]"
         # round 5: the headline of every traversal line is WITH predecessors (python-cugraph's default, what the Graph500 protocol validates);
         # `distance_only` inside each line is the same roots without them (the figure rounds 1-4 quoted)
         t = traversal_bench(cg, h, 24, 16, args.extra_roots, "int", False, True, True, 20, not args.no_cpu_baseline, not args.no_check)
