@@ -96,6 +96,14 @@ def run_single(args):
     plan = cg.PageRankPlan(h, g, 0.85)
     h.sync()
     plan_s = time.perf_counter() - t0
+    # The plan tunes itself (extensions.h cugraph_amd_pagerank_plan_tune): the same plan runs in a +-2.5 % band on this part depending on which physical
+    # pages its streamed arrays got, so it times itself on --placements fresh allocations of them and keeps the fastest -- same data, same kernels,
+    # same bits.  Part of the plan's construction, outside the timed region like the graph build (tune_s below); --placements 1 turns it off
+    # (profiles/r6t_placement_trials.txt, r6u_warmup_or_placement.txt: what it buys, in fresh processes of this command line).
+    t0 = time.perf_counter()
+    tuned_ms = plan.tune(args.placements) if args.placements > 1 else 0.0
+    h.sync()
+    run_single.tune = {"placements": args.placements, "seconds": round(time.perf_counter() - t0, 3), "ms_per_iteration_of_the_kept_placement": round(tuned_ms, 4)}
     plan.step(args.warmup)
     h.sync()
     torch.cuda.synchronize()
@@ -198,6 +206,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scale", type=int, default=26)
+    ap.add_argument("--placements", type=int, default=8, help="plan.tune(n): the plan keeps the fastest of n placements of its streamed arrays (1 = off)")
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--hot-tile", type=int, default=None, help="x entries staged in LDS per workgroup (default: library choice)")
     ap.add_argument("--cpu-scale", type=int, default=22, help="RMAT scale of the bounded CPU-baseline sample")
@@ -289,9 +298,11 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"PageRank power iteration, RMAT scale {args.scale} edge factor {args.edge_factor} "
                                "(a,b,c)=(0.57,0.19,0.19) seed 0, int32 ids, fp32 ranks, alpha 0.85, CSC with degree-descending renumbering",
-                   "vertices": nv, "edges": ne, "parallelism": "1 GPU", "iterations": "fixed count (epsilon = 0, no host synchronisation inside the timed region): the L1 change is not evaluated, so the epilogue does not re-read the previous iterate, and pr -- the result buffer; the iteration state is x = pr/out_w -- is written by the last iteration of the call (DESIGN.md section 3.1, item 5; CUGRAPH_AMD_PAGERANK_DIFF=1 CUGRAPH_AMD_PAGERANK_WRITE_PR=1 restore both)"},
+                   "vertices": nv, "edges": ne, "parallelism": "1 GPU",
+                   "plan": f"tuned before the timed region: the fastest of {args.placements} placements of the plan's streamed arrays (cugraph_amd_pagerank_plan_tune; same data, same kernels, bit-identical results; --placements 1 = untuned)" if args.placements > 1 else "untuned (--placements 1)",
+                   "iterations": "fixed count (epsilon = 0, no host synchronisation inside the timed region): the L1 change is not evaluated, so the epilogue does not re-read the previous iterate, and pr -- the result buffer; the iteration state is x = pr/out_w -- is written by the last iteration of the call (DESIGN.md section 3.1, item 5; CUGRAPH_AMD_PAGERANK_DIFF=1 CUGRAPH_AMD_PAGERANK_WRITE_PR=1 restore both)"},
         "iters_per_sec": round(args.steps / dt, 2),
-        "graph_build_s": round(build_s, 3), "plan_build_s": round(plan_s, 3),
+        "graph_build_s": round(build_s, 3), "plan_build_s": round(plan_s, 3), "plan_tune": run_single.tune,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_basis": "algorithmic bytes of one iteration / ms_per_step (wall clock of the timed region; no per-launch events inside it)",
                      "region_event_ms_per_step": round(region_ms / args.steps, 4),

@@ -158,6 +158,7 @@ PROTOTYPES = {
     "cugraph_amd_generate_rmat_edgelist": (C.c_int, [_P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_uint64, _P, _P, _PP]),
     "cugraph_amd_pagerank_plan_create": (C.c_int, [_P] * 8 + [C.c_double, _PP, _PP]),
     "cugraph_amd_pagerank_plan_step": (C.c_int, [_P, C.c_double, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int), _PP]),
+    "cugraph_amd_pagerank_plan_tune": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_double), _PP]),
     "cugraph_amd_pagerank_plan_result": (C.c_int, [_P, C.c_size_t, C.c_int, _PP, _PP]),
     "cugraph_amd_pagerank_plan_free": (None, [_P]),
     "cugraph_amd_pagerank_mg_plan_create": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _P, _P, _P, C.POINTER(C.c_size_t),

@@ -584,6 +584,9 @@ struct pagerank_plan_base {
   virtual ~pagerank_plan_base() = default;
   virtual void step(double epsilon, size_t max_iterations, size_t* done, bool* converged) = 0;
   virtual centrality_result_t* result(size_t total_iterations, bool converged)          = 0;
+  // cugraph_amd_pagerank_plan_tune: time the plan on `placements` placements of its streamed arrays, keep the fastest; the milliseconds per iteration of
+  // the kept one (0: this kind of plan has nothing to tune)
+  virtual double tune(int /*placements*/) { return 0.0; }
 };
 
 template <typename WT>
@@ -846,6 +849,99 @@ struct pagerank_plan : pagerank_plan_base {
     pending_finish   = true;
     const_rows_stale = crows.nI_act > 0;
   }
+  bool const_rows_allowed{false};
+  bool stepped{false};  // step() ran: the iteration state is the caller's
+  void tiled_initial_state()
+  {
+    int64_t const nv = g.nv;
+    setup_const_rows(const_rows_allowed);
+    int n = tiled_prologue<WT>(h, *tc, (WT const*)pr.data(), outw, x0.data(), nv, tpartials.data());
+    // the rows without in-edges start from the uniform value (there is no user vector when they are left out)
+    tiled_finish<WT>(h, tiled_epi(nullptr), n, crows.nI_act > 0 ? (double)(WT(1) / (WT)nv) : -1.0);
+    cur              = 0;
+    pending_finish   = false;
+    const_rows_stale = false;
+    h.sync();
+  }
+
+  // Placement trials (cugraph_amd_pagerank_plan_tune; CUGRAPH_AMD_PR_PLACEMENT_TRIALS=n runs them inside every plan creation).  The SAME plan (same
+  // kernels, same bytes) on other physical pages runs anywhere in a +-2.5 % band on this part (RMAT-26: phase 1 0.92-0.99 ms, phase 2 0.40-0.45 ms;
+  // DESIGN.md section 3.1, profiles/r6c_*, r6d_*, r6e_*, r6t_*, r6u_*).  Where the streamed arrays lie decides how their streams meet in the memory
+  // system; an offset inside one allocation changes nothing (measured), other pages do, and user space cannot choose pages -- but it can SAMPLE them:
+  // the plan times itself on `placements` fresh allocations of its large streamed arrays (contents copied device to device) and keeps the fastest.
+  // Same data, same kernels, same bits; only the addresses differ.  It costs ~10 iterations + one copy per placement, so it is the caller's decision
+  // (a solver that runs the plan hundreds of times; a one-shot cugraph_pagerank of 20 iterations would lose): NOT done by default.  The re-blocked
+  // arrays are cached on the graph, so later plans of the graph start from the kept placement.  Only before the first step(): the trial iterations run on
+  // the plan's own vectors, which are set back to the initial state afterwards (the initial vector itself is never written by them).
+  template <typename T>
+  static dvec<T> clone_dvec(handle_t const& h, dvec<T> const& a)
+  {
+    dvec<T> b(a.size());
+    if (a.size()) HIP_TRY(hipMemcpyAsync(b.data(), a.data(), a.size() * sizeof(T), hipMemcpyDeviceToDevice, h.stream));
+    return b;
+  }
+  double tune(int placements) override
+  {
+    HIP_TRY(hipSetDevice(h.device));
+    CGA_EXPECTS(!stepped, CUGRAPH_INVALID_INPUT, "pagerank plan: tune() must come before the first step()");
+    if (!tiled || placements <= 1 || g.ne == 0 || force_diff || force_write_pr) return 0.0;
+    bool const trace = getenv("CUGRAPH_AMD_PR_PLACEMENT_TRACE") != nullptr;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    constexpr int kWarm = 2, kTimed = 8;
+    auto time_plan = [&]() -> double {
+      for (int i = 0; i < kWarm; ++i) { iterate_tiled(false, false); cur ^= 1; }
+      HIP_TRY(hipEventRecord(e0, h.stream));
+      for (int i = 0; i < kTimed; ++i) { iterate_tiled(false, false); cur ^= 1; }
+      HIP_TRY(hipEventRecord(e1, h.stream));
+      HIP_TRY(hipEventSynchronize(e1));
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+      return (double)ms / kTimed;
+    };
+    struct placement_t {  // the arrays an iteration streams: phase 1 reads src16 / bits / weights / wrec / delta1 and writes part, phase 2 reads part and dstl*
+      dvec<uint16_t> src16; dvec<uint32_t> bits; dev_buf weights; dvec<uint32_t> delta1, wrec, dstl12; dvec<uint16_t> dstl16; dvec<WT> part;
+    };
+    auto swap_in = [&](placement_t& p) {
+      std::swap(tc->src16, p.src16); std::swap(tc->bits, p.bits); std::swap(tc->weights, p.weights); std::swap(tc->delta1, p.delta1);
+      std::swap(tc->wrec, p.wrec); std::swap(tc->dstl12, p.dstl12); std::swap(tc->dstl16, p.dstl16); std::swap(part, p.part);
+    };
+    size_t const clone_bytes = tc->src16.buf.bytes + tc->bits.buf.bytes + tc->weights.bytes + tc->delta1.buf.bytes + tc->wrec.buf.bytes + tc->dstl12.buf.bytes +
+                               tc->dstl16.buf.bytes + part.buf.bytes;
+    (void)time_plan();  // (the first timing after a build is 2-5 % slow whatever the placement: clocks, first touches)
+    double best = time_plan();
+    if (trace) fprintf(stderr, "[pagerank plan] placement 0: %.4f ms per iteration\n", best);
+    std::vector<placement_t> losers;  // kept until the end: a block handed back to the pool would be the next trial's "fresh" allocation
+    try {
+      for (int t = 1; t < placements; ++t) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        if ((losers.size() + 2) * clone_bytes > total_b / 4) break;  // the trials never hold more than a quarter of the device
+        placement_t p;
+        p.src16 = clone_dvec(h, tc->src16); p.bits = clone_dvec(h, tc->bits); p.delta1 = clone_dvec(h, tc->delta1); p.wrec = clone_dvec(h, tc->wrec);
+        p.dstl12 = clone_dvec(h, tc->dstl12); p.dstl16 = clone_dvec(h, tc->dstl16); p.part = clone_dvec(h, part);
+        if (tc->weights.ptr) {
+          p.weights.alloc(tc->weights.bytes);
+          HIP_TRY(hipMemcpyAsync(p.weights.ptr, tc->weights.ptr, tc->weights.bytes, hipMemcpyDeviceToDevice, h.stream));
+        }
+        swap_in(p);  // p now holds the previous best
+        double const ms = time_plan();
+        if (trace) fprintf(stderr, "[pagerank plan] placement %d: %.4f ms per iteration%s\n", t, ms, ms < best ? "  (kept)" : "");
+        if (ms < best) best = ms; else swap_in(p);  // p holds the loser either way
+        losers.push_back(std::move(p));
+      }
+    } catch (api_error const& e) {  // no memory for another copy: the best placement so far stays
+      if (e.code != CUGRAPH_ALLOC_ERROR) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); throw; }
+    }
+    h.sync();
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    losers.clear();
+    tiled_initial_state();  // the trial iterations ran on the plan's own vectors
+    return best;
+  }
+
   void flush_tiled_scalars()
   {
     if (!pending_finish) return;
@@ -926,12 +1022,9 @@ struct pagerank_plan : pagerank_plan_base {
     }
     // iteration-0 state: x = pr / out_w, dangling mass, base
     if (tiled) {
-      setup_const_rows(!personalized && !ig_s);
-      int n = tiled_prologue<WT>(h, *tc, (WT const*)pr.data(), outw, x0.data(), nv, tpartials.data());
-      // the rows without in-edges start from the uniform value (there is no user vector when they are left out)
-      tiled_finish<WT>(h, tiled_epi(nullptr), n, crows.nI_act > 0 ? (double)(WT(1) / (WT)nv) : -1.0);
-      cur = 0;
-      h.sync();
+      const_rows_allowed = !personalized && !ig_s;
+      tiled_initial_state();
+      if (char const* env = getenv("CUGRAPH_AMD_PR_PLACEMENT_TRIALS")) (void)tune(atoi(env));  // (default: the caller asks for it, cugraph_amd_pagerank_plan_tune)
       return;
     }
     int pgrid = std::min(grid_for(nv, 256, 2048), 2048);
@@ -954,6 +1047,7 @@ struct pagerank_plan : pagerank_plan_base {
   void step(double epsilon, size_t max_iterations, size_t* done, bool* converged) override
   {
     HIP_TRY(hipSetDevice(h.device));
+    stepped = true;
     static bool attr_set[4] = {false, false, false, false};
     auto set_attr = [&](auto kernel, int slot) {
       if (!attr_set[slot]) {
@@ -2343,6 +2437,16 @@ extern "C" cugraph_error_code_t cugraph_amd_pagerank_plan_step(cugraph_amd_pager
     reinterpret_cast<pagerank_plan_base*>(plan)->step(epsilon, max_iterations, &done, &conv);
     if (iterations_done) *iterations_done = done;
     if (converged) *converged = conv ? TRUE : FALSE;
+  });
+}
+extern "C" cugraph_error_code_t cugraph_amd_pagerank_plan_tune(cugraph_amd_pagerank_plan_t* plan, size_t placements, double* ms_per_iteration,
+                                                               cugraph_error_t** error)
+{
+  if (ms_per_iteration) *ms_per_iteration = 0.0;
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr, CUGRAPH_INVALID_INPUT, "plan is NULL");
+    double const ms = reinterpret_cast<pagerank_plan_base*>(plan)->tune((int)std::min<size_t>(placements, 64));
+    if (ms_per_iteration) *ms_per_iteration = ms;
   });
 }
 extern "C" cugraph_error_code_t cugraph_amd_pagerank_plan_result(cugraph_amd_pagerank_plan_t* plan, size_t total_iterations, bool_t converged,

@@ -659,6 +659,13 @@ class PageRankPlan:
         self.ptr = plan
         self.iterations = 0
 
+    def tune(self, placements=8):
+        """extensions.h cugraph_amd_pagerank_plan_tune: before the first step, time the plan on `placements` placements of its streamed arrays and keep
+        the fastest; returns the kept placement's milliseconds per iteration (0.0: nothing to tune)"""
+        ms, err = C.c_double(0.0), C.c_void_p()
+        assert_success(capi.lib().cugraph_amd_pagerank_plan_tune(self.ptr, int(placements), C.byref(ms), C.byref(err)), err, "cugraph_amd_pagerank_plan_tune")
+        return float(ms.value)
+
     def step(self, n_iterations, epsilon=0.0):
         done, conv, err = C.c_size_t(0), C.c_int(0), C.c_void_p()
         code = capi.lib().cugraph_amd_pagerank_plan_step(self.ptr, float(epsilon), int(n_iterations), C.byref(done), C.byref(conv), C.byref(err))

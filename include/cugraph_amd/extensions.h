@@ -44,6 +44,13 @@ CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_plan_create(
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_plan_step(
   cugraph_amd_pagerank_plan_t* plan, double epsilon, size_t max_iterations, size_t* iterations_done,
   bool_t* converged, cugraph_error_t** error);
+/* Optional, before the first step: the plan times itself (about ten iterations each) on `placements` fresh allocations of its large streamed arrays
+ * -- same contents, other physical pages -- and keeps the fastest; *ms_per_iteration = the kept one's time (0: nothing to tune for this plan / graph).
+ * On MI355X the same plan runs in a +-2.5 % band depending on where its arrays lie; a solver that steps the plan hundreds
+ * of times gets ~2 % for ~0.15 s at RMAT-26, a one-shot cugraph_pagerank would lose -- hence an explicit call (CUGRAPH_AMD_PR_PLACEMENT_TRIALS=n makes
+ * every plan creation do it).  The result vector is unaffected bit for bit. */
+CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_plan_tune(cugraph_amd_pagerank_plan_t* plan, size_t placements,
+                                                                  double* ms_per_iteration, cugraph_error_t** error);
 CUGRAPH_EXPORT cugraph_error_code_t cugraph_amd_pagerank_plan_result(
   cugraph_amd_pagerank_plan_t* plan, size_t total_iterations, bool_t converged,
   cugraph_centrality_result_t** result, cugraph_error_t** error);

@@ -371,6 +371,31 @@ def test_pagerank_is_reproducible(cg, handle, orc, monkeypatch):
         assert np.array_equal(a, b), kern
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_pagerank_plan_tune_keeps_the_bits(cg, handle, orc, weighted):
+    """cugraph_amd_pagerank_plan_tune (the plan times itself on several placements of its streamed arrays and keeps the fastest): only addresses
+    change -- a tuned plan and an untuned one must produce bit-identical vectors, the tuned placement (cached on the graph) must serve a later
+    plan and the ordinary entry point as well, and tuning after the first step is refused."""
+    s, d = rmat_graph(orc, 16)
+    w = int_weights(s.size) if weighted else None
+    g = make_graph(cg, handle, s, d, w, transposed=True, renumber=True, vertices=np.arange(1 << 16))
+    a = cg.PageRankPlan(handle, g, 0.85)
+    a.step(9)
+    _, pa, _ = a.result()
+    b = cg.PageRankPlan(handle, g, 0.85)
+    assert b.tune(5) > 0.0
+    b.step(9)
+    vb, pb, _ = b.result()
+    assert np.array_equal(pa.cpu().numpy(), pb.cpu().numpy())
+    with pytest.raises(Exception):
+        b.tune(2)
+    c = cg.PageRankPlan(handle, g, 0.85)  # a later plan of the graph: the arrays the tuned plan kept
+    c.step(9)
+    assert np.array_equal(c.result()[1].cpu().numpy(), pa.cpu().numpy())
+    v, pr, _ = cg.pagerank(handle, g, None, None, None, None, 0.85, 0.0, 9, False, fail_on_nonconvergence=False)
+    assert np.array_equal(pr.cpu().numpy(), pa.cpu().numpy()) and np.array_equal(v.cpu().numpy(), vb.cpu().numpy())
+
+
 @pytest.mark.parametrize("hot", [0, 256, 1024, 16384, 32768])
 def test_pagerank_lds_tile_sizes_agree(cg, handle, orc, hot):
     s, d = rmat_graph(orc, 15, seed=2)

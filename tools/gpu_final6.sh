@@ -13,9 +13,11 @@ cp "$O/traffic_latest.json" profiles/traffic_latest.json
 timeout 900 python bench.py 2>"$O/${TAG}_bench.err" > "$O/${TAG}_bench_s26.json"; echo "bench rc=$?"; cut -c1-200 "$O/${TAG}_bench_s26.json"
 # the driver's own command line, three fresh processes (the spread between processes: DESIGN.md section 3.1, round 6)
 for i in 1 2 3; do timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-check 2>/dev/null > "$O/${TAG}_bench_s26_rep$i.json"; cut -c1-130 "$O/${TAG}_bench_s26_rep$i.json"; done
+# the same without the plan's placement tuning (what rounds 1-5 and the first r6z session measured)
+for i in 1 2 3; do timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --placements 1 --no-extras --no-cpu-baseline --no-check 2>/dev/null > "$O/${TAG}_bench_s26_untuned_rep$i.json"; cut -c1-130 "$O/${TAG}_bench_s26_untuned_rep$i.json"; done
 for sc in 22 23 24 25; do timeout 300 python bench.py --scale $sc --no-extras --cpu-scale 20 2>/dev/null > "$O/${TAG}_bench_s$sc.json"; cut -c1-120 "$O/${TAG}_bench_s$sc.json"; done
 ( cd /tmp && export TMPDIR=/tmp
-rm -rf "$O/prof_$TAG"; timeout 300 rocprofv3 --kernel-trace --stats -d "$O/prof_$TAG/pr" -o run -- python "$R/bench.py" --steps 20 --warmup 1 --no-check --no-cpu-baseline --no-extras > "$O/prof_$TAG.log" 2>&1
+rm -rf "$O/prof_$TAG"; timeout 300 rocprofv3 --kernel-trace --stats -d "$O/prof_$TAG/pr" -o run -- python "$R/bench.py" --steps 20 --warmup 1 --placements 1 --no-check --no-cpu-baseline --no-extras > "$O/prof_$TAG.log" 2>&1  # (untuned: every launch of the trace is a launch of the ONE placement the line's averages are about)
 timeout 300 rocprofv3 --kernel-trace --stats -d "$O/prof_$TAG/trav" -o run -- python "$R/bench_traversal.py" --scale 24 --weights int --roots 8 --no-cpu-baseline --no-check >> "$O/prof_$TAG.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d "$O/prof_$TAG/louv" -o run -- python "$R/bench_louvain.py" --scale 22 --cpu-scale 0 --repeats 3 >> "$O/prof_$TAG.log" 2>&1
 python "$R/tools/rocpd_summary.py" "$O/prof_$TAG/pr" > "$O/${TAG}_s26_rocprofv3_summary.txt" 2>&1

@@ -63,7 +63,7 @@ def measure(key, cmd_lo, cmd_hi, units_lo, units_hi, what):
 def main():
     py = sys.executable
     only = set(sys.argv[1:])
-    bench = [py, str(ROOT / "bench.py"), "--scale", "26", "--warmup", "1", "--no-check", "--no-cpu-baseline", "--no-extras", "--no-phase-pass"]
+    bench = [py, str(ROOT / "bench.py"), "--scale", "26", "--warmup", "1", "--no-check", "--no-cpu-baseline", "--no-extras", "--no-phase-pass", "--placements", "1"]
     trav = [py, str(ROOT / "bench_traversal.py"), "--scale", "24", "--no-cpu-baseline", "--no-check", "--single-variant"]  # with predecessors (the headline since round 5)
     louv = [py, str(ROOT / "bench_louvain.py"), "--scale", "22", "--cpu-scale", "0"]
     work = {
