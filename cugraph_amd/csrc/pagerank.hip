@@ -886,60 +886,112 @@ struct pagerank_plan : pagerank_plan_base {
     CGA_EXPECTS(!stepped, CUGRAPH_INVALID_INPUT, "pagerank plan: tune() must come before the first step()");
     if (!tiled || placements <= 1 || g.ne == 0 || force_diff || force_write_pr) return 0.0;
     bool const trace = getenv("CUGRAPH_AMD_PR_PLACEMENT_TRACE") != nullptr;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
     constexpr int kWarm = 2, kTimed = 8;
-    auto time_plan = [&]() -> double {
+    hipEvent_t ev[2 * kTimed + 1];
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    auto free_events = [&] { for (auto& e : ev) (void)hipEventDestroy(e); };
+    struct times_t { double p1, p2; double total() const { return p1 + p2; } };
+    // one event in front of every launch of the timed iterations: phase 1 of iteration i = ev[2i] .. ev[2i + 1] (the launch gap rides with it), phase 2 =
+    // ev[2i + 1] .. ev[2i + 2]
+    auto time_plan = [&]() -> times_t {
       for (int i = 0; i < kWarm; ++i) { iterate_tiled(false, false); cur ^= 1; }
-      HIP_TRY(hipEventRecord(e0, h.stream));
-      for (int i = 0; i < kTimed; ++i) { iterate_tiled(false, false); cur ^= 1; }
-      HIP_TRY(hipEventRecord(e1, h.stream));
-      HIP_TRY(hipEventSynchronize(e1));
-      float ms = 0;
-      HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-      return (double)ms / kTimed;
+      for (int i = 0; i < kTimed; ++i) {
+        WT const* xcur = cur == 0 ? x0.data() : x1.data();
+        WT* xnext      = cur == 0 ? x1.data() : x0.data();
+        tiled_epilogue<WT> e = tiled_epi(xnext);
+        e.need_diff = false; e.write_pr = false;
+        HIP_TRY(hipEventRecord(ev[2 * i], h.stream));
+        tiled_phase1<WT>(h, *tc, xcur, alpha, part.data(), counters.data(), tiled_x_map<WT>{}, pending_finish ? &e : nullptr);
+        HIP_TRY(hipEventRecord(ev[2 * i + 1], h.stream));
+        tiled_phase2<WT>(h, *tc, (WT const*)part.data(), e, counters.data());
+        pending_finish = true;
+        cur ^= 1;
+      }
+      HIP_TRY(hipEventRecord(ev[2 * kTimed], h.stream));
+      HIP_TRY(hipEventSynchronize(ev[2 * kTimed]));
+      times_t t{0, 0};
+      for (int i = 0; i < kTimed; ++i) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, ev[2 * i], ev[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, ev[2 * i + 1], ev[2 * i + 2]));
+        t.p1 += a / kTimed; t.p2 += b / kTimed;
+      }
+      return t;
     };
-    struct placement_t {  // the arrays an iteration streams: phase 1 reads src16 / bits / weights / wrec / delta1 and writes part, phase 2 reads part and dstl*
+    // The arrays an iteration streams, in three groups: A = what phase 1 reads (src16, bits, weights, delta1, wrec), B = the partial buffer (phase 1 writes
+    // it, phase 2 reads it), C = the destinations phase 2 reads (dstl12 / dstl16)
+    struct placement_t {
       dvec<uint16_t> src16; dvec<uint32_t> bits; dev_buf weights; dvec<uint32_t> delta1, wrec, dstl12; dvec<uint16_t> dstl16; dvec<WT> part;
+      unsigned groups{0};
     };
-    auto swap_in = [&](placement_t& p) {
-      std::swap(tc->src16, p.src16); std::swap(tc->bits, p.bits); std::swap(tc->weights, p.weights); std::swap(tc->delta1, p.delta1);
-      std::swap(tc->wrec, p.wrec); std::swap(tc->dstl12, p.dstl12); std::swap(tc->dstl16, p.dstl16); std::swap(part, p.part);
-    };
-    size_t const clone_bytes = tc->src16.buf.bytes + tc->bits.buf.bytes + tc->weights.bytes + tc->delta1.buf.bytes + tc->wrec.buf.bytes + tc->dstl12.buf.bytes +
-                               tc->dstl16.buf.bytes + part.buf.bytes;
-    (void)time_plan();  // (the first timing after a build is 2-5 % slow whatever the placement: clocks, first touches)
-    double best = time_plan();
-    if (trace) fprintf(stderr, "[pagerank plan] placement 0: %.4f ms per iteration\n", best);
-    std::vector<placement_t> losers;  // kept until the end: a block handed back to the pool would be the next trial's "fresh" allocation
-    try {
-      for (int t = 1; t < placements; ++t) {
-        size_t free_b = 0, total_b = 0;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        if ((losers.size() + 2) * clone_bytes > total_b / 4) break;  // the trials never hold more than a quarter of the device
-        placement_t p;
+    enum : unsigned { GA = 1, GB = 2, GC = 4 };
+    auto clone = [&](unsigned groups) {
+      placement_t p;
+      p.groups = groups;
+      if (groups & GA) {
         p.src16 = clone_dvec(h, tc->src16); p.bits = clone_dvec(h, tc->bits); p.delta1 = clone_dvec(h, tc->delta1); p.wrec = clone_dvec(h, tc->wrec);
-        p.dstl12 = clone_dvec(h, tc->dstl12); p.dstl16 = clone_dvec(h, tc->dstl16); p.part = clone_dvec(h, part);
         if (tc->weights.ptr) {
           p.weights.alloc(tc->weights.bytes);
           HIP_TRY(hipMemcpyAsync(p.weights.ptr, tc->weights.ptr, tc->weights.bytes, hipMemcpyDeviceToDevice, h.stream));
         }
-        swap_in(p);  // p now holds the previous best
-        double const ms = time_plan();
-        if (trace) fprintf(stderr, "[pagerank plan] placement %d: %.4f ms per iteration%s\n", t, ms, ms < best ? "  (kept)" : "");
-        if (ms < best) best = ms; else swap_in(p);  // p holds the loser either way
+      }
+      if (groups & GB) p.part = clone_dvec(h, part);
+      if (groups & GC) { p.dstl12 = clone_dvec(h, tc->dstl12); p.dstl16 = clone_dvec(h, tc->dstl16); }
+      return p;
+    };
+    auto swap_in = [&](placement_t& p) {
+      if (p.groups & GA) { std::swap(tc->src16, p.src16); std::swap(tc->bits, p.bits); std::swap(tc->weights, p.weights); std::swap(tc->delta1, p.delta1); std::swap(tc->wrec, p.wrec); }
+      if (p.groups & GB) std::swap(part, p.part);
+      if (p.groups & GC) { std::swap(tc->dstl12, p.dstl12); std::swap(tc->dstl16, p.dstl16); }
+    };
+    size_t const bytes_a = tc->src16.buf.bytes + tc->bits.buf.bytes + tc->weights.bytes + tc->delta1.buf.bytes + tc->wrec.buf.bytes;
+    size_t const bytes_b = part.buf.bytes, bytes_c = tc->dstl12.buf.bytes + tc->dstl16.buf.bytes;
+    (void)time_plan();  // (the first timing after a build is 2-5 % slow whatever the placement: clocks, first touches)
+    times_t best = time_plan();
+    auto where = [&] {
+      char buf[256];
+      snprintf(buf, sizeof buf, " | part %p (%zu of %zu granted) src16 %p (%zu of %zu) dstl12 %p (%zu of %zu)", (void*)part.data(), part.buf.bytes, part.buf.granted, (void*)tc->src16.data(),
+               tc->src16.buf.bytes, tc->src16.buf.granted, (void*)tc->dstl12.data(), tc->dstl12.buf.bytes, tc->dstl12.buf.granted);
+      return std::string(buf);
+    };
+    if (trace) fprintf(stderr, "[pagerank plan] placement 0: phase 1 %.4f + phase 2 %.4f = %.4f ms per iteration%s\n", best.p1, best.p2, best.total(), where().c_str());
+    std::vector<placement_t> losers;  // kept until the end: a block handed back to the pool would be the next trial's "fresh" allocation
+    size_t held = 0;
+    // the schedule: the first placements re-roll everything; the later ones one group at a time, judged by the phase(s) that stream it.  What the traces
+    // say (profiles/r6v_placement_groups.txt): the partial buffer (B) decides most -- a "bad" one costs phase 1 0.02 ms AND phase 2 0.025 ms at RMAT-26 --,
+    // phase 1's read streams (A) are bimodal as well (0.93 / 0.98 ms), C is worth up to 0.01 ms of phase 2; allocations made late, with much memory
+    // held, are mostly bad (14 placements are no better than 8)
+    auto groups_of = [&](int t) -> unsigned {
+      if (t <= 4) return GA | GB | GC;
+      switch ((t - 5) % 3) { case 0: return GA; case 1: return GC; default: return GB; }
+    };
+    try {
+      for (int t = 1; t < placements; ++t) {
+        unsigned const gr = groups_of(t);
+        size_t const need = ((gr & GA) ? bytes_a : 0) + ((gr & GB) ? bytes_b : 0) + ((gr & GC) ? bytes_c : 0);
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        if (held + 2 * need > total_b / 4) break;  // the trials never hold more than a quarter of the device
+        placement_t p = clone(gr);
+        swap_in(p);  // p now holds the previous best's arrays of these groups
+        times_t const ms = time_plan();
+        // a group is judged by the phases that stream it: A by phase 1, C by phase 2, B and whole placements by the iteration
+        bool const better = gr == GA ? ms.p1 < best.p1 : gr == GC ? ms.p2 < best.p2 : ms.total() < best.total();
+        if (trace)
+          fprintf(stderr, "[pagerank plan] placement %d (%s%s%s): phase 1 %.4f + phase 2 %.4f = %.4f ms per iteration%s\n", t, (gr & GA) ? "A" : "", (gr & GB) ? "B" : "",
+                  (gr & GC) ? "C" : "", ms.p1, ms.p2, ms.total(), (std::string(better ? "  (kept)" : "") + where()).c_str());
+        if (better) best = ms; else swap_in(p);  // p holds the loser either way
+        held += need;
         losers.push_back(std::move(p));
       }
     } catch (api_error const& e) {  // no memory for another copy: the best placement so far stays
-      if (e.code != CUGRAPH_ALLOC_ERROR) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); throw; }
+      if (e.code != CUGRAPH_ALLOC_ERROR) { free_events(); throw; }
     }
     h.sync();
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    free_events();
     losers.clear();
     tiled_initial_state();  // the trial iterations ran on the plan's own vectors
-    return best;
+    return best.total();
   }
 
   void flush_tiled_scalars()
