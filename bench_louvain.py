@@ -31,6 +31,11 @@ def undirected_rmat(cg, h, scale, edge_factor, seed=5):
     lo, hi = key >> 32, key & 0xFFFFFFFF
     wt = (1 + (lo * 7 + hi * 13) % 8).to(torch.float32)
     s2, d2, w2 = torch.cat([lo, hi]), torch.cat([hi, lo]), torch.cat([wt, wt])
+    if os.environ.get("BENCH_LOUVAIN_RELABEL") == "degree":  # experiment: the same graph with its vertices numbered by descending degree (another clustering: ties break on ids)
+        deg = torch.bincount(s2, minlength=1 << scale)
+        rank = torch.empty_like(deg)
+        rank[torch.argsort(-deg, stable=True)] = torch.arange(deg.numel(), device=deg.device)
+        s2, d2 = rank[s2], rank[d2]
     order = torch.argsort(s2 << 32 | d2)
     return s2[order].to(torch.int32), d2[order].to(torch.int32), w2[order]
 

@@ -259,7 +259,8 @@ __global__ void k_segment_best(lv_flat_args A)
 constexpr int LVH_B = 512, LVH_CAP = 2 * LVH_B, LVH_SLOTS = 2048, LVH_THREADS = LVH_THREADS_N;
 constexpr unsigned long long LVH_EMPTY = ~0ull;
 struct lv_hash_args {
-  int32_t const* src; int32_t const* dst; int32_t const* off; double const* w; int32_t const* c; double const* k; double const* a;
+  int32_t const* src; int32_t const* dst; double const* w; double const* k;
+  int4 const* ca;                 // [nv] per vertex u: (c[u], -, a[c[u]] as two words) -- ONE 16-byte gather per edge instead of c[u] and then a[c[u]] (k_lv_pack_ca, once per sweep)
   double m, resolution, scale, inv_scale; int64_t ne;
   unsigned long long* best_bits;  // [nv]
   int32_t* best_c;                // [nv]
@@ -267,12 +268,13 @@ struct lv_hash_args {
   // what depends on the level's graph only (round 5: computed once per level by k_lv_chunk_prep instead of by every sweep's workgroups --
   // a chain of four dependent loads on ONE thread before a workgroup could start, and src -> off per edge)
   long long const* range;         // [chunks][2] edge range [p0, p1) of every chunk (p1 <= p0: nothing)
-  uint16_t const* rs;             // [ne] row slot of every edge = position of its row's first edge inside that row's window (off[src] mod LVH_B)
+  uint16_t const* rs;             // [ne] row slot of every edge = position of its row's first edge inside that row's window (off[src] mod LVH_B); bit 15: the edge is a self-loop
 };
 __device__ __forceinline__ uint32_t lvh_slot(uint32_t rs, uint32_t cl) { return ((rs * 0x9E3779B1u) ^ (cl * 0x85EBCA6Bu) ^ (cl >> 15)) & (LVH_SLOTS - 1); }
-static_assert((LVH_B & (LVH_B - 1)) == 0, "the row slot is off[v] mod LVH_B");
+static_assert((LVH_B & (LVH_B - 1)) == 0 && LVH_B <= 0x8000, "the row slot is off[v] mod LVH_B and shares 16 bits with the self-loop flag");
+static_assert(LVH_CAP % LVH_THREADS == 0, "a chunk's edges live in registers between the passes: LVH_CAP / LVH_THREADS per thread");
 // once per level: the edge range of every chunk (the rule of round 3, see above) and the row slot of every edge
-__global__ void k_lv_chunk_prep(int32_t const* src, int32_t const* off, int64_t ne, long long* range, uint16_t* rs)
+__global__ void k_lv_chunk_prep(int32_t const* src, int32_t const* dst, int32_t const* off, int64_t ne, long long* range, uint16_t* rs)
 {
   int64_t const t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
   int64_t const n_chunks = (ne + LVH_B - 1) / LVH_B;
@@ -288,98 +290,132 @@ __global__ void k_lv_chunk_prep(int32_t const* src, int32_t const* off, int64_t 
     range[2 * b]     = p0;
     range[2 * b + 1] = p1 > p0 ? p1 : p0;
   }
-  for (int64_t e = t; e < ne; e += stride) rs[e] = (uint16_t)((uint32_t)off[src[e]] & (uint32_t)(LVH_B - 1));
+  for (int64_t e = t; e < ne; e += stride) rs[e] = (uint16_t)(((uint32_t)off[src[e]] & (uint32_t)(LVH_B - 1)) | (src[e] == dst[e] ? 0x8000u : 0u));
 }
+// once per sweep: the destination's cluster and that cluster's weight side by side (nv gathers of a[] instead of one per edge)
+__global__ void k_lv_pack_ca(int32_t const* c, double const* a, int64_t nv, int4* ca)
+{
+  LV_LOOP(v, nv)
+  {
+    int32_t const cl = c[v];
+    long long const ab = __double_as_longlong(a[cl]);
+    ca[v] = make_int4(cl, 0, (int32_t)(uint32_t)(unsigned long long)ab, (int32_t)(uint32_t)((unsigned long long)ab >> 32));
+  }
+}
+__device__ __forceinline__ double lv_ca_weight(int4 const& q) { return __longlong_as_double((long long)(((unsigned long long)(uint32_t)q.w << 32) | (unsigned long long)(uint32_t)q.z)); }
+// LVH_E = LVH_CAP / LVH_THREADS edges per thread (a chunk has fewer than 2 * LVH_B edges): an edge's cluster, table slot, cluster weight and gain
+// stay in registers between the passes; global memory is touched once per edge -- (row slot, destination, weight) streamed, ONE 16-byte gather --
+// and once per row (source, the row's own pair, its vertex weight).  Round 6: was two dependent gathers per edge (c[dst], then a[c[dst]] in
+// the second pass) and a re-probe of the table per edge.
+constexpr int LVH_E = LVH_CAP / LVH_THREADS;
 __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
 {
   __shared__ unsigned long long s_key[LVH_SLOTS], s_sum[LVH_SLOTS];
-  __shared__ unsigned long long s_bits[LVH_CAP];
   __shared__ unsigned long long s_sub[LVH_B], s_best[LVH_B];
   __shared__ double s_k[LVH_B], s_acv[LVH_B];  // per row: the vertex's weight, the weight of its cluster (gathered once per row, by the row's first edge)
   __shared__ int32_t s_bestc[LVH_B], s_cv[LVH_B];
-  __shared__ uint32_t s_cl[LVH_CAP];
-  __shared__ uint16_t s_rs[LVH_CAP];
   __shared__ unsigned long long s_int;
   int const tid = threadIdx.x;
   int64_t const e_lo = blockIdx.x * (int64_t)LVH_B;
   int64_t const p0   = A.range[2 * (int64_t)blockIdx.x];
   int const n        = (int)(A.range[2 * (int64_t)blockIdx.x + 1] - p0);  // < 2 * LVH_B
   if (n <= 0) return;
+  uint32_t rsf[LVH_E];
+  int32_t u[LVH_E];
+  double w[LVH_E];
+#pragma unroll
+  for (int j = 0; j < LVH_E; ++j) {  // (in flight while the tables are cleared)
+    int const i = tid + j * LVH_THREADS;
+    rsf[j] = 0; u[j] = 0; w[j] = 0.0;
+    if (i < n) { rsf[j] = A.rs[p0 + i]; u[j] = A.dst[p0 + i]; w[j] = A.w[p0 + i]; }
+  }
   if (tid == 0) s_int = 0;
   for (int i = tid; i < LVH_SLOTS; i += LVH_THREADS) { s_key[i] = LVH_EMPTY; s_sum[i] = 0; }
   for (int i = tid; i < LVH_B; i += LVH_THREADS) { s_sub[i] = 0; s_best[i] = 0; s_bestc[i] = 0x7f7f7f7f; }
+  int4 cau[LVH_E], cav[LVH_E];
+  int32_t v[LVH_E];
+  double kv[LVH_E];
+  bool first[LVH_E];
+#pragma unroll
+  for (int j = 0; j < LVH_E; ++j) {
+    int const i = tid + j * LVH_THREADS;
+    cau[j] = make_int4(0, 0, 0, 0); cav[j] = cau[j]; v[j] = -1; kv[j] = 0.0;
+    first[j] = i < n && (uint32_t)(p0 + i - e_lo) == (rsf[j] & 0x7fffu);  // the row's first edge (rows of a chunk start inside its window)
+    if (i < n) cau[j] = A.ca[u[j]];
+    if (first[j]) v[j] = A.src[p0 + i];
+  }
+#pragma unroll
+  for (int j = 0; j < LVH_E; ++j)
+    if (first[j]) { cav[j] = A.ca[v[j]]; kv[j] = A.k[v[j]]; }
   __syncthreads();
   // pass 1: (row slot, cluster of destination) -> sum of weights; self-loops per row; the row's own operands of the gain
-  for (int i = tid; i < n; i += LVH_THREADS) {
-    int64_t const e  = p0 + i;
-    int32_t const v  = A.src[e], u = A.dst[e];
-    uint32_t const rs = A.rs[e];
-    uint32_t const cl = (uint32_t)A.c[u];
-    unsigned long long const wf  = (unsigned long long)__double2ll_rn(A.w[e] * A.scale);
-    unsigned long long const key = ((unsigned long long)rs << 32) | cl;
-    s_cl[i] = cl;
-    s_rs[i] = (uint16_t)rs;
-    if ((uint32_t)(e - e_lo) == rs) {  // the row's first edge (rows of a chunk start inside its window)
-      int32_t const cv = A.c[v];
-      s_cv[rs]  = cv;
-      s_k[rs]   = A.k[v];
-      s_acv[rs] = A.a[cv];
+  uint32_t slot[LVH_E];
+#pragma unroll
+  for (int j = 0; j < LVH_E; ++j) {
+    uint32_t const rs = rsf[j] & 0x7fffu, cl = (uint32_t)cau[j].x;
+    slot[j] = lvh_slot(rs, cl);
+    if (tid + j * LVH_THREADS < n) {
+      unsigned long long const wf  = (unsigned long long)__double2ll_rn(w[j] * A.scale);
+      unsigned long long const key = ((unsigned long long)rs << 32) | cl;
+      for (;;) {
+        unsigned long long const old = atomicCAS(&s_key[slot[j]], LVH_EMPTY, key);
+        if (old == LVH_EMPTY || old == key) break;
+        slot[j] = (slot[j] + 1) & (LVH_SLOTS - 1);
+      }
+      atomicAdd(&s_sum[slot[j]], wf);
+      if (rsf[j] & 0x8000u) atomicAdd(&s_sub[rs], wf);
     }
-    uint32_t slot = lvh_slot(rs, cl);
-    for (;;) {
-      unsigned long long const old = atomicCAS(&s_key[slot], LVH_EMPTY, key);
-      if (old == LVH_EMPTY || old == key) break;
-      slot = (slot + 1) & (LVH_SLOTS - 1);
-    }
-    atomicAdd(&s_sum[slot], wf);
-    if (u == v) atomicAdd(&s_sub[rs], wf);
+    if (first[j]) { s_cv[rs] = cav[j].x; s_k[rs] = kv[j]; s_acv[rs] = lv_ca_weight(cav[j]); }
   }
   __syncthreads();
-  auto lookup = [&](uint32_t rs, uint32_t cl) -> unsigned long long {  // 0 when the row has no edge into the cluster
-    unsigned long long const key = ((unsigned long long)rs << 32) | cl;
-    uint32_t slot = lvh_slot(rs, cl);
+  auto lookup = [&](uint32_t rs2, uint32_t cl2) -> unsigned long long {  // 0 when the row has no edge into the cluster
+    unsigned long long const key = ((unsigned long long)rs2 << 32) | cl2;
+    uint32_t sl = lvh_slot(rs2, cl2);
     for (;;) {
-      unsigned long long const k2 = s_key[slot];
-      if (k2 == key) return s_sum[slot];
+      unsigned long long const k2 = s_key[sl];
+      if (k2 == key) return s_sum[sl];
       if (k2 == LVH_EMPTY) return 0ull;
-      slot = (slot + 1) & (LVH_SLOTS - 1);
+      sl = (sl + 1) & (LVH_SLOTS - 1);
     }
   };
-  // pass 2: the gain of every edge's (row, cluster) pair (pairs that occur on several edges are evaluated as often: same value); the only
-  // global access left here is the weight of the destination's cluster
-  for (int i = tid; i < n; i += LVH_THREADS) {
-    uint32_t const rs = s_rs[i], cl = s_cl[i];
-    int32_t const cv  = s_cv[rs];
-    unsigned long long const sfix = lookup(rs, cl);
-    unsigned long long const self = (int32_t)cl == cv ? sfix : lookup(rs, (uint32_t)cv);
-    unsigned long long const subf = s_sub[rs];
-    double const s       = (double)(long long)sfix * A.inv_scale;
-    double const sub     = (double)(long long)subf * A.inv_scale;
-    double const old_sum = (double)(long long)(self - subf) * A.inv_scale;
-    double const new_sum = (int32_t)cl == cv ? s - sub : s;
-    double const delta   = lv_delta(new_sum, old_sum, A.a[cl], s_acv[rs], s_k[rs], A.m, A.resolution);
-    unsigned long long const bits = delta > 0.0 ? (unsigned long long)__double_as_longlong(delta) : 0ull;
-    s_bits[i] = bits;
-    if (bits) atomicMax(&s_best[rs], bits);  // positive doubles order like their bit patterns
+  // pass 2: the gain of every edge's (row, cluster) pair (pairs that occur on several edges are evaluated as often: same value)
+  unsigned long long bits[LVH_E];
+#pragma unroll
+  for (int j = 0; j < LVH_E; ++j) {
+    bits[j] = 0;
+    if (tid + j * LVH_THREADS < n) {
+      uint32_t const rs = rsf[j] & 0x7fffu, cl = (uint32_t)cau[j].x;
+      int32_t const cv = s_cv[rs];
+      unsigned long long const sfix = s_sum[slot[j]];
+      unsigned long long const self = (int32_t)cl == cv ? sfix : lookup(rs, (uint32_t)cv);
+      unsigned long long const subf = s_sub[rs];
+      double const s       = (double)(long long)sfix * A.inv_scale;
+      double const sub     = (double)(long long)subf * A.inv_scale;
+      double const old_sum = (double)(long long)(self - subf) * A.inv_scale;
+      double const new_sum = (int32_t)cl == cv ? s - sub : s;
+      double const delta   = lv_delta(new_sum, old_sum, lv_ca_weight(cau[j]), s_acv[rs], s_k[rs], A.m, A.resolution);
+      bits[j] = delta > 0.0 ? (unsigned long long)__double_as_longlong(delta) : 0ull;
+      if (bits[j]) atomicMax(&s_best[rs], bits[j]);  // positive doubles order like their bit patterns
+    }
   }
   __syncthreads();
   // pass 3: the smallest cluster id among the pairs that attain the row's maximum (the reference's tie rule)
-  for (int i = tid; i < n; i += LVH_THREADS) {
-    unsigned long long const bits = s_bits[i];
-    if (bits && bits == s_best[s_rs[i]]) atomicMin(&s_bestc[s_rs[i]], (int32_t)s_cl[i]);
+#pragma unroll
+  for (int j = 0; j < LVH_E; ++j) {
+    uint32_t const rs = rsf[j] & 0x7fffu;
+    if (bits[j] && bits[j] == s_best[rs]) atomicMin(&s_bestc[rs], cau[j].x);
   }
   __syncthreads();
-  for (int i = tid; i < n; i += LVH_THREADS) {
-    int64_t const e   = p0 + i;
-    uint32_t const rs = s_rs[i];
-    if ((uint32_t)(e - e_lo) == rs) {  // first edge of a row
-      int32_t const v = A.src[e];
-      A.best_bits[v] = s_best[rs];
-      A.best_c[v]    = s_best[rs] ? s_bestc[rs] : 0x7f7f7f7f;
-      unsigned long long const self = lookup(rs, (uint32_t)s_cv[rs]);
+#pragma unroll
+  for (int j = 0; j < LVH_E; ++j)
+    if (first[j]) {
+      uint32_t const rs = rsf[j] & 0x7fffu;
+      unsigned long long const best = s_best[rs];
+      A.best_bits[v[j]] = best;
+      A.best_c[v[j]]    = best ? s_bestc[rs] : 0x7f7f7f7f;
+      unsigned long long const self = lookup(rs, (uint32_t)cav[j].x);
       if (self) atomicAdd(&s_int, self);
     }
-  }
   __syncthreads();
   if (tid == 0 && s_int) atomicAdd(A.ifix, s_int);
 }
@@ -953,15 +989,37 @@ struct level_t {
   int64_t nv{0}, ne{0};
   dvec<int32_t> src, dst, off;
   dvec<double> w;
+  bool have_off{false};  // off[] holds the rows' offsets
 };
 
+// row offsets of a level whose edges are stored grouped by source, ascending (every level is: CSR order at level 0, the contraction's segment
+// order afterwards): every row's first and last position are found at the boundaries of the source column (one streaming pass), the row lengths
+// are scanned (round 6: was a histogram of the sources -- a partition by the top bits + windowed LDS counters, 1 ms per level at RMAT-22)
+__global__ void k_row_bounds(int32_t const* src, int64_t ne, uint32_t* first, uint32_t* last)  // both zero on entry
+{
+  LV_LOOP(i, ne)
+  {
+    int32_t const v = src[i];
+    if (i == 0 || src[i - 1] != v) first[v] = (uint32_t)i;
+    if (i + 1 == ne || src[i + 1] != v) last[v] = (uint32_t)(i + 1);
+  }
+}
+__global__ void k_row_lengths(uint32_t const* first, uint32_t* last, int64_t nv) { LV_LOOP(v, nv) last[v] -= first[v]; }
 void build_offsets(handle_t const& h, level_t& L)
 {
+  if (L.have_off) return;  // (level 0 of a single-GPU graph: the graph's own offsets)
   L.off.resize_discard((size_t)L.nv + 1);
-  dvec<uint32_t> cnt((size_t)L.nv + 1);
-  HIP_TRY(hipMemsetAsync(cnt.data(), 0, ((size_t)L.nv + 1) * sizeof(uint32_t), h.stream));
-  if (L.ne > 0) histogram_i32(h, L.src.data(), L.ne, cnt.data(), L.nv);
-  exclusive_scan_u32(h, cnt.data(), reinterpret_cast<uint32_t*>(L.off.data()), L.nv + 1);
+  dvec<uint32_t> fl(2 * ((size_t)L.nv + 1));
+  uint32_t* const first = fl.data();
+  uint32_t* const last  = fl.data() + L.nv + 1;
+  HIP_TRY(hipMemsetAsync(fl.data(), 0, 2 * ((size_t)L.nv + 1) * sizeof(uint32_t), h.stream));
+  if (L.ne > 0) {
+    hipLaunchKernelGGL(k_row_bounds, grid_for(L.ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)L.src.data(), L.ne, first, last);
+    hipLaunchKernelGGL(k_row_lengths, grid_for(L.nv, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)first, last, L.nv);
+  }
+  exclusive_scan_u32(h, last, reinterpret_cast<uint32_t*>(L.off.data()), L.nv + 1);
+  h.sync();  // `fl` is released here
+  L.have_off = true;
 }
 
 void sort_pairs(handle_t const& h, dvec<uint64_t>& keys, dvec<uint32_t>& vals, int64_t n, int bits)
@@ -1024,10 +1082,13 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   dvec<int32_t> big_c;
   dvec<long long> chunk_range;
   dvec<uint16_t> chunk_rs;
+  dvec<int4> ca;
   if (use_hash) {
+    ca.resize_discard((size_t)std::max<int64_t>(nv, 1));
     chunk_range.resize_discard((size_t)((ne + LVH_B - 1) / LVH_B) * 2);
     chunk_rs.resize_discard((size_t)ne);
-    hipLaunchKernelGGL(k_lv_chunk_prep, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.off.data(), ne, chunk_range.data(), chunk_rs.data());
+    hipLaunchKernelGGL(k_lv_chunk_prep, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.dst.data(), (int32_t const*)L.off.data(), ne, chunk_range.data(),
+                       chunk_rs.data());
     dvec<uint32_t> flag((size_t)ne + 1), pos((size_t)ne + 1);
     hipLaunchKernelGGL(k_lv_hub_flags, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.off.data(), ne, (int32_t)(use_mid ? LVM_MAX : LVH_B),
                        flag.data());
@@ -1137,7 +1198,8 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
       hipLaunchKernelGGL(k_segment_best<1>, g_s, kBlock, 0, h.stream, A);
     }
     if (use_hash && n_sorted < ne) {
-      lv_hash_args HA{L.src.data(), L.dst.data(), L.off.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale, ne,
+      hipLaunchKernelGGL(k_lv_pack_ca, g_v, kBlock, 0, h.stream, (int32_t const*)c.data(), (double const*)a.data(), nv, ca.data());
+      lv_hash_args HA{L.src.data(), L.dst.data(), L.w.data(), k.data(), ca.data(), m, resolution, scale, 1.0 / scale, ne,
                       vfix.data() + 2 * nv, best_c.data(), ifix, chunk_range.data(), chunk_rs.data()};
       hipLaunchKernelGGL(k_lv_hash_chunks, (int)((ne + LVH_B - 1) / LVH_B), LVH_THREADS, 0, h.stream, HA);
     }
@@ -1460,6 +1522,9 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
     if (L.ne > 0) {
       hipLaunchKernelGGL(k_expand_src, grid_for(nv0 * 16, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)o.offsets.data(), nv0, L.src.data());
       HIP_TRY(hipMemcpyAsync(L.dst.data(), o.indices.data(), L.ne * sizeof(int32_t), hipMemcpyDeviceToDevice, h.stream));
+      L.off.resize_discard((size_t)nv0 + 1);
+      HIP_TRY(hipMemcpyAsync(L.off.data(), o.offsets.data(), ((size_t)nv0 + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, h.stream));
+      L.have_off = true;
       int const ge = grid_for(L.ne, kBlock, 8192);
       if (!g.has_weights) hipLaunchKernelGGL(k_to_double<float>, ge, kBlock, 0, h.stream, (float const*)nullptr, L.ne, L.w.data());  // constant weight 1 (louvain.cpp:86-92)
       else if (g.weight_type == FLOAT64) hipLaunchKernelGGL(k_to_double<double>, ge, kBlock, 0, h.stream, o.weights.as<double const>(), L.ne, L.w.data());

@@ -122,6 +122,40 @@ def overlap(db, rx_a, rx_b, show=12):
         print(f"   {w}  start {(s0 - t0) / 1e3:>10.1f} us  end {(e0 - t0) / 1e3:>10.1f} us  dur {(e0 - s0) / 1e3:>8.1f} us")
 
 
+def segments(db, marker, last=6, top=9):
+    """Kernel time between consecutive dispatches of the kernel matching `marker` (Louvain: k_lv_chunk_prep runs once per level, so a
+    segment = one level + the contraction behind it): the `last` segments of the trace, the `top` kernels of each."""
+    import re
+
+    c = sqlite3.connect(db)
+    cur = c.cursor()
+    kcols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    st = next((x for x in ("start", "start_timestamp", "begin") if x in kcols), None)
+    en = next((x for x in ("end", "end_timestamp") if x in kcols), None)
+    if st is None or en is None:
+        print("segments: no start/end columns in", kcols)
+        return
+    rows = cur.execute(f"select name, {st}, {en} from kernels order by {st}").fetchall()
+    cuts = [i for i, r in enumerate(rows) if re.search(marker, r[0])]
+    if not cuts:
+        print(f"segments: no dispatch matches /{marker}/ in {db}")
+        return
+    cuts.append(len(rows))
+    print(f"# segments between dispatches of /{marker}/ (the last {last}) {db}")
+    for a, b in list(zip(cuts[:-1], cuts[1:]))[-last:]:
+        seg = [r for r in rows[a:b] if "cga::" in r[0]]
+        if not seg:
+            continue
+        agg = defaultdict(lambda: [0, 0])
+        for n, s0, e0 in seg:
+            k = re.sub(r"\(.*", "", n.replace("cga::(anonymous namespace)::", "").replace("void ", ""))
+            agg[k][0] += 1
+            agg[k][1] += e0 - s0
+        busy = sum(v[1] for v in agg.values())
+        print(f"  segment of {len(seg)} dispatches: wall {(seg[-1][2] - seg[0][1]) / 1e6:.3f} ms, kernels {busy / 1e6:.3f} ms: "
+              + ", ".join(f"{k} {v[0]}x {v[1] / 1e6:.3f}" for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]))
+
+
 if __name__ == "__main__":
     if "--overlap" in sys.argv:
         i = sys.argv.index("--overlap")
@@ -134,6 +168,18 @@ if __name__ == "__main__":
                     overlap(d, rx_a, rx_b)
                 except Exception as e:
                     print("overlap:", d, e)
+        sys.exit(0)
+    if "--segments" in sys.argv:
+        i = sys.argv.index("--segments")
+        rx = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
+        for a in sys.argv[1:]:
+            dbs = [a] if a.endswith(".db") else sorted(glob.glob(os.path.join(a, "**", "*.db"), recursive=True))
+            for d in dbs:
+                try:
+                    segments(d, rx)
+                except Exception as e:
+                    print("segments:", d, e)
         sys.exit(0)
     if "--per-dispatch" in sys.argv:
         i = sys.argv.index("--per-dispatch")
