@@ -264,7 +264,8 @@ struct lv_hash_args {
   double m, resolution, scale, inv_scale; int64_t ne;
   unsigned long long* best_bits;  // [nv]
   int32_t* best_c;                // [nv]
-  unsigned long long* ifix;       // += weight of the rows' edges that stay inside their cluster (fixed point): the modularity's first term
+  unsigned long long* ipart;      // [chunks] weight of the chunk's rows' edges that stay inside their cluster (fixed point): the modularity's first term.  One word per
+                                  // workgroup, summed afterwards (round 6: was one atomic per workgroup on ONE address -- 127 K of them per sweep at RMAT-22)
   // what depends on the level's graph only (round 5: computed once per level by k_lv_chunk_prep instead of by every sweep's workgroups --
   // a chain of four dependent loads on ONE thread before a workgroup could start, and src -> off per edge)
   long long const* range;         // [chunks][2] edge range [p0, p1) of every chunk (p1 <= p0: nothing)
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
   int64_t const e_lo = blockIdx.x * (int64_t)LVH_B;
   int64_t const p0   = A.range[2 * (int64_t)blockIdx.x];
   int const n        = (int)(A.range[2 * (int64_t)blockIdx.x + 1] - p0);  // < 2 * LVH_B
-  if (n <= 0) return;
+  if (n <= 0) { if (tid == 0) A.ipart[blockIdx.x] = 0; return; }
   uint32_t rsf[LVH_E];
   int32_t u[LVH_E];
   double w[LVH_E];
@@ -417,7 +418,7 @@ __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
       if (self) atomicAdd(&s_int, self);
     }
   __syncthreads();
-  if (tid == 0 && s_int) atomicAdd(A.ifix, s_int);
+  if (tid == 0) A.ipart[blockIdx.x] = s_int;
 }
 // Round 4: rows of LVH_B < degree <= LVM_MAX edges ("mid rows": a quarter of the edges of RMAT-22 that used to take the sorted path with
 // the hubs): ONE workgroup per row, the row's (cluster -> weight) sums in an LDS open-addressing table keyed by the cluster alone (at most
@@ -792,18 +793,45 @@ __global__ void __launch_bounds__(1024) k_count_moves(int32_t const* c, int32_t 
   __syncthreads();
   if (threadIdx.x < 2 && s_cnt[threadIdx.x]) atomicAdd(count + threadIdx.x, s_cnt[threadIdx.x]);
 }
-// the move, and the two cluster weights it changes (fixed point: exact, order-free)
-__global__ void k_apply_moves(int32_t* c, int32_t const* best_c, double const* best_d, double min_gain, int up_down, int64_t nv,
-                              long long const* kfix, unsigned long long* afix)
+// the move, and the two cluster weights it changes (fixed point: exact, order-free).  The changes of a workgroup's 1024 vertices are first added up per
+// cluster in an LDS table and leave as ONE global atomic per (workgroup, cluster): at a contracted level most moves go into a handful of giant clusters,
+// and one device atomic per vertex on those few addresses serialised (0.5 ms for 2.5 M vertices at the second level of RMAT-22; round 6)
+constexpr int LVA_THREADS = 1024, LVA_SLOTS = 4096;  // at most 2 * LVA_THREADS keys per round: the table stays half empty
+__global__ void __launch_bounds__(LVA_THREADS) k_apply_moves(int32_t* c, int32_t const* best_c, double const* best_d, double min_gain, int up_down, int64_t nv,
+                                                             long long const* kfix, unsigned long long* afix)
 {
-  LV_LOOP(v, nv)
-  {
-    if (best_d[v] > min_gain && ((best_c[v] > c[v]) == (up_down != 0))) {
+  __shared__ uint32_t s_key[LVA_SLOTS];
+  __shared__ unsigned long long s_val[LVA_SLOTS];
+  for (int i = threadIdx.x; i < LVA_SLOTS; i += LVA_THREADS) { s_key[i] = 0xFFFFFFFFu; s_val[i] = 0; }
+  __syncthreads();
+  auto add = [&](uint32_t cl, unsigned long long x) {
+    uint32_t slot = ((cl * 0x9E3779B1u) ^ (cl >> 15)) & (uint32_t)(LVA_SLOTS - 1);
+    for (;;) {
+      uint32_t const old = atomicCAS(&s_key[slot], 0xFFFFFFFFu, cl);
+      if (old == 0xFFFFFFFFu || old == cl) break;
+      slot = (slot + 1) & (uint32_t)(LVA_SLOTS - 1);
+    }
+    atomicAdd(&s_val[slot], x);
+  };
+  int64_t const rounds = (nv + LVA_THREADS - 1) / LVA_THREADS;
+  for (int64_t r = blockIdx.x; r < rounds; r += gridDim.x) {  // (uniform trip count: the barriers below are reached by every thread)
+    int64_t const v = r * LVA_THREADS + threadIdx.x;
+    if (v < nv && best_d[v] > min_gain && ((best_c[v] > c[v]) == (up_down != 0))) {
       unsigned long long const kv = (unsigned long long)kfix[v];
-      atomicAdd(&afix[best_c[v]], kv);
-      atomicAdd(&afix[c[v]], 0ull - kv);
+      add((uint32_t)best_c[v], kv);
+      add((uint32_t)c[v], 0ull - kv);
       c[v] = best_c[v];
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LVA_SLOTS; i += LVA_THREADS) {
+      uint32_t const cl = s_key[i];
+      if (cl != 0xFFFFFFFFu) {
+        unsigned long long const x = s_val[i];
+        if (x) atomicAdd(&afix[cl], x);
+        s_key[i] = 0xFFFFFFFFu; s_val[i] = 0;
+      }
+    }
+    __syncthreads();
   }
 }
 __global__ void k_fix_to_double(unsigned long long const* fix, int64_t n, double inv_scale, double* out)
@@ -1083,8 +1111,10 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   dvec<long long> chunk_range;
   dvec<uint16_t> chunk_rs;
   dvec<int4> ca;
+  dvec<unsigned long long> chunk_int;
   if (use_hash) {
     ca.resize_discard((size_t)std::max<int64_t>(nv, 1));
+    chunk_int.resize_discard((size_t)((ne + LVH_B - 1) / LVH_B));
     chunk_range.resize_discard((size_t)((ne + LVH_B - 1) / LVH_B) * 2);
     chunk_rs.resize_discard((size_t)ne);
     hipLaunchKernelGGL(k_lv_chunk_prep, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.dst.data(), (int32_t const*)L.off.data(), ne, chunk_range.data(),
@@ -1200,8 +1230,10 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     if (use_hash && n_sorted < ne) {
       hipLaunchKernelGGL(k_lv_pack_ca, g_v, kBlock, 0, h.stream, (int32_t const*)c.data(), (double const*)a.data(), nv, ca.data());
       lv_hash_args HA{L.src.data(), L.dst.data(), L.w.data(), k.data(), ca.data(), m, resolution, scale, 1.0 / scale, ne,
-                      vfix.data() + 2 * nv, best_c.data(), ifix, chunk_range.data(), chunk_rs.data()};
-      hipLaunchKernelGGL(k_lv_hash_chunks, (int)((ne + LVH_B - 1) / LVH_B), LVH_THREADS, 0, h.stream, HA);
+                      vfix.data() + 2 * nv, best_c.data(), chunk_int.data(), chunk_range.data(), chunk_rs.data()};
+      int64_t const n_chunks = (ne + LVH_B - 1) / LVH_B;
+      hipLaunchKernelGGL(k_lv_hash_chunks, (int)n_chunks, LVH_THREADS, 0, h.stream, HA);
+      hipLaunchKernelGGL(k_lv_sum_u64, (int)std::max<int64_t>(1, std::min<int64_t>((n_chunks + 1023) / 1024, 256)), 1024, 0, h.stream, (unsigned long long const*)chunk_int.data(), n_chunks, ifix);
     }
     if (n_mid[0] + n_mid[1] > 0 || big_hash) {
       static bool attr_done = false;
@@ -1269,8 +1301,8 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     ++st.sweeps_in_level;
     if (ev.moves[up_down ? 1 : 0] == 0) up_down = !up_down;
     // the moves + compute_cluster_keys_and_values: cluster weights of the new clustering
-    hipLaunchKernelGGL(k_apply_moves, g_v, kBlock, 0, h.stream, c.data(), (int32_t const*)best_c.data(), (double const*)best_d.data(), min_gain, up_down ? 1 : 0, nv,
-                       (long long const*)kfix.data(), afix.data());
+    hipLaunchKernelGGL(k_apply_moves, (int)std::max<int64_t>(1, std::min<int64_t>((nv + LVA_THREADS - 1) / LVA_THREADS, (int64_t)h.num_cus * 2)), LVA_THREADS, 0, h.stream, c.data(),
+                       (int32_t const*)best_c.data(), (double const*)best_d.data(), min_gain, up_down ? 1 : 0, nv, (long long const*)kfix.data(), afix.data());
     if (mg) {  // every rank moved ITS vertices: merge the labels, rebuild the cluster weights from them (integers: the same values the
                // single-GPU run reaches by adding and subtracting)
       mg->merge_owned<int32_t>(c.data(), nv);
