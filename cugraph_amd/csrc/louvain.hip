@@ -328,7 +328,8 @@ __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
   for (int j = 0; j < LVH_E; ++j) {  // (in flight while the tables are cleared)
     int const i = tid + j * LVH_THREADS;
     rsf[j] = 0; u[j] = 0; w[j] = 0.0;
-    if (i < n) { rsf[j] = A.rs[p0 + i]; u[j] = A.dst[p0 + i]; w[j] = A.w[p0 + i]; }
+    // (streamed once per sweep: non-temporal, the lines the gathers below want stay in L2 -- 1 % of the call, profiles/r6x2)
+    if (i < n) { rsf[j] = __builtin_nontemporal_load(&A.rs[p0 + i]); u[j] = __builtin_nontemporal_load(&A.dst[p0 + i]); w[j] = __builtin_nontemporal_load(&A.w[p0 + i]); }
   }
   if (tid == 0) s_int = 0;
   for (int i = tid; i < LVH_SLOTS; i += LVH_THREADS) { s_key[i] = LVH_EMPTY; s_sum[i] = 0; }
@@ -436,6 +437,11 @@ struct lv_mid_args {
 template <int SLOTS>
 __global__ void __launch_bounds__(LVM_THREADS) k_lv_hash_rows(lv_mid_args A)
 {
+  // Round 6: a row's loads are issued together -- all of a thread's (destination, weight) pairs, then all their clusters, then all the weights of the
+  // clusters in its slots -- and the NEXT row's header (vertex, offsets, cluster) is fetched while this row is worked on: a row used to be a chain of
+  // eight dependent global round trips with the whole workgroup waiting on each.
+  constexpr int EPT = SLOTS / 2 / LVM_THREADS;  // a launch's rows have at most SLOTS / 2 edges
+  constexpr int SPT = SLOTS / LVM_THREADS;
   extern __shared__ unsigned long long lvm_smem[];
   unsigned long long* const s_sum = lvm_smem;                                  // [SLOTS]
   uint32_t* const s_key           = reinterpret_cast<uint32_t*>(s_sum + SLOTS);  // [SLOTS]
@@ -444,29 +450,49 @@ __global__ void __launch_bounds__(LVM_THREADS) k_lv_hash_rows(lv_mid_args A)
   int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto slot_of = [](uint32_t cl) { return ((cl * 0x9E3779B1u) ^ (cl >> 15)) & (uint32_t)(SLOTS - 1); };
   unsigned long long internal = 0;  // (the same value in every thread)
+  int32_t v_n = 0, b_n = 0, d_n = 0, cv_n = 0;
+  if ((int)blockIdx.x < A.n_rows) { v_n = A.rows[blockIdx.x]; b_n = A.off[v_n]; d_n = A.off[v_n + 1] - b_n; cv_n = A.c[v_n]; }
   for (int r = blockIdx.x; r < A.n_rows; r += gridDim.x) {
-    int32_t const v = A.rows[r];
-    int32_t const b = A.off[v], d = A.off[v + 1] - b;
+    int32_t const v = v_n, b = b_n, d = d_n, cv = cv_n;
+    int32_t u[EPT];
+    double w[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      int const i = tid + j * LVM_THREADS;
+      u[j] = 0; w[j] = 0.0;
+      if (i < d) { u[j] = A.dst[b + i]; w[j] = A.w[b + i]; }
+    }
+    double const a_old = A.a[cv], kk = A.k[v];
+    if (r + (int)gridDim.x < A.n_rows) { v_n = A.rows[r + gridDim.x]; b_n = A.off[v_n]; d_n = A.off[v_n + 1] - b_n; cv_n = A.c[v_n]; }
     for (int i = tid; i < SLOTS; i += LVM_THREADS) { s_key[i] = 0xFFFFFFFFu; s_sum[i] = 0; }
     if (tid == 0) s_sub = 0;
+    uint32_t cl[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) cl[j] = tid + j * LVM_THREADS < d ? (uint32_t)A.c[u[j]] : 0u;
     __syncthreads();
     unsigned long long sub = 0;
-    for (int i = tid; i < d; i += LVM_THREADS) {
-      int32_t const u   = A.dst[b + i];
-      uint32_t const cl = (uint32_t)A.c[u];
-      unsigned long long const wf = (unsigned long long)__double2ll_rn(A.w[b + i] * A.scale);
-      uint32_t slot = slot_of(cl);
-      for (;;) {
-        uint32_t const old = atomicCAS(&s_key[slot], 0xFFFFFFFFu, cl);
-        if (old == 0xFFFFFFFFu || old == cl) break;
-        slot = (slot + 1) & (uint32_t)(SLOTS - 1);
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      if (tid + j * LVM_THREADS < d) {
+        unsigned long long const wf = (unsigned long long)__double2ll_rn(w[j] * A.scale);
+        uint32_t slot = slot_of(cl[j]);
+        for (;;) {
+          uint32_t const old = atomicCAS(&s_key[slot], 0xFFFFFFFFu, cl[j]);
+          if (old == 0xFFFFFFFFu || old == cl[j]) break;
+          slot = (slot + 1) & (uint32_t)(SLOTS - 1);
+        }
+        atomicAdd(&s_sum[slot], wf);
+        if (u[j] == v) sub += wf;
       }
-      atomicAdd(&s_sum[slot], wf);
-      if (u == v) sub += wf;
     }
     if (sub) atomicAdd(&s_sub, sub);
     __syncthreads();
-    int32_t const cv = A.c[v];
+    uint32_t kcl[SPT];
+    double acl[SPT];
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) kcl[j] = s_key[tid + j * LVM_THREADS];
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) acl[j] = kcl[j] != 0xFFFFFFFFu ? A.a[kcl[j]] : 0.0;
     unsigned long long self = 0;
     {
       uint32_t slot = slot_of((uint32_t)cv);
@@ -480,17 +506,17 @@ __global__ void __launch_bounds__(LVM_THREADS) k_lv_hash_rows(lv_mid_args A)
     internal += self;
     unsigned long long const subf = s_sub;
     double const sub_d = (double)(long long)subf * A.inv_scale, old_sum = (double)(long long)(self - subf) * A.inv_scale;
-    double const a_old = A.a[cv], kk = A.k[v];
     unsigned long long best = 0;
     int32_t best_c = 0x7f7f7f7f;
-    for (int i = tid; i < SLOTS; i += LVM_THREADS) {
-      uint32_t const cl = s_key[i];
-      if (cl == 0xFFFFFFFFu) continue;
-      double const sd      = (double)(long long)s_sum[i] * A.inv_scale;
-      double const new_sum = (int32_t)cl == cv ? sd - sub_d : sd;
-      double const delta   = lv_delta(new_sum, old_sum, A.a[cl], a_old, kk, A.m, A.resolution);
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      uint32_t const c2 = kcl[j];
+      if (c2 == 0xFFFFFFFFu) continue;
+      double const sd      = (double)(long long)s_sum[tid + j * LVM_THREADS] * A.inv_scale;
+      double const new_sum = (int32_t)c2 == cv ? sd - sub_d : sd;
+      double const delta   = lv_delta(new_sum, old_sum, acl[j], a_old, kk, A.m, A.resolution);
       unsigned long long const bits = delta > 0.0 ? (unsigned long long)__double_as_longlong(delta) : 0ull;
-      if (bits > best || (bits == best && bits && (int32_t)cl < best_c)) { best = bits; best_c = (int32_t)cl; }
+      if (bits > best || (bits == best && bits && (int32_t)c2 < best_c)) { best = bits; best_c = (int32_t)c2; }
     }
     for (int o = 32; o; o >>= 1) {
       unsigned long long const ob = __shfl_xor(best, o);
@@ -560,22 +586,35 @@ __global__ void __launch_bounds__(LVB_THREADS) k_lv_hash_big(lv_big_args A)
     unsigned long long self = 0;
     uint32_t const* const ecl           = A.ecl + (uint32_t)item.w;
     unsigned long long const* const ewf = A.ewf + (uint32_t)item.w;
-    for (int i = tid; i < d; i += LVB_THREADS) {
-      uint32_t const cl           = ecl[i];
-      unsigned long long const wf = ewf[i];
-      if ((int32_t)cl == cv) self += wf;
-      if (lvb_range(cl, R) != r) continue;
-      uint32_t slot = slot_of(cl);
-      bool placed   = false;
-      for (int probes = 0; probes < LVB_SLOTS; ++probes) {
-        uint32_t const old = atomicCAS(&s_key[slot], 0xFFFFFFFFu, cl);
-        if (old == 0xFFFFFFFFu) { placed = atomicAdd(&s_used, 1u) < A.max_used; if (!placed) s_full = 1; break; }
-        if (old == cl) { placed = true; break; }
-        if (*(volatile uint32_t*)&s_full) break;
-        slot = (slot + 1) & (uint32_t)(LVB_SLOTS - 1);
+    constexpr int LVB_UNROLL = 4;  // (round 6: four (cluster, weight) pairs per thread in flight; the loop used to wait for each pair)
+    for (int i0 = tid; i0 < d; i0 += LVB_THREADS * LVB_UNROLL) {
+      uint32_t cls[LVB_UNROLL];
+      unsigned long long wfs[LVB_UNROLL];
+#pragma unroll
+      for (int j = 0; j < LVB_UNROLL; ++j) {
+        int const i = i0 + j * LVB_THREADS;
+        cls[j] = 0; wfs[j] = 0;
+        if (i < d) { cls[j] = ecl[i]; wfs[j] = ewf[i]; }
       }
-      if (placed) atomicAdd(&s_sum[slot], wf);
-      else s_full = 1;
+#pragma unroll
+      for (int j = 0; j < LVB_UNROLL; ++j) {
+        if (i0 + j * LVB_THREADS >= d) continue;
+        uint32_t const cl           = cls[j];
+        unsigned long long const wf = wfs[j];
+        if ((int32_t)cl == cv) self += wf;
+        if (lvb_range(cl, R) != r) continue;
+        uint32_t slot = slot_of(cl);
+        bool placed   = false;
+        for (int probes = 0; probes < LVB_SLOTS; ++probes) {
+          uint32_t const old = atomicCAS(&s_key[slot], 0xFFFFFFFFu, cl);
+          if (old == 0xFFFFFFFFu) { placed = atomicAdd(&s_used, 1u) < A.max_used; if (!placed) s_full = 1; break; }
+          if (old == cl) { placed = true; break; }
+          if (*(volatile uint32_t*)&s_full) break;
+          slot = (slot + 1) & (uint32_t)(LVB_SLOTS - 1);
+        }
+        if (placed) atomicAdd(&s_sum[slot], wf);
+        else s_full = 1;
+      }
     }
     if (self) atomicAdd(&s_self, self);
     __syncthreads();
@@ -590,12 +629,20 @@ __global__ void __launch_bounds__(LVB_THREADS) k_lv_hash_big(lv_big_args A)
     double const a_old = A.a[cv], kk = A.k[v];
     unsigned long long best = 0;
     int32_t best_c = 0x7f7f7f7f;
-    for (int i = tid; i < LVB_SLOTS; i += LVB_THREADS) {
-      uint32_t const cl = s_key[i];
+    constexpr int LVB_SPT = LVB_SLOTS / LVB_THREADS;
+    uint32_t kcl[LVB_SPT];
+    double acl[LVB_SPT];
+#pragma unroll
+    for (int j = 0; j < LVB_SPT; ++j) kcl[j] = s_key[tid + j * LVB_THREADS];
+#pragma unroll
+    for (int j = 0; j < LVB_SPT; ++j) acl[j] = kcl[j] != 0xFFFFFFFFu ? A.a[kcl[j]] : 0.0;
+#pragma unroll
+    for (int j = 0; j < LVB_SPT; ++j) {
+      uint32_t const cl = kcl[j];
       if (cl == 0xFFFFFFFFu) continue;
-      double const sd      = (double)(long long)s_sum[i] * A.inv_scale;
+      double const sd      = (double)(long long)s_sum[tid + j * LVB_THREADS] * A.inv_scale;
       double const new_sum = (int32_t)cl == cv ? sd - sub_d : sd;
-      double const delta   = lv_delta(new_sum, old_sum, A.a[cl], a_old, kk, A.m, A.resolution);
+      double const delta   = lv_delta(new_sum, old_sum, acl[j], a_old, kk, A.m, A.resolution);
       unsigned long long const bits = delta > 0.0 ? (unsigned long long)__double_as_longlong(delta) : 0ull;
       if (bits > best || (bits == best && bits && (int32_t)cl < best_c)) { best = bits; best_c = (int32_t)cl; }
     }
