@@ -260,28 +260,35 @@ __global__ void __launch_bounds__(256) k_mg_bucket_scatter(int32_t const* cand, 
 }
 
 // ---- owner side
-__global__ void k_mg_bfs_apply(int32_t const* in, size_t n, int32_t level, int32_t* dist, int32_t* pred, int32_t* q_next, uint32_t* newfront, counters_t* cnt,
-                               int32_t const* out_offsets, int32_t const* in_offsets /* nullptr: no degree sums (no bottom-up levels) */)
+// (n_dev != nullptr: the device-driven exchange of traversal_mg_driver.hip, where no host knows the counts: sender s wrote n_dev[s] tuples into ITS slot of the
+// window, seg_tuples tuples apart; blockIdx.y = sender, the grid is fixed and every workgroup strides over its sender's list -- trip counts are uniform per
+// workgroup, so the wavefront-wide appends stay whole)
+__global__ void k_mg_bfs_apply(int32_t const* in, size_t n_host, uint32_t const* n_dev, size_t seg_tuples, int32_t level, int32_t* dist, int32_t* pred, int32_t* q_next,
+                               uint32_t* newfront, counters_t* cnt, int32_t const* out_offsets, int32_t const* in_offsets /* nullptr: no degree sums (no bottom-up levels) */)
 {
-  size_t i      = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  bool fresh    = false;
-  int32_t row   = 0;
+  size_t const n = n_dev ? (size_t)n_dev[blockIdx.y] : n_host;
+  in += 2 * seg_tuples * blockIdx.y;
   unsigned long long acc_out = 0, acc_in = 0;
-  if (i < n) {
-    row                = in[2 * i];
-    int32_t const par  = in[2 * i + 1];
-    int32_t const old  = atomicCAS(&dist[row], INT32_MAX, level);
-    fresh              = old == INT32_MAX;
-    if (fresh) {
-      atomicOr(&newfront[row >> 5], 1u << (row & 31));
-      if (in_offsets) {  // the direction heuristic's sums (bfs_impl.cuh:598-607 counts the same two quantities)
-        acc_out = (unsigned long long)(eoff(out_offsets, row + 1) - eoff(out_offsets, row));
-        acc_in  = (unsigned long long)(eoff(in_offsets, row + 1) - eoff(in_offsets, row));
+  for (size_t base = blockIdx.x * (size_t)blockDim.x; base < n; base += (size_t)gridDim.x * blockDim.x) {
+    size_t const i = base + threadIdx.x;
+    bool fresh     = false;
+    int32_t row    = 0;
+    if (i < n) {
+      row                = in[2 * i];
+      int32_t const par  = in[2 * i + 1];
+      int32_t const old  = atomicCAS(&dist[row], INT32_MAX, level);
+      fresh              = old == INT32_MAX;
+      if (fresh) {
+        atomicOr(&newfront[row >> 5], 1u << (row & 31));
+        if (in_offsets) {  // the direction heuristic's sums (bfs_impl.cuh:598-607 counts the same two quantities)
+          acc_out += (unsigned long long)(eoff(out_offsets, row + 1) - eoff(out_offsets, row));
+          acc_in  += (unsigned long long)(eoff(in_offsets, row + 1) - eoff(in_offsets, row));
+        }
       }
+      if (pred && (fresh || old == level) && par < __hip_atomic_load(&pred[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&pred[row], par);
     }
-    if (pred && (fresh || old == level) && par < __hip_atomic_load(&pred[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&pred[row], par);
+    wave_push(fresh, row, q_next, &cnt->n_next, threadIdx.x & 63);
   }
-  wave_push(fresh, row, q_next, &cnt->n_next, threadIdx.x & 63);
   if (in_offsets) {
     for (int o = 32; o > 0; o >>= 1) { acc_out += __shfl_xor(acc_out, o); acc_in += __shfl_xor(acc_in, o); }
     if ((threadIdx.x & 63) == 0 && (acc_out | acc_in)) { counter_sums_t* r = cnt_replica(cnt); atomicAdd(&r->out_edges, acc_out); atomicAdd(&r->in_edges, acc_in); }
@@ -589,11 +596,12 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_reset(cugraph_amd_
   });
 }
 
-/* Expands the local frontier; on return send holds, grouped by owner rank, send_counts[r] tuples for rank r. */
-extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_expand(cugraph_amd_traversal_mg_plan_t* plan, size_t* send_counts, cugraph_error_t** error)
+// the launch half of expand: on completion `send` holds the candidates grouped by owner, totals[r] = (start of owner r, start of owner r + 1) and the
+// counters the list's length -- all on the device.  The exported call below reads them back; the library's BFS driver hands them to the other ranks
+// from the device instead (traversal_mg_driver.hip: no host in a top-down level's exchange)
+namespace cga {
+void mg_plan_expand_launch(cugraph_amd_traversal_mg_plan_t* plan)
 {
-  return guarded(error, [&] {
-    CGA_EXPECTS(plan != nullptr && send_counts != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
     traversal_mg_plan& p = TP(plan);
     handle_t const& h    = *p.h;
     HIP_TRY(hipSetDevice(h.device));
@@ -625,6 +633,19 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_expand(cugraph_amd
     else
       hipLaunchKernelGGL(k_mg_bucket_scatter<1>, nb, 256, 0, h.stream, (int32_t const*)p.cand.data(), (counters_t const*)p.cnt.data(), (uint32_t)p.L, p.P,
                          (uint32_t const*)p.block_hist.data(), (int32_t*)nullptr, p.cand_best.data(), p.touched.data(), p.send);
+}
+unsigned long long const* mg_plan_totals(cugraph_amd_traversal_mg_plan_t* plan) { return TP(plan).totals.data(); }
+size_t mg_plan_capacity(cugraph_amd_traversal_mg_plan_t* plan) { return TP(plan).capacity; }
+}  // namespace cga
+
+/* Expands the local frontier; on return send holds, grouped by owner rank, send_counts[r] tuples for rank r. */
+extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_expand(cugraph_amd_traversal_mg_plan_t* plan, size_t* send_counts, cugraph_error_t** error)
+{
+  return guarded(error, [&] {
+    CGA_EXPECTS(plan != nullptr && send_counts != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
+    mg_plan_expand_launch(plan);
+    traversal_mg_plan& p = TP(plan);
+    handle_t const& h    = *p.h;
     // counts: totals[r] = (start of r, start of r + 1); the list length closes the last bucket
     struct { unsigned long long t[MG_MAX_RANKS]; } tot;
     HIP_TRY(hipMemcpyAsync(h.pinned, p.totals.data(), sizeof(unsigned long long) * MG_MAX_RANKS, hipMemcpyDeviceToHost, h.stream));
@@ -651,9 +672,11 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_expand(cugraph_amd
 // between; the library's own BFS driver (traversal_mg_driver.hip) ships the level's counters to every rank FROM THE DEVICE between the two
 // halves (mg_plan_counters) and adopts what came back, so a level costs one host synchronisation less.
 namespace cga {
-void mg_plan_apply_launch(cugraph_amd_traversal_mg_plan_t* plan, int32_t const* recv, size_t n_tuples, uint32_t level)
+// (n_tuples_dev != nullptr: recv holds P slots of L tuples, slot s filled by sender s with n_tuples_dev[s] tuples -- counts no host has seen)
+void mg_plan_apply_launch(cugraph_amd_traversal_mg_plan_t* plan, int32_t const* recv, size_t n_tuples, uint32_t level, uint32_t const* n_tuples_dev)
 {
   traversal_mg_plan& p = TP(plan);
+  CGA_EXPECTS(n_tuples_dev == nullptr || p.mode == 0, CUGRAPH_INVALID_INPUT, "device-side tuple counts are a BFS level's");
   handle_t const& h    = *p.h;
   HIP_TRY(hipSetDevice(h.device));
   if (p.mode == 1 && p.n_local > 0) {  // apply appends behind what expand put there
@@ -665,10 +688,10 @@ void mg_plan_apply_launch(cugraph_amd_traversal_mg_plan_t* plan, int32_t const* 
     HIP_TRY(hipMemsetAsync(p.cnt.data(), 0, sizeof(counters_t), h.stream));
   }
   if (p.mode == 0) HIP_TRY(hipMemsetAsync(p.newfront.data(), 0, p.L / 8, h.stream));
-  if (n_tuples) {
-    int const g = (int)((n_tuples + 255) / 256);
+  if (n_tuples || n_tuples_dev) {
+    int const g = n_tuples_dev ? std::max(h.num_cus * 8 / p.P, 8) : (int)((n_tuples + 255) / 256);
     if (p.mode == 0)
-      hipLaunchKernelGGL(k_mg_bfs_apply, g, 256, 0, h.stream, recv, n_tuples, (int32_t)level, p.dist.data(), p.with_pred ? p.pred.data() : (int32_t*)nullptr,
+      hipLaunchKernelGGL(k_mg_bfs_apply, dim3((unsigned)g, n_tuples_dev ? (unsigned)p.P : 1u), dim3(256), 0, h.stream, recv, n_tuples, n_tuples_dev, (size_t)p.L, (int32_t)level, p.dist.data(), p.with_pred ? p.pred.data() : (int32_t*)nullptr,
                          p.q_next, p.newfront.data(), p.cnt.data(), p.offsets, p.in_offsets);
     else
       hipLaunchKernelGGL(k_mg_sssp_apply, g, 256, 0, h.stream, recv, n_tuples, p.round, p.st.data(), p.mark.data(), p.q_next, p.cnt.data(), float_bits(p.hi), p.win,
@@ -715,7 +738,7 @@ extern "C" cugraph_error_code_t cugraph_amd_traversal_mg_plan_apply(cugraph_amd_
 {
   return guarded(error, [&] {
     CGA_EXPECTS(plan != nullptr && n_next != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
-    mg_plan_apply_launch(plan, recv, n_tuples, level);
+    mg_plan_apply_launch(plan, recv, n_tuples, level, nullptr);
     traversal_mg_plan& p = TP(plan);
     counters_t c{};
     p.h->read_back(&c, p.cnt.data(), 1);

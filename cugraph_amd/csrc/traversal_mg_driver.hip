@@ -17,7 +17,9 @@
 namespace cga {
 
 // traversal_mg.hip: the launch half and the host half of the plan's apply / bottom_up (the exported calls synchronise in between)
-void mg_plan_apply_launch(cugraph_amd_traversal_mg_plan_t* plan, int32_t const* recv, size_t n_tuples, uint32_t level);
+void mg_plan_expand_launch(cugraph_amd_traversal_mg_plan_t* plan);
+unsigned long long const* mg_plan_totals(cugraph_amd_traversal_mg_plan_t* plan);
+void mg_plan_apply_launch(cugraph_amd_traversal_mg_plan_t* plan, int32_t const* recv, size_t n_tuples, uint32_t level, uint32_t const* n_tuples_dev);
 void mg_plan_bottom_up_launch(cugraph_amd_traversal_mg_plan_t* plan, uint32_t const* front, uint32_t level);
 void const* mg_plan_counters(cugraph_amd_traversal_mg_plan_t* plan);
 void mg_plan_adopt_level(cugraph_amd_traversal_mg_plan_t* plan, size_t n_next, unsigned long long out_edges, unsigned long long in_edges);
@@ -79,6 +81,30 @@ __global__ void k_put_stats_dev(unsigned long long* const* peer_s, int rank, int
   }
 }
 
+
+// A top-down BFS level's all-to-all-v with no host in it (the reference: a device all-to-all of the counts, then of the tuples --
+// cpp/include/cugraph/utilities/shuffle_comm.cuh:139-186): the bucket boundaries of `send` are read where the counting sort left them (totals, the list
+// length in the counters), owner k's share goes to THIS rank's slot of k's window (slot = L tuples: a sender names a destination at most once per level,
+// so no count matrix is needed to place it) and its length to word `rank` of k's count window.  blockIdx.y = owner.
+__global__ void __launch_bounds__(256) k_push_tuples_dev(uint32_t const* send, unsigned long long const* totals, counters_t const* cnt, uint32_t* const* peer_slots,
+                                                        uint32_t* const* peer_counts, int rank, int P, int64_t slot_words, int tw)
+{
+  int const k          = blockIdx.y;
+  uint32_t const first = (uint32_t)totals[k];
+  uint32_t const next  = k + 1 < P ? (uint32_t)(totals[k] >> 32) : cnt->n_next;
+  int64_t const n      = (int64_t)(next - first) * tw;
+  uint32_t const* src  = send + (int64_t)first * tw;
+  uint32_t* dst        = peer_slots[k] + (int64_t)rank * slot_words;
+  int64_t i            = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int64_t const stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    uint32_t const a = src[i], b = src[i + stride], c = src[i + 2 * stride], e = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = e;
+  }
+  for (; i < n; i += stride) dst[i] = src[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) peer_counts[k][rank] = next - first;
+}
+
 }  // namespace
 
 // the plan of one traversal family on one graph + its exchange windows (created on first use, freed with the graph: collective)
@@ -92,7 +118,9 @@ struct mg_traversal_run_t {
   comm_window_t* twin{nullptr};                  // received candidate tuples, grouped by sender
   comm_window_t* bwin[2]{nullptr, nullptr};      // BFS: [P][L / 32] gathered new-frontier bits, by level parity
   comm_window_t* swin[2]{nullptr, nullptr};      // BFS: [P][4] (discoveries, their out- and in-degree sums)
+  comm_window_t* cwin{nullptr};                  // BFS: [P] tuples every sender put into its slot of twin this level (written by the senders' devices)
   dvec<unsigned long long*> d_peer_s[2];
+  dvec<uint32_t*> d_peer_t, d_peer_c;
   int channel{0};
   bool bottom_up_set{false};
   double delta{0.0};  // SSSP: width of the near / far window (32 x average weight / average degree over the whole graph; 0 = not computed yet)
@@ -102,6 +130,7 @@ struct mg_traversal_run_t {
       // (not h->stream: the resource handle of the first traversal may be gone by the time the graph is freed -- advisor finding, round 4)
       if (c) { (void)hipSetDevice(c->device); (void)hipDeviceSynchronize(); }
       if (plan) cugraph_amd_traversal_mg_plan_free(plan);
+      if (cwin) c->window_free(cwin);
       for (int b = 1; b >= 0; --b) { if (swin[b]) c->window_free(swin[b]); if (bwin[b]) c->window_free(bwin[b]); }
       if (twin) c->window_free(twin);
       if (channel >= 2) c->channel_free(channel);
@@ -138,7 +167,7 @@ mg_traversal_run_t& ensure_run(handle_t const& h, graph_t& g, mg_traversal_part_
   // every sender sends a destination at most once per level: at most L tuples per (sender, owner) pair
   r->channel = c.channel_alloc();
   r->twin    = c.window_create((size_t)P * (size_t)t.L * r->tw * 4);
-  if (mode == 0)
+  if (mode == 0) {
     for (int b = 0; b < 2; ++b) {
       r->bwin[b] = c.window_create((size_t)P * (size_t)(t.L / 32) * 4);
       r->swin[b] = c.window_create((size_t)P * 4 * sizeof(unsigned long long));
@@ -147,6 +176,13 @@ mg_traversal_run_t& ensure_run(handle_t const& h, graph_t& g, mg_traversal_part_
       r->d_peer_s[b].resize_discard(P);
       HIP_TRY(hipMemcpyAsync(r->d_peer_s[b].data(), r->swin[b]->peer.data(), (size_t)P * sizeof(void*), hipMemcpyHostToDevice, h.stream));
     }
+    r->cwin = c.window_create((size_t)kCommMaxRanks * 4);
+    HIP_TRY(hipMemsetAsync(r->cwin->local, 0, (size_t)kCommMaxRanks * 4, h.stream));
+    r->d_peer_t.resize_discard(P);
+    r->d_peer_c.resize_discard(P);
+    HIP_TRY(hipMemcpyAsync(r->d_peer_t.data(), r->twin->peer.data(), (size_t)P * sizeof(void*), hipMemcpyHostToDevice, h.stream));
+    HIP_TRY(hipMemcpyAsync(r->d_peer_c.data(), r->cwin->peer.data(), (size_t)P * sizeof(void*), hipMemcpyHostToDevice, h.stream));
+  }
   h.sync();
   c.host_barrier();
   t.run = r;
@@ -176,6 +212,20 @@ size_t exchange_tuples(handle_t const& h, mg_traversal_run_t& r, int P, int me, 
   c.push_multi(h.stream, d);
   c.wait(h.stream, r.channel, c.signal(h.stream, r.channel));
   return (size_t)total;
+}
+
+// the same for a BFS level without the host: counts and tuples travel from the device (k_push_tuples_dev); what the local window then holds is described by
+// the count window -- the owner-side apply reads it there
+void exchange_tuples_dev(handle_t const& h, mg_traversal_run_t& r, mg_traversal_part_t const& t)
+{
+  comm_t& c   = *r.c;
+  int const P = t.P;
+  // (at most L tuples per owner: enough workgroups for a full slot, few enough that an empty level costs one short launch)
+  unsigned const gx = (unsigned)std::min<int64_t>(std::max<int64_t>((t.L * r.tw + 4095) / 4096, 1), std::max(h.num_cus * 8 / P, 8));
+  hipLaunchKernelGGL(k_push_tuples_dev, dim3(gx, (unsigned)P), dim3(256), 0, h.stream, (uint32_t const*)r.send.data(), mg_plan_totals(r.plan),
+                     static_cast<counters_t const*>(mg_plan_counters(r.plan)), (uint32_t* const*)r.d_peer_t.data(), (uint32_t* const*)r.d_peer_c.data(), t.rank, P,
+                     (int64_t)t.L * r.tw, r.tw);
+  c.wait(h.stream, r.channel, c.signal(h.stream, r.channel));
 }
 
 struct level_stats_t { unsigned long long n, out_sum, in_sum; };
@@ -318,6 +368,8 @@ paths_result_t* mg_run_bfs(handle_t& h, graph_t& g, device_array_view_t const* s
   double const alpha = getenv("CUGRAPH_AMD_BFS_ALPHA") ? atof(getenv("CUGRAPH_AMD_BFS_ALPHA")) : 60.0;
   double const beta  = getenv("CUGRAPH_AMD_BFS_BETA") ? atof(getenv("CUGRAPH_AMD_BFS_BETA")) : 24.0;
   char const* force  = getenv("CUGRAPH_AMD_MG_BFS");  // "bottomup" / "topdown": pin the direction (tests)
+  // "0": the count matrix of a top-down level through the host (round 5's exchange: kept as the cross-check of the device-driven one)
+  bool const dev_exchange = !(getenv("CUGRAPH_AMD_MG_BFS_DEVICE_EXCHANGE") && std::string(getenv("CUGRAPH_AMD_MG_BFS_DEVICE_EXCHANGE")) == "0");
   unsigned long long n_front = (unsigned long long)loc.n_sources, frontier_out = loc.out_deg_sum, unvisited_in = (unsigned long long)t.ne_global;
   uint64_t const limit = depth_limit > (size_t)INT32_MAX ? (uint64_t)INT32_MAX : (uint64_t)depth_limit;
   bool bottom_up = false;
@@ -339,10 +391,16 @@ paths_result_t* mg_run_bfs(handle_t& h, graph_t& g, device_array_view_t const* s
       mg_plan_bottom_up_launch(r.plan, static_cast<uint32_t const*>(r.bwin[(level - 1) & 1]->local), (uint32_t)level);
       ++bu_levels;
     } else {
-      size_t counts[kCommMaxRanks];
-      ck(cugraph_amd_traversal_mg_plan_expand(r.plan, counts, &err), err, "expand");
-      size_t const got = exchange_tuples(h, r, P, me, counts);
-      mg_plan_apply_launch(r.plan, static_cast<int32_t const*>(r.twin->local), got, (uint32_t)level);
+      if (dev_exchange) {  // no host in the exchange: the level's only synchronisation is share_frontier's
+        mg_plan_expand_launch(r.plan);
+        exchange_tuples_dev(h, r, t);
+        mg_plan_apply_launch(r.plan, static_cast<int32_t const*>(r.twin->local), 0, (uint32_t)level, static_cast<uint32_t const*>(r.cwin->local));
+      } else {
+        size_t counts[kCommMaxRanks];
+        ck(cugraph_amd_traversal_mg_plan_expand(r.plan, counts, &err), err, "expand");
+        size_t const got = exchange_tuples(h, r, P, me, counts);
+        mg_plan_apply_launch(r.plan, static_cast<int32_t const*>(r.twin->local), got, (uint32_t)level, nullptr);
+      }
     }
     unsigned long long own[4] = {0, 0, 0, 0};
     level_stats_t const tot = share_frontier(h, r, t, (int)(level & 1), level_stats_t{0, 0, 0}, static_cast<counters_t const*>(mg_plan_counters(r.plan)), own);

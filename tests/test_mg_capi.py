@@ -299,6 +299,14 @@ def _bfs_case(orc, tmp_path, world, direction, env=None):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,direction", [(2, "topdown"), (4, "")])
+def test_mg_capi_bfs_count_matrix_through_the_host(orc, tmp_path, world, direction):
+    """The default top-down level exchanges counts and tuples from the device (no host in it: k_push_tuples_dev, the reference's device all-to-all of
+    shuffle_comm.cuh:139-186); CUGRAPH_AMD_MG_BFS_DEVICE_EXCHANGE=0 is round 5's exchange (count matrix all-gathered by the hosts): same answers."""
+    _bfs_case(orc, tmp_path, world, direction, env={"CUGRAPH_AMD_MG_BFS_DEVICE_EXCHANGE": "0"})
+
+
+@pytest.mark.gpu
 def test_mg_capi_bfs_depth_limit(orc, tmp_path):
     from test_mg_traversal import check_bfs
 
