@@ -1105,6 +1105,54 @@ void sort_pairs(handle_t const& h, dvec<uint64_t>& keys, dvec<uint32_t>& vals, i
   radix_sort_u64_u32(h, keys.data(), vals.data(), kt.data(), vt.data(), n, 0, bits);
 }
 
+// ---- numbering of a contracted level.  graph_contraction (detail/common_methods.cuh:231-263) builds the coarse graph with coarsen_graph(...,
+// renumber = true), i.e. the coarse vertices are numbered as every graph creation numbers vertices: by degree, descending
+// (structure/renumber_edgelist_impl.cuh, "4. sort local vertices by degree (descending)": a stable key sort over the id-sorted vertex list, so equal
+// degrees keep ascending label order); degree = coarse edges leaving the vertex = its distinct neighbour clusters.  The ids are not cosmetic: the next
+// level breaks equal gains towards the smaller cluster id (reduce_op_t) and moves up or down by comparing ids.  Rounds 1-5 numbered the coarse vertices
+// by label order and missed the reference's karate goldens at resolution 1 (cpp/tests/community/louvain_test.cpp:228-237: 0.39907956, three levels).
+__global__ void k_lv_row_lengths_of(int32_t const* off, int64_t n, uint32_t* len) { LV_LOOP(v, n) len[v] = (uint32_t)off[v + 1] - (uint32_t)off[v]; }
+__global__ void k_lv_degree_keys(uint32_t const* deg, int64_t n, uint64_t* keys, uint32_t* vals)
+{
+  LV_LOOP(v, n) { keys[v] = (uint64_t)(0xFFFFFFFFu - deg[v]); vals[v] = (uint32_t)v; }
+}
+__global__ void k_lv_new_ids(uint64_t const* keys, uint32_t const* old_of, int64_t n, uint32_t* new_id, uint32_t* len)
+{
+  LV_LOOP(r, n) { new_id[old_of[r]] = (uint32_t)r; len[r] = 0xFFFFFFFFu - (uint32_t)keys[r]; }
+}
+// deg[ncl] (coarse out-degrees in the label-order ids) -> new_id[old] (position in the order by (degree descending, old id ascending)) and
+// new_off[ncl + 1] (the rows' offsets in that order)
+void coarse_degree_order(handle_t const& h, uint32_t const* deg, int64_t ncl, dvec<uint32_t>& new_id, dvec<uint32_t>& new_off)
+{
+  size_t const n1 = (size_t)std::max<int64_t>(ncl, 1);
+  dvec<uint64_t> keys(n1);
+  dvec<uint32_t> old_of(n1), len(n1 + 1);
+  new_id.resize_discard(n1 + 1);
+  new_off.resize_discard(n1 + 1);
+  HIP_TRY(hipMemsetAsync(len.data(), 0, (n1 + 1) * sizeof(uint32_t), h.stream));
+  if (ncl > 0) {
+    hipLaunchKernelGGL(k_lv_degree_keys, grid_for(ncl, kBlock, 8192), kBlock, 0, h.stream, deg, ncl, keys.data(), old_of.data());
+    sort_pairs(h, keys, old_of, ncl, 32);  // LSD radix passes are stable: equal degrees stay in ascending id order
+    hipLaunchKernelGGL(k_lv_new_ids, grid_for(ncl, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)old_of.data(), ncl, new_id.data(), len.data());
+  }
+  exclusive_scan_u32(h, len.data(), new_off.data(), ncl + 1);
+  h.sync();  // (temporaries die here)
+}
+// the rows of a coarse edge list (sorted by source in the OLD ids, offsets old_off) move to where the new numbering puts them; a row keeps its internal order
+__global__ void k_lv_renumber_rows(int32_t const* src, int32_t const* dst, unsigned long long const* wfix, int64_t ne, int32_t const* old_off, uint32_t const* new_off,
+                                   uint32_t const* new_id, double inv_scale, int32_t* src2, int32_t* dst2, double* w2)
+{
+  LV_LOOP(p, ne)
+  {
+    int32_t const o  = src[p];
+    uint32_t const r = new_id[o];
+    uint32_t const q = new_off[r] + ((uint32_t)p - (uint32_t)old_off[o]);
+    src2[q] = (int32_t)r;
+    dst2[q] = (int32_t)new_id[dst[p]];
+    w2[q]   = (double)(long long)wfix[p] * inv_scale;
+  }
+}
+
 // fixed-order sum of n values produced chunk-wise by `launch_parts(parts)`
 template <typename F>
 void chunked_sum(handle_t const& h, int64_t n, dvec<double>& parts, double* out, F&& launch_parts)
@@ -1346,10 +1394,12 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     cur_q = new_q;
     ++st.sweeps;
     ++st.sweeps_in_level;
-    if (ev.moves[up_down ? 1 : 0] == 0) up_down = !up_down;
+    // update_clustering_by_delta_modularity takes up_down BY VALUE (detail/common_methods.cuh:277, 445): a sweep without a move in its direction applies the
+    // moves of the other direction, and that flip does not outlive the sweep -- the loop's own toggle below starts from the direction the sweep was given
+    bool const dir = ev.moves[up_down ? 1 : 0] == 0 ? !up_down : up_down;
     // the moves + compute_cluster_keys_and_values: cluster weights of the new clustering
     hipLaunchKernelGGL(k_apply_moves, (int)std::max<int64_t>(1, std::min<int64_t>((nv + LVA_THREADS - 1) / LVA_THREADS, (int64_t)h.num_cus * 2)), LVA_THREADS, 0, h.stream, c.data(),
-                       (int32_t const*)best_c.data(), (double const*)best_d.data(), min_gain, up_down ? 1 : 0, nv, (long long const*)kfix.data(), afix.data());
+                       (int32_t const*)best_c.data(), (double const*)best_d.data(), min_gain, dir ? 1 : 0, nv, (long long const*)kfix.data(), afix.data());
     if (mg) {  // every rank moved ITS vertices: merge the labels, rebuild the cluster weights from them (integers: the same values the
                // single-GPU run reaches by adding and subtracting)
       mg->merge_owned<int32_t>(c.data(), nv);
@@ -1490,7 +1540,6 @@ clustering_result_t* mg_run_louvain(handle_t const& h, graph_t& g, size_t max_le
     uint32_t ncl = 0;
     h.read_back(&ncl, rank.data() + L.nv, 1);
     hipLaunchKernelGGL(k_relabel, grid_for(L.nv, kBlock, 8192), kBlock, 0, h.stream, cl.data(), (uint32_t const*)rank.data(), L.nv);
-    if (n_own > 0) hipLaunchKernelGGL(k_compose, grid_for(n_own, kBlock, 8192), kBlock, 0, h.stream, part_own.data(), (int32_t const*)cl.data(), n_own);
     // coarse edges: local aggregation, all-to-all to the owner of the source cluster, second aggregation (integers: the single-GPU sums)
     int const cb = bits_of_u((uint64_t)std::max<int64_t>((int64_t)ncl - 1, 1));
     dvec<int32_t> lsrc, ldst;
@@ -1549,6 +1598,41 @@ clustering_result_t* mg_run_louvain(handle_t const& h, graph_t& g, size_t max_le
         N.ne = 0;
         N.src.resize_discard(1); N.dst.resize_discard(1); N.w.resize_discard(1);
       }
+    }
+    // The coarse vertices in the reference's numbering (coarse_degree_order): a coarse vertex's edges are all with its owner now, so the owners' row
+    // lengths ARE the degrees; every rank receives all of them (one merge), sorts them the same way, renames its coarse edges, and the edges move to
+    // the owners of the NEW ids (a second, smaller all-to-all: the numbering decides the next level's ties, so it cannot stay the label order).
+    {
+      dvec<uint32_t> deg((size_t)ncl + 1), new_id, new_off;
+      HIP_TRY(hipMemsetAsync(deg.data(), 0, ((size_t)ncl + 1) * sizeof(uint32_t), h.stream));
+      if (N.ne > 0) {
+        dvec<uint32_t> fl((size_t)ncl + 1);
+        HIP_TRY(hipMemsetAsync(fl.data(), 0, ((size_t)ncl + 1) * sizeof(uint32_t), h.stream));
+        hipLaunchKernelGGL(k_row_bounds, grid_for(N.ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)N.src.data(), N.ne, fl.data(), deg.data());
+        hipLaunchKernelGGL(k_row_lengths, grid_for((int64_t)ncl, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)fl.data(), deg.data(), (int64_t)ncl);
+        h.sync();  // (`fl`)
+      }
+      M.level_begin((int64_t)ncl);
+      M.merge_owned<uint32_t>(deg.data(), (int64_t)ncl);  // deg[v] <- the row length rank v % P holds
+      M.level_end();
+      coarse_degree_order(h, deg.data(), (int64_t)ncl, new_id, new_off);
+      hipLaunchKernelGGL(k_relabel, grid_for(L.nv, kBlock, 8192), kBlock, 0, h.stream, cl.data(), (uint32_t const*)new_id.data(), L.nv);
+      if (n_own > 0) hipLaunchKernelGGL(k_compose, grid_for(n_own, kBlock, 8192), kBlock, 0, h.stream, part_own.data(), (int32_t const*)cl.data(), n_own);
+      size_t const n1 = (size_t)std::max<int64_t>(N.ne, 1);
+      dvec<int32_t> owner(n1);
+      if (N.ne > 0) {
+        hipLaunchKernelGGL(k_relabel, grid_for(N.ne, kBlock, 8192), kBlock, 0, h.stream, N.src.data(), (uint32_t const*)new_id.data(), N.ne);
+        hipLaunchKernelGGL(k_relabel, grid_for(N.ne, kBlock, 8192), kBlock, 0, h.stream, N.dst.data(), (uint32_t const*)new_id.data(), N.ne);
+        hipLaunchKernelGGL(k_lv_owner_of, grid_for(N.ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)N.src.data(), N.ne, P, owner.data());
+      }
+      std::vector<dev_buf> got;
+      int64_t const n_r = mg_shuffle_by_owner(h, c, owner.data(), N.ne, {{N.src.data(), 4}, {N.dst.data(), 4}, {N.w.data(), 8}}, got);
+      CGA_EXPECTS(n_r <= kMaxSignedEdges, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "multi-GPU Louvain: a rank's coarse share must hold fewer than 2^31 edges");
+      level_t R;
+      R.nv = ncl;
+      lv_sort_edges(h, got[0].as<int32_t const>(), got[1].as<int32_t const>(), got[2].as<double const>(), n_r, (int64_t)ncl, R);
+      h.sync();
+      N = std::move(R);
     }
     L = std::move(N);
   }
@@ -1647,9 +1731,9 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
       uint32_t ncl = 0;
       h.read_back(&ncl, rank.data() + L.nv, 1);
       hipLaunchKernelGGL(k_relabel, grid_for(L.nv, kBlock, 8192), kBlock, 0, h.stream, c.data(), (uint32_t const*)rank.data(), L.nv);
-      hipLaunchKernelGGL(k_compose, grid_for(nv0, kBlock, 8192), kBlock, 0, h.stream, part->buf.as<int32_t>(), (int32_t const*)c.data(), nv0);
       level_t N;
       N.nv = ncl;
+      dvec<uint32_t> new_id, new_off;
       if (L.ne > 0) {
         dvec<uint64_t> keys((size_t)L.ne);
         dvec<uint32_t> perm((size_t)L.ne), head((size_t)L.ne + 1), pos((size_t)L.ne + 1);
@@ -1670,13 +1754,29 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
         hipLaunchKernelGGL(k_coarse_edges, grid_for(L.ne, kBlock, 8192), kBlock, 0, h.stream, (uint64_t const*)keys.data(), (uint32_t const*)perm.data(),
                            (uint32_t const*)head.data(), (uint32_t const*)pos.data(), (double const*)L.w.data(), L.ne, cb, scale, N.src.data(), N.dst.data(),
                            cwfix.data());
-        hipLaunchKernelGGL(k_fix_to_double, grid_for((int64_t)n1, kBlock, 8192), kBlock, 0, h.stream, (unsigned long long const*)cwfix.data(), (int64_t)n1,
-                           1.0 / scale, N.w.data());
+        // the coarse vertices in the reference's numbering (coarse_degree_order): degrees = the rows' lengths, the rows move, the weights leave fixed point
+        build_offsets(h, N);  // (rows of the label-order ids)
+        dvec<uint32_t> deg((size_t)ncl + 1);
+        hipLaunchKernelGGL(k_lv_row_lengths_of, grid_for((int64_t)ncl, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)N.off.data(), (int64_t)ncl, deg.data());
+        coarse_degree_order(h, deg.data(), (int64_t)ncl, new_id, new_off);
+        dvec<int32_t> src2(n1), dst2(n1);
+        hipLaunchKernelGGL(k_lv_renumber_rows, grid_for((int64_t)nce, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)N.src.data(), (int32_t const*)N.dst.data(),
+                           (unsigned long long const*)cwfix.data(), (int64_t)nce, (int32_t const*)N.off.data(), (uint32_t const*)new_off.data(), (uint32_t const*)new_id.data(),
+                           1.0 / scale, src2.data(), dst2.data(), N.w.data());
+        HIP_TRY(hipMemcpyAsync(N.off.data(), new_off.data(), ((size_t)ncl + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, h.stream));
         h.sync();
+        N.src = std::move(src2);
+        N.dst = std::move(dst2);
       } else {
         N.ne = 0;
         N.src.resize_discard(1); N.dst.resize_discard(1); N.w.resize_discard(1);
+        dvec<uint32_t> deg((size_t)ncl + 1);  // no edges: every degree is zero, the numbering stays the label order
+        HIP_TRY(hipMemsetAsync(deg.data(), 0, ((size_t)ncl + 1) * sizeof(uint32_t), h.stream));
+        coarse_degree_order(h, deg.data(), (int64_t)ncl, new_id, new_off);
       }
+      hipLaunchKernelGGL(k_relabel, grid_for(L.nv, kBlock, 8192), kBlock, 0, h.stream, c.data(), (uint32_t const*)new_id.data(), L.nv);
+      hipLaunchKernelGGL(k_compose, grid_for(nv0, kBlock, 8192), kBlock, 0, h.stream, part->buf.as<int32_t>(), (int32_t const*)c.data(), nv0);
+      h.sync();
       L = std::move(N);
     }
     if (trace)

@@ -410,8 +410,10 @@ static double lv_level(int64_t nv, int64_t ne, const int32_t* src, const int32_t
     }
     int64_t moves = 0;
     for (int64_t v = 0; v < nv; ++v) moves += best_d[v] > min_gain && ((best_c[v] > c[v]) == (up_down != 0));
-    if (moves == 0) up_down = !up_down;
-    for (int64_t v = 0; v < nv; ++v) if (best_d[v] > min_gain && ((best_c[v] > c[v]) == (up_down != 0))) c[v] = best_c[v];
+    /* update_clustering_by_delta_modularity takes up_down BY VALUE (common_methods.cuh:277, 445): a sweep without a move in its direction applies
+     * the moves of the other one, and that flip does not outlive the sweep */
+    int const dir = moves == 0 ? !up_down : up_down;
+    for (int64_t v = 0; v < nv; ++v) if (best_d[v] > min_gain && ((best_c[v] > c[v]) == (dir != 0))) c[v] = best_c[v];
     for (int64_t v = 0; v < nv; ++v) a[v] = 0.0;
     for (int64_t v = 0; v < nv; ++v) a[c[v]] += k[v];
     up_down = !up_down;
@@ -477,6 +479,41 @@ int orc_louvain(int64_t nv, int64_t ne, const int32_t* src_in, const int32_t* ds
       }
       qsort(lst, (size_t)n, sizeof(lv_cw), cmp_lv_cw);
       for (int64_t j = 0; j < n; ++j) { src[out] = cs; dst[out] = lst[j].c; w[out] = acc[lst[j].c]; ++out; }  /* out <= cur_ne: in place is safe (reads are in gd/gw) */
+      coff[cs] = out - n;  /* (row cs of the fine list has been consumed: from here on coff[cs] = start of COARSE row cs) */
+    }
+    coff[ncl] = out;
+    /* graph_contraction (common_methods.cuh:231-263) = coarsen_graph(..., renumber = true): the coarse vertices are numbered as every graph creation
+     * numbers vertices -- by degree, descending, equal degrees in ascending label order (renumber_edgelist_impl.cuh, step 4: a stable key sort over
+     * the id-sorted vertex list); degree = coarse edges leaving the vertex = its distinct neighbour clusters.  The ids decide the ties (smaller
+     * cluster id wins) and the up / down rule of the next level: part of the algorithm (the reference's karate goldens at resolution 1,
+     * cpp/tests/community/louvain_test.cpp:228-237, are missed with label-order ids). */
+    {
+      int64_t maxd = 0;
+      for (int32_t v = 0; v < ncl; ++v) if (coff[v + 1] - coff[v] > maxd) maxd = coff[v + 1] - coff[v];
+      int64_t* bin = (int64_t*)calloc((size_t)maxd + 2, sizeof(int64_t));  /* counting sort by (maxd - degree): stable, so labels stay ascending */
+      for (int32_t v = 0; v < ncl; ++v) bin[maxd - (coff[v + 1] - coff[v]) + 1]++;
+      for (int64_t d = 0; d <= maxd; ++d) bin[d + 1] += bin[d];
+      int32_t* new_id = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ncl > 0 ? ncl : 1));
+      int32_t* old_of = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ncl > 0 ? ncl : 1));
+      for (int32_t v = 0; v < ncl; ++v) { int64_t const at = bin[maxd - (coff[v + 1] - coff[v])]++; new_id[v] = (int32_t)at; old_of[at] = v; }
+      for (int64_t v = 0; v < nv; ++v) clusters[v] = new_id[clusters[v]];
+      /* rows in the new order, every row ascending in the new neighbour ids (gd / gw are free again: the coarse list is in src / dst / w) */
+      int64_t at = 0;
+      for (int32_t r = 0; r < ncl; ++r) {
+        int32_t const o = old_of[r];
+        int64_t const n = coff[o + 1] - coff[o];
+        for (int64_t j = 0; j < n; ++j) { lst[j].c = new_id[dst[coff[o] + j]]; lst[j].w = w[coff[o] + j]; }
+        qsort(lst, (size_t)n, sizeof(lv_cw), cmp_lv_cw);
+        for (int64_t j = 0; j < n; ++j) { gd[at + j] = lst[j].c; gw[at + j] = lst[j].w; }
+        at += n;
+      }
+      at = 0;
+      for (int32_t r = 0; r < ncl; ++r) {
+        int64_t const n = coff[old_of[r] + 1] - coff[old_of[r]];
+        for (int64_t j = 0; j < n; ++j) { src[at + j] = r; dst[at + j] = gd[at + j]; w[at + j] = gw[at + j]; }
+        at += n;
+      }
+      free(bin); free(new_id); free(old_of);
     }
     cur_ne = out;
     cur_nv = ncl;

@@ -382,9 +382,8 @@ def _louvain_level(nv, src, dst, w, threshold, resolution, m, noise_floor=1e-15)
                 best_d[v], best_c[v] = dd, cc
         want = best_d > min_gain
         moves = want & ((best_c > c) == up_down)
-        if not moves.any():
-            up_down = not up_down
-            moves = want & ((best_c > c) == up_down)
+        if not moves.any():  # update_clustering_by_delta_modularity takes up_down BY VALUE (common_methods.cuh:277): its flip lasts for this sweep only
+            moves = want & ((best_c > c) == (not up_down))
         c = np.where(moves, best_c, c)
         a = np.zeros(nv)
         np.add.at(a, c, k)
@@ -419,9 +418,20 @@ def louvain(nv, src, dst, w=None, max_level=100, threshold=1e-7, resolution=1.0,
         if q <= best:
             break
         best = q
+        # graph_contraction (common_methods.cuh:231-263): coarsen_graph(..., renumber = true) numbers the coarse vertices as every graph
+        # creation does -- by degree, descending (renumber_edgelist_impl.cuh: "4. sort local vertices by degree (descending)", a stable key
+        # sort over the id-sorted vertex list, so equal degrees keep ascending label order); degree = number of coarse edges leaving the
+        # vertex, i.e. of DISTINCT neighbour clusters (its own included when it has internal weight).  The ids decide every tie of the next
+        # level (smaller cluster id wins, reduce_op_t) and its up / down rule, so they are part of the algorithm: with label-order ids the
+        # restatement missed the reference's karate goldens (cpp/tests/community/louvain_test.cpp:228-237) at resolution 1.
         used = np.zeros(cur_nv, bool)
         used[c] = True
-        rank = np.cumsum(used) - 1                            # new id = rank of the label among the labels in use
+        labels = np.flatnonzero(used)
+        pair_keys = np.unique(c[src].astype(np.int64) * cur_nv + c[dst])
+        deg = np.bincount(pair_keys // cur_nv, minlength=cur_nv)[labels]
+        by_degree = np.lexsort((labels, -deg))
+        rank = np.full(cur_nv, -1, np.int64)
+        rank[labels[by_degree]] = np.arange(labels.size)
         c = rank[c]
         part = c[part]
         cur_nv = int(used.sum())

@@ -1139,6 +1139,23 @@ def test_capi_louvain_goldens(cg, handle, orc, store_transposed):
     assert canonical_partition(by_vertex(v, c1)[0]) == canonical_partition(oc) and abs(q1 - oq) <= 1e-12
 
 
+def test_louvain_reference_karate_goldens(cg, handle, orc, golden):
+    """cpp/tests/community/louvain_test.cpp:228-237 -- the reference's own expectations for karate (renumber = false, float weights): modularity
+    0.39907956 (defaults, and max_level 20 / threshold 1e-3), 0.48573306 at resolution 0.8; ASSERT_FLOAT_EQ = 4 float ulps.  The second and third
+    level of these runs are decided by how graph_contraction NUMBERS the coarse vertices (by degree, descending: coarse_degree_order in
+    csrc/louvain.hip); with label-order ids the run ends at 0.4197896.  Clusters equal the restatement's vertex for vertex."""
+    k = golden["graphs"]["karate.csv"]
+    src, dst = np.array(k["src"], np.int32), np.array(k["dst"], np.int32)
+    w = np.ones(src.size, np.float32)
+    g = cg.SGGraph(handle, cg.GraphProperties(is_symmetric=True), T(src, np.int32), T(dst, np.int32), T(w, np.float32), renumber=False)
+    for args, q_ref in (((100, 1e-7, 1.0), 0.39907956), ((20, 1e-3, 1.0), 0.39907956), ((100, 1e-3, 0.8), 0.48573306)):
+        v, c, q = cg.louvain(handle, g, args[0], args[1], args[2], False)
+        (c,) = by_vertex(v, c)
+        assert abs(np.float32(q) - np.float32(q_ref)) <= 4 * np.spacing(np.float32(q_ref)), (args, q)
+        oc, oq, olevels = orc.louvain(34, src, dst, w, *args)
+        assert olevels == 3 and np.array_equal(c, oc) and abs(q - oq) <= 1e-12
+
+
 @pytest.mark.parametrize("scale,resolution", [(8, 1.0), (10, 1.0), (10, 0.5)])
 def test_louvain_rmat_vs_oracle(cg, handle, orc, scale, resolution):
     """Undirected RMAT with integer weights (every sum is exact): the clustering must equal the oracle's vertex for vertex, the

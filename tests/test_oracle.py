@@ -216,6 +216,27 @@ def test_louvain_restatement_pinned_to_c_api_goldens(orc):
     assert abs(orc.louvain_modularity(src, dst, np.ones(16), c) - q) <= 1e-12
 
 
+def test_louvain_restatement_pinned_to_the_reference_karate_goldens(orc, golden):
+    """cpp/tests/community/louvain_test.cpp:228-237 (Tests_Louvain_File, karate.mtx, renumber = false, weight_t = float, check_correctness): the
+    reference's own (levels, modularity) for three parameter sets -- ASSERT_EQ on the level count, ASSERT_FLOAT_EQ (4 float ulps) on the modularity.
+    Larger than the two 6-vertex C-API goldens, three levels deep, and sensitive to how the coarse graph of a level is NUMBERED (coarsen_graph
+    renumbers by degree; the ids decide the ties and the up / down rule of the next level): the restatement of rounds 1-5, with label-order ids,
+    returned 0.4197896 where the reference holds 0.39907956.  Both restatements (numpy, C) are held to it; datasets/karate.mtx is the same edge
+    set as datasets/karate.csv (the fixture graph)."""
+    k = golden["graphs"]["karate.csv"]
+    src, dst = np.array(k["src"], np.int32), np.array(k["dst"], np.int32)
+    assert src.size == 156 and int(max(src.max(), dst.max())) == 33
+    w = np.ones(src.size, np.float32)
+    cases = [((100, 1e-7, 1.0), 3, 0.39907956), ((20, 1e-3, 1.0), 3, 0.39907956), ((100, 1e-3, 0.8), 3, 0.48573306)]
+    for args, levels, q_ref in cases:
+        for fn in (orc.louvain, orc.louvain_c):
+            out = fn(34, src, dst, w, *args)
+            c, q, lv = out[0], out[1], out[2]
+            assert lv == levels, (args, fn.__name__, lv)
+            assert abs(np.float32(q) - np.float32(q_ref)) <= 4 * np.spacing(np.float32(q_ref)), (args, fn.__name__, q)
+            assert abs(orc.louvain_modularity(src, dst, np.ones(src.size), c, args[2]) - q) <= 1e-12
+
+
 def test_louvain_restatement_vs_networkx_modularity(orc):
     """The reported modularity is the modularity of the returned partition (NetworkX's definition on the same
     undirected weighted graph), and it is not worse than NetworkX's own Louvain by more than a few percent."""
