@@ -334,8 +334,11 @@ ORC_SSSP_MIN_PRED(orc_sssp_min_pred_f64, double, DBL_MAX)
  * Follows detail::louvain (cpp/src/community/louvain_impl.cuh:78-262) with rng_state = nullopt: synchronous local moving --
  * every vertex takes the neighbouring cluster with the largest modularity gain (update_clustering_by_delta_modularity,
  * detail/common_methods.cuh:259-447; gain expression :70-125), ties to the smaller cluster id, moves only "up" or only "down"
- * in alternate sweeps -- a modularity test per sweep (compute_modularity, :176-228) and contraction per level
- * (graph_contraction, :230-257).  Per vertex the weights are accumulated per neighbouring cluster in STORED EDGE ORDER (a
+ * in alternate sweeps (a sweep with no move in its direction applies the other direction's; that flip is local to the sweep: up_down is
+ * a by-value argument, :277) -- a modularity test per sweep (compute_modularity, :176-228) and contraction per level
+ * (graph_contraction, :230-257), whose coarse vertices are numbered BY DEGREE, descending (coarsen_graph(renumber = true) ->
+ * renumber_edgelist_impl.cuh step 4; equal degrees in label order).  Pinned to the reference's two C-API goldens AND its three karate
+ * goldens (cpp/tests/community/louvain_test.cpp:228-237) by tests/test_oracle.py.  Per vertex the weights are accumulated per neighbouring cluster in STORED EDGE ORDER (a
  * marker array instead of the numpy version's lexsort: same sums in the same order), clusters are then visited in ascending
  * order.  Edges must be grouped by source (any order inside a source).
  * DEVIATION from the reference, on purpose: every sum and every gain here is fp64 whatever the graph's weight type; the reference computes
