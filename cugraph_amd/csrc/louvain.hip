@@ -65,8 +65,8 @@ __global__ void k_expand_src(int32_t const* offsets, int64_t nv, int32_t* src)
   int64_t const wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   int const lane = threadIdx.x & 63;
   for (int64_t v = wave; v < nv; v += nwaves) {
-    int32_t const b = offsets[v], e = offsets[v + 1];
-    for (int32_t p = b + lane; p < e; p += 64) src[p] = (int32_t)v;
+    uint32_t const b = (uint32_t)offsets[v], e = (uint32_t)offsets[v + 1];  // (positions: unsigned words)
+    for (int64_t p = (int64_t)b + lane; p < (int64_t)e; p += 64) src[p] = (int32_t)v;
   }
 }
 template <typename WT>
@@ -270,12 +270,13 @@ struct lv_hash_args {
   // a chain of four dependent loads on ONE thread before a workgroup could start, and src -> off per edge)
   long long const* range;         // [chunks][2] edge range [p0, p1) of every chunk (p1 <= p0: nothing)
   uint16_t const* rs;             // [ne] row slot of every edge = position of its row's first edge inside that row's window (off[src] mod LVH_B); bit 15: the edge is a self-loop
+  int64_t chunk0;                 // first chunk of this launch (a launch holds fewer than 2^32 threads: levels of more than 2^31 edges take several)
 };
 __device__ __forceinline__ uint32_t lvh_slot(uint32_t rs, uint32_t cl) { return ((rs * 0x9E3779B1u) ^ (cl * 0x85EBCA6Bu) ^ (cl >> 15)) & (LVH_SLOTS - 1); }
 static_assert((LVH_B & (LVH_B - 1)) == 0 && LVH_B <= 0x8000, "the row slot is off[v] mod LVH_B and shares 16 bits with the self-loop flag");
 static_assert(LVH_CAP % LVH_THREADS == 0, "a chunk's edges live in registers between the passes: LVH_CAP / LVH_THREADS per thread");
 // once per level: the edge range of every chunk (the rule of round 3, see above) and the row slot of every edge
-__global__ void k_lv_chunk_prep(int32_t const* src, int32_t const* dst, int32_t const* off, int64_t ne, long long* range, uint16_t* rs)
+__global__ void k_lv_chunk_prep(int32_t const* src, int32_t const* dst, uint32_t const* off, int64_t ne, long long* range, uint16_t* rs)
 {
   int64_t const t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
   int64_t const n_chunks = (ne + LVH_B - 1) / LVH_B;
@@ -317,10 +318,11 @@ __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
   __shared__ int32_t s_bestc[LVH_B], s_cv[LVH_B];
   __shared__ unsigned long long s_int;
   int const tid = threadIdx.x;
-  int64_t const e_lo = blockIdx.x * (int64_t)LVH_B;
-  int64_t const p0   = A.range[2 * (int64_t)blockIdx.x];
-  int const n        = (int)(A.range[2 * (int64_t)blockIdx.x + 1] - p0);  // < 2 * LVH_B
-  if (n <= 0) { if (tid == 0) A.ipart[blockIdx.x] = 0; return; }
+  int64_t const chunk = A.chunk0 + blockIdx.x;
+  int64_t const e_lo = chunk * (int64_t)LVH_B;
+  int64_t const p0   = A.range[2 * chunk];
+  int const n        = (int)(A.range[2 * chunk + 1] - p0);  // < 2 * LVH_B
+  if (n <= 0) { if (tid == 0) A.ipart[chunk] = 0; return; }
   uint32_t rsf[LVH_E];
   int32_t u[LVH_E];
   double w[LVH_E];
@@ -419,7 +421,7 @@ __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
       if (self) atomicAdd(&s_int, self);
     }
   __syncthreads();
-  if (tid == 0) A.ipart[blockIdx.x] = s_int;
+  if (tid == 0) A.ipart[chunk] = s_int;
 }
 // Round 4: rows of LVH_B < degree <= LVM_MAX edges ("mid rows": a quarter of the edges of RMAT-22 that used to take the sorted path with
 // the hubs): ONE workgroup per row, the row's (cluster -> weight) sums in an LDS open-addressing table keyed by the cluster alone (at most
@@ -429,7 +431,7 @@ __global__ void __launch_bounds__(LVH_THREADS) k_lv_hash_chunks(lv_hash_args A)
 constexpr int LVM_MAX = 4096, LVM_THREADS = 512;
 struct lv_mid_args {
   int32_t const* rows; int32_t n_rows;  // vertices with LVH_B < degree <= max_deg of this launch, any order
-  int32_t const* dst; int32_t const* off; double const* w; int32_t const* c; double const* k; double const* a;
+  int32_t const* dst; uint32_t const* off; double const* w; int32_t const* c; double const* k; double const* a;
   double m, resolution, scale, inv_scale;
   unsigned long long* best_bits; int32_t* best_c;
   unsigned long long* ifix;  // += the rows' weight into their own clusters
@@ -450,10 +452,12 @@ __global__ void __launch_bounds__(LVM_THREADS) k_lv_hash_rows(lv_mid_args A)
   int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto slot_of = [](uint32_t cl) { return ((cl * 0x9E3779B1u) ^ (cl >> 15)) & (uint32_t)(SLOTS - 1); };
   unsigned long long internal = 0;  // (the same value in every thread)
-  int32_t v_n = 0, b_n = 0, d_n = 0, cv_n = 0;
-  if ((int)blockIdx.x < A.n_rows) { v_n = A.rows[blockIdx.x]; b_n = A.off[v_n]; d_n = A.off[v_n + 1] - b_n; cv_n = A.c[v_n]; }
+  int32_t v_n = 0, d_n = 0, cv_n = 0;
+  uint32_t b_n = 0;
+  if ((int)blockIdx.x < A.n_rows) { v_n = A.rows[blockIdx.x]; b_n = A.off[v_n]; d_n = (int32_t)(A.off[v_n + 1] - b_n); cv_n = A.c[v_n]; }
   for (int r = blockIdx.x; r < A.n_rows; r += gridDim.x) {
-    int32_t const v = v_n, b = b_n, d = d_n, cv = cv_n;
+    int32_t const v = v_n, d = d_n, cv = cv_n;
+    uint32_t const b = b_n;
     int32_t u[EPT];
     double w[EPT];
 #pragma unroll
@@ -463,7 +467,7 @@ __global__ void __launch_bounds__(LVM_THREADS) k_lv_hash_rows(lv_mid_args A)
       if (i < d) { u[j] = A.dst[b + i]; w[j] = A.w[b + i]; }
     }
     double const a_old = A.a[cv], kk = A.k[v];
-    if (r + (int)gridDim.x < A.n_rows) { v_n = A.rows[r + gridDim.x]; b_n = A.off[v_n]; d_n = A.off[v_n + 1] - b_n; cv_n = A.c[v_n]; }
+    if (r + (int)gridDim.x < A.n_rows) { v_n = A.rows[r + gridDim.x]; b_n = A.off[v_n]; d_n = (int32_t)(A.off[v_n + 1] - b_n); cv_n = A.c[v_n]; }
     for (int i = tid; i < SLOTS; i += LVM_THREADS) { s_key[i] = 0xFFFFFFFFu; s_sum[i] = 0; }
     if (tid == 0) s_sub = 0;
     uint32_t cl[EPT];
@@ -555,7 +559,7 @@ struct lv_big_args {
   int4 const* items; int32_t n_items;  // (row, r, R, position of the row's first edge in the big rows' edge list)
   uint32_t const* ecl; unsigned long long const* ewf;  // per edge of that list: cluster of the destination (this sweep), fixed-point weight (this level)
   unsigned long long const* rowsub;                    // [nv] self-loop weight of a row (this level)
-  int32_t const* off; int32_t const* c; double const* k; double const* a;
+  uint32_t const* off; int32_t const* c; double const* k; double const* a;
   double m, resolution, scale, inv_scale;
   unsigned long long* best_bits; int32_t* best_c;
   unsigned long long* item_bits; int32_t* item_c;  // [n_items]
@@ -578,7 +582,7 @@ __global__ void __launch_bounds__(LVB_THREADS) k_lv_hash_big(lv_big_args A)
     int4 const item = A.items[it];
     int32_t const v = item.x;
     uint32_t const r = (uint32_t)item.y, R = (uint32_t)item.z;
-    int32_t const d = A.off[v + 1] - A.off[v];
+    int32_t const d = (int32_t)(A.off[v + 1] - A.off[v]);
     for (int i = tid; i < LVB_SLOTS; i += LVB_THREADS) { s_key[i] = 0xFFFFFFFFu; s_sum[i] = 0; }
     if (tid == 0) { s_self = 0; s_used = 0; s_full = 0; }
     __syncthreads();
@@ -672,11 +676,11 @@ __global__ void k_lv_big_ties(lv_big_args A)
     if (bits && bits == A.best_bits[v]) atomicMin(&A.best_c[v], A.item_c[i]);
   }
 }
-__global__ void k_lv_big_items(int32_t const* off, uint32_t const* pos, int64_t nv, int longer_than, int4* items, uint32_t* count)
+__global__ void k_lv_big_items(uint32_t const* off, uint32_t const* pos, int64_t nv, int longer_than, int4* items, uint32_t* count)
 {
   LV_LOOP(v, nv)
   {
-    int32_t const d = off[v + 1] - off[v];
+    int32_t const d = (int32_t)(off[v + 1] - off[v]);
     if (d > longer_than) {
       int32_t const R   = (d + LVB_SHARE - 1) / LVB_SHARE;
       uint32_t const at = atomicAdd(count, (uint32_t)R);
@@ -696,11 +700,11 @@ __global__ void k_lv_big_prep(int32_t const* hs, int32_t const* hd, double const
 }
 // once per sweep: the cluster of every big-row edge's destination (the items of a row then re-read 12 sequential bytes per edge)
 __global__ void k_lv_big_gather(int32_t const* hd, int32_t const* c, int64_t n, uint32_t* ecl) { LV_LOOP(q, n) ecl[q] = (uint32_t)c[hd[q]]; }
-__global__ void k_lv_mid_rows(int32_t const* off, int64_t nv, int lo, int hi, int32_t* rows, uint32_t* count)
+__global__ void k_lv_mid_rows(uint32_t const* off, int64_t nv, int lo, int hi, int32_t* rows, uint32_t* count)
 {
   LV_LOOP(v, nv)
   {
-    int32_t const d = off[v + 1] - off[v];
+    int32_t const d = (int32_t)(off[v + 1] - off[v]);
     if (d > lo && d <= hi) rows[atomicAdd(count, 1u)] = (int32_t)v;
   }
 }
@@ -713,7 +717,7 @@ __global__ void k_lv_mid_rows(int32_t const* off, int64_t nv, int lo, int hi, in
 // k_lv_hub_eval<0/1> walks the table slots flat -- slot t belongs to the row of hub edge t / 2 -- and reduces the best gain / the
 // smallest cluster among the best per row exactly as the sorted path's k_segment_best does.  Same integers, same gains, same ties.
 struct lv_hub_args {
-  int32_t const* hs; int32_t const* hd; double const* hw; uint32_t const* hrow0; int32_t const* off;  // hub list + first hub position of the edge's row
+  int32_t const* hs; int32_t const* hd; double const* hw; uint32_t const* hrow0; uint32_t const* off;  // hub list + first hub position of the edge's row
   int32_t const* c; double const* k; double const* a; double m, resolution, scale, inv_scale; int64_t n_h;
   unsigned long long* keys; unsigned long long* sums;  // [2 * n_h]: keys = cluster id, ~0 = empty (set by the caller), sums = 0
   unsigned long long* selffix; unsigned long long* subfix; unsigned long long* best_bits; int32_t* best_c;  // [nv]
@@ -800,11 +804,11 @@ __global__ void k_lv_hub_eval(lv_hub_args A)
   }
 }
 // hub rows (more than LVH_B edges): their edges, compacted once per level, go through the sorted path
-__global__ void k_lv_hub_flags(int32_t const* src, int32_t const* off, int64_t ne, int32_t longer_than, uint32_t* flag)
+__global__ void k_lv_hub_flags(int32_t const* src, uint32_t const* off, int64_t ne, int32_t longer_than, uint32_t* flag)
 {
-  LV_LOOP(e, ne) { int32_t const v = src[e]; flag[e] = (off[v + 1] - off[v] > longer_than) ? 1u : 0u; }
+  LV_LOOP(e, ne) { int32_t const v = src[e]; flag[e] = ((int32_t)(off[v + 1] - off[v]) > longer_than) ? 1u : 0u; }
 }
-__global__ void k_lv_hub_compact(int32_t const* src, int32_t const* dst, double const* w, int32_t const* off, uint32_t const* flag, uint32_t const* pos, int64_t ne,
+__global__ void k_lv_hub_compact(int32_t const* src, int32_t const* dst, double const* w, uint32_t const* off, uint32_t const* flag, uint32_t const* pos, int64_t ne,
                                  int32_t* hs, int32_t* hd, double* hw, uint32_t* hrow0)
 {
   LV_LOOP(e, ne) if (flag[e]) { uint32_t const q = pos[e]; hs[q] = src[e]; hd[q] = dst[e]; hw[q] = w[e]; hrow0[q] = pos[off[src[e]]]; }
@@ -1062,7 +1066,8 @@ __global__ void k_cluster_weights(int32_t const* c, long long const* kfix, int64
 
 struct level_t {
   int64_t nv{0}, ne{0};
-  dvec<int32_t> src, dst, off;
+  dvec<int32_t> src, dst;
+  dvec<uint32_t> off;  // edge positions are unsigned 32-bit words (a level may hold 2^31 or more edges)
   dvec<double> w;
   bool have_off{false};  // off[] holds the rows' offsets
 };
@@ -1092,7 +1097,7 @@ void build_offsets(handle_t const& h, level_t& L)
     hipLaunchKernelGGL(k_row_bounds, grid_for(L.ne, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)L.src.data(), L.ne, first, last);
     hipLaunchKernelGGL(k_row_lengths, grid_for(L.nv, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)first, last, L.nv);
   }
-  exclusive_scan_u32(h, last, reinterpret_cast<uint32_t*>(L.off.data()), L.nv + 1);
+  exclusive_scan_u32(h, last, L.off.data(), L.nv + 1);
   h.sync();  // `fl` is released here
   L.have_off = true;
 }
@@ -1111,7 +1116,7 @@ void sort_pairs(handle_t const& h, dvec<uint64_t>& keys, dvec<uint32_t>& vals, i
 // degrees keep ascending label order); degree = coarse edges leaving the vertex = its distinct neighbour clusters.  The ids are not cosmetic: the next
 // level breaks equal gains towards the smaller cluster id (reduce_op_t) and moves up or down by comparing ids.  Rounds 1-5 numbered the coarse vertices
 // by label order and missed the reference's karate goldens at resolution 1 (cpp/tests/community/louvain_test.cpp:228-237: 0.39907956, three levels).
-__global__ void k_lv_row_lengths_of(int32_t const* off, int64_t n, uint32_t* len) { LV_LOOP(v, n) len[v] = (uint32_t)off[v + 1] - (uint32_t)off[v]; }
+__global__ void k_lv_row_lengths_of(uint32_t const* off, int64_t n, uint32_t* len) { LV_LOOP(v, n) len[v] = (uint32_t)off[v + 1] - (uint32_t)off[v]; }
 __global__ void k_lv_degree_keys(uint32_t const* deg, int64_t n, uint64_t* keys, uint32_t* vals)
 {
   LV_LOOP(v, n) { keys[v] = (uint64_t)(0xFFFFFFFFu - deg[v]); vals[v] = (uint32_t)v; }
@@ -1139,7 +1144,7 @@ void coarse_degree_order(handle_t const& h, uint32_t const* deg, int64_t ncl, dv
   h.sync();  // (temporaries die here)
 }
 // the rows of a coarse edge list (sorted by source in the OLD ids, offsets old_off) move to where the new numbering puts them; a row keeps its internal order
-__global__ void k_lv_renumber_rows(int32_t const* src, int32_t const* dst, unsigned long long const* wfix, int64_t ne, int32_t const* old_off, uint32_t const* new_off,
+__global__ void k_lv_renumber_rows(int32_t const* src, int32_t const* dst, unsigned long long const* wfix, int64_t ne, uint32_t const* old_off, uint32_t const* new_off,
                                    uint32_t const* new_id, double inv_scale, int32_t* src2, int32_t* dst2, double* w2)
 {
   LV_LOOP(p, ne)
@@ -1212,10 +1217,10 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     chunk_int.resize_discard((size_t)((ne + LVH_B - 1) / LVH_B));
     chunk_range.resize_discard((size_t)((ne + LVH_B - 1) / LVH_B) * 2);
     chunk_rs.resize_discard((size_t)ne);
-    hipLaunchKernelGGL(k_lv_chunk_prep, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.dst.data(), (int32_t const*)L.off.data(), ne, chunk_range.data(),
+    hipLaunchKernelGGL(k_lv_chunk_prep, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.dst.data(), (uint32_t const*)L.off.data(), ne, chunk_range.data(),
                        chunk_rs.data());
     dvec<uint32_t> flag((size_t)ne + 1), pos((size_t)ne + 1);
-    hipLaunchKernelGGL(k_lv_hub_flags, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.off.data(), ne, (int32_t)(use_mid ? LVM_MAX : LVH_B),
+    hipLaunchKernelGGL(k_lv_hub_flags, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (uint32_t const*)L.off.data(), ne, (int32_t)(use_mid ? LVM_MAX : LVH_B),
                        flag.data());
     HIP_TRY(hipMemsetAsync(flag.data() + ne, 0, sizeof(uint32_t), h.stream));
     exclusive_scan_u32(h, flag.data(), pos.data(), ne + 1);
@@ -1223,11 +1228,11 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
       size_t const cap = (size_t)(ne / LVH_B + 2);  // rows of more than LVH_B edges
       mid_rows[0].resize_discard(cap); mid_rows[1].resize_discard(cap);
       HIP_TRY(hipMemsetAsync(mid_count.data(), 0, 3 * sizeof(uint32_t), h.stream));
-      hipLaunchKernelGGL(k_lv_mid_rows, g_v, kBlock, 0, h.stream, (int32_t const*)L.off.data(), nv, LVH_B, LVM_MAX / 2, mid_rows[0].data(), mid_count.data());
-      hipLaunchKernelGGL(k_lv_mid_rows, g_v, kBlock, 0, h.stream, (int32_t const*)L.off.data(), nv, LVM_MAX / 2, LVM_MAX, mid_rows[1].data(), mid_count.data() + 1);
+      hipLaunchKernelGGL(k_lv_mid_rows, g_v, kBlock, 0, h.stream, (uint32_t const*)L.off.data(), nv, LVH_B, LVM_MAX / 2, mid_rows[0].data(), mid_count.data());
+      hipLaunchKernelGGL(k_lv_mid_rows, g_v, kBlock, 0, h.stream, (uint32_t const*)L.off.data(), nv, LVM_MAX / 2, LVM_MAX, mid_rows[1].data(), mid_count.data() + 1);
       if (use_big) {
         big_items.resize_discard((size_t)(ne / LVB_SHARE + ne / LVM_MAX + 2));  // sum over the big rows of ceil(degree / LVB_SHARE)
-        hipLaunchKernelGGL(k_lv_big_items, g_v, kBlock, 0, h.stream, (int32_t const*)L.off.data(), (uint32_t const*)pos.data(), nv, LVM_MAX, big_items.data(),
+        hipLaunchKernelGGL(k_lv_big_items, g_v, kBlock, 0, h.stream, (uint32_t const*)L.off.data(), (uint32_t const*)pos.data(), nv, LVM_MAX, big_items.data(),
                            mid_count.data() + 2);
       }
       h.read_back(n_mid, mid_count.data(), 3);
@@ -1241,7 +1246,7 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     hrow0.resize_discard(h1);
     if (n_sorted > 0)
       hipLaunchKernelGGL(k_lv_hub_compact, g_e, kBlock, 0, h.stream, (int32_t const*)L.src.data(), (int32_t const*)L.dst.data(), (double const*)L.w.data(),
-                         (int32_t const*)L.off.data(), (uint32_t const*)flag.data(), (uint32_t const*)pos.data(), ne, Lh.src.data(), Lh.dst.data(), Lh.w.data(),
+                         (uint32_t const*)L.off.data(), (uint32_t const*)flag.data(), (uint32_t const*)pos.data(), ne, Lh.src.data(), Lh.dst.data(), Lh.w.data(),
                          hrow0.data());
     h.sync();
   }
@@ -1325,9 +1330,12 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     if (use_hash && n_sorted < ne) {
       hipLaunchKernelGGL(k_lv_pack_ca, g_v, kBlock, 0, h.stream, (int32_t const*)c.data(), (double const*)a.data(), nv, ca.data());
       lv_hash_args HA{L.src.data(), L.dst.data(), L.w.data(), k.data(), ca.data(), m, resolution, scale, 1.0 / scale, ne,
-                      vfix.data() + 2 * nv, best_c.data(), chunk_int.data(), chunk_range.data(), chunk_rs.data()};
+                      vfix.data() + 2 * nv, best_c.data(), chunk_int.data(), chunk_range.data(), chunk_rs.data(), 0};
       int64_t const n_chunks = (ne + LVH_B - 1) / LVH_B;
-      hipLaunchKernelGGL(k_lv_hash_chunks, (int)n_chunks, LVH_THREADS, 0, h.stream, HA);
+      constexpr int64_t kChunksPerLaunch = ((int64_t)1 << 31) / LVH_THREADS;  // (grid x block must stay below 2^32 threads)
+      for (HA.chunk0 = 0; HA.chunk0 < n_chunks; HA.chunk0 += kChunksPerLaunch)
+        hipLaunchKernelGGL(k_lv_hash_chunks, (int)std::min<int64_t>(n_chunks - HA.chunk0, kChunksPerLaunch), LVH_THREADS, 0, h.stream, HA);
+      HIP_TRY(hipGetLastError());  // (an oversized grid is refused at launch, silently otherwise)
       hipLaunchKernelGGL(k_lv_sum_u64, (int)std::max<int64_t>(1, std::min<int64_t>((n_chunks + 1023) / 1024, 256)), 1024, 0, h.stream, (unsigned long long const*)chunk_int.data(), n_chunks, ifix);
     }
     if (n_mid[0] + n_mid[1] > 0 || big_hash) {
@@ -1673,7 +1681,7 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
       *result = reinterpret_cast<cugraph_hierarchical_clustering_result_t*>(r);
       return;
     }
-    CGA_EXPECTS(g.ne <= kMaxSignedEdges, CUGRAPH_UNSUPPORTED_TYPE_COMBINATION, "Louvain: graphs of 2^31 or more edges are not supported");
+    // (round 6: edge positions are unsigned words on the single-GPU path, as in graph construction and the traversals: up to kMaxGraphEdges, which creation enforces)
     ensure_orientation(h, g, false);  // louvain expects store_transposed == false (louvain.cpp:60-66)
     orientation_t const& o = g.csr;
     int64_t const nv0 = g.nv;
@@ -1757,11 +1765,11 @@ extern "C" cugraph_error_code_t cugraph_louvain(const cugraph_resource_handle_t*
         // the coarse vertices in the reference's numbering (coarse_degree_order): degrees = the rows' lengths, the rows move, the weights leave fixed point
         build_offsets(h, N);  // (rows of the label-order ids)
         dvec<uint32_t> deg((size_t)ncl + 1);
-        hipLaunchKernelGGL(k_lv_row_lengths_of, grid_for((int64_t)ncl, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)N.off.data(), (int64_t)ncl, deg.data());
+        hipLaunchKernelGGL(k_lv_row_lengths_of, grid_for((int64_t)ncl, kBlock, 8192), kBlock, 0, h.stream, (uint32_t const*)N.off.data(), (int64_t)ncl, deg.data());
         coarse_degree_order(h, deg.data(), (int64_t)ncl, new_id, new_off);
         dvec<int32_t> src2(n1), dst2(n1);
         hipLaunchKernelGGL(k_lv_renumber_rows, grid_for((int64_t)nce, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)N.src.data(), (int32_t const*)N.dst.data(),
-                           (unsigned long long const*)cwfix.data(), (int64_t)nce, (int32_t const*)N.off.data(), (uint32_t const*)new_off.data(), (uint32_t const*)new_id.data(),
+                           (unsigned long long const*)cwfix.data(), (int64_t)nce, (uint32_t const*)N.off.data(), (uint32_t const*)new_off.data(), (uint32_t const*)new_id.data(),
                            1.0 / scale, src2.data(), dst2.data(), N.w.data());
         HIP_TRY(hipMemcpyAsync(N.off.data(), new_off.data(), ((size_t)ncl + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, h.stream));
         h.sync();

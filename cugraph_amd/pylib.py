@@ -33,6 +33,14 @@ _NP_TO_C = {"int8": capi.INT8, "int16": capi.INT16, "int32": capi.INT32, "int64"
             "float64": capi.FLOAT64, "bool": capi.BOOL}
 
 
+
+def _lib_at_exit():
+    """the library for a finalizer: None once the interpreter has torn this module's globals down (objects that outlive it are released with the process)"""
+    try:
+        return capi.lib()
+    except Exception:  # noqa: BLE001
+        return None
+
 class FailedToConvergeError(Exception):
     """Raised when an iterative algorithm does not converge (pylibcugraph/exceptions.py:9)."""
 
@@ -172,8 +180,8 @@ class ResourceHandle:
 
     def __del__(self):
         p = getattr(self, "c_resource_handle_ptr", None)
-        if p:
-            capi.lib().cugraph_free_resource_handle(p)
+        if p and _lib_at_exit() is not None:
+            _lib_at_exit().cugraph_free_resource_handle(p)
             self.c_resource_handle_ptr = None
 
     # --- harness helpers (extensions.h)
@@ -268,8 +276,8 @@ class SGGraph:
 
     def __del__(self):
         p = getattr(self, "c_graph_ptr", None)
-        if p:
-            capi.lib().cugraph_graph_free(p)
+        if p and _lib_at_exit() is not None:
+            _lib_at_exit().cugraph_graph_free(p)
             self.c_graph_ptr = None
 
     @property
@@ -682,6 +690,6 @@ class PageRankPlan:
 
     def __del__(self):
         p = getattr(self, "ptr", None)
-        if p:
-            capi.lib().cugraph_amd_pagerank_plan_free(p)
+        if p and _lib_at_exit() is not None:
+            _lib_at_exit().cugraph_amd_pagerank_plan_free(p)
             self.ptr = None

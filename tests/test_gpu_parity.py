@@ -1340,6 +1340,60 @@ def test_louvain_rmat_golden(cg, handle, scale):
     assert hashlib.sha256(np.ascontiguousarray(c, np.int32).tobytes()).hexdigest() == gold["clusters_sha256"]
 
 
+def test_louvain_two_to_the_31_edges(cg, handle):
+    """Round 6: Louvain on a graph of more than 2^31 directed edges (undirected simple RMAT-27, edge factor 9: 2.4 G stored edges) -- the level's
+    edge positions are unsigned 32-bit words on the single-GPU path, as in graph construction and the traversals (rounds 1-5 refused such a graph;
+    the reference needs 64-bit edge types for it: cpp/src/c_api/graph_sg.cpp:745-779).  The oracle cannot run at this size (hours); checked through
+    size-independent properties: the returned modularity equals the modularity of the returned clustering recomputed from the edge list (torch, fp64;
+    integer weights: every sum is exact), the full run is no worse than its own first level, and a second run returns the same bits."""
+    import sys
+    from pathlib import Path
+
+    import torch
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    scale, nv = 27, 1 << 27
+    # the construction of undirected_rmat without its final sort by (src, dst) (torch sorts hold fewer than 2^31 elements; creation orders the edges itself)
+    src, dst = cg.generate_rmat_edgelist(handle, scale, 9 << scale, seed=5)
+    s, d = src.to(torch.int64), dst.to(torch.int64)
+    del src, dst
+    keep = s != d
+    key = torch.minimum(s, d)[keep] << 32 | torch.maximum(s, d)[keep]
+    del s, d, keep
+    key = torch.unique(key)
+    lo, hi = (key >> 32).to(torch.int32), (key & 0xFFFFFFFF).to(torch.int32)
+    del key
+    wt = (1 + (lo.long() * 7 + hi.long() * 13) % 8).to(torch.float32)
+    src, dst, w = torch.cat([lo, hi]), torch.cat([hi, lo]), torch.cat([wt, wt])
+    del lo, hi, wt
+    ne = int(src.numel())
+    assert (1 << 31) < ne < (1 << 32) - 4097
+    torch.cuda.empty_cache()
+    g = cg.SGGraph(handle, cg.GraphProperties(is_symmetric=True), src, dst, w, renumber=False, vertices_array=torch.arange(nv, dtype=torch.int32, device="cuda"))
+    v, c, q = cg.louvain(handle, g, 100, 1e-7, 1.0, False)
+    cl = torch.empty(nv, dtype=torch.int64, device="cuda")
+    cl[v.to(torch.int64)] = c.to(torch.int64)
+    assert int(cl.min()) >= 0 and int(cl.max()) < nv
+    m = float(w.double().sum())
+    # integer sums (the weights are 1..8): torch's fp64 scatter-adds are compare-and-swap loops, and a hub or a giant cluster queues 10^8 of them on one address
+    internal, k = 0, torch.zeros(nv, dtype=torch.int64, device="cuda")
+    step = 1 << 28
+    for lo in range(0, ne, step):  # (in slices: the whole list as int64 would take 60 GB of temporaries)
+        s, d, ww = src[lo:lo + step].long(), dst[lo:lo + step].long(), w[lo:lo + step].long()
+        internal += int((ww * (cl[s] == cl[d])).sum())
+        k.index_add_(0, s, ww)  # vertex weights
+        del s, d, ww
+    a = torch.zeros(nv, dtype=torch.int64, device="cuda").index_add_(0, cl, k).double()  # cluster weights
+    q_torch = internal / m - float((a * a).sum()) / (m * m)
+    assert abs(q_torch - q) <= 1e-9, (q_torch, q)
+    v1, c1, q1 = cg.louvain(handle, g, 1, 1e-7, 1.0, False)
+    assert q >= q1 > 0.0
+    v2, c2, q2 = cg.louvain(handle, g, 100, 1e-7, 1.0, False)
+    assert q2 == q and torch.equal(v2, v) and torch.equal(c2, c)
+    del g, src, dst, w, cl, a, k
+    torch.cuda.empty_cache()
+
+
 def test_capi_generators_edge_columns_and_decompress(cg, handle):
     """cugraph_generate_rmat_edgelists / _edge_ids / _edge_types (graph_generators.h), cugraph_data_type_id_from_dlpack,
     cugraph_graph_create_mg on a one-rank handle and cugraph_decompress_to_edgelist (external ids, by-source order)."""
