@@ -80,8 +80,11 @@ cugraph_error_code_t degrees_impl(const cugraph_resource_handle_t* handle, cugra
     if (GM(graph).mg) {  // a graph from cugraph_graph_create_mg on a communicator handle: collective, every rank answers for its share of the vertices
       graph_t& mgg = GM(graph);
       vertex_column_in c_msv;  // INT64 ids: compact int32 ids from here on (unknown ids -1: refused below like any id that is no vertex)
-      device_array_view_t const* msv = c_msv.get(h, mgg, sv_user, "source_vertices");
-      CGA_EXPECTS(msv == nullptr || msv->type == INT32, CUGRAPH_INVALID_INPUT, "vertex type of graph and source_vertices must match");
+      device_array_view_t const* msv = nullptr;
+      mg_agree(mgg, [&] {  // rank-local argument checks: every rank fails or none does (a rank that threw alone would leave its peers in the collective below)
+        msv = c_msv.get(h, mgg, sv_user, "source_vertices");
+        CGA_EXPECTS(msv == nullptr || msv->type == INT32, CUGRAPH_INVALID_INPUT, "vertex type of graph and source_vertices must match");
+      }, "cugraph_degrees");
       bool const msym   = mgg.props.is_symmetric == TRUE;
       bool const mshare = want_in && want_out && msym;  // degrees.cu:84-88
       dvec<int32_t> ids, din, dout;
@@ -256,9 +259,12 @@ extern "C" cugraph_error_code_t cugraph_extract_paths(const cugraph_resource_han
     graph_t& g        = GM(graph);
     auto pr           = reinterpret_cast<paths_result_t const*>(paths_result);
     auto dv           = reinterpret_cast<device_array_view_t const*>(destinations);
-    CGA_EXPECTS(result != nullptr && pr != nullptr && dv != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
-    CGA_EXPECTS(pr->distances != nullptr && pr->distances->type == g.api_vertex_type(), CUGRAPH_INVALID_INPUT,
-                "Invalid input argument: distances must come from cugraph_bfs (vertex-typed hop counts)");
+    auto const local_checks = [&] {
+      CGA_EXPECTS(result != nullptr && pr != nullptr && dv != nullptr, CUGRAPH_INVALID_INPUT, "NULL argument");
+      CGA_EXPECTS(pr->distances != nullptr && pr->distances->type == g.api_vertex_type(), CUGRAPH_INVALID_INPUT,
+                  "Invalid input argument: distances must come from cugraph_bfs (vertex-typed hop counts)");
+    };
+    if (!g.mg) local_checks();
     if (g.mg) {
       // A graph from cugraph_graph_create_mg (extract_paths.cpp:57-119 with multi_gpu = true; extract_bfs_paths_impl.cuh:130-240 looks the
       // predecessors of vertices other ranks own up through a distributed key-value store, one hop per round).  COLLECTIVE: the BFS
@@ -267,11 +273,13 @@ extern "C" cugraph_error_code_t cugraph_extract_paths(const cugraph_resource_han
       // each rank then walks its own destinations locally -- any destination, whoever owns it.  The matrix is as wide on every rank
       // (the longest path over all ranks' destinations), as the reference's host_scalar_allreduce makes it.
       mg_graph_t& mg    = *g.mg;
-      int64_t const n   = (int64_t)pr->vertex_ids->size;
-      bool const bad_in = pr->predecessors == nullptr || (int64_t)pr->predecessors->size != n || (int64_t)pr->distances->size != n;
       HIP_TRY(hipSetDevice(h.device));
       vertex_column_in c_mdv;
-      dv = c_mdv.get(h, g, dv, "destinations");
+      // rank-local argument checks: every rank fails or none does (round 6; a rank that threw alone left its peers in mg_gather_paths until the
+      // communicator's timeout)
+      mg_agree(g, [&] { local_checks(); dv = c_mdv.get(h, g, dv, "destinations"); }, "cugraph_extract_paths");
+      int64_t const n   = (int64_t)pr->vertex_ids->size;
+      bool const bad_in = pr->predecessors == nullptr || (int64_t)pr->predecessors->size != n || (int64_t)pr->distances->size != n;
       int64_t const nd = (int64_t)dv->size, n1 = std::max<int64_t>(n, 1);
       dvec<int32_t> vert((size_t)n1), pred((size_t)n1), dist32((size_t)n1), scal(2);
       if (!bad_in && n > 0) {

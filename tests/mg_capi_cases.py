@@ -140,7 +140,11 @@ def run(what, cg, h, comm, rank, size, outdir, args):
                            ("epsilon", lambda: cg.pagerank(h, g, None, None, None, None, 0.85, -1.0 if rank == size - 1 else 0.0, 3, False, fail_on_nonconvergence=False)),
                            ("iterations", lambda: cg.pagerank(h, g, None, None, None, None, 0.85, 0.0, 3 + (rank == 0), False, fail_on_nonconvergence=False)),
                            ("source", lambda: cg.sssp(h, g, xid(int(s[0]) if rank == 0 else int(d[0])), 3.0e38, False, False)),
-                           ("depth", lambda: cg.bfs(h, g, X(np.array([int(s[0])], np.int32) if rank == 0 else np.zeros(0, np.int32)), False, 2 + rank, False, False))):
+                           ("depth", lambda: cg.bfs(h, g, X(np.array([int(s[0])], np.int32) if rank == 0 else np.zeros(0, np.int32)), False, 2 + rank, False, False)),
+                           # a vertex column of the wrong id type on ONE rank (the degree calls and extract_paths are collective on a multi-GPU graph too)
+                           ("degrees", lambda: cg.out_degrees(h, g, T(np.zeros(1, np.int32 if WIDE else np.int64)) if rank == 0 else X(verts[:1]))),
+                           ("paths", lambda: cg.bfs_extract_paths(h, g, X(np.array([int(s[0])], np.int32) if rank == 0 else np.zeros(0, np.int32)),
+                                                                  T(np.zeros(1, np.int32 if WIDE else np.int64)) if rank == size - 1 else X(verts[:1])))):
             try:
                 call()
                 msgs[name] = "accepted"

@@ -206,6 +206,8 @@ def test_mg_capi_bad_argument_on_one_rank_fails_everywhere(tmp_path, world):
         assert all(m != "accepted" for m in r["messages"].values()), r["messages"]
         assert "alpha" in r["messages"]["alpha"] or "rejected its arguments" in r["messages"]["alpha"]
         assert "different scalar arguments" in r["messages"]["iterations"] and "different scalar arguments" in r["messages"]["source"]
+        for name in ("degrees", "paths"):  # (a wrongly typed vertex column on one rank)
+            assert "must match" in r["messages"][name] or "rejected its arguments" in r["messages"][name], r["messages"]
     assert sum(r["rows_after"] for r in res) == 1 << 10
 
 
