@@ -1137,6 +1137,9 @@ __device__ __forceinline__ WT p1_compute(p1_args<WT> const& a, WT const* xs, WT*
   return s;
 }
 
+#ifndef P1_ISSUE_PRIO
+#define P1_ISSUE_PRIO 2  // wavefront priority of phase 1's issue part (k_tiled_phase1: body)
+#endif
 struct p1_iter {  // position in this workgroup's item sequence (all fields wave-uniform); item < 0: exhausted
   int item, end, pos, tile;
 };
@@ -1246,6 +1249,12 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
     vm_wait0();
   }
   auto body = [&](p1_regs& cur, p1_runs& qc, p1_regs& nxt, p1_runs& qn) {
+    // The issue part of an iteration -- stores of item i, slot deltas of item i + 1, edge data of item i + 2: ~30 memory instructions -- runs at raised
+    // wavefront priority: the SIMD's other three wavefronts are mostly inside a compute (VALU 60 % / LDS 40 % busy), and at equal priority the issuing
+    // wavefront's requests leave interleaved with their arithmetic, i.e. late.  Fresh processes of the driver's line, alternating, 2 x 8 pairs: 1.341 ->
+    // 1.318-1.323 ms at RMAT-26, phase 1 0.934 -> 0.913 (profiles/r6an_ab_fresh.txt, r6ao_ab_fresh.txt; levels 1 / 2 / 3 alike; the same around phase 2's
+    // loads: no effect).  Same instructions, same arithmetic: bit-identical results.
+    __builtin_amdgcn_s_setprio(P1_ISSUE_PRIO);
     bool const have_next = Jt.item >= 0;
     if (have_next) p1_counts(lane, nxt, qn);
     if (busy) {
@@ -1264,6 +1273,7 @@ __global__ void __launch_bounds__(TP_BLOCK, 4) k_tiled_phase1(p1_args<WT> a)
     I  = Jt;
     Jt = K;
     busy = false;
+    __builtin_amdgcn_s_setprio(0);
     if (I.item >= 0) {
       if (I.pos != old_pos) {  // next item belongs to another chunk: all wavefronts are done with the tile
         __syncthreads();
