@@ -25,6 +25,7 @@ python "$R/tools/rocpd_summary.py" "$O/prof_$TAG/trav" > "$O/${TAG}_traversal_s2
 python "$R/tools/rocpd_summary.py" "$O/prof_$TAG/louv" > "$O/${TAG}_louvain_s22_rocprofv3_summary.txt" 2>&1
 find "$O/prof_$TAG" -name "*.db" -delete
 head -8 "$O/${TAG}_s26_rocprofv3_summary.txt" | cut -c1-150 )
+TAG=$TAG bash tools/gpu_prof_tuned.sh  # the driver's own line (tuned plan) under rocprofv3: the trace's last 20 launches per kernel = the timed region
 timeout 600 python bench_traversal.py --scale 24 --weights int --out "$O/${TAG}_traversal_s24_int.json" > /dev/null 2>&1
 timeout 600 python bench_traversal.py --scale 24 --weights unit --out "$O/${TAG}_traversal_s24_unit.json" > /dev/null 2>&1
 CUGRAPH_AMD_SSSP_FILTER=0 timeout 600 python bench_traversal.py --scale 24 --weights int --roots 16 --no-cpu-baseline --out "$O/${TAG}_traversal_s24_int_nofilter.json" > /dev/null 2>&1

@@ -46,6 +46,31 @@ def summarize(db):
         print("counters_collection:", e)
 
 
+def last_dispatches(db, n, regex):
+    """stats of the LAST n dispatches of every kernel matching `regex` (by start time): with `bench.py --no-phase-pass` these are the launches of the timed
+    region -- a tuned plan's earlier launches ran on the placements its tuning tried and discarded"""
+    import re
+
+    c = sqlite3.connect(db)
+    cur = c.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    order = next((x for x in ("start", "start_time", "begin", "id") if x in cols), None)
+    if order is None:
+        print("last dispatches: no start column in", cols)
+        return
+    names = [r[0] for r in cur.execute("select distinct name from kernels")]
+    print(f"# last {n} dispatches per kernel matching /{regex}/ (ordered by {order})")
+    tot = 0.0
+    for name in names:
+        if not re.search(regex, name):
+            continue
+        d = [r[0] for r in cur.execute(f"select duration from kernels where name = ? order by {order} desc limit ?", (name, n))]
+        if d:
+            tot += sum(d) / len(d)
+            print(f"{name[:70]:<70} {len(d):>6} {sum(d)/1e6:>10.3f} {sum(d)/len(d)/1e3:>10.2f} {min(d)/1e3:>10.2f} {max(d)/1e3:>10.2f}")
+    print(f"# sum of the averages: {tot / 1e3:.2f} us")
+
+
 def per_dispatch(db, regex):
     """one line per dispatch of the kernels matching `regex`: duration (when the kernels view has it) and every counter"""
     import re
@@ -181,6 +206,11 @@ if __name__ == "__main__":
                 except Exception as e:
                     print("segments:", d, e)
         sys.exit(0)
+    last = None
+    if "--last" in sys.argv:  # --last N REGEX: after the summary, the last N dispatches of the matching kernels
+        i = sys.argv.index("--last")
+        last = (int(sys.argv[i + 1]), sys.argv[i + 2])
+        del sys.argv[i:i + 3]
     if "--per-dispatch" in sys.argv:
         i = sys.argv.index("--per-dispatch")
         rx = sys.argv[i + 1]
@@ -197,3 +227,8 @@ if __name__ == "__main__":
         dbs = [a] if a.endswith(".db") else sorted(glob.glob(os.path.join(a, "**", "*.db"), recursive=True))
         for d in dbs:
             summarize(d)
+            if last:
+                try:
+                    last_dispatches(d, last[0], last[1])
+                except Exception as e:
+                    print("last:", d, e)
