@@ -566,6 +566,7 @@ struct lv_big_args {
   uint32_t* overflow;
   unsigned long long* ifix;  // += the rows' weight into their own clusters (by a row's first item)
   uint32_t max_used;  // slots an item may occupy (an eighth stays free: probes stay short)
+  uint32_t* cursor;   // next item (zero on entry): items are drawn dynamically, the longest rows' items first (k_lv_big_items is launched longest rows first)
 };
 __device__ __forceinline__ uint32_t lvb_range(uint32_t cl, uint32_t R) { return (uint32_t)(((unsigned long long)(cl * 0x85EBCA6Bu + 0x27D4EB2Fu) * R) >> 32); }
 __global__ void __launch_bounds__(LVB_THREADS) k_lv_hash_big(lv_big_args A)
@@ -575,10 +576,16 @@ __global__ void __launch_bounds__(LVB_THREADS) k_lv_hash_big(lv_big_args A)
   uint32_t* const s_key           = reinterpret_cast<uint32_t*>(s_sum + LVB_SLOTS);  // [LVB_SLOTS]
   __shared__ unsigned long long s_self, s_red_bits[LVB_THREADS / 64];
   __shared__ int32_t s_red_c[LVB_THREADS / 64];
-  __shared__ uint32_t s_used, s_full;
+  __shared__ uint32_t s_used, s_full, s_it;
   int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto slot_of = [](uint32_t cl) { return ((cl * 0x9E3779B1u) ^ (cl >> 15)) & (uint32_t)(LVB_SLOTS - 1); };
-  for (int it = blockIdx.x; it < A.n_items; it += gridDim.x) {
+  // An item of a row of 855 K edges scans 280 times what an item of a row of 8 K edges scans (RMAT-26): items are drawn from a queue, longest rows first,
+  // instead of being dealt out by index (round 6)
+  for (;;) {
+    if (tid == 0) s_it = atomicAdd(A.cursor, 1u);
+    __syncthreads();
+    int const it = (int)s_it;
+    if (it >= A.n_items) break;  // (uniform)
     int4 const item = A.items[it];
     int32_t const v = item.x;
     uint32_t const r = (uint32_t)item.y, R = (uint32_t)item.z;
@@ -676,12 +683,12 @@ __global__ void k_lv_big_ties(lv_big_args A)
     if (bits && bits == A.best_bits[v]) atomicMin(&A.best_c[v], A.item_c[i]);
   }
 }
-__global__ void k_lv_big_items(uint32_t const* off, uint32_t const* pos, int64_t nv, int longer_than, int4* items, uint32_t* count)
+__global__ void k_lv_big_items(uint32_t const* off, uint32_t const* pos, int64_t nv, int longer_than, int up_to, int4* items, uint32_t* count)
 {
   LV_LOOP(v, nv)
   {
     int32_t const d = (int32_t)(off[v + 1] - off[v]);
-    if (d > longer_than) {
+    if (d > longer_than && d <= up_to) {
       int32_t const R   = (d + LVB_SHARE - 1) / LVB_SHARE;
       uint32_t const at = atomicAdd(count, (uint32_t)R);
       for (int32_t r = 0; r < R; ++r) items[at + r] = make_int4((int32_t)v, r, R, (int32_t)pos[off[v]]);
@@ -1202,7 +1209,7 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   // rows of more than LVM_MAX edges: LDS tables too, several work items per row (k_lv_hash_big); CUGRAPH_AMD_LOUVAIN_BIG=0: sorted path
   bool const use_big = use_mid && !(getenv("CUGRAPH_AMD_LOUVAIN_BIG") && atoi(getenv("CUGRAPH_AMD_LOUVAIN_BIG")) == 0);
   dvec<int32_t> mid_rows[2];
-  dvec<uint32_t> mid_count(3);
+  dvec<uint32_t> mid_count(3), big_cursor(1);
   uint32_t n_mid[3] = {0, 0, 0};  // [2] = work items of the big rows
   dvec<int4> big_items;
   dvec<unsigned long long> big_bits, big_ewf, big_rowsub;
@@ -1232,7 +1239,11 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
       hipLaunchKernelGGL(k_lv_mid_rows, g_v, kBlock, 0, h.stream, (uint32_t const*)L.off.data(), nv, LVM_MAX / 2, LVM_MAX, mid_rows[1].data(), mid_count.data() + 1);
       if (use_big) {
         big_items.resize_discard((size_t)(ne / LVB_SHARE + ne / LVM_MAX + 2));  // sum over the big rows of ceil(degree / LVB_SHARE)
-        hipLaunchKernelGGL(k_lv_big_items, g_v, kBlock, 0, h.stream, (uint32_t const*)L.off.data(), (uint32_t const*)pos.data(), nv, LVM_MAX, big_items.data(),
+        // the items of the longest rows first (two classes; inside a class in whatever order the atomics land): k_lv_hash_big draws them in this order
+        constexpr int kLongRow = 16 * LVB_SHARE;
+        hipLaunchKernelGGL(k_lv_big_items, g_v, kBlock, 0, h.stream, (uint32_t const*)L.off.data(), (uint32_t const*)pos.data(), nv, kLongRow, INT32_MAX, big_items.data(),
+                           mid_count.data() + 2);
+        hipLaunchKernelGGL(k_lv_big_items, g_v, kBlock, 0, h.stream, (uint32_t const*)L.off.data(), (uint32_t const*)pos.data(), nv, LVM_MAX, kLongRow, big_items.data(),
                            mid_count.data() + 2);
       }
       h.read_back(n_mid, mid_count.data(), 3);
@@ -1357,7 +1368,8 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
       }
       if (big_hash) {
         lv_big_args BA{big_items.data(), (int32_t)n_mid[2], big_ecl.data(), big_ewf.data(), big_rowsub.data(), L.off.data(), c.data(), k.data(), a.data(), m, resolution,
-                       scale, 1.0 / scale, vfix.data() + 2 * nv, best_c.data(), big_bits.data(), big_c.data(), count + 2, ifix, big_max_used};
+                       scale, 1.0 / scale, vfix.data() + 2 * nv, best_c.data(), big_bits.data(), big_c.data(), count + 2, ifix, big_max_used, big_cursor.data()};
+        HIP_TRY(hipMemsetAsync(big_cursor.data(), 0, sizeof(uint32_t), h.stream));
         hipLaunchKernelGGL(k_lv_big_gather, g_s, kBlock, 0, h.stream, s_dst, (int32_t const*)c.data(), n_sorted, big_ecl.data());
         hipLaunchKernelGGL(k_lv_hash_big, (int)std::min<uint32_t>(n_mid[2], (uint32_t)h.num_cus * 8), LVB_THREADS, LVB_SLOTS * 12, h.stream, BA);
         hipLaunchKernelGGL(k_lv_big_ties, grid_for((int64_t)n_mid[2], kBlock, 1024), kBlock, 0, h.stream, BA);
