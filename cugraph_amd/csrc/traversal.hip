@@ -1243,10 +1243,13 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
     g.weight_sum_valid = true;
   }
   double const wsum_h = g.weight_sum;
-  // delta = 32 * average weight / average degree (sssp_impl.cuh:233-247)
+  // The reference's bucket width is 32 * average weight / average degree (sssp_impl.cuh:233-247); the width decides the schedule, never the result
+  // (distances and canonical parents are unique).  Here it is FOUR times that: with the streamed wide rounds and the distance filter the cost of a
+  // traversal's tail is its number of rounds (19 -> 14 at RMAT-24, relaxations per edge unchanged at 1.47), not the re-relaxations a wider window
+  // allows -- 8.6 -> 8.1-8.2 ms over 32 roots for x 4 ... x 64, 10.0 ms at x 1024, 10.3 ... 27.5 ms for x 1/4 ... x 1/32 (profiles/r6av, r6aw)
   double avg_w   = g.ne > 0 ? wsum_h / (double)g.ne : 1.0;
   double avg_deg = nv > 0 ? (double)g.ne / (double)nv : 1.0;
-  double delta   = avg_w * 32.0 / std::max(avg_deg, 1.0);
+  double delta   = 4.0 * avg_w * 32.0 / std::max(avg_deg, 1.0);
   if (char const* e = getenv("CUGRAPH_AMD_SSSP_DELTA_SCALE")) delta *= atof(e);  // tuning knob (bucket width multiplier)
   if (!(delta > 0.0) || !std::isfinite(delta)) delta = 1.0;
   // Schedules that were built, tested bit for bit against Dijkstra and measured SLOWER than this one over rounds 2-5 are gone from the source
