@@ -738,13 +738,15 @@ __device__ __forceinline__ int sf_band(typename dist_bits<WT>::type const* dist,
 }
 template <typename WT, bool PK>
 __global__ void __launch_bounds__(256) k_sssp_filter_hist(int32_t const* front, int64_t n, typename dist_bits<WT>::type const* dist, int32_t const* out_offsets, WT lower,
-                                                          WT inv_band, unsigned long long* hist /* [SF_BANDS + 1] */, unsigned long long plus)
-{  // front == nullptr: all vertices 0 .. n - 1
+                                                          WT inv_band, unsigned long long* hist /* [SF_BANDS + 1] */, unsigned long long plus, int sample)
+{  // front == nullptr: all vertices 0 .. n - 1.  sample = S: every S-th block of 256 consecutive entries only -- the histograms steer a heuristic (the
+   // threshold of an exact filter), a 1 / S sample of a million entries has the same shape, and the two passes were 160 us of every filtered round
   __shared__ unsigned long long h[SF_BANDS + 1];
   for (int i = threadIdx.x; i <= SF_BANDS; i += blockDim.x) h[i] = 0ull;
   __syncthreads();
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t blk = blockIdx.x; blk * sample * 256 < n; blk += gridDim.x) {
+    int64_t const i = blk * sample * 256 + threadIdx.x;
+    if (i >= n) continue;
     int32_t const v = front ? front[i] : (int32_t)i;
     int const b     = sf_band<WT, PK>(dist, v, lower, inv_band);
     if (b < SF_BANDS) atomicAdd(&h[b], plus + (unsigned long long)(eoff(out_offsets, v + 1) - eoff(out_offsets, v)));
@@ -757,31 +759,38 @@ template <typename WT>
 __global__ void __launch_bounds__(SF_BANDS) k_sssp_filter_pick(unsigned long long* hist_front, unsigned long long* hist_all, WT lower, WT band, WT avg_w, int uniform_weights,
                                                                WT* t_out)
 {
-  __shared__ double hf[SF_BANDS], ha[SF_BANDS], score[SF_BANDS];
+  // (round 6, last session: single precision, one reciprocal, a tree for the maximum -- 39 -> a few us per filtered round; the choice steers a heuristic)
+  __shared__ float hf[SF_BANDS], ha[SF_BANDS], score[SF_BANDS];
+  __shared__ int arg[SF_BANDS];
   int const b = threadIdx.x;
-  hf[b] = (double)hist_front[b]; ha[b] = (double)hist_all[b];
+  hf[b] = (float)hist_front[b]; ha[b] = (float)hist_all[b];
   hist_front[b] = 0ull; hist_all[b] = 0ull;  // ready for the next round
   __syncthreads();
   // threshold T = lower + b * band: destinations below it = bands [0, b); a frontier vertex of band c relaxes with nd = (lower + (c + 0.5) band) + w
-  double below = 0.0;
+  float below = 0.0f;
   for (int c = 0; c < b; ++c) below += ha[c];
-  double above = 0.0;
+  float above = 0.0f;
+  float const inv2w = 1.0f / (2.0f * (float)avg_w);
   for (int c = 0; c < SF_BANDS; ++c) {
-    double const need = ((double)b - ((double)c + 0.5)) * (double)band;  // nd >= T  <=>  w >= need
-    double pw;
-    if (need <= 0.0) pw = 1.0;
-    else if (uniform_weights) pw = (double)avg_w >= need ? 1.0 : 0.0;
-    else pw = fmax(0.0, 1.0 - need / (2.0 * (double)avg_w));
+    float const need = ((float)b - ((float)c + 0.5f)) * (float)band;  // nd >= T  <=>  w >= need
+    float pw;
+    if (need <= 0.0f) pw = 1.0f;
+    else if (uniform_weights) pw = (float)avg_w >= need ? 1.0f : 0.0f;
+    else pw = fmaxf(0.0f, 1.0f - need * inv2w);
     above += hf[c] * pw;
   }
   score[b] = below * above;
+  arg[b]   = b;
   __syncthreads();
-  if (b == 0) {
-    int best = 0;
-    for (int c = 1; c < SF_BANDS; ++c)
-      if (score[c] > score[best]) best = c;
-    *t_out = lower + (WT)best * band;  // (best == 0: T = lower, nothing is below it: the filter passes everything)
+  for (int o = SF_BANDS / 2; o > 0; o >>= 1) {  // maximum, the smallest band among equals (as the sequential scan chose)
+    if (b < o) {
+      float const s1 = score[b + o];
+      int const a1   = arg[b + o];
+      if (s1 > score[b] || (s1 == score[b] && a1 < arg[b])) { score[b] = s1; arg[b] = a1; }
+    }
+    __syncthreads();
   }
+  if (b == 0) *t_out = lower + (WT)arg[0] * band;  // (band 0: T = lower, nothing is below it: the filter passes everything)
 }
 template <typename WT, bool PK>
 __global__ void __launch_bounds__(256) k_sssp_filter_bits(typename dist_bits<WT>::type const* dist, int64_t nv, WT const* t, uint32_t* bits)
@@ -1306,6 +1315,10 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
   bool const filter_force = env_flt && std::string(env_flt) == "force";  // every round, whatever its size (the parity test)
   bool const filter_on = filter_force || (!(env_flt && std::string(env_flt) == "0") && nv >= 4096);
   uint64_t const filter_min_edges = filter_force ? 0 : std::max<uint64_t>((uint64_t)g.ne / 32, (uint64_t)1 << 20);
+  // the filter's histograms are built from every 32nd block of 256 entries (k_sssp_filter_hist): RMAT-24, 32 roots: 8.09 ms with every entry, 7.53 with every 8th block,
+  // 7.41 with every 32nd (profiles/r6bb_sssp_filter_sample.txt); CUGRAPH_AMD_SSSP_FILTER_SAMPLE=1: every entry
+  int sf_sample = 32;
+  if (char const* e = getenv("CUGRAPH_AMD_SSSP_FILTER_SAMPLE")) sf_sample = std::max(1, atoi(e));
   char const* env_sw = getenv("CUGRAPH_AMD_SSSP_SWEEP");  // share of the graph's edges a frontier must hold for a streamed round (0: never)
   double const sweep_frac = env_sw ? atof(env_sw) : 0.25;
   bool const sweep_on = sweep_frac > 0.0 && g.ne > 0;
@@ -1348,9 +1361,11 @@ paths_result_t* run_sssp(handle_t& h, graph_t& g, size_t source_ext, double cuto
       WT const band = (WT)(delta / SF_BANDS), inv = (WT)(SF_BANDS / delta);
       with_words([&](auto pkc) {
         constexpr bool PKC = decltype(pkc)::value;
-        hipLaunchKernelGGL((k_sssp_filter_hist<WT, PKC>), grid_for(n_front, 256, 1024), 256, 0, h.stream, front, n_front, dist_words, row_beg, lo, inv, fhist.data(), 0ull);
-        hipLaunchKernelGGL((k_sssp_filter_hist<WT, PKC>), grid_for(nv, 256, 2048), 256, 0, h.stream, (int32_t const*)nullptr, nv, dist_words, row_beg, lo, inv,
-                           fhist.data() + (SF_BANDS + 1), 1ull);
+        // (at least 2^16 samples: a 1 / 32 sample from 2 M entries on)
+        int const s_f = (int)std::clamp<int64_t>(n_front >> 16, 1, sf_sample), s_v = (int)std::clamp<int64_t>(nv >> 16, 1, sf_sample);
+        hipLaunchKernelGGL((k_sssp_filter_hist<WT, PKC>), grid_for(n_front / s_f + 1, 256, 1024), 256, 0, h.stream, front, n_front, dist_words, row_beg, lo, inv, fhist.data(), 0ull, s_f);
+        hipLaunchKernelGGL((k_sssp_filter_hist<WT, PKC>), grid_for(nv / s_v + 1, 256, 2048), 256, 0, h.stream, (int32_t const*)nullptr, nv, dist_words, row_beg, lo, inv,
+                           fhist.data() + (SF_BANDS + 1), 1ull, s_v);
         hipLaunchKernelGGL(k_sssp_filter_pick<WT>, 1, SF_BANDS, 0, h.stream, fhist.data(), fhist.data() + (SF_BANDS + 1), lo, band, (WT)avg_w, g.weights_uniform ? 1 : 0, ft.data());
         hipLaunchKernelGGL((k_sssp_filter_bits<WT, PKC>), grid_for(nv, 256, 2048), 256, 0, h.stream, dist_words, nv, (WT const*)ft.data(), fbits.data());
       });
