@@ -502,8 +502,13 @@ __global__ void __launch_bounds__(TV_BLOCK) k_sssp_expand2(int32_t const* q, int
   int64_t const gwave  = (int64_t)blockIdx.x * TV_WAVES + wave;
   int64_t const nwaves = (int64_t)gridDim.x * TV_WAVES;
   unsigned long long inspected = 0;
-  for (int64_t base = gwave * 64; base < n; base += nwaves * 64) {
-    int64_t const i = base + lane;
+  // A wavefront's 64 frontier entries are taken with a STRIDE (the queue seen as 64 rows of `stride` entries, wavefront j takes column j), not as 64
+  // consecutive ones: the hub round's frontier is sorted by distance, i.e. by degree on a power-law graph, and consecutive entries put 64 rows of thousands
+  // of edges into the first wavefronts and 64 rows of twenty into the last (a wavefront walks its rows of >= 64 edges one at a time); lane order is still
+  // the sorted order inside a wavefront.  (round 6, last session: the hub round of an RMAT-24 traversal 0.9 ms for 7 M edges before)
+  int64_t const stride = (n + 63) / 64;
+  for (int64_t col = gwave; col < stride; col += nwaves) {
+    int64_t const i = (int64_t)lane * stride + col;
     int32_t u = -1, deg = 0;
     eoff_t beg = 0;
     bits_t du  = 0;
