@@ -567,8 +567,12 @@ struct lv_big_args {
   unsigned long long* ifix;  // += the rows' weight into their own clusters (by a row's first item)
   uint32_t max_used;  // slots an item may occupy (an eighth stays free: probes stay short)
   uint32_t* cursor;   // next item (zero on entry): items are drawn dynamically, the longest rows' items first (k_lv_big_items is launched longest rows first)
+  // this sweep's partition of every big row by item (k_lv_big_partition): item i owns entries [seg[i].x, seg[i].x + seg[i].y) of (pcl, pwf)
+  uint2 const* seg; uint32_t const* pcl; unsigned long long const* pwf;
+  unsigned long long const* rowself;  // [nv] weight of a big row into its own cluster (this sweep)
 };
 __device__ __forceinline__ uint32_t lvb_range(uint32_t cl, uint32_t R) { return (uint32_t)(((unsigned long long)(cl * 0x85EBCA6Bu + 0x27D4EB2Fu) * R) >> 32); }
+template <bool PART>  // PART: the items read their own pairs from this sweep's partition (k_lv_big_partition); otherwise every item scans its whole row
 __global__ void __launch_bounds__(LVB_THREADS) k_lv_hash_big(lv_big_args A)
 {
   extern __shared__ unsigned long long lvm_smem[];
@@ -589,31 +593,38 @@ __global__ void __launch_bounds__(LVB_THREADS) k_lv_hash_big(lv_big_args A)
     int4 const item = A.items[it];
     int32_t const v = item.x;
     uint32_t const r = (uint32_t)item.y, R = (uint32_t)item.z;
-    int32_t const d = (int32_t)(A.off[v + 1] - A.off[v]);
     for (int i = tid; i < LVB_SLOTS; i += LVB_THREADS) { s_key[i] = 0xFFFFFFFFu; s_sum[i] = 0; }
     if (tid == 0) { s_self = 0; s_used = 0; s_full = 0; }
     __syncthreads();
     int32_t const cv = A.c[v];
+    // PART: k_lv_big_partition has grouped this sweep's (cluster, weight) pairs of every big row by item, and the item reads its own pairs only
+    // (round 6, last session).  Otherwise every item scans the WHOLE row and keeps its range -- d R pairs read per row: 2.3 x the big rows' edges at RMAT-22,
+    // where that is cheaper than partitioning them (0.0636 against 0.0668 s), 11 x at RMAT-26, where it is not (1.40 against 1.30 s); run_level decides by that factor
+    constexpr bool part = PART;
+    uint2 const sg  = part ? A.seg[it] : make_uint2((uint32_t)item.w, A.off[v + 1] - A.off[v]);
+    int const d_it  = (int)sg.y;
+    uint32_t const* const ecl           = (part ? A.pcl : A.ecl) + sg.x;
+    unsigned long long const* const ewf = (part ? A.pwf : A.ewf) + sg.x;
     unsigned long long self = 0;
-    uint32_t const* const ecl           = A.ecl + (uint32_t)item.w;
-    unsigned long long const* const ewf = A.ewf + (uint32_t)item.w;
     constexpr int LVB_UNROLL = 4;  // (round 6: four (cluster, weight) pairs per thread in flight; the loop used to wait for each pair)
-    for (int i0 = tid; i0 < d; i0 += LVB_THREADS * LVB_UNROLL) {
+    for (int i0 = tid; i0 < d_it; i0 += LVB_THREADS * LVB_UNROLL) {
       uint32_t cls[LVB_UNROLL];
       unsigned long long wfs[LVB_UNROLL];
 #pragma unroll
       for (int j = 0; j < LVB_UNROLL; ++j) {
         int const i = i0 + j * LVB_THREADS;
         cls[j] = 0; wfs[j] = 0;
-        if (i < d) { cls[j] = ecl[i]; wfs[j] = ewf[i]; }
+        if (i < d_it) { cls[j] = ecl[i]; wfs[j] = ewf[i]; }
       }
 #pragma unroll
       for (int j = 0; j < LVB_UNROLL; ++j) {
-        if (i0 + j * LVB_THREADS >= d) continue;
+        if (i0 + j * LVB_THREADS >= d_it) continue;
         uint32_t const cl           = cls[j];
         unsigned long long const wf = wfs[j];
-        if ((int32_t)cl == cv) self += wf;
-        if (lvb_range(cl, R) != r) continue;
+        if constexpr (!part) {
+          if ((int32_t)cl == cv) self += wf;
+          if (lvb_range(cl, R) != r) continue;
+        }
         uint32_t slot = slot_of(cl);
         bool placed   = false;
         for (int probes = 0; probes < LVB_SLOTS; ++probes) {
@@ -627,14 +638,14 @@ __global__ void __launch_bounds__(LVB_THREADS) k_lv_hash_big(lv_big_args A)
         else s_full = 1;
       }
     }
-    if (self) atomicAdd(&s_self, self);
+    if (!part && self) atomicAdd(&s_self, self);
     __syncthreads();
     if (s_full) {  // (uniform: read after the barrier)
       if (tid == 0) { atomicOr(A.overflow, 1u); A.item_bits[it] = 0; A.item_c[it] = 0x7f7f7f7f; }
       __syncthreads();
       continue;
     }
-    unsigned long long const subf = A.rowsub[v], selff = s_self;
+    unsigned long long const subf = A.rowsub[v], selff = part ? A.rowself[v] : s_self;
     if (r == 0 && tid == 0 && selff) atomicAdd(A.ifix, selff);
     double const sub_d = (double)(long long)subf * A.inv_scale, old_sum = (double)(long long)(selff - subf) * A.inv_scale;
     double const a_old = A.a[cv], kk = A.k[v];
@@ -683,7 +694,11 @@ __global__ void k_lv_big_ties(lv_big_args A)
     if (bits && bits == A.best_bits[v]) atomicMin(&A.best_c[v], A.item_c[i]);
   }
 }
-__global__ void k_lv_big_items(uint32_t const* off, uint32_t const* pos, int64_t nv, int longer_than, int up_to, int4* items, uint32_t* count)
+constexpr int LVP_THREADS = 1024, LVP_MAX_R = 8192;  // k_lv_big_partition: one workgroup per big row, a counter per item of the row in LDS
+// count[0] += items, count[1] |= "a row needs more than LVP_MAX_R items" (rows of more than 25 M edges: no partition), count[2] += rows, *rescan += d R (the pairs the
+// items of the row read when each of them scans the whole row);
+// rows[k] = (row, its first item, R, position of its first edge in the big rows' edge list)
+__global__ void k_lv_big_items(uint32_t const* off, uint32_t const* pos, int64_t nv, int longer_than, int up_to, int4* items, uint32_t* count, int4* rows, unsigned long long* rescan)
 {
   LV_LOOP(v, nv)
   {
@@ -691,8 +706,97 @@ __global__ void k_lv_big_items(uint32_t const* off, uint32_t const* pos, int64_t
     if (d > longer_than && d <= up_to) {
       int32_t const R   = (d + LVB_SHARE - 1) / LVB_SHARE;
       uint32_t const at = atomicAdd(count, (uint32_t)R);
-      for (int32_t r = 0; r < R; ++r) items[at + r] = make_int4((int32_t)v, r, R, (int32_t)pos[off[v]]);
+      int32_t const b0  = (int32_t)pos[off[v]];
+      if (R > LVP_MAX_R) atomicOr(count + 1, 1u);
+      atomicAdd(rescan, (unsigned long long)d * (unsigned long long)R);
+      rows[atomicAdd(count + 2, 1u)] = make_int4((int32_t)v, (int32_t)at, R, b0);
+      for (int32_t r = 0; r < R; ++r) items[at + r] = make_int4((int32_t)v, r, R, b0);
     }
+  }
+}
+// Once per sweep, one workgroup per big row (rows drawn from a queue, longest first): the row's (cluster of destination, weight) pairs grouped by the item whose
+// range the cluster falls into -- a counting sort in LDS: count per item, scan, scatter -- so that k_lv_hash_big's items read their own pairs only; the row's
+// weight into its own cluster on the way (every item needs it for the gains).  The order inside an item's segment is whatever the atomics give: the sums are
+// integers and the choice among equal gains goes by cluster id, so the result does not depend on it.
+__global__ void __launch_bounds__(LVP_THREADS) k_lv_big_partition(int4 const* rows, int n_rows, uint32_t const* off, uint32_t const* ecl, unsigned long long const* ewf, int32_t const* c,
+                                                                  uint32_t* pcl, unsigned long long* pwf, uint2* seg, unsigned long long* rowself, uint32_t* cursor)
+{
+  __shared__ uint32_t s_cnt[LVP_MAX_R];
+  __shared__ uint32_t s_wsum[LVP_THREADS / 64], s_row;
+  __shared__ unsigned long long s_self;
+  int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (;;) {
+    if (tid == 0) s_row = atomicAdd(cursor, 1u);
+    __syncthreads();
+    int const k = (int)s_row;
+    if (k >= n_rows) break;  // (uniform)
+    int4 const rw = rows[k];
+    int32_t const v = rw.x;
+    uint32_t const item0 = (uint32_t)rw.y, R = (uint32_t)rw.z, b0 = (uint32_t)rw.w;
+    uint32_t const d = off[v + 1] - off[v];
+    int32_t const cv = c[v];
+    for (uint32_t i = tid; i < R; i += LVP_THREADS) s_cnt[i] = 0;
+    if (tid == 0) s_self = 0;
+    __syncthreads();
+    unsigned long long self = 0;
+    constexpr int U = 8;  // loads in flight per thread: the longest rows (10^7 edges at the coarse levels of RMAT-26) are walked by ONE workgroup
+    for (uint32_t i0 = tid; i0 < d; i0 += LVP_THREADS * U) {
+      uint32_t cls[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) { uint32_t const i = i0 + (uint32_t)j * LVP_THREADS; cls[j] = i < d ? ecl[b0 + i] : 0xFFFFFFFFu; }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        uint32_t const i = i0 + (uint32_t)j * LVP_THREADS;
+        if (i < d) {
+          atomicAdd(&s_cnt[lvb_range(cls[j], R)], 1u);
+          if ((int32_t)cls[j] == cv) self += ewf[b0 + i];
+        }
+      }
+    }
+    for (int o = 32; o; o >>= 1) self += __shfl_xor(self, o);
+    if (lane == 0 && self) atomicAdd(&s_self, self);
+    __syncthreads();
+    // exclusive scan of the R counts: a thread takes a run of consecutive counters
+    uint32_t const per = (R + LVP_THREADS - 1) / LVP_THREADS, lo = (uint32_t)tid * per, hi = lo + per < R ? lo + per : R;
+    uint32_t sum = 0;
+    for (uint32_t j = lo; j < hi; ++j) sum += s_cnt[j];
+    uint32_t inc = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t const t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += s_wsum[w];
+    uint32_t run = before + inc - sum;
+    for (uint32_t j = lo; j < hi; ++j) {
+      uint32_t const n = s_cnt[j];
+      s_cnt[j]         = run;
+      seg[item0 + j]   = make_uint2(b0 + run, n);
+      run += n;
+    }
+    __syncthreads();
+    for (uint32_t i0 = tid; i0 < d; i0 += LVP_THREADS * U) {
+      uint32_t cls[U];
+      unsigned long long wfs[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        uint32_t const i = i0 + (uint32_t)j * LVP_THREADS;
+        cls[j] = 0; wfs[j] = 0;
+        if (i < d) { cls[j] = ecl[b0 + i]; wfs[j] = ewf[b0 + i]; }
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        if (i0 + (uint32_t)j * LVP_THREADS < d) {
+          uint32_t const at = b0 + atomicAdd(&s_cnt[lvb_range(cls[j], R)], 1u);
+          pcl[at] = cls[j];
+          pwf[at] = wfs[j];
+        }
+      }
+    }
+    if (tid == 0) rowself[v] = s_self;
+    __syncthreads();
   }
 }
 // once per level: fixed-point weights of the big rows' edges, self-loop weight per row
@@ -1209,9 +1313,14 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
   // rows of more than LVM_MAX edges: LDS tables too, several work items per row (k_lv_hash_big); CUGRAPH_AMD_LOUVAIN_BIG=0: sorted path
   bool const use_big = use_mid && !(getenv("CUGRAPH_AMD_LOUVAIN_BIG") && atoi(getenv("CUGRAPH_AMD_LOUVAIN_BIG")) == 0);
   dvec<int32_t> mid_rows[2];
-  dvec<uint32_t> mid_count(3), big_cursor(1);
-  uint32_t n_mid[3] = {0, 0, 0};  // [2] = work items of the big rows
-  dvec<int4> big_items;
+  dvec<uint32_t> mid_count(5), big_cursor(2);  // big_cursor: [0] k_lv_hash_big's items, [1] k_lv_big_partition's rows
+  uint32_t n_mid[5] = {0, 0, 0, 0, 0};  // [2] = work items of the big rows, [3] != 0: a row needs more items than k_lv_big_partition counts in LDS, [4] = big rows
+  dvec<int4> big_items, big_rows;
+  dvec<uint32_t> big_pcl;
+  dvec<unsigned long long> big_pwf, big_rowself;
+  dvec<uint2> big_seg;
+  dvec<unsigned long long> big_rescan(1);
+  unsigned long long big_rescan_h = 0;  // sum over the big rows of d R
   dvec<unsigned long long> big_bits, big_ewf, big_rowsub;
   dvec<uint32_t> big_ecl;
   dvec<int32_t> big_c;
@@ -1234,19 +1343,22 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     if (use_mid) {
       size_t const cap = (size_t)(ne / LVH_B + 2);  // rows of more than LVH_B edges
       mid_rows[0].resize_discard(cap); mid_rows[1].resize_discard(cap);
-      HIP_TRY(hipMemsetAsync(mid_count.data(), 0, 3 * sizeof(uint32_t), h.stream));
+      HIP_TRY(hipMemsetAsync(mid_count.data(), 0, 5 * sizeof(uint32_t), h.stream));
       hipLaunchKernelGGL(k_lv_mid_rows, g_v, kBlock, 0, h.stream, (uint32_t const*)L.off.data(), nv, LVH_B, LVM_MAX / 2, mid_rows[0].data(), mid_count.data());
       hipLaunchKernelGGL(k_lv_mid_rows, g_v, kBlock, 0, h.stream, (uint32_t const*)L.off.data(), nv, LVM_MAX / 2, LVM_MAX, mid_rows[1].data(), mid_count.data() + 1);
       if (use_big) {
         big_items.resize_discard((size_t)(ne / LVB_SHARE + ne / LVM_MAX + 2));  // sum over the big rows of ceil(degree / LVB_SHARE)
         // the items of the longest rows first (two classes; inside a class in whatever order the atomics land): k_lv_hash_big draws them in this order
         constexpr int kLongRow = 16 * LVB_SHARE;
+        big_rows.resize_discard((size_t)(ne / LVM_MAX + 2));
+        HIP_TRY(hipMemsetAsync(big_rescan.data(), 0, sizeof(unsigned long long), h.stream));
         hipLaunchKernelGGL(k_lv_big_items, g_v, kBlock, 0, h.stream, (uint32_t const*)L.off.data(), (uint32_t const*)pos.data(), nv, kLongRow, INT32_MAX, big_items.data(),
-                           mid_count.data() + 2);
+                           mid_count.data() + 2, big_rows.data(), big_rescan.data());
         hipLaunchKernelGGL(k_lv_big_items, g_v, kBlock, 0, h.stream, (uint32_t const*)L.off.data(), (uint32_t const*)pos.data(), nv, LVM_MAX, kLongRow, big_items.data(),
-                           mid_count.data() + 2);
+                           mid_count.data() + 2, big_rows.data(), big_rescan.data());
+        h.read_back(&big_rescan_h, (unsigned long long const*)big_rescan.data(), 1);
       }
-      h.read_back(n_mid, mid_count.data(), 3);
+      h.read_back(n_mid, mid_count.data(), 5);
       if (n_mid[2]) { big_bits.resize_discard(n_mid[2]); big_c.resize_discard(n_mid[2]); }
     }
     uint32_t nh = 0;
@@ -1277,6 +1389,18 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
     HIP_TRY(hipMemsetAsync(big_rowsub.data(), 0, (size_t)nv * sizeof(unsigned long long), h.stream));
     hipLaunchKernelGGL(k_lv_big_prep, grid_for(n_sorted, kBlock, 8192), kBlock, 0, h.stream, (int32_t const*)Lh.src.data(), (int32_t const*)Lh.dst.data(),
                        (double const*)Lh.w.data(), n_sorted, scale, big_ewf.data(), big_rowsub.data());
+  }
+  // the big rows' pairs are partitioned by item every sweep when the items would otherwise read them more than kPartitionFrom times over
+  // (CUGRAPH_AMD_LOUVAIN_PARTITION=0 / 1: never / whenever possible)
+  constexpr double kPartitionFrom = 8.0;  // (RMAT-22's third level, 6.5: 12.6 ms partitioned against 11.1; RMAT-26's levels, 9.2 ... 34: 1.40 -> 1.30 s for the call)
+  char const* env_part = getenv("CUGRAPH_AMD_LOUVAIN_PARTITION");
+  bool const big_part = big_hash && n_mid[3] == 0 && n_mid[4] > 0 &&
+                        (env_part ? atoi(env_part) != 0 : (double)big_rescan_h > kPartitionFrom * (double)std::max<int64_t>(n_sorted, 1));
+  if (getenv("CUGRAPH_AMD_LOUVAIN_TRACE") && big_hash)
+    fprintf(stderr, "[louvain]   big rows: %u rows, %u items, %lld edges, items would read them %.1f times over: %s\n", n_mid[4], n_mid[2], (long long)n_sorted,
+            (double)big_rescan_h / (double)std::max<int64_t>(n_sorted, 1), big_part ? "partitioned by item every sweep" : "every item scans its row");
+  if (big_part) {
+    big_pcl.resize_discard((size_t)n_sorted); big_pwf.resize_discard((size_t)n_sorted); big_seg.resize_discard((size_t)n_mid[2]); big_rowself.resize_discard((size_t)nv);
   }
   // CUGRAPH_AMD_LOUVAIN_BIG_SLOTS=n (tests): an item gives up after n distinct clusters -- exercises the fall-back to the sorted path
   uint32_t const big_max_used = getenv("CUGRAPH_AMD_LOUVAIN_BIG_SLOTS") ? (uint32_t)std::max(1, atoi(getenv("CUGRAPH_AMD_LOUVAIN_BIG_SLOTS"))) : (uint32_t)(LVB_SLOTS - LVB_SLOTS / 8);
@@ -1353,7 +1477,8 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
       static bool attr_done = false;
       if (!attr_done) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_lv_hash_rows<LVM_MAX * 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LVM_MAX * 2 * 12));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_lv_hash_big), hipFuncAttributeMaxDynamicSharedMemorySize, LVB_SLOTS * 12));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_lv_hash_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LVB_SLOTS * 12));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(k_lv_hash_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LVB_SLOTS * 12));
         attr_done = true;
       }
       lv_mid_args MA{nullptr, 0, L.dst.data(), L.off.data(), L.w.data(), c.data(), k.data(), a.data(), m, resolution, scale, 1.0 / scale,
@@ -1368,10 +1493,16 @@ double run_level(handle_t const& h, level_t const& L, double m, double threshold
       }
       if (big_hash) {
         lv_big_args BA{big_items.data(), (int32_t)n_mid[2], big_ecl.data(), big_ewf.data(), big_rowsub.data(), L.off.data(), c.data(), k.data(), a.data(), m, resolution,
-                       scale, 1.0 / scale, vfix.data() + 2 * nv, best_c.data(), big_bits.data(), big_c.data(), count + 2, ifix, big_max_used, big_cursor.data()};
-        HIP_TRY(hipMemsetAsync(big_cursor.data(), 0, sizeof(uint32_t), h.stream));
+                       scale, 1.0 / scale, vfix.data() + 2 * nv, best_c.data(), big_bits.data(), big_c.data(), count + 2, ifix, big_max_used, big_cursor.data(),
+                       big_part ? big_seg.data() : (uint2*)nullptr, big_pcl.data(), big_pwf.data(), big_rowself.data()};
+        HIP_TRY(hipMemsetAsync(big_cursor.data(), 0, 2 * sizeof(uint32_t), h.stream));
         hipLaunchKernelGGL(k_lv_big_gather, g_s, kBlock, 0, h.stream, s_dst, (int32_t const*)c.data(), n_sorted, big_ecl.data());
-        hipLaunchKernelGGL(k_lv_hash_big, (int)std::min<uint32_t>(n_mid[2], (uint32_t)h.num_cus * 8), LVB_THREADS, LVB_SLOTS * 12, h.stream, BA);
+        if (big_part)
+          hipLaunchKernelGGL(k_lv_big_partition, (int)std::min<uint32_t>(n_mid[4], (uint32_t)h.num_cus * 2), LVP_THREADS, 0, h.stream, (int4 const*)big_rows.data(), (int)n_mid[4],
+                           (uint32_t const*)L.off.data(), (uint32_t const*)big_ecl.data(), (unsigned long long const*)big_ewf.data(), (int32_t const*)c.data(), big_pcl.data(),
+                           big_pwf.data(), big_seg.data(), big_rowself.data(), big_cursor.data() + 1);
+        if (big_part) hipLaunchKernelGGL(k_lv_hash_big<true>, (int)std::min<uint32_t>(n_mid[2], (uint32_t)h.num_cus * 8), LVB_THREADS, LVB_SLOTS * 12, h.stream, BA);
+        else hipLaunchKernelGGL(k_lv_hash_big<false>, (int)std::min<uint32_t>(n_mid[2], (uint32_t)h.num_cus * 8), LVB_THREADS, LVB_SLOTS * 12, h.stream, BA);
         hipLaunchKernelGGL(k_lv_big_ties, grid_for((int64_t)n_mid[2], kBlock, 1024), kBlock, 0, h.stream, BA);
       }
     }

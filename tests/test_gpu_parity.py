@@ -1260,9 +1260,12 @@ def test_louvain_hash_path_equals_sorted_path(cg, handle, orc, monkeypatch, scal
     # tables too), mid rows back on the sorted path, big rows back on it, and big rows whose table "fills up" after 16 clusters (the fall-back
     # to the sorted path in the middle of a level)
     variants = {"1hash": {"HASH": "1", "HUB": "hash"}, "1sort": {"HASH": "1", "HUB": "sort", "MID": "0"}, "0sort": {"HASH": "0", "HUB": "sort"},
-                "default": {}, "mid0": {"MID": "0"}, "big0": {"BIG": "0"}, "overflow": {"BIG_SLOTS": "16"}}
+                "default": {}, "mid0": {"MID": "0"}, "big0": {"BIG": "0"}, "overflow": {"BIG_SLOTS": "16"},
+                # round 6: the big rows' pairs partitioned by work item every sweep (k_lv_big_partition; by default only where the items would re-read a row many
+                # times over: RMAT-26-sized hubs), forced on and forced off, and forced on together with a table that fills up
+                "partition": {"PARTITION": "1"}, "no_partition": {"PARTITION": "0"}, "partition_overflow": {"PARTITION": "1", "BIG_SLOTS": "16"}}
     for name, env in variants.items():
-        for k in ("HASH", "HUB", "MID", "BIG", "BIG_SLOTS"):
+        for k in ("HASH", "HUB", "MID", "BIG", "BIG_SLOTS", "PARTITION"):
             monkeypatch.delenv("CUGRAPH_AMD_LOUVAIN_" + k, raising=False)
         for k, val in env.items():
             monkeypatch.setenv("CUGRAPH_AMD_LOUVAIN_" + k, val)
