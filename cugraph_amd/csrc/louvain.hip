@@ -548,11 +548,15 @@ __global__ void __launch_bounds__(LVM_THREADS) k_lv_hash_rows(lv_mid_args A)
 // lower best_c[v] -- the same maximum and the same tie rule as the sorted path's k_segment_best<0/1>.
 // A table that fills up (keys that defeat the range hash) raises *overflow and the item gives up: the caller repeats the sweep's
 // evaluation with the sorted path for these rows.
+// Table size and workgroup shape (round 6, last session, with the partition of the big rows' pairs in place: an item's cost is then its latency chain, not the
+// pairs it reads, and smaller tables mean more items in flight per CU): 4096 slots x 512 threads (48 KB: three workgroups per CU) RMAT-26 1.24-1.25 s, RMAT-22
+// 0.0626; 8192 x 1024 (one per CU; the default while every item scanned its whole row, where it won 1.33 against 1.36 s) 1.28 / 0.0625; 4096 x 1024 1.31-1.35 /
+// 0.066-0.068; 4096 x 256 1.25 / 0.0647; 2048 x 256 1.26 / 0.065; 2048 x 512 1.26-1.28 / 0.0644 (profiles/r6bn, r6bo)
 #ifndef LVB_SLOTS_N
-#define LVB_SLOTS_N 8192
+#define LVB_SLOTS_N 4096
 #endif
 #ifndef LVB_THREADS_N
-#define LVB_THREADS_N 1024  // one workgroup of 96 KB LDS per CU: 16 waves instead of 8 (RMAT-26 1.45 -> 1.33 s; 4096 slots x 512 threads: 1.36 s)
+#define LVB_THREADS_N 512
 #endif
 constexpr int LVB_SLOTS = LVB_SLOTS_N, LVB_SHARE = LVB_SLOTS * 3 / 8, LVB_THREADS = LVB_THREADS_N;
 struct lv_big_args {
